@@ -1,0 +1,77 @@
+"""ctypes loader for the in-tree C-ABI library (candle_vllm_amd/libmi355vllm.so).
+
+The product path has NO fallback: if the library is missing or a symbol declared in
+include/mi355_vllm.h is not exported, importing this module raises."""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355vllm.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mi355_vllm.h")
+
+
+def declared_symbols(header_path=HEADER_PATH):
+    """Every function name declared in the public header."""
+    src = open(header_path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"^\s*(?:void|int|int64_t)\s+(\w+)\s*\(", src, flags=re.M)
+    return sorted(set(names))
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: run `python __graft_entry__.py` (hipcc --offload-arch=gfx950) first; "
+        "there is no CPU fallback for the MI355X decode path")
+
+lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+
+_missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+if _missing:
+    raise ImportError(f"{LIB_PATH} does not export: {_missing}")
+
+c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+class QmmDesc(ctypes.Structure):
+    """mirror of `mi355_qmm_desc` (include/mi355_vllm.h)"""
+    _fields_ = [
+        ("nseg", c_i32), ("w_tiles", c_vp * 3), ("ggml_type", c_i32 * 3), ("n_rows", c_i32 * 3),
+        ("x", c_vp), ("ldx", c_i32), ("k", c_i32), ("num_tokens", c_i32),
+        ("norm_weight", c_vp), ("norm_eps", c_f32), ("epilogue", c_i32),
+        ("out", c_vp), ("ldo", c_i32), ("residual", c_vp), ("bias", c_vp),
+        ("cos_table", c_vp), ("sin_table", c_vp), ("positions", c_vp), ("slot_mapping", c_vp),
+        ("q_out", c_vp), ("key_cache", c_vp), ("value_cache", c_vp),
+        ("num_heads", c_i32), ("num_kv_heads", c_i32), ("head_dim", c_i32), ("rotary_dim", c_i32),
+        ("block_size", c_i32), ("kv_layout", c_i32),
+    ]
+
+
+def _sig(name, restype, argtypes):
+    f = getattr(lib, name)
+    f.restype = restype
+    f.argtypes = argtypes
+    return f
+
+
+for _n in ("copy_blocks_bf16", "copy_blocks_f16", "copy_blocks_f32", "copy_blocks_u8"):
+    _sig(_n, None, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
+_sig("mi355_swap_blocks", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i64])
+_sig("mi355_reshape_and_cache", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp] + [c_i32] * 6 + [c_i64])
+_sig("mi355_paged_attention_v1", ctypes.c_int,
+     [c_vp] * 6 + [c_i32] * 7 + [c_f32, c_f32, c_i32, c_i32, c_i64])
+_sig("mi355_paged_attention_v2", ctypes.c_int,
+     [c_vp] * 9 + [c_i32] * 8 + [c_f32, c_f32, c_i32, c_i32, c_i64])
+_sig("mi355_rope_inplace", ctypes.c_int, [c_vp] * 5 + [c_i32] * 7 + [c_i64])
+_sig("mi355_rms_norm", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_i32, c_i64])
+_sig("mi355_silu_mul", ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64])
+_sig("mi355_add_f32", ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64])
+_sig("mi355_cast", ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i64])
+_sig("mi355_embedding_f32", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i64])
+_sig("mi355_argmax_f32", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64])
+_sig("mi355_dequantize", ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_i64])
+_sig("mi355_qmatmul_ref", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64])
+_sig("mi355_qweight_repacked_size", c_i64, [c_i32, c_i64, c_i64])
+_sig("mi355_qweight_repack", ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_i64])
+_sig("mi355_qmatmul", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64])
+_sig("mi355_qmatmul_fused", ctypes.c_int, [ctypes.POINTER(QmmDesc), c_i64])

@@ -1,0 +1,67 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.  wave = 64 lanes, always.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MI355_WAVE 64
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+#include "../../include/mi355_vllm.h"   // dtype / layout / epilogue codes of the C ABI
+
+static inline hipStream_t to_stream(int64_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- bf16 <-> f32 (bit-exact round-to-nearest-even, NaN -> quiet NaN) -------------------------
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ float bf16lo_to_f32(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi_to_f32(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FC0;
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t h) {
+    _Float16 v = __builtin_bit_cast(_Float16, h);
+    return (float)v;
+}
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
+    _Float16 v = (_Float16)f;
+    return __builtin_bit_cast(uint16_t, v);
+}
+
+// ---- wavefront reductions (ds_bpermute / DPP through __shfl_xor, 64 lanes) ---------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// reduce over lane groups of width W (power of two <= 64); result valid in every lane of the group
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum for blocks of up to 1024 threads; `red` must hold >= 16 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float t = (lane < nw) ? red[lane] : 0.f;
+    t = wave_sum(t);
+    __syncthreads();
+    return t;
+}

@@ -1,0 +1,228 @@
+// Small memory-bound operators of the decode step for gfx950: RMSNorm (K8), RoPE (K7), SiLU*mul (K9),
+// residual add, embedding gather (K16), argmax (K18), dtype casts.  All vectorised to 16 B per lane
+// where the layout allows; fp32 math throughout.
+//
+// Reference semantics:
+//   rms_norm   candle_nn::ops::rms_norm       src/openai/models/layers/qrmsnorm.rs:28-31
+//   rope       FusedRope::apply_inplace[_partial] / candle rope, rope_i   layers/rotary_emb.rs:52-101
+//   silu_mul   candle_nn::ops::silu(w1) * w3   src/openai/models/quantized_llama.rs:33-37
+//   argmax     logits.argmax(-1) (first max)   src/openai/logits_processor.rs:92-95
+#include "common.h"
+#include "../../include/mi355_vllm.h"
+
+// ------------------------------------------------------------------------------------------------ RMSNorm
+template <typename T> __device__ __forceinline__ float ld_as_f32(const T* p, int64_t i);
+template <> __device__ __forceinline__ float ld_as_f32<float>(const float* p, int64_t i) { return p[i]; }
+template <> __device__ __forceinline__ float ld_as_f32<uint16_t>(const uint16_t* p, int64_t i) { return bf16_to_f32(p[i]); }
+template <typename T> __device__ __forceinline__ void st_from_f32(T* p, int64_t i, float v);
+template <> __device__ __forceinline__ void st_from_f32<float>(float* p, int64_t i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void st_from_f32<uint16_t>(uint16_t* p, int64_t i, float v) { p[i] = f32_to_bf16(v); }
+
+// one workgroup per row; x is re-read from L1/L2 in the second pass (row <= 64 KB).
+// WT = weight element type (GGUF path: f32 weights with f32 x; safetensors path: bf16/bf16).
+template <typename T, typename WT>
+__global__ void __launch_bounds__(256) rms_norm_kernel(T* __restrict__ out, const T* __restrict__ x,
+                                                       const WT* __restrict__ w, int hidden, float eps) {
+    __shared__ float red[16];
+    const int64_t row = blockIdx.x;
+    const T* xr = x + row * hidden;
+    T* orow = out + row * hidden;
+    float ss = 0.f;
+    if constexpr (sizeof(T) == 4) {
+        if ((hidden & 3) == 0) {
+            const float4* x4 = reinterpret_cast<const float4*>(xr);
+            for (int i = threadIdx.x; i < hidden / 4; i += blockDim.x) {
+                float4 v = x4[i];
+                ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
+        } else {
+            for (int i = threadIdx.x; i < hidden; i += blockDim.x) { float v = xr[i]; ss += v * v; }
+        }
+    } else {
+        for (int i = threadIdx.x; i < hidden; i += blockDim.x) { float v = ld_as_f32<T>(xr, i); ss += v * v; }
+    }
+    ss = block_sum(ss, red);
+    const float inv = rsqrtf(ss / (float)hidden + eps);
+    for (int i = threadIdx.x; i < hidden; i += blockDim.x)
+        st_from_f32<T>(orow, i, ld_as_f32<T>(xr, i) * inv * ld_as_f32<WT>(w, i));
+}
+
+extern "C" int mi355_rms_norm(void* out, const void* x, const void* w, int32_t num_tokens, int32_t hidden,
+                              float eps, int32_t dtype, int32_t w_dtype, int64_t stream) {
+    if (num_tokens <= 0) return 0;
+    hipStream_t st = to_stream(stream);
+    if (dtype == MI355_DTYPE_F32 && w_dtype == MI355_DTYPE_F32)
+        hipLaunchKernelGGL((rms_norm_kernel<float, float>), dim3(num_tokens), dim3(256), 0, st, (float*)out,
+                           (const float*)x, (const float*)w, hidden, eps);
+    else if (dtype == MI355_DTYPE_BF16 && w_dtype == MI355_DTYPE_BF16)
+        hipLaunchKernelGGL((rms_norm_kernel<uint16_t, uint16_t>), dim3(num_tokens), dim3(256), 0, st,
+                           (uint16_t*)out, (const uint16_t*)x, (const uint16_t*)w, hidden, eps);
+    else if (dtype == MI355_DTYPE_BF16 && w_dtype == MI355_DTYPE_F32)
+        hipLaunchKernelGGL((rms_norm_kernel<uint16_t, float>), dim3(num_tokens), dim3(256), 0, st,
+                           (uint16_t*)out, (const uint16_t*)x, (const float*)w, hidden, eps);
+    else
+        return (int)hipErrorInvalidValue;
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ RoPE (in place)
+// q [T, H, D], k [T, Hkv, D]; cos/sin f32 [max_seq, rot/2]; positions i64 [T].
+// is_rope_i != 0: interleaved pairs (x[2i], x[2i+1])  (GGUF llama);  else half-split (x[i], x[i+rot/2]).
+template <typename T>
+__global__ void __launch_bounds__(256) rope_kernel(T* __restrict__ q, T* __restrict__ k,
+                                                   const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                   const int64_t* __restrict__ positions, int H, int Hkv, int D,
+                                                   int rot, int is_rope_i) {
+    const int t = blockIdx.x;
+    const int64_t pos = positions[t];
+    const int half = rot >> 1;
+    const float* c = cosT + pos * half;
+    const float* s = sinT + pos * half;
+    const int npairs = (H + Hkv) * half;
+    for (int i = threadIdx.x; i < npairs; i += blockDim.x) {
+        const int h = i / half, j = i % half;
+        T* base = (h < H) ? q + ((int64_t)t * H + h) * D : k + ((int64_t)t * Hkv + (h - H)) * D;
+        const int i0 = is_rope_i ? 2 * j : j;
+        const int i1 = is_rope_i ? 2 * j + 1 : j + half;
+        const float x0 = ld_as_f32<T>(base, i0), x1 = ld_as_f32<T>(base, i1);
+        const float cc = c[j], sn = s[j];
+        st_from_f32<T>(base, i0, x0 * cc - x1 * sn);
+        st_from_f32<T>(base, i1, x0 * sn + x1 * cc);
+    }
+}
+
+extern "C" int mi355_rope_inplace(void* q, void* k, const float* cos_t, const float* sin_t,
+                                  const int64_t* positions, int32_t num_tokens, int32_t num_heads,
+                                  int32_t num_kv_heads, int32_t head_dim, int32_t rotary_dim,
+                                  int32_t is_rope_i, int32_t dtype, int64_t stream) {
+    if (num_tokens <= 0) return 0;
+    if (rotary_dim <= 0 || rotary_dim > head_dim || (rotary_dim & 1)) return (int)hipErrorInvalidValue;
+    hipStream_t st = to_stream(stream);
+    if (dtype == MI355_DTYPE_F32)
+        hipLaunchKernelGGL(rope_kernel<float>, dim3(num_tokens), dim3(256), 0, st, (float*)q, (float*)k, cos_t,
+                           sin_t, positions, num_heads, num_kv_heads, head_dim, rotary_dim, is_rope_i);
+    else if (dtype == MI355_DTYPE_BF16)
+        hipLaunchKernelGGL(rope_kernel<uint16_t>, dim3(num_tokens), dim3(256), 0, st, (uint16_t*)q,
+                           (uint16_t*)k, cos_t, sin_t, positions, num_heads, num_kv_heads, head_dim, rotary_dim,
+                           is_rope_i);
+    else
+        return (int)hipErrorInvalidValue;
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ SiLU * mul, add, casts
+template <typename T>
+__global__ void __launch_bounds__(256) silu_mul_kernel(T* __restrict__ out, const T* __restrict__ g,
+                                                       const T* __restrict__ u, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float a = ld_as_f32<T>(g, i), b = ld_as_f32<T>(u, i);
+        st_from_f32<T>(out, i, a / (1.f + __expf(-a)) * b);
+    }
+}
+extern "C" int mi355_silu_mul(void* out, const void* gate, const void* up, int64_t n, int32_t dtype, int64_t stream) {
+    if (n <= 0) return 0;
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    if (dtype == MI355_DTYPE_F32)
+        hipLaunchKernelGGL(silu_mul_kernel<float>, dim3(grid), dim3(256), 0, to_stream(stream), (float*)out,
+                           (const float*)gate, (const float*)up, n);
+    else if (dtype == MI355_DTYPE_BF16)
+        hipLaunchKernelGGL(silu_mul_kernel<uint16_t>, dim3(grid), dim3(256), 0, to_stream(stream), (uint16_t*)out,
+                           (const uint16_t*)gate, (const uint16_t*)up, n);
+    else
+        return (int)hipErrorInvalidValue;
+    return (int)hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) add_f32_kernel(float* __restrict__ out, const float* __restrict__ a,
+                                                      const float* __restrict__ b, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = a[i] + b[i];
+}
+extern "C" int mi355_add_f32(float* out, const float* a, const float* b, int64_t n, int64_t stream) {
+    if (n <= 0) return 0;
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(add_f32_kernel, dim3(grid), dim3(256), 0, to_stream(stream), out, a, b, n);
+    return (int)hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) cast_f32_bf16_kernel(uint16_t* __restrict__ out, const float* __restrict__ in, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = f32_to_bf16(in[i]);
+}
+__global__ void __launch_bounds__(256) cast_bf16_f32_kernel(float* __restrict__ out, const uint16_t* __restrict__ in, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = bf16_to_f32(in[i]);
+}
+extern "C" int mi355_cast(void* out, const void* in, int64_t n, int32_t src_dtype, int32_t dst_dtype, int64_t stream) {
+    if (n <= 0) return 0;
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    if (src_dtype == MI355_DTYPE_F32 && dst_dtype == MI355_DTYPE_BF16)
+        hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, to_stream(stream), (uint16_t*)out, (const float*)in, n);
+    else if (src_dtype == MI355_DTYPE_BF16 && dst_dtype == MI355_DTYPE_F32)
+        hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid), dim3(256), 0, to_stream(stream), (float*)out, (const uint16_t*)in, n);
+    else
+        return (int)hipErrorInvalidValue;
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ embedding gather
+// table f32 [V, hidden] (GGUF: dequantised once at load, quantized_llama.rs:262-264) -> out f32 [T, hidden]
+__global__ void __launch_bounds__(256) embedding_f32_kernel(float* __restrict__ out, const float* __restrict__ table,
+                                                            const uint32_t* __restrict__ ids, int hidden) {
+    const int64_t t = blockIdx.x;
+    const float* src = table + (int64_t)ids[t] * hidden;
+    float* dst = out + t * hidden;
+    if ((hidden & 3) == 0) {
+        for (int i = threadIdx.x; i < hidden / 4; i += blockDim.x)
+            reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    } else {
+        for (int i = threadIdx.x; i < hidden; i += blockDim.x) dst[i] = src[i];
+    }
+}
+extern "C" int mi355_embedding_f32(float* out, const float* table, const uint32_t* ids, int32_t num_tokens,
+                                   int32_t hidden, int64_t stream) {
+    if (num_tokens <= 0) return 0;
+    hipLaunchKernelGGL(embedding_f32_kernel, dim3(num_tokens), dim3(256), 0, to_stream(stream), out, table, ids, hidden);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ argmax (greedy)
+// logits f32 [B, V] -> u32 [B]; ties -> lowest index (candle argmax keeps the first maximum [EXT]).
+// NaN handling: NaNs never win a `>` comparison, matching a sequential `if v > best` scan.
+__global__ void __launch_bounds__(1024) argmax_f32_kernel(uint32_t* __restrict__ out, const float* __restrict__ logits, int V) {
+    __shared__ float sv[16];
+    __shared__ uint32_t si[16];
+    const float* row = logits + (int64_t)blockIdx.x * V;
+    float best = -INFINITY;
+    uint32_t bi = 0xFFFFFFFFu;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+        const float v = row[i];
+        if (v > best || (v == best && (uint32_t)i < bi)) { best = v; bi = (uint32_t)i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const uint32_t oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { sv[wid] = best; si[wid] = bi; }
+    __syncthreads();
+    if (wid == 0) {
+        const int nw = blockDim.x >> 6;
+        best = (lane < nw) ? sv[lane] : -INFINITY;
+        bi = (lane < nw) ? si[lane] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const uint32_t oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) out[blockIdx.x] = (bi == 0xFFFFFFFFu) ? 0u : bi;
+    }
+}
+extern "C" int mi355_argmax_f32(uint32_t* out, const float* logits, int32_t batch, int32_t vocab, int64_t stream) {
+    if (batch <= 0) return 0;
+    hipLaunchKernelGGL(argmax_f32_kernel, dim3(batch), dim3(1024), 0, to_stream(stream), out, logits, vocab);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,422 @@
+// Paged-attention decode for gfx950 (MI355X): K2 `paged_attention_v1`, K3 `paged_attention_v2` + reduce.
+//
+// Reference boundary: attention_rs::PagedAttention::forward as called from
+//   src/openai/models/layers/attention.rs:707-719,983-995 with the InputMetadata of
+//   src/openai/pipelines/inputs.rs:552-568 (block_tables u32 [B,max_blocks], context_lens u32 [B]).
+// Math (oracle): NaiveAttention, src/openai/models/mod.rs:1288-1306 -- softmax(q.k^T*scale [softcap]).v
+// with GQA expansion (:1240-1247); fp32 scores / softmax / accumulation, 16-bit output.
+//
+// Design (HBM-bound: every live K/V byte is read exactly once):
+//   * one workgroup (4 waves) per (kv head, sequence, context partition); the G = H/Hkv query heads of
+//     the GQA group share each K/V byte out of registers,
+//   * a token's head row (D 16-bit elements) is spread over LPT = D/8 lanes, 16 B per lane -> a wave
+//     reads 64/LPT tokens per instruction as fully used 128-B lines (FLASH layout) ,
+//   * q.k partial dots are reduced over the LPT lanes with DPP row operations (no LDS),
+//   * chunked online softmax (UNR tokens per chunk, one rescale per chunk),
+//   * lane-group states merge with ds_bpermute shuffles, wave states through 8.3 KB of LDS,
+//   * v2: partitions write (normalised out, max_logit, exp_sum); a tiny reduce kernel merges them.
+#include "common.h"
+#include "../../include/mi355_vllm.h"
+
+#define PA_THREADS 256
+#define PA_UNR 4
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// all-reduce sum over aligned groups of LPT lanes
+template <int LPT>
+__device__ __forceinline__ float lpt_sum(float v) {
+    if constexpr (LPT >= 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (LPT >= 16) v += dpp_mov<0x140>(v);   // row_mirror      : lane i <-> 15-i
+    if constexpr (LPT >= 8) v += dpp_mov<0x141>(v);    // row_half_mirror : lane i <-> 7-i
+    v += dpp_mov<0x4E>(v);                             // quad_perm [2,3,0,1]
+    v += dpp_mov<0xB1>(v);                             // quad_perm [1,0,3,2]
+    return v;
+}
+
+template <int KVT>
+__device__ __forceinline__ void unpack8(const uint4& w, float (&f)[8]) {
+    const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if constexpr (KVT == MI355_DTYPE_BF16) {
+            f[2 * i] = bf16lo_to_f32(u[i]);
+            f[2 * i + 1] = bf16hi_to_f32(u[i]);
+        } else {
+            f[2 * i] = f16_bits_to_f32((uint16_t)(u[i] & 0xFFFF));
+            f[2 * i + 1] = f16_bits_to_f32((uint16_t)(u[i] >> 16));
+        }
+    }
+}
+
+struct PAParams {
+    void* out;                 // v1: [B,H,D] 16-bit ; v2: unused
+    float* tmp_out;            // v2: [B,H,P,D] f32 (normalised per partition)
+    float* max_logits;         // v2: [B,H,P]
+    float* exp_sums;           // v2: [B,H,P]
+    const void* q;             // [B,H,D] 16-bit
+    const void* kc;            // FLASH: [NB, bs, Hkv, D]
+    const void* vc;
+    const uint32_t* block_tables;   // [B, max_blocks]
+    const uint32_t* context_lens;   // [B]
+    int H, Hkv, D, block_size, max_blocks;
+    int partition_size;        // tokens per partition (v1: >= max context)
+    int max_partitions;        // P (stride of the v2 temporaries); 1 for v1
+    float scale, softcap;      // softcap <= 0 -> disabled
+    int64_t q_stride;          // elements between sequences in q (H*D when contiguous)
+};
+
+template <int LPT, int GP, int KVT, bool PARTITIONED>
+__global__ void __launch_bounds__(PA_THREADS) paged_attn_flash_kernel(const PAParams p) {
+    constexpr int TW = 64 / LPT;            // token groups per wave
+    constexpr int TI = 4 * TW;              // tokens per workgroup iteration
+    const int hk = blockIdx.x, b = blockIdx.y, part = blockIdx.z;
+    const int ctx = (int)p.context_lens[b];
+    const int t0 = part * p.partition_size;
+    if (t0 >= ctx) return;
+    const int t1 = min(ctx, t0 + p.partition_size);
+    const int G = p.H / p.Hkv;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPT, tg = wave * TW + lane / LPT;
+    const bool dact = sub * 8 < p.D;        // head_dim not a power of two (e.g. 80): upper lanes idle
+    const uint16_t* kc = static_cast<const uint16_t*>(p.kc);
+    const uint16_t* vc = static_cast<const uint16_t*>(p.vc);
+    const uint32_t* bt = p.block_tables + (int64_t)b * p.max_blocks;
+
+    // q (pre-scaled) for the G heads of this kv head, this lane's 8 channels
+    float q[GP][8];
+#pragma unroll
+    for (int g = 0; g < GP; ++g) {
+        if (g < G && dact) {
+            const uint16_t* qp = static_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_stride +
+                                 (int64_t)(hk * G + g) * p.D + sub * 8;
+            float f[8];
+            unpack8<KVT>(*reinterpret_cast<const uint4*>(qp), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q[g][e] = f[e] * p.scale;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q[g][e] = 0.f;
+        }
+    }
+
+    float m[GP], l[GP], acc[GP][8];
+#pragma unroll
+    for (int g = 0; g < GP; ++g) {
+        m[g] = -1e30f;
+        l[g] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+    }
+
+    const int64_t tok_stride = (int64_t)p.Hkv * p.D;            // elements between tokens of a block
+    for (int base = t0 + tg; base < t1; base += TI * PA_UNR) {
+        uint4 kw[PA_UNR], vw[PA_UNR];
+        bool valid[PA_UNR];
+#pragma unroll
+        for (int u = 0; u < PA_UNR; ++u) {
+            const int tok = base + u * TI;
+            valid[u] = tok < t1;
+            kw[u] = make_uint4(0, 0, 0, 0);
+            vw[u] = make_uint4(0, 0, 0, 0);
+            if (valid[u] && dact) {
+                const int64_t blk = (int64_t)bt[tok / p.block_size];
+                const int64_t off = (blk * p.block_size + (tok % p.block_size)) * tok_stride +
+                                    (int64_t)hk * p.D + sub * 8;
+                kw[u] = *reinterpret_cast<const uint4*>(kc + off);
+                vw[u] = *reinterpret_cast<const uint4*>(vc + off);
+            }
+        }
+        float s[PA_UNR][GP];
+        float mx[GP];
+#pragma unroll
+        for (int g = 0; g < GP; ++g) mx[g] = m[g];
+#pragma unroll
+        for (int u = 0; u < PA_UNR; ++u) {
+            float kf[8];
+            unpack8<KVT>(kw[u], kf);
+#pragma unroll
+            for (int g = 0; g < GP; ++g) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d = fmaf(q[g][e], kf[e], d);
+                d = lpt_sum<LPT>(d);
+                if (p.softcap > 0.f) d = tanhf(d / p.softcap) * p.softcap;
+                s[u][g] = d;
+                if (valid[u]) mx[g] = fmaxf(mx[g], d);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < GP; ++g) {
+            const float alpha = __expf(m[g] - mx[g]);
+            m[g] = mx[g];
+            l[g] *= alpha;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[g][e] *= alpha;
+        }
+#pragma unroll
+        for (int u = 0; u < PA_UNR; ++u) {
+            float vf[8];
+            unpack8<KVT>(vw[u], vf);
+#pragma unroll
+            for (int g = 0; g < GP; ++g) {
+                const float pr = valid[u] ? __expf(s[u][g] - m[g]) : 0.f;
+                l[g] += pr;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[g][e] = fmaf(pr, vf[e], acc[g][e]);
+            }
+        }
+    }
+
+    // ---- merge the TW lane groups of this wave (same `sub`, different tokens)
+#pragma unroll
+    for (int g = 0; g < GP; ++g) {
+        float M = m[g];
+#pragma unroll
+        for (int o = LPT; o < 64; o <<= 1) M = fmaxf(M, __shfl_xor(M, o, 64));
+        const float w = __expf(m[g] - M);
+        float ll = l[g] * w;
+#pragma unroll
+        for (int o = LPT; o < 64; o <<= 1) ll += __shfl_xor(ll, o, 64);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = acc[g][e] * w;
+#pragma unroll
+            for (int o = LPT; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+            acc[g][e] = a;
+        }
+        m[g] = M;
+        l[g] = ll;
+    }
+
+    // ---- merge the 4 waves through LDS
+    constexpr int DP = LPT * 8;                        // padded head dim
+    __shared__ float s_acc[4][GP][DP];
+    __shared__ float s_m[4][GP], s_l[4][GP];
+    if (lane < LPT) {
+#pragma unroll
+        for (int g = 0; g < GP; ++g) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_acc[wave][g][sub * 8 + e] = acc[g][e];
+            if (lane == 0) { s_m[wave][g] = m[g]; s_l[wave][g] = l[g]; }
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < G * p.D; idx += PA_THREADS) {
+        const int g = idx / p.D, d = idx % p.D;
+        float M = fmaxf(fmaxf(s_m[0][g], s_m[1][g]), fmaxf(s_m[2][g], s_m[3][g]));
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = __expf(s_m[w][g] - M);
+            num += s_acc[w][g][d] * f;
+            den += s_l[w][g] * f;
+        }
+        const float o = num / den;
+        const int h = hk * G + g;
+        if constexpr (PARTITIONED) {
+            const int64_t pi = ((int64_t)b * p.H + h) * p.max_partitions + part;
+            p.tmp_out[pi * p.D + d] = o;
+            if (d == 0) { p.max_logits[pi] = M; p.exp_sums[pi] = den; }
+        } else {
+            uint16_t* op = static_cast<uint16_t*>(p.out) + ((int64_t)b * p.H + h) * p.D + d;
+            *op = (KVT == MI355_DTYPE_BF16) ? f32_to_bf16(o) : f32_to_f16_bits(o);
+        }
+    }
+}
+
+// v2 reduce: grid (H, B); merges the partitions of one (sequence, head).
+template <int KVT>
+__global__ void __launch_bounds__(128) paged_attn_reduce_kernel(void* __restrict__ out, const float* __restrict__ tmp_out,
+                                                                const float* __restrict__ max_logits,
+                                                                const float* __restrict__ exp_sums,
+                                                                const uint32_t* __restrict__ context_lens, int H,
+                                                                int D, int partition_size, int max_partitions) {
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int ctx = (int)context_lens[b];
+    const int P = (ctx + partition_size - 1) / partition_size;
+    const int64_t base = ((int64_t)b * H + h) * max_partitions;
+    float M = -1e30f;
+    for (int i = 0; i < P; ++i) M = fmaxf(M, max_logits[base + i]);
+    float den = 0.f;
+    for (int i = 0; i < P; ++i) den += exp_sums[base + i] * __expf(max_logits[base + i] - M);
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float num = 0.f;
+        for (int i = 0; i < P; ++i)
+            num += tmp_out[(base + i) * D + d] * exp_sums[base + i] * __expf(max_logits[base + i] - M);
+        const float o = (P > 0) ? num / den : 0.f;
+        uint16_t* op = static_cast<uint16_t*>(out) + ((int64_t)b * H + h) * D + d;
+        *op = (KVT == MI355_DTYPE_BF16) ? f32_to_bf16(o) : f32_to_f16_bits(o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PAGED (vLLM) layout: K [NB,Hkv,D/8,bs,8], V [NB,Hkv,D,bs] (16-bit).  Functional kernel: one workgroup
+// per (head, sequence); lane = token, logits staged in LDS.  Correct for every block size / head dim;
+// the FLASH layout above is the tuned path (cache_engine.rs:188-193 makes FLASH the cuda-build default).
+template <int KVT>
+__global__ void __launch_bounds__(256) paged_attn_paged_layout_kernel(const PAParams p) {
+    extern __shared__ float s_logits[];                  // [partition tokens]
+    __shared__ float red[16];
+    __shared__ float s_q[256];
+    const int h = blockIdx.x, b = blockIdx.y, part = blockIdx.z;
+    const int ctx = (int)p.context_lens[b];
+    const int t0 = part * p.partition_size;
+    if (t0 >= ctx) return;
+    const int t1 = min(ctx, t0 + p.partition_size);
+    const int n = t1 - t0;
+    const int G = p.H / p.Hkv, hk = h / G, D = p.D, bs = p.block_size;
+    const uint16_t* kc = static_cast<const uint16_t*>(p.kc);
+    const uint16_t* vc = static_cast<const uint16_t*>(p.vc);
+    const uint32_t* bt = p.block_tables + (int64_t)b * p.max_blocks;
+    const uint16_t* qp = static_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_stride + (int64_t)h * D;
+    for (int d = threadIdx.x; d < D; d += blockDim.x)
+        s_q[d] = ((KVT == MI355_DTYPE_BF16) ? bf16_to_f32(qp[d]) : f16_bits_to_f32(qp[d])) * p.scale;
+    __syncthreads();
+    float lmax = -1e30f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int tok = t0 + i;
+        const int64_t blk = (int64_t)bt[tok / bs];
+        const int off = tok % bs;
+        const uint16_t* kb = kc + ((blk * p.Hkv + hk) * (D / 8)) * (int64_t)bs * 8 + (int64_t)off * 8;
+        float s = 0.f;
+        for (int dg = 0; dg < D / 8; ++dg) {
+            float f[8];
+            unpack8<KVT>(*reinterpret_cast<const uint4*>(kb + (int64_t)dg * bs * 8), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = fmaf(s_q[dg * 8 + e], f[e], s);
+        }
+        if (p.softcap > 0.f) s = tanhf(s / p.softcap) * p.softcap;
+        s_logits[i] = s;
+        lmax = fmaxf(lmax, s);
+    }
+    {   // block max
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        lmax = wave_max(lmax);
+        if (lane == 0) red[wid] = lmax;
+        __syncthreads();
+        lmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+    }
+    float lsum = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float e = __expf(s_logits[i] - lmax);
+        s_logits[i] = e;
+        lsum += e;
+    }
+    lsum = block_sum(lsum, red);                         // includes the barrier that publishes s_logits
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float a = 0.f;
+        for (int i = 0; i < n; ++i) {
+            const int tok = t0 + i;
+            const int64_t blk = (int64_t)bt[tok / bs];
+            const uint16_t vv = vc[((blk * p.Hkv + hk) * D + d) * (int64_t)bs + tok % bs];
+            a = fmaf(s_logits[i], (KVT == MI355_DTYPE_BF16) ? bf16_to_f32(vv) : f16_bits_to_f32(vv), a);
+        }
+        const float o = a / lsum;
+        if (p.max_partitions > 1) {
+            const int64_t pi = ((int64_t)b * p.H + h) * p.max_partitions + part;
+            p.tmp_out[pi * D + d] = o;
+            if (d == 0) { p.max_logits[pi] = lmax; p.exp_sums[pi] = lsum; }
+        } else {
+            uint16_t* op = static_cast<uint16_t*>(p.out) + ((int64_t)b * p.H + h) * D + d;
+            *op = (KVT == MI355_DTYPE_BF16) ? f32_to_bf16(o) : f32_to_f16_bits(o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+template <int LPT, int KVT, bool PART>
+static int launch_flash_g(const PAParams& p, int B, int P, hipStream_t st) {
+    const int G = p.H / p.Hkv;
+    dim3 grid(p.Hkv, B, P), block(PA_THREADS);
+    if (G <= 1) hipLaunchKernelGGL((paged_attn_flash_kernel<LPT, 1, KVT, PART>), grid, block, 0, st, p);
+    else if (G <= 2) hipLaunchKernelGGL((paged_attn_flash_kernel<LPT, 2, KVT, PART>), grid, block, 0, st, p);
+    else if (G <= 4) hipLaunchKernelGGL((paged_attn_flash_kernel<LPT, 4, KVT, PART>), grid, block, 0, st, p);
+    else if (G <= 8) hipLaunchKernelGGL((paged_attn_flash_kernel<LPT, 8, KVT, PART>), grid, block, 0, st, p);
+    else return (int)hipErrorInvalidValue;
+    return (int)hipGetLastError();
+}
+template <int KVT, bool PART>
+static int launch_flash(const PAParams& p, int B, int P, hipStream_t st) {
+    if (p.D <= 64) return launch_flash_g<8, KVT, PART>(p, B, P, st);
+    if (p.D <= 128) return launch_flash_g<16, KVT, PART>(p, B, P, st);
+    if (p.D <= 256) return launch_flash_g<32, KVT, PART>(p, B, P, st);
+    return (int)hipErrorInvalidValue;
+}
+
+static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t stream) {
+    if (B <= 0) return 0;
+    if (p.H % p.Hkv || (p.D & 7) || p.D > 256) return (int)hipErrorInvalidValue;
+    if (dtype != MI355_DTYPE_BF16 && dtype != MI355_DTYPE_F16) return (int)hipErrorInvalidValue;
+    hipStream_t st = to_stream(stream);
+    int rc;
+    if (layout == MI355_KV_FLASH) {
+        if (P > 1)
+            rc = (dtype == MI355_DTYPE_BF16) ? launch_flash<MI355_DTYPE_BF16, true>(p, B, P, st)
+                                             : launch_flash<MI355_DTYPE_F16, true>(p, B, P, st);
+        else
+            rc = (dtype == MI355_DTYPE_BF16) ? launch_flash<MI355_DTYPE_BF16, false>(p, B, P, st)
+                                             : launch_flash<MI355_DTYPE_F16, false>(p, B, P, st);
+    } else if (layout == MI355_KV_PAGED) {
+        const size_t shm = (size_t)p.partition_size * sizeof(float);
+        if (shm > 60 * 1024) return (int)hipErrorInvalidValue;   // caller must partition (v2) long contexts
+        dim3 grid(p.H, B, P), block(256);
+        if (dtype == MI355_DTYPE_BF16)
+            hipLaunchKernelGGL(paged_attn_paged_layout_kernel<MI355_DTYPE_BF16>, grid, block, shm, st, p);
+        else
+            hipLaunchKernelGGL(paged_attn_paged_layout_kernel<MI355_DTYPE_F16>, grid, block, shm, st, p);
+        rc = (int)hipGetLastError();
+    } else {
+        return (int)hipErrorInvalidValue;
+    }
+    if (rc != 0 || P <= 1) return rc;
+    dim3 rgrid(p.H, B), rblock(128);
+    if (dtype == MI355_DTYPE_BF16)
+        hipLaunchKernelGGL(paged_attn_reduce_kernel<MI355_DTYPE_BF16>, rgrid, rblock, 0, st, p.out, p.tmp_out,
+                           p.max_logits, p.exp_sums, p.context_lens, p.H, p.D, p.partition_size, p.max_partitions);
+    else
+        hipLaunchKernelGGL(paged_attn_reduce_kernel<MI355_DTYPE_F16>, rgrid, rblock, 0, st, p.out, p.tmp_out,
+                           p.max_logits, p.exp_sums, p.context_lens, p.H, p.D, p.partition_size, p.max_partitions);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mi355_paged_attention_v1(void* out, const void* q, const void* key_cache, const void* value_cache,
+                                        const uint32_t* block_tables, const uint32_t* context_lens,
+                                        int32_t num_seqs, int32_t num_heads, int32_t num_kv_heads,
+                                        int32_t head_dim, int32_t block_size, int32_t max_blocks_per_seq,
+                                        int32_t max_context_len, float scale, float softcap, int32_t layout,
+                                        int32_t dtype, int64_t stream) {
+    PAParams p{};
+    p.out = out; p.q = q; p.kc = key_cache; p.vc = value_cache;
+    p.block_tables = block_tables; p.context_lens = context_lens;
+    p.H = num_heads; p.Hkv = num_kv_heads; p.D = head_dim; p.block_size = block_size;
+    p.max_blocks = max_blocks_per_seq;
+    p.partition_size = max_context_len > 0 ? max_context_len : 1;
+    p.max_partitions = 1;
+    p.scale = scale; p.softcap = softcap; p.q_stride = (int64_t)num_heads * head_dim;
+    return pa_dispatch(p, num_seqs, 1, layout, dtype, stream);
+}
+
+extern "C" int mi355_paged_attention_v2(void* out, float* exp_sums, float* max_logits, float* tmp_out,
+                                        const void* q, const void* key_cache, const void* value_cache,
+                                        const uint32_t* block_tables, const uint32_t* context_lens,
+                                        int32_t num_seqs, int32_t num_heads, int32_t num_kv_heads,
+                                        int32_t head_dim, int32_t block_size, int32_t max_blocks_per_seq,
+                                        int32_t max_context_len, int32_t partition_size, float scale,
+                                        float softcap, int32_t layout, int32_t dtype, int64_t stream) {
+    if (partition_size <= 0) return (int)hipErrorInvalidValue;
+    PAParams p{};
+    p.out = out; p.tmp_out = tmp_out; p.max_logits = max_logits; p.exp_sums = exp_sums;
+    p.q = q; p.kc = key_cache; p.vc = value_cache;
+    p.block_tables = block_tables; p.context_lens = context_lens;
+    p.H = num_heads; p.Hkv = num_kv_heads; p.D = head_dim; p.block_size = block_size;
+    p.max_blocks = max_blocks_per_seq;
+    p.partition_size = partition_size;
+    p.max_partitions = (max_context_len + partition_size - 1) / partition_size;
+    if (p.max_partitions < 1) p.max_partitions = 1;
+    p.scale = scale; p.softcap = softcap; p.q_stride = (int64_t)num_heads * head_dim;
+    return pa_dispatch(p, num_seqs, p.max_partitions, layout, dtype, stream);
+}

@@ -1,0 +1,666 @@
+// GGUF k-quant (Q4_K / Q6_K) dequant-matmul for gfx950 (MI355X): K11 `QMatMul::forward`.
+//
+// Reference boundary: candle `QMatMul::forward(&x_f32)` as called from
+//   src/openai/models/layers/attention.rs:920-922,1004 (wq/wk/wv/wo),
+//   src/openai/models/quantized_llama.rs:33-37 (w1/w3/w2), src/openai/distributed.rs:1633 (lm_head);
+//   x is f32 [T,K], W is [N, K/256] super-blocks, y is f32 [T,N].
+//
+// Decode (T <= 8 per M-tile) is a pure HBM stream of the weights: 144 B (Q4_K) / 210 B (Q6_K) per 256
+// weights, each byte read exactly once.  Design:
+//   * weights are re-tiled once at load time (mi355_qweight_repack) into 16-row x 256-k tiles whose
+//     quant payload is lane-linear: every wave load is one contiguous 1-KiB `global_load_dwordx4`;
+//     a row tile's k-blocks are contiguous, so a workgroup streams one contiguous span of HBM;
+//   * the int4/int6 codes are unpacked IN REGISTERS to bf16 (128+q is exact in bf16: 0x4300|q) and fed
+//     straight to MFMA (v_mfma_f32_16x16x32_bf16, one MFMA = one 32-weight sub-block so the per-sub-block
+//     scale is applied to the fp32 MFMA result; Q6_K uses the K=16 MFMA for its 16-weight sub-blocks);
+//   * activations stay fp32-accurate: x is split x = hi + lo (two bf16), hi rows and lo rows ride in the
+//     same MFMA as extra M rows (rows 0-7 hi, 8-15 lo) and are summed after scaling (error ~2^-17);
+//   * the "+128" code offset and the Q4_K minimum are folded into one term  c_j * sum_k(x)  per sub-block;
+//   * x (optionally RMS-normalised on the fly: fused K8) is staged once per workgroup into LDS in
+//     MFMA-fragment order while the first weight loads are already in flight; waves of a workgroup split
+//     K, partial sums meet in LDS, and the epilogue fuses bias/residual (K-free adds), SiLU*mul (K9),
+//     interleaved RoPE + bf16 cast + paged-cache scatter (K7 + K1).
+#include "common.h"
+#include "../../include/mi355_vllm.h"
+#include <string.h>
+
+#define Q4K_BLOCK 144
+#define Q6K_BLOCK 210
+#define Q4K_TILE (16 * Q4K_BLOCK)   // 2304
+#define Q6K_TILE (16 * Q6K_BLOCK)   // 3360
+#define BF16_128 0x43004300u        // two bf16 128.0 ; OR-ing a code q < 128 into the mantissa gives 128+q
+
+static inline int tile_bytes_of(int type) { return type == MI355_GGML_Q4_K ? Q4K_TILE : Q6K_TILE; }
+static inline int block_bytes_of(int type) { return type == MI355_GGML_Q4_K ? Q4K_BLOCK : Q6K_BLOCK; }
+
+// ================================================================================================
+// Host-side repack: native GGUF rows [N][K/256][block] -> tiles [ceil(N/16)][K/256][tile].
+//   Q4_K tile (2304 B): hdr[16 rows][16 B = d,dmin,scales[12]] | qs_p0[64 lanes][16 B] | qs_p1[64][16 B]
+//       lane = kg*16 + r ; 16 B = { qs[32*(2p)+8kg .. +8] , qs[32*(2p+1)+8kg .. +8] } of row r
+//   Q6_K tile (3360 B): sc[16 rows][16 x i8] | ql_n0[64][16 B] | ql_n1[64][16 B] | qh[64][16 B] | d[16 x f16]
+//       ql_n lane = { ql[64n+4kg..+4], ql[64n+32+4kg..+4], ql[64n+16+4kg..+4], ql[64n+48+4kg..+4] }
+//       qh   lane = { qh[4kg..+4], qh[16+4kg..+4], qh[32+4kg..+4], qh[48+4kg..+4] }
+extern "C" int64_t mi355_qweight_repacked_size(int32_t ggml_type, int64_t n_rows, int64_t k) {
+    if ((ggml_type != MI355_GGML_Q4_K && ggml_type != MI355_GGML_Q6_K) || k <= 0 || (k % 256) || n_rows <= 0) return -1;
+    return ((n_rows + 15) / 16) * (k / 256) * (int64_t)tile_bytes_of(ggml_type);
+}
+
+extern "C" int mi355_qweight_repack(void* dst_v, const void* src_v, int32_t ggml_type, int64_t n_rows, int64_t k) {
+    if (mi355_qweight_repacked_size(ggml_type, n_rows, k) < 0) return (int)hipErrorInvalidValue;
+    const int64_t nkb = k / 256, ntile = (n_rows + 15) / 16;
+    uint8_t* dst = static_cast<uint8_t*>(dst_v);
+    const uint8_t* src = static_cast<const uint8_t*>(src_v);
+    const int bb = block_bytes_of(ggml_type), tb = tile_bytes_of(ggml_type);
+#pragma omp parallel for schedule(static)
+    for (int64_t rt = 0; rt < ntile; ++rt) {
+        for (int64_t kb = 0; kb < nkb; ++kb) {
+            uint8_t* t = dst + (rt * nkb + kb) * tb;
+            memset(t, 0, tb);
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = rt * 16 + r;
+                if (row >= n_rows) continue;                       // padded rows stay all-zero (d = 0)
+                const uint8_t* b = src + (row * nkb + kb) * bb;
+                if (ggml_type == MI355_GGML_Q4_K) {
+                    memcpy(t + r * 16, b, 16);
+                    const uint8_t* qs = b + 16;
+                    for (int p = 0; p < 2; ++p)
+                        for (int kg = 0; kg < 4; ++kg) {
+                            uint8_t* o = t + 256 + p * 1024 + (kg * 16 + r) * 16;
+                            memcpy(o, qs + 32 * (2 * p) + 8 * kg, 8);
+                            memcpy(o + 8, qs + 32 * (2 * p + 1) + 8 * kg, 8);
+                        }
+                } else {
+                    const uint8_t *ql = b, *qh = b + 128, *sc = b + 192, *d = b + 208;
+                    memcpy(t + r * 16, sc, 16);
+                    for (int n = 0; n < 2; ++n)
+                        for (int kg = 0; kg < 4; ++kg) {
+                            uint8_t* o = t + 256 + n * 1024 + (kg * 16 + r) * 16;
+                            memcpy(o + 0, ql + 64 * n + 4 * kg, 4);
+                            memcpy(o + 4, ql + 64 * n + 32 + 4 * kg, 4);
+                            memcpy(o + 8, ql + 64 * n + 16 + 4 * kg, 4);
+                            memcpy(o + 12, ql + 64 * n + 48 + 4 * kg, 4);
+                        }
+                    for (int kg = 0; kg < 4; ++kg) {
+                        uint8_t* o = t + 2304 + (kg * 16 + r) * 16;
+                        memcpy(o + 0, qh + 4 * kg, 4);
+                        memcpy(o + 4, qh + 16 + 4 * kg, 4);
+                        memcpy(o + 8, qh + 32 + 4 * kg, 4);
+                        memcpy(o + 12, qh + 48 + 4 * kg, 4);
+                    }
+                    memcpy(t + 3328 + 2 * r, d, 2);
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+// ================================================================================================
+// Reference kernels on the NATIVE GGUF layout (simple, obviously-correct; used for dequantisation at
+// load time -- token_embd, quantized_llama.rs:262-264 -- and as an on-device cross-check of the MFMA path).
+__device__ __forceinline__ float dequant_native(int type, const uint8_t* __restrict__ blk, int i) {
+    if (type == MI355_GGML_Q4_K) {
+        const float d = f16_bits_to_f32(*reinterpret_cast<const uint16_t*>(blk));
+        const float dmin = f16_bits_to_f32(*reinterpret_cast<const uint16_t*>(blk + 2));
+        const uint8_t* s = blk + 4;
+        const int j = i >> 5, l = i & 31, g = j >> 1;
+        int sc, m;
+        if (j < 4) { sc = s[j] & 63; m = s[j + 4] & 63; }
+        else { sc = (s[j + 4] & 0xF) | ((s[j - 4] >> 6) << 4); m = (s[j + 4] >> 4) | ((s[j] >> 6) << 4); }
+        const uint8_t qb = blk[16 + 32 * g + l];
+        const int q = (j & 1) ? (qb >> 4) : (qb & 0xF);
+        return d * (float)sc * (float)q - dmin * (float)m;
+    } else {
+        const uint8_t *ql = blk, *qh = blk + 128;
+        const int8_t* sc = reinterpret_cast<const int8_t*>(blk + 192);
+        const float d = f16_bits_to_f32(*reinterpret_cast<const uint16_t*>(blk + 208));
+        const int n = i >> 7, t = (i >> 5) & 3, l = i & 31;
+        const uint8_t lb = ql[64 * n + 32 * (t & 1) + l];
+        const int lo4 = (t & 2) ? (lb >> 4) : (lb & 0xF);
+        const int hi2 = (qh[32 * n + l] >> (2 * t)) & 3;
+        const int q = (lo4 | (hi2 << 4)) - 32;
+        return d * (float)sc[8 * n + 2 * t + (l >> 4)] * (float)q;
+    }
+}
+
+__global__ void __launch_bounds__(256) dequantize_native_kernel(float* __restrict__ out, const uint8_t* __restrict__ w,
+                                                                int type, int64_t n_blocks) {
+    const int bb = (type == MI355_GGML_Q4_K) ? Q4K_BLOCK : Q6K_BLOCK;
+    for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x)
+        out[b * 256 + threadIdx.x] = dequant_native(type, w + b * bb, threadIdx.x);
+}
+extern "C" int mi355_dequantize(float* out, const void* w_native, int32_t ggml_type, int64_t n_elems, int64_t stream) {
+    if ((ggml_type != MI355_GGML_Q4_K && ggml_type != MI355_GGML_Q6_K) || (n_elems % 256)) return (int)hipErrorInvalidValue;
+    if (n_elems == 0) return 0;
+    const int64_t nb = n_elems / 256;
+    hipLaunchKernelGGL(dequantize_native_kernel, dim3((unsigned)(nb < 65535 ? nb : 65535)), dim3(256), 0,
+                       to_stream(stream), out, (const uint8_t*)w_native, ggml_type, nb);
+    return (int)hipGetLastError();
+}
+
+// one wave per (row, token): y[t][row] = sum_k x[t][k] * dequant(W[row][k])
+__global__ void __launch_bounds__(256) qmatmul_ref_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                          const uint8_t* __restrict__ w, int type, int T, int N, int K) {
+    const int bb = (type == MI355_GGML_Q4_K) ? Q4K_BLOCK : Q6K_BLOCK;
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= (int64_t)T * N) return;
+    const int t = (int)(wid / N), row = (int)(wid % N);
+    const uint8_t* wr = w + (int64_t)row * (K / 256) * bb;
+    const float* xr = x + (int64_t)t * K;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc = fmaf(xr[k], dequant_native(type, wr + (int64_t)(k >> 8) * bb, k & 255), acc);
+    acc = wave_sum(acc);
+    if (lane == 0) out[(int64_t)t * N + row] = acc;
+}
+extern "C" int mi355_qmatmul_ref(float* out, const float* x, const void* w_native, int32_t ggml_type, int32_t T,
+                                 int32_t N, int32_t K, int64_t stream) {
+    if ((ggml_type != MI355_GGML_Q4_K && ggml_type != MI355_GGML_Q6_K) || (K % 256) || T < 0 || N <= 0) return (int)hipErrorInvalidValue;
+    if (T == 0) return 0;
+    const int64_t waves = (int64_t)T * N;
+    hipLaunchKernelGGL(qmatmul_ref_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, to_stream(stream), out, x,
+                       (const uint8_t*)w_native, ggml_type, T, N, K);
+    return (int)hipGetLastError();
+}
+
+// ================================================================================================
+// The MFMA streaming kernel.
+struct QmmSeg {
+    const uint8_t* w;     // repacked tiles [n_tiles][nkb][tile]
+    int32_t type;         // MI355_GGML_Q4_K / Q6_K
+    int32_t n_tiles;      // 16-row tiles in this segment
+    int32_t row0;         // first output row of this segment (in the concatenated output space)
+    int32_t n_rows;       // true rows (<= 16*n_tiles)
+};
+
+struct QmmArgs {
+    QmmSeg seg[3];
+    int32_t nseg;
+    int32_t paired;           // 1: seg[0] = gate, seg[1] = up, workgroup t handles tile t of both (R = 2)
+    const float* x;           // [B][ldx] f32
+    int32_t ldx, K, B, kch;   // kch = k-blocks staged per LDS chunk
+    const float* norm_w;      // fused RMSNorm weight [K] or null
+    float eps;
+    int32_t epi;              // MI355_EPI_*
+    float* out;               // [B][ldo]
+    int32_t ldo;
+    const float* resid;       // [B][ldo] (EPI_RESID), may alias out
+    const float* bias;        // [sum rows] or null
+    // EPI_QKV_ROPE_CACHE
+    const float* cos_t;
+    const float* sin_t;
+    const int64_t* positions;
+    const int64_t* slot_mapping;
+    uint16_t* q_out;          // bf16 [B][Hq*D]
+    uint16_t* kcache;
+    uint16_t* vcache;
+    int32_t Hq, Hkv, D, rot, block_size, kv_layout;
+};
+
+struct TileRegs { uint4 a, b, c, d; uint32_t e; };
+
+__device__ __forceinline__ TileRegs load_tile(int type, const uint8_t* __restrict__ t, int lane) {
+    TileRegs r;
+    const int row = lane & 15;
+    if (type == MI355_GGML_Q4_K) {
+        r.a = *reinterpret_cast<const uint4*>(t + row * 16);                 // d, dmin, scales[12]
+        r.b = *reinterpret_cast<const uint4*>(t + 256 + lane * 16);          // groups 0,1
+        r.c = *reinterpret_cast<const uint4*>(t + 1280 + lane * 16);         // groups 2,3
+        r.d = make_uint4(0, 0, 0, 0);
+        r.e = 0;
+    } else {
+        r.a = *reinterpret_cast<const uint4*>(t + row * 16);                 // 16 x i8 scales
+        r.b = *reinterpret_cast<const uint4*>(t + 256 + lane * 16);          // ql half 0
+        r.c = *reinterpret_cast<const uint4*>(t + 1280 + lane * 16);         // ql half 1
+        r.d = *reinterpret_cast<const uint4*>(t + 2304 + lane * 16);         // qh
+        r.e = *reinterpret_cast<const uint16_t*>(t + 3328 + row * 2);        // d (f16)
+    }
+    return r;
+}
+
+// LDS image of the staged activations for one chunk of `kch` k-blocks (BT batch entries):
+//   ximg : [kch*32 entries][2*BT rows][8 bf16]  entry E <-> elements 8E..8E+7 in order {0,2,1,3,4,6,5,7};
+//          rows 0..BT-1 = hi(bf16(x)), rows BT..2BT-1 = lo(bf16(x - hi))
+//   xs32 : [kch*8 ][2][BT] f32   sum of the 32 staged bf16 values (hi / lo) of each 32-sub-block
+//   xs16 : [kch*16][2][BT] f32   same per 16-sub-block (Q6_K)
+template <int BT>
+struct XLds {
+    uint8_t* ximg;
+    float* xs32;
+    float* xs16;
+};
+
+template <int BT, int NV>
+__device__ __forceinline__ void compute_q4k(const TileRegs& w, const XLds<BT>& L, int kbl, int lane, float (&y)[NV]) {
+    const int m = lane & 15, kg = lane >> 4;
+    const float d = f16_bits_to_f32((uint16_t)(w.a.x & 0xFFFF));
+    const float dmin = f16_bits_to_f32((uint16_t)(w.a.x >> 16));
+    const uint32_t s0 = w.a.y, s1 = w.a.z, s2 = w.a.w;
+    // 6-bit scales / mins, 4 at a time in byte lanes (get_scale_min_k4)
+    const uint32_t scl = s0 & 0x3F3F3F3Fu, mnl = s1 & 0x3F3F3F3Fu;
+    const uint32_t sch = (s2 & 0x0F0F0F0Fu) | ((s0 >> 2) & 0x30303030u);
+    const uint32_t mnh = ((s2 >> 4) & 0x0F0F0F0Fu) | ((s1 >> 2) & 0x30303030u);
+    float dsc[8], cj[8];
+    const float d128 = d * 128.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = (float)((scl >> (8 * j)) & 0xFF), b = (float)((sch >> (8 * j)) & 0xFF);
+        const float ma = (float)((mnl >> (8 * j)) & 0xFF), mb = (float)((mnh >> (8 * j)) & 0xFF);
+        dsc[j] = d * a;
+        dsc[j + 4] = d * b;
+        cj[j] = fmaf(dmin, ma, d128 * a);
+        cj[j + 4] = fmaf(dmin, mb, d128 * b);
+    }
+    // A-fragment row of this lane (hi rows 0..BT-1 -> MFMA rows 0..7, lo rows -> MFMA rows 8..15)
+    const bool arow_ok = (m < BT) || (m >= 8 && m < 8 + BT);
+    const int arow = (m < 8) ? m : (BT + m - 8);
+    const int hl = kg >> 1;                                           // C rows 4kg+v : kg 0,1 = hi ; 2,3 = lo
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const uint4 qs = p ? w.c : w.b;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const uint32_t w0 = pr ? qs.z : qs.x, w1 = pr ? qs.w : qs.y;
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) {
+                const int j = 4 * p + 2 * pr + hi;                    // sub-block index 0..7
+                const int sh = hi * 4;
+                uint4 bw;
+                bw.x = ((w0 >> sh) & 0x000F000Fu) | BF16_128;        // elements (b0, b2)
+                bw.y = ((w0 >> (sh + 8)) & 0x000F000Fu) | BF16_128;  // elements (b1, b3)
+                bw.z = ((w1 >> sh) & 0x000F000Fu) | BF16_128;        // elements (b4, b6)
+                bw.w = ((w1 >> (sh + 8)) & 0x000F000Fu) | BF16_128;  // elements (b5, b7)
+                uint4 aw = make_uint4(0, 0, 0, 0);
+                if (arow_ok) {
+                    const int E = (kbl * 8 + j) * 4 + kg;
+                    aw = *reinterpret_cast<const uint4*>(L.ximg + ((size_t)E * (2 * BT) + arow) * 16);
+                }
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw),
+                                                              __builtin_bit_cast(bf16x8_t, bw), acc, 0, 0, 0);
+                const float* xs = L.xs32 + ((size_t)(kbl * 8 + j) * 2 + hl) * BT;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const float xsum = xs[(4 * (kg & 1) + v) & (BT - 1)];
+                    y[v] = fmaf(dsc[j], acc[v], y[v]);
+                    y[v] = fmaf(-cj[j], xsum, y[v]);
+                }
+            }
+        }
+    }
+}
+
+template <int BT, int NV>
+__device__ __forceinline__ void compute_q6k(const TileRegs& w, const XLds<BT>& L, int kbl, int lane, float (&y)[NV]) {
+    const int m = lane & 15, kg = lane >> 4;
+    const float d = f16_bits_to_f32((uint16_t)(w.e & 0xFFFF));
+    const uint32_t scw[4] = {w.a.x, w.a.y, w.a.z, w.a.w};
+    const uint32_t qhw[4] = {w.d.x, w.d.y, w.d.z, w.d.w};
+    const bool arow_ok = (m < BT) || (m >= 8 && m < 8 + BT);
+    const int arow = (m < 8) ? m : (BT + m - 8);
+    const int hl = kg >> 1;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const uint4 ql = n ? w.c : w.b;
+#pragma unroll
+        for (int is = 0; is < 2; ++is) {
+            const uint32_t a = is ? ql.z : ql.x, b = is ? ql.w : ql.y, h = qhw[2 * n + is];
+            uint32_t t[4];
+            t[0] = (a & 0x0F0F0F0Fu) | ((h << 4) & 0x30303030u);
+            t[1] = (b & 0x0F0F0F0Fu) | ((h << 2) & 0x30303030u);
+            t[2] = ((a >> 4) & 0x0F0F0F0Fu) | (h & 0x30303030u);
+            t[3] = ((b >> 4) & 0x0F0F0F0Fu) | ((h >> 2) & 0x30303030u);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int s = 8 * n + 2 * tt + is;                    // 16-sub-block index 0..15
+                uint2 bw;
+                bw.x = (t[tt] & 0x00FF00FFu) | BF16_128;              // elements (b0, b2)
+                bw.y = ((t[tt] >> 8) & 0x00FF00FFu) | BF16_128;       // elements (b1, b3)
+                uint2 aw = make_uint2(0, 0);
+                if (arow_ok) {
+                    const int E = kbl * 32 + 2 * s + (kg >> 1);
+                    aw = *reinterpret_cast<const uint2*>(L.ximg + ((size_t)E * (2 * BT) + arow) * 16 + (kg & 1) * 8);
+                }
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, aw),
+                                                                __builtin_bit_cast(s16x4_t, bw), acc, 0, 0, 0);
+                const int sc8 = (int)(int8_t)((scw[s >> 2] >> (8 * (s & 3))) & 0xFF);
+                const float dsc = d * (float)sc8;
+                const float* xs = L.xs16 + ((size_t)(kbl * 16 + s) * 2 + hl) * BT;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const float xsum = xs[(4 * (kg & 1) + v) & (BT - 1)];
+                    y[v] = fmaf(dsc, fmaf(-160.f, xsum, acc[v]), y[v]);   // code = q+32 (+128 bf16 offset)
+                }
+            }
+        }
+    }
+}
+
+// Stage `nkb` k-blocks [kb0, kb0+nkb) of x (all BT batch rows) into the LDS image.
+template <int BT>
+__device__ __forceinline__ void stage_x(const QmmArgs& a, const XLds<BT>& L, int kb0, int nkb, const float* inv_rms) {
+    const int nE = nkb * 32;
+    for (int idx = threadIdx.x; idx < nE * BT; idx += blockDim.x) {
+        const int El = idx % nE, b = idx / nE;
+        float v[8];
+        float hsum = 0.f, lsum = 0.f;
+        uint32_t hw[4], lw[4];
+        if (b < a.B) {
+            const int k = (kb0 * 32 + El) * 8;
+            const float4 v0 = *reinterpret_cast<const float4*>(a.x + (size_t)b * a.ldx + k);
+            const float4 v1 = *reinterpret_cast<const float4*>(a.x + (size_t)b * a.ldx + k + 4);
+            v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+            if (a.norm_w) {
+                const float4 n0 = *reinterpret_cast<const float4*>(a.norm_w + k);
+                const float4 n1 = *reinterpret_cast<const float4*>(a.norm_w + k + 4);
+                const float s = inv_rms[b];
+                v[0] = v[0] * s * n0.x; v[1] = v[1] * s * n0.y; v[2] = v[2] * s * n0.z; v[3] = v[3] * s * n0.w;
+                v[4] = v[4] * s * n1.x; v[5] = v[5] * s * n1.y; v[6] = v[6] * s * n1.z; v[7] = v[7] * s * n1.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+        uint16_t hb[8], lb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            hb[e] = f32_to_bf16(v[e]);
+            const float hf = bf16_to_f32(hb[e]);
+            lb[e] = f32_to_bf16(v[e] - hf);
+            hsum += hf;
+            lsum += bf16_to_f32(lb[e]);
+        }
+        // fragment element order {0,2,1,3,4,6,5,7}
+        hw[0] = hb[0] | ((uint32_t)hb[2] << 16); hw[1] = hb[1] | ((uint32_t)hb[3] << 16);
+        hw[2] = hb[4] | ((uint32_t)hb[6] << 16); hw[3] = hb[5] | ((uint32_t)hb[7] << 16);
+        lw[0] = lb[0] | ((uint32_t)lb[2] << 16); lw[1] = lb[1] | ((uint32_t)lb[3] << 16);
+        lw[2] = lb[4] | ((uint32_t)lb[6] << 16); lw[3] = lb[5] | ((uint32_t)lb[7] << 16);
+        *reinterpret_cast<uint4*>(L.ximg + ((size_t)El * (2 * BT) + b) * 16) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        *reinterpret_cast<uint4*>(L.ximg + ((size_t)El * (2 * BT) + BT + b) * 16) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        // 16- and 32-element sums: lanes of a quad hold consecutive entries of the same batch row
+        const float h16 = hsum + __shfl_xor(hsum, 1, 64), l16 = lsum + __shfl_xor(lsum, 1, 64);
+        const float h32 = h16 + __shfl_xor(h16, 2, 64), l32 = l16 + __shfl_xor(l16, 2, 64);
+        if ((El & 1) == 0) {
+            L.xs16[((size_t)(El >> 1) * 2 + 0) * BT + b] = h16;
+            L.xs16[((size_t)(El >> 1) * 2 + 1) * BT + b] = l16;
+        }
+        if ((El & 3) == 0) {
+            L.xs32[((size_t)(El >> 2) * 2 + 0) * BT + b] = h32;
+            L.xs32[((size_t)(El >> 2) * 2 + 1) * BT + b] = l32;
+        }
+    }
+}
+
+__device__ __forceinline__ float silu_f(float g) { return g / (1.f + __expf(-g)); }
+
+template <int BT, int R>
+__global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) {
+    constexpr int NV = BT < 4 ? BT : 4;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
+    const int nkb = a.K >> 8;
+
+    // ---- which tile(s) does this workgroup own?
+    int segi[R], tile[R];
+    if (R == 2) {
+        segi[0] = 0; tile[0] = blockIdx.x;
+        segi[R - 1] = 1; tile[R - 1] = blockIdx.x;
+    } else {
+        int t = blockIdx.x, s = 0;
+        while (s + 1 < a.nseg && t >= a.seg[s].n_tiles) { t -= a.seg[s].n_tiles; ++s; }
+        segi[0] = s; tile[0] = t;
+    }
+    const uint8_t* wbase[R];
+    int wtype[R], wtb[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        wtype[r] = a.seg[segi[r]].type;
+        wtb[r] = (wtype[r] == MI355_GGML_Q4_K) ? Q4K_TILE : Q6K_TILE;
+        wbase[r] = a.seg[segi[r]].w + (size_t)tile[r] * nkb * wtb[r];
+    }
+
+    // ---- LDS carve-up (all offsets multiples of 16)
+    const int kch = a.kch;
+    XLds<BT> L;
+    L.ximg = smem;
+    L.xs32 = reinterpret_cast<float*>(smem + (size_t)kch * 32 * 2 * BT * 16);
+    L.xs16 = L.xs32 + (size_t)kch * 8 * 2 * BT;
+    float* red = L.xs16 + (size_t)kch * 16 * 2 * BT;             // [NW][R][BT][16]
+    float* inv_rms = red + (size_t)NW * R * BT * 16;              // [BT]
+
+    float y[R][NV];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) y[r][v] = 0.f;
+
+    // first weight loads go out before anything else so they overlap the activation staging
+    TileRegs cur[R], nxt[R];
+    int kb = wave;                                                // this wave's k-blocks: wave, wave+NW, ...
+    if (kb < nkb) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) cur[r] = load_tile(wtype[r], wbase[r] + (size_t)kb * wtb[r], lane);
+    }
+
+    // ---- fused RMSNorm statistics (one wave per batch row, no barrier until the end)
+    if (a.norm_w) {
+        for (int b = wave; b < a.B; b += NW) {
+            const float4* xr = reinterpret_cast<const float4*>(a.x + (size_t)b * a.ldx);
+            float ss = 0.f;
+            for (int i = lane; i < a.K / 4; i += 64) {
+                const float4 v = xr[i];
+                ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) inv_rms[b] = rsqrtf(ss / (float)a.K + a.eps);
+        }
+        __syncthreads();
+    }
+
+    for (int c0 = 0; c0 < nkb; c0 += kch) {
+        const int cn = min(kch, nkb - c0);
+        if (c0 > 0) __syncthreads();                              // previous chunk fully consumed
+        stage_x<BT>(a, L, c0, cn, inv_rms);
+        __syncthreads();
+        // this wave's k-blocks inside [c0, c0+cn)
+        for (; kb < c0 + cn; kb += NW) {
+            const int kn = kb + NW;
+            if (kn < nkb) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) nxt[r] = load_tile(wtype[r], wbase[r] + (size_t)kn * wtb[r], lane);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (wtype[r] == MI355_GGML_Q4_K) compute_q4k<BT, NV>(cur[r], L, kb - c0, lane, y[r]);
+                else compute_q6k<BT, NV>(cur[r], L, kb - c0, lane, y[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) cur[r] = nxt[r];
+        }
+    }
+
+    // ---- hi + lo, then cross-wave reduction in LDS.  After the xor-32 add, lanes 0..31 hold batch 4*kg+v.
+    const int kg = lane >> 4, row = lane & 15;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            y[r][v] += __shfl_xor(y[r][v], 32, 64);
+            const int b = 4 * kg + v;
+            if (kg < 2 && b < BT) red[(((size_t)wave * R + r) * BT + b) * 16 + row] = y[r][v];
+        }
+    __syncthreads();
+
+    // ---- epilogue: thread -> (b, row) of the (first) tile; sums over waves
+    const int nout = BT * 16;
+    for (int idx = threadIdx.x; idx < nout; idx += blockDim.x) {
+        const int b = idx >> 4, rr = idx & 15;
+        if (b >= a.B) continue;
+        float val[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float s = 0.f;
+            for (int w = 0; w < NW; ++w) s += red[(((size_t)w * R + r) * BT + b) * 16 + rr];
+            val[r] = s;
+        }
+        const QmmSeg& sg = a.seg[segi[0]];
+        const int lrow = tile[0] * 16 + rr;                       // row inside the segment
+        if (lrow >= sg.n_rows) continue;
+        const int orow = sg.row0 + lrow;
+        if (a.bias) val[0] += a.bias[orow];
+        if (a.epi == MI355_EPI_STORE) {
+            a.out[(size_t)b * a.ldo + orow] = val[0];
+        } else if (a.epi == MI355_EPI_RESID) {
+            a.out[(size_t)b * a.ldo + orow] = a.resid[(size_t)b * a.ldo + orow] + val[0];
+        } else if (a.epi == MI355_EPI_SILU_MUL) {
+            if (a.bias) val[R - 1] += a.bias[a.seg[1].row0 + lrow];
+            a.out[(size_t)b * a.ldo + lrow] = silu_f(val[0]) * val[R - 1];
+        } else if (a.epi == MI355_EPI_QKV_ROPE_CACHE) {
+            // segment 0 = q, 1 = k, 2 = v ; interleaved RoPE on (even,odd) channel pairs of q and k
+            const int D = a.D, d = lrow % D, hh = lrow / D;
+            float o = val[0];
+            if (segi[0] < 2 && d < a.rot) {
+                // partner value = same thread set? no: partner row rr^1 lives in another thread -> recompute its sum
+                float pv = 0.f;
+                for (int w = 0; w < NW; ++w) pv += red[(((size_t)w * R) * BT + b) * 16 + (rr ^ 1)];
+                if (a.bias) pv += a.bias[orow ^ 1];
+                const int64_t pos = a.positions[b];
+                const float c = a.cos_t[pos * (a.rot >> 1) + (d >> 1)], s = a.sin_t[pos * (a.rot >> 1) + (d >> 1)];
+                o = (d & 1) ? (pv * s + val[0] * c) : (val[0] * c - pv * s);
+            }
+            const uint16_t ob = f32_to_bf16(o);
+            if (segi[0] == 0) {
+                a.q_out[(size_t)b * a.Hq * D + lrow] = ob;
+            } else {
+                const int64_t slot = a.slot_mapping[b];
+                if (slot >= 0) {
+                    uint16_t* cache = (segi[0] == 1) ? a.kcache : a.vcache;
+                    if (a.kv_layout == MI355_KV_FLASH) {
+                        cache[(slot * a.Hkv + hh) * D + d] = ob;
+                    } else {
+                        const int64_t blk = slot / a.block_size, off = slot % a.block_size;
+                        if (segi[0] == 1)
+                            cache[((((blk * a.Hkv + hh) * (D / 8) + d / 8) * a.block_size + off) * 8) + d % 8] = ob;
+                        else
+                            cache[((blk * a.Hkv + hh) * D + d) * (int64_t)a.block_size + off] = ob;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launcher
+static size_t qmm_lds_bytes(int BT, int R, int NW, int kch) {
+    return (size_t)kch * 32 * 2 * BT * 16 + (size_t)kch * 8 * 2 * BT * 4 + (size_t)kch * 16 * 2 * BT * 4 +
+           (size_t)NW * R * BT * 16 * 4 + (size_t)BT * 4 + 64;
+}
+
+template <int BT>
+static int qmm_launch_bt(QmmArgs& a, int n_wg, int NW, hipStream_t st) {
+    const int R = a.paired ? 2 : 1;
+    const int nkb = a.K / 256;
+    // k-blocks per LDS chunk: keep the image <= ~72 KB so two workgroups fit a CU
+    const size_t per_kb = (size_t)32 * 2 * BT * 16 + 8 * 2 * BT * 4 + 16 * 2 * BT * 4;
+    int kch = (int)((72 * 1024) / per_kb);
+    if (kch < 1) kch = 1;
+    if (kch > nkb) kch = nkb;
+    a.kch = kch;
+    const size_t shm = qmm_lds_bytes(BT, R, NW, kch);
+    if (R == 2) {
+        static bool attr_done = false;
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)qmm_kernel<BT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+        hipLaunchKernelGGL((qmm_kernel<BT, 2>), dim3(n_wg), dim3(64 * NW), shm, st, a);
+    } else {
+        static bool attr_done = false;
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)qmm_kernel<BT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+        hipLaunchKernelGGL((qmm_kernel<BT, 1>), dim3(n_wg), dim3(64 * NW), shm, st, a);
+    }
+    return (int)hipGetLastError();
+}
+
+// Run one fused quantised mat-mul over batch rows [0,B) in M-tiles of 8 batch entries.
+int mi355_qmm_launch(QmmArgs a, int64_t stream) {
+    if (a.K <= 0 || (a.K % 256) || a.B < 0 || a.nseg < 1 || a.nseg > 3) return (int)hipErrorInvalidValue;
+    if (a.B == 0) return 0;
+    for (int s = 0; s < a.nseg; ++s)
+        if (a.seg[s].type != MI355_GGML_Q4_K && a.seg[s].type != MI355_GGML_Q6_K) return (int)hipErrorInvalidValue;
+    if (a.paired && (a.nseg != 2 || a.seg[0].n_tiles != a.seg[1].n_tiles)) return (int)hipErrorInvalidValue;
+    int n_wg = 0;
+    if (a.paired) n_wg = a.seg[0].n_tiles;
+    else for (int s = 0; s < a.nseg; ++s) n_wg += a.seg[s].n_tiles;
+    const int nkb = a.K / 256;
+    int NW = 8;
+    while (NW > 1 && nkb < NW) NW >>= 1;
+    hipStream_t st = to_stream(stream);
+    const int B = a.B;
+    const float* x0 = a.x;
+    float* out0 = a.out;
+    const float* resid0 = a.resid;
+    uint16_t* q0 = a.q_out;
+    const int64_t* pos0 = a.positions;
+    const int64_t* slot0 = a.slot_mapping;
+    for (int b0 = 0; b0 < B; b0 += 8) {                       // M-tiles of 8 batch entries
+        const int bn = (B - b0 < 8) ? B - b0 : 8;
+        a.B = bn;
+        a.x = x0 + (size_t)b0 * a.ldx;
+        a.out = out0 ? out0 + (size_t)b0 * a.ldo : nullptr;
+        a.resid = resid0 ? resid0 + (size_t)b0 * a.ldo : nullptr;
+        a.q_out = q0 ? q0 + (size_t)b0 * a.Hq * a.D : nullptr;
+        a.positions = pos0 ? pos0 + b0 : nullptr;
+        a.slot_mapping = slot0 ? slot0 + b0 : nullptr;
+        int rc;
+        if (bn == 1) rc = qmm_launch_bt<1>(a, n_wg, NW, st);
+        else if (bn == 2) rc = qmm_launch_bt<2>(a, n_wg, NW, st);
+        else if (bn <= 4) rc = qmm_launch_bt<4>(a, n_wg, NW, st);
+        else rc = qmm_launch_bt<8>(a, n_wg, NW, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" int mi355_qmatmul(float* out, const float* x, const void* w_tiles, int32_t ggml_type, int32_t T,
+                             int32_t N, int32_t K, const float* bias, int64_t stream) {
+    if (N <= 0) return (int)hipErrorInvalidValue;
+    QmmArgs a{};
+    a.seg[0] = QmmSeg{static_cast<const uint8_t*>(w_tiles), ggml_type, (N + 15) / 16, 0, N};
+    a.nseg = 1;
+    a.x = x; a.ldx = K; a.K = K; a.B = T;
+    a.epi = MI355_EPI_STORE; a.out = out; a.ldo = N; a.bias = bias;
+    return mi355_qmm_launch(a, stream);
+}
+
+extern "C" int mi355_qmatmul_fused(const mi355_qmm_desc* d, int64_t stream) {
+    if (!d) return (int)hipErrorInvalidValue;
+    QmmArgs a{};
+    a.nseg = d->nseg;
+    if (d->nseg < 1 || d->nseg > 3) return (int)hipErrorInvalidValue;
+    int row0 = 0;
+    for (int s = 0; s < d->nseg; ++s) {
+        a.seg[s] = QmmSeg{static_cast<const uint8_t*>(d->w_tiles[s]), d->ggml_type[s], (d->n_rows[s] + 15) / 16, row0, d->n_rows[s]};
+        row0 += d->n_rows[s];
+    }
+    a.paired = (d->epilogue == MI355_EPI_SILU_MUL);
+    if (a.paired) { a.seg[1].row0 = a.seg[0].n_rows; }
+    a.x = d->x; a.ldx = d->ldx; a.K = d->k; a.B = d->num_tokens;
+    a.norm_w = d->norm_weight; a.eps = d->norm_eps;
+    a.epi = d->epilogue; a.out = d->out; a.ldo = d->ldo; a.resid = d->residual; a.bias = d->bias;
+    a.cos_t = d->cos_table; a.sin_t = d->sin_table; a.positions = d->positions; a.slot_mapping = d->slot_mapping;
+    a.q_out = static_cast<uint16_t*>(d->q_out); a.kcache = static_cast<uint16_t*>(d->key_cache);
+    a.vcache = static_cast<uint16_t*>(d->value_cache);
+    a.Hq = d->num_heads; a.Hkv = d->num_kv_heads; a.D = d->head_dim; a.rot = d->rotary_dim;
+    a.block_size = d->block_size; a.kv_layout = d->kv_layout;
+    if (a.epi == MI355_EPI_QKV_ROPE_CACHE) {
+        if (d->nseg != 3 || !a.q_out || !a.kcache || !a.vcache || !a.cos_t || !a.sin_t || !a.positions ||
+            !a.slot_mapping || a.D <= 0 || (a.D & 1) || a.rot <= 0 || (a.rot & 1) || a.rot > a.D ||
+            d->n_rows[0] != a.Hq * a.D || d->n_rows[1] != a.Hkv * a.D || d->n_rows[2] != a.Hkv * a.D ||
+            (d->n_rows[0] % 16) || (d->n_rows[1] % 16))
+            return (int)hipErrorInvalidValue;
+    }
+    if (a.epi == MI355_EPI_RESID && !a.resid) return (int)hipErrorInvalidValue;
+    if ((a.epi == MI355_EPI_STORE || a.epi == MI355_EPI_RESID || a.epi == MI355_EPI_SILU_MUL) && !a.out)
+        return (int)hipErrorInvalidValue;
+    return mi355_qmm_launch(a, stream);
+}

@@ -1,0 +1,171 @@
+/* mi355_vllm.h -- C ABI of the MI355X (gfx950) paged-attention + quantised-matmul decode path.
+ *
+ * Drop-in boundary for candle-vllm's `src/backend` (reference @ /root/reference, crate v0.8.9).
+ * The reference binds its device code through `attention_rs::kernels::ffi` (an `extern "C"` block:
+ * void return, raw device pointers, i32 dims, the stream handle as i64 -- src/backend/cache.rs:127-162,
+ * src/backend/gptq.rs:99-199) plus the Rust-level API of attention-rs / candle that has no C spelling
+ * (PagedAttention::forward, FusedRope, cache::swap_blocks, QMatMul::forward, rms_norm ...).
+ *
+ * Conventions (identical to the reference FFI unless stated):
+ *   - every entry point enqueues asynchronously on `stream` (a hipStream_t passed as int64_t; 0 = null stream);
+ *   - pointers are raw DEVICE pointers unless the comment says HOST; the caller owns all buffers;
+ *   - symbols spelled exactly like the reference FFI (`copy_blocks_bf16` ...) keep its `void` signature
+ *     verbatim so the Rust `extern "C"` block binds unchanged;
+ *   - `mi355_*` entry points return an int status (0 = ok, otherwise a hipError_t value) because the
+ *     Python/C++ harness has no other error channel; a Rust binding may ignore it.
+ *   - no torch / candle types anywhere in this file.
+ */
+#ifndef MI355_VLLM_H
+#define MI355_VLLM_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element dtype codes */
+#define MI355_DTYPE_F32 0
+#define MI355_DTYPE_F16 1
+#define MI355_DTYPE_BF16 2
+#define MI355_DTYPE_U8 3
+/* KV cache layouts -- src/scheduler/cache_engine.rs:298-341 */
+#define MI355_KV_FLASH 0 /* K,V [num_blocks, block_size, num_kv_heads, head_dim]            (:326-341) */
+#define MI355_KV_PAGED 1 /* K [nb, Hkv, D/x, bs, x], V [nb, Hkv, D, bs], x = 16/elem_size   (:298-324) */
+/* ggml tensor type ids (GGUF) */
+#define MI355_GGML_Q4_K 12
+#define MI355_GGML_Q6_K 14
+/* swap directions */
+#define MI355_SWAP_H2D 0
+#define MI355_SWAP_D2H 1
+#define MI355_SWAP_D2D 2
+/* fused epilogues of mi355_qmatmul_fused */
+#define MI355_EPI_STORE 0          /* out[t][row] = y (+bias)                                         */
+#define MI355_EPI_RESID 1          /* out[t][row] = residual[t][row] + y (+bias)   (out may alias)    */
+#define MI355_EPI_SILU_MUL 2       /* 2 segments (gate, up): out[t][row] = silu(gate)*up             */
+#define MI355_EPI_QKV_ROPE_CACHE 3 /* 3 segments (q,k,v): interleaved RoPE on q,k; bf16 cast; q -> q_out,
+                                      k,v scattered into the paged cache at slot_mapping[t]          */
+
+/* ---------------------------------------------------------------------------------------------
+ * 1. Reference FFI symbols, verbatim (attention_rs::kernels::ffi).
+ * ------------------------------------------------------------------------------------------- */
+/* replaces attention_rs::kernels::ffi::copy_blocks_{bf16,f16,f32} -- src/backend/cache.rs:127-162.
+ * key_cache_ptrs / value_cache_ptrs: HOST arrays u64[num_layers] of device addresses;
+ * block_mapping: HOST i64[2*num_pairs] = (src,dst) pairs; numel_per_block = elements of key_cache[0]. */
+void copy_blocks_bf16(void* key_cache_ptrs, void* value_cache_ptrs, const void* block_mapping,
+                      int32_t num_layers, int32_t num_pairs, int32_t numel_per_block, int64_t stream);
+void copy_blocks_f16(void* key_cache_ptrs, void* value_cache_ptrs, const void* block_mapping,
+                     int32_t num_layers, int32_t num_pairs, int32_t numel_per_block, int64_t stream);
+void copy_blocks_f32(void* key_cache_ptrs, void* value_cache_ptrs, const void* block_mapping,
+                     int32_t num_layers, int32_t num_pairs, int32_t numel_per_block, int64_t stream);
+/* same, for the fp8 KV cache the reference stores as u8 (src/main.rs:263-267); not in the reference FFI */
+void copy_blocks_u8(void* key_cache_ptrs, void* value_cache_ptrs, const void* block_mapping,
+                    int32_t num_layers, int32_t num_pairs, int32_t numel_per_block, int64_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 2. attention-rs Rust-level API re-expressed as C.
+ * ------------------------------------------------------------------------------------------- */
+/* replaces attention_rs::cache::swap_blocks(src, dst, &HashMap) -- src/scheduler/cache_engine.rs:527-535.
+ * mapping_pairs: HOST i64[2*num_pairs] (src_block, dst_block); bytes_per_block = elem_count/dim0*elem_size. */
+int mi355_swap_blocks(const void* src, void* dst, const int64_t* mapping_pairs, int32_t num_pairs,
+                      int64_t bytes_per_block, int32_t kind, int64_t stream);
+
+/* the cache-write half of PagedAttention::forward -- src/openai/models/layers/attention.rs:983-995.
+ * k, v: [num_tokens, num_kv_heads, head_dim] (elem_size bytes/elem, copied bit-exactly);
+ * slot_mapping: i64 [num_tokens], slot = block*block_size + offset, negative = skip (llm_engine.rs:94). */
+int mi355_reshape_and_cache(const void* k, const void* v, void* key_cache, void* value_cache,
+                            const int64_t* slot_mapping, int32_t num_tokens, int32_t num_kv_heads,
+                            int32_t head_dim, int32_t block_size, int32_t elem_size, int32_t layout,
+                            int64_t stream);
+
+/* the decode half of PagedAttention::forward (same call site; metadata src/openai/pipelines/inputs.rs:552-568).
+ * q, out: [num_seqs, num_heads, head_dim] 16-bit (dtype = MI355_DTYPE_BF16 / F16, also the cache dtype);
+ * block_tables: u32 [num_seqs, max_blocks_per_seq] (0-padded); context_lens: u32 [num_seqs];
+ * softcap <= 0 disables soft-capping.  v1 = one partition per sequence; v2 = context split into
+ * partition_size-token partitions merged by a log-sum-exp reduce
+ * (tmp_out f32 [num_seqs,num_heads,P,head_dim], exp_sums/max_logits f32 [num_seqs,num_heads,P],
+ *  P = ceil(max_context_len/partition_size)). */
+int mi355_paged_attention_v1(void* out, const void* q, const void* key_cache, const void* value_cache,
+                             const uint32_t* block_tables, const uint32_t* context_lens, int32_t num_seqs,
+                             int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                             int32_t max_blocks_per_seq, int32_t max_context_len, float scale, float softcap,
+                             int32_t layout, int32_t dtype, int64_t stream);
+int mi355_paged_attention_v2(void* out, float* exp_sums, float* max_logits, float* tmp_out, const void* q,
+                             const void* key_cache, const void* value_cache, const uint32_t* block_tables,
+                             const uint32_t* context_lens, int32_t num_seqs, int32_t num_heads,
+                             int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                             int32_t max_blocks_per_seq, int32_t max_context_len, int32_t partition_size,
+                             float scale, float softcap, int32_t layout, int32_t dtype, int64_t stream);
+
+/* replaces attention_rs::fused_rope::FusedRope::apply_inplace[_partial] -- layers/rotary_emb.rs:58-70.
+ * q [T,H,D], k [T,Hkv,D] rotated in place; cos/sin f32 [max_seq, rotary_dim/2]; positions i64 [T];
+ * is_rope_i != 0 -> interleaved pairs (GGUF llama), else half-split ("neox"). dtype F32 or BF16. */
+int mi355_rope_inplace(void* q, void* k, const float* cos_table, const float* sin_table,
+                       const int64_t* positions, int32_t num_tokens, int32_t num_heads,
+                       int32_t num_kv_heads, int32_t head_dim, int32_t rotary_dim, int32_t is_rope_i,
+                       int32_t dtype, int64_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 3. candle ops on the path.
+ * ------------------------------------------------------------------------------------------- */
+/* candle_nn::ops::rms_norm(x, w, eps) -- layers/qrmsnorm.rs:28-31.  x,out [T,hidden]; dtype F32 or BF16. */
+int mi355_rms_norm(void* out, const void* x, const void* weight, int32_t num_tokens, int32_t hidden,
+                   float eps, int32_t dtype, int32_t weight_dtype, int64_t stream);
+/* candle_nn::ops::silu(gate) * up -- quantized_llama.rs:33-37 */
+int mi355_silu_mul(void* out, const void* gate, const void* up, int64_t n, int32_t dtype, int64_t stream);
+/* residual add (quantized_llama.rs:464,470) */
+int mi355_add_f32(float* out, const float* a, const float* b, int64_t n, int64_t stream);
+/* Tensor::to_dtype between F32 and BF16 (attention.rs:977-981, 1004) */
+int mi355_cast(void* out, const void* in, int64_t n, int32_t src_dtype, int32_t dst_dtype, int64_t stream);
+/* Embedding::forward on the dequantised table (quantized_llama.rs:262-264, 450) */
+int mi355_embedding_f32(float* out, const float* table, const uint32_t* ids, int32_t num_tokens,
+                        int32_t hidden, int64_t stream);
+/* logits.argmax(-1) -- src/openai/logits_processor.rs:92-95 (first maximum wins) */
+int mi355_argmax_f32(uint32_t* out, const float* logits, int32_t batch, int32_t vocab, int64_t stream);
+
+/* candle QTensor::dequantize on NATIVE GGUF blocks (quantized_llama.rs:262-264) -> f32 */
+int mi355_dequantize(float* out, const void* w_native, int32_t ggml_type, int64_t n_elems, int64_t stream);
+/* candle QMatMul::forward reference path on NATIVE blocks (simple kernel; cross-check / small matrices) */
+int mi355_qmatmul_ref(float* out, const float* x, const void* w_native, int32_t ggml_type, int32_t num_tokens,
+                      int32_t n, int32_t k, int64_t stream);
+
+/* One-time (load-time) re-tiling of a GGUF matrix [n_rows, k] into the MI355X tile order consumed by
+ * mi355_qmatmul / mi355_qmatmul_fused.  HOST -> HOST; same byte count per weight; rows padded to 16. */
+int64_t mi355_qweight_repacked_size(int32_t ggml_type, int64_t n_rows, int64_t k);
+int mi355_qweight_repack(void* dst_host, const void* src_native_host, int32_t ggml_type, int64_t n_rows, int64_t k);
+
+/* candle QMatMul::forward (attention.rs:920-922,1004; quantized_llama.rs:33-37):
+ * out f32 [num_tokens, n] = x f32 [num_tokens, k] . dequant(W)^T (+ bias f32 [n] or NULL) */
+int mi355_qmatmul(float* out, const float* x, const void* w_tiles, int32_t ggml_type, int32_t num_tokens,
+                  int32_t n, int32_t k, const float* bias, int64_t stream);
+
+/* Fused decode building block: [RMSNorm ->] up to 3 quantised matrices sharing x -> epilogue. */
+typedef struct mi355_qmm_desc {
+    int32_t nseg;               /* 1..3 weight matrices that share the input x                         */
+    const void* w_tiles[3];     /* repacked weights                                                    */
+    int32_t ggml_type[3];
+    int32_t n_rows[3];          /* output rows of each matrix                                          */
+    const float* x;             /* f32 [num_tokens, ldx]                                               */
+    int32_t ldx, k, num_tokens;
+    const float* norm_weight;   /* non-NULL: x <- rms_norm(x, norm_weight, norm_eps) before the matmul */
+    float norm_eps;
+    int32_t epilogue;           /* MI355_EPI_*                                                         */
+    float* out;                 /* f32 [num_tokens, ldo]                                               */
+    int32_t ldo;
+    const float* residual;      /* EPI_RESID                                                           */
+    const float* bias;          /* f32 [sum n_rows] or NULL                                            */
+    /* EPI_QKV_ROPE_CACHE only */
+    const float* cos_table;
+    const float* sin_table;
+    const int64_t* positions;
+    const int64_t* slot_mapping;
+    void* q_out;                /* bf16 [num_tokens, num_heads*head_dim]                               */
+    void* key_cache;            /* bf16 paged cache                                                    */
+    void* value_cache;
+    int32_t num_heads, num_kv_heads, head_dim, rotary_dim, block_size, kv_layout;
+} mi355_qmm_desc;
+int mi355_qmatmul_fused(const mi355_qmm_desc* desc, int64_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_VLLM_H */

@@ -1,0 +1,310 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY) -- the decode hot path's operators, restated in numpy.
+
+PARITY UNPINNED for the floating-point operators: the reference has no tests, golden vectors or
+CPU implementation for them; each function cites the reference
+call site whose semantics it follows.  Integer / index operators are exact restatements.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import numpy as np
+
+PAD_SLOT_ID = -1          # src/openai/pipelines/llm_engine.rs:94 (_PAD_SLOT_ID)
+
+
+# --------------------------------------------------------------------------- bf16 helpers
+def f32_to_bf16_bits(x):
+    """round-to-nearest-even f32 -> bf16 bit pattern (uint16); NaN preserved as quiet NaN."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    rounding = np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))
+    r = ((u + rounding) >> np.uint32(16)).astype(np.uint16)
+    nan = np.isnan(np.asarray(x, np.float32))
+    if np.any(nan):
+        r = np.where(nan, np.uint16(0x7FC0), r)
+    return r
+
+
+def bf16_bits_to_f32(b):
+    return (np.ascontiguousarray(b, np.uint16).astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
+def round_bf16(x):
+    return bf16_bits_to_f32(f32_to_bf16_bits(x))
+
+
+# --------------------------------------------------------------------------- norms / activations
+def rms_norm(x, w, eps):
+    """candle_nn::ops::rms_norm(x, w, eps): x*rsqrt(mean(x^2)+eps)*w in f32.
+    Reference call: src/openai/models/layers/qrmsnorm.rs:28-31."""
+    x64 = np.asarray(x, np.float64)
+    ms = (x64 * x64).mean(-1, keepdims=True)
+    return (x64 / np.sqrt(ms + eps) * np.asarray(w, np.float64)).astype(np.float32)
+
+
+def silu_mul(gate, up):
+    """candle_nn::ops::silu(&w1)? * w3  -- src/openai/models/quantized_llama.rs:33-37."""
+    g = np.asarray(gate, np.float64)
+    return (g / (1.0 + np.exp(-g)) * np.asarray(up, np.float64)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------- RoPE
+def rope_tables(rope_theta, rotary_dim, max_seq_len):
+    """cos/sin [max_seq, rotary_dim/2] f32 -- src/openai/models/layers/rotary_emb.rs:14-48.
+    inv_freq[i] = (1 / theta^(2i/dim)) as f32 ; idx_theta = pos (f32) * inv_freq (f32 matmul)."""
+    i = np.arange(0, rotary_dim, 2, dtype=np.float64)
+    inv_freq = (1.0 / np.power(float(rope_theta), i / rotary_dim)).astype(np.float32)
+    pos = np.arange(max_seq_len, dtype=np.float32)[:, None]
+    idx_theta = (pos * inv_freq[None, :]).astype(np.float32)
+    return np.cos(idx_theta).astype(np.float32), np.sin(idx_theta).astype(np.float32)
+
+
+def rope_apply(x, cos, sin, positions, interleaved, rotary_dim=None):
+    """x [T, H, D] f32; returns rotated copy.
+
+    interleaved=True  -> candle `rope_i`: pairs (x[2i], x[2i+1])      (GGUF llama,
+                         src/openai/models/quantized_llama.rs:313-318 passes is_gpt_neox=false)
+    interleaved=False -> candle `rope`  : pairs (x[i], x[i+rot/2])    (HF llama, llama.rs:222)
+    Partial rotary: only the first `rotary_dim` channels rotate (rotary_emb.rs:80-94).
+    """
+    x = np.asarray(x, np.float32)
+    T, H, D = x.shape
+    rot = D if rotary_dim is None else rotary_dim
+    c = cos[np.asarray(positions)][:, None, : rot // 2].astype(np.float32)
+    s = sin[np.asarray(positions)][:, None, : rot // 2].astype(np.float32)
+    out = x.copy()
+    xr = x[..., :rot]
+    if interleaved:
+        x0 = xr[..., 0::2]
+        x1 = xr[..., 1::2]
+        out[..., 0:rot:2] = x0 * c - x1 * s
+        out[..., 1:rot:2] = x0 * s + x1 * c
+    else:
+        x0 = xr[..., : rot // 2]
+        x1 = xr[..., rot // 2:]
+        out[..., : rot // 2] = x0 * c - x1 * s
+        out[..., rot // 2: rot] = x0 * s + x1 * c
+    return out
+
+
+# --------------------------------------------------------------------------- KV cache layouts
+def kv_cache_shapes(num_blocks, block_size, num_kv_heads, head_dim, elem_size, flash_layout):
+    """src/scheduler/cache_engine.rs:298-341.  Returns (key_shape, value_shape)."""
+    if flash_layout:
+        s = (num_blocks, block_size, num_kv_heads, head_dim)
+        return s, s
+    x = 16 // elem_size
+    return ((num_blocks, num_kv_heads, head_dim // x, block_size, x),
+            (num_blocks, num_kv_heads, head_dim, block_size))
+
+
+def reshape_and_cache(k, v, key_cache, value_cache, slot_mapping, flash_layout):
+    """Scatter new K/V rows into the paged cache (in place).  k, v: [T, Hkv, D] (any dtype array,
+    copied bit-exactly); slot = block*block_size + offset; slot < 0 -> skipped.
+    Reference call: PagedAttention::forward, src/openai/models/layers/attention.rs:983-995;
+    slot construction src/openai/pipelines/inputs.rs:410-423."""
+    T, Hkv, D = k.shape
+    if flash_layout:
+        bs = key_cache.shape[1]
+        for t in range(T):
+            slot = int(slot_mapping[t])
+            if slot < 0:
+                continue
+            key_cache[slot // bs, slot % bs] = k[t]
+            value_cache[slot // bs, slot % bs] = v[t]
+    else:
+        bs = key_cache.shape[3]
+        x = key_cache.shape[4]
+        for t in range(T):
+            slot = int(slot_mapping[t])
+            if slot < 0:
+                continue
+            blk, off = slot // bs, slot % bs
+            key_cache[blk, :, :, off, :] = k[t].reshape(Hkv, D // x, x)
+            value_cache[blk, :, :, off] = v[t]
+
+
+def gather_kv(key_cache, value_cache, block_table, context_len, flash_layout):
+    """Collect [context_len, Hkv, D] K and V for one sequence through its block table."""
+    if flash_layout:
+        bs = key_cache.shape[1]
+    else:
+        bs = key_cache.shape[3]
+    ks, vs = [], []
+    for pos in range(context_len):
+        blk = int(block_table[pos // bs])
+        off = pos % bs
+        if flash_layout:
+            ks.append(key_cache[blk, off])
+            vs.append(value_cache[blk, off])
+        else:
+            kk = key_cache[blk, :, :, off, :]
+            ks.append(kk.reshape(kk.shape[0], -1))
+            vs.append(value_cache[blk, :, :, off])
+    return np.stack(ks), np.stack(vs)
+
+
+def paged_attention_decode(q, key_cache, value_cache, block_tables, context_lens, scale,
+                           flash_layout, softcap=None, kv_is_bf16_bits=True):
+    """Decode attention over the paged cache.  q: [B, H, D] f32 values (already bf16-rounded by the
+    caller, as attention.rs:977-981 casts q,k,v to bf16).  Caches hold bf16 bit patterns (uint16)
+    when kv_is_bf16_bits else float arrays.  Math = NaiveAttention, src/openai/models/mod.rs:1288-1306
+    (repeat_kv GQA expansion :1240-1247, q.k^T*scale, optional tanh softcap, softmax_last_dim, .v),
+    accumulated in f64; output rounded to bf16 (the kernel's output dtype).  Returns f32 [B, H, D]."""
+    B, H, D = q.shape
+    out = np.zeros((B, H, D), np.float32)
+    for b in range(B):
+        n = int(context_lens[b])
+        if n == 0:
+            continue
+        k, v = gather_kv(key_cache, value_cache, block_tables[b], n, flash_layout)
+        if kv_is_bf16_bits:
+            k = bf16_bits_to_f32(k)
+            v = bf16_bits_to_f32(v)
+        Hkv = k.shape[1]
+        g = H // Hkv
+        for h in range(H):
+            kh = k[:, h // g, :].astype(np.float64)
+            vh = v[:, h // g, :].astype(np.float64)
+            s = kh @ q[b, h].astype(np.float64) * scale
+            if softcap is not None:
+                s = np.tanh(s / softcap) * softcap
+            s = s - s.max()
+            p = np.exp(s)
+            p /= p.sum()
+            out[b, h] = (p @ vh).astype(np.float32)
+    return round_bf16(out)
+
+
+def copy_blocks(key_caches, value_caches, block_mapping_pairs):
+    """src/backend/cache.rs:103-162: for every layer and every (src,dst) pair copy block src->dst
+    of K and of V (dim 0 = block).  block_mapping_pairs: flat [src0,dst0,src1,dst1,...]."""
+    pairs = np.asarray(block_mapping_pairs, np.int64).reshape(-1, 2)
+    for kc, vc in zip(key_caches, value_caches):
+        for src, dst in pairs:
+            kc[dst] = kc[src]
+            vc[dst] = vc[src]
+
+
+def swap_blocks(src, dst, mapping):
+    """attention_rs::cache::swap_blocks(src, dst, &HashMap<src_blk,dst_blk>) --
+    src/scheduler/cache_engine.rs:527-535: per-block copy between two tensors whose dim 0 = block."""
+    for s, d in mapping.items():
+        dst[d] = src[s]
+
+
+# --------------------------------------------------------------------------- input preparation (integer, bit-exact)
+def used_blocks_for_len(seq_len, block_size, table_len):
+    """src/openai/pipelines/inputs.rs:12-22."""
+    if seq_len == 0:
+        return 0
+    return min(-(-seq_len // block_size), table_len)
+
+
+def prepare_decode(seqs, block_size):
+    """src/openai/pipelines/inputs.rs:376-454.  seqs: list of dicts
+    {"tokens": [...all token ids so far...], "block_table": [block ids]} in batch order.
+    Returns dict of int arrays exactly as the reference builds them."""
+    input_ids, positions, slot_mapping, context_lens, tables = [], [], [], [], []
+    for s in seqs:
+        toks = s["tokens"]
+        table = list(s["block_table"])
+        n = len(toks)
+        input_ids.append(toks[-1])
+        position = n - 1
+        positions.append(position)
+        context_lens.append(n)
+        if position // block_size >= len(table):
+            raise ValueError("Block table is too small (completion)!")
+        slot_mapping.append(table[position // block_size] * block_size + position % block_size)
+        tables.append(table[: used_blocks_for_len(n, block_size, len(table))])
+    maxlen = max(len(t) for t in tables)
+    bt = np.zeros((len(tables), maxlen), np.uint32)       # _make_tensor_with_pad(..., pad=0)
+    for i, t in enumerate(tables):
+        bt[i, : len(t)] = t
+    return {
+        "input_ids": np.asarray(input_ids, np.uint32),
+        "positions": np.asarray(positions, np.int64),
+        "slot_mapping": np.asarray(slot_mapping, np.int64),
+        "context_lens": np.asarray(context_lens, np.uint32),
+        "block_tables": bt,
+        "max_context_len": int(max(context_lens)),
+    }
+
+
+def prepare_prompt(seqs, block_size, num_cached_tokens=None):
+    """src/openai/pipelines/inputs.rs:90-230 (non-flashinfer part): flatten prompts, slot per
+    token, cu_seqlens_q/k, context_lens = cached + chunk.  seqs: {"tokens", "block_table"};
+    num_cached_tokens[i] tokens of sequence i are already in the cache (prefix cache / chunk)."""
+    input_ids, positions, slot_mapping = [], [], []
+    cu_q, cu_k, context_lens = [0], [0], []
+    tables = []
+    for i, s in enumerate(seqs):
+        cached = 0 if num_cached_tokens is None else int(num_cached_tokens[i])
+        toks = s["tokens"][cached:]
+        table = list(s["block_table"])
+        for j, t in enumerate(toks):
+            pos = cached + j
+            input_ids.append(t)
+            positions.append(pos)
+            if pos // block_size >= len(table):
+                slot_mapping.append(PAD_SLOT_ID)
+            else:
+                slot_mapping.append(table[pos // block_size] * block_size + pos % block_size)
+        cu_q.append(cu_q[-1] + len(toks))
+        cu_k.append(cu_k[-1] + cached + len(toks))
+        context_lens.append(cached + len(toks))
+        tables.append(table)
+    maxlen = max(len(t) for t in tables)
+    bt = np.zeros((len(tables), maxlen), np.uint32)
+    for i, t in enumerate(tables):
+        bt[i, : len(t)] = t
+    return {
+        "input_ids": np.asarray(input_ids, np.uint32),
+        "positions": np.asarray(positions, np.int64),
+        "slot_mapping": np.asarray(slot_mapping, np.int64),
+        "context_lens": np.asarray(context_lens, np.uint32),
+        "block_tables": bt,
+        "cu_seqlens_q": np.asarray(cu_q, np.uint32),
+        "cu_seqlens_k": np.asarray(cu_k, np.uint32),
+        "max_seqlen_q": int(max(np.diff(cu_q))),
+        "max_seqlen_k": int(max(np.diff(cu_k))),
+        "max_context_len": int(max(context_lens)),
+    }
+
+
+def num_gpu_blocks(mem_mb, dsize, block_size, num_kv_heads_local, head_dim, num_layers):
+    """get_cache_config: src/lib.rs:181-188 -- blocks = mem_MB*2^20 / (dsize*bs*Hkv*D*layers*2)."""
+    return (mem_mb * 1024 * 1024) // (dsize * block_size * num_kv_heads_local * head_dim * num_layers * 2)
+
+
+def kv_head_shard(total_kv_heads, rank, world_size):
+    """src/openai/distributed.rs:725-765 -> (local_kv_heads, shard_rank, shard_world)."""
+    if total_kv_heads == 0 or world_size == 0 or rank >= world_size:
+        raise ValueError("bad tensor-parallel arguments")
+    if total_kv_heads >= world_size:
+        if total_kv_heads % world_size:
+            raise ValueError("KV heads must be divisible by world_size")
+        return total_kv_heads // world_size, rank, world_size
+    if world_size % total_kv_heads:
+        raise ValueError("world_size must be divisible by KV heads")
+    return 1, rank // (world_size // total_kv_heads), total_kv_heads
+
+
+def prefill_attention(q, k, v, scale, softcap=None):
+    """Causal self-attention for ONE sequence without cached prefix.  q [T,H,D], k/v [T,Hkv,D]
+    f32 values already bf16-rounded.  NaiveAttention math (models/mod.rs:1288-1306) with the
+    causal additive mask of layers/mask.rs:32-53.  Output bf16-rounded f32 [T,H,D]."""
+    T, H, D = q.shape
+    Hkv = k.shape[1]
+    g = H // Hkv
+    out = np.zeros((T, H, D), np.float32)
+    mask = np.triu(np.ones((T, T), bool), 1)
+    for h in range(H):
+        s = q[:, h].astype(np.float64) @ k[:, h // g].astype(np.float64).T * scale
+        if softcap is not None:
+            s = np.tanh(s / softcap) * softcap
+        s = np.where(mask, -np.inf, s)
+        s = s - s.max(-1, keepdims=True)
+        p = np.exp(s)
+        p /= p.sum(-1, keepdims=True)
+        out[:, h] = (p @ v[:, h // g].astype(np.float64)).astype(np.float32)
+    return round_bf16(out)
