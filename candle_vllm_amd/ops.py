@@ -1,0 +1,365 @@
+"""Host-side mirror of the reference's operator interface for the decode hot path, over the C ABI.
+
+Every function takes torch tensors that live on the MI355X (torch is only the owner of device memory and
+of the stream), hands raw pointers to `libmi355vllm.so`, and raises on any failure -- there is no eager /
+CPU fallback.  Names, argument order and semantics follow the reference call sites:
+
+  copy_blocks(key_caches, value_caches, block_mapping)        src/backend/cache.rs:15-165
+  swap_blocks(src, dst, mapping)                               src/scheduler/cache_engine.rs:527-535
+  PagedAttention(...).forward(q,k,v,mask,kc,vc,meta,softcap)   src/openai/models/layers/attention.rs:983-995
+  FusedRope.apply_inplace[_partial]                            src/openai/models/layers/rotary_emb.rs:58-70
+  QMatMul.forward(x_f32)                                       src/openai/models/layers/attention.rs:920-922
+  rms_norm / silu_mul                                          layers/qrmsnorm.rs:28-31, quantized_llama.rs:33-37
+  InputMetadata                                                src/openai/pipelines/inputs.rs:552-568
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from ._lib import lib, QmmDesc
+
+DT_F32, DT_F16, DT_BF16, DT_U8 = 0, 1, 2, 3
+KV_FLASH, KV_PAGED = 0, 1
+GGML_Q4_K, GGML_Q6_K = 12, 14
+EPI_STORE, EPI_RESID, EPI_SILU_MUL, EPI_QKV_ROPE_CACHE = 0, 1, 2, 3
+SWAP_H2D, SWAP_D2H, SWAP_D2D = 0, 1, 2
+
+_DT = {torch.float32: DT_F32, torch.float16: DT_F16, torch.bfloat16: DT_BF16, torch.uint8: DT_U8}
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with hipError {rc}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU: the MI355X path has no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+@dataclass
+class InputMetadata:
+    """attention_rs::InputMetadata as the reference fills it (inputs.rs:351-367 prefill, :552-568 decode)."""
+    is_prefill: bool
+    slot_mapping: torch.Tensor                       # i64 [T]
+    block_tables: Optional[torch.Tensor] = None      # u32 [n, max_blocks] (stored as int32 bits)
+    context_lens: Optional[torch.Tensor] = None      # u32 [n]
+    cu_seqlens_q: Optional[torch.Tensor] = None
+    cu_seqlens_k: Optional[torch.Tensor] = None
+    max_seqlen_q: int = 0
+    max_seqlen_k: int = 0
+    max_context_len: int = 0
+    sequence_ids: Optional[List[int]] = None
+    seqlens: Optional[List[int]] = None
+    is_mla: bool = False
+    is_mtp_verify: bool = False
+
+    @staticmethod
+    def from_oracle_meta(meta: dict, device, is_prefill=False):
+        def t(a, dt):
+            return torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(device)
+        return InputMetadata(
+            is_prefill=is_prefill,
+            slot_mapping=t(meta["slot_mapping"], np.int64),
+            block_tables=t(meta["block_tables"].astype(np.int64), np.int32),
+            context_lens=t(meta["context_lens"].astype(np.int64), np.int32),
+            max_context_len=int(meta["max_context_len"]),
+            cu_seqlens_q=t(meta["cu_seqlens_q"].astype(np.int64), np.int32) if "cu_seqlens_q" in meta else None,
+            cu_seqlens_k=t(meta["cu_seqlens_k"].astype(np.int64), np.int32) if "cu_seqlens_k" in meta else None,
+            max_seqlen_q=int(meta.get("max_seqlen_q", 0)), max_seqlen_k=int(meta.get("max_seqlen_k", 0)))
+
+
+# ----------------------------------------------------------------------------------------------- cache ops
+def kv_layout_of(key_cache: torch.Tensor) -> int:
+    if key_cache.dim() == 4:
+        return KV_FLASH          # [NB, bs, Hkv, D]           cache_engine.rs:326-341
+    if key_cache.dim() == 5:
+        return KV_PAGED          # [NB, Hkv, D/x, bs, x]      cache_engine.rs:298-312
+    raise ValueError("unrecognised KV cache rank")
+
+
+def copy_blocks(key_caches: List[torch.Tensor], value_caches: List[torch.Tensor],
+                block_mapping: Dict[int, List[int]]):
+    """src/backend/cache.rs:15-165: for every layer copy block src -> each dst of K and of V."""
+    if len(key_caches) == 0:
+        return
+    kc0, vc0 = key_caches[0], value_caches[0]
+    if not kc0.is_cuda:
+        raise RuntimeError("copy_blocks: not implemented for CPU (cache.rs:251-258); caches must be on the GPU")
+    if kc0.device != vc0.device:
+        raise RuntimeError("`key` and `value` caches have different devices")
+    if kc0.dtype != vc0.dtype:
+        raise RuntimeError("Key and value caches have different types")
+    fn = {torch.bfloat16: lib.copy_blocks_bf16, torch.float16: lib.copy_blocks_f16,
+          torch.float32: lib.copy_blocks_f32, torch.uint8: lib.copy_blocks_u8}.get(kc0.dtype)
+    if fn is None:
+        raise RuntimeError("only f32, f16, bf16 (and u8/fp8) input data type supported!")
+    kptrs = (ctypes.c_uint64 * len(key_caches))(*[_dev(k, "key cache") for k in key_caches])
+    vptrs = (ctypes.c_uint64 * len(value_caches))(*[_dev(v, "value cache") for v in value_caches])
+    pairs = []
+    for src, dsts in block_mapping.items():
+        for d in dsts:
+            pairs += [int(src), int(d)]
+    if not pairs:
+        return
+    bm = (ctypes.c_int64 * len(pairs))(*pairs)
+    numel_per_block = int(np.prod(kc0.shape[1:]))
+    fn(ctypes.cast(kptrs, ctypes.c_void_p), ctypes.cast(vptrs, ctypes.c_void_p),
+       ctypes.cast(bm, ctypes.c_void_p), len(key_caches), len(pairs) // 2, numel_per_block, _stream())
+
+
+def swap_blocks(src: torch.Tensor, dst: torch.Tensor, mapping: Dict[int, int]):
+    """attention_rs::cache::swap_blocks -- cache_engine.rs:527-535 (either side may be a CPU tensor)."""
+    if not mapping:
+        return 0
+    if not src.is_contiguous() or not dst.is_contiguous():
+        raise RuntimeError("swap_blocks needs contiguous tensors")
+    if src.is_cuda and dst.is_cuda:
+        kind = SWAP_D2D
+    elif src.is_cuda:
+        kind = SWAP_D2H
+    elif dst.is_cuda:
+        kind = SWAP_H2D
+    else:
+        raise RuntimeError("swap_blocks: at least one side must be on the GPU")
+    bytes_per_block = (src.numel() // src.shape[0]) * src.element_size()
+    flat = []
+    for s, d in mapping.items():
+        flat += [int(s), int(d)]
+    arr = (ctypes.c_int64 * len(flat))(*flat)
+    _check(lib.mi355_swap_blocks(src.data_ptr(), dst.data_ptr(), ctypes.cast(arr, ctypes.c_void_p),
+                                 len(flat) // 2, bytes_per_block, kind, _stream()), "swap_blocks")
+    return bytes_per_block * len(mapping)
+
+
+def reshape_and_cache(k, v, key_cache, value_cache, slot_mapping):
+    layout = kv_layout_of(key_cache)
+    T, Hkv, D = k.shape
+    bs = key_cache.shape[1] if layout == KV_FLASH else key_cache.shape[3]
+    if k.dtype != key_cache.dtype:
+        raise RuntimeError("k/v dtype must equal the cache dtype")
+    _check(lib.mi355_reshape_and_cache(_dev(k), _dev(v), _dev(key_cache), _dev(value_cache),
+                                       _dev(slot_mapping), T, Hkv, D, bs, k.element_size(), layout, _stream()),
+           "reshape_and_cache")
+
+
+# ----------------------------------------------------------------------------------------------- attention
+V1_MAX_CONTEXT = 512          # above this the context is partitioned (v2), vLLM-style
+TARGET_WORKGROUPS = 1024      # >> 256 CUs
+
+
+def choose_partition(num_seqs, num_kv_heads, max_context_len):
+    """Partition size (tokens) for v2 so that the grid has >> 256 workgroups; multiple of 64."""
+    if max_context_len <= V1_MAX_CONTEXT:
+        return 0
+    per_seq = max(1, -(-TARGET_WORKGROUPS // max(1, num_seqs * num_kv_heads)))
+    ps = -(-max_context_len // per_seq)
+    ps = max(128, ((ps + 63) // 64) * 64)
+    return ps if ps < max_context_len else 0
+
+
+class PagedAttention:
+    """attention_rs::PagedAttention -- constructed as in attention.rs:888-897, forward as :983-995."""
+
+    def __init__(self, num_heads, head_dim, scale, num_kv_heads=None, sliding_window=None, device=None,
+                 alibi_slopes=None, fp8_kvcache=False):
+        if sliding_window is not None or alibi_slopes is not None:
+            raise NotImplementedError("sliding window / alibi are not used by the BASELINE models")
+        if fp8_kvcache:
+            raise NotImplementedError("fp8 KV cache: SURVEY section 8(f4), not built yet")
+        self.num_heads, self.head_dim, self.scale = num_heads, head_dim, float(scale)
+        self.num_kv_heads = num_kv_heads or num_heads
+        self._tmp = None
+
+    def _workspace(self, B, P, device):
+        need = (B, self.num_heads, P)
+        if self._tmp is None or self._tmp[0] != need:
+            self._tmp = (need,
+                         torch.empty((B, self.num_heads, P, self.head_dim), dtype=torch.float32, device=device),
+                         torch.empty((B, self.num_heads, P), dtype=torch.float32, device=device),
+                         torch.empty((B, self.num_heads, P), dtype=torch.float32, device=device))
+        return self._tmp[1:]
+
+    def forward(self, q, k, v, mask, key_cache, value_cache, input_metadata: InputMetadata,
+                softcapping: Optional[float] = None, partition_size: Optional[int] = None):
+        """q [T,H,D], k/v [T,Hkv,D] 16-bit.  Writes k,v into the paged cache (K1) then attends (K2/K3)."""
+        if key_cache is None or value_cache is None:
+            raise RuntimeError("PagedAttention.forward needs the paged KV cache")
+        reshape_and_cache(k, v, key_cache, value_cache, input_metadata.slot_mapping)
+        if input_metadata.is_prefill:
+            raise NotImplementedError("prefill attention kernel (K4) is not built yet -- SURVEY section 8(a) a9")
+        return self.decode(q, key_cache, value_cache, input_metadata, softcapping, partition_size)
+
+    def decode(self, q, key_cache, value_cache, meta: InputMetadata, softcapping=None, partition_size=None):
+        layout = kv_layout_of(key_cache)
+        B, H, D = q.shape
+        bs = key_cache.shape[1] if layout == KV_FLASH else key_cache.shape[3]
+        out = torch.empty_like(q)
+        dt = _DT[q.dtype]
+        bt, cl = meta.block_tables, meta.context_lens
+        sc = float(softcapping) if softcapping else 0.0
+        ps = choose_partition(B, self.num_kv_heads, meta.max_context_len) if partition_size is None else partition_size
+        if layout == KV_PAGED and ps == 0 and meta.max_context_len > 8192:
+            ps = 4096
+        if ps == 0:
+            _check(lib.mi355_paged_attention_v1(_dev(out), _dev(q), _dev(key_cache), _dev(value_cache), _dev(bt),
+                                                _dev(cl), B, H, self.num_kv_heads, D, bs, bt.shape[1],
+                                                meta.max_context_len, self.scale, sc, layout, dt, _stream()),
+                   "paged_attention_v1")
+        else:
+            P = -(-meta.max_context_len // ps)
+            tmp, mx, sm = self._workspace(B, P, q.device)
+            _check(lib.mi355_paged_attention_v2(_dev(out), _dev(sm), _dev(mx), _dev(tmp), _dev(q), _dev(key_cache),
+                                                _dev(value_cache), _dev(bt), _dev(cl), B, H, self.num_kv_heads, D,
+                                                bs, bt.shape[1], meta.max_context_len, ps, self.scale, sc, layout,
+                                                dt, _stream()),
+                   "paged_attention_v2")
+        return out
+
+
+class FusedRope:
+    """attention_rs::fused_rope::FusedRope (rotary_emb.rs:58-70); q,k rotated IN PLACE."""
+
+    @staticmethod
+    def apply_inplace(q, k, cos, sin, positions, is_rope_i):
+        FusedRope.apply_inplace_partial(q, k, cos, sin, positions, is_rope_i, q.shape[-1])
+
+    @staticmethod
+    def apply_inplace_partial(q, k, cos, sin, positions, is_rope_i, rotary_dim):
+        T, H, D = q.shape
+        if cos.dtype != torch.float32 or sin.dtype != torch.float32:
+            raise RuntimeError("cos/sin tables are F32 (llama.rs:222, quantized_llama.rs:313-318)")
+        _check(lib.mi355_rope_inplace(_dev(q), _dev(k), _dev(cos), _dev(sin), _dev(positions), T, H, k.shape[1], D,
+                                      int(rotary_dim), 1 if is_rope_i else 0, _DT[q.dtype], _stream()), "rope")
+
+
+# ----------------------------------------------------------------------------------------------- small ops
+def rms_norm(x, w, eps):
+    out = torch.empty_like(x)
+    _check(lib.mi355_rms_norm(_dev(out), _dev(x), _dev(w), x.shape[0], x.shape[1], float(eps), _DT[x.dtype],
+                              _DT[w.dtype], _stream()), "rms_norm")
+    return out
+
+
+def silu_mul(gate, up):
+    out = torch.empty_like(gate)
+    _check(lib.mi355_silu_mul(_dev(out), _dev(gate), _dev(up), gate.numel(), _DT[gate.dtype], _stream()), "silu_mul")
+    return out
+
+
+def add(a, b):
+    out = torch.empty_like(a)
+    _check(lib.mi355_add_f32(_dev(out), _dev(a), _dev(b), a.numel(), _stream()), "add")
+    return out
+
+
+def cast(x, dtype):
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _check(lib.mi355_cast(_dev(out), _dev(x), x.numel(), _DT[x.dtype], _DT[dtype], _stream()), "cast")
+    return out
+
+
+def embedding(table, ids_u32):
+    out = torch.empty((ids_u32.shape[0], table.shape[1]), dtype=torch.float32, device=table.device)
+    _check(lib.mi355_embedding_f32(_dev(out), _dev(table), _dev(ids_u32), ids_u32.shape[0], table.shape[1],
+                                   _stream()), "embedding")
+    return out
+
+
+def argmax(logits):
+    out = torch.empty((logits.shape[0],), dtype=torch.int32, device=logits.device)
+    _check(lib.mi355_argmax_f32(_dev(out), _dev(logits), logits.shape[0], logits.shape[1], _stream()), "argmax")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- quantised matmul
+def repack_qweight(blocks_native: np.ndarray, ggml_type: int, n_rows: int, k: int) -> np.ndarray:
+    """Load-time re-tiling (host).  blocks_native: uint8 [n_rows, k/256, block_bytes]."""
+    n = lib.mi355_qweight_repacked_size(ggml_type, n_rows, k)
+    if n < 0:
+        raise ValueError("unsupported ggml type / shape")
+    src = np.ascontiguousarray(blocks_native, dtype=np.uint8)
+    dst = np.empty(n, np.uint8)
+    _check(lib.mi355_qweight_repack(dst.ctypes.data, src.ctypes.data, ggml_type, n_rows, k), "qweight_repack")
+    return dst
+
+
+class QMatMul:
+    """candle_core::quantized::QMatMul over a GGUF Q4_K / Q6_K tensor [N, K] (attention.rs:875-881)."""
+
+    def __init__(self, blocks_native: np.ndarray, ggml_type: int, device):
+        self.ggml_type = ggml_type
+        self.n = blocks_native.shape[0]
+        self.k = blocks_native.shape[1] * 256
+        self.native = torch.from_numpy(np.ascontiguousarray(blocks_native)).to(device)
+        self.tiles = torch.from_numpy(repack_qweight(blocks_native, ggml_type, self.n, self.k)).to(device)
+
+    def forward(self, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if x.dtype != torch.float32:
+            raise RuntimeError("QMatMul::forward takes F32 activations (linear.rs:769-782)")
+        T = x.shape[0]
+        out = torch.empty((T, self.n), dtype=torch.float32, device=x.device)
+        _check(lib.mi355_qmatmul(_dev(out), _dev(x), _dev(self.tiles), self.ggml_type, T, self.n, self.k,
+                                 _dev(bias) if bias is not None else None, _stream()), "qmatmul")
+        return out
+
+    def forward_ref(self, x: torch.Tensor) -> torch.Tensor:
+        """simple native-layout kernel (on-device cross-check)"""
+        T = x.shape[0]
+        out = torch.empty((T, self.n), dtype=torch.float32, device=x.device)
+        _check(lib.mi355_qmatmul_ref(_dev(out), _dev(x), _dev(self.native), self.ggml_type, T, self.n, self.k,
+                                     _stream()), "qmatmul_ref")
+        return out
+
+    def dequantize(self) -> torch.Tensor:
+        out = torch.empty((self.n, self.k), dtype=torch.float32, device=self.native.device)
+        _check(lib.mi355_dequantize(_dev(out), _dev(self.native), self.ggml_type, self.n * self.k, _stream()),
+               "dequantize")
+        return out
+
+
+def qmatmul_fused(mats: List[QMatMul], x, *, epilogue, out=None, norm_weight=None, norm_eps=0.0, residual=None,
+                  bias=None, rope=None):
+    """[RMSNorm ->] several QMatMuls sharing x -> fused epilogue (see include/mi355_vllm.h).
+    rope = dict(cos, sin, positions, slot_mapping, q_out, key_cache, value_cache, num_heads, num_kv_heads,
+                head_dim, rotary_dim) for EPI_QKV_ROPE_CACHE."""
+    d = QmmDesc()
+    d.nseg = len(mats)
+    for i, m in enumerate(mats):
+        d.w_tiles[i] = _dev(m.tiles)
+        d.ggml_type[i] = m.ggml_type
+        d.n_rows[i] = m.n
+    d.x = _dev(x)
+    d.ldx = x.shape[1]
+    d.k = mats[0].k
+    d.num_tokens = x.shape[0]
+    d.norm_weight = _dev(norm_weight) if norm_weight is not None else None
+    d.norm_eps = float(norm_eps)
+    d.epilogue = epilogue
+    if out is not None:
+        d.out = _dev(out)
+        d.ldo = out.shape[1]
+    d.residual = _dev(residual) if residual is not None else None
+    d.bias = _dev(bias) if bias is not None else None
+    if rope is not None:
+        kc = rope["key_cache"]
+        layout = kv_layout_of(kc)
+        d.cos_table, d.sin_table = _dev(rope["cos"]), _dev(rope["sin"])
+        d.positions, d.slot_mapping = _dev(rope["positions"]), _dev(rope["slot_mapping"])
+        d.q_out, d.key_cache, d.value_cache = _dev(rope["q_out"]), _dev(kc), _dev(rope["value_cache"])
+        d.num_heads, d.num_kv_heads, d.head_dim = rope["num_heads"], rope["num_kv_heads"], rope["head_dim"]
+        d.rotary_dim = rope.get("rotary_dim", rope["head_dim"])
+        d.block_size = kc.shape[1] if layout == KV_FLASH else kc.shape[3]
+        d.kv_layout = layout
+    _check(lib.mi355_qmatmul_fused(ctypes.byref(d), _stream()), "qmatmul_fused")
+    return out

@@ -1,0 +1,364 @@
+"""GPU parity tests (run with -m gpu on the MI355X): every kernel of the hot path through the C ABI vs the
+CPU oracle on the same seeded inputs.  Index/byte ops are bit-exact; floating point ops carry their
+tolerance next to the assert."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import kquants as kq          # noqa: E402
+from oracle import ops as O               # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def cv(lib):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (torch.cuda.is_available() is False)")
+    import candle_vllm_amd.ops as ops
+    return ops
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def bf16_dev(bits_u16):
+    """uint16 bf16 bit patterns -> torch.bfloat16 cuda tensor (bit-exact)"""
+    return torch.from_numpy(np.ascontiguousarray(bits_u16).view(np.int16)).cuda().view(torch.bfloat16)
+
+
+def bf16_bits(t):
+    return t.detach().view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+def rel_err(got, ref):
+    return float(np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64)).max() /
+                 max(1e-30, np.abs(np.asarray(ref, np.float64)).max()))
+
+
+# ------------------------------------------------------------------------------------------------ cache ops
+@pytest.mark.parametrize("flash", [True, False])
+@pytest.mark.parametrize("Hkv,D,bs", [(8, 128, 64), (2, 80, 16), (4, 64, 32)])
+def test_reshape_and_cache_bit_exact(cv, flash, Hkv, D, bs):
+    rng = np.random.default_rng(1)
+    NB, T = 12, 37
+    ks, vs = O.kv_cache_shapes(NB, bs, Hkv, D, 2, flash)
+    kc = rng.integers(0, 65536, ks).astype(np.uint16)
+    vc = rng.integers(0, 65536, vs).astype(np.uint16)
+    k = rng.integers(0, 65536, (T, Hkv, D)).astype(np.uint16)
+    v = rng.integers(0, 65536, (T, Hkv, D)).astype(np.uint16)
+    slots = rng.permutation(NB * bs)[:T].astype(np.int64)
+    slots[[3, 17]] = -1                                           # _PAD_SLOT_ID
+    kcd, vcd = bf16_dev(kc), bf16_dev(vc)
+    cv.reshape_and_cache(bf16_dev(k), bf16_dev(v), kcd, vcd, dev(slots))
+    O.reshape_and_cache(k, v, kc, vc, slots, flash)
+    torch.cuda.synchronize()
+    assert np.array_equal(bf16_bits(kcd), kc)
+    assert np.array_equal(bf16_bits(vcd), vc)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_copy_blocks_bit_exact(cv, dtype):
+    rng = np.random.default_rng(2)
+    L, NB = 5, 40
+    shape = (NB, 16, 2, 64)
+    kcs, vcs = [], []
+    for _ in range(L):
+        if dtype == "bf16":
+            kcs.append(rng.integers(0, 65536, shape).astype(np.uint16))
+            vcs.append(rng.integers(0, 65536, shape).astype(np.uint16))
+        else:
+            kcs.append(rng.normal(size=shape).astype(np.float32))
+            vcs.append(rng.normal(size=shape).astype(np.float32))
+    todev = bf16_dev if dtype == "bf16" else dev
+    kd, vd = [todev(k) for k in kcs], [todev(v) for v in vcs]
+    mapping = {0: [20, 21], 3: [22], 7: [23, 24, 25], 9: [30]}
+    cv.copy_blocks(kd, vd, mapping)
+    pairs = [p for s, ds in mapping.items() for d in ds for p in (s, d)]
+    O.copy_blocks(kcs, vcs, pairs)
+    torch.cuda.synchronize()
+    for a, b in zip(kd + vd, kcs + vcs):
+        got = bf16_bits(a) if dtype == "bf16" else a.cpu().numpy()
+        assert np.array_equal(got, b)
+
+
+def test_copy_blocks_many_pairs_and_empty(cv):
+    """more pairs than one launch chunk carries (96) + the empty map"""
+    rng = np.random.default_rng(3)
+    NB = 400
+    kc = rng.integers(0, 65536, (NB, 4, 8)).astype(np.uint16)
+    vc = rng.integers(0, 65536, (NB, 4, 8)).astype(np.uint16)
+    kd, vd = bf16_dev(kc), bf16_dev(vc)
+    cv.copy_blocks([kd], [vd], {})
+    mapping = {i: [200 + i] for i in range(150)}
+    cv.copy_blocks([kd], [vd], mapping)
+    O.copy_blocks([kc], [vc], [p for s, ds in mapping.items() for d in ds for p in (s, d)])
+    torch.cuda.synchronize()
+    assert np.array_equal(bf16_bits(kd), kc) and np.array_equal(bf16_bits(vd), vc)
+
+
+def test_swap_blocks_round_trip(cv):
+    rng = np.random.default_rng(4)
+    gpu = rng.integers(0, 65536, (32, 64, 8, 128)).astype(np.uint16)
+    cpu = np.zeros((16, 64, 8, 128), np.uint16)
+    g = bf16_dev(gpu)
+    c = torch.from_numpy(cpu.view(np.int16)).view(torch.bfloat16).pin_memory()
+    out_map = {5: 0, 6: 1, 7: 2, 20: 9, 31: 15}                 # gpu -> cpu (swap_out), with a mergeable run
+    nbytes = cv.swap_blocks(g, c, out_map)
+    torch.cuda.synchronize()
+    assert nbytes == 64 * 8 * 128 * 2 * len(out_map)
+    O.swap_blocks(gpu, cpu, out_map)
+    assert np.array_equal(c.view(torch.int16).numpy().view(np.uint16), cpu)
+    in_map = {0: 11, 1: 12, 9: 3}                                # cpu -> gpu (swap_in)
+    cv.swap_blocks(c, g, in_map)
+    O.swap_blocks(cpu, gpu, in_map)
+    g2 = torch.zeros_like(g)
+    cv.swap_blocks(g, g2, {11: 1, 3: 2})                         # device -> device
+    torch.cuda.synchronize()
+    assert np.array_equal(bf16_bits(g), gpu)
+    assert np.array_equal(bf16_bits(g2)[1], gpu[11]) and np.array_equal(bf16_bits(g2)[2], gpu[3])
+
+
+# ------------------------------------------------------------------------------------------------ small fp ops
+def test_rms_norm(cv):
+    rng = np.random.default_rng(5)
+    for T, hid in ((1, 4096), (7, 2560), (3, 250)):
+        x = rng.normal(0, 2, (T, hid)).astype(np.float32)
+        w = (1 + rng.normal(0, 0.1, hid)).astype(np.float32)
+        got = cv.rms_norm(dev(x), dev(w), 1e-5).cpu().numpy()
+        assert rel_err(got, O.rms_norm(x, w, 1e-5)) < 2e-6       # f32 op, f64 oracle
+    xb = O.round_bf16(rng.normal(0, 2, (4, 512)).astype(np.float32))
+    wb = O.round_bf16((1 + rng.normal(0, 0.1, 512)).astype(np.float32))
+    got = cv.rms_norm(dev(xb, torch.bfloat16), dev(wb, torch.bfloat16), 1e-6).float().cpu().numpy()
+    assert rel_err(got, O.rms_norm(xb, wb, 1e-6)) < 2 ** -8      # one bf16 rounding of the output
+
+
+@pytest.mark.parametrize("interleaved", [True, False])
+@pytest.mark.parametrize("H,Hkv,D,rot", [(32, 8, 128, 128), (4, 4, 80, 20)])
+def test_rope_inplace(cv, interleaved, H, Hkv, D, rot):
+    rng = np.random.default_rng(6)
+    T, max_seq = 9, 300
+    q = rng.normal(size=(T, H, D)).astype(np.float32)
+    k = rng.normal(size=(T, Hkv, D)).astype(np.float32)
+    pos = rng.integers(0, max_seq, T).astype(np.int64)
+    cos, sin = O.rope_tables(500000.0, rot, max_seq)
+    qd, kd = dev(q), dev(k)
+    cv.FusedRope.apply_inplace_partial(qd, kd, dev(cos), dev(sin), dev(pos), interleaved, rot)
+    rq = O.rope_apply(q, cos, sin, pos, interleaved, rot)
+    rk = O.rope_apply(k, cos, sin, pos, interleaved, rot)
+    assert rel_err(qd.cpu().numpy(), rq) < 1e-6 and rel_err(kd.cpu().numpy(), rk) < 1e-6
+
+
+def test_silu_mul_add_cast_embedding_argmax(cv):
+    rng = np.random.default_rng(7)
+    g = rng.normal(0, 3, (5, 14336)).astype(np.float32)
+    u = rng.normal(0, 1, (5, 14336)).astype(np.float32)
+    assert rel_err(cv.silu_mul(dev(g), dev(u)).cpu().numpy(), O.silu_mul(g, u)) < 2e-6
+    assert np.array_equal(cv.add(dev(g), dev(u)).cpu().numpy(), g + u)
+    got = bf16_bits(cv.cast(dev(g), torch.bfloat16))
+    assert np.array_equal(got, O.f32_to_bf16_bits(g))            # RNE cast is bit-exact
+    back = cv.cast(bf16_dev(got), torch.float32).cpu().numpy()
+    assert np.array_equal(back, O.bf16_bits_to_f32(got))
+    table = rng.normal(size=(1000, 256)).astype(np.float32)
+    ids = rng.integers(0, 1000, 13).astype(np.int32)
+    assert np.array_equal(cv.embedding(dev(table), dev(ids)).cpu().numpy(), table[ids])
+    logits = rng.normal(size=(6, 128256)).astype(np.float32)
+    logits[2, 77] = logits[2, 99000] = 50.0                      # tie -> first index
+    logits[4, 128255] = 60.0
+    assert np.array_equal(cv.argmax(dev(logits)).cpu().numpy(), logits.argmax(-1).astype(np.int32))
+
+
+# ------------------------------------------------------------------------------------------------ paged attention
+def _attn_case(rng, B, H, Hkv, D, bs, ctx_lens, flash, NB=None):
+    maxblk = max(-(-c // bs) for c in ctx_lens)
+    NB = NB or (sum(-(-c // bs) for c in ctx_lens) + 3)
+    ks, vs = O.kv_cache_shapes(NB, bs, Hkv, D, 2, flash)
+    kc = O.f32_to_bf16_bits(rng.normal(0, 1, ks).astype(np.float32))
+    vc = O.f32_to_bf16_bits(rng.normal(0, 1, vs).astype(np.float32))
+    perm = rng.permutation(NB)                                    # shuffled physical blocks
+    bt = np.zeros((B, maxblk), np.uint32)
+    nxt = 0
+    for b, c in enumerate(ctx_lens):
+        n = -(-c // bs)
+        bt[b, :n] = perm[nxt:nxt + n]
+        nxt += n
+    q = O.round_bf16(rng.normal(0, 1, (B, H, D)).astype(np.float32))
+    return q, kc, vc, bt, np.asarray(ctx_lens, np.uint32)
+
+
+@pytest.mark.parametrize("flash", [True, False])
+@pytest.mark.parametrize("H,Hkv,D,bs,ctx", [
+    (32, 8, 128, 64, [1, 63, 64, 65, 300, 517]),     # llama-3 heads, ragged, block-boundary lengths
+    (28, 4, 128, 64, [200, 5]),                      # qwen2: GQA group of 7
+    (4, 4, 80, 32, [100, 33]),                       # stablelm: head_dim 80, MHA
+    (8, 2, 64, 16, [129, 7, 16]),
+    (4, 1, 256, 64, [70]),
+])
+def test_paged_attention_v1_v2(cv, flash, H, Hkv, D, bs, ctx):
+    rng = np.random.default_rng(8)
+    B = len(ctx)
+    q, kc, vc, bt, cl = _attn_case(rng, B, H, Hkv, D, bs, ctx, flash)
+    scale = 1.0 / np.sqrt(D)
+    ref = O.paged_attention_decode(q, kc, vc, bt, cl, scale, flash)
+    pa = cv.PagedAttention(H, D, scale, Hkv)
+    meta = cv.InputMetadata(False, dev(np.zeros(B, np.int64)), dev(bt.astype(np.int32)), dev(cl.astype(np.int32)),
+                            max_context_len=int(max(ctx)))
+    qd, kcd, vcd = dev(q, torch.bfloat16), bf16_dev(kc), bf16_dev(vc)
+    for ps in (0, 64, 128):                                       # v1, v2 with two partition sizes
+        got = pa.decode(qd, kcd, vcd, meta, None, partition_size=ps).float().cpu().numpy()
+        # fp32 softmax/accumulate, output rounded to bf16: <= 1 bf16 ulp of the largest output + eps
+        assert np.abs(got - ref).max() <= 2 ** -7 * np.abs(ref).max() + 1e-6, (ps, np.abs(got - ref).max())
+
+
+def test_paged_attention_softcap_and_forward_writes_cache(cv):
+    rng = np.random.default_rng(9)
+    H, Hkv, D, bs = 8, 2, 128, 64
+    ctx = [130, 64]
+    B = len(ctx)
+    q, kc, vc, bt, cl = _attn_case(rng, B, H, Hkv, D, bs, ctx, True)
+    k_new = O.f32_to_bf16_bits(rng.normal(size=(B, Hkv, D)).astype(np.float32))
+    v_new = O.f32_to_bf16_bits(rng.normal(size=(B, Hkv, D)).astype(np.float32))
+    slots = np.array([int(bt[b, (c - 1) // bs]) * bs + (c - 1) % bs for b, c in enumerate(ctx)], np.int64)
+    kcd, vcd = bf16_dev(kc), bf16_dev(vc)
+    pa = cv.PagedAttention(H, D, 1 / np.sqrt(D), Hkv)
+    meta = cv.InputMetadata(False, dev(slots), dev(bt.astype(np.int32)), dev(cl.astype(np.int32)),
+                            max_context_len=max(ctx))
+    got = pa.forward(dev(q, torch.bfloat16), bf16_dev(k_new), bf16_dev(v_new), None, kcd, vcd, meta, 30.0)
+    O.reshape_and_cache(k_new, v_new, kc, vc, slots, True)
+    ref = O.paged_attention_decode(q, kc, vc, bt, cl, 1 / np.sqrt(D), True, softcap=30.0)
+    assert np.array_equal(bf16_bits(kcd), kc) and np.array_equal(bf16_bits(vcd), vc)
+    assert np.abs(got.float().cpu().numpy() - ref).max() <= 2 ** -7 * np.abs(ref).max() + 1e-6
+
+
+def test_paged_attention_long_context_property(cv):
+    """BASELINE-size decode (ctx ~4.6k, llama-3-8B heads): uniform V -> output must equal that V row;
+    and v1 == v2 (partition-merge invariance)."""
+    rng = np.random.default_rng(10)
+    H, Hkv, D, bs, ctx = 32, 8, 128, 64, [4608, 4097]
+    q, kc, vc, bt, cl = _attn_case(rng, 2, H, Hkv, D, bs, ctx, True)
+    pa = cv.PagedAttention(H, D, 1 / np.sqrt(D), Hkv)
+    meta = cv.InputMetadata(False, dev(np.zeros(2, np.int64)), dev(bt.astype(np.int32)), dev(cl.astype(np.int32)),
+                            max_context_len=max(ctx))
+    qd, kcd, vcd = dev(q, torch.bfloat16), bf16_dev(kc), bf16_dev(vc)
+    a = pa.decode(qd, kcd, vcd, meta, None, partition_size=0).float().cpu().numpy()
+    b = pa.decode(qd, kcd, vcd, meta, None, partition_size=256).float().cpu().numpy()
+    c = pa.decode(qd, kcd, vcd, meta, None).float().cpu().numpy()
+    assert np.abs(a - b).max() <= 2 ** -7 * np.abs(a).max() and np.abs(a - c).max() <= 2 ** -7 * np.abs(a).max()
+    vrow = O.round_bf16(rng.normal(size=(Hkv, D)).astype(np.float32))
+    vc2 = np.broadcast_to(O.f32_to_bf16_bits(vrow)[None, None], vc.shape).copy()
+    got = pa.decode(qd, kcd, bf16_dev(vc2), meta, None).float().cpu().numpy()
+    expect = np.repeat(vrow, H // Hkv, axis=0)[None].repeat(2, 0)
+    assert np.abs(got - expect).max() <= 2 ** -7 * np.abs(expect).max()
+
+
+# ------------------------------------------------------------------------------------------------ quantised matmul
+@pytest.mark.parametrize("t", [kq.GGML_Q4_K, kq.GGML_Q6_K])
+def test_dequantize_and_ref_kernel(cv, t):
+    rng = np.random.default_rng(11)
+    N, K = 40, 1024
+    blocks = kq.quantize(rng.normal(0, 0.05, (N, K)).astype(np.float32), t)
+    mm = cv.QMatMul(blocks, t, "cuda")
+    deq = mm.dequantize().cpu().numpy()
+    assert rel_err(deq, kq.dequantize(blocks, t)) < 1e-6
+    x = rng.normal(size=(3, K)).astype(np.float32)
+    assert rel_err(mm.forward_ref(dev(x)).cpu().numpy(), kq.qmatmul_o1(x, blocks, t)) < 1e-5
+
+
+@pytest.mark.parametrize("t", [kq.GGML_Q4_K, kq.GGML_Q6_K])
+@pytest.mark.parametrize("T,N,K", [(1, 64, 256), (1, 4096, 4096), (1, 40, 512), (2, 48, 1024), (3, 128, 4096),
+                                   (5, 32, 14336), (8, 256, 2048), (9, 64, 512), (32, 96, 4096)])
+def test_qmatmul_vs_oracle(cv, t, T, N, K):
+    rng = np.random.default_rng(12 + T + N)
+    blocks = kq.quantize(rng.normal(0, 0.05, (N, K)).astype(np.float32), t)
+    x = rng.normal(0, 1, (T, K)).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    mm = cv.QMatMul(blocks, t, "cuda")
+    ref = kq.qmatmul_o1(x, blocks, t)
+    got = mm.forward(dev(x)).cpu().numpy()
+    # hi/lo bf16 split carries 16 mantissa bits of x; fp32 accumulation.  Bar from BASELINE: 1e-3.
+    assert rel_err(got, ref) < 1e-4, rel_err(got, ref)
+    got_b = mm.forward(dev(x), dev(bias)).cpu().numpy()
+    assert rel_err(got_b, ref + bias) < 1e-4
+    assert rel_err(got, mm.forward_ref(dev(x)).cpu().numpy()) < 1e-4       # MFMA path == simple kernel
+
+
+def test_qmatmul_random_bytes_all_code_points(cv):
+    """Blocks of random BYTES (every nibble / 6-bit scale pattern), sane f16 d/dmin: exercises the unpack."""
+    rng = np.random.default_rng(13)
+    N, K = 64, 1024
+    for t, bb in ((kq.GGML_Q4_K, 144), (kq.GGML_Q6_K, 210)):
+        blocks = rng.integers(0, 256, (N, K // 256, bb)).astype(np.uint8)
+        d = (rng.uniform(0.5, 2.0, (N, K // 256)) * 1e-3).astype(np.float16)
+        if t == kq.GGML_Q4_K:
+            blocks[..., 0:2] = d[..., None].view(np.uint8)
+            blocks[..., 2:4] = d[..., None].view(np.uint8)
+        else:
+            blocks[..., 208:210] = d[..., None].view(np.uint8)
+        x = rng.normal(size=(2, K)).astype(np.float32)
+        mm = cv.QMatMul(blocks, t, "cuda")
+        assert rel_err(mm.forward(dev(x)).cpu().numpy(), kq.qmatmul_o1(x, blocks, t)) < 1e-4
+
+
+def test_fused_norm_qkv_rope_cache(cv):
+    """[RMSNorm -> wq,wk,wv -> interleaved RoPE -> bf16 -> q_out / paged cache] == composition of oracles."""
+    rng = np.random.default_rng(14)
+    hid, H, Hkv, D, bs, NB, B = 1024, 8, 2, 128, 64, 6, 3
+    types = (kq.GGML_Q4_K, kq.GGML_Q4_K, kq.GGML_Q6_K)
+    Ws = [kq.quantize(rng.normal(0, 0.05, (n, hid)).astype(np.float32), t)
+          for n, t in zip((H * D, Hkv * D, Hkv * D), types)]
+    mats = [cv.QMatMul(w, t, "cuda") for w, t in zip(Ws, types)]
+    x = rng.normal(size=(B, hid)).astype(np.float32)
+    nw = (1 + rng.normal(0, 0.1, hid)).astype(np.float32)
+    pos = np.array([5, 130, 64], np.int64)
+    slots = np.array([70, -1, 200], np.int64)
+    cos, sin = O.rope_tables(500000.0, D, 512)
+    for flash in (True, False):
+        ks, vs = O.kv_cache_shapes(NB, bs, Hkv, D, 2, flash)
+        kc = rng.integers(0, 65536, ks).astype(np.uint16)
+        vc = rng.integers(0, 65536, vs).astype(np.uint16)
+        kcd, vcd = bf16_dev(kc), bf16_dev(vc)
+        q_out = torch.zeros((B, H * D), dtype=torch.bfloat16, device="cuda")
+        cv.qmatmul_fused(mats, dev(x), epilogue=cv.EPI_QKV_ROPE_CACHE, norm_weight=dev(nw), norm_eps=1e-5,
+                         rope=dict(cos=dev(cos), sin=dev(sin), positions=dev(pos), slot_mapping=dev(slots),
+                                   q_out=q_out, key_cache=kcd, value_cache=vcd, num_heads=H, num_kv_heads=Hkv,
+                                   head_dim=D))
+        xn = O.rms_norm(x, nw, 1e-5)
+        q = O.rope_apply(kq.qmatmul_o1(xn, Ws[0], types[0]).reshape(B, H, D), cos, sin, pos, True)
+        k = O.rope_apply(kq.qmatmul_o1(xn, Ws[1], types[1]).reshape(B, Hkv, D), cos, sin, pos, True)
+        v = kq.qmatmul_o1(xn, Ws[2], types[2]).reshape(B, Hkv, D)
+        got_q = q_out.float().cpu().numpy().reshape(B, H, D)
+        assert np.abs(got_q - O.round_bf16(q)).max() <= 2 ** -7 * np.abs(q).max()
+        kref, vref = kc.copy(), vc.copy()
+        O.reshape_and_cache(O.f32_to_bf16_bits(k), O.f32_to_bf16_bits(v), kref, vref, slots, flash)
+        gkb, gvb = bf16_bits(kcd), bf16_bits(vcd)
+        # untouched slots stay bit-identical (the cache was seeded with random bit patterns, NaNs included);
+        # written rows agree to 1 bf16 ulp
+        wk, wv = (kref != kc), (vref != vc)
+        assert np.array_equal(gkb[~wk], kc[~wk]) and np.array_equal(gvb[~wv], vc[~wv])
+        assert np.abs(O.bf16_bits_to_f32(gkb[wk]) - O.bf16_bits_to_f32(kref[wk])).max() <= 2 ** -7 * np.abs(k).max()
+        assert np.abs(O.bf16_bits_to_f32(gvb[wv]) - O.bf16_bits_to_f32(vref[wv])).max() <= 2 ** -7 * np.abs(v).max()
+
+
+def test_fused_silu_pair_and_residual(cv):
+    rng = np.random.default_rng(15)
+    hid, I, B = 1024, 512, 2
+    wg = kq.quantize(rng.normal(0, 0.05, (I, hid)).astype(np.float32), kq.GGML_Q4_K)
+    wu = kq.quantize(rng.normal(0, 0.05, (I, hid)).astype(np.float32), kq.GGML_Q4_K)
+    wd = kq.quantize(rng.normal(0, 0.05, (hid, I)).astype(np.float32), kq.GGML_Q6_K)
+    mg, mu, md = (cv.QMatMul(w, t, "cuda") for w, t in ((wg, 12), (wu, 12), (wd, 14)))
+    x = rng.normal(size=(B, hid)).astype(np.float32)
+    nw = (1 + rng.normal(0, 0.1, hid)).astype(np.float32)
+    h = torch.empty((B, I), dtype=torch.float32, device="cuda")
+    cv.qmatmul_fused([mg, mu], dev(x), epilogue=cv.EPI_SILU_MUL, out=h, norm_weight=dev(nw), norm_eps=1e-5)
+    xn = O.rms_norm(x, nw, 1e-5)
+    href = O.silu_mul(kq.qmatmul_o1(xn, wg, 12), kq.qmatmul_o1(xn, wu, 12))
+    assert rel_err(h.cpu().numpy(), href) < 1e-4
+    res = dev(x.copy())
+    cv.qmatmul_fused([md], h, epilogue=cv.EPI_RESID, out=res, residual=res)      # in place: x += W2 h
+    ref = x + kq.qmatmul_o1(h.cpu().numpy(), wd, 14)
+    assert rel_err(res.cpu().numpy(), ref) < 1e-4
