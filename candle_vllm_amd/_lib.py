@@ -37,7 +37,7 @@ class QmmDesc(ctypes.Structure):
     """mirror of `mi355_qmm_desc` (include/mi355_vllm.h)"""
     _fields_ = [
         ("nseg", c_i32), ("w_tiles", c_vp * 3), ("ggml_type", c_i32 * 3), ("n_rows", c_i32 * 3),
-        ("x", c_vp), ("ldx", c_i32), ("k", c_i32), ("num_tokens", c_i32),
+        ("x", c_vp), ("x_dtype", c_i32), ("ldx", c_i32), ("k", c_i32), ("num_tokens", c_i32),
         ("norm_weight", c_vp), ("norm_eps", c_f32), ("epilogue", c_i32),
         ("out", c_vp), ("ldo", c_i32), ("residual", c_vp), ("bias", c_vp),
         ("cos_table", c_vp), ("sin_table", c_vp), ("positions", c_vp), ("slot_mapping", c_vp),
@@ -75,3 +75,4 @@ _sig("mi355_qweight_repacked_size", c_i64, [c_i32, c_i64, c_i64])
 _sig("mi355_qweight_repack", ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_i64])
 _sig("mi355_qmatmul", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64])
 _sig("mi355_qmatmul_fused", ctypes.c_int, [ctypes.POINTER(QmmDesc), c_i64])
+_sig("mi355_set_tuning", None, [c_i32, c_i32])

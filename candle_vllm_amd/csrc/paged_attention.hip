@@ -227,26 +227,52 @@ __global__ void __launch_bounds__(PA_THREADS) paged_attn_flash_kernel(const PAPa
     }
 }
 
-// v2 reduce: grid (H, B); merges the partitions of one (sequence, head).
+// v2 reduce: grid (H, B); merges the partitions of one (sequence, head).  Partition statistics are pulled
+// into LDS in parallel (no serial dependent-load chain), then every thread owns output channels and sums the
+// partitions with independent loads.
 template <int KVT>
 __global__ void __launch_bounds__(128) paged_attn_reduce_kernel(void* __restrict__ out, const float* __restrict__ tmp_out,
                                                                 const float* __restrict__ max_logits,
                                                                 const float* __restrict__ exp_sums,
                                                                 const uint32_t* __restrict__ context_lens, int H,
                                                                 int D, int partition_size, int max_partitions) {
+    extern __shared__ float s_w[];                          // [P] merge weights
+    __shared__ float red[16];
     const int h = blockIdx.x, b = blockIdx.y;
     const int ctx = (int)context_lens[b];
     const int P = (ctx + partition_size - 1) / partition_size;
     const int64_t base = ((int64_t)b * H + h) * max_partitions;
     float M = -1e30f;
-    for (int i = 0; i < P; ++i) M = fmaxf(M, max_logits[base + i]);
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        const float ml = max_logits[base + i];
+        s_w[i] = ml;
+        M = fmaxf(M, ml);
+    }
+    M = wave_max(M);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = M;
+    __syncthreads();
+    M = fmaxf(red[0], red[1]);
+    __syncthreads();
     float den = 0.f;
-    for (int i = 0; i < P; ++i) den += exp_sums[base + i] * __expf(max_logits[base + i] - M);
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        const float w = exp_sums[base + i] * __expf(s_w[i] - M);
+        s_w[i] = w;
+        den += w;
+    }
+    den = block_sum(den, red);                              // barrier inside publishes s_w
+    const float inv = (P > 0 && den > 0.f) ? 1.f / den : 0.f;
     for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        float num = 0.f;
-        for (int i = 0; i < P; ++i)
-            num += tmp_out[(base + i) * D + d] * exp_sums[base + i] * __expf(max_logits[base + i] - M);
-        const float o = (P > 0) ? num / den : 0.f;
+        const float* tp = tmp_out + base * D + d;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int i = 0;
+        for (; i + 4 <= P; i += 4) {
+            a0 = fmaf(tp[(int64_t)i * D], s_w[i], a0);
+            a1 = fmaf(tp[(int64_t)(i + 1) * D], s_w[i + 1], a1);
+            a2 = fmaf(tp[(int64_t)(i + 2) * D], s_w[i + 2], a2);
+            a3 = fmaf(tp[(int64_t)(i + 3) * D], s_w[i + 3], a3);
+        }
+        for (; i < P; ++i) a0 = fmaf(tp[(int64_t)i * D], s_w[i], a0);
+        const float o = (a0 + a1 + a2 + a3) * inv;
         uint16_t* op = static_cast<uint16_t*>(out) + ((int64_t)b * H + h) * D + d;
         *op = (KVT == MI355_DTYPE_BF16) ? f32_to_bf16(o) : f32_to_f16_bits(o);
     }
@@ -374,11 +400,13 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
     }
     if (rc != 0 || P <= 1) return rc;
     dim3 rgrid(p.H, B), rblock(128);
+    const size_t rshm = (size_t)p.max_partitions * sizeof(float);
+    if (rshm > 60 * 1024) return (int)hipErrorInvalidValue;
     if (dtype == MI355_DTYPE_BF16)
-        hipLaunchKernelGGL(paged_attn_reduce_kernel<MI355_DTYPE_BF16>, rgrid, rblock, 0, st, p.out, p.tmp_out,
+        hipLaunchKernelGGL(paged_attn_reduce_kernel<MI355_DTYPE_BF16>, rgrid, rblock, rshm, st, p.out, p.tmp_out,
                            p.max_logits, p.exp_sums, p.context_lens, p.H, p.D, p.partition_size, p.max_partitions);
     else
-        hipLaunchKernelGGL(paged_attn_reduce_kernel<MI355_DTYPE_F16>, rgrid, rblock, 0, st, p.out, p.tmp_out,
+        hipLaunchKernelGGL(paged_attn_reduce_kernel<MI355_DTYPE_F16>, rgrid, rblock, rshm, st, p.out, p.tmp_out,
                            p.max_logits, p.exp_sums, p.context_lens, p.H, p.D, p.partition_size, p.max_partitions);
     return (int)hipGetLastError();
 }

@@ -176,8 +176,9 @@ struct QmmSeg {
 struct QmmArgs {
     QmmSeg seg[3];
     int32_t nseg;
-    int32_t paired;           // 1: seg[0] = gate, seg[1] = up, workgroup t handles tile t of both (R = 2)
-    const float* x;           // [B][ldx] f32
+    int32_t paired;           // 1: seg[0] = gate, seg[1] = up; slot r of a workgroup = tile (r/2) of seg (r&1)
+    const void* x;            // [B][ldx] f32 (or bf16 when x_dtype == MI355_DTYPE_BF16)
+    int32_t x_dtype;
     int32_t ldx, K, B, kch;   // kch = k-blocks staged per LDS chunk
     const float* norm_w;      // fused RMSNorm weight [K] or null
     float eps;
@@ -195,25 +196,39 @@ struct QmmArgs {
     uint16_t* kcache;
     uint16_t* vcache;
     int32_t Hq, Hkv, D, rot, block_size, kv_layout;
+    int32_t dbg;              // experiments: 1 = stream the weights but skip unpack/MFMA (memory-path probe)
 };
 
 struct TileRegs { uint4 a, b, c, d; uint32_t e; };
 
+// WT = MI355_GGML_Q4_K / MI355_GGML_Q6_K when every tile of the launch has that type (3 resp. 5 loads per unit),
+// 0 for mixed launches: both types then issue 5 loads (Q4_K adds two same-line dummies) so that the number of
+// outstanding loads is a compile-time constant and the compiler can emit COUNTED s_waitcnt vmcnt(N).
+// Weights are streamed once -> non-temporal loads.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_nt16(const uint4* p) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+template <int WT>
 __device__ __forceinline__ TileRegs load_tile(int type, const uint8_t* __restrict__ t, int lane) {
     TileRegs r;
     const int row = lane & 15;
-    if (type == MI355_GGML_Q4_K) {
-        r.a = *reinterpret_cast<const uint4*>(t + row * 16);                 // d, dmin, scales[12]
-        r.b = *reinterpret_cast<const uint4*>(t + 256 + lane * 16);          // groups 0,1
-        r.c = *reinterpret_cast<const uint4*>(t + 1280 + lane * 16);         // groups 2,3
+    const uint4* t4 = reinterpret_cast<const uint4*>(t);
+    r.a = ld_nt16(t4 + row);                    // Q4_K: d,dmin,scales[12] ; Q6_K: 16 x i8 scales
+    r.b = ld_nt16(t4 + 16 + lane);              // Q4_K: groups 0,1 ; Q6_K: ql half 0
+    r.c = ld_nt16(t4 + 80 + lane);              // Q4_K: groups 2,3 ; Q6_K: ql half 1
+    if (WT == MI355_GGML_Q4_K) {
         r.d = make_uint4(0, 0, 0, 0);
         r.e = 0;
+    } else if (WT == MI355_GGML_Q6_K) {
+        r.d = ld_nt16(t4 + 144 + lane);         // qh
+        r.e = __builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(t + 3328) + row);   // d (f16)
     } else {
-        r.a = *reinterpret_cast<const uint4*>(t + row * 16);                 // 16 x i8 scales
-        r.b = *reinterpret_cast<const uint4*>(t + 256 + lane * 16);          // ql half 0
-        r.c = *reinterpret_cast<const uint4*>(t + 1280 + lane * 16);         // ql half 1
-        r.d = *reinterpret_cast<const uint4*>(t + 2304 + lane * 16);         // qh
-        r.e = *reinterpret_cast<const uint16_t*>(t + 3328 + row * 2);        // d (f16)
+        const bool q6 = (type == MI355_GGML_Q6_K);
+        r.d = ld_nt16(t4 + (q6 ? 144 + lane : 0));
+        r.e = __builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(t + (q6 ? 3328 : 0)) + (q6 ? row : 0));
     }
     return r;
 }
@@ -230,13 +245,33 @@ struct XLds {
     float* xs16;
 };
 
+// A-fragment row of a lane: MFMA rows 0..7 carry hi(x) of batch 0..7, rows 8..15 carry lo(x).  Rows beyond
+// the staged batch (m >= BT) just re-read a staged row: MFMA rows are independent and those outputs are
+// never consumed, so no zero-fill and no branch is needed.
+template <int BT>
+__device__ __forceinline__ int a_row_of(int m) {
+    const int mm = (m & 7) < BT ? (m & 7) : (BT - 1);
+    return (m < 8) ? mm : BT + mm;
+}
+
 template <int BT, int NV>
 __device__ __forceinline__ void compute_q4k(const TileRegs& w, const XLds<BT>& L, int kbl, int lane, float (&y)[NV]) {
     const int m = lane & 15, kg = lane >> 4;
+    // ---- issue every LDS read of this k-block first (8 A fragments + the sub-block sums)
+    const uint8_t* abase = L.ximg + ((size_t)(kbl * 32 + kg) * (2 * BT) + a_row_of<BT>(m)) * 16;
+    uint4 aw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) aw[j] = *reinterpret_cast<const uint4*>(abase + (size_t)j * 4 * (2 * BT) * 16);
+    const float* xs = L.xs32 + ((size_t)(kbl * 2 + (kg >> 1)) * 8) * BT + ((4 * (kg & 1)) & (BT - 1));
+    float xsum[8][NV];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) xsum[j][v] = xs[j * BT + v];
+    // ---- 6-bit scales / mins, 4 at a time in byte lanes (get_scale_min_k4)
     const float d = f16_bits_to_f32((uint16_t)(w.a.x & 0xFFFF));
     const float dmin = f16_bits_to_f32((uint16_t)(w.a.x >> 16));
     const uint32_t s0 = w.a.y, s1 = w.a.z, s2 = w.a.w;
-    // 6-bit scales / mins, 4 at a time in byte lanes (get_scale_min_k4)
     const uint32_t scl = s0 & 0x3F3F3F3Fu, mnl = s1 & 0x3F3F3F3Fu;
     const uint32_t sch = (s2 & 0x0F0F0F0Fu) | ((s0 >> 2) & 0x30303030u);
     const uint32_t mnh = ((s2 >> 4) & 0x0F0F0F0Fu) | ((s1 >> 2) & 0x30303030u);
@@ -244,61 +279,57 @@ __device__ __forceinline__ void compute_q4k(const TileRegs& w, const XLds<BT>& L
     const float d128 = d * 128.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float a = (float)((scl >> (8 * j)) & 0xFF), b = (float)((sch >> (8 * j)) & 0xFF);
+        const float sa = (float)((scl >> (8 * j)) & 0xFF), sb = (float)((sch >> (8 * j)) & 0xFF);
         const float ma = (float)((mnl >> (8 * j)) & 0xFF), mb = (float)((mnh >> (8 * j)) & 0xFF);
-        dsc[j] = d * a;
-        dsc[j + 4] = d * b;
-        cj[j] = fmaf(dmin, ma, d128 * a);
-        cj[j + 4] = fmaf(dmin, mb, d128 * b);
+        dsc[j] = d * sa;
+        dsc[j + 4] = d * sb;
+        cj[j] = fmaf(dmin, ma, d128 * sa);
+        cj[j + 4] = fmaf(dmin, mb, d128 * sb);
     }
-    // A-fragment row of this lane (hi rows 0..BT-1 -> MFMA rows 0..7, lo rows -> MFMA rows 8..15)
-    const bool arow_ok = (m < BT) || (m >= 8 && m < 8 + BT);
-    const int arow = (m < 8) ? m : (BT + m - 8);
-    const int hl = kg >> 1;                                           // C rows 4kg+v : kg 0,1 = hi ; 2,3 = lo
+    // ---- 8 independent MFMAs (one per 32-weight sub-block)
+    f32x4_t acc[8];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int j = 0; j < 8; ++j) {
+        const int p = j >> 2, pr = (j >> 1) & 1, sh = (j & 1) * 4;
         const uint4 qs = p ? w.c : w.b;
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-            const uint32_t w0 = pr ? qs.z : qs.x, w1 = pr ? qs.w : qs.y;
-#pragma unroll
-            for (int hi = 0; hi < 2; ++hi) {
-                const int j = 4 * p + 2 * pr + hi;                    // sub-block index 0..7
-                const int sh = hi * 4;
-                uint4 bw;
-                bw.x = ((w0 >> sh) & 0x000F000Fu) | BF16_128;        // elements (b0, b2)
-                bw.y = ((w0 >> (sh + 8)) & 0x000F000Fu) | BF16_128;  // elements (b1, b3)
-                bw.z = ((w1 >> sh) & 0x000F000Fu) | BF16_128;        // elements (b4, b6)
-                bw.w = ((w1 >> (sh + 8)) & 0x000F000Fu) | BF16_128;  // elements (b5, b7)
-                uint4 aw = make_uint4(0, 0, 0, 0);
-                if (arow_ok) {
-                    const int E = (kbl * 8 + j) * 4 + kg;
-                    aw = *reinterpret_cast<const uint4*>(L.ximg + ((size_t)E * (2 * BT) + arow) * 16);
-                }
-                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw),
-                                                              __builtin_bit_cast(bf16x8_t, bw), acc, 0, 0, 0);
-                const float* xs = L.xs32 + ((size_t)(kbl * 8 + j) * 2 + hl) * BT;
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    const float xsum = xs[(4 * (kg & 1) + v) & (BT - 1)];
-                    y[v] = fmaf(dsc[j], acc[v], y[v]);
-                    y[v] = fmaf(-cj[j], xsum, y[v]);
-                }
-            }
-        }
+        const uint32_t w0 = pr ? qs.z : qs.x, w1 = pr ? qs.w : qs.y;
+        uint4 bw;
+        bw.x = ((w0 >> sh) & 0x000F000Fu) | BF16_128;        // elements (b0, b2)
+        bw.y = ((w0 >> (sh + 8)) & 0x000F000Fu) | BF16_128;  // elements (b1, b3)
+        bw.z = ((w1 >> sh) & 0x000F000Fu) | BF16_128;        // elements (b4, b6)
+        bw.w = ((w1 >> (sh + 8)) & 0x000F000Fu) | BF16_128;  // elements (b5, b7)
+        const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw[j]),
+                                                         __builtin_bit_cast(bf16x8_t, bw), zero, 0, 0, 0);
     }
+    // ---- per-sub-block scale, folded "+128" offset and minimum
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            y[v] = fmaf(dsc[j], acc[j][v], y[v]);
+            y[v] = fmaf(-cj[j], xsum[j][v], y[v]);
+        }
 }
 
 template <int BT, int NV>
 __device__ __forceinline__ void compute_q6k(const TileRegs& w, const XLds<BT>& L, int kbl, int lane, float (&y)[NV]) {
     const int m = lane & 15, kg = lane >> 4;
+    // A fragment of 16-sub-block s: entry 2s + (kg>>1), 8-byte half (kg&1)
+    const uint8_t* abase = L.ximg + ((size_t)(kbl * 32 + (kg >> 1)) * (2 * BT) + a_row_of<BT>(m)) * 16 + (kg & 1) * 8;
+    uint2 aw[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) aw[s] = *reinterpret_cast<const uint2*>(abase + (size_t)s * 2 * (2 * BT) * 16);
+    const float* xs = L.xs16 + ((size_t)(kbl * 2 + (kg >> 1)) * 16) * BT + ((4 * (kg & 1)) & (BT - 1));
+    float xsum[16][NV];
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) xsum[s][v] = xs[s * BT + v];
     const float d = f16_bits_to_f32((uint16_t)(w.e & 0xFFFF));
     const uint32_t scw[4] = {w.a.x, w.a.y, w.a.z, w.a.w};
     const uint32_t qhw[4] = {w.d.x, w.d.y, w.d.z, w.d.w};
-    const bool arow_ok = (m < BT) || (m >= 8 && m < 8 + BT);
-    const int arow = (m < 8) ? m : (BT + m - 8);
-    const int hl = kg >> 1;
+    f32x4_t acc[16];
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const uint4 ql = n ? w.c : w.b;
@@ -316,106 +347,121 @@ __device__ __forceinline__ void compute_q6k(const TileRegs& w, const XLds<BT>& L
                 uint2 bw;
                 bw.x = (t[tt] & 0x00FF00FFu) | BF16_128;              // elements (b0, b2)
                 bw.y = ((t[tt] >> 8) & 0x00FF00FFu) | BF16_128;       // elements (b1, b3)
-                uint2 aw = make_uint2(0, 0);
-                if (arow_ok) {
-                    const int E = kbl * 32 + 2 * s + (kg >> 1);
-                    aw = *reinterpret_cast<const uint2*>(L.ximg + ((size_t)E * (2 * BT) + arow) * 16 + (kg & 1) * 8);
-                }
-                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, aw),
-                                                                __builtin_bit_cast(s16x4_t, bw), acc, 0, 0, 0);
-                const int sc8 = (int)(int8_t)((scw[s >> 2] >> (8 * (s & 3))) & 0xFF);
-                const float dsc = d * (float)sc8;
-                const float* xs = L.xs16 + ((size_t)(kbl * 16 + s) * 2 + hl) * BT;
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    const float xsum = xs[(4 * (kg & 1) + v) & (BT - 1)];
-                    y[v] = fmaf(dsc, fmaf(-160.f, xsum, acc[v]), y[v]);   // code = q+32 (+128 bf16 offset)
-                }
+                const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+                acc[s] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, aw[s]),
+                                                                   __builtin_bit_cast(s16x4_t, bw), zero, 0, 0, 0);
             }
         }
     }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int sc8 = (int)(int8_t)((scw[s >> 2] >> (8 * (s & 3))) & 0xFF);
+        const float dsc = d * (float)sc8;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) y[v] = fmaf(dsc, fmaf(-160.f, xsum[s][v], acc[s][v]), y[v]);   // code = q+32 (+128)
+    }
 }
 
-// Stage `nkb` k-blocks [kb0, kb0+nkb) of x (all BT batch rows) into the LDS image.
+// Stage k-blocks [kb0, kb0+nkb) of x (all BT batch rows) into the LDS image.  When an RMSNorm is fused the
+// staged value is x*w_norm; the per-row scalar 1/rms is applied in the epilogue (y is linear in x), so the
+// statistics (sum x^2, accumulated here into ss[]) never sit on the critical path.
 template <int BT>
-__device__ __forceinline__ void stage_x(const QmmArgs& a, const XLds<BT>& L, int kb0, int nkb, const float* inv_rms) {
+__device__ __forceinline__ void stage_x(const QmmArgs& a, const XLds<BT>& L, int kb0, int nkb, float (&ss)[BT]) {
     const int nE = nkb * 32;
-    for (int idx = threadIdx.x; idx < nE * BT; idx += blockDim.x) {
-        const int El = idx % nE, b = idx / nE;
-        float v[8];
-        float hsum = 0.f, lsum = 0.f;
-        uint32_t hw[4], lw[4];
-        if (b < a.B) {
-            const int k = (kb0 * 32 + El) * 8;
-            const float4 v0 = *reinterpret_cast<const float4*>(a.x + (size_t)b * a.ldx + k);
-            const float4 v1 = *reinterpret_cast<const float4*>(a.x + (size_t)b * a.ldx + k + 4);
-            v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-            if (a.norm_w) {
-                const float4 n0 = *reinterpret_cast<const float4*>(a.norm_w + k);
-                const float4 n1 = *reinterpret_cast<const float4*>(a.norm_w + k + 4);
-                const float s = inv_rms[b];
-                v[0] = v[0] * s * n0.x; v[1] = v[1] * s * n0.y; v[2] = v[2] * s * n0.z; v[3] = v[3] * s * n0.w;
-                v[4] = v[4] * s * n1.x; v[5] = v[5] * s * n1.y; v[6] = v[6] * s * n1.z; v[7] = v[7] * s * n1.w;
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+        for (int El = threadIdx.x; El < nE; El += blockDim.x) {
+            float v[8];
+            if (b < a.B) {
+                const int k = (kb0 * 32 + El) * 8;
+                if (a.x_dtype == MI355_DTYPE_BF16) {
+                    const uint4 w = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(a.x) + (size_t)b * a.ldx + k);
+                    v[0] = bf16lo_to_f32(w.x); v[1] = bf16hi_to_f32(w.x); v[2] = bf16lo_to_f32(w.y); v[3] = bf16hi_to_f32(w.y);
+                    v[4] = bf16lo_to_f32(w.z); v[5] = bf16hi_to_f32(w.z); v[6] = bf16lo_to_f32(w.w); v[7] = bf16hi_to_f32(w.w);
+                } else {
+                    const float* xp = static_cast<const float*>(a.x) + (size_t)b * a.ldx + k;
+                    const float4 v0 = *reinterpret_cast<const float4*>(xp);
+                    const float4 v1 = *reinterpret_cast<const float4*>(xp + 4);
+                    v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+                }
+                if (a.norm_w) {
+                    const float4 n0 = *reinterpret_cast<const float4*>(a.norm_w + k);
+                    const float4 n1 = *reinterpret_cast<const float4*>(a.norm_w + k + 4);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ss[b] = fmaf(v[e], v[e], ss[b]);
+                    v[0] *= n0.x; v[1] *= n0.y; v[2] *= n0.z; v[3] *= n0.w;
+                    v[4] *= n1.x; v[5] *= n1.y; v[6] *= n1.z; v[7] *= n1.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
             }
-        } else {
+            float hsum = 0.f, lsum = 0.f;
+            uint32_t hb[8], lb[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.f;
-        }
-        uint16_t hb[8], lb[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            hb[e] = f32_to_bf16(v[e]);
-            const float hf = bf16_to_f32(hb[e]);
-            lb[e] = f32_to_bf16(v[e] - hf);
-            hsum += hf;
-            lsum += bf16_to_f32(lb[e]);
-        }
-        // fragment element order {0,2,1,3,4,6,5,7}
-        hw[0] = hb[0] | ((uint32_t)hb[2] << 16); hw[1] = hb[1] | ((uint32_t)hb[3] << 16);
-        hw[2] = hb[4] | ((uint32_t)hb[6] << 16); hw[3] = hb[5] | ((uint32_t)hb[7] << 16);
-        lw[0] = lb[0] | ((uint32_t)lb[2] << 16); lw[1] = lb[1] | ((uint32_t)lb[3] << 16);
-        lw[2] = lb[4] | ((uint32_t)lb[6] << 16); lw[3] = lb[5] | ((uint32_t)lb[7] << 16);
-        *reinterpret_cast<uint4*>(L.ximg + ((size_t)El * (2 * BT) + b) * 16) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-        *reinterpret_cast<uint4*>(L.ximg + ((size_t)El * (2 * BT) + BT + b) * 16) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
-        // 16- and 32-element sums: lanes of a quad hold consecutive entries of the same batch row
-        const float h16 = hsum + __shfl_xor(hsum, 1, 64), l16 = lsum + __shfl_xor(lsum, 1, 64);
-        const float h32 = h16 + __shfl_xor(h16, 2, 64), l32 = l16 + __shfl_xor(l16, 2, 64);
-        if ((El & 1) == 0) {
-            L.xs16[((size_t)(El >> 1) * 2 + 0) * BT + b] = h16;
-            L.xs16[((size_t)(El >> 1) * 2 + 1) * BT + b] = l16;
-        }
-        if ((El & 3) == 0) {
-            L.xs32[((size_t)(El >> 2) * 2 + 0) * BT + b] = h32;
-            L.xs32[((size_t)(El >> 2) * 2 + 1) * BT + b] = l32;
+            for (int e = 0; e < 8; ++e) {
+                hb[e] = f32_to_bf16(v[e]);
+                const float hf = __uint_as_float(hb[e] << 16);
+                lb[e] = f32_to_bf16(v[e] - hf);
+                hsum += hf;
+                lsum += __uint_as_float(lb[e] << 16);
+            }
+            // fragment element order {0,2,1,3,4,6,5,7}
+            *reinterpret_cast<uint4*>(L.ximg + ((size_t)El * (2 * BT) + b) * 16) =
+                make_uint4(hb[0] | (hb[2] << 16), hb[1] | (hb[3] << 16), hb[4] | (hb[6] << 16), hb[5] | (hb[7] << 16));
+            *reinterpret_cast<uint4*>(L.ximg + ((size_t)El * (2 * BT) + BT + b) * 16) =
+                make_uint4(lb[0] | (lb[2] << 16), lb[1] | (lb[3] << 16), lb[4] | (lb[6] << 16), lb[5] | (lb[7] << 16));
+            // 16- and 32-element sums: the lanes of a quad hold consecutive entries of one batch row
+            const float h16 = hsum + __shfl_xor(hsum, 1, 64), l16 = lsum + __shfl_xor(lsum, 1, 64);
+            const float h32 = h16 + __shfl_xor(h16, 2, 64), l32 = l16 + __shfl_xor(l16, 2, 64);
+            if ((El & 1) == 0) {                                  // [kbl][hl][16 s][BT]
+                const int kbl = El >> 5, s16 = (El >> 1) & 15;
+                L.xs16[((size_t)(kbl * 2 + 0) * 16 + s16) * BT + b] = h16;
+                L.xs16[((size_t)(kbl * 2 + 1) * 16 + s16) * BT + b] = l16;
+            }
+            if ((El & 3) == 0) {                                  // [kbl][hl][8 j][BT]
+                const int kbl = El >> 5, j = (El >> 2) & 7;
+                L.xs32[((size_t)(kbl * 2 + 0) * 8 + j) * BT + b] = h32;
+                L.xs32[((size_t)(kbl * 2 + 1) * 8 + j) * BT + b] = l32;
+            }
         }
     }
 }
 
 __device__ __forceinline__ float silu_f(float g) { return g / (1.f + __expf(-g)); }
 
-template <int BT, int R>
+#define QMM_PF 4   // weight-prefetch ring depth in (k-block, tile) units per wave
+
+// One workgroup = R row tiles x all of K.  Its NW waves split the k-blocks (wave w owns k-blocks w, w+NW, ...);
+// every wave walks its (k-block, tile) units through a QMM_PF-deep register ring.  The ring loop is fully
+// static (unrolled over the ring slots, loads issued unconditionally -- past the end they hit one dummy line)
+// so the compiler emits counted vmcnt waits and ~QMM_PF KiB-sized loads per lane stay in flight.
+template <int BT, int R, int WT>
 __global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) {
     constexpr int NV = BT < 4 ? BT : 4;
+    constexpr int PF = QMM_PF;
+    constexpr int PFK = PF / R;                                  // ring depth in k-blocks
+    static_assert(PF % R == 0, "ring depth must be a multiple of the tiles per workgroup");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
     const int nkb = a.K >> 8;
 
-    // ---- which tile(s) does this workgroup own?
+    // ---- which tiles does this workgroup own?  slot r in [0,R)
     int segi[R], tile[R];
-    if (R == 2) {
-        segi[0] = 0; tile[0] = blockIdx.x;
-        segi[R - 1] = 1; tile[R - 1] = blockIdx.x;
+    if (a.paired) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { segi[r] = r & 1; tile[r] = blockIdx.x * (R / 2 > 0 ? R / 2 : 1) + (r >> 1); }
     } else {
-        int t = blockIdx.x, s = 0;
+        int t = blockIdx.x * R, s = 0;
         while (s + 1 < a.nseg && t >= a.seg[s].n_tiles) { t -= a.seg[s].n_tiles; ++s; }
-        segi[0] = s; tile[0] = t;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { segi[r] = s; tile[r] = t + r; }      // launcher guarantees n_tiles % R == 0
     }
     const uint8_t* wbase[R];
     int wtype[R], wtb[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        wtype[r] = a.seg[segi[r]].type;
+        wtype[r] = WT ? WT : a.seg[segi[r]].type;
         wtb[r] = (wtype[r] == MI355_GGML_Q4_K) ? Q4K_TILE : Q6K_TILE;
         wbase[r] = a.seg[segi[r]].w + (size_t)tile[r] * nkb * wtb[r];
     }
@@ -427,56 +473,53 @@ __global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) {
     L.xs32 = reinterpret_cast<float*>(smem + (size_t)kch * 32 * 2 * BT * 16);
     L.xs16 = L.xs32 + (size_t)kch * 8 * 2 * BT;
     float* red = L.xs16 + (size_t)kch * 16 * 2 * BT;             // [NW][R][BT][16]
-    float* inv_rms = red + (size_t)NW * R * BT * 16;              // [BT]
+    float* red_ss = red + (size_t)NW * R * BT * 16;               // [NW][BT]
 
     float y[R][NV];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int v = 0; v < NV; ++v) y[r][v] = 0.f;
-
-    // first weight loads go out before anything else so they overlap the activation staging
-    TileRegs cur[R], nxt[R];
-    int kb = wave;                                                // this wave's k-blocks: wave, wave+NW, ...
-    if (kb < nkb) {
+    float ss[BT];
 #pragma unroll
-        for (int r = 0; r < R; ++r) cur[r] = load_tile(wtype[r], wbase[r] + (size_t)kb * wtb[r], lane);
+    for (int b = 0; b < BT; ++b) ss[b] = 0.f;
+
+    // this wave's k-blocks: kb = wave + NW*kbi, kbi in [0, n_my_kb); ring slot s <-> (kbi0 + s/R, tile s%R)
+    const int n_my_kb = (nkb > wave) ? (nkb - wave + NW - 1) / NW : 0;
+    TileRegs buf[PF];
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+        const int r = s % R, kbi = s / R;
+        const bool ok = kbi < n_my_kb;
+        buf[s] = load_tile<WT>(wtype[r], ok ? wbase[r] + (size_t)(wave + NW * kbi) * wtb[r] : wbase[r], ok ? lane : 0);
     }
 
-    // ---- fused RMSNorm statistics (one wave per batch row, no barrier until the end)
-    if (a.norm_w) {
-        for (int b = wave; b < a.B; b += NW) {
-            const float4* xr = reinterpret_cast<const float4*>(a.x + (size_t)b * a.ldx);
-            float ss = 0.f;
-            for (int i = lane; i < a.K / 4; i += 64) {
-                const float4 v = xr[i];
-                ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-            }
-            ss = wave_sum(ss);
-            if (lane == 0) inv_rms[b] = rsqrtf(ss / (float)a.K + a.eps);
-        }
-        __syncthreads();
-    }
-
+    int kbi0 = 0;
     for (int c0 = 0; c0 < nkb; c0 += kch) {
         const int cn = min(kch, nkb - c0);
         if (c0 > 0) __syncthreads();                              // previous chunk fully consumed
-        stage_x<BT>(a, L, c0, cn, inv_rms);
+        stage_x<BT>(a, L, c0, cn, ss);
         __syncthreads();
-        // this wave's k-blocks inside [c0, c0+cn)
-        for (; kb < c0 + cn; kb += NW) {
-            const int kn = kb + NW;
-            if (kn < nkb) {
+        const int kb_hi = c0 + cn;                                // first k-block beyond the chunk
+        const int kbi_end = (kb_hi > wave) ? (kb_hi - wave + NW - 1) / NW : 0;   // launcher: kch % (NW*PFK) == 0
+        for (; kbi0 < kbi_end; kbi0 += PFK) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) nxt[r] = load_tile(wtype[r], wbase[r] + (size_t)kn * wtb[r], lane);
+            for (int s = 0; s < PF; ++s) {
+                const int r = s % R, kbi = kbi0 + s / R;
+                if (kbi < kbi_end) {
+                    const int kbl = wave + NW * kbi - c0;
+                    if (a.dbg == 1) {
+                        y[r][0] += __uint_as_float((buf[s].a.x ^ buf[s].b.x ^ buf[s].c.x ^ buf[s].d.x ^ buf[s].b.w ^ buf[s].c.w) & 0x3FFFFFu);
+                    } else if (wtype[r] == MI355_GGML_Q4_K) {
+                        compute_q4k<BT, NV>(buf[s], L, kbl, lane, y[r]);
+                    } else {
+                        compute_q6k<BT, NV>(buf[s], L, kbl, lane, y[r]);
+                    }
+                }
+                const int kbn = kbi + PFK;
+                const bool ok = kbn < n_my_kb;
+                buf[s] = load_tile<WT>(wtype[r], ok ? wbase[r] + (size_t)(wave + NW * kbn) * wtb[r] : wbase[r], ok ? lane : 0);
             }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (wtype[r] == MI355_GGML_Q4_K) compute_q4k<BT, NV>(cur[r], L, kb - c0, lane, y[r]);
-                else compute_q6k<BT, NV>(cur[r], L, kb - c0, lane, y[r]);
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) cur[r] = nxt[r];
         }
     }
 
@@ -490,57 +533,76 @@ __global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) {
             const int b = 4 * kg + v;
             if (kg < 2 && b < BT) red[(((size_t)wave * R + r) * BT + b) * 16 + row] = y[r][v];
         }
+    if (a.norm_w) {
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            const float t = wave_sum(ss[b]);
+            if (lane == 0) red_ss[wave * BT + b] = t;
+        }
+    }
     __syncthreads();
 
-    // ---- epilogue: thread -> (b, row) of the (first) tile; sums over waves
-    const int nout = BT * 16;
+    // ---- epilogue: thread -> (slot r, batch b, row rr)
+    constexpr int RO = R;                                          // output slots
+    const int nout = RO * BT * 16;
     for (int idx = threadIdx.x; idx < nout; idx += blockDim.x) {
-        const int b = idx >> 4, rr = idx & 15;
+        const int rr = idx & 15, b = (idx >> 4) % BT, r = idx / (16 * BT);
         if (b >= a.B) continue;
-        float val[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float s = 0.f;
-            for (int w = 0; w < NW; ++w) s += red[(((size_t)w * R + r) * BT + b) * 16 + rr];
-            val[r] = s;
+        float rs = 1.f;
+        if (a.norm_w) {
+            float t = 0.f;
+            for (int w = 0; w < NW; ++w) t += red_ss[w * BT + b];
+            rs = rsqrtf(t / (float)a.K + a.eps);
         }
-        const QmmSeg& sg = a.seg[segi[0]];
-        const int lrow = tile[0] * 16 + rr;                       // row inside the segment
+        auto sum_of = [&](int slot, int rowi) {
+            float s = 0.f;
+            for (int w = 0; w < NW; ++w) s += red[(((size_t)w * R + slot) * BT + b) * 16 + rowi];
+            return s * rs;
+        };
+        // runtime slot index (r) only touches scalars here
+        int sgi = 0, tl = 0;
+#pragma unroll
+        for (int q = 0; q < R; ++q) if (q == r) { sgi = segi[q]; tl = tile[q]; }
+        const QmmSeg& sg = a.seg[sgi];
+        const int lrow = tl * 16 + rr;                             // row inside the segment
         if (lrow >= sg.n_rows) continue;
         const int orow = sg.row0 + lrow;
-        if (a.bias) val[0] += a.bias[orow];
+        if (a.epi == MI355_EPI_SILU_MUL) {
+            if (r & 1) continue;                                   // even slot = gate, odd slot = up of the same rows
+            float g = sum_of(r, rr), up = sum_of(r + 1, rr);
+            if (a.bias) { g += a.bias[orow]; up += a.bias[a.seg[1].row0 + lrow]; }
+            a.out[(size_t)b * a.ldo + lrow] = silu_f(g) * up;
+            continue;
+        }
+        float val = sum_of(r, rr);
+        if (a.bias) val += a.bias[orow];
         if (a.epi == MI355_EPI_STORE) {
-            a.out[(size_t)b * a.ldo + orow] = val[0];
+            a.out[(size_t)b * a.ldo + orow] = val;
         } else if (a.epi == MI355_EPI_RESID) {
-            a.out[(size_t)b * a.ldo + orow] = a.resid[(size_t)b * a.ldo + orow] + val[0];
-        } else if (a.epi == MI355_EPI_SILU_MUL) {
-            if (a.bias) val[R - 1] += a.bias[a.seg[1].row0 + lrow];
-            a.out[(size_t)b * a.ldo + lrow] = silu_f(val[0]) * val[R - 1];
+            a.out[(size_t)b * a.ldo + orow] = a.resid[(size_t)b * a.ldo + orow] + val;
         } else if (a.epi == MI355_EPI_QKV_ROPE_CACHE) {
             // segment 0 = q, 1 = k, 2 = v ; interleaved RoPE on (even,odd) channel pairs of q and k
             const int D = a.D, d = lrow % D, hh = lrow / D;
-            float o = val[0];
-            if (segi[0] < 2 && d < a.rot) {
-                // partner value = same thread set? no: partner row rr^1 lives in another thread -> recompute its sum
-                float pv = 0.f;
-                for (int w = 0; w < NW; ++w) pv += red[(((size_t)w * R) * BT + b) * 16 + (rr ^ 1)];
+            float o = val;
+            if (sgi < 2 && d < a.rot) {
+                float pv = sum_of(r, rr ^ 1);
                 if (a.bias) pv += a.bias[orow ^ 1];
                 const int64_t pos = a.positions[b];
                 const float c = a.cos_t[pos * (a.rot >> 1) + (d >> 1)], s = a.sin_t[pos * (a.rot >> 1) + (d >> 1)];
-                o = (d & 1) ? (pv * s + val[0] * c) : (val[0] * c - pv * s);
+                o = (d & 1) ? (pv * s + val * c) : (val * c - pv * s);
             }
             const uint16_t ob = f32_to_bf16(o);
-            if (segi[0] == 0) {
+            if (sgi == 0) {
                 a.q_out[(size_t)b * a.Hq * D + lrow] = ob;
             } else {
                 const int64_t slot = a.slot_mapping[b];
                 if (slot >= 0) {
-                    uint16_t* cache = (segi[0] == 1) ? a.kcache : a.vcache;
+                    uint16_t* cache = (sgi == 1) ? a.kcache : a.vcache;
                     if (a.kv_layout == MI355_KV_FLASH) {
                         cache[(slot * a.Hkv + hh) * D + d] = ob;
                     } else {
                         const int64_t blk = slot / a.block_size, off = slot % a.block_size;
-                        if (segi[0] == 1)
+                        if (sgi == 1)
                             cache[((((blk * a.Hkv + hh) * (D / 8) + d / 8) * a.block_size + off) * 8) + d % 8] = ob;
                         else
                             cache[((blk * a.Hkv + hh) * D + d) * (int64_t)a.block_size + off] = ob;
@@ -552,32 +614,56 @@ __global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ launcher
+static int g_tune_nw = 0, g_tune_r = 0, g_tune_dbg = 0;   // 0 = heuristic; mi355_set_tuning (experiments only)
+extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
+    if (key == 0) g_tune_nw = value;
+    else if (key == 1) g_tune_r = value;
+    else if (key == 2) g_tune_dbg = value;
+}
+
 static size_t qmm_lds_bytes(int BT, int R, int NW, int kch) {
     return (size_t)kch * 32 * 2 * BT * 16 + (size_t)kch * 8 * 2 * BT * 4 + (size_t)kch * 16 * 2 * BT * 4 +
-           (size_t)NW * R * BT * 16 * 4 + (size_t)BT * 4 + 64;
+           (size_t)NW * R * BT * 16 * 4 + (size_t)NW * BT * 4 + 64;
+}
+
+template <int BT, int R, int WT>
+static int qmm_launch_btrw(QmmArgs& a, int n_wg, int NW, hipStream_t st) {
+    constexpr int PFK = QMM_PF / R;
+    const int nkb = a.K / 256;
+    // k-blocks per LDS chunk: whole K when it fits (<= 144 KB), else the largest multiple of NW*PFK within 64 KB
+    const size_t per_kb = (size_t)32 * 2 * BT * 16 + 8 * 2 * BT * 4 + 16 * 2 * BT * 4;
+    int kch = nkb;
+    if ((size_t)nkb * per_kb > 144 * 1024 || ((size_t)nkb * per_kb > 72 * 1024 && BT > 1)) {
+        int budget = (int)((64 * 1024) / per_kb);
+        while (NW > 1 && NW * PFK > budget) NW >>= 1;
+        if (NW * PFK > budget) budget = NW * PFK;                 // BT=8, R=1: one ring group per chunk
+        kch = (budget / (NW * PFK)) * (NW * PFK);
+        if (kch > nkb) kch = nkb;
+    }
+    a.kch = kch;
+    const size_t shm = qmm_lds_bytes(BT, R, NW, kch);
+    if (shm > 160 * 1024) return (int)hipErrorInvalidValue;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)qmm_kernel<BT, R, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((qmm_kernel<BT, R, WT>), dim3(n_wg), dim3(64 * NW), shm, st, a);
+    return (int)hipGetLastError();
+}
+
+template <int BT, int R>
+static int qmm_launch_btr(QmmArgs& a, int wt, int n_wg, int NW, hipStream_t st) {
+    if (wt == MI355_GGML_Q4_K) return qmm_launch_btrw<BT, R, MI355_GGML_Q4_K>(a, n_wg, NW, st);
+    if (wt == MI355_GGML_Q6_K) return qmm_launch_btrw<BT, R, MI355_GGML_Q6_K>(a, n_wg, NW, st);
+    return qmm_launch_btrw<BT, R, 0>(a, n_wg, NW, st);
 }
 
 template <int BT>
-static int qmm_launch_bt(QmmArgs& a, int n_wg, int NW, hipStream_t st) {
-    const int R = a.paired ? 2 : 1;
-    const int nkb = a.K / 256;
-    // k-blocks per LDS chunk: keep the image <= ~72 KB so two workgroups fit a CU
-    const size_t per_kb = (size_t)32 * 2 * BT * 16 + 8 * 2 * BT * 4 + 16 * 2 * BT * 4;
-    int kch = (int)((72 * 1024) / per_kb);
-    if (kch < 1) kch = 1;
-    if (kch > nkb) kch = nkb;
-    a.kch = kch;
-    const size_t shm = qmm_lds_bytes(BT, R, NW, kch);
-    if (R == 2) {
-        static bool attr_done = false;
-        if (!attr_done) { (void)hipFuncSetAttribute((const void*)qmm_kernel<BT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
-        hipLaunchKernelGGL((qmm_kernel<BT, 2>), dim3(n_wg), dim3(64 * NW), shm, st, a);
-    } else {
-        static bool attr_done = false;
-        if (!attr_done) { (void)hipFuncSetAttribute((const void*)qmm_kernel<BT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
-        hipLaunchKernelGGL((qmm_kernel<BT, 1>), dim3(n_wg), dim3(64 * NW), shm, st, a);
-    }
-    return (int)hipGetLastError();
+static int qmm_launch_bt(QmmArgs& a, int R, int wt, int n_wg, int NW, hipStream_t st) {
+    if (R == 4) return qmm_launch_btr<BT, 4>(a, wt, n_wg, NW, st);
+    if (R == 2) return qmm_launch_btr<BT, 2>(a, wt, n_wg, NW, st);
+    return qmm_launch_btr<BT, 1>(a, wt, n_wg, NW, st);
 }
 
 // Run one fused quantised mat-mul over batch rows [0,B) in M-tiles of 8 batch entries.
@@ -587,15 +673,39 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
     for (int s = 0; s < a.nseg; ++s)
         if (a.seg[s].type != MI355_GGML_Q4_K && a.seg[s].type != MI355_GGML_Q6_K) return (int)hipErrorInvalidValue;
     if (a.paired && (a.nseg != 2 || a.seg[0].n_tiles != a.seg[1].n_tiles)) return (int)hipErrorInvalidValue;
-    int n_wg = 0;
-    if (a.paired) n_wg = a.seg[0].n_tiles;
-    else for (int s = 0; s < a.nseg; ++s) n_wg += a.seg[s].n_tiles;
+    int total_tiles = 0;
+    bool div4 = true, div2 = true;
+    for (int s = 0; s < a.nseg; ++s) {
+        total_tiles += a.seg[s].n_tiles;
+        if (a.seg[s].n_tiles % 4) div4 = false;
+        if (a.seg[s].n_tiles % 2) div2 = false;
+    }
+    // tiles per workgroup: amortise the activation staging but keep >= ~1024 workgroups (4 per CU)
+    int R;
+    if (a.paired) {
+        R = (a.seg[0].n_tiles % 2 == 0 && a.seg[0].n_tiles / 2 >= 1024) ? 4 : 2;
+    } else {
+        R = 1;
+        if (div2 && total_tiles / 2 >= 1024) R = 2;
+        if (div4 && total_tiles / 4 >= 1024) R = 4;
+    }
+    if (g_tune_r > 0 && !(a.paired && g_tune_r == 1)) {
+        if (g_tune_r == 4 && (a.paired ? a.seg[0].n_tiles % 2 == 0 : div4)) R = 4;
+        else if (g_tune_r == 2 && (a.paired || div2)) R = 2;
+        else if (g_tune_r == 1 && !a.paired) R = 1;
+    }
+    const int n_wg = a.paired ? a.seg[0].n_tiles / (R / 2) : total_tiles / R;
     const int nkb = a.K / 256;
-    int NW = 8;
+    int NW = (n_wg >= 768) ? 4 : 8;
+    if (g_tune_nw > 0) NW = g_tune_nw;
     while (NW > 1 && nkb < NW) NW >>= 1;
     hipStream_t st = to_stream(stream);
+    int wt = a.seg[0].type;                                   // uniform tile type of the launch, else 0 (mixed)
+    for (int s = 1; s < a.nseg; ++s) if (a.seg[s].type != wt) wt = 0;
+    a.dbg = g_tune_dbg;
     const int B = a.B;
-    const float* x0 = a.x;
+    const size_t xes = (a.x_dtype == MI355_DTYPE_BF16) ? 2 : 4;
+    const uint8_t* x0 = static_cast<const uint8_t*>(a.x);
     float* out0 = a.out;
     const float* resid0 = a.resid;
     uint16_t* q0 = a.q_out;
@@ -604,17 +714,17 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
     for (int b0 = 0; b0 < B; b0 += 8) {                       // M-tiles of 8 batch entries
         const int bn = (B - b0 < 8) ? B - b0 : 8;
         a.B = bn;
-        a.x = x0 + (size_t)b0 * a.ldx;
+        a.x = x0 + (size_t)b0 * a.ldx * xes;
         a.out = out0 ? out0 + (size_t)b0 * a.ldo : nullptr;
         a.resid = resid0 ? resid0 + (size_t)b0 * a.ldo : nullptr;
         a.q_out = q0 ? q0 + (size_t)b0 * a.Hq * a.D : nullptr;
         a.positions = pos0 ? pos0 + b0 : nullptr;
         a.slot_mapping = slot0 ? slot0 + b0 : nullptr;
         int rc;
-        if (bn == 1) rc = qmm_launch_bt<1>(a, n_wg, NW, st);
-        else if (bn == 2) rc = qmm_launch_bt<2>(a, n_wg, NW, st);
-        else if (bn <= 4) rc = qmm_launch_bt<4>(a, n_wg, NW, st);
-        else rc = qmm_launch_bt<8>(a, n_wg, NW, st);
+        if (bn == 1) rc = qmm_launch_bt<1>(a, R, wt, n_wg, NW, st);
+        else if (bn == 2) rc = qmm_launch_bt<2>(a, R, wt, n_wg, NW, st);
+        else if (bn <= 4) rc = qmm_launch_bt<4>(a, R, wt, n_wg, NW, st);
+        else rc = qmm_launch_bt<8>(a, R, wt, n_wg, NW, st);
         if (rc) return rc;
     }
     return 0;
@@ -627,7 +737,7 @@ extern "C" int mi355_qmatmul(float* out, const float* x, const void* w_tiles, in
     QmmArgs a{};
     a.seg[0] = QmmSeg{static_cast<const uint8_t*>(w_tiles), ggml_type, (N + 15) / 16, 0, N};
     a.nseg = 1;
-    a.x = x; a.ldx = K; a.K = K; a.B = T;
+    a.x = x; a.x_dtype = MI355_DTYPE_F32; a.ldx = K; a.K = K; a.B = T;
     a.epi = MI355_EPI_STORE; a.out = out; a.ldo = N; a.bias = bias;
     return mi355_qmm_launch(a, stream);
 }
@@ -644,7 +754,8 @@ extern "C" int mi355_qmatmul_fused(const mi355_qmm_desc* d, int64_t stream) {
     }
     a.paired = (d->epilogue == MI355_EPI_SILU_MUL);
     if (a.paired) { a.seg[1].row0 = a.seg[0].n_rows; }
-    a.x = d->x; a.ldx = d->ldx; a.K = d->k; a.B = d->num_tokens;
+    a.x = d->x; a.x_dtype = d->x_dtype; a.ldx = d->ldx; a.K = d->k; a.B = d->num_tokens;
+    if (a.x_dtype != MI355_DTYPE_F32 && a.x_dtype != MI355_DTYPE_BF16) return (int)hipErrorInvalidValue;
     a.norm_w = d->norm_weight; a.eps = d->norm_eps;
     a.epi = d->epilogue; a.out = d->out; a.ldo = d->ldo; a.resid = d->residual; a.bias = d->bias;
     a.cos_t = d->cos_table; a.sin_t = d->sin_table; a.positions = d->positions; a.slot_mapping = d->slot_mapping;

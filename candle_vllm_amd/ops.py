@@ -164,7 +164,7 @@ def choose_partition(num_seqs, num_kv_heads, max_context_len):
         return 0
     per_seq = max(1, -(-TARGET_WORKGROUPS // max(1, num_seqs * num_kv_heads)))
     ps = -(-max_context_len // per_seq)
-    ps = max(128, ((ps + 63) // 64) * 64)
+    ps = max(64, ((ps + 63) // 64) * 64)
     return ps if ps < max_context_len else 0
 
 
@@ -340,6 +340,7 @@ def qmatmul_fused(mats: List[QMatMul], x, *, epilogue, out=None, norm_weight=Non
         d.ggml_type[i] = m.ggml_type
         d.n_rows[i] = m.n
     d.x = _dev(x)
+    d.x_dtype = _DT[x.dtype]
     d.ldx = x.shape[1]
     d.k = mats[0].k
     d.num_tokens = x.shape[0]

@@ -144,7 +144,8 @@ typedef struct mi355_qmm_desc {
     const void* w_tiles[3];     /* repacked weights                                                    */
     int32_t ggml_type[3];
     int32_t n_rows[3];          /* output rows of each matrix                                          */
-    const float* x;             /* f32 [num_tokens, ldx]                                               */
+    const void* x;              /* [num_tokens, ldx]; f32, or bf16 (x_dtype) e.g. the attention output   */
+    int32_t x_dtype;            /* MI355_DTYPE_F32 / MI355_DTYPE_BF16                                  */
     int32_t ldx, k, num_tokens;
     const float* norm_weight;   /* non-NULL: x <- rms_norm(x, norm_weight, norm_eps) before the matmul */
     float norm_eps;
@@ -164,6 +165,8 @@ typedef struct mi355_qmm_desc {
     int32_t num_heads, num_kv_heads, head_dim, rotary_dim, block_size, kv_layout;
 } mi355_qmm_desc;
 int mi355_qmatmul_fused(const mi355_qmm_desc* desc, int64_t stream);
+/* experiment knob (0: waves per workgroup, 1: row tiles per workgroup; value 0 = heuristic) */
+void mi355_set_tuning(int32_t key, int32_t value);
 
 #ifdef __cplusplus
 }

@@ -62,8 +62,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--ctx", type=int, default=4608)
+    ap.add_argument("--nw", type=int, default=0)
+    ap.add_argument("--r", type=int, default=0)
+    ap.add_argument("--dbg", type=int, default=0)
+    ap.add_argument("--only-qmm", action="store_true")
     args = ap.parse_args()
     dev = "cuda"
+    cv.lib.mi355_set_tuning(0, args.nw)
+    cv.lib.mi355_set_tuning(1, args.r)
+    cv.lib.mi355_set_tuning(2, args.dbg)
+    print(f"tuning nw={args.nw} r={args.r} dbg={args.dbg}", flush=True)
     B = args.batch
     hid, I, H, Hkv, D, V = 4096, 14336, 32, 8, 128, 128256
     flush = torch.zeros(128 * 1024 * 1024, dtype=torch.float32, device=dev)
@@ -111,6 +119,8 @@ def main():
     f = lambda: cv.qmatmul_fused([mg, mu], x, epilogue=cv.EPI_SILU_MUL, out=h, norm_weight=nw, norm_eps=1e-5)
     med, mn = timeit(f, flush=flush)
     report("norm+gate/up+silu", med, mn, mg.bytes + mu.bytes)
+    if args.only_qmm:
+        return
     # --- paged attention
     pa = cv.PagedAttention(H, D, D ** -0.5, Hkv)
     cl = torch.full((B,), args.ctx + 1, dtype=torch.int32, device=dev)

@@ -70,8 +70,9 @@ def _u32(buf, off):
 
 
 def _arow(m, BT):
-    ok = (m < BT) or (8 <= m < 8 + BT)
-    return ok, (m if m < 8 else BT + m - 8)
+    """a_row_of<BT>: rows beyond the staged batch re-read a staged row (their MFMA outputs are unused)"""
+    mm = (m & 7) if (m & 7) < BT else BT - 1
+    return True, (mm if m < 8 else BT + mm)
 
 
 def compute_q4k(tile, ximg, xs32, kb, BT, NV, y):
