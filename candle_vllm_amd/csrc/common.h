@@ -26,6 +26,12 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
+// two f32 -> packed bf16x2 (lo in bits 0-15), round-to-nearest-even in hardware (gfx950 v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
 __device__ __forceinline__ float f16_bits_to_f32(uint16_t h) {
     _Float16 v = __builtin_bit_cast(_Float16, h);
     return (float)v;

@@ -286,7 +286,10 @@ __device__ __forceinline__ void compute_q4k(const TileRegs& w, const XLds<BT>& L
         cj[j] = fmaf(dmin, ma, d128 * sa);
         cj[j + 4] = fmaf(dmin, mb, d128 * sb);
     }
-    // ---- 8 independent MFMAs (one per 32-weight sub-block)
+    // ---- 8 independent MFMAs (one per 32-weight sub-block).  The nibble mask lives in a VGPR so that
+    // (w >> s) & mask | 0x43004300 is one v_and_or_b32 (gfx9 VOP3 allows a single literal/SGPR operand).
+    uint32_t nib = 0x000F000Fu;
+    asm volatile("" : "+v"(nib));
     f32x4_t acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -294,10 +297,10 @@ __device__ __forceinline__ void compute_q4k(const TileRegs& w, const XLds<BT>& L
         const uint4 qs = p ? w.c : w.b;
         const uint32_t w0 = pr ? qs.z : qs.x, w1 = pr ? qs.w : qs.y;
         uint4 bw;
-        bw.x = ((w0 >> sh) & 0x000F000Fu) | BF16_128;        // elements (b0, b2)
-        bw.y = ((w0 >> (sh + 8)) & 0x000F000Fu) | BF16_128;  // elements (b1, b3)
-        bw.z = ((w1 >> sh) & 0x000F000Fu) | BF16_128;        // elements (b4, b6)
-        bw.w = ((w1 >> (sh + 8)) & 0x000F000Fu) | BF16_128;  // elements (b5, b7)
+        bw.x = ((w0 >> sh) & nib) | BF16_128;                // elements (b0, b2)
+        bw.y = ((w0 >> (sh + 8)) & nib) | BF16_128;          // elements (b1, b3)
+        bw.z = ((w1 >> sh) & nib) | BF16_128;                // elements (b4, b6)
+        bw.w = ((w1 >> (sh + 8)) & nib) | BF16_128;          // elements (b5, b7)
         const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
         acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw[j]),
                                                          __builtin_bit_cast(bf16x8_t, bw), zero, 0, 0, 0);
@@ -329,6 +332,8 @@ __device__ __forceinline__ void compute_q6k(const TileRegs& w, const XLds<BT>& L
     const float d = f16_bits_to_f32((uint16_t)(w.e & 0xFFFF));
     const uint32_t scw[4] = {w.a.x, w.a.y, w.a.z, w.a.w};
     const uint32_t qhw[4] = {w.d.x, w.d.y, w.d.z, w.d.w};
+    uint32_t bmask = 0x00FF00FFu;
+    asm volatile("" : "+v"(bmask));
     f32x4_t acc[16];
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -345,8 +350,8 @@ __device__ __forceinline__ void compute_q6k(const TileRegs& w, const XLds<BT>& L
             for (int tt = 0; tt < 4; ++tt) {
                 const int s = 8 * n + 2 * tt + is;                    // 16-sub-block index 0..15
                 uint2 bw;
-                bw.x = (t[tt] & 0x00FF00FFu) | BF16_128;              // elements (b0, b2)
-                bw.y = ((t[tt] >> 8) & 0x00FF00FFu) | BF16_128;       // elements (b1, b3)
+                bw.x = (t[tt] & bmask) | BF16_128;                    // elements (b0, b2)
+                bw.y = ((t[tt] >> 8) & bmask) | BF16_128;             // elements (b1, b3)
                 const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
                 acc[s] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, aw[s]),
                                                                    __builtin_bit_cast(s16x4_t, bw), zero, 0, 0, 0);
@@ -362,68 +367,77 @@ __device__ __forceinline__ void compute_q6k(const TileRegs& w, const XLds<BT>& L
     }
 }
 
-// Stage k-blocks [kb0, kb0+nkb) of x (all BT batch rows) into the LDS image.  When an RMSNorm is fused the
-// staged value is x*w_norm; the per-row scalar 1/rms is applied in the epilogue (y is linear in x), so the
-// statistics (sum x^2, accumulated here into ss[]) never sit on the critical path.
+// ---- activations: every wave stages the k-block it is about to consume into its OWN 1.2*BT KB of LDS
+// (no workgroup barrier, no prologue: the first x loads leave together with the first weight loads).
+// Lane L of the wave owns elements 4L..4L+3 of the k-block for every batch row.
 template <int BT>
-__device__ __forceinline__ void stage_x(const QmmArgs& a, const XLds<BT>& L, int kb0, int nkb, float (&ss)[BT]) {
-    const int nE = nkb * 32;
+struct XRegs {
+    uint4 v[BT];      // f32 x: 4 floats ; bf16 x: .x/.y hold 4 bf16
+    float4 nw;        // RMSNorm weight of the 4 elements (1 when no norm is fused)
+};
+
+template <int BT>
+__device__ __forceinline__ XRegs<BT> load_x(const QmmArgs& a, int kb, int lane, const float* nwp) {
+    XRegs<BT> r;
+    const size_t k = (size_t)kb * 256 + 4 * lane;
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
-        for (int El = threadIdx.x; El < nE; El += blockDim.x) {
-            float v[8];
-            if (b < a.B) {
-                const int k = (kb0 * 32 + El) * 8;
-                if (a.x_dtype == MI355_DTYPE_BF16) {
-                    const uint4 w = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(a.x) + (size_t)b * a.ldx + k);
-                    v[0] = bf16lo_to_f32(w.x); v[1] = bf16hi_to_f32(w.x); v[2] = bf16lo_to_f32(w.y); v[3] = bf16hi_to_f32(w.y);
-                    v[4] = bf16lo_to_f32(w.z); v[5] = bf16hi_to_f32(w.z); v[6] = bf16lo_to_f32(w.w); v[7] = bf16hi_to_f32(w.w);
-                } else {
-                    const float* xp = static_cast<const float*>(a.x) + (size_t)b * a.ldx + k;
-                    const float4 v0 = *reinterpret_cast<const float4*>(xp);
-                    const float4 v1 = *reinterpret_cast<const float4*>(xp + 4);
-                    v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-                }
-                if (a.norm_w) {
-                    const float4 n0 = *reinterpret_cast<const float4*>(a.norm_w + k);
-                    const float4 n1 = *reinterpret_cast<const float4*>(a.norm_w + k + 4);
+        const int bb = b < a.B ? b : a.B - 1;                     // padded rows re-read the last row (zeroed later)
+        if (a.x_dtype == MI355_DTYPE_BF16) {
+            const uint2 t = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(a.x) + (size_t)bb * a.ldx + k);
+            r.v[b] = make_uint4(t.x, t.y, 0, 0);
+        } else {
+            r.v[b] = *reinterpret_cast<const uint4*>(static_cast<const float*>(a.x) + (size_t)bb * a.ldx + k);
+        }
+    }
+    r.nw = *reinterpret_cast<const float4*>(nwp + k);
+    return r;
+}
+
+// Convert one k-block of x to the MFMA fragment image (hi/lo bf16 split, element order {0,2,1,3} per half entry)
+// in this wave's LDS scratch, plus the 16-/32-element sums of the staged values.  With a fused RMSNorm the
+// staged value is x*w_norm; the per-row 1/rms is applied in the epilogue (y is linear in x); sum x^2 -> ss[].
+template <int BT>
+__device__ __forceinline__ void stage_kblock(const QmmArgs& a, const XRegs<BT>& xr, const XLds<BT>& L, int lane,
+                                             float (&ss)[BT]) {
+    const int E = lane >> 1, half = lane & 1;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) ss[b] = fmaf(v[e], v[e], ss[b]);
-                    v[0] *= n0.x; v[1] *= n0.y; v[2] *= n0.z; v[3] *= n0.w;
-                    v[4] *= n1.x; v[5] *= n1.y; v[6] *= n1.z; v[7] *= n1.w;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = 0.f;
-            }
-            float hsum = 0.f, lsum = 0.f;
-            uint32_t hb[8], lb[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                hb[e] = f32_to_bf16(v[e]);
-                const float hf = __uint_as_float(hb[e] << 16);
-                lb[e] = f32_to_bf16(v[e] - hf);
-                hsum += hf;
-                lsum += __uint_as_float(lb[e] << 16);
-            }
-            // fragment element order {0,2,1,3,4,6,5,7}
-            *reinterpret_cast<uint4*>(L.ximg + ((size_t)El * (2 * BT) + b) * 16) =
-                make_uint4(hb[0] | (hb[2] << 16), hb[1] | (hb[3] << 16), hb[4] | (hb[6] << 16), hb[5] | (hb[7] << 16));
-            *reinterpret_cast<uint4*>(L.ximg + ((size_t)El * (2 * BT) + BT + b) * 16) =
-                make_uint4(lb[0] | (lb[2] << 16), lb[1] | (lb[3] << 16), lb[4] | (lb[6] << 16), lb[5] | (lb[7] << 16));
-            // 16- and 32-element sums: the lanes of a quad hold consecutive entries of one batch row
-            const float h16 = hsum + __shfl_xor(hsum, 1, 64), l16 = lsum + __shfl_xor(lsum, 1, 64);
-            const float h32 = h16 + __shfl_xor(h16, 2, 64), l32 = l16 + __shfl_xor(l16, 2, 64);
-            if ((El & 1) == 0) {                                  // [kbl][hl][16 s][BT]
-                const int kbl = El >> 5, s16 = (El >> 1) & 15;
-                L.xs16[((size_t)(kbl * 2 + 0) * 16 + s16) * BT + b] = h16;
-                L.xs16[((size_t)(kbl * 2 + 1) * 16 + s16) * BT + b] = l16;
-            }
-            if ((El & 3) == 0) {                                  // [kbl][hl][8 j][BT]
-                const int kbl = El >> 5, j = (El >> 2) & 7;
-                L.xs32[((size_t)(kbl * 2 + 0) * 8 + j) * BT + b] = h32;
-                L.xs32[((size_t)(kbl * 2 + 1) * 8 + j) * BT + b] = l32;
-            }
+    for (int b = 0; b < BT; ++b) {
+        float v[4];
+        if (a.x_dtype == MI355_DTYPE_BF16) {
+            v[0] = bf16lo_to_f32(xr.v[b].x); v[1] = bf16hi_to_f32(xr.v[b].x);
+            v[2] = bf16lo_to_f32(xr.v[b].y); v[3] = bf16hi_to_f32(xr.v[b].y);
+        } else {
+            v[0] = __uint_as_float(xr.v[b].x); v[1] = __uint_as_float(xr.v[b].y);
+            v[2] = __uint_as_float(xr.v[b].z); v[3] = __uint_as_float(xr.v[b].w);
+        }
+        if (b >= a.B) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+        if (a.norm_w) {
+            ss[b] = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], ss[b]))));
+            v[0] *= xr.nw.x; v[1] *= xr.nw.y; v[2] *= xr.nw.z; v[3] *= xr.nw.w;
+        }
+        // hi = bf16(v) (RNE, v_cvt_pk_bf16_f32), lo = bf16(v - hi); packed in fragment order (e0,e2),(e1,e3)
+        const uint32_t h02 = cvt_pk_bf16(v[0], v[2]), h13 = cvt_pk_bf16(v[1], v[3]);
+        const float hf0 = bf16lo_to_f32(h02), hf2 = bf16hi_to_f32(h02), hf1 = bf16lo_to_f32(h13), hf3 = bf16hi_to_f32(h13);
+        const uint32_t l02 = cvt_pk_bf16(v[0] - hf0, v[2] - hf2), l13 = cvt_pk_bf16(v[1] - hf1, v[3] - hf3);
+        const float hsum = (hf0 + hf1) + (hf2 + hf3);
+        const float lsum = (bf16lo_to_f32(l02) + bf16lo_to_f32(l13)) + (bf16hi_to_f32(l02) + bf16hi_to_f32(l13));
+        uint8_t* row_hi = L.ximg + ((size_t)E * (2 * BT) + b) * 16 + half * 8;
+        uint8_t* row_lo = L.ximg + ((size_t)E * (2 * BT) + BT + b) * 16 + half * 8;
+        *reinterpret_cast<uint2*>(row_hi) = make_uint2(h02, h13);
+        *reinterpret_cast<uint2*>(row_lo) = make_uint2(l02, l13);
+        // 16-element sums over 4 lanes, 32-element sums over 8 lanes
+        float h16 = hsum + __shfl_xor(hsum, 1, 64), l16 = lsum + __shfl_xor(lsum, 1, 64);
+        h16 += __shfl_xor(h16, 2, 64);
+        l16 += __shfl_xor(l16, 2, 64);
+        const float h32 = h16 + __shfl_xor(h16, 4, 64), l32 = l16 + __shfl_xor(l16, 4, 64);
+        if ((lane & 3) == 0) {                                    // xs16: [hl][16 s][BT]
+            L.xs16[((size_t)0 * 16 + (lane >> 2)) * BT + b] = h16;
+            L.xs16[((size_t)1 * 16 + (lane >> 2)) * BT + b] = l16;
+        }
+        if ((lane & 7) == 0) {                                    // xs32: [hl][8 j][BT]
+            L.xs32[((size_t)0 * 8 + (lane >> 3)) * BT + b] = h32;
+            L.xs32[((size_t)1 * 8 + (lane >> 3)) * BT + b] = l32;
         }
     }
 }
@@ -435,7 +449,8 @@ __device__ __forceinline__ float silu_f(float g) { return g / (1.f + __expf(-g))
 // One workgroup = R row tiles x all of K.  Its NW waves split the k-blocks (wave w owns k-blocks w, w+NW, ...);
 // every wave walks its (k-block, tile) units through a QMM_PF-deep register ring.  The ring loop is fully
 // static (unrolled over the ring slots, loads issued unconditionally -- past the end they hit one dummy line)
-// so the compiler emits counted vmcnt waits and ~QMM_PF KiB-sized loads per lane stay in flight.
+// so the compiler emits counted vmcnt waits and ~QMM_PF KiB-sized loads per lane stay in flight.  There is no
+// workgroup-level prologue: the only barrier is the one in front of the epilogue.
 template <int BT, int R, int WT>
 __global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) {
     constexpr int NV = BT < 4 ? BT : 4;
@@ -465,14 +480,16 @@ __global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) {
         wtb[r] = (wtype[r] == MI355_GGML_Q4_K) ? Q4K_TILE : Q6K_TILE;
         wbase[r] = a.seg[segi[r]].w + (size_t)tile[r] * nkb * wtb[r];
     }
+    // RMSNorm weights, or any readable K floats when no norm is fused (keeps the load count static)
+    const float* nwp = a.norm_w ? a.norm_w : reinterpret_cast<const float*>(a.seg[0].w);
 
-    // ---- LDS carve-up (all offsets multiples of 16)
-    const int kch = a.kch;
+    // ---- LDS carve-up: per-wave activation scratch, then the cross-wave reduction area
+    constexpr int XW = 32 * 2 * BT * 16 + 8 * 2 * BT * 4 + 16 * 2 * BT * 4;   // bytes per wave (multiple of 16)
     XLds<BT> L;
-    L.ximg = smem;
-    L.xs32 = reinterpret_cast<float*>(smem + (size_t)kch * 32 * 2 * BT * 16);
-    L.xs16 = L.xs32 + (size_t)kch * 8 * 2 * BT;
-    float* red = L.xs16 + (size_t)kch * 16 * 2 * BT;             // [NW][R][BT][16]
+    L.ximg = smem + (size_t)wave * XW;
+    L.xs32 = reinterpret_cast<float*>(L.ximg + 32 * 2 * BT * 16);
+    L.xs16 = L.xs32 + 8 * 2 * BT;
+    float* red = reinterpret_cast<float*>(smem + (size_t)NW * XW);   // [NW][R][BT][16]
     float* red_ss = red + (size_t)NW * R * BT * 16;               // [NW][BT]
 
     float y[R][NV];
@@ -486,39 +503,42 @@ __global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) {
 
     // this wave's k-blocks: kb = wave + NW*kbi, kbi in [0, n_my_kb); ring slot s <-> (kbi0 + s/R, tile s%R)
     const int n_my_kb = (nkb > wave) ? (nkb - wave + NW - 1) / NW : 0;
+    const int kb_last = n_my_kb > 0 ? wave + NW * (n_my_kb - 1) : 0;
+    XRegs<BT> xr[PFK];
     TileRegs buf[PF];
 #pragma unroll
-    for (int s = 0; s < PF; ++s) {
-        const int r = s % R, kbi = s / R;
-        const bool ok = kbi < n_my_kb;
-        buf[s] = load_tile<WT>(wtype[r], ok ? wbase[r] + (size_t)(wave + NW * kbi) * wtb[r] : wbase[r], ok ? lane : 0);
+    for (int q = 0; q < PFK; ++q) {
+        const int kb = wave + NW * q;
+        xr[q] = load_x<BT>(a, kb <= kb_last ? kb : kb_last, lane, nwp);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool ok = q < n_my_kb;
+            buf[q * R + r] = load_tile<WT>(wtype[r], ok ? wbase[r] + (size_t)kb * wtb[r] : wbase[r], ok ? lane : 0);
+        }
     }
 
-    int kbi0 = 0;
-    for (int c0 = 0; c0 < nkb; c0 += kch) {
-        const int cn = min(kch, nkb - c0);
-        if (c0 > 0) __syncthreads();                              // previous chunk fully consumed
-        stage_x<BT>(a, L, c0, cn, ss);
-        __syncthreads();
-        const int kb_hi = c0 + cn;                                // first k-block beyond the chunk
-        const int kbi_end = (kb_hi > wave) ? (kb_hi - wave + NW - 1) / NW : 0;   // launcher: kch % (NW*PFK) == 0
-        for (; kbi0 < kbi_end; kbi0 += PFK) {
+    for (int kbi0 = 0; kbi0 < n_my_kb; kbi0 += PFK) {
 #pragma unroll
-            for (int s = 0; s < PF; ++s) {
-                const int r = s % R, kbi = kbi0 + s / R;
-                if (kbi < kbi_end) {
-                    const int kbl = wave + NW * kbi - c0;
+        for (int q = 0; q < PFK; ++q) {
+            const int kbi = kbi0 + q;
+            const bool active = kbi < n_my_kb;                    // wave-uniform
+            if (active) stage_kblock<BT>(a, xr[q], L, lane, ss);
+            const int kbn = wave + NW * (kbi + PFK);
+            xr[q] = load_x<BT>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int s = q * R + r;
+                if (active) {
                     if (a.dbg == 1) {
                         y[r][0] += __uint_as_float((buf[s].a.x ^ buf[s].b.x ^ buf[s].c.x ^ buf[s].d.x ^ buf[s].b.w ^ buf[s].c.w) & 0x3FFFFFu);
                     } else if (wtype[r] == MI355_GGML_Q4_K) {
-                        compute_q4k<BT, NV>(buf[s], L, kbl, lane, y[r]);
+                        compute_q4k<BT, NV>(buf[s], L, 0, lane, y[r]);
                     } else {
-                        compute_q6k<BT, NV>(buf[s], L, kbl, lane, y[r]);
+                        compute_q6k<BT, NV>(buf[s], L, 0, lane, y[r]);
                     }
                 }
-                const int kbn = kbi + PFK;
-                const bool ok = kbn < n_my_kb;
-                buf[s] = load_tile<WT>(wtype[r], ok ? wbase[r] + (size_t)(wave + NW * kbn) * wtb[r] : wbase[r], ok ? lane : 0);
+                const bool ok = kbi + PFK < n_my_kb;
+                buf[s] = load_tile<WT>(wtype[r], ok ? wbase[r] + (size_t)kbn * wtb[r] : wbase[r], ok ? lane : 0);
             }
         }
     }
@@ -621,33 +641,52 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     else if (key == 2) g_tune_dbg = value;
 }
 
-static size_t qmm_lds_bytes(int BT, int R, int NW, int kch) {
-    return (size_t)kch * 32 * 2 * BT * 16 + (size_t)kch * 8 * 2 * BT * 4 + (size_t)kch * 16 * 2 * BT * 4 +
-           (size_t)NW * R * BT * 16 * 4 + (size_t)NW * BT * 4 + 64;
+static size_t qmm_lds_bytes(int BT, int R, int NW) {
+    const size_t xw = (size_t)32 * 2 * BT * 16 + 8 * 2 * BT * 4 + 16 * 2 * BT * 4;
+    return (size_t)NW * xw + (size_t)NW * R * BT * 16 * 4 + (size_t)NW * BT * 4 + 64;
+}
+
+static int g_num_cus = 0;
+
+// Waves per workgroup: the largest NW in {8,4,2,1} for which every workgroup of the launch is resident at
+// once (no second dispatch round => no tail), judged by the occupancy the runtime reports for this variant.
+template <int BT, int R, int WT>
+static int qmm_pick_nw(int n_wg, int nkb) {
+    static int blocks_per_cu[4] = {-1, -1, -1, -1};       // NW = 8,4,2,1
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    int pick = 1;
+    for (int i = 0; i < 4; ++i) {
+        const int nw = 8 >> i;
+        if (nw > nkb) continue;
+        if (blocks_per_cu[i] < 0) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)qmm_kernel<BT, R, WT>, 64 * nw,
+                                                             qmm_lds_bytes(BT, R, nw)) != hipSuccess || nb < 1) nb = 1;
+            blocks_per_cu[i] = nb;
+        }
+        pick = nw;
+        if ((long)n_wg <= (long)blocks_per_cu[i] * g_num_cus) return nw;
+    }
+    // more workgroups than the chip holds even at the smallest NW: several rounds anyway -> 4 waves
+    return nkb >= 4 ? 4 : pick;
 }
 
 template <int BT, int R, int WT>
 static int qmm_launch_btrw(QmmArgs& a, int n_wg, int NW, hipStream_t st) {
-    constexpr int PFK = QMM_PF / R;
-    const int nkb = a.K / 256;
-    // k-blocks per LDS chunk: whole K when it fits (<= 144 KB), else the largest multiple of NW*PFK within 64 KB
-    const size_t per_kb = (size_t)32 * 2 * BT * 16 + 8 * 2 * BT * 4 + 16 * 2 * BT * 4;
-    int kch = nkb;
-    if ((size_t)nkb * per_kb > 144 * 1024 || ((size_t)nkb * per_kb > 72 * 1024 && BT > 1)) {
-        int budget = (int)((64 * 1024) / per_kb);
-        while (NW > 1 && NW * PFK > budget) NW >>= 1;
-        if (NW * PFK > budget) budget = NW * PFK;                 // BT=8, R=1: one ring group per chunk
-        kch = (budget / (NW * PFK)) * (NW * PFK);
-        if (kch > nkb) kch = nkb;
-    }
-    a.kch = kch;
-    const size_t shm = qmm_lds_bytes(BT, R, NW, kch);
-    if (shm > 160 * 1024) return (int)hipErrorInvalidValue;
+    a.kch = 0;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)qmm_kernel<BT, R, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
+    if (NW <= 0) NW = qmm_pick_nw<BT, R, WT>(n_wg, a.K / 256);
+    const size_t shm = qmm_lds_bytes(BT, R, NW);
+    if (shm > 160 * 1024) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL((qmm_kernel<BT, R, WT>), dim3(n_wg), dim3(64 * NW), shm, st, a);
     return (int)hipGetLastError();
 }
@@ -696,9 +735,8 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
     }
     const int n_wg = a.paired ? a.seg[0].n_tiles / (R / 2) : total_tiles / R;
     const int nkb = a.K / 256;
-    int NW = (n_wg >= 768) ? 4 : 8;
-    if (g_tune_nw > 0) NW = g_tune_nw;
-    while (NW > 1 && nkb < NW) NW >>= 1;
+    int NW = 0;                                               // 0 = occupancy-aware choice per kernel variant
+    if (g_tune_nw > 0) { NW = g_tune_nw; while (NW > 1 && nkb < NW) NW >>= 1; }
     hipStream_t st = to_stream(stream);
     int wt = a.seg[0].type;                                   // uniform tile type of the launch, else 0 (mixed)
     for (int s = 1; s < a.nseg; ++s) if (a.seg[s].type != wt) wt = 0;
