@@ -15,7 +15,7 @@ def declared_symbols(header_path=HEADER_PATH):
     """Every function name declared in the public header."""
     src = open(header_path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"^\s*(?:void|int|int64_t)\s+(\w+)\s*\(", src, flags=re.M)
+    names = re.findall(r"^\s*(?:void\*?|int|int64_t|float\*)\s+(\w+)\s*\(", src, flags=re.M)
     return sorted(set(names))
 
 
@@ -76,3 +76,28 @@ _sig("mi355_qweight_repack", ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_i64])
 _sig("mi355_qmatmul", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64])
 _sig("mi355_qmatmul_fused", ctypes.c_int, [ctypes.POINTER(QmmDesc), c_i64])
 _sig("mi355_set_tuning", None, [c_i32, c_i32])
+
+
+class LlamaConfig(ctypes.Structure):
+    """mirror of `mi355_llama_config`"""
+    _fields_ = [(n, c_i32) for n in ("hidden", "n_layers", "n_heads", "n_kv_heads", "head_dim", "intermediate",
+                                     "vocab", "max_seq", "block_size", "kv_layout", "max_batch",
+                                     "max_blocks_per_seq")] + \
+               [("rms_eps", c_f32), ("rope_theta", c_f32), ("tp_rank", c_i32), ("tp_world", c_i32)]
+
+
+_sig("mi355_llama_create", c_vp, [ctypes.POINTER(LlamaConfig)])
+_sig("mi355_llama_destroy", None, [c_vp])
+_sig("mi355_llama_set_qweight", ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32])
+_sig("mi355_llama_set_qweight_tiles", ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32])
+_sig("mi355_llama_set_f32", ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_i64])
+_sig("mi355_llama_alloc_kv_cache", ctypes.c_int, [c_vp, c_i32])
+_sig("mi355_llama_kv_ptr", c_vp, [c_vp, c_i32, c_i32])
+_sig("mi355_llama_kv_bytes_per_tensor", c_i64, [c_vp])
+_sig("mi355_llama_kv_copy", ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_i64, c_i32])
+_sig("mi355_llama_forward_decode", ctypes.c_int, [c_vp] * 6 + [c_i32, c_i32, c_i32, c_vp, c_i64])
+_sig("mi355_llama_decode_begin", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
+_sig("mi355_llama_set_graph", ctypes.c_int, [c_vp, c_i32])
+_sig("mi355_llama_decode_step", ctypes.c_int, [c_vp, c_i64])
+_sig("mi355_llama_decode_read_tokens", ctypes.c_int, [c_vp, c_vp, c_i64])
+_sig("mi355_llama_logits_ptr", c_vp, [c_vp])

@@ -1,0 +1,467 @@
+// Host side of the decode hot path above the kernel C ABI (C++ because the reference's host side is compiled
+// Rust and no Rust toolchain exists here).  Mirrors, for the GGUF llama path:
+//   GGUFLLaMa::forward_inner            src/openai/models/quantized_llama.rs:424-506   (layer loop, residuals)
+//   QuantizedAttention::forward         src/openai/models/layers/attention.rs:910-1011 (qkv, rope, paged attn, wo)
+//   Mlp::forward                        src/openai/models/quantized_llama.rs:30-45
+//   CacheEngine::allocate_kv_cache      src/scheduler/cache_engine.rs:122-294,298-341
+//   LLMEngine::prepare_decode           src/openai/pipelines/inputs.rs:376-454 (slot = table[pos/bs]*bs + pos%bs)
+//   decode graph capture / replay       src/backend/graph.rs:471-661,685 ; src/openai/pipelines/pipeline.rs:2091-2135
+//   LogitsProcessor::sample_argmax      src/openai/logits_processor.rs:92-95
+// Per layer the step is 5 launches (+1 when the context is partitioned):
+//   [RMSNorm + wq|wk|wv + RoPE + bf16 + cache scatter] -> [paged attention (+reduce)] -> [wo + residual]
+//   -> [RMSNorm + w1|w3 + SiLU*mul] -> [w2 + residual]
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/mi355_vllm.h"
+
+#define HCHECK(expr)                                   \
+    do {                                               \
+        hipError_t e_ = (expr);                        \
+        if (e_ != hipSuccess) return (int)e_;          \
+    } while (0)
+#define RCHECK(expr)                                   \
+    do {                                               \
+        int r_ = (expr);                               \
+        if (r_ != 0) return r_;                        \
+    } while (0)
+
+namespace {
+
+struct QW {
+    void* tiles = nullptr;
+    int type = 0, n_rows = 0, k = 0;
+    bool owned = false;
+};
+
+struct Layer {
+    float* attn_norm = nullptr;
+    float* ffn_norm = nullptr;
+    QW w[7];   // MI355_W_WQ .. MI355_W_W3
+};
+
+struct Model {
+    mi355_llama_config cfg{};
+    std::vector<Layer> layers;
+    float* tok_embd = nullptr;      // f32 [vocab, hidden]  (dequantised at load, quantized_llama.rs:262-264)
+    float* output_norm = nullptr;
+    QW output;
+    float *cos_t = nullptr, *sin_t = nullptr;
+    // activations
+    float* xs = nullptr;            // residual stream f32 [B, hidden]
+    uint16_t* q = nullptr;          // bf16 [B, H*D]
+    uint16_t* attn = nullptr;       // bf16 [B, H*D]
+    float* h = nullptr;             // f32 [B, I]
+    float* logits = nullptr;        // f32 [B, vocab]
+    float *pa_tmp = nullptr, *pa_max = nullptr, *pa_sum = nullptr;
+    int pa_cap_partitions = 0;
+    // CacheEngine
+    void* kv_slab = nullptr;
+    std::vector<void*> kcache, vcache;
+    int num_blocks = 0;
+    // static step inputs (graph mode)
+    uint32_t* d_tokens = nullptr;
+    int64_t* d_positions = nullptr;
+    int64_t* d_slots = nullptr;
+    uint32_t* d_ctx = nullptr;
+    uint32_t* d_bt = nullptr;
+    int cur_batch = 0, cur_max_blocks = 0, cur_ctx_cap = 0;
+    // hipGraph
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    int g_batch = 0, g_max_blocks = 0, g_ctx_cap = 0;
+    int w_batch = 0, w_max_blocks = 0, w_ctx_cap = 0;     // shape of the last EAGER step (kernel attrs warmed)
+    bool use_graph = true;
+};
+
+int local_heads(const Model* m) { return m->cfg.n_heads / (m->cfg.tp_world > 0 ? m->cfg.tp_world : 1); }
+int local_kv_heads(const Model* m) {
+    const int w = m->cfg.tp_world > 0 ? m->cfg.tp_world : 1;
+    const int l = m->cfg.n_kv_heads / w;
+    return l > 0 ? l : 1;   // kv_head_shard: replicated when Hkv < W (distributed.rs:725-765)
+}
+
+// positions / slots for the NEXT step from the block table: prepare_decode restated on the device so that a
+// captured graph can run step after step without host input (inputs.rs:389-423).
+__global__ void advance_kernel(uint32_t* tokens, const uint32_t* next_tokens, int64_t* positions, int64_t* slots,
+                               uint32_t* ctx, const uint32_t* bt, int max_blocks, int block_size, int batch) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    tokens[b] = next_tokens[b];
+    const uint32_t n = ctx[b] + 1;              // sequence length after appending the sampled token
+    ctx[b] = n;
+    const int64_t pos = (int64_t)n - 1;
+    positions[b] = pos;
+    const int64_t blk = bt[(size_t)b * max_blocks + pos / block_size];
+    slots[b] = blk * block_size + pos % block_size;
+}
+
+int choose_partition(int batch, int kv_heads, int ctx_cap) {
+    if (ctx_cap <= 512) return 0;
+    int per_seq = (1024 + batch * kv_heads - 1) / (batch * kv_heads);
+    if (per_seq < 1) per_seq = 1;
+    int ps = (ctx_cap + per_seq - 1) / per_seq;
+    ps = ((ps + 63) / 64) * 64;
+    if (ps < 64) ps = 64;
+    return ps < ctx_cap ? ps : 0;
+}
+
+// one decode step over device-resident inputs (everything enqueued on `st`)
+int forward_decode(Model* m, const uint32_t* tokens, const int64_t* positions, const int64_t* slots,
+                   const uint32_t* bt, const uint32_t* ctx, int B, int max_blocks, int ctx_cap, float* logits,
+                   int64_t st) {
+    const mi355_llama_config& c = m->cfg;
+    const int H = local_heads(m), Hkv = local_kv_heads(m), D = c.head_dim, hid = c.hidden;
+    const int I = m->layers[0].w[MI355_W_W1].n_rows;
+    if (B < 1 || B > c.max_batch) return (int)hipErrorInvalidValue;
+    if ((int)m->kcache.size() != c.n_layers) return (int)hipErrorInvalidValue;
+    RCHECK(mi355_embedding_f32(m->xs, m->tok_embd, tokens, B, hid, st));
+    const int ps = choose_partition(B, Hkv, ctx_cap);
+    const float scale = 1.0f / sqrtf((float)D);
+    for (int l = 0; l < c.n_layers; ++l) {
+        Layer& L = m->layers[l];
+        mi355_qmm_desc d;
+        // --- attention_norm + wq|wk|wv + interleaved RoPE + bf16 cast + cache scatter
+        memset(&d, 0, sizeof(d));
+        d.nseg = 3;
+        const int qkv[3] = {MI355_W_WQ, MI355_W_WK, MI355_W_WV};
+        for (int s = 0; s < 3; ++s) {
+            d.w_tiles[s] = L.w[qkv[s]].tiles; d.ggml_type[s] = L.w[qkv[s]].type; d.n_rows[s] = L.w[qkv[s]].n_rows;
+        }
+        d.x = m->xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
+        d.norm_weight = L.attn_norm; d.norm_eps = c.rms_eps;
+        d.epilogue = MI355_EPI_QKV_ROPE_CACHE;
+        d.cos_table = m->cos_t; d.sin_table = m->sin_t; d.positions = positions; d.slot_mapping = slots;
+        d.q_out = m->q; d.key_cache = m->kcache[l]; d.value_cache = m->vcache[l];
+        d.num_heads = H; d.num_kv_heads = Hkv; d.head_dim = D; d.rotary_dim = D;
+        d.block_size = c.block_size; d.kv_layout = c.kv_layout;
+        RCHECK(mi355_qmatmul_fused(&d, st));
+        // --- paged attention over the cache (the new token's K/V are already in place)
+        if (ps == 0)
+            RCHECK(mi355_paged_attention_v1(m->attn, m->q, m->kcache[l], m->vcache[l], bt, ctx, B, H, Hkv, D,
+                                            c.block_size, max_blocks, ctx_cap, scale, 0.f, c.kv_layout,
+                                            MI355_DTYPE_BF16, st));
+        else
+            RCHECK(mi355_paged_attention_v2(m->attn, m->pa_sum, m->pa_max, m->pa_tmp, m->q, m->kcache[l],
+                                            m->vcache[l], bt, ctx, B, H, Hkv, D, c.block_size, max_blocks, ctx_cap,
+                                            ps, scale, 0.f, c.kv_layout, MI355_DTYPE_BF16, st));
+        // --- wo(y.to_dtype(F32)) + residual          (attention.rs:1004, quantized_llama.rs:464)
+        memset(&d, 0, sizeof(d));
+        d.nseg = 1;
+        d.w_tiles[0] = L.w[MI355_W_WO].tiles; d.ggml_type[0] = L.w[MI355_W_WO].type; d.n_rows[0] = L.w[MI355_W_WO].n_rows;
+        d.x = m->attn; d.x_dtype = MI355_DTYPE_BF16; d.ldx = H * D; d.k = H * D; d.num_tokens = B;
+        d.epilogue = MI355_EPI_RESID; d.out = m->xs; d.ldo = hid; d.residual = m->xs;
+        RCHECK(mi355_qmatmul_fused(&d, st));
+        // --- ffn_norm + w1|w3 + silu*mul              (quantized_llama.rs:33-37, 468)
+        memset(&d, 0, sizeof(d));
+        d.nseg = 2;
+        d.w_tiles[0] = L.w[MI355_W_W1].tiles; d.ggml_type[0] = L.w[MI355_W_W1].type; d.n_rows[0] = L.w[MI355_W_W1].n_rows;
+        d.w_tiles[1] = L.w[MI355_W_W3].tiles; d.ggml_type[1] = L.w[MI355_W_W3].type; d.n_rows[1] = L.w[MI355_W_W3].n_rows;
+        d.x = m->xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
+        d.norm_weight = L.ffn_norm; d.norm_eps = c.rms_eps;
+        d.epilogue = MI355_EPI_SILU_MUL; d.out = m->h; d.ldo = I;
+        RCHECK(mi355_qmatmul_fused(&d, st));
+        // --- w2 + residual                            (quantized_llama.rs:37, 470)
+        memset(&d, 0, sizeof(d));
+        d.nseg = 1;
+        d.w_tiles[0] = L.w[MI355_W_W2].tiles; d.ggml_type[0] = L.w[MI355_W_W2].type; d.n_rows[0] = L.w[MI355_W_W2].n_rows;
+        d.x = m->h; d.x_dtype = MI355_DTYPE_F32; d.ldx = I; d.k = I; d.num_tokens = B;
+        d.epilogue = MI355_EPI_RESID; d.out = m->xs; d.ldo = hid; d.residual = m->xs;
+        RCHECK(mi355_qmatmul_fused(&d, st));
+    }
+    // --- output_norm + lm_head -> logits f32       (quantized_llama.rs:500-505)
+    mi355_qmm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.nseg = 1;
+    d.w_tiles[0] = m->output.tiles; d.ggml_type[0] = m->output.type; d.n_rows[0] = m->output.n_rows;
+    d.x = m->xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
+    d.norm_weight = m->output_norm; d.norm_eps = c.rms_eps;
+    d.epilogue = MI355_EPI_STORE; d.out = logits; d.ldo = m->output.n_rows;
+    RCHECK(mi355_qmatmul_fused(&d, st));
+    return 0;
+}
+
+void free_qw(QW& w) {
+    if (w.owned && w.tiles) (void)hipFree(w.tiles);
+    w = QW{};
+}
+
+int set_qw(QW& dst, int type, const void* tiles_dev, int n_rows, int k, bool owned) {
+    free_qw(dst);
+    dst.tiles = const_cast<void*>(tiles_dev);
+    dst.type = type; dst.n_rows = n_rows; dst.k = k; dst.owned = owned;
+    return 0;
+}
+
+QW* qw_slot(Model* m, int layer, int which) {
+    if (layer < 0) return which == MI355_W_OUTPUT ? &m->output : nullptr;
+    if (layer >= m->cfg.n_layers || which < MI355_W_WQ || which > MI355_W_W3) return nullptr;
+    return &m->layers[layer].w[which];
+}
+
+void drop_graph(Model* m) {
+    if (m->gexec) { (void)hipGraphExecDestroy(m->gexec); m->gexec = nullptr; }
+    if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+}
+
+}  // namespace
+
+extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
+    if (!cfg || cfg->hidden <= 0 || cfg->n_layers <= 0 || cfg->max_batch <= 0 || cfg->head_dim <= 0 ||
+        (cfg->hidden % 256) || cfg->max_blocks_per_seq <= 0)
+        return nullptr;
+    Model* m = new Model();
+    m->cfg = *cfg;
+    if (m->cfg.tp_world <= 0) { m->cfg.tp_world = 1; m->cfg.tp_rank = 0; }
+    m->layers.resize(cfg->n_layers);
+    const int B = cfg->max_batch, H = local_heads(m), D = cfg->head_dim;
+    bool ok = true;
+    auto alloc = [&](void** p, size_t bytes) { if (hipMalloc(p, bytes) != hipSuccess) ok = false; };
+    alloc((void**)&m->xs, (size_t)B * cfg->hidden * 4);
+    alloc((void**)&m->q, (size_t)B * H * D * 2);
+    alloc((void**)&m->attn, (size_t)B * H * D * 2);
+    alloc((void**)&m->h, (size_t)B * cfg->intermediate * 4);
+    alloc((void**)&m->logits, (size_t)B * cfg->vocab * 4);
+    m->pa_cap_partitions = (cfg->max_seq + 63) / 64;
+    alloc((void**)&m->pa_tmp, (size_t)B * H * m->pa_cap_partitions * D * 4);
+    alloc((void**)&m->pa_max, (size_t)B * H * m->pa_cap_partitions * 4);
+    alloc((void**)&m->pa_sum, (size_t)B * H * m->pa_cap_partitions * 4);
+    alloc((void**)&m->d_tokens, (size_t)B * 4);
+    alloc((void**)&m->d_positions, (size_t)B * 8);
+    alloc((void**)&m->d_slots, (size_t)B * 8);
+    alloc((void**)&m->d_ctx, (size_t)B * 4);
+    alloc((void**)&m->d_bt, (size_t)B * cfg->max_blocks_per_seq * 4);
+    // RoPE tables (rotary_emb.rs:14-48): inv_freq f32, idx_theta = pos(f32) * inv_freq(f32), cos/sin in f32
+    const int half = D / 2;
+    std::vector<float> ct((size_t)cfg->max_seq * half), stb((size_t)cfg->max_seq * half);
+    for (int i = 0; i < half; ++i) {
+        const float inv = (float)(1.0 / pow((double)cfg->rope_theta, (double)(2 * i) / (double)D));
+        for (int p = 0; p < cfg->max_seq; ++p) {
+            const float th = (float)p * inv;
+            ct[(size_t)p * half + i] = (float)cos((double)th);
+            stb[(size_t)p * half + i] = (float)sin((double)th);
+        }
+    }
+    alloc((void**)&m->cos_t, ct.size() * 4);
+    alloc((void**)&m->sin_t, stb.size() * 4);
+    if (ok) {
+        ok = hipMemcpy(m->cos_t, ct.data(), ct.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(m->sin_t, stb.data(), stb.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (!ok) { mi355_llama_destroy(m); return nullptr; }
+    return m;
+}
+
+extern "C" void mi355_llama_destroy(void* mp) {
+    Model* m = static_cast<Model*>(mp);
+    if (!m) return;
+    drop_graph(m);
+    for (auto& L : m->layers) {
+        for (auto& w : L.w) free_qw(w);
+        if (L.attn_norm) (void)hipFree(L.attn_norm);
+        if (L.ffn_norm) (void)hipFree(L.ffn_norm);
+    }
+    free_qw(m->output);
+    void* ptrs[] = {m->tok_embd, m->output_norm, m->cos_t, m->sin_t, m->xs, m->q, m->attn, m->h, m->logits,
+                    m->pa_tmp, m->pa_max, m->pa_sum, m->kv_slab, m->d_tokens, m->d_positions, m->d_slots,
+                    m->d_ctx, m->d_bt};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete m;
+}
+
+extern "C" int mi355_llama_set_qweight(void* mp, int32_t layer, int32_t which, int32_t ggml_type,
+                                       const void* native_host, int32_t n_rows, int32_t k) {
+    Model* m = static_cast<Model*>(mp);
+    QW* slot = m ? qw_slot(m, layer, which) : nullptr;
+    if (!slot) return (int)hipErrorInvalidValue;
+    const int64_t n = mi355_qweight_repacked_size(ggml_type, n_rows, k);
+    if (n < 0) return (int)hipErrorInvalidValue;
+    std::vector<uint8_t> tiles((size_t)n);
+    RCHECK(mi355_qweight_repack(tiles.data(), native_host, ggml_type, n_rows, k));
+    void* dev = nullptr;
+    HCHECK(hipMalloc(&dev, (size_t)n));
+    HCHECK(hipMemcpy(dev, tiles.data(), (size_t)n, hipMemcpyHostToDevice));
+    drop_graph(m);
+    return set_qw(*slot, ggml_type, dev, n_rows, k, true);
+}
+
+extern "C" int mi355_llama_set_qweight_tiles(void* mp, int32_t layer, int32_t which, int32_t ggml_type,
+                                             const void* tiles_dev, int32_t n_rows, int32_t k) {
+    Model* m = static_cast<Model*>(mp);
+    QW* slot = m ? qw_slot(m, layer, which) : nullptr;
+    if (!slot || mi355_qweight_repacked_size(ggml_type, n_rows, k) < 0) return (int)hipErrorInvalidValue;
+    drop_graph(m);
+    return set_qw(*slot, ggml_type, tiles_dev, n_rows, k, false);
+}
+
+extern "C" int mi355_llama_set_f32(void* mp, int32_t layer, int32_t which, const float* host, int64_t n) {
+    Model* m = static_cast<Model*>(mp);
+    if (!m || !host || n <= 0) return (int)hipErrorInvalidValue;
+    float** dst = nullptr;
+    if (layer < 0) {
+        if (which == MI355_W_TOK_EMBD) dst = &m->tok_embd;
+        else if (which == MI355_W_OUTPUT_NORM) dst = &m->output_norm;
+    } else if (layer < m->cfg.n_layers) {
+        if (which == MI355_W_ATTN_NORM) dst = &m->layers[layer].attn_norm;
+        else if (which == MI355_W_FFN_NORM) dst = &m->layers[layer].ffn_norm;
+    }
+    if (!dst) return (int)hipErrorInvalidValue;
+    if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+    HCHECK(hipMalloc((void**)dst, (size_t)n * 4));
+    HCHECK(hipMemcpy(*dst, host, (size_t)n * 4, hipMemcpyHostToDevice));
+    drop_graph(m);
+    return 0;
+}
+
+// CacheEngine::allocate_kv_cache: per layer K and V, zero-initialised, layout by cfg.kv_layout.
+extern "C" int mi355_llama_alloc_kv_cache(void* mp, int32_t num_blocks) {
+    Model* m = static_cast<Model*>(mp);
+    if (!m || num_blocks <= 0) return (int)hipErrorInvalidValue;
+    const mi355_llama_config& c = m->cfg;
+    const size_t per = (size_t)num_blocks * c.block_size * local_kv_heads(m) * c.head_dim * 2;   // bf16
+    if (m->kv_slab) { (void)hipFree(m->kv_slab); m->kv_slab = nullptr; }
+    HCHECK(hipMalloc(&m->kv_slab, per * 2 * c.n_layers));
+    HCHECK(hipMemset(m->kv_slab, 0, per * 2 * c.n_layers));
+    m->kcache.resize(c.n_layers);
+    m->vcache.resize(c.n_layers);
+    for (int l = 0; l < c.n_layers; ++l) {
+        m->kcache[l] = static_cast<uint8_t*>(m->kv_slab) + per * (2 * l);
+        m->vcache[l] = static_cast<uint8_t*>(m->kv_slab) + per * (2 * l + 1);
+    }
+    m->num_blocks = num_blocks;
+    drop_graph(m);
+    return 0;
+}
+
+extern "C" int64_t mi355_llama_kv_bytes_per_tensor(void* mp);
+extern "C" void* mi355_llama_kv_ptr(void* mp, int32_t layer, int32_t which) {
+    Model* m = static_cast<Model*>(mp);
+    if (!m || layer < 0 || layer >= (int)m->kcache.size()) return nullptr;
+    return which == 0 ? m->kcache[layer] : m->vcache[layer];
+}
+
+// copy into / out of one layer's K or V tensor (src/dst may be host or device memory)
+extern "C" int mi355_llama_kv_copy(void* mp, int32_t layer, int32_t which, void* buf, int64_t bytes, int32_t to_model) {
+    Model* m = static_cast<Model*>(mp);
+    void* kv = mi355_llama_kv_ptr(mp, layer, which);
+    if (!m || !kv || !buf || bytes <= 0 || bytes > mi355_llama_kv_bytes_per_tensor(mp)) return (int)hipErrorInvalidValue;
+    HCHECK(hipDeviceSynchronize());
+    if (to_model) HCHECK(hipMemcpy(kv, buf, (size_t)bytes, hipMemcpyDefault));
+    else HCHECK(hipMemcpy(buf, kv, (size_t)bytes, hipMemcpyDefault));
+    return 0;
+}
+
+extern "C" int64_t mi355_llama_kv_bytes_per_tensor(void* mp) {
+    Model* m = static_cast<Model*>(mp);
+    if (!m) return -1;
+    return (int64_t)m->num_blocks * m->cfg.block_size * local_kv_heads(m) * m->cfg.head_dim * 2;
+}
+
+extern "C" int mi355_llama_forward_decode(void* mp, const uint32_t* tokens, const int64_t* positions,
+                                          const int64_t* slot_mapping, const uint32_t* block_tables,
+                                          const uint32_t* context_lens, int32_t batch, int32_t max_blocks,
+                                          int32_t max_context_len, float* logits, int64_t stream) {
+    Model* m = static_cast<Model*>(mp);
+    if (!m || !logits) return (int)hipErrorInvalidValue;
+    return forward_decode(m, tokens, positions, slot_mapping, block_tables, context_lens, batch, max_blocks,
+                          max_context_len, logits, stream);
+}
+
+// ---- greedy decode loop on static device buffers (graph replay) ---------------------------------------------
+// tokens_host[b]   : last token of sequence b (the one this step consumes)
+// seq_lens_host[b] : sequence length INCLUDING that token (= context_len of this step)
+// block_tables_host: [batch, max_blocks] (blocks for every step that will be run must already be reserved,
+//                    as the scheduler does ahead of the step)
+// ctx_cap          : upper bound of the context length over the steps to come (sizes the attention grid)
+extern "C" int mi355_llama_decode_begin(void* mp, const uint32_t* tokens_host, const uint32_t* seq_lens_host,
+                                        const uint32_t* block_tables_host, int32_t batch, int32_t max_blocks,
+                                        int32_t ctx_cap, int64_t stream) {
+    Model* m = static_cast<Model*>(mp);
+    if (!m || batch < 1 || batch > m->cfg.max_batch || max_blocks < 1 || max_blocks > m->cfg.max_blocks_per_seq)
+        return (int)hipErrorInvalidValue;
+    const int bs = m->cfg.block_size;
+    std::vector<int64_t> pos(batch), slot(batch);
+    for (int b = 0; b < batch; ++b) {
+        if (seq_lens_host[b] < 1) return (int)hipErrorInvalidValue;
+        pos[b] = (int64_t)seq_lens_host[b] - 1;
+        if (pos[b] / bs >= max_blocks) return (int)hipErrorInvalidValue;          // "Block table is too small"
+        slot[b] = (int64_t)block_tables_host[(size_t)b * max_blocks + pos[b] / bs] * bs + pos[b] % bs;
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HCHECK(hipMemcpyAsync(m->d_tokens, tokens_host, (size_t)batch * 4, hipMemcpyHostToDevice, st));
+    HCHECK(hipMemcpyAsync(m->d_ctx, seq_lens_host, (size_t)batch * 4, hipMemcpyHostToDevice, st));
+    HCHECK(hipMemcpyAsync(m->d_bt, block_tables_host, (size_t)batch * max_blocks * 4, hipMemcpyHostToDevice, st));
+    HCHECK(hipMemcpyAsync(m->d_positions, pos.data(), (size_t)batch * 8, hipMemcpyHostToDevice, st));
+    HCHECK(hipMemcpyAsync(m->d_slots, slot.data(), (size_t)batch * 8, hipMemcpyHostToDevice, st));
+    HCHECK(hipStreamSynchronize(st));                     // host vectors go out of scope
+    m->cur_batch = batch; m->cur_max_blocks = max_blocks; m->cur_ctx_cap = ctx_cap;
+    return 0;
+}
+
+static int record_step(Model* m, int64_t stream) {
+    const int B = m->cur_batch;
+    RCHECK(forward_decode(m, m->d_tokens, m->d_positions, m->d_slots, m->d_bt, m->d_ctx, B, m->cur_max_blocks,
+                          m->cur_ctx_cap, m->logits, stream));
+    // greedy sample, then prepare the next step's inputs on the device
+    uint32_t* next = reinterpret_cast<uint32_t*>(m->q);   // scratch: q is dead after the last layer
+    RCHECK(mi355_argmax_f32(next, m->logits, B, m->output.n_rows, stream));
+    hipLaunchKernelGGL(advance_kernel, dim3((B + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
+                       m->d_tokens, next, m->d_positions, m->d_slots, m->d_ctx, m->d_bt, m->cur_max_blocks,
+                       m->cfg.block_size, B);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mi355_llama_set_graph(void* mp, int32_t enable) {
+    Model* m = static_cast<Model*>(mp);
+    if (!m) return (int)hipErrorInvalidValue;
+    m->use_graph = enable != 0;
+    if (!m->use_graph) drop_graph(m);
+    return 0;
+}
+
+// One greedy decode step: logits -> argmax -> next-step inputs.  With graphs enabled the launch sequence is
+// captured once per (batch, max_blocks, ctx_cap) and replayed (graph.rs:471-661 captures per batch size).
+extern "C" int mi355_llama_decode_step(void* mp, int64_t stream) {
+    Model* m = static_cast<Model*>(mp);
+    if (!m || m->cur_batch < 1) return (int)hipErrorInvalidValue;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!m->use_graph || stream == 0) return record_step(m, stream);
+    if (m->w_batch != m->cur_batch || m->w_max_blocks != m->cur_max_blocks || m->w_ctx_cap != m->cur_ctx_cap) {
+        // first step of a new shape runs eagerly: lazily-set kernel attributes and occupancy queries must not
+        // happen inside a stream capture
+        m->w_batch = m->cur_batch; m->w_max_blocks = m->cur_max_blocks; m->w_ctx_cap = m->cur_ctx_cap;
+        return record_step(m, stream);
+    }
+    if (!m->gexec || m->g_batch != m->cur_batch || m->g_max_blocks != m->cur_max_blocks || m->g_ctx_cap != m->cur_ctx_cap) {
+        drop_graph(m);
+        HCHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        const int rc = record_step(m, stream);
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(st, &g);
+        if (rc != 0) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) return (int)e;
+        m->graph = g;
+        HCHECK(hipGraphInstantiate(&m->gexec, m->graph, nullptr, nullptr, 0));
+        m->g_batch = m->cur_batch; m->g_max_blocks = m->cur_max_blocks; m->g_ctx_cap = m->cur_ctx_cap;
+    }
+    HCHECK(hipGraphLaunch(m->gexec, st));
+    return 0;
+}
+
+// D2H of the tokens the last step sampled (they are the inputs of the next step)
+extern "C" int mi355_llama_decode_read_tokens(void* mp, uint32_t* host_out, int64_t stream) {
+    Model* m = static_cast<Model*>(mp);
+    if (!m || m->cur_batch < 1) return (int)hipErrorInvalidValue;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HCHECK(hipMemcpyAsync(host_out, m->d_tokens, (size_t)m->cur_batch * 4, hipMemcpyDeviceToHost, st));
+    HCHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" float* mi355_llama_logits_ptr(void* mp) {
+    Model* m = static_cast<Model*>(mp);
+    return m ? m->logits : nullptr;
+}

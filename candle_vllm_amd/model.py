@@ -1,0 +1,211 @@
+"""GGUFLLaMa on the MI355X decode path: thin ctypes wrapper over the C++ host layer (csrc/host_model.cpp),
+which mirrors src/openai/models/quantized_llama.rs (forward), src/scheduler/cache_engine.rs (KV cache) and
+src/backend/graph.rs (decode graph).  torch only supplies streams / device memory for tests and the bench."""
+import ctypes
+
+import numpy as np
+import torch
+
+from ._lib import lib, LlamaConfig
+from .ops import _check, GGML_Q4_K, GGML_Q6_K, KV_FLASH, KV_PAGED  # noqa: F401
+
+W_WQ, W_WK, W_WV, W_WO, W_W1, W_W2, W_W3, W_ATTN_NORM, W_FFN_NORM, W_TOK_EMBD, W_OUTPUT_NORM, W_OUTPUT = range(12)
+_SLOT = {"wq": W_WQ, "wk": W_WK, "wv": W_WV, "wo": W_WO, "w1": W_W1, "w2": W_W2, "w3": W_W3}
+_TILE_BYTES = {GGML_Q4_K: 2304, GGML_Q6_K: 3360}
+
+
+def q4km_type_for(name, layer, n_layers):
+    """llama.cpp Q4_K_M mixture [EXT]: output Q6_K; attn_v / ffn_down Q6_K on `use_more_bits` layers."""
+    if name == "output":
+        return GGML_Q6_K
+    if name in ("wv", "w2"):
+        n8 = n_layers // 8
+        if layer < n8 or layer >= 7 * n8 or (layer - n8) % 3 == 2:
+            return GGML_Q6_K
+    return GGML_Q4_K
+
+
+def random_tiles(ggml_type, n_rows, k, device, gen, d_scale=0.0025):
+    """Random but VALID repacked weights made directly on the GPU: random codes and sub-block scales,
+    f16 super-block scales chosen so that dequantised weights have std ~0.02 (synthetic llama weights)."""
+    nb = lib.mi355_qweight_repacked_size(ggml_type, n_rows, k)
+    t = torch.randint(0, 256, (nb,), dtype=torch.uint8, device=device, generator=gen)
+    ntile = (n_rows + 15) // 16 * (k // 256)
+    if ggml_type == GGML_Q4_K:
+        # w = d*sc*q - dmin*m with sc,m ~U[0,63], q ~U[0,15]: d = dmin*2.3 centres the weights near zero
+        d = np.array([d_scale * 0.08], np.float16).view(np.uint8)
+        dm = np.array([d_scale * 0.6], np.float16).view(np.uint8)
+        tv = t.view(ntile, 2304)
+        tv[:, 0:256:16] = int(d[0]); tv[:, 1:256:16] = int(d[1])
+        tv[:, 2:256:16] = int(dm[0]); tv[:, 3:256:16] = int(dm[1])
+    else:
+        d = np.array([d_scale * 0.005], np.float16).view(np.uint8)
+        tv = t.view(ntile, 3360)
+        tv[:, 3328:3360:2] = int(d[0]); tv[:, 3329:3360:2] = int(d[1])
+    return t
+
+
+class GGUFLLaMa:
+    def __init__(self, cfg, max_batch=1, max_blocks_per_seq=None, kv_layout=KV_FLASH, tp_rank=0, tp_world=1):
+        """cfg: oracle.llama.LlamaConfig-like (hidden, n_layers, n_heads, n_kv_heads, head_dim, intermediate, vocab,
+        rms_eps, rope_theta, max_seq, block_size)."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("GGUFLLaMa needs the MI355X: there is no CPU fallback")
+        self.cfg = cfg
+        c = LlamaConfig()
+        c.hidden, c.n_layers, c.n_heads, c.n_kv_heads = cfg.hidden, cfg.n_layers, cfg.n_heads, cfg.n_kv_heads
+        c.head_dim, c.intermediate, c.vocab = cfg.head_dim, cfg.intermediate, cfg.vocab
+        c.max_seq, c.block_size, c.kv_layout, c.max_batch = cfg.max_seq, cfg.block_size, kv_layout, max_batch
+        c.max_blocks_per_seq = max_blocks_per_seq or -(-cfg.max_seq // cfg.block_size)
+        c.rms_eps, c.rope_theta, c.tp_rank, c.tp_world = cfg.rms_eps, cfg.rope_theta, tp_rank, tp_world
+        self.c = c
+        self.kv_layout = kv_layout
+        self.max_batch = max_batch
+        self.h = lib.mi355_llama_create(ctypes.byref(c))
+        if not self.h:
+            raise RuntimeError("mi355_llama_create failed")
+        self._keep = []
+        self.weight_bytes = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.mi355_llama_destroy(self.h)
+            self.h = None
+
+    # ------------------------------------------------------------------ weights
+    def load_oracle_weights(self, W):
+        """W: dict produced by oracle.llama.make_weights (native GGUF blocks on the host)."""
+        def f32(layer, which, a):
+            a = np.ascontiguousarray(a, np.float32)
+            _check(lib.mi355_llama_set_f32(self.h, layer, which, a.ctypes.data, a.size), "set_f32")
+
+        def qw(layer, which, tw):
+            t, blocks = tw
+            b = np.ascontiguousarray(blocks)
+            _check(lib.mi355_llama_set_qweight(self.h, layer, which, t, b.ctypes.data, b.shape[0], b.shape[1] * 256),
+                   "set_qweight")
+            self.weight_bytes += b.size
+        f32(-1, W_TOK_EMBD, W["tok_embd"])
+        f32(-1, W_OUTPUT_NORM, W["output_norm"])
+        qw(-1, W_OUTPUT, W["output"])
+        for l, lw in enumerate(W["layers"]):
+            f32(l, W_ATTN_NORM, lw["attn_norm"])
+            f32(l, W_FFN_NORM, lw["ffn_norm"])
+            for name, slot in _SLOT.items():
+                qw(l, slot, lw[name])
+
+    def load_synthetic(self, seed=1235, recipe="q4_k_m"):
+        """Random-init weights of the configured architecture, generated on the GPU already in tile order."""
+        cfg = self.cfg
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(seed)
+        H, Hkv, D, hid, I = cfg.n_heads, cfg.n_kv_heads, cfg.head_dim, cfg.hidden, cfg.intermediate
+        shapes = {"wq": (H * D, hid), "wk": (Hkv * D, hid), "wv": (Hkv * D, hid), "wo": (hid, H * D),
+                  "w1": (I, hid), "w2": (hid, I), "w3": (I, hid)}
+
+        def f32(layer, which, a):
+            a = np.ascontiguousarray(a, np.float32)
+            _check(lib.mi355_llama_set_f32(self.h, layer, which, a.ctypes.data, a.size), "set_f32")
+
+        def qw(layer, which, name, n, k):
+            t = q4km_type_for(name, layer, cfg.n_layers) if recipe == "q4_k_m" else \
+                (GGML_Q6_K if name == "output" else GGML_Q4_K)
+            tiles = random_tiles(t, n, k, "cuda", gen)
+            self._keep.append(tiles)
+            _check(lib.mi355_llama_set_qweight_tiles(self.h, layer, which, t, tiles.data_ptr(), n, k), "set_tiles")
+            self.weight_bytes += (n // 16) * (k // 256) * _TILE_BYTES[t]
+        rng = np.random.default_rng(seed)
+        emb = torch.randn((cfg.vocab, hid), device="cuda", generator=gen) * 0.02
+        f32(-1, W_TOK_EMBD, emb.cpu().numpy())
+        del emb
+        f32(-1, W_OUTPUT_NORM, 1.0 + rng.normal(0, 0.02, hid))
+        qw(-1, W_OUTPUT, "output", cfg.vocab, hid)
+        for l in range(cfg.n_layers):
+            f32(l, W_ATTN_NORM, 1.0 + rng.normal(0, 0.02, hid))
+            f32(l, W_FFN_NORM, 1.0 + rng.normal(0, 0.02, hid))
+            for name, slot in _SLOT.items():
+                qw(l, slot, name, *shapes[name])
+        torch.cuda.synchronize()
+
+    # ------------------------------------------------------------------ KV cache (CacheEngine)
+    def alloc_kv_cache(self, num_blocks):
+        _check(lib.mi355_llama_alloc_kv_cache(self.h, num_blocks), "alloc_kv_cache")
+        self.num_blocks = num_blocks
+
+    def kv_shape(self):
+        c = self.cfg
+        if self.kv_layout == KV_FLASH:
+            s = (self.num_blocks, c.block_size, c.n_kv_heads, c.head_dim)
+            return s, s
+        return ((self.num_blocks, c.n_kv_heads, c.head_dim // 8, c.block_size, 8),
+                (self.num_blocks, c.n_kv_heads, c.head_dim, c.block_size))
+
+    def kv_upload(self, layer, k_bits, v_bits):
+        """k_bits/v_bits: uint16 numpy arrays (bf16 bit patterns) in the cache layout."""
+        for which, a in ((0, k_bits), (1, v_bits)):
+            a = np.ascontiguousarray(a, np.uint16)
+            _check(lib.mi355_llama_kv_copy(self.h, layer, which, a.ctypes.data, a.nbytes, 1), "kv_copy")
+
+    def kv_download(self, layer):
+        ks, vs = self.kv_shape()
+        k, v = np.empty(ks, np.uint16), np.empty(vs, np.uint16)
+        _check(lib.mi355_llama_kv_copy(self.h, layer, 0, k.ctypes.data, k.nbytes, 0), "kv_copy")
+        _check(lib.mi355_llama_kv_copy(self.h, layer, 1, v.ctypes.data, v.nbytes, 0), "kv_copy")
+        return k, v
+
+    def kv_fill_random(self, seed=7):
+        """synthetic context: random bf16 K/V (std 1) in every block, as if a prompt had been prefetched"""
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(seed)
+        n = lib.mi355_llama_kv_bytes_per_tensor(self.h) // 2
+        for l in range(self.cfg.n_layers):
+            for which in (0, 1):
+                t = torch.randn((n,), device="cuda", generator=gen).to(torch.bfloat16)
+                _check(lib.mi355_llama_kv_copy(self.h, l, which, t.data_ptr(), n * 2, 1), "kv_copy")
+
+    # ------------------------------------------------------------------ forward
+    def forward_decode(self, meta, stream=None):
+        """One eager decode step.  meta: dict from oracle.ops.prepare_decode (numpy).  Returns logits (torch f32)."""
+        dev = "cuda"
+        B = len(meta["input_ids"])
+        tok = torch.from_numpy(meta["input_ids"].astype(np.int64).astype(np.int32)).to(dev)
+        pos = torch.from_numpy(meta["positions"].astype(np.int64)).to(dev)
+        slots = torch.from_numpy(meta["slot_mapping"].astype(np.int64)).to(dev)
+        bt = torch.from_numpy(meta["block_tables"].astype(np.int64).astype(np.int32)).contiguous().to(dev)
+        ctx = torch.from_numpy(meta["context_lens"].astype(np.int64).astype(np.int32)).to(dev)
+        logits = torch.empty((B, self.cfg.vocab), dtype=torch.float32, device=dev)
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        _check(lib.mi355_llama_forward_decode(self.h, tok.data_ptr(), pos.data_ptr(), slots.data_ptr(), bt.data_ptr(),
+                                              ctx.data_ptr(), B, bt.shape[1], int(meta["max_context_len"]),
+                                              logits.data_ptr(), st), "forward_decode")
+        torch.cuda.synchronize()
+        return logits
+
+    def decode_begin(self, tokens, seq_lens, block_tables, ctx_cap, stream):
+        tokens = np.ascontiguousarray(tokens, np.uint32)
+        seq_lens = np.ascontiguousarray(seq_lens, np.uint32)
+        bt = np.ascontiguousarray(block_tables, np.uint32)
+        _check(lib.mi355_llama_decode_begin(self.h, tokens.ctypes.data, seq_lens.ctypes.data, bt.ctypes.data,
+                                            len(tokens), bt.shape[1], int(ctx_cap), stream), "decode_begin")
+        self._batch = len(tokens)
+
+    def decode_step(self, stream):
+        _check(lib.mi355_llama_decode_step(self.h, stream), "decode_step")
+
+    def read_tokens(self, stream):
+        out = np.empty(self._batch, np.uint32)
+        _check(lib.mi355_llama_decode_read_tokens(self.h, out.ctypes.data, stream), "read_tokens")
+        return out
+
+    def set_graph(self, enable):
+        _check(lib.mi355_llama_set_graph(self.h, 1 if enable else 0), "set_graph")
+
+    def logits_numpy(self, batch):
+        """logits of the last decode_step (device buffer of the model) -> numpy f32 [batch, vocab]"""
+        torch.cuda.synchronize()
+        out = np.empty((batch, self.cfg.vocab), np.float32)
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        hip.hipMemcpy.restype = ctypes.c_int
+        _check(hip.hipMemcpy(out.ctypes.data, lib.mi355_llama_logits_ptr(self.h), out.nbytes, 2), "hipMemcpy D2H")
+        return out

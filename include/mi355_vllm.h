@@ -168,6 +168,59 @@ int mi355_qmatmul_fused(const mi355_qmm_desc* desc, int64_t stream);
 /* experiment knob (0: waves per workgroup, 1: row tiles per workgroup; value 0 = heuristic) */
 void mi355_set_tuning(int32_t key, int32_t value);
 
+/* ---------------------------------------------------------------------------------------------
+ * 4. Host layer: the GGUF llama decode step (GGUFLLaMa::forward + CacheEngine + decode graph), C handles.
+ *    Mirrors src/openai/models/quantized_llama.rs:424-506, src/scheduler/cache_engine.rs:122-341,
+ *    src/backend/graph.rs:471-661,685.  Everything a Rust `DefaultPipeline::forward` arm would call.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mi355_llama_config {
+    int32_t hidden, n_layers, n_heads, n_kv_heads, head_dim, intermediate, vocab;
+    int32_t max_seq, block_size, kv_layout, max_batch, max_blocks_per_seq;
+    float rms_eps, rope_theta;
+    int32_t tp_rank, tp_world;   /* heads / kv heads / rows are the LOCAL shard when tp_world > 1 */
+} mi355_llama_config;
+/* weight slots */
+#define MI355_W_WQ 0
+#define MI355_W_WK 1
+#define MI355_W_WV 2
+#define MI355_W_WO 3
+#define MI355_W_W1 4 /* ffn_gate */
+#define MI355_W_W2 5 /* ffn_down */
+#define MI355_W_W3 6 /* ffn_up */
+#define MI355_W_ATTN_NORM 7
+#define MI355_W_FFN_NORM 8
+#define MI355_W_TOK_EMBD 9     /* layer = -1 */
+#define MI355_W_OUTPUT_NORM 10 /* layer = -1 */
+#define MI355_W_OUTPUT 11      /* layer = -1 */
+
+void* mi355_llama_create(const mi355_llama_config* cfg);
+void mi355_llama_destroy(void* model);
+/* native GGUF blocks on the HOST -> repacked + uploaded (owned by the model) */
+int mi355_llama_set_qweight(void* model, int32_t layer, int32_t which, int32_t ggml_type, const void* native_host,
+                            int32_t n_rows, int32_t k);
+/* already-repacked tiles on the DEVICE, borrowed (caller keeps them alive) */
+int mi355_llama_set_qweight_tiles(void* model, int32_t layer, int32_t which, int32_t ggml_type,
+                                  const void* tiles_dev, int32_t n_rows, int32_t k);
+int mi355_llama_set_f32(void* model, int32_t layer, int32_t which, const float* host, int64_t n);
+int mi355_llama_alloc_kv_cache(void* model, int32_t num_blocks);
+void* mi355_llama_kv_ptr(void* model, int32_t layer, int32_t which /* 0 = K, 1 = V */);
+int64_t mi355_llama_kv_bytes_per_tensor(void* model);
+/* copy a layer's K or V tensor from (to_model != 0) / to a host or device buffer */
+int mi355_llama_kv_copy(void* model, int32_t layer, int32_t which, void* buf, int64_t bytes, int32_t to_model);
+/* one eager decode step over DEVICE inputs (InputMetadata fields as raw pointers); logits f32 [batch, vocab] */
+int mi355_llama_forward_decode(void* model, const uint32_t* tokens, const int64_t* positions,
+                               const int64_t* slot_mapping, const uint32_t* block_tables,
+                               const uint32_t* context_lens, int32_t batch, int32_t max_blocks,
+                               int32_t max_context_len, float* logits, int64_t stream);
+/* greedy decode loop on static device buffers; the step is replayed from a hipGraph when stream != 0 */
+int mi355_llama_decode_begin(void* model, const uint32_t* tokens_host, const uint32_t* seq_lens_host,
+                             const uint32_t* block_tables_host, int32_t batch, int32_t max_blocks, int32_t ctx_cap,
+                             int64_t stream);
+int mi355_llama_set_graph(void* model, int32_t enable);
+int mi355_llama_decode_step(void* model, int64_t stream);
+int mi355_llama_decode_read_tokens(void* model, uint32_t* host_out, int64_t stream);
+float* mi355_llama_logits_ptr(void* model);
+
 #ifdef __cplusplus
 }
 #endif

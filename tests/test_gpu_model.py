@@ -1,0 +1,99 @@
+"""GPU end-to-end parity: the C++ GGUFLLaMa decode step (eager and hipGraph replay) vs the numpy oracle on a
+tiny synthetic llama (same seeded weights), logits within the BASELINE tolerance (1e-3 relative), greedy tokens
+identical, KV cache contents equal to 1 bf16 ulp; plus the committed golden logits."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import llama                  # noqa: E402
+from oracle import ops as O               # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "tiny_llama_logits.json")
+
+
+def _setup(lib, flash=True):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from candle_vllm_amd import model as M
+    cfg = llama.LlamaConfig.tiny()
+    W = llama.make_weights(cfg, seed=1234)
+    orc = llama.OracleLlama(cfg, W, flash_layout=flash)
+    rng = np.random.default_rng(7)
+    seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 19)], "block_table": [3, 7]},
+            {"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 5)], "block_table": [1]}]
+    cache = orc.new_cache(16)
+    lg = orc.forward(O.prepare_prompt(seqs, cfg.block_size), cache, is_prefill=True)
+    for s, row in zip(seqs, lg):
+        s["tokens"].append(int(row.argmax()))
+    gm = M.GGUFLLaMa(cfg, max_batch=4, kv_layout=M.KV_FLASH if flash else M.KV_PAGED)
+    gm.load_oracle_weights(W)
+    gm.alloc_kv_cache(16)
+    for l, (kc, vc) in enumerate(cache):                 # the prefix KV the oracle prefill produced
+        gm.kv_upload(l, kc, vc)
+    return cfg, orc, gm, seqs, cache
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+@pytest.mark.parametrize("flash", [True, False])
+def test_decode_step_logits_match_oracle_and_golden(lib, flash):
+    cfg, orc, gm, seqs, cache = _setup(lib, flash)
+    meta = O.prepare_decode(seqs, cfg.block_size)
+    ref = orc.forward(meta, cache)
+    got = gm.forward_decode(meta).cpu().numpy()
+    assert _rel(got, ref) < 1e-3, _rel(got, ref)          # BASELINE.json: within 1e-3 relative
+    assert [int(r.argmax()) for r in got] == [int(r.argmax()) for r in ref]
+    gold = json.load(open(GOLDEN))
+    assert gold["next_tokens"] == [int(r.argmax()) for r in got]
+    assert np.abs(np.asarray(gold["logits_head"], np.float32) - got[:, :16]).max() < 1e-3 * np.abs(ref).max()
+    for l, (kc, vc) in enumerate(cache):                  # the step wrote this token's K/V at its slot
+        gk, gv = gm.kv_download(l)
+        dk = np.abs(O.bf16_bits_to_f32(gk) - O.bf16_bits_to_f32(kc)).max()
+        dv = np.abs(O.bf16_bits_to_f32(gv) - O.bf16_bits_to_f32(vc)).max()
+        assert dk <= 2 ** -6 * np.abs(O.bf16_bits_to_f32(kc)).max() and dv <= 2 ** -6 * np.abs(O.bf16_bits_to_f32(vc)).max()
+
+
+def test_greedy_decode_loop_graph_equals_eager_equals_oracle(lib):
+    """8 greedy steps: oracle tokens == eager C++ loop == hipGraph replay (device-side input advance)."""
+    cfg, orc, gm, seqs, cache = _setup(lib, True)
+    steps = 8
+    # block tables with room for the whole run (the scheduler reserves blocks ahead of the step)
+    for s, extra in zip(seqs, ([9], [5])):
+        s["block_table"] = s["block_table"] + extra
+    bt = np.zeros((2, 3), np.uint32)
+    for i, s in enumerate(seqs):
+        bt[i, :len(s["block_table"])] = s["block_table"]
+    toks0 = [s["tokens"][-1] for s in seqs]
+    lens0 = [len(s["tokens"]) for s in seqs]
+    # oracle
+    o_seqs = [{"tokens": list(s["tokens"]), "block_table": list(s["block_table"])} for s in seqs]
+    o_cache = [(k.copy(), v.copy()) for k, v in cache]
+    want = []
+    for _ in range(steps):
+        lg = orc.forward(O.prepare_decode(o_seqs, cfg.block_size), o_cache)
+        nxt = [int(r.argmax()) for r in lg]
+        want.append(nxt)
+        for s, t in zip(o_seqs, nxt):
+            s["tokens"].append(t)
+    stream = torch.cuda.Stream()
+    for use_graph in (False, True):
+        for l, (kc, vc) in enumerate(cache):
+            gm.kv_upload(l, kc, vc)
+        gm.set_graph(use_graph)
+        gm.decode_begin(toks0, lens0, bt, ctx_cap=max(lens0) + steps, stream=stream.cuda_stream)
+        got = []
+        for _ in range(steps):
+            gm.decode_step(stream.cuda_stream)
+            got.append([int(t) for t in gm.read_tokens(stream.cuda_stream)])
+        assert got == want, (use_graph, got, want)
+    last = gm.logits_numpy(2)
+    ref_last = orc.forward(O.prepare_decode([{"tokens": s["tokens"][:-1], "block_table": s["block_table"]} for s in o_seqs],
+                                            cfg.block_size), [(k.copy(), v.copy()) for k, v in o_cache])
+    assert _rel(last, ref_last) < 1e-3
