@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""bench.py -- Llama-3-8B Q4_K_M greedy decode on MI355X through the C-ABI decode path.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+  metric/unit : BASELINE.json's metric -- decode tokens/s (greedy, batch 1, Llama-3-8B Q4_K GGUF shapes)
+  a "step"    : one decode step of the whole model over the batch (1 token per sequence)
+  workload    : BASELINE.json configs[1] -- "Llama-3-8B Q4_K GGUF, batch=1, 1xMI355X"; prompt context 4096 tokens
+                already in the paged KV cache (README protocol "input 4k"), then K decode steps
+  value       : tokens/s over the timed K steps, inputs/weights/KV resident in HBM, max over ranks
+  N > 1       : tensor parallel over N GPUs (one process per GPU, RCCL all-reduce / all-gather), same batch ->
+                "strong" scaling
+Extra objects: `roofline` (dominant kernel, HIP-event timed inside this script), `cpu_baseline` (C port of the
+reference CPU arithmetic on the host cores), `step` (whole-step algorithmic bytes and achieved GB/s).
+Synthetic data: random-init weights of the named architecture in Q4_K_M mixture, random KV prefix.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+
+
+def llama3_8b():
+    from oracle.llama import LlamaConfig   # dataclass of dims only (no arithmetic)
+    return LlamaConfig.llama3_8b()
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--ctx", type=int, default=4096, help="prompt tokens already in the KV cache")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--layers", type=int, default=0, help="debug only: fewer layers (result marked invalid)")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, steps, ctx=64):
+    """C port of the reference's CPU arithmetic (Q8_K activations, integer dots, OpenMP over rows) on the host
+    cores: `steps` decode steps of the same model shape at a SHORT context (bounded sample)."""
+    from oracle import cref
+    from candle_vllm_amd.model import q4km_type_for
+    cref.build()
+    names = ["wq", "wk", "wv", "wo", "w1", "w2", "w3"]
+    types = [q4km_type_for(n, l, cfg.n_layers) for l in range(cfg.n_layers) for n in names]
+    types.append(q4km_type_for("output", 0, cfg.n_layers))
+    t0 = time.time()
+    m = cref.CLlama(cfg, W=None, types=types, seed=1235)
+    nblk = -(-(ctx + steps + 1) // cfg.block_size) + 1
+    rng = np.random.default_rng(3)
+    shape = (nblk, cfg.block_size, cfg.n_kv_heads, cfg.head_dim)
+    cache = [((rng.standard_normal(shape).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16),
+              (rng.standard_normal(shape).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16))
+             for _ in range(cfg.n_layers)]
+    setup = time.time() - t0
+    table = list(range(nblk))
+    toks = [int(t) for t in rng.integers(0, cfg.vocab, ctx)]
+    from oracle import ops as O
+    times = []
+    for _ in range(steps):
+        meta = O.prepare_decode([{"tokens": toks, "block_table": table}], cfg.block_size)
+        t1 = time.time()
+        lg = m.decode(meta, cache, o2=True)
+        times.append(time.time() - t1)
+        toks.append(int(lg[0].argmax()))
+    best = min(times)
+    return {"value": round(1.0 / best, 4), "unit": "tokens/s", "cores": int(cref.lib().orc_num_threads()),
+            "kind": "port",
+            "sample": f"{steps} decode steps, batch 1, ctx {ctx}, full {cfg.n_layers}-layer Q4_K_M model, "
+                      f"candle-CPU-style Q8_K integer dot (oracle/oracle.c, OpenMP), best step; setup {setup:.1f}s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+    if rank == 0 or not os.path.exists(ge.LIB):
+        pass
+    from candle_vllm_amd import model as M
+
+    cfg = llama3_8b()
+    invalid = None
+    if args.layers:
+        cfg.n_layers = args.layers
+        invalid = "debug run with fewer layers"
+    B, K, Wm = args.batch, args.steps, args.warmup
+    blocks_per_seq = -(-(args.ctx + K + Wm + 2) // cfg.block_size)
+    num_blocks = B * blocks_per_seq + 8
+    gm = M.GGUFLLaMa(cfg, max_batch=B, max_blocks_per_seq=blocks_per_seq, kv_layout=M.KV_FLASH,
+                     tp_rank=rank, tp_world=world)
+    if world > 1:
+        gm.init_comm(dist)
+    gm.load_synthetic(seed=1235, recipe="q4_k_m")
+    gm.alloc_kv_cache(num_blocks)
+    gm.kv_fill_random(seed=7 + rank)
+
+    # block tables: physical blocks in shuffled order (stresses the gather), identical on every rank
+    rng = np.random.default_rng(1235)
+    perm = rng.permutation(num_blocks - 1)[: B * blocks_per_seq] + 1
+    bt = perm.reshape(B, blocks_per_seq).astype(np.uint32)
+    tokens = rng.integers(0, cfg.vocab, B).astype(np.uint32)
+    seq_lens = np.full(B, args.ctx + 1, np.uint32)            # prompt + the first generated token
+    stream = torch.cuda.Stream()
+    st = stream.cuda_stream
+    gm.set_graph(not args.no_graph and world == 1)
+    ctx_cap = args.ctx + K + Wm + 2
+    gm.decode_begin(tokens, seq_lens, bt, ctx_cap=ctx_cap, stream=st)
+
+    def run(n):
+        for _ in range(n):
+            gm.decode_step(st)
+            gm.read_tokens(st)                                # greedy sample -> host every step, as the engine does
+
+    run(Wm)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(K)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    tok_s = B * K / dt
+
+    # ---- algorithmic bytes of one step: every weight byte once + live KV once (+ the write)
+    mean_ctx = args.ctx + 1 + Wm + (K - 1) / 2.0
+    kv_per_tok = 2 * cfg.n_layers * cfg.n_kv_heads * cfg.head_dim * 2
+    step_bytes = gm.weight_bytes_global + B * (mean_ctx + 1) * kv_per_tok
+    achieved = step_bytes * (K / dt) / 1e9
+
+    out = {
+        "metric": "decode tokens/s (greedy), Llama-3-8B Q4_K GGUF",
+        "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": round(1e3 * dt / K, 4), "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+        "dtype": "q4_k/q6_k weights, f32 activations, bf16 KV+attention", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: Llama-3-8B Q4_K_M GGUF shapes, greedy decode, "
+                               f"batch={B}, prompt ctx {args.ctx} in paged KV (block 64), {K} decode steps",
+                   "batch": B, "ctx_start": args.ctx + 1 + Wm, "ctx_end": args.ctx + Wm + K,
+                   "parallelism": f"tp{world}", "graph": bool(not args.no_graph and world == 1),
+                   "kv_layout": "flash [NB,64,Hkv,128] bf16"},
+        "step": {"algorithmic_bytes": int(step_bytes), "achieved_GBs": round(achieved, 1),
+                 "frac_of_8TBs": round(achieved / HBM_PEAK_GBS, 4), "frac_of_6.29TBs_copy": round(achieved / 6290.0, 4),
+                 "roofline_tok_s_at_8TBs": round(B * HBM_PEAK_GBS * 1e9 / step_bytes, 1)},
+    }
+    if invalid:
+        out["invalid"] = invalid
+    if rank == 0:
+        out["roofline"] = gm.dominant_kernel_roofline(stream, HBM_PEAK_GBS)
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps)
+            except Exception as e:                            # the baseline must never sink the GPU number
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,3 +101,6 @@ _sig("mi355_llama_set_graph", ctypes.c_int, [c_vp, c_i32])
 _sig("mi355_llama_decode_step", ctypes.c_int, [c_vp, c_i64])
 _sig("mi355_llama_decode_read_tokens", ctypes.c_int, [c_vp, c_vp, c_i64])
 _sig("mi355_llama_logits_ptr", c_vp, [c_vp])
+_sig("mi355_comm_unique_id", ctypes.c_int, [c_vp])
+_sig("mi355_llama_init_comm", ctypes.c_int, [c_vp, c_vp])
+_sig("mi355_llama_run_part", ctypes.c_int, [c_vp, c_i32, c_i32, c_i64])

@@ -11,6 +11,7 @@
 //   [RMSNorm + wq|wk|wv + RoPE + bf16 + cache scatter] -> [paged attention (+reduce)] -> [wo + residual]
 //   -> [RMSNorm + w1|w3 + SiLU*mul] -> [w2 + residual]
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -30,6 +31,47 @@
     } while (0)
 
 namespace {
+
+// ---- RCCL through dlopen: the communicator lives beside the decode step (one process per GPU; the reference
+// creates one cudarc nccl `Comm` per process -- src/openai/pipelines/pipeline.rs:805-812, distributed.rs:547-654).
+// The library is resolved at run time so the .so still loads on a CPU-only box.
+struct NcclId { char internal[128]; };
+typedef int (*nccl_get_id_t)(NcclId*);
+typedef int (*nccl_init_rank_t)(void**, int, NcclId, int);
+typedef int (*nccl_allreduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_allgather_t)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*nccl_destroy_t)(void*);
+struct Rccl {
+    void* h = nullptr;
+    nccl_get_id_t get_id = nullptr;
+    nccl_init_rank_t init_rank = nullptr;
+    nccl_allreduce_t all_reduce = nullptr;
+    nccl_allgather_t all_gather = nullptr;
+    nccl_destroy_t destroy = nullptr;
+};
+Rccl g_rccl;
+bool rccl_load() {
+    if (g_rccl.h) return true;
+    const char* env = getenv("MI355_RCCL_PATH");
+    const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* h = nullptr;
+    for (int pass = 0; pass < 2 && !h; ++pass)            // pass 0: only a copy that is already loaded (torch's)
+        for (const char* n : names) {
+            if (!n) continue;
+            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+            if (h) break;
+        }
+    if (!h) return false;
+    g_rccl.get_id = (nccl_get_id_t)dlsym(h, "ncclGetUniqueId");
+    g_rccl.init_rank = (nccl_init_rank_t)dlsym(h, "ncclCommInitRank");
+    g_rccl.all_reduce = (nccl_allreduce_t)dlsym(h, "ncclAllReduce");
+    g_rccl.all_gather = (nccl_allgather_t)dlsym(h, "ncclAllGather");
+    g_rccl.destroy = (nccl_destroy_t)dlsym(h, "ncclCommDestroy");
+    if (!g_rccl.get_id || !g_rccl.init_rank || !g_rccl.all_reduce || !g_rccl.all_gather) return false;
+    g_rccl.h = h;
+    return true;
+}
+enum { NCCL_FLOAT32 = 7, NCCL_SUM = 0 };
 
 struct QW {
     void* tiles = nullptr;
@@ -75,6 +117,10 @@ struct Model {
     int g_batch = 0, g_max_blocks = 0, g_ctx_cap = 0;
     int w_batch = 0, w_max_blocks = 0, w_ctx_cap = 0;     // shape of the last EAGER step (kernel attrs warmed)
     bool use_graph = true;
+    // tensor parallel
+    void* comm = nullptr;           // ncclComm_t
+    float* logits_local = nullptr;  // [B, vocab/W]
+    float* logits_gather = nullptr; // [W, B, vocab/W]
 };
 
 int local_heads(const Model* m) { return m->cfg.n_heads / (m->cfg.tp_world > 0 ? m->cfg.tp_world : 1); }
@@ -109,23 +155,62 @@ int choose_partition(int batch, int kv_heads, int ctx_cap) {
     return ps < ctx_cap ? ps : 0;
 }
 
-// one decode step over device-resident inputs (everything enqueued on `st`)
-int forward_decode(Model* m, const uint32_t* tokens, const int64_t* positions, const int64_t* slots,
-                   const uint32_t* bt, const uint32_t* ctx, int B, int max_blocks, int ctx_cap, float* logits,
-                   int64_t st) {
+struct StepIn {
+    const uint32_t* tokens; const int64_t* positions; const int64_t* slots; const uint32_t* bt; const uint32_t* ctx;
+    int B, max_blocks, ctx_cap;
+};
+
+// [W, B, Vl] -> [B, W*Vl]   (VocabParallelLinear: all-gather then un-interleave, distributed.rs:1637-1663)
+__global__ void gather_transpose_kernel(float* out, const float* in, int W, int B, int Vl) {
+    const int64_t n = (int64_t)W * B * Vl;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % Vl), b = (int)((i / Vl) % B), w = (int)(i / ((int64_t)Vl * B));
+        out[((int64_t)b * W + w) * Vl + v] = in[i];
+    }
+}
+
+int all_reduce_xs(Model* m, int B, int64_t st) {
+    if (m->cfg.tp_world <= 1) return 0;
+    if (!m->comm) return (int)hipErrorNotInitialized;
+    // C1/C2: all-reduce(sum) of [B, hidden] after o_proj / down_proj (distributed.rs:696-711).  The reference
+    // sends bf16 (attention.rs:1005-1009); we keep the f32 residual stream on the wire (decode messages are
+    // latency-bound: 16 KiB at B=1).
+    return g_rccl.all_reduce(m->xs, m->xs, (size_t)B * m->cfg.hidden, NCCL_FLOAT32, NCCL_SUM, m->comm,
+                             reinterpret_cast<hipStream_t>(st)) == 0 ? 0 : (int)hipErrorUnknown;
+}
+
+enum { PART_QKV = 0, PART_ATTN = 1, PART_WO = 2, PART_GATEUP = 3, PART_DOWN = 4, PART_HEAD = 5, PART_EMBED = 6 };
+
+// one launch group of the step; `l` = layer (ignored for EMBED / HEAD)
+int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t st) {
     const mi355_llama_config& c = m->cfg;
-    const int H = local_heads(m), Hkv = local_kv_heads(m), D = c.head_dim, hid = c.hidden;
-    const int I = m->layers[0].w[MI355_W_W1].n_rows;
-    if (B < 1 || B > c.max_batch) return (int)hipErrorInvalidValue;
-    if ((int)m->kcache.size() != c.n_layers) return (int)hipErrorInvalidValue;
-    RCHECK(mi355_embedding_f32(m->xs, m->tok_embd, tokens, B, hid, st));
-    const int ps = choose_partition(B, Hkv, ctx_cap);
-    const float scale = 1.0f / sqrtf((float)D);
-    for (int l = 0; l < c.n_layers; ++l) {
-        Layer& L = m->layers[l];
-        mi355_qmm_desc d;
+    const int H = local_heads(m), Hkv = local_kv_heads(m), D = c.head_dim, hid = c.hidden, B = in.B;
+    const bool lead = c.tp_rank == 0;                              // the rank that carries the residual into the sum
+    mi355_qmm_desc d;
+    memset(&d, 0, sizeof(d));
+    if (part == PART_EMBED) return mi355_embedding_f32(m->xs, m->tok_embd, in.tokens, B, hid, st);
+    if (part == PART_HEAD) {
+        // --- output_norm + lm_head -> logits f32       (quantized_llama.rs:500-505; vocab-parallel under TP)
+        d.nseg = 1;
+        d.w_tiles[0] = m->output.tiles; d.ggml_type[0] = m->output.type; d.n_rows[0] = m->output.n_rows;
+        d.x = m->xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
+        d.norm_weight = m->output_norm; d.norm_eps = c.rms_eps;
+        d.epilogue = MI355_EPI_STORE; d.ldo = m->output.n_rows;
+        if (c.tp_world <= 1) { d.out = logits; return mi355_qmatmul_fused(&d, st); }
+        d.out = m->logits_local;
+        RCHECK(mi355_qmatmul_fused(&d, st));
+        if (!m->comm) return (int)hipErrorNotInitialized;
+        const size_t cnt = (size_t)B * m->output.n_rows;
+        if (g_rccl.all_gather(m->logits_local, m->logits_gather, cnt, NCCL_FLOAT32, m->comm,
+                              reinterpret_cast<hipStream_t>(st)) != 0) return (int)hipErrorUnknown;
+        hipLaunchKernelGGL(gather_transpose_kernel, dim3(512), dim3(256), 0, reinterpret_cast<hipStream_t>(st), logits,
+                           m->logits_gather, c.tp_world, B, m->output.n_rows);
+        return (int)hipGetLastError();
+    }
+    Layer& L = m->layers[l];
+    const int I = L.w[MI355_W_W1].n_rows;
+    if (part == PART_QKV) {
         // --- attention_norm + wq|wk|wv + interleaved RoPE + bf16 cast + cache scatter
-        memset(&d, 0, sizeof(d));
         d.nseg = 3;
         const int qkv[3] = {MI355_W_WQ, MI355_W_WK, MI355_W_WV};
         for (int s = 0; s < 3; ++s) {
@@ -134,54 +219,67 @@ int forward_decode(Model* m, const uint32_t* tokens, const int64_t* positions, c
         d.x = m->xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
         d.norm_weight = L.attn_norm; d.norm_eps = c.rms_eps;
         d.epilogue = MI355_EPI_QKV_ROPE_CACHE;
-        d.cos_table = m->cos_t; d.sin_table = m->sin_t; d.positions = positions; d.slot_mapping = slots;
+        d.cos_table = m->cos_t; d.sin_table = m->sin_t; d.positions = in.positions; d.slot_mapping = in.slots;
         d.q_out = m->q; d.key_cache = m->kcache[l]; d.value_cache = m->vcache[l];
         d.num_heads = H; d.num_kv_heads = Hkv; d.head_dim = D; d.rotary_dim = D;
         d.block_size = c.block_size; d.kv_layout = c.kv_layout;
-        RCHECK(mi355_qmatmul_fused(&d, st));
+        return mi355_qmatmul_fused(&d, st);
+    }
+    if (part == PART_ATTN) {
         // --- paged attention over the cache (the new token's K/V are already in place)
+        const int ps = choose_partition(B, Hkv, in.ctx_cap);
+        const float scale = 1.0f / sqrtf((float)D);
         if (ps == 0)
-            RCHECK(mi355_paged_attention_v1(m->attn, m->q, m->kcache[l], m->vcache[l], bt, ctx, B, H, Hkv, D,
-                                            c.block_size, max_blocks, ctx_cap, scale, 0.f, c.kv_layout,
-                                            MI355_DTYPE_BF16, st));
-        else
-            RCHECK(mi355_paged_attention_v2(m->attn, m->pa_sum, m->pa_max, m->pa_tmp, m->q, m->kcache[l],
-                                            m->vcache[l], bt, ctx, B, H, Hkv, D, c.block_size, max_blocks, ctx_cap,
-                                            ps, scale, 0.f, c.kv_layout, MI355_DTYPE_BF16, st));
-        // --- wo(y.to_dtype(F32)) + residual          (attention.rs:1004, quantized_llama.rs:464)
-        memset(&d, 0, sizeof(d));
+            return mi355_paged_attention_v1(m->attn, m->q, m->kcache[l], m->vcache[l], in.bt, in.ctx, B, H, Hkv, D,
+                                            c.block_size, in.max_blocks, in.ctx_cap, scale, 0.f, c.kv_layout,
+                                            MI355_DTYPE_BF16, st);
+        return mi355_paged_attention_v2(m->attn, m->pa_sum, m->pa_max, m->pa_tmp, m->q, m->kcache[l], m->vcache[l],
+                                        in.bt, in.ctx, B, H, Hkv, D, c.block_size, in.max_blocks, in.ctx_cap, ps,
+                                        scale, 0.f, c.kv_layout, MI355_DTYPE_BF16, st);
+    }
+    if (part == PART_WO) {
+        // --- wo(y.to_dtype(F32)) + residual (+ all-reduce)   (attention.rs:1004-1009, quantized_llama.rs:464)
         d.nseg = 1;
         d.w_tiles[0] = L.w[MI355_W_WO].tiles; d.ggml_type[0] = L.w[MI355_W_WO].type; d.n_rows[0] = L.w[MI355_W_WO].n_rows;
         d.x = m->attn; d.x_dtype = MI355_DTYPE_BF16; d.ldx = H * D; d.k = H * D; d.num_tokens = B;
-        d.epilogue = MI355_EPI_RESID; d.out = m->xs; d.ldo = hid; d.residual = m->xs;
+        d.epilogue = lead ? MI355_EPI_RESID : MI355_EPI_STORE; d.out = m->xs; d.ldo = hid; d.residual = m->xs;
         RCHECK(mi355_qmatmul_fused(&d, st));
+        return all_reduce_xs(m, B, st);
+    }
+    if (part == PART_GATEUP) {
         // --- ffn_norm + w1|w3 + silu*mul              (quantized_llama.rs:33-37, 468)
-        memset(&d, 0, sizeof(d));
         d.nseg = 2;
         d.w_tiles[0] = L.w[MI355_W_W1].tiles; d.ggml_type[0] = L.w[MI355_W_W1].type; d.n_rows[0] = L.w[MI355_W_W1].n_rows;
         d.w_tiles[1] = L.w[MI355_W_W3].tiles; d.ggml_type[1] = L.w[MI355_W_W3].type; d.n_rows[1] = L.w[MI355_W_W3].n_rows;
         d.x = m->xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
         d.norm_weight = L.ffn_norm; d.norm_eps = c.rms_eps;
         d.epilogue = MI355_EPI_SILU_MUL; d.out = m->h; d.ldo = I;
-        RCHECK(mi355_qmatmul_fused(&d, st));
-        // --- w2 + residual                            (quantized_llama.rs:37, 470)
-        memset(&d, 0, sizeof(d));
+        return mi355_qmatmul_fused(&d, st);
+    }
+    if (part == PART_DOWN) {
+        // --- w2 + residual (+ all-reduce)             (quantized_llama.rs:37-42, 470)
         d.nseg = 1;
         d.w_tiles[0] = L.w[MI355_W_W2].tiles; d.ggml_type[0] = L.w[MI355_W_W2].type; d.n_rows[0] = L.w[MI355_W_W2].n_rows;
         d.x = m->h; d.x_dtype = MI355_DTYPE_F32; d.ldx = I; d.k = I; d.num_tokens = B;
-        d.epilogue = MI355_EPI_RESID; d.out = m->xs; d.ldo = hid; d.residual = m->xs;
+        d.epilogue = lead ? MI355_EPI_RESID : MI355_EPI_STORE; d.out = m->xs; d.ldo = hid; d.residual = m->xs;
         RCHECK(mi355_qmatmul_fused(&d, st));
+        return all_reduce_xs(m, B, st);
     }
-    // --- output_norm + lm_head -> logits f32       (quantized_llama.rs:500-505)
-    mi355_qmm_desc d;
-    memset(&d, 0, sizeof(d));
-    d.nseg = 1;
-    d.w_tiles[0] = m->output.tiles; d.ggml_type[0] = m->output.type; d.n_rows[0] = m->output.n_rows;
-    d.x = m->xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
-    d.norm_weight = m->output_norm; d.norm_eps = c.rms_eps;
-    d.epilogue = MI355_EPI_STORE; d.out = logits; d.ldo = m->output.n_rows;
-    RCHECK(mi355_qmatmul_fused(&d, st));
-    return 0;
+    return (int)hipErrorInvalidValue;
+}
+
+// one decode step over device-resident inputs (everything enqueued on `st`)
+int forward_decode(Model* m, const uint32_t* tokens, const int64_t* positions, const int64_t* slots,
+                   const uint32_t* bt, const uint32_t* ctx, int B, int max_blocks, int ctx_cap, float* logits,
+                   int64_t st) {
+    const mi355_llama_config& c = m->cfg;
+    if (B < 1 || B > c.max_batch) return (int)hipErrorInvalidValue;
+    if ((int)m->kcache.size() != c.n_layers) return (int)hipErrorInvalidValue;
+    const StepIn in{tokens, positions, slots, bt, ctx, B, max_blocks, ctx_cap};
+    RCHECK(run_part(m, 0, PART_EMBED, in, logits, st));
+    for (int l = 0; l < c.n_layers; ++l)
+        for (int part = PART_QKV; part <= PART_DOWN; ++part) RCHECK(run_part(m, l, part, in, logits, st));
+    return run_part(m, 0, PART_HEAD, in, logits, st);
 }
 
 void free_qw(QW& w) {
@@ -225,6 +323,10 @@ extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
     alloc((void**)&m->attn, (size_t)B * H * D * 2);
     alloc((void**)&m->h, (size_t)B * cfg->intermediate * 4);
     alloc((void**)&m->logits, (size_t)B * cfg->vocab * 4);
+    if (m->cfg.tp_world > 1) {
+        alloc((void**)&m->logits_local, (size_t)B * cfg->vocab * 4 / m->cfg.tp_world + 64);
+        alloc((void**)&m->logits_gather, (size_t)B * cfg->vocab * 4 + 64 * m->cfg.tp_world);
+    }
     m->pa_cap_partitions = (cfg->max_seq + 63) / 64;
     alloc((void**)&m->pa_tmp, (size_t)B * H * m->pa_cap_partitions * D * 4);
     alloc((void**)&m->pa_max, (size_t)B * H * m->pa_cap_partitions * 4);
@@ -267,7 +369,8 @@ extern "C" void mi355_llama_destroy(void* mp) {
     free_qw(m->output);
     void* ptrs[] = {m->tok_embd, m->output_norm, m->cos_t, m->sin_t, m->xs, m->q, m->attn, m->h, m->logits,
                     m->pa_tmp, m->pa_max, m->pa_sum, m->kv_slab, m->d_tokens, m->d_positions, m->d_slots,
-                    m->d_ctx, m->d_bt};
+                    m->d_ctx, m->d_bt, m->logits_local, m->logits_gather};
+    if (m->comm && g_rccl.destroy) (void)g_rccl.destroy(m->comm);
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete m;
 }
@@ -428,7 +531,7 @@ extern "C" int mi355_llama_decode_step(void* mp, int64_t stream) {
     Model* m = static_cast<Model*>(mp);
     if (!m || m->cur_batch < 1) return (int)hipErrorInvalidValue;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (!m->use_graph || stream == 0) return record_step(m, stream);
+    if (!m->use_graph || stream == 0 || m->cfg.tp_world > 1) return record_step(m, stream);   // TP: eager (RCCL in-stream)
     if (m->w_batch != m->cur_batch || m->w_max_blocks != m->cur_max_blocks || m->w_ctx_cap != m->cur_ctx_cap) {
         // first step of a new shape runs eagerly: lazily-set kernel attributes and occupancy queries must not
         // happen inside a stream capture
@@ -464,4 +567,28 @@ extern "C" int mi355_llama_decode_read_tokens(void* mp, uint32_t* host_out, int6
 extern "C" float* mi355_llama_logits_ptr(void* mp) {
     Model* m = static_cast<Model*>(mp);
     return m ? m->logits : nullptr;
+}
+
+// ---- tensor-parallel communicator -----------------------------------------------------------------------------
+// rank 0 makes the id (ncclGetUniqueId), the launcher ships the 128 bytes to the other ranks (the reference
+// passes it through the DAEMON_PAYLOAD env / TCP, communicator.rs:761-769,877), every rank calls init.
+extern "C" int mi355_comm_unique_id(void* out128) {
+    if (!rccl_load()) return (int)hipErrorSharedObjectInitFailed;
+    return g_rccl.get_id(static_cast<NcclId*>(out128)) == 0 ? 0 : (int)hipErrorUnknown;
+}
+extern "C" int mi355_llama_init_comm(void* mp, const void* id128) {
+    Model* m = static_cast<Model*>(mp);
+    if (!m || !id128) return (int)hipErrorInvalidValue;
+    if (!rccl_load()) return (int)hipErrorSharedObjectInitFailed;
+    NcclId id;
+    memcpy(&id, id128, sizeof(id));
+    return g_rccl.init_rank(&m->comm, m->cfg.tp_world, id, m->cfg.tp_rank) == 0 ? 0 : (int)hipErrorUnknown;
+}
+
+// ---- per-part launch for measurement: runs launch group `part` of layer `layer` on the static step inputs
+extern "C" int mi355_llama_run_part(void* mp, int32_t layer, int32_t part, int64_t stream) {
+    Model* m = static_cast<Model*>(mp);
+    if (!m || m->cur_batch < 1 || layer < 0 || layer >= m->cfg.n_layers) return (int)hipErrorInvalidValue;
+    const StepIn in{m->d_tokens, m->d_positions, m->d_slots, m->d_bt, m->d_ctx, m->cur_batch, m->cur_max_blocks, m->cur_ctx_cap};
+    return run_part(m, layer, part, in, m->logits, stream);
 }

@@ -65,7 +65,13 @@ class GGUFLLaMa:
         if not self.h:
             raise RuntimeError("mi355_llama_create failed")
         self._keep = []
-        self.weight_bytes = 0
+        self.weight_bytes = 0            # local (this rank's) quantised weight bytes touched per step
+        self.tp_rank, self.tp_world = tp_rank, tp_world
+        self.part_bytes = {}             # (layer, part) -> algorithmic weight bytes of that launch group
+        if cfg.n_heads % tp_world:
+            raise ValueError("num_attention_heads must be divisible by the TP world size (attention.rs:553-554)")
+        self.local_heads = cfg.n_heads // tp_world
+        self.local_kv_heads = max(cfg.n_kv_heads // tp_world, 1)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -99,9 +105,14 @@ class GGUFLLaMa:
         cfg = self.cfg
         gen = torch.Generator(device="cuda")
         gen.manual_seed(seed)
-        H, Hkv, D, hid, I = cfg.n_heads, cfg.n_kv_heads, cfg.head_dim, cfg.hidden, cfg.intermediate
+        Wn = self.tp_world
+        H, Hkv, D, hid = self.local_heads, self.local_kv_heads, cfg.head_dim, cfg.hidden
+        I, V = cfg.intermediate // Wn, cfg.vocab // Wn
+        if (I % 256) or (cfg.intermediate % Wn) or (cfg.vocab % (16 * Wn)) or ((H * D) % 256):
+            raise ValueError("TP shard is not block aligned (the reference re-quantises to Q8_0 here; not built)")
         shapes = {"wq": (H * D, hid), "wk": (Hkv * D, hid), "wv": (Hkv * D, hid), "wo": (hid, H * D),
                   "w1": (I, hid), "w2": (hid, I), "w3": (I, hid)}
+        part_of = {"wq": 0, "wk": 0, "wv": 0, "wo": 2, "w1": 3, "w3": 3, "w2": 4}
 
         def f32(layer, which, a):
             a = np.ascontiguousarray(a, np.float32)
@@ -113,19 +124,73 @@ class GGUFLLaMa:
             tiles = random_tiles(t, n, k, "cuda", gen)
             self._keep.append(tiles)
             _check(lib.mi355_llama_set_qweight_tiles(self.h, layer, which, t, tiles.data_ptr(), n, k), "set_tiles")
-            self.weight_bytes += (n // 16) * (k // 256) * _TILE_BYTES[t]
+            nbytes = (n // 16) * (k // 256) * _TILE_BYTES[t]
+            self.weight_bytes += nbytes
+            key = (layer, 5 if layer < 0 else part_of[name])
+            self.part_bytes[key] = self.part_bytes.get(key, 0) + nbytes
         rng = np.random.default_rng(seed)
-        emb = torch.randn((cfg.vocab, hid), device="cuda", generator=gen) * 0.02
+        emb = torch.randn((cfg.vocab, hid), device="cuda", generator=gen) * 0.02      # identical on every rank
+        gen.manual_seed(seed + 1000 * (self.tp_rank + 1))                              # shards differ per rank
         f32(-1, W_TOK_EMBD, emb.cpu().numpy())
         del emb
         f32(-1, W_OUTPUT_NORM, 1.0 + rng.normal(0, 0.02, hid))
-        qw(-1, W_OUTPUT, "output", cfg.vocab, hid)
+        qw(-1, W_OUTPUT, "output", V, hid)
         for l in range(cfg.n_layers):
             f32(l, W_ATTN_NORM, 1.0 + rng.normal(0, 0.02, hid))
             f32(l, W_FFN_NORM, 1.0 + rng.normal(0, 0.02, hid))
             for name, slot in _SLOT.items():
                 qw(l, slot, name, *shapes[name])
         torch.cuda.synchronize()
+
+    @property
+    def weight_bytes_global(self):
+        return self.weight_bytes * self.tp_world
+
+    # ------------------------------------------------------------------ tensor parallel
+    def init_comm(self, dist):
+        """RCCL communicator for this rank: rank 0 draws the unique id, torch.distributed ships the 128 bytes."""
+        buf = np.zeros(128, np.uint8)
+        if self.tp_rank == 0:
+            _check(lib.mi355_comm_unique_id(buf.ctypes.data), "comm_unique_id")
+        t = torch.from_numpy(buf).cuda()
+        dist.broadcast(t, src=0)
+        buf = np.ascontiguousarray(t.cpu().numpy())
+        _check(lib.mi355_llama_init_comm(self.h, buf.ctypes.data), "init_comm")
+
+    # ------------------------------------------------------------------ measurement
+    def dominant_kernel_roofline(self, stream, peak_gbs, reps=3):
+        """HIP-event timing of every launch group of the decode step (eager, on the step's own stream, weights of
+        all layers in turn so each launch streams from HBM).  Returns the `roofline` object of the group that
+        takes the most time, plus the per-group table."""
+        names = {0: "norm+qkv+rope+cache (qmm_kernel)", 1: "paged_attention_v2 (+reduce)", 2: "wo+residual (qmm_kernel)",
+                 3: "norm+gate/up+silu (qmm_kernel)", 4: "down+residual (qmm_kernel)"}
+        L = self.cfg.n_layers
+        st = stream.cuda_stream
+        ctx = getattr(self, "_ctx_now", 0)
+        kv_bytes = self._batch * ctx * 2 * self.local_kv_heads * self.cfg.head_dim * 2
+        rows = {}
+        for part in range(5):
+            evs = []
+            for _ in range(reps):
+                for l in range(L):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    _check(lib.mi355_llama_run_part(self.h, l, part, st), "run_part")
+                    e1.record(stream)
+                    evs.append((e0, e1))
+            torch.cuda.synchronize()
+            us = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+            avg = float(np.mean(us))
+            nbytes = kv_bytes if part == 1 else float(np.mean([self.part_bytes[(l, part)] for l in range(L)]))
+            rows[part] = {"kernel": names[part], "avg_us": round(avg, 2), "median_us": round(us[len(us) // 2], 2),
+                          "bytes": int(nbytes), "GBs": round(nbytes / avg / 1e3, 1), "launches_per_step": L}
+        dom = max(rows, key=lambda p: rows[p]["avg_us"] * L)
+        r = rows[dom]
+        return {"bound": "hbm", "kernel": r["kernel"], "achieved": r["GBs"], "peak": peak_gbs, "unit": "GB/s",
+                "frac": round(r["GBs"] / peak_gbs, 4), "traffic": None, "avg_us": r["avg_us"],
+                "algorithmic_bytes_per_launch": r["bytes"],
+                "timing": "hipEvent pairs around each launch on the step stream, eager, all layers x %d reps" % reps,
+                "groups": [rows[p] for p in sorted(rows)]}
 
     # ------------------------------------------------------------------ KV cache (CacheEngine)
     def alloc_kv_cache(self, num_blocks):
@@ -135,10 +200,10 @@ class GGUFLLaMa:
     def kv_shape(self):
         c = self.cfg
         if self.kv_layout == KV_FLASH:
-            s = (self.num_blocks, c.block_size, c.n_kv_heads, c.head_dim)
+            s = (self.num_blocks, c.block_size, self.local_kv_heads, c.head_dim)
             return s, s
-        return ((self.num_blocks, c.n_kv_heads, c.head_dim // 8, c.block_size, 8),
-                (self.num_blocks, c.n_kv_heads, c.head_dim, c.block_size))
+        return ((self.num_blocks, self.local_kv_heads, c.head_dim // 8, c.block_size, 8),
+                (self.num_blocks, self.local_kv_heads, c.head_dim, c.block_size))
 
     def kv_upload(self, layer, k_bits, v_bits):
         """k_bits/v_bits: uint16 numpy arrays (bf16 bit patterns) in the cache layout."""
@@ -188,9 +253,11 @@ class GGUFLLaMa:
         _check(lib.mi355_llama_decode_begin(self.h, tokens.ctypes.data, seq_lens.ctypes.data, bt.ctypes.data,
                                             len(tokens), bt.shape[1], int(ctx_cap), stream), "decode_begin")
         self._batch = len(tokens)
+        self._ctx_now = int(np.max(seq_lens))
 
     def decode_step(self, stream):
         _check(lib.mi355_llama_decode_step(self.h, stream), "decode_step")
+        self._ctx_now += 1
 
     def read_tokens(self, stream):
         out = np.empty(self._batch, np.uint32)

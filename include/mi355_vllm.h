@@ -220,6 +220,13 @@ int mi355_llama_set_graph(void* model, int32_t enable);
 int mi355_llama_decode_step(void* model, int64_t stream);
 int mi355_llama_decode_read_tokens(void* model, uint32_t* host_out, int64_t stream);
 float* mi355_llama_logits_ptr(void* model);
+/* tensor parallel: RCCL communicator (one process per GPU).  rank 0: mi355_comm_unique_id -> 128 bytes that the
+ * launcher ships to every rank -> mi355_llama_init_comm on every rank (cudarc Comm::from_rank, pipeline.rs:805-812) */
+int mi355_comm_unique_id(void* out128);
+int mi355_llama_init_comm(void* model, const void* id128);
+/* measurement hook: one launch group of the step on the static inputs (part 0 qkv, 1 attention, 2 wo,
+ * 3 gate/up, 4 down, 5 lm_head, 6 embedding) */
+int mi355_llama_run_part(void* model, int32_t layer, int32_t part, int64_t stream);
 
 #ifdef __cplusplus
 }

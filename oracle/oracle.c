@@ -1,0 +1,460 @@
+/* CPU oracle, C twin (TEST INFRASTRUCTURE ONLY -- never linked into the product path).
+ *
+ * A plain-C restatement of the reference's CPU arithmetic for the decode hot path, used (a) as a second,
+ * independent statement of the numpy oracle (oracle/kquants.py, oracle/ops.py, oracle/llama.py) and
+ * (b) as the `cpu_baseline` of bench.py (kind "port": the reference binary itself cannot be built here --
+ * no Rust toolchain, and its arithmetic lives in un-vendored git dependencies).
+ *
+ * PARITY UNPINNED: no reference fixture exists for this path.  What is restated, with the call sites:
+ *   QMatMul::forward on CPU = quantise activations per 256 to Q8_K, integer vec-dot   [EXT candle k_quants.rs]
+ *       called from src/openai/models/layers/attention.rs:920-922,1004 ; quantized_llama.rs:33-37
+ *   candle_nn::ops::rms_norm            src/openai/models/layers/qrmsnorm.rs:28-31
+ *   candle rope_i (interleaved)         src/openai/models/layers/rotary_emb.rs:72-100, quantized_llama.rs:313-318
+ *   NaiveAttention math                 src/openai/models/mod.rs:1288-1306 (GQA repeat_kv :1240-1247)
+ *   layer loop / residuals / lm_head    src/openai/models/quantized_llama.rs:424-506
+ *   slot / block table semantics        src/openai/pipelines/inputs.rs:376-454
+ * Build: gcc -O3 -march=x86-64-v3 -fopenmp -shared -fPIC oracle/oracle.c -o oracle/liboracle.so -lm
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define QK_K 256
+#define Q4K_BYTES 144
+#define Q6K_BYTES 210
+#define T_Q4K 12
+#define T_Q6K 14
+
+/* ---- f16 / bf16 helpers ---------------------------------------------------------------------- */
+static float f16_to_f32(uint16_t h) {
+    const uint32_t s = (uint32_t)(h & 0x8000) << 16;
+    uint32_t e = (h >> 10) & 0x1F, m = h & 0x3FF, u;
+    if (e == 0) {
+        if (m == 0) u = s;
+        else {
+            e = 127 - 15 + 1;
+            while (!(m & 0x400)) { m <<= 1; --e; }
+            u = s | (e << 23) | ((m & 0x3FF) << 13);
+        }
+    } else if (e == 31) u = s | 0x7F800000u | (m << 13);
+    else u = s | ((e + 127 - 15) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FC0;
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float bf16_to_f32(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+
+/* ---- k-quant formats ------------------------------------------------------- */
+static void scale_min_k4(int j, const uint8_t* q, uint8_t* d, uint8_t* m) {
+    if (j < 4) { *d = q[j] & 63; *m = q[j + 4] & 63; }
+    else { *d = (q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4); *m = (q[j + 4] >> 4) | ((q[j] >> 6) << 4); }
+}
+
+void orc_dequantize_q4k(const uint8_t* b, float* y, int64_t nblocks) {
+    for (int64_t i = 0; i < nblocks; ++i, b += Q4K_BYTES) {
+        uint16_t dh, mh;
+        memcpy(&dh, b, 2);
+        memcpy(&mh, b + 2, 2);
+        const float d = f16_to_f32(dh), dmin = f16_to_f32(mh);
+        const uint8_t* q = b + 16;
+        int is = 0;
+        for (int j = 0; j < QK_K; j += 64) {
+            uint8_t sc, m;
+            scale_min_k4(is + 0, b + 4, &sc, &m);
+            const float d1 = d * sc, m1 = dmin * m;
+            scale_min_k4(is + 1, b + 4, &sc, &m);
+            const float d2 = d * sc, m2 = dmin * m;
+            for (int l = 0; l < 32; ++l) *y++ = d1 * (q[l] & 0xF) - m1;
+            for (int l = 0; l < 32; ++l) *y++ = d2 * (q[l] >> 4) - m2;
+            q += 32;
+            is += 2;
+        }
+    }
+}
+
+void orc_dequantize_q6k(const uint8_t* b, float* y, int64_t nblocks) {
+    for (int64_t i = 0; i < nblocks; ++i, b += Q6K_BYTES) {
+        const uint8_t *ql = b, *qh = b + 128;
+        const int8_t* sc = (const int8_t*)(b + 192);
+        uint16_t dh;
+        memcpy(&dh, b + 208, 2);
+        const float d = f16_to_f32(dh);
+        for (int n = 0; n < QK_K; n += 128) {
+            for (int l = 0; l < 32; ++l) {
+                const int is = l / 16;
+                const int q1 = (int)((ql[l] & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32;
+                const int q2 = (int)((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32;
+                const int q3 = (int)((ql[l] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32;
+                const int q4 = (int)((ql[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32;
+                y[l] = d * sc[is] * q1;
+                y[l + 32] = d * sc[is + 2] * q2;
+                y[l + 64] = d * sc[is + 4] * q3;
+                y[l + 96] = d * sc[is + 6] * q4;
+            }
+            y += 128; ql += 64; qh += 32; sc += 8;
+        }
+    }
+}
+
+/* Q8_K: f32 d; i8 qs[256]; i16 bsums[16]  -- ggml quantize_row_q8_K [EXT] */
+void orc_quantize_q8k(const float* x, int k, float* d, int8_t* q, int16_t* bsums) {
+    const int nb = k / QK_K;
+    for (int i = 0; i < nb; ++i) {
+        float max = 0, amax = 0;
+        for (int j = 0; j < QK_K; ++j) {
+            const float ax = fabsf(x[j]);
+            if (ax > amax) { amax = ax; max = x[j]; }
+        }
+        if (amax == 0) {
+            d[i] = 0;
+            memset(q, 0, QK_K);
+            memset(bsums, 0, 32);
+        } else {
+            const float iscale = -128.f / max;
+            for (int j = 0; j < QK_K; ++j) {
+                int v = (int)nearbyintf(iscale * x[j]);
+                q[j] = (int8_t)(v > 127 ? 127 : v);
+            }
+            for (int j = 0; j < 16; ++j) {
+                int s = 0;
+                for (int l = 0; l < 16; ++l) s += q[j * 16 + l];
+                bsums[j] = (int16_t)s;
+            }
+            d[i] = 1.f / iscale;
+        }
+        x += QK_K; q += QK_K; bsums += 16;
+    }
+}
+
+float orc_vec_dot_q4k_q8k(const uint8_t* w, int nb, const float* xd, const int8_t* xq, const int16_t* xb) {
+    float sumf = 0;
+    for (int i = 0; i < nb; ++i, w += Q4K_BYTES, xq += QK_K, xb += 16) {
+        uint16_t dh, mh;
+        memcpy(&dh, w, 2);
+        memcpy(&mh, w + 2, 2);
+        const float d = f16_to_f32(dh) * xd[i], dmin = f16_to_f32(mh) * xd[i];
+        const uint8_t* q4 = w + 16;
+        int32_t sumi = 0, summ = 0;
+        for (int j = 0; j < 8; ++j) {
+            uint8_t sc, m;
+            scale_min_k4(j, w + 4, &sc, &m);
+            const uint8_t* qs = q4 + 32 * (j / 2);
+            const int8_t* q8 = xq + 32 * j;
+            int32_t s = 0;
+            if (j & 1) for (int l = 0; l < 32; ++l) s += (qs[l] >> 4) * q8[l];
+            else for (int l = 0; l < 32; ++l) s += (qs[l] & 0xF) * q8[l];
+            sumi += s * sc;
+            summ += (xb[2 * j] + xb[2 * j + 1]) * m;
+        }
+        sumf += d * (float)sumi - dmin * (float)summ;
+    }
+    return sumf;
+}
+
+float orc_vec_dot_q6k_q8k(const uint8_t* w, int nb, const float* xd, const int8_t* xq) {
+    float sumf = 0;
+    for (int i = 0; i < nb; ++i, w += Q6K_BYTES, xq += QK_K) {
+        const uint8_t *ql = w, *qh = w + 128;
+        const int8_t* sc = (const int8_t*)(w + 192);
+        uint16_t dh;
+        memcpy(&dh, w + 208, 2);
+        const float d = f16_to_f32(dh) * xd[i];
+        int32_t sumi = 0;
+        const int8_t* q8 = xq;
+        for (int n = 0; n < 2; ++n) {
+            int32_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int l = 0; l < 32; ++l) {
+                const int is = l / 16;
+                s[is] += ((int)((ql[l] & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32) * q8[l];
+                s[is + 2] += ((int)((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32) * q8[l + 32];
+                s[is + 4] += ((int)((ql[l] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32) * q8[l + 64];
+                s[is + 6] += ((int)((ql[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32) * q8[l + 96];
+            }
+            for (int j = 0; j < 8; ++j) sumi += s[j] * sc[j];
+            ql += 64; qh += 32; sc += 8; q8 += 128;
+        }
+        sumf += d * (float)sumi;
+    }
+    return sumf;
+}
+
+/* y[T,N] = x[T,K] . dequant(W[N,K])^T.  o2 != 0: candle-CPU-faithful (Q8_K activations, integer dot);
+ * o2 == 0: dequantise each row, accumulate in double (oracle O1). */
+void orc_qmatmul(const uint8_t* w, int type, int N, int K, const float* x, int T, float* y, int o2) {
+    const int nb = K / QK_K, bb = type == T_Q4K ? Q4K_BYTES : Q6K_BYTES;
+    if (o2) {
+        float* xd = (float*)malloc((size_t)T * nb * 4);
+        int8_t* xq = (int8_t*)malloc((size_t)T * K);
+        int16_t* xb = (int16_t*)malloc((size_t)T * nb * 16 * 2);
+        for (int t = 0; t < T; ++t)
+            orc_quantize_q8k(x + (size_t)t * K, K, xd + (size_t)t * nb, xq + (size_t)t * K, xb + (size_t)t * nb * 16);
+#pragma omp parallel for schedule(static)
+        for (int n = 0; n < N; ++n) {
+            const uint8_t* row = w + (size_t)n * nb * bb;
+            for (int t = 0; t < T; ++t)
+                y[(size_t)t * N + n] = type == T_Q4K
+                    ? orc_vec_dot_q4k_q8k(row, nb, xd + (size_t)t * nb, xq + (size_t)t * K, xb + (size_t)t * nb * 16)
+                    : orc_vec_dot_q6k_q8k(row, nb, xd + (size_t)t * nb, xq + (size_t)t * K);
+        }
+        free(xd); free(xq); free(xb);
+    } else {
+#pragma omp parallel
+        {
+            float* wr = (float*)malloc((size_t)K * 4);
+#pragma omp for schedule(static)
+            for (int n = 0; n < N; ++n) {
+                const uint8_t* row = w + (size_t)n * nb * bb;
+                if (type == T_Q4K) orc_dequantize_q4k(row, wr, nb); else orc_dequantize_q6k(row, wr, nb);
+                for (int t = 0; t < T; ++t) {
+                    double acc = 0;
+                    const float* xr = x + (size_t)t * K;
+                    for (int k = 0; k < K; ++k) acc += (double)xr[k] * (double)wr[k];
+                    y[(size_t)t * N + n] = (float)acc;
+                }
+            }
+            free(wr);
+        }
+    }
+}
+
+/* ---- small ops --------------------------------------------------------------------------------- */
+void orc_rms_norm(const float* x, const float* w, float eps, int T, int hid, float* y) {
+    for (int t = 0; t < T; ++t) {
+        double ss = 0;
+        for (int i = 0; i < hid; ++i) ss += (double)x[(size_t)t * hid + i] * x[(size_t)t * hid + i];
+        const double inv = 1.0 / sqrt(ss / hid + eps);
+        for (int i = 0; i < hid; ++i) y[(size_t)t * hid + i] = (float)(x[(size_t)t * hid + i] * inv * w[i]);
+    }
+}
+
+/* interleaved rope (candle rope_i) in place; x [T, H, D]; cos/sin [max_seq, D/2] */
+void orc_rope_i(float* x, const float* cosT, const float* sinT, const int64_t* pos, int T, int H, int D) {
+    for (int t = 0; t < T; ++t)
+        for (int h = 0; h < H; ++h) {
+            float* v = x + ((size_t)t * H + h) * D;
+            for (int i = 0; i < D / 2; ++i) {
+                const float c = cosT[pos[t] * (D / 2) + i], s = sinT[pos[t] * (D / 2) + i];
+                const float x0 = v[2 * i], x1 = v[2 * i + 1];
+                v[2 * i] = x0 * c - x1 * s;
+                v[2 * i + 1] = x0 * s + x1 * c;
+            }
+        }
+}
+
+/* ---- the model ---------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t hidden, n_layers, n_heads, n_kv_heads, head_dim, intermediate, vocab, max_seq, block_size;
+    float rms_eps, rope_theta;
+} orc_cfg;
+
+typedef struct { const uint8_t* w; int type, n, k; } orc_qw;
+typedef struct {
+    orc_cfg c;
+    orc_qw* lw;            /* [n_layers][7] */
+    float** norms;         /* [n_layers][2] */
+    const float* tok_embd; /* f32 [vocab, hidden] or NULL (then the embedding row is synthesised) */
+    const float* out_norm;
+    orc_qw out;
+    float *cosT, *sinT;
+    uint8_t* owned;        /* random weights allocated by orc_llama_create_random */
+    float* owned_f;
+} orc_model;
+
+void* orc_llama_create(const orc_cfg* c) {
+    orc_model* m = (orc_model*)calloc(1, sizeof(orc_model));
+    m->c = *c;
+    m->lw = (orc_qw*)calloc((size_t)c->n_layers * 7, sizeof(orc_qw));
+    m->norms = (float**)calloc((size_t)c->n_layers * 2, sizeof(float*));
+    const int half = c->head_dim / 2;
+    m->cosT = (float*)malloc((size_t)c->max_seq * half * 4);
+    m->sinT = (float*)malloc((size_t)c->max_seq * half * 4);
+    for (int i = 0; i < half; ++i) {
+        const float inv = (float)(1.0 / pow((double)c->rope_theta, (double)(2 * i) / (double)c->head_dim));
+        for (int p = 0; p < c->max_seq; ++p) {
+            const float th = (float)p * inv;
+            m->cosT[(size_t)p * half + i] = (float)cos((double)th);
+            m->sinT[(size_t)p * half + i] = (float)sin((double)th);
+        }
+    }
+    return m;
+}
+void orc_llama_destroy(void* mp) {
+    orc_model* m = (orc_model*)mp;
+    if (!m) return;
+    free(m->lw); free(m->norms); free(m->cosT); free(m->sinT); free(m->owned); free(m->owned_f); free(m);
+}
+/* which: 0 wq 1 wk 2 wv 3 wo 4 w1 5 w2 6 w3 ; layer -1, which 11: output.  Pointers are borrowed. */
+void orc_llama_set_qweight(void* mp, int layer, int which, int type, const uint8_t* blocks, int n, int k) {
+    orc_model* m = (orc_model*)mp;
+    orc_qw q = {blocks, type, n, k};
+    if (layer < 0) m->out = q; else m->lw[(size_t)layer * 7 + which] = q;
+}
+/* which: 7 attn_norm 8 ffn_norm ; layer -1: 9 tok_embd 10 output_norm */
+void orc_llama_set_f32(void* mp, int layer, int which, const float* p) {
+    orc_model* m = (orc_model*)mp;
+    if (layer < 0) { if (which == 9) m->tok_embd = p; else m->out_norm = p; }
+    else m->norms[(size_t)layer * 2 + (which == 7 ? 0 : 1)] = (float*)p;
+}
+
+static uint64_t xs64(uint64_t* s) { uint64_t x = *s; x ^= x << 13; x ^= x >> 7; x ^= x << 17; return *s = x; }
+
+/* Random VALID weights (Q4_K_M-style type mixture decided by the caller through types[]) for the CPU
+ * baseline timing: bytes from xorshift, f16 super-block scales set to sane constants. */
+static void fill_random(uint8_t* p, int type, int64_t nblocks, uint64_t* seed) {
+    const int bb = type == T_Q4K ? Q4K_BYTES : Q6K_BYTES;
+    uint64_t* q = (uint64_t*)p;
+    const int64_t n8 = nblocks * bb / 8;
+    for (int64_t i = 0; i < n8; ++i) q[i] = xs64(seed);
+    for (int64_t i = n8 * 8; i < nblocks * bb; ++i) p[i] = (uint8_t)xs64(seed);
+    const uint16_t d4 = 0x0A8E /* 2e-4 */, dm4 = 0x1625 /* 1.5e-3 */, d6 = 0x00D2 /* 1.25e-5 */;
+    for (int64_t i = 0; i < nblocks; ++i) {
+        if (type == T_Q4K) { memcpy(p + i * bb, &d4, 2); memcpy(p + i * bb + 2, &dm4, 2); }
+        else memcpy(p + i * bb + 208, &d6, 2);
+    }
+}
+
+/* allocate + fill all weights; types: int[n_layers*7 + 1] (last = output) */
+int orc_llama_fill_random(void* mp, const int32_t* types, uint64_t seed) {
+    orc_model* m = (orc_model*)mp;
+    const orc_cfg* c = &m->c;
+    const int H = c->n_heads, Hkv = c->n_kv_heads, D = c->head_dim, hid = c->hidden, I = c->intermediate;
+    const int rows[7] = {H * D, Hkv * D, Hkv * D, hid, I, hid, I};
+    const int cols[7] = {hid, hid, hid, H * D, hid, I, hid};
+    size_t total = 0;
+    for (int l = 0; l < c->n_layers; ++l)
+        for (int w = 0; w < 7; ++w)
+            total += (size_t)rows[w] * (cols[w] / QK_K) * (types[l * 7 + w] == T_Q4K ? Q4K_BYTES : Q6K_BYTES);
+    const int ot = types[c->n_layers * 7];
+    total += (size_t)c->vocab * (hid / QK_K) * (ot == T_Q4K ? Q4K_BYTES : Q6K_BYTES);
+    m->owned = (uint8_t*)malloc(total);
+    m->owned_f = (float*)malloc(((size_t)c->n_layers * 2 + 1) * hid * 4);
+    if (!m->owned || !m->owned_f) return -1;
+    uint64_t s = seed ? seed : 88172645463325252ull;
+    uint8_t* p = m->owned;
+    for (int l = 0; l < c->n_layers; ++l) {
+        for (int w = 0; w < 7; ++w) {
+            const int t = types[l * 7 + w];
+            const int64_t nbk = (int64_t)rows[w] * (cols[w] / QK_K);
+            fill_random(p, t, nbk, &s);
+            orc_llama_set_qweight(m, l, w, t, p, rows[w], cols[w]);
+            p += nbk * (t == T_Q4K ? Q4K_BYTES : Q6K_BYTES);
+        }
+        for (int k = 0; k < 2; ++k) {
+            float* nw = m->owned_f + ((size_t)l * 2 + k) * hid;
+            for (int i = 0; i < hid; ++i) nw[i] = 1.0f;
+            m->norms[(size_t)l * 2 + k] = nw;
+        }
+    }
+    fill_random(p, ot, (int64_t)c->vocab * (hid / QK_K), &s);
+    orc_llama_set_qweight(m, -1, 11, ot, p, c->vocab, hid);
+    float* on = m->owned_f + (size_t)c->n_layers * 2 * hid;
+    for (int i = 0; i < hid; ++i) on[i] = 1.0f;
+    m->out_norm = on;
+    m->tok_embd = NULL;
+    return 0;
+}
+
+/* One decode step (flash KV layout [NB, bs, Hkv, D], bf16 bit patterns).  logits f32 [B, vocab]. */
+void orc_llama_decode(void* mp, const uint32_t* tokens, const int64_t* positions, const int64_t* slots,
+                      const uint32_t* bt, const uint32_t* ctx, int B, int max_blocks, uint16_t** kcache,
+                      uint16_t** vcache, float* logits, int o2) {
+    orc_model* m = (orc_model*)mp;
+    const orc_cfg* c = &m->c;
+    const int H = c->n_heads, Hkv = c->n_kv_heads, D = c->head_dim, hid = c->hidden, I = c->intermediate;
+    const int G = H / Hkv, bs = c->block_size;
+    float* xs = (float*)malloc((size_t)B * hid * 4);
+    float* xn = (float*)malloc((size_t)B * hid * 4);
+    float* q = (float*)malloc((size_t)B * H * D * 4);
+    float* k = (float*)malloc((size_t)B * Hkv * D * 4);
+    float* v = (float*)malloc((size_t)B * Hkv * D * 4);
+    float* att = (float*)malloc((size_t)B * H * D * 4);
+    float* g = (float*)malloc((size_t)B * I * 4);
+    float* u = (float*)malloc((size_t)B * I * 4);
+    float* tmp = (float*)malloc((size_t)B * hid * 4);
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < hid; ++i)
+            xs[(size_t)b * hid + i] = m->tok_embd ? m->tok_embd[(size_t)tokens[b] * hid + i]
+                                                  : 0.02f * sinf((float)(tokens[b] % 977) * 0.37f + (float)i * 0.011f);
+    const float scale = 1.0f / sqrtf((float)D);
+    for (int l = 0; l < c->n_layers; ++l) {
+        const orc_qw* W = m->lw + (size_t)l * 7;
+        orc_rms_norm(xs, m->norms[(size_t)l * 2], c->rms_eps, B, hid, xn);
+        orc_qmatmul(W[0].w, W[0].type, W[0].n, W[0].k, xn, B, q, o2);
+        orc_qmatmul(W[1].w, W[1].type, W[1].n, W[1].k, xn, B, k, o2);
+        orc_qmatmul(W[2].w, W[2].type, W[2].n, W[2].k, xn, B, v, o2);
+        orc_rope_i(q, m->cosT, m->sinT, positions, B, H, D);
+        orc_rope_i(k, m->cosT, m->sinT, positions, B, Hkv, D);
+        for (int b = 0; b < B; ++b) {                      /* cast to bf16 + cache write (attention.rs:977-995) */
+            if (slots[b] < 0) continue;
+            for (int i = 0; i < Hkv * D; ++i) {
+                kcache[l][(size_t)slots[b] * Hkv * D + i] = f32_to_bf16(k[(size_t)b * Hkv * D + i]);
+                vcache[l][(size_t)slots[b] * Hkv * D + i] = f32_to_bf16(v[(size_t)b * Hkv * D + i]);
+            }
+        }
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int b = 0; b < B; ++b)
+            for (int h = 0; h < H; ++h) {
+                const int n = (int)ctx[b], hk = h / G;
+                float* sc = (float*)malloc((size_t)n * 4);
+                float qb[512];
+                for (int d = 0; d < D; ++d) qb[d] = round_bf16(q[((size_t)b * H + h) * D + d]);
+                float mx = -1e30f;
+                for (int t = 0; t < n; ++t) {
+                    const size_t blk = bt[(size_t)b * max_blocks + t / bs];
+                    const uint16_t* kr = kcache[l] + ((blk * bs + t % bs) * Hkv + hk) * D;
+                    float s = 0;
+                    for (int d = 0; d < D; ++d) s += qb[d] * bf16_to_f32(kr[d]);
+                    sc[t] = s * scale;
+                    if (sc[t] > mx) mx = sc[t];
+                }
+                double den = 0;
+                for (int t = 0; t < n; ++t) { sc[t] = expf(sc[t] - mx); den += sc[t]; }
+                float* o = att + ((size_t)b * H + h) * D;
+                for (int d = 0; d < D; ++d) o[d] = 0;
+                for (int t = 0; t < n; ++t) {
+                    const size_t blk = bt[(size_t)b * max_blocks + t / bs];
+                    const uint16_t* vr = vcache[l] + ((blk * bs + t % bs) * Hkv + hk) * D;
+                    const float p = (float)(sc[t] / den);
+                    for (int d = 0; d < D; ++d) o[d] += p * bf16_to_f32(vr[d]);
+                }
+                for (int d = 0; d < D; ++d) o[d] = round_bf16(o[d]);
+                free(sc);
+            }
+        orc_qmatmul(W[3].w, W[3].type, W[3].n, W[3].k, att, B, tmp, o2);
+        for (size_t i = 0; i < (size_t)B * hid; ++i) xs[i] += tmp[i];
+        orc_rms_norm(xs, m->norms[(size_t)l * 2 + 1], c->rms_eps, B, hid, xn);
+        orc_qmatmul(W[4].w, W[4].type, W[4].n, W[4].k, xn, B, g, o2);
+        orc_qmatmul(W[6].w, W[6].type, W[6].n, W[6].k, xn, B, u, o2);
+        for (size_t i = 0; i < (size_t)B * I; ++i) g[i] = g[i] / (1.f + expf(-g[i])) * u[i];
+        orc_qmatmul(W[5].w, W[5].type, W[5].n, W[5].k, g, B, tmp, o2);
+        for (size_t i = 0; i < (size_t)B * hid; ++i) xs[i] += tmp[i];
+    }
+    orc_rms_norm(xs, m->out_norm, c->rms_eps, B, hid, xn);
+    orc_qmatmul(m->out.w, m->out.type, m->out.n, m->out.k, xn, B, logits, o2);
+    free(xs); free(xn); free(q); free(k); free(v); free(att); free(g); free(u); free(tmp);
+}
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

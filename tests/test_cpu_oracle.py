@@ -232,3 +232,42 @@ def test_c_abi_exports_every_declared_symbol(lib):
         assert hasattr(lib, n), n
     for n in ("copy_blocks_bf16", "copy_blocks_f16", "copy_blocks_f32"):       # reference FFI, verbatim
         assert n in names
+
+
+# ------------------------------------------------------------------------------------------------ C twin of the oracle
+def test_c_oracle_matches_numpy_oracle():
+    from oracle import cref
+    cref.build()
+    rng = np.random.default_rng(21)
+    x = rng.normal(size=(3, 1024)).astype(np.float32)
+    for t in (kq.GGML_Q4_K, kq.GGML_Q6_K):
+        b = kq.quantize(rng.normal(0, 0.05, (24, 1024)).astype(np.float32), t)
+        o1 = kq.qmatmul_o1(x, b, t)
+        assert np.abs(cref.qmatmul(x, b, t, o2=False) - o1).max() < 2e-6 * np.abs(o1).max()
+        o2 = kq.qmatmul_o2(x, b, t)
+        assert np.abs(cref.qmatmul(x, b, t, o2=True) - o2).max() < 2e-5 * np.abs(o2).max()
+
+
+def test_c_oracle_decode_step_matches_numpy_llama():
+    from oracle import cref
+    cref.build()
+    cfg = llama.LlamaConfig.tiny()
+    W = llama.make_weights(cfg, seed=1234)
+    M = llama.OracleLlama(cfg, W)
+    rng = np.random.default_rng(7)
+    seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 19)], "block_table": [3, 7]},
+            {"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 5)], "block_table": [1]}]
+    cache = M.new_cache(16)
+    lg = M.forward(O.prepare_prompt(seqs, cfg.block_size), cache, is_prefill=True)
+    for s, row in zip(seqs, lg):
+        s["tokens"].append(int(row.argmax()))
+    meta = O.prepare_decode(seqs, cfg.block_size)
+    c_cache = [(k.copy(), v.copy()) for k, v in cache]
+    ref = M.forward(meta, cache)
+    got = cref.CLlama(cfg, W).decode(meta, c_cache, o2=False)
+    assert np.abs(got - ref).max() < 2e-4 * np.abs(ref).max()
+    for (k1, v1), (k2, v2) in zip(cache, c_cache):
+        assert np.abs(O.bf16_bits_to_f32(k1) - O.bf16_bits_to_f32(k2)).max() <= 2 ** -7 * np.abs(O.bf16_bits_to_f32(k1)).max()
+    # candle-CPU-faithful arithmetic (Q8_K activations) stays within ~a few % of the exact-dequant logits
+    got2 = cref.CLlama(cfg, W).decode(meta, [(k.copy(), v.copy()) for k, v in c_cache], o2=True)
+    assert np.abs(got2 - ref).max() < 0.1 * np.abs(ref).max()
