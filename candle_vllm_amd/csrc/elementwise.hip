@@ -188,41 +188,62 @@ extern "C" int mi355_embedding_f32(float* out, const float* table, const uint32_
 
 // ------------------------------------------------------------------------------------------------ argmax (greedy)
 // logits f32 [B, V] -> u32 [B]; ties -> lowest index (candle argmax keeps the first maximum [EXT]).
-// NaN handling: NaNs never win a `>` comparison, matching a sequential `if v > best` scan.
-__global__ void __launch_bounds__(1024) argmax_f32_kernel(uint32_t* __restrict__ out, const float* __restrict__ logits, int V) {
-    __shared__ float sv[16];
-    __shared__ uint32_t si[16];
-    const float* row = logits + (int64_t)blockIdx.x * V;
-    float best = -INFINITY;
-    uint32_t bi = 0xFFFFFFFFu;
-    for (int i = threadIdx.x; i < V; i += blockDim.x) {
-        const float v = row[i];
-        if (v > best || (v == best && (uint32_t)i < bi)) { best = v; bi = (uint32_t)i; }
+// NaNs never win (they map to the lowest key), matching a sequential `if v > best` scan.
+// Stage 1: grid (ARGMAX_SPLIT, B) workgroups reduce a slice each and atomicMax a packed 64-bit key
+//          (order-preserving value bits << 32 | ~index) into a per-row slot; stage 2 decodes and re-zeroes the
+//          slot, so the scratch is self-cleaning and the pair is safe to replay from a hipGraph.
+#define ARGMAX_SPLIT 64
+#define ARGMAX_MAX_ROWS 4096
+static unsigned long long* g_argmax_slots = nullptr;
+
+__device__ __forceinline__ unsigned long long argmax_key(float v, uint32_t idx) {
+    uint32_t u = __float_as_uint(v);
+    uint32_t k = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    if (v != v) k = 0;
+    return ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+
+__global__ void __launch_bounds__(256) argmax_stage1_kernel(unsigned long long* __restrict__ slots,
+                                                            const float* __restrict__ logits, int V) {
+    __shared__ unsigned long long sk[4];
+    const float* row = logits + (int64_t)blockIdx.y * V;
+    const int per = (V + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(V, lo + per);
+    unsigned long long best = 0;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const unsigned long long k = argmax_key(row[i], (uint32_t)i);
+        best = k > best ? k : best;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const uint32_t oi = __shfl_xor(bi, o, 64);
-        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        const unsigned long long ok = __shfl_xor(best, o, 64);
+        best = ok > best ? ok : best;
     }
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (lane == 0) { sv[wid] = best; si[wid] = bi; }
+    if ((threadIdx.x & 63) == 0) sk[threadIdx.x >> 6] = best;
     __syncthreads();
-    if (wid == 0) {
-        const int nw = blockDim.x >> 6;
-        best = (lane < nw) ? sv[lane] : -INFINITY;
-        bi = (lane < nw) ? si[lane] : 0xFFFFFFFFu;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o, 64);
-            const uint32_t oi = __shfl_xor(bi, o, 64);
-            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-        }
-        if (lane == 0) out[blockIdx.x] = (bi == 0xFFFFFFFFu) ? 0u : bi;
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) best = sk[w] > best ? sk[w] : best;
+        atomicMax(slots + blockIdx.y, best);
     }
+}
+__global__ void argmax_stage2_kernel(uint32_t* __restrict__ out, unsigned long long* __restrict__ slots, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const unsigned long long k = slots[b];
+    slots[b] = 0;
+    out[b] = (k >> 32) == 0 ? 0u : (0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFu));
 }
 extern "C" int mi355_argmax_f32(uint32_t* out, const float* logits, int32_t batch, int32_t vocab, int64_t stream) {
     if (batch <= 0) return 0;
-    hipLaunchKernelGGL(argmax_f32_kernel, dim3(batch), dim3(1024), 0, to_stream(stream), out, logits, vocab);
+    if (batch > ARGMAX_MAX_ROWS || vocab <= 0) return (int)hipErrorInvalidValue;
+    if (!g_argmax_slots) {                                  // first call (never inside a stream capture: the
+        hipError_t e = hipMalloc((void**)&g_argmax_slots, ARGMAX_MAX_ROWS * 8);   // host layer warms up eagerly)
+        if (e != hipSuccess) return (int)e;
+        e = hipMemset(g_argmax_slots, 0, ARGMAX_MAX_ROWS * 8);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipStream_t st = to_stream(stream);
+    hipLaunchKernelGGL(argmax_stage1_kernel, dim3(ARGMAX_SPLIT, batch), dim3(256), 0, st, g_argmax_slots, logits, vocab);
+    hipLaunchKernelGGL(argmax_stage2_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, out, g_argmax_slots, batch);
     return (int)hipGetLastError();
 }

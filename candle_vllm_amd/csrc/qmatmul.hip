@@ -444,7 +444,9 @@ __device__ __forceinline__ void stage_kblock(const QmmArgs& a, const XRegs<BT>& 
 
 __device__ __forceinline__ float silu_f(float g) { return g / (1.f + __expf(-g)); }
 
-#define QMM_PF 4   // weight-prefetch ring depth in (k-block, tile) units per wave
+#ifndef QMM_PF_MIN
+#define QMM_PF_MIN 2   // weight-prefetch ring depth in (k-block, tile) units per wave = max(R, QMM_PF_MIN)
+#endif
 
 // One workgroup = R row tiles x all of K.  Its NW waves split the k-blocks (wave w owns k-blocks w, w+NW, ...);
 // every wave walks its (k-block, tile) units through a QMM_PF-deep register ring.  The ring loop is fully
@@ -454,7 +456,7 @@ __device__ __forceinline__ float silu_f(float g) { return g / (1.f + __expf(-g))
 template <int BT, int R, int WT>
 __global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) {
     constexpr int NV = BT < 4 ? BT : 4;
-    constexpr int PF = QMM_PF;
+    constexpr int PF = (R > QMM_PF_MIN) ? R : QMM_PF_MIN;
     constexpr int PFK = PF / R;                                  // ring depth in k-blocks
     static_assert(PF % R == 0, "ring depth must be a multiple of the tiles per workgroup");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -660,7 +662,7 @@ static int qmm_pick_nw(int n_wg, int nkb) {
         if (g_num_cus <= 0) g_num_cus = 256;
     }
     int pick = 1;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 3; ++i) {                         // never below 2 waves: one wave per tile serialises K
         const int nw = 8 >> i;
         if (nw > nkb) continue;
         if (blocks_per_cu[i] < 0) {
@@ -672,7 +674,7 @@ static int qmm_pick_nw(int n_wg, int nkb) {
         pick = nw;
         if ((long)n_wg <= (long)blocks_per_cu[i] * g_num_cus) return nw;
     }
-    // more workgroups than the chip holds even at the smallest NW: several rounds anyway -> 4 waves
+    // more workgroups than the chip holds even at 2 waves each: several rounds anyway -> 4 waves
     return nkb >= 4 ? 4 : pick;
 }
 
