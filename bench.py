@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--kv-layout", choices=["flash", "paged"], default="paged",
+                    help="paged = vLLM layout (reference default without flash-attn features; MFMA attention), "
+                         "flash = [NB,bs,Hkv,D]")
     ap.add_argument("--layers", type=int, default=0, help="debug only: fewer layers (result marked invalid)")
     return ap.parse_args()
 
@@ -107,7 +110,8 @@ def main():
     B, K, Wm = args.batch, args.steps, args.warmup
     blocks_per_seq = -(-(args.ctx + K + Wm + 2) // cfg.block_size)
     num_blocks = B * blocks_per_seq + 8
-    gm = M.GGUFLLaMa(cfg, max_batch=B, max_blocks_per_seq=blocks_per_seq, kv_layout=M.KV_FLASH,
+    kv_layout = M.KV_PAGED if args.kv_layout == "paged" else M.KV_FLASH
+    gm = M.GGUFLLaMa(cfg, max_batch=B, max_blocks_per_seq=blocks_per_seq, kv_layout=kv_layout,
                      tp_rank=rank, tp_world=world)
     if world > 1:
         gm.init_comm(dist)
@@ -164,7 +168,8 @@ def main():
                                f"batch={B}, prompt ctx {args.ctx} in paged KV (block 64), {K} decode steps",
                    "batch": B, "ctx_start": args.ctx + 1 + Wm, "ctx_end": args.ctx + Wm + K,
                    "parallelism": f"tp{world}", "graph": bool(not args.no_graph and world == 1),
-                   "kv_layout": "flash [NB,64,Hkv,128] bf16"},
+                   "kv_layout": ("paged K[NB,Hkv,D/8,64,8] V[NB,Hkv,D,64] bf16" if args.kv_layout == "paged"
+                                 else "flash [NB,64,Hkv,128] bf16")},
         "step": {"algorithmic_bytes": int(step_bytes), "achieved_GBs": round(achieved, 1),
                  "frac_of_8TBs": round(achieved / HBM_PEAK_GBS, 4), "frac_of_6.29TBs_copy": round(achieved / 6290.0, 4),
                  "roofline_tok_s_at_8TBs": round(B * HBM_PEAK_GBS * 1e9 / step_bytes, 1)},

@@ -145,13 +145,14 @@ __global__ void advance_kernel(uint32_t* tokens, const uint32_t* next_tokens, in
     slots[b] = blk * block_size + pos % block_size;
 }
 
+// v2 partition = what ONE wave streams (32 tokens per wave-chunk for head_dim 128): aim at ~8 waves per CU
 int choose_partition(int batch, int kv_heads, int ctx_cap) {
-    if (ctx_cap <= 512) return 0;
-    int per_seq = (1024 + batch * kv_heads - 1) / (batch * kv_heads);
+    if (ctx_cap <= 256) return 0;
+    int per_seq = (2048 + batch * kv_heads - 1) / (batch * kv_heads);
     if (per_seq < 1) per_seq = 1;
     int ps = (ctx_cap + per_seq - 1) / per_seq;
-    ps = ((ps + 63) / 64) * 64;
-    if (ps < 64) ps = 64;
+    ps = ((ps + 31) / 32) * 32;
+    if (ps < 32) ps = 32;
     return ps < ctx_cap ? ps : 0;
 }
 
@@ -227,8 +228,11 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
     }
     if (part == PART_ATTN) {
         // --- paged attention over the cache (the new token's K/V are already in place)
-        const int ps = choose_partition(B, Hkv, in.ctx_cap);
+        int ps = choose_partition(B, Hkv, in.ctx_cap);
+        if (ps > 0 && c.kv_layout == MI355_KV_PAGED) ps = ps <= 32 ? 32 : (ps <= 64 ? 64 : 128);   // MFMA kernel sizes
         const float scale = 1.0f / sqrtf((float)D);
+        if (ps > 0 && (in.ctx_cap + ps - 1) / ps > m->pa_cap_partitions) return (int)hipErrorInvalidValue;
+        if (in.ctx_cap > c.max_seq) return (int)hipErrorInvalidValue;
         if (ps == 0)
             return mi355_paged_attention_v1(m->attn, m->q, m->kcache[l], m->vcache[l], in.bt, in.ctx, B, H, Hkv, D,
                                             c.block_size, in.max_blocks, in.ctx_cap, scale, 0.f, c.kv_layout,
@@ -327,7 +331,7 @@ extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
         alloc((void**)&m->logits_local, (size_t)B * cfg->vocab * 4 / m->cfg.tp_world + 64);
         alloc((void**)&m->logits_gather, (size_t)B * cfg->vocab * 4 + 64 * m->cfg.tp_world);
     }
-    m->pa_cap_partitions = (cfg->max_seq + 63) / 64;
+    m->pa_cap_partitions = (cfg->max_seq + 31) / 32 + 1;   // v2 partitions are >= 32 tokens (choose_partition)
     alloc((void**)&m->pa_tmp, (size_t)B * H * m->pa_cap_partitions * D * 4);
     alloc((void**)&m->pa_max, (size_t)B * H * m->pa_cap_partitions * 4);
     alloc((void**)&m->pa_sum, (size_t)B * H * m->pa_cap_partitions * 4);

@@ -18,8 +18,6 @@
 #include "common.h"
 #include "../../include/mi355_vllm.h"
 
-#define PA_THREADS 256
-#define PA_UNR 4
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
@@ -68,10 +66,12 @@ struct PAParams {
     int64_t q_stride;          // elements between sequences in q (H*D when contiguous)
 };
 
-template <int LPT, int GP, int KVT, bool PARTITIONED>
-__global__ void __launch_bounds__(PA_THREADS) paged_attn_flash_kernel(const PAParams p) {
+// NWV waves per workgroup.  The partitioned (v2) path runs ONE wave per workgroup (no LDS, no barrier: a
+// partition is what a single wave streams with UNR loads in flight); v1 keeps 4 waves merged through LDS.
+template <int LPT, int GP, int KVT, bool PARTITIONED, int NWV, int UNR>
+__global__ void __launch_bounds__(64 * NWV) paged_attn_flash_kernel(const PAParams p) {
     constexpr int TW = 64 / LPT;            // token groups per wave
-    constexpr int TI = 4 * TW;              // tokens per workgroup iteration
+    constexpr int TI = NWV * TW;            // tokens per workgroup iteration
     const int hk = blockIdx.x, b = blockIdx.y, part = blockIdx.z;
     const int ctx = (int)p.context_lens[b];
     const int t0 = part * p.partition_size;
@@ -112,11 +112,11 @@ __global__ void __launch_bounds__(PA_THREADS) paged_attn_flash_kernel(const PAPa
     }
 
     const int64_t tok_stride = (int64_t)p.Hkv * p.D;            // elements between tokens of a block
-    for (int base = t0 + tg; base < t1; base += TI * PA_UNR) {
-        uint4 kw[PA_UNR], vw[PA_UNR];
-        bool valid[PA_UNR];
+    for (int base = t0 + tg; base < t1; base += TI * UNR) {
+        uint4 kw[UNR], vw[UNR];
+        bool valid[UNR];
 #pragma unroll
-        for (int u = 0; u < PA_UNR; ++u) {
+        for (int u = 0; u < UNR; ++u) {
             const int tok = base + u * TI;
             valid[u] = tok < t1;
             kw[u] = make_uint4(0, 0, 0, 0);
@@ -129,12 +129,12 @@ __global__ void __launch_bounds__(PA_THREADS) paged_attn_flash_kernel(const PAPa
                 vw[u] = *reinterpret_cast<const uint4*>(vc + off);
             }
         }
-        float s[PA_UNR][GP];
+        float s[UNR][GP];
         float mx[GP];
 #pragma unroll
         for (int g = 0; g < GP; ++g) mx[g] = m[g];
 #pragma unroll
-        for (int u = 0; u < PA_UNR; ++u) {
+        for (int u = 0; u < UNR; ++u) {
             float kf[8];
             unpack8<KVT>(kw[u], kf);
 #pragma unroll
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(PA_THREADS) paged_attn_flash_kernel(const PAPa
             for (int e = 0; e < 8; ++e) acc[g][e] *= alpha;
         }
 #pragma unroll
-        for (int u = 0; u < PA_UNR; ++u) {
+        for (int u = 0; u < UNR; ++u) {
             float vf[8];
             unpack8<KVT>(vw[u], vf);
 #pragma unroll
@@ -191,7 +191,31 @@ __global__ void __launch_bounds__(PA_THREADS) paged_attn_flash_kernel(const PAPa
         l[g] = ll;
     }
 
-    // ---- merge the 4 waves through LDS
+    if constexpr (NWV == 1) {
+        // single wave: lanes 0..LPT-1 hold the merged state of their 8 channels -> write the partial directly
+        if (lane < LPT && dact) {
+#pragma unroll
+            for (int g = 0; g < GP; ++g) {
+                if (g >= G) break;
+                const int h = hk * G + g;
+                const float inv = l[g] > 0.f ? 1.f / l[g] : 0.f;
+                if constexpr (PARTITIONED) {
+                    const int64_t pi = ((int64_t)b * p.H + h) * p.max_partitions + part;
+                    float4* tp = reinterpret_cast<float4*>(p.tmp_out + pi * p.D + sub * 8);
+                    tp[0] = make_float4(acc[g][0] * inv, acc[g][1] * inv, acc[g][2] * inv, acc[g][3] * inv);
+                    tp[1] = make_float4(acc[g][4] * inv, acc[g][5] * inv, acc[g][6] * inv, acc[g][7] * inv);
+                    if (sub == 0) { p.max_logits[pi] = m[g]; p.exp_sums[pi] = l[g]; }
+                } else {
+                    uint16_t* op = static_cast<uint16_t*>(p.out) + ((int64_t)b * p.H + h) * p.D + sub * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        op[e] = (KVT == MI355_DTYPE_BF16) ? f32_to_bf16(acc[g][e] * inv) : f32_to_f16_bits(acc[g][e] * inv);
+                }
+            }
+        }
+        return;
+    }
+    // ---- merge the NWV waves through LDS
     constexpr int DP = LPT * 8;                        // padded head dim
     __shared__ float s_acc[4][GP][DP];
     __shared__ float s_m[4][GP], s_l[4][GP];
@@ -204,7 +228,7 @@ __global__ void __launch_bounds__(PA_THREADS) paged_attn_flash_kernel(const PAPa
         }
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < G * p.D; idx += PA_THREADS) {
+    for (int idx = threadIdx.x; idx < G * p.D; idx += 64 * NWV) {
         const int g = idx / p.D, d = idx % p.D;
         float M = fmaxf(fmaxf(s_m[0][g], s_m[1][g]), fmaxf(s_m[2][g], s_m[3][g]));
         float num = 0.f, den = 0.f;
@@ -239,12 +263,14 @@ __global__ void __launch_bounds__(128) paged_attn_reduce_kernel(void* __restrict
     extern __shared__ float s_w[];                          // [P] merge weights
     __shared__ float red[16];
     const int h = blockIdx.x, b = blockIdx.y;
+    const int64_t base = ((int64_t)b * H + h) * max_partitions;
+    // statistics of every possible partition are fetched while context_lens is still in flight
+    float ml0 = (threadIdx.x < max_partitions) ? max_logits[base + threadIdx.x] : -1e30f;
     const int ctx = (int)context_lens[b];
     const int P = (ctx + partition_size - 1) / partition_size;
-    const int64_t base = ((int64_t)b * H + h) * max_partitions;
     float M = -1e30f;
     for (int i = threadIdx.x; i < P; i += blockDim.x) {
-        const float ml = max_logits[base + i];
+        const float ml = (i == (int)threadIdx.x) ? ml0 : max_logits[base + i];
         s_w[i] = ml;
         M = fmaxf(M, ml);
     }
@@ -353,15 +379,166 @@ __global__ void __launch_bounds__(256) paged_attn_paged_layout_kernel(const PAPa
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// MFMA decode attention on the PAGED (vLLM) layout -- the layout candle-vllm builds use when no flash-attn
+// feature is enabled (cache_engine.rs:188-193), i.e. what a ROCm build of the reference would allocate.
+// K [NB,Hkv,D/8,bs,8] hands the QK^T A-fragment (16 B = 8 channels of one token) and V [NB,Hkv,D,bs] the
+// P.V B-fragment (8 B = 4 tokens of one channel) straight from global memory: no LDS, no transpose.
+//   * one wave per (kv head, sequence, partition of 16*NT tokens); the G <= 16 query heads of the GQA group are
+//     the 16 MFMA columns (swapped product S^T = K.Q^T, so the softmax output is already the A operand of P.V);
+//   * the whole partition's scores stay in registers -> one max per partition, no online rescale;
+//   * P is rounded to bf16 for the P.V MFMA (fp32 accumulate), output normalised per partition;
+//   * all K and V loads of the partition are issued before the first MFMA.
+template <int D32, int NT>
+__global__ void __launch_bounds__(64) paged_attn_mfma_kernel(const PAParams p) {
+    constexpr int D = 32 * D32, NTD = D / 16;
+    const int hk = blockIdx.x, b = blockIdx.y, part = blockIdx.z;
+    const int ctx = (int)p.context_lens[b];
+    const int t0 = part * p.partition_size;
+    if (t0 >= ctx) return;
+    const int t1 = min(ctx, t0 + p.partition_size);
+    const int G = p.H / p.Hkv, bs = p.block_size;
+    const int lane = threadIdx.x, c = lane & 15, kg = lane >> 4;
+    const uint16_t* kc = static_cast<const uint16_t*>(p.kc);
+    const uint16_t* vc = static_cast<const uint16_t*>(p.vc);
+    const uint32_t* bt = p.block_tables + (int64_t)b * p.max_blocks;
+
+    // block ids of the NT tiles (a 16-token tile never straddles a block: t0 % 16 == 0, bs % 16 == 0)
+    int64_t blk[NT];
+    int off[NT];
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+        const int tok0 = t0 + 16 * it;
+        const bool live = tok0 < t1;
+        blk[it] = live ? (int64_t)bt[tok0 / bs] : (int64_t)bt[t0 / bs];
+        off[it] = live ? tok0 % bs : t0 % bs;
+    }
+    // Q^T fragments: lane (head c, kg) holds Q[head][32j + 8kg .. +8]
+    uint4 qf[D32];
+#pragma unroll
+    for (int j = 0; j < D32; ++j) {
+        qf[j] = make_uint4(0, 0, 0, 0);
+        if (c < G)
+            qf[j] = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_stride +
+                                                    (int64_t)(hk * G + c) * D + 32 * j + 8 * kg);
+    }
+    // all K and V fragments of the partition
+    uint4 kf[NT][D32];
+    uint2 vf[NT][NTD];
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+        const uint16_t* kb = kc + ((blk[it] * p.Hkv + hk) * (D / 8)) * (int64_t)bs * 8 + (int64_t)(off[it] + c) * 8;
+#pragma unroll
+        for (int j = 0; j < D32; ++j) kf[it][j] = *reinterpret_cast<const uint4*>(kb + (int64_t)(4 * j + kg) * bs * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+        const uint16_t* vb = vc + ((blk[it] * p.Hkv + hk) * D + c) * (int64_t)bs + off[it] + 4 * kg;
+#pragma unroll
+        for (int nt = 0; nt < NTD; ++nt) vf[it][nt] = *reinterpret_cast<const uint2*>(vb + (int64_t)(16 * nt) * bs);
+    }
+    // ---- S^T = K . Q^T : lane (head c, tokens 4kg+v)
+    float sc[NT][4];
+    float m = -1e30f;
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < D32; ++j)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[it][j]),
+                                                          __builtin_bit_cast(bf16x8_t, qf[j]), acc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            float s = acc[v] * p.scale;
+            if (p.softcap > 0.f) s = tanhf(s / p.softcap) * p.softcap;
+            const bool ok = t0 + 16 * it + 4 * kg + v < t1;
+            s = ok ? s : -1e30f;
+            sc[it][v] = s;
+            m = fmaxf(m, s);
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float lsum = 0.f;
+    uint2 pf[NT];
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+        float pr[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const bool ok = t0 + 16 * it + 4 * kg + v < t1;
+            pr[v] = ok ? __expf(sc[it][v] - m) : 0.f;
+        }
+        pf[it] = make_uint2(cvt_pk_bf16(pr[0], pr[1]), cvt_pk_bf16(pr[2], pr[3]));
+        // the normaliser must match what the MFMA sums: the bf16-rounded probabilities
+        lsum += (bf16lo_to_f32(pf[it].x) + bf16hi_to_f32(pf[it].x)) + (bf16lo_to_f32(pf[it].y) + bf16hi_to_f32(pf[it].y));
+    }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    // ---- O = P . V : lane (channel 16nt + c, heads 4kg+v)
+    f32x4_t o[NTD];
+#pragma unroll
+    for (int nt = 0; nt < NTD; ++nt) o[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+        const bool partial = t0 + 16 * it + 16 > t1;              // tile reaches beyond the context
+#pragma unroll
+        for (int nt = 0; nt < NTD; ++nt) {
+            uint2 vv = vf[it][nt];
+            if (partial) {                                        // never multiply 0 by unwritten (maybe NaN) V
+                const int tk = t0 + 16 * it + 4 * kg;
+                if (tk + 0 >= t1) vv.x &= 0xFFFF0000u;
+                if (tk + 1 >= t1) vv.x &= 0x0000FFFFu;
+                if (tk + 2 >= t1) vv.y &= 0xFFFF0000u;
+                if (tk + 3 >= t1) vv.y &= 0x0000FFFFu;
+            }
+            o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, pf[it]),
+                                                              __builtin_bit_cast(s16x4_t, vv), o[nt], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: rows (heads 4kg+v) need the column statistics of lane (4kg+v)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int head = 4 * kg + v;
+        const float lh = __shfl(lsum, head, 64), mh = __shfl(m, head, 64);
+        if (head >= G) continue;
+        const int h = hk * G + head;
+        const float inv = lh > 0.f ? 1.f / lh : 0.f;
+        if (p.max_partitions > 1) {
+            const int64_t pi = ((int64_t)b * p.H + h) * p.max_partitions + part;
+#pragma unroll
+            for (int nt = 0; nt < NTD; ++nt) p.tmp_out[pi * D + 16 * nt + c] = o[nt][v] * inv;
+            if (c == 0) { p.max_logits[pi] = mh; p.exp_sums[pi] = lh; }
+        } else {
+            uint16_t* op = static_cast<uint16_t*>(p.out) + ((int64_t)b * p.H + h) * D;
+#pragma unroll
+            for (int nt = 0; nt < NTD; ++nt) op[16 * nt + c] = f32_to_bf16(o[nt][v] * inv);
+        }
+    }
+}
+
+template <int D32>
+static int launch_mfma(const PAParams& p, int B, int P, hipStream_t st) {
+    dim3 grid(p.Hkv, B, P), block(64);
+    const int nt = p.partition_size / 16;
+    if (nt == 2) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 2>), grid, block, 0, st, p);
+    else if (nt == 4) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 4>), grid, block, 0, st, p);
+    else if (nt == 8) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 8>), grid, block, 0, st, p);
+    else return (int)hipErrorInvalidValue;
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 template <int LPT, int KVT, bool PART>
 static int launch_flash_g(const PAParams& p, int B, int P, hipStream_t st) {
     const int G = p.H / p.Hkv;
-    dim3 grid(p.Hkv, B, P), block(PA_THREADS);
-    if (G <= 1) hipLaunchKernelGGL((paged_attn_flash_kernel<LPT, 1, KVT, PART>), grid, block, 0, st, p);
-    else if (G <= 2) hipLaunchKernelGGL((paged_attn_flash_kernel<LPT, 2, KVT, PART>), grid, block, 0, st, p);
-    else if (G <= 4) hipLaunchKernelGGL((paged_attn_flash_kernel<LPT, 4, KVT, PART>), grid, block, 0, st, p);
-    else if (G <= 8) hipLaunchKernelGGL((paged_attn_flash_kernel<LPT, 8, KVT, PART>), grid, block, 0, st, p);
+    constexpr int NWV = PART ? 1 : 4;                   // v2: one wave per partition; v1: 4 waves + LDS merge
+    constexpr int UNR = PART ? 8 : 4;
+    dim3 grid(p.Hkv, B, P), block(64 * NWV);
+    if (G <= 1) hipLaunchKernelGGL((paged_attn_flash_kernel<LPT, 1, KVT, PART, NWV, UNR>), grid, block, 0, st, p);
+    else if (G <= 2) hipLaunchKernelGGL((paged_attn_flash_kernel<LPT, 2, KVT, PART, NWV, UNR>), grid, block, 0, st, p);
+    else if (G <= 4) hipLaunchKernelGGL((paged_attn_flash_kernel<LPT, 4, KVT, PART, NWV, UNR>), grid, block, 0, st, p);
+    else if (G <= 8) hipLaunchKernelGGL((paged_attn_flash_kernel<LPT, 8, KVT, PART, NWV, UNR>), grid, block, 0, st, p);
     else return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
 }
@@ -386,6 +563,10 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
         else
             rc = (dtype == MI355_DTYPE_BF16) ? launch_flash<MI355_DTYPE_BF16, false>(p, B, P, st)
                                              : launch_flash<MI355_DTYPE_F16, false>(p, B, P, st);
+    } else if (layout == MI355_KV_PAGED && dtype == MI355_DTYPE_BF16 && (p.D == 128 || p.D == 64) &&
+               p.H / p.Hkv <= 16 && (p.block_size % 16) == 0 &&
+               (p.partition_size == 32 || p.partition_size == 64 || p.partition_size == 128)) {
+        rc = (p.D == 128) ? launch_mfma<4>(p, B, P, st) : launch_mfma<2>(p, B, P, st);
     } else if (layout == MI355_KV_PAGED) {
         const size_t shm = (size_t)p.partition_size * sizeof(float);
         if (shm > 60 * 1024) return (int)hipErrorInvalidValue;   // caller must partition (v2) long contexts

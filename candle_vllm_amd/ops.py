@@ -154,8 +154,8 @@ def reshape_and_cache(k, v, key_cache, value_cache, slot_mapping):
 
 
 # ----------------------------------------------------------------------------------------------- attention
-V1_MAX_CONTEXT = 512          # above this the context is partitioned (v2), vLLM-style
-TARGET_WORKGROUPS = 1024      # >> 256 CUs
+V1_MAX_CONTEXT = 256          # above this the context is partitioned (v2), vLLM-style
+TARGET_WORKGROUPS = 2048      # one wave per partition: ~8 waves per CU
 
 
 def choose_partition(num_seqs, num_kv_heads, max_context_len):
@@ -164,7 +164,7 @@ def choose_partition(num_seqs, num_kv_heads, max_context_len):
         return 0
     per_seq = max(1, -(-TARGET_WORKGROUPS // max(1, num_seqs * num_kv_heads)))
     ps = -(-max_context_len // per_seq)
-    ps = max(64, ((ps + 63) // 64) * 64)
+    ps = max(32, ((ps + 31) // 32) * 32)
     return ps if ps < max_context_len else 0
 
 

@@ -1,4 +1,3 @@
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r01 -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 64 --warmup 8 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/bench_prof.json 2>/dev/null
-ls -R $GRAFT_REPO_ROOT/gpurun_out/prof_r01 | head -20
+timeout 150 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof6 -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 32 --warmup 8 --no-cpu-baseline > /dev/null 2>&1
