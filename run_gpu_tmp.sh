@@ -1,3 +1,6 @@
 mkdir -p gpurun_out
-cd /tmp && export TMPDIR=/tmp
-timeout 150 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof6 -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 32 --warmup 8 --no-cpu-baseline > /dev/null 2>&1
+timeout 200 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -15
+timeout 200 python bench.py --batch 32 --ctx 2688 --steps 16 --warmup 4 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(d['value'],'tok/s', d['ms_per_step'],'ms', d['step'])
+for g in d['roofline']['groups']: print(g)"

@@ -304,18 +304,21 @@ def test_qmatmul_random_bytes_all_code_points(cv):
         assert rel_err(mm.forward(dev(x)).cpu().numpy(), kq.qmatmul_o1(x, blocks, t)) < 1e-4
 
 
-def test_fused_norm_qkv_rope_cache(cv):
-    """[RMSNorm -> wq,wk,wv -> interleaved RoPE -> bf16 -> q_out / paged cache] == composition of oracles."""
+@pytest.mark.parametrize("B", [3, 12, 32])
+def test_fused_norm_qkv_rope_cache(cv, B):
+    """[RMSNorm -> wq,wk,wv -> interleaved RoPE -> bf16 -> q_out / paged cache] == composition of oracles
+    (B=3: per-wave kernel, B=12/32: wide-batch kernel)."""
     rng = np.random.default_rng(14)
-    hid, H, Hkv, D, bs, NB, B = 1024, 8, 2, 128, 64, 6, 3
+    hid, H, Hkv, D, bs, NB = 1024, 8, 2, 128, 64, 6
     types = (kq.GGML_Q4_K, kq.GGML_Q4_K, kq.GGML_Q6_K)
     Ws = [kq.quantize(rng.normal(0, 0.05, (n, hid)).astype(np.float32), t)
           for n, t in zip((H * D, Hkv * D, Hkv * D), types)]
     mats = [cv.QMatMul(w, t, "cuda") for w, t in zip(Ws, types)]
     x = rng.normal(size=(B, hid)).astype(np.float32)
     nw = (1 + rng.normal(0, 0.1, hid)).astype(np.float32)
-    pos = np.array([5, 130, 64], np.int64)
-    slots = np.array([70, -1, 200], np.int64)
+    pos = rng.integers(0, 500, B).astype(np.int64)
+    slots = rng.permutation(NB * bs)[:B].astype(np.int64)
+    slots[1] = -1
     cos, sin = O.rope_tables(500000.0, D, 512)
     for flash in (True, False):
         ks, vs = O.kv_cache_shapes(NB, bs, Hkv, D, 2, flash)
@@ -344,9 +347,10 @@ def test_fused_norm_qkv_rope_cache(cv):
         assert np.abs(O.bf16_bits_to_f32(gvb[wv]) - O.bf16_bits_to_f32(vref[wv])).max() <= 2 ** -7 * np.abs(v).max()
 
 
-def test_fused_silu_pair_and_residual(cv):
+@pytest.mark.parametrize("B", [2, 9, 32])
+def test_fused_silu_pair_and_residual(cv, B):
     rng = np.random.default_rng(15)
-    hid, I, B = 1024, 512, 2
+    hid, I = 1024, 512
     wg = kq.quantize(rng.normal(0, 0.05, (I, hid)).astype(np.float32), kq.GGML_Q4_K)
     wu = kq.quantize(rng.normal(0, 0.05, (I, hid)).astype(np.float32), kq.GGML_Q4_K)
     wd = kq.quantize(rng.normal(0, 0.05, (hid, I)).astype(np.float32), kq.GGML_Q6_K)
