@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-batch32", action="store_true", help="skip the secondary batch-32 measurement")
+    ap.add_argument("--b32-steps", type=int, default=24)
     ap.add_argument("--kv-layout", choices=["flash", "paged"], default="paged",
                     help="paged = vLLM layout (reference default without flash-attn features; MFMA attention), "
                          "flash = [NB,bs,Hkv,D]")
@@ -84,6 +86,35 @@ def cpu_baseline(cfg, steps, ctx=64):
                       f"candle-CPU-style Q8_K integer dot (oracle/oracle.c, OpenMP), best step; setup {setup:.1f}s"}
 
 
+def bench_batch32(gm, cfg, args, perm, blocks_per_seq, stream, kv_per_tok):
+    """Secondary measurement of BASELINE's metric at batch 32 (same weights, ragged contexts U[256,4096],
+    shuffled block tables, hipGraph replay, greedy tokens read back every step)."""
+    import torch
+    B, K, Wm = 32, args.b32_steps, 4
+    rng = np.random.default_rng(4321)
+    seq_lens = rng.integers(256, 4097, B).astype(np.uint32)
+    bt = perm[: B * blocks_per_seq].reshape(B, blocks_per_seq).astype(np.uint32)
+    tokens = rng.integers(0, cfg.vocab, B).astype(np.uint32)
+    st = stream.cuda_stream
+    gm.decode_begin(tokens, seq_lens, bt, ctx_cap=int(seq_lens.max()) + K + Wm + 2, stream=st)
+    for _ in range(Wm):
+        gm.decode_step(st)
+        gm.read_tokens(st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        gm.decode_step(st)
+        gm.read_tokens(st)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    mean_ctx = float(seq_lens.mean()) + Wm + (K - 1) / 2.0
+    step_bytes = gm.weight_bytes_global + B * (mean_ctx + 1) * kv_per_tok
+    return {"value": round(B * K / dt, 1), "unit": "tokens/s", "batch": B, "steps": K, "ms_per_step": round(1e3 * dt / K, 3),
+            "mean_ctx": round(mean_ctx, 1), "algorithmic_bytes": int(step_bytes),
+            "achieved_GBs": round(step_bytes * K / dt / 1e9, 1),
+            "roofline_tok_s_at_8TBs": round(B * HBM_PEAK_GBS * 1e9 / step_bytes, 1)}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -108,10 +139,12 @@ def main():
         cfg.n_layers = args.layers
         invalid = "debug run with fewer layers"
     B, K, Wm = args.batch, args.steps, args.warmup
-    blocks_per_seq = -(-(args.ctx + K + Wm + 2) // cfg.block_size)
-    num_blocks = B * blocks_per_seq + 8
+    do_b32 = (not args.no_batch32) and world == 1 and B == 1
+    B32 = 32
+    blocks_per_seq = -(-(max(args.ctx, 4096 if do_b32 else 0) + max(K, args.b32_steps) + Wm + 2) // cfg.block_size)
+    num_blocks = (B32 if do_b32 else B) * blocks_per_seq + 8
     kv_layout = M.KV_PAGED if args.kv_layout == "paged" else M.KV_FLASH
-    gm = M.GGUFLLaMa(cfg, max_batch=B, max_blocks_per_seq=blocks_per_seq, kv_layout=kv_layout,
+    gm = M.GGUFLLaMa(cfg, max_batch=(B32 if do_b32 else B), max_blocks_per_seq=blocks_per_seq, kv_layout=kv_layout,
                      tp_rank=rank, tp_world=world)
     if world > 1:
         gm.init_comm(dist)
@@ -121,8 +154,8 @@ def main():
 
     # block tables: physical blocks in shuffled order (stresses the gather), identical on every rank
     rng = np.random.default_rng(1235)
-    perm = rng.permutation(num_blocks - 1)[: B * blocks_per_seq] + 1
-    bt = perm.reshape(B, blocks_per_seq).astype(np.uint32)
+    perm = rng.permutation(num_blocks - 1) + 1
+    bt = perm[: B * blocks_per_seq].reshape(B, blocks_per_seq).astype(np.uint32)
     tokens = rng.integers(0, cfg.vocab, B).astype(np.uint32)
     seq_lens = np.full(B, args.ctx + 1, np.uint32)            # prompt + the first generated token
     stream = torch.cuda.Stream()
@@ -178,6 +211,8 @@ def main():
         out["invalid"] = invalid
     if rank == 0:
         out["roofline"] = gm.dominant_kernel_roofline(stream, HBM_PEAK_GBS)
+        if do_b32:
+            out["batch32"] = bench_batch32(gm, cfg, args, perm, blocks_per_seq, stream, kv_per_tok)
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps)

@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -119,6 +120,7 @@ struct Model {
     bool use_graph = true;
     // tensor parallel
     void* comm = nullptr;           // ncclComm_t
+    bool use_comm = false;          // tp_world > 1, or forced (single-rank plumbing test: MI355_FORCE_COMM=1)
     float* logits_local = nullptr;  // [B, vocab/W]
     float* logits_gather = nullptr; // [W, B, vocab/W]
 };
@@ -171,7 +173,7 @@ __global__ void gather_transpose_kernel(float* out, const float* in, int W, int 
 }
 
 int all_reduce_xs(Model* m, int B, int64_t st) {
-    if (m->cfg.tp_world <= 1) return 0;
+    if (!m->use_comm) return 0;
     if (!m->comm) return (int)hipErrorNotInitialized;
     // C1/C2: all-reduce(sum) of [B, hidden] after o_proj / down_proj (distributed.rs:696-711).  The reference
     // sends bf16 (attention.rs:1005-1009); we keep the f32 residual stream on the wire (decode messages are
@@ -197,7 +199,7 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
         d.x = m->xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
         d.norm_weight = m->output_norm; d.norm_eps = c.rms_eps;
         d.epilogue = MI355_EPI_STORE; d.ldo = m->output.n_rows;
-        if (c.tp_world <= 1) { d.out = logits; return mi355_qmatmul_fused(&d, st); }
+        if (!m->use_comm) { d.out = logits; return mi355_qmatmul_fused(&d, st); }
         d.out = m->logits_local;
         RCHECK(mi355_qmatmul_fused(&d, st));
         if (!m->comm) return (int)hipErrorNotInitialized;
@@ -318,6 +320,8 @@ extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
     Model* m = new Model();
     m->cfg = *cfg;
     if (m->cfg.tp_world <= 0) { m->cfg.tp_world = 1; m->cfg.tp_rank = 0; }
+    const char* force = getenv("MI355_FORCE_COMM");
+    m->use_comm = m->cfg.tp_world > 1 || (force && force[0] == '1');
     m->layers.resize(cfg->n_layers);
     const int B = cfg->max_batch, H = local_heads(m), D = cfg->head_dim;
     bool ok = true;
@@ -327,7 +331,7 @@ extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
     alloc((void**)&m->attn, (size_t)B * H * D * 2);
     alloc((void**)&m->h, (size_t)B * cfg->intermediate * 4);
     alloc((void**)&m->logits, (size_t)B * cfg->vocab * 4);
-    if (m->cfg.tp_world > 1) {
+    if (m->use_comm) {
         alloc((void**)&m->logits_local, (size_t)B * cfg->vocab * 4 / m->cfg.tp_world + 64);
         alloc((void**)&m->logits_gather, (size_t)B * cfg->vocab * 4 + 64 * m->cfg.tp_world);
     }
@@ -535,7 +539,7 @@ extern "C" int mi355_llama_decode_step(void* mp, int64_t stream) {
     Model* m = static_cast<Model*>(mp);
     if (!m || m->cur_batch < 1) return (int)hipErrorInvalidValue;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (!m->use_graph || stream == 0 || m->cfg.tp_world > 1) return record_step(m, stream);   // TP: eager (RCCL in-stream)
+    if (!m->use_graph || stream == 0 || m->use_comm) return record_step(m, stream);   // TP: eager (RCCL in-stream)
     if (m->w_batch != m->cur_batch || m->w_max_blocks != m->cur_max_blocks || m->w_ctx_cap != m->cur_ctx_cap) {
         // first step of a new shape runs eagerly: lazily-set kernel attributes and occupancy queries must not
         // happen inside a stream capture

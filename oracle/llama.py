@@ -94,8 +94,11 @@ def _qmm(x, tw, o2):
 
 
 class OracleLlama:
-    def __init__(self, cfg, W, flash_layout=True, o2=False):
-        self.cfg, self.W, self.flash, self.o2 = cfg, W, flash_layout, o2
+    def __init__(self, cfg, W, flash_layout=True, o2=False, comm=None):
+        """comm: None, or an object with all_reduce(np.ndarray)->np.ndarray and all_gather(np.ndarray)->list
+        (tensor-parallel run: cfg/W are then the LOCAL shard, see candle_vllm_amd/tp.py; collectives C1/C2/C3
+        of src/openai/distributed.rs:696-711,1632-1667)."""
+        self.cfg, self.W, self.flash, self.o2, self.comm = cfg, W, flash_layout, o2, comm
         self.cos, self.sin = ops.rope_tables(cfg.rope_theta, cfg.head_dim, cfg.max_seq)
         self.scale = 1.0 / np.sqrt(float(cfg.head_dim))
 
@@ -134,14 +137,22 @@ class OracleLlama:
                                                self.scale, self.flash)
             y = y.reshape(T, c.n_heads * c.head_dim)
             attn = _qmm(y, lw["wo"], self.o2)
+            if self.comm is not None:
+                attn = self.comm.all_reduce(attn)                      # C1 (attention.rs:1005-1009)
             xs = attn + xs
             x = ops.rms_norm(xs, lw["ffn_norm"], c.rms_eps)
             h = ops.silu_mul(_qmm(x, lw["w1"], self.o2), _qmm(x, lw["w3"], self.o2))
-            xs = _qmm(h, lw["w2"], self.o2) + xs
+            mlp = _qmm(h, lw["w2"], self.o2)
+            if self.comm is not None:
+                mlp = self.comm.all_reduce(mlp)                        # C2 (quantized_llama.rs:38-42)
+            xs = mlp + xs
             if trace is not None:
                 trace.append(xs.copy())
         if is_prefill:
             idx = np.asarray(meta["cu_seqlens_q"][1:], np.int64) - 1
             xs = xs[idx]
         xs = ops.rms_norm(xs, W["output_norm"], c.rms_eps)
-        return _qmm(xs, W["output"], self.o2)
+        logits = _qmm(xs, W["output"], self.o2)
+        if self.comm is not None:                                      # C3: vocab-parallel all-gather
+            logits = np.concatenate(self.comm.all_gather(logits), axis=-1)
+        return logits

@@ -1,6 +1,5 @@
 mkdir -p gpurun_out
-timeout 200 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -15
-timeout 200 python bench.py --batch 32 --ctx 2688 --steps 16 --warmup 4 --no-cpu-baseline 2>&1 | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(d['value'],'tok/s', d['ms_per_step'],'ms', d['step'])
-for g in d['roofline']['groups']: print(g)"
+timeout 280 python bench.py > gpurun_out/bench2.json 2> gpurun_out/bench2.err; tail -2 gpurun_out/bench2.err
+python -c "
+import json
+d=json.load(open('gpurun_out/bench2.json')); print(d['value'],'tok/s', d['ms_per_step'],'ms'); print(d['batch32']); print(d['cpu_baseline']); print(d['roofline']['kernel'], d['roofline']['achieved'], d['roofline']['frac'])"

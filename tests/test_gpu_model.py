@@ -97,3 +97,21 @@ def test_greedy_decode_loop_graph_equals_eager_equals_oracle(lib):
     ref_last = orc.forward(O.prepare_decode([{"tokens": s["tokens"][:-1], "block_table": s["block_table"]} for s in o_seqs],
                                             cfg.block_size), [(k.copy(), v.copy()) for k, v in o_cache])
     assert _rel(last, ref_last) < 1e-3
+
+
+def test_rccl_plumbing_single_rank(lib, monkeypatch):
+    """The tensor-parallel code path (RCCL through dlopen: unique id, comm init, in-stream all-reduce of the
+    residual stream, all-gather + transpose of the logits) with a 1-rank communicator must reproduce the
+    plain step.  Multi-GPU runs are the driver's; this pins the plumbing on the one GPU we have."""
+    monkeypatch.setenv("MI355_FORCE_COMM", "1")
+    cfg, orc, gm, seqs, cache = _setup(lib, True)
+
+    class _Dist:                                       # single process: broadcast is the identity
+        @staticmethod
+        def broadcast(t, src=0):
+            return None
+    gm.init_comm(_Dist)
+    meta = O.prepare_decode(seqs, cfg.block_size)
+    ref = orc.forward(meta, cache)
+    got = gm.forward_decode(meta).cpu().numpy()
+    assert _rel(got, ref) < 1e-3
