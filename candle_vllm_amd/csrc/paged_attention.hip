@@ -64,6 +64,7 @@ struct PAParams {
     int max_partitions;        // P (stride of the v2 temporaries); 1 for v1
     float scale, softcap;      // softcap <= 0 -> disabled
     int64_t q_stride;          // elements between sequences in q (H*D when contiguous)
+    unsigned* arrive;          // [B*Hkv] arrival counters (zero between launches) or null: fused partition merge
 };
 
 // NWV waves per workgroup.  The partitioned (v2) path runs ONE wave per workgroup (no LDS, no barrier: a
@@ -506,13 +507,87 @@ __global__ void __launch_bounds__(64) paged_attn_mfma_kernel(const PAParams p) {
         const float inv = lh > 0.f ? 1.f / lh : 0.f;
         if (p.max_partitions > 1) {
             const int64_t pi = ((int64_t)b * p.H + h) * p.max_partitions + part;
+            if (p.arrive) {
+                // fused merge: partials go out WRITE-THROUGH (sc1: relaxed agent-scope stores), so the hand-off
+                // needs no release fence (a release would write back the whole L2 from every wave)
 #pragma unroll
-            for (int nt = 0; nt < NTD; ++nt) p.tmp_out[pi * D + 16 * nt + c] = o[nt][v] * inv;
-            if (c == 0) { p.max_logits[pi] = mh; p.exp_sums[pi] = lh; }
+                for (int nt = 0; nt < NTD; ++nt)
+                    __hip_atomic_store(p.tmp_out + pi * D + 16 * nt + c, o[nt][v] * inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c == 0) {
+                    __hip_atomic_store(p.max_logits + pi, mh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p.exp_sums + pi, lh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < NTD; ++nt) p.tmp_out[pi * D + 16 * nt + c] = o[nt][v] * inv;
+                if (c == 0) { p.max_logits[pi] = mh; p.exp_sums[pi] = lh; }
+            }
         } else {
             uint16_t* op = static_cast<uint16_t*>(p.out) + ((int64_t)b * p.H + h) * D;
 #pragma unroll
             for (int nt = 0; nt < NTD; ++nt) op[16 * nt + c] = f32_to_bf16(o[nt][v] * inv);
+        }
+    }
+    if (p.max_partitions <= 1 || p.arrive == nullptr) return;
+
+    // ---- fused merge of the partitions (replaces the separate reduce launch): the wave that arrives last for
+    // this (sequence, kv head) merges all partials.  Placement-independent hand-off (guide G16, form R1): the
+    // payload was stored write-through, every wave drains its stores, then takes an arrival ticket; the last
+    // arriver does ONE agent-scope acquire and reads with plain loads.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(p.arrive + (int64_t)b * p.Hkv + hk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __shfl(ticket, 0, 64);
+    const int P = (ctx + p.partition_size - 1) / p.partition_size;
+    if ((int)ticket != P - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (lane == 0) __hip_atomic_store(p.arrive + (int64_t)b * p.Hkv + hk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    constexpr int DL = D / 16;                                     // channels per lane: 16 lanes cover one head
+    for (int g0 = 0; g0 < G; g0 += 4) {
+        const int g = g0 + kg;                                     // 4 heads in flight, 16 lanes each
+        const bool gl = g < G;
+        const int64_t pi0 = ((int64_t)b * p.H + hk * G + (gl ? g : 0)) * p.max_partitions;
+        float M = -1e30f;
+        for (int q = c; q < P; q += 16) M = fmaxf(M, p.max_logits[pi0 + q]);
+        M = fmaxf(M, __shfl_xor(M, 8, 64));
+        M = fmaxf(M, __shfl_xor(M, 4, 64));
+        M = fmaxf(M, __shfl_xor(M, 2, 64));
+        M = fmaxf(M, __shfl_xor(M, 1, 64));
+        float accv[DL];
+#pragma unroll
+        for (int e = 0; e < DL; ++e) accv[e] = 0.f;
+        float den = 0.f;
+        constexpr int MU = 4;                                      // partials in flight per lane
+        for (int q0 = 0; q0 < P; q0 += MU) {
+            float4 t[MU][DL / 4];
+            float es[MU], ml[MU];
+#pragma unroll
+            for (int u = 0; u < MU; ++u) {
+                const int q = (q0 + u < P) ? q0 + u : P - 1;
+                es[u] = p.exp_sums[pi0 + q];
+                ml[u] = p.max_logits[pi0 + q];
+                const float4* tp = reinterpret_cast<const float4*>(p.tmp_out + (pi0 + q) * D + c * DL);
+#pragma unroll
+                for (int e = 0; e < DL / 4; ++e) t[u][e] = tp[e];
+            }
+#pragma unroll
+            for (int u = 0; u < MU; ++u) {
+                const float wq = (q0 + u < P) ? es[u] * __expf(ml[u] - M) : 0.f;
+                den += wq;
+#pragma unroll
+                for (int e = 0; e < DL / 4; ++e) {
+                    accv[4 * e + 0] = fmaf(t[u][e].x, wq, accv[4 * e + 0]);
+                    accv[4 * e + 1] = fmaf(t[u][e].y, wq, accv[4 * e + 1]);
+                    accv[4 * e + 2] = fmaf(t[u][e].z, wq, accv[4 * e + 2]);
+                    accv[4 * e + 3] = fmaf(t[u][e].w, wq, accv[4 * e + 3]);
+                }
+            }
+        }
+        if (gl) {
+            const float inv = den > 0.f ? 1.f / den : 0.f;
+            uint16_t* op = static_cast<uint16_t*>(p.out) + ((int64_t)b * p.H + hk * G + g) * D + c * DL;
+#pragma unroll
+            for (int e = 0; e < DL; ++e) op[e] = f32_to_bf16(accv[e] * inv);
         }
     }
 }
@@ -550,6 +625,10 @@ static int launch_flash(const PAParams& p, int B, int P, hipStream_t st) {
     return (int)hipErrorInvalidValue;
 }
 
+static unsigned* g_pa_arrive = nullptr;
+#define PA_ARRIVE_SLOTS 65536
+static int g_pa_fused = 1;                                          // mi355_set_tuning(3, 0) -> separate reduce launch
+
 static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t stream) {
     if (B <= 0) return 0;
     if (p.H % p.Hkv || (p.D & 7) || p.D > 256) return (int)hipErrorInvalidValue;
@@ -566,7 +645,18 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
     } else if (layout == MI355_KV_PAGED && dtype == MI355_DTYPE_BF16 && (p.D == 128 || p.D == 64) &&
                p.H / p.Hkv <= 16 && (p.block_size % 16) == 0 &&
                (p.partition_size == 32 || p.partition_size == 64 || p.partition_size == 128)) {
+        bool fused = false;
+        // the in-kernel merge is one wave per (sequence, kv head): worth it only when there are many of them
+        if (P > 1 && g_pa_fused && (int64_t)B * p.Hkv >= (g_pa_fused > 1 ? 1 : 64) && (int64_t)B * p.Hkv <= PA_ARRIVE_SLOTS) {
+            if (!g_pa_arrive) {                                     // first call (eager warm-up), never in a capture
+                if (hipMalloc((void**)&g_pa_arrive, PA_ARRIVE_SLOTS * 4) != hipSuccess) return (int)hipErrorOutOfMemory;
+                if (hipMemset(g_pa_arrive, 0, PA_ARRIVE_SLOTS * 4) != hipSuccess) return (int)hipErrorUnknown;
+            }
+            p.arrive = g_pa_arrive;
+            fused = true;
+        }
         rc = (p.D == 128) ? launch_mfma<4>(p, B, P, st) : launch_mfma<2>(p, B, P, st);
+        if (fused) return rc;
     } else if (layout == MI355_KV_PAGED) {
         const size_t shm = (size_t)p.partition_size * sizeof(float);
         if (shm > 60 * 1024) return (int)hipErrorInvalidValue;   // caller must partition (v2) long contexts
@@ -591,6 +681,8 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
                            p.max_logits, p.exp_sums, p.context_lens, p.H, p.D, p.partition_size, p.max_partitions);
     return (int)hipGetLastError();
 }
+
+void mi355_pa_set_fused(int v) { g_pa_fused = v; }
 
 extern "C" int mi355_paged_attention_v1(void* out, const void* q, const void* key_cache, const void* value_cache,
                                         const uint32_t* block_tables, const uint32_t* context_lens,

@@ -1017,11 +1017,13 @@ static int qmw_launch_mt(const QmmArgs& a, int wt, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------ launcher
+void mi355_pa_set_fused(int v);
 static int g_tune_nw = 0, g_tune_r = 0, g_tune_dbg = 0;   // 0 = heuristic; mi355_set_tuning (experiments only)
 extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     if (key == 0) g_tune_nw = value;
     else if (key == 1) g_tune_r = value;
     else if (key == 2) g_tune_dbg = value;
+    else if (key == 3) mi355_pa_set_fused(value);
 }
 
 static size_t qmm_lds_bytes(int BT, int R, int NW) {

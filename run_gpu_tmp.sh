@@ -1,5 +1,6 @@
 mkdir -p gpurun_out
-timeout 280 python bench.py > gpurun_out/bench2.json 2> gpurun_out/bench2.err; tail -2 gpurun_out/bench2.err
-python -c "
-import json
-d=json.load(open('gpurun_out/bench2.json')); print(d['value'],'tok/s', d['ms_per_step'],'ms'); print(d['batch32']); print(d['cpu_baseline']); print(d['roofline']['kernel'], d['roofline']['achieved'], d['roofline']['frac'])"
+timeout 200 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -8
+timeout 200 python bench.py --steps 64 --warmup 8 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print(d['value'],'tok/s', d['ms_per_step'],'ms'); print(d['batch32'])
+for g in d['roofline']['groups'][1:2]: print(g)"

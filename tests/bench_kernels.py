@@ -131,6 +131,13 @@ def main():
         med, mn = timeit(f, flush=flush)
         auto = cv.choose_partition(B, Hkv, args.ctx + 1)
         report(f"paged_attn ps={'auto(%d)' % auto if ps is None else ps}", med, mn, kv_bytes)
+    # vLLM (paged) layout: MFMA kernel
+    kcp = torch.randn(NB, Hkv, D // 8, 64, 8, device=dev).to(torch.bfloat16)
+    vcp = torch.randn(NB, Hkv, D, 64, device=dev).to(torch.bfloat16)
+    for ps in (32, 64, 128):
+        f = lambda: pa.decode(q_out.view(B, H, D), kcp, vcp, meta, None, partition_size=ps)
+        med, mn = timeit(f, flush=flush)
+        report(f"paged_attn MFMA ps={ps}", med, mn, kv_bytes)
     # --- small ops
     f = lambda: cv.rms_norm(x, nw, 1e-5)
     med, mn = timeit(f)

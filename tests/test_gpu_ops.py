@@ -366,3 +366,33 @@ def test_fused_silu_pair_and_residual(cv, B):
     cv.qmatmul_fused([md], h, epilogue=cv.EPI_RESID, out=res, residual=res)      # in place: x += W2 h
     ref = x + kq.qmatmul_o1(h.cpu().numpy(), wd, 14)
     assert rel_err(res.cpu().numpy(), ref) < 1e-4
+
+
+def test_paged_attention_fused_merge_is_stable(cv):
+    """MFMA attention with the in-kernel last-arriver merge (agent-scope release/acquire hand-off) must agree with
+    the separate-reduce path on every one of many back-to-back launches, ragged batch, L2-warm."""
+    rng = np.random.default_rng(31)
+    H, Hkv, D, bs = 32, 8, 128, 64
+    ctx = [int(c) for c in rng.integers(200, 3000, 16)]
+    q, kc, vc, bt, cl = _attn_case(rng, len(ctx), H, Hkv, D, bs, ctx, False)
+    pa = cv.PagedAttention(H, D, 1 / np.sqrt(D), Hkv)
+    meta = cv.InputMetadata(False, dev(np.zeros(len(ctx), np.int64)), dev(bt.astype(np.int32)), dev(cl.astype(np.int32)),
+                            max_context_len=max(ctx))
+    qd, kcd, vcd = dev(q, torch.bfloat16), bf16_dev(kc), bf16_dev(vc)
+    cv.lib.mi355_set_tuning(3, 0)
+    ref = pa.decode(qd, kcd, vcd, meta, None, partition_size=64).float().cpu().numpy()
+    cv.lib.mi355_set_tuning(3, 2)                                  # 2 = force the fused merge for any batch
+    tol = 2 ** -7 * np.abs(ref).max()
+    for i in range(30):
+        qi = torch.roll(qd, i, 0) if i % 3 == 0 else qd            # vary the data now and then
+        got = pa.decode(qi, kcd, vcd, meta, None, partition_size=(32, 64, 128)[i % 3]).float().cpu().numpy()
+        if i % 3 == 0:
+            cv.lib.mi355_set_tuning(3, 0)
+            want = pa.decode(qi, kcd, vcd, meta, None, partition_size=64).float().cpu().numpy()
+            cv.lib.mi355_set_tuning(3, 2)
+        else:
+            want = ref
+        assert np.abs(got - want).max() <= tol, i
+    cv.lib.mi355_set_tuning(3, 1)
+    oracle = O.paged_attention_decode(q, kc, vc, bt, cl, 1 / np.sqrt(D), False)
+    assert np.abs(ref - oracle).max() <= tol
