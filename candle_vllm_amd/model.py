@@ -186,8 +186,18 @@ class GGUFLLaMa:
                           "bytes": int(nbytes), "GBs": round(nbytes / avg / 1e3, 1), "launches_per_step": L}
         dom = max(rows, key=lambda p: rows[p]["avg_us"] * L)
         r = rows[dom]
+        traffic = None
+        try:        # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
+            import json, os
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                              "profiles", "r01_pmc_traffic.json")))
+            if dom == 3 and self._batch == 1 and self.tp_world == 1:
+                e = pmc["kernels"]["void qmm_kernel<1, 2, 12>(QmmArgs) wgs=896"]
+                traffic = int(e["fetch_bytes_corrected"] + e["WRITE_SIZE_KiB_avg"] * 1024)
+        except Exception:
+            traffic = None
         return {"bound": "hbm", "kernel": r["kernel"], "achieved": r["GBs"], "peak": peak_gbs, "unit": "GB/s",
-                "frac": round(r["GBs"] / peak_gbs, 4), "traffic": None, "avg_us": r["avg_us"],
+                "frac": round(r["GBs"] / peak_gbs, 4), "traffic": traffic, "avg_us": r["avg_us"],
                 "algorithmic_bytes_per_launch": r["bytes"],
                 "timing": "hipEvent pairs around each launch on the step stream, eager, all layers x %d reps" % reps,
                 "groups": [rows[p] for p in sorted(rows)]}

@@ -1,6 +1,5 @@
 mkdir -p gpurun_out
-timeout 200 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -8
-timeout 200 python bench.py --steps 64 --warmup 8 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print(d['value'],'tok/s', d['ms_per_step'],'ms'); print(d['batch32'])
-for g in d['roofline']['groups'][1:2]: print(g)"
+cd /tmp && export TMPDIR=/tmp
+timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-batch32 --no-graph > /dev/null 2>&1
+timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $GRAFT_REPO_ROOT/gpurun_out/pmc_write -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-batch32 --no-graph > /dev/null 2>&1
+ls $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch $GRAFT_REPO_ROOT/gpurun_out/pmc_write
