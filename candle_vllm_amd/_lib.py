@@ -15,7 +15,7 @@ def declared_symbols(header_path=HEADER_PATH):
     """Every function name declared in the public header."""
     src = open(header_path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"^\s*(?:void\*?|int|int64_t|float\*)\s+(\w+)\s*\(", src, flags=re.M)
+    names = re.findall(r"^\s*(?:void\*?|int|int32_t|int64_t|float\*)\s+(\w+)\s*\(", src, flags=re.M)
     return sorted(set(names))
 
 
@@ -76,6 +76,15 @@ _sig("mi355_qweight_repack", ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_i64])
 _sig("mi355_qmatmul", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64])
 _sig("mi355_qmatmul_fused", ctypes.c_int, [ctypes.POINTER(QmmDesc), c_i64])
 _sig("mi355_set_tuning", None, [c_i32, c_i32])
+for _n in ("marlin_4bit_f16", "marlin_4bit_bf16", "marlin_awq_4bit_f16", "marlin_awq_4bit_bf16"):
+    _sig(_n, None, [c_vp] * 6 + [c_i32] * 3 + [c_vp, c_i32, c_i64])
+_sig("gemm_half_q_half_alt", None, [c_vp] * 6 + [c_i32] * 4 + [c_i64])
+_sig("gptq_repack", None, [c_vp, c_vp, c_i32, c_i32, c_i64])
+_sig("awq_repack", None, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
+_sig("mi355_marlin_scale_pos", c_i32, [c_i32, c_i32])
+_sig("mi355_marlin_zero_pos", c_i32, [c_i32])
+_sig("mi355_linear", ctypes.c_int, [c_vp] * 5 + [c_i32] * 5 + [c_i64])
+_sig("mi355_gptq_linear", ctypes.c_int, [c_vp] * 5 + [c_i32, c_i32, c_vp, c_vp] + [c_i32] * 6 + [c_i64])
 
 
 class LlamaConfig(ctypes.Structure):

@@ -1,0 +1,475 @@
+// Skinny (decode-shaped) linear layers on the reference's NATIVE weight layouts, for the safetensors path:
+//   K10  dense 16-bit   `Linear::forward`  y = x.W^T (+b)        src/openai/models/linear.rs:124-172
+//   K12  marlin_4bit_{bf16,f16}            y = x.(s*(q-8))       src/backend/gptq.rs:132-178
+//   K13  marlin_awq_4bit_*                 y = x.(s*(q-z))       src/backend/gptq.rs:116-131,148-162
+//   K14  gemm_half_q_half_alt (f16, act-order g_idx)             src/backend/gptq.rs:181-197
+//   K15  gptq_repack / awq_repack                                src/backend/gptq.rs:313-332
+// Decode is an HBM stream of the weights (2 B resp. ~0.53 B per weight, each read once); MFMA does the
+// contraction with the tokens on the M rows (16 tokens per M tile; activations are exactly 16-bit so no hi/lo
+// split is needed).  No LDS staging: weight fragments come straight from global memory in fragment order
+// (a 16x16x32 B-fragment is 8 consecutive k of one output row = 16 B of a dense row, or ONE u32 of a GPTQ
+// k-packed column), activation fragments straight from L2.
+//
+// Our packed 4-bit layout IS the GPTQ checkpoint layout qweight[k/8][n] (bits 4i.. = code of k = 8*row+i):
+// `gptq_repack` is therefore a copy and `awq_repack` is the only real transform (AWQ packs along n with the
+// interleave [0,2,4,6,1,3,5,7]).  Scales (and AWQ zero points) arrive Marlin-permuted from the reference's host
+// code (`marlin_permute_scales`, linear.rs:341-379; examples/convert_awq_marlin.py:72-115) and are un-permuted
+// by index arithmetic here.
+#include "common.h"
+#include "../../include/mi355_vllm.h"
+#include <hip/hip_runtime.h>
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int dg_u32x4 __attribute__((ext_vector_type(4)));
+
+enum { DW_DENSE = 0, DW_GPTQ4 = 1 };
+enum { SP_NONE = 0, SP_GROUPED = 1, SP_SINGLE = 2 };
+
+struct DenseArgs {
+    const void* w;            // DENSE: 16-bit [N][ldw] ; GPTQ4: u32 [K/8][N]
+    int32_t ldw;
+    const void* scales;       // GPTQ4: 16-bit [K/g][N]
+    const uint32_t* qzeros;   // packed zero points [K/g][N/8] or null
+    int32_t zmode, sperm;     // MI355_ZERO_* ; SP_*
+    int32_t group_size;       // resolved: multiple of 32, <= K
+    const void* x;            // 16-bit [T][ldx]
+    int32_t ldx, T, N, K;
+    void* out;                // 16-bit [T][ldo]
+    int32_t ldo;
+    const void* bias;         // 16-bit [N] or null
+    const void* resid;        // 16-bit [T][ldo] (EPI_RESID)
+    int32_t epi;              // MI355_EPI_STORE / RESID / SILU_MUL
+    int32_t pair_offset;      // SILU_MUL: rows of `up` start at pair_offset (packed gate_up weight, mlp.rs:324-352)
+};
+
+template <int DT> __device__ __forceinline__ float h2f(uint16_t h) {
+    return DT == MI355_DTYPE_BF16 ? bf16_to_f32(h) : f16_bits_to_f32(h);
+}
+template <int DT> __device__ __forceinline__ uint16_t f2h(float f) {
+    return DT == MI355_DTYPE_BF16 ? f32_to_bf16(f) : f32_to_f16_bits(f);
+}
+template <int DT> __device__ __forceinline__ float rnd(float f) { return h2f<DT>(f2h<DT>(f)); }
+
+template <int DT>
+__device__ __forceinline__ f32x4_t mfma32(const uint4& a, const uint4& b, const f32x4_t& c) {
+    if constexpr (DT == MI355_DTYPE_BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+// position of natural column n inside a Marlin-permuted row (inverse of linear.rs:341-379)
+//   grouped: new[64c + 8i + j] = old[64c + i + 8j]
+//   single : new[32c + 8i + jj] = old[32c + 2i + {0,1,8,9,16,17,24,25}[jj]]
+__host__ __device__ __forceinline__ int marlin_scale_pos(int n, int sperm) {
+    if (sperm == SP_GROUPED) {
+        const int c = n & 63;
+        return (n & ~63) + 8 * (c & 7) + (c >> 3);
+    }
+    if (sperm == SP_SINGLE) {
+        const int c = n & 31;
+        return (n & ~31) + 8 * ((c >> 1) & 3) + 2 * (c >> 3) + (c & 1);
+    }
+    return n;
+}
+
+__device__ __forceinline__ float zero_point(const DenseArgs& a, int g, int col) {
+    if (a.zmode == MI355_ZERO_SYM8 || !a.qzeros) return 8.f;
+    if (a.zmode == MI355_ZERO_GPTQ_PLUS1)   // AutoGPTQ v1: stored zero = z - 1, nibble n%8 of qzeros[g][n/8]
+        return (float)(((a.qzeros[(size_t)g * (a.N / 8) + col / 8] >> (4 * (col & 7))) & 0xF) + 1);
+    // marlin zero points (convert_awq_marlin.py:72-91): scale_perm, then interleave [0,2,4,6,1,3,5,7], then pack
+    const int p1 = marlin_scale_pos(col, SP_GROUPED);
+    const int u = p1 & 7;
+    const int t = ((u & 1) << 2) | (u >> 1);            // argsort([0,2,4,6,1,3,5,7]) = [0,4,1,5,2,6,3,7]
+    const int p2 = (p1 & ~7) + t;
+    return (float)((a.qzeros[(size_t)g * (a.N / 8) + p2 / 8] >> (4 * (p2 & 7))) & 0xF);
+}
+
+// One workgroup = R row tiles (R = 2 for the packed gate/up pair) x all of K; the waves split the 256-wide
+// k-blocks; MT = ceil(T/16) M tiles.  GJ (4-bit only) = 32-wide k runs per quantisation group inside a k-block
+// (group 32/64/128/>=256 -> 1/2/4/8): the MFMA chain runs over a whole group and the scale is applied once.
+template <int DT, int WTYPE, int MT, int R, int GJ>
+__global__ void __launch_bounds__(512) dense_kernel(const DenseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float dg_red[];   // [NW][R][MT][16 m][16 rows]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int nkb = a.K >> 8;
+    int row0[R];
+    row0[0] = blockIdx.x * 16;
+    if (R == 2) row0[R - 1] = a.pair_offset + blockIdx.x * 16;
+    const uint16_t* x16 = static_cast<const uint16_t*>(a.x);
+
+    f32x4_t y[R][MT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) y[r][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int kb = wave; kb < nkb; kb += NW) {
+        // ---- all loads of this k-block first: 8 weight fragments per tile, 8 activation fragments per M tile
+        uint4 bw[R][8];
+        uint4 aw[MT][8];
+        if constexpr (WTYPE == DW_DENSE) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint16_t* wp = static_cast<const uint16_t*>(a.w) + (size_t)(row0[r] + r16) * a.ldw + (size_t)kb * 256 + 8 * kg;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const dg_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const dg_u32x4*>(wp + 32 * j));
+                    bw[r][j] = make_uint4(v.x, v.y, v.z, v.w);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t* qp = static_cast<const uint32_t*>(a.w) + (size_t)(kb * 32 + kg) * a.N + row0[r] + r16;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bw[r][j].x = __builtin_nontemporal_load(qp + (size_t)(4 * j) * a.N);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = min(mt * 16 + r16, a.T - 1);
+            const uint16_t* xp = x16 + (size_t)m * a.ldx + (size_t)kb * 256 + 8 * kg;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) aw[mt][j] = *reinterpret_cast<const uint4*>(xp + 32 * j);
+        }
+        // ---- contraction
+        if constexpr (WTYPE == DW_DENSE) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) y[r][mt] = mfma32<DT>(aw[mt][j], bw[r][j], y[r][mt]);
+        } else {
+            // 128+q (bf16) / 1024+q (f16): OR the 4-bit code into the mantissa of a constant; code pairs
+            // (n_i, n_{i+4}) give the element order {0,4,1,5,2,6,3,7} -> permute the activations to match.
+            constexpr uint32_t KOFF = (DT == MI355_DTYPE_BF16) ? 0x43004300u : 0x64006400u;
+            constexpr float OFF = (DT == MI355_DTYPE_BF16) ? 128.f : 1024.f;
+            constexpr uint32_t ONE2 = (DT == MI355_DTYPE_BF16) ? 0x3F803F80u : 0x3C003C00u;
+            uint32_t nib = 0x000F000Fu;
+            asm volatile("" : "+v"(nib));
+            const uint4 ones = make_uint4(ONE2, ONE2, ONE2, ONE2);
+            const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint4 v = aw[mt][j];        // v.x=(x0,x1) v.y=(x2,x3) v.z=(x4,x5) v.w=(x6,x7)
+                    aw[mt][j].x = __builtin_amdgcn_perm(v.z, v.x, 0x05040100u);   // (x0, x4)
+                    aw[mt][j].y = __builtin_amdgcn_perm(v.z, v.x, 0x07060302u);   // (x1, x5)
+                    aw[mt][j].z = __builtin_amdgcn_perm(v.w, v.y, 0x05040100u);   // (x2, x6)
+                    aw[mt][j].w = __builtin_amdgcn_perm(v.w, v.y, 0x07060302u);   // (x3, x7)
+                }
+#pragma unroll
+            for (int gq = 0; gq < 8 / GJ; ++gq) {
+                const int g = (kb * 256 + 32 * GJ * gq) / a.group_size;
+                // row sums of x over the group (every column of a ones-MFMA result holds it)
+                f32x4_t xs[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    xs[mt] = zero4;
+#pragma unroll
+                    for (int jj = 0; jj < GJ; ++jj) xs[mt] = mfma32<DT>(aw[mt][gq * GJ + jj], ones, xs[mt]);
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int col = row0[r] + r16;
+                    const float s = h2f<DT>(static_cast<const uint16_t*>(a.scales)[(size_t)g * a.N + marlin_scale_pos(col, a.sperm)]);
+                    const float c = -(OFF + zero_point(a, g, col)) * s;
+                    f32x4_t acc[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt] = zero4;
+#pragma unroll
+                    for (int jj = 0; jj < GJ; ++jj) {
+                        const uint32_t w = bw[r][gq * GJ + jj].x;
+                        uint4 b;
+                        b.x = (w & nib) | KOFF;
+                        b.y = ((w >> 4) & nib) | KOFF;
+                        b.z = ((w >> 8) & nib) | KOFF;
+                        b.w = ((w >> 12) & nib) | KOFF;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma32<DT>(aw[mt][gq * GJ + jj], b, acc[mt]);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) y[r][mt][v] += s * acc[mt][v] + c * xs[mt][v];
+                }
+            }
+        }
+    }
+
+    // ---- cross-wave reduction: C layout lane (col = weight row r16, rows m = 4kg+v)
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                dg_red[((((size_t)wave * R + r) * MT + mt) * 16 + 4 * kg + v) * 16 + r16] = y[r][mt][v];
+    __syncthreads();
+    const int nout = MT * 16 * 16;
+    for (int idx = threadIdx.x; idx < nout; idx += blockDim.x) {
+        const int rr = idx & 15, m = idx >> 4;
+        if (m >= a.T) continue;
+        float val[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float s = 0.f;
+            for (int w = 0; w < NW; ++w) s += dg_red[((((size_t)w * R + r) * MT + (m >> 4)) * 16 + (m & 15)) * 16 + rr];
+            val[r] = s;
+        }
+        const int row = row0[0] + rr;
+        const uint16_t* b16 = static_cast<const uint16_t*>(a.bias);
+        // candle rounds the matmul result to the model dtype, then the bias add rounds again (linear.rs:124-172)
+        float o = rnd<DT>(val[0]);
+        if (b16) o = rnd<DT>(o + h2f<DT>(b16[row]));
+        if (a.epi == MI355_EPI_SILU_MUL) {
+            float u = rnd<DT>(val[R - 1]);
+            if (b16) u = rnd<DT>(u + h2f<DT>(b16[a.pair_offset + row]));
+            o = rnd<DT>(rnd<DT>(o / (1.f + __expf(-o))) * u);               // silu(gate) * up (mlp.rs:457)
+        } else if (a.epi == MI355_EPI_RESID) {
+            o = rnd<DT>(o + h2f<DT>(static_cast<const uint16_t*>(a.resid)[(size_t)m * a.ldo + row]));
+        }
+        static_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + row] = f2h<DT>(o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launch
+template <int DT, int WTYPE, int MT, int R>
+static int dense_launch_gj(const DenseArgs& a, int gj, int nw, hipStream_t st) {
+    const int tiles = (a.epi == MI355_EPI_SILU_MUL ? a.pair_offset : a.N) / 16;
+    const size_t lds = (size_t)nw * R * MT * 256 * sizeof(float);
+    dim3 grid(tiles), block(nw * 64);
+    if constexpr (WTYPE == DW_DENSE) {
+        hipLaunchKernelGGL((dense_kernel<DT, WTYPE, MT, R, 8>), grid, block, lds, st, a);
+    } else {
+        switch (gj) {
+            case 1: hipLaunchKernelGGL((dense_kernel<DT, WTYPE, MT, R, 1>), grid, block, lds, st, a); break;
+            case 2: hipLaunchKernelGGL((dense_kernel<DT, WTYPE, MT, R, 2>), grid, block, lds, st, a); break;
+            case 4: hipLaunchKernelGGL((dense_kernel<DT, WTYPE, MT, R, 4>), grid, block, lds, st, a); break;
+            default: hipLaunchKernelGGL((dense_kernel<DT, WTYPE, MT, R, 8>), grid, block, lds, st, a); break;
+        }
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <int DT, int WTYPE>
+static int dense_launch_dt(const DenseArgs& a, hipStream_t st) {
+    if (a.T < 1 || a.T > 64 || (a.N & 15) || (a.K & 255)) return -2;
+    const bool pair = a.epi == MI355_EPI_SILU_MUL;
+    const int mt = (a.T + 15) / 16;
+    int gj = 8;
+    if (WTYPE == DW_GPTQ4) {
+        if (a.group_size >= 256) { if (a.group_size % 256) return -2; gj = 8; }
+        else if (a.group_size == 128) gj = 4;
+        else if (a.group_size == 64) gj = 2;
+        else if (a.group_size == 32) gj = 1;
+        else return -2;
+    }
+    // waves per workgroup: split K so that tiles * waves covers the chip several times, capped by the k-blocks
+    const int tiles = (pair ? a.pair_offset : a.N) / 16;
+    const int nkb = a.K >> 8;
+    int nw = 8;
+    while (nw > 1 && (nw > nkb || (size_t)tiles * nw > 256 * 32)) nw >>= 1;
+    if (mt >= 3 && nw > 4) nw = 4;
+#define DG_CASE(MT_, R_) return dense_launch_gj<DT, WTYPE, MT_, R_>(a, gj, nw, st)
+    if (pair) {
+        switch (mt) { case 1: DG_CASE(1, 2); case 2: DG_CASE(2, 2); default: return -3; }
+    }
+    switch (mt) { case 1: DG_CASE(1, 1); case 2: DG_CASE(2, 1); case 3: DG_CASE(3, 1); default: DG_CASE(4, 1); }
+#undef DG_CASE
+}
+
+static int dense_dispatch(const DenseArgs& a, int wtype, int dt, hipStream_t st) {
+    if (dt == MI355_DTYPE_BF16)
+        return wtype == DW_DENSE ? dense_launch_dt<MI355_DTYPE_BF16, DW_DENSE>(a, st) : dense_launch_dt<MI355_DTYPE_BF16, DW_GPTQ4>(a, st);
+    if (dt == MI355_DTYPE_F16)
+        return wtype == DW_DENSE ? dense_launch_dt<MI355_DTYPE_F16, DW_DENSE>(a, st) : dense_launch_dt<MI355_DTYPE_F16, DW_GPTQ4>(a, st);
+    return -2;
+}
+
+// SILU_MUL with more than 32 tokens, or any T > 64: run in token chunks
+static int dense_run(DenseArgs a, int wtype, int dt, hipStream_t st) {
+    const int chunk = a.epi == MI355_EPI_SILU_MUL ? 32 : 64;
+    const int T = a.T;
+    if (T < 1) return -2;
+    for (int t0 = 0; t0 < T; t0 += chunk) {
+        DenseArgs c = a;
+        c.T = T - t0 < chunk ? T - t0 : chunk;
+        c.x = static_cast<const uint16_t*>(a.x) + (size_t)t0 * a.ldx;
+        c.out = static_cast<uint16_t*>(a.out) + (size_t)t0 * a.ldo;
+        if (a.resid) c.resid = static_cast<const uint16_t*>(a.resid) + (size_t)t0 * a.ldo;
+        const int rc = dense_dispatch(c, wtype, dt, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ K15 repack
+__global__ void awq_repack_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int K, int NP) {
+    // in [K][NP] : nibble i of in[k][c] = code(k, 8c + {0,2,4,6,1,3,5,7}[i])   [EXT: AutoAWQ order_map]
+    // out [K/8][8 NP] : nibble i of out[kr][n] = code(8kr + i, n)
+    const int N = NP * 8;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)(K / 8) * N) return;
+    const int n = (int)(idx % N), kr = (int)(idx / N);
+    const int u = n & 7;
+    const int pos = ((u & 1) << 2) | (u >> 1);
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o |= ((in[(size_t)(8 * kr + i) * NP + (n >> 3)] >> (4 * pos)) & 0xFu) << (4 * i);
+    out[idx] = o;
+}
+
+// ------------------------------------------------------------------------------------------------ K14 exllama
+// act-order GPTQ: every k has its own group g_idx[k], so the scale cannot be factored out of an MFMA chain; the
+// weights are dequantised to f16 (w = s * (q - (z+1)) rounded to f16, as a half-precision dequant kernel does)
+// and contracted on MFMA.  One workgroup per 16-column tile, its 4 waves split K.
+template <int MT>
+__global__ void __launch_bounds__(256) exllama_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
+                                                      const uint32_t* __restrict__ qz, const uint16_t* __restrict__ sc,
+                                                      const int32_t* __restrict__ g_idx, uint16_t* __restrict__ out,
+                                                      int T, int N, int K, int group_size) {
+    __shared__ float red[4][MT][16][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int col = blockIdx.x * 16 + r16;
+    f32x4_t y[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) y[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int k32 = wave; k32 < K / 32; k32 += 4) {
+        const int k0 = k32 * 32 + 8 * kg;
+        const uint32_t w = qw[(size_t)(k0 >> 3) * N + col];
+        f16x8_t bf;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int g = g_idx ? g_idx[k0 + i] : (k0 + i) / group_size;
+            const float s = f16_bits_to_f32(sc[(size_t)g * N + col]);
+            const int z = (int)((qz[(size_t)g * (N / 8) + (col >> 3)] >> (4 * (col & 7))) & 0xF) + 1;
+            bf[i] = (_Float16)(s * (float)((int)((w >> (4 * i)) & 0xF) - z));
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = min(mt * 16 + r16, T - 1);
+            const f16x8_t af = *reinterpret_cast<const f16x8_t*>(x + (size_t)m * K + k0);
+            y[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, y[mt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) red[wave][mt][4 * kg + v][r16] = y[mt][v];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < MT * 256; idx += 256) {
+        const int rr = idx & 15, m = idx >> 4;
+        if (m >= T) continue;
+        const float s = red[0][m >> 4][m & 15][rr] + red[1][m >> 4][m & 15][rr] + red[2][m >> 4][m & 15][rr] + red[3][m >> 4][m & 15][rr];
+        out[(size_t)m * N + blockIdx.x * 16 + rr] = f32_to_f16_bits(s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+static int marlin_common(const void* in, const int32_t* qweight, const void* scales, const void* zeros, void* out,
+                         int m, int k, int n, int group_size, int dt, int awq, int64_t stream) {
+    DenseArgs a{};
+    a.w = qweight; a.scales = scales;
+    a.group_size = (group_size <= 0 || group_size > k) ? k : group_size;
+    a.sperm = a.group_size < k ? SP_GROUPED : SP_SINGLE;
+    a.qzeros = awq ? static_cast<const uint32_t*>(zeros) : nullptr;
+    a.zmode = awq ? MI355_ZERO_AWQ_MARLIN : MI355_ZERO_SYM8;
+    a.x = in; a.ldx = k; a.T = m; a.N = n; a.K = k;
+    a.out = out; a.ldo = n; a.epi = MI355_EPI_STORE;
+    return dense_run(a, DW_GPTQ4, dt, (hipStream_t)stream);
+}
+
+extern "C" {
+
+void marlin_4bit_f16(const void* in, const int32_t* qweight, const void* scales, const void* zeros, const void* g_idx,
+                     void* out, int32_t m, int32_t k, int32_t n, const void* workspace, int32_t group_size, int64_t stream) {
+    (void)g_idx; (void)workspace;
+    marlin_common(in, qweight, scales, zeros, out, m, k, n, group_size, MI355_DTYPE_F16, 0, stream);
+}
+void marlin_4bit_bf16(const void* in, const int32_t* qweight, const void* scales, const void* zeros, const void* g_idx,
+                      void* out, int32_t m, int32_t k, int32_t n, const void* workspace, int32_t group_size, int64_t stream) {
+    (void)g_idx; (void)workspace;
+    marlin_common(in, qweight, scales, zeros, out, m, k, n, group_size, MI355_DTYPE_BF16, 0, stream);
+}
+void marlin_awq_4bit_f16(const void* in, const int32_t* qweight, const void* scales, const void* zeros, const void* g_idx,
+                         void* out, int32_t m, int32_t k, int32_t n, const void* workspace, int32_t group_size, int64_t stream) {
+    (void)g_idx; (void)workspace;
+    marlin_common(in, qweight, scales, zeros, out, m, k, n, group_size, MI355_DTYPE_F16, 1, stream);
+}
+void marlin_awq_4bit_bf16(const void* in, const int32_t* qweight, const void* scales, const void* zeros, const void* g_idx,
+                          void* out, int32_t m, int32_t k, int32_t n, const void* workspace, int32_t group_size, int64_t stream) {
+    (void)g_idx; (void)workspace;
+    marlin_common(in, qweight, scales, zeros, out, m, k, n, group_size, MI355_DTYPE_BF16, 1, stream);
+}
+
+void gemm_half_q_half_alt(const void* a, const uint32_t* b_q_weight, const uint32_t* b_gptq_qzeros, const void* b_gptq_scales,
+                          const int32_t* b_g_idx, void* c, int32_t m, int32_t n, int32_t k, int32_t bit, int64_t stream) {
+    if (bit != 4 || (n & 15) || (k & 31)) return;
+    hipStream_t st = (hipStream_t)stream;
+    // without g_idx the group is k / group_size; the op does not pass group_size, so g_idx is required by the
+    // reference for act-order checkpoints (linear.rs:298-314 always loads it for gptq)
+    const int gs = k;
+    for (int t0 = 0; t0 < m; t0 += 32) {
+        const int T = m - t0 < 32 ? m - t0 : 32;
+        const uint16_t* x = static_cast<const uint16_t*>(a) + (size_t)t0 * k;
+        uint16_t* o = static_cast<uint16_t*>(c) + (size_t)t0 * n;
+        if (T <= 16)
+            hipLaunchKernelGGL((exllama_kernel<1>), dim3(n / 16), dim3(256), 0, st, x, b_q_weight, b_gptq_qzeros,
+                               static_cast<const uint16_t*>(b_gptq_scales), b_g_idx, o, T, n, k, gs);
+        else
+            hipLaunchKernelGGL((exllama_kernel<2>), dim3(n / 16), dim3(256), 0, st, x, b_q_weight, b_gptq_qzeros,
+                               static_cast<const uint16_t*>(b_gptq_scales), b_g_idx, o, T, n, k, gs);
+    }
+}
+
+void gptq_repack(const void* in, void* out, int32_t k_packed, int32_t n, int64_t stream) {
+    // our Marlin-slot layout is the checkpoint layout: [k/8][n] u32 (the [k/16, 2n] shape holds the same words)
+    hipMemcpyAsync(out, in, (size_t)k_packed * n * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+}
+void awq_repack(const void* in, void* out, int32_t k, int32_t n_packed, int32_t bits, int64_t stream) {
+    if (bits != 4 || (k & 7)) return;
+    const size_t total = (size_t)(k / 8) * n_packed * 8;
+    hipLaunchKernelGGL(awq_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const uint32_t*>(in), static_cast<uint32_t*>(out), k, n_packed);
+}
+
+/* host-side index arithmetic of the Marlin permutations (unit-tested on CPU against the reference's Python) */
+int32_t mi355_marlin_scale_pos(int32_t n, int32_t grouped) { return marlin_scale_pos(n, grouped ? SP_GROUPED : SP_SINGLE); }
+int32_t mi355_marlin_zero_pos(int32_t n) {
+    const int p1 = marlin_scale_pos(n, SP_GROUPED);
+    const int u = p1 & 7;
+    return (p1 & ~7) + (((u & 1) << 2) | (u >> 1));
+}
+
+int mi355_linear(void* out, const void* x, const void* w, const void* bias, const void* residual, int32_t num_tokens,
+                 int32_t n, int32_t k, int32_t dtype, int32_t epilogue, int64_t stream) {
+    DenseArgs a{};
+    a.w = w; a.ldw = k; a.x = x; a.ldx = k; a.T = num_tokens; a.K = k; a.N = n;
+    a.bias = bias; a.resid = residual; a.epi = epilogue; a.out = out;
+    if (epilogue == MI355_EPI_SILU_MUL) { a.pair_offset = n / 2; a.ldo = n / 2; } else a.ldo = n;
+    if (epilogue == MI355_EPI_RESID && !residual) return -2;
+    return dense_run(a, DW_DENSE, dtype, (hipStream_t)stream);
+}
+
+int mi355_gptq_linear(void* out, const void* x, const void* qweight, const void* scales, const void* qzeros,
+                      int32_t zero_mode, int32_t scales_permuted, const void* bias, const void* residual,
+                      int32_t num_tokens, int32_t n, int32_t k, int32_t group_size, int32_t dtype, int32_t epilogue,
+                      int64_t stream) {
+    DenseArgs a{};
+    a.w = qweight; a.scales = scales; a.qzeros = static_cast<const uint32_t*>(qzeros); a.zmode = zero_mode;
+    a.group_size = (group_size <= 0 || group_size > k) ? k : group_size;
+    a.sperm = !scales_permuted ? SP_NONE : (a.group_size < k ? SP_GROUPED : SP_SINGLE);
+    a.x = x; a.ldx = k; a.T = num_tokens; a.K = k; a.N = n;
+    a.bias = bias; a.resid = residual; a.epi = epilogue; a.out = out;
+    if (epilogue == MI355_EPI_SILU_MUL) { a.pair_offset = n / 2; a.ldo = n / 2; } else a.ldo = n;
+    if (epilogue == MI355_EPI_RESID && !residual) return -2;
+    return dense_run(a, DW_GPTQ4, dtype, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -364,3 +364,110 @@ def qmatmul_fused(mats: List[QMatMul], x, *, epilogue, out=None, norm_weight=Non
         d.kv_layout = layout
     _check(lib.mi355_qmatmul_fused(ctypes.byref(d), _stream()), "qmatmul_fused")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ safetensors path
+ZERO_SYM8, ZERO_GPTQ_PLUS1, ZERO_AWQ_MARLIN = 0, 1, 2
+
+
+def _dt16(t):
+    if t.dtype not in (torch.bfloat16, torch.float16):
+        raise RuntimeError("16-bit linear layers take bf16 / f16 activations (linear.rs:124-172, gptq.rs:229-238)")
+    return _DT[t.dtype]
+
+
+class Linear:
+    """`Linear` of src/openai/models/linear.rs:64-172: y = x.W^T (+b), weight [out, in] as stored in the checkpoint.
+    epilogue (decode fusions): EPI_STORE, EPI_RESID (y + residual), EPI_SILU_MUL (packed gate_up, mlp.rs:324-352)."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
+        self.weight, self.bias = weight, bias
+        self.n, self.k = weight.shape
+
+    def forward(self, x, *, epilogue=EPI_STORE, residual=None, out=None):
+        dt = _dt16(x)
+        if self.weight.dtype != x.dtype:
+            raise RuntimeError("weight / activation dtype mismatch")
+        x2 = x.reshape(-1, self.k)
+        T = x2.shape[0]
+        n_out = self.n // 2 if epilogue == EPI_SILU_MUL else self.n
+        if out is None:
+            out = torch.empty((T, n_out), dtype=x.dtype, device=x.device)
+        _check(lib.mi355_linear(_dev(out), _dev(x2), _dev(self.weight), _dev(self.bias) if self.bias is not None else None,
+                                _dev(residual) if residual is not None else None, T, self.n, self.k, dt, epilogue,
+                                _stream()), "linear")
+        return out
+
+
+def marlin_weight_repack(qweight: torch.Tensor, bits: int, is_awq: bool) -> torch.Tensor:
+    """`marlin_weight_repack` (src/backend/gptq.rs:264-359): u32 checkpoint tensor -> the layout the marlin entry
+    points consume, returned with the reference's output shape [k/16, 2n]."""
+    if qweight.dtype not in (torch.int32, torch.uint32):
+        raise RuntimeError("qweight must be a u32 tensor")
+    if bits != 4:
+        raise RuntimeError("only 4-bit checkpoints are supported on this path")
+    pack = 32 // bits
+    d0, d1 = qweight.shape
+    if is_awq:
+        k, n = d0, d1 * pack
+    else:
+        k, n = d0 * pack, d1
+    out = torch.empty((k // 16, 2 * n), dtype=qweight.dtype, device=qweight.device)
+    if is_awq:
+        lib.awq_repack(_dev(qweight), _dev(out), d0, d1, bits, _stream())
+    else:
+        lib.gptq_repack(_dev(qweight), _dev(out), d0, d1, _stream())
+    return out
+
+
+def gptq_matmul(x, qweight, scales, qzeros, g_idx, workspace, bits, group_size, is_awq):
+    """`gptq_matmul` (src/backend/gptq.rs:242-262) -> GPTQMatMul::cuda_fwd_t (:26-204): same dispatch.
+    workspace is not None  <=>  marlin format (qweight [k/16, 2n] from marlin_weight_repack, permuted scales);
+    otherwise the exllama arm (f16 only, qweight [k/8, n])."""
+    dt = _dt16(x)
+    marlin = workspace is not None
+    if marlin:
+        k, n = qweight.shape[0] * 16, qweight.shape[1] // 2
+    else:
+        k, n = qweight.shape[0] * 8, qweight.shape[1]
+    x2 = x.reshape(-1, k)
+    m = x2.shape[0]
+    out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    zp = _dev(qzeros) if qzeros is not None else None
+    gp = _dev(g_idx) if g_idx is not None else None
+    if marlin:
+        name = ("marlin_awq_4bit_" if is_awq else "marlin_4bit_") + ("f16" if dt == DT_F16 else "bf16")
+        getattr(lib, name)(_dev(x2), _dev(qweight), _dev(scales), zp if is_awq else None, gp, _dev(out), m, k, n,
+                           _dev(workspace), group_size, _stream())
+    else:
+        if dt != DT_F16:
+            raise RuntimeError("GPTQMatMul is only supported for f16 non-marlin matmul (gptq.rs:196)")
+        if qzeros is None or g_idx is None:
+            raise RuntimeError("the exllama arm needs qzeros and g_idx")
+        lib.gemm_half_q_half_alt(_dev(x2), _dev(qweight), zp, _dev(scales), gp, _dev(out), m, n, k, bits, _stream())
+    return out.reshape(*x.shape[:-1], n)
+
+
+class GPTQLinear:
+    """QLinear GPTQ arm (linear.rs:854-906) with the decode epilogues fused; qweight in checkpoint layout
+    [k/8, n] (= our marlin-slot layout), scales natural or Marlin-permuted."""
+
+    def __init__(self, qweight, scales, group_size, qzeros=None, zero_mode=ZERO_SYM8, scales_permuted=False, bias=None):
+        self.qweight, self.scales, self.qzeros, self.bias = qweight, scales, qzeros, bias
+        self.group_size, self.zero_mode, self.scales_permuted = group_size, zero_mode, scales_permuted
+        self.k, self.n = qweight.numel() * 8 // scales.shape[-1], scales.shape[-1]
+
+    def forward(self, x, *, epilogue=EPI_STORE, residual=None, out=None):
+        dt = _dt16(x)
+        x2 = x.reshape(-1, self.k)
+        T = x2.shape[0]
+        n_out = self.n // 2 if epilogue == EPI_SILU_MUL else self.n
+        if out is None:
+            out = torch.empty((T, n_out), dtype=x.dtype, device=x.device)
+        _check(lib.mi355_gptq_linear(_dev(out), _dev(x2), _dev(self.qweight), _dev(self.scales),
+                                     _dev(self.qzeros) if self.qzeros is not None else None, self.zero_mode,
+                                     1 if self.scales_permuted else 0,
+                                     _dev(self.bias) if self.bias is not None else None,
+                                     _dev(residual) if residual is not None else None, T, self.n, self.k,
+                                     self.group_size, dt, epilogue, _stream()), "gptq_linear")
+        return out

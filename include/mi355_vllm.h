@@ -169,6 +169,52 @@ int mi355_qmatmul_fused(const mi355_qmm_desc* desc, int64_t stream);
 void mi355_set_tuning(int32_t key, int32_t value);
 
 /* ---------------------------------------------------------------------------------------------
+ * 3b. Safetensors path: dense 16-bit and GPTQ/AWQ/Marlin 4-bit linears (decode-shaped, any num_tokens).
+ * ------------------------------------------------------------------------------------------- */
+/* Reference FFI symbols, verbatim (attention_rs::kernels::ffi, src/backend/gptq.rs:99-199,313-332).
+ * in [m,k] 16-bit; qweight = output of gptq_repack / awq_repack (opaque to the caller, shape [k/16, 2n] u32);
+ * scales [k/g, n] 16-bit, Marlin-permuted by the caller (linear.rs:341-379); zeros: NULL (sym, z = 8) or the
+ * Marlin-permuted packed zero points [k/g, n/8] u32 (AWQ, examples/convert_awq_marlin.py:72-115);
+ * g_idx, workspace: accepted and unused (no act-order on this path; no global reduction locks needed);
+ * out [m,n] 16-bit; group_size 32/64/128/multiple of 256/-1. */
+void marlin_4bit_f16(const void* in, const int32_t* qweight, const void* scales, const void* zeros, const void* g_idx,
+                     void* out, int32_t m, int32_t k, int32_t n, const void* workspace, int32_t group_size, int64_t stream);
+void marlin_4bit_bf16(const void* in, const int32_t* qweight, const void* scales, const void* zeros, const void* g_idx,
+                      void* out, int32_t m, int32_t k, int32_t n, const void* workspace, int32_t group_size, int64_t stream);
+void marlin_awq_4bit_f16(const void* in, const int32_t* qweight, const void* scales, const void* zeros, const void* g_idx,
+                         void* out, int32_t m, int32_t k, int32_t n, const void* workspace, int32_t group_size, int64_t stream);
+void marlin_awq_4bit_bf16(const void* in, const int32_t* qweight, const void* scales, const void* zeros, const void* g_idx,
+                          void* out, int32_t m, int32_t k, int32_t n, const void* workspace, int32_t group_size, int64_t stream);
+/* exllama-style GPTQ (act-order), f16 only -- gptq.rs:181-197.  a [m,k] f16; b_q_weight [k/8,n] u32 (checkpoint
+ * layout); qzeros [k/g, n/8] u32 (stored zero - 1); scales [k/g,n] f16; g_idx [k] (required); c [m,n] f16 */
+void gemm_half_q_half_alt(const void* a, const uint32_t* b_q_weight, const uint32_t* b_gptq_qzeros, const void* b_gptq_scales,
+                          const int32_t* b_g_idx, void* c, int32_t m, int32_t n, int32_t k, int32_t bit, int64_t stream);
+/* load-time repack -- gptq.rs:313-332.  gptq: in [k_packed = k/8, n] u32; awq: in [k, n_packed = n/8] u32
+ * (AutoAWQ nibble order [0,2,4,6,1,3,5,7]); out: k*n/8 u32 in the layout the marlin_* entry points consume. */
+void gptq_repack(const void* in, void* out, int32_t k_packed, int32_t n, int64_t stream);
+void awq_repack(const void* in, void* out, int32_t k, int32_t n_packed, int32_t bits, int64_t stream);
+
+/* position of natural column n inside a Marlin-permuted scale row (grouped: group_size < k; else "single"),
+ * and inside a Marlin zero-point row (nibble index) -- host helpers, used by the kernels' index arithmetic */
+int32_t mi355_marlin_scale_pos(int32_t n, int32_t grouped);
+int32_t mi355_marlin_zero_pos(int32_t n);
+
+#define MI355_ZERO_SYM8 0        /* z = 8                                                    */
+#define MI355_ZERO_GPTQ_PLUS1 1  /* qzeros in checkpoint packing, z = stored + 1 (AutoGPTQ)  */
+#define MI355_ZERO_AWQ_MARLIN 2  /* Marlin-permuted packed zero points, z = stored           */
+/* `Linear::forward` (linear.rs:124-172): out = x . w^T (+bias), all tensors `dtype` (BF16/F16), w [n,k] row-major
+ * as stored in the checkpoint.  epilogue: STORE; RESID (out = residual + y, out may alias residual);
+ * SILU_MUL (w is the packed [gate;up] matrix of mlp.rs:324-352 with n = 2*intermediate rows: out [T, n/2] =
+ * silu(gate)*up with candle's per-op rounding).  Every op result is rounded to `dtype` as candle does. */
+int mi355_linear(void* out, const void* x, const void* w, const void* bias, const void* residual, int32_t num_tokens,
+                 int32_t n, int32_t k, int32_t dtype, int32_t epilogue, int64_t stream);
+/* `QLinear::forward` GPTQ arm (linear.rs:854-906) with the same fused epilogues; qweight [k/8, n] u32. */
+int mi355_gptq_linear(void* out, const void* x, const void* qweight, const void* scales, const void* qzeros,
+                      int32_t zero_mode, int32_t scales_permuted, const void* bias, const void* residual,
+                      int32_t num_tokens, int32_t n, int32_t k, int32_t group_size, int32_t dtype, int32_t epilogue,
+                      int64_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * 4. Host layer: the GGUF llama decode step (GGUFLLaMa::forward + CacheEngine + decode graph), C handles.
  *    Mirrors src/openai/models/quantized_llama.rs:424-506, src/scheduler/cache_engine.rs:122-341,
  *    src/backend/graph.rs:471-661,685.  Everything a Rust `DefaultPipeline::forward` arm would call.

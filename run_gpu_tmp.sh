@@ -1,5 +1,3 @@
 mkdir -p gpurun_out
-cd /tmp && export TMPDIR=/tmp
-timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-batch32 --no-graph > /dev/null 2>&1
-timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $GRAFT_REPO_ROOT/gpurun_out/pmc_write -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-batch32 --no-graph > /dev/null 2>&1
-ls $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch $GRAFT_REPO_ROOT/gpurun_out/pmc_write
+timeout 400 python -m pytest tests/test_gpu_linear.py -m gpu -q > gpurun_out/lin_tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/lin_tests.log
+tail -15 gpurun_out/lin_tests.log

@@ -1,0 +1,85 @@
+"""CPU tests for the safetensors-path oracle (GPTQ/AWQ/Marlin tensors, 16-bit linears): the oracle against the
+golden vectors generated from the reference's in-tree Python, and the C-ABI host helpers against the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import gptq as G
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "marlin_perms.json")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(GOLD) as f:
+        return json.load(f)
+
+
+def test_scale_perms_match_reference(gold):
+    sp, sps = G.scale_perms()
+    assert sp.tolist() == gold["scale_perm"]
+    assert sps.tolist() == gold["scale_perm_single"]
+
+
+def test_pack_and_zero_points_match_reference(gold):
+    for c in gold["cases"]:
+        zp = np.array(c["zp"], np.int64)
+        Gn, N = c["G"], c["N"]
+        assert (G.pack_cols(zp) == np.array(c["pack_cols"], np.uint32)).all()
+        assert (G.unpack_cols(np.array(c["pack_cols"], np.uint32)) == zp).all()
+        assert (G.marlin_zero_points(zp, Gn, N) == np.array(c["marlin_zero_points"], np.uint32)).all()
+        awq = np.array(c["awq_packed"], np.uint32)
+        assert (G.awq_pack(zp) == awq).all()                     # AWQ nibble order
+        assert (G.awq_unpack(awq) == zp).all()
+        assert (G.awq_to_marlin_zero_points(awq, Gn, N) == np.array(c["awq_to_marlin_zero_points"], np.uint32)).all()
+
+
+def test_gptq_pack_roundtrip():
+    rng = np.random.default_rng(0)
+    q = rng.integers(0, 16, (256, 48))
+    assert (G.gptq_unpack(G.gptq_pack(q)) == q).all()
+    w = G.gptq_pack(q)
+    assert ((w[3, 5] >> np.uint32(4 * 6)) & 0xF) == q[3 * 8 + 6, 5]
+
+
+def test_host_index_helpers_invert_the_permutations(lib, gold):
+    """mi355_marlin_scale_pos / zero_pos (the kernels' index arithmetic) vs the reference permutations."""
+    N = 256
+    nat = np.arange(N)
+    for grouped, gs in ((1, 128), (0, -1)):
+        perm = G.marlin_permute_scales(nat.reshape(1, N).astype(np.float32), 1024, N, gs)[0].astype(np.int64)
+        for n in range(N):
+            assert perm[lib.mi355_marlin_scale_pos(n, grouped)] == n
+    for c in gold["cases"]:
+        zp, N = np.array(c["zp"]), c["N"]
+        packed = np.array(c["marlin_zero_points"], np.uint32)
+        for g in range(c["G"]):
+            for n in range(N):
+                p = lib.mi355_marlin_zero_pos(n)
+                assert ((packed[g, p // 8] >> np.uint32(4 * (p % 8))) & 0xF) == zp[g, n]
+
+
+def test_dequant_and_linear_definitions():
+    rng = np.random.default_rng(1)
+    K, N, gs = 256, 32, 64
+    q = rng.integers(0, 16, (K, N))
+    s = G.round_dt(rng.uniform(0.01, 0.03, (K // gs, N)), "f16")
+    w = G.gptq_dequant(q, s, None, gs)
+    assert w.shape == (K, N)
+    assert np.allclose(w[70, 3], s[1, 3] * (q[70, 3] - 8))
+    z = rng.integers(1, 17, (K // gs, N))
+    w2 = G.gptq_dequant(q, s, z, gs)
+    assert np.allclose(w2[130, 7], s[2, 7] * (q[130, 7] - z[2, 7]))
+    gi = rng.permutation(K) // gs
+    w3 = G.gptq_dequant(q, s, z, g_idx=gi)
+    assert np.allclose(w3[5, 1], s[gi[5], 1] * (q[5, 1] - z[gi[5], 1]))
+    assert (G.unpack_cols(G.gptq_pack_zeros(z)) + 1 == z).all()
+    x = G.round_dt(rng.normal(0, 1, (3, K)), "bf16")
+    wd = G.round_dt(rng.normal(0, 0.05, (N, K)), "bf16")
+    b = G.round_dt(rng.normal(0, 0.1, N), "bf16")
+    y = G.linear16(x, wd, b, "bf16")
+    assert (G.round_dt(y, "bf16") == y).all()
+    ref = (x.astype(np.float64) @ wd.astype(np.float64).T) + b
+    assert np.abs(y - ref).max() <= 2 ** -7 * np.abs(ref).max()

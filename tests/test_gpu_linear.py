@@ -1,0 +1,175 @@
+"""GPU parity tests for the safetensors path (K10, K12-K15): dense 16-bit and GPTQ/AWQ/Marlin 4-bit linears through
+the C ABI vs the numpy oracle.  Repack / permutation results are bit-exact; matmul outputs are 16-bit values
+compared at 1 ulp of the output dtype (tolerance next to the assert)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import gptq as G               # noqa: E402
+
+TD = {"bf16": torch.bfloat16, "f16": torch.float16}
+ULP = {"bf16": 2.0 ** -8, "f16": 2.0 ** -11}
+
+
+@pytest.fixture(scope="module")
+def cv(lib):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (torch.cuda.is_available() is False)")
+    import candle_vllm_amd.ops as ops
+    return ops
+
+
+def dev16(a_f32, dt):
+    """f32 numpy values (already exactly representable) -> 16-bit cuda tensor, bit-exact"""
+    bits = G.to_bits(a_f32, dt)
+    return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).cuda().view(TD[dt])
+
+
+def host16(t, dt):
+    return G.from_bits(t.detach().view(torch.int16).cpu().numpy().view(np.uint16), dt)
+
+
+def dev_u32(a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).cuda()
+
+
+def check_ulp(got, ref, dt, ulps=1.01, what="", mag=None):
+    """|got-ref| <= ulps * ulp(mag) elementwise (mag = |ref|, or the largest intermediate of a rounding chain:
+    a 1-ulp flip of the matmul result survives a cancelling bias / residual add), plus a small absolute floor for
+    cancellation inside the dot product (f32 accumulation order differs from the f64 oracle)."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    mag = np.abs(ref) if mag is None else np.maximum(np.abs(ref), np.abs(mag))
+    tol = ulps * 2 * ULP[dt] * mag                              # ulp(v) <= 2 * 2^-p * |v|
+    floor = 1e-3 * np.abs(ref).max() * (ULP[dt] / ULP["bf16"])
+    bad = np.abs(got - ref) > np.maximum(tol, floor)
+    assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} off, max abs err {np.abs(got - ref).max()}"
+
+
+# ------------------------------------------------------------------------------------------------ K10 dense
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("T,N,K", [(1, 256, 512), (5, 48, 256), (16, 1024, 1024), (17, 64, 768), (33, 128, 512),
+                                   (64, 96, 256), (70, 32, 512)])
+def test_linear_matches_oracle(cv, dt, T, N, K):
+    rng = np.random.default_rng(T * 1000 + N)
+    x = G.round_dt(rng.normal(0, 1, (T, K)), dt)
+    w = G.round_dt(rng.normal(0, 0.05, (N, K)), dt)
+    b = G.round_dt(rng.normal(0, 0.2, N), dt)
+    lin = cv.Linear(dev16(w, dt), dev16(b, dt))
+    y = host16(lin.forward(dev16(x, dt)), dt)
+    check_ulp(y, G.linear16(x, w, b, dt), dt, what="linear+bias", ulps=2.01, mag=G.linear16(x, w, None, dt))
+    lin2 = cv.Linear(dev16(w, dt))
+    res = G.round_dt(rng.normal(0, 1, (T, N)), dt)
+    y2 = host16(lin2.forward(dev16(x, dt), epilogue=cv.EPI_RESID, residual=dev16(res, dt)), dt)
+    check_ulp(y2, G.round_dt(G.linear16(x, w, None, dt) + res, dt), dt, what="linear+resid", ulps=2.01,
+              mag=G.linear16(x, w, None, dt))
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("T", [1, 8, 32, 40])
+def test_linear_gate_up_silu(cv, dt, T):
+    rng = np.random.default_rng(T)
+    K, I = 512, 192
+    x = G.round_dt(rng.normal(0, 1, (T, K)), dt)
+    w = G.round_dt(rng.normal(0, 0.06, (2 * I, K)), dt)          # packed [gate; up] (mlp.rs:324-352)
+    lin = cv.Linear(dev16(w, dt))
+    y = host16(lin.forward(dev16(x, dt), epilogue=cv.EPI_SILU_MUL), dt)
+    gu = G.linear16(x, w, None, dt)
+    ref = G.silu_mul16(gu[:, :I], gu[:, I:], dt)
+    # the 1-ulp differences of gate/up (f32 vs f64 accumulation) propagate through silu*up: 3 ulp
+    check_ulp(y, ref, dt, ulps=3.0, what="silu(gate)*up")
+
+
+# ------------------------------------------------------------------------------------------------ K15 repack
+def test_repack_bit_exact(cv):
+    rng = np.random.default_rng(3)
+    K, N = 512, 128
+    q = rng.integers(0, 16, (K, N))
+    gq = G.gptq_pack(q)
+    out = cv.marlin_weight_repack(dev_u32(gq), 4, False)
+    assert tuple(out.shape) == (K // 16, 2 * N)                   # gptq.rs:291-297
+    assert (out.cpu().numpy().view(np.uint32).reshape(K // 8, N) == gq).all()
+    out2 = cv.marlin_weight_repack(dev_u32(G.awq_pack(q)), 4, True)
+    assert tuple(out2.shape) == (K // 16, 2 * N)                  # gptq.rs:285-290
+    assert (out2.cpu().numpy().view(np.uint32).reshape(K // 8, N) == gq).all()
+
+
+# ------------------------------------------------------------------------------------------------ K12 / K13 marlin
+def _gptq_case(rng, K, N, gs, dt):
+    q = rng.integers(0, 16, (K, N))
+    ng = 1 if gs == -1 else K // gs
+    s = G.round_dt(rng.uniform(0.005, 0.02, (ng, N)), dt)
+    return q, s
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("T,N,K,gs", [(1, 128, 512, 128), (3, 64, 256, 64), (16, 256, 1024, 128), (20, 64, 512, -1),
+                                      (33, 128, 512, 32), (64, 64, 768, 256), (7, 192, 512, 64)])
+def test_marlin_4bit_matches_oracle(cv, dt, T, N, K, gs):
+    rng = np.random.default_rng(K + N + T)
+    q, s = _gptq_case(rng, K, N, gs, dt)
+    x = G.round_dt(rng.normal(0, 1, (T, K)), dt)
+    qw = cv.marlin_weight_repack(dev_u32(G.gptq_pack(q)), 4, False)
+    sp = G.marlin_permute_scales(s, K, N, gs)                    # what the reference's loader hands over
+    ws = torch.zeros(N, dtype=torch.int32, device="cuda")
+    y = cv.gptq_matmul(dev16(x, dt).reshape(1, T, K), qw, dev16(sp, dt), None, None, ws, 4, gs, False)
+    assert tuple(y.shape) == (1, T, N)
+    ref = G.gptq_linear(x, G.gptq_dequant(q, s, None, gs), None, dt)
+    check_ulp(host16(y, dt).reshape(T, N), ref, dt, what="marlin_4bit")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("T,N,K,gs", [(1, 128, 512, 128), (9, 64, 256, 64), (32, 192, 512, 128)])
+def test_marlin_awq_matches_oracle(cv, dt, T, N, K, gs):
+    rng = np.random.default_rng(K + N + T + 1)
+    q, s = _gptq_case(rng, K, N, gs, dt)
+    z = rng.integers(0, 16, (K // gs, N))
+    x = G.round_dt(rng.normal(0, 1, (T, K)), dt)
+    qw = cv.marlin_weight_repack(dev_u32(G.awq_pack(q)), 4, True)
+    awq_qzeros = G.awq_pack(z)                                   # AWQ checkpoint packing
+    mzp = G.awq_to_marlin_zero_points(awq_qzeros, K // gs, N)    # examples/convert_awq_marlin.py
+    sp = G.marlin_permute_scales(s, K, N, gs)
+    ws = torch.zeros(N, dtype=torch.int32, device="cuda")
+    y = cv.gptq_matmul(dev16(x, dt).reshape(1, T, K), qw, dev16(sp, dt), dev_u32(mzp), None, ws, 4, gs, True)
+    ref = G.gptq_linear(x, G.gptq_dequant(q, s, z, gs), None, dt)
+    check_ulp(host16(y, dt).reshape(T, N), ref, dt, what="marlin_awq_4bit")
+
+
+# ------------------------------------------------------------------------------------------------ K14 exllama
+@pytest.mark.parametrize("T,N,K,gs", [(1, 64, 256, 64), (5, 128, 512, 128), (24, 64, 256, 32), (40, 32, 128, 32)])
+def test_exllama_act_order_matches_oracle(cv, T, N, K, gs):
+    rng = np.random.default_rng(K + T)
+    q, s = _gptq_case(rng, K, N, gs, "f16")
+    z = rng.integers(1, 17, (K // gs, N))
+    g_idx = (rng.permutation(K) // gs).astype(np.int32)          # desc_act
+    x = G.round_dt(rng.normal(0, 1, (T, K)), "f16")
+    y = cv.gptq_matmul(dev16(x, "f16").reshape(1, T, K), dev_u32(G.gptq_pack(q)), dev16(s, "f16"),
+                       dev_u32(G.gptq_pack_zeros(z)), torch.from_numpy(g_idx).cuda(), None, 4, gs, False)
+    w16 = G.gptq_dequant(q, s, z, g_idx=g_idx, round_to="f16")   # half-precision dequant, as the exllama family does
+    ref = G.gptq_linear(x, w16, None, "f16")
+    check_ulp(host16(y, "f16").reshape(T, N), ref, "f16", what="gemm_half_q_half_alt")
+    # and within north_star's 1e-3 of the exact (unrounded-weight) definition
+    exact = x.astype(np.float64) @ G.gptq_dequant(q, s, z, g_idx=g_idx)
+    assert np.abs(host16(y, "f16").reshape(T, N) - exact).max() <= 2e-3 * np.abs(exact).max()
+
+
+# ------------------------------------------------------------------------------------------------ fused GPTQ epilogues
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_gptq_linear_fused_epilogues(cv, dt):
+    rng = np.random.default_rng(11)
+    T, K, I, gs = 6, 512, 128, 128
+    q, s = _gptq_case(rng, K, 2 * I, gs, dt)
+    x = G.round_dt(rng.normal(0, 1, (T, K)), dt)
+    lin = cv.GPTQLinear(dev_u32(G.gptq_pack(q)), dev16(s, dt), gs)
+    y = host16(lin.forward(dev16(x, dt), epilogue=cv.EPI_SILU_MUL), dt)
+    gu = G.gptq_linear(x, G.gptq_dequant(q, s, None, gs), None, dt)
+    check_ulp(y, G.silu_mul16(gu[:, :I], gu[:, I:], dt), dt, ulps=3.0, what="gptq silu*up")
+    z = rng.integers(1, 17, (K // gs, 2 * I))
+    lin2 = cv.GPTQLinear(dev_u32(G.gptq_pack(q)), dev16(s, dt), gs, qzeros=dev_u32(G.gptq_pack_zeros(z)),
+                         zero_mode=cv.ZERO_GPTQ_PLUS1)
+    res = G.round_dt(rng.normal(0, 1, (T, 2 * I)), dt)
+    y2 = host16(lin2.forward(dev16(x, dt), epilogue=cv.EPI_RESID, residual=dev16(res, dt)), dt)
+    ref2 = G.round_dt(G.gptq_linear(x, G.gptq_dequant(q, s, z, gs), None, dt) + res, dt)
+    check_ulp(y2, ref2, dt, what="gptq asym + resid", ulps=2.01, mag=G.gptq_linear(x, G.gptq_dequant(q, s, z, gs), None, dt))
