@@ -62,6 +62,8 @@ _sig("mi355_paged_attention_v1", ctypes.c_int,
      [c_vp] * 6 + [c_i32] * 7 + [c_f32, c_f32, c_i32, c_i32, c_i64])
 _sig("mi355_paged_attention_v2", ctypes.c_int,
      [c_vp] * 9 + [c_i32] * 8 + [c_f32, c_f32, c_i32, c_i32, c_i64])
+_sig("mi355_prefill_attention", ctypes.c_int,
+     [c_vp] * 9 + [c_i32] * 7 + [c_f32, c_f32, c_i32, c_i32, c_i64])
 _sig("mi355_rope_inplace", ctypes.c_int, [c_vp] * 5 + [c_i32] * 7 + [c_i64])
 _sig("mi355_rms_norm", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_i32, c_i64])
 _sig("mi355_silu_mul", ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64])

@@ -1,0 +1,323 @@
+// K4 -- prefill attention: causal, variable-length (cu_seqlens_q), grouped-query, optionally over a cached prefix
+// that lives in the paged KV cache (prefix cache / chunked prefill: context_len = cached + chunk).
+// The prefill half of PagedAttention::forward (attention-rs; call sites src/openai/models/layers/attention.rs:707-719,
+// 983-995; metadata src/openai/pipelines/inputs.rs:90-230,351-367).
+//
+// MI355X design: a flash-attention loop with everything on the 16x16x32 MFMA and NO LDS / barriers:
+//   S^T = K . Q^T   (A = K rows straight from global: 16 B per lane; B = Q held in registers for the whole loop)
+//         -> C layout: lane (query = lane&15) holds keys 4*(lane>>4)+v, i.e. each lane owns ONE query: the online
+//            softmax state (m, l) and the O rescale factor are per-lane scalars, P never leaves its lane.
+//   O^T = V^T . P^T (B = P packed to 16-bit in registers; A = V^T)
+// V^T needs 8 keys at a fixed d per lane while row-major V gives 8 d at a fixed key.  The transpose is done by the
+// matrix core itself: MFMA(A = V rows, B = identity slice) returns, in C layout, exactly lane (d, keys 4kg+v) --
+// exact in f32, so the round trip through 16-bit is lossless.  The vLLM-style paged V cache [D][block] already has
+// keys contiguous and is loaded directly.
+// One wave = 32 queries (2 sub-tiles) of one head; a workgroup = 4 waves = 128 consecutive queries (so the K/V
+// tiles they share hit L1/L2).  grid = (ceil(max_seqlen_q/128), heads, seqs): >> 256 workgroups for real prompts.
+#include "common.h"
+#include "../../include/mi355_vllm.h"
+#include <hip/hip_runtime.h>
+
+typedef _Float16 pf_f16x8_t __attribute__((ext_vector_type(8)));
+
+enum { SRC_CONTIG = 0, SRC_FLASH = 1, SRC_PAGED = 2 };
+
+struct PrefillParams {
+    void* out;                 // [T, H, D]
+    const void* q;             // [T, H, D]
+    const void* k;             // [T, Hkv, D] (SRC_CONTIG) or key cache
+    const void* v;
+    const uint32_t* block_tables;   // [num_seqs, max_blocks]
+    const uint32_t* context_lens;   // [num_seqs] = cached + chunk, or null (= chunk)
+    const uint32_t* cu_q;           // [num_seqs + 1]
+    int32_t H, Hkv, block_size, max_blocks;
+    float scale_log2, softcap;      // scale * log2(e) (softcap == 0) ; softcap > 0: scale applied before tanh
+    float scale;
+};
+
+template <int DT>
+__device__ __forceinline__ f32x4_t pf_mfma(const uint4& a, const uint4& b, const f32x4_t& c) {
+    if constexpr (DT == MI355_DTYPE_BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pf_f16x8_t, a), __builtin_bit_cast(pf_f16x8_t, b), c, 0, 0, 0);
+}
+template <int DT> __device__ __forceinline__ uint32_t pf_pack(float lo, float hi) {
+    if constexpr (DT == MI355_DTYPE_BF16) return cvt_pk_bf16(lo, hi);
+    else return (uint32_t)f32_to_f16_bits(lo) | ((uint32_t)f32_to_f16_bits(hi) << 16);
+}
+
+// 16-byte chunk (8 consecutive d starting at d0) of key/value ROW j of kv head hk
+template <int SRC, int D>
+__device__ __forceinline__ const uint4* row_chunk(const PrefillParams& p, const void* base, const uint32_t* bt, int q_begin,
+                                                  int hk, int j, int d0) {
+    const uint16_t* b = static_cast<const uint16_t*>(base);
+    if constexpr (SRC == SRC_CONTIG) {
+        return reinterpret_cast<const uint4*>(b + ((size_t)(q_begin + j) * p.Hkv + hk) * D + d0);
+    } else if constexpr (SRC == SRC_FLASH) {
+        const size_t slot = (size_t)bt[j / p.block_size] * p.block_size + j % p.block_size;
+        return reinterpret_cast<const uint4*>(b + (slot * p.Hkv + hk) * D + d0);
+    } else {   // K cache [NB, Hkv, D/8, bs, 8]
+        const size_t blk = bt[j / p.block_size];
+        return reinterpret_cast<const uint4*>(b + (((blk * p.Hkv + hk) * (D / 8) + d0 / 8) * p.block_size + j % p.block_size) * 8);
+    }
+}
+
+template <int DT, int D, int SRC>
+__global__ void __launch_bounds__(256) prefill_attn_kernel(const PrefillParams p) {
+    constexpr int NC = D / 32;     // 32-wide d chunks (QK contraction, V row loads)
+    constexpr int NDT = D / 16;    // 16-wide d tiles of O
+    const int seq = blockIdx.z, h = blockIdx.y;
+    const int q_begin = (int)p.cu_q[seq], qlen = (int)p.cu_q[seq + 1] - q_begin;
+    const int ctx = p.context_lens ? (int)p.context_lens[seq] : qlen;
+    const int cached = ctx - qlen;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int qw0 = blockIdx.x * 128 + wave * 32;          // first query (chunk-local) of this wave
+    if (qw0 >= qlen) return;
+    const int hk = h / (p.H / p.Hkv);
+    const uint32_t* bt = p.block_tables ? p.block_tables + (size_t)seq * p.max_blocks : nullptr;
+    const uint16_t* q16 = static_cast<const uint16_t*>(p.q);
+
+    // ---- Q fragments (B operand: lane = query r16, k = d 32c + 8kg ..)
+    uint4 qf[2][NC];
+    int pos[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int ql = qw0 + 16 * s + r16;
+        pos[s] = cached + min(ql, qlen - 1);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            qf[s][c] = make_uint4(0, 0, 0, 0);
+            if (ql < qlen) qf[s][c] = *reinterpret_cast<const uint4*>(q16 + ((size_t)(q_begin + ql) * p.H + h) * D + 32 * c + 8 * kg);
+        }
+    }
+    // identity slices for the MFMA transpose: B[k][n] = (k == 16*half + n), lane holds k = 8kg .. 8kg+7
+    constexpr uint32_t ONE = (DT == MI355_DTYPE_BF16) ? 0x3F80u : 0x3C00u;
+    uint4 ident[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int i = 16 * half + r16 - 8 * kg;              // element index inside this lane's 8, if 0..7
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (i == 2 * e) ? ONE : ((i == 2 * e + 1) ? (ONE << 16) : 0u);
+        ident[half] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    f32x4_t o[2][NDT];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) o[s][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    const int kend = min(ctx, cached + min(qw0 + 32, qlen));   // keys this wave can see (exclusive)
+    for (int j0 = 0; j0 < kend; j0 += 32) {
+        // ---- K rows (A operand: lane = key r16 of key tile kt) and S^T
+        uint4 kf[2][NC];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int j = min(j0 + 16 * kt + r16, ctx - 1);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) kf[kt][c] = *row_chunk<SRC, D>(p, p.k, bt, q_begin, hk, j, 32 * c + 8 * kg);
+        }
+        // ---- V^T fragments (A operand of PV: lane = d r16 of d tile, k = keys {4kg..4kg+3} of kt 0 and of kt 1)
+        uint4 vt[NDT];
+        if constexpr (SRC == SRC_PAGED) {
+            const uint16_t* vb = static_cast<const uint16_t*>(p.v);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                uint32_t w[4];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    const int jv = j0 + 16 * kt + 4 * kg;                        // 4 consecutive keys, same block
+                    const int jc = min(jv, ctx - 1);
+                    const size_t blk = bt[jc / p.block_size];
+                    const uint2 t = *reinterpret_cast<const uint2*>(vb + ((blk * p.Hkv + hk) * D + 16 * dt + r16) * p.block_size + (jv % p.block_size));
+                    w[2 * kt] = t.x; w[2 * kt + 1] = t.y;
+                    if (jv + 3 >= ctx) {      // slots past the context hold arbitrary bits: zero them (0 * NaN would poison O)
+                        if (jv + 0 >= ctx) w[2 * kt] &= 0xFFFF0000u;
+                        if (jv + 1 >= ctx) w[2 * kt] &= 0x0000FFFFu;
+                        if (jv + 2 >= ctx) w[2 * kt + 1] &= 0xFFFF0000u;
+                        if (jv + 3 >= ctx) w[2 * kt + 1] &= 0x0000FFFFu;
+                    }
+                }
+                vt[dt] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        } else {
+            uint4 vr[2][NC];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const int j = min(j0 + 16 * kt + r16, ctx - 1);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) vr[kt][c] = *row_chunk<SRC == SRC_CONTIG ? SRC_CONTIG : SRC_FLASH, D>(p, p.v, bt, q_begin, hk, j, 32 * c + 8 * kg);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const f32x4_t t0 = pf_mfma<DT>(vr[0][c], ident[half], zero4);   // lane (d = 32c+16half+r16): keys 4kg+v of kt 0
+                    const f32x4_t t1 = pf_mfma<DT>(vr[1][c], ident[half], zero4);
+                    vt[2 * c + half] = make_uint4(pf_pack<DT>(t0[0], t0[1]), pf_pack<DT>(t0[2], t0[3]),
+                                                  pf_pack<DT>(t1[0], t1[1]), pf_pack<DT>(t1[2], t1[3]));
+                }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x4_t st[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                st[kt] = zero4;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) st[kt] = pf_mfma<DT>(kf[kt][c], qf[s][c], st[kt]);
+            }
+            // ---- online softmax; this lane owns query r16 of sub-tile s, keys j0 + 16kt + 4kg + v
+            float x[8];
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int j = j0 + 16 * kt + 4 * kg + v;
+                    float sv = st[kt][v];
+                    if (p.softcap > 0.f) sv = tanhf(sv * p.scale / p.softcap) * p.softcap * 1.4426950408889634f;
+                    else sv *= p.scale_log2;
+                    sv = (j <= pos[s]) ? sv : -INFINITY;          // causal (j < ctx follows from j <= pos)
+                    x[4 * kt + v] = sv;
+                    tmax = fmaxf(tmax, sv);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float m_new = fmaxf(m_run[s], tmax);           // finite: key 0 is visible to every query
+            const float alpha = exp2f(m_run[s] - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { x[i] = exp2f(x[i] - m_new); psum += x[i]; }
+            psum += __shfl_xor(psum, 16);
+            psum += __shfl_xor(psum, 32);
+            l_run[s] = l_run[s] * alpha + psum;
+            m_run[s] = m_new;
+            const uint4 pb = make_uint4(pf_pack<DT>(x[0], x[1]), pf_pack<DT>(x[2], x[3]), pf_pack<DT>(x[4], x[5]), pf_pack<DT>(x[6], x[7]));
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                o[s][dt][0] *= alpha; o[s][dt][1] *= alpha; o[s][dt][2] *= alpha; o[s][dt][3] *= alpha;
+                o[s][dt] = pf_mfma<DT>(vt[dt], pb, o[s][dt]);   // C: col = query r16, rows d = 16dt + 4kg + v
+            }
+        }
+    }
+    // ---- epilogue
+    uint16_t* out16 = static_cast<uint16_t*>(p.out);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int ql = qw0 + 16 * s + r16;
+        if (ql >= qlen) continue;
+        const float inv = 1.f / l_run[s];
+        uint16_t* op = out16 + ((size_t)(q_begin + ql) * p.H + h) * D + 4 * kg;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            uint2 w;
+            w.x = pf_pack<DT>(o[s][dt][0] * inv, o[s][dt][1] * inv);
+            w.y = pf_pack<DT>(o[s][dt][2] * inv, o[s][dt][3] * inv);
+            *reinterpret_cast<uint2*>(op + 16 * dt) = w;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ generic fallback
+// any head_dim <= 256 / block size: one wave per (query, head); lanes split d, keys visited one by one.
+// Correctness path for shapes the MFMA kernel does not cover (e.g. StableLM's D = 80).
+template <int DT>
+__global__ void __launch_bounds__(64) prefill_attn_generic_kernel(const PrefillParams p, int D, int src) {
+    const int seq = blockIdx.z, h = blockIdx.y, ql = blockIdx.x;
+    const int q_begin = (int)p.cu_q[seq], qlen = (int)p.cu_q[seq + 1] - q_begin;
+    if (ql >= qlen) return;
+    const int ctx = p.context_lens ? (int)p.context_lens[seq] : qlen;
+    const int cached = ctx - qlen, lane = threadIdx.x;
+    const int hk = h / (p.H / p.Hkv), pos = cached + ql;
+    const uint32_t* bt = p.block_tables ? p.block_tables + (size_t)seq * p.max_blocks : nullptr;
+    const uint16_t* q16 = static_cast<const uint16_t*>(p.q) + ((size_t)(q_begin + ql) * p.H + h) * D;
+    auto cvt = [](uint16_t b) { return DT == MI355_DTYPE_BF16 ? bf16_to_f32(b) : f16_bits_to_f32(b); };
+    float qv[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) { const int d = lane + 64 * i; qv[i] = d < D ? cvt(q16[d]) : 0.f; }
+    float m = -INFINITY, l = 0.f;
+    for (int j = 0; j <= pos; ++j) {
+        float kv[4], vv[4], dot = 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int d = lane + 64 * i;
+            kv[i] = vv[i] = 0.f;
+            if (d >= D) continue;
+            size_t ko, vo;
+            if (src == SRC_CONTIG) { ko = vo = ((size_t)(q_begin + j) * p.Hkv + hk) * D + d; }
+            else {
+                const size_t blk = bt[j / p.block_size]; const int off = j % p.block_size;
+                if (src == SRC_FLASH) ko = vo = ((blk * p.block_size + off) * p.Hkv + hk) * D + d;
+                else { ko = (((blk * p.Hkv + hk) * (D / 8) + d / 8) * p.block_size + off) * 8 + d % 8;
+                       vo = ((blk * p.Hkv + hk) * D + d) * p.block_size + off; }
+            }
+            kv[i] = cvt(static_cast<const uint16_t*>(p.k)[ko]);
+            vv[i] = cvt(static_cast<const uint16_t*>(p.v)[vo]);
+            dot += qv[i] * kv[i];
+        }
+        dot = wave_sum(dot) * p.scale;
+        if (p.softcap > 0.f) dot = tanhf(dot / p.softcap) * p.softcap;
+        const float m_new = fmaxf(m, dot), alpha = __expf(m - m_new), pj = __expf(dot - m_new);
+        l = l * alpha + pj; m = m_new;
+        for (int i = 0; i < 4; ++i) acc[i] = acc[i] * alpha + pj * vv[i];
+    }
+    uint16_t* o16 = static_cast<uint16_t*>(p.out) + ((size_t)(q_begin + ql) * p.H + h) * D;
+    for (int i = 0; i < 4; ++i) {
+        const int d = lane + 64 * i;
+        if (d < D) o16[d] = DT == MI355_DTYPE_BF16 ? f32_to_bf16(acc[i] / l) : f32_to_f16_bits(acc[i] / l);
+    }
+}
+
+template <int DT, int D>
+static void prefill_launch_src(const PrefillParams& p, int src, dim3 grid, hipStream_t st) {
+    switch (src) {
+        case SRC_CONTIG: hipLaunchKernelGGL((prefill_attn_kernel<DT, D, SRC_CONTIG>), grid, dim3(256), 0, st, p); break;
+        case SRC_FLASH: hipLaunchKernelGGL((prefill_attn_kernel<DT, D, SRC_FLASH>), grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL((prefill_attn_kernel<DT, D, SRC_PAGED>), grid, dim3(256), 0, st, p); break;
+    }
+}
+
+extern "C" int mi355_prefill_attention(void* out, const void* q, const void* k, const void* v, const void* key_cache,
+                                       const void* value_cache, const uint32_t* block_tables, const uint32_t* context_lens,
+                                       const uint32_t* cu_seqlens_q, int32_t num_seqs, int32_t max_seqlen_q,
+                                       int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                                       int32_t max_blocks_per_seq, float scale, float softcap, int32_t layout,
+                                       int32_t dtype, int64_t stream) {
+    if (num_seqs <= 0 || max_seqlen_q <= 0) return 0;
+    if (dtype != MI355_DTYPE_BF16 && dtype != MI355_DTYPE_F16) return (int)hipErrorInvalidValue;
+    if (num_heads % num_kv_heads || head_dim > 256) return (int)hipErrorInvalidValue;
+    const bool cached = key_cache != nullptr;
+    if (cached && (!block_tables || !context_lens || !value_cache)) return (int)hipErrorInvalidValue;
+    if (!cached && (!k || !v)) return (int)hipErrorInvalidValue;
+    PrefillParams p{};
+    p.out = out; p.q = q;
+    p.k = cached ? key_cache : k; p.v = cached ? value_cache : v;
+    p.block_tables = cached ? block_tables : nullptr;
+    p.context_lens = cached ? context_lens : nullptr;
+    p.cu_q = cu_seqlens_q;
+    p.H = num_heads; p.Hkv = num_kv_heads; p.block_size = block_size; p.max_blocks = max_blocks_per_seq;
+    p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f; p.softcap = softcap > 0.f ? softcap : 0.f;
+    const int src = !cached ? SRC_CONTIG : (layout == MI355_KV_FLASH ? SRC_FLASH : SRC_PAGED);
+    hipStream_t st = (hipStream_t)stream;
+    const bool mfma_ok = (head_dim == 64 || head_dim == 128) && (src != SRC_PAGED || block_size % 16 == 0);
+    if (mfma_ok) {
+        dim3 grid((max_seqlen_q + 127) / 128, num_heads, num_seqs);
+        if (dtype == MI355_DTYPE_BF16) {
+            if (head_dim == 128) prefill_launch_src<MI355_DTYPE_BF16, 128>(p, src, grid, st);
+            else prefill_launch_src<MI355_DTYPE_BF16, 64>(p, src, grid, st);
+        } else {
+            if (head_dim == 128) prefill_launch_src<MI355_DTYPE_F16, 128>(p, src, grid, st);
+            else prefill_launch_src<MI355_DTYPE_F16, 64>(p, src, grid, st);
+        }
+    } else {
+        if (src == SRC_PAGED && head_dim % 8) return (int)hipErrorInvalidValue;
+        dim3 grid(max_seqlen_q, num_heads, num_seqs);
+        if (dtype == MI355_DTYPE_BF16) hipLaunchKernelGGL((prefill_attn_generic_kernel<MI355_DTYPE_BF16>), grid, dim3(64), 0, st, p, head_dim, src);
+        else hipLaunchKernelGGL((prefill_attn_generic_kernel<MI355_DTYPE_F16>), grid, dim3(64), 0, st, p, head_dim, src);
+    }
+    return (int)hipGetLastError();
+}

@@ -197,8 +197,31 @@ class PagedAttention:
             raise RuntimeError("PagedAttention.forward needs the paged KV cache")
         reshape_and_cache(k, v, key_cache, value_cache, input_metadata.slot_mapping)
         if input_metadata.is_prefill:
-            raise NotImplementedError("prefill attention kernel (K4) is not built yet -- SURVEY section 8(a) a9")
+            return self.prefill(q, k, v, key_cache, value_cache, input_metadata, softcapping)
         return self.decode(q, key_cache, value_cache, input_metadata, softcapping, partition_size)
+
+    def prefill(self, q, k, v, key_cache, value_cache, meta: InputMetadata, softcapping=None):
+        """K4.  Cached prefix (cu_seqlens_k != cu_seqlens_q, `use_cached_kv` inputs.rs:133-143) -> keys come from
+        the paged cache; otherwise from the chunk's own k, v."""
+        T, H, D = q.shape
+        out = torch.empty_like(q)
+        sc = float(softcapping) if softcapping else 0.0
+        n = meta.cu_seqlens_q.shape[0] - 1
+        use_cached = meta.max_seqlen_k > meta.max_seqlen_q
+        if use_cached:
+            layout = kv_layout_of(key_cache)
+            bs = key_cache.shape[1] if layout == KV_FLASH else key_cache.shape[3]
+            _check(lib.mi355_prefill_attention(_dev(out), _dev(q), None, None, _dev(key_cache), _dev(value_cache),
+                                               _dev(meta.block_tables), _dev(meta.context_lens),
+                                               _dev(meta.cu_seqlens_q), n, meta.max_seqlen_q, H, self.num_kv_heads,
+                                               D, bs, meta.block_tables.shape[1], self.scale, sc, layout,
+                                               _DT[q.dtype], _stream()), "prefill_attention")
+        else:
+            _check(lib.mi355_prefill_attention(_dev(out), _dev(q), _dev(k), _dev(v), None, None, None, None,
+                                               _dev(meta.cu_seqlens_q), n, meta.max_seqlen_q, H, self.num_kv_heads,
+                                               D, 0, 0, self.scale, sc, 0, _DT[q.dtype], _stream()),
+                   "prefill_attention")
+        return out
 
     def decode(self, q, key_cache, value_cache, meta: InputMetadata, softcapping=None, partition_size=None):
         layout = kv_layout_of(key_cache)

@@ -96,6 +96,20 @@ int mi355_paged_attention_v2(void* out, float* exp_sums, float* max_logits, floa
                              int32_t max_blocks_per_seq, int32_t max_context_len, int32_t partition_size,
                              float scale, float softcap, int32_t layout, int32_t dtype, int64_t stream);
 
+/* the prefill half of PagedAttention::forward (K4; attention.rs:707-719, metadata inputs.rs:90-230,351-367):
+ * causal variable-length attention.  q, out [num_tokens, num_heads, head_dim], 16-bit `dtype`;
+ * cu_seqlens_q u32 [num_seqs+1] delimits each sequence's chunk inside the flattened token dim.
+ * key_cache == NULL: no cached prefix, K/V come from k, v [num_tokens, num_kv_heads, head_dim].
+ * key_cache != NULL (prefix cache / chunked prefill, `use_cached_kv` inputs.rs:133-143): every key of a sequence
+ * (cached prefix AND the current chunk, which reshape_and_cache has already written) is read from the paged cache
+ * through block_tables; context_lens[i] = cached_i + chunk_i; query t of the chunk sees keys 0 .. cached_i + t. */
+int mi355_prefill_attention(void* out, const void* q, const void* k, const void* v, const void* key_cache,
+                            const void* value_cache, const uint32_t* block_tables, const uint32_t* context_lens,
+                            const uint32_t* cu_seqlens_q, int32_t num_seqs, int32_t max_seqlen_q,
+                            int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                            int32_t max_blocks_per_seq, float scale, float softcap, int32_t layout,
+                            int32_t dtype, int64_t stream);
+
 /* replaces attention_rs::fused_rope::FusedRope::apply_inplace[_partial] -- layers/rotary_emb.rs:58-70.
  * q [T,H,D], k [T,Hkv,D] rotated in place; cos/sin f32 [max_seq, rotary_dim/2]; positions i64 [T];
  * is_rope_i != 0 -> interleaved pairs (GGUF llama), else half-split ("neox"). dtype F32 or BF16. */

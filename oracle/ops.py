@@ -289,15 +289,16 @@ def kv_head_shard(total_kv_heads, rank, world_size):
     return 1, rank // (world_size // total_kv_heads), total_kv_heads
 
 
-def prefill_attention(q, k, v, scale, softcap=None):
-    """Causal self-attention for ONE sequence without cached prefix.  q [T,H,D], k/v [T,Hkv,D]
-    f32 values already bf16-rounded.  NaiveAttention math (models/mod.rs:1288-1306) with the
-    causal additive mask of layers/mask.rs:32-53.  Output bf16-rounded f32 [T,H,D]."""
+def prefill_attention(q, k, v, scale, softcap=None, cached=0, rnd=None):
+    """Causal self-attention for ONE sequence.  q [T,H,D] (the chunk), k/v [cached+T,Hkv,D] (cached prefix
+    followed by the chunk; `use_cached_kv`, inputs.rs:133-143) -- f32 values already rounded to the 16-bit dtype.
+    NaiveAttention math (models/mod.rs:1288-1306) with the causal additive mask of layers/mask.rs:32-53:
+    query t sees keys 0 .. cached+t.  Output rounded by `rnd` (default bf16) f32 [T,H,D]."""
     T, H, D = q.shape
     Hkv = k.shape[1]
     g = H // Hkv
     out = np.zeros((T, H, D), np.float32)
-    mask = np.triu(np.ones((T, T), bool), 1)
+    mask = np.triu(np.ones((T, cached + T), bool), cached + 1)
     for h in range(H):
         s = q[:, h].astype(np.float64) @ k[:, h // g].astype(np.float64).T * scale
         if softcap is not None:
@@ -307,4 +308,4 @@ def prefill_attention(q, k, v, scale, softcap=None):
         p = np.exp(s)
         p /= p.sum(-1, keepdims=True)
         out[:, h] = (p @ v[:, h // g].astype(np.float64)).astype(np.float32)
-    return round_bf16(out)
+    return round_bf16(out) if rnd is None else rnd(out)

@@ -1,0 +1,120 @@
+"""GPU parity tests for K4 (prefill attention) through the C ABI vs the numpy oracle (softmax in f64).
+Tolerance: flash-attention arithmetic (P rounded to 16 bit, f32 accumulation) vs exact softmax -> 2e-2 of the
+output scale for bf16, 4e-3 for f16, stated next to the assert; the output itself is a 16-bit value."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import ops as O                # noqa: E402
+from oracle import gptq as G               # noqa: E402  (16-bit helpers)
+
+TD = {"bf16": torch.bfloat16, "f16": torch.float16}
+TOL = {"bf16": 2e-2, "f16": 4e-3}
+
+
+@pytest.fixture(scope="module")
+def cv(lib):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (torch.cuda.is_available() is False)")
+    import candle_vllm_amd.ops as ops
+    return ops
+
+
+def dev16(a, dt):
+    return torch.from_numpy(np.ascontiguousarray(G.to_bits(a, dt)).view(np.int16)).cuda().view(TD[dt])
+
+
+def host16(t, dt):
+    return G.from_bits(t.detach().view(torch.int16).cpu().numpy().view(np.uint16), dt)
+
+
+def make_case(rng, lens, cached, H, Hkv, D, bs, dt, flash):
+    """sequences with `cached[i]` tokens already in the cache and lens[i] new tokens; shuffled block ids"""
+    n = len(lens)
+    ctx = [c + l for c, l in zip(cached, lens)]
+    nblk = [-(-c // bs) for c in ctx]
+    NB = sum(nblk) + 3
+    ids = rng.permutation(NB)[: sum(nblk)]
+    tables, o = [], 0
+    for b in nblk:
+        tables.append(ids[o:o + b].tolist())
+        o += b
+    ks, vs = O.kv_cache_shapes(NB, bs, Hkv, D, 2, flash)
+    kc = rng.integers(0, 65536, ks).astype(np.uint16)          # arbitrary bits (incl. NaN patterns) in unused slots
+    vc = rng.integers(0, 65536, vs).astype(np.uint16)
+    k_all = [G.round_dt(rng.normal(0, 1, (c, Hkv, D)), dt) for c in ctx]
+    v_all = [G.round_dt(rng.normal(0, 1, (c, Hkv, D)), dt) for c in ctx]
+    q = [G.round_dt(rng.normal(0, 1, (l, H, D)), dt) for l in lens]
+    # the whole context (prefix + chunk) is in the cache, as after reshape_and_cache
+    for i in range(n):
+        slots = np.array([tables[i][j // bs] * bs + j % bs for j in range(ctx[i])], np.int64)
+        O.reshape_and_cache(G.to_bits(k_all[i], dt), G.to_bits(v_all[i], dt), kc, vc, slots, flash)
+    seqs = [{"tokens": list(range(ctx[i])), "block_table": tables[i]} for i in range(n)]
+    meta = O.prepare_prompt(seqs, bs, cached)
+    return q, k_all, v_all, kc, vc, meta
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("H,Hkv,D", [(8, 2, 128), (4, 4, 64), (4, 2, 80)])
+@pytest.mark.parametrize("lens", [[1], [37], [130, 5, 64], [257]])
+def test_prefill_no_cache(cv, dt, H, Hkv, D, lens):
+    rng = np.random.default_rng(sum(lens) + D)
+    q, k_all, v_all, kc, vc, meta = make_case(rng, lens, [0] * len(lens), H, Hkv, D, 16, dt, True)
+    scale = 1.0 / np.sqrt(D)
+    pa = cv.PagedAttention(H, D, scale, Hkv)
+    im = cv.InputMetadata.from_oracle_meta(meta, "cuda", is_prefill=True)
+    kcat, vcat = np.concatenate(k_all), np.concatenate(v_all)
+    out = pa.prefill(dev16(np.concatenate(q), dt), dev16(kcat, dt), dev16(vcat, dt), None, None, im)
+    got = host16(out, dt)
+    o = 0
+    for i, l in enumerate(lens):
+        ref = O.prefill_attention(q[i], k_all[i], v_all[i], scale, rnd=lambda a: G.round_dt(a, dt))
+        assert np.abs(got[o:o + l] - ref).max() <= TOL[dt] * max(1.0, np.abs(ref).max()), f"seq {i}"
+        o += l
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("flash", [True, False])
+@pytest.mark.parametrize("H,Hkv,D,bs", [(8, 2, 128, 64), (4, 4, 64, 16), (4, 2, 80, 16)])
+def test_prefill_cached_prefix(cv, dt, flash, H, Hkv, D, bs):
+    rng = np.random.default_rng(D + bs + int(flash))
+    lens, cached = [70, 3, 129], [50, 0, 200]                     # chunked prefill / prefix-cache hit / fresh
+    q, k_all, v_all, kc, vc, meta = make_case(rng, lens, cached, H, Hkv, D, bs, dt, flash)
+    scale = 1.0 / np.sqrt(D)
+    pa = cv.PagedAttention(H, D, scale, Hkv)
+    im = cv.InputMetadata.from_oracle_meta(meta, "cuda", is_prefill=True)
+    assert im.max_seqlen_k > im.max_seqlen_q
+    kcd = torch.from_numpy(kc.view(np.int16)).cuda().view(TD[dt])
+    vcd = torch.from_numpy(vc.view(np.int16)).cuda().view(TD[dt])
+    out = pa.prefill(dev16(np.concatenate(q), dt), None, None, kcd, vcd, im)
+    got = host16(out, dt)
+    assert np.isfinite(got).all()
+    o = 0
+    for i, l in enumerate(lens):
+        ref = O.prefill_attention(q[i], k_all[i], v_all[i], scale, cached=cached[i], rnd=lambda a: G.round_dt(a, dt))
+        assert np.abs(got[o:o + l] - ref).max() <= TOL[dt] * max(1.0, np.abs(ref).max()), f"seq {i}"
+        o += l
+
+
+def test_prefill_softcap_and_decode_consistency(cv):
+    """softcap path; and the last prefill row equals the decode kernel's answer for the same context"""
+    dt, H, Hkv, D, bs = "bf16", 8, 2, 128, 16
+    rng = np.random.default_rng(5)
+    lens = [90]
+    q, k_all, v_all, kc, vc, meta = make_case(rng, lens, [0], H, Hkv, D, bs, dt, False)
+    scale = 1.0 / np.sqrt(D)
+    pa = cv.PagedAttention(H, D, scale, Hkv)
+    im = cv.InputMetadata.from_oracle_meta(meta, "cuda", is_prefill=True)
+    out = pa.prefill(dev16(q[0], dt), dev16(k_all[0], dt), dev16(v_all[0], dt), None, None, im, softcapping=30.0)
+    ref = O.prefill_attention(q[0], k_all[0], v_all[0], scale, softcap=30.0)
+    assert np.abs(host16(out, dt) - ref).max() <= TOL[dt] * max(1.0, np.abs(ref).max())
+    out2 = host16(pa.prefill(dev16(q[0], dt), dev16(k_all[0], dt), dev16(v_all[0], dt), None, None, im), dt)
+    kcd = torch.from_numpy(kc.view(np.int16)).cuda().view(TD[dt])
+    vcd = torch.from_numpy(vc.view(np.int16)).cuda().view(TD[dt])
+    dmeta = O.prepare_decode([{"tokens": list(range(90)), "block_table": meta["block_tables"][0].tolist()}], bs)
+    dm = cv.InputMetadata.from_oracle_meta(dmeta, "cuda")
+    dec = host16(pa.decode(dev16(q[0][-1:], dt), kcd, vcd, dm), dt)
+    assert np.abs(dec[0] - out2[-1]).max() <= TOL[dt]
