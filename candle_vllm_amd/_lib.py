@@ -107,6 +107,7 @@ _sig("mi355_llama_kv_ptr", c_vp, [c_vp, c_i32, c_i32])
 _sig("mi355_llama_kv_bytes_per_tensor", c_i64, [c_vp])
 _sig("mi355_llama_kv_copy", ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_i64, c_i32])
 _sig("mi355_llama_forward_decode", ctypes.c_int, [c_vp] * 6 + [c_i32, c_i32, c_i32, c_vp, c_i64])
+_sig("mi355_llama_forward_prefill", ctypes.c_int, [c_vp] * 7 + [c_i32] * 4 + [c_vp, c_i64])
 _sig("mi355_llama_decode_begin", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
 _sig("mi355_llama_set_graph", ctypes.c_int, [c_vp, c_i32])
 _sig("mi355_llama_decode_step", ctypes.c_int, [c_vp, c_i64])

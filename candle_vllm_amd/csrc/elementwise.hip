@@ -241,6 +241,8 @@ extern "C" int mi355_argmax_f32(uint32_t* out, const float* logits, int32_t batc
         if (e != hipSuccess) return (int)e;
         e = hipMemset(g_argmax_slots, 0, ARGMAX_MAX_ROWS * 8);
         if (e != hipSuccess) return (int)e;
+        e = hipDeviceSynchronize();     // the memset runs on the null stream; `stream` may be non-blocking
+        if (e != hipSuccess) return (int)e;
     }
     hipStream_t st = to_stream(stream);
     hipLaunchKernelGGL(argmax_stage1_kernel, dim3(ARGMAX_SPLIT, batch), dim3(256), 0, st, g_argmax_slots, logits, vocab);

@@ -123,6 +123,9 @@ struct Model {
     bool use_comm = false;          // tp_world > 1, or forced (single-rank plumbing test: MI355_FORCE_COMM=1)
     float* logits_local = nullptr;  // [B, vocab/W]
     float* logits_gather = nullptr; // [W, B, vocab/W]
+    // prefill workspace (grow-only, sized by the largest chunk seen): same roles as xs / q / attn / h
+    float* p_xs = nullptr; uint16_t* p_q = nullptr; uint16_t* p_attn = nullptr; float* p_h = nullptr;
+    int p_cap = 0;
 };
 
 int local_heads(const Model* m) { return m->cfg.n_heads / (m->cfg.tp_world > 0 ? m->cfg.tp_world : 1); }
@@ -161,7 +164,17 @@ int choose_partition(int batch, int kv_heads, int ctx_cap) {
 struct StepIn {
     const uint32_t* tokens; const int64_t* positions; const int64_t* slots; const uint32_t* bt; const uint32_t* ctx;
     int B, max_blocks, ctx_cap;
+    // activation buffers of this step (decode: the model's static ones; prefill: the T-row workspace)
+    float* xs; uint16_t* q; uint16_t* attn; float* h;
+    // prefill only (is_prefill): cu_seqlens_q [num_seqs+1], B = total tokens
+    bool is_prefill; const uint32_t* cu_q; int num_seqs, max_seqlen_q;
 };
+
+// xs rows of the last token of every sequence -> [num_seqs, hidden]   (quantized_llama.rs:495-499)
+__global__ void select_last_rows_kernel(float* dst, const float* src, const uint32_t* cu_q, int hidden) {
+    const size_t row = (size_t)cu_q[blockIdx.x + 1] - 1;
+    for (int i = threadIdx.x; i < hidden; i += blockDim.x) dst[(size_t)blockIdx.x * hidden + i] = src[row * hidden + i];
+}
 
 // [W, B, Vl] -> [B, W*Vl]   (VocabParallelLinear: all-gather then un-interleave, distributed.rs:1637-1663)
 __global__ void gather_transpose_kernel(float* out, const float* in, int W, int B, int Vl) {
@@ -172,13 +185,13 @@ __global__ void gather_transpose_kernel(float* out, const float* in, int W, int 
     }
 }
 
-int all_reduce_xs(Model* m, int B, int64_t st) {
+int all_reduce_xs(Model* m, float* xs, int B, int64_t st) {
     if (!m->use_comm) return 0;
     if (!m->comm) return (int)hipErrorNotInitialized;
     // C1/C2: all-reduce(sum) of [B, hidden] after o_proj / down_proj (distributed.rs:696-711).  The reference
     // sends bf16 (attention.rs:1005-1009); we keep the f32 residual stream on the wire (decode messages are
     // latency-bound: 16 KiB at B=1).
-    return g_rccl.all_reduce(m->xs, m->xs, (size_t)B * m->cfg.hidden, NCCL_FLOAT32, NCCL_SUM, m->comm,
+    return g_rccl.all_reduce(xs, xs, (size_t)B * m->cfg.hidden, NCCL_FLOAT32, NCCL_SUM, m->comm,
                              reinterpret_cast<hipStream_t>(st)) == 0 ? 0 : (int)hipErrorUnknown;
 }
 
@@ -191,12 +204,12 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
     const bool lead = c.tp_rank == 0;                              // the rank that carries the residual into the sum
     mi355_qmm_desc d;
     memset(&d, 0, sizeof(d));
-    if (part == PART_EMBED) return mi355_embedding_f32(m->xs, m->tok_embd, in.tokens, B, hid, st);
+    if (part == PART_EMBED) return mi355_embedding_f32(in.xs, m->tok_embd, in.tokens, B, hid, st);
     if (part == PART_HEAD) {
         // --- output_norm + lm_head -> logits f32       (quantized_llama.rs:500-505; vocab-parallel under TP)
         d.nseg = 1;
         d.w_tiles[0] = m->output.tiles; d.ggml_type[0] = m->output.type; d.n_rows[0] = m->output.n_rows;
-        d.x = m->xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
+        d.x = in.xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
         d.norm_weight = m->output_norm; d.norm_eps = c.rms_eps;
         d.epilogue = MI355_EPI_STORE; d.ldo = m->output.n_rows;
         if (!m->use_comm) { d.out = logits; return mi355_qmatmul_fused(&d, st); }
@@ -219,14 +232,20 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
         for (int s = 0; s < 3; ++s) {
             d.w_tiles[s] = L.w[qkv[s]].tiles; d.ggml_type[s] = L.w[qkv[s]].type; d.n_rows[s] = L.w[qkv[s]].n_rows;
         }
-        d.x = m->xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
+        d.x = in.xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
         d.norm_weight = L.attn_norm; d.norm_eps = c.rms_eps;
         d.epilogue = MI355_EPI_QKV_ROPE_CACHE;
         d.cos_table = m->cos_t; d.sin_table = m->sin_t; d.positions = in.positions; d.slot_mapping = in.slots;
-        d.q_out = m->q; d.key_cache = m->kcache[l]; d.value_cache = m->vcache[l];
+        d.q_out = in.q; d.key_cache = m->kcache[l]; d.value_cache = m->vcache[l];
         d.num_heads = H; d.num_kv_heads = Hkv; d.head_dim = D; d.rotary_dim = D;
         d.block_size = c.block_size; d.kv_layout = c.kv_layout;
         return mi355_qmatmul_fused(&d, st);
+    }
+    if (part == PART_ATTN && in.is_prefill) {
+        // --- K4: every key (cached prefix + this chunk, just written by the QKV epilogue) comes from the cache
+        return mi355_prefill_attention(in.attn, in.q, nullptr, nullptr, m->kcache[l], m->vcache[l], in.bt, in.ctx,
+                                       in.cu_q, in.num_seqs, in.max_seqlen_q, H, Hkv, D, c.block_size, in.max_blocks,
+                                       1.0f / sqrtf((float)D), 0.f, c.kv_layout, MI355_DTYPE_BF16, st);
     }
     if (part == PART_ATTN) {
         // --- paged attention over the cache (the new token's K/V are already in place)
@@ -236,10 +255,10 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
         if (ps > 0 && (in.ctx_cap + ps - 1) / ps > m->pa_cap_partitions) return (int)hipErrorInvalidValue;
         if (in.ctx_cap > c.max_seq) return (int)hipErrorInvalidValue;
         if (ps == 0)
-            return mi355_paged_attention_v1(m->attn, m->q, m->kcache[l], m->vcache[l], in.bt, in.ctx, B, H, Hkv, D,
+            return mi355_paged_attention_v1(in.attn, in.q, m->kcache[l], m->vcache[l], in.bt, in.ctx, B, H, Hkv, D,
                                             c.block_size, in.max_blocks, in.ctx_cap, scale, 0.f, c.kv_layout,
                                             MI355_DTYPE_BF16, st);
-        return mi355_paged_attention_v2(m->attn, m->pa_sum, m->pa_max, m->pa_tmp, m->q, m->kcache[l], m->vcache[l],
+        return mi355_paged_attention_v2(in.attn, m->pa_sum, m->pa_max, m->pa_tmp, in.q, m->kcache[l], m->vcache[l],
                                         in.bt, in.ctx, B, H, Hkv, D, c.block_size, in.max_blocks, in.ctx_cap, ps,
                                         scale, 0.f, c.kv_layout, MI355_DTYPE_BF16, st);
     }
@@ -247,29 +266,29 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
         // --- wo(y.to_dtype(F32)) + residual (+ all-reduce)   (attention.rs:1004-1009, quantized_llama.rs:464)
         d.nseg = 1;
         d.w_tiles[0] = L.w[MI355_W_WO].tiles; d.ggml_type[0] = L.w[MI355_W_WO].type; d.n_rows[0] = L.w[MI355_W_WO].n_rows;
-        d.x = m->attn; d.x_dtype = MI355_DTYPE_BF16; d.ldx = H * D; d.k = H * D; d.num_tokens = B;
-        d.epilogue = lead ? MI355_EPI_RESID : MI355_EPI_STORE; d.out = m->xs; d.ldo = hid; d.residual = m->xs;
+        d.x = in.attn; d.x_dtype = MI355_DTYPE_BF16; d.ldx = H * D; d.k = H * D; d.num_tokens = B;
+        d.epilogue = lead ? MI355_EPI_RESID : MI355_EPI_STORE; d.out = in.xs; d.ldo = hid; d.residual = in.xs;
         RCHECK(mi355_qmatmul_fused(&d, st));
-        return all_reduce_xs(m, B, st);
+        return all_reduce_xs(m, in.xs, B, st);
     }
     if (part == PART_GATEUP) {
         // --- ffn_norm + w1|w3 + silu*mul              (quantized_llama.rs:33-37, 468)
         d.nseg = 2;
         d.w_tiles[0] = L.w[MI355_W_W1].tiles; d.ggml_type[0] = L.w[MI355_W_W1].type; d.n_rows[0] = L.w[MI355_W_W1].n_rows;
         d.w_tiles[1] = L.w[MI355_W_W3].tiles; d.ggml_type[1] = L.w[MI355_W_W3].type; d.n_rows[1] = L.w[MI355_W_W3].n_rows;
-        d.x = m->xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
+        d.x = in.xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
         d.norm_weight = L.ffn_norm; d.norm_eps = c.rms_eps;
-        d.epilogue = MI355_EPI_SILU_MUL; d.out = m->h; d.ldo = I;
+        d.epilogue = MI355_EPI_SILU_MUL; d.out = in.h; d.ldo = I;
         return mi355_qmatmul_fused(&d, st);
     }
     if (part == PART_DOWN) {
         // --- w2 + residual (+ all-reduce)             (quantized_llama.rs:37-42, 470)
         d.nseg = 1;
         d.w_tiles[0] = L.w[MI355_W_W2].tiles; d.ggml_type[0] = L.w[MI355_W_W2].type; d.n_rows[0] = L.w[MI355_W_W2].n_rows;
-        d.x = m->h; d.x_dtype = MI355_DTYPE_F32; d.ldx = I; d.k = I; d.num_tokens = B;
-        d.epilogue = lead ? MI355_EPI_RESID : MI355_EPI_STORE; d.out = m->xs; d.ldo = hid; d.residual = m->xs;
+        d.x = in.h; d.x_dtype = MI355_DTYPE_F32; d.ldx = I; d.k = I; d.num_tokens = B;
+        d.epilogue = lead ? MI355_EPI_RESID : MI355_EPI_STORE; d.out = in.xs; d.ldo = hid; d.residual = in.xs;
         RCHECK(mi355_qmatmul_fused(&d, st));
-        return all_reduce_xs(m, B, st);
+        return all_reduce_xs(m, in.xs, B, st);
     }
     return (int)hipErrorInvalidValue;
 }
@@ -281,7 +300,8 @@ int forward_decode(Model* m, const uint32_t* tokens, const int64_t* positions, c
     const mi355_llama_config& c = m->cfg;
     if (B < 1 || B > c.max_batch) return (int)hipErrorInvalidValue;
     if ((int)m->kcache.size() != c.n_layers) return (int)hipErrorInvalidValue;
-    const StepIn in{tokens, positions, slots, bt, ctx, B, max_blocks, ctx_cap};
+    const StepIn in{tokens, positions, slots, bt, ctx, B, max_blocks, ctx_cap, m->xs, m->q, m->attn, m->h,
+                    false, nullptr, 0, 0};
     RCHECK(run_part(m, 0, PART_EMBED, in, logits, st));
     for (int l = 0; l < c.n_layers; ++l)
         for (int part = PART_QKV; part <= PART_DOWN; ++part) RCHECK(run_part(m, l, part, in, logits, st));
@@ -377,7 +397,7 @@ extern "C" void mi355_llama_destroy(void* mp) {
     free_qw(m->output);
     void* ptrs[] = {m->tok_embd, m->output_norm, m->cos_t, m->sin_t, m->xs, m->q, m->attn, m->h, m->logits,
                     m->pa_tmp, m->pa_max, m->pa_sum, m->kv_slab, m->d_tokens, m->d_positions, m->d_slots,
-                    m->d_ctx, m->d_bt, m->logits_local, m->logits_gather};
+                    m->d_ctx, m->d_bt, m->logits_local, m->logits_gather, m->p_xs, m->p_q, m->p_attn, m->p_h};
     if (m->comm && g_rccl.destroy) (void)g_rccl.destroy(m->comm);
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete m;
@@ -436,6 +456,7 @@ extern "C" int mi355_llama_alloc_kv_cache(void* mp, int32_t num_blocks) {
     if (m->kv_slab) { (void)hipFree(m->kv_slab); m->kv_slab = nullptr; }
     HCHECK(hipMalloc(&m->kv_slab, per * 2 * c.n_layers));
     HCHECK(hipMemset(m->kv_slab, 0, per * 2 * c.n_layers));
+    HCHECK(hipDeviceSynchronize());
     m->kcache.resize(c.n_layers);
     m->vcache.resize(c.n_layers);
     for (int l = 0; l < c.n_layers; ++l) {
@@ -469,6 +490,47 @@ extern "C" int64_t mi355_llama_kv_bytes_per_tensor(void* mp) {
     Model* m = static_cast<Model*>(mp);
     if (!m) return -1;
     return (int64_t)m->num_blocks * m->cfg.block_size * local_kv_heads(m) * m->cfg.head_dim * 2;
+}
+
+static int ensure_prefill_cap(Model* m, int T) {
+    if (T <= m->p_cap) return 0;
+    void* old[] = {m->p_xs, m->p_q, m->p_attn, m->p_h};
+    HCHECK(hipDeviceSynchronize());
+    for (void* p : old) if (p) (void)hipFree(p);
+    m->p_xs = nullptr; m->p_q = nullptr; m->p_attn = nullptr; m->p_h = nullptr; m->p_cap = 0;
+    const int H = local_heads(m), D = m->cfg.head_dim;
+    const int cap = (T + 255) / 256 * 256;
+    HCHECK(hipMalloc((void**)&m->p_xs, (size_t)cap * m->cfg.hidden * 4));
+    HCHECK(hipMalloc((void**)&m->p_q, (size_t)cap * H * D * 2));
+    HCHECK(hipMalloc((void**)&m->p_attn, (size_t)cap * H * D * 2));
+    HCHECK(hipMalloc((void**)&m->p_h, (size_t)cap * m->cfg.intermediate * 4));
+    m->p_cap = cap;
+    return 0;
+}
+
+// GGUFLLaMa::forward_inner on a PROMPT step (quantized_llama.rs:424-506 with input_metadata.is_prefill):
+// tokens of all sequences flattened [T]; logits f32 [num_seqs, vocab] of each sequence's last chunk token.
+extern "C" int mi355_llama_forward_prefill(void* mp, const uint32_t* tokens, const int64_t* positions,
+                                           const int64_t* slot_mapping, const uint32_t* block_tables,
+                                           const uint32_t* context_lens, const uint32_t* cu_seqlens_q,
+                                           int32_t num_seqs, int32_t num_tokens, int32_t max_seqlen_q,
+                                           int32_t max_blocks, float* logits, int64_t stream) {
+    Model* m = static_cast<Model*>(mp);
+    if (!m || !logits || num_seqs < 1 || num_tokens < num_seqs || num_seqs > m->cfg.max_batch)
+        return (int)hipErrorInvalidValue;
+    const mi355_llama_config& c = m->cfg;
+    if ((int)m->kcache.size() != c.n_layers) return (int)hipErrorInvalidValue;
+    RCHECK(ensure_prefill_cap(m, num_tokens));
+    StepIn in{tokens, positions, slot_mapping, block_tables, context_lens, num_tokens, max_blocks, 0,
+              m->p_xs, m->p_q, m->p_attn, m->p_h, true, cu_seqlens_q, num_seqs, max_seqlen_q};
+    RCHECK(run_part(m, 0, PART_EMBED, in, logits, stream));
+    for (int l = 0; l < c.n_layers; ++l)
+        for (int part = PART_QKV; part <= PART_DOWN; ++part) RCHECK(run_part(m, l, part, in, logits, stream));
+    // last-token row select, then final norm + lm_head on num_seqs rows (the decode buffers are large enough)
+    hipLaunchKernelGGL(select_last_rows_kernel, dim3(num_seqs), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       m->xs, m->p_xs, cu_seqlens_q, c.hidden);
+    in.xs = m->xs; in.B = num_seqs;
+    return run_part(m, 0, PART_HEAD, in, logits, stream);
 }
 
 extern "C" int mi355_llama_forward_decode(void* mp, const uint32_t* tokens, const int64_t* positions,
@@ -597,6 +659,7 @@ extern "C" int mi355_llama_init_comm(void* mp, const void* id128) {
 extern "C" int mi355_llama_run_part(void* mp, int32_t layer, int32_t part, int64_t stream) {
     Model* m = static_cast<Model*>(mp);
     if (!m || m->cur_batch < 1 || layer < 0 || layer >= m->cfg.n_layers) return (int)hipErrorInvalidValue;
-    const StepIn in{m->d_tokens, m->d_positions, m->d_slots, m->d_bt, m->d_ctx, m->cur_batch, m->cur_max_blocks, m->cur_ctx_cap};
+    const StepIn in{m->d_tokens, m->d_positions, m->d_slots, m->d_bt, m->d_ctx, m->cur_batch, m->cur_max_blocks, m->cur_ctx_cap,
+                    m->xs, m->q, m->attn, m->h, false, nullptr, 0, 0};
     return run_part(m, layer, part, in, m->logits, stream);
 }

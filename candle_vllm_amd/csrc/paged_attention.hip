@@ -651,6 +651,7 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
             if (!g_pa_arrive) {                                     // first call (eager warm-up), never in a capture
                 if (hipMalloc((void**)&g_pa_arrive, PA_ARRIVE_SLOTS * 4) != hipSuccess) return (int)hipErrorOutOfMemory;
                 if (hipMemset(g_pa_arrive, 0, PA_ARRIVE_SLOTS * 4) != hipSuccess) return (int)hipErrorUnknown;
+                if (hipDeviceSynchronize() != hipSuccess) return (int)hipErrorUnknown;   // null-stream memset vs a non-blocking `stream`
             }
             p.arrive = g_pa_arrive;
             fused = true;

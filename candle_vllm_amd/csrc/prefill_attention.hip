@@ -199,10 +199,23 @@ __global__ void __launch_bounds__(256) prefill_attn_kernel(const PrefillParams p
             l_run[s] = l_run[s] * alpha + psum;
             m_run[s] = m_new;
             const uint4 pb = make_uint4(pf_pack<DT>(x[0], x[1]), pf_pack<DT>(x[2], x[3]), pf_pack<DT>(x[4], x[5]), pf_pack<DT>(x[6], x[7]));
+            // bf16 keeps 8 bits of a probability: carry the rounding residual in a second operand so that P.V
+            // matches the f32-softmax definition to ~2^-17 (the 1e-3 logit tolerance is against exact softmax)
+            uint4 pl = make_uint4(0, 0, 0, 0);
+            if constexpr (DT == MI355_DTYPE_BF16) {
+                float r[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t w = (i & 1) ? ((&pb.x)[i >> 1] & 0xFFFF0000u) : ((&pb.x)[i >> 1] << 16);
+                    r[i] = x[i] - __uint_as_float(w);
+                }
+                pl = make_uint4(pf_pack<DT>(r[0], r[1]), pf_pack<DT>(r[2], r[3]), pf_pack<DT>(r[4], r[5]), pf_pack<DT>(r[6], r[7]));
+            }
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
                 o[s][dt][0] *= alpha; o[s][dt][1] *= alpha; o[s][dt][2] *= alpha; o[s][dt][3] *= alpha;
                 o[s][dt] = pf_mfma<DT>(vt[dt], pb, o[s][dt]);   // C: col = query r16, rows d = 16dt + 4kg + v
+                if constexpr (DT == MI355_DTYPE_BF16) o[s][dt] = pf_mfma<DT>(vt[dt], pl, o[s][dt]);
             }
         }
     }

@@ -256,6 +256,26 @@ class GGUFLLaMa:
         torch.cuda.synchronize()
         return logits
 
+    def forward_prefill(self, meta, stream=None):
+        """One prompt step (is_prefill).  meta: dict from oracle.ops.prepare_prompt (numpy).  Returns the logits of
+        every sequence's last chunk token, f32 [num_seqs, vocab]."""
+        dev = "cuda"
+        n = len(meta["context_lens"])
+        T = len(meta["input_ids"])
+        tok = torch.from_numpy(meta["input_ids"].astype(np.int64).astype(np.int32)).to(dev)
+        pos = torch.from_numpy(meta["positions"].astype(np.int64)).to(dev)
+        slots = torch.from_numpy(meta["slot_mapping"].astype(np.int64)).to(dev)
+        bt = torch.from_numpy(meta["block_tables"].astype(np.int64).astype(np.int32)).contiguous().to(dev)
+        ctx = torch.from_numpy(meta["context_lens"].astype(np.int64).astype(np.int32)).to(dev)
+        cu = torch.from_numpy(meta["cu_seqlens_q"].astype(np.int64).astype(np.int32)).to(dev)
+        logits = torch.empty((n, self.cfg.vocab), dtype=torch.float32, device=dev)
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        _check(lib.mi355_llama_forward_prefill(self.h, tok.data_ptr(), pos.data_ptr(), slots.data_ptr(), bt.data_ptr(),
+                                               ctx.data_ptr(), cu.data_ptr(), n, T, int(meta["max_seqlen_q"]),
+                                               bt.shape[1], logits.data_ptr(), st), "forward_prefill")
+        torch.cuda.synchronize()
+        return logits
+
     def decode_begin(self, tokens, seq_lens, block_tables, ctx_cap, stream):
         tokens = np.ascontiguousarray(tokens, np.uint32)
         seq_lens = np.ascontiguousarray(seq_lens, np.uint32)

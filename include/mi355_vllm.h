@@ -272,6 +272,15 @@ int mi355_llama_forward_decode(void* model, const uint32_t* tokens, const int64_
                                const int64_t* slot_mapping, const uint32_t* block_tables,
                                const uint32_t* context_lens, int32_t batch, int32_t max_blocks,
                                int32_t max_context_len, float* logits, int64_t stream);
+/* one PROMPT step (is_prefill; prepare_prompt fields as raw DEVICE pointers, inputs.rs:90-230): tokens of all
+ * sequences flattened [num_tokens]; cu_seqlens_q u32 [num_seqs+1]; context_lens[i] = cached_i + chunk_i;
+ * K/V of the chunk are written to the paged cache and attention (K4) reads prefix + chunk from it;
+ * logits f32 [num_seqs, vocab] for the LAST chunk token of every sequence (quantized_llama.rs:495-505). */
+int mi355_llama_forward_prefill(void* model, const uint32_t* tokens, const int64_t* positions,
+                                const int64_t* slot_mapping, const uint32_t* block_tables,
+                                const uint32_t* context_lens, const uint32_t* cu_seqlens_q, int32_t num_seqs,
+                                int32_t num_tokens, int32_t max_seqlen_q, int32_t max_blocks, float* logits,
+                                int64_t stream);
 /* greedy decode loop on static device buffers; the step is replayed from a hipGraph when stream != 0 */
 int mi355_llama_decode_begin(void* model, const uint32_t* tokens_host, const uint32_t* seq_lens_host,
                              const uint32_t* block_tables_host, int32_t batch, int32_t max_blocks, int32_t ctx_cap,

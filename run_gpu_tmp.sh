@@ -1,3 +1,4 @@
 mkdir -p gpurun_out
-timeout 400 python -m pytest tests/test_gpu_linear.py tests/test_gpu_prefill.py -m gpu -q > gpurun_out/pf_tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/pf_tests.log
-tail -25 gpurun_out/pf_tests.log
+timeout 300 python -m pytest tests/test_gpu_model.py -m gpu -q -k greedy 2>&1 | grep -E "passed|failed" > gpurun_out/full.log
+timeout 800 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|^E  .*Assert|^FAILED" >> gpurun_out/full.log
+cat gpurun_out/full.log
