@@ -15,7 +15,7 @@ def declared_symbols(header_path=HEADER_PATH):
     """Every function name declared in the public header."""
     src = open(header_path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"^\s*(?:void\*?|int|int32_t|int64_t|float\*)\s+(\w+)\s*\(", src, flags=re.M)
+    names = re.findall(r"^\s*(?:void\*?|int|int32_t|int64_t|uint64_t|float\*)\s+(\w+)\s*\(", src, flags=re.M)
     return sorted(set(names))
 
 
@@ -116,3 +116,46 @@ _sig("mi355_llama_logits_ptr", c_vp, [c_vp])
 _sig("mi355_comm_unique_id", ctypes.c_int, [c_vp])
 _sig("mi355_llama_init_comm", ctypes.c_int, [c_vp, c_vp])
 _sig("mi355_llama_run_part", ctypes.c_int, [c_vp, c_i32, c_i32, c_i64])
+
+
+# ---- host block manager (section 5 of the header): every entry point takes plain ints / pointers
+c_u32, c_u64 = ctypes.c_uint32, ctypes.c_uint64
+_sig("mi355_be_create", c_vp, [c_i32] * 5)
+_sig("mi355_be_destroy", None, [c_vp])
+for _n in ("mi355_be_num_free_blocks", "mi355_be_num_free_cpu_blocks", "mi355_be_num_blocks",
+           "mi355_be_prefix_cache_blocks", "mi355_pc_cached_blocks", "mi355_pc_lru_len"):
+    _sig(_n, c_i32, [c_vp])
+_sig("mi355_be_free_block_ids", c_i32, [c_vp, c_vp, c_i32])
+_sig("mi355_be_seq_create", c_i32, [c_vp, c_i64, c_vp, c_i32])
+for _n in ("mi355_be_seq_remove", "mi355_be_seq_len", "mi355_be_seq_logical_blocks", "mi355_be_seq_get_cached_tokens",
+           "mi355_be_seq_has_prefix_hash", "mi355_be_pop_back_block", "mi355_be_free_sequence",
+           "mi355_be_cache_sequence", "mi355_be_fallback_to_full_prefill"):
+    _sig(_n, c_i32, [c_vp, c_i64])
+_sig("mi355_be_seq_add_token", c_i32, [c_vp, c_i64, c_u32])
+for _n in ("mi355_be_seq_set_cached_tokens", "mi355_be_seq_set_warmup_tokens", "mi355_be_seq_prefill_chunk_tokens",
+           "mi355_be_rebuild_with_cached_prefix"):
+    _sig(_n, c_i32, [c_vp, c_i64, c_i32])
+_sig("mi355_be_block_table", c_i32, [c_vp, c_i64, c_vp, c_i32])
+_sig("mi355_be_block_refcount", c_i32, [c_vp, c_i32])
+for _n in ("mi355_be_can_allocate", "mi355_be_allocate", "mi355_be_prefill_chunk_blocks_required",
+           "mi355_be_can_append_prefill_chunk", "mi355_be_append_prefill_chunk_slots"):
+    _sig(_n, c_i32, [c_vp, c_vp, c_i32, c_i32])
+for _n in ("mi355_be_can_append_token", "mi355_be_can_swap_out", "mi355_be_swap_in_required_blocks",
+           "mi355_be_can_swap_in"):
+    _sig(_n, c_i32, [c_vp, c_vp, c_i32])
+_sig("mi355_be_append_token_slot", c_i32, [c_vp, c_i64, c_vp, c_vp])
+for _n in ("mi355_be_evict_prefix_cache_blocks", "mi355_be_evict_prefix_cache_until_free"):
+    _sig(_n, c_i32, [c_vp, c_i32])
+_sig("mi355_be_query_prefix_match_tokens", c_i32, [c_vp, c_vp, c_i32])
+for _n in ("mi355_be_swap_out", "mi355_be_swap_in"):
+    _sig(_n, c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i32])
+for _n in ("mi355_be_finalize_swap_out", "mi355_be_rollback_swap_out", "mi355_be_finalize_swap_in",
+           "mi355_be_rollback_swap_in"):
+    _sig(_n, None, [c_vp, c_i64])
+_sig("mi355_pc_create", c_vp, [c_i32] * 4)
+_sig("mi355_pc_insert", c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32])
+_sig("mi355_pc_match", c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32])
+_sig("mi355_pc_evict", c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32])
+_sig("mi355_pc_hash_for_blocks", c_u64, [c_vp, c_vp, c_i32, c_i32, c_i32, c_u64, c_i32])
+_sig("mi355_be_prepare_decode", c_i32, [c_vp, c_vp, c_i32] + [c_vp] * 5 + [c_i32])
+_sig("mi355_be_prepare_prompt", c_i32, [c_vp, c_vp, c_i32, c_i32] + [c_vp] * 7 + [c_i32, c_i32, c_vp])

@@ -297,6 +297,77 @@ int mi355_llama_init_comm(void* model, const void* id128);
  * 3 gate/up, 4 down, 5 lm_head, 6 embedding) */
 int mi355_llama_run_part(void* model, int32_t layer, int32_t part, int64_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * 5. Host block manager: BlockEngine + PrefixCache + Sequence bookkeeping + input preparation.
+ *    Mirrors src/scheduler/block_engine.rs:190-1474, prefix_cache.rs:36-384, sequence.rs:90-300 and
+ *    src/openai/pipelines/inputs.rs:90-230,376-454.  Pure host code (no device work).  A block is an int32
+ *    code: id >= 0 on the GPU, -1-id on the CPU.  A "group" is passed as an array of sequence ids.
+ * ------------------------------------------------------------------------------------------- */
+void* mi355_be_create(int32_t block_size, int32_t num_gpu_blocks, int32_t num_cpu_blocks, int32_t prefix_cache_enabled,
+                      int32_t max_cached_blocks);
+void mi355_be_destroy(void* be);
+int32_t mi355_be_num_free_blocks(void* be);
+int32_t mi355_be_num_free_cpu_blocks(void* be);
+int32_t mi355_be_num_blocks(void* be);
+int32_t mi355_be_prefix_cache_blocks(void* be);
+int32_t mi355_be_free_block_ids(void* be, int32_t* out, int32_t cap);
+/* Sequence (_Sequence::new / add_token / prefill_chunk_tokens ...) */
+int32_t mi355_be_seq_create(void* be, int64_t seq_id, const uint32_t* prompt, int32_t n);
+int32_t mi355_be_seq_remove(void* be, int64_t seq_id);
+int32_t mi355_be_seq_add_token(void* be, int64_t seq_id, uint32_t token);
+int32_t mi355_be_seq_len(void* be, int64_t seq_id);
+int32_t mi355_be_seq_logical_blocks(void* be, int64_t seq_id);
+int32_t mi355_be_seq_get_cached_tokens(void* be, int64_t seq_id);
+int32_t mi355_be_seq_set_cached_tokens(void* be, int64_t seq_id, int32_t n);
+int32_t mi355_be_seq_set_warmup_tokens(void* be, int64_t seq_id, int32_t n);
+int32_t mi355_be_seq_prefill_chunk_tokens(void* be, int64_t seq_id, int32_t chunk);
+int32_t mi355_be_seq_has_prefix_hash(void* be, int64_t seq_id);
+/* block tables */
+int32_t mi355_be_block_table(void* be, int64_t seq_id, int32_t* out, int32_t cap);
+int32_t mi355_be_block_refcount(void* be, int32_t block_code);
+int32_t mi355_be_pop_back_block(void* be, int64_t seq_id);
+/* can_allocate[_for_prefill]: 0 Ok / 1 Later / 2 Impossible (block_engine.rs:292-373); allocate[_for_prefill] */
+int32_t mi355_be_can_allocate(void* be, const int64_t* seq_ids, int32_t n, int32_t chunk);
+int32_t mi355_be_allocate(void* be, const int64_t* seq_ids, int32_t n, int32_t chunk);
+int32_t mi355_be_can_append_token(void* be, const int64_t* seq_ids, int32_t n);
+/* append_token_slot_to_seq: returns 1 and (src,dst) when the shared last block was copied-on-write */
+int32_t mi355_be_append_token_slot(void* be, int64_t seq_id, int32_t* cow_src, int32_t* cow_dst);
+int32_t mi355_be_prefill_chunk_blocks_required(void* be, const int64_t* seq_ids, int32_t n, int32_t chunk);
+int32_t mi355_be_can_append_prefill_chunk(void* be, const int64_t* seq_ids, int32_t n, int32_t chunk);
+int32_t mi355_be_append_prefill_chunk_slots(void* be, const int64_t* seq_ids, int32_t n, int32_t chunk);
+int32_t mi355_be_free_sequence(void* be, int64_t seq_id);
+int32_t mi355_be_cache_sequence(void* be, int64_t seq_id);
+int32_t mi355_be_evict_prefix_cache_blocks(void* be, int32_t num_blocks);
+int32_t mi355_be_evict_prefix_cache_until_free(void* be, int32_t min_free);
+int32_t mi355_be_query_prefix_match_tokens(void* be, const uint32_t* tokens, int32_t n);
+int32_t mi355_be_fallback_to_full_prefill(void* be, int64_t seq_id);
+int32_t mi355_be_rebuild_with_cached_prefix(void* be, int64_t seq_id, int32_t cached_tokens);
+/* swap: pairs out = (src_block, dst_block) to hand to mi355_swap_blocks; returns the pair count */
+int32_t mi355_be_can_swap_out(void* be, const int64_t* seq_ids, int32_t n);
+int32_t mi355_be_swap_in_required_blocks(void* be, const int64_t* seq_ids, int32_t n);
+int32_t mi355_be_can_swap_in(void* be, const int64_t* seq_ids, int32_t n);
+int32_t mi355_be_swap_out(void* be, int64_t group_id, const int64_t* seq_ids, int32_t n, int64_t* pairs, int32_t cap);
+int32_t mi355_be_swap_in(void* be, int64_t group_id, const int64_t* seq_ids, int32_t n, int64_t* pairs, int32_t cap);
+void mi355_be_finalize_swap_out(void* be, int64_t group_id);
+void mi355_be_rollback_swap_out(void* be, int64_t group_id);
+void mi355_be_finalize_swap_in(void* be, int64_t group_id);
+void mi355_be_rollback_swap_in(void* be, int64_t group_id);
+/* bare PrefixCache (the unit under test in prefix_cache.rs:386-599) */
+void* mi355_pc_create(int32_t block_size, int32_t enabled, int32_t max_cached_blocks, int32_t num_block_ids);
+int32_t mi355_pc_insert(void* pc, const uint32_t* tokens, int32_t n, const int32_t* blocks, int32_t nblocks, int32_t* evicted, int32_t cap);
+int32_t mi355_pc_match(void* pc, const uint32_t* tokens, int32_t n, int32_t* blocks, int32_t cap);
+int32_t mi355_pc_evict(void* pc, int32_t num, const uint32_t* protect_tokens, int32_t protect_n, int32_t* evicted, int32_t cap);
+int32_t mi355_pc_cached_blocks(void* pc);
+int32_t mi355_pc_lru_len(void* pc);
+uint64_t mi355_pc_hash_for_blocks(void* pc, const uint32_t* tokens, int32_t n, int32_t full_blocks, int32_t has_seed, uint64_t seed, int32_t seed_block);
+/* a1 / a2: InputMetadata arrays on the HOST from the engine state (inputs.rs:376-454 / :90-230) */
+int32_t mi355_be_prepare_decode(void* be, const int64_t* seq_ids, int32_t n, uint32_t* tokens, int64_t* positions,
+                                int64_t* slot_mapping, uint32_t* context_lens, uint32_t* block_tables, int32_t bt_cap_cols);
+int32_t mi355_be_prepare_prompt(void* be, const int64_t* seq_ids, int32_t n, int32_t chunk, uint32_t* tokens,
+                                int64_t* positions, int64_t* slot_mapping, uint32_t* context_lens, uint32_t* cu_q,
+                                uint32_t* cu_k, uint32_t* block_tables, int32_t tok_cap, int32_t bt_cap_cols,
+                                int32_t* max_blocks_out);
+
 #ifdef __cplusplus
 }
 #endif
