@@ -159,3 +159,21 @@ _sig("mi355_pc_evict", c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32])
 _sig("mi355_pc_hash_for_blocks", c_u64, [c_vp, c_vp, c_i32, c_i32, c_i32, c_u64, c_i32])
 _sig("mi355_be_prepare_decode", c_i32, [c_vp, c_vp, c_i32] + [c_vp] * 5 + [c_i32])
 _sig("mi355_be_prepare_prompt", c_i32, [c_vp, c_vp, c_i32, c_i32] + [c_vp] * 7 + [c_i32, c_i32, c_vp])
+
+# ---- scheduler (section 6)
+_sig("mi355_sched_create", c_vp, [c_i32] * 8)
+_sig("mi355_sched_destroy", None, [c_vp])
+_sig("mi355_sched_block_engine", c_vp, [c_vp])
+_sig("mi355_sched_add_group", c_i32, [c_vp, c_i64, c_vp, c_i32, c_u64])
+for _n in ("mi355_sched_group_status", "mi355_sched_set_group_finished"):
+    _sig(_n, c_i32, [c_vp, c_i64])
+_sig("mi355_sched_queue_len", c_i32, [c_vp, c_i32])
+for _n in ("mi355_sched_has_unfinished", "mi355_sched_is_last_prefill"):
+    _sig(_n, c_i32, [c_vp])
+_sig("mi355_sched_schedule", c_i32, [c_vp, c_u64])
+_sig("mi355_sched_result", c_i32, [c_vp, c_i32, c_vp, c_i32])
+_sig("mi355_sched_filter_prefill_finished", c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32])
+_sig("mi355_sched_free_finished", c_i32, [c_vp, c_vp, c_i32])
+_sig("mi355_sched_abort_sequences", c_i32, [c_vp, c_vp, c_i32])
+for _n in ("mi355_sched_rollback_swap_in", "mi355_sched_rollback_swap_out"):
+    _sig(_n, None, [c_vp, c_i64])

@@ -279,3 +279,117 @@ class PrefixCache:
         h = lib.mi355_pc_hash_for_blocks(self.h, p, n, full_blocks, int(seed is not None), int(seed or 0),
                                          -1 if seed_block is None else int(seed_block))
         return h or None
+
+
+class _BorrowedEngine(BlockEngine):
+    """the engine owned by a Scheduler (not destroyed by this wrapper)"""
+
+    def __init__(self, handle, block_size):
+        self.h, self.block_size = handle, block_size
+
+    def __del__(self):
+        self.h = None
+
+
+class SchedulerOutput:
+    def __init__(self, is_prompt, scheduled, ignored, swap_in, swap_out, copy, swap_in_groups, swap_out_groups):
+        self.is_prompt = is_prompt                      # the step kind (`is_last_prefill` after the call)
+        self.scheduled = scheduled                      # group ids
+        self.ignored_seq_groups = ignored
+        self.blocks_to_swap_in = swap_in                # {cpu_block: gpu_block}
+        self.blocks_to_swap_out = swap_out              # {gpu_block: cpu_block}
+        self.blocks_to_copy = copy                      # {src: [dst, ...]}
+        self.swap_in_groups, self.swap_out_groups = swap_in_groups, swap_out_groups
+
+
+class Scheduler:
+    """`Scheduler` of src/scheduler/mod.rs (new :98-121, add_sequence :123, schedule :183-455, filter_prefill_finished
+    :542-616, free_finished_sequence_groups :465-504, abort_sequences :618-657).  Groups are (group_id, [Sequence])."""
+    WAITING, PENDING, RUNNING, SWAPPED, FINISHED, ABORTED, IGNORED = range(7)
+
+    def __init__(self, block_size, num_gpu_blocks, num_cpu_blocks, max_num_parallel_reqs, max_num_batched_tokens,
+                 prefill_chunk_size=0, prefix_cache_enabled=False, max_cached_blocks=0):
+        self.h = lib.mi355_sched_create(block_size, num_gpu_blocks, num_cpu_blocks, int(prefix_cache_enabled),
+                                        max_cached_blocks, max_num_parallel_reqs, max_num_batched_tokens,
+                                        prefill_chunk_size)
+        if not self.h:
+            raise ValueError("bad scheduler arguments")
+        self.block_engine = _BorrowedEngine(lib.mi355_sched_block_engine(self.h), block_size)
+        self.groups = {}
+        self._arrival = 0
+
+    def __del__(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib.mi355_sched_destroy(self.h)
+            self.h = None
+
+    def add_sequence(self, group_id, seqs, arrival=None):
+        a, p, n = _ids([s.id for s in seqs])
+        if arrival is None:
+            self._arrival += 1
+            arrival = self._arrival
+        if lib.mi355_sched_add_group(self.h, group_id, p, n, arrival) != 0:
+            raise ValueError("bad group")
+        self.groups[group_id] = list(seqs)
+
+    def _result(self, which):
+        out = np.zeros(1 << 15, np.int64)
+        k = lib.mi355_sched_result(self.h, which, out.ctypes.data, len(out))
+        return out[:k].tolist()
+
+    def schedule(self, now_ms=0):
+        is_prompt = lib.mi355_sched_schedule(self.h, int(now_ms)) == 1
+        def pairs(w):
+            v = self._result(w)
+            return list(zip(v[0::2], v[1::2]))
+        copy = {}
+        for s, d in pairs(4):
+            copy.setdefault(s, []).append(d)
+        return SchedulerOutput(is_prompt, self._result(0), self._result(1), dict(pairs(2)), dict(pairs(3)), copy,
+                               self._result(5), self._result(6))
+
+    def take_pending_runner_releases(self):
+        return self._result(7)
+
+    def filter_prefill_finished(self, scheduled):
+        a, p, n = _ids(scheduled)
+        out = np.zeros(max(1, n), np.int64)
+        k = lib.mi355_sched_filter_prefill_finished(self.h, p, n, out.ctypes.data, len(out))
+        if k < 0:
+            raise RuntimeError("filter_prefill_finished needs a prefill chunk size")
+        return out[:k].tolist()
+
+    def set_finished(self, group_id):
+        lib.mi355_sched_set_group_finished(self.h, group_id)
+
+    def free_finished_sequence_groups(self):
+        out = np.zeros(4096, np.int64)
+        k = lib.mi355_sched_free_finished(self.h, out.ctypes.data, len(out))
+        return out[:k].tolist()
+
+    def abort_sequences(self, seq_ids):
+        a, p, n = _ids(seq_ids)
+        return lib.mi355_sched_abort_sequences(self.h, p, n)
+
+    def status(self, group_id):
+        return lib.mi355_sched_group_status(self.h, group_id)
+
+    def num_waiting(self):
+        return lib.mi355_sched_queue_len(self.h, 0)
+
+    def num_running(self):
+        return lib.mi355_sched_queue_len(self.h, 1)
+
+    def num_swapped(self):
+        return lib.mi355_sched_queue_len(self.h, 2)
+
+    def has_unfinished_sequences(self):
+        return lib.mi355_sched_has_unfinished(self.h) == 1
+
+    def rollback_swap_in_groups(self, gids):
+        for g in gids:
+            lib.mi355_sched_rollback_swap_in(self.h, g)
+
+    def rollback_swap_out_groups(self, gids):
+        for g in gids:
+            lib.mi355_sched_rollback_swap_out(self.h, g)

@@ -819,3 +819,309 @@ int32_t mi355_be_prepare_prompt(void* be, const int64_t* seq_ids, int32_t n, int
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// Continuous-batching scheduler (src/scheduler/mod.rs:66-839): three queues (waiting / running / swapped), prompt
+// steps and decode steps alternate (`is_last_prefill`), per-step prefill token budget, chunked prefill re-queueing,
+// preemption of the latest arrivals by recompute (no prefix cache, single sequence) or swap, FCFS priorities.
+// Wall-clock inputs of the reference (arrival time, swap cooling period of 300 ms, mod.rs:41) are explicit arguments
+// here so the policy is deterministic and testable.
+// =====================================================================================================================
+namespace {
+
+enum GroupStatus { G_WAITING = 0, G_PENDING = 1, G_RUNNING = 2, G_SWAPPED = 3, G_FINISHED = 4, G_ABORTED = 5, G_IGNORED = 6 };
+enum { R_SCHEDULED = 0, R_IGNORED = 1, R_SWAP_IN_PAIRS = 2, R_SWAP_OUT_PAIRS = 3, R_COPY_PAIRS = 4, R_SWAP_IN_GROUPS = 5,
+       R_SWAP_OUT_GROUPS = 6, R_RUNNER_RELEASES = 7, R_COUNT = 8 };
+
+struct Group { std::vector<int64_t> seqs; uint64_t arrival = 0; int status = G_WAITING; bool has_swapped_time = false; uint64_t swapped_ms = 0; };
+
+struct Sched {
+    Engine* eng = nullptr;
+    std::deque<int64_t> waiting, running, swapped;
+    std::unordered_map<int64_t, Group> groups;
+    int max_parallel = 1, max_batched_tokens = 1, chunk = 0;
+    bool is_last_prefill = false;
+    std::vector<int64_t> result[R_COUNT];
+    std::vector<int64_t> pending_releases;
+
+    Group& g(int64_t id) { return groups[id]; }
+    int group_prefill_tokens(const Group& gr) { int t = 0; for (int64_t s : gr.seqs) { Seq* q = find_seq(eng, s); if (q) t += eng->prefill_chunk_tokens(*q, chunk); } return t; }
+    bool has_block_table(const Group& gr) { for (int64_t s : gr.seqs) if (!eng->tables.count(s)) return false; return true; }
+    void free_group(const Group& gr, bool cache_prefix) {                       // _free (mod.rs:766-775)
+        for (int64_t s : gr.seqs) {
+            if (cache_prefix && gr.status == G_FINISHED) mi355_be_cache_sequence(eng, s);
+            mi355_be_free_sequence(eng, s);
+        }
+    }
+    void request_release(const Group& gr) { for (int64_t s : gr.seqs) if (std::find(pending_releases.begin(), pending_releases.end(), s) == pending_releases.end()) pending_releases.push_back(s); }
+    void remove_everywhere(int64_t gid) {
+        for (auto* q : {&waiting, &running, &swapped}) { auto it = std::find(q->begin(), q->end(), gid); if (it != q->end()) q->erase(it); }
+    }
+    void abort_group(int64_t gid) { remove_everywhere(gid); Group& gr = g(gid); gr.status = G_ABORTED; free_group(gr, false); }
+    void preempt_by_recompute(int64_t gid) {                                    // :718-723
+        Group& gr = g(gid);
+        request_release(gr);
+        gr.status = G_WAITING;
+        free_group(gr, false);
+        waiting.push_front(gid);
+    }
+    void preempt(int64_t gid, uint64_t now_ms) {                                // :700-764
+        Group& gr = g(gid);
+        if (gr.seqs.size() == 1 && !eng->has_cache) { preempt_by_recompute(gid); return; }
+        if (!mi355_be_can_swap_out(eng, gr.seqs.data(), (int)gr.seqs.size())) {
+            if (gr.seqs.size() == 1) { preempt_by_recompute(gid); return; }
+            request_release(gr);
+            abort_group(gid);
+            return;
+        }
+        std::vector<int64_t> pairs(2 * 8192);
+        const int k = mi355_be_swap_out(eng, gid, gr.seqs.data(), (int)gr.seqs.size(), pairs.data(), 8192);
+        for (int i = 0; i < k; ++i) { result[R_SWAP_OUT_PAIRS].push_back(pairs[2 * i]); result[R_SWAP_OUT_PAIRS].push_back(pairs[2 * i + 1]); }
+        result[R_SWAP_OUT_GROUPS].push_back(gid);
+        gr.has_swapped_time = true; gr.swapped_ms = now_ms;
+        gr.status = G_SWAPPED;
+        swapped.push_back(gid);
+    }
+    void append_token_slots(const Group& gr) {                                  // :680-698
+        for (int64_t s : gr.seqs) {
+            int32_t src = -1, dst = -1;
+            if (mi355_be_append_token_slot(eng, s, &src, &dst) == 1) { result[R_COPY_PAIRS].push_back(src); result[R_COPY_PAIRS].push_back(dst); }
+        }
+    }
+    bool ensure_prefill_chunk_slots(const Group& gr) {                          // :814-838
+        const int req = mi355_be_prefill_chunk_blocks_required(eng, gr.seqs.data(), (int)gr.seqs.size(), chunk);
+        if (req > (int)eng->gpu.free_ids.size()) eng->evict_until_free(req);
+        if (mi355_be_can_append_prefill_chunk(eng, gr.seqs.data(), (int)gr.seqs.size(), chunk) != 1) return false;
+        mi355_be_append_prefill_chunk_slots(eng, gr.seqs.data(), (int)gr.seqs.size(), chunk);
+        return true;
+    }
+    int evict_under_pressure() {                                                // :804-812 (10 % of the cache, at least one)
+        const int cached = eng->has_cache ? (int)eng->cache.entries.size() : 0;
+        if (cached == 0) return 0;
+        int blocks = (int)((cached + 9) / 10);
+        if (blocks < 1) blocks = 1;
+        return mi355_be_evict_prefix_cache_blocks(eng, blocks);
+    }
+    void sort_fcfs(std::deque<int64_t>& q) {                                    // earliest arrival LAST (:777-789)
+        std::stable_sort(q.begin(), q.end(), [&](int64_t a, int64_t b) { return groups[a].arrival < groups[b].arrival; });
+        std::reverse(q.begin(), q.end());
+    }
+};
+
+Sched* S(void* p) { return static_cast<Sched*>(p); }
+
+}  // namespace
+
+extern "C" {
+
+void* mi355_sched_create(int32_t block_size, int32_t num_gpu_blocks, int32_t num_cpu_blocks, int32_t prefix_cache_enabled,
+                         int32_t max_cached_blocks, int32_t max_num_parallel_reqs, int32_t max_num_batched_tokens,
+                         int32_t prefill_chunk_size) {
+    void* be = mi355_be_create(block_size, num_gpu_blocks, num_cpu_blocks, prefix_cache_enabled, max_cached_blocks);
+    if (!be) return nullptr;
+    Sched* s = new Sched();
+    s->eng = E(be);
+    s->max_parallel = std::max(1, max_num_parallel_reqs);
+    s->max_batched_tokens = std::max(1, max_num_batched_tokens);
+    s->chunk = std::max(0, prefill_chunk_size);
+    return s;
+}
+void mi355_sched_destroy(void* sp) { Sched* s = S(sp); if (!s) return; delete s->eng; delete s; }
+void* mi355_sched_block_engine(void* sp) { return S(sp)->eng; }
+
+/* Scheduler::add_sequence (mod.rs:123-125); the sequences were created with mi355_be_seq_create on the engine */
+int32_t mi355_sched_add_group(void* sp, int64_t group_id, const int64_t* seq_ids, int32_t n, uint64_t arrival) {
+    Sched* s = S(sp);
+    if (n < 1 || s->groups.count(group_id)) return -1;
+    for (int i = 0; i < n; ++i) if (!find_seq(s->eng, seq_ids[i])) return -1;
+    Group gr; gr.seqs.assign(seq_ids, seq_ids + n); gr.arrival = arrival;
+    s->groups[group_id] = gr;
+    s->waiting.push_back(group_id);
+    return 0;
+}
+int32_t mi355_sched_group_status(void* sp, int64_t group_id) { auto it = S(sp)->groups.find(group_id); return it == S(sp)->groups.end() ? -1 : it->second.status; }
+int32_t mi355_sched_set_group_finished(void* sp, int64_t group_id) { auto it = S(sp)->groups.find(group_id); if (it == S(sp)->groups.end()) return -1; it->second.status = G_FINISHED; return 0; }
+int32_t mi355_sched_queue_len(void* sp, int32_t which) { Sched* s = S(sp); return (int32_t)(which == 0 ? s->waiting.size() : which == 1 ? s->running.size() : s->swapped.size()); }
+int32_t mi355_sched_has_unfinished(void* sp) { Sched* s = S(sp); return (!s->running.empty() || !s->waiting.empty()) ? 1 : 0; }
+int32_t mi355_sched_is_last_prefill(void* sp) { return S(sp)->is_last_prefill ? 1 : 0; }
+/* results of the last schedule() / take_pending_runner_releases(): which = R_* above; pairs come flattened */
+int32_t mi355_sched_result(void* sp, int32_t which, int64_t* out, int32_t cap) {
+    Sched* s = S(sp);
+    if (which < 0 || which >= R_COUNT) return -1;
+    if (which == R_RUNNER_RELEASES) { s->result[which] = s->pending_releases; s->pending_releases.clear(); }
+    const auto& v = s->result[which];
+    for (size_t i = 0; i < v.size() && (int)i < cap; ++i) out[i] = v[i];
+    return (int32_t)v.size();
+}
+
+/* Scheduler::schedule (mod.rs:183-455).  Returns 1 for a PROMPT step (scheduled = newly admitted groups), 0 for a
+ * DECODE step (scheduled = the running queue).  now_ms feeds the swap cooling period. */
+int32_t mi355_sched_schedule(void* sp, uint64_t now_ms) {
+    Sched* s = S(sp);
+    Engine* e = s->eng;
+    for (int i = 0; i < R_RUNNER_RELEASES; ++i) s->result[i].clear();
+    if (s->swapped.empty()) {
+        const size_t pre_existing_running = s->running.size();
+        int scheduled_tokens = 0;
+        while (!s->waiting.empty()) {
+            if (s->is_last_prefill && pre_existing_running > 0) break;             // interleave prompt and decode steps
+            const int64_t gid = s->waiting.front();
+            Group& gr = s->g(gid);
+            const int group_tokens = s->group_prefill_tokens(gr);
+            if (group_tokens > 0 && scheduled_tokens + group_tokens > s->max_batched_tokens) break;
+            if ((int)s->running.size() >= s->max_parallel) break;
+            size_t individual = 0;
+            for (int64_t rg : s->running) individual += s->g(rg).seqs.size();
+            if ((int)individual + 1 > s->max_parallel) break;
+            if (!s->has_block_table(gr)) {
+                const int st = mi355_be_can_allocate(e, gr.seqs.data(), (int)gr.seqs.size(), s->chunk);
+                if (st == 1) break;                                                // Later
+                if (st == 2) {                                                     // Impossible: prompt exceeds the pool
+                    gr.status = G_IGNORED;
+                    s->result[R_IGNORED].push_back(gid);
+                    s->waiting.pop_front();
+                    continue;
+                }
+                if (mi355_be_allocate(e, gr.seqs.data(), (int)gr.seqs.size(), s->chunk) != 0) break;
+            } else if (!s->ensure_prefill_chunk_slots(gr)) {
+                break;
+            }
+            gr.status = G_RUNNING;
+            s->waiting.pop_front();
+            s->running.push_back(gid);
+            s->result[R_SCHEDULED].push_back(gid);
+            scheduled_tokens += group_tokens;
+        }
+        if (!s->result[R_SCHEDULED].empty() || !s->result[R_IGNORED].empty()) { s->is_last_prefill = true; return 1; }
+    }
+    // ---- decode step: reserve a token slot for every running group, preempting the latest arrivals when out of blocks
+    s->sort_fcfs(s->running);
+    std::deque<int64_t> running;
+    bool any_preempted = false;
+    while (!s->running.empty()) {
+        if ((int)running.size() >= s->max_parallel) {
+            while (!s->running.empty()) { const int64_t ex = s->running.front(); s->running.pop_front(); s->preempt(ex, now_ms); any_preempted = true; }
+            break;
+        }
+        const int64_t gid = s->running.front(); s->running.pop_front();
+        bool self_preempted = false;
+        while (mi355_be_can_append_token(e, s->g(gid).seqs.data(), (int)s->g(gid).seqs.size()) != 1) {
+            if (s->evict_under_pressure() > 0) continue;
+            if (!s->running.empty()) {
+                const int64_t victim = s->running.back(); s->running.pop_back();
+                s->preempt(victim, now_ms); any_preempted = true;
+            } else {
+                s->preempt(gid, now_ms); any_preempted = true; self_preempted = true;
+                break;
+            }
+        }
+        if (!self_preempted) { s->append_token_slots(s->g(gid)); running.push_back(gid); }
+    }
+    s->running = running;
+    s->sort_fcfs(s->swapped);
+    if (!any_preempted) {
+        while (!s->swapped.empty()) {
+            const int64_t gid = s->swapped.front();
+            Group& gr = s->g(gid);
+            if (gr.has_swapped_time && now_ms - gr.swapped_ms < 300) break;          // SWAP_COOLING_PERIOD
+            if (mi355_be_can_swap_in(e, gr.seqs.data(), (int)gr.seqs.size()) != 1) {
+                e->evict_until_free(mi355_be_swap_in_required_blocks(e, gr.seqs.data(), (int)gr.seqs.size()));
+                if (mi355_be_can_swap_in(e, gr.seqs.data(), (int)gr.seqs.size()) != 1) break;
+            }
+            s->swapped.pop_front();
+            std::vector<int64_t> pairs(2 * 8192);
+            const int k = mi355_be_swap_in(e, gid, gr.seqs.data(), (int)gr.seqs.size(), pairs.data(), 8192);
+            for (int i = 0; i < k; ++i) { s->result[R_SWAP_IN_PAIRS].push_back(pairs[2 * i]); s->result[R_SWAP_IN_PAIRS].push_back(pairs[2 * i + 1]); }
+            s->result[R_SWAP_IN_GROUPS].push_back(gid);
+            gr.has_swapped_time = false;
+            gr.status = G_RUNNING;
+            s->append_token_slots(gr);
+            s->running.push_back(gid);
+        }
+    }
+    s->is_last_prefill = false;
+    for (int64_t gid : s->running) s->result[R_SCHEDULED].push_back(gid);
+    return 0;
+}
+
+/* filter_prefill_finished (mod.rs:542-616): after a prompt step, groups whose prompt is not finished advance
+ * num_cached_tokens by the chunk and go back to `waiting`; returns the count of FINISHED groups (ids in out). */
+int32_t mi355_sched_filter_prefill_finished(void* sp, const int64_t* scheduled, int32_t n, int64_t* finished_out, int32_t cap) {
+    Sched* s = S(sp);
+    if (s->chunk <= 0) return -1;
+    int k = 0;
+    for (int i = 0; i < n; ++i) {
+        auto it = s->groups.find(scheduled[i]);
+        if (it == s->groups.end()) return -1;
+        Seq* q = find_seq(s->eng, it->second.seqs[0]);
+        const int take = s->eng->prefill_chunk_tokens(*q, s->chunk);
+        if (take == 0 || q->num_cached + take >= q->prompt_len) {
+            if (k < cap) finished_out[k] = scheduled[i];
+            ++k;
+        } else {
+            q->num_cached += take;
+            if (!(q->has_warmup && q->warmup > q->num_cached && q->warmup < q->prompt_len)) q->has_warmup = false;
+            it->second.status = G_PENDING;
+            s->waiting.push_back(scheduled[i]);
+            auto r = std::find(s->running.begin(), s->running.end(), scheduled[i]);
+            if (r != s->running.end()) s->running.erase(r);
+        }
+    }
+    return k;
+}
+/* free_finished_sequence_groups (mod.rs:465-504): returns the released sequence ids */
+int32_t mi355_sched_free_finished(void* sp, int64_t* released_out, int32_t cap) {
+    Sched* s = S(sp);
+    std::deque<int64_t> keep; std::vector<int64_t> fin;
+    for (int64_t gid : s->running) (s->g(gid).status == G_FINISHED ? (void)fin.push_back(gid) : (void)keep.push_back(gid));
+    s->running = keep;
+    int k = 0;
+    for (int64_t gid : fin) {
+        Group& gr = s->g(gid);
+        for (int64_t q : gr.seqs) { if (k < cap) released_out[k] = q; ++k; }
+        s->free_group(gr, true);
+    }
+    return k;
+}
+/* abort_sequences (mod.rs:618-657): the whole group of every named sequence is removed and freed */
+int32_t mi355_sched_abort_sequences(void* sp, const int64_t* seq_ids, int32_t n) {
+    Sched* s = S(sp);
+    std::vector<int64_t> gids;
+    for (auto& kv : s->groups) {
+        if (kv.second.status == G_ABORTED || kv.second.status == G_IGNORED) continue;
+        bool queued = false;
+        for (auto* q : {&s->waiting, &s->running, &s->swapped}) if (std::find(q->begin(), q->end(), kv.first) != q->end()) queued = true;
+        if (!queued) continue;
+        for (int64_t q : kv.second.seqs) if (std::find(seq_ids, seq_ids + n, q) != seq_ids + n) { gids.push_back(kv.first); break; }
+    }
+    for (int64_t gid : gids) {
+        Group& gr = s->g(gid);
+        const bool has_table = s->has_block_table(gr);
+        s->remove_everywhere(gid);
+        gr.status = G_ABORTED;
+        if (has_table) s->free_group(gr, false);
+    }
+    return (int32_t)gids.size();
+}
+/* rollback_swap_in_groups / rollback_swap_out_groups (mod.rs:146-181) + the engine-side table rollback */
+void mi355_sched_rollback_swap_in(void* sp, int64_t group_id) {
+    Sched* s = S(sp);
+    auto it = std::find(s->running.begin(), s->running.end(), group_id);
+    if (it == s->running.end()) return;
+    s->running.erase(it);
+    s->g(group_id).status = G_SWAPPED;
+    s->swapped.push_front(group_id);
+    mi355_be_rollback_swap_in(s->eng, group_id);
+}
+void mi355_sched_rollback_swap_out(void* sp, int64_t group_id) {
+    Sched* s = S(sp);
+    auto it = std::find(s->swapped.begin(), s->swapped.end(), group_id);
+    if (it == s->swapped.end()) return;
+    s->swapped.erase(it);
+    Group& gr = s->g(group_id);
+    gr.status = G_RUNNING; gr.has_swapped_time = false;
+    s->running.push_front(group_id);
+    mi355_be_rollback_swap_out(s->eng, group_id);
+}
+
+}  // extern "C"

@@ -368,6 +368,46 @@ int32_t mi355_be_prepare_prompt(void* be, const int64_t* seq_ids, int32_t n, int
                                 uint32_t* cu_k, uint32_t* block_tables, int32_t tok_cap, int32_t bt_cap_cols,
                                 int32_t* max_blocks_out);
 
+/* ---------------------------------------------------------------------------------------------
+ * 6. Continuous-batching scheduler (src/scheduler/mod.rs:66-839) on top of the block manager.
+ *    Wall-clock inputs (arrival order, the 300 ms swap cooling period) are explicit arguments.
+ * ------------------------------------------------------------------------------------------- */
+#define MI355_SCHED_SCHEDULED 0       /* group ids of this step                                */
+#define MI355_SCHED_IGNORED 1         /* groups whose prompt can never fit (FinishedIgnored)    */
+#define MI355_SCHED_SWAP_IN_PAIRS 2   /* (cpu_block, gpu_block) flattened                       */
+#define MI355_SCHED_SWAP_OUT_PAIRS 3  /* (gpu_block, cpu_block) flattened                       */
+#define MI355_SCHED_COPY_PAIRS 4      /* copy-on-write (src, dst) flattened                     */
+#define MI355_SCHED_SWAP_IN_GROUPS 5
+#define MI355_SCHED_SWAP_OUT_GROUPS 6
+#define MI355_SCHED_RUNNER_RELEASES 7 /* take_pending_runner_releases: sequence ids             */
+/* group status codes returned by mi355_sched_group_status */
+#define MI355_GROUP_WAITING 0
+#define MI355_GROUP_PENDING 1
+#define MI355_GROUP_RUNNING 2
+#define MI355_GROUP_SWAPPED 3
+#define MI355_GROUP_FINISHED 4
+#define MI355_GROUP_ABORTED 5
+#define MI355_GROUP_IGNORED 6
+void* mi355_sched_create(int32_t block_size, int32_t num_gpu_blocks, int32_t num_cpu_blocks, int32_t prefix_cache_enabled,
+                         int32_t max_cached_blocks, int32_t max_num_parallel_reqs, int32_t max_num_batched_tokens,
+                         int32_t prefill_chunk_size);
+void mi355_sched_destroy(void* sched);
+void* mi355_sched_block_engine(void* sched);   /* the mi355_be_* handle owned by the scheduler */
+int32_t mi355_sched_add_group(void* sched, int64_t group_id, const int64_t* seq_ids, int32_t n, uint64_t arrival);
+int32_t mi355_sched_group_status(void* sched, int64_t group_id);
+int32_t mi355_sched_set_group_finished(void* sched, int64_t group_id);
+int32_t mi355_sched_queue_len(void* sched, int32_t which /* 0 waiting, 1 running, 2 swapped */);
+int32_t mi355_sched_has_unfinished(void* sched);
+int32_t mi355_sched_is_last_prefill(void* sched);
+/* 1 = prompt step, 0 = decode step; read the step's lists with mi355_sched_result */
+int32_t mi355_sched_schedule(void* sched, uint64_t now_ms);
+int32_t mi355_sched_result(void* sched, int32_t which, int64_t* out, int32_t cap);
+int32_t mi355_sched_filter_prefill_finished(void* sched, const int64_t* scheduled, int32_t n, int64_t* finished_out, int32_t cap);
+int32_t mi355_sched_free_finished(void* sched, int64_t* released_out, int32_t cap);
+int32_t mi355_sched_abort_sequences(void* sched, const int64_t* seq_ids, int32_t n);
+void mi355_sched_rollback_swap_in(void* sched, int64_t group_id);
+void mi355_sched_rollback_swap_out(void* sched, int64_t group_id);
+
 #ifdef __cplusplus
 }
 #endif

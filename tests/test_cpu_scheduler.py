@@ -1,0 +1,183 @@
+"""Scheduling policy of src/scheduler/mod.rs restated over the C ABI: scenario tests of the observable policy
+(the reference has no unit tests for `schedule` itself; each assert cites the rule it checks), and an end-to-end
+simulation of BASELINE config 3's shape: 32 staggered sequences through prompt + decode steps to completion with
+block-table invariants checked every step."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def be(lib):
+    from candle_vllm_amd import block_engine
+    return block_engine
+
+
+def _mk(be, **kw):
+    args = dict(block_size=4, num_gpu_blocks=16, num_cpu_blocks=16, max_num_parallel_reqs=8,
+                max_num_batched_tokens=64, prefill_chunk_size=0)
+    args.update(kw)
+    return be.Scheduler(**args)
+
+
+def test_prompt_and_decode_steps_alternate(be):
+    s = _mk(be)
+    a = s.block_engine.new_sequence(1, list(range(6)))
+    s.add_sequence(10, [a])
+    out = s.schedule()
+    assert out.is_prompt and out.scheduled == [10]                 # waiting -> running on a prompt step (mod.rs:196-257)
+    b = s.block_engine.new_sequence(2, list(range(5)))
+    s.add_sequence(11, [b])
+    out = s.schedule()
+    assert not out.is_prompt and out.scheduled == [10]             # is_last_prefill && running: decode first (:197-199)
+    out = s.schedule()
+    assert out.is_prompt and out.scheduled == [11]                 # then the new prompt
+    out = s.schedule()
+    assert not out.is_prompt and sorted(out.scheduled) == [10, 11]
+    assert out.scheduled == [11, 10]                               # FCFS sort puts the earliest arrival last (:777-782)
+
+
+def test_prefill_token_budget_and_parallel_limit(be):
+    s = _mk(be, max_num_batched_tokens=10, max_num_parallel_reqs=3, num_gpu_blocks=64)
+    for i in range(5):
+        s.add_sequence(i, [s.block_engine.new_sequence(i, list(range(4)))])
+    out = s.schedule()
+    assert out.scheduled == [0, 1]                                 # 4 + 4 <= 10 < 12 (:202-212)
+    s.schedule()                                                   # decode
+    out = s.schedule()
+    assert out.is_prompt and out.scheduled == [2]                  # running.len() reaches max_num_parallel_reqs = 3 (:214-216)
+    s.schedule()
+    out = s.schedule()
+    assert not out.is_prompt and s.num_waiting() == 2
+
+
+def test_prompt_longer_than_the_pool_is_ignored(be):
+    s = _mk(be, num_gpu_blocks=4, max_num_batched_tokens=1000)
+    s.add_sequence(1, [s.block_engine.new_sequence(1, list(range(100)))])
+    s.add_sequence(2, [s.block_engine.new_sequence(2, list(range(5)))])
+    out = s.schedule()
+    assert out.ignored_seq_groups == [1] and out.scheduled == [2]  # AllocStatus::Impossible (:233-241)
+    assert s.status(1) == be.Scheduler.IGNORED
+
+
+def test_chunked_prefill_requeues_until_the_prompt_is_done(be):
+    s = _mk(be, prefill_chunk_size=8, num_gpu_blocks=32)
+    q = s.block_engine.new_sequence(1, list(range(20)))
+    s.add_sequence(1, [q])
+    steps = []
+    for _ in range(3):
+        out = s.schedule()
+        assert out.is_prompt and out.scheduled == [1]
+        meta = s.block_engine.prepare_prompt([q], chunk=8)
+        steps.append((int(meta["cu_seqlens_q"][1]), int(meta["context_lens"][0]), len(s.block_engine.block_table(q))))
+        fin = s.filter_prefill_finished(out.scheduled)
+        if fin:
+            break
+        assert s.num_waiting() == 1 and s.num_running() == 0       # pushed back to waiting as Pending (:566-580)
+        assert s.status(1) == be.Scheduler.PENDING
+    assert steps == [(8, 8, 2), (8, 16, 4), (4, 20, 5)]            # chunk tokens, context, blocks reserved per chunk
+    assert fin == [1] and s.num_running() == 1
+
+
+def test_out_of_blocks_preempts_by_recompute(be):
+    """The running queue is sorted by arrival DESCENDING (sort ascending then reverse, mod.rs:777-782), visited from
+    the front and preempted from the BACK (:296-311): with the pool exhausted it is the EARLIEST arrival that is
+    recomputed -- the reference's own comment says "preempting the lowest (earliest) first".  Mirrored as is."""
+    s = _mk(be, num_gpu_blocks=4, block_size=4)
+    a = s.block_engine.new_sequence(1, list(range(7)))             # 2 blocks
+    b = s.block_engine.new_sequence(2, list(range(7)))             # 2 blocks
+    s.add_sequence(1, [a])
+    s.add_sequence(2, [b])
+    assert s.schedule().scheduled == [1, 2]
+    for q in (a, b):
+        q.add_token(99)                                            # 8 tokens -> 3 logical blocks each, pool is empty
+    out = s.schedule()
+    assert not out.is_prompt and out.scheduled == [2]
+    assert s.status(1) == be.Scheduler.WAITING and s.num_waiting() == 1
+    assert s.take_pending_runner_releases() == [1]                 # recompute: runner state released (:718-723)
+    assert s.block_engine.get_num_free_blocks() == 1               # 2 freed, 1 taken by the survivor's new slot
+    assert len(s.block_engine.block_table(b)) == 3
+
+
+def test_preemption_swaps_when_the_prefix_cache_is_on(be):
+    s = _mk(be, num_gpu_blocks=4, num_cpu_blocks=8, prefix_cache_enabled=True, max_cached_blocks=2)
+    a = s.block_engine.new_sequence(1, list(range(7)))
+    b = s.block_engine.new_sequence(2, list(range(100, 107)))
+    s.add_sequence(1, [a])
+    s.add_sequence(2, [b])
+    s.schedule()
+    for q in (a, b):
+        q.add_token(5)                                             # 8 tokens -> a third block each, none free
+    out = s.schedule(now_ms=1000)
+    assert out.scheduled == [2] and out.swap_out_groups == [1]     # _preempt_by_swap of the back of the queue (:725-755)
+    assert len(out.blocks_to_swap_out) == 2
+    assert s.status(1) == be.Scheduler.SWAPPED and s.num_swapped() == 1
+    assert all(c < 0 for c in s.block_engine.block_table(a))       # table now points at CPU blocks
+    s.set_finished(2)
+    assert s.free_finished_sequence_groups() == [2]
+    out = s.schedule(now_ms=1100)
+    assert out.swap_in_groups == []                                # 300 ms cooling period (:364-373)
+    out = s.schedule(now_ms=1400)
+    assert out.swap_in_groups == [1] and out.scheduled == [1]
+    assert all(c >= 0 for c in s.block_engine.block_table(a))
+
+
+def test_abort_frees_blocks(be):
+    s = _mk(be)
+    a = s.block_engine.new_sequence(1, list(range(9)))
+    s.add_sequence(1, [a])
+    s.schedule()
+    free = s.block_engine.get_num_free_blocks()
+    assert s.abort_sequences([1]) == 1
+    assert s.status(1) == be.Scheduler.ABORTED
+    assert s.block_engine.get_num_free_blocks() == free + 3 and not s.has_unfinished_sequences()
+
+
+def test_continuous_batching_simulation_32_sequences(be):
+    """BASELINE config 3's shape, scaled down: 32 sequences, prompt lengths U[16,256], staggered arrival, decode to a
+    random length; every step the scheduled block tables must be disjoint across sequences, slots must be unique,
+    and at the end every block is back in the pool."""
+    rng = np.random.default_rng(32)
+    bs, nblk = 16, 160
+    s = _mk(be, block_size=bs, num_gpu_blocks=nblk, num_cpu_blocks=64, max_num_parallel_reqs=32,
+            max_num_batched_tokens=512, prefill_chunk_size=128)
+    eng = s.block_engine
+    seqs, target, done = {}, {}, set()
+    arrivals = sorted(rng.integers(0, 40, 32).tolist())
+    next_id, step, prompt_steps, decode_steps, preempted = 0, 0, 0, 0, 0
+    while len(done) < 32 and step < 5000:
+        while next_id < 32 and arrivals[next_id] <= step:
+            n = int(rng.integers(16, 257))
+            seqs[next_id] = eng.new_sequence(next_id, rng.integers(0, 1000, n).tolist())
+            target[next_id] = n + int(rng.integers(4, 64))
+            s.add_sequence(next_id, [seqs[next_id]])
+            next_id += 1
+        out = s.schedule(now_ms=step * 50)
+        preempted += len(s.take_pending_runner_releases())
+        group = [seqs[g] for g in out.scheduled]
+        if out.is_prompt:
+            prompt_steps += 1
+            meta = eng.prepare_prompt(group, chunk=128)
+            assert int(meta["cu_seqlens_q"][-1]) <= 512                       # per-step prefill token budget
+            finished = s.filter_prefill_finished(out.scheduled)
+            decoding = [seqs[g] for g in finished]
+        else:
+            decode_steps += 1
+            decoding = group
+            if group:
+                meta = eng.prepare_decode(group)
+                assert len(set(meta["slot_mapping"].tolist())) == len(group)   # one distinct slot per sequence
+        tables = [eng.block_table(q) for q in group]
+        flat = [b for t in tables for b in t]
+        assert len(flat) == len(set(flat))                                     # no block shared between live sequences
+        for q in decoding:                                                     # "sample" one token each
+            if q.id in done:
+                continue
+            q.add_token(int(rng.integers(0, 1000)))
+            if q.get_len() >= target[q.id]:
+                s.set_finished(q.id)
+                done.add(q.id)
+        s.free_finished_sequence_groups()
+        step += 1
+    assert len(done) == 32, (len(done), step)
+    assert eng.get_num_free_blocks() == nblk and not s.has_unfinished_sequences()
+    assert prompt_steps > 0 and decode_steps > 0
