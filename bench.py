@@ -132,6 +132,9 @@ def main():
     if rank == 0 or not os.path.exists(ge.LIB):
         pass
     from candle_vllm_amd import model as M
+    for kv in filter(None, os.environ.get("MI355_TUNE", "").split(",")):    # experiments only: "key=value,..."
+        k, v = kv.split("=")
+        M.lib.mi355_set_tuning(int(k), int(v))
 
     cfg = llama3_8b()
     invalid = None

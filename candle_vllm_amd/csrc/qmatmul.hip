@@ -646,12 +646,11 @@ __global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) {
 static inline size_t qmw_kb_bytes(int MT) { return (size_t)MT * 8 * 1216; }
 
 template <int MT>
-__global__ void __launch_bounds__(256) qmm_prep_kernel(uint8_t* __restrict__ img, const QmmArgs a) {
+__global__ void __launch_bounds__(256) qmm_prep_kernel(uint8_t* __restrict__ img, const QmmArgs a, const size_t kbb) {
     constexpr int BP = MT * 8;
     __shared__ float red[16];
     const int b = blockIdx.x;                        // one workgroup per (padded) batch row
     const int nkb = a.K >> 8;
-    const size_t kbb = (size_t)BP * 1216;
     const bool live = b < a.B;
     float inv = 1.f;
     if (a.norm_w) {
@@ -970,6 +969,254 @@ __global__ void __launch_bounds__(64 * NW) qmm_wide_kernel(const QmmArgs a, cons
     }
 }
 
+
+// ================================================================================================
+// Wide path, second generation: GEMM and epilogue split.  The first generation (above) keeps one wave on a row tile
+// for ALL of K with the epilogue fused, which caps the grid at tiles/NW workgroups and runs 1-2 waves per SIMD at
+// ~200 VGPRs: latency-bound (0.9 TB/s on gate/up at 32 tokens).  Here the GEMM kernel also splits K across
+// gridDim.y so that every launch has >= ~2048 waves, stays under 128 VGPRs (4 waves per SIMD, two 8-wave workgroups
+// per CU), stages the activation image global -> LDS by DMA (no staging registers), and writes f32 partial sums
+// [ks][token][row]; a small second kernel adds the partials and applies the epilogue (deterministic: no atomics).
+static inline size_t qmg_kb_bytes(int MT) { return (((size_t)MT * 8 * 1216) + 1023) / 1024 * 1024; }
+
+typedef const void __attribute__((address_space(1)))* qmg_gptr_t;
+typedef void __attribute__((address_space(3)))* qmg_lptr_t;
+
+// image + per-k-block sum of squares in ONE pass: grid = k-blocks, a workgroup builds k-block kb for every token
+// row.  The RMSNorm weight is applied here, the 1/rms factor (a per-token scalar) is applied by the epilogue kernel
+// from the per-k-block partial sums ssp[kb][row] -- no second pass over x, no atomics.
+template <int MT>
+__global__ void __launch_bounds__(256) qmm_prep2_kernel(uint8_t* __restrict__ img, float* __restrict__ ssp, const QmmArgs a, const size_t kbb) {
+    constexpr int BP = MT * 8;
+    const int kb = blockIdx.x;
+    uint8_t* kbase = img + (size_t)kb * kbb;
+    float* xs32 = reinterpret_cast<float*>(kbase + (size_t)32 * MT * 16 * 16);
+    float* xs16 = xs32 + 8 * 2 * BP;
+    for (int e = threadIdx.x; e < BP * 32; e += blockDim.x) {       // 32 consecutive lanes = the 32 entries of one row
+        const int b = e >> 5, El = e & 31;
+        const bool live = b < a.B;
+        const int mt = b >> 3, m = b & 7;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+        const int k = kb * 256 + El * 8;
+        if (live) {
+            if (a.x_dtype == MI355_DTYPE_BF16) {
+                const uint4 w = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(a.x) + (size_t)b * a.ldx + k);
+                v[0] = bf16lo_to_f32(w.x); v[1] = bf16hi_to_f32(w.x); v[2] = bf16lo_to_f32(w.y); v[3] = bf16hi_to_f32(w.y);
+                v[4] = bf16lo_to_f32(w.z); v[5] = bf16hi_to_f32(w.z); v[6] = bf16lo_to_f32(w.w); v[7] = bf16hi_to_f32(w.w);
+            } else {
+                const float* xp = static_cast<const float*>(a.x) + (size_t)b * a.ldx + k;
+                const float4 v0 = *reinterpret_cast<const float4*>(xp), v1 = *reinterpret_cast<const float4*>(xp + 4);
+                v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+            }
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ss += v[i] * v[i];
+        if (a.norm_w && live) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] *= a.norm_w[k + i];
+        }
+        const uint32_t h02 = cvt_pk_bf16(v[0], v[2]), h13 = cvt_pk_bf16(v[1], v[3]);
+        const uint32_t h46 = cvt_pk_bf16(v[4], v[6]), h57 = cvt_pk_bf16(v[5], v[7]);
+        const float hf[8] = {bf16lo_to_f32(h02), bf16lo_to_f32(h13), bf16hi_to_f32(h02), bf16hi_to_f32(h13),
+                             bf16lo_to_f32(h46), bf16lo_to_f32(h57), bf16hi_to_f32(h46), bf16hi_to_f32(h57)};
+        const uint32_t l02 = cvt_pk_bf16(v[0] - hf[0], v[2] - hf[2]), l13 = cvt_pk_bf16(v[1] - hf[1], v[3] - hf[3]);
+        const uint32_t l46 = cvt_pk_bf16(v[4] - hf[4], v[6] - hf[6]), l57 = cvt_pk_bf16(v[5] - hf[5], v[7] - hf[7]);
+        float hsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hsum += hf[i];
+        const float lsum = (bf16lo_to_f32(l02) + bf16hi_to_f32(l02)) + (bf16lo_to_f32(l13) + bf16hi_to_f32(l13)) +
+                           (bf16lo_to_f32(l46) + bf16hi_to_f32(l46)) + (bf16lo_to_f32(l57) + bf16hi_to_f32(l57));
+        uint8_t* ent = kbase + ((size_t)El * (MT * 16) + mt * 16) * 16;
+        *reinterpret_cast<uint4*>(ent + (size_t)m * 16) = make_uint4(h02, h13, h46, h57);
+        *reinterpret_cast<uint4*>(ent + (size_t)(8 + m) * 16) = make_uint4(l02, l13, l46, l57);
+        const float h16 = hsum + __shfl_xor(hsum, 1, 64), l16 = lsum + __shfl_xor(lsum, 1, 64);
+        const float h32 = h16 + __shfl_xor(h16, 2, 64), l32 = l16 + __shfl_xor(l16, 2, 64);
+        if ((El & 1) == 0) {
+            xs16[((El >> 1) * 2 + 0) * BP + b] = h16;
+            xs16[((El >> 1) * 2 + 1) * BP + b] = l16;
+        }
+        if ((El & 3) == 0) {
+            xs32[((El >> 2) * 2 + 0) * BP + b] = h32;
+            xs32[((El >> 2) * 2 + 1) * BP + b] = l32;
+        }
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) ss += __shfl_xor(ss, o, 64);
+        if (El == 0) ssp[(size_t)kb * BP + b] = ss;
+    }
+}
+
+template <int MT>
+__global__ void __launch_bounds__(512, 4) qmm_gemm_kernel(const QmmArgs a, const uint8_t* __restrict__ img, float* __restrict__ part,
+                                                          const int ldp, const int n_slots) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
+    constexpr int BP = MT * 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nkb = a.K >> 8;
+    const size_t kbb = (((size_t)MT * 8 * 1216) + 1023) / 1024 * 1024;
+    const int nchunk = (int)(kbb >> 10);                              // 1 KiB = one wave-wide 16-B DMA
+    int slot = blockIdx.x * 8 + wave;
+    const bool have = slot < n_slots;
+    if (!have) slot = 0;
+    int t = slot, sg = 0;
+    while (sg + 1 < a.nseg && t >= a.seg[sg].n_tiles) { t -= a.seg[sg].n_tiles; ++sg; }
+    const int wtype = a.seg[sg].type;
+    const int wtb = (wtype == MI355_GGML_Q4_K) ? Q4K_TILE : Q6K_TILE;
+    const uint8_t* wbase = a.seg[sg].w + (size_t)t * nkb * wtb;
+    const int kb_per = (nkb + gridDim.y - 1) / gridDim.y;
+    const int kb_lo = blockIdx.y * kb_per, kb_hi = min(nkb, kb_lo + kb_per);
+    float y[1][MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) y[0][mt][v] = 0.f;
+
+    if (kb_lo < kb_hi) {
+        // activation image: global -> LDS by DMA (wave-uniform LDS base + lane * 16), no staging registers
+        auto dma_kb = [&](int kb, int buf) {
+            const uint8_t* src = img + (size_t)kb * kbb;
+            uint8_t* dst = smem + (size_t)buf * kbb;
+            for (int c = wave; c < nchunk; c += 8)
+                __builtin_amdgcn_global_load_lds((qmg_gptr_t)(src + (size_t)c * 1024 + lane * 16), (qmg_lptr_t)(dst + (size_t)c * 1024), 16, 0, 0);
+        };
+        dma_kb(kb_lo, kb_lo & 1);
+        TileRegs cur = load_tile<0>(wtype, wbase + (size_t)kb_lo * wtb, lane), nxt;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kb = kb_lo; kb < kb_hi; ++kb) {
+            const uint8_t* Lc = smem + (size_t)(kb & 1) * kbb;
+            const bool more = kb + 1 < kb_hi;
+            if (more && a.dbg != 2) dma_kb(kb + 1, (kb + 1) & 1);
+            nxt = load_tile<0>(wtype, more ? wbase + (size_t)(kb + 1) * wtb : wbase, more ? lane : 0);
+            if (a.dbg == 1) { y[0][0][0] += __uint_as_float(cur.a.x ^ cur.b.y ^ cur.c.z ^ cur.d.w ^ cur.e); }
+            else if (wtype == MI355_GGML_Q4_K) wide_q4k<MT>(cur, Lc, lane, y[0]);
+            else wide_q6k<MT>(cur, Lc, lane, y[0]);
+            cur = nxt;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // next image landed (and the next tile)
+            __syncthreads();                                        // everyone is done with Lc
+        }
+    }
+    // hi + lo halves of the M tile, then plain stores of the partial sums
+    const int kg = lane >> 4, rr = lane & 15;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) y[0][mt][v] += __shfl_xor(y[0][mt][v], 32, 64);
+    if (have && kg < 2) {
+        float* pp = part + (size_t)blockIdx.y * BP * ldp + (size_t)slot * 16 + rr;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) pp[(size_t)(8 * mt + 4 * kg + v) * ldp] = y[0][mt][v];
+    }
+}
+
+// partial sums -> epilogue; one thread per (token, concatenated padded row)
+__global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, const float* __restrict__ part, const int ldp,
+                                                           const int ks, const int BP, const float* __restrict__ ssp) {
+    const int prow = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (prow >= ldp || b >= a.B) return;
+    float inv = 1.f;                                               // deferred RMSNorm scale of this token
+    if (a.norm_w) {
+        float ss = 0.f;
+        for (int kb = 0; kb < (a.K >> 8); ++kb) ss += ssp[(size_t)kb * BP + b];
+        inv = rsqrtf(ss / (float)a.K + a.eps);
+    }
+    int sg = 0, lrow = prow;
+    while (sg + 1 < a.nseg && lrow >= a.seg[sg].n_tiles * 16) { lrow -= a.seg[sg].n_tiles * 16; ++sg; }
+    if (lrow >= a.seg[sg].n_rows) return;
+    auto total = [&](int pr) {
+        float s = 0.f;
+        for (int k = 0; k < ks; ++k) s += part[((size_t)k * BP + b) * ldp + pr];
+        return s * inv;
+    };
+    const int orow = a.seg[sg].row0 + lrow;
+    float val = total(prow);
+    if (a.bias) val += a.bias[orow];
+    if (a.epi == MI355_EPI_STORE) {
+        a.out[(size_t)b * a.ldo + orow] = val;
+    } else if (a.epi == MI355_EPI_RESID) {
+        a.out[(size_t)b * a.ldo + orow] = a.resid[(size_t)b * a.ldo + orow] + val;
+    } else if (a.epi == MI355_EPI_SILU_MUL) {
+        if (sg != 0) return;                                          // gate rows drive; up = same row of segment 1
+        float up = total(a.seg[0].n_tiles * 16 + lrow);
+        if (a.bias) up += a.bias[a.seg[1].row0 + lrow];
+        a.out[(size_t)b * a.ldo + lrow] = silu_f(val) * up;
+    } else if (a.epi == MI355_EPI_QKV_ROPE_CACHE) {
+        const int D = a.D, d = lrow % D, hh = lrow / D;
+        float o = val;
+        if (sg < 2 && d < a.rot) {
+            float partner = total(prow ^ 1);
+            if (a.bias) partner += a.bias[orow ^ 1];
+            const int64_t pos = a.positions[b];
+            const float c = a.cos_t[pos * (a.rot >> 1) + (d >> 1)], sn = a.sin_t[pos * (a.rot >> 1) + (d >> 1)];
+            o = (d & 1) ? (partner * sn + val * c) : (val * c - partner * sn);
+        }
+        const uint16_t ob = f32_to_bf16(o);
+        if (sg == 0) {
+            a.q_out[(size_t)b * a.Hq * D + lrow] = ob;
+        } else {
+            const int64_t slot = a.slot_mapping[b];
+            if (slot < 0) return;
+            uint16_t* cache = (sg == 1) ? a.kcache : a.vcache;
+            if (a.kv_layout == MI355_KV_FLASH) {
+                cache[(slot * a.Hkv + hh) * D + d] = ob;
+            } else {
+                const int64_t blk = slot / a.block_size, off = slot % a.block_size;
+                if (sg == 1) cache[((((blk * a.Hkv + hh) * (D / 8) + d / 8) * a.block_size + off) * 8) + d % 8] = ob;
+                else cache[((blk * a.Hkv + hh) * D + d) * (int64_t)a.block_size + off] = ob;
+            }
+        }
+    }
+}
+
+static uint8_t* g_qmg_img = nullptr;
+static size_t g_qmg_img_bytes = 0;
+static float* g_qmg_part = nullptr;
+static size_t g_qmg_part_bytes = 0;
+
+static int qmg_grow(void** p, size_t* have, size_t need, hipStream_t st) {
+    if (need <= *have) return 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return (int)hipErrorStreamCaptureUnsupported;
+    if (*p) { (void)hipDeviceSynchronize(); (void)hipFree(*p); *p = nullptr; *have = 0; }
+    const hipError_t e = hipMalloc(p, need * 2);
+    if (e != hipSuccess) return (int)e;
+    *have = need * 2;
+    return 0;
+}
+
+template <int MT>
+static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
+    QmmArgs a = a0;
+    if (a.paired) a.paired = 0;                 // slots are plain (segment, tile) order; the epilogue pairs gate/up rows
+    const int nkb = a.K / 256;
+    int n_slots = 0;
+    for (int s = 0; s < a.nseg; ++s) n_slots += a.seg[s].n_tiles;
+    const int ldp = n_slots * 16;
+    const size_t kbb = qmg_kb_bytes(MT);
+    // split K until the launch has >= 2048 waves (8 per CU), keeping >= 2 k-blocks per workgroup
+    int ks = 1;
+    while (n_slots * ks < 2048 && nkb / (ks * 2) >= 2) ks *= 2;
+    int rc = qmg_grow((void**)&g_qmg_img, &g_qmg_img_bytes, kbb * nkb + (size_t)nkb * MT * 8 * sizeof(float), st);
+    if (rc) return rc;
+    rc = qmg_grow((void**)&g_qmg_part, &g_qmg_part_bytes, (size_t)ks * MT * 8 * ldp * sizeof(float), st);
+    if (rc) return rc;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)qmm_gemm_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    float* ssp = reinterpret_cast<float*>(g_qmg_img + kbb * nkb);           // [nkb][MT*8] after the image
+    hipLaunchKernelGGL((qmm_prep2_kernel<MT>), dim3(nkb), dim3(256), 0, st, g_qmg_img, ssp, a, kbb);
+    hipLaunchKernelGGL((qmm_gemm_kernel<MT>), dim3((n_slots + 7) / 8, ks), dim3(512), 2 * kbb, st, a, g_qmg_img, g_qmg_part, ldp, n_slots);
+    hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, a.B), dim3(256), 0, st, a, g_qmg_part, ldp, ks, MT * 8, ssp);
+    return (int)hipGetLastError();
+}
+
 static uint8_t* g_qmw_img = nullptr;
 static size_t g_qmw_img_bytes = 0;
 
@@ -992,7 +1239,7 @@ static int qmw_launch(const QmmArgs& a, int n_slots, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)qmm_wide_kernel<MT, R, WT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((qmm_prep_kernel<MT>), dim3(MT * 8), dim3(256), 0, st, g_qmw_img, a);
+    hipLaunchKernelGGL((qmm_prep_kernel<MT>), dim3(MT * 8), dim3(256), 0, st, g_qmw_img, a, kbb);
     // 8 waves per workgroup share one image copy; 4 when that is needed to put a workgroup on every CU;
     // narrow outputs with the in-place residual epilogue additionally split K (atomic accumulation)
     if ((n_slots + 8 * R - 1) / (8 * R) >= 256) {
@@ -1019,11 +1266,13 @@ static int qmw_launch_mt(const QmmArgs& a, int wt, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------ launcher
 void mi355_pa_set_fused(int v);
 static int g_tune_nw = 0, g_tune_r = 0, g_tune_dbg = 0;   // 0 = heuristic; mi355_set_tuning (experiments only)
+static int g_tune_wide = 2;                                // wide path generation (1 = fused single-pass, 2 = split GEMM + epilogue)
 extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     if (key == 0) g_tune_nw = value;
     else if (key == 1) g_tune_r = value;
     else if (key == 2) g_tune_dbg = value;
     else if (key == 3) mi355_pa_set_fused(value);
+    else if (key == 4) g_tune_wide = value;
 }
 
 static size_t qmm_lds_bytes(int BT, int R, int NW) {
@@ -1146,7 +1395,11 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
             a.positions = pos0 ? pos0 + b0 : nullptr;
             a.slot_mapping = slot0 ? slot0 + b0 : nullptr;
             int rcw;
-            if (bn <= 16) rcw = qmw_launch_mt<2>(a, wt, st);
+            if (g_tune_wide == 2) {
+                if (bn <= 16) rcw = qmg_launch<2>(a, st);
+                else if (bn <= 24) rcw = qmg_launch<3>(a, st);
+                else rcw = qmg_launch<4>(a, st);
+            } else if (bn <= 16) rcw = qmw_launch_mt<2>(a, wt, st);
             else if (bn <= 24) rcw = qmw_launch_mt<3>(a, wt, st);
             else rcw = qmw_launch_mt<4>(a, wt, st);
             if (rcw) return rcw;

@@ -1,4 +1,3 @@
 mkdir -p gpurun_out
-timeout 300 python -m pytest tests/test_gpu_model.py -m gpu -q -k greedy 2>&1 | grep -E "passed|failed" > gpurun_out/full.log
-timeout 800 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|^E  .*Assert|^FAILED" >> gpurun_out/full.log
-cat gpurun_out/full.log
+for t in "4=1" "4=2" "4=1" "4=2"; do echo "TUNE $t"; MI355_TUNE=$t timeout 200 python bench.py --batch 32 --steps 16 --warmup 4 --no-cpu-baseline --no-batch32 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('B32', d['value'], d['ms_per_step'])"; done > gpurun_out/ab.log 2>&1
+cat gpurun_out/ab.log
