@@ -256,12 +256,12 @@ __global__ void __launch_bounds__(64 * NWV) paged_attn_flash_kernel(const PAPara
 // into LDS in parallel (no serial dependent-load chain), then every thread owns output channels and sums the
 // partitions with independent loads.
 template <int KVT>
-__global__ void __launch_bounds__(128) paged_attn_reduce_kernel(void* __restrict__ out, const float* __restrict__ tmp_out,
+__global__ void __launch_bounds__(512) paged_attn_reduce_kernel(void* __restrict__ out, const float* __restrict__ tmp_out,
                                                                 const float* __restrict__ max_logits,
                                                                 const float* __restrict__ exp_sums,
                                                                 const uint32_t* __restrict__ context_lens, int H,
                                                                 int D, int partition_size, int max_partitions) {
-    extern __shared__ float s_w[];                          // [P] merge weights
+    extern __shared__ float s_w[];                          // [P] merge weights, then [NG][DP] partial outputs
     __shared__ float red[16];
     const int h = blockIdx.x, b = blockIdx.y;
     const int64_t base = ((int64_t)b * H + h) * max_partitions;
@@ -278,7 +278,8 @@ __global__ void __launch_bounds__(128) paged_attn_reduce_kernel(void* __restrict
     M = wave_max(M);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = M;
     __syncthreads();
-    M = fmaxf(red[0], red[1]);
+    M = red[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) M = fmaxf(M, red[w]);
     __syncthreads();
     float den = 0.f;
     for (int i = threadIdx.x; i < P; i += blockDim.x) {
@@ -288,18 +289,30 @@ __global__ void __launch_bounds__(128) paged_attn_reduce_kernel(void* __restrict
     }
     den = block_sum(den, red);                              // barrier inside publishes s_w
     const float inv = (P > 0 && den > 0.f) ? 1.f / den : 0.f;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    // the partitions are dealt round-robin to NG thread groups (one output channel per thread, 8 independent loads
+    // in flight each): the partial rows come from other XCDs' writes, i.e. from memory -- latency, not bandwidth
+    const int DP = D <= 64 ? 64 : (D <= 128 ? 128 : 256);
+    const int NG = blockDim.x / DP, g = threadIdx.x / DP, d = threadIdx.x % DP;
+    float acc = 0.f;
+    if (d < D) {
         const float* tp = tmp_out + base * D + d;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int i = 0;
-        for (; i + 4 <= P; i += 4) {
-            a0 = fmaf(tp[(int64_t)i * D], s_w[i], a0);
-            a1 = fmaf(tp[(int64_t)(i + 1) * D], s_w[i + 1], a1);
-            a2 = fmaf(tp[(int64_t)(i + 2) * D], s_w[i + 2], a2);
-            a3 = fmaf(tp[(int64_t)(i + 3) * D], s_w[i + 3], a3);
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int i = g;
+        for (; i + 7 * NG < P; i += 8 * NG) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = fmaf(tp[(int64_t)(i + u * NG) * D], s_w[i + u * NG], a[u]);
         }
-        for (; i < P; ++i) a0 = fmaf(tp[(int64_t)i * D], s_w[i], a0);
-        const float o = (a0 + a1 + a2 + a3) * inv;
+        for (; i < P; i += NG) a[0] = fmaf(tp[(int64_t)i * D], s_w[i], a[0]);
+        acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    __syncthreads();                                        // everybody is done reading the weights
+    float* s_o = s_w;                                       // reuse: [NG][DP]
+    s_o[g * DP + d] = acc;
+    __syncthreads();
+    if (g == 0 && d < D) {
+        float o = 0.f;
+        for (int k = 0; k < NG; ++k) o += s_o[k * DP + d];
+        o *= inv;
         uint16_t* op = static_cast<uint16_t*>(out) + ((int64_t)b * H + h) * D + d;
         *op = (KVT == MI355_DTYPE_BF16) ? f32_to_bf16(o) : f32_to_f16_bits(o);
     }
@@ -671,8 +684,8 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
         return (int)hipErrorInvalidValue;
     }
     if (rc != 0 || P <= 1) return rc;
-    dim3 rgrid(p.H, B), rblock(128);
-    const size_t rshm = (size_t)p.max_partitions * sizeof(float);
+    dim3 rgrid(p.H, B), rblock(512);
+    const size_t rshm = (size_t)(p.max_partitions > 512 ? p.max_partitions : 512) * sizeof(float);
     if (rshm > 60 * 1024) return (int)hipErrorInvalidValue;
     if (dtype == MI355_DTYPE_BF16)
         hipLaunchKernelGGL(paged_attn_reduce_kernel<MI355_DTYPE_BF16>, rgrid, rblock, rshm, st, p.out, p.tmp_out,

@@ -1,3 +1,5 @@
 mkdir -p gpurun_out
-for t in "4=1" "4=2" "4=1" "4=2"; do echo "TUNE $t"; MI355_TUNE=$t timeout 200 python bench.py --batch 32 --steps 16 --warmup 4 --no-cpu-baseline --no-batch32 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('B32', d['value'], d['ms_per_step'])"; done > gpurun_out/ab.log 2>&1
-cat gpurun_out/ab.log
+timeout 300 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -m gpu -q -x 2>&1 | grep -E "passed|failed|^E  |^FAILED" > gpurun_out/red.log
+timeout 200 python bench.py --no-cpu-baseline --no-batch32 2>&1 | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('B1', d['value'], d['ms_per_step']); [print(g['kernel'], g['avg_us']) for g in d['roofline']['groups']]" >> gpurun_out/red.log 2>&1
+cat gpurun_out/red.log
