@@ -177,3 +177,21 @@ _sig("mi355_sched_free_finished", c_i32, [c_vp, c_vp, c_i32])
 _sig("mi355_sched_abort_sequences", c_i32, [c_vp, c_vp, c_i32])
 for _n in ("mi355_sched_rollback_swap_in", "mi355_sched_rollback_swap_out"):
     _sig(_n, None, [c_vp, c_i64])
+
+
+# ---- dense 16-bit model host layer (section 4b)
+class DenseConfig(ctypes.Structure):
+    """mirror of `mi355_dense_config`"""
+    _fields_ = [(n, c_i32) for n in ("hidden", "n_layers", "n_heads", "n_kv_heads", "head_dim", "intermediate",
+                                     "vocab", "max_seq", "block_size", "kv_layout", "max_batch",
+                                     "max_blocks_per_seq")] + \
+               [("rms_eps", c_f32), ("rope_theta", c_f32), ("dtype", c_i32), ("rope_interleaved", c_i32)]
+
+
+_sig("mi355_dense_create", c_vp, [ctypes.POINTER(DenseConfig)])
+_sig("mi355_dense_destroy", None, [c_vp])
+_sig("mi355_dense_set_weight", ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_i64])
+_sig("mi355_dense_set_weight_dev", ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_i64])
+_sig("mi355_dense_alloc_kv_cache", ctypes.c_int, [c_vp, c_i32])
+_sig("mi355_dense_kv_ptr", c_vp, [c_vp, c_i32, c_i32])
+_sig("mi355_dense_forward", ctypes.c_int, [c_vp] * 7 + [c_i32] * 5 + [c_vp, c_i64])

@@ -1,0 +1,267 @@
+// Host layer for the safetensors (16-bit) llama-family models: `Llama::forward_inner` (src/openai/models/llama.rs:
+// 139-201), `Block::forward` (:46-63), `Attention::forward_ext` (layers/attention.rs:585-734), `Mlp::forward`
+// (layers/mlp.rs:440-458, packed gate_up :324-352), with Qwen2's qkv bias (qwen.rs).  Every op result is rounded to
+// the model dtype exactly where candle rounds (the residual stream is 16-bit here, unlike the GGUF path).
+// Kernels: dense_gemv.hip (linears + fused residual / silu*up), elementwise.hip (rms_norm, rope on 16-bit data
+// = upcast-rotate-downcast), cache_kernels.hip (reshape_and_cache), paged_attention.hip / prefill_attention.hip.
+// Eager only (no graph capture, no tensor parallelism on this path yet).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/mi355_vllm.h"
+
+namespace {
+
+#define DCHECK(expr) do { const int rc_ = (expr); if (rc_ != 0) return rc_; } while (0)
+#define DHIP(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+struct DLayer {
+    uint16_t *wq = nullptr, *wk = nullptr, *wv = nullptr, *wo = nullptr, *gate_up = nullptr, *w2 = nullptr;
+    uint16_t *bq = nullptr, *bk = nullptr, *bv = nullptr;
+    uint16_t *attn_norm = nullptr, *ffn_norm = nullptr;
+};
+
+struct DModel {
+    mi355_dense_config cfg{};
+    std::vector<DLayer> layers;
+    uint16_t *tok_embd = nullptr, *output_norm = nullptr, *output = nullptr;
+    float *cos_t = nullptr, *sin_t = nullptr;
+    // activations (grow-only, T rows)
+    int cap = 0;
+    uint16_t *xs = nullptr, *xn = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *attn = nullptr, *h = nullptr, *lg16 = nullptr;
+    float *pa_tmp = nullptr, *pa_max = nullptr, *pa_sum = nullptr;
+    int pa_cap_partitions = 0;
+    void* kv_slab = nullptr;
+    std::vector<void*> kcache, vcache;
+    int num_blocks = 0;
+};
+
+__global__ void embedding16_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ table,
+                                   const uint32_t* __restrict__ ids, int hidden) {
+    const uint16_t* src = table + (size_t)ids[blockIdx.x] * hidden;
+    uint16_t* dst = out + (size_t)blockIdx.x * hidden;
+    for (int i = threadIdx.x; i < hidden; i += blockDim.x) dst[i] = src[i];
+}
+__global__ void select_last_rows16_kernel(uint16_t* dst, const uint16_t* src, const uint32_t* cu_q, int hidden) {
+    const size_t row = (size_t)cu_q[blockIdx.x + 1] - 1;
+    for (int i = threadIdx.x; i < hidden; i += blockDim.x) dst[(size_t)blockIdx.x * hidden + i] = src[row * hidden + i];
+}
+
+int ensure_cap(DModel* m, int T) {
+    if (T <= m->cap) return 0;
+    DHIP(hipDeviceSynchronize());
+    void* old[] = {m->xs, m->xn, m->q, m->k, m->v, m->attn, m->h, m->lg16};
+    for (void* p : old) if (p) (void)hipFree(p);
+    const mi355_dense_config& c = m->cfg;
+    const int cap = (T + 63) / 64 * 64;
+    const size_t hid = c.hidden, HD = (size_t)c.n_heads * c.head_dim, KD = (size_t)c.n_kv_heads * c.head_dim;
+    DHIP(hipMalloc((void**)&m->xs, cap * hid * 2));
+    DHIP(hipMalloc((void**)&m->xn, cap * hid * 2));
+    DHIP(hipMalloc((void**)&m->q, cap * HD * 2));
+    DHIP(hipMalloc((void**)&m->k, cap * KD * 2));
+    DHIP(hipMalloc((void**)&m->v, cap * KD * 2));
+    DHIP(hipMalloc((void**)&m->attn, cap * HD * 2));
+    DHIP(hipMalloc((void**)&m->h, (size_t)cap * c.intermediate * 2));
+    DHIP(hipMalloc((void**)&m->lg16, (size_t)c.max_batch * c.vocab * 2));
+    m->cap = cap;
+    return 0;
+}
+
+int choose_partition(int batch, int kv_heads, int ctx_cap) {
+    if (ctx_cap <= 256) return 0;
+    int per_seq = (2048 + batch * kv_heads - 1) / (batch * kv_heads);
+    if (per_seq < 1) per_seq = 1;
+    int ps = (ctx_cap + per_seq - 1) / per_seq;
+    ps = ((ps + 31) / 32) * 32;
+    if (ps < 32) ps = 32;
+    return ps < ctx_cap ? ps : 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void* mi355_dense_create(const mi355_dense_config* cfg) {
+    if (!cfg || cfg->hidden <= 0 || (cfg->hidden % 256) || (cfg->intermediate % 256) || cfg->n_layers <= 0 ||
+        cfg->max_batch <= 0 || cfg->head_dim <= 0 || (cfg->dtype != MI355_DTYPE_BF16 && cfg->dtype != MI355_DTYPE_F16))
+        return nullptr;
+    if (cfg->dtype != MI355_DTYPE_BF16) return nullptr;       // the attention kernels of this path are bf16
+    DModel* m = new DModel();
+    m->cfg = *cfg;
+    m->layers.resize(cfg->n_layers);
+    const int D = cfg->head_dim, half = D / 2;
+    std::vector<float> ct((size_t)cfg->max_seq * half), st((size_t)cfg->max_seq * half);
+    for (int i = 0; i < half; ++i) {                          // rotary_emb.rs:14-48
+        const float inv = (float)(1.0 / pow((double)cfg->rope_theta, (double)(2 * i) / (double)D));
+        for (int p = 0; p < cfg->max_seq; ++p) {
+            const float th = (float)p * inv;
+            ct[(size_t)p * half + i] = (float)cos((double)th);
+            st[(size_t)p * half + i] = (float)sin((double)th);
+        }
+    }
+    bool ok = hipMalloc((void**)&m->cos_t, ct.size() * 4) == hipSuccess && hipMalloc((void**)&m->sin_t, st.size() * 4) == hipSuccess;
+    ok = ok && hipMemcpy(m->cos_t, ct.data(), ct.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(m->sin_t, st.data(), st.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    m->pa_cap_partitions = (cfg->max_seq + 31) / 32 + 1;
+    const size_t B = cfg->max_batch, H = cfg->n_heads;
+    ok = ok && hipMalloc((void**)&m->pa_tmp, B * H * m->pa_cap_partitions * D * 4) == hipSuccess &&
+         hipMalloc((void**)&m->pa_max, B * H * m->pa_cap_partitions * 4) == hipSuccess &&
+         hipMalloc((void**)&m->pa_sum, B * H * m->pa_cap_partitions * 4) == hipSuccess;
+    if (!ok) { mi355_dense_destroy(m); return nullptr; }
+    return m;
+}
+
+void mi355_dense_destroy(void* mp) {
+    DModel* m = static_cast<DModel*>(mp);
+    if (!m) return;
+    for (auto& L : m->layers) {
+        void* ps[] = {L.wq, L.wk, L.wv, L.wo, L.gate_up, L.w2, L.bq, L.bk, L.bv, L.attn_norm, L.ffn_norm};
+        for (void* p : ps) if (p) (void)hipFree(p);
+    }
+    void* ps[] = {m->tok_embd, m->output_norm, m->output, m->cos_t, m->sin_t, m->xs, m->xn, m->q, m->k, m->v, m->attn,
+                  m->h, m->lg16, m->pa_tmp, m->pa_max, m->pa_sum, m->kv_slab};
+    for (void* p : ps) if (p) (void)hipFree(p);
+    delete m;
+}
+
+/* 16-bit tensors from the HOST in checkpoint layout ([out, in] row-major); gate (W1) and up (W3) are packed into one
+ * [2I, hidden] matrix as the reference's unquantised MLP does (mlp.rs:324-352). */
+static int dense_set_weight_impl(void* mp, int32_t layer, int32_t which, const void* host, int64_t n_elems, hipMemcpyKind kind);
+int mi355_dense_set_weight(void* mp, int32_t layer, int32_t which, const void* host, int64_t n_elems) {
+    return dense_set_weight_impl(mp, layer, which, host, n_elems, hipMemcpyHostToDevice);
+}
+/* same, from a DEVICE buffer (copied) */
+int mi355_dense_set_weight_dev(void* mp, int32_t layer, int32_t which, const void* dev, int64_t n_elems) {
+    return dense_set_weight_impl(mp, layer, which, dev, n_elems, hipMemcpyDeviceToDevice);
+}
+static int dense_set_weight_impl(void* mp, int32_t layer, int32_t which, const void* host, int64_t n_elems, hipMemcpyKind kind) {
+    DModel* m = static_cast<DModel*>(mp);
+    if (!m || !host || n_elems <= 0) return (int)hipErrorInvalidValue;
+    const mi355_dense_config& c = m->cfg;
+    const int64_t hid = c.hidden, HD = (int64_t)c.n_heads * c.head_dim, KD = (int64_t)c.n_kv_heads * c.head_dim, I = c.intermediate;
+    uint16_t** slot = nullptr;
+    int64_t expect = 0, offset = 0, total = 0;
+    if (layer < 0) {
+        if (which == MI355_W_TOK_EMBD) { slot = &m->tok_embd; expect = (int64_t)c.vocab * hid; }
+        else if (which == MI355_W_OUTPUT_NORM) { slot = &m->output_norm; expect = hid; }
+        else if (which == MI355_W_OUTPUT) { slot = &m->output; expect = (int64_t)c.vocab * hid; }
+        else return (int)hipErrorInvalidValue;
+    } else {
+        if (layer >= c.n_layers) return (int)hipErrorInvalidValue;
+        DLayer& L = m->layers[layer];
+        switch (which) {
+            case MI355_W_WQ: slot = &L.wq; expect = HD * hid; break;
+            case MI355_W_WK: slot = &L.wk; expect = KD * hid; break;
+            case MI355_W_WV: slot = &L.wv; expect = KD * hid; break;
+            case MI355_W_WO: slot = &L.wo; expect = hid * HD; break;
+            case MI355_W_W1: slot = &L.gate_up; expect = I * hid; total = 2 * I * hid; offset = 0; break;
+            case MI355_W_W3: slot = &L.gate_up; expect = I * hid; total = 2 * I * hid; offset = I * hid; break;
+            case MI355_W_W2: slot = &L.w2; expect = hid * I; break;
+            case MI355_W_ATTN_NORM: slot = &L.attn_norm; expect = hid; break;
+            case MI355_W_FFN_NORM: slot = &L.ffn_norm; expect = hid; break;
+            case MI355_W_BQ: slot = &L.bq; expect = HD; break;
+            case MI355_W_BK: slot = &L.bk; expect = KD; break;
+            case MI355_W_BV: slot = &L.bv; expect = KD; break;
+            default: return (int)hipErrorInvalidValue;
+        }
+    }
+    if (n_elems != expect) return (int)hipErrorInvalidValue;
+    if (total == 0) total = expect;
+    if (!*slot) DHIP(hipMalloc((void**)slot, (size_t)total * 2));
+    DHIP(hipMemcpy(*slot + offset, host, (size_t)n_elems * 2, kind));
+    return 0;
+}
+
+int mi355_dense_alloc_kv_cache(void* mp, int32_t num_blocks) {
+    DModel* m = static_cast<DModel*>(mp);
+    if (!m || num_blocks <= 0) return (int)hipErrorInvalidValue;
+    const mi355_dense_config& c = m->cfg;
+    const size_t per = (size_t)num_blocks * c.block_size * c.n_kv_heads * c.head_dim * 2;
+    if (m->kv_slab) { (void)hipFree(m->kv_slab); m->kv_slab = nullptr; }
+    DHIP(hipMalloc(&m->kv_slab, per * 2 * c.n_layers));
+    DHIP(hipMemset(m->kv_slab, 0, per * 2 * c.n_layers));
+    DHIP(hipDeviceSynchronize());
+    m->kcache.resize(c.n_layers); m->vcache.resize(c.n_layers);
+    for (int l = 0; l < c.n_layers; ++l) {
+        m->kcache[l] = static_cast<uint8_t*>(m->kv_slab) + per * (2 * l);
+        m->vcache[l] = static_cast<uint8_t*>(m->kv_slab) + per * (2 * l + 1);
+    }
+    m->num_blocks = num_blocks;
+    return 0;
+}
+void* mi355_dense_kv_ptr(void* mp, int32_t layer, int32_t which) {
+    DModel* m = static_cast<DModel*>(mp);
+    if (!m || layer < 0 || layer >= (int)m->kcache.size()) return nullptr;
+    return which == 0 ? m->kcache[layer] : m->vcache[layer];
+}
+
+/* One step (prompt when cu_seqlens_q != NULL, else decode).  Inputs are DEVICE arrays exactly as prepare_prompt /
+ * prepare_decode build them.  logits: f32 [num_seqs, vocab] (`.to_dtype(F32)` of the 16-bit lm_head output). */
+int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positions, const int64_t* slot_mapping,
+                        const uint32_t* block_tables, const uint32_t* context_lens, const uint32_t* cu_seqlens_q,
+                        int32_t num_seqs, int32_t num_tokens, int32_t max_seqlen_q, int32_t max_blocks,
+                        int32_t max_context_len, float* logits, int64_t stream) {
+    DModel* m = static_cast<DModel*>(mp);
+    if (!m || !logits || num_seqs < 1 || num_tokens < num_seqs || num_seqs > m->cfg.max_batch) return (int)hipErrorInvalidValue;
+    const mi355_dense_config& c = m->cfg;
+    if ((int)m->kcache.size() != c.n_layers || !m->tok_embd || !m->output || !m->output_norm) return (int)hipErrorInvalidValue;
+    const bool prefill = cu_seqlens_q != nullptr;
+    if (!prefill && num_tokens != num_seqs) return (int)hipErrorInvalidValue;
+    DCHECK(ensure_cap(m, num_tokens));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int T = num_tokens, H = c.n_heads, Hkv = c.n_kv_heads, D = c.head_dim, hid = c.hidden, I = c.intermediate;
+    const int dt = c.dtype;
+    const float scale = 1.0f / sqrtf((float)D);
+    hipLaunchKernelGGL(embedding16_kernel, dim3(T), dim3(256), 0, st, m->xs, m->tok_embd, tokens, hid);
+    for (int l = 0; l < c.n_layers; ++l) {
+        DLayer& L = m->layers[l];
+        if (!L.wq || !L.wk || !L.wv || !L.wo || !L.gate_up || !L.w2 || !L.attn_norm || !L.ffn_norm) return (int)hipErrorInvalidValue;
+        // x = rms_1(xs)                                                     llama.rs:53-54
+        DCHECK(mi355_rms_norm(m->xn, m->xs, L.attn_norm, T, hid, c.rms_eps, dt, dt, stream));
+        // q,k,v projections (+bias)                                          attention.rs:597-607
+        DCHECK(mi355_linear(m->q, m->xn, L.wq, L.bq, nullptr, T, H * D, hid, dt, MI355_EPI_STORE, stream));
+        DCHECK(mi355_linear(m->k, m->xn, L.wk, L.bk, nullptr, T, Hkv * D, hid, dt, MI355_EPI_STORE, stream));
+        DCHECK(mi355_linear(m->v, m->xn, L.wv, L.bv, nullptr, T, Hkv * D, hid, dt, MI355_EPI_STORE, stream));
+        // q,k -> f32 -> rope -> model dtype                                  attention.rs:644-690
+        DCHECK(mi355_rope_inplace(m->q, m->k, m->cos_t, m->sin_t, positions, T, H, Hkv, D, D, c.rope_interleaved, dt, stream));
+        // PagedAttention::forward: cache write, then prefill / decode attention   attention.rs:707-719
+        DCHECK(mi355_reshape_and_cache(m->k, m->v, m->kcache[l], m->vcache[l], slot_mapping, T, Hkv, D, c.block_size, 2,
+                                       c.kv_layout, stream));
+        if (prefill) {
+            DCHECK(mi355_prefill_attention(m->attn, m->q, nullptr, nullptr, m->kcache[l], m->vcache[l], block_tables,
+                                           context_lens, cu_seqlens_q, num_seqs, max_seqlen_q, H, Hkv, D, c.block_size,
+                                           max_blocks, scale, 0.f, c.kv_layout, dt, stream));
+        } else {
+            int ps = choose_partition(T, Hkv, max_context_len);
+            if (ps > 0 && c.kv_layout == MI355_KV_PAGED) ps = ps <= 32 ? 32 : (ps <= 64 ? 64 : 128);
+            if (ps > 0 && (max_context_len + ps - 1) / ps > m->pa_cap_partitions) return (int)hipErrorInvalidValue;
+            if (ps == 0)
+                DCHECK(mi355_paged_attention_v1(m->attn, m->q, m->kcache[l], m->vcache[l], block_tables, context_lens, T, H,
+                                                Hkv, D, c.block_size, max_blocks, max_context_len, scale, 0.f, c.kv_layout, dt, stream));
+            else
+                DCHECK(mi355_paged_attention_v2(m->attn, m->pa_sum, m->pa_max, m->pa_tmp, m->q, m->kcache[l], m->vcache[l],
+                                                block_tables, context_lens, T, H, Hkv, D, c.block_size, max_blocks,
+                                                max_context_len, ps, scale, 0.f, c.kv_layout, dt, stream));
+        }
+        // xs = o_proj(y) + residual                                          llama.rs:55-58
+        DCHECK(mi355_linear(m->xs, m->attn, L.wo, nullptr, m->xs, T, hid, H * D, dt, MI355_EPI_RESID, stream));
+        // xs = down(silu(gate) * up) + residual                              llama.rs:59-61, mlp.rs:440-458
+        DCHECK(mi355_rms_norm(m->xn, m->xs, L.ffn_norm, T, hid, c.rms_eps, dt, dt, stream));
+        DCHECK(mi355_linear(m->h, m->xn, L.gate_up, nullptr, nullptr, T, 2 * I, hid, dt, MI355_EPI_SILU_MUL, stream));
+        DCHECK(mi355_linear(m->xs, m->h, L.w2, nullptr, m->xs, T, hid, I, dt, MI355_EPI_RESID, stream));
+    }
+    const uint16_t* last = m->xs;
+    if (prefill) {                                                          // llama.rs:190-194
+        hipLaunchKernelGGL(select_last_rows16_kernel, dim3(num_seqs), dim3(256), 0, st, m->xn, m->xs, cu_seqlens_q, hid);
+        DHIP(hipMemcpyAsync(m->xs, m->xn, (size_t)num_seqs * hid * 2, hipMemcpyDeviceToDevice, st));
+        last = m->xs;
+    }
+    DCHECK(mi355_rms_norm(m->xn, last, m->output_norm, num_seqs, hid, c.rms_eps, dt, dt, stream));
+    DCHECK(mi355_linear(m->lg16, m->xn, m->output, nullptr, nullptr, num_seqs, c.vocab, hid, dt, MI355_EPI_STORE, stream));
+    return mi355_cast(logits, m->lg16, (int64_t)num_seqs * c.vocab, dt, MI355_DTYPE_F32, stream);
+}
+
+}  // extern "C"

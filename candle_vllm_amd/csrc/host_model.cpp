@@ -128,6 +128,7 @@ struct Model {
     int p_cap = 0;
 };
 
+int g_host_ps_override = 0;     // experiments: mi355_set_tuning(5, partition_size)
 int local_heads(const Model* m) { return m->cfg.n_heads / (m->cfg.tp_world > 0 ? m->cfg.tp_world : 1); }
 int local_kv_heads(const Model* m) {
     const int w = m->cfg.tp_world > 0 ? m->cfg.tp_world : 1;
@@ -251,6 +252,7 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
         // --- paged attention over the cache (the new token's K/V are already in place)
         int ps = choose_partition(B, Hkv, in.ctx_cap);
         if (ps > 0 && c.kv_layout == MI355_KV_PAGED) ps = ps <= 32 ? 32 : (ps <= 64 ? 64 : 128);   // MFMA kernel sizes
+        if (g_host_ps_override > 0 && ps > 0) ps = g_host_ps_override;
         const float scale = 1.0f / sqrtf((float)D);
         if (ps > 0 && (in.ctx_cap + ps - 1) / ps > m->pa_cap_partitions) return (int)hipErrorInvalidValue;
         if (in.ctx_cap > c.max_seq) return (int)hipErrorInvalidValue;
@@ -332,6 +334,8 @@ void drop_graph(Model* m) {
 }
 
 }  // namespace
+
+extern "C" void mi355_host_set_partition_override(int v) { g_host_ps_override = v; }
 
 extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
     if (!cfg || cfg->hidden <= 0 || cfg->n_layers <= 0 || cfg->max_batch <= 0 || cfg->head_dim <= 0 ||

@@ -1265,6 +1265,7 @@ static int qmw_launch_mt(const QmmArgs& a, int wt, hipStream_t st) {
 
 // ------------------------------------------------------------------------------------------------ launcher
 void mi355_pa_set_fused(int v);
+extern "C" void mi355_host_set_partition_override(int v);
 static int g_tune_nw = 0, g_tune_r = 0, g_tune_dbg = 0;   // 0 = heuristic; mi355_set_tuning (experiments only)
 static int g_tune_wide = 2;                                // wide path generation (1 = fused single-pass, 2 = split GEMM + epilogue)
 extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
@@ -1273,6 +1274,7 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     else if (key == 2) g_tune_dbg = value;
     else if (key == 3) mi355_pa_set_fused(value);
     else if (key == 4) g_tune_wide = value;
+    else if (key == 5) mi355_host_set_partition_override(value);
 }
 
 static size_t qmm_lds_bytes(int BT, int R, int NW) {

@@ -1,0 +1,142 @@
+"""Python harness over the `mi355_dense_*` handle (16-bit safetensors llama-family host layer): mirrors
+`Llama::forward` (src/openai/models/llama.rs:118-201).  No CPU fallback."""
+import ctypes
+
+import numpy as np
+import torch
+
+from ._lib import lib, DenseConfig
+from .ops import _check, KV_FLASH, KV_PAGED  # noqa: F401
+
+W_SLOTS = {"wq": 0, "wk": 1, "wv": 2, "wo": 3, "w1": 4, "w2": 5, "w3": 6, "attn_norm": 7, "ffn_norm": 8,
+           "tok_embd": 9, "output_norm": 10, "output": 11, "bq": 12, "bk": 13, "bv": 14}
+DT_BF16 = 2
+
+
+def _bf16_bits(a):
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+class DenseLlama:
+    def __init__(self, cfg, max_batch=8, max_blocks_per_seq=64, kv_layout=KV_PAGED, rope_interleaved=False):
+        self.cfg, self.kv_layout = cfg, kv_layout
+        c = DenseConfig(hidden=cfg.hidden, n_layers=cfg.n_layers, n_heads=cfg.n_heads, n_kv_heads=cfg.n_kv_heads,
+                        head_dim=cfg.head_dim, intermediate=cfg.intermediate, vocab=cfg.vocab, max_seq=cfg.max_seq,
+                        block_size=cfg.block_size, kv_layout=kv_layout, max_batch=max_batch,
+                        max_blocks_per_seq=max_blocks_per_seq, rms_eps=cfg.rms_eps, rope_theta=cfg.rope_theta,
+                        dtype=DT_BF16, rope_interleaved=int(rope_interleaved))
+        self.h = lib.mi355_dense_create(ctypes.byref(c))
+        if not self.h:
+            raise RuntimeError("mi355_dense_create failed (bad config or no GPU memory)")
+
+    def __del__(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib.mi355_dense_destroy(self.h)
+            self.h = None
+
+    def set_weight(self, layer, name, values_f32):
+        """values: f32 numpy, exactly representable in bf16 (checkpoint tensors)"""
+        bits = _bf16_bits(values_f32)
+        _check(lib.mi355_dense_set_weight(self.h, layer, W_SLOTS[name], bits.ctypes.data, bits.size), f"set_weight {name}")
+
+    def load_oracle_weights(self, W):
+        for name in ("tok_embd", "output_norm", "output"):
+            self.set_weight(-1, name, W[name])
+        for l, lw in enumerate(W["layers"]):
+            for name, v in lw.items():
+                self.set_weight(l, name, v)
+
+    def load_synthetic(self, seed=0, std=0.02):
+        """random bf16 weights generated on the GPU (bench)"""
+        c = self.cfg
+        g = torch.Generator(device="cuda").manual_seed(seed)
+
+        def rnd(n, s=std, mean=0.0):
+            return (torch.randn(n, generator=g, device="cuda") * s + mean).to(torch.bfloat16)
+
+        def put(layer, name, t):
+            _check(lib.mi355_dense_set_weight_dev(self.h, layer, W_SLOTS[name], t.data_ptr(), t.numel()), name)
+            torch.cuda.synchronize()
+        HD, KD = c.n_heads * c.head_dim, c.n_kv_heads * c.head_dim
+        put(-1, "tok_embd", rnd(c.vocab * c.hidden, 0.5))
+        put(-1, "output_norm", rnd(c.hidden, 0.02, 1.0))
+        put(-1, "output", rnd(c.vocab * c.hidden))
+        for l in range(c.n_layers):
+            put(l, "attn_norm", rnd(c.hidden, 0.02, 1.0))
+            put(l, "ffn_norm", rnd(c.hidden, 0.02, 1.0))
+            put(l, "wq", rnd(HD * c.hidden)); put(l, "wk", rnd(KD * c.hidden)); put(l, "wv", rnd(KD * c.hidden))
+            put(l, "wo", rnd(c.hidden * HD))
+            put(l, "w1", rnd(c.intermediate * c.hidden)); put(l, "w3", rnd(c.intermediate * c.hidden))
+            put(l, "w2", rnd(c.hidden * c.intermediate))
+
+    def weight_bytes(self):
+        c = self.cfg
+        HD, KD = c.n_heads * c.head_dim, c.n_kv_heads * c.head_dim
+        per_layer = (HD + 2 * KD) * c.hidden + c.hidden * HD + 3 * c.intermediate * c.hidden
+        return 2 * (c.n_layers * per_layer + c.vocab * c.hidden)
+
+    def alloc_kv_cache(self, num_blocks):
+        _check(lib.mi355_dense_alloc_kv_cache(self.h, num_blocks), "alloc_kv_cache")
+        self.num_blocks = num_blocks
+
+    def kv_shape(self):
+        c = self.cfg
+        if self.kv_layout == KV_FLASH:
+            s = (self.num_blocks, c.block_size, c.n_kv_heads, c.head_dim)
+            return s, s
+        return ((self.num_blocks, c.n_kv_heads, c.head_dim // 8, c.block_size, 8),
+                (self.num_blocks, c.n_kv_heads, c.head_dim, c.block_size))
+
+    def kv_download(self, layer):
+        out = []
+        for which in (0, 1):
+            shape = self.kv_shape()[which]
+            n = int(np.prod(shape))
+            host = np.empty(n, np.uint16)
+            ptr = lib.mi355_dense_kv_ptr(self.h, layer, which)
+            t = torch.empty(n, dtype=torch.int16, device="cuda")
+            torch.cuda.synchronize()
+            ctypes.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(ptr),
+                                                                 ctypes.c_size_t(n * 2), 3)
+            host[:] = t.cpu().numpy().view(np.uint16)
+            out.append(host.reshape(shape))
+        return out
+
+    def kv_upload(self, layer, k_bits, v_bits):
+        for which, bits in ((0, k_bits), (1, v_bits)):
+            t = torch.from_numpy(np.ascontiguousarray(bits).view(np.int16).reshape(-1)).cuda()
+            ptr = lib.mi355_dense_kv_ptr(self.h, layer, which)
+            torch.cuda.synchronize()
+            ctypes.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(ctypes.c_void_p(ptr), ctypes.c_void_p(t.data_ptr()),
+                                                                 ctypes.c_size_t(t.numel() * 2), 3)
+            torch.cuda.synchronize()
+
+    def forward(self, meta, is_prefill=False, stream=None, sync=True):
+        """meta: dict from oracle.ops.prepare_decode / prepare_prompt or BlockEngine.prepare_*  -> logits f32"""
+        dev = "cuda"
+        n = len(meta["context_lens"])
+        T = len(meta["input_ids"])
+        tok = torch.from_numpy(np.asarray(meta["input_ids"]).astype(np.int64).astype(np.int32)).to(dev)
+        pos = torch.from_numpy(np.asarray(meta["positions"]).astype(np.int64)).to(dev)
+        slots = torch.from_numpy(np.asarray(meta["slot_mapping"]).astype(np.int64)).to(dev)
+        bt = torch.from_numpy(np.asarray(meta["block_tables"]).astype(np.int64).astype(np.int32)).contiguous().to(dev)
+        ctx = torch.from_numpy(np.asarray(meta["context_lens"]).astype(np.int64).astype(np.int32)).to(dev)
+        cu = None
+        if is_prefill:
+            cu = torch.from_numpy(np.asarray(meta["cu_seqlens_q"]).astype(np.int64).astype(np.int32)).to(dev)
+        logits = torch.empty((n, self.cfg.vocab), dtype=torch.float32, device=dev)
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        _check(lib.mi355_dense_forward(self.h, tok.data_ptr(), pos.data_ptr(), slots.data_ptr(), bt.data_ptr(),
+                                       ctx.data_ptr(), cu.data_ptr() if cu is not None else None, n, T,
+                                       int(meta.get("max_seqlen_q", 0)), bt.shape[1], int(meta["max_context_len"]),
+                                       logits.data_ptr(), st), "dense_forward")
+        if sync:
+            torch.cuda.synchronize()
+        return logits
+
+    def forward_device(self, tok, pos, slots, bt, ctx, max_context_len, logits, stream):
+        """decode step over device tensors that stay resident (bench loop)"""
+        _check(lib.mi355_dense_forward(self.h, tok.data_ptr(), pos.data_ptr(), slots.data_ptr(), bt.data_ptr(),
+                                       ctx.data_ptr(), None, tok.shape[0], tok.shape[0], 0, bt.shape[1],
+                                       int(max_context_len), logits.data_ptr(), stream), "dense_forward")

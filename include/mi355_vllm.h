@@ -298,6 +298,36 @@ int mi355_llama_init_comm(void* model, const void* id128);
 int mi355_llama_run_part(void* model, int32_t layer, int32_t part, int64_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * 4b. Host layer for 16-bit safetensors llama-family models (Llama / Qwen2 shapes): src/openai/models/llama.rs:
+ *     39-201, layers/attention.rs:585-734, layers/mlp.rs:440-458.  Residual stream and every op result in the
+ *     model dtype, rounded where candle rounds.  Eager, single GPU.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mi355_dense_config {
+    int32_t hidden, n_layers, n_heads, n_kv_heads, head_dim, intermediate, vocab;
+    int32_t max_seq, block_size, kv_layout, max_batch, max_blocks_per_seq;
+    float rms_eps, rope_theta;
+    int32_t dtype;             /* MI355_DTYPE_BF16 */
+    int32_t rope_interleaved;  /* 0 = half-split ("neox", HF llama / qwen), 1 = interleaved */
+} mi355_dense_config;
+#define MI355_W_BQ 12 /* q_proj.bias (Qwen2) */
+#define MI355_W_BK 13
+#define MI355_W_BV 14
+void* mi355_dense_create(const mi355_dense_config* cfg);
+void mi355_dense_destroy(void* model);
+/* 16-bit tensor from the HOST in checkpoint layout [out, in]; slots MI355_W_* (W1 = gate_proj, W3 = up_proj are
+ * packed into one gate_up matrix as mlp.rs:324-352 does) */
+int mi355_dense_set_weight(void* model, int32_t layer, int32_t which, const void* host, int64_t n_elems);
+int mi355_dense_set_weight_dev(void* model, int32_t layer, int32_t which, const void* dev, int64_t n_elems);
+int mi355_dense_alloc_kv_cache(void* model, int32_t num_blocks);
+void* mi355_dense_kv_ptr(void* model, int32_t layer, int32_t which);
+/* one step: prompt when cu_seqlens_q != NULL (flattened tokens), else decode (num_tokens == num_seqs);
+ * DEVICE inputs as prepare_prompt / prepare_decode build them; logits f32 [num_seqs, vocab] */
+int mi355_dense_forward(void* model, const uint32_t* tokens, const int64_t* positions, const int64_t* slot_mapping,
+                        const uint32_t* block_tables, const uint32_t* context_lens, const uint32_t* cu_seqlens_q,
+                        int32_t num_seqs, int32_t num_tokens, int32_t max_seqlen_q, int32_t max_blocks,
+                        int32_t max_context_len, float* logits, int64_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * 5. Host block manager: BlockEngine + PrefixCache + Sequence bookkeeping + input preparation.
  *    Mirrors src/scheduler/block_engine.rs:190-1474, prefix_cache.rs:36-384, sequence.rs:90-300 and
  *    src/openai/pipelines/inputs.rs:90-230,376-454.  Pure host code (no device work).  A block is an int32

@@ -1,0 +1,113 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY) -- the 16-bit safetensors llama-family step restated in numpy with candle's
+rounding points: every op result is rounded to the model dtype (bf16).
+  Llama::forward_inner / Block::forward        src/openai/models/llama.rs:46-63,139-201
+  Attention::forward_ext                       src/openai/models/layers/attention.rs:585-734 (q,k -> f32 -> rope -> dtype)
+  Mlp::forward (packed gate_up)                src/openai/models/layers/mlp.rs:324-352,440-458
+  Linear::forward                              src/openai/models/linear.rs:124-172
+  Qwen2 qkv bias                               src/openai/models/qwen.rs
+PARITY UNPINNED (no reference fixtures exist for this path)."""
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import gptq as G
+from . import ops
+
+DT = "bf16"
+
+
+def R(a):
+    return G.round_dt(a, DT)
+
+
+@dataclass
+class DenseConfig:
+    hidden: int = 4096
+    n_layers: int = 32
+    n_heads: int = 32
+    n_kv_heads: int = 8
+    head_dim: int = 128
+    intermediate: int = 14336
+    vocab: int = 128256
+    rms_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    max_seq: int = 8192
+    block_size: int = 64
+    qkv_bias: bool = False
+
+    @staticmethod
+    def tiny(qkv_bias=False):
+        return DenseConfig(hidden=256, n_layers=2, n_heads=4, n_kv_heads=2, head_dim=64, intermediate=512, vocab=512,
+                           rope_theta=10000.0, max_seq=256, block_size=16, qkv_bias=qkv_bias)
+
+
+def make_weights(cfg, seed=4321, std=0.05):
+    rng = np.random.default_rng(seed)
+    H, Hkv, D, hid, I = cfg.n_heads, cfg.n_kv_heads, cfg.head_dim, cfg.hidden, cfg.intermediate
+
+    def w(*shape, s=std):
+        return R(rng.normal(0.0, s, size=shape).astype(np.float32))
+    W = {"tok_embd": w(cfg.vocab, hid, s=0.5), "layers": []}
+    for _ in range(cfg.n_layers):
+        lw = {"attn_norm": R(1.0 + rng.normal(0, 0.05, hid)), "ffn_norm": R(1.0 + rng.normal(0, 0.05, hid)),
+              "wq": w(H * D, hid), "wk": w(Hkv * D, hid), "wv": w(Hkv * D, hid), "wo": w(hid, H * D),
+              "w1": w(I, hid), "w3": w(I, hid), "w2": w(hid, I)}
+        if cfg.qkv_bias:
+            lw.update({"bq": w(H * D, s=0.1), "bk": w(Hkv * D, s=0.1), "bv": w(Hkv * D, s=0.1)})
+        W["layers"].append(lw)
+    W["output_norm"] = R(1.0 + rng.normal(0, 0.05, hid))
+    W["output"] = w(cfg.vocab, hid)
+    return W
+
+
+def rms_norm16(x, w, eps):
+    """candle rms_norm on 16-bit data: f32 internally, result rounded (layers/others.rs NormX)."""
+    x = np.asarray(x, np.float32)
+    inv = 1.0 / np.sqrt((x.astype(np.float64) ** 2).mean(-1, keepdims=True) + eps)
+    return R(x * inv * np.asarray(w, np.float32))
+
+
+class OracleDenseLlama:
+    def __init__(self, cfg, W, flash_layout=True):
+        self.cfg, self.W, self.flash = cfg, W, flash_layout
+        self.cos, self.sin = ops.rope_tables(cfg.rope_theta, cfg.head_dim, cfg.max_seq)
+        self.scale = 1.0 / np.sqrt(float(cfg.head_dim))
+
+    def new_cache(self, num_blocks):
+        c = self.cfg
+        ks, vs = ops.kv_cache_shapes(num_blocks, c.block_size, c.n_kv_heads, c.head_dim, 2, self.flash)
+        return [(np.zeros(ks, np.uint16), np.zeros(vs, np.uint16)) for _ in range(c.n_layers)]
+
+    def forward(self, meta, kv_caches, is_prefill=False):
+        c, W = self.cfg, self.W
+        toks, pos = meta["input_ids"], meta["positions"]
+        T = len(toks)
+        xs = W["tok_embd"][toks].astype(np.float32)
+        for l, lw in enumerate(W["layers"]):
+            x = rms_norm16(xs, lw["attn_norm"], c.rms_eps)
+            q = G.linear16(x, lw["wq"], lw.get("bq"), DT).reshape(T, c.n_heads, c.head_dim)
+            k = G.linear16(x, lw["wk"], lw.get("bk"), DT).reshape(T, c.n_kv_heads, c.head_dim)
+            v = G.linear16(x, lw["wv"], lw.get("bv"), DT).reshape(T, c.n_kv_heads, c.head_dim)
+            q = R(ops.rope_apply(q, self.cos, self.sin, pos, interleaved=False))     # f32 rope, back to dtype
+            k = R(ops.rope_apply(k, self.cos, self.sin, pos, interleaved=False))
+            kb, vb = ops.f32_to_bf16_bits(k), ops.f32_to_bf16_bits(v)
+            kc, vc = kv_caches[l]
+            ops.reshape_and_cache(kb, vb, kc, vc, meta["slot_mapping"], self.flash)
+            if is_prefill:
+                ys, cu = [], meta["cu_seqlens_q"]
+                for i in range(len(cu) - 1):
+                    a, b = int(cu[i]), int(cu[i + 1])
+                    ys.append(ops.prefill_attention(q[a:b], k[a:b], v[a:b], self.scale))
+                y = np.concatenate(ys, 0)
+            else:
+                y = ops.paged_attention_decode(q, kc, vc, meta["block_tables"], meta["context_lens"], self.scale, self.flash)
+            y = y.reshape(T, c.n_heads * c.head_dim)
+            xs = R(G.linear16(y, lw["wo"], None, DT) + xs)
+            x = rms_norm16(xs, lw["ffn_norm"], c.rms_eps)
+            gate, up = G.linear16(x, lw["w1"], None, DT), G.linear16(x, lw["w3"], None, DT)
+            h = G.silu_mul16(gate, up, DT)
+            xs = R(G.linear16(h, lw["w2"], None, DT) + xs)
+        if is_prefill:
+            xs = xs[np.asarray(meta["cu_seqlens_q"][1:], np.int64) - 1]
+        xs = rms_norm16(xs, W["output_norm"], c.rms_eps)
+        return G.linear16(xs, W["output"], None, DT).astype(np.float32)
