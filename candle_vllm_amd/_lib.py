@@ -185,9 +185,11 @@ class DenseConfig(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("hidden", "n_layers", "n_heads", "n_kv_heads", "head_dim", "intermediate",
                                      "vocab", "max_seq", "block_size", "kv_layout", "max_batch",
                                      "max_blocks_per_seq")] + \
-               [("rms_eps", c_f32), ("rope_theta", c_f32), ("dtype", c_i32), ("rope_interleaved", c_i32)]
+               [("rms_eps", c_f32), ("rope_theta", c_f32), ("dtype", c_i32), ("rope_interleaved", c_i32),
+                ("norm_type", c_i32), ("rotary_dim", c_i32)]
 
 
+_sig("mi355_layer_norm", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_i64])
 _sig("mi355_dense_create", c_vp, [ctypes.POINTER(DenseConfig)])
 _sig("mi355_dense_destroy", None, [c_vp])
 _sig("mi355_dense_set_weight", ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_i64])

@@ -21,13 +21,13 @@ namespace {
 struct DLayer {
     uint16_t *wq = nullptr, *wk = nullptr, *wv = nullptr, *wo = nullptr, *gate_up = nullptr, *w2 = nullptr;
     uint16_t *bq = nullptr, *bk = nullptr, *bv = nullptr;
-    uint16_t *attn_norm = nullptr, *ffn_norm = nullptr;
+    uint16_t *attn_norm = nullptr, *ffn_norm = nullptr, *attn_norm_b = nullptr, *ffn_norm_b = nullptr;
 };
 
 struct DModel {
     mi355_dense_config cfg{};
     std::vector<DLayer> layers;
-    uint16_t *tok_embd = nullptr, *output_norm = nullptr, *output = nullptr;
+    uint16_t *tok_embd = nullptr, *output_norm = nullptr, *output_norm_b = nullptr, *output = nullptr;
     float *cos_t = nullptr, *sin_t = nullptr;
     // activations (grow-only, T rows)
     int cap = 0;
@@ -70,6 +70,13 @@ int ensure_cap(DModel* m, int T) {
     return 0;
 }
 
+// NormX::forward (layers/others.rs:11-34): RMSNorm, or LayerNorm for StableLM
+int norm(const DModel* m, uint16_t* out, const uint16_t* x, const uint16_t* w, const uint16_t* b, int T, int64_t stream) {
+    const mi355_dense_config& c = m->cfg;
+    if (c.norm_type == 1) return mi355_layer_norm(out, x, w, b, T, c.hidden, c.rms_eps, c.dtype, stream);
+    return mi355_rms_norm(out, x, w, T, c.hidden, c.rms_eps, c.dtype, c.dtype, stream);
+}
+
 int choose_partition(int batch, int kv_heads, int ctx_cap) {
     if (ctx_cap <= 256) return 0;
     int per_seq = (2048 + batch * kv_heads - 1) / (batch * kv_heads);
@@ -92,10 +99,11 @@ void* mi355_dense_create(const mi355_dense_config* cfg) {
     DModel* m = new DModel();
     m->cfg = *cfg;
     m->layers.resize(cfg->n_layers);
-    const int D = cfg->head_dim, half = D / 2;
+    if (m->cfg.rotary_dim <= 0 || m->cfg.rotary_dim > cfg->head_dim) m->cfg.rotary_dim = cfg->head_dim;
+    const int D = cfg->head_dim, rot = m->cfg.rotary_dim, half = rot / 2;
     std::vector<float> ct((size_t)cfg->max_seq * half), st((size_t)cfg->max_seq * half);
-    for (int i = 0; i < half; ++i) {                          // rotary_emb.rs:14-48
-        const float inv = (float)(1.0 / pow((double)cfg->rope_theta, (double)(2 * i) / (double)D));
+    for (int i = 0; i < half; ++i) {                          // rotary_emb.rs:14-48 (dim = rotary_dim)
+        const float inv = (float)(1.0 / pow((double)cfg->rope_theta, (double)(2 * i) / (double)rot));
         for (int p = 0; p < cfg->max_seq; ++p) {
             const float th = (float)p * inv;
             ct[(size_t)p * half + i] = (float)cos((double)th);
@@ -118,10 +126,10 @@ void mi355_dense_destroy(void* mp) {
     DModel* m = static_cast<DModel*>(mp);
     if (!m) return;
     for (auto& L : m->layers) {
-        void* ps[] = {L.wq, L.wk, L.wv, L.wo, L.gate_up, L.w2, L.bq, L.bk, L.bv, L.attn_norm, L.ffn_norm};
+        void* ps[] = {L.wq, L.wk, L.wv, L.wo, L.gate_up, L.w2, L.bq, L.bk, L.bv, L.attn_norm, L.ffn_norm, L.attn_norm_b, L.ffn_norm_b};
         for (void* p : ps) if (p) (void)hipFree(p);
     }
-    void* ps[] = {m->tok_embd, m->output_norm, m->output, m->cos_t, m->sin_t, m->xs, m->xn, m->q, m->k, m->v, m->attn,
+    void* ps[] = {m->tok_embd, m->output_norm, m->output_norm_b, m->output, m->cos_t, m->sin_t, m->xs, m->xn, m->q, m->k, m->v, m->attn,
                   m->h, m->lg16, m->pa_tmp, m->pa_max, m->pa_sum, m->kv_slab};
     for (void* p : ps) if (p) (void)hipFree(p);
     delete m;
@@ -148,6 +156,7 @@ static int dense_set_weight_impl(void* mp, int32_t layer, int32_t which, const v
         if (which == MI355_W_TOK_EMBD) { slot = &m->tok_embd; expect = (int64_t)c.vocab * hid; }
         else if (which == MI355_W_OUTPUT_NORM) { slot = &m->output_norm; expect = hid; }
         else if (which == MI355_W_OUTPUT) { slot = &m->output; expect = (int64_t)c.vocab * hid; }
+        else if (which == MI355_W_OUTPUT_NORM_B) { slot = &m->output_norm_b; expect = hid; }
         else return (int)hipErrorInvalidValue;
     } else {
         if (layer >= c.n_layers) return (int)hipErrorInvalidValue;
@@ -165,6 +174,8 @@ static int dense_set_weight_impl(void* mp, int32_t layer, int32_t which, const v
             case MI355_W_BQ: slot = &L.bq; expect = HD; break;
             case MI355_W_BK: slot = &L.bk; expect = KD; break;
             case MI355_W_BV: slot = &L.bv; expect = KD; break;
+            case MI355_W_ATTN_NORM_B: slot = &L.attn_norm_b; expect = hid; break;
+            case MI355_W_FFN_NORM_B: slot = &L.ffn_norm_b; expect = hid; break;
             default: return (int)hipErrorInvalidValue;
         }
     }
@@ -220,13 +231,13 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
         DLayer& L = m->layers[l];
         if (!L.wq || !L.wk || !L.wv || !L.wo || !L.gate_up || !L.w2 || !L.attn_norm || !L.ffn_norm) return (int)hipErrorInvalidValue;
         // x = rms_1(xs)                                                     llama.rs:53-54
-        DCHECK(mi355_rms_norm(m->xn, m->xs, L.attn_norm, T, hid, c.rms_eps, dt, dt, stream));
+        DCHECK(norm(m, m->xn, m->xs, L.attn_norm, L.attn_norm_b, T, stream));
         // q,k,v projections (+bias)                                          attention.rs:597-607
         DCHECK(mi355_linear(m->q, m->xn, L.wq, L.bq, nullptr, T, H * D, hid, dt, MI355_EPI_STORE, stream));
         DCHECK(mi355_linear(m->k, m->xn, L.wk, L.bk, nullptr, T, Hkv * D, hid, dt, MI355_EPI_STORE, stream));
         DCHECK(mi355_linear(m->v, m->xn, L.wv, L.bv, nullptr, T, Hkv * D, hid, dt, MI355_EPI_STORE, stream));
         // q,k -> f32 -> rope -> model dtype                                  attention.rs:644-690
-        DCHECK(mi355_rope_inplace(m->q, m->k, m->cos_t, m->sin_t, positions, T, H, Hkv, D, D, c.rope_interleaved, dt, stream));
+        DCHECK(mi355_rope_inplace(m->q, m->k, m->cos_t, m->sin_t, positions, T, H, Hkv, D, c.rotary_dim, c.rope_interleaved, dt, stream));
         // PagedAttention::forward: cache write, then prefill / decode attention   attention.rs:707-719
         DCHECK(mi355_reshape_and_cache(m->k, m->v, m->kcache[l], m->vcache[l], slot_mapping, T, Hkv, D, c.block_size, 2,
                                        c.kv_layout, stream));
@@ -249,7 +260,7 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
         // xs = o_proj(y) + residual                                          llama.rs:55-58
         DCHECK(mi355_linear(m->xs, m->attn, L.wo, nullptr, m->xs, T, hid, H * D, dt, MI355_EPI_RESID, stream));
         // xs = down(silu(gate) * up) + residual                              llama.rs:59-61, mlp.rs:440-458
-        DCHECK(mi355_rms_norm(m->xn, m->xs, L.ffn_norm, T, hid, c.rms_eps, dt, dt, stream));
+        DCHECK(norm(m, m->xn, m->xs, L.ffn_norm, L.ffn_norm_b, T, stream));
         DCHECK(mi355_linear(m->h, m->xn, L.gate_up, nullptr, nullptr, T, 2 * I, hid, dt, MI355_EPI_SILU_MUL, stream));
         DCHECK(mi355_linear(m->xs, m->h, L.w2, nullptr, m->xs, T, hid, I, dt, MI355_EPI_RESID, stream));
     }
@@ -259,7 +270,7 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
         DHIP(hipMemcpyAsync(m->xs, m->xn, (size_t)num_seqs * hid * 2, hipMemcpyDeviceToDevice, st));
         last = m->xs;
     }
-    DCHECK(mi355_rms_norm(m->xn, last, m->output_norm, num_seqs, hid, c.rms_eps, dt, dt, stream));
+    DCHECK(norm(m, m->xn, last, m->output_norm, m->output_norm_b, num_seqs, stream));
     DCHECK(mi355_linear(m->lg16, m->xn, m->output, nullptr, nullptr, num_seqs, c.vocab, hid, dt, MI355_EPI_STORE, stream));
     return mi355_cast(logits, m->lg16, (int64_t)num_seqs * c.vocab, dt, MI355_DTYPE_F32, stream);
 }

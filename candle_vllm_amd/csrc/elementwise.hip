@@ -65,6 +65,43 @@ extern "C" int mi355_rms_norm(void* out, const void* x, const void* w, int32_t n
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// candle_nn::LayerNorm (StableLM: src/openai/models/stable_lm.rs:61-72) on 16-bit data: statistics and the affine
+// in f32, one rounding at the end (the fused candle_nn::ops::layer_norm path for contiguous inputs [EXT]).
+template <typename T>
+__global__ void __launch_bounds__(256) layer_norm_kernel(T* __restrict__ out, const T* __restrict__ x, const T* __restrict__ w,
+                                                         const T* __restrict__ b, int hidden, float eps) {
+    __shared__ float red[16];
+    const int64_t row = blockIdx.x;
+    const T* xr = x + row * hidden;
+    T* orow = out + row * hidden;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < hidden; i += blockDim.x) s += ld_as_f32<T>(xr, i);
+    const float mean = block_sum(s, red) / (float)hidden;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < hidden; i += blockDim.x) { const float d = ld_as_f32<T>(xr, i) - mean; ss += d * d; }
+    const float inv = rsqrtf(block_sum(ss, red) / (float)hidden + eps);
+    for (int i = threadIdx.x; i < hidden; i += blockDim.x) {
+        float v = (ld_as_f32<T>(xr, i) - mean) * inv * ld_as_f32<T>(w, i);
+        if (b) v += ld_as_f32<T>(b, i);
+        st_from_f32<T>(orow, i, v);
+    }
+}
+extern "C" int mi355_layer_norm(void* out, const void* x, const void* w, const void* b, int32_t num_tokens, int32_t hidden,
+                                float eps, int32_t dtype, int64_t stream) {
+    if (num_tokens <= 0) return 0;
+    hipStream_t st = to_stream(stream);
+    if (dtype == MI355_DTYPE_BF16)
+        hipLaunchKernelGGL((layer_norm_kernel<uint16_t>), dim3(num_tokens), dim3(256), 0, st, (uint16_t*)out, (const uint16_t*)x,
+                           (const uint16_t*)w, (const uint16_t*)b, hidden, eps);
+    else if (dtype == MI355_DTYPE_F32)
+        hipLaunchKernelGGL((layer_norm_kernel<float>), dim3(num_tokens), dim3(256), 0, st, (float*)out, (const float*)x,
+                           (const float*)w, (const float*)b, hidden, eps);
+    else
+        return (int)hipErrorInvalidValue;
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ RoPE (in place)
 // q [T, H, D], k [T, Hkv, D]; cos/sin f32 [max_seq, rot/2]; positions i64 [T].
 // is_rope_i != 0: interleaved pairs (x[2i], x[2i+1])  (GGUF llama);  else half-split (x[i], x[i+rot/2]).

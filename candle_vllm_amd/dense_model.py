@@ -9,7 +9,8 @@ from ._lib import lib, DenseConfig
 from .ops import _check, KV_FLASH, KV_PAGED  # noqa: F401
 
 W_SLOTS = {"wq": 0, "wk": 1, "wv": 2, "wo": 3, "w1": 4, "w2": 5, "w3": 6, "attn_norm": 7, "ffn_norm": 8,
-           "tok_embd": 9, "output_norm": 10, "output": 11, "bq": 12, "bk": 13, "bv": 14}
+           "tok_embd": 9, "output_norm": 10, "output": 11, "bq": 12, "bk": 13, "bv": 14,
+           "attn_norm_b": 15, "ffn_norm_b": 16, "output_norm_b": 17}
 DT_BF16 = 2
 
 
@@ -25,7 +26,9 @@ class DenseLlama:
                         head_dim=cfg.head_dim, intermediate=cfg.intermediate, vocab=cfg.vocab, max_seq=cfg.max_seq,
                         block_size=cfg.block_size, kv_layout=kv_layout, max_batch=max_batch,
                         max_blocks_per_seq=max_blocks_per_seq, rms_eps=cfg.rms_eps, rope_theta=cfg.rope_theta,
-                        dtype=DT_BF16, rope_interleaved=int(rope_interleaved))
+                        dtype=DT_BF16, rope_interleaved=int(rope_interleaved),
+                        norm_type=1 if getattr(cfg, "layer_norm", False) else 0,
+                        rotary_dim=int(getattr(cfg, "rotary_dim", 0) or 0))
         self.h = lib.mi355_dense_create(ctypes.byref(c))
         if not self.h:
             raise RuntimeError("mi355_dense_create failed (bad config or no GPU memory)")
@@ -41,8 +44,9 @@ class DenseLlama:
         _check(lib.mi355_dense_set_weight(self.h, layer, W_SLOTS[name], bits.ctypes.data, bits.size), f"set_weight {name}")
 
     def load_oracle_weights(self, W):
-        for name in ("tok_embd", "output_norm", "output"):
-            self.set_weight(-1, name, W[name])
+        for name in ("tok_embd", "output_norm", "output", "output_norm_b"):
+            if name in W:
+                self.set_weight(-1, name, W[name])
         for l, lw in enumerate(W["layers"]):
             for name, v in lw.items():
                 self.set_weight(l, name, v)

@@ -126,6 +126,9 @@ int mi355_rms_norm(void* out, const void* x, const void* weight, int32_t num_tok
                    float eps, int32_t dtype, int32_t weight_dtype, int64_t stream);
 /* candle_nn::ops::silu(gate) * up -- quantized_llama.rs:33-37 */
 int mi355_silu_mul(void* out, const void* gate, const void* up, int64_t n, int32_t dtype, int64_t stream);
+/* candle_nn::LayerNorm with bias (StableLM, stable_lm.rs:61-72): f32 statistics, one rounding; dtype BF16 / F32 */
+int mi355_layer_norm(void* out, const void* x, const void* w, const void* b, int32_t num_tokens, int32_t hidden,
+                     float eps, int32_t dtype, int64_t stream);
 /* residual add (quantized_llama.rs:464,470) */
 int mi355_add_f32(float* out, const float* a, const float* b, int64_t n, int64_t stream);
 /* Tensor::to_dtype between F32 and BF16 (attention.rs:977-981, 1004) */
@@ -307,11 +310,16 @@ typedef struct mi355_dense_config {
     int32_t max_seq, block_size, kv_layout, max_batch, max_blocks_per_seq;
     float rms_eps, rope_theta;
     int32_t dtype;             /* MI355_DTYPE_BF16 */
-    int32_t rope_interleaved;  /* 0 = half-split ("neox", HF llama / qwen), 1 = interleaved */
+    int32_t rope_interleaved;  /* 0 = half-split ("neox", HF llama / qwen / stablelm), 1 = interleaved */
+    int32_t norm_type;         /* 0 = RMSNorm, 1 = LayerNorm with bias (StableLM, stable_lm.rs:61-72) */
+    int32_t rotary_dim;        /* <= head_dim; StableLM: partial_rotary_factor 0.25 (stable_lm.rs:28); 0 = head_dim */
 } mi355_dense_config;
-#define MI355_W_BQ 12 /* q_proj.bias (Qwen2) */
+#define MI355_W_BQ 12 /* q_proj.bias (Qwen2, StableLM use_qkv_bias) */
 #define MI355_W_BK 13
 #define MI355_W_BV 14
+#define MI355_W_ATTN_NORM_B 15   /* LayerNorm biases */
+#define MI355_W_FFN_NORM_B 16
+#define MI355_W_OUTPUT_NORM_B 17 /* layer = -1 */
 void* mi355_dense_create(const mi355_dense_config* cfg);
 void mi355_dense_destroy(void* model);
 /* 16-bit tensor from the HOST in checkpoint layout [out, in]; slots MI355_W_* (W1 = gate_proj, W3 = up_proj are

@@ -34,6 +34,20 @@ class DenseConfig:
     max_seq: int = 8192
     block_size: int = 64
     qkv_bias: bool = False
+    layer_norm: bool = False        # StableLM: LayerNorm with bias (stable_lm.rs:61-72)
+    rotary_dim: int = 0             # 0 = head_dim; StableLM: 0.25 * head_dim (stable_lm.rs:28)
+
+    @staticmethod
+    def stablelm_3b():
+        """BASELINE configs[0] shapes: StableLM-3B-4e1t"""
+        return DenseConfig(hidden=2560, n_layers=32, n_heads=32, n_kv_heads=32, head_dim=80, intermediate=6912,
+                           vocab=50304, rms_eps=1e-5, rope_theta=10000.0, max_seq=4096, block_size=64,
+                           layer_norm=True, rotary_dim=20)
+
+    @staticmethod
+    def tiny_stablelm():
+        return DenseConfig(hidden=1280, n_layers=2, n_heads=16, n_kv_heads=16, head_dim=80, intermediate=512, vocab=512,
+                           rope_theta=10000.0, max_seq=256, block_size=16, qkv_bias=True, layer_norm=True, rotary_dim=20)
 
     @staticmethod
     def tiny(qkv_bias=False):
@@ -54,7 +68,11 @@ def make_weights(cfg, seed=4321, std=0.05):
               "w1": w(I, hid), "w3": w(I, hid), "w2": w(hid, I)}
         if cfg.qkv_bias:
             lw.update({"bq": w(H * D, s=0.1), "bk": w(Hkv * D, s=0.1), "bv": w(Hkv * D, s=0.1)})
+        if cfg.layer_norm:
+            lw.update({"attn_norm_b": w(hid, s=0.05), "ffn_norm_b": w(hid, s=0.05)})
         W["layers"].append(lw)
+    if cfg.layer_norm:
+        W["output_norm_b"] = w(hid, s=0.05)
     W["output_norm"] = R(1.0 + rng.normal(0, 0.05, hid))
     W["output"] = w(cfg.vocab, hid)
     return W
@@ -67,11 +85,28 @@ def rms_norm16(x, w, eps):
     return R(x * inv * np.asarray(w, np.float32))
 
 
+def layer_norm16(x, w, b, eps):
+    """candle_nn LayerNorm on 16-bit data: f32 statistics and affine, one rounding [EXT fused path]."""
+    x = np.asarray(x, np.float64)
+    mu = x.mean(-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(-1, keepdims=True)
+    y = (x - mu) / np.sqrt(var + eps) * np.asarray(w, np.float64)
+    if b is not None:
+        y = y + np.asarray(b, np.float64)
+    return R(y.astype(np.float32))
+
+
 class OracleDenseLlama:
     def __init__(self, cfg, W, flash_layout=True):
         self.cfg, self.W, self.flash = cfg, W, flash_layout
-        self.cos, self.sin = ops.rope_tables(cfg.rope_theta, cfg.head_dim, cfg.max_seq)
+        self.rot = cfg.rotary_dim or cfg.head_dim
+        self.cos, self.sin = ops.rope_tables(cfg.rope_theta, self.rot, cfg.max_seq)
         self.scale = 1.0 / np.sqrt(float(cfg.head_dim))
+
+    def _norm(self, x, w, b):
+        if self.cfg.layer_norm:
+            return layer_norm16(x, w, b, self.cfg.rms_eps)
+        return rms_norm16(x, w, self.cfg.rms_eps)
 
     def new_cache(self, num_blocks):
         c = self.cfg
@@ -84,12 +119,12 @@ class OracleDenseLlama:
         T = len(toks)
         xs = W["tok_embd"][toks].astype(np.float32)
         for l, lw in enumerate(W["layers"]):
-            x = rms_norm16(xs, lw["attn_norm"], c.rms_eps)
+            x = self._norm(xs, lw["attn_norm"], lw.get("attn_norm_b"))
             q = G.linear16(x, lw["wq"], lw.get("bq"), DT).reshape(T, c.n_heads, c.head_dim)
             k = G.linear16(x, lw["wk"], lw.get("bk"), DT).reshape(T, c.n_kv_heads, c.head_dim)
             v = G.linear16(x, lw["wv"], lw.get("bv"), DT).reshape(T, c.n_kv_heads, c.head_dim)
-            q = R(ops.rope_apply(q, self.cos, self.sin, pos, interleaved=False))     # f32 rope, back to dtype
-            k = R(ops.rope_apply(k, self.cos, self.sin, pos, interleaved=False))
+            q = R(ops.rope_apply(q, self.cos, self.sin, pos, interleaved=False, rotary_dim=self.rot))   # f32 rope, back to dtype
+            k = R(ops.rope_apply(k, self.cos, self.sin, pos, interleaved=False, rotary_dim=self.rot))
             kb, vb = ops.f32_to_bf16_bits(k), ops.f32_to_bf16_bits(v)
             kc, vc = kv_caches[l]
             ops.reshape_and_cache(kb, vb, kc, vc, meta["slot_mapping"], self.flash)
@@ -103,11 +138,11 @@ class OracleDenseLlama:
                 y = ops.paged_attention_decode(q, kc, vc, meta["block_tables"], meta["context_lens"], self.scale, self.flash)
             y = y.reshape(T, c.n_heads * c.head_dim)
             xs = R(G.linear16(y, lw["wo"], None, DT) + xs)
-            x = rms_norm16(xs, lw["ffn_norm"], c.rms_eps)
+            x = self._norm(xs, lw["ffn_norm"], lw.get("ffn_norm_b"))
             gate, up = G.linear16(x, lw["w1"], None, DT), G.linear16(x, lw["w3"], None, DT)
             h = G.silu_mul16(gate, up, DT)
             xs = R(G.linear16(h, lw["w2"], None, DT) + xs)
         if is_prefill:
             xs = xs[np.asarray(meta["cu_seqlens_q"][1:], np.int64) - 1]
-        xs = rms_norm16(xs, W["output_norm"], c.rms_eps)
+        xs = self._norm(xs, W["output_norm"], W.get("output_norm_b"))
         return G.linear16(xs, W["output"], None, DT).astype(np.float32)

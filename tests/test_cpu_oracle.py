@@ -271,3 +271,29 @@ def test_c_oracle_decode_step_matches_numpy_llama():
     # candle-CPU-faithful arithmetic (Q8_K activations) stays within ~a few % of the exact-dequant logits
     got2 = cref.CLlama(cfg, W).decode(meta, [(k.copy(), v.copy()) for k, v in c_cache], o2=True)
     assert np.abs(got2 - ref).max() < 0.1 * np.abs(ref).max()
+
+
+def test_stablelm_oracle_plumbing_decode_equals_prefill():
+    """BASELINE configs[0] (StableLM-3B bf16, CPU plumbing): the numpy restatement with LayerNorm + bias, head_dim 80,
+    partial rotary (20 of 80 channels) and qkv bias runs a prompt step and greedy decode steps; a decode step equals
+    the last row of the prompt step over the same tokens (cache write / gather / rotary positions are consistent)."""
+    from oracle import dense_llama as DL
+    from oracle import ops as O
+    cfg = DL.DenseConfig.tiny_stablelm()
+    full = DL.DenseConfig.stablelm_3b()
+    assert (full.hidden, full.n_heads * full.head_dim, full.rotary_dim, full.intermediate) == (2560, 2560, 20, 6912)
+    W = DL.make_weights(cfg)
+    m = DL.OracleDenseLlama(cfg, W)
+    rng = np.random.default_rng(0)
+    seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 19)], "block_table": [3, 7]},
+            {"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 5)], "block_table": [1]}]
+    cache = m.new_cache(16)
+    lg = m.forward(O.prepare_prompt(seqs, cfg.block_size), cache, is_prefill=True)
+    assert lg.shape == (2, cfg.vocab) and np.isfinite(lg).all()
+    for _ in range(2):
+        for s, row in zip(seqs, lg):
+            s["tokens"].append(int(row.argmax()))
+        lg = m.forward(O.prepare_decode(seqs, cfg.block_size), cache)
+    fresh = m.new_cache(16)
+    again = m.forward(O.prepare_prompt(seqs, cfg.block_size), fresh, is_prefill=True)
+    assert np.array_equal(again, lg)

@@ -73,3 +73,35 @@ def test_dense_llama_decode_from_oracle_cache_is_tight(lib):
     got = gm.forward(dmeta).cpu().numpy()
     assert _rel(got, ref) < 1.5e-2, _rel(got, ref)
     assert [int(r.argmax()) for r in got] == [int(r.argmax()) for r in ref]
+
+
+@pytest.mark.parametrize("flash", [True, False])
+def test_stablelm_shape_prompt_then_decode(lib, flash):
+    """BASELINE configs[0] plumbing on the GPU: LayerNorm + bias, head_dim 80, partial rotary 25 % (rot dim 20),
+    qkv bias (stable_lm.rs:28,61-72) -- generic attention kernels for the odd head size."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from candle_vllm_amd import dense_model as M
+    cfg = DL.DenseConfig.tiny_stablelm()
+    W = DL.make_weights(cfg)
+    orc = DL.OracleDenseLlama(cfg, W, flash_layout=flash)
+    rng = np.random.default_rng(8)
+    seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 23)], "block_table": [3, 7]},
+            {"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 6)], "block_table": [1]}]
+    cache = orc.new_cache(16)
+    meta = O.prepare_prompt(seqs, cfg.block_size)
+    ref = orc.forward(meta, cache, is_prefill=True)
+    gm = M.DenseLlama(cfg, max_batch=4, kv_layout=M.KV_FLASH if flash else M.KV_PAGED)
+    gm.load_oracle_weights(W)
+    gm.alloc_kv_cache(16)
+    got = gm.forward(meta, is_prefill=True).cpu().numpy()
+    assert _rel(got, ref) < 2e-2, _rel(got, ref)
+    assert [int(r.argmax()) for r in got] == [int(r.argmax()) for r in ref]
+    for step in range(2):
+        for s, row in zip(seqs, ref):
+            s["tokens"].append(int(row.argmax()))
+        dmeta = O.prepare_decode(seqs, cfg.block_size)
+        ref = orc.forward(dmeta, cache)
+        got = gm.forward(dmeta).cpu().numpy()
+        assert _rel(got, ref) < 2e-2, (step, _rel(got, ref))
+        assert [int(r.argmax()) for r in got] == [int(r.argmax()) for r in ref]
