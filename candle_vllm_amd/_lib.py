@@ -194,6 +194,7 @@ _sig("mi355_dense_create", c_vp, [ctypes.POINTER(DenseConfig)])
 _sig("mi355_dense_destroy", None, [c_vp])
 _sig("mi355_dense_set_weight", ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_i64])
 _sig("mi355_dense_set_weight_dev", ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_i64])
+_sig("mi355_dense_set_gptq", ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32])
 _sig("mi355_dense_alloc_kv_cache", ctypes.c_int, [c_vp, c_i32])
 _sig("mi355_dense_kv_ptr", c_vp, [c_vp, c_i32, c_i32])
 _sig("mi355_dense_forward", ctypes.c_int, [c_vp] * 7 + [c_i32] * 5 + [c_vp, c_i64])

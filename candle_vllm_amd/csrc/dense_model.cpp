@@ -18,8 +18,13 @@ namespace {
 #define DCHECK(expr) do { const int rc_ = (expr); if (rc_ != 0) return rc_; } while (0)
 #define DHIP(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
 
+// GPTQ (4-bit, symmetric, group scales) variant of a projection: qweight [K/8, N] u32 + scales [K/g, N] 16-bit, both in
+// checkpoint layout (linear.rs:226-252); gate and up are concatenated along N for the fused silu*up epilogue.
+struct QLin { uint32_t* qw = nullptr; uint16_t* scales = nullptr; int group = 0; };
+
 struct DLayer {
     uint16_t *wq = nullptr, *wk = nullptr, *wv = nullptr, *wo = nullptr, *gate_up = nullptr, *w2 = nullptr;
+    QLin gq[7];                // indexed by MI355_W_WQ .. MI355_W_W3 (W1 holds the packed gate_up, W3 unused)
     uint16_t *bq = nullptr, *bk = nullptr, *bv = nullptr;
     uint16_t *attn_norm = nullptr, *ffn_norm = nullptr, *attn_norm_b = nullptr, *ffn_norm_b = nullptr;
 };
@@ -77,6 +82,15 @@ int norm(const DModel* m, uint16_t* out, const uint16_t* x, const uint16_t* w, c
     return mi355_rms_norm(out, x, w, T, c.hidden, c.rms_eps, c.dtype, c.dtype, stream);
 }
 
+// Linear::forward or the QLinear GPTQ arm (linear.rs:124-172 / 854-906), same fused epilogues
+int linear(const DModel* m, const uint16_t* w, const QLin& g, void* out, const void* x, const void* bias, const void* resid,
+           int T, int n, int k, int epi, int64_t stream) {
+    if (g.qw)
+        return mi355_gptq_linear(out, x, g.qw, g.scales, nullptr, MI355_ZERO_SYM8, 0, bias, resid, T, n, k, g.group, m->cfg.dtype, epi, stream);
+    if (!w) return (int)hipErrorInvalidValue;
+    return mi355_linear(out, x, w, bias, resid, T, n, k, m->cfg.dtype, epi, stream);
+}
+
 int choose_partition(int batch, int kv_heads, int ctx_cap) {
     if (ctx_cap <= 256) return 0;
     int per_seq = (2048 + batch * kv_heads - 1) / (batch * kv_heads);
@@ -128,6 +142,7 @@ void mi355_dense_destroy(void* mp) {
     for (auto& L : m->layers) {
         void* ps[] = {L.wq, L.wk, L.wv, L.wo, L.gate_up, L.w2, L.bq, L.bk, L.bv, L.attn_norm, L.ffn_norm, L.attn_norm_b, L.ffn_norm_b};
         for (void* p : ps) if (p) (void)hipFree(p);
+        for (auto& g : L.gq) { if (g.qw) (void)hipFree(g.qw); if (g.scales) (void)hipFree(g.scales); }
     }
     void* ps[] = {m->tok_embd, m->output_norm, m->output_norm_b, m->output, m->cos_t, m->sin_t, m->xs, m->xn, m->q, m->k, m->v, m->attn,
                   m->h, m->lg16, m->pa_tmp, m->pa_max, m->pa_sum, m->kv_slab};
@@ -186,6 +201,29 @@ static int dense_set_weight_impl(void* mp, int32_t layer, int32_t which, const v
     return 0;
 }
 
+/* GPTQ projection from HOST checkpoint tensors: qweight u32 [k/8, n], scales 16-bit [k/g, n] (natural order, sym
+ * 4-bit, no act-order: the Marlin-eligible case of linear.rs:319-325).  gate_proj (W1) and up_proj (W3) are
+ * concatenated along n so the silu*up epilogue stays fused. */
+int mi355_dense_set_gptq(void* mp, int32_t layer, int32_t which, const void* qweight_host, const void* scales_host,
+                         int32_t n, int32_t k, int32_t group_size) {
+    DModel* m = static_cast<DModel*>(mp);
+    if (!m || layer < 0 || layer >= m->cfg.n_layers || !qweight_host || !scales_host) return (int)hipErrorInvalidValue;
+    if (which < MI355_W_WQ || which > MI355_W_W3 || (k % 256) || (n % 16)) return (int)hipErrorInvalidValue;
+    const int g = (group_size <= 0 || group_size > k) ? k : group_size;
+    const int I = m->cfg.intermediate;
+    const bool gu = which == MI355_W_W1 || which == MI355_W_W3;
+    QLin& q = m->layers[layer].gq[gu ? MI355_W_W1 : which];
+    const int ntot = gu ? 2 * I : n, col0 = which == MI355_W_W3 ? I : 0;
+    if (gu && n != I) return (int)hipErrorInvalidValue;
+    if (q.group && q.group != g) return (int)hipErrorInvalidValue;
+    q.group = g;
+    if (!q.qw) DHIP(hipMalloc((void**)&q.qw, (size_t)(k / 8) * ntot * 4));
+    if (!q.scales) DHIP(hipMalloc((void**)&q.scales, (size_t)(k / g) * ntot * 2));
+    DHIP(hipMemcpy2D(q.qw + col0, (size_t)ntot * 4, qweight_host, (size_t)n * 4, (size_t)n * 4, k / 8, hipMemcpyHostToDevice));
+    DHIP(hipMemcpy2D(q.scales + col0, (size_t)ntot * 2, scales_host, (size_t)n * 2, (size_t)n * 2, k / g, hipMemcpyHostToDevice));
+    return 0;
+}
+
 int mi355_dense_alloc_kv_cache(void* mp, int32_t num_blocks) {
     DModel* m = static_cast<DModel*>(mp);
     if (!m || num_blocks <= 0) return (int)hipErrorInvalidValue;
@@ -229,13 +267,13 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
     hipLaunchKernelGGL(embedding16_kernel, dim3(T), dim3(256), 0, st, m->xs, m->tok_embd, tokens, hid);
     for (int l = 0; l < c.n_layers; ++l) {
         DLayer& L = m->layers[l];
-        if (!L.wq || !L.wk || !L.wv || !L.wo || !L.gate_up || !L.w2 || !L.attn_norm || !L.ffn_norm) return (int)hipErrorInvalidValue;
+        if (!L.attn_norm || !L.ffn_norm) return (int)hipErrorInvalidValue;
         // x = rms_1(xs)                                                     llama.rs:53-54
         DCHECK(norm(m, m->xn, m->xs, L.attn_norm, L.attn_norm_b, T, stream));
         // q,k,v projections (+bias)                                          attention.rs:597-607
-        DCHECK(mi355_linear(m->q, m->xn, L.wq, L.bq, nullptr, T, H * D, hid, dt, MI355_EPI_STORE, stream));
-        DCHECK(mi355_linear(m->k, m->xn, L.wk, L.bk, nullptr, T, Hkv * D, hid, dt, MI355_EPI_STORE, stream));
-        DCHECK(mi355_linear(m->v, m->xn, L.wv, L.bv, nullptr, T, Hkv * D, hid, dt, MI355_EPI_STORE, stream));
+        DCHECK(linear(m, L.wq, L.gq[MI355_W_WQ], m->q, m->xn, L.bq, nullptr, T, H * D, hid, MI355_EPI_STORE, stream));
+        DCHECK(linear(m, L.wk, L.gq[MI355_W_WK], m->k, m->xn, L.bk, nullptr, T, Hkv * D, hid, MI355_EPI_STORE, stream));
+        DCHECK(linear(m, L.wv, L.gq[MI355_W_WV], m->v, m->xn, L.bv, nullptr, T, Hkv * D, hid, MI355_EPI_STORE, stream));
         // q,k -> f32 -> rope -> model dtype                                  attention.rs:644-690
         DCHECK(mi355_rope_inplace(m->q, m->k, m->cos_t, m->sin_t, positions, T, H, Hkv, D, c.rotary_dim, c.rope_interleaved, dt, stream));
         // PagedAttention::forward: cache write, then prefill / decode attention   attention.rs:707-719
@@ -258,11 +296,11 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
                                                 max_context_len, ps, scale, 0.f, c.kv_layout, dt, stream));
         }
         // xs = o_proj(y) + residual                                          llama.rs:55-58
-        DCHECK(mi355_linear(m->xs, m->attn, L.wo, nullptr, m->xs, T, hid, H * D, dt, MI355_EPI_RESID, stream));
+        DCHECK(linear(m, L.wo, L.gq[MI355_W_WO], m->xs, m->attn, nullptr, m->xs, T, hid, H * D, MI355_EPI_RESID, stream));
         // xs = down(silu(gate) * up) + residual                              llama.rs:59-61, mlp.rs:440-458
         DCHECK(norm(m, m->xn, m->xs, L.ffn_norm, L.ffn_norm_b, T, stream));
-        DCHECK(mi355_linear(m->h, m->xn, L.gate_up, nullptr, nullptr, T, 2 * I, hid, dt, MI355_EPI_SILU_MUL, stream));
-        DCHECK(mi355_linear(m->xs, m->h, L.w2, nullptr, m->xs, T, hid, I, dt, MI355_EPI_RESID, stream));
+        DCHECK(linear(m, L.gate_up, L.gq[MI355_W_W1], m->h, m->xn, nullptr, nullptr, T, 2 * I, hid, MI355_EPI_SILU_MUL, stream));
+        DCHECK(linear(m, L.w2, L.gq[MI355_W_W2], m->xs, m->h, nullptr, m->xs, T, hid, I, MI355_EPI_RESID, stream));
     }
     const uint16_t* last = m->xs;
     if (prefill) {                                                          // llama.rs:190-194

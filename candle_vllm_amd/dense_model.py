@@ -43,13 +43,24 @@ class DenseLlama:
         bits = _bf16_bits(values_f32)
         _check(lib.mi355_dense_set_weight(self.h, layer, W_SLOTS[name], bits.ctypes.data, bits.size), f"set_weight {name}")
 
+    def set_gptq(self, layer, name, qweight_u32, scales_f32, group_size):
+        """qweight [k/8, n] u32, scales [k/g, n] f32 values exactly representable in bf16"""
+        qw = np.ascontiguousarray(qweight_u32, np.uint32)
+        sc = _bf16_bits(scales_f32)
+        k, n = qw.shape[0] * 8, qw.shape[1]
+        _check(lib.mi355_dense_set_gptq(self.h, layer, W_SLOTS[name], qw.ctypes.data, sc.ctypes.data, n, k, group_size),
+               f"set_gptq {name}")
+
     def load_oracle_weights(self, W):
         for name in ("tok_embd", "output_norm", "output", "output_norm_b"):
             if name in W:
                 self.set_weight(-1, name, W[name])
         for l, lw in enumerate(W["layers"]):
             for name, v in lw.items():
-                self.set_weight(l, name, v)
+                if isinstance(v, dict):                       # GPTQ projection {"qweight", "scales", "group"}
+                    self.set_gptq(l, name, v["qweight"], v["scales"], v["group"])
+                else:
+                    self.set_weight(l, name, v)
 
     def load_synthetic(self, seed=0, std=0.02):
         """random bf16 weights generated on the GPU (bench)"""

@@ -326,6 +326,10 @@ void mi355_dense_destroy(void* model);
  * packed into one gate_up matrix as mlp.rs:324-352 does) */
 int mi355_dense_set_weight(void* model, int32_t layer, int32_t which, const void* host, int64_t n_elems);
 int mi355_dense_set_weight_dev(void* model, int32_t layer, int32_t which, const void* dev, int64_t n_elems);
+/* GPTQ 4-bit projection (QLinear GPTQ arm, linear.rs:854-906) instead of a dense one: qweight u32 [k/8, n], scales
+ * 16-bit [k/g, n] from the HOST in checkpoint order; sym, no act-order (the Marlin-eligible case, linear.rs:319-325) */
+int mi355_dense_set_gptq(void* model, int32_t layer, int32_t which, const void* qweight_host, const void* scales_host,
+                         int32_t n, int32_t k, int32_t group_size);
 int mi355_dense_alloc_kv_cache(void* model, int32_t num_blocks);
 void* mi355_dense_kv_ptr(void* model, int32_t layer, int32_t which);
 /* one step: prompt when cu_seqlens_q != NULL (flattened tokens), else decode (num_tokens == num_seqs);

@@ -78,6 +78,34 @@ def make_weights(cfg, seed=4321, std=0.05):
     return W
 
 
+def quantize_gptq(W, group=128, seed=7):
+    """replace every projection by an RTN 4-bit symmetric GPTQ tensor (bits=4, sym, desc_act=false: the
+    Marlin-eligible case, linear.rs:319-325).  The dict keeps qweight / scales for the device and
+    the dequantised [out, in] matrix the oracle multiplies with."""
+    out = {k: v for k, v in W.items() if k != "layers"}
+    out["layers"] = []
+    for lw in W["layers"]:
+        nl = dict(lw)
+        for name in ("wq", "wk", "wv", "wo", "w1", "w2", "w3"):
+            w = np.asarray(lw[name], np.float32).T                      # [k, n]
+            K, N = w.shape
+            g = group if 0 < group < K else K
+            wg = w.reshape(K // g, g, N)
+            s = R(np.maximum(np.abs(wg).max(1), 1e-8) / 7.0)            # scales in the model dtype
+            q = np.clip(np.rint(wg / s[:, None, :]) + 8, 0, 15).astype(np.int64).reshape(K, N)
+            deq = G.gptq_dequant(q, s, None, g)                         # f64 [k, n]
+            nl[name] = {"qweight": G.gptq_pack(q), "scales": s, "group": g, "deq": deq}
+        out["layers"].append(nl)
+    return out
+
+
+def _lin(x, w, b=None):
+    """Linear::forward or the QLinear GPTQ arm (linear.rs:124-172 / 854-906)"""
+    if isinstance(w, dict):
+        return G.gptq_linear(x, w["deq"], b, DT)
+    return G.linear16(x, w, b, DT)
+
+
 def rms_norm16(x, w, eps):
     """candle rms_norm on 16-bit data: f32 internally, result rounded (layers/others.rs NormX)."""
     x = np.asarray(x, np.float32)
@@ -120,9 +148,9 @@ class OracleDenseLlama:
         xs = W["tok_embd"][toks].astype(np.float32)
         for l, lw in enumerate(W["layers"]):
             x = self._norm(xs, lw["attn_norm"], lw.get("attn_norm_b"))
-            q = G.linear16(x, lw["wq"], lw.get("bq"), DT).reshape(T, c.n_heads, c.head_dim)
-            k = G.linear16(x, lw["wk"], lw.get("bk"), DT).reshape(T, c.n_kv_heads, c.head_dim)
-            v = G.linear16(x, lw["wv"], lw.get("bv"), DT).reshape(T, c.n_kv_heads, c.head_dim)
+            q = _lin(x, lw["wq"], lw.get("bq")).reshape(T, c.n_heads, c.head_dim)
+            k = _lin(x, lw["wk"], lw.get("bk")).reshape(T, c.n_kv_heads, c.head_dim)
+            v = _lin(x, lw["wv"], lw.get("bv")).reshape(T, c.n_kv_heads, c.head_dim)
             q = R(ops.rope_apply(q, self.cos, self.sin, pos, interleaved=False, rotary_dim=self.rot))   # f32 rope, back to dtype
             k = R(ops.rope_apply(k, self.cos, self.sin, pos, interleaved=False, rotary_dim=self.rot))
             kb, vb = ops.f32_to_bf16_bits(k), ops.f32_to_bf16_bits(v)
@@ -137,11 +165,11 @@ class OracleDenseLlama:
             else:
                 y = ops.paged_attention_decode(q, kc, vc, meta["block_tables"], meta["context_lens"], self.scale, self.flash)
             y = y.reshape(T, c.n_heads * c.head_dim)
-            xs = R(G.linear16(y, lw["wo"], None, DT) + xs)
+            xs = R(_lin(y, lw["wo"]) + xs)
             x = self._norm(xs, lw["ffn_norm"], lw.get("ffn_norm_b"))
-            gate, up = G.linear16(x, lw["w1"], None, DT), G.linear16(x, lw["w3"], None, DT)
+            gate, up = _lin(x, lw["w1"]), _lin(x, lw["w3"])
             h = G.silu_mul16(gate, up, DT)
-            xs = R(G.linear16(h, lw["w2"], None, DT) + xs)
+            xs = R(_lin(h, lw["w2"]) + xs)
         if is_prefill:
             xs = xs[np.asarray(meta["cu_seqlens_q"][1:], np.int64) - 1]
         xs = self._norm(xs, W["output_norm"], W.get("output_norm_b"))

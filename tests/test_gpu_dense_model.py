@@ -105,3 +105,33 @@ def test_stablelm_shape_prompt_then_decode(lib, flash):
         got = gm.forward(dmeta).cpu().numpy()
         assert _rel(got, ref) < 2e-2, (step, _rel(got, ref))
         assert [int(r.argmax()) for r in got] == [int(r.argmax()) for r in ref]
+
+
+def test_qwen2_gptq_shape_prompt_then_decode(lib):
+    """BASELINE config 4 shape, tiny: every projection GPTQ 4-bit sym group 128 (QLinear GPTQ arm) + qkv bias."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from candle_vllm_amd import dense_model as M
+    cfg = DL.DenseConfig.tiny(qkv_bias=True)
+    W = DL.quantize_gptq(DL.make_weights(cfg), group=128)
+    orc = DL.OracleDenseLlama(cfg, W, flash_layout=False)
+    rng = np.random.default_rng(21)
+    seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 29)], "block_table": [3, 7]},
+            {"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 7)], "block_table": [1]}]
+    cache = orc.new_cache(16)
+    meta = O.prepare_prompt(seqs, cfg.block_size)
+    ref = orc.forward(meta, cache, is_prefill=True)
+    gm = M.DenseLlama(cfg, max_batch=4, kv_layout=M.KV_PAGED)
+    gm.load_oracle_weights(W)
+    gm.alloc_kv_cache(16)
+    got = gm.forward(meta, is_prefill=True).cpu().numpy()
+    assert _rel(got, ref) < 2e-2, _rel(got, ref)
+    assert [int(r.argmax()) for r in got] == [int(r.argmax()) for r in ref]
+    for step in range(2):
+        for s, row in zip(seqs, ref):
+            s["tokens"].append(int(row.argmax()))
+        dmeta = O.prepare_decode(seqs, cfg.block_size)
+        ref = orc.forward(dmeta, cache)
+        got = gm.forward(dmeta).cpu().numpy()
+        assert _rel(got, ref) < 2e-2, (step, _rel(got, ref))
+        assert [int(r.argmax()) for r in got] == [int(r.argmax()) for r in ref]
