@@ -15,7 +15,7 @@ def declared_symbols(header_path=HEADER_PATH):
     """Every function name declared in the public header."""
     src = open(header_path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"^\s*(?:void\*?|int|int32_t|int64_t|uint64_t|float\*)\s+(\w+)\s*\(", src, flags=re.M)
+    names = re.findall(r"^\s*(?:(?:const )?void\*?|int|int32_t|int64_t|uint64_t|float\*)\s+(\w+)\s*\(", src, flags=re.M)
     return sorted(set(names))
 
 
@@ -198,3 +198,16 @@ _sig("mi355_dense_set_gptq", ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp, c_i3
 _sig("mi355_dense_alloc_kv_cache", ctypes.c_int, [c_vp, c_i32])
 _sig("mi355_dense_kv_ptr", c_vp, [c_vp, c_i32, c_i32])
 _sig("mi355_dense_forward", ctypes.c_int, [c_vp] * 7 + [c_i32] * 5 + [c_vp, c_i64])
+
+# ---- GGUF reader (section 7)
+_sig("mi355_gguf_open", c_vp, [ctypes.c_char_p])
+_sig("mi355_gguf_close", None, [c_vp])
+_sig("mi355_gguf_version", c_i32, [c_vp])
+_sig("mi355_gguf_n_tensors", c_i32, [c_vp])
+_sig("mi355_gguf_get_u64", c_i32, [c_vp, ctypes.c_char_p, c_vp])
+_sig("mi355_gguf_get_f64", c_i32, [c_vp, ctypes.c_char_p, c_vp])
+_sig("mi355_gguf_get_str", c_i32, [c_vp, ctypes.c_char_p, c_vp, c_i32])
+_sig("mi355_gguf_find", c_i32, [c_vp, ctypes.c_char_p])
+_sig("mi355_gguf_tensor_info", c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp])
+_sig("mi355_gguf_tensor_data", c_vp, [c_vp, c_i32])
+_sig("mi355_llama_load_gguf", ctypes.c_int, [ctypes.c_char_p] + [c_i32] * 5 + [c_vp, c_vp])

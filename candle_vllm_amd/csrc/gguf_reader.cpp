@@ -1,0 +1,194 @@
+// GGUF on-disk format reader: header, metadata key/values, tensor directory, mmap'ed tensor data.
+// What the reference reads through candle's `gguf_file::Content` (src/backend/gguf.rs:48-102,623-712;
+// layers/quantized_var_builder.rs:27-58) and the keys / tensor names GGUFLLaMa consumes
+// (src/openai/models/quantized_llama.rs:225-371).  Format: magic "GGUF", version 2/3 (little endian), u64 tensor
+// and kv counts, then kvs {string key, u32 type, value}, tensor infos {string name, u32 n_dims, u64 dims[] (fastest
+// first), u32 ggml type, u64 offset}, then padding to `general.alignment` (default 32) and the data section.  [EXT: the
+// published GGUF specification]
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "../../include/mi355_vllm.h"
+
+namespace {
+
+enum { T_U8 = 0, T_I8, T_U16, T_I16, T_U32, T_I32, T_F32, T_BOOL, T_STRING, T_ARRAY, T_U64, T_I64, T_F64 };
+
+struct Value { uint32_t type = 0; uint64_t u = 0; int64_t i = 0; double f = 0; std::string s; uint32_t arr_type = 0; uint64_t arr_len = 0; };
+struct TInfo { std::string name; uint32_t n_dims = 0; uint64_t dims[4] = {1, 1, 1, 1}; uint32_t type = 0; uint64_t offset = 0, nbytes = 0; };
+
+struct Gguf {
+    int fd = -1; const uint8_t* base = nullptr; size_t size = 0;
+    uint32_t version = 0; uint64_t data_off = 0; uint32_t alignment = 32;
+    std::unordered_map<std::string, Value> kv;
+    std::vector<TInfo> tensors;
+    std::unordered_map<std::string, int> index;
+};
+
+struct Cur {
+    const uint8_t* p; const uint8_t* end; bool ok = true;
+    template <typename T> T rd() { T v{}; if (p + sizeof(T) > end) { ok = false; return v; } memcpy(&v, p, sizeof(T)); p += sizeof(T); return v; }
+    std::string str() { const uint64_t n = rd<uint64_t>(); if (!ok || p + n > end) { ok = false; return {}; } std::string s((const char*)p, n); p += n; return s; }
+};
+
+// bytes of `n` elements of ggml type t (block formats: elements per block / bytes per block)
+bool type_layout(uint32_t t, uint64_t* elems_per_block, uint64_t* bytes_per_block) {
+    switch (t) {
+        case 0: *elems_per_block = 1; *bytes_per_block = 4; return true;      // F32
+        case 1: *elems_per_block = 1; *bytes_per_block = 2; return true;      // F16
+        case 2: *elems_per_block = 32; *bytes_per_block = 18; return true;    // Q4_0
+        case 3: *elems_per_block = 32; *bytes_per_block = 20; return true;    // Q4_1
+        case 6: *elems_per_block = 32; *bytes_per_block = 22; return true;    // Q5_0
+        case 7: *elems_per_block = 32; *bytes_per_block = 24; return true;    // Q5_1
+        case 8: *elems_per_block = 32; *bytes_per_block = 34; return true;    // Q8_0
+        case 10: *elems_per_block = 256; *bytes_per_block = 84; return true;  // Q2_K
+        case 11: *elems_per_block = 256; *bytes_per_block = 110; return true; // Q3_K
+        case 12: *elems_per_block = 256; *bytes_per_block = 144; return true; // Q4_K
+        case 13: *elems_per_block = 256; *bytes_per_block = 176; return true; // Q5_K
+        case 14: *elems_per_block = 256; *bytes_per_block = 210; return true; // Q6_K
+        case 15: *elems_per_block = 256; *bytes_per_block = 292; return true; // Q8_K
+        case 30: *elems_per_block = 1; *bytes_per_block = 2; return true;     // BF16
+        default: return false;
+    }
+}
+
+bool read_value(Cur& c, uint32_t type, Value* v, int depth = 0) {
+    v->type = type;
+    switch (type) {
+        case T_U8: v->u = c.rd<uint8_t>(); break;
+        case T_I8: v->i = c.rd<int8_t>(); v->u = (uint64_t)v->i; break;
+        case T_U16: v->u = c.rd<uint16_t>(); break;
+        case T_I16: v->i = c.rd<int16_t>(); v->u = (uint64_t)v->i; break;
+        case T_U32: v->u = c.rd<uint32_t>(); break;
+        case T_I32: v->i = c.rd<int32_t>(); v->u = (uint64_t)v->i; break;
+        case T_F32: v->f = c.rd<float>(); break;
+        case T_BOOL: v->u = c.rd<uint8_t>(); break;
+        case T_STRING: v->s = c.str(); break;
+        case T_U64: v->u = c.rd<uint64_t>(); break;
+        case T_I64: v->i = c.rd<int64_t>(); v->u = (uint64_t)v->i; break;
+        case T_F64: v->f = c.rd<double>(); break;
+        case T_ARRAY: {
+            if (depth > 0) return false;
+            v->arr_type = c.rd<uint32_t>(); v->arr_len = c.rd<uint64_t>();
+            for (uint64_t k = 0; k < v->arr_len && c.ok; ++k) { Value e; if (!read_value(c, v->arr_type, &e, 1)) return false; }   // skipped (tokenizer tables)
+            break;
+        }
+        default: return false;
+    }
+    if (type != T_I8 && type != T_I16 && type != T_I32 && type != T_I64) v->i = (int64_t)v->u;
+    return c.ok;
+}
+
+Gguf* G(void* p) { return static_cast<Gguf*>(p); }
+
+}  // namespace
+
+extern "C" {
+
+void* mi355_gguf_open(const char* path) {
+    Gguf* g = new Gguf();
+    g->fd = open(path, O_RDONLY);
+    struct stat st;
+    if (g->fd < 0 || fstat(g->fd, &st) != 0) { if (g->fd >= 0) close(g->fd); delete g; return nullptr; }
+    g->size = (size_t)st.st_size;
+    void* m = mmap(nullptr, g->size, PROT_READ, MAP_PRIVATE, g->fd, 0);
+    if (m == MAP_FAILED) { close(g->fd); delete g; return nullptr; }
+    g->base = static_cast<const uint8_t*>(m);
+    Cur c{g->base, g->base + g->size};
+    const uint32_t magic = c.rd<uint32_t>();
+    g->version = c.rd<uint32_t>();
+    bool ok = c.ok && magic == 0x46554747u && (g->version == 2 || g->version == 3);   // "GGUF"
+    uint64_t n_tensors = 0, n_kv = 0;
+    if (ok) { n_tensors = c.rd<uint64_t>(); n_kv = c.rd<uint64_t>(); ok = c.ok && n_tensors < (1u << 24) && n_kv < (1u << 24); }
+    for (uint64_t i = 0; ok && i < n_kv; ++i) {
+        const std::string key = c.str();
+        const uint32_t type = c.rd<uint32_t>();
+        Value v;
+        ok = c.ok && read_value(c, type, &v);
+        if (ok) g->kv[key] = v;
+    }
+    for (uint64_t i = 0; ok && i < n_tensors; ++i) {
+        TInfo t;
+        t.name = c.str();
+        t.n_dims = c.rd<uint32_t>();
+        ok = c.ok && t.n_dims >= 1 && t.n_dims <= 4;
+        for (uint32_t d = 0; ok && d < t.n_dims; ++d) t.dims[d] = c.rd<uint64_t>();
+        t.type = c.rd<uint32_t>();
+        t.offset = c.rd<uint64_t>();
+        uint64_t epb = 0, bpb = 0;
+        ok = ok && c.ok && type_layout(t.type, &epb, &bpb);
+        if (ok) {
+            uint64_t n = 1;
+            for (uint32_t d = 0; d < t.n_dims; ++d) n *= t.dims[d];
+            ok = (t.dims[0] % epb) == 0;
+            t.nbytes = n / epb * bpb;
+            g->index[t.name] = (int)g->tensors.size();
+            g->tensors.push_back(t);
+        }
+    }
+    if (ok) {
+        auto al = g->kv.find("general.alignment");
+        if (al != g->kv.end() && al->second.u > 0) g->alignment = (uint32_t)al->second.u;
+        const uint64_t pos = (uint64_t)(c.p - g->base);
+        g->data_off = (pos + g->alignment - 1) / g->alignment * g->alignment;
+        for (auto& t : g->tensors) if (g->data_off + t.offset + t.nbytes > g->size) ok = false;
+    }
+    if (!ok) { munmap(m, g->size); close(g->fd); delete g; return nullptr; }
+    return g;
+}
+void mi355_gguf_close(void* h) {
+    Gguf* g = G(h);
+    if (!g) return;
+    if (g->base) munmap(const_cast<uint8_t*>(g->base), g->size);
+    if (g->fd >= 0) close(g->fd);
+    delete g;
+}
+int32_t mi355_gguf_version(void* h) { return (int32_t)G(h)->version; }
+int32_t mi355_gguf_n_tensors(void* h) { return (int32_t)G(h)->tensors.size(); }
+/* metadata: returns 1 when the key exists with a compatible type */
+int32_t mi355_gguf_get_u64(void* h, const char* key, uint64_t* out) {
+    auto it = G(h)->kv.find(key);
+    if (it == G(h)->kv.end() || it->second.type == T_STRING || it->second.type == T_ARRAY || it->second.type == T_F32 || it->second.type == T_F64) return 0;
+    *out = it->second.u; return 1;
+}
+int32_t mi355_gguf_get_f64(void* h, const char* key, double* out) {
+    auto it = G(h)->kv.find(key);
+    if (it == G(h)->kv.end() || (it->second.type != T_F32 && it->second.type != T_F64)) return 0;
+    *out = it->second.f; return 1;
+}
+int32_t mi355_gguf_get_str(void* h, const char* key, char* out, int32_t cap) {
+    auto it = G(h)->kv.find(key);
+    if (it == G(h)->kv.end() || it->second.type != T_STRING) return -1;
+    const int n = (int)it->second.s.size();
+    if (out && cap > 0) { const int k = n < cap - 1 ? n : cap - 1; memcpy(out, it->second.s.data(), k); out[k] = 0; }
+    return n;
+}
+int32_t mi355_gguf_find(void* h, const char* name) { auto it = G(h)->index.find(name); return it == G(h)->index.end() ? -1 : it->second; }
+/* dims are returned slowest-first ([rows, cols] for a matrix, as candle reports shapes; GGUF stores fastest-first) */
+int32_t mi355_gguf_tensor_info(void* h, int32_t i, char* name, int32_t name_cap, int64_t* dims4, int32_t* n_dims, int32_t* ggml_type,
+                               uint64_t* nbytes) {
+    Gguf* g = G(h);
+    if (i < 0 || i >= (int)g->tensors.size()) return -1;
+    const TInfo& t = g->tensors[i];
+    if (name && name_cap > 0) { const int k = (int)t.name.size() < name_cap - 1 ? (int)t.name.size() : name_cap - 1; memcpy(name, t.name.data(), k); name[k] = 0; }
+    if (dims4) for (uint32_t d = 0; d < 4; ++d) dims4[d] = d < t.n_dims ? (int64_t)t.dims[t.n_dims - 1 - d] : 1;
+    if (n_dims) *n_dims = (int32_t)t.n_dims;
+    if (ggml_type) *ggml_type = (int32_t)t.type;
+    if (nbytes) *nbytes = t.nbytes;
+    return 0;
+}
+const void* mi355_gguf_tensor_data(void* h, int32_t i) {
+    Gguf* g = G(h);
+    if (i < 0 || i >= (int)g->tensors.size()) return nullptr;
+    return g->base + g->data_off + g->tensors[i].offset;
+}
+
+}  // extern "C"

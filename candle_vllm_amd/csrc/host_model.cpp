@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <string>
 #include <vector>
 
 #include "../../include/mi355_vllm.h"
@@ -641,6 +642,105 @@ extern "C" int mi355_llama_decode_read_tokens(void* mp, uint32_t* host_out, int6
 extern "C" float* mi355_llama_logits_ptr(void* mp) {
     Model* m = static_cast<Model*>(mp);
     return m ? m->logits : nullptr;
+}
+
+// ---- GGUFLLaMa::from_gguf (quantized_llama.rs:203-420) over the GGUF reader ------------------------------------
+extern "C" int mi355_llama_load_gguf(const char* path, int32_t max_batch, int32_t max_blocks_per_seq, int32_t block_size,
+                                     int32_t kv_layout, int32_t max_seq, void** model_out, mi355_llama_config* cfg_out) {
+    if (!path || !model_out) return (int)hipErrorInvalidValue;
+    *model_out = nullptr;
+    void* g = mi355_gguf_open(path);
+    if (!g) return (int)hipErrorFileNotFound;
+    struct Closer { void* g; ~Closer() { mi355_gguf_close(g); } } closer{g};
+    char arch[64];
+    if (mi355_gguf_get_str(g, "general.architecture", arch, sizeof(arch)) <= 0) return (int)hipErrorInvalidValue;
+    auto key = [&](const char* suffix) { return std::string(arch) + "." + suffix; };
+    auto u = [&](const std::string& k, uint64_t* out) { return mi355_gguf_get_u64(g, k.c_str(), out) == 1; };
+    uint64_t head_count = 0, head_count_kv = 0, block_count = 0, embd = 0, ctx_len = 8192, key_len = 0, n_expert = 0;
+    if (!u(key("attention.head_count"), &head_count) || !u(key("attention.head_count_kv"), &head_count_kv) ||
+        !u(key("block_count"), &block_count) || !u(key("embedding_length"), &embd))
+        return (int)hipErrorInvalidValue;
+    (void)u(key("context_length"), &ctx_len);
+    (void)u(key("expert_count"), &n_expert);
+    if (n_expert > 1) return (int)hipErrorNotSupported;           // MoE GGUF: SURVEY 8 f4, not built
+    if (!u(key("attention.key_length"), &key_len)) key_len = embd / head_count;
+    double eps = 0, theta = 10000.0;
+    if (mi355_gguf_get_f64(g, key("attention.layer_norm_rms_epsilon").c_str(), &eps) != 1) return (int)hipErrorInvalidValue;
+    (void)mi355_gguf_get_f64(g, key("rope.freq_base").c_str(), &theta);
+
+    auto info = [&](const std::string& name, int64_t* dims, int32_t* type, uint64_t* nbytes) {
+        const int i = mi355_gguf_find(g, name.c_str());
+        if (i < 0) return -1;
+        int32_t nd = 0;
+        if (mi355_gguf_tensor_info(g, i, nullptr, 0, dims, &nd, type, nbytes) != 0) return -1;
+        return i;
+    };
+    int64_t d[4]; int32_t ty; uint64_t nb;
+    const int i_embd = info("token_embd.weight", d, &ty, &nb);
+    if (i_embd < 0) return (int)hipErrorInvalidValue;
+    const int64_t vocab = d[0];
+    int64_t dff[4]; int32_t tff; uint64_t nbff;
+    if (info("blk.0.ffn_gate.weight", dff, &tff, &nbff) < 0) return (int)hipErrorInvalidValue;
+
+    mi355_llama_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.hidden = (int32_t)embd; cfg.n_layers = (int32_t)block_count; cfg.n_heads = (int32_t)head_count;
+    cfg.n_kv_heads = (int32_t)head_count_kv; cfg.head_dim = (int32_t)key_len; cfg.intermediate = (int32_t)dff[0];
+    cfg.vocab = (int32_t)vocab;
+    cfg.max_seq = (max_seq > 0 && (uint64_t)max_seq < ctx_len) ? max_seq : (int32_t)ctx_len;
+    cfg.block_size = block_size; cfg.kv_layout = kv_layout; cfg.max_batch = max_batch; cfg.max_blocks_per_seq = max_blocks_per_seq;
+    cfg.rms_eps = (float)eps; cfg.rope_theta = (float)theta; cfg.tp_rank = 0; cfg.tp_world = 1;
+    Model* m = static_cast<Model*>(mi355_llama_create(&cfg));
+    if (!m) return (int)hipErrorInvalidValue;
+    struct Guard { Model* m; bool keep = false; ~Guard() { if (!keep) mi355_llama_destroy(m); } } guard{m};
+
+    auto load_q = [&](const std::string& name, int layer, int which) -> int {
+        int64_t dd[4]; int32_t t; uint64_t n;
+        const int i = info(name, dd, &t, &n);
+        if (i < 0) return (int)hipErrorInvalidValue;
+        if (t != MI355_GGML_Q4_K && t != MI355_GGML_Q6_K) return (int)hipErrorNotSupported;   // other ggml types: out of scope
+        return mi355_llama_set_qweight(m, layer, which, t, mi355_gguf_tensor_data(g, i), (int32_t)dd[0], (int32_t)dd[1]);
+    };
+    auto load_f32 = [&](const std::string& name, int layer, int which) -> int {
+        int64_t dd[4]; int32_t t; uint64_t n;
+        const int i = info(name, dd, &t, &n);
+        if (i < 0 || t != 0) return (int)hipErrorInvalidValue;
+        return mi355_llama_set_f32(m, layer, which, static_cast<const float*>(mi355_gguf_tensor_data(g, i)), (int64_t)(n / 4));
+    };
+    // token_embd: dequantised once (quantized_llama.rs:262-264)
+    if (ty == 0) {
+        RCHECK(mi355_llama_set_f32(m, -1, MI355_W_TOK_EMBD, static_cast<const float*>(mi355_gguf_tensor_data(g, i_embd)), vocab * (int64_t)embd));
+    } else if (ty == MI355_GGML_Q4_K || ty == MI355_GGML_Q6_K) {
+        void* native = nullptr;
+        HCHECK(hipMalloc(&native, nb));
+        HCHECK(hipMemcpy(native, mi355_gguf_tensor_data(g, i_embd), nb, hipMemcpyHostToDevice));
+        if (m->tok_embd) { (void)hipFree(m->tok_embd); m->tok_embd = nullptr; }
+        hipError_t e = hipMalloc((void**)&m->tok_embd, (size_t)vocab * embd * 4);
+        int rc = e == hipSuccess ? mi355_dequantize(m->tok_embd, native, ty, vocab * (int64_t)embd, 0) : (int)e;
+        (void)hipDeviceSynchronize();
+        (void)hipFree(native);
+        if (rc) return rc;
+    } else {
+        return (int)hipErrorNotSupported;
+    }
+    RCHECK(load_f32("output_norm.weight", -1, MI355_W_OUTPUT_NORM));
+    RCHECK(load_q(mi355_gguf_find(g, "output.weight") >= 0 ? "output.weight" : "token_embd.weight", -1, MI355_W_OUTPUT));
+    for (int l = 0; l < cfg.n_layers; ++l) {
+        const std::string p = "blk." + std::to_string(l) + ".";
+        RCHECK(load_q(p + "attn_q.weight", l, MI355_W_WQ));
+        RCHECK(load_q(p + "attn_k.weight", l, MI355_W_WK));
+        RCHECK(load_q(p + "attn_v.weight", l, MI355_W_WV));
+        RCHECK(load_q(p + "attn_output.weight", l, MI355_W_WO));
+        RCHECK(load_q(p + "ffn_gate.weight", l, MI355_W_W1));
+        RCHECK(load_q(p + "ffn_down.weight", l, MI355_W_W2));
+        RCHECK(load_q(p + "ffn_up.weight", l, MI355_W_W3));
+        RCHECK(load_f32(p + "attn_norm.weight", l, MI355_W_ATTN_NORM));
+        RCHECK(load_f32(p + "ffn_norm.weight", l, MI355_W_FFN_NORM));
+    }
+    guard.keep = true;
+    *model_out = m;
+    if (cfg_out) *cfg_out = cfg;
+    return 0;
 }
 
 // ---- tensor-parallel communicator -----------------------------------------------------------------------------

@@ -450,6 +450,26 @@ int32_t mi355_sched_abort_sequences(void* sched, const int64_t* seq_ids, int32_t
 void mi355_sched_rollback_swap_in(void* sched, int64_t group_id);
 void mi355_sched_rollback_swap_out(void* sched, int64_t group_id);
 
+/* ---------------------------------------------------------------------------------------------
+ * 7. GGUF file reader: src/backend/gguf.rs:48-102,623-712, quantized_var_builder.rs:27-58;
+ *    keys and tensor names as GGUFLLaMa reads them (quantized_llama.rs:225-371).  mmap, zero copy.
+ * ------------------------------------------------------------------------------------------- */
+void* mi355_gguf_open(const char* path);
+void mi355_gguf_close(void* gguf);
+int32_t mi355_gguf_version(void* gguf);
+int32_t mi355_gguf_n_tensors(void* gguf);
+int32_t mi355_gguf_get_u64(void* gguf, const char* key, uint64_t* out);
+int32_t mi355_gguf_get_f64(void* gguf, const char* key, double* out);
+int32_t mi355_gguf_get_str(void* gguf, const char* key, char* out, int32_t cap);
+int32_t mi355_gguf_find(void* gguf, const char* name);
+int32_t mi355_gguf_tensor_info(void* gguf, int32_t i, char* name, int32_t name_cap, int64_t* dims4, int32_t* n_dims,
+                               int32_t* ggml_type, uint64_t* nbytes);
+const void* mi355_gguf_tensor_data(void* gguf, int32_t i);
+/* GGUFLLaMa::from_gguf (quantized_llama.rs:203-420): config from the metadata, every tensor handed to the model
+ * (matrices Q4_K / Q6_K re-tiled, token_embd dequantised on the device, norms F32).  *model_out = mi355_llama handle. */
+int mi355_llama_load_gguf(const char* path, int32_t max_batch, int32_t max_blocks_per_seq, int32_t block_size,
+                          int32_t kv_layout, int32_t max_seq, void** model_out, mi355_llama_config* cfg_out);
+
 #ifdef __cplusplus
 }
 #endif

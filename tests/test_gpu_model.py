@@ -184,3 +184,37 @@ def test_chunked_prefill_equals_one_shot(lib):
     got = two.forward_prefill(O.prepare_prompt(seqs, cfg.block_size, num_cached_tokens=[20, 20])).cpu().numpy()
     assert _rel(got, ref) < 3e-3, _rel(got, ref)
     assert [int(r.argmax()) for r in got] == [int(r.argmax()) for r in ref]
+
+
+def test_model_loaded_from_gguf_file_equals_setter_path(lib, tmp_path):
+    """f3: write the oracle's tiny llama as a GGUF file (test writer), load it through the C++ GGUF reader
+    (`mi355_llama_load_gguf`: metadata -> config, Q4_K/Q6_K tensors re-tiled, token_embd dequantised on the device)
+    and check the decode logits are bit-identical to the model built through the setters from the same tensors."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from candle_vllm_amd import model as M
+    from oracle import gguf_writer as GW
+    from oracle import kquants as kq
+    cfg = llama.LlamaConfig.tiny()
+    W = llama.make_weights(cfg, seed=1234)
+    # the file stores token_embd as Q6_K (as llama.cpp files do); the setter path gets the same dequantised table
+    W = dict(W)
+    W["tok_embd"] = kq.dequantize_q6_k(kq.quantize(W["tok_embd"], kq.GGML_Q6_K)).reshape(cfg.vocab, cfg.hidden).astype(np.float32)
+    path = os.path.join(tmp_path, "tiny.gguf")
+    GW.llama_to_gguf(path, cfg, W)
+    a = M.GGUFLLaMa.from_gguf(path, max_batch=4, max_blocks_per_seq=16, block_size=cfg.block_size, kv_layout=M.KV_FLASH)
+    got_cfg = (a.cfg.hidden, a.cfg.n_layers, a.cfg.n_heads, a.cfg.n_kv_heads, a.cfg.head_dim, a.cfg.intermediate, a.cfg.vocab)
+    assert got_cfg == (cfg.hidden, cfg.n_layers, cfg.n_heads, cfg.n_kv_heads, cfg.head_dim, cfg.intermediate, cfg.vocab)
+    b = M.GGUFLLaMa(cfg, max_batch=4, kv_layout=M.KV_FLASH)
+    b.load_oracle_weights(W)
+    rng = np.random.default_rng(7)
+    seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 19)], "block_table": [3, 7]},
+            {"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 5)], "block_table": [1]}]
+    meta = O.prepare_prompt(seqs, cfg.block_size)
+    for m in (a, b):
+        m.alloc_kv_cache(16)
+    la = a.forward_prefill(meta).cpu().numpy()
+    lb = b.forward_prefill(meta).cpu().numpy()
+    assert np.array_equal(la, lb)
+    ref = llama.OracleLlama(cfg, W).forward(meta, llama.OracleLlama(cfg, W).new_cache(16), is_prefill=True)
+    assert _rel(la, ref) < 3e-3
