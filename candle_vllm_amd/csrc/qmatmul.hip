@@ -723,7 +723,7 @@ __global__ void __launch_bounds__(256) qmm_prep_kernel(uint8_t* __restrict__ img
     }
 }
 
-template <int MT>
+template <int MT, bool PIN = true>
 __device__ __forceinline__ void wide_q4k(const TileRegs& w, const uint8_t* __restrict__ L, int lane, float (&y)[MT][4]) {
     constexpr int BP = MT * 8;
     const int m = lane & 15, kg = lane >> 4;
@@ -764,12 +764,14 @@ __device__ __forceinline__ void wide_q4k(const TileRegs& w, const uint8_t* __res
             y[mt][2] = fmaf(dsc, acc[2], fmaf(-cj, xsv.z, y[mt][2]));
             y[mt][3] = fmaf(dsc, acc[3], fmaf(-cj, xsv.w, y[mt][3]));
         }
-        asm volatile("" ::: "memory");              // one sub-block at a time: no hoisting of the next LDS reads,
-        __builtin_amdgcn_sched_barrier(0);          // keeps the live set small (no spills)
+        if (PIN) {
+            asm volatile("" ::: "memory");          // one sub-block at a time: no hoisting of the next LDS reads,
+            __builtin_amdgcn_sched_barrier(0);      // keeps the live set small (no spills)
+        }
     }
 }
 
-template <int MT>
+template <int MT, bool PIN = true>
 __device__ __forceinline__ void wide_q6k(const TileRegs& w, const uint8_t* __restrict__ L, int lane, float (&y)[MT][4]) {
     constexpr int BP = MT * 8;
     const int m = lane & 15, kg = lane >> 4;
@@ -812,8 +814,10 @@ __device__ __forceinline__ void wide_q6k(const TileRegs& w, const uint8_t* __res
                     y[mt][2] = fmaf(dsc, acc[2], fmaf(c160, xsv.z, y[mt][2]));
                     y[mt][3] = fmaf(dsc, acc[3], fmaf(c160, xsv.w, y[mt][3]));
                 }
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
+                if (PIN) {
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     }
@@ -1048,55 +1052,69 @@ __global__ void __launch_bounds__(256) qmm_prep2_kernel(uint8_t* __restrict__ im
     }
 }
 
-template <int MT>
+// Wave specialisation: waves 0..6 are CONSUMERS (one row tile each: weight stream with a two-deep register prefetch +
+// unpack + MFMA), wave 7 is the LOADER of the shared activation image (global -> LDS DMA for the next k-block).  Keeping
+// the LDS-DMA out of the consumers' instruction stream matters: with a DMA in flight hipcc puts `s_waitcnt vmcnt(0)` in
+// front of the next use of ANY loaded register, which serialised load -> wait -> compute in the first version
+// (measured: 36 of 45 us of the gate/up GEMM were the load/barrier skeleton).  One barrier per k-block.
+#define QMG_NC 7
+template <int MT, int WT>
 __global__ void __launch_bounds__(512, 4) qmm_gemm_kernel(const QmmArgs a, const uint8_t* __restrict__ img, float* __restrict__ part,
-                                                          const int ldp, const int n_slots) {
+                                                          const int ldp, const int n_slots, const int slot_base) {
     extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
     constexpr int BP = MT * 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nkb = a.K >> 8;
     const size_t kbb = (((size_t)MT * 8 * 1216) + 1023) / 1024 * 1024;
-    const int nchunk = (int)(kbb >> 10);                              // 1 KiB = one wave-wide 16-B DMA
-    int slot = blockIdx.x * 8 + wave;
+    const int kb_per = (nkb + gridDim.y - 1) / gridDim.y;
+    const int kb_lo = blockIdx.y * kb_per, kb_hi = min(nkb, kb_lo + kb_per);
+    if (kb_lo >= kb_hi) return;                                       // uniform for the workgroup
+
+    if (wave == QMG_NC) {
+        // ---------------- loader wave: the image of k-block kb+1 lands while the consumers work on kb
+        const int nchunk = (int)(kbb >> 10);                          // 1 KiB = one wave-wide 16-B DMA
+        auto dma_kb = [&](int kb, int buf) {
+            const uint8_t* src = img + (size_t)kb * kbb;
+            uint8_t* dst = smem + (size_t)buf * kbb;
+            for (int c = 0; c < nchunk; ++c)
+                __builtin_amdgcn_global_load_lds((qmg_gptr_t)(src + (size_t)c * 1024 + lane * 16), (qmg_lptr_t)(dst + (size_t)c * 1024), 16, 0, 0);
+        };
+        dma_kb(kb_lo, kb_lo & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kb = kb_lo; kb < kb_hi; ++kb) {
+            if (kb + 1 < kb_hi && a.dbg != 2) dma_kb(kb + 1, (kb + 1) & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        return;
+    }
+    // ---------------- consumer waves
+    int slot = blockIdx.x * QMG_NC + wave;
     const bool have = slot < n_slots;
     if (!have) slot = 0;
     int t = slot, sg = 0;
     while (sg + 1 < a.nseg && t >= a.seg[sg].n_tiles) { t -= a.seg[sg].n_tiles; ++sg; }
-    const int wtype = a.seg[sg].type;
+    const int wtype = WT ? WT : a.seg[sg].type;                       // WT != 0: every tile of the launch has that type
     const int wtb = (wtype == MI355_GGML_Q4_K) ? Q4K_TILE : Q6K_TILE;
     const uint8_t* wbase = a.seg[sg].w + (size_t)t * nkb * wtb;
-    const int kb_per = (nkb + gridDim.y - 1) / gridDim.y;
-    const int kb_lo = blockIdx.y * kb_per, kb_hi = min(nkb, kb_lo + kb_per);
     float y[1][MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int v = 0; v < 4; ++v) y[0][mt][v] = 0.f;
-
-    if (kb_lo < kb_hi) {
-        // activation image: global -> LDS by DMA (wave-uniform LDS base + lane * 16), no staging registers
-        auto dma_kb = [&](int kb, int buf) {
-            const uint8_t* src = img + (size_t)kb * kbb;
-            uint8_t* dst = smem + (size_t)buf * kbb;
-            for (int c = wave; c < nchunk; c += 8)
-                __builtin_amdgcn_global_load_lds((qmg_gptr_t)(src + (size_t)c * 1024 + lane * 16), (qmg_lptr_t)(dst + (size_t)c * 1024), 16, 0, 0);
-        };
-        dma_kb(kb_lo, kb_lo & 1);
-        TileRegs cur = load_tile<0>(wtype, wbase + (size_t)kb_lo * wtb, lane), nxt;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int kb = kb_lo; kb < kb_hi; ++kb) {
-            const uint8_t* Lc = smem + (size_t)(kb & 1) * kbb;
-            const bool more = kb + 1 < kb_hi;
-            if (more && a.dbg != 2) dma_kb(kb + 1, (kb + 1) & 1);
-            nxt = load_tile<0>(wtype, more ? wbase + (size_t)(kb + 1) * wtb : wbase, more ? lane : 0);
-            if (a.dbg == 1) { y[0][0][0] += __uint_as_float(cur.a.x ^ cur.b.y ^ cur.c.z ^ cur.d.w ^ cur.e); }
-            else if (wtype == MI355_GGML_Q4_K) wide_q4k<MT>(cur, Lc, lane, y[0]);
-            else wide_q6k<MT>(cur, Lc, lane, y[0]);
-            cur = nxt;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // next image landed (and the next tile)
-            __syncthreads();                                        // everyone is done with Lc
-        }
+    TileRegs cur = load_tile<WT>(wtype, wbase + (size_t)kb_lo * wtb, lane);
+    __syncthreads();                                                  // first image landed
+    for (int kb = kb_lo; kb < kb_hi; ++kb) {
+        const uint8_t* Lc = smem + (size_t)(kb & 1) * kbb;
+        const bool more = kb + 1 < kb_hi;
+        // the next tile streams in while this one is unpacked and multiplied (counted vmcnt: no DMA in this wave)
+        TileRegs nxt = load_tile<WT>(wtype, more ? wbase + (size_t)(kb + 1) * wtb : wbase, more ? lane : 0);
+        if (a.dbg == 1) { y[0][0][0] += __uint_as_float(cur.a.x ^ cur.b.y ^ cur.c.z); }
+        else if (wtype == MI355_GGML_Q4_K) wide_q4k<MT, WT == 0>(cur, Lc, lane, y[0]);   // pin the schedule only in the mixed build
+        else wide_q6k<MT, WT == 0>(cur, Lc, lane, y[0]);
+        cur = nxt;
+        __syncthreads();                                              // everyone is done with Lc; the loader filled the other buffer
     }
     // hi + lo halves of the M tile, then plain stores of the partial sums
     const int kg = lane >> 4, rr = lane & 15;
@@ -1105,7 +1123,7 @@ __global__ void __launch_bounds__(512, 4) qmm_gemm_kernel(const QmmArgs a, const
 #pragma unroll
         for (int v = 0; v < 4; ++v) y[0][mt][v] += __shfl_xor(y[0][mt][v], 32, 64);
     if (have && kg < 2) {
-        float* pp = part + (size_t)blockIdx.y * BP * ldp + (size_t)slot * 16 + rr;
+        float* pp = part + (size_t)blockIdx.y * BP * ldp + (size_t)(slot_base + slot) * 16 + rr;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -1207,12 +1225,29 @@ static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
     if (rc) return rc;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)qmm_gemm_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qmm_gemm_kernel<MT, MI355_GGML_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qmm_gemm_kernel<MT, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     float* ssp = reinterpret_cast<float*>(g_qmg_img + kbb * nkb);           // [nkb][MT*8] after the image
     hipLaunchKernelGGL((qmm_prep2_kernel<MT>), dim3(nkb), dim3(256), 0, st, g_qmg_img, ssp, a, kbb);
-    hipLaunchKernelGGL((qmm_gemm_kernel<MT>), dim3((n_slots + 7) / 8, ks), dim3(512), 2 * kbb, st, a, g_qmg_img, g_qmg_part, ldp, n_slots);
+    // one GEMM launch per run of same-type segments: the type-specialised builds need no schedule pinning and do not
+    // spill (the mixed build did); each run writes its own columns of the partial-sum buffer
+    for (int s0 = 0, slot_base = 0; s0 < a.nseg;) {
+        int s1 = s0 + 1;
+        while (s1 < a.nseg && a.seg[s1].type == a.seg[s0].type) ++s1;
+        QmmArgs r = a;
+        r.nseg = s1 - s0;
+        int run_slots = 0;
+        for (int q = 0; q < r.nseg; ++q) { r.seg[q] = a.seg[s0 + q]; run_slots += r.seg[q].n_tiles; }
+        const dim3 ggrid((run_slots + QMG_NC - 1) / QMG_NC, ks);
+        if (r.seg[0].type == MI355_GGML_Q4_K)
+            hipLaunchKernelGGL((qmm_gemm_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), 2 * kbb, st, r, g_qmg_img, g_qmg_part, ldp, run_slots, slot_base);
+        else
+            hipLaunchKernelGGL((qmm_gemm_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, r, g_qmg_img, g_qmg_part, ldp, run_slots, slot_base);
+        slot_base += run_slots;
+        s0 = s1;
+    }
     hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, a.B), dim3(256), 0, st, a, g_qmg_part, ldp, ks, MT * 8, ssp);
     return (int)hipGetLastError();
 }
