@@ -59,6 +59,48 @@ __global__ void __launch_bounds__(256) reshape_and_cache_paged_kernel(
     }
 }
 
+// fp8 KV cache (`--kvcache-dtype fp8`, src/main.rs:263-267; K layout x = 16, cache_engine.rs:304-311): bf16 k, v are
+// stored as OCP e4m3fn bytes = e4m3(value / scale), round-to-nearest-even, saturating at +-448 (scale 1.0 is what the
+// reference passes today [EXT: conversion lives in attention-rs]).
+__device__ __forceinline__ uint8_t to_e4m3(float f) {
+    f = fminf(fmaxf(f, -448.f), 448.f);                      // saturate (NaN passes through the min/max as NaN -> 0x7F)
+    const int p = __builtin_amdgcn_cvt_pk_fp8_f32(f, 0.f, 0, false);
+    return (uint8_t)(p & 0xFF);
+}
+__global__ void __launch_bounds__(256) reshape_and_cache_fp8_kernel(const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+                                                                    uint8_t* __restrict__ kc, uint8_t* __restrict__ vc,
+                                                                    const int64_t* __restrict__ slot_mapping, int Hkv, int D, int bs,
+                                                                    int layout, float inv_k_scale, float inv_v_scale) {
+    const int t = blockIdx.x;
+    const int64_t slot = slot_mapping[t];
+    if (slot < 0) return;
+    const int64_t blk = slot / bs, off = slot % bs;
+    const int n = Hkv * D;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int h = i / D, d = i % D;
+        const float kf = bf16_to_f32(k[(int64_t)t * n + i]) * inv_k_scale, vf = bf16_to_f32(v[(int64_t)t * n + i]) * inv_v_scale;
+        int64_t ko, vo;
+        if (layout == MI355_KV_FLASH) { ko = vo = (slot * Hkv + h) * D + d; }
+        else {
+            ko = (((blk * Hkv + h) * (D / 16) + d / 16) * bs + off) * 16 + d % 16;
+            vo = ((blk * Hkv + h) * D + d) * (int64_t)bs + off;
+        }
+        kc[ko] = to_e4m3(kf);
+        vc[vo] = to_e4m3(vf);
+    }
+}
+extern "C" int mi355_reshape_and_cache_fp8(const void* k, const void* v, void* key_cache, void* value_cache,
+                                           const int64_t* slot_mapping, int32_t num_tokens, int32_t num_kv_heads,
+                                           int32_t head_dim, int32_t block_size, int32_t layout, float k_scale, float v_scale,
+                                           int64_t stream) {
+    if (num_tokens <= 0) return 0;
+    if (layout == MI355_KV_PAGED && (head_dim % 16)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(reshape_and_cache_fp8_kernel, dim3(num_tokens), dim3(256), 0, to_stream(stream), (const uint16_t*)k,
+                       (const uint16_t*)v, (uint8_t*)key_cache, (uint8_t*)value_cache, slot_mapping, num_kv_heads, head_dim,
+                       block_size, layout, 1.f / k_scale, 1.f / v_scale);
+    return (int)hipGetLastError();
+}
+
 extern "C" int mi355_reshape_and_cache(const void* k, const void* v, void* key_cache, void* value_cache,
                                        const int64_t* slot_mapping, int32_t num_tokens,
                                        int32_t num_kv_heads, int32_t head_dim, int32_t block_size,

@@ -110,6 +110,7 @@ void* mi355_dense_create(const mi355_dense_config* cfg) {
         cfg->max_batch <= 0 || cfg->head_dim <= 0 || (cfg->dtype != MI355_DTYPE_BF16 && cfg->dtype != MI355_DTYPE_F16))
         return nullptr;
     if (cfg->dtype != MI355_DTYPE_BF16) return nullptr;       // the attention kernels of this path are bf16
+    if (cfg->kv_fp8 && (cfg->kv_layout != MI355_KV_PAGED || (cfg->head_dim % 16))) return nullptr;
     DModel* m = new DModel();
     m->cfg = *cfg;
     m->layers.resize(cfg->n_layers);
@@ -228,7 +229,7 @@ int mi355_dense_alloc_kv_cache(void* mp, int32_t num_blocks) {
     DModel* m = static_cast<DModel*>(mp);
     if (!m || num_blocks <= 0) return (int)hipErrorInvalidValue;
     const mi355_dense_config& c = m->cfg;
-    const size_t per = (size_t)num_blocks * c.block_size * c.n_kv_heads * c.head_dim * 2;
+    const size_t per = (size_t)num_blocks * c.block_size * c.n_kv_heads * c.head_dim * (c.kv_fp8 ? 1 : 2);
     if (m->kv_slab) { (void)hipFree(m->kv_slab); m->kv_slab = nullptr; }
     DHIP(hipMalloc(&m->kv_slab, per * 2 * c.n_layers));
     DHIP(hipMemset(m->kv_slab, 0, per * 2 * c.n_layers));
@@ -277,6 +278,23 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
         // q,k -> f32 -> rope -> model dtype                                  attention.rs:644-690
         DCHECK(mi355_rope_inplace(m->q, m->k, m->cos_t, m->sin_t, positions, T, H, Hkv, D, c.rotary_dim, c.rope_interleaved, dt, stream));
         // PagedAttention::forward: cache write, then prefill / decode attention   attention.rs:707-719
+        if (c.kv_fp8) {
+            // `--kvcache-dtype fp8` (is_fp8_keys, attention.rs:574): e4m3fn cache, every key read back from it
+            DCHECK(mi355_reshape_and_cache_fp8(m->k, m->v, m->kcache[l], m->vcache[l], slot_mapping, T, Hkv, D, c.block_size,
+                                               c.kv_layout, 1.f, 1.f, stream));
+            if (prefill) {
+                DCHECK(mi355_prefill_attention_fp8(m->attn, m->q, m->kcache[l], m->vcache[l], block_tables, context_lens,
+                                                   cu_seqlens_q, num_seqs, max_seqlen_q, H, Hkv, D, c.block_size, max_blocks,
+                                                   scale, 0.f, 1.f, 1.f, dt, stream));
+            } else {
+                int ps = choose_partition(T, Hkv, max_context_len);
+                if (ps > 0) ps = ps <= 32 ? 32 : (ps <= 64 ? 64 : 128);
+                if (ps > 0 && (max_context_len + ps - 1) / ps > m->pa_cap_partitions) return (int)hipErrorInvalidValue;
+                DCHECK(mi355_paged_attention_fp8(m->attn, m->pa_sum, m->pa_max, m->pa_tmp, m->q, m->kcache[l], m->vcache[l],
+                                                 block_tables, context_lens, T, H, Hkv, D, c.block_size, max_blocks,
+                                                 max_context_len, ps, scale, 0.f, 1.f, 1.f, stream));
+            }
+        } else {
         DCHECK(mi355_reshape_and_cache(m->k, m->v, m->kcache[l], m->vcache[l], slot_mapping, T, Hkv, D, c.block_size, 2,
                                        c.kv_layout, stream));
         if (prefill) {
@@ -294,6 +312,7 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
                 DCHECK(mi355_paged_attention_v2(m->attn, m->pa_sum, m->pa_max, m->pa_tmp, m->q, m->kcache[l], m->vcache[l],
                                                 block_tables, context_lens, T, H, Hkv, D, c.block_size, max_blocks,
                                                 max_context_len, ps, scale, 0.f, c.kv_layout, dt, stream));
+        }
         }
         // xs = o_proj(y) + residual                                          llama.rs:55-58
         DCHECK(linear(m, L.wo, L.gq[MI355_W_WO], m->xs, m->attn, nullptr, m->xs, T, hid, H * D, MI355_EPI_RESID, stream));

@@ -16,6 +16,7 @@
 //   * lane-group states merge with ds_bpermute shuffles, wave states through 8.3 KB of LDS,
 //   * v2: partitions write (normalised out, max_logit, exp_sum); a tiny reduce kernel merges them.
 #include "common.h"
+#include <type_traits>
 #include "../../include/mi355_vllm.h"
 
 
@@ -65,7 +66,21 @@ struct PAParams {
     float scale, softcap;      // softcap <= 0 -> disabled
     int64_t q_stride;          // elements between sequences in q (H*D when contiguous)
     unsigned* arrive;          // [B*Hkv] arrival counters (zero between launches) or null: fused partition merge
+    int kv8;                   // 1: the cache holds OCP e4m3fn bytes (K layout x = 16), value = byte * {k,v}_scale
+    float k_scale, v_scale;
 };
+
+// 4 e4m3fn bytes -> 4 bf16 (exact: 3 mantissa bits), 8 bytes -> 8 bf16
+__device__ __forceinline__ uint2 fp8x4_to_bf16x4(uint32_t w) {
+    typedef float pa_f32x2 __attribute__((ext_vector_type(2)));
+    const pa_f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
+    return make_uint2(cvt_pk_bf16(a.x, a.y), cvt_pk_bf16(b.x, b.y));
+}
+__device__ __forceinline__ float fp8_to_f32(uint8_t b) {
+    typedef float pa_f32x2 __attribute__((ext_vector_type(2)));
+    const pa_f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)b, false);
+    return a.x;
+}
 
 // NWV waves per workgroup.  The partitioned (v2) path runs ONE wave per workgroup (no LDS, no barrier: a
 // partition is what a single wave streams with UNR loads in flight); v1 keeps 4 waves merged through LDS.
@@ -346,13 +361,23 @@ __global__ void __launch_bounds__(256) paged_attn_paged_layout_kernel(const PAPa
         const int tok = t0 + i;
         const int64_t blk = (int64_t)bt[tok / bs];
         const int off = tok % bs;
-        const uint16_t* kb = kc + ((blk * p.Hkv + hk) * (D / 8)) * (int64_t)bs * 8 + (int64_t)off * 8;
         float s = 0.f;
-        for (int dg = 0; dg < D / 8; ++dg) {
-            float f[8];
-            unpack8<KVT>(*reinterpret_cast<const uint4*>(kb + (int64_t)dg * bs * 8), f);
+        if (p.kv8) {                                       // K [NB,Hkv,D/16,bs,16] e4m3fn
+            const uint8_t* kb8 = static_cast<const uint8_t*>(p.kc) + ((blk * p.Hkv + hk) * (D / 16)) * (int64_t)bs * 16 + (int64_t)off * 16;
+            for (int dg = 0; dg < D / 16; ++dg) {
+                const uint4 w = *reinterpret_cast<const uint4*>(kb8 + (int64_t)dg * bs * 16);
+                const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s = fmaf(s_q[dg * 8 + e], f[e], s);
+                for (int e = 0; e < 16; ++e) s = fmaf(s_q[dg * 16 + e], fp8_to_f32((uint8_t)(ww[e >> 2] >> (8 * (e & 3)))) * p.k_scale, s);
+            }
+        } else {
+            const uint16_t* kb = kc + ((blk * p.Hkv + hk) * (D / 8)) * (int64_t)bs * 8 + (int64_t)off * 8;
+            for (int dg = 0; dg < D / 8; ++dg) {
+                float f[8];
+                unpack8<KVT>(*reinterpret_cast<const uint4*>(kb + (int64_t)dg * bs * 8), f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s = fmaf(s_q[dg * 8 + e], f[e], s);
+            }
         }
         if (p.softcap > 0.f) s = tanhf(s / p.softcap) * p.softcap;
         s_logits[i] = s;
@@ -378,8 +403,11 @@ __global__ void __launch_bounds__(256) paged_attn_paged_layout_kernel(const PAPa
         for (int i = 0; i < n; ++i) {
             const int tok = t0 + i;
             const int64_t blk = (int64_t)bt[tok / bs];
-            const uint16_t vv = vc[((blk * p.Hkv + hk) * D + d) * (int64_t)bs + tok % bs];
-            a = fmaf(s_logits[i], (KVT == MI355_DTYPE_BF16) ? bf16_to_f32(vv) : f16_bits_to_f32(vv), a);
+            const int64_t vo = ((blk * p.Hkv + hk) * D + d) * (int64_t)bs + tok % bs;
+            float vf;
+            if (p.kv8) vf = fp8_to_f32(static_cast<const uint8_t*>(p.vc)[vo]) * p.v_scale;
+            else { const uint16_t vv = vc[vo]; vf = (KVT == MI355_DTYPE_BF16) ? bf16_to_f32(vv) : f16_bits_to_f32(vv); }
+            a = fmaf(s_logits[i], vf, a);
         }
         const float o = a / lsum;
         if (p.max_partitions > 1) {
@@ -403,7 +431,7 @@ __global__ void __launch_bounds__(256) paged_attn_paged_layout_kernel(const PAPa
 //   * the whole partition's scores stay in registers -> one max per partition, no online rescale;
 //   * P is rounded to bf16 for the P.V MFMA (fp32 accumulate), output normalised per partition;
 //   * all K and V loads of the partition are issued before the first MFMA.
-template <int D32, int NT>
+template <int D32, int NT, bool KV8 = false>
 __global__ void __launch_bounds__(64) paged_attn_mfma_kernel(const PAParams p) {
     constexpr int D = 32 * D32, NTD = D / 16;
     const int hk = blockIdx.x, b = blockIdx.y, part = blockIdx.z;
@@ -436,21 +464,38 @@ __global__ void __launch_bounds__(64) paged_attn_mfma_kernel(const PAParams p) {
             qf[j] = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_stride +
                                                     (int64_t)(hk * G + c) * D + 32 * j + 8 * kg);
     }
-    // all K and V fragments of the partition
-    uint4 kf[NT][D32];
-    uint2 vf[NT][NTD];
+    // all K and V fragments of the partition (fp8 cache: raw bytes now, converted to bf16 fragments at use --
+    // e4m3 is exact in bf16; the dequantisation scales fold into the logit scale and the final normalisation)
+    typedef typename std::conditional<KV8, uint2, uint4>::type kraw_t;
+    typedef typename std::conditional<KV8, uint32_t, uint2>::type vraw_t;
+    kraw_t kf[NT][D32];
+    vraw_t vf[NT][NTD];
 #pragma unroll
     for (int it = 0; it < NT; ++it) {
-        const uint16_t* kb = kc + ((blk[it] * p.Hkv + hk) * (D / 8)) * (int64_t)bs * 8 + (int64_t)(off[it] + c) * 8;
+        if constexpr (KV8) {
+            const uint8_t* kb = static_cast<const uint8_t*>(p.kc) + ((blk[it] * p.Hkv + hk) * (D / 16)) * (int64_t)bs * 16 +
+                                (int64_t)(off[it] + c) * 16 + 8 * (kg & 1);
 #pragma unroll
-        for (int j = 0; j < D32; ++j) kf[it][j] = *reinterpret_cast<const uint4*>(kb + (int64_t)(4 * j + kg) * bs * 8);
+            for (int j = 0; j < D32; ++j) kf[it][j] = *reinterpret_cast<const uint2*>(kb + (int64_t)(2 * j + (kg >> 1)) * bs * 16);
+        } else {
+            const uint16_t* kb = kc + ((blk[it] * p.Hkv + hk) * (D / 8)) * (int64_t)bs * 8 + (int64_t)(off[it] + c) * 8;
+#pragma unroll
+            for (int j = 0; j < D32; ++j) kf[it][j] = *reinterpret_cast<const uint4*>(kb + (int64_t)(4 * j + kg) * bs * 8);
+        }
     }
 #pragma unroll
     for (int it = 0; it < NT; ++it) {
-        const uint16_t* vb = vc + ((blk[it] * p.Hkv + hk) * D + c) * (int64_t)bs + off[it] + 4 * kg;
+        if constexpr (KV8) {
+            const uint8_t* vb = static_cast<const uint8_t*>(p.vc) + ((blk[it] * p.Hkv + hk) * D + c) * (int64_t)bs + off[it] + 4 * kg;
 #pragma unroll
-        for (int nt = 0; nt < NTD; ++nt) vf[it][nt] = *reinterpret_cast<const uint2*>(vb + (int64_t)(16 * nt) * bs);
+            for (int nt = 0; nt < NTD; ++nt) vf[it][nt] = *reinterpret_cast<const uint32_t*>(vb + (int64_t)(16 * nt) * bs);
+        } else {
+            const uint16_t* vb = vc + ((blk[it] * p.Hkv + hk) * D + c) * (int64_t)bs + off[it] + 4 * kg;
+#pragma unroll
+            for (int nt = 0; nt < NTD; ++nt) vf[it][nt] = *reinterpret_cast<const uint2*>(vb + (int64_t)(16 * nt) * bs);
+        }
     }
+    const float qk_scale = KV8 ? p.scale * p.k_scale : p.scale;
     // ---- S^T = K . Q^T : lane (head c, tokens 4kg+v)
     float sc[NT][4];
     float m = -1e30f;
@@ -458,12 +503,16 @@ __global__ void __launch_bounds__(64) paged_attn_mfma_kernel(const PAParams p) {
     for (int it = 0; it < NT; ++it) {
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < D32; ++j)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[it][j]),
+        for (int j = 0; j < D32; ++j) {
+            uint4 ka;
+            if constexpr (KV8) { const uint2 lo = fp8x4_to_bf16x4(kf[it][j].x), hi = fp8x4_to_bf16x4(kf[it][j].y); ka = make_uint4(lo.x, lo.y, hi.x, hi.y); }
+            else ka = kf[it][j];
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ka),
                                                           __builtin_bit_cast(bf16x8_t, qf[j]), acc, 0, 0, 0);
+        }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            float s = acc[v] * p.scale;
+            float s = acc[v] * qk_scale;
             if (p.softcap > 0.f) s = tanhf(s / p.softcap) * p.softcap;
             const bool ok = t0 + 16 * it + 4 * kg + v < t1;
             s = ok ? s : -1e30f;
@@ -498,7 +547,8 @@ __global__ void __launch_bounds__(64) paged_attn_mfma_kernel(const PAParams p) {
         const bool partial = t0 + 16 * it + 16 > t1;              // tile reaches beyond the context
 #pragma unroll
         for (int nt = 0; nt < NTD; ++nt) {
-            uint2 vv = vf[it][nt];
+            uint2 vv;
+            if constexpr (KV8) vv = fp8x4_to_bf16x4(vf[it][nt]); else vv = vf[it][nt];
             if (partial) {                                        // never multiply 0 by unwritten (maybe NaN) V
                 const int tk = t0 + 16 * it + 4 * kg;
                 if (tk + 0 >= t1) vv.x &= 0xFFFF0000u;
@@ -517,7 +567,7 @@ __global__ void __launch_bounds__(64) paged_attn_mfma_kernel(const PAParams p) {
         const float lh = __shfl(lsum, head, 64), mh = __shfl(m, head, 64);
         if (head >= G) continue;
         const int h = hk * G + head;
-        const float inv = lh > 0.f ? 1.f / lh : 0.f;
+        const float inv = (lh > 0.f ? 1.f / lh : 0.f) * (KV8 ? p.v_scale : 1.f);
         if (p.max_partitions > 1) {
             const int64_t pi = ((int64_t)b * p.H + h) * p.max_partitions + part;
             if (p.arrive) {
@@ -609,6 +659,13 @@ template <int D32>
 static int launch_mfma(const PAParams& p, int B, int P, hipStream_t st) {
     dim3 grid(p.Hkv, B, P), block(64);
     const int nt = p.partition_size / 16;
+    if (p.kv8) {
+        if (nt == 2) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 2, true>), grid, block, 0, st, p);
+        else if (nt == 4) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 4, true>), grid, block, 0, st, p);
+        else if (nt == 8) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 8, true>), grid, block, 0, st, p);
+        else return (int)hipErrorInvalidValue;
+        return (int)hipGetLastError();
+    }
     if (nt == 2) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 2>), grid, block, 0, st, p);
     else if (nt == 4) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 4>), grid, block, 0, st, p);
     else if (nt == 8) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 8>), grid, block, 0, st, p);
@@ -648,6 +705,7 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
     if (dtype != MI355_DTYPE_BF16 && dtype != MI355_DTYPE_F16) return (int)hipErrorInvalidValue;
     hipStream_t st = to_stream(stream);
     int rc;
+    if (p.kv8 && (layout != MI355_KV_PAGED || dtype != MI355_DTYPE_BF16 || (p.D % 16))) return (int)hipErrorInvalidValue;
     if (layout == MI355_KV_FLASH) {
         if (P > 1)
             rc = (dtype == MI355_DTYPE_BF16) ? launch_flash<MI355_DTYPE_BF16, true>(p, B, P, st)
@@ -697,6 +755,31 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
 }
 
 void mi355_pa_set_fused(int v) { g_pa_fused = v; }
+
+// decode attention over an fp8 (e4m3fn) KV cache in the PAGED layout (K x = 16); partition_size 0 = one pass (v1)
+extern "C" int mi355_paged_attention_fp8(void* out, float* exp_sums, float* max_logits, float* tmp_out, const void* q,
+                                         const void* key_cache, const void* value_cache, const uint32_t* block_tables,
+                                         const uint32_t* context_lens, int32_t num_seqs, int32_t num_heads,
+                                         int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                                         int32_t max_blocks_per_seq, int32_t max_context_len, int32_t partition_size,
+                                         float scale, float softcap, float k_scale, float v_scale, int64_t stream) {
+    PAParams p{};
+    p.out = out; p.tmp_out = tmp_out; p.max_logits = max_logits; p.exp_sums = exp_sums;
+    p.q = q; p.kc = key_cache; p.vc = value_cache;
+    p.block_tables = block_tables; p.context_lens = context_lens;
+    p.H = num_heads; p.Hkv = num_kv_heads; p.D = head_dim; p.block_size = block_size; p.max_blocks = max_blocks_per_seq;
+    p.kv8 = 1; p.k_scale = k_scale; p.v_scale = v_scale;
+    p.scale = scale; p.softcap = softcap; p.q_stride = (int64_t)num_heads * head_dim;
+    if (partition_size <= 0) {
+        p.partition_size = max_context_len > 0 ? max_context_len : 1; p.max_partitions = 1;
+        return pa_dispatch(p, num_seqs, 1, MI355_KV_PAGED, MI355_DTYPE_BF16, stream);
+    }
+    if (!exp_sums || !max_logits || !tmp_out) return (int)hipErrorInvalidValue;
+    p.partition_size = partition_size;
+    p.max_partitions = (max_context_len + partition_size - 1) / partition_size;
+    if (p.max_partitions < 1) p.max_partitions = 1;
+    return pa_dispatch(p, num_seqs, p.max_partitions, MI355_KV_PAGED, MI355_DTYPE_BF16, stream);
+}
 
 extern "C" int mi355_paged_attention_v1(void* out, const void* q, const void* key_cache, const void* value_cache,
                                         const uint32_t* block_tables, const uint32_t* context_lens,

@@ -33,6 +33,8 @@ struct PrefillParams {
     int32_t H, Hkv, block_size, max_blocks;
     float scale_log2, softcap;      // scale * log2(e) (softcap == 0) ; softcap > 0: scale applied before tanh
     float scale;
+    int32_t kv8;                    // generic kernel only: e4m3fn cache (PAGED layout, K x = 16)
+    float k_scale, v_scale;
 };
 
 template <int DT>
@@ -268,8 +270,17 @@ __global__ void __launch_bounds__(64) prefill_attn_generic_kernel(const PrefillP
                 else { ko = (((blk * p.Hkv + hk) * (D / 8) + d / 8) * p.block_size + off) * 8 + d % 8;
                        vo = ((blk * p.Hkv + hk) * D + d) * p.block_size + off; }
             }
-            kv[i] = cvt(static_cast<const uint16_t*>(p.k)[ko]);
-            vv[i] = cvt(static_cast<const uint16_t*>(p.v)[vo]);
+            if (p.kv8) {
+                typedef float pf_f32x2 __attribute__((ext_vector_type(2)));
+                const size_t blk = bt[j / p.block_size]; const int off = j % p.block_size;
+                ko = (((blk * p.Hkv + hk) * (D / 16) + d / 16) * p.block_size + off) * 16 + d % 16;
+                const pf_f32x2 kk = __builtin_amdgcn_cvt_pk_f32_fp8((int)static_cast<const uint8_t*>(p.k)[ko], false);
+                const pf_f32x2 vq = __builtin_amdgcn_cvt_pk_f32_fp8((int)static_cast<const uint8_t*>(p.v)[vo], false);
+                kv[i] = kk.x * p.k_scale; vv[i] = vq.x * p.v_scale;
+            } else {
+                kv[i] = cvt(static_cast<const uint16_t*>(p.k)[ko]);
+                vv[i] = cvt(static_cast<const uint16_t*>(p.v)[vo]);
+            }
             dot += qv[i] * kv[i];
         }
         dot = wave_sum(dot) * p.scale;
@@ -332,5 +343,27 @@ extern "C" int mi355_prefill_attention(void* out, const void* q, const void* k, 
         if (dtype == MI355_DTYPE_BF16) hipLaunchKernelGGL((prefill_attn_generic_kernel<MI355_DTYPE_BF16>), grid, dim3(64), 0, st, p, head_dim, src);
         else hipLaunchKernelGGL((prefill_attn_generic_kernel<MI355_DTYPE_F16>), grid, dim3(64), 0, st, p, head_dim, src);
     }
+    return (int)hipGetLastError();
+}
+
+// prefill over an fp8 (e4m3fn) KV cache (PAGED layout, K x = 16): every key -- cached prefix and the current chunk,
+// already written by mi355_reshape_and_cache_fp8 -- is read from the cache.  Generic kernel (correctness path).
+extern "C" int mi355_prefill_attention_fp8(void* out, const void* q, const void* key_cache, const void* value_cache,
+                                           const uint32_t* block_tables, const uint32_t* context_lens,
+                                           const uint32_t* cu_seqlens_q, int32_t num_seqs, int32_t max_seqlen_q,
+                                           int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                                           int32_t max_blocks_per_seq, float scale, float softcap, float k_scale,
+                                           float v_scale, int32_t dtype, int64_t stream) {
+    if (num_seqs <= 0 || max_seqlen_q <= 0) return 0;
+    if (dtype != MI355_DTYPE_BF16 || (head_dim % 16) || head_dim > 256 || num_heads % num_kv_heads) return (int)hipErrorInvalidValue;
+    if (!key_cache || !value_cache || !block_tables || !context_lens) return (int)hipErrorInvalidValue;
+    PrefillParams p{};
+    p.out = out; p.q = q; p.k = key_cache; p.v = value_cache;
+    p.block_tables = block_tables; p.context_lens = context_lens; p.cu_q = cu_seqlens_q;
+    p.H = num_heads; p.Hkv = num_kv_heads; p.block_size = block_size; p.max_blocks = max_blocks_per_seq;
+    p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f; p.softcap = softcap > 0.f ? softcap : 0.f;
+    p.kv8 = 1; p.k_scale = k_scale; p.v_scale = v_scale;
+    dim3 grid(max_seqlen_q, num_heads, num_seqs);
+    hipLaunchKernelGGL((prefill_attn_generic_kernel<MI355_DTYPE_BF16>), grid, dim3(64), 0, (hipStream_t)stream, p, head_dim, SRC_PAGED);
     return (int)hipGetLastError();
 }

@@ -28,7 +28,8 @@ class DenseLlama:
                         max_blocks_per_seq=max_blocks_per_seq, rms_eps=cfg.rms_eps, rope_theta=cfg.rope_theta,
                         dtype=DT_BF16, rope_interleaved=int(rope_interleaved),
                         norm_type=1 if getattr(cfg, "layer_norm", False) else 0,
-                        rotary_dim=int(getattr(cfg, "rotary_dim", 0) or 0))
+                        rotary_dim=int(getattr(cfg, "rotary_dim", 0) or 0),
+                        kv_fp8=1 if getattr(cfg, "kv_fp8", False) else 0)
         self.h = lib.mi355_dense_create(ctypes.byref(c))
         if not self.h:
             raise RuntimeError("mi355_dense_create failed (bad config or no GPU memory)")

@@ -175,8 +175,8 @@ class PagedAttention:
                  alibi_slopes=None, fp8_kvcache=False):
         if sliding_window is not None or alibi_slopes is not None:
             raise NotImplementedError("sliding window / alibi are not used by the BASELINE models")
-        if fp8_kvcache:
-            raise NotImplementedError("fp8 KV cache: SURVEY section 8(f4), not built yet")
+        self.fp8_kvcache = bool(fp8_kvcache)           # is_fp8_keys (attention.rs:574,896): U8 cache, e4m3fn, PAGED layout
+        self.k_scale = self.v_scale = 1.0
         self.num_heads, self.head_dim, self.scale = num_heads, head_dim, float(scale)
         self.num_kv_heads = num_kv_heads or num_heads
         self._tmp = None
@@ -195,10 +195,47 @@ class PagedAttention:
         """q [T,H,D], k/v [T,Hkv,D] 16-bit.  Writes k,v into the paged cache (K1) then attends (K2/K3)."""
         if key_cache is None or value_cache is None:
             raise RuntimeError("PagedAttention.forward needs the paged KV cache")
+        if self.fp8_kvcache:
+            return self._forward_fp8(q, k, v, key_cache, value_cache, input_metadata, softcapping, partition_size)
         reshape_and_cache(k, v, key_cache, value_cache, input_metadata.slot_mapping)
         if input_metadata.is_prefill:
             return self.prefill(q, k, v, key_cache, value_cache, input_metadata, softcapping)
         return self.decode(q, key_cache, value_cache, input_metadata, softcapping, partition_size)
+
+    def _forward_fp8(self, q, k, v, key_cache, value_cache, meta, softcapping, partition_size):
+        """fp8 (e4m3fn) KV cache, PAGED layout with x = 16: K [NB,Hkv,D/16,bs,16], V [NB,Hkv,D,bs] uint8."""
+        if key_cache.dtype != torch.uint8 or key_cache.dim() != 5 or q.dtype != torch.bfloat16:
+            raise RuntimeError("fp8 KV cache: uint8 caches in the paged layout and bf16 activations")
+        T, H, D = q.shape
+        bs = key_cache.shape[3]
+        sc = float(softcapping) if softcapping else 0.0
+        _check(lib.mi355_reshape_and_cache_fp8(_dev(k), _dev(v), _dev(key_cache), _dev(value_cache),
+                                               _dev(meta.slot_mapping), T, self.num_kv_heads, D, bs, KV_PAGED,
+                                               self.k_scale, self.v_scale, _stream()), "reshape_and_cache_fp8")
+        out = torch.empty_like(q)
+        bt, cl = meta.block_tables, meta.context_lens
+        if meta.is_prefill:
+            n = meta.cu_seqlens_q.shape[0] - 1
+            _check(lib.mi355_prefill_attention_fp8(_dev(out), _dev(q), _dev(key_cache), _dev(value_cache), _dev(bt),
+                                                   _dev(cl), _dev(meta.cu_seqlens_q), n, meta.max_seqlen_q, H,
+                                                   self.num_kv_heads, D, bs, bt.shape[1], self.scale, sc,
+                                                   self.k_scale, self.v_scale, DT_BF16, _stream()), "prefill_attention_fp8")
+            return out
+        ps = choose_partition(T, self.num_kv_heads, meta.max_context_len) if partition_size is None else partition_size
+        if ps:
+            ps = 32 if ps <= 32 else (64 if ps <= 64 else 128)
+            P = -(-meta.max_context_len // ps)
+            tmp, mx, sm = self._workspace(T, P, q.device)
+            _check(lib.mi355_paged_attention_fp8(_dev(out), _dev(sm), _dev(mx), _dev(tmp), _dev(q), _dev(key_cache),
+                                                 _dev(value_cache), _dev(bt), _dev(cl), T, H, self.num_kv_heads, D, bs,
+                                                 bt.shape[1], meta.max_context_len, ps, self.scale, sc, self.k_scale,
+                                                 self.v_scale, _stream()), "paged_attention_fp8")
+        else:
+            _check(lib.mi355_paged_attention_fp8(_dev(out), None, None, None, _dev(q), _dev(key_cache),
+                                                 _dev(value_cache), _dev(bt), _dev(cl), T, H, self.num_kv_heads, D, bs,
+                                                 bt.shape[1], meta.max_context_len, 0, self.scale, sc, self.k_scale,
+                                                 self.v_scale, _stream()), "paged_attention_fp8")
+        return out
 
     def prefill(self, q, k, v, key_cache, value_cache, meta: InputMetadata, softcapping=None):
         """K4.  Cached prefix (cu_seqlens_k != cu_seqlens_q, `use_cached_kv` inputs.rs:133-143) -> keys come from

@@ -110,6 +110,27 @@ int mi355_prefill_attention(void* out, const void* q, const void* k, const void*
                             int32_t max_blocks_per_seq, float scale, float softcap, int32_t layout,
                             int32_t dtype, int64_t stream);
 
+/* fp8 KV cache (`--kvcache-dtype fp8`: U8 cache tensors src/main.rs:263-267, K layout x = 16 cache_engine.rs:304-311,
+ * PagedAttention built with is_fp8_keys attention.rs:574,896).  Values are stored as OCP e4m3fn(value / scale),
+ * round-to-nearest-even, saturating; k, v, q, out are bf16.  PAGED layout for the attention entry points. */
+int mi355_reshape_and_cache_fp8(const void* k, const void* v, void* key_cache, void* value_cache,
+                                const int64_t* slot_mapping, int32_t num_tokens, int32_t num_kv_heads,
+                                int32_t head_dim, int32_t block_size, int32_t layout, float k_scale, float v_scale,
+                                int64_t stream);
+/* partition_size 0 = one pass (v1; exp_sums / max_logits / tmp_out may be NULL), else v2 temporaries as above */
+int mi355_paged_attention_fp8(void* out, float* exp_sums, float* max_logits, float* tmp_out, const void* q,
+                              const void* key_cache, const void* value_cache, const uint32_t* block_tables,
+                              const uint32_t* context_lens, int32_t num_seqs, int32_t num_heads,
+                              int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                              int32_t max_blocks_per_seq, int32_t max_context_len, int32_t partition_size,
+                              float scale, float softcap, float k_scale, float v_scale, int64_t stream);
+int mi355_prefill_attention_fp8(void* out, const void* q, const void* key_cache, const void* value_cache,
+                                const uint32_t* block_tables, const uint32_t* context_lens,
+                                const uint32_t* cu_seqlens_q, int32_t num_seqs, int32_t max_seqlen_q,
+                                int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                                int32_t max_blocks_per_seq, float scale, float softcap, float k_scale,
+                                float v_scale, int32_t dtype, int64_t stream);
+
 /* replaces attention_rs::fused_rope::FusedRope::apply_inplace[_partial] -- layers/rotary_emb.rs:58-70.
  * q [T,H,D], k [T,Hkv,D] rotated in place; cos/sin f32 [max_seq, rotary_dim/2]; positions i64 [T];
  * is_rope_i != 0 -> interleaved pairs (GGUF llama), else half-split ("neox"). dtype F32 or BF16. */
@@ -313,6 +334,7 @@ typedef struct mi355_dense_config {
     int32_t rope_interleaved;  /* 0 = half-split ("neox", HF llama / qwen / stablelm), 1 = interleaved */
     int32_t norm_type;         /* 0 = RMSNorm, 1 = LayerNorm with bias (StableLM, stable_lm.rs:61-72) */
     int32_t rotary_dim;        /* <= head_dim; StableLM: partial_rotary_factor 0.25 (stable_lm.rs:28); 0 = head_dim */
+    int32_t kv_fp8;            /* 1 = `--kvcache-dtype fp8`: U8 e4m3fn cache (PAGED layout, x = 16), scale 1.0 */
 } mi355_dense_config;
 #define MI355_W_BQ 12 /* q_proj.bias (Qwen2, StableLM use_qkv_bias) */
 #define MI355_W_BK 13

@@ -36,6 +36,7 @@ class DenseConfig:
     qkv_bias: bool = False
     layer_norm: bool = False        # StableLM: LayerNorm with bias (stable_lm.rs:61-72)
     rotary_dim: int = 0             # 0 = head_dim; StableLM: 0.25 * head_dim (stable_lm.rs:28)
+    kv_fp8: bool = False            # `--kvcache-dtype fp8`: e4m3fn cache, every key/value read back from it
 
     @staticmethod
     def stablelm_3b():
@@ -138,8 +139,27 @@ class OracleDenseLlama:
 
     def new_cache(self, num_blocks):
         c = self.cfg
+        if c.kv_fp8:
+            ks, vs = ops.kv_cache_shapes(num_blocks, c.block_size, c.n_kv_heads, c.head_dim, 1, False)
+            return [(np.zeros(ks, np.uint8), np.zeros(vs, np.uint8)) for _ in range(c.n_layers)]
         ks, vs = ops.kv_cache_shapes(num_blocks, c.block_size, c.n_kv_heads, c.head_dim, 2, self.flash)
         return [(np.zeros(ks, np.uint16), np.zeros(vs, np.uint16)) for _ in range(c.n_layers)]
+
+    def _attend_fp8(self, meta, q, k, v, kc, vc, is_prefill):
+        """fp8 cache: write e4m3fn, then every key (prefix and current tokens) comes back dequantised."""
+        c = self.cfg
+        ops.reshape_and_cache_fp8(k, v, kc, vc, meta["slot_mapping"], False)
+        kb, vb = ops.fp8_cache_as_bf16_bits(kc, vc, False)
+        if not is_prefill:
+            return ops.paged_attention_decode(q, kb, vb, meta["block_tables"], meta["context_lens"], self.scale, False)
+        ys, cu = [], meta["cu_seqlens_q"]
+        for i in range(len(cu) - 1):
+            a, b = int(cu[i]), int(cu[i + 1])
+            n = int(meta["context_lens"][i])
+            table = meta["block_tables"][i]
+            kk, vv = ops.gather_kv(kb, vb, table, n, False)
+            ys.append(ops.prefill_attention(q[a:b], ops.bf16_bits_to_f32(kk), ops.bf16_bits_to_f32(vv), self.scale, cached=n - (b - a)))
+        return np.concatenate(ys, 0)
 
     def forward(self, meta, kv_caches, is_prefill=False):
         c, W = self.cfg, self.W
@@ -153,8 +173,16 @@ class OracleDenseLlama:
             v = _lin(x, lw["wv"], lw.get("bv")).reshape(T, c.n_kv_heads, c.head_dim)
             q = R(ops.rope_apply(q, self.cos, self.sin, pos, interleaved=False, rotary_dim=self.rot))   # f32 rope, back to dtype
             k = R(ops.rope_apply(k, self.cos, self.sin, pos, interleaved=False, rotary_dim=self.rot))
-            kb, vb = ops.f32_to_bf16_bits(k), ops.f32_to_bf16_bits(v)
             kc, vc = kv_caches[l]
+            if c.kv_fp8:
+                y = self._attend_fp8(meta, q, k, v, kc, vc, is_prefill)
+                y = y.reshape(T, c.n_heads * c.head_dim)
+                xs = R(_lin(y, lw["wo"]) + xs)
+                x = self._norm(xs, lw["ffn_norm"], lw.get("ffn_norm_b"))
+                gate, up = _lin(x, lw["w1"]), _lin(x, lw["w3"])
+                xs = R(_lin(G.silu_mul16(gate, up, DT), lw["w2"]) + xs)
+                continue
+            kb, vb = ops.f32_to_bf16_bits(k), ops.f32_to_bf16_bits(v)
             ops.reshape_and_cache(kb, vb, kc, vc, meta["slot_mapping"], self.flash)
             if is_prefill:
                 ys, cu = [], meta["cu_seqlens_q"]

@@ -309,3 +309,55 @@ def prefill_attention(q, k, v, scale, softcap=None, cached=0, rnd=None):
         p /= p.sum(-1, keepdims=True)
         out[:, h] = (p @ v[:, h // g].astype(np.float64)).astype(np.float32)
     return round_bf16(out) if rnd is None else rnd(out)
+
+
+# ------------------------------------------------------------------------------------------------ fp8 KV cache
+# `--kvcache-dtype fp8`: the cache tensors are U8 (src/main.rs:263-267), K layout x = 16 for 1-byte elements
+# (cache_engine.rs:304-311); PagedAttention is built with is_fp8_keys (attention.rs:574,896).  The conversion kernels
+# live in attention-rs (un-vendored): OCP e4m3fn, round-to-nearest-even, saturating at +-448, scale 1.0 [EXT].
+def f32_to_e4m3fn(x):
+    """f32 -> OCP e4m3fn bytes (uint8): RNE, saturate to +-448 (0x7E), NaN -> 0x7F."""
+    x = np.asarray(x, np.float32)
+    sign = (np.signbit(x)).astype(np.uint8) << 7
+    a = np.minimum(np.abs(x.astype(np.float64)), 448.0)
+    out = np.zeros(x.shape, np.uint8)
+    nz = a > 0
+    e = np.floor(np.log2(a, where=nz, out=np.zeros_like(a)))
+    e = np.clip(e, -6, 8)                                  # subnormals share exponent -6
+    step = np.exp2(e - 3)                                  # 3 mantissa bits
+    q = np.rint(a / step) * step                           # numpy rint = round half to even
+    q = np.minimum(q, 448.0)
+    e2 = np.floor(np.log2(q, where=q > 0, out=np.zeros_like(q)))
+    e2 = np.clip(e2, -6, 8)
+    man = np.rint(q / np.exp2(e2 - 3)).astype(np.int64)   # 8..15 normal, 0..7 subnormal
+    normal = man >= 8
+    bits = np.where(normal, ((e2 + 7).astype(np.int64) << 3) | (man - 8), man)
+    out = np.where(nz, bits, 0).astype(np.uint8)
+    out = np.where(np.isnan(x), np.uint8(0x7F), out | sign)
+    return out.astype(np.uint8)
+
+
+def e4m3fn_to_f32(b):
+    b = np.asarray(b, np.uint8).astype(np.int64)
+    s = np.where(b & 0x80, -1.0, 1.0)
+    e = (b >> 3) & 0xF
+    m = b & 7
+    v = np.where(e == 0, m / 8.0 * 2.0 ** -6, (1.0 + m / 8.0) * np.exp2(e - 7.0))
+    v = np.where((e == 15) & (m == 7), np.nan, v)
+    return (s * v).astype(np.float32)
+
+
+def reshape_and_cache_fp8(k_f32, v_f32, key_cache_u8, value_cache_u8, slot_mapping, flash_layout=False):
+    """k, v values [T,Hkv,D] (already rounded to the model dtype) -> e4m3fn bytes scattered like reshape_and_cache."""
+    reshape_and_cache(f32_to_e4m3fn(k_f32), f32_to_e4m3fn(v_f32), key_cache_u8, value_cache_u8, slot_mapping, flash_layout)
+
+
+def fp8_cache_as_bf16_bits(key_cache_u8, value_cache_u8, flash_layout=False):
+    """e4m3fn caches -> bf16-bit caches in the 2-byte layouts (every e4m3 value is exact in bf16), so the 16-bit
+    attention restatements apply unchanged.  PAGED K: [NB,Hkv,D/16,bs,16] -> [NB,Hkv,D/8,bs,8]."""
+    kf = f32_to_bf16_bits(e4m3fn_to_f32(key_cache_u8))
+    vf = f32_to_bf16_bits(e4m3fn_to_f32(value_cache_u8))
+    if not flash_layout:
+        nb, h, d16, s, x = kf.shape
+        kf = kf.reshape(nb, h, d16, s, 2, 8).transpose(0, 1, 2, 4, 3, 5).reshape(nb, h, d16 * 2, s, 8)
+    return np.ascontiguousarray(kf), np.ascontiguousarray(vf)

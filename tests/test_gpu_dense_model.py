@@ -135,3 +135,34 @@ def test_qwen2_gptq_shape_prompt_then_decode(lib):
         got = gm.forward(dmeta).cpu().numpy()
         assert _rel(got, ref) < 2e-2, (step, _rel(got, ref))
         assert [int(r.argmax()) for r in got] == [int(r.argmax()) for r in ref]
+
+
+def test_dense_llama_with_fp8_kv_cache(lib):
+    """`--kvcache-dtype fp8` on the 16-bit host path: e4m3fn cache (PAGED, x = 16), decode through the MFMA fp8
+    kernel / one-pass kernel, prompt step through the fp8 prefill kernel; oracle attends over the dequantised cache."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from candle_vllm_amd import dense_model as M
+    cfg = DL.DenseConfig.tiny()
+    cfg.kv_fp8 = True
+    W = DL.make_weights(cfg)
+    orc = DL.OracleDenseLlama(cfg, W, flash_layout=False)
+    rng = np.random.default_rng(31)
+    seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 33)], "block_table": [3, 7, 2]},
+            {"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 6)], "block_table": [1]}]
+    cache = orc.new_cache(16)
+    meta = O.prepare_prompt(seqs, cfg.block_size)
+    ref = orc.forward(meta, cache, is_prefill=True)
+    gm = M.DenseLlama(cfg, max_batch=4, kv_layout=M.KV_PAGED)
+    gm.load_oracle_weights(W)
+    gm.alloc_kv_cache(16)
+    got = gm.forward(meta, is_prefill=True).cpu().numpy()
+    # an e4m3 rounding flip of a K/V entry is a 6 % change of that entry: looser than the bf16-cache bound
+    assert _rel(got, ref) < 6e-2, _rel(got, ref)
+    for step in range(2):
+        for s, row in zip(seqs, ref):
+            s["tokens"].append(int(row.argmax()))
+        dmeta = O.prepare_decode(seqs, cfg.block_size)
+        ref = orc.forward(dmeta, cache)
+        got = gm.forward(dmeta).cpu().numpy()
+        assert _rel(got, ref) < 6e-2, (step, _rel(got, ref))

@@ -1,0 +1,134 @@
+"""fp8 (OCP e4m3fn) KV cache (`--kvcache-dtype fp8`): cache write bit-exact vs the numpy conversion
+(round-to-nearest-even, saturating), decode attention (MFMA partitions and the one-pass kernel) and prefill over the
+quantised cache vs the oracle run on the dequantised cache."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import ops as O               # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def cv(lib):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    import candle_vllm_amd.ops as ops
+    return ops
+
+
+def bf16_dev(vals_f32):
+    bits = O.f32_to_bf16_bits(np.asarray(vals_f32, np.float32))
+    return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).cuda().view(torch.bfloat16)
+
+
+def bf16_host(t):
+    return O.bf16_bits_to_f32(t.detach().view(torch.int16).cpu().numpy().view(np.uint16))
+
+
+def test_e4m3_cache_write_is_bit_exact(cv):
+    rng = np.random.default_rng(0)
+    NB, bs, Hkv, D, T = 6, 16, 2, 64, 41
+    # values that hit ties, subnormals, saturation and negatives
+    base = np.concatenate([rng.normal(0, 1, T * Hkv * D - 16), [0.0, -0.0, 1.0625, 1.1875, 447.9, 460.0, -1e6, 2 ** -9,
+                                                               2 ** -10, 3 * 2 ** -10, 0.0175, -0.0175, 300.0, 17.0, 0.3, -0.3]])
+    k = O.round_bf16(base.reshape(T, Hkv, D).astype(np.float32))
+    v = O.round_bf16(rng.normal(0, 30, (T, Hkv, D)).astype(np.float32))
+    ks, vs = O.kv_cache_shapes(NB, bs, Hkv, D, 1, False)
+    kc = rng.integers(0, 256, ks).astype(np.uint8)
+    vc = rng.integers(0, 256, vs).astype(np.uint8)
+    slots = rng.permutation(NB * bs)[:T].astype(np.int64)
+    slots[5] = -1
+    kcd, vcd = torch.from_numpy(kc).cuda(), torch.from_numpy(vc).cuda()
+    kd, vd, sd = bf16_dev(k), bf16_dev(v), torch.from_numpy(slots).cuda()       # keep the device buffers alive
+    rc = cv.lib.mi355_reshape_and_cache_fp8(kd.data_ptr(), vd.data_ptr(), kcd.data_ptr(), vcd.data_ptr(),
+                                            sd.data_ptr(), T, Hkv, D, bs, cv.KV_PAGED, 1.0, 1.0, 0)
+    assert rc == 0
+    torch.cuda.synchronize()
+    O.reshape_and_cache_fp8(k, v, kc, vc, slots, False)
+    assert np.array_equal(kcd.cpu().numpy(), kc)
+    assert np.array_equal(vcd.cpu().numpy(), vc)
+
+
+@pytest.mark.parametrize("H,Hkv,D,bs,ctxs,ps", [(8, 2, 128, 64, [300, 64, 129], None), (4, 4, 64, 16, [40, 7], 0),
+                                                (8, 2, 128, 16, [200, 33], 32), (4, 2, 80, 16, [50], 0)])
+def test_decode_attention_over_fp8_cache(cv, H, Hkv, D, bs, ctxs, ps):
+    if D % 16:
+        pytest.skip("x = 16 layout needs head_dim % 16 == 0")
+    rng = np.random.default_rng(D + bs + len(ctxs))
+    B = len(ctxs)
+    nblk = [-(-c // bs) for c in ctxs]
+    NB = sum(nblk) + 2
+    ids = rng.permutation(NB)[: sum(nblk)]
+    ks, vs = O.kv_cache_shapes(NB, bs, Hkv, D, 1, False)
+    kc = np.zeros(ks, np.uint8)
+    vc = np.zeros(vs, np.uint8)
+    # unused slots hold arbitrary bytes, including the NaN encodings 0x7F / 0xFF
+    kc[:] = rng.integers(0, 256, ks)
+    vc[:] = rng.integers(0, 256, vs)
+    seqs, o = [], 0
+    pa = cv.PagedAttention(H, D, 1.0 / np.sqrt(D), Hkv, fp8_kvcache=True)
+    kcd, vcd = torch.from_numpy(kc).cuda(), torch.from_numpy(vc).cuda()
+    for b, c in enumerate(ctxs):
+        table = ids[o:o + nblk[b]].tolist()
+        o += nblk[b]
+        seqs.append({"tokens": list(range(c)), "block_table": table})
+        kk = O.round_bf16(rng.normal(0, 1.5, (c - 1, Hkv, D)).astype(np.float32))
+        vv = O.round_bf16(rng.normal(0, 1.5, (c - 1, Hkv, D)).astype(np.float32))
+        slots = np.array([table[j // bs] * bs + j % bs for j in range(c - 1)], np.int64)
+        O.reshape_and_cache_fp8(kk, vv, kc, vc, slots, False)
+    kcd.copy_(torch.from_numpy(kc)); vcd.copy_(torch.from_numpy(vc))
+    meta = O.prepare_decode(seqs, bs)
+    im = cv.InputMetadata.from_oracle_meta(meta, "cuda")
+    q = O.round_bf16(rng.normal(0, 1, (B, H, D)).astype(np.float32))
+    k = O.round_bf16(rng.normal(0, 1.5, (B, Hkv, D)).astype(np.float32))
+    v = O.round_bf16(rng.normal(0, 1.5, (B, Hkv, D)).astype(np.float32))
+    out = pa.forward(bf16_dev(q), bf16_dev(k), bf16_dev(v), None, kcd, vcd, im, partition_size=ps)
+    O.reshape_and_cache_fp8(k, v, kc, vc, meta["slot_mapping"], False)
+    assert np.array_equal(kcd.cpu().numpy(), kc) and np.array_equal(vcd.cpu().numpy(), vc)
+    kb, vb = O.fp8_cache_as_bf16_bits(kc, vc, False)
+    ref = O.paged_attention_decode(q, kb, vb, meta["block_tables"], meta["context_lens"], 1.0 / np.sqrt(D), False)
+    got = bf16_host(out)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 2e-2 * max(1.0, np.abs(ref).max())     # bf16 P and output rounding
+
+
+def test_prefill_over_fp8_cache(cv):
+    rng = np.random.default_rng(9)
+    H, Hkv, D, bs = 4, 2, 64, 16
+    lens, cached = [37, 20], [0, 24]
+    pa = cv.PagedAttention(H, D, 1.0 / np.sqrt(D), Hkv, fp8_kvcache=True)
+    ctx = [c + l for c, l in zip(cached, lens)]
+    nblk = [-(-c // bs) for c in ctx]
+    NB = sum(nblk) + 1
+    ids = rng.permutation(NB)[: sum(nblk)]
+    ks, vs = O.kv_cache_shapes(NB, bs, Hkv, D, 1, False)
+    kc = rng.integers(0, 256, ks).astype(np.uint8)
+    vc = rng.integers(0, 256, vs).astype(np.uint8)
+    seqs, o, k_all, v_all = [], 0, [], []
+    for b, c in enumerate(ctx):
+        table = ids[o:o + nblk[b]].tolist()
+        o += nblk[b]
+        seqs.append({"tokens": list(range(c)), "block_table": table})
+        k_all.append(O.round_bf16(rng.normal(0, 1.5, (c, Hkv, D)).astype(np.float32)))
+        v_all.append(O.round_bf16(rng.normal(0, 1.5, (c, Hkv, D)).astype(np.float32)))
+        if cached[b]:
+            slots = np.array([table[j // bs] * bs + j % bs for j in range(cached[b])], np.int64)
+            O.reshape_and_cache_fp8(k_all[b][:cached[b]], v_all[b][:cached[b]], kc, vc, slots, False)
+    meta = O.prepare_prompt(seqs, bs, cached)
+    im = cv.InputMetadata.from_oracle_meta(meta, "cuda", is_prefill=True)
+    q = [O.round_bf16(rng.normal(0, 1, (l, H, D)).astype(np.float32)) for l in lens]
+    kcd, vcd = torch.from_numpy(kc).cuda(), torch.from_numpy(vc).cuda()
+    kn = np.concatenate([k_all[b][cached[b]:] for b in range(2)])
+    vn = np.concatenate([v_all[b][cached[b]:] for b in range(2)])
+    out = bf16_host(pa.forward(bf16_dev(np.concatenate(q)), bf16_dev(kn), bf16_dev(vn), None, kcd, vcd, im))
+    O.reshape_and_cache_fp8(kn, vn, kc, vc, meta["slot_mapping"], False)
+    assert np.array_equal(kcd.cpu().numpy(), kc)
+    o = 0
+    for b, l in enumerate(lens):
+        kq = O.e4m3fn_to_f32(O.f32_to_e4m3fn(k_all[b]))
+        vq = O.e4m3fn_to_f32(O.f32_to_e4m3fn(v_all[b]))
+        ref = O.prefill_attention(q[b], kq, vq, 1.0 / np.sqrt(D), cached=cached[b])
+        assert np.abs(out[o:o + l] - ref).max() <= 2e-2 * max(1.0, np.abs(ref).max())
+        o += l
