@@ -44,6 +44,7 @@ class QmmDesc(ctypes.Structure):
         ("q_out", c_vp), ("key_cache", c_vp), ("value_cache", c_vp),
         ("num_heads", c_i32), ("num_kv_heads", c_i32), ("head_dim", c_i32), ("rotary_dim", c_i32),
         ("block_size", c_i32), ("kv_layout", c_i32),
+        ("moe_expert_ids", c_vp), ("moe_pairs", c_i32), ("moe_x_div", c_i32), ("moe_expert_stride", c_i64 * 3),
     ]
 
 
@@ -81,6 +82,8 @@ _sig("mi355_qweight_repack", ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_i64])
 _sig("mi355_qmatmul", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64])
 _sig("mi355_qmatmul_fused", ctypes.c_int, [ctypes.POINTER(QmmDesc), c_i64])
 _sig("mi355_set_tuning", None, [c_i32, c_i32])
+_sig("mi355_moe_route", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64])
+_sig("mi355_moe_combine", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64])
 for _n in ("marlin_4bit_f16", "marlin_4bit_bf16", "marlin_awq_4bit_f16", "marlin_awq_4bit_bf16"):
     _sig(_n, None, [c_vp] * 6 + [c_i32] * 3 + [c_vp, c_i32, c_i64])
 _sig("gemm_half_q_half_alt", None, [c_vp] * 6 + [c_i32] * 4 + [c_i64])

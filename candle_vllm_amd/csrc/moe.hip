@@ -1,0 +1,81 @@
+// Mixture-of-experts routing for the GGUF llama path (Mixtral): `MlpOrMoe::forward`, src/openai/models/quantized_llama.rs:
+// 56-123.  The reference pulls the routing weights to the host (`to_vec2`, :70), sorts there and issues per-expert
+// index_select / index_add; here routing stays on the device so the decode graph has no host round trip:
+//   mi355_moe_route   : rms_norm -> router logits -> softmax -> top-k -> renormalised weights     (one workgroup / token)
+//   expert mat-vecs   : qmm_kernel with blockIdx.y = (token, slot) pair and the expert id read on the device
+//   mi355_moe_combine : residual += sum_j w_j * expert_j(x)
+#include "common.h"
+#include "../../include/mi355_vllm.h"
+
+__global__ void __launch_bounds__(256) moe_route_kernel(int32_t* __restrict__ ids, float* __restrict__ wts, const float* __restrict__ x,
+                                                        const float* __restrict__ norm_w, float eps, const float* __restrict__ gate,
+                                                        int hidden, int E, int K) {
+    __shared__ float red[16];
+    __shared__ float s_logit[256];
+    const int t = blockIdx.x;
+    const float* xr = x + (size_t)t * hidden;
+    float inv = 1.f;
+    if (norm_w) {
+        float ss = 0.f;
+        for (int i = threadIdx.x; i < hidden; i += blockDim.x) ss += xr[i] * xr[i];
+        inv = rsqrtf(block_sum(ss, red) / (float)hidden + eps);
+    }
+    for (int e = 0; e < E; ++e) {                               // E <= 256 experts, each a block-wide dot product
+        float acc = 0.f;
+        const float* g = gate + (size_t)e * hidden;
+        for (int i = threadIdx.x; i < hidden; i += blockDim.x) {
+            const float xv = norm_w ? xr[i] * inv * norm_w[i] : xr[i];
+            acc = fmaf(xv, g[i], acc);
+        }
+        acc = block_sum(acc, red);
+        if (threadIdx.x == 0) s_logit[e] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = -INFINITY;
+        for (int e = 0; e < E; ++e) m = fmaxf(m, s_logit[e]);
+        float den = 0.f;
+        for (int e = 0; e < E; ++e) { s_logit[e] = expf(s_logit[e] - m); den += s_logit[e]; }
+        for (int e = 0; e < E; ++e) s_logit[e] /= den;          // softmax_last_dim
+        float sum = 0.f;
+        for (int j = 0; j < K; ++j) {                           // selection sort = stable descending order
+            int best = -1; float bv = -INFINITY;
+            for (int e = 0; e < E; ++e) {
+                bool taken = false;
+                for (int q = 0; q < j; ++q) taken |= ids[(size_t)t * K + q] == e;
+                if (!taken && s_logit[e] > bv) { bv = s_logit[e]; best = e; }
+            }
+            ids[(size_t)t * K + j] = best;
+            wts[(size_t)t * K + j] = bv;
+            sum += bv;
+        }
+        for (int j = 0; j < K; ++j) wts[(size_t)t * K + j] /= sum;
+    }
+}
+
+__global__ void __launch_bounds__(256) moe_combine_kernel(float* __restrict__ ys, const float* __restrict__ yp, const float* __restrict__ wts,
+                                                          int hidden, int K, int accumulate) {
+    const int t = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hidden) return;
+    float acc = accumulate ? ys[(size_t)t * hidden + i] : 0.f;
+    for (int j = 0; j < K; ++j) acc = fmaf(wts[(size_t)t * K + j], yp[((size_t)t * K + j) * hidden + i], acc);
+    ys[(size_t)t * hidden + i] = acc;
+}
+
+extern "C" int mi355_moe_route(int32_t* expert_ids, float* weights, const float* x, const float* norm_weight, float norm_eps,
+                               const float* gate_inp, int32_t num_tokens, int32_t hidden, int32_t n_expert, int32_t top_k,
+                               int64_t stream) {
+    if (num_tokens <= 0) return 0;
+    if (n_expert < 1 || n_expert > 256 || top_k < 1 || top_k > n_expert) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(moe_route_kernel, dim3(num_tokens), dim3(256), 0, to_stream(stream), expert_ids, weights, x, norm_weight,
+                       norm_eps, gate_inp, hidden, n_expert, top_k);
+    return (int)hipGetLastError();
+}
+extern "C" int mi355_moe_combine(float* ys, const float* y_pairs, const float* weights, int32_t num_tokens, int32_t hidden,
+                                 int32_t top_k, int32_t accumulate, int64_t stream) {
+    if (num_tokens <= 0) return 0;
+    hipLaunchKernelGGL(moe_combine_kernel, dim3((hidden + 255) / 256, num_tokens), dim3(256), 0, to_stream(stream), ys, y_pairs,
+                       weights, hidden, top_k, accumulate);
+    return (int)hipGetLastError();
+}

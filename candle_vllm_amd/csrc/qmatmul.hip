@@ -197,6 +197,11 @@ struct QmmArgs {
     uint16_t* vcache;
     int32_t Hq, Hkv, D, rot, block_size, kv_layout;
     int32_t dbg;              // experiments: 1 = stream the weights but skip unpack/MFMA (memory-path probe)
+    // mixture of experts (quantized_llama.rs:56-123 on the device): blockIdx.y = (token, slot) pair; the pair's expert
+    // id is read from device memory and selects the weight slab, its x row is pair / moe_xdiv, its out row is pair
+    const int32_t* moe_expert;
+    int32_t moe_pairs, moe_xdiv;
+    int64_t moe_stride[3];    // bytes between consecutive experts of each segment
 };
 
 struct TileRegs { uint4 a, b, c, d; uint32_t e; };
@@ -454,7 +459,17 @@ __device__ __forceinline__ float silu_f(float g) { return g / (1.f + __expf(-g))
 // so the compiler emits counted vmcnt waits and ~QMM_PF KiB-sized loads per lane stay in flight.  There is no
 // workgroup-level prologue: the only barrier is the one in front of the epilogue.
 template <int BT, int R, int WT>
-__global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) {
+__global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a_in) {
+    QmmArgs a = a_in;
+    if (a.moe_expert) {                                           // wave-uniform: everything below stays scalar
+        const int pair = blockIdx.y;
+        const int64_t e = a.moe_expert[pair];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) a.seg[s].w += e * a.moe_stride[s];
+        const size_t xes = (a.x_dtype == MI355_DTYPE_BF16) ? 2 : 4;
+        a.x = static_cast<const uint8_t*>(a.x) + (size_t)(pair / a.moe_xdiv) * a.ldx * xes;
+        a.out += (size_t)pair * a.ldo;
+    }
     constexpr int NV = BT < 4 ? BT : 4;
     constexpr int PF = (R > QMM_PF_MIN) ? R : QMM_PF_MIN;
     constexpr int PFK = PF / R;                                  // ring depth in k-blocks
@@ -1358,7 +1373,7 @@ static int qmm_launch_btrw(QmmArgs& a, int n_wg, int NW, hipStream_t st) {
     if (NW <= 0) NW = qmm_pick_nw<BT, R, WT>(n_wg, a.K / 256);
     const size_t shm = qmm_lds_bytes(BT, R, NW);
     if (shm > 160 * 1024) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL((qmm_kernel<BT, R, WT>), dim3(n_wg), dim3(64 * NW), shm, st, a);
+    hipLaunchKernelGGL((qmm_kernel<BT, R, WT>), dim3(n_wg, a.moe_expert ? a.moe_pairs : 1), dim3(64 * NW), shm, st, a);
     return (int)hipGetLastError();
 }
 
@@ -1412,6 +1427,11 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
     int wt = a.seg[0].type;                                   // uniform tile type of the launch, else 0 (mixed)
     for (int s = 1; s < a.nseg; ++s) if (a.seg[s].type != wt) wt = 0;
     a.dbg = g_tune_dbg;
+    if (a.moe_expert) {                                       // every (token, slot) pair is a 1-token mat-vec of its own expert
+        if (a.moe_pairs < 1 || a.moe_xdiv < 1 || a.epi == MI355_EPI_QKV_ROPE_CACHE || a.epi == MI355_EPI_RESID) return (int)hipErrorInvalidValue;
+        a.B = 1;
+        return qmm_launch_bt<1>(a, R, wt, n_wg, NW, st);
+    }
     const int B = a.B;
     const size_t xes = (a.x_dtype == MI355_DTYPE_BF16) ? 2 : 4;
     const uint8_t* x0 = static_cast<const uint8_t*>(a.x);
@@ -1504,5 +1524,7 @@ extern "C" int mi355_qmatmul_fused(const mi355_qmm_desc* d, int64_t stream) {
     if (a.epi == MI355_EPI_RESID && !a.resid) return (int)hipErrorInvalidValue;
     if ((a.epi == MI355_EPI_STORE || a.epi == MI355_EPI_RESID || a.epi == MI355_EPI_SILU_MUL) && !a.out)
         return (int)hipErrorInvalidValue;
+    a.moe_expert = d->moe_expert_ids; a.moe_pairs = d->moe_pairs; a.moe_xdiv = d->moe_x_div;
+    for (int s = 0; s < 3; ++s) a.moe_stride[s] = d->moe_expert_stride[s];
     return mi355_qmm_launch(a, stream);
 }

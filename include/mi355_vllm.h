@@ -201,8 +201,26 @@ typedef struct mi355_qmm_desc {
     void* key_cache;            /* bf16 paged cache                                                    */
     void* value_cache;
     int32_t num_heads, num_kv_heads, head_dim, rotary_dim, block_size, kv_layout;
+    /* mixture of experts (NULL / 0 = off): one launch covers moe_pairs (token, slot) pairs; pair p multiplies row
+     * p / moe_x_div of x with expert moe_expert_ids[p] (DEVICE i32 [moe_pairs]) whose tiles start
+     * moe_expert_stride[s] bytes after the previous expert's in w_tiles[s]; out row = p.  num_tokens is ignored;
+     * epilogues STORE and SILU_MUL only. */
+    const int32_t* moe_expert_ids;
+    int32_t moe_pairs, moe_x_div;
+    int64_t moe_expert_stride[3];
 } mi355_qmm_desc;
 int mi355_qmatmul_fused(const mi355_qmm_desc* desc, int64_t stream);
+/* MoE routing on the device (MlpOrMoe::forward, quantized_llama.rs:56-123, without the host round trip):
+ * logits = gate_inp . rms_norm(x) ; softmax ; top-k (descending, ties -> lower expert id, as the stable sort there);
+ * weights renormalised over the selected experts.  x f32 [T, hidden] (un-normalised residual stream when norm_weight
+ * != NULL), gate_inp f32 [n_expert, hidden]; expert_ids i32 [T, k], weights f32 [T, k]. */
+int mi355_moe_route(int32_t* expert_ids, float* weights, const float* x, const float* norm_weight, float norm_eps,
+                    const float* gate_inp, int32_t num_tokens, int32_t hidden, int32_t n_expert, int32_t top_k,
+                    int64_t stream);
+/* ys[t] (+)= sum_j weights[t][j] * y_pairs[t*k + j]   (index_add of the weighted expert outputs); accumulate != 0
+ * adds into ys (the residual stream), else overwrites */
+int mi355_moe_combine(float* ys, const float* y_pairs, const float* weights, int32_t num_tokens, int32_t hidden,
+                      int32_t top_k, int32_t accumulate, int64_t stream);
 /* experiment knob (0: waves per workgroup, 1: row tiles per workgroup; value 0 = heuristic) */
 void mi355_set_tuning(int32_t key, int32_t value);
 

@@ -93,12 +93,56 @@ def _qmm(x, tw, o2):
     return kq.qmatmul_o2(x, blocks, t) if o2 else kq.qmatmul_o1(x, blocks, t)
 
 
+def moe_route(x, gate_inp, top_k):
+    """MlpOrMoe::forward routing (quantized_llama.rs:63-91): softmax over the router logits, top-k by a STABLE
+    descending sort (ties -> lower expert id), weights renormalised over the selected experts.
+    Returns ids [T,k] int32, weights [T,k] f32."""
+    logits = np.asarray(x, np.float64) @ np.asarray(gate_inp, np.float64).T
+    p = np.exp(logits - logits.max(-1, keepdims=True))
+    p = (p / p.sum(-1, keepdims=True)).astype(np.float32)
+    ids = np.argsort(-p, axis=-1, kind="stable")[:, :top_k].astype(np.int32)
+    w = np.take_along_axis(p, ids, axis=-1)
+    return ids, (w / w.sum(-1, keepdims=True)).astype(np.float32)
+
+
+def moe_forward(x, lw, top_k, o2=False):
+    """ys = sum_j w_j * expert_j(x) (quantized_llama.rs:93-119); lw["experts"] = list of {"w1","w2","w3"}."""
+    ids, w = moe_route(x, lw["gate_inp"], top_k)
+    ys = np.zeros_like(np.asarray(x, np.float32))
+    for t in range(x.shape[0]):
+        for j in range(top_k):
+            ex = lw["experts"][int(ids[t, j])]
+            h = ops.silu_mul(_qmm(x[t:t + 1], ex["w1"], o2), _qmm(x[t:t + 1], ex["w3"], o2))
+            ys[t] += w[t, j] * _qmm(h, ex["w2"], o2)[0]
+    return ys
+
+
+def make_moe_weights(cfg, n_expert, seed=1234, std=0.02):
+    """Mixtral-style synthetic weights: the dense MLP of every layer replaced by n_expert Q4_K experts + an F32 router
+    (tensor names ffn_gate_inp / ffn_{gate,down,up}.{i}, quantized_llama.rs:347-365)."""
+    W = make_weights(cfg, seed=seed, std=std)
+    rng = np.random.default_rng(seed + 99)
+    I, hid = cfg.intermediate, cfg.hidden
+    for lw in W["layers"]:
+        for k in ("w1", "w2", "w3"):
+            lw.pop(k)
+        lw["gate_inp"] = rng.normal(0.0, 0.5, size=(n_expert, hid)).astype(np.float32)
+        lw["experts"] = []
+        for _ in range(n_expert):
+            def q(rows, cols):
+                w = rng.normal(0.0, std, size=(rows, cols)).astype(np.float32)
+                return (kq.GGML_Q4_K, kq.quantize(w, kq.GGML_Q4_K))
+            lw["experts"].append({"w1": q(I, hid), "w2": q(hid, I), "w3": q(I, hid)})
+    return W
+
+
 class OracleLlama:
     def __init__(self, cfg, W, flash_layout=True, o2=False, comm=None):
         """comm: None, or an object with all_reduce(np.ndarray)->np.ndarray and all_gather(np.ndarray)->list
         (tensor-parallel run: cfg/W are then the LOCAL shard, see candle_vllm_amd/tp.py; collectives C1/C2/C3
         of src/openai/distributed.rs:696-711,1632-1667)."""
         self.cfg, self.W, self.flash, self.o2, self.comm = cfg, W, flash_layout, o2, comm
+        self.moe_top_k = 2                                           # llama.expert_used_count (Mixtral: 2)
         self.cos, self.sin = ops.rope_tables(cfg.rope_theta, cfg.head_dim, cfg.max_seq)
         self.scale = 1.0 / np.sqrt(float(cfg.head_dim))
 
@@ -141,8 +185,11 @@ class OracleLlama:
                 attn = self.comm.all_reduce(attn)                      # C1 (attention.rs:1005-1009)
             xs = attn + xs
             x = ops.rms_norm(xs, lw["ffn_norm"], c.rms_eps)
-            h = ops.silu_mul(_qmm(x, lw["w1"], self.o2), _qmm(x, lw["w3"], self.o2))
-            mlp = _qmm(h, lw["w2"], self.o2)
+            if "experts" in lw:
+                mlp = moe_forward(x, lw, self.moe_top_k, self.o2)
+            else:
+                h = ops.silu_mul(_qmm(x, lw["w1"], self.o2), _qmm(x, lw["w3"], self.o2))
+                mlp = _qmm(h, lw["w2"], self.o2)
             if self.comm is not None:
                 mlp = self.comm.all_reduce(mlp)                        # C2 (quantized_llama.rs:38-42)
             xs = mlp + xs

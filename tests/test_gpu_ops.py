@@ -396,3 +396,65 @@ def test_paged_attention_fused_merge_is_stable(cv):
     cv.lib.mi355_set_tuning(3, 1)
     oracle = O.paged_attention_decode(q, kc, vc, bt, cl, 1 / np.sqrt(D), False)
     assert np.abs(ref - oracle).max() <= tol
+
+
+# ------------------------------------------------------------------------------------------------ mixture of experts
+@pytest.mark.parametrize("T", [1, 2, 5])
+def test_moe_route_experts_combine(cv, T):
+    """MlpOrMoe::forward on the device (quantized_llama.rs:56-123): routing ids bit-exact, weights and the combined
+    expert output within the quantised mat-mul tolerance."""
+    from oracle import llama as L
+    rng = np.random.default_rng(T)
+    hid, I, E, K = 256, 512, 8, 2
+    x = rng.normal(0, 1, (T, hid)).astype(np.float32)
+    nw = (1.0 + rng.normal(0, 0.05, hid)).astype(np.float32)
+    gate = rng.normal(0, 0.5, (E, hid)).astype(np.float32)
+    experts = []
+    for _ in range(E):
+        def q(r, c):
+            return (kq.GGML_Q4_K, kq.quantize(rng.normal(0, 0.05, (r, c)).astype(np.float32), kq.GGML_Q4_K))
+        experts.append({"w1": q(I, hid), "w2": q(hid, I), "w3": q(I, hid)})
+    xn = O.rms_norm(x, nw, 1e-5)
+    ids_ref, w_ref = L.moe_route(xn, gate, K)
+    ref = L.moe_forward(xn, {"gate_inp": gate, "experts": experts}, K)
+    # device: slabs of repacked expert tiles
+    def slab(name, rows, cols):
+        parts = [cv.repack_qweight(e[name][1], kq.GGML_Q4_K, rows, cols) for e in experts]
+        stride = parts[0].size
+        return torch.from_numpy(np.concatenate(parts)).cuda(), stride
+    w1, s1 = slab("w1", I, hid)
+    w3, s3 = slab("w3", I, hid)
+    w2, s2 = slab("w2", hid, I)
+    xd, ids, wts = dev(x), torch.zeros((T, K), dtype=torch.int32, device="cuda"), torch.zeros((T, K), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert cv.lib.mi355_moe_route(ids.data_ptr(), wts.data_ptr(), xd.data_ptr(), dev(nw).data_ptr(), 1e-5, dev(gate).data_ptr(),
+                                  T, hid, E, K, st) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(ids.cpu().numpy(), ids_ref)
+    assert np.abs(wts.cpu().numpy() - w_ref).max() < 1e-5
+    nwd = dev(nw)
+    h = torch.empty((T * K, I), dtype=torch.float32, device="cuda")
+    d = cv.QmmDesc()
+    d.nseg = 2
+    d.w_tiles[0], d.w_tiles[1] = w1.data_ptr(), w3.data_ptr()
+    d.ggml_type[0] = d.ggml_type[1] = kq.GGML_Q4_K
+    d.n_rows[0] = d.n_rows[1] = I
+    d.x, d.x_dtype, d.ldx, d.k, d.num_tokens = xd.data_ptr(), cv.DT_F32, hid, hid, 1
+    d.norm_weight, d.norm_eps = nwd.data_ptr(), 1e-5
+    d.epilogue, d.out, d.ldo = cv.EPI_SILU_MUL, h.data_ptr(), I
+    d.moe_expert_ids, d.moe_pairs, d.moe_x_div = ids.data_ptr(), T * K, K
+    d.moe_expert_stride[0], d.moe_expert_stride[1] = s1, s3
+    assert cv.lib.mi355_qmatmul_fused(d, st) == 0
+    yp = torch.empty((T * K, hid), dtype=torch.float32, device="cuda")
+    d2 = cv.QmmDesc()
+    d2.nseg = 1
+    d2.w_tiles[0], d2.ggml_type[0], d2.n_rows[0] = w2.data_ptr(), kq.GGML_Q4_K, hid
+    d2.x, d2.x_dtype, d2.ldx, d2.k, d2.num_tokens = h.data_ptr(), cv.DT_F32, I, I, 1
+    d2.epilogue, d2.out, d2.ldo = cv.EPI_STORE, yp.data_ptr(), hid
+    d2.moe_expert_ids, d2.moe_pairs, d2.moe_x_div = ids.data_ptr(), T * K, 1
+    d2.moe_expert_stride[0] = s2
+    assert cv.lib.mi355_qmatmul_fused(d2, st) == 0
+    ys = torch.zeros((T, hid), dtype=torch.float32, device="cuda")
+    assert cv.lib.mi355_moe_combine(ys.data_ptr(), yp.data_ptr(), wts.data_ptr(), T, hid, K, 0, st) == 0
+    torch.cuda.synchronize()
+    assert rel_err(ys.cpu().numpy(), ref) < 1e-3
