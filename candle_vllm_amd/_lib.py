@@ -100,9 +100,11 @@ class LlamaConfig(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("hidden", "n_layers", "n_heads", "n_kv_heads", "head_dim", "intermediate",
                                      "vocab", "max_seq", "block_size", "kv_layout", "max_batch",
                                      "max_blocks_per_seq")] + \
-               [("rms_eps", c_f32), ("rope_theta", c_f32), ("tp_rank", c_i32), ("tp_world", c_i32)]
+               [("rms_eps", c_f32), ("rope_theta", c_f32), ("tp_rank", c_i32), ("tp_world", c_i32),
+                ("n_expert", c_i32), ("n_expert_used", c_i32)]
 
 
+_sig("mi355_llama_set_moe_expert", ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32])
 _sig("mi355_llama_create", c_vp, [ctypes.POINTER(LlamaConfig)])
 _sig("mi355_llama_destroy", None, [c_vp])
 _sig("mi355_llama_set_qweight", ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32])

@@ -85,6 +85,11 @@ struct Layer {
     float* attn_norm = nullptr;
     float* ffn_norm = nullptr;
     QW w[7];   // MI355_W_WQ .. MI355_W_W3
+    // MoE (n_expert > 1): router + one slab of repacked tiles per projection, experts back to back
+    float* gate_inp = nullptr;          // f32 [n_expert, hidden]
+    uint8_t* eslab[3] = {nullptr, nullptr, nullptr};   // W1, W2, W3
+    int etype[3] = {0, 0, 0}, erows[3] = {0, 0, 0}, ek[3] = {0, 0, 0};
+    int64_t estride[3] = {0, 0, 0};
 };
 
 struct Model {
@@ -127,6 +132,9 @@ struct Model {
     // prefill workspace (grow-only, sized by the largest chunk seen): same roles as xs / q / attn / h
     float* p_xs = nullptr; uint16_t* p_q = nullptr; uint16_t* p_attn = nullptr; float* p_h = nullptr;
     int p_cap = 0;
+    // MoE routing scratch (sized for the decode batch; prompt steps use their own, below)
+    int32_t* moe_ids = nullptr; float* moe_w = nullptr; float* moe_y = nullptr;
+    int32_t* p_moe_ids = nullptr; float* p_moe_w = nullptr; float* p_moe_y = nullptr;
 };
 
 int g_host_ps_override = 0;     // experiments: mi355_set_tuning(5, partition_size)
@@ -168,6 +176,7 @@ struct StepIn {
     int B, max_blocks, ctx_cap;
     // activation buffers of this step (decode: the model's static ones; prefill: the T-row workspace)
     float* xs; uint16_t* q; uint16_t* attn; float* h;
+    int32_t* moe_ids; float* moe_w; float* moe_y;     // MoE scratch matching the buffers above
     // prefill only (is_prefill): cu_seqlens_q [num_seqs+1], B = total tokens
     bool is_prefill; const uint32_t* cu_q; int num_seqs, max_seqlen_q;
 };
@@ -226,7 +235,34 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
         return (int)hipGetLastError();
     }
     Layer& L = m->layers[l];
-    const int I = L.w[MI355_W_W1].n_rows;
+    const bool moe = c.n_expert > 1;
+    const int I = moe ? L.erows[0] : L.w[MI355_W_W1].n_rows;
+    if (moe && (part == PART_GATEUP || part == PART_DOWN)) {
+        // --- MlpOrMoe::forward (quantized_llama.rs:56-123) without the host round trip
+        const int K = c.n_expert_used, pairs = B * K;
+        if (!L.gate_inp || !L.eslab[0] || !L.eslab[1] || !L.eslab[2]) return (int)hipErrorInvalidValue;
+        if (part == PART_GATEUP) {
+            RCHECK(mi355_moe_route(in.moe_ids, in.moe_w, in.xs, L.ffn_norm, c.rms_eps, L.gate_inp, B, hid, c.n_expert, K, st));
+            d.nseg = 2;
+            d.w_tiles[0] = L.eslab[0]; d.ggml_type[0] = L.etype[0]; d.n_rows[0] = L.erows[0];
+            d.w_tiles[1] = L.eslab[2]; d.ggml_type[1] = L.etype[2]; d.n_rows[1] = L.erows[2];
+            d.x = in.xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = 1;
+            d.norm_weight = L.ffn_norm; d.norm_eps = c.rms_eps;
+            d.epilogue = MI355_EPI_SILU_MUL; d.out = in.h; d.ldo = I;
+            d.moe_expert_ids = in.moe_ids; d.moe_pairs = pairs; d.moe_x_div = K;
+            d.moe_expert_stride[0] = L.estride[0]; d.moe_expert_stride[1] = L.estride[2];
+            return mi355_qmatmul_fused(&d, st);
+        }
+        d.nseg = 1;
+        d.w_tiles[0] = L.eslab[1]; d.ggml_type[0] = L.etype[1]; d.n_rows[0] = L.erows[1];
+        d.x = in.h; d.x_dtype = MI355_DTYPE_F32; d.ldx = I; d.k = I; d.num_tokens = 1;
+        d.epilogue = MI355_EPI_STORE; d.out = in.moe_y; d.ldo = hid;
+        d.moe_expert_ids = in.moe_ids; d.moe_pairs = pairs; d.moe_x_div = 1;
+        d.moe_expert_stride[0] = L.estride[1];
+        RCHECK(mi355_qmatmul_fused(&d, st));
+        // ys.index_add(weighted expert outputs) + residual (quantized_llama.rs:112-113, 470)
+        return mi355_moe_combine(in.xs, in.moe_y, in.moe_w, B, hid, K, 1, st);
+    }
     if (part == PART_QKV) {
         // --- attention_norm + wq|wk|wv + interleaved RoPE + bf16 cast + cache scatter
         d.nseg = 3;
@@ -304,7 +340,7 @@ int forward_decode(Model* m, const uint32_t* tokens, const int64_t* positions, c
     if (B < 1 || B > c.max_batch) return (int)hipErrorInvalidValue;
     if ((int)m->kcache.size() != c.n_layers) return (int)hipErrorInvalidValue;
     const StepIn in{tokens, positions, slots, bt, ctx, B, max_blocks, ctx_cap, m->xs, m->q, m->attn, m->h,
-                    false, nullptr, 0, 0};
+                    m->moe_ids, m->moe_w, m->moe_y, false, nullptr, 0, 0};
     RCHECK(run_part(m, 0, PART_EMBED, in, logits, st));
     for (int l = 0; l < c.n_layers; ++l)
         for (int part = PART_QKV; part <= PART_DOWN; ++part) RCHECK(run_part(m, l, part, in, logits, st));
@@ -354,7 +390,14 @@ extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
     alloc((void**)&m->xs, (size_t)B * cfg->hidden * 4);
     alloc((void**)&m->q, (size_t)B * H * D * 2);
     alloc((void**)&m->attn, (size_t)B * H * D * 2);
-    alloc((void**)&m->h, (size_t)B * cfg->intermediate * 4);
+    const int KE = cfg->n_expert > 1 ? (cfg->n_expert_used > 0 ? cfg->n_expert_used : 1) : 1;
+    if (cfg->n_expert > 1 && (cfg->n_expert_used < 1 || cfg->n_expert_used > cfg->n_expert || m->cfg.tp_world > 1)) { delete m; return nullptr; }
+    alloc((void**)&m->h, (size_t)B * KE * cfg->intermediate * 4);
+    if (cfg->n_expert > 1) {
+        alloc((void**)&m->moe_ids, (size_t)B * KE * 4);
+        alloc((void**)&m->moe_w, (size_t)B * KE * 4);
+        alloc((void**)&m->moe_y, (size_t)B * KE * cfg->hidden * 4);
+    }
     alloc((void**)&m->logits, (size_t)B * cfg->vocab * 4);
     if (m->use_comm) {
         alloc((void**)&m->logits_local, (size_t)B * cfg->vocab * 4 / m->cfg.tp_world + 64);
@@ -398,11 +441,14 @@ extern "C" void mi355_llama_destroy(void* mp) {
         for (auto& w : L.w) free_qw(w);
         if (L.attn_norm) (void)hipFree(L.attn_norm);
         if (L.ffn_norm) (void)hipFree(L.ffn_norm);
+        if (L.gate_inp) (void)hipFree(L.gate_inp);
+        for (uint8_t* p : L.eslab) if (p) (void)hipFree(p);
     }
     free_qw(m->output);
     void* ptrs[] = {m->tok_embd, m->output_norm, m->cos_t, m->sin_t, m->xs, m->q, m->attn, m->h, m->logits,
                     m->pa_tmp, m->pa_max, m->pa_sum, m->kv_slab, m->d_tokens, m->d_positions, m->d_slots,
-                    m->d_ctx, m->d_bt, m->logits_local, m->logits_gather, m->p_xs, m->p_q, m->p_attn, m->p_h};
+                    m->d_ctx, m->d_bt, m->logits_local, m->logits_gather, m->p_xs, m->p_q, m->p_attn, m->p_h,
+                    m->moe_ids, m->moe_w, m->moe_y, m->p_moe_ids, m->p_moe_w, m->p_moe_y};
     if (m->comm && g_rccl.destroy) (void)g_rccl.destroy(m->comm);
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete m;
@@ -433,6 +479,29 @@ extern "C" int mi355_llama_set_qweight_tiles(void* mp, int32_t layer, int32_t wh
     return set_qw(*slot, ggml_type, tiles_dev, n_rows, k, false);
 }
 
+extern "C" int mi355_llama_set_moe_expert(void* mp, int32_t layer, int32_t which, int32_t expert, int32_t ggml_type,
+                                          const void* native_host, int32_t n_rows, int32_t k) {
+    Model* m = static_cast<Model*>(mp);
+    if (!m || layer < 0 || layer >= m->cfg.n_layers || expert < 0 || expert >= m->cfg.n_expert || !native_host)
+        return (int)hipErrorInvalidValue;
+    const int slot = which == MI355_W_W1 ? 0 : (which == MI355_W_W2 ? 1 : (which == MI355_W_W3 ? 2 : -1));
+    if (slot < 0) return (int)hipErrorInvalidValue;
+    Layer& L = m->layers[layer];
+    const int64_t n = mi355_qweight_repacked_size(ggml_type, n_rows, k);
+    if (n < 0) return (int)hipErrorInvalidValue;
+    if (!L.eslab[slot]) {
+        HCHECK(hipMalloc((void**)&L.eslab[slot], (size_t)n * m->cfg.n_expert));
+        L.etype[slot] = ggml_type; L.erows[slot] = n_rows; L.ek[slot] = k; L.estride[slot] = n;
+    } else if (L.etype[slot] != ggml_type || L.erows[slot] != n_rows || L.ek[slot] != k) {
+        return (int)hipErrorInvalidValue;                 // experts of one projection share type and shape
+    }
+    std::vector<uint8_t> tiles((size_t)n);
+    RCHECK(mi355_qweight_repack(tiles.data(), native_host, ggml_type, n_rows, k));
+    HCHECK(hipMemcpy(L.eslab[slot] + (size_t)expert * n, tiles.data(), (size_t)n, hipMemcpyHostToDevice));
+    drop_graph(m);
+    return 0;
+}
+
 extern "C" int mi355_llama_set_f32(void* mp, int32_t layer, int32_t which, const float* host, int64_t n) {
     Model* m = static_cast<Model*>(mp);
     if (!m || !host || n <= 0) return (int)hipErrorInvalidValue;
@@ -443,6 +512,7 @@ extern "C" int mi355_llama_set_f32(void* mp, int32_t layer, int32_t which, const
     } else if (layer < m->cfg.n_layers) {
         if (which == MI355_W_ATTN_NORM) dst = &m->layers[layer].attn_norm;
         else if (which == MI355_W_FFN_NORM) dst = &m->layers[layer].ffn_norm;
+        else if (which == MI355_W_GATE_INP) dst = &m->layers[layer].gate_inp;
     }
     if (!dst) return (int)hipErrorInvalidValue;
     if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
@@ -508,7 +578,15 @@ static int ensure_prefill_cap(Model* m, int T) {
     HCHECK(hipMalloc((void**)&m->p_xs, (size_t)cap * m->cfg.hidden * 4));
     HCHECK(hipMalloc((void**)&m->p_q, (size_t)cap * H * D * 2));
     HCHECK(hipMalloc((void**)&m->p_attn, (size_t)cap * H * D * 2));
-    HCHECK(hipMalloc((void**)&m->p_h, (size_t)cap * m->cfg.intermediate * 4));
+    const int KE = m->cfg.n_expert > 1 ? m->cfg.n_expert_used : 1;
+    HCHECK(hipMalloc((void**)&m->p_h, (size_t)cap * KE * m->cfg.intermediate * 4));
+    if (m->cfg.n_expert > 1) {
+        void* oldm[] = {m->p_moe_ids, m->p_moe_w, m->p_moe_y};
+        for (void* p : oldm) if (p) (void)hipFree(p);
+        HCHECK(hipMalloc((void**)&m->p_moe_ids, (size_t)cap * KE * 4));
+        HCHECK(hipMalloc((void**)&m->p_moe_w, (size_t)cap * KE * 4));
+        HCHECK(hipMalloc((void**)&m->p_moe_y, (size_t)cap * KE * m->cfg.hidden * 4));
+    }
     m->p_cap = cap;
     return 0;
 }
@@ -527,7 +605,7 @@ extern "C" int mi355_llama_forward_prefill(void* mp, const uint32_t* tokens, con
     if ((int)m->kcache.size() != c.n_layers) return (int)hipErrorInvalidValue;
     RCHECK(ensure_prefill_cap(m, num_tokens));
     StepIn in{tokens, positions, slot_mapping, block_tables, context_lens, num_tokens, max_blocks, 0,
-              m->p_xs, m->p_q, m->p_attn, m->p_h, true, cu_seqlens_q, num_seqs, max_seqlen_q};
+              m->p_xs, m->p_q, m->p_attn, m->p_h, m->p_moe_ids, m->p_moe_w, m->p_moe_y, true, cu_seqlens_q, num_seqs, max_seqlen_q};
     RCHECK(run_part(m, 0, PART_EMBED, in, logits, stream));
     for (int l = 0; l < c.n_layers; ++l)
         for (int part = PART_QKV; part <= PART_DOWN; ++part) RCHECK(run_part(m, l, part, in, logits, stream));
@@ -662,7 +740,8 @@ extern "C" int mi355_llama_load_gguf(const char* path, int32_t max_batch, int32_
         return (int)hipErrorInvalidValue;
     (void)u(key("context_length"), &ctx_len);
     (void)u(key("expert_count"), &n_expert);
-    if (n_expert > 1) return (int)hipErrorNotSupported;           // MoE GGUF: SURVEY 8 f4, not built
+    uint64_t n_expert_used = 0;
+    (void)u(key("expert_used_count"), &n_expert_used);
     if (!u(key("attention.key_length"), &key_len)) key_len = embd / head_count;
     double eps = 0, theta = 10000.0;
     if (mi355_gguf_get_f64(g, key("attention.layer_norm_rms_epsilon").c_str(), &eps) != 1) return (int)hipErrorInvalidValue;
@@ -680,7 +759,7 @@ extern "C" int mi355_llama_load_gguf(const char* path, int32_t max_batch, int32_
     if (i_embd < 0) return (int)hipErrorInvalidValue;
     const int64_t vocab = d[0];
     int64_t dff[4]; int32_t tff; uint64_t nbff;
-    if (info("blk.0.ffn_gate.weight", dff, &tff, &nbff) < 0) return (int)hipErrorInvalidValue;
+    if (info(n_expert > 1 ? "blk.0.ffn_gate.0.weight" : "blk.0.ffn_gate.weight", dff, &tff, &nbff) < 0) return (int)hipErrorInvalidValue;
 
     mi355_llama_config cfg;
     memset(&cfg, 0, sizeof(cfg));
@@ -690,6 +769,7 @@ extern "C" int mi355_llama_load_gguf(const char* path, int32_t max_batch, int32_
     cfg.max_seq = (max_seq > 0 && (uint64_t)max_seq < ctx_len) ? max_seq : (int32_t)ctx_len;
     cfg.block_size = block_size; cfg.kv_layout = kv_layout; cfg.max_batch = max_batch; cfg.max_blocks_per_seq = max_blocks_per_seq;
     cfg.rms_eps = (float)eps; cfg.rope_theta = (float)theta; cfg.tp_rank = 0; cfg.tp_world = 1;
+    cfg.n_expert = n_expert > 1 ? (int32_t)n_expert : 0; cfg.n_expert_used = n_expert > 1 ? (int32_t)n_expert_used : 0;
     Model* m = static_cast<Model*>(mi355_llama_create(&cfg));
     if (!m) return (int)hipErrorInvalidValue;
     struct Guard { Model* m; bool keep = false; ~Guard() { if (!keep) mi355_llama_destroy(m); } } guard{m};
@@ -731,9 +811,23 @@ extern "C" int mi355_llama_load_gguf(const char* path, int32_t max_batch, int32_
         RCHECK(load_q(p + "attn_k.weight", l, MI355_W_WK));
         RCHECK(load_q(p + "attn_v.weight", l, MI355_W_WV));
         RCHECK(load_q(p + "attn_output.weight", l, MI355_W_WO));
-        RCHECK(load_q(p + "ffn_gate.weight", l, MI355_W_W1));
-        RCHECK(load_q(p + "ffn_down.weight", l, MI355_W_W2));
-        RCHECK(load_q(p + "ffn_up.weight", l, MI355_W_W3));
+        if (cfg.n_expert > 1) {                               // quantized_llama.rs:347-365
+            RCHECK(load_f32(p + "ffn_gate_inp.weight", l, MI355_W_GATE_INP));
+            for (int e = 0; e < cfg.n_expert; ++e) {
+                const char* names[3] = {"ffn_gate.", "ffn_down.", "ffn_up."};
+                const int which[3] = {MI355_W_W1, MI355_W_W2, MI355_W_W3};
+                for (int q = 0; q < 3; ++q) {
+                    int64_t dd[4]; int32_t t; uint64_t nbq;
+                    const int i = info(p + names[q] + std::to_string(e) + ".weight", dd, &t, &nbq);
+                    if (i < 0) return (int)hipErrorInvalidValue;
+                    RCHECK(mi355_llama_set_moe_expert(m, l, which[q], e, t, mi355_gguf_tensor_data(g, i), (int32_t)dd[0], (int32_t)dd[1]));
+                }
+            }
+        } else {
+            RCHECK(load_q(p + "ffn_gate.weight", l, MI355_W_W1));
+            RCHECK(load_q(p + "ffn_down.weight", l, MI355_W_W2));
+            RCHECK(load_q(p + "ffn_up.weight", l, MI355_W_W3));
+        }
         RCHECK(load_f32(p + "attn_norm.weight", l, MI355_W_ATTN_NORM));
         RCHECK(load_f32(p + "ffn_norm.weight", l, MI355_W_FFN_NORM));
     }
@@ -764,6 +858,6 @@ extern "C" int mi355_llama_run_part(void* mp, int32_t layer, int32_t part, int64
     Model* m = static_cast<Model*>(mp);
     if (!m || m->cur_batch < 1 || layer < 0 || layer >= m->cfg.n_layers) return (int)hipErrorInvalidValue;
     const StepIn in{m->d_tokens, m->d_positions, m->d_slots, m->d_bt, m->d_ctx, m->cur_batch, m->cur_max_blocks, m->cur_ctx_cap,
-                    m->xs, m->q, m->attn, m->h, false, nullptr, 0, 0};
+                    m->xs, m->q, m->attn, m->h, m->moe_ids, m->moe_w, m->moe_y, false, nullptr, 0, 0};
     return run_part(m, layer, part, in, m->logits, stream);
 }

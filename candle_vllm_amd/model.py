@@ -58,6 +58,8 @@ class GGUFLLaMa:
         c.max_seq, c.block_size, c.kv_layout, c.max_batch = cfg.max_seq, cfg.block_size, kv_layout, max_batch
         c.max_blocks_per_seq = max_blocks_per_seq or -(-cfg.max_seq // cfg.block_size)
         c.rms_eps, c.rope_theta, c.tp_rank, c.tp_world = cfg.rms_eps, cfg.rope_theta, tp_rank, tp_world
+        c.n_expert = int(getattr(cfg, "n_expert", 0) or 0)            # Mixtral-style MoE MLP (llama.expert_count)
+        c.n_expert_used = int(getattr(cfg, "n_expert_used", 0) or 0)
         self.c = c
         self.kv_layout = kv_layout
         self.max_batch = max_batch
@@ -118,6 +120,18 @@ class GGUFLLaMa:
         for l, lw in enumerate(W["layers"]):
             f32(l, W_ATTN_NORM, lw["attn_norm"])
             f32(l, W_FFN_NORM, lw["ffn_norm"])
+            if "experts" in lw:                                        # MoE layer (quantized_llama.rs:347-365)
+                f32(l, 12, lw["gate_inp"])
+                for e, ex in enumerate(lw["experts"]):
+                    for name in ("w1", "w2", "w3"):
+                        t, blocks = ex[name]
+                        b = np.ascontiguousarray(blocks)
+                        _check(lib.mi355_llama_set_moe_expert(self.h, l, _SLOT[name], e, t, b.ctypes.data, b.shape[0],
+                                                              b.shape[1] * 256), "set_moe_expert")
+                        self.weight_bytes += b.size
+                for name in ("wq", "wk", "wv", "wo"):
+                    qw(l, _SLOT[name], lw[name])
+                continue
             for name, slot in _SLOT.items():
                 qw(l, slot, lw[name])
 

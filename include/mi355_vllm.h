@@ -280,6 +280,7 @@ typedef struct mi355_llama_config {
     int32_t max_seq, block_size, kv_layout, max_batch, max_blocks_per_seq;
     float rms_eps, rope_theta;
     int32_t tp_rank, tp_world;   /* heads / kv heads / rows are the LOCAL shard when tp_world > 1 */
+    int32_t n_expert, n_expert_used;   /* > 1: Mixtral-style MoE MLP (llama.expert_count / expert_used_count) */
 } mi355_llama_config;
 /* weight slots */
 #define MI355_W_WQ 0
@@ -304,6 +305,12 @@ int mi355_llama_set_qweight(void* model, int32_t layer, int32_t which, int32_t g
 int mi355_llama_set_qweight_tiles(void* model, int32_t layer, int32_t which, int32_t ggml_type,
                                   const void* tiles_dev, int32_t n_rows, int32_t k);
 int mi355_llama_set_f32(void* model, int32_t layer, int32_t which, const float* host, int64_t n);
+/* MoE layers (quantized_llama.rs:347-365): router `ffn_gate_inp` f32 [n_expert, hidden] through mi355_llama_set_f32
+ * with which = MI355_W_GATE_INP; expert `e`'s ffn_gate / ffn_down / ffn_up (which = W1 / W2 / W3) as native GGUF
+ * blocks -- all experts of one (layer, which) share the ggml type */
+#define MI355_W_GATE_INP 12
+int mi355_llama_set_moe_expert(void* model, int32_t layer, int32_t which, int32_t expert, int32_t ggml_type,
+                               const void* native_host, int32_t n_rows, int32_t k);
 int mi355_llama_alloc_kv_cache(void* model, int32_t num_blocks);
 void* mi355_llama_kv_ptr(void* model, int32_t layer, int32_t which /* 0 = K, 1 = V */);
 int64_t mi355_llama_kv_bytes_per_tensor(void* model);

@@ -62,6 +62,9 @@ def llama_to_gguf(path, cfg, W):
           "llama.attention.head_count_kv": cfg.n_kv_heads, "llama.attention.key_length": cfg.head_dim,
           "llama.attention.layer_norm_rms_epsilon": float(cfg.rms_eps), "llama.rope.freq_base": float(cfg.rope_theta),
           "tokenizer.ggml.tokens": ["<a>", "<b>", "<c>"]}
+    if any("experts" in lw for lw in W["layers"]):
+        md["llama.expert_count"] = len(W["layers"][0]["experts"])
+        md["llama.expert_used_count"] = int(getattr(cfg, "n_expert_used", 2) or 2)
     ts = []
 
     def q(name, tw, rows, cols):
@@ -83,9 +86,16 @@ def llama_to_gguf(path, cfg, W):
         q(p + "attn_k.weight", lw["wk"], Hkv * D, hid)
         q(p + "attn_v.weight", lw["wv"], Hkv * D, hid)
         q(p + "attn_output.weight", lw["wo"], hid, H * D)
-        q(p + "ffn_gate.weight", lw["w1"], I, hid)
-        q(p + "ffn_down.weight", lw["w2"], hid, I)
-        q(p + "ffn_up.weight", lw["w3"], I, hid)
+        if "experts" in lw:                                            # quantized_llama.rs:347-365
+            f32(p + "ffn_gate_inp.weight", lw["gate_inp"])
+            for e, ex in enumerate(lw["experts"]):
+                q(p + f"ffn_gate.{e}.weight", ex["w1"], I, hid)
+                q(p + f"ffn_down.{e}.weight", ex["w2"], hid, I)
+                q(p + f"ffn_up.{e}.weight", ex["w3"], I, hid)
+        else:
+            q(p + "ffn_gate.weight", lw["w1"], I, hid)
+            q(p + "ffn_down.weight", lw["w2"], hid, I)
+            q(p + "ffn_up.weight", lw["w3"], I, hid)
         f32(p + "attn_norm.weight", lw["attn_norm"])
         f32(p + "ffn_norm.weight", lw["ffn_norm"])
     write_gguf(path, md, ts)

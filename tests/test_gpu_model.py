@@ -218,3 +218,68 @@ def test_model_loaded_from_gguf_file_equals_setter_path(lib, tmp_path):
     assert np.array_equal(la, lb)
     ref = llama.OracleLlama(cfg, W).forward(meta, llama.OracleLlama(cfg, W).new_cache(16), is_prefill=True)
     assert _rel(la, ref) < 3e-3
+    # a Mixtral-shaped file: expert_count / expert_used_count metadata, ffn_gate_inp + ffn_{gate,down,up}.{e} tensors
+    cfg2 = llama.LlamaConfig.tiny()
+    cfg2.n_expert, cfg2.n_expert_used = 4, 2
+    W2 = dict(llama.make_moe_weights(cfg2, 4, seed=5))
+    W2["tok_embd"] = kq.dequantize_q6_k(kq.quantize(W2["tok_embd"], kq.GGML_Q6_K)).reshape(cfg2.vocab, cfg2.hidden).astype(np.float32)
+    path2 = os.path.join(tmp_path, "tiny_moe.gguf")
+    GW.llama_to_gguf(path2, cfg2, W2)
+    c = M.GGUFLLaMa.from_gguf(path2, max_batch=4, max_blocks_per_seq=16, block_size=cfg2.block_size, kv_layout=M.KV_FLASH)
+    assert (c.c.n_expert, c.c.n_expert_used) == (4, 2)
+    c.alloc_kv_cache(16)
+    d = M.GGUFLLaMa(cfg2, max_batch=4, kv_layout=M.KV_FLASH)
+    d.load_oracle_weights(W2)
+    d.alloc_kv_cache(16)
+    assert np.array_equal(c.forward_prefill(meta).cpu().numpy(), d.forward_prefill(meta).cpu().numpy())
+
+
+def test_moe_model_prompt_and_graph_decode(lib):
+    """Mixtral-shaped tiny model (4 experts, top-2): prompt step and greedy decode (eager and hipGraph replay -- the
+    routing never leaves the device) vs the oracle's MlpOrMoe restatement (quantized_llama.rs:56-123)."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from candle_vllm_amd import model as M
+    cfg = llama.LlamaConfig.tiny()
+    cfg.n_expert, cfg.n_expert_used = 4, 2
+    W = llama.make_moe_weights(cfg, 4, seed=77)
+    orc = llama.OracleLlama(cfg, W, flash_layout=True)
+    rng = np.random.default_rng(17)
+    seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 21)], "block_table": [3, 7, 9]},
+            {"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 6)], "block_table": [1, 5]}]
+    cache = orc.new_cache(16)
+    meta = O.prepare_prompt(seqs, cfg.block_size)
+    ref = orc.forward(meta, cache, is_prefill=True)
+    gm = M.GGUFLLaMa(cfg, max_batch=4, kv_layout=M.KV_FLASH)
+    gm.load_oracle_weights(W)
+    gm.alloc_kv_cache(16)
+    got = gm.forward_prefill(meta).cpu().numpy()
+    assert _rel(got, ref) < 3e-3, _rel(got, ref)
+    assert [int(r.argmax()) for r in got] == [int(r.argmax()) for r in ref]
+    for s, row in zip(seqs, ref):
+        s["tokens"].append(int(row.argmax()))
+    steps = 6
+    bt = np.zeros((2, 3), np.uint32)
+    for i, s in enumerate(seqs):
+        bt[i, :len(s["block_table"])] = s["block_table"]
+    toks0, lens0 = [s["tokens"][-1] for s in seqs], [len(s["tokens"]) for s in seqs]
+    o_seqs = [{"tokens": list(s["tokens"]), "block_table": list(s["block_table"])} for s in seqs]
+    want = []
+    for _ in range(steps):
+        lg = orc.forward(O.prepare_decode(o_seqs, cfg.block_size), cache)
+        nxt = [int(r.argmax()) for r in lg]
+        want.append(nxt)
+        for s, t in zip(o_seqs, nxt):
+            s["tokens"].append(t)
+    snap = [gm.kv_download(l) for l in range(cfg.n_layers)]
+    stream = torch.cuda.Stream()
+    for use_graph in (False, True):
+        for l, (kc, vc) in enumerate(snap):
+            gm.kv_upload(l, kc, vc)
+        gm.set_graph(use_graph)
+        gm.decode_begin(toks0, lens0, bt, ctx_cap=max(lens0) + steps, stream=stream.cuda_stream)
+        got_t = []
+        for _ in range(steps):
+            gm.decode_step(stream.cuda_stream)
+            got_t.append([int(t) for t in gm.read_tokens(stream.cuda_stream)])
+        assert got_t == want, (use_graph, got_t, want)
