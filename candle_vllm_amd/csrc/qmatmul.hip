@@ -459,17 +459,7 @@ __device__ __forceinline__ float silu_f(float g) { return g / (1.f + __expf(-g))
 // so the compiler emits counted vmcnt waits and ~QMM_PF KiB-sized loads per lane stay in flight.  There is no
 // workgroup-level prologue: the only barrier is the one in front of the epilogue.
 template <int BT, int R, int WT>
-__global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a_in) {
-    QmmArgs a = a_in;
-    if (a.moe_expert) {                                           // wave-uniform: everything below stays scalar
-        const int pair = blockIdx.y;
-        const int64_t e = a.moe_expert[pair];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) a.seg[s].w += e * a.moe_stride[s];
-        const size_t xes = (a.x_dtype == MI355_DTYPE_BF16) ? 2 : 4;
-        a.x = static_cast<const uint8_t*>(a.x) + (size_t)(pair / a.moe_xdiv) * a.ldx * xes;
-        a.out += (size_t)pair * a.ldo;
-    }
+__device__ __forceinline__ void qmm_body(const QmmArgs& a) {
     constexpr int NV = BT < 4 ? BT : 4;
     constexpr int PF = (R > QMM_PF_MIN) ? R : QMM_PF_MIN;
     constexpr int PFK = PF / R;                                  // ring depth in k-blocks
@@ -648,6 +638,24 @@ __global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a_in) {
             }
         }
     }
+}
+
+template <int BT, int R, int WT>
+__global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) { qmm_body<BT, R, WT>(a); }
+
+// MoE variant (decode-shaped, BT = 1): blockIdx.y = (token, slot) pair.  The adjusted descriptor is a private copy
+// -- kept out of the dense kernel, where the kernel arguments must stay scalar loads from the kernarg segment.
+template <int R, int WT>
+__global__ void __launch_bounds__(512) qmm_moe_kernel(const QmmArgs a_in) {
+    QmmArgs a = a_in;
+    const int pair = blockIdx.y;
+    const int64_t e = a.moe_expert[pair];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) a.seg[s].w += e * a.moe_stride[s];
+    const size_t xes = (a.x_dtype == MI355_DTYPE_BF16) ? 2 : 4;
+    a.x = static_cast<const uint8_t*>(a.x) + (size_t)(pair / a.moe_xdiv) * a.ldx * xes;
+    a.out += (size_t)pair * a.ldo;
+    qmm_body<1, R, WT>(a);
 }
 
 // ================================================================================================
@@ -1373,7 +1381,20 @@ static int qmm_launch_btrw(QmmArgs& a, int n_wg, int NW, hipStream_t st) {
     if (NW <= 0) NW = qmm_pick_nw<BT, R, WT>(n_wg, a.K / 256);
     const size_t shm = qmm_lds_bytes(BT, R, NW);
     if (shm > 160 * 1024) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL((qmm_kernel<BT, R, WT>), dim3(n_wg, a.moe_expert ? a.moe_pairs : 1), dim3(64 * NW), shm, st, a);
+    if (a.moe_expert) {
+        if constexpr (BT == 1) {
+            static bool moe_attr_done = false;
+            if (!moe_attr_done) {
+                (void)hipFuncSetAttribute((const void*)qmm_moe_kernel<R, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                moe_attr_done = true;
+            }
+            hipLaunchKernelGGL((qmm_moe_kernel<R, WT>), dim3(n_wg, a.moe_pairs), dim3(64 * NW), shm, st, a);
+        } else {
+            return (int)hipErrorInvalidValue;
+        }
+    } else {
+        hipLaunchKernelGGL((qmm_kernel<BT, R, WT>), dim3(n_wg), dim3(64 * NW), shm, st, a);
+    }
     return (int)hipGetLastError();
 }
 
