@@ -62,11 +62,6 @@ __global__ void __launch_bounds__(256) reshape_and_cache_paged_kernel(
 // fp8 KV cache (`--kvcache-dtype fp8`, src/main.rs:263-267; K layout x = 16, cache_engine.rs:304-311): bf16 k, v are
 // stored as OCP e4m3fn bytes = e4m3(value / scale), round-to-nearest-even, saturating at +-448 (scale 1.0 is what the
 // reference passes today [EXT: conversion lives in attention-rs]).
-__device__ __forceinline__ uint8_t to_e4m3(float f) {
-    f = fminf(fmaxf(f, -448.f), 448.f);                      // saturate (NaN passes through the min/max as NaN -> 0x7F)
-    const int p = __builtin_amdgcn_cvt_pk_fp8_f32(f, 0.f, 0, false);
-    return (uint8_t)(p & 0xFF);
-}
 __global__ void __launch_bounds__(256) reshape_and_cache_fp8_kernel(const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
                                                                     uint8_t* __restrict__ kc, uint8_t* __restrict__ vc,
                                                                     const int64_t* __restrict__ slot_mapping, int Hkv, int D, int bs,

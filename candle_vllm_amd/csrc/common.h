@@ -41,6 +41,13 @@ __device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
     return __builtin_bit_cast(uint16_t, v);
 }
 
+// f32 -> OCP e4m3fn byte: round-to-nearest-even in hardware (gfx950 v_cvt_pk_fp8_f32), saturating at +-448
+__device__ __forceinline__ uint8_t to_e4m3(float f) {
+    f = fminf(fmaxf(f, -448.f), 448.f);
+    const int p = __builtin_amdgcn_cvt_pk_fp8_f32(f, 0.f, 0, false);
+    return (uint8_t)(p & 0xFF);
+}
+
 // ---- wavefront reductions (ds_bpermute / DPP through __shfl_xor, 64 lanes) ---------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -279,6 +279,19 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
         d.block_size = c.block_size; d.kv_layout = c.kv_layout;
         return mi355_qmatmul_fused(&d, st);
     }
+    if (part == PART_ATTN && c.kv_layout == MI355_KV_PAGED_FP8) {
+        // `--kvcache-dtype fp8` (is_fp8_keys, attention.rs:896): every key comes back from the e4m3fn cache
+        const float scale = 1.0f / sqrtf((float)D);
+        if (in.is_prefill)
+            return mi355_prefill_attention_fp8(in.attn, in.q, m->kcache[l], m->vcache[l], in.bt, in.ctx, in.cu_q, in.num_seqs,
+                                               in.max_seqlen_q, H, Hkv, D, c.block_size, in.max_blocks, scale, 0.f, 1.f, 1.f,
+                                               MI355_DTYPE_BF16, st);
+        int ps = choose_partition(B, Hkv, in.ctx_cap);
+        if (ps > 0) ps = ps <= 32 ? 32 : (ps <= 64 ? 64 : 128);
+        if (ps > 0 && (in.ctx_cap + ps - 1) / ps > m->pa_cap_partitions) return (int)hipErrorInvalidValue;
+        return mi355_paged_attention_fp8(in.attn, m->pa_sum, m->pa_max, m->pa_tmp, in.q, m->kcache[l], m->vcache[l], in.bt, in.ctx,
+                                         B, H, Hkv, D, c.block_size, in.max_blocks, in.ctx_cap, ps, scale, 0.f, 1.f, 1.f, st);
+    }
     if (part == PART_ATTN && in.is_prefill) {
         // --- K4: every key (cached prefix + this chunk, just written by the QKV epilogue) comes from the cache
         return mi355_prefill_attention(in.attn, in.q, nullptr, nullptr, m->kcache[l], m->vcache[l], in.bt, in.ctx,
@@ -527,7 +540,9 @@ extern "C" int mi355_llama_alloc_kv_cache(void* mp, int32_t num_blocks) {
     Model* m = static_cast<Model*>(mp);
     if (!m || num_blocks <= 0) return (int)hipErrorInvalidValue;
     const mi355_llama_config& c = m->cfg;
-    const size_t per = (size_t)num_blocks * c.block_size * local_kv_heads(m) * c.head_dim * 2;   // bf16
+    if (c.kv_layout == MI355_KV_PAGED_FP8 && (c.head_dim % 16)) return (int)hipErrorInvalidValue;
+    const size_t per = (size_t)num_blocks * c.block_size * local_kv_heads(m) * c.head_dim *
+                       (c.kv_layout == MI355_KV_PAGED_FP8 ? 1 : 2);                                // e4m3 bytes or bf16
     if (m->kv_slab) { (void)hipFree(m->kv_slab); m->kv_slab = nullptr; }
     HCHECK(hipMalloc(&m->kv_slab, per * 2 * c.n_layers));
     HCHECK(hipMemset(m->kv_slab, 0, per * 2 * c.n_layers));
@@ -564,7 +579,8 @@ extern "C" int mi355_llama_kv_copy(void* mp, int32_t layer, int32_t which, void*
 extern "C" int64_t mi355_llama_kv_bytes_per_tensor(void* mp) {
     Model* m = static_cast<Model*>(mp);
     if (!m) return -1;
-    return (int64_t)m->num_blocks * m->cfg.block_size * local_kv_heads(m) * m->cfg.head_dim * 2;
+    return (int64_t)m->num_blocks * m->cfg.block_size * local_kv_heads(m) * m->cfg.head_dim *
+           (m->cfg.kv_layout == MI355_KV_PAGED_FP8 ? 1 : 2);
 }
 
 static int ensure_prefill_cap(Model* m, int T) {

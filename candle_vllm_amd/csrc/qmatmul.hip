@@ -625,7 +625,13 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
                 const int64_t slot = a.slot_mapping[b];
                 if (slot >= 0) {
                     uint16_t* cache = (sgi == 1) ? a.kcache : a.vcache;
-                    if (a.kv_layout == MI355_KV_FLASH) {
+                    if (a.kv_layout == MI355_KV_PAGED_FP8) {        // e4m3fn of the bf16 value, K layout x = 16
+                        uint8_t* c8 = reinterpret_cast<uint8_t*>(cache);
+                        const int64_t blk = slot / a.block_size, off = slot % a.block_size;
+                        const uint8_t q8 = to_e4m3(bf16_to_f32(ob));
+                        if (sgi == 1) c8[((((blk * a.Hkv + hh) * (D / 16) + d / 16) * a.block_size + off) * 16) + d % 16] = q8;
+                        else c8[((blk * a.Hkv + hh) * D + d) * (int64_t)a.block_size + off] = q8;
+                    } else if (a.kv_layout == MI355_KV_FLASH) {
                         cache[(slot * a.Hkv + hh) * D + d] = ob;
                     } else {
                         const int64_t blk = slot / a.block_size, off = slot % a.block_size;
@@ -1203,7 +1209,13 @@ __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, cons
             const int64_t slot = a.slot_mapping[b];
             if (slot < 0) return;
             uint16_t* cache = (sg == 1) ? a.kcache : a.vcache;
-            if (a.kv_layout == MI355_KV_FLASH) {
+            if (a.kv_layout == MI355_KV_PAGED_FP8) {                // e4m3fn of the bf16 value, K layout x = 16
+                uint8_t* c8 = reinterpret_cast<uint8_t*>(cache);
+                const int64_t blk = slot / a.block_size, off = slot % a.block_size;
+                const uint8_t q8 = to_e4m3(bf16_to_f32(ob));
+                if (sg == 1) c8[((((blk * a.Hkv + hh) * (D / 16) + d / 16) * a.block_size + off) * 16) + d % 16] = q8;
+                else c8[((blk * a.Hkv + hh) * D + d) * (int64_t)a.block_size + off] = q8;
+            } else if (a.kv_layout == MI355_KV_FLASH) {
                 cache[(slot * a.Hkv + hh) * D + d] = ob;
             } else {
                 const int64_t blk = slot / a.block_size, off = slot % a.block_size;
@@ -1473,7 +1485,7 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
             a.positions = pos0 ? pos0 + b0 : nullptr;
             a.slot_mapping = slot0 ? slot0 + b0 : nullptr;
             int rcw;
-            if (g_tune_wide == 2) {
+            if (g_tune_wide == 2 || a.kv_layout == MI355_KV_PAGED_FP8) {
                 if (bn <= 16) rcw = qmg_launch<2>(a, st);
                 else if (bn <= 24) rcw = qmg_launch<3>(a, st);
                 else rcw = qmg_launch<4>(a, st);

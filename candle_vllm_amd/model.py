@@ -9,6 +9,8 @@ import torch
 from ._lib import lib, LlamaConfig
 from .ops import _check, GGML_Q4_K, GGML_Q6_K, KV_FLASH, KV_PAGED  # noqa: F401
 
+KV_PAGED_FP8 = 2          # `--kvcache-dtype fp8`: e4m3fn bytes in the paged layout with x = 16
+
 W_WQ, W_WK, W_WV, W_WO, W_W1, W_W2, W_W3, W_ATTN_NORM, W_FFN_NORM, W_TOK_EMBD, W_OUTPUT_NORM, W_OUTPUT = range(12)
 _SLOT = {"wq": W_WQ, "wk": W_WK, "wv": W_WV, "wo": W_WO, "w1": W_W1, "w2": W_W2, "w3": W_W3}
 _TILE_BYTES = {GGML_Q4_K: 2304, GGML_Q6_K: 3360}
@@ -247,8 +249,17 @@ class GGUFLLaMa:
         if self.kv_layout == KV_FLASH:
             s = (self.num_blocks, c.block_size, self.local_kv_heads, c.head_dim)
             return s, s
-        return ((self.num_blocks, self.local_kv_heads, c.head_dim // 8, c.block_size, 8),
+        x = 16 if self.kv_layout == KV_PAGED_FP8 else 8
+        return ((self.num_blocks, self.local_kv_heads, c.head_dim // x, c.block_size, x),
                 (self.num_blocks, self.local_kv_heads, c.head_dim, c.block_size))
+
+    def kv_download_u8(self, layer):
+        """fp8 cache bytes (KV_PAGED_FP8)"""
+        ks, vs = self.kv_shape()
+        k, v = np.empty(ks, np.uint8), np.empty(vs, np.uint8)
+        _check(lib.mi355_llama_kv_copy(self.h, layer, 0, k.ctypes.data, k.nbytes, 0), "kv_copy")
+        _check(lib.mi355_llama_kv_copy(self.h, layer, 1, v.ctypes.data, v.nbytes, 0), "kv_copy")
+        return k, v
 
     def kv_upload(self, layer, k_bits, v_bits):
         """k_bits/v_bits: uint16 numpy arrays (bf16 bit patterns) in the cache layout."""

@@ -31,6 +31,7 @@ extern "C" {
 /* KV cache layouts -- src/scheduler/cache_engine.rs:298-341 */
 #define MI355_KV_FLASH 0 /* K,V [num_blocks, block_size, num_kv_heads, head_dim]            (:326-341) */
 #define MI355_KV_PAGED 1 /* K [nb, Hkv, D/x, bs, x], V [nb, Hkv, D, bs], x = 16/elem_size   (:298-324) */
+#define MI355_KV_PAGED_FP8 2 /* the same with 1-byte OCP e4m3fn elements (x = 16): `--kvcache-dtype fp8` (host layers) */
 /* ggml tensor type ids (GGUF) */
 #define MI355_GGML_Q4_K 12
 #define MI355_GGML_Q6_K 14

@@ -143,13 +143,31 @@ class OracleLlama:
         of src/openai/distributed.rs:696-711,1632-1667)."""
         self.cfg, self.W, self.flash, self.o2, self.comm = cfg, W, flash_layout, o2, comm
         self.moe_top_k = 2                                           # llama.expert_used_count (Mixtral: 2)
+        self.kv_fp8 = False                                          # `--kvcache-dtype fp8`: e4m3fn cache (paged, x = 16)
         self.cos, self.sin = ops.rope_tables(cfg.rope_theta, cfg.head_dim, cfg.max_seq)
         self.scale = 1.0 / np.sqrt(float(cfg.head_dim))
 
     def new_cache(self, num_blocks):
         c = self.cfg
+        if self.kv_fp8:
+            ks, vs = ops.kv_cache_shapes(num_blocks, c.block_size, c.n_kv_heads, c.head_dim, 1, False)
+            return [(np.zeros(ks, np.uint8), np.zeros(vs, np.uint8)) for _ in range(c.n_layers)]
         ks, vs = ops.kv_cache_shapes(num_blocks, c.block_size, c.n_kv_heads, c.head_dim, 2, self.flash)
         return [(np.zeros(ks, np.uint16), np.zeros(vs, np.uint16)) for _ in range(c.n_layers)]
+
+    def _attend_fp8(self, meta, qb, k, v, kc, vc, is_prefill):
+        """e4m3fn cache: the bf16-rounded k, v are quantised on write and every key comes back dequantised."""
+        ops.reshape_and_cache_fp8(ops.round_bf16(k), ops.round_bf16(v), kc, vc, meta["slot_mapping"], False)
+        kb, vb = ops.fp8_cache_as_bf16_bits(kc, vc, False)
+        if not is_prefill:
+            return ops.paged_attention_decode(qb, kb, vb, meta["block_tables"], meta["context_lens"], self.scale, False)
+        ys, cu = [], meta["cu_seqlens_q"]
+        for i in range(len(cu) - 1):
+            a, b = int(cu[i]), int(cu[i + 1])
+            n = int(meta["context_lens"][i])
+            kk, vv = ops.gather_kv(kb, vb, meta["block_tables"][i], n, False)
+            ys.append(ops.prefill_attention(qb[a:b], ops.bf16_bits_to_f32(kk), ops.bf16_bits_to_f32(vv), self.scale, cached=n - (b - a)))
+        return np.concatenate(ys, 0)
 
     def forward(self, meta, kv_caches, is_prefill=False, trace=None):
         """meta: dict from ops.prepare_decode / prepare_prompt.  Returns logits f32 [B, V]."""
@@ -167,8 +185,13 @@ class OracleLlama:
             k = ops.rope_apply(k, self.cos, self.sin, pos, interleaved=True)
             qb, kb, vb = ops.round_bf16(q), ops.f32_to_bf16_bits(k), ops.f32_to_bf16_bits(v)
             kc, vc = kv_caches[l]
-            ops.reshape_and_cache(kb, vb, kc, vc, meta["slot_mapping"], self.flash)
-            if is_prefill:
+            if self.kv_fp8:
+                y = self._attend_fp8(meta, qb, k, v, kc, vc, is_prefill)
+            else:
+                ops.reshape_and_cache(kb, vb, kc, vc, meta["slot_mapping"], self.flash)
+            if self.kv_fp8:
+                pass
+            elif is_prefill:
                 ys = []
                 cu = meta["cu_seqlens_q"]
                 for i in range(len(cu) - 1):

@@ -283,3 +283,44 @@ def test_moe_model_prompt_and_graph_decode(lib):
             gm.decode_step(stream.cuda_stream)
             got_t.append([int(t) for t in gm.read_tokens(stream.cuda_stream)])
         assert got_t == want, (use_graph, got_t, want)
+
+
+def test_mixtral_shape_with_fp8_kv_and_chunked_prefill(lib):
+    """BASELINE config 5's ingredients on one GPU, tiny: MoE MLP (4 experts, top-2) + fp8 (e4m3fn) KV cache +
+    chunked prefill (second chunk attends to the quantised first chunk) + decode; vs the oracle with the same choices.
+    Tolerance: e4m3 rounding flips of K/V entries (6 % each) -> 6e-2 of the logit scale."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from candle_vllm_amd import model as M
+    cfg = llama.LlamaConfig.tiny()
+    cfg.n_expert, cfg.n_expert_used = 4, 2
+    W = llama.make_moe_weights(cfg, 4, seed=78)
+    orc = llama.OracleLlama(cfg, W, flash_layout=False)
+    orc.kv_fp8 = True
+    rng = np.random.default_rng(19)
+    seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 40)], "block_table": [3, 7, 9]},
+            {"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 30)], "block_table": [1, 5]}]
+    cache = orc.new_cache(16)
+    gm = M.GGUFLLaMa(cfg, max_batch=4, kv_layout=M.KV_PAGED_FP8)
+    gm.load_oracle_weights(W)
+    gm.alloc_kv_cache(16)
+    first = [{"tokens": s["tokens"][:16], "block_table": s["block_table"]} for s in seqs]
+    m1 = O.prepare_prompt(first, cfg.block_size)
+    orc.forward(m1, cache, is_prefill=True)
+    gm.forward_prefill(m1)
+    m2 = O.prepare_prompt(seqs, cfg.block_size, num_cached_tokens=[16, 16])
+    ref = orc.forward(m2, cache, is_prefill=True)
+    got = gm.forward_prefill(m2).cpu().numpy()
+    assert _rel(got, ref) < 6e-2, _rel(got, ref)
+    gk, gv = gm.kv_download_u8(0)                         # layer 0's cache bytes: equal up to rare 1-step e4m3 flips
+    used = sorted(b for s in seqs for b in s["block_table"])
+    for got_b, ref_b in ((gk[used], cache[0][0][used]), (gv[used], cache[0][1][used])):
+        a, b = O.e4m3fn_to_f32(got_b), O.e4m3fn_to_f32(ref_b)
+        assert (got_b != ref_b).mean() < 0.02
+        assert np.abs(a - b).max() <= 0.126 * np.maximum(np.abs(a), np.abs(b)).max()
+    for s, row in zip(seqs, ref):
+        s["tokens"].append(int(row.argmax()))
+    dmeta = O.prepare_decode(seqs, cfg.block_size)
+    dref = orc.forward(dmeta, cache)
+    dgot = gm.forward_decode(dmeta).cpu().numpy()
+    assert _rel(dgot, dref) < 6e-2, _rel(dgot, dref)
