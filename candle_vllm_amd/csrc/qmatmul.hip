@@ -1287,6 +1287,153 @@ static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+// ================================================================================================
+// Prompt-step path (num_tokens >= QMP_MIN_TOKENS): the matmul is compute-bound, so it is run as a plain GEMM on the
+// matrix cores instead of streaming the quantised weights once per 32 tokens.
+//   1. `qmp_dequant_kernel`  : repacked Q4_K / Q6_K tiles -> bf16 hi + bf16 lo, row-major [N, K] (w = hi + lo to 2^-17)
+//   2. `qmp_xsplit_kernel`   : activations (RMSNorm applied here) -> bf16 hi + lo, row-major [T, K]
+//   3. three library GEMMs (rocBLAS, bf16 inputs, f32 accumulate): hi.hi + hi.lo + lo.hi  -> f32 [T, N]
+//      (candle's own GPU path dequantises to f16 and calls the vendor GEMM for prompts [EXT]; the hi/lo split keeps
+//       the result at f32-activation accuracy so the same 1e-3 logit bound holds as for decode)
+//   4. `qmm_epilogue_kernel` : the same fused epilogues (bias / residual / SiLU*mul / RoPE + cache scatter)
+// rocBLAS is bound with dlopen (the copy torch already loaded if there is one), like RCCL in host_model.cpp.
+#include <dlfcn.h>
+#define QMP_MIN_TOKENS 96
+
+__device__ __forceinline__ float dequant_tile(int type, const uint8_t* __restrict__ t, int r, int i) {
+    if (type == MI355_GGML_Q4_K) {
+        const uint8_t* h = t + r * 16;
+        const float d = f16_bits_to_f32(*reinterpret_cast<const uint16_t*>(h));
+        const float dmin = f16_bits_to_f32(*reinterpret_cast<const uint16_t*>(h + 2));
+        const uint8_t* s = h + 4;
+        const int j = i >> 5, l = i & 31, g = j >> 1;
+        int sc, m;
+        if (j < 4) { sc = s[j] & 63; m = s[j + 4] & 63; }
+        else { sc = (s[j + 4] & 0xF) | ((s[j - 4] >> 6) << 4); m = (s[j + 4] >> 4) | ((s[j] >> 6) << 4); }
+        const uint8_t qb = t[256 + (g >> 1) * 1024 + ((l >> 3) * 16 + r) * 16 + (g & 1) * 8 + (l & 7)];
+        const int q = (j & 1) ? (qb >> 4) : (qb & 0xF);
+        return d * (float)sc * (float)q - dmin * (float)m;
+    } else {
+        const int8_t* sc = reinterpret_cast<const int8_t*>(t + r * 16);
+        const float d = f16_bits_to_f32(*reinterpret_cast<const uint16_t*>(t + 3328 + 2 * r));
+        const int n = i >> 7, tt = (i >> 5) & 3, l = i & 31;
+        const int w = 32 * (tt & 1) + l;                              // index inside ql[64n .. 64n+63]
+        const int seg = w >> 4, kg = (w >> 2) & 3, e = w & 3;
+        const int segoff = (seg == 0) ? 0 : (seg == 1 ? 8 : (seg == 2 ? 4 : 12));
+        const uint8_t lb = t[256 + n * 1024 + (kg * 16 + r) * 16 + segoff + e];
+        const int lo4 = (tt & 2) ? (lb >> 4) : (lb & 0xF);
+        const int v = 32 * n + l;                                     // index inside qh[0..63]
+        const uint8_t hb = t[2304 + (((v >> 2) & 3) * 16 + r) * 16 + 4 * (v >> 4) + (v & 3)];
+        const int q = (lo4 | (((hb >> (2 * tt)) & 3) << 4)) - 32;
+        return d * (float)sc[8 * n + 2 * tt + (l >> 4)] * (float)q;
+    }
+}
+
+// grid (k-blocks, row tiles); 256 threads = the 256 k of the block; loop over the 16 rows
+__global__ void __launch_bounds__(256) qmp_dequant_kernel(uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, const uint8_t* __restrict__ tiles,
+                                                          int type, int n_rows, int K) {
+    const int kb = blockIdx.x, rt = blockIdx.y, nkb = K >> 8;
+    const int tb = (type == MI355_GGML_Q4_K) ? Q4K_TILE : Q6K_TILE;
+    const uint8_t* t = tiles + ((size_t)rt * nkb + kb) * tb;
+    for (int r = 0; r < 16; ++r) {
+        const int row = rt * 16 + r;
+        if (row >= n_rows) break;
+        const float w = dequant_tile(type, t, r, threadIdx.x);
+        const uint16_t h = f32_to_bf16(w);
+        const size_t o = (size_t)row * K + (size_t)kb * 256 + threadIdx.x;
+        hi[o] = h;
+        lo[o] = f32_to_bf16(w - bf16_to_f32(h));
+    }
+}
+
+// one workgroup per token row: optional RMSNorm, then hi/lo bf16
+__global__ void __launch_bounds__(256) qmp_xsplit_kernel(uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, const QmmArgs a) {
+    __shared__ float red[16];
+    const int b = blockIdx.x;
+    float inv = 1.f;
+    auto ldx = [&](int k) -> float {
+        if (a.x_dtype == MI355_DTYPE_BF16) return bf16_to_f32(static_cast<const uint16_t*>(a.x)[(size_t)b * a.ldx + k]);
+        return static_cast<const float*>(a.x)[(size_t)b * a.ldx + k];
+    };
+    if (a.norm_w) {
+        float ss = 0.f;
+        for (int k = threadIdx.x; k < a.K; k += blockDim.x) { const float v = ldx(k); ss += v * v; }
+        inv = rsqrtf(block_sum(ss, red) / (float)a.K + a.eps);
+    }
+    for (int k = threadIdx.x; k < a.K; k += blockDim.x) {
+        float v = ldx(k);
+        if (a.norm_w) v = v * inv * a.norm_w[k];
+        const uint16_t h = f32_to_bf16(v);
+        hi[(size_t)b * a.K + k] = h;
+        lo[(size_t)b * a.K + k] = f32_to_bf16(v - bf16_to_f32(h));
+    }
+}
+
+struct QmpBlas {
+    void* lib = nullptr; void* handle = nullptr;
+    int (*create)(void**) = nullptr;
+    int (*set_stream)(void*, hipStream_t) = nullptr;
+    int (*gemm_ex)(void*, int, int, int, int, int, const void*, const void*, int, int, const void*, int, int, const void*,
+                   const void*, int, int, void*, int, int, int, int, int32_t, uint32_t) = nullptr;
+};
+static QmpBlas g_blas;
+static bool qmp_blas_load() {
+    if (g_blas.handle) return true;
+    if (!g_blas.lib) {
+        const char* names[] = {"librocblas.so", "librocblas.so.5", "/opt/rocm/lib/librocblas.so"};
+        for (const char* n : names) { g_blas.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (g_blas.lib) break; }
+        for (const char* n : names) { if (g_blas.lib) break; g_blas.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); }
+        if (!g_blas.lib) return false;
+        g_blas.create = (int (*)(void**))dlsym(g_blas.lib, "rocblas_create_handle");
+        g_blas.set_stream = (int (*)(void*, hipStream_t))dlsym(g_blas.lib, "rocblas_set_stream");
+        g_blas.gemm_ex = (decltype(g_blas.gemm_ex))dlsym(g_blas.lib, "rocblas_gemm_ex");
+        if (!g_blas.create || !g_blas.set_stream || !g_blas.gemm_ex) return false;
+    }
+    return g_blas.create(&g_blas.handle) == 0 && g_blas.handle;
+}
+
+static void* g_qmp_ws = nullptr;
+static size_t g_qmp_ws_bytes = 0;
+
+static int qmp_launch(const QmmArgs& a0, hipStream_t st) {
+    QmmArgs a = a0;
+    a.paired = 0;
+    if (!qmp_blas_load()) return (int)hipErrorSharedObjectInitFailed;
+    int n_slots = 0, n_rows_total = 0;
+    for (int s = 0; s < a.nseg; ++s) { n_slots += a.seg[s].n_tiles; n_rows_total += a.seg[s].n_tiles * 16; }
+    const int T = a.B, K = a.K, ldp = n_slots * 16;
+    // workspace: w_hi, w_lo [ldp, K] bf16 | x_hi, x_lo [T, K] bf16 | C [T, ldp] f32
+    const size_t wb = (size_t)ldp * K * 2, xb = (size_t)T * K * 2, cb = (size_t)T * ldp * 4;
+    int rc = qmg_grow(&g_qmp_ws, &g_qmp_ws_bytes, 2 * wb + 2 * xb + cb + 1024, st);
+    if (rc) return rc;
+    uint16_t* w_hi = static_cast<uint16_t*>(g_qmp_ws);
+    uint16_t* w_lo = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(g_qmp_ws) + wb);
+    uint16_t* x_hi = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(g_qmp_ws) + 2 * wb);
+    uint16_t* x_lo = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(g_qmp_ws) + 2 * wb + xb);
+    float* C = reinterpret_cast<float*>(static_cast<uint8_t*>(g_qmp_ws) + 2 * wb + 2 * xb);
+    int row0 = 0;
+    for (int s = 0; s < a.nseg; ++s) {                     // concatenated padded row space, as the epilogue expects
+        hipLaunchKernelGGL(qmp_dequant_kernel, dim3(K >> 8, a.seg[s].n_tiles), dim3(256), 0, st, w_hi + (size_t)row0 * K,
+                           w_lo + (size_t)row0 * K, a.seg[s].w, a.seg[s].type, a.seg[s].n_tiles * 16, K);
+        row0 += a.seg[s].n_tiles * 16;
+    }
+    hipLaunchKernelGGL(qmp_xsplit_kernel, dim3(T), dim3(256), 0, st, x_hi, x_lo, a);
+    if (g_blas.set_stream(g_blas.handle, st) != 0) return (int)hipErrorUnknown;
+    // row-major C[T, ldp] = X[T,K] . W[ldp,K]^T   ==   column-major C^T[ldp, T] = op_T(W^T[K, ldp]) . X^T[K, T]
+    const float one = 1.f, zero = 0.f;
+    const int BF16 = 168, F32 = 151, OP_N = 111, OP_T = 112;
+    const uint16_t* Ws[3] = {w_hi, w_lo, w_hi};
+    const uint16_t* Xs[3] = {x_hi, x_hi, x_lo};
+    for (int g = 0; g < 3; ++g) {
+        const int st_rc = g_blas.gemm_ex(g_blas.handle, OP_T, OP_N, ldp, T, K, &one, Ws[g], BF16, K, Xs[g], BF16, K, g == 0 ? &zero : &one,
+                                         C, F32, ldp, C, F32, ldp, F32, 0, 0, 0);
+        if (st_rc != 0) return (int)hipErrorUnknown;
+    }
+    a.norm_w = nullptr;                                     // already applied to x
+    hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, T), dim3(256), 0, st, a, C, ldp, 1, T, (const float*)nullptr);
+    return (int)hipGetLastError();
+}
+
 static uint8_t* g_qmw_img = nullptr;
 static size_t g_qmw_img_bytes = 0;
 
@@ -1337,6 +1484,7 @@ static int qmw_launch_mt(const QmmArgs& a, int wt, hipStream_t st) {
 void mi355_pa_set_fused(int v);
 extern "C" void mi355_host_set_partition_override(int v);
 static int g_tune_nw = 0, g_tune_r = 0, g_tune_dbg = 0;   // 0 = heuristic; mi355_set_tuning (experiments only)
+static int g_tune_prefill_gemm = 1;                        // 0 = always stream the quantised weights (experiments)
 static int g_tune_wide = 2;                                // wide path generation (1 = fused single-pass, 2 = split GEMM + epilogue)
 extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     if (key == 0) g_tune_nw = value;
@@ -1345,6 +1493,7 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     else if (key == 3) mi355_pa_set_fused(value);
     else if (key == 4) g_tune_wide = value;
     else if (key == 5) mi355_host_set_partition_override(value);
+    else if (key == 6) g_tune_prefill_gemm = value;
 }
 
 static size_t qmm_lds_bytes(int BT, int R, int NW) {
@@ -1464,6 +1613,10 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
         if (a.moe_pairs < 1 || a.moe_xdiv < 1 || a.epi == MI355_EPI_QKV_ROPE_CACHE || a.epi == MI355_EPI_RESID) return (int)hipErrorInvalidValue;
         a.B = 1;
         return qmm_launch_bt<1>(a, R, wt, n_wg, NW, st);
+    }
+    if (a.B >= QMP_MIN_TOKENS && g_tune_prefill_gemm) {      // prompt step: dequantise once, library GEMM on the matrix cores
+        const int rcp = qmp_launch(a, st);
+        if (rcp != (int)hipErrorSharedObjectInitFailed) return rcp;     // no rocBLAS on this box: stream the weights instead
     }
     const int B = a.B;
     const size_t xes = (a.x_dtype == MI355_DTYPE_BF16) ? 2 : 4;

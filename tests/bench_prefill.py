@@ -1,0 +1,38 @@
+"""Scratch benchmark (run on the MI355X): GGUF Llama-3-8B Q4_K_M prompt step, synthetic weights -- tokens/s of one
+`forward_prefill` over a T-token prompt with the GEMM path on / off."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import llama, ops as O  # noqa: E402
+from candle_vllm_amd import model as M  # noqa: E402
+
+
+def main():
+    cfg = llama.LlamaConfig.llama3_8b()
+    gm = M.GGUFLLaMa(cfg, max_batch=4, max_blocks_per_seq=80, kv_layout=M.KV_PAGED)
+    gm.load_synthetic()
+    gm.alloc_kv_cache(160)
+    rng = np.random.default_rng(0)
+    for T in (512, 2048, 4096):
+        seqs = [{"tokens": rng.integers(0, cfg.vocab, T).tolist(), "block_table": list(range(1, 1 + -(-T // cfg.block_size)))}]
+        meta = O.prepare_prompt(seqs, cfg.block_size)
+        for mode in (1, 0):
+            if mode == 0 and T > 512:
+                continue
+            M.lib.mi355_set_tuning(6, mode)
+            gm.forward_prefill(meta)
+            t0 = time.perf_counter()
+            gm.forward_prefill(meta)
+            dt = time.perf_counter() - t0
+            flops = 2.0 * (gm.weight_bytes / 0.5625) * T          # ~ 2 * params * tokens (Q4_K: 0.5625 B / weight)
+            print(f"prefill T={T:5d} gemm={mode}: {T / dt:9.1f} tok/s  {dt * 1e3:8.1f} ms  ~{flops / dt / 1e12:6.1f} TFLOP/s", flush=True)
+    M.lib.mi355_set_tuning(6, 1)
+
+
+if __name__ == "__main__":
+    main()

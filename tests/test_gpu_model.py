@@ -324,3 +324,30 @@ def test_mixtral_shape_with_fp8_kv_and_chunked_prefill(lib):
     dref = orc.forward(dmeta, cache)
     dgot = gm.forward_decode(dmeta).cpu().numpy()
     assert _rel(dgot, dref) < 6e-2, _rel(dgot, dref)
+
+
+def test_long_prompt_uses_the_gemm_path_and_matches(lib):
+    """a 150-token prompt step goes through the prompt GEMM path (dequantise once + matrix-core GEMM, hi/lo split):
+    same logits as streaming the quantised weights 32 tokens at a time, and within the prefill bound of the oracle."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from candle_vllm_amd import model as M
+    cfg = llama.LlamaConfig.tiny()
+    W = llama.make_weights(cfg, seed=1234)
+    orc = llama.OracleLlama(cfg, W, flash_layout=False)
+    rng = np.random.default_rng(23)
+    seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 110)], "block_table": list(range(1, 8))},
+            {"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 40)], "block_table": [9, 10, 11]}]
+    meta = O.prepare_prompt(seqs, cfg.block_size)
+    ref = orc.forward(meta, orc.new_cache(16), is_prefill=True)
+    outs = []
+    for use_gemm in (1, 0):
+        M.lib.mi355_set_tuning(6, use_gemm)
+        gm = M.GGUFLLaMa(cfg, max_batch=4, kv_layout=M.KV_PAGED)
+        gm.load_oracle_weights(W)
+        gm.alloc_kv_cache(16)
+        outs.append(gm.forward_prefill(meta).cpu().numpy())
+    M.lib.mi355_set_tuning(6, 1)
+    assert _rel(outs[0], ref) < 3e-3, _rel(outs[0], ref)
+    assert _rel(outs[0], outs[1]) < 2e-3
+    assert [int(r.argmax()) for r in outs[0]] == [int(r.argmax()) for r in ref]

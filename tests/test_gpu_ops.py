@@ -271,7 +271,8 @@ def test_dequantize_and_ref_kernel(cv, t):
 
 @pytest.mark.parametrize("t", [kq.GGML_Q4_K, kq.GGML_Q6_K])
 @pytest.mark.parametrize("T,N,K", [(1, 64, 256), (1, 4096, 4096), (1, 40, 512), (2, 48, 1024), (3, 128, 4096),
-                                   (5, 32, 14336), (8, 256, 2048), (9, 64, 512), (32, 96, 4096)])
+                                   (5, 32, 14336), (8, 256, 2048), (9, 64, 512), (32, 96, 4096),
+                                   (128, 96, 1024), (200, 40, 512)])      # >= 96 tokens: prompt-step GEMM path
 def test_qmatmul_vs_oracle(cv, t, T, N, K):
     rng = np.random.default_rng(12 + T + N)
     blocks = kq.quantize(rng.normal(0, 0.05, (N, K)).astype(np.float32), t)
@@ -304,7 +305,7 @@ def test_qmatmul_random_bytes_all_code_points(cv):
         assert rel_err(mm.forward(dev(x)).cpu().numpy(), kq.qmatmul_o1(x, blocks, t)) < 1e-4
 
 
-@pytest.mark.parametrize("B", [3, 12, 32])
+@pytest.mark.parametrize("B", [3, 12, 32, 130])
 def test_fused_norm_qkv_rope_cache(cv, B):
     """[RMSNorm -> wq,wk,wv -> interleaved RoPE -> bf16 -> q_out / paged cache] == composition of oracles
     (B=3: per-wave kernel, B=12/32: wide-batch kernel)."""
@@ -347,7 +348,7 @@ def test_fused_norm_qkv_rope_cache(cv, B):
         assert np.abs(O.bf16_bits_to_f32(gvb[wv]) - O.bf16_bits_to_f32(vref[wv])).max() <= 2 ** -7 * np.abs(v).max()
 
 
-@pytest.mark.parametrize("B", [2, 9, 32])
+@pytest.mark.parametrize("B", [2, 9, 32, 128])
 def test_fused_silu_pair_and_residual(cv, B):
     rng = np.random.default_rng(15)
     hid, I = 1024, 512
