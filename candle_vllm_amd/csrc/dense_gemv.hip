@@ -291,8 +291,65 @@ static int dense_dispatch(const DenseArgs& a, int wtype, int dt, hipStream_t st)
     return -2;
 }
 
+// ---- prompt steps (T >= 96, dense weights): the matmul is compute-bound -> library GEMM on the matrix cores (bf16 / f16
+// output rounded once from the f32 accumulator, exactly what candle's Linear does through the vendor BLAS), then one
+// elementwise kernel for candle's rounding chain (+bias, +residual, silu(gate)*up).
+int mi355_internal_gemm_rowmajor(void* out, int out_dtype, int ldo, const void* x, const void* w, int in_dtype, int T, int N, int K,
+                                 hipStream_t st);
+
+template <int DT>
+__global__ void __launch_bounds__(256) dense_chain_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ y, const uint16_t* __restrict__ bias,
+                                                          const uint16_t* __restrict__ resid, int N, int ldo, int epi, int pair_offset) {
+    const int t = blockIdx.y;
+    const int n_out = epi == MI355_EPI_SILU_MUL ? pair_offset : N;
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_out) return;
+    float o = h2f<DT>(y[(size_t)t * N + row]);
+    if (bias) o = rnd<DT>(o + h2f<DT>(bias[row]));
+    if (epi == MI355_EPI_SILU_MUL) {
+        float u = h2f<DT>(y[(size_t)t * N + pair_offset + row]);
+        if (bias) u = rnd<DT>(u + h2f<DT>(bias[pair_offset + row]));
+        o = rnd<DT>(rnd<DT>(o / (1.f + __expf(-o))) * u);
+    } else if (epi == MI355_EPI_RESID) {
+        o = rnd<DT>(o + h2f<DT>(resid[(size_t)t * ldo + row]));
+    }
+    out[(size_t)t * ldo + row] = f2h<DT>(o);
+}
+
+static void* g_dense_ws = nullptr;
+static size_t g_dense_ws_bytes = 0;
+
+static int dense_prompt_gemm(const DenseArgs& a, int dt, hipStream_t st) {
+    const bool direct = a.epi == MI355_EPI_STORE && !a.bias;                 // no chain: the GEMM writes `out` itself
+    uint16_t* y = static_cast<uint16_t*>(a.out);
+    if (!direct) {
+        const size_t need = (size_t)a.T * a.N * 2;
+        if (need > g_dense_ws_bytes) {
+            if (g_dense_ws) { (void)hipDeviceSynchronize(); (void)hipFree(g_dense_ws); g_dense_ws = nullptr; g_dense_ws_bytes = 0; }
+            if (hipMalloc(&g_dense_ws, need * 2) != hipSuccess) return (int)hipErrorOutOfMemory;
+            g_dense_ws_bytes = need * 2;
+        }
+        y = static_cast<uint16_t*>(g_dense_ws);
+    }
+    const int rc = mi355_internal_gemm_rowmajor(y, dt, direct ? a.ldo : a.N, a.x, a.w, dt, a.T, a.N, a.K, st);
+    if (rc || direct) return rc;
+    const int n_out = a.epi == MI355_EPI_SILU_MUL ? a.pair_offset : a.N;
+    dim3 grid((n_out + 255) / 256, a.T);
+    if (dt == MI355_DTYPE_BF16)
+        hipLaunchKernelGGL((dense_chain_kernel<MI355_DTYPE_BF16>), grid, dim3(256), 0, st, static_cast<uint16_t*>(a.out), y,
+                           static_cast<const uint16_t*>(a.bias), static_cast<const uint16_t*>(a.resid), a.N, a.ldo, a.epi, a.pair_offset);
+    else
+        hipLaunchKernelGGL((dense_chain_kernel<MI355_DTYPE_F16>), grid, dim3(256), 0, st, static_cast<uint16_t*>(a.out), y,
+                           static_cast<const uint16_t*>(a.bias), static_cast<const uint16_t*>(a.resid), a.N, a.ldo, a.epi, a.pair_offset);
+    return (int)hipGetLastError();
+}
+
 // SILU_MUL with more than 32 tokens, or any T > 64: run in token chunks
 static int dense_run(DenseArgs a, int wtype, int dt, hipStream_t st) {
+    if (wtype == DW_DENSE && a.T >= 96 && a.ldx == a.K && a.ldw == a.K) {
+        const int rc = dense_prompt_gemm(a, dt, st);
+        if (rc != (int)hipErrorSharedObjectInitFailed) return rc;          // no rocBLAS: keep streaming in chunks
+    }
     const int chunk = a.epi == MI355_EPI_SILU_MUL ? 32 : 64;
     const int T = a.T;
     if (T < 1) return -2;

@@ -1392,6 +1392,20 @@ static bool qmp_blas_load() {
     return g_blas.create(&g_blas.handle) == 0 && g_blas.handle;
 }
 
+// plain row-major GEMM on the library for the other translation units (dense_gemv.hip):
+//   out[T, ldo] (bf16 / f16 when out_dtype says so, else f32) = x[T, K] . w[N, K]^T, f32 accumulate, inputs `in_dtype`
+// returns hipErrorSharedObjectInitFailed when rocBLAS cannot be loaded (callers then keep their own kernels)
+int mi355_internal_gemm_rowmajor(void* out, int out_dtype, int ldo, const void* x, const void* w, int in_dtype, int T, int N, int K,
+                                 hipStream_t st) {
+    if (!qmp_blas_load()) return (int)hipErrorSharedObjectInitFailed;
+    if (g_blas.set_stream(g_blas.handle, st) != 0) return (int)hipErrorUnknown;
+    auto ty = [](int dt) { return dt == MI355_DTYPE_BF16 ? 168 : (dt == MI355_DTYPE_F16 ? 150 : 151); };
+    const float one = 1.f, zero = 0.f;
+    const int rc = g_blas.gemm_ex(g_blas.handle, 112, 111, N, T, K, &one, w, ty(in_dtype), K, x, ty(in_dtype), K, &zero, out, ty(out_dtype), ldo,
+                                  out, ty(out_dtype), ldo, 151, 0, 0, 0);
+    return rc == 0 ? 0 : (int)hipErrorUnknown;
+}
+
 static void* g_qmp_ws = nullptr;
 static size_t g_qmp_ws_bytes = 0;
 

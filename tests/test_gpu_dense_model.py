@@ -28,7 +28,7 @@ def test_dense_llama_prompt_then_decode(lib, flash, qkv_bias):
     rng = np.random.default_rng(3)
     seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 37)], "block_table": [3, 7, 2]},
             {"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 5)], "block_table": [1]},
-            {"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 18)], "block_table": [9, 4]}]
+            {"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 74)], "block_table": [9, 4, 5, 6, 8]}]   # 116 tokens: GEMM path
     cache = orc.new_cache(16)
     meta = O.prepare_prompt(seqs, cfg.block_size)
     ref = orc.forward(meta, cache, is_prefill=True)

@@ -51,7 +51,7 @@ def check_ulp(got, ref, dt, ulps=1.01, what="", mag=None):
 # ------------------------------------------------------------------------------------------------ K10 dense
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("T,N,K", [(1, 256, 512), (5, 48, 256), (16, 1024, 1024), (17, 64, 768), (33, 128, 512),
-                                   (64, 96, 256), (70, 32, 512)])
+                                   (64, 96, 256), (70, 32, 512), (128, 64, 512), (200, 48, 256)])   # >= 96: library GEMM path
 def test_linear_matches_oracle(cv, dt, T, N, K):
     rng = np.random.default_rng(T * 1000 + N)
     x = G.round_dt(rng.normal(0, 1, (T, K)), dt)
@@ -68,7 +68,7 @@ def test_linear_matches_oracle(cv, dt, T, N, K):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
-@pytest.mark.parametrize("T", [1, 8, 32, 40])
+@pytest.mark.parametrize("T", [1, 8, 32, 40, 130])
 def test_linear_gate_up_silu(cv, dt, T):
     rng = np.random.default_rng(T)
     K, I = 512, 192
