@@ -115,6 +115,30 @@ def bench_batch32(gm, cfg, args, perm, blocks_per_seq, stream, kv_per_tok):
             "roofline_tok_s_at_8TBs": round(B * HBM_PEAK_GBS * 1e9 / step_bytes, 1)}
 
 
+def bench_prefill(gm, cfg, perm, blocks_per_seq, T=2048):
+    """Secondary: one prompt step over a T-token prompt (the prompt-step GEMM path; MFMA-bound, not HBM-bound)."""
+    import torch
+    from candle_vllm_amd.block_engine import BlockEngine      # the product's own block manager builds the step inputs
+    rng = np.random.default_rng(99)
+    nblk = -(-T // cfg.block_size)
+    eng = BlockEngine(cfg.block_size, nblk + 1, 0)
+    seq = eng.new_sequence(0, rng.integers(0, cfg.vocab, T).tolist())
+    eng.allocate([seq])
+    meta = eng.prepare_prompt([seq])
+    gm.forward_prefill(meta)                                   # warm-up (rocBLAS handle, workspaces)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gm.forward_prefill(meta)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    params = gm.weight_bytes_global / 0.5625                   # Q4_K: 0.5625 B per weight (Q6_K rows slightly under-counted)
+    useful = 2.0 * params * T / dt / 1e12
+    return {"value": round(T / dt, 1), "unit": "prompt tokens/s", "tokens": T, "ms": round(dt * 1e3, 2),
+            "useful_TFLOPs": round(useful, 1), "issued_TFLOPs_bf16": round(3 * useful, 1),
+            "frac_of_2.5PF_dense_bf16": round(3 * useful / 2500.0, 3),
+            "note": "hi/lo split = 3 bf16 GEMMs per matmul (rocBLAS) + dequant + prefill attention"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -216,6 +240,10 @@ def main():
         out["roofline"] = gm.dominant_kernel_roofline(stream, HBM_PEAK_GBS)
         if do_b32:
             out["batch32"] = bench_batch32(gm, cfg, args, perm, blocks_per_seq, stream, kv_per_tok)
+            try:
+                out["prefill"] = bench_prefill(gm, cfg, perm, blocks_per_seq)
+            except Exception as e:                            # secondary number only
+                out["prefill"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps)

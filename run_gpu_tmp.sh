@@ -1,3 +1,5 @@
 mkdir -p gpurun_out
-timeout 400 python -m pytest tests/test_gpu_linear.py tests/test_gpu_dense_model.py -m gpu -q 2>&1 | grep -E "passed|failed|^E  |^FAILED|Error" | head -20 > gpurun_out/dg.log
-cat gpurun_out/dg.log
+timeout 500 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+python -c "
+import json; d=json.load(open('gpurun_out/bench_default.json'))
+print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['batch32']['value'], d['prefill'], d['cpu_baseline']['value'])"
