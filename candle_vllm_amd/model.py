@@ -208,15 +208,15 @@ class GGUFLLaMa:
         rows = {}
         for part in range(5):
             evs = []
-            for _ in range(reps):
-                for l in range(L):
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(stream)
+            for _ in range(reps + 1):                         # first sweep = warm-up
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for l in range(L):                            # back to back: the host runs ahead of the GPU
                     _check(lib.mi355_llama_run_part(self.h, l, part, st), "run_part")
-                    e1.record(stream)
-                    evs.append((e0, e1))
+                e1.record(stream)
+                evs.append((e0, e1))
             torch.cuda.synchronize()
-            us = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+            us = sorted(a.elapsed_time(b) * 1e3 / L for a, b in evs[1:])
             avg = float(np.mean(us))
             nbytes = kv_bytes if part == 1 else float(np.mean([self.part_bytes[(l, part)] for l in range(L)]))
             rows[part] = {"kernel": names[part], "avg_us": round(avg, 2), "median_us": round(us[len(us) // 2], 2),
@@ -236,7 +236,8 @@ class GGUFLLaMa:
         return {"bound": "hbm", "kernel": r["kernel"], "achieved": r["GBs"], "peak": peak_gbs, "unit": "GB/s",
                 "frac": round(r["GBs"] / peak_gbs, 4), "traffic": traffic, "avg_us": r["avg_us"],
                 "algorithmic_bytes_per_launch": r["bytes"],
-                "timing": "hipEvent pairs around each launch on the step stream, eager, all layers x %d reps" % reps,
+                "timing": "one hipEvent pair around the launches of all %d layers back to back on the step stream "
+                          "(each streams its own weights from HBM), / %d, %d sweeps" % (L, L, reps),
                 "groups": [rows[p] for p in sorted(rows)]}
 
     # ------------------------------------------------------------------ KV cache (CacheEngine)
