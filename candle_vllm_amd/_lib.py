@@ -7,7 +7,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355vllm.so")
+LIB_PATH = os.environ.get("MI355_LIB_PATH") or os.path.join(_HERE, "libmi355vllm.so")   # env override: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mi355_vllm.h")
 
 
@@ -194,7 +194,7 @@ class DenseConfig(ctypes.Structure):
                                      "vocab", "max_seq", "block_size", "kv_layout", "max_batch",
                                      "max_blocks_per_seq")] + \
                [("rms_eps", c_f32), ("rope_theta", c_f32), ("dtype", c_i32), ("rope_interleaved", c_i32),
-                ("norm_type", c_i32), ("rotary_dim", c_i32), ("kv_fp8", c_i32)]
+                ("norm_type", c_i32), ("rotary_dim", c_i32), ("kv_fp8", c_i32), ("tp_rank", c_i32), ("tp_world", c_i32)]
 
 
 _sig("mi355_layer_norm", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_i64])
@@ -203,6 +203,11 @@ _sig("mi355_dense_destroy", None, [c_vp])
 _sig("mi355_dense_set_weight", ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_i64])
 _sig("mi355_dense_set_weight_dev", ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_i64])
 _sig("mi355_dense_set_gptq", ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32])
+_sig("mi355_dense_set_comm", ctypes.c_int, [c_vp, c_vp])
+_sig("mi355_comm_create", c_vp, [c_vp, c_i32, c_i32])
+_sig("mi355_comm_destroy", None, [c_vp])
+_sig("mi355_comm_all_reduce", ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i64])
+_sig("mi355_comm_all_gather", ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64])
 _sig("mi355_dense_alloc_kv_cache", ctypes.c_int, [c_vp, c_i32])
 _sig("mi355_dense_kv_ptr", c_vp, [c_vp, c_i32, c_i32])
 _sig("mi355_dense_forward", ctypes.c_int, [c_vp] * 7 + [c_i32] * 5 + [c_vp, c_i64])

@@ -9,9 +9,11 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/mi355_vllm.h"
+#include "common.h"
 
 namespace {
 
@@ -42,7 +44,27 @@ struct DModel {
     void* kv_slab = nullptr;
     std::vector<void*> kcache, vcache;
     int num_blocks = 0;
+    void* comm = nullptr;                 // borrowed communicator (tp_world > 1, or a 1-rank plumbing test)
+    uint16_t* lg_gather = nullptr;        // [W, B, V/W]
 };
+
+// [W, B, Vl] -> [B, W*Vl]   (VocabParallelLinear: all-gather then un-interleave, distributed.rs:1637-1663)
+__global__ void gather_transpose16_kernel(uint16_t* out, const uint16_t* in, int W, int B, int Vl) {
+    const int64_t n = (int64_t)W * B * Vl;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % Vl), b = (int)((i / Vl) % B), w = (int)(i / ((int64_t)Vl * B));
+        out[((int64_t)b * W + w) * Vl + v] = in[i];
+    }
+}
+
+// xs = round(xs + y): the block's residual add after the row-parallel all-reduce (llama.rs:55-58 over
+// TensorParallelRowLinear::forward, distributed.rs:696-711)
+__global__ void add16_kernel(uint16_t* xs, const uint16_t* y, int64_t n, int is_bf16) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (is_bf16) xs[i] = f32_to_bf16(bf16_to_f32(xs[i]) + bf16_to_f32(y[i]));
+        else xs[i] = f32_to_f16_bits(f16_bits_to_f32(xs[i]) + f16_bits_to_f32(y[i]));
+    }
+}
 
 __global__ void embedding16_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ table,
                                    const uint32_t* __restrict__ ids, int hidden) {
@@ -60,6 +82,7 @@ int ensure_cap(DModel* m, int T) {
     DHIP(hipDeviceSynchronize());
     void* old[] = {m->xs, m->xn, m->q, m->k, m->v, m->attn, m->h, m->lg16};
     for (void* p : old) if (p) (void)hipFree(p);
+    m->xs = m->xn = m->q = m->k = m->v = m->attn = m->h = m->lg16 = nullptr;
     const mi355_dense_config& c = m->cfg;
     const int cap = (T + 63) / 64 * 64;
     const size_t hid = c.hidden, HD = (size_t)c.n_heads * c.head_dim, KD = (size_t)c.n_kv_heads * c.head_dim;
@@ -70,7 +93,10 @@ int ensure_cap(DModel* m, int T) {
     DHIP(hipMalloc((void**)&m->v, cap * KD * 2));
     DHIP(hipMalloc((void**)&m->attn, cap * HD * 2));
     DHIP(hipMalloc((void**)&m->h, (size_t)cap * c.intermediate * 2));
-    DHIP(hipMalloc((void**)&m->lg16, (size_t)c.max_batch * c.vocab * 2));
+    const int W = c.tp_world > 1 ? c.tp_world : 1;
+    DHIP(hipMalloc((void**)&m->lg16, (size_t)c.max_batch * c.vocab * W * 2));
+    if (m->lg_gather) (void)hipFree(m->lg_gather);
+    DHIP(hipMalloc((void**)&m->lg_gather, (size_t)c.max_batch * c.vocab * W * 2));
     m->cap = cap;
     return 0;
 }
@@ -146,7 +172,7 @@ void mi355_dense_destroy(void* mp) {
         for (auto& g : L.gq) { if (g.qw) (void)hipFree(g.qw); if (g.scales) (void)hipFree(g.scales); }
     }
     void* ps[] = {m->tok_embd, m->output_norm, m->output_norm_b, m->output, m->cos_t, m->sin_t, m->xs, m->xn, m->q, m->k, m->v, m->attn,
-                  m->h, m->lg16, m->pa_tmp, m->pa_max, m->pa_sum, m->kv_slab};
+                  m->h, m->lg16, m->pa_tmp, m->pa_max, m->pa_sum, m->kv_slab, m->lg_gather};
     for (void* p : ps) if (p) (void)hipFree(p);
     delete m;
 }
@@ -222,6 +248,13 @@ int mi355_dense_set_gptq(void* mp, int32_t layer, int32_t which, const void* qwe
     if (!q.scales) DHIP(hipMalloc((void**)&q.scales, (size_t)(k / g) * ntot * 2));
     DHIP(hipMemcpy2D(q.qw + col0, (size_t)ntot * 4, qweight_host, (size_t)n * 4, (size_t)n * 4, k / 8, hipMemcpyHostToDevice));
     DHIP(hipMemcpy2D(q.scales + col0, (size_t)ntot * 2, scales_host, (size_t)n * 2, (size_t)n * 2, k / g, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int mi355_dense_set_comm(void* mp, void* comm) {
+    DModel* m = static_cast<DModel*>(mp);
+    if (!m) return (int)hipErrorInvalidValue;
+    m->comm = comm;
     return 0;
 }
 
@@ -315,11 +348,27 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
         }
         }
         // xs = o_proj(y) + residual                                          llama.rs:55-58
-        DCHECK(linear(m, L.wo, L.gq[MI355_W_WO], m->xs, m->attn, nullptr, m->xs, T, hid, H * D, MI355_EPI_RESID, stream));
+        // TP (TensorParallelRowLinear, distributed.rs:696-711): the rounded partial products are all-reduced in the
+        // model dtype, then the block adds the residual -- the same three rounding points as the reference
+        const bool tp = m->comm != nullptr;
+        const int add_grid = (int)std::min<int64_t>(((int64_t)T * hid + 255) / 256, 2048);
+        if (tp) {
+            DCHECK(linear(m, L.wo, L.gq[MI355_W_WO], m->xn, m->attn, nullptr, nullptr, T, hid, H * D, MI355_EPI_STORE, stream));
+            DCHECK(mi355_comm_all_reduce(m->comm, m->xn, (int64_t)T * hid, dt, stream));
+            hipLaunchKernelGGL(add16_kernel, dim3(add_grid), dim3(256), 0, st, m->xs, m->xn, (int64_t)T * hid, dt == MI355_DTYPE_BF16);
+        } else {
+            DCHECK(linear(m, L.wo, L.gq[MI355_W_WO], m->xs, m->attn, nullptr, m->xs, T, hid, H * D, MI355_EPI_RESID, stream));
+        }
         // xs = down(silu(gate) * up) + residual                              llama.rs:59-61, mlp.rs:440-458
         DCHECK(norm(m, m->xn, m->xs, L.ffn_norm, L.ffn_norm_b, T, stream));
         DCHECK(linear(m, L.gate_up, L.gq[MI355_W_W1], m->h, m->xn, nullptr, nullptr, T, 2 * I, hid, MI355_EPI_SILU_MUL, stream));
-        DCHECK(linear(m, L.w2, L.gq[MI355_W_W2], m->xs, m->h, nullptr, m->xs, T, hid, I, MI355_EPI_RESID, stream));
+        if (tp) {
+            DCHECK(linear(m, L.w2, L.gq[MI355_W_W2], m->xn, m->h, nullptr, nullptr, T, hid, I, MI355_EPI_STORE, stream));
+            DCHECK(mi355_comm_all_reduce(m->comm, m->xn, (int64_t)T * hid, dt, stream));
+            hipLaunchKernelGGL(add16_kernel, dim3(add_grid), dim3(256), 0, st, m->xs, m->xn, (int64_t)T * hid, dt == MI355_DTYPE_BF16);
+        } else {
+            DCHECK(linear(m, L.w2, L.gq[MI355_W_W2], m->xs, m->h, nullptr, m->xs, T, hid, I, MI355_EPI_RESID, stream));
+        }
     }
     const uint16_t* last = m->xs;
     if (prefill) {                                                          // llama.rs:190-194
@@ -328,6 +377,13 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
         last = m->xs;
     }
     DCHECK(norm(m, m->xn, last, m->output_norm, m->output_norm_b, num_seqs, stream));
+    if (m->comm) {                                                          // VocabParallelLinear (distributed.rs:1632-1667)
+        const int W = c.tp_world > 1 ? c.tp_world : 1;
+        DCHECK(mi355_linear(m->lg16, m->xn, m->output, nullptr, nullptr, num_seqs, c.vocab, hid, dt, MI355_EPI_STORE, stream));
+        DCHECK(mi355_comm_all_gather(m->comm, m->lg16, m->lg_gather, (int64_t)num_seqs * c.vocab, dt, stream));
+        hipLaunchKernelGGL(gather_transpose16_kernel, dim3(512), dim3(256), 0, st, m->lg16, m->lg_gather, W, num_seqs, c.vocab);
+        return mi355_cast(logits, m->lg16, (int64_t)num_seqs * c.vocab * W, dt, MI355_DTYPE_F32, stream);
+    }
     DCHECK(mi355_linear(m->lg16, m->xn, m->output, nullptr, nullptr, num_seqs, c.vocab, hid, dt, MI355_EPI_STORE, stream));
     return mi355_cast(logits, m->lg16, (int64_t)num_seqs * c.vocab, dt, MI355_DTYPE_F32, stream);
 }

@@ -869,6 +869,28 @@ extern "C" int mi355_llama_init_comm(void* mp, const void* id128) {
     return g_rccl.init_rank(&m->comm, m->cfg.tp_world, id, m->cfg.tp_rank) == 0 ? 0 : (int)hipErrorUnknown;
 }
 
+// ---- generic communicator handle (the reference's `Comm`, one per process: pipeline.rs:805-812) for the other host
+// layers: create from the 128-byte unique id, in-stream all-reduce(sum) / all-gather, dtype = MI355_DTYPE_F32 / BF16 / F16
+static int nccl_dtype_of(int dt) { return dt == MI355_DTYPE_F32 ? 7 : (dt == MI355_DTYPE_F16 ? 6 : (dt == MI355_DTYPE_BF16 ? 9 : -1)); }
+extern "C" void* mi355_comm_create(const void* id128, int32_t rank, int32_t world) {
+    if (!id128 || world < 1 || rank < 0 || rank >= world || !rccl_load()) return nullptr;
+    NcclId id;
+    memcpy(&id, id128, sizeof(id));
+    void* comm = nullptr;
+    return g_rccl.init_rank(&comm, world, id, rank) == 0 ? comm : nullptr;
+}
+extern "C" void mi355_comm_destroy(void* comm) { if (comm && g_rccl.destroy) (void)g_rccl.destroy(comm); }
+extern "C" int mi355_comm_all_reduce(void* comm, void* buf, int64_t count, int32_t dtype, int64_t stream) {
+    const int dt = nccl_dtype_of(dtype);
+    if (!comm || dt < 0) return (int)hipErrorInvalidValue;
+    return g_rccl.all_reduce(buf, buf, (size_t)count, dt, NCCL_SUM, comm, reinterpret_cast<hipStream_t>(stream)) == 0 ? 0 : (int)hipErrorUnknown;
+}
+extern "C" int mi355_comm_all_gather(void* comm, const void* send, void* recv, int64_t count, int32_t dtype, int64_t stream) {
+    const int dt = nccl_dtype_of(dtype);
+    if (!comm || dt < 0) return (int)hipErrorInvalidValue;
+    return g_rccl.all_gather(send, recv, (size_t)count, dt, comm, reinterpret_cast<hipStream_t>(stream)) == 0 ? 0 : (int)hipErrorUnknown;
+}
+
 // ---- per-part launch for measurement: runs launch group `part` of layer `layer` on the static step inputs
 extern "C" int mi355_llama_run_part(void* mp, int32_t layer, int32_t part, int64_t stream) {
     Model* m = static_cast<Model*>(mp);

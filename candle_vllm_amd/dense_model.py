@@ -20,8 +20,10 @@ def _bf16_bits(a):
 
 
 class DenseLlama:
-    def __init__(self, cfg, max_batch=8, max_blocks_per_seq=64, kv_layout=KV_PAGED, rope_interleaved=False):
-        self.cfg, self.kv_layout = cfg, kv_layout
+    def __init__(self, cfg, max_batch=8, max_blocks_per_seq=64, kv_layout=KV_PAGED, rope_interleaved=False,
+                 tp_rank=0, tp_world=1):
+        """cfg: this rank's shard when tp_world > 1 (candle_vllm_amd.tp.shard_dense_config)"""
+        self.cfg, self.kv_layout, self.tp_rank, self.tp_world, self.comm = cfg, kv_layout, tp_rank, tp_world, None
         c = DenseConfig(hidden=cfg.hidden, n_layers=cfg.n_layers, n_heads=cfg.n_heads, n_kv_heads=cfg.n_kv_heads,
                         head_dim=cfg.head_dim, intermediate=cfg.intermediate, vocab=cfg.vocab, max_seq=cfg.max_seq,
                         block_size=cfg.block_size, kv_layout=kv_layout, max_batch=max_batch,
@@ -29,7 +31,7 @@ class DenseLlama:
                         dtype=DT_BF16, rope_interleaved=int(rope_interleaved),
                         norm_type=1 if getattr(cfg, "layer_norm", False) else 0,
                         rotary_dim=int(getattr(cfg, "rotary_dim", 0) or 0),
-                        kv_fp8=1 if getattr(cfg, "kv_fp8", False) else 0)
+                        kv_fp8=1 if getattr(cfg, "kv_fp8", False) else 0, tp_rank=tp_rank, tp_world=tp_world)
         self.h = lib.mi355_dense_create(ctypes.byref(c))
         if not self.h:
             raise RuntimeError("mi355_dense_create failed (bad config or no GPU memory)")
@@ -38,6 +40,23 @@ class DenseLlama:
         if getattr(self, "h", None) and lib is not None:
             lib.mi355_dense_destroy(self.h)
             self.h = None
+        if getattr(self, "comm", None) and lib is not None:
+            lib.mi355_comm_destroy(self.comm)
+            self.comm = None
+
+    def init_comm(self, id128=None):
+        """RCCL communicator of the tensor-parallel group (one process per GPU): rank 0 makes the id, the launcher
+        ships it (torch.distributed broadcast_object_list / the reference's pipe, pipeline.rs:805-812)."""
+        buf = np.zeros(128, np.uint8)
+        if id128 is None:
+            _check(lib.mi355_comm_unique_id(buf.ctypes.data), "comm_unique_id")
+        else:
+            buf[:] = np.frombuffer(bytes(id128), np.uint8)
+        self.comm = lib.mi355_comm_create(buf.ctypes.data, self.tp_rank, self.tp_world)
+        if not self.comm:
+            raise RuntimeError("mi355_comm_create failed (librccl missing or rendezvous error)")
+        _check(lib.mi355_dense_set_comm(self.h, self.comm), "dense_set_comm")
+        return bytes(buf)
 
     def set_weight(self, layer, name, values_f32):
         """values: f32 numpy, exactly representable in bf16 (checkpoint tensors)"""
@@ -141,7 +160,7 @@ class DenseLlama:
         cu = None
         if is_prefill:
             cu = torch.from_numpy(np.asarray(meta["cu_seqlens_q"]).astype(np.int64).astype(np.int32)).to(dev)
-        logits = torch.empty((n, self.cfg.vocab), dtype=torch.float32, device=dev)
+        logits = torch.empty((n, self.cfg.vocab * (self.tp_world if self.comm else 1)), dtype=torch.float32, device=dev)
         st = torch.cuda.current_stream().cuda_stream if stream is None else stream
         _check(lib.mi355_dense_forward(self.h, tok.data_ptr(), pos.data_ptr(), slots.data_ptr(), bt.data_ptr(),
                                        ctx.data_ptr(), cu.data_ptr() if cu is not None else None, n, T,

@@ -347,6 +347,13 @@ int mi355_llama_init_comm(void* model, const void* id128);
  * 3 gate/up, 4 down, 5 lm_head, 6 embedding) */
 int mi355_llama_run_part(void* model, int32_t layer, int32_t part, int64_t stream);
 
+/* generic communicator (the reference's per-process nccl `Comm`, pipeline.rs:805-812; collectives of
+ * distributed.rs:547-654,1335-1446): RCCL bound by dlopen; id128 from mi355_comm_unique_id on rank 0 */
+void* mi355_comm_create(const void* id128, int32_t rank, int32_t world);
+void mi355_comm_destroy(void* comm);
+int mi355_comm_all_reduce(void* comm, void* buf, int64_t count, int32_t dtype, int64_t stream);   /* sum, in place */
+int mi355_comm_all_gather(void* comm, const void* send, void* recv, int64_t count, int32_t dtype, int64_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * 4b. Host layer for 16-bit safetensors llama-family models (Llama / Qwen2 shapes): src/openai/models/llama.rs:
  *     39-201, layers/attention.rs:585-734, layers/mlp.rs:440-458.  Residual stream and every op result in the
@@ -361,6 +368,7 @@ typedef struct mi355_dense_config {
     int32_t norm_type;         /* 0 = RMSNorm, 1 = LayerNorm with bias (StableLM, stable_lm.rs:61-72) */
     int32_t rotary_dim;        /* <= head_dim; StableLM: partial_rotary_factor 0.25 (stable_lm.rs:28); 0 = head_dim */
     int32_t kv_fp8;            /* 1 = `--kvcache-dtype fp8`: U8 e4m3fn cache (PAGED layout, x = 16), scale 1.0 */
+    int32_t tp_rank, tp_world; /* tensor parallel: n_heads / n_kv_heads / intermediate / vocab are the LOCAL shard */
 } mi355_dense_config;
 #define MI355_W_BQ 12 /* q_proj.bias (Qwen2, StableLM use_qkv_bias) */
 #define MI355_W_BK 13
@@ -378,6 +386,9 @@ int mi355_dense_set_weight_dev(void* model, int32_t layer, int32_t which, const 
  * 16-bit [k/g, n] from the HOST in checkpoint order; sym, no act-order (the Marlin-eligible case, linear.rs:319-325) */
 int mi355_dense_set_gptq(void* model, int32_t layer, int32_t which, const void* qweight_host, const void* scales_host,
                          int32_t n, int32_t k, int32_t group_size);
+/* tensor parallel (distributed.rs:243-249,492-534,696-711,1632-1667): comm from mi355_comm_create (borrowed);
+ * all-reduce of the 16-bit stream after o_proj / down_proj, vocab-parallel lm_head + all-gather */
+int mi355_dense_set_comm(void* model, void* comm);
 int mi355_dense_alloc_kv_cache(void* model, int32_t num_blocks);
 void* mi355_dense_kv_ptr(void* model, int32_t layer, int32_t which);
 /* one step: prompt when cu_seqlens_q != NULL (flattened tokens), else decode (num_tokens == num_seqs);

@@ -126,11 +126,21 @@ def layer_norm16(x, w, b, eps):
 
 
 class OracleDenseLlama:
-    def __init__(self, cfg, W, flash_layout=True):
-        self.cfg, self.W, self.flash = cfg, W, flash_layout
+    def __init__(self, cfg, W, flash_layout=True, comm=None):
+        """comm: None, or an object with all_reduce(np.ndarray)->np.ndarray and all_gather(np.ndarray)->list (tensor
+        parallel; cfg / W are then this rank's shard).  The collectives run in the model dtype: the reduced sum is
+        rounded (distributed.rs:696-711), the gathered logits are exact (distributed.rs:1637-1663)."""
+        self.cfg, self.W, self.flash, self.comm = cfg, W, flash_layout, comm
         self.rot = cfg.rotary_dim or cfg.head_dim
         self.cos, self.sin = ops.rope_tables(cfg.rope_theta, self.rot, cfg.max_seq)
         self.scale = 1.0 / np.sqrt(float(cfg.head_dim))
+
+    def _row_lin(self, x, w, resid):
+        """o_proj / down_proj + residual; under TP: round(partial) -> all-reduce in dtype -> + residual"""
+        p = _lin(x, w)
+        if self.comm is not None:
+            p = R(self.comm.all_reduce(p))
+        return R(p + resid)
 
     def _norm(self, x, w, b):
         if self.cfg.layer_norm:
@@ -177,10 +187,10 @@ class OracleDenseLlama:
             if c.kv_fp8:
                 y = self._attend_fp8(meta, q, k, v, kc, vc, is_prefill)
                 y = y.reshape(T, c.n_heads * c.head_dim)
-                xs = R(_lin(y, lw["wo"]) + xs)
+                xs = self._row_lin(y, lw["wo"], xs)
                 x = self._norm(xs, lw["ffn_norm"], lw.get("ffn_norm_b"))
                 gate, up = _lin(x, lw["w1"]), _lin(x, lw["w3"])
-                xs = R(_lin(G.silu_mul16(gate, up, DT), lw["w2"]) + xs)
+                xs = self._row_lin(G.silu_mul16(gate, up, DT), lw["w2"], xs)
                 continue
             kb, vb = ops.f32_to_bf16_bits(k), ops.f32_to_bf16_bits(v)
             ops.reshape_and_cache(kb, vb, kc, vc, meta["slot_mapping"], self.flash)
@@ -193,12 +203,15 @@ class OracleDenseLlama:
             else:
                 y = ops.paged_attention_decode(q, kc, vc, meta["block_tables"], meta["context_lens"], self.scale, self.flash)
             y = y.reshape(T, c.n_heads * c.head_dim)
-            xs = R(_lin(y, lw["wo"]) + xs)
+            xs = self._row_lin(y, lw["wo"], xs)
             x = self._norm(xs, lw["ffn_norm"], lw.get("ffn_norm_b"))
             gate, up = _lin(x, lw["w1"]), _lin(x, lw["w3"])
             h = G.silu_mul16(gate, up, DT)
-            xs = R(_lin(h, lw["w2"]) + xs)
+            xs = self._row_lin(h, lw["w2"], xs)
         if is_prefill:
             xs = xs[np.asarray(meta["cu_seqlens_q"][1:], np.int64) - 1]
         xs = self._norm(xs, W["output_norm"], W.get("output_norm_b"))
-        return G.linear16(xs, W["output"], None, DT).astype(np.float32)
+        logits = G.linear16(xs, W["output"], None, DT).astype(np.float32)
+        if self.comm is not None:
+            logits = np.concatenate(self.comm.all_gather(logits), axis=-1)
+        return logits

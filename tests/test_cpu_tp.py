@@ -102,3 +102,88 @@ def test_shard_plan_shapes_and_replication():
     assert l.intermediate % 256 == 0 and l.vocab % 16 == 0
     with pytest.raises(ValueError):
         tp.shard_config(cfg, 0, 3)
+
+
+# ---- 16-bit safetensors / GPTQ path (BASELINE config 4: Qwen2 GPTQ, TP=2) -------------------------------------------
+class GlooComm16(GlooComm):
+    """collectives in the model dtype: gloo has no bf16 sum, so sum in f32 -- exact for two bf16 addends, the
+    caller rounds (OracleDenseLlama._row_lin)"""
+
+
+def _dense_case(gptq):
+    from oracle import dense_llama as DL
+    cfg = DL.DenseConfig(hidden=256, n_layers=2, n_heads=4, n_kv_heads=2, head_dim=64, intermediate=512, vocab=512,
+                         rope_theta=10000.0, max_seq=256, block_size=16, qkv_bias=True)
+    W = DL.make_weights(cfg, seed=31)
+    if gptq:
+        W = DL.quantize_gptq(W, group=128)
+    rng = np.random.default_rng(8)
+    seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 19)], "block_table": [3, 1]},
+            {"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 7)], "block_table": [2]}]
+    return cfg, W, seqs
+
+
+def _dense_run(m, cfg, seqs):
+    cache = m.new_cache(8)
+    pre = m.forward(O.prepare_prompt(seqs, cfg.block_size), cache, is_prefill=True)
+    for s, row in zip(seqs, pre):
+        s["tokens"].append(int(row.argmax()))
+    return pre, m.forward(O.prepare_decode(seqs, cfg.block_size), cache)
+
+
+def _dense_worker(rank, world, port, q, gptq):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from candle_vllm_amd import tp
+    from oracle import dense_llama as DL
+    cfg, W, seqs = _dense_case(gptq)
+    m = DL.OracleDenseLlama(tp.shard_dense_config(cfg, rank, world), tp.shard_dense_weights(W, cfg, rank, world),
+                            flash_layout=False, comm=GlooComm16())
+    out = _dense_run(m, cfg, seqs)
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("gptq", [False, True])
+def test_tp2_dense_oracle_close_to_unsharded(gptq):
+    """the row-parallel all-reduce rounds each rank's partial product before the sum (distributed.rs:696-711), so
+    TP=2 is not bit-identical to TP=1 in 16-bit arithmetic; it must agree to bf16 accumulation noise and pick the
+    same greedy tokens."""
+    import __graft_entry__ as ge
+    ge.build()
+    from oracle import dense_llama as DL
+    cfg, W, seqs = _dense_case(gptq)
+    pre, dec = _dense_run(DL.OracleDenseLlama(cfg, W, flash_layout=False), cfg, seqs)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dense_worker, args=(r, 2, port, q, gptq)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got_pre, got_dec = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got_pre.shape == pre.shape and got_dec.shape == dec.shape
+    assert np.abs(got_pre - pre).max() < 3e-2 * np.abs(pre).max()
+    assert np.abs(got_dec - dec).max() < 3e-2 * np.abs(dec).max()
+    assert (got_pre.argmax(-1) == pre.argmax(-1)).all()
+
+
+def test_dense_shard_plan_gptq_shapes():
+    from candle_vllm_amd import tp
+    from oracle import dense_llama as DL
+    cfg, W, _ = _dense_case(True)
+    l0 = tp.shard_dense_weights(W, cfg, 0, 2)["layers"][0]
+    assert l0["wq"]["qweight"].shape == (256 // 8, 128) and l0["wq"]["scales"].shape == (2, 128)      # out shard
+    assert l0["wo"]["qweight"].shape == (128 // 8, 256) and l0["wo"]["scales"].shape == (1, 256)      # in shard
+    assert l0["w2"]["qweight"].shape == (256 // 8, 256) and l0["bk"].shape == (64,)
+    # the shards tile the global tensor
+    l1 = tp.shard_dense_weights(W, cfg, 1, 2)["layers"][0]
+    assert np.array_equal(np.concatenate([l0["wo"]["qweight"], l1["wo"]["qweight"]], 0), W["layers"][0]["wo"]["qweight"])
+    assert np.array_equal(np.concatenate([l0["w1"]["qweight"], l1["w1"]["qweight"]], 1), W["layers"][0]["w1"]["qweight"])
+    with pytest.raises(ValueError):
+        tp.shard_dense_weights(W, cfg, 0, 4)          # 256/4 = 64 rows < group 128
