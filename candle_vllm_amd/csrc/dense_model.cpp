@@ -195,7 +195,8 @@ static int dense_set_weight_impl(void* mp, int32_t layer, int32_t which, const v
     uint16_t** slot = nullptr;
     int64_t expect = 0, offset = 0, total = 0;
     if (layer < 0) {
-        if (which == MI355_W_TOK_EMBD) { slot = &m->tok_embd; expect = (int64_t)c.vocab * hid; }
+        // the embedding table is replicated under TP (full vocabulary), lm_head is vocab-parallel (distributed.rs:1632)
+        if (which == MI355_W_TOK_EMBD) { slot = &m->tok_embd; expect = (int64_t)c.vocab * (c.tp_world > 1 ? c.tp_world : 1) * hid; }
         else if (which == MI355_W_OUTPUT_NORM) { slot = &m->output_norm; expect = hid; }
         else if (which == MI355_W_OUTPUT) { slot = &m->output; expect = (int64_t)c.vocab * hid; }
         else if (which == MI355_W_OUTPUT_NORM_B) { slot = &m->output_norm_b; expect = hid; }

@@ -138,6 +138,7 @@ struct Model {
 };
 
 int g_host_ps_override = 0;     // experiments: mi355_set_tuning(5, partition_size)
+
 int local_heads(const Model* m) { return m->cfg.n_heads / (m->cfg.tp_world > 0 ? m->cfg.tp_world : 1); }
 int local_kv_heads(const Model* m) {
     const int w = m->cfg.tp_world > 0 ? m->cfg.tp_world : 1;

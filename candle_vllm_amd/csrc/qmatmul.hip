@@ -238,18 +238,9 @@ __device__ __forceinline__ TileRegs load_tile(int type, const uint8_t* __restric
     return r;
 }
 
-// LDS image of the staged activations for one chunk of `kch` k-blocks (BT batch entries):
-//   ximg : [kch*32 entries][2*BT rows][8 bf16]  entry E <-> elements 8E..8E+7 in order {0,2,1,3,4,6,5,7};
+// LDS image of the staged activations of one k-block (BT batch entries), private to a wave:
+//   ximg : [32 entries][2*BT rows][8 bf16]  entry E <-> elements 8E..8E+7 in order {0,2,1,3,4,6,5,7};
 //          rows 0..BT-1 = hi(bf16(x)), rows BT..2BT-1 = lo(bf16(x - hi))
-//   xs32 : [kch*8 ][2][BT] f32   sum of the 32 staged bf16 values (hi / lo) of each 32-sub-block
-//   xs16 : [kch*16][2][BT] f32   same per 16-sub-block (Q6_K)
-template <int BT>
-struct XLds {
-    uint8_t* ximg;
-    float* xs32;
-    float* xs16;
-};
-
 // A-fragment row of a lane: MFMA rows 0..7 carry hi(x) of batch 0..7, rows 8..15 carry lo(x).  Rows beyond
 // the staged batch (m >= BT) just re-read a staged row: MFMA rows are independent and those outputs are
 // never consumed, so no zero-fill and no branch is needed.
@@ -257,119 +248,6 @@ template <int BT>
 __device__ __forceinline__ int a_row_of(int m) {
     const int mm = (m & 7) < BT ? (m & 7) : (BT - 1);
     return (m < 8) ? mm : BT + mm;
-}
-
-template <int BT, int NV>
-__device__ __forceinline__ void compute_q4k(const TileRegs& w, const XLds<BT>& L, int kbl, int lane, float (&y)[NV]) {
-    const int m = lane & 15, kg = lane >> 4;
-    // ---- issue every LDS read of this k-block first (8 A fragments + the sub-block sums)
-    const uint8_t* abase = L.ximg + ((size_t)(kbl * 32 + kg) * (2 * BT) + a_row_of<BT>(m)) * 16;
-    uint4 aw[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) aw[j] = *reinterpret_cast<const uint4*>(abase + (size_t)j * 4 * (2 * BT) * 16);
-    const float* xs = L.xs32 + ((size_t)(kbl * 2 + (kg >> 1)) * 8) * BT + ((4 * (kg & 1)) & (BT - 1));
-    float xsum[8][NV];
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int v = 0; v < NV; ++v) xsum[j][v] = xs[j * BT + v];
-    // ---- 6-bit scales / mins, 4 at a time in byte lanes (get_scale_min_k4)
-    const float d = f16_bits_to_f32((uint16_t)(w.a.x & 0xFFFF));
-    const float dmin = f16_bits_to_f32((uint16_t)(w.a.x >> 16));
-    const uint32_t s0 = w.a.y, s1 = w.a.z, s2 = w.a.w;
-    const uint32_t scl = s0 & 0x3F3F3F3Fu, mnl = s1 & 0x3F3F3F3Fu;
-    const uint32_t sch = (s2 & 0x0F0F0F0Fu) | ((s0 >> 2) & 0x30303030u);
-    const uint32_t mnh = ((s2 >> 4) & 0x0F0F0F0Fu) | ((s1 >> 2) & 0x30303030u);
-    float dsc[8], cj[8];
-    const float d128 = d * 128.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float sa = (float)((scl >> (8 * j)) & 0xFF), sb = (float)((sch >> (8 * j)) & 0xFF);
-        const float ma = (float)((mnl >> (8 * j)) & 0xFF), mb = (float)((mnh >> (8 * j)) & 0xFF);
-        dsc[j] = d * sa;
-        dsc[j + 4] = d * sb;
-        cj[j] = fmaf(dmin, ma, d128 * sa);
-        cj[j + 4] = fmaf(dmin, mb, d128 * sb);
-    }
-    // ---- 8 independent MFMAs (one per 32-weight sub-block).  The nibble mask lives in a VGPR so that
-    // (w >> s) & mask | 0x43004300 is one v_and_or_b32 (gfx9 VOP3 allows a single literal/SGPR operand).
-    uint32_t nib = 0x000F000Fu;
-    asm volatile("" : "+v"(nib));
-    f32x4_t acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int p = j >> 2, pr = (j >> 1) & 1, sh = (j & 1) * 4;
-        const uint4 qs = p ? w.c : w.b;
-        const uint32_t w0 = pr ? qs.z : qs.x, w1 = pr ? qs.w : qs.y;
-        uint4 bw;
-        bw.x = ((w0 >> sh) & nib) | BF16_128;                // elements (b0, b2)
-        bw.y = ((w0 >> (sh + 8)) & nib) | BF16_128;          // elements (b1, b3)
-        bw.z = ((w1 >> sh) & nib) | BF16_128;                // elements (b4, b6)
-        bw.w = ((w1 >> (sh + 8)) & nib) | BF16_128;          // elements (b5, b7)
-        const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw[j]),
-                                                         __builtin_bit_cast(bf16x8_t, bw), zero, 0, 0, 0);
-    }
-    // ---- per-sub-block scale, folded "+128" offset and minimum
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            y[v] = fmaf(dsc[j], acc[j][v], y[v]);
-            y[v] = fmaf(-cj[j], xsum[j][v], y[v]);
-        }
-}
-
-template <int BT, int NV>
-__device__ __forceinline__ void compute_q6k(const TileRegs& w, const XLds<BT>& L, int kbl, int lane, float (&y)[NV]) {
-    const int m = lane & 15, kg = lane >> 4;
-    // A fragment of 16-sub-block s: entry 2s + (kg>>1), 8-byte half (kg&1)
-    const uint8_t* abase = L.ximg + ((size_t)(kbl * 32 + (kg >> 1)) * (2 * BT) + a_row_of<BT>(m)) * 16 + (kg & 1) * 8;
-    uint2 aw[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) aw[s] = *reinterpret_cast<const uint2*>(abase + (size_t)s * 2 * (2 * BT) * 16);
-    const float* xs = L.xs16 + ((size_t)(kbl * 2 + (kg >> 1)) * 16) * BT + ((4 * (kg & 1)) & (BT - 1));
-    float xsum[16][NV];
-#pragma unroll
-    for (int s = 0; s < 16; ++s)
-#pragma unroll
-        for (int v = 0; v < NV; ++v) xsum[s][v] = xs[s * BT + v];
-    const float d = f16_bits_to_f32((uint16_t)(w.e & 0xFFFF));
-    const uint32_t scw[4] = {w.a.x, w.a.y, w.a.z, w.a.w};
-    const uint32_t qhw[4] = {w.d.x, w.d.y, w.d.z, w.d.w};
-    uint32_t bmask = 0x00FF00FFu;
-    asm volatile("" : "+v"(bmask));
-    f32x4_t acc[16];
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const uint4 ql = n ? w.c : w.b;
-#pragma unroll
-        for (int is = 0; is < 2; ++is) {
-            const uint32_t a = is ? ql.z : ql.x, b = is ? ql.w : ql.y, h = qhw[2 * n + is];
-            uint32_t t[4];
-            t[0] = (a & 0x0F0F0F0Fu) | ((h << 4) & 0x30303030u);
-            t[1] = (b & 0x0F0F0F0Fu) | ((h << 2) & 0x30303030u);
-            t[2] = ((a >> 4) & 0x0F0F0F0Fu) | (h & 0x30303030u);
-            t[3] = ((b >> 4) & 0x0F0F0F0Fu) | ((h >> 2) & 0x30303030u);
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const int s = 8 * n + 2 * tt + is;                    // 16-sub-block index 0..15
-                uint2 bw;
-                bw.x = (t[tt] & bmask) | BF16_128;                    // elements (b0, b2)
-                bw.y = ((t[tt] >> 8) & bmask) | BF16_128;             // elements (b1, b3)
-                const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
-                acc[s] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, aw[s]),
-                                                                   __builtin_bit_cast(s16x4_t, bw), zero, 0, 0, 0);
-            }
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        const int sc8 = (int)(int8_t)((scw[s >> 2] >> (8 * (s & 3))) & 0xFF);
-        const float dsc = d * (float)sc8;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) y[v] = fmaf(dsc, fmaf(-160.f, xsum[s][v], acc[s][v]), y[v]);   // code = q+32 (+128)
-    }
 }
 
 // ---- activations: every wave stages the k-block it is about to consume into its OWN 1.2*BT KB of LDS
@@ -399,12 +277,17 @@ __device__ __forceinline__ XRegs<BT> load_x(const QmmArgs& a, int kb, int lane, 
     return r;
 }
 
-// Convert one k-block of x to the MFMA fragment image (hi/lo bf16 split, element order {0,2,1,3} per half entry)
-// in this wave's LDS scratch, plus the 16-/32-element sums of the staged values.  With a fused RMSNorm the
-// staged value is x*w_norm; the per-row 1/rms is applied in the epilogue (y is linear in x); sum x^2 -> ss[].
+// ================= inner math of the decode mat-vec ============================================================
+// The decode mat-vec is VALU-issue bound, not HBM bound (rocprofv3: VALU pipe ~80 % busy over a wave's lifetime,
+// same duration with the weights resident in the Infinity Cache), so the inner loop is trimmed to the essentials:
+//   * the "+128" of the bf16 code trick is cancelled INSIDE the MFMA: one extra MFMA per sub-block with a constant
+//     B operand of -128 (Q6_K: -160) yields C_in = -128*sum(x) in accumulator layout; the weight MFMA then starts
+//     from C_in and returns the true dot product.  The same C_in is the sub-block sum the Q4_K minimum term needs
+//     -> no shuffle reductions and no sum arrays in the staging step, no per-sub-block offset FMAs;
+//   * d and dmin are applied once per tile (sum_j sc_j*P_j and sum_j m_j*S_j are formed first);
+//   * tiles of one k-block that share a type are computed together so C_in and the A fragments are shared.
 template <int BT>
-__device__ __forceinline__ void stage_kblock(const QmmArgs& a, const XRegs<BT>& xr, const XLds<BT>& L, int lane,
-                                             float (&ss)[BT]) {
+__device__ __forceinline__ void stage_kblock3(const QmmArgs& a, const XRegs<BT>& xr, uint8_t* ximg, int lane, float (&ss)[BT]) {
     const int E = lane >> 1, half = lane & 1;
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
@@ -421,29 +304,129 @@ __device__ __forceinline__ void stage_kblock(const QmmArgs& a, const XRegs<BT>& 
             ss[b] = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], ss[b]))));
             v[0] *= xr.nw.x; v[1] *= xr.nw.y; v[2] *= xr.nw.z; v[3] *= xr.nw.w;
         }
-        // hi = bf16(v) (RNE, v_cvt_pk_bf16_f32), lo = bf16(v - hi); packed in fragment order (e0,e2),(e1,e3)
         const uint32_t h02 = cvt_pk_bf16(v[0], v[2]), h13 = cvt_pk_bf16(v[1], v[3]);
-        const float hf0 = bf16lo_to_f32(h02), hf2 = bf16hi_to_f32(h02), hf1 = bf16lo_to_f32(h13), hf3 = bf16hi_to_f32(h13);
-        const uint32_t l02 = cvt_pk_bf16(v[0] - hf0, v[2] - hf2), l13 = cvt_pk_bf16(v[1] - hf1, v[3] - hf3);
-        const float hsum = (hf0 + hf1) + (hf2 + hf3);
-        const float lsum = (bf16lo_to_f32(l02) + bf16lo_to_f32(l13)) + (bf16hi_to_f32(l02) + bf16hi_to_f32(l13));
-        uint8_t* row_hi = L.ximg + ((size_t)E * (2 * BT) + b) * 16 + half * 8;
-        uint8_t* row_lo = L.ximg + ((size_t)E * (2 * BT) + BT + b) * 16 + half * 8;
-        *reinterpret_cast<uint2*>(row_hi) = make_uint2(h02, h13);
-        *reinterpret_cast<uint2*>(row_lo) = make_uint2(l02, l13);
-        // 16-element sums over 4 lanes, 32-element sums over 8 lanes
-        float h16 = hsum + __shfl_xor(hsum, 1, 64), l16 = lsum + __shfl_xor(lsum, 1, 64);
-        h16 += __shfl_xor(h16, 2, 64);
-        l16 += __shfl_xor(l16, 2, 64);
-        const float h32 = h16 + __shfl_xor(h16, 4, 64), l32 = l16 + __shfl_xor(l16, 4, 64);
-        if ((lane & 3) == 0) {                                    // xs16: [hl][16 s][BT]
-            L.xs16[((size_t)0 * 16 + (lane >> 2)) * BT + b] = h16;
-            L.xs16[((size_t)1 * 16 + (lane >> 2)) * BT + b] = l16;
+        const uint32_t l02 = cvt_pk_bf16(v[0] - bf16lo_to_f32(h02), v[2] - bf16hi_to_f32(h02));
+        const uint32_t l13 = cvt_pk_bf16(v[1] - bf16lo_to_f32(h13), v[3] - bf16hi_to_f32(h13));
+        *reinterpret_cast<uint2*>(ximg + ((size_t)E * (2 * BT) + b) * 16 + half * 8) = make_uint2(h02, h13);
+        *reinterpret_cast<uint2*>(ximg + ((size_t)E * (2 * BT) + BT + b) * 16 + half * 8) = make_uint2(l02, l13);
+    }
+}
+
+template <int BT, int NV, int RR>
+__device__ __forceinline__ void compute3_q4k(const TileRegs* w, const uint8_t* ximg, int lane, float (*y)[NV]) {
+    const int m = lane & 15, kg = lane >> 4;
+    const uint8_t* abase = ximg + ((size_t)kg * (2 * BT) + a_row_of<BT>(m)) * 16;
+    uint4 aw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) aw[j] = *reinterpret_cast<const uint4*>(abase + (size_t)j * 4 * (2 * BT) * 16);
+    float d[RR], dm[RR];
+    uint32_t scl[RR], sch[RR], mnl[RR], mnh[RR];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        d[r] = f16_bits_to_f32((uint16_t)(w[r].a.x & 0xFFFF));
+        dm[r] = f16_bits_to_f32((uint16_t)(w[r].a.x >> 16)) * (1.f / 128.f);
+        const uint32_t s0 = w[r].a.y, s1 = w[r].a.z, s2 = w[r].a.w;
+        scl[r] = s0 & 0x3F3F3F3Fu;
+        mnl[r] = s1 & 0x3F3F3F3Fu;
+        sch[r] = (s2 & 0x0F0F0F0Fu) | ((s0 >> 2) & 0x30303030u);
+        mnh[r] = ((s2 >> 4) & 0x0F0F0F0Fu) | ((s1 >> 2) & 0x30303030u);
+        // opaque: four 6-bit values per word, one v_cvt_f32_ubyteN each (no per-byte re-masking)
+        asm volatile("" : "+v"(scl[r]), "+v"(sch[r]), "+v"(mnl[r]), "+v"(mnh[r]));
+    }
+    uint32_t nib = 0x000F000Fu, n128 = 0xC300C300u;              // bf16 -128.0 twice
+    asm volatile("" : "+v"(nib), "+v"(n128));
+    const uint4 negw = make_uint4(n128, n128, n128, n128);
+    float sP[RR][NV], sM[RR][NV];
+#pragma unroll
+    for (int r = 0; r < RR; ++r)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { sP[r][v] = 0.f; sM[r][v] = 0.f; }
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, aw[j]);
+        const f32x4_t cin = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8_t, negw), zero, 0, 0, 0);
+        const int p = j >> 2, pr = (j >> 1) & 1, sh = (j & 1) * 4;
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+            const uint4 qs = p ? w[r].c : w[r].b;
+            const uint32_t w0 = pr ? qs.z : qs.x, w1 = pr ? qs.w : qs.y;
+            uint4 bw;
+            bw.x = ((w0 >> sh) & nib) | BF16_128;                // elements (b0, b2)
+            bw.y = ((w0 >> (sh + 8)) & nib) | BF16_128;          // elements (b1, b3)
+            bw.z = ((w1 >> sh) & nib) | BF16_128;                // elements (b4, b6)
+            bw.w = ((w1 >> (sh + 8)) & nib) | BF16_128;          // elements (b5, b7)
+            const f32x4_t acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8_t, bw), cin, 0, 0, 0);
+            const float sc = (float)((((j < 4) ? scl[r] : sch[r]) >> (8 * (j & 3))) & 0xFF);
+            const float mn = (float)((((j < 4) ? mnl[r] : mnh[r]) >> (8 * (j & 3))) & 0xFF);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                sP[r][v] = fmaf(sc, acc[v], sP[r][v]);
+                sM[r][v] = fmaf(mn, cin[v], sM[r][v]);           // cin = -128 * sum(x): minimum term, sign folded
+            }
         }
-        if ((lane & 7) == 0) {                                    // xs32: [hl][8 j][BT]
-            L.xs32[((size_t)0 * 8 + (lane >> 3)) * BT + b] = h32;
-            L.xs32[((size_t)1 * 8 + (lane >> 3)) * BT + b] = l32;
+    }
+#pragma unroll
+    for (int r = 0; r < RR; ++r)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) y[r][v] = fmaf(d[r], sP[r][v], fmaf(dm[r], sM[r][v], y[r][v]));
+}
+
+template <int BT, int NV, int RR>
+__device__ __forceinline__ void compute3_q6k(const TileRegs* w, const uint8_t* ximg, int lane, float (*y)[NV]) {
+    const int m = lane & 15, kg = lane >> 4;
+    const uint8_t* abase = ximg + ((size_t)(kg >> 1) * (2 * BT) + a_row_of<BT>(m)) * 16 + (kg & 1) * 8;
+    uint2 aw[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) aw[s] = *reinterpret_cast<const uint2*>(abase + (size_t)s * 2 * (2 * BT) * 16);
+    uint32_t bmask = 0x00FF00FFu, n160 = 0xC320C320u;            // bf16 -160.0 twice (code = q + 32, +128)
+    asm volatile("" : "+v"(bmask), "+v"(n160));
+    const uint2 negw = make_uint2(n160, n160);
+    float sP[RR][NV];
+#pragma unroll
+    for (int r = 0; r < RR; ++r)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) sP[r][v] = 0.f;
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+#pragma unroll
+        for (int is = 0; is < 2; ++is) {
+            uint32_t t[RR][4];
+#pragma unroll
+            for (int r = 0; r < RR; ++r) {
+                const uint4 ql = n ? w[r].c : w[r].b;
+                const uint32_t qa = is ? ql.z : ql.x, qb = is ? ql.w : ql.y;
+                const uint32_t h = (n ? (is ? w[r].d.w : w[r].d.z) : (is ? w[r].d.y : w[r].d.x));
+                t[r][0] = (qa & 0x0F0F0F0Fu) | ((h << 4) & 0x30303030u);
+                t[r][1] = (qb & 0x0F0F0F0Fu) | ((h << 2) & 0x30303030u);
+                t[r][2] = ((qa >> 4) & 0x0F0F0F0Fu) | (h & 0x30303030u);
+                t[r][3] = ((qb >> 4) & 0x0F0F0F0Fu) | ((h >> 2) & 0x30303030u);
+            }
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int s = 8 * n + 2 * tt + is;                    // 16-sub-block index 0..15
+                const s16x4_t af = __builtin_bit_cast(s16x4_t, aw[s]);
+                const f32x4_t cin = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af, __builtin_bit_cast(s16x4_t, negw), zero, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < RR; ++r) {
+                    uint2 bw;
+                    bw.x = (t[r][tt] & bmask) | BF16_128;                 // elements (b0, b2)
+                    bw.y = ((t[r][tt] >> 8) & bmask) | BF16_128;          // elements (b1, b3)
+                    const f32x4_t acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af, __builtin_bit_cast(s16x4_t, bw), cin, 0, 0, 0);
+                    const uint32_t scw = (s >> 2) == 0 ? w[r].a.x : ((s >> 2) == 1 ? w[r].a.y : ((s >> 2) == 2 ? w[r].a.z : w[r].a.w));
+                    const float sc = (float)(int)(int8_t)((scw >> (8 * (s & 3))) & 0xFF);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) sP[r][v] = fmaf(sc, acc[v], sP[r][v]);
+                }
+            }
         }
+    }
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        const float d = f16_bits_to_f32((uint16_t)(w[r].e & 0xFFFF));
+#pragma unroll
+        for (int v = 0; v < NV; ++v) y[r][v] = fmaf(d, sP[r][v], y[r][v]);
     }
 }
 
@@ -491,11 +474,8 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
     const float* nwp = a.norm_w ? a.norm_w : reinterpret_cast<const float*>(a.seg[0].w);
 
     // ---- LDS carve-up: per-wave activation scratch, then the cross-wave reduction area
-    constexpr int XW = 32 * 2 * BT * 16 + 8 * 2 * BT * 4 + 16 * 2 * BT * 4;   // bytes per wave (multiple of 16)
-    XLds<BT> L;
-    L.ximg = smem + (size_t)wave * XW;
-    L.xs32 = reinterpret_cast<float*>(L.ximg + 32 * 2 * BT * 16);
-    L.xs16 = L.xs32 + 8 * 2 * BT;
+    constexpr int XW = 32 * 2 * BT * 16;                          // bytes per wave: the hi/lo fragment image of one k-block
+    uint8_t* ximg = smem + (size_t)wave * XW;
     float* red = reinterpret_cast<float*>(smem + (size_t)NW * XW);   // [NW][R][BT][16]
     float* red_ss = red + (size_t)NW * R * BT * 16;               // [NW][BT]
 
@@ -529,23 +509,43 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
         for (int q = 0; q < PFK; ++q) {
             const int kbi = kbi0 + q;
             const bool active = kbi < n_my_kb;                    // wave-uniform
-            if (active) stage_kblock<BT>(a, xr[q], L, lane, ss);
+            if (active) stage_kblock3<BT>(a, xr[q], ximg, lane, ss);
             const int kbn = wave + NW * (kbi + PFK);
             xr[q] = load_x<BT>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp);
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int s = q * R + r;
+            const bool ok = kbi + PFK < n_my_kb;
+            if constexpr (WT != 0) {
+                // every tile of the launch has one type: the R tiles of this k-block share C_in and the A fragments
                 if (active) {
                     if (a.dbg == 1) {
-                        y[r][0] += __uint_as_float((buf[s].a.x ^ buf[s].b.x ^ buf[s].c.x ^ buf[s].d.x ^ buf[s].b.w ^ buf[s].c.w) & 0x3FFFFFu);
-                    } else if (wtype[r] == MI355_GGML_Q4_K) {
-                        compute_q4k<BT, NV>(buf[s], L, 0, lane, y[r]);
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const TileRegs& t = buf[q * R + r];
+                            y[r][0] += __uint_as_float((t.a.x ^ t.b.x ^ t.c.x ^ t.d.x ^ t.b.w ^ t.c.w) & 0x3FFFFFu);
+                        }
+                    } else if (WT == MI355_GGML_Q4_K) {
+                        compute3_q4k<BT, NV, R>(&buf[q * R], ximg, lane, y);
                     } else {
-                        compute_q6k<BT, NV>(buf[s], L, 0, lane, y[r]);
+                        compute3_q6k<BT, NV, R>(&buf[q * R], ximg, lane, y);
                     }
                 }
-                const bool ok = kbi + PFK < n_my_kb;
-                buf[s] = load_tile<WT>(wtype[r], ok ? wbase[r] + (size_t)kbn * wtb[r] : wbase[r], ok ? lane : 0);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    buf[q * R + r] = load_tile<WT>(wtype[r], ok ? wbase[r] + (size_t)kbn * wtb[r] : wbase[r], ok ? lane : 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int s = q * R + r;
+                    if (active) {
+                        if (a.dbg == 1) {
+                            y[r][0] += __uint_as_float((buf[s].a.x ^ buf[s].b.x ^ buf[s].c.x ^ buf[s].d.x ^ buf[s].b.w ^ buf[s].c.w) & 0x3FFFFFu);
+                        } else if (wtype[r] == MI355_GGML_Q4_K) {
+                            compute3_q4k<BT, NV, 1>(&buf[s], ximg, lane, &y[r]);
+                        } else {
+                            compute3_q6k<BT, NV, 1>(&buf[s], ximg, lane, &y[r]);
+                        }
+                    }
+                    buf[s] = load_tile<WT>(wtype[r], ok ? wbase[r] + (size_t)kbn * wtb[r] : wbase[r], ok ? lane : 0);
+                }
             }
         }
     }
@@ -1511,7 +1511,7 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
 }
 
 static size_t qmm_lds_bytes(int BT, int R, int NW) {
-    const size_t xw = (size_t)32 * 2 * BT * 16 + 8 * 2 * BT * 4 + 16 * 2 * BT * 4;
+    const size_t xw = (size_t)32 * 2 * BT * 16;
     return (size_t)NW * xw + (size_t)NW * R * BT * 16 * 4 + (size_t)NW * BT * 4 + 64;
 }
 

@@ -188,12 +188,14 @@ def test_tp_shard_through_rccl_communicator(lib, gptq):
         pytest.fail("GPU tests need a visible MI355X")
     from candle_vllm_amd import dense_model as M
     from candle_vllm_amd import tp
-    cfg = DL.DenseConfig.tiny(qkv_bias=True)
+    cfg = DL.DenseConfig(hidden=512, n_layers=2, n_heads=8, n_kv_heads=2, head_dim=64, intermediate=1024, vocab=512,
+                         rope_theta=10000.0, max_seq=256, block_size=16, qkv_bias=True)   # shards keep k % 256 == 0
     W = DL.make_weights(cfg)
     if gptq:
         W = DL.quantize_gptq(W, group=128)
     lcfg, lW = tp.shard_dense_config(cfg, 1, 2), tp.shard_dense_weights(W, cfg, 1, 2)
-    assert (lcfg.n_heads, lcfg.n_kv_heads, lcfg.intermediate, lcfg.vocab) == (2, 1, 256, 256)
+    lW["tok_embd"] = lW["tok_embd"][:lcfg.vocab]       # 1-rank group: the (replicated) table is the local vocabulary
+    assert (lcfg.n_heads, lcfg.n_kv_heads, lcfg.intermediate, lcfg.vocab) == (4, 1, 512, 256)
     orc = DL.OracleDenseLlama(lcfg, lW, flash_layout=False, comm=_OneRankComm())
     rng = np.random.default_rng(23)
     seqs = [{"tokens": [int(t) for t in rng.integers(0, lcfg.vocab, 21)], "block_table": [3, 7]},

@@ -1,14 +1,22 @@
-"""summarise a rocprofv3 --pmc results DB: per kernel (name, workgroups) average of every counter + duration"""
-import sqlite3, sys, json
+"""aggregate a rocprofv3 --pmc counter_collection csv: per (kernel, grid) mean of every counter -> json"""
+import csv
+import glob
+import json
+import sys
 from collections import defaultdict
-c = sqlite3.connect(sys.argv[1])
-rows = c.execute("select kernel_name, grid_size_x/workgroup_size_x, counter_name, avg(value), avg(end-start), count(*) "
-                 "from counters_collection where kernel_name like '%qmm%' or kernel_name like '%paged%' or kernel_name like '%argmax%' "
-                 "group by kernel_name, grid_size_x, counter_name").fetchall()
-d = defaultdict(dict)
-for r in rows:
-    k = f"{r[0][:48]} wgs={r[1]}"
-    d[k][r[2]] = r[3]
-    d[k]["dur_us"] = r[4] / 1e3
-    d[k]["launches"] = r[5]
-print(json.dumps(d, indent=1))
+
+root, out = sys.argv[1], sys.argv[2]
+acc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            key = "%s grid=%s wg=%s" % (r.get("Kernel_Name", "?")[:90], r.get("Grid_Size", "?"), r.get("Workgroup_Size", "?"))
+            acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res = {}
+for k, cs in acc.items():
+    res[k] = {"launches": max(len(v) for v in cs.values())}
+    for c, v in cs.items():
+        res[k][c] = round(sum(v) / len(v), 1)
+json.dump(res, open(out, "w"), indent=1)
+for k in sorted(res, key=lambda k: -res[k].get("SQ_WAVE_CYCLES", 0) * res[k]["launches"]):
+    print(k, res[k])
