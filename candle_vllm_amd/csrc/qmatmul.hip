@@ -205,6 +205,8 @@ struct QmmArgs {
 };
 
 struct TileRegs { uint4 a, b, c, d; uint32_t e; };
+typedef const void __attribute__((address_space(1)))* qmg_gptr_t;
+typedef void __attribute__((address_space(3)))* qmg_lptr_t;
 
 // WT = MI355_GGML_Q4_K / MI355_GGML_Q6_K when every tile of the launch has that type (3 resp. 5 loads per unit),
 // 0 for mixed launches: both types then issue 5 loads (Q4_K adds two same-line dummies) so that the number of
@@ -441,6 +443,132 @@ __device__ __forceinline__ float silu_f(float g) { return g / (1.f + __expf(-g))
 // static (unrolled over the ring slots, loads issued unconditionally -- past the end they hit one dummy line)
 // so the compiler emits counted vmcnt waits and ~QMM_PF KiB-sized loads per lane stay in flight.  There is no
 // workgroup-level prologue: the only barrier is the one in front of the epilogue.
+// per-lane segment index -> fields by select over the (<= 3) segments: the descriptor stays in SGPRs (a runtime-indexed
+// a.seg[i] would be a vector load from the kernarg segment on the critical path)
+__device__ __forceinline__ int seg_pick(int v0, int v1, int v2, int i) {
+    v0 = __builtin_amdgcn_readfirstlane(v0); v1 = __builtin_amdgcn_readfirstlane(v1); v2 = __builtin_amdgcn_readfirstlane(v2);
+    asm volatile("" : "+s"(v0), "+s"(v1), "+s"(v2));              // opaque SGPRs: the selects must not be re-fused into a load
+    return i == 0 ? v0 : (i == 1 ? v1 : v2);
+}
+__device__ __forceinline__ int seg_n_rows(const QmmArgs& a, int i) { return seg_pick(a.seg[0].n_rows, a.seg[1].n_rows, a.seg[2].n_rows, i); }
+__device__ __forceinline__ int seg_row0(const QmmArgs& a, int i) { return seg_pick(a.seg[0].row0, a.seg[1].row0, a.seg[2].row0, i); }
+
+// ---- epilogue operands that do not depend on the mat-vec (residual, RoPE cos/sin, cache slot) are fetched under the
+// weight stream by the threads that will write the outputs: `early` goes out ahead of the first weight loads (the
+// position, the slot, the residual), `late` right after them (cos/sin need the position)
+struct EpiPre { int64_t pos, slot; float f0, f1; int lrow, sgi; bool live, rope; };
+template <int BT, int R>
+__device__ __forceinline__ void epi_pre_early(const QmmArgs& a, const int (&segi)[R], const int (&tile)[R], EpiPre& ep) {
+    constexpr int NOUT = R * BT * 16;
+    const int e_rr = threadIdx.x & 15, e_b = ((int)threadIdx.x >> 4) % BT, e_r = (int)threadIdx.x / (16 * BT);
+    int e_tl = 0;
+    ep.sgi = 0;
+#pragma unroll
+    for (int q = 0; q < R; ++q) if (q == e_r) { ep.sgi = segi[q]; e_tl = tile[q]; }
+    ep.lrow = e_tl * 16 + e_rr;
+    ep.live = (int)threadIdx.x < NOUT && e_b < a.B && ep.lrow < seg_n_rows(a, ep.sgi);
+    ep.rope = ep.live && a.epi == MI355_EPI_QKV_ROPE_CACHE;
+    ep.pos = 0; ep.slot = -1; ep.f0 = 0.f; ep.f1 = 0.f;               // RESID: f0 = residual value ; ROPE: f0, f1 = cos, sin
+    if (ep.rope && ep.sgi < 2) ep.pos = a.positions[e_b];
+    if (ep.rope && ep.sgi != 0) ep.slot = a.slot_mapping[e_b];
+    if (ep.live && a.epi == MI355_EPI_RESID) ep.f0 = a.resid[(size_t)e_b * a.ldo + seg_row0(a, ep.sgi) + ep.lrow];
+    __builtin_amdgcn_sched_barrier(0);                             // keep these loads ahead of the weight loads (in-order vmcnt)
+}
+__device__ __forceinline__ void epi_pre_late(const QmmArgs& a, EpiPre& ep) {
+    if (ep.rope && ep.sgi < 2) {
+        const int d = ep.lrow % a.D;
+        if (d < a.rot) {
+            ep.f0 = a.cos_t[ep.pos * (a.rot >> 1) + (d >> 1)];
+            ep.f1 = a.sin_t[ep.pos * (a.rot >> 1) + (d >> 1)];
+        }
+    }
+}
+
+// red: [NW][R][BT][16] partial sums of the NW compute waves, red_ss: [NW][BT] partial sum x^2 (fused RMSNorm)
+template <int BT, int R>
+__device__ __forceinline__ void qmm_epilogue(const QmmArgs& a, const float* red, const float* red_ss, const int NW,
+                                             const int (&segi)[R], const int (&tile)[R], const EpiPre& ep) {
+    // ---- epilogue: thread -> (slot r, batch b, row rr)
+    constexpr int NOUT = R * BT * 16;
+    const int nout = NOUT;
+    for (int idx = threadIdx.x; idx < nout; idx += blockDim.x) {
+        const int rr = idx & 15, b = (idx >> 4) % BT, r = idx / (16 * BT);
+        const bool pre = idx == (int)threadIdx.x;                   // first pass: operands were prefetched
+        if (b >= a.B) continue;
+        float rs = 1.f;
+        if (a.norm_w) {
+            float t = 0.f;
+            for (int w = 0; w < NW; ++w) t += red_ss[w * BT + b];
+            rs = rsqrtf(t / (float)a.K + a.eps);
+        }
+        auto sum_of = [&](int slot, int rowi) {
+            float s = 0.f;
+            for (int w = 0; w < NW; ++w) s += red[(((size_t)w * R + slot) * BT + b) * 16 + rowi];
+            return s * rs;
+        };
+        // runtime slot index (r) only touches scalars here
+        int sgi = 0, tl = 0;
+#pragma unroll
+        for (int q = 0; q < R; ++q) if (q == r) { sgi = segi[q]; tl = tile[q]; }
+        const int lrow = tl * 16 + rr;                             // row inside the segment
+        if (lrow >= seg_n_rows(a, sgi)) continue;
+        const int orow = seg_row0(a, sgi) + lrow;
+        if (a.epi == MI355_EPI_SILU_MUL) {
+            if (r & 1) continue;                                   // even slot = gate, odd slot = up of the same rows
+            float g = sum_of(r, rr), up = sum_of(r + 1, rr);
+            if (a.bias) { g += a.bias[orow]; up += a.bias[a.seg[1].row0 + lrow]; }
+            a.out[(size_t)b * a.ldo + lrow] = silu_f(g) * up;
+            continue;
+        }
+        float val = sum_of(r, rr);
+        if (a.bias) val += a.bias[orow];
+        if (a.epi == MI355_EPI_STORE) {
+            a.out[(size_t)b * a.ldo + orow] = val;
+        } else if (a.epi == MI355_EPI_RESID) {
+            a.out[(size_t)b * a.ldo + orow] = (pre ? ep.f0 : a.resid[(size_t)b * a.ldo + orow]) + val;
+        } else if (a.epi == MI355_EPI_QKV_ROPE_CACHE) {
+            // segment 0 = q, 1 = k, 2 = v ; interleaved RoPE on (even,odd) channel pairs of q and k
+            const int D = a.D, d = lrow % D, hh = lrow / D;
+            float o = val;
+            if (sgi < 2 && d < a.rot) {
+                float pv = sum_of(r, rr ^ 1);
+                if (a.bias) pv += a.bias[orow ^ 1];
+                float c = ep.f0, s = ep.f1;
+                if (!pre) {
+                    const int64_t pos = a.positions[b];
+                    c = a.cos_t[pos * (a.rot >> 1) + (d >> 1)];
+                    s = a.sin_t[pos * (a.rot >> 1) + (d >> 1)];
+                }
+                o = (d & 1) ? (pv * s + val * c) : (val * c - pv * s);
+            }
+            const uint16_t ob = f32_to_bf16(o);
+            if (sgi == 0) {
+                a.q_out[(size_t)b * a.Hq * D + lrow] = ob;
+            } else {
+                const int64_t slot = pre ? ep.slot : a.slot_mapping[b];
+                if (slot >= 0) {
+                    uint16_t* cache = (sgi == 1) ? a.kcache : a.vcache;
+                    if (a.kv_layout == MI355_KV_PAGED_FP8) {        // e4m3fn of the bf16 value, K layout x = 16
+                        uint8_t* c8 = reinterpret_cast<uint8_t*>(cache);
+                        const int64_t blk = slot / a.block_size, off = slot % a.block_size;
+                        const uint8_t q8 = to_e4m3(bf16_to_f32(ob));
+                        if (sgi == 1) c8[((((blk * a.Hkv + hh) * (D / 16) + d / 16) * a.block_size + off) * 16) + d % 16] = q8;
+                        else c8[((blk * a.Hkv + hh) * D + d) * (int64_t)a.block_size + off] = q8;
+                    } else if (a.kv_layout == MI355_KV_FLASH) {
+                        cache[(slot * a.Hkv + hh) * D + d] = ob;
+                    } else {
+                        const int64_t blk = slot / a.block_size, off = slot % a.block_size;
+                        if (sgi == 1)
+                            cache[((((blk * a.Hkv + hh) * (D / 8) + d / 8) * a.block_size + off) * 8) + d % 8] = ob;
+                        else
+                            cache[((blk * a.Hkv + hh) * D + d) * (int64_t)a.block_size + off] = ob;
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int BT, int R, int WT>
 __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
     constexpr int NV = BT < 4 ? BT : 4;
@@ -488,6 +616,9 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
 #pragma unroll
     for (int b = 0; b < BT; ++b) ss[b] = 0.f;
 
+    EpiPre ep;
+    epi_pre_early<BT, R>(a, segi, tile, ep);
+
     // this wave's k-blocks: kb = wave + NW*kbi, kbi in [0, n_my_kb); ring slot s <-> (kbi0 + s/R, tile s%R)
     const int n_my_kb = (nkb > wave) ? (nkb - wave + NW - 1) / NW : 0;
     const int kb_last = n_my_kb > 0 ? wave + NW * (n_my_kb - 1) : 0;
@@ -504,19 +635,21 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
         }
     }
 
+    epi_pre_late(a, ep);
+
     for (int kbi0 = 0; kbi0 < n_my_kb; kbi0 += PFK) {
 #pragma unroll
         for (int q = 0; q < PFK; ++q) {
             const int kbi = kbi0 + q;
             const bool active = kbi < n_my_kb;                    // wave-uniform
-            if (active) stage_kblock3<BT>(a, xr[q], ximg, lane, ss);
+            if (active && a.dbg < 3) stage_kblock3<BT>(a, xr[q], ximg, lane, ss);
             const int kbn = wave + NW * (kbi + PFK);
-            xr[q] = load_x<BT>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp);
+            if (a.dbg < 3) xr[q] = load_x<BT>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp);
             const bool ok = kbi + PFK < n_my_kb;
             if constexpr (WT != 0) {
                 // every tile of the launch has one type: the R tiles of this k-block share C_in and the A fragments
                 if (active) {
-                    if (a.dbg == 1) {
+                    if (a.dbg >= 1) {
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
                             const TileRegs& t = buf[q * R + r];
@@ -536,7 +669,7 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
                 for (int r = 0; r < R; ++r) {
                     const int s = q * R + r;
                     if (active) {
-                        if (a.dbg == 1) {
+                        if (a.dbg >= 1) {
                             y[r][0] += __uint_as_float((buf[s].a.x ^ buf[s].b.x ^ buf[s].c.x ^ buf[s].d.x ^ buf[s].b.w ^ buf[s].c.w) & 0x3FFFFFu);
                         } else if (wtype[r] == MI355_GGML_Q4_K) {
                             compute3_q4k<BT, NV, 1>(&buf[s], ximg, lane, &y[r]);
@@ -550,6 +683,13 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
         }
     }
 
+    if (a.dbg == 4) {                                              // probe: weight stream only, no reduction / epilogue
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) t += y[r][0];
+        if (t == 1.2345e-30f) a.out[0] = t;
+        return;
+    }
     // ---- hi + lo, then cross-wave reduction in LDS.  After the xor-32 add, lanes 0..31 hold batch 4*kg+v.
     const int kg = lane >> 4, row = lane & 15;
 #pragma unroll
@@ -569,85 +709,12 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
     }
     __syncthreads();
 
-    // ---- epilogue: thread -> (slot r, batch b, row rr)
-    constexpr int RO = R;                                          // output slots
-    const int nout = RO * BT * 16;
-    for (int idx = threadIdx.x; idx < nout; idx += blockDim.x) {
-        const int rr = idx & 15, b = (idx >> 4) % BT, r = idx / (16 * BT);
-        if (b >= a.B) continue;
-        float rs = 1.f;
-        if (a.norm_w) {
-            float t = 0.f;
-            for (int w = 0; w < NW; ++w) t += red_ss[w * BT + b];
-            rs = rsqrtf(t / (float)a.K + a.eps);
-        }
-        auto sum_of = [&](int slot, int rowi) {
-            float s = 0.f;
-            for (int w = 0; w < NW; ++w) s += red[(((size_t)w * R + slot) * BT + b) * 16 + rowi];
-            return s * rs;
-        };
-        // runtime slot index (r) only touches scalars here
-        int sgi = 0, tl = 0;
-#pragma unroll
-        for (int q = 0; q < R; ++q) if (q == r) { sgi = segi[q]; tl = tile[q]; }
-        const QmmSeg& sg = a.seg[sgi];
-        const int lrow = tl * 16 + rr;                             // row inside the segment
-        if (lrow >= sg.n_rows) continue;
-        const int orow = sg.row0 + lrow;
-        if (a.epi == MI355_EPI_SILU_MUL) {
-            if (r & 1) continue;                                   // even slot = gate, odd slot = up of the same rows
-            float g = sum_of(r, rr), up = sum_of(r + 1, rr);
-            if (a.bias) { g += a.bias[orow]; up += a.bias[a.seg[1].row0 + lrow]; }
-            a.out[(size_t)b * a.ldo + lrow] = silu_f(g) * up;
-            continue;
-        }
-        float val = sum_of(r, rr);
-        if (a.bias) val += a.bias[orow];
-        if (a.epi == MI355_EPI_STORE) {
-            a.out[(size_t)b * a.ldo + orow] = val;
-        } else if (a.epi == MI355_EPI_RESID) {
-            a.out[(size_t)b * a.ldo + orow] = a.resid[(size_t)b * a.ldo + orow] + val;
-        } else if (a.epi == MI355_EPI_QKV_ROPE_CACHE) {
-            // segment 0 = q, 1 = k, 2 = v ; interleaved RoPE on (even,odd) channel pairs of q and k
-            const int D = a.D, d = lrow % D, hh = lrow / D;
-            float o = val;
-            if (sgi < 2 && d < a.rot) {
-                float pv = sum_of(r, rr ^ 1);
-                if (a.bias) pv += a.bias[orow ^ 1];
-                const int64_t pos = a.positions[b];
-                const float c = a.cos_t[pos * (a.rot >> 1) + (d >> 1)], s = a.sin_t[pos * (a.rot >> 1) + (d >> 1)];
-                o = (d & 1) ? (pv * s + val * c) : (val * c - pv * s);
-            }
-            const uint16_t ob = f32_to_bf16(o);
-            if (sgi == 0) {
-                a.q_out[(size_t)b * a.Hq * D + lrow] = ob;
-            } else {
-                const int64_t slot = a.slot_mapping[b];
-                if (slot >= 0) {
-                    uint16_t* cache = (sgi == 1) ? a.kcache : a.vcache;
-                    if (a.kv_layout == MI355_KV_PAGED_FP8) {        // e4m3fn of the bf16 value, K layout x = 16
-                        uint8_t* c8 = reinterpret_cast<uint8_t*>(cache);
-                        const int64_t blk = slot / a.block_size, off = slot % a.block_size;
-                        const uint8_t q8 = to_e4m3(bf16_to_f32(ob));
-                        if (sgi == 1) c8[((((blk * a.Hkv + hh) * (D / 16) + d / 16) * a.block_size + off) * 16) + d % 16] = q8;
-                        else c8[((blk * a.Hkv + hh) * D + d) * (int64_t)a.block_size + off] = q8;
-                    } else if (a.kv_layout == MI355_KV_FLASH) {
-                        cache[(slot * a.Hkv + hh) * D + d] = ob;
-                    } else {
-                        const int64_t blk = slot / a.block_size, off = slot % a.block_size;
-                        if (sgi == 1)
-                            cache[((((blk * a.Hkv + hh) * (D / 8) + d / 8) * a.block_size + off) * 8) + d % 8] = ob;
-                        else
-                            cache[((blk * a.Hkv + hh) * D + d) * (int64_t)a.block_size + off] = ob;
-                    }
-                }
-            }
-        }
-    }
+    qmm_epilogue<BT, R>(a, red, red_ss, NW, segi, tile, ep);
 }
 
 template <int BT, int R, int WT>
 __global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) { qmm_body<BT, R, WT>(a); }
+
 
 // MoE variant (decode-shaped, BT = 1): blockIdx.y = (token, slot) pair.  The adjusted descriptor is a private copy
 // -- kept out of the dense kernel, where the kernel arguments must stay scalar loads from the kernarg segment.
@@ -1012,8 +1079,6 @@ __global__ void __launch_bounds__(64 * NW) qmm_wide_kernel(const QmmArgs a, cons
 // [ks][token][row]; a small second kernel adds the partials and applies the epilogue (deterministic: no atomics).
 static inline size_t qmg_kb_bytes(int MT) { return (((size_t)MT * 8 * 1216) + 1023) / 1024 * 1024; }
 
-typedef const void __attribute__((address_space(1)))* qmg_gptr_t;
-typedef void __attribute__((address_space(3)))* qmg_lptr_t;
 
 // image + per-k-block sum of squares in ONE pass: grid = k-blocks, a workgroup builds k-block kb for every token
 // row.  The RMSNorm weight is applied here, the 1/rms factor (a per-token scalar) is applied by the epilogue kernel
@@ -1618,7 +1683,7 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
     const int n_wg = a.paired ? a.seg[0].n_tiles / (R / 2) : total_tiles / R;
     const int nkb = a.K / 256;
     int NW = 0;                                               // 0 = occupancy-aware choice per kernel variant
-    if (g_tune_nw > 0) { NW = g_tune_nw; while (NW > 1 && nkb < NW) NW >>= 1; }
+    if (g_tune_nw > 0) { NW = g_tune_nw; while (NW > 1 && nkb < NW) NW >>= 1; if (NW > 8) NW = 8; }
     hipStream_t st = to_stream(stream);
     int wt = a.seg[0].type;                                   // uniform tile type of the launch, else 0 (mixed)
     for (int s = 1; s < a.nseg; ++s) if (a.seg[s].type != wt) wt = 0;
