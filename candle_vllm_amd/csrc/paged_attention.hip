@@ -445,16 +445,22 @@ __global__ void __launch_bounds__(64) paged_attn_mfma_kernel(const PAParams p) {
     const uint16_t* vc = static_cast<const uint16_t*>(p.vc);
     const uint32_t* bt = p.block_tables + (int64_t)b * p.max_blocks;
 
-    // block ids of the NT tiles (a 16-token tile never straddles a block: t0 % 16 == 0, bs % 16 == 0)
-    int64_t blk[NT];
-    int off[NT];
-#pragma unroll
-    for (int it = 0; it < NT; ++it) {
-        const int tok0 = t0 + 16 * it;
-        const bool live = tok0 < t1;
-        blk[it] = live ? (int64_t)bt[tok0 / bs] : (int64_t)bt[t0 / bs];
-        off[it] = live ? tok0 % bs : t0 % bs;
-    }
+    // Token order inside a 32-token pair of tiles is chosen for the MEMORY side: tile A row 4g+v <-> token 8g+v, tile B
+    // row 4g+v <-> token 8g+4+v.  Then (i) a lane's probabilities of tiles A and B are the 8 consecutive tokens
+    // 8kg..8kg+7 -> the A fragment of ONE 16x16x32 P.V MFMA, register for register, and (ii) V can be fetched as
+    // 16 contiguous bytes per lane with the four lanes of a quad on one channel row (quad = 64 contiguous bytes)
+    // and moved to the MFMA's (channel = lane&15, token group = lane>>4) placement by ds_bpermute.  Measured reason
+    // (rocprofv3, batch 32): with the fragment-shaped 8-byte V loads every lane of a quad hit a different 128-B row,
+    // 40 M L1 accesses per launch for 2.1 M lines -- the kernel was bound by the L1 tag rate, not by HBM.
+    constexpr int NP = NT / 2;
+    static_assert(NT % 2 == 0, "tiles come in pairs");
+    const bool bs_pow2 = (bs & (bs - 1)) == 0;
+    const int bs_shift = __ffs(bs) - 1;
+    auto locate = [&](int tok, int64_t& blk, int& off) {
+        const int q = bs_pow2 ? (tok >> bs_shift) : (tok / bs);
+        blk = (int64_t)bt[q];
+        off = tok - q * bs;
+    };
     // Q^T fragments: lane (head c, kg) holds Q[head][32j + 8kg .. +8]
     uint4 qf[D32];
 #pragma unroll
@@ -464,39 +470,49 @@ __global__ void __launch_bounds__(64) paged_attn_mfma_kernel(const PAParams p) {
             qf[j] = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_stride +
                                                     (int64_t)(hk * G + c) * D + 32 * j + 8 * kg);
     }
-    // all K and V fragments of the partition (fp8 cache: raw bytes now, converted to bf16 fragments at use --
-    // e4m3 is exact in bf16; the dequantisation scales fold into the logit scale and the final normalisation)
+    // all K and V of the partition are requested before the first MFMA (fp8 cache: raw bytes now, converted to bf16
+    // fragments at use -- e4m3 is exact in bf16; the dequantisation scales fold into the logit scale / normalisation)
     typedef typename std::conditional<KV8, uint2, uint4>::type kraw_t;
-    typedef typename std::conditional<KV8, uint32_t, uint2>::type vraw_t;
+    typedef typename std::conditional<KV8, uint2, uint4>::type vraw_t;   // 8 tokens of one channel
     kraw_t kf[NT][D32];
-    vraw_t vf[NT][NTD];
+    vraw_t vraw[NP][NTD];
+    const int krow_tok = 8 * (c >> 2) + (c & 3);                  // token of MFMA row c inside its pair (tile A; B: +4)
 #pragma unroll
     for (int it = 0; it < NT; ++it) {
+        int tok = t0 + 32 * (it >> 1) + krow_tok + 4 * (it & 1);
+        if (tok >= t1) tok = t0;                                  // masked below; any valid address will do
+        int64_t blk; int off;
+        locate(tok, blk, off);
         if constexpr (KV8) {
-            const uint8_t* kb = static_cast<const uint8_t*>(p.kc) + ((blk[it] * p.Hkv + hk) * (D / 16)) * (int64_t)bs * 16 +
-                                (int64_t)(off[it] + c) * 16 + 8 * (kg & 1);
+            const uint8_t* kb = static_cast<const uint8_t*>(p.kc) + ((blk * p.Hkv + hk) * (D / 16)) * (int64_t)bs * 16 +
+                                (int64_t)off * 16 + 8 * (kg & 1);
 #pragma unroll
             for (int j = 0; j < D32; ++j) kf[it][j] = *reinterpret_cast<const uint2*>(kb + (int64_t)(2 * j + (kg >> 1)) * bs * 16);
         } else {
-            const uint16_t* kb = kc + ((blk[it] * p.Hkv + hk) * (D / 8)) * (int64_t)bs * 8 + (int64_t)(off[it] + c) * 8;
+            const uint16_t* kb = kc + ((blk * p.Hkv + hk) * (D / 8)) * (int64_t)bs * 8 + (int64_t)off * 8;
 #pragma unroll
             for (int j = 0; j < D32; ++j) kf[it][j] = *reinterpret_cast<const uint4*>(kb + (int64_t)(4 * j + kg) * bs * 8);
         }
     }
+    const int vq = lane & 3, vch = lane >> 2;                      // load placement: 8-token chunk vq of channel 16nt + vch
 #pragma unroll
-    for (int it = 0; it < NT; ++it) {
+    for (int ip = 0; ip < NP; ++ip) {
+        int tok = t0 + 32 * ip + 8 * vq;
+        if (tok >= t1) tok = t0;
+        int64_t blk; int off;
+        locate(tok, blk, off);                                     // 8 consecutive tokens never straddle a block (bs % 8 == 0)
         if constexpr (KV8) {
-            const uint8_t* vb = static_cast<const uint8_t*>(p.vc) + ((blk[it] * p.Hkv + hk) * D + c) * (int64_t)bs + off[it] + 4 * kg;
+            const uint8_t* vb = static_cast<const uint8_t*>(p.vc) + ((blk * p.Hkv + hk) * D + vch) * (int64_t)bs + off;
 #pragma unroll
-            for (int nt = 0; nt < NTD; ++nt) vf[it][nt] = *reinterpret_cast<const uint32_t*>(vb + (int64_t)(16 * nt) * bs);
+            for (int nt = 0; nt < NTD; ++nt) vraw[ip][nt] = *reinterpret_cast<const uint2*>(vb + (int64_t)(16 * nt) * bs);
         } else {
-            const uint16_t* vb = vc + ((blk[it] * p.Hkv + hk) * D + c) * (int64_t)bs + off[it] + 4 * kg;
+            const uint16_t* vb = vc + ((blk * p.Hkv + hk) * D + vch) * (int64_t)bs + off;
 #pragma unroll
-            for (int nt = 0; nt < NTD; ++nt) vf[it][nt] = *reinterpret_cast<const uint2*>(vb + (int64_t)(16 * nt) * bs);
+            for (int nt = 0; nt < NTD; ++nt) vraw[ip][nt] = *reinterpret_cast<const uint4*>(vb + (int64_t)(16 * nt) * bs);
         }
     }
     const float qk_scale = KV8 ? p.scale * p.k_scale : p.scale;
-    // ---- S^T = K . Q^T : lane (head c, tokens 4kg+v)
+    // ---- S^T = K . Q^T : lane (head c, rows 4kg+v); row 4kg+v of tile `it` is token 32*(it/2) + 8kg + 4*(it&1) + v
     float sc[NT][4];
     float m = -1e30f;
 #pragma unroll
@@ -510,12 +526,12 @@ __global__ void __launch_bounds__(64) paged_attn_mfma_kernel(const PAParams p) {
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ka),
                                                           __builtin_bit_cast(bf16x8_t, qf[j]), acc, 0, 0, 0);
         }
+        const int tokb = t0 + 32 * (it >> 1) + 8 * kg + 4 * (it & 1);
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             float s = acc[v] * qk_scale;
             if (p.softcap > 0.f) s = tanhf(s / p.softcap) * p.softcap;
-            const bool ok = t0 + 16 * it + 4 * kg + v < t1;
-            s = ok ? s : -1e30f;
+            s = (tokb + v < t1) ? s : -1e30f;
             sc[it][v] = s;
             m = fmaxf(m, s);
         }
@@ -526,38 +542,52 @@ __global__ void __launch_bounds__(64) paged_attn_mfma_kernel(const PAParams p) {
     uint2 pf[NT];
 #pragma unroll
     for (int it = 0; it < NT; ++it) {
+        const int tokb = t0 + 32 * (it >> 1) + 8 * kg + 4 * (it & 1);
         float pr[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const bool ok = t0 + 16 * it + 4 * kg + v < t1;
-            pr[v] = ok ? __expf(sc[it][v] - m) : 0.f;
-        }
+        for (int v = 0; v < 4; ++v) pr[v] = (tokb + v < t1) ? __expf(sc[it][v] - m) : 0.f;
         pf[it] = make_uint2(cvt_pk_bf16(pr[0], pr[1]), cvt_pk_bf16(pr[2], pr[3]));
         // the normaliser must match what the MFMA sums: the bf16-rounded probabilities
         lsum += (bf16lo_to_f32(pf[it].x) + bf16hi_to_f32(pf[it].x)) + (bf16lo_to_f32(pf[it].y) + bf16hi_to_f32(pf[it].y));
     }
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
-    // ---- O = P . V : lane (channel 16nt + c, heads 4kg+v)
+    // ---- O = P . V : lane (channel 16nt + c, heads 4kg+v); contraction index 8kg+e <-> token 32*ip + 8kg + e
     f32x4_t o[NTD];
 #pragma unroll
     for (int nt = 0; nt < NTD; ++nt) o[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int src_lane4 = 4 * (4 * c + kg);                        // byte address of lane 4c+kg for ds_bpermute
 #pragma unroll
-    for (int it = 0; it < NT; ++it) {
-        const bool partial = t0 + 16 * it + 16 > t1;              // tile reaches beyond the context
+    for (int ip = 0; ip < NP; ++ip) {
+        const uint4 pa = make_uint4(pf[2 * ip].x, pf[2 * ip].y, pf[2 * ip + 1].x, pf[2 * ip + 1].y);
+        const int tk = t0 + 32 * ip + 8 * kg;                     // first token of this lane's 8
+        const bool partial = t0 + 32 * ip + 32 > t1;              // pair reaches beyond the context
 #pragma unroll
         for (int nt = 0; nt < NTD; ++nt) {
-            uint2 vv;
-            if constexpr (KV8) vv = fp8x4_to_bf16x4(vf[it][nt]); else vv = vf[it][nt];
+            uint4 vv;
+            if constexpr (KV8) {
+                const uint32_t r0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)vraw[ip][nt].x);
+                const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)vraw[ip][nt].y);
+                const uint2 lo = fp8x4_to_bf16x4(r0), hi = fp8x4_to_bf16x4(r1);
+                vv = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            } else {
+                vv.x = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)vraw[ip][nt].x);
+                vv.y = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)vraw[ip][nt].y);
+                vv.z = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)vraw[ip][nt].z);
+                vv.w = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)vraw[ip][nt].w);
+            }
             if (partial) {                                        // never multiply 0 by unwritten (maybe NaN) V
-                const int tk = t0 + 16 * it + 4 * kg;
                 if (tk + 0 >= t1) vv.x &= 0xFFFF0000u;
                 if (tk + 1 >= t1) vv.x &= 0x0000FFFFu;
                 if (tk + 2 >= t1) vv.y &= 0xFFFF0000u;
                 if (tk + 3 >= t1) vv.y &= 0x0000FFFFu;
+                if (tk + 4 >= t1) vv.z &= 0xFFFF0000u;
+                if (tk + 5 >= t1) vv.z &= 0x0000FFFFu;
+                if (tk + 6 >= t1) vv.w &= 0xFFFF0000u;
+                if (tk + 7 >= t1) vv.w &= 0x0000FFFFu;
             }
-            o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, pf[it]),
-                                                              __builtin_bit_cast(s16x4_t, vv), o[nt], 0, 0, 0);
+            o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pa),
+                                                            __builtin_bit_cast(bf16x8_t, vv), o[nt], 0, 0, 0);
         }
     }
     // ---- epilogue: rows (heads 4kg+v) need the column statistics of lane (4kg+v)
