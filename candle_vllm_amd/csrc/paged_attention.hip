@@ -431,16 +431,14 @@ __global__ void __launch_bounds__(256) paged_attn_paged_layout_kernel(const PAPa
 //   * the whole partition's scores stay in registers -> one max per partition, no online rescale;
 //   * P is rounded to bf16 for the P.V MFMA (fp32 accumulate), output normalised per partition;
 //   * all K and V loads of the partition are issued before the first MFMA.
-template <int D32, int NT, bool KV8 = false>
-__global__ void __launch_bounds__(64) paged_attn_mfma_kernel(const PAParams p) {
+// one partition [t0, t1) of (sequence b, kv head hk) on one wave: unnormalised O (lane: channel 16nt + (lane&15), heads
+// 4(lane>>4)+v), the partition's row maxima m and bf16-rounded probability sums lsum (valid in lane == head)
+template <int D32, int NT, bool KV8>
+__device__ __forceinline__ void pa_mfma_partition(const PAParams& p, const int b, const int hk, const int t0, const int t1,
+                                                  const int lane, f32x4_t (&o)[2 * D32], float& m, float& lsum) {
     constexpr int D = 32 * D32, NTD = D / 16;
-    const int hk = blockIdx.x, b = blockIdx.y, part = blockIdx.z;
-    const int ctx = (int)p.context_lens[b];
-    const int t0 = part * p.partition_size;
-    if (t0 >= ctx) return;
-    const int t1 = min(ctx, t0 + p.partition_size);
     const int G = p.H / p.Hkv, bs = p.block_size;
-    const int lane = threadIdx.x, c = lane & 15, kg = lane >> 4;
+    const int c = lane & 15, kg = lane >> 4;
     const uint16_t* kc = static_cast<const uint16_t*>(p.kc);
     const uint16_t* vc = static_cast<const uint16_t*>(p.vc);
     const uint32_t* bt = p.block_tables + (int64_t)b * p.max_blocks;
@@ -514,7 +512,7 @@ __global__ void __launch_bounds__(64) paged_attn_mfma_kernel(const PAParams p) {
     const float qk_scale = KV8 ? p.scale * p.k_scale : p.scale;
     // ---- S^T = K . Q^T : lane (head c, rows 4kg+v); row 4kg+v of tile `it` is token 32*(it/2) + 8kg + 4*(it&1) + v
     float sc[NT][4];
-    float m = -1e30f;
+    m = -1e30f;
 #pragma unroll
     for (int it = 0; it < NT; ++it) {
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -538,7 +536,7 @@ __global__ void __launch_bounds__(64) paged_attn_mfma_kernel(const PAParams p) {
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float lsum = 0.f;
+    lsum = 0.f;
     uint2 pf[NT];
 #pragma unroll
     for (int it = 0; it < NT; ++it) {
@@ -553,7 +551,6 @@ __global__ void __launch_bounds__(64) paged_attn_mfma_kernel(const PAParams p) {
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
     // ---- O = P . V : lane (channel 16nt + c, heads 4kg+v); contraction index 8kg+e <-> token 32*ip + 8kg + e
-    f32x4_t o[NTD];
 #pragma unroll
     for (int nt = 0; nt < NTD; ++nt) o[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int src_lane4 = 4 * (4 * c + kg);                        // byte address of lane 4c+kg for ds_bpermute
@@ -590,6 +587,126 @@ __global__ void __launch_bounds__(64) paged_attn_mfma_kernel(const PAParams p) {
                                                             __builtin_bit_cast(bf16x8_t, vv), o[nt], 0, 0, 0);
         }
     }
+}
+
+// WPB = waves per workgroup.  1: one partition per workgroup (many sequences: the grid is large anyway).  > 1: the
+// workgroup takes WPB consecutive partitions, one per wave, and merges them in LDS before anything goes to global
+// memory -- WPB x fewer partials for the reduce / fused merge, which is what bounds the step at batch 1 (129
+// partitions per head at 4 k context).
+template <int D32, int NT, bool KV8 = false, int WPB = 1>
+__global__ void __launch_bounds__(64 * WPB) paged_attn_mfma_kernel(const PAParams p) {
+    constexpr int D = 32 * D32, NTD = D / 16;
+    const int hk = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int part = blockIdx.z * WPB + wave;
+    const int ctx = (int)p.context_lens[b];
+    if (blockIdx.z * WPB * p.partition_size >= ctx) return;        // uniform for the workgroup
+    const int t0 = part * p.partition_size;
+    const bool live = t0 < ctx;
+    const int t1 = min(ctx, t0 + p.partition_size);
+    const int G = p.H / p.Hkv;
+    const int c = lane & 15, kg = lane >> 4;
+    extern __shared__ __attribute__((aligned(16))) float pa_smem[];   // WPB > 1 only
+    f32x4_t o[NTD];
+    float m = -1e30f, lsum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NTD; ++nt) o[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (live) pa_mfma_partition<D32, NT, KV8>(p, b, hk, t0, t1, lane, o, m, lsum);
+    const int group_tokens = p.partition_size * WPB;               // tokens behind one partial in tmp_out
+    const int pslot = blockIdx.z;
+    if constexpr (WPB > 1) {
+        // ---- in-workgroup merge: [wave][head < G][D] unnormalised O + (m, lsum) per (wave, head)
+        float* sm_o = pa_smem;                                     // [WPB][G][D]
+        float* sm_m = sm_o + (size_t)WPB * G * D;                  // [WPB][G]
+        float* sm_l = sm_m + WPB * G;                              // [WPB][G]
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int head = 4 * kg + v;
+            if (head < G) {
+#pragma unroll
+                for (int nt = 0; nt < NTD; ++nt) sm_o[((size_t)wave * G + head) * D + 16 * nt + c] = o[nt][v];
+            }
+        }
+        if (lane < G) { sm_m[wave * G + lane] = m; sm_l[wave * G + lane] = lsum; }
+        __syncthreads();
+        const float vs = KV8 ? p.v_scale : 1.f;
+        for (int idx = threadIdx.x; idx < G * D; idx += 64 * WPB) {
+            const int g = idx / D, d = idx - g * D;
+            float M = -1e30f;
+#pragma unroll
+            for (int w = 0; w < WPB; ++w) M = fmaxf(M, sm_m[w * G + g]);
+            float den = 0.f, val = 0.f;
+#pragma unroll
+            for (int w = 0; w < WPB; ++w) {
+                const float e = __expf(sm_m[w * G + g] - M);
+                den = fmaf(sm_l[w * G + g], e, den);
+                val = fmaf(sm_o[((size_t)w * G + g) * D + d], e, val);
+            }
+            const float outv = (den > 0.f ? val / den : 0.f) * vs;
+            const int h = hk * G + g;
+            if (p.max_partitions > 1) {
+                const int64_t pi = ((int64_t)b * p.H + h) * p.max_partitions + pslot;
+                if (p.arrive) {
+                    __hip_atomic_store(p.tmp_out + pi * D + d, outv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (d == 0) {
+                        __hip_atomic_store(p.max_logits + pi, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(p.exp_sums + pi, den, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else {
+                    p.tmp_out[pi * D + d] = outv;
+                    if (d == 0) { p.max_logits[pi] = M; p.exp_sums[pi] = den; }
+                }
+            } else {
+                static_cast<uint16_t*>(p.out)[((int64_t)b * p.H + h) * D + d] = f32_to_bf16(outv);
+            }
+        }
+        if (p.max_partitions <= 1 || p.arrive == nullptr) return;
+        // fused merge, workgroup form: every wave drains its write-through stores, one thread takes the ticket, the
+        // last workgroup merges with one WAVE per query head (64 lanes x D/64 channels)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* sm_t = reinterpret_cast<unsigned*>(pa_smem);
+        if (threadIdx.x == 0)
+            sm_t[0] = __hip_atomic_fetch_add(p.arrive + (int64_t)b * p.Hkv + hk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int Pg = (ctx + group_tokens - 1) / group_tokens;
+        if ((int)sm_t[0] != Pg - 1) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (threadIdx.x == 0) __hip_atomic_store(p.arrive + (int64_t)b * p.Hkv + hk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        constexpr int DL2 = D / 64, MU2 = 8;
+        for (int g = wave; g < G; g += WPB) {
+            const int64_t pi0 = ((int64_t)b * p.H + hk * G + g) * p.max_partitions;
+            float M = -1e30f;
+            for (int q = lane; q < Pg; q += 64) M = fmaxf(M, p.max_logits[pi0 + q]);
+            M = wave_max(M);
+            float accv[DL2], den = 0.f;
+#pragma unroll
+            for (int e = 0; e < DL2; ++e) accv[e] = 0.f;
+            for (int q0 = 0; q0 < Pg; q0 += MU2) {
+                float tv[MU2][DL2], es[MU2], ml[MU2];
+#pragma unroll
+                for (int u = 0; u < MU2; ++u) {
+                    const int q = (q0 + u < Pg) ? q0 + u : Pg - 1;
+                    es[u] = p.exp_sums[pi0 + q];
+                    ml[u] = p.max_logits[pi0 + q];
+#pragma unroll
+                    for (int e = 0; e < DL2; ++e) tv[u][e] = p.tmp_out[(pi0 + q) * D + lane * DL2 + e];
+                }
+#pragma unroll
+                for (int u = 0; u < MU2; ++u) {
+                    const float wq = (q0 + u < Pg) ? es[u] * __expf(ml[u] - M) : 0.f;
+                    den += wq;
+#pragma unroll
+                    for (int e = 0; e < DL2; ++e) accv[e] = fmaf(tv[u][e], wq, accv[e]);
+                }
+            }
+            const float inv = den > 0.f ? 1.f / den : 0.f;
+            uint16_t* op = static_cast<uint16_t*>(p.out) + ((int64_t)b * p.H + hk * G + g) * D + lane * DL2;
+#pragma unroll
+            for (int e = 0; e < DL2; ++e) op[e] = f32_to_bf16(accv[e] * inv);
+        }
+        return;
+    } else {
     // ---- epilogue: rows (heads 4kg+v) need the column statistics of lane (4kg+v)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -599,7 +716,7 @@ __global__ void __launch_bounds__(64) paged_attn_mfma_kernel(const PAParams p) {
         const int h = hk * G + head;
         const float inv = (lh > 0.f ? 1.f / lh : 0.f) * (KV8 ? p.v_scale : 1.f);
         if (p.max_partitions > 1) {
-            const int64_t pi = ((int64_t)b * p.H + h) * p.max_partitions + part;
+            const int64_t pi = ((int64_t)b * p.H + h) * p.max_partitions + pslot;
             if (p.arrive) {
                 // fused merge: partials go out WRITE-THROUGH (sc1: relaxed agent-scope stores), so the hand-off
                 // needs no release fence (a release would write back the whole L2 from every wave)
@@ -622,16 +739,17 @@ __global__ void __launch_bounds__(64) paged_attn_mfma_kernel(const PAParams p) {
         }
     }
     if (p.max_partitions <= 1 || p.arrive == nullptr) return;
+    }
 
     // ---- fused merge of the partitions (replaces the separate reduce launch): the wave that arrives last for
     // this (sequence, kv head) merges all partials.  Placement-independent hand-off (guide G16, form R1): the
     // payload was stored write-through, every wave drains its stores, then takes an arrival ticket; the last
     // arriver does ONE agent-scope acquire and reads with plain loads.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (WPB == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned ticket = 0;
     if (lane == 0) ticket = __hip_atomic_fetch_add(p.arrive + (int64_t)b * p.Hkv + hk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ticket = __shfl(ticket, 0, 64);
-    const int P = (ctx + p.partition_size - 1) / p.partition_size;
+    const int P = (ctx + group_tokens - 1) / group_tokens;
     if ((int)ticket != P - 1) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (lane == 0) __hip_atomic_store(p.arrive + (int64_t)b * p.Hkv + hk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -685,22 +803,27 @@ __global__ void __launch_bounds__(64) paged_attn_mfma_kernel(const PAParams p) {
     }
 }
 
-template <int D32>
-static int launch_mfma(const PAParams& p, int B, int P, hipStream_t st) {
-    dim3 grid(p.Hkv, B, P), block(64);
+template <int D32, int WPB>
+static int launch_mfma_w(const PAParams& p, int B, int P, hipStream_t st) {
+    dim3 grid(p.Hkv, B, (P + WPB - 1) / WPB), block(64 * WPB);
     const int nt = p.partition_size / 16;
+    const size_t shm = WPB > 1 ? (size_t)WPB * (p.H / p.Hkv) * (32 * D32 + 2) * sizeof(float) : 0;
     if (p.kv8) {
-        if (nt == 2) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 2, true>), grid, block, 0, st, p);
-        else if (nt == 4) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 4, true>), grid, block, 0, st, p);
-        else if (nt == 8) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 8, true>), grid, block, 0, st, p);
+        if (nt == 2) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 2, true, WPB>), grid, block, shm, st, p);
+        else if (nt == 4) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 4, true, WPB>), grid, block, shm, st, p);
+        else if (nt == 8 && WPB == 1) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 8, true, 1>), grid, block, shm, st, p);
         else return (int)hipErrorInvalidValue;
         return (int)hipGetLastError();
     }
-    if (nt == 2) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 2>), grid, block, 0, st, p);
-    else if (nt == 4) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 4>), grid, block, 0, st, p);
-    else if (nt == 8) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 8>), grid, block, 0, st, p);
+    if (nt == 2) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 2, false, WPB>), grid, block, shm, st, p);
+    else if (nt == 4) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 4, false, WPB>), grid, block, shm, st, p);
+    else if (nt == 8 && WPB == 1) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 8, false, 1>), grid, block, shm, st, p);
     else return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
+}
+template <int D32>
+static int launch_mfma(const PAParams& p, int B, int P, int wpb, hipStream_t st) {
+    return wpb == 4 ? launch_mfma_w<D32, 4>(p, B, P, st) : launch_mfma_w<D32, 1>(p, B, P, st);
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -728,13 +851,14 @@ static int launch_flash(const PAParams& p, int B, int P, hipStream_t st) {
 static unsigned* g_pa_arrive = nullptr;
 #define PA_ARRIVE_SLOTS 65536
 static int g_pa_fused = 1;                                          // mi355_set_tuning(3, 0) -> separate reduce launch
+static int g_pa_wpb = 0;                                            // mi355_set_tuning(8, 1 | 4): waves (partitions) per workgroup, 0 = auto
 
 static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t stream) {
     if (B <= 0) return 0;
     if (p.H % p.Hkv || (p.D & 7) || p.D > 256) return (int)hipErrorInvalidValue;
     if (dtype != MI355_DTYPE_BF16 && dtype != MI355_DTYPE_F16) return (int)hipErrorInvalidValue;
     hipStream_t st = to_stream(stream);
-    int rc;
+    int rc, wpb = 1;
     if (p.kv8 && (layout != MI355_KV_PAGED || dtype != MI355_DTYPE_BF16 || (p.D % 16))) return (int)hipErrorInvalidValue;
     if (layout == MI355_KV_FLASH) {
         if (P > 1)
@@ -747,6 +871,9 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
                p.H / p.Hkv <= 16 && (p.block_size % 16) == 0 &&
                (p.partition_size == 32 || p.partition_size == 64 || p.partition_size == 128)) {
         bool fused = false;
+        // few sequences, many partitions: 4 partitions per workgroup, merged in LDS (4 x fewer partials to reduce)
+        if (g_pa_wpb > 0) wpb = (g_pa_wpb == 4 && p.partition_size <= 64) ? 4 : 1;
+        else wpb = (P >= 8 && p.partition_size <= 64) ? 4 : 1;
         // the in-kernel merge is one wave per (sequence, kv head): worth it only when there are many of them
         if (P > 1 && g_pa_fused && (int64_t)B * p.Hkv >= (g_pa_fused > 1 ? 1 : 64) && (int64_t)B * p.Hkv <= PA_ARRIVE_SLOTS) {
             if (!g_pa_arrive) {                                     // first call (eager warm-up), never in a capture
@@ -757,7 +884,7 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
             p.arrive = g_pa_arrive;
             fused = true;
         }
-        rc = (p.D == 128) ? launch_mfma<4>(p, B, P, st) : launch_mfma<2>(p, B, P, st);
+        rc = (p.D == 128) ? launch_mfma<4>(p, B, P, wpb, st) : launch_mfma<2>(p, B, P, wpb, st);
         if (fused) return rc;
     } else if (layout == MI355_KV_PAGED) {
         const size_t shm = (size_t)p.partition_size * sizeof(float);
@@ -777,14 +904,15 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
     if (rshm > 60 * 1024) return (int)hipErrorInvalidValue;
     if (dtype == MI355_DTYPE_BF16)
         hipLaunchKernelGGL(paged_attn_reduce_kernel<MI355_DTYPE_BF16>, rgrid, rblock, rshm, st, p.out, p.tmp_out,
-                           p.max_logits, p.exp_sums, p.context_lens, p.H, p.D, p.partition_size, p.max_partitions);
+                           p.max_logits, p.exp_sums, p.context_lens, p.H, p.D, p.partition_size * wpb, p.max_partitions);
     else
         hipLaunchKernelGGL(paged_attn_reduce_kernel<MI355_DTYPE_F16>, rgrid, rblock, rshm, st, p.out, p.tmp_out,
-                           p.max_logits, p.exp_sums, p.context_lens, p.H, p.D, p.partition_size, p.max_partitions);
+                           p.max_logits, p.exp_sums, p.context_lens, p.H, p.D, p.partition_size * wpb, p.max_partitions);
     return (int)hipGetLastError();
 }
 
 void mi355_pa_set_fused(int v) { g_pa_fused = v; }
+void mi355_pa_set_wpb(int v) { g_pa_wpb = v; }
 
 // decode attention over an fp8 (e4m3fn) KV cache in the PAGED layout (K x = 16); partition_size 0 = one pass (v1)
 extern "C" int mi355_paged_attention_fp8(void* out, float* exp_sums, float* max_logits, float* tmp_out, const void* q,

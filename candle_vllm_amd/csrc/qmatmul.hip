@@ -1561,6 +1561,7 @@ static int qmw_launch_mt(const QmmArgs& a, int wt, hipStream_t st) {
 
 // ------------------------------------------------------------------------------------------------ launcher
 void mi355_pa_set_fused(int v);
+void mi355_pa_set_wpb(int v);
 extern "C" void mi355_host_set_partition_override(int v);
 static int g_tune_nw = 0, g_tune_r = 0, g_tune_dbg = 0;   // 0 = heuristic; mi355_set_tuning (experiments only)
 static int g_tune_prefill_gemm = 1;                        // 0 = always stream the quantised weights (experiments)
@@ -1573,6 +1574,7 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     else if (key == 4) g_tune_wide = value;
     else if (key == 5) mi355_host_set_partition_override(value);
     else if (key == 6) g_tune_prefill_gemm = value;
+    else if (key == 8) mi355_pa_set_wpb(value);
 }
 
 static size_t qmm_lds_bytes(int BT, int R, int NW) {
