@@ -45,6 +45,7 @@ class QmmDesc(ctypes.Structure):
         ("num_heads", c_i32), ("num_kv_heads", c_i32), ("head_dim", c_i32), ("rotary_dim", c_i32),
         ("block_size", c_i32), ("kv_layout", c_i32),
         ("moe_expert_ids", c_vp), ("moe_pairs", c_i32), ("moe_x_div", c_i32), ("moe_expert_stride", c_i64 * 3),
+        ("chain_next", c_i32), ("chain_next_k", c_i32), ("chain_next_norm", c_vp),
     ]
 
 

@@ -321,6 +321,8 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
         d.w_tiles[0] = L.w[MI355_W_WO].tiles; d.ggml_type[0] = L.w[MI355_W_WO].type; d.n_rows[0] = L.w[MI355_W_WO].n_rows;
         d.x = in.attn; d.x_dtype = MI355_DTYPE_BF16; d.ldx = H * D; d.k = H * D; d.num_tokens = B;
         d.epilogue = lead ? MI355_EPI_RESID : MI355_EPI_STORE; d.out = in.xs; d.ldo = hid; d.residual = in.xs;
+        // 9..32 tokens: the epilogue stages the gate/up launch's activation image (xs is final here unless TP reduces it)
+        if (!m->use_comm && !moe) { d.chain_next = 1; d.chain_next_k = hid; d.chain_next_norm = L.ffn_norm; }
         RCHECK(mi355_qmatmul_fused(&d, st));
         return all_reduce_xs(m, in.xs, B, st);
     }
@@ -332,6 +334,7 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
         d.x = in.xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
         d.norm_weight = L.ffn_norm; d.norm_eps = c.rms_eps;
         d.epilogue = MI355_EPI_SILU_MUL; d.out = in.h; d.ldo = I;
+        d.chain_next = 1; d.chain_next_k = I; d.chain_next_norm = nullptr;          // -> w2
         return mi355_qmatmul_fused(&d, st);
     }
     if (part == PART_DOWN) {
@@ -340,6 +343,10 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
         d.w_tiles[0] = L.w[MI355_W_W2].tiles; d.ggml_type[0] = L.w[MI355_W_W2].type; d.n_rows[0] = L.w[MI355_W_W2].n_rows;
         d.x = in.h; d.x_dtype = MI355_DTYPE_F32; d.ldx = I; d.k = I; d.num_tokens = B;
         d.epilogue = lead ? MI355_EPI_RESID : MI355_EPI_STORE; d.out = in.xs; d.ldo = hid; d.residual = in.xs;
+        if (!m->use_comm) {                                         // -> next layer's QKV, or the lm_head
+            d.chain_next = 1; d.chain_next_k = hid;
+            d.chain_next_norm = (l + 1 < c.n_layers) ? m->layers[l + 1].attn_norm : m->output_norm;
+        }
         RCHECK(mi355_qmatmul_fused(&d, st));
         return all_reduce_xs(m, in.xs, B, st);
     }

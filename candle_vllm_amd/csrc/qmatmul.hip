@@ -197,6 +197,10 @@ struct QmmArgs {
     uint16_t* vcache;
     int32_t Hq, Hkv, D, rot, block_size, kv_layout;
     int32_t dbg;              // experiments: 1 = stream the weights but skip unpack/MFMA (memory-path probe)
+    // chain request (wide path): the epilogue also stages the activation image of the NEXT mat-mul, whose x is this
+    // `out` with k = next_k and RMSNorm weight next_norm_w (or null)
+    const float* next_norm_w;
+    int32_t chain_next, next_k;
     // mixture of experts (quantized_llama.rs:56-123 on the device): blockIdx.y = (token, slot) pair; the pair's expert
     // id is read from device memory and selects the weight slab, its x row is pair / moe_xdiv, its out row is pair
     const int32_t* moe_expert;
@@ -1083,17 +1087,60 @@ static inline size_t qmg_kb_bytes(int MT) { return (((size_t)MT * 8 * 1216) + 10
 // image + per-k-block sum of squares in ONE pass: grid = k-blocks, a workgroup builds k-block kb for every token
 // row.  The RMSNorm weight is applied here, the 1/rms factor (a per-token scalar) is applied by the epilogue kernel
 // from the per-k-block partial sums ssp[kb][row] -- no second pass over x, no atomics.
+// one image entry (8 consecutive elements El of k-block kb, token row b): hi/lo bf16 fragments, sub-block sums, and the
+// sum of squares of the row's k-block (reduced over the 32 consecutive lanes that hold its 32 entries)
+__device__ __forceinline__ void qmg_prep_entry(uint8_t* __restrict__ img, float* __restrict__ ssp, float (&v)[8], const bool live,
+                                               const float* __restrict__ norm_w, const int MT, const size_t kbb,
+                                               const int kb, const int b, const int El) {
+    const int BP = MT * 8;
+    uint8_t* kbase = img + (size_t)kb * kbb;
+    float* xs32 = reinterpret_cast<float*>(kbase + (size_t)32 * MT * 16 * 16);
+    float* xs16 = xs32 + 8 * 2 * BP;
+    const int mt = b >> 3, m = b & 7;
+    const int k = kb * 256 + El * 8;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss += v[i] * v[i];
+    if (norm_w && live) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= norm_w[k + i];
+    }
+    const uint32_t h02 = cvt_pk_bf16(v[0], v[2]), h13 = cvt_pk_bf16(v[1], v[3]);
+    const uint32_t h46 = cvt_pk_bf16(v[4], v[6]), h57 = cvt_pk_bf16(v[5], v[7]);
+    const float hf[8] = {bf16lo_to_f32(h02), bf16lo_to_f32(h13), bf16hi_to_f32(h02), bf16hi_to_f32(h13),
+                         bf16lo_to_f32(h46), bf16lo_to_f32(h57), bf16hi_to_f32(h46), bf16hi_to_f32(h57)};
+    const uint32_t l02 = cvt_pk_bf16(v[0] - hf[0], v[2] - hf[2]), l13 = cvt_pk_bf16(v[1] - hf[1], v[3] - hf[3]);
+    const uint32_t l46 = cvt_pk_bf16(v[4] - hf[4], v[6] - hf[6]), l57 = cvt_pk_bf16(v[5] - hf[5], v[7] - hf[7]);
+    float hsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hsum += hf[i];
+    const float lsum = (bf16lo_to_f32(l02) + bf16hi_to_f32(l02)) + (bf16lo_to_f32(l13) + bf16hi_to_f32(l13)) +
+                       (bf16lo_to_f32(l46) + bf16hi_to_f32(l46)) + (bf16lo_to_f32(l57) + bf16hi_to_f32(l57));
+    uint8_t* ent = kbase + ((size_t)El * (MT * 16) + mt * 16) * 16;
+    *reinterpret_cast<uint4*>(ent + (size_t)m * 16) = make_uint4(h02, h13, h46, h57);
+    *reinterpret_cast<uint4*>(ent + (size_t)(8 + m) * 16) = make_uint4(l02, l13, l46, l57);
+    const float h16 = hsum + __shfl_xor(hsum, 1, 64), l16 = lsum + __shfl_xor(lsum, 1, 64);
+    const float h32 = h16 + __shfl_xor(h16, 2, 64), l32 = l16 + __shfl_xor(l16, 2, 64);
+    if ((El & 1) == 0) {
+        xs16[((El >> 1) * 2 + 0) * BP + b] = h16;
+        xs16[((El >> 1) * 2 + 1) * BP + b] = l16;
+    }
+    if ((El & 3) == 0) {
+        xs32[((El >> 2) * 2 + 0) * BP + b] = h32;
+        xs32[((El >> 2) * 2 + 1) * BP + b] = l32;
+    }
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) ss += __shfl_xor(ss, o, 64);
+    if (El == 0) ssp[(size_t)kb * BP + b] = ss;
+}
+
 template <int MT>
 __global__ void __launch_bounds__(256) qmm_prep2_kernel(uint8_t* __restrict__ img, float* __restrict__ ssp, const QmmArgs a, const size_t kbb) {
     constexpr int BP = MT * 8;
     const int kb = blockIdx.x;
-    uint8_t* kbase = img + (size_t)kb * kbb;
-    float* xs32 = reinterpret_cast<float*>(kbase + (size_t)32 * MT * 16 * 16);
-    float* xs16 = xs32 + 8 * 2 * BP;
     for (int e = threadIdx.x; e < BP * 32; e += blockDim.x) {       // 32 consecutive lanes = the 32 entries of one row
         const int b = e >> 5, El = e & 31;
         const bool live = b < a.B;
-        const int mt = b >> 3, m = b & 7;
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = 0.f;
@@ -1109,40 +1156,7 @@ __global__ void __launch_bounds__(256) qmm_prep2_kernel(uint8_t* __restrict__ im
                 v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
             }
         }
-        float ss = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ss += v[i] * v[i];
-        if (a.norm_w && live) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] *= a.norm_w[k + i];
-        }
-        const uint32_t h02 = cvt_pk_bf16(v[0], v[2]), h13 = cvt_pk_bf16(v[1], v[3]);
-        const uint32_t h46 = cvt_pk_bf16(v[4], v[6]), h57 = cvt_pk_bf16(v[5], v[7]);
-        const float hf[8] = {bf16lo_to_f32(h02), bf16lo_to_f32(h13), bf16hi_to_f32(h02), bf16hi_to_f32(h13),
-                             bf16lo_to_f32(h46), bf16lo_to_f32(h57), bf16hi_to_f32(h46), bf16hi_to_f32(h57)};
-        const uint32_t l02 = cvt_pk_bf16(v[0] - hf[0], v[2] - hf[2]), l13 = cvt_pk_bf16(v[1] - hf[1], v[3] - hf[3]);
-        const uint32_t l46 = cvt_pk_bf16(v[4] - hf[4], v[6] - hf[6]), l57 = cvt_pk_bf16(v[5] - hf[5], v[7] - hf[7]);
-        float hsum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) hsum += hf[i];
-        const float lsum = (bf16lo_to_f32(l02) + bf16hi_to_f32(l02)) + (bf16lo_to_f32(l13) + bf16hi_to_f32(l13)) +
-                           (bf16lo_to_f32(l46) + bf16hi_to_f32(l46)) + (bf16lo_to_f32(l57) + bf16hi_to_f32(l57));
-        uint8_t* ent = kbase + ((size_t)El * (MT * 16) + mt * 16) * 16;
-        *reinterpret_cast<uint4*>(ent + (size_t)m * 16) = make_uint4(h02, h13, h46, h57);
-        *reinterpret_cast<uint4*>(ent + (size_t)(8 + m) * 16) = make_uint4(l02, l13, l46, l57);
-        const float h16 = hsum + __shfl_xor(hsum, 1, 64), l16 = lsum + __shfl_xor(lsum, 1, 64);
-        const float h32 = h16 + __shfl_xor(h16, 2, 64), l32 = l16 + __shfl_xor(l16, 2, 64);
-        if ((El & 1) == 0) {
-            xs16[((El >> 1) * 2 + 0) * BP + b] = h16;
-            xs16[((El >> 1) * 2 + 1) * BP + b] = l16;
-        }
-        if ((El & 3) == 0) {
-            xs32[((El >> 2) * 2 + 0) * BP + b] = h32;
-            xs32[((El >> 2) * 2 + 1) * BP + b] = l32;
-        }
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) ss += __shfl_xor(ss, o, 64);
-        if (El == 0) ssp[(size_t)kb * BP + b] = ss;
+        qmg_prep_entry(img, ssp, v, live, a.norm_w, MT, kbb, kb, b, El);
     }
 }
 
@@ -1226,11 +1240,9 @@ __global__ void __launch_bounds__(512, 4) qmm_gemm_kernel(const QmmArgs a, const
 }
 
 // partial sums -> epilogue; one thread per (token, concatenated padded row)
-__global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, const float* __restrict__ part, const int ldp,
-                                                           const int ks, const int BP, const float* __restrict__ ssp) {
-    const int prow = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = blockIdx.y;
-    if (prow >= ldp || b >= a.B) return;
+// returns the f32 value written to a.out for (token b, out column = the chain's k index), 0 when nothing was written
+__device__ __forceinline__ float qmm_epilogue_one(const QmmArgs& a, const float* __restrict__ part, const int ldp, const int ks,
+                                                  const int BP, const float* __restrict__ ssp, const int prow, const int b) {
     float inv = 1.f;                                               // deferred RMSNorm scale of this token
     if (a.norm_w) {
         float ss = 0.f;
@@ -1239,7 +1251,7 @@ __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, cons
     }
     int sg = 0, lrow = prow;
     while (sg + 1 < a.nseg && lrow >= a.seg[sg].n_tiles * 16) { lrow -= a.seg[sg].n_tiles * 16; ++sg; }
-    if (lrow >= a.seg[sg].n_rows) return;
+    if (lrow >= a.seg[sg].n_rows) return 0.f;
     auto total = [&](int pr) {
         float s = 0.f;
         for (int k = 0; k < ks; ++k) s += part[((size_t)k * BP + b) * ldp + pr];
@@ -1250,13 +1262,18 @@ __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, cons
     if (a.bias) val += a.bias[orow];
     if (a.epi == MI355_EPI_STORE) {
         a.out[(size_t)b * a.ldo + orow] = val;
+        return val;
     } else if (a.epi == MI355_EPI_RESID) {
-        a.out[(size_t)b * a.ldo + orow] = a.resid[(size_t)b * a.ldo + orow] + val;
+        const float o = a.resid[(size_t)b * a.ldo + orow] + val;
+        a.out[(size_t)b * a.ldo + orow] = o;
+        return o;
     } else if (a.epi == MI355_EPI_SILU_MUL) {
-        if (sg != 0) return;                                          // gate rows drive; up = same row of segment 1
+        if (sg != 0) return 0.f;                                      // gate rows drive; up = same row of segment 1
         float up = total(a.seg[0].n_tiles * 16 + lrow);
         if (a.bias) up += a.bias[a.seg[1].row0 + lrow];
-        a.out[(size_t)b * a.ldo + lrow] = silu_f(val) * up;
+        const float o = silu_f(val) * up;
+        a.out[(size_t)b * a.ldo + lrow] = o;
+        return o;
     } else if (a.epi == MI355_EPI_QKV_ROPE_CACHE) {
         const int D = a.D, d = lrow % D, hh = lrow / D;
         float o = val;
@@ -1272,7 +1289,7 @@ __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, cons
             a.q_out[(size_t)b * a.Hq * D + lrow] = ob;
         } else {
             const int64_t slot = a.slot_mapping[b];
-            if (slot < 0) return;
+            if (slot < 0) return 0.f;
             uint16_t* cache = (sg == 1) ? a.kcache : a.vcache;
             if (a.kv_layout == MI355_KV_PAGED_FP8) {                // e4m3fn of the bf16 value, K layout x = 16
                 uint8_t* c8 = reinterpret_cast<uint8_t*>(cache);
@@ -1289,10 +1306,43 @@ __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, cons
             }
         }
     }
+    return 0.f;
 }
 
-static uint8_t* g_qmg_img = nullptr;
-static size_t g_qmg_img_bytes = 0;
+// chain target: where the epilogue stages the NEXT wide mat-mul's activation image (img == null: no chain)
+struct QmgChainOut { uint8_t* img; float* ssp; const float* norm_w; int K, MT; size_t kbb; };
+
+// grid = (padded rows / 256, tokens).  With a chain target the y extent covers the PADDED token rows (MT*8) and every
+// workgroup = (token b, 256 consecutive output columns) = one (row, k-block) of the next image: the outputs meet in LDS
+// and 32 threads build the 32 entries.
+__global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, const float* __restrict__ part, const int ldp,
+                                                           const int ks, const int BP, const float* __restrict__ ssp,
+                                                           const QmgChainOut ch) {
+    const int prow = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    float o = 0.f;
+    if (prow < ldp && b < a.B) o = qmm_epilogue_one(a, part, ldp, ks, BP, ssp, prow, b);
+    if (!ch.img) return;
+    const int kb = blockIdx.x;
+    if (kb * 256 >= ch.K) return;                                    // uniform: e.g. the `up` half of the gate/up rows
+    __shared__ float sm_o[256];
+    sm_o[threadIdx.x] = o;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = sm_o[threadIdx.x * 8 + i];
+        qmg_prep_entry(ch.img, ch.ssp, v, b < a.B, ch.norm_w, ch.MT, ch.kbb, kb, b, (int)threadIdx.x);
+    }
+}
+
+static uint8_t* g_qmg_imgs[2] = {nullptr, nullptr};           // two images: an epilogue stages the next one while its own ssp is live
+static size_t g_qmg_img_bytes[2] = {0, 0};
+static int g_qmg_cur = 0;
+// image staged by the last chained epilogue: valid for exactly the next wide launch if it consumes the same activations
+struct QmgChainState { bool valid; const void* x; int B, K, MT, buf; const float* norm_w; hipStream_t st; };
+static QmgChainState g_qmg_chain = {false, nullptr, 0, 0, 0, 0, nullptr, nullptr};
+static int g_tune_chain = 1;                                  // mi355_set_tuning(9, 0): never chain (A/B experiments)
 static float* g_qmg_part = nullptr;
 static size_t g_qmg_part_bytes = 0;
 
@@ -1319,8 +1369,17 @@ static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
     // split K until the launch has >= 2048 waves (8 per CU), keeping >= 2 k-blocks per workgroup
     int ks = 1;
     while (n_slots * ks < 2048 && nkb / (ks * 2) >= 2) ks *= 2;
-    int rc = qmg_grow((void**)&g_qmg_img, &g_qmg_img_bytes, kbb * nkb + (size_t)nkb * MT * 8 * sizeof(float), st);
-    if (rc) return rc;
+    // activation image: staged by the previous launch's epilogue (chain) or by the prep kernel now
+    const bool chained = g_qmg_chain.valid && g_qmg_chain.x == a.x && g_qmg_chain.B == a.B && g_qmg_chain.K == a.K &&
+                         g_qmg_chain.MT == MT && g_qmg_chain.norm_w == a.norm_w && g_qmg_chain.st == st &&
+                         a.x_dtype == MI355_DTYPE_F32 && a.ldx == a.K;
+    g_qmg_chain.valid = false;
+    const int cur = chained ? g_qmg_chain.buf : g_qmg_cur;
+    int rc = 0;
+    if (!chained) {
+        rc = qmg_grow((void**)&g_qmg_imgs[cur], &g_qmg_img_bytes[cur], kbb * nkb + (size_t)nkb * MT * 8 * sizeof(float), st);
+        if (rc) return rc;
+    }
     rc = qmg_grow((void**)&g_qmg_part, &g_qmg_part_bytes, (size_t)ks * MT * 8 * ldp * sizeof(float), st);
     if (rc) return rc;
     static bool attr_done = false;
@@ -1329,8 +1388,9 @@ static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)qmm_gemm_kernel<MT, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    float* ssp = reinterpret_cast<float*>(g_qmg_img + kbb * nkb);           // [nkb][MT*8] after the image
-    hipLaunchKernelGGL((qmm_prep2_kernel<MT>), dim3(nkb), dim3(256), 0, st, g_qmg_img, ssp, a, kbb);
+    uint8_t* img = g_qmg_imgs[cur];
+    float* ssp = reinterpret_cast<float*>(img + kbb * nkb);                 // [nkb][MT*8] after the image
+    if (!chained) hipLaunchKernelGGL((qmm_prep2_kernel<MT>), dim3(nkb), dim3(256), 0, st, img, ssp, a, kbb);
     // one GEMM launch per run of same-type segments: the type-specialised builds need no schedule pinning and do not
     // spill (the mixed build did); each run writes its own columns of the partial-sum buffer
     for (int s0 = 0, slot_base = 0; s0 < a.nseg;) {
@@ -1342,13 +1402,27 @@ static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
         for (int q = 0; q < r.nseg; ++q) { r.seg[q] = a.seg[s0 + q]; run_slots += r.seg[q].n_tiles; }
         const dim3 ggrid((run_slots + QMG_NC - 1) / QMG_NC, ks);
         if (r.seg[0].type == MI355_GGML_Q4_K)
-            hipLaunchKernelGGL((qmm_gemm_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), 2 * kbb, st, r, g_qmg_img, g_qmg_part, ldp, run_slots, slot_base);
+            hipLaunchKernelGGL((qmm_gemm_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), 2 * kbb, st, r, img, g_qmg_part, ldp, run_slots, slot_base);
         else
-            hipLaunchKernelGGL((qmm_gemm_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, r, g_qmg_img, g_qmg_part, ldp, run_slots, slot_base);
+            hipLaunchKernelGGL((qmm_gemm_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, r, img, g_qmg_part, ldp, run_slots, slot_base);
         slot_base += run_slots;
         s0 = s1;
     }
-    hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, a.B), dim3(256), 0, st, a, g_qmg_part, ldp, ks, MT * 8, ssp);
+    // chain: this epilogue also stages the image of the next wide mat-mul (x = our out) into the other buffer
+    QmgChainOut ch{nullptr, nullptr, nullptr, 0, 0, 0};
+    const bool want = g_tune_chain && a.chain_next && a.next_k > 0 && (a.next_k % 256) == 0 && a.ldo == a.next_k &&
+                      (a.epi == MI355_EPI_RESID || a.epi == MI355_EPI_SILU_MUL || a.epi == MI355_EPI_STORE) &&
+                      (a.epi == MI355_EPI_SILU_MUL ? a.seg[0].n_rows == a.next_k : (a.nseg == 1 && a.seg[0].n_rows == a.next_k));
+    if (want) {
+        const int other = cur ^ 1, nkb2 = a.next_k / 256;
+        rc = qmg_grow((void**)&g_qmg_imgs[other], &g_qmg_img_bytes[other], kbb * nkb2 + (size_t)nkb2 * MT * 8 * sizeof(float), st);
+        if (rc) return rc;
+        ch = QmgChainOut{g_qmg_imgs[other], reinterpret_cast<float*>(g_qmg_imgs[other] + kbb * nkb2), a.next_norm_w, a.next_k, MT, kbb};
+        g_qmg_chain = QmgChainState{true, a.out, a.B, a.next_k, MT, other, a.next_norm_w, st};
+    }
+    g_qmg_cur = cur;
+    hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, want ? MT * 8 : a.B), dim3(256), 0, st, a, g_qmg_part, ldp, ks,
+                       MT * 8, ssp, ch);
     return (int)hipGetLastError();
 }
 
@@ -1509,7 +1583,8 @@ static int qmp_launch(const QmmArgs& a0, hipStream_t st) {
         if (st_rc != 0) return (int)hipErrorUnknown;
     }
     a.norm_w = nullptr;                                     // already applied to x
-    hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, T), dim3(256), 0, st, a, C, ldp, 1, T, (const float*)nullptr);
+    hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, T), dim3(256), 0, st, a, C, ldp, 1, T, (const float*)nullptr,
+                       QmgChainOut{nullptr, nullptr, nullptr, 0, 0, 0});
     return (int)hipGetLastError();
 }
 
@@ -1575,6 +1650,7 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     else if (key == 5) mi355_host_set_partition_override(value);
     else if (key == 6) g_tune_prefill_gemm = value;
     else if (key == 8) mi355_pa_set_wpb(value);
+    else if (key == 9) g_tune_chain = value;
 }
 
 static size_t qmm_lds_bytes(int BT, int R, int NW) {
@@ -1793,5 +1869,7 @@ extern "C" int mi355_qmatmul_fused(const mi355_qmm_desc* d, int64_t stream) {
         return (int)hipErrorInvalidValue;
     a.moe_expert = d->moe_expert_ids; a.moe_pairs = d->moe_pairs; a.moe_xdiv = d->moe_x_div;
     for (int s = 0; s < 3; ++s) a.moe_stride[s] = d->moe_expert_stride[s];
+    a.chain_next = (d->chain_next && !d->moe_expert_ids && d->num_tokens > 8 && d->num_tokens <= 8 * QMW_MAXMT) ? 1 : 0;
+    a.next_k = d->chain_next_k; a.next_norm_w = d->chain_next_norm;
     return mi355_qmm_launch(a, stream);
 }

@@ -209,6 +209,12 @@ typedef struct mi355_qmm_desc {
     const int32_t* moe_expert_ids;
     int32_t moe_pairs, moe_x_div;
     int64_t moe_expert_stride[3];
+    /* chain hint (0 / NULL = off; 9..32 tokens only, ignored elsewhere): the NEXT mi355_qmatmul_fused call on this
+     * stream reads this call's `out` as its x (k = chain_next_k = ldo, norm_weight = chain_next_norm or NULL).  The
+     * epilogue then also stages that call's activation image, and the next call skips its own staging pass when its
+     * arguments match (it silently stages itself when they do not). */
+    int32_t chain_next, chain_next_k;
+    const float* chain_next_norm;
 } mi355_qmm_desc;
 int mi355_qmatmul_fused(const mi355_qmm_desc* desc, int64_t stream);
 /* MoE routing on the device (MlpOrMoe::forward, quantized_llama.rs:56-123, without the host round trip):

@@ -351,3 +351,39 @@ def test_long_prompt_uses_the_gemm_path_and_matches(lib):
     assert _rel(outs[0], ref) < 3e-3, _rel(outs[0], ref)
     assert _rel(outs[0], outs[1]) < 2e-3
     assert [int(r.argmax()) for r in outs[0]] == [int(r.argmax()) for r in ref]
+
+
+def test_batch12_decode_wide_path_chained_equals_unchained_equals_oracle(lib):
+    """9..32 tokens take the wide path; its epilogues stage the next launch's activation image (chain).  The chained
+    step must be bit-identical to the unchained one (same arithmetic, one staging pass less) and match the oracle."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from candle_vllm_amd import model as M
+    cfg = llama.LlamaConfig.tiny()
+    W = llama.make_weights(cfg, seed=77)
+    orc = llama.OracleLlama(cfg, W, flash_layout=False)
+    rng = np.random.default_rng(11)
+    B = 12
+    seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, int(n))], "block_table": [2 * i + 1, 2 * i + 2]}
+            for i, n in enumerate(rng.integers(3, 2 * cfg.block_size - 4, B))]
+    cache = orc.new_cache(2 * B + 2)
+    lg = orc.forward(O.prepare_prompt(seqs, cfg.block_size), cache, is_prefill=True)
+    for s, row in zip(seqs, lg):
+        s["tokens"].append(int(row.argmax()))
+    gm = M.GGUFLLaMa(cfg, max_batch=B, kv_layout=M.KV_PAGED)
+    gm.load_oracle_weights(W)
+    gm.alloc_kv_cache(2 * B + 2)
+    meta = O.prepare_decode(seqs, cfg.block_size)
+    ref = orc.forward(meta, [(k.copy(), v.copy()) for k, v in cache])
+    outs = {}
+    try:
+        for chain in (1, 0):
+            for l, (kc, vc) in enumerate(cache):
+                gm.kv_upload(l, kc, vc)
+            M.lib.mi355_set_tuning(9, chain)
+            outs[chain] = gm.forward_decode(meta).cpu().numpy()
+    finally:
+        M.lib.mi355_set_tuning(9, 1)
+    assert np.array_equal(outs[1], outs[0])
+    assert _rel(outs[1], ref) < 1e-3, _rel(outs[1], ref)
+    assert [int(r.argmax()) for r in outs[1]] == [int(r.argmax()) for r in ref]
