@@ -382,9 +382,6 @@ template <int BT, int NV, int RR>
 __device__ __forceinline__ void compute3_q6k(const TileRegs* w, const uint8_t* ximg, int lane, float (*y)[NV]) {
     const int m = lane & 15, kg = lane >> 4;
     const uint8_t* abase = ximg + ((size_t)(kg >> 1) * (2 * BT) + a_row_of<BT>(m)) * 16 + (kg & 1) * 8;
-    uint2 aw[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) aw[s] = *reinterpret_cast<const uint2*>(abase + (size_t)s * 2 * (2 * BT) * 16);
     uint32_t bmask = 0x00FF00FFu, n160 = 0xC320C320u;            // bf16 -160.0 twice (code = q + 32, +128)
     asm volatile("" : "+v"(bmask), "+v"(n160));
     const uint2 negw = make_uint2(n160, n160);
@@ -396,6 +393,9 @@ __device__ __forceinline__ void compute3_q6k(const TileRegs* w, const uint8_t* x
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
+        uint2 aw[8];                                                  // A fragments of the 8 sub-blocks of this half
+#pragma unroll
+        for (int s = 0; s < 8; ++s) aw[s] = *reinterpret_cast<const uint2*>(abase + (size_t)(8 * n + s) * 2 * (2 * BT) * 16);
 #pragma unroll
         for (int is = 0; is < 2; ++is) {
             uint32_t t[RR][4];
@@ -412,7 +412,7 @@ __device__ __forceinline__ void compute3_q6k(const TileRegs* w, const uint8_t* x
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 const int s = 8 * n + 2 * tt + is;                    // 16-sub-block index 0..15
-                const s16x4_t af = __builtin_bit_cast(s16x4_t, aw[s]);
+                const s16x4_t af = __builtin_bit_cast(s16x4_t, aw[2 * tt + is]);
                 const f32x4_t cin = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af, __builtin_bit_cast(s16x4_t, negw), zero, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < RR; ++r) {
@@ -659,10 +659,14 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
                             const TileRegs& t = buf[q * R + r];
                             y[r][0] += __uint_as_float((t.a.x ^ t.b.x ^ t.c.x ^ t.d.x ^ t.b.w ^ t.c.w) & 0x3FFFFFu);
                         }
-                    } else if (WT == MI355_GGML_Q4_K) {
-                        compute3_q4k<BT, NV, R>(&buf[q * R], ximg, lane, y);
                     } else {
-                        compute3_q6k<BT, NV, R>(&buf[q * R], ximg, lane, y);
+                        // at most two tiles share C_in / the A fragments: four at once cost 248 VGPRs (2 waves/SIMD)
+                        constexpr int RJ = (R < 2 || (R > 2 && WT == MI355_GGML_Q6_K)) ? 1 : 2;   // Q6_K x 4 tiles (lm_head): one at a time keeps 3 waves/SIMD
+#pragma unroll
+                        for (int r0 = 0; r0 < R; r0 += RJ) {
+                            if (WT == MI355_GGML_Q4_K) compute3_q4k<BT, NV, RJ>(&buf[q * R + r0], ximg, lane, y + r0);
+                            else compute3_q6k<BT, NV, RJ>(&buf[q * R + r0], ximg, lane, y + r0);
+                        }
                     }
                 }
 #pragma unroll
