@@ -459,3 +459,32 @@ def test_moe_route_experts_combine(cv, T):
     assert cv.lib.mi355_moe_combine(ys.data_ptr(), yp.data_ptr(), wts.data_ptr(), T, hid, K, 0, st) == 0
     torch.cuda.synchronize()
     assert rel_err(ys.cpu().numpy(), ref) < 1e-3
+
+
+@pytest.mark.parametrize("bs,ctx", [(64, [4100, 37, 520]), (16, [1000, 259])])
+def test_paged_attention_workgroup_merge_equals_one_wave_per_partition(cv, bs, ctx):
+    """4 partitions per workgroup merged in LDS (few sequences, long contexts) vs one wave per partition: same
+    partition arithmetic, different merge tree -> equal to accumulation noise, both within 1 bf16 ulp of the oracle."""
+    rng = np.random.default_rng(41)
+    H, Hkv, D = 32, 8, 128
+    q, kc, vc, bt, cl = _attn_case(rng, len(ctx), H, Hkv, D, bs, ctx, False)
+    pa = cv.PagedAttention(H, D, 1 / np.sqrt(D), Hkv)
+    meta = cv.InputMetadata(False, dev(np.zeros(len(ctx), np.int64)), dev(bt.astype(np.int32)), dev(cl.astype(np.int32)),
+                            max_context_len=max(ctx))
+    qd, kcd, vcd = dev(q, torch.bfloat16), bf16_dev(kc), bf16_dev(vc)
+    oracle = O.paged_attention_decode(q, kc, vc, bt, cl, 1 / np.sqrt(D), False)
+    tol = 2 ** -7 * np.abs(oracle).max() + 1e-6
+    outs = {}
+    try:
+        for wpb in (1, 4):
+            cv.lib.mi355_set_tuning(8, wpb)
+            for ps in (32, 64):
+                for fused in (0, 2):
+                    cv.lib.mi355_set_tuning(3, fused)
+                    got = pa.decode(qd, kcd, vcd, meta, None, partition_size=ps).float().cpu().numpy()
+                    assert np.abs(got - oracle).max() <= tol, (wpb, ps, fused, np.abs(got - oracle).max())
+                    outs[(wpb, ps, fused)] = got
+    finally:
+        cv.lib.mi355_set_tuning(8, 0)
+        cv.lib.mi355_set_tuning(3, 1)
+    assert np.abs(outs[(4, 32, 0)] - outs[(1, 32, 0)]).max() <= tol
