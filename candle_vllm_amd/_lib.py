@@ -49,6 +49,14 @@ class QmmDesc(ctypes.Structure):
     ]
 
 
+class RopeScaling(ctypes.Structure):
+    """mirror of `mi355_rope_scaling`"""
+    _fields_ = [("type", c_i32), ("factor", ctypes.c_double), ("low_freq_factor", ctypes.c_double),
+                ("high_freq_factor", ctypes.c_double), ("original_max_position_embeddings", ctypes.c_double),
+                ("alpha", ctypes.c_double), ("beta_fast", ctypes.c_double), ("beta_slow", ctypes.c_double),
+                ("attn_factor", ctypes.c_double), ("extrapolation_factor", ctypes.c_double)]
+
+
 def _sig(name, restype, argtypes):
     f = getattr(lib, name)
     f.restype = restype
@@ -205,6 +213,10 @@ _sig("mi355_dense_set_weight", ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_i64])
 _sig("mi355_dense_set_weight_dev", ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_i64])
 _sig("mi355_dense_set_gptq", ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32])
 _sig("mi355_dense_set_comm", ctypes.c_int, [c_vp, c_vp])
+_sig("mi355_dense_set_rope_tables", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32])
+_sig("mi355_llama_set_rope_tables", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32])
+_sig("mi355_rope_table_len", c_i32, [c_vp, c_i32, c_i32])
+_sig("mi355_rope_tables", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, ctypes.c_double, c_vp, c_i32, c_i32])
 _sig("mi355_comm_create", c_vp, [c_vp, c_i32, c_i32])
 _sig("mi355_comm_destroy", None, [c_vp])
 _sig("mi355_comm_all_reduce", ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i64])

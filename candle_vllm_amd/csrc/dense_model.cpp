@@ -143,15 +143,8 @@ void* mi355_dense_create(const mi355_dense_config* cfg) {
     if (m->cfg.rotary_dim <= 0 || m->cfg.rotary_dim > cfg->head_dim) m->cfg.rotary_dim = cfg->head_dim;
     const int D = cfg->head_dim, rot = m->cfg.rotary_dim, half = rot / 2;
     std::vector<float> ct((size_t)cfg->max_seq * half), st((size_t)cfg->max_seq * half);
-    for (int i = 0; i < half; ++i) {                          // rotary_emb.rs:14-48 (dim = rotary_dim)
-        const float inv = (float)(1.0 / pow((double)cfg->rope_theta, (double)(2 * i) / (double)rot));
-        for (int p = 0; p < cfg->max_seq; ++p) {
-            const float th = (float)p * inv;
-            ct[(size_t)p * half + i] = (float)cos((double)th);
-            st[(size_t)p * half + i] = (float)sin((double)th);
-        }
-    }
-    bool ok = hipMalloc((void**)&m->cos_t, ct.size() * 4) == hipSuccess && hipMalloc((void**)&m->sin_t, st.size() * 4) == hipSuccess;
+    const bool tables_ok = mi355_rope_tables(ct.data(), st.data(), rot, cfg->max_seq, (double)cfg->rope_theta, nullptr, cfg->max_seq, 0) == 0;
+    bool ok = tables_ok && hipMalloc((void**)&m->cos_t, ct.size() * 4) == hipSuccess && hipMalloc((void**)&m->sin_t, st.size() * 4) == hipSuccess;
     ok = ok && hipMemcpy(m->cos_t, ct.data(), ct.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(m->sin_t, st.data(), st.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     m->pa_cap_partitions = (cfg->max_seq + 31) / 32 + 1;
@@ -249,6 +242,21 @@ int mi355_dense_set_gptq(void* mp, int32_t layer, int32_t which, const void* qwe
     if (!q.scales) DHIP(hipMalloc((void**)&q.scales, (size_t)(k / g) * ntot * 2));
     DHIP(hipMemcpy2D(q.qw + col0, (size_t)ntot * 4, qweight_host, (size_t)n * 4, (size_t)n * 4, k / 8, hipMemcpyHostToDevice));
     DHIP(hipMemcpy2D(q.scales + col0, (size_t)ntot * 2, scales_host, (size_t)n * 2, (size_t)n * 2, k / g, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int mi355_dense_set_rope_tables(void* mp, const float* cos_host, const float* sin_host, int32_t n_positions) {
+    DModel* m = static_cast<DModel*>(mp);
+    if (!m || !cos_host || !sin_host || n_positions < m->cfg.max_seq) return (int)hipErrorInvalidValue;
+    const size_t bytes = (size_t)n_positions * (m->cfg.rotary_dim / 2) * 4;
+    float *c = nullptr, *s = nullptr;
+    DHIP(hipMalloc((void**)&c, bytes));
+    DHIP(hipMalloc((void**)&s, bytes));
+    DHIP(hipMemcpy(c, cos_host, bytes, hipMemcpyHostToDevice));
+    DHIP(hipMemcpy(s, sin_host, bytes, hipMemcpyHostToDevice));
+    DHIP(hipDeviceSynchronize());
+    (void)hipFree(m->cos_t); (void)hipFree(m->sin_t);
+    m->cos_t = c; m->sin_t = s;
     return 0;
 }
 

@@ -436,14 +436,7 @@ extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
     // RoPE tables (rotary_emb.rs:14-48): inv_freq f32, idx_theta = pos(f32) * inv_freq(f32), cos/sin in f32
     const int half = D / 2;
     std::vector<float> ct((size_t)cfg->max_seq * half), stb((size_t)cfg->max_seq * half);
-    for (int i = 0; i < half; ++i) {
-        const float inv = (float)(1.0 / pow((double)cfg->rope_theta, (double)(2 * i) / (double)D));
-        for (int p = 0; p < cfg->max_seq; ++p) {
-            const float th = (float)p * inv;
-            ct[(size_t)p * half + i] = (float)cos((double)th);
-            stb[(size_t)p * half + i] = (float)sin((double)th);
-        }
-    }
+    if (mi355_rope_tables(ct.data(), stb.data(), D, cfg->max_seq, (double)cfg->rope_theta, nullptr, cfg->max_seq, 0) != 0) ok = false;
     alloc((void**)&m->cos_t, ct.size() * 4);
     alloc((void**)&m->sin_t, stb.size() * 4);
     if (ok) {
@@ -452,6 +445,22 @@ extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
     }
     if (!ok) { mi355_llama_destroy(m); return nullptr; }
     return m;
+}
+
+extern "C" int mi355_llama_set_rope_tables(void* mp, const float* cos_host, const float* sin_host, int32_t n_positions) {
+    Model* m = static_cast<Model*>(mp);
+    if (!m || !cos_host || !sin_host || n_positions < m->cfg.max_seq) return (int)hipErrorInvalidValue;
+    const size_t bytes = (size_t)n_positions * (m->cfg.head_dim / 2) * 4;
+    float *c = nullptr, *s = nullptr;
+    HCHECK(hipMalloc((void**)&c, bytes));
+    HCHECK(hipMalloc((void**)&s, bytes));
+    HCHECK(hipMemcpy(c, cos_host, bytes, hipMemcpyHostToDevice));
+    HCHECK(hipMemcpy(s, sin_host, bytes, hipMemcpyHostToDevice));
+    HCHECK(hipDeviceSynchronize());
+    drop_graph(m);                                                  // captured launches hold the old pointers
+    (void)hipFree(m->cos_t); (void)hipFree(m->sin_t);
+    m->cos_t = c; m->sin_t = s;
+    return 0;
 }
 
 extern "C" void mi355_llama_destroy(void* mp) {

@@ -58,6 +58,11 @@ class DenseLlama:
         _check(lib.mi355_dense_set_comm(self.h, self.comm), "dense_set_comm")
         return bytes(buf)
 
+    def set_rope_tables(self, cos, sin):
+        """replace the default RoPE tables: f32 [n >= max_seq, rotary_dim/2]"""
+        cos, sin = np.ascontiguousarray(cos, np.float32), np.ascontiguousarray(sin, np.float32)
+        _check(lib.mi355_dense_set_rope_tables(self.h, cos.ctypes.data, sin.ctypes.data, cos.shape[0]), "set_rope_tables")
+
     def set_weight(self, layer, name, values_f32):
         """values: f32 numpy, exactly representable in bf16 (checkpoint tensors)"""
         bits = _bf16_bits(values_f32)

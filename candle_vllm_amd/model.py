@@ -194,6 +194,11 @@ class GGUFLLaMa:
         buf = np.ascontiguousarray(t.cpu().numpy())
         _check(lib.mi355_llama_init_comm(self.h, buf.ctypes.data), "init_comm")
 
+    def set_rope_tables(self, cos, sin):
+        """replace the default RoPE tables (e.g. llama3 / yarn scaling built by `ops.rope_tables`): f32 [n >= max_seq, D/2]"""
+        cos, sin = np.ascontiguousarray(cos, np.float32), np.ascontiguousarray(sin, np.float32)
+        _check(lib.mi355_llama_set_rope_tables(self.h, cos.ctypes.data, sin.ctypes.data, cos.shape[0]), "set_rope_tables")
+
     # ------------------------------------------------------------------ measurement
     def dominant_kernel_roofline(self, stream, peak_gbs, reps=3):
         """HIP-event timing of every launch group of the decode step (eager, on the step's own stream, weights of

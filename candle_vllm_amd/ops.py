@@ -531,3 +531,18 @@ class GPTQLinear:
                                      _dev(residual) if residual is not None else None, T, self.n, self.k,
                                      self.group_size, dt, epilogue, _stream()), "gptq_linear")
         return out
+
+
+def rope_tables(rope_theta, rotary_dim, max_seq_len, scaling=None, max_position_embeddings=0):
+    """`ScalingRotaryEmbedding::new` (layers/rotary_emb.rs:107-341): cos, sin f32 [n, rotary_dim/2] built by the
+    library's host code.  scaling: None or a `_lib.RopeScaling`."""
+    import ctypes
+    scp = ctypes.byref(scaling) if scaling is not None else None
+    n = lib.mi355_rope_table_len(scp, max_seq_len, max_position_embeddings)
+    if n <= 0:
+        raise ValueError("unknown rope scaling type")
+    cos = np.empty((n, rotary_dim // 2), np.float32)
+    sin = np.empty_like(cos)
+    _check(lib.mi355_rope_tables(cos.ctypes.data, sin.ctypes.data, rotary_dim, n, float(rope_theta), scp, max_seq_len,
+                                 max_position_embeddings), "rope_tables")
+    return cos, sin

@@ -277,6 +277,24 @@ int mi355_gptq_linear(void* out, const void* x, const void* qweight, const void*
                       int32_t num_tokens, int32_t n, int32_t k, int32_t group_size, int32_t dtype, int32_t epilogue,
                       int64_t stream);
 
+/* RoPE cos/sin table builders (HOST): DefaultRotaryEmbedding::new / ScalingRotaryEmbedding::new
+ * (layers/rotary_emb.rs:14-48,107-341,358-457) in the reference's f32 arithmetic.  Tables are f32
+ * [n_positions, rotary_dim/2].  0 / negative fields of the scaling struct mean "absent" (the reference's defaults). */
+#define MI355_ROPE_DEFAULT 0
+#define MI355_ROPE_LINEAR 1
+#define MI355_ROPE_LLAMA3 2
+#define MI355_ROPE_DYNAMIC 3
+#define MI355_ROPE_YARN 4
+typedef struct mi355_rope_scaling {
+    int32_t type;                                   /* MI355_ROPE_* = rope_scaling["rope_type"]                     */
+    double factor, low_freq_factor, high_freq_factor, original_max_position_embeddings, alpha;
+    double beta_fast, beta_slow, attn_factor, extrapolation_factor;   /* yarn (defaults 32, 1, 1, 1)               */
+} mi355_rope_scaling;
+/* number of positions the reference tabulates for this configuration */
+int32_t mi355_rope_table_len(const mi355_rope_scaling* sc, int32_t max_seq_len, int32_t max_position_embeddings);
+int mi355_rope_tables(float* cos_out_host, float* sin_out_host, int32_t rotary_dim, int32_t n_positions, double rope_theta,
+                      const mi355_rope_scaling* sc /* NULL = default */, int32_t max_seq_len, int32_t max_position_embeddings);
+
 /* ---------------------------------------------------------------------------------------------
  * 4. Host layer: the GGUF llama decode step (GGUFLLaMa::forward + CacheEngine + decode graph), C handles.
  *    Mirrors src/openai/models/quantized_llama.rs:424-506, src/scheduler/cache_engine.rs:122-341,
@@ -349,6 +367,8 @@ float* mi355_llama_logits_ptr(void* model);
  * launcher ships to every rank -> mi355_llama_init_comm on every rank (cudarc Comm::from_rank, pipeline.rs:805-812) */
 int mi355_comm_unique_id(void* out128);
 int mi355_llama_init_comm(void* model, const void* id128);
+/* replace the default RoPE tables (built at create from rope_theta) by scaled ones: HOST f32 [n_positions >= max_seq, head_dim/2] */
+int mi355_llama_set_rope_tables(void* model, const float* cos_host, const float* sin_host, int32_t n_positions);
 /* measurement hook: one launch group of the step on the static inputs (part 0 qkv, 1 attention, 2 wo,
  * 3 gate/up, 4 down, 5 lm_head, 6 embedding) */
 int mi355_llama_run_part(void* model, int32_t layer, int32_t part, int64_t stream);
@@ -395,6 +415,7 @@ int mi355_dense_set_gptq(void* model, int32_t layer, int32_t which, const void* 
 /* tensor parallel (distributed.rs:243-249,492-534,696-711,1632-1667): comm from mi355_comm_create (borrowed);
  * all-reduce of the 16-bit stream after o_proj / down_proj, vocab-parallel lm_head + all-gather */
 int mi355_dense_set_comm(void* model, void* comm);
+int mi355_dense_set_rope_tables(void* model, const float* cos_host, const float* sin_host, int32_t n_positions);   /* [n, rotary_dim/2] */
 int mi355_dense_alloc_kv_cache(void* model, int32_t num_blocks);
 void* mi355_dense_kv_ptr(void* model, int32_t layer, int32_t which);
 /* one step: prompt when cu_seqlens_q != NULL (flattened tokens), else decode (num_tokens == num_seqs);

@@ -49,12 +49,93 @@ def silu_mul(gate, up):
 # --------------------------------------------------------------------------- RoPE
 def rope_tables(rope_theta, rotary_dim, max_seq_len):
     """cos/sin [max_seq, rotary_dim/2] f32 -- src/openai/models/layers/rotary_emb.rs:14-48.
-    inv_freq[i] = (1 / theta^(2i/dim)) as f32 ; idx_theta = pos (f32) * inv_freq (f32 matmul)."""
-    i = np.arange(0, rotary_dim, 2, dtype=np.float64)
-    inv_freq = (1.0 / np.power(float(rope_theta), i / rotary_dim)).astype(np.float32)
+    inv_freq[i] = 1f32 / (theta^(2i/dim) as f32) ; idx_theta = pos (f32) * inv_freq (f32 matmul)."""
+    inv_freq = _default_inv_freq(rope_theta, rotary_dim)          # 1f32 / (pow(...) as f32): the reciprocal is an f32 op
     pos = np.arange(max_seq_len, dtype=np.float32)[:, None]
     idx_theta = (pos * inv_freq[None, :]).astype(np.float32)
     return np.cos(idx_theta).astype(np.float32), np.sin(idx_theta).astype(np.float32)
+
+
+def _default_inv_freq(base, dim):
+    """calculate_default_inv_freq (rotary_emb.rs:14-19): base^(i/dim) in f64, reciprocal in f32"""
+    i = np.arange(0, dim, 2, dtype=np.float64)
+    return (np.float32(1.0) / np.power(float(base), i / dim).astype(np.float32)).astype(np.float32)
+
+
+def rope_tables_scaled(rope_theta, rotary_dim, max_seq_len, scaling=None, max_position_embeddings=0):
+    """ScalingRotaryEmbedding::new (rotary_emb.rs:107-341, yarn :358-457): cos/sin f32 [n, rotary_dim/2].
+    scaling: None or dict with rope_type in {default, linear, llama3, dynamic, yarn} and the reference's keys."""
+    f32 = np.float32
+    sc = dict(scaling or {})
+    rtype = sc.get("rope_type", sc.get("type", "default"))
+    if scaling is None or rtype == "default":
+        return rope_tables(rope_theta, rotary_dim, max_seq_len)
+    if "original_max_position_embeddings" in sc:
+        orig = float(sc["original_max_position_embeddings"])
+    elif "factor" in sc and max_position_embeddings:
+        orig = float(max_position_embeddings) / float(sc["factor"])
+    else:
+        orig = float(max_position_embeddings or max_seq_len)
+
+    def tables(inv_freq, n, pos_div=None, mscale=None):
+        t = np.arange(n, dtype=f32)
+        if pos_div is not None:
+            t = (t.astype(np.float64) / float(pos_div)).astype(f32)          # f32 tensor / f64 scalar
+        th = (t[:, None] * inv_freq[None, :]).astype(f32)
+        c, s = np.cos(th).astype(f32), np.sin(th).astype(f32)
+        if mscale is not None:
+            c, s = (c.astype(np.float64) * mscale).astype(f32), (s.astype(np.float64) * mscale).astype(f32)
+        return c, s
+
+    if rtype == "linear":                                                       # :138-167
+        factor = float(sc["factor"])
+        return tables(_default_inv_freq(rope_theta, rotary_dim), int(orig * factor), pos_div=factor)
+    if rtype == "llama3":                                                       # :168-224
+        factor, lo, hi = f32(sc["factor"]), float(sc["low_freq_factor"]), float(sc["high_freq_factor"])
+        low_wl, high_wl = f32(orig / lo), f32(orig / hi)
+        out = []
+        for freq in _default_inv_freq(rope_theta, rotary_dim):
+            wavelen = f32(2.0) * f32(np.pi) / freq
+            if wavelen < high_wl:
+                out.append(freq)
+            elif wavelen > low_wl:
+                out.append(f32(freq / factor))
+            else:
+                smooth = f32((f32(orig) / wavelen - f32(lo)) / f32(hi - lo))
+                out.append(f32(f32((f32(1.0) - smooth) * freq) / factor + smooth * freq))
+        return tables(np.asarray(out, f32), max_seq_len)
+    if rtype == "dynamic":                                                      # :227-277
+        if "alpha" in sc:
+            s_ = float(sc["alpha"])
+            n = int(max_position_embeddings)
+            theta = (rope_theta * s_) ** (rotary_dim / (rotary_dim - 2))
+        else:
+            s_ = float(sc["factor"])
+            n = int(orig * s_)
+            theta = (rope_theta * ((s_ * n / orig) - (s_ - 1.0))) ** (rotary_dim / (rotary_dim - 2))
+        return tables(_default_inv_freq(theta, rotary_dim), n)
+    if rtype == "yarn":                                                         # :278-320, :400-457
+        factor = f32(sc["factor"])
+        beta_fast, beta_slow = f32(sc.get("beta_fast", 32.0)), f32(sc.get("beta_slow", 1.0))
+        attn_factor, extrap = f32(sc.get("attn_factor", 1.0)), f32(sc.get("extrapolation_factor", 1.0))
+        base, dim = f32(rope_theta), rotary_dim
+
+        def corr(num_rot):
+            return f32(f32(dim) * np.log(f32(f32(int(orig)) / f32(num_rot * f32(2.0) * f32(np.pi))))) / f32(f32(2.0) * np.log(base))
+        low, high = max(np.floor(corr(beta_fast)), f32(0.0)), min(np.ceil(corr(beta_slow)), f32(dim - 1))
+        if low == high:
+            high = f32(high + f32(0.001))
+        k = np.arange(dim // 2, dtype=f32)
+        pw = np.power(base, (2 * k / f32(dim)).astype(f32)).astype(f32)
+        extra, inter = (f32(1.0) / pw).astype(f32), (f32(1.0) / (factor * pw).astype(f32)).astype(f32)
+        ramp = ((k.astype(np.float64) - float(low)).astype(f32).astype(np.float64) / (float(high) - float(low))).astype(f32)
+        ramp = np.clip(ramp, f32(0.0), f32(1.0))
+        mask = ((1.0 - ramp.astype(np.float64)).astype(f32).astype(np.float64) * float(extrap)).astype(f32)
+        inv = (inter * (1.0 - mask.astype(np.float64)).astype(f32) + extra * mask).astype(f32)
+        mp = int(max_position_embeddings or max_seq_len)
+        mscale = (f32(1.0) if factor <= 1 else f32(f32(0.1) * np.log(factor) + f32(1.0))) * attn_factor
+        return tables(inv, int(f32(mp) * factor), mscale=float(mscale))
+    raise ValueError(f"Unknown rope_type: {rtype}")
 
 
 def rope_apply(x, cos, sin, positions, interleaved, rotary_dim=None):

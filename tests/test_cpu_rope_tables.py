@@ -1,0 +1,63 @@
+"""RoPE table builders (host C++ behind the C ABI) vs the numpy restatement of the reference's
+ScalingRotaryEmbedding::new (src/openai/models/layers/rotary_emb.rs:107-341,358-457).  No GPU."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import ops as O
+
+CASES = [
+    ("default", None, dict(theta=5e5, dim=128, max_seq=512, mpe=0)),
+    ("llama3.1", {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                  "original_max_position_embeddings": 8192}, dict(theta=5e5, dim=128, max_seq=700, mpe=131072)),
+    ("linear", {"type": "linear", "factor": 4.0}, dict(theta=1e4, dim=64, max_seq=300, mpe=512)),
+    ("dynamic-alpha", {"rope_type": "dynamic", "alpha": 2.5}, dict(theta=1e4, dim=128, max_seq=256, mpe=384)),
+    ("dynamic-factor", {"rope_type": "dynamic", "factor": 2.0, "original_max_position_embeddings": 128},
+     dict(theta=1e4, dim=96, max_seq=256, mpe=256)),
+    ("yarn", {"rope_type": "yarn", "factor": 4.0, "original_max_position_embeddings": 256, "beta_fast": 32.0,
+              "beta_slow": 1.0}, dict(theta=1e4, dim=128, max_seq=256, mpe=256)),
+    ("partial-rotary", None, dict(theta=1e4, dim=20, max_seq=128, mpe=0)),
+]
+TYPES = {"default": 0, "linear": 1, "llama3": 2, "dynamic": 3, "yarn": 4}
+
+
+@pytest.mark.parametrize("name,scaling,kw", CASES, ids=[c[0] for c in CASES])
+def test_rope_tables_match_the_reference_restatement(name, scaling, kw):
+    import __graft_entry__ as ge
+    ge.build()
+    from candle_vllm_amd._lib import lib, RopeScaling
+    ref_c, ref_s = O.rope_tables_scaled(kw["theta"], kw["dim"], kw["max_seq"], scaling, kw["mpe"])
+    sc = None
+    if scaling is not None:
+        sc = RopeScaling()
+        sc.type = TYPES[scaling.get("rope_type", scaling.get("type"))]
+        for k in ("factor", "low_freq_factor", "high_freq_factor", "original_max_position_embeddings", "alpha",
+                  "beta_fast", "beta_slow", "attn_factor", "extrapolation_factor"):
+            setattr(sc, k, float(scaling.get(k, 0.0)))
+    scp = ctypes.byref(sc) if sc is not None else None
+    n = lib.mi355_rope_table_len(scp, kw["max_seq"], kw["mpe"])
+    assert n == ref_c.shape[0], (n, ref_c.shape)
+    cos = np.empty((n, kw["dim"] // 2), np.float32)
+    sin = np.empty_like(cos)
+    assert lib.mi355_rope_tables(cos.ctypes.data, sin.ctypes.data, kw["dim"], n, kw["theta"], scp, kw["max_seq"], kw["mpe"]) == 0
+    # same formulas in f32; powf / cosf of two math libraries may differ by 1 ulp, and 1 ulp of an inverse frequency is
+    # an angle error of position * 2^-24 at the highest frequencies
+    tol = max(4e-7, 1.2e-7 * n) * max(1.0, float(np.abs(ref_c).max()))
+    assert np.abs(cos - ref_c).max() <= tol and np.abs(sin - ref_s).max() <= tol, (np.abs(cos - ref_c).max(), np.abs(sin - ref_s).max())
+    if name == "llama3.1":                                            # the scaling actually changed the low frequencies
+        d_c, _ = O.rope_tables(kw["theta"], kw["dim"], kw["max_seq"])
+        assert np.abs(d_c - ref_c).max() > 1e-2 and np.array_equal(d_c[:, :8], ref_c[:, :8])
+
+
+def test_bad_arguments_are_rejected():
+    import __graft_entry__ as ge
+    ge.build()
+    from candle_vllm_amd._lib import lib, RopeScaling
+    buf = np.empty((4, 4), np.float32)
+    sc = RopeScaling()
+    sc.type = 2                                                       # llama3 without its factors
+    assert lib.mi355_rope_tables(buf.ctypes.data, buf.ctypes.data, 8, 4, 1e4, ctypes.byref(sc), 4, 0) != 0
+    assert lib.mi355_rope_tables(buf.ctypes.data, buf.ctypes.data, 7, 4, 1e4, None, 4, 0) != 0      # odd rotary dim
+    sc.type = 9
+    assert lib.mi355_rope_table_len(ctypes.byref(sc), 4, 0) == -1

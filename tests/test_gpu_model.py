@@ -387,3 +387,29 @@ def test_batch12_decode_wide_path_chained_equals_unchained_equals_oracle(lib):
     assert np.array_equal(outs[1], outs[0])
     assert _rel(outs[1], ref) < 1e-3, _rel(outs[1], ref)
     assert [int(r.argmax()) for r in outs[1]] == [int(r.argmax()) for r in ref]
+
+
+def test_llama3_rope_scaling_tables_through_the_model(lib):
+    """Llama-3.1-style rope_scaling: the host builds the scaled tables (mi355_rope_tables), the model swaps them in;
+    decode logits must match the oracle run with the numpy restatement of the same tables -- and differ from the
+    unscaled model (the scaling is really applied)."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from candle_vllm_amd import model as M, ops as cvo
+    from candle_vllm_amd._lib import RopeScaling
+    cfg, orc, gm, seqs, cache = _setup(lib, False)
+    meta = O.prepare_decode(seqs, cfg.block_size)
+    base = gm.forward_decode(meta).cpu().numpy()
+    scaling = {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+               "original_max_position_embeddings": 16}
+    sc = RopeScaling()
+    sc.type, sc.factor, sc.low_freq_factor, sc.high_freq_factor, sc.original_max_position_embeddings = 2, 8.0, 1.0, 4.0, 16.0
+    cos, sin = cvo.rope_tables(cfg.rope_theta, cfg.head_dim, cfg.max_seq, sc)
+    orc.cos, orc.sin = O.rope_tables_scaled(cfg.rope_theta, cfg.head_dim, cfg.max_seq, scaling)
+    for l, (kc, vc) in enumerate(cache):
+        gm.kv_upload(l, kc, vc)
+    gm.set_rope_tables(cos, sin)
+    ref = orc.forward(meta, [(k.copy(), v.copy()) for k, v in cache])
+    got = gm.forward_decode(meta).cpu().numpy()
+    assert _rel(got, ref) < 1e-3, _rel(got, ref)
+    assert _rel(got, base) > 1e-3                                   # not the default tables
