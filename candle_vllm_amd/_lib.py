@@ -218,6 +218,10 @@ _sig("mi355_llama_set_rope_tables", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32])
 _sig("mi355_rope_table_len", c_i32, [c_vp, c_i32, c_i32])
 _sig("mi355_rope_tables", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, ctypes.c_double, c_vp, c_i32, c_i32])
 _sig("mi355_comm_create", c_vp, [c_vp, c_i32, c_i32])
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, c_vp, c_vp, c_i64, c_i32, c_i64)
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, c_vp, c_vp, c_vp, c_i64, c_i32, c_i64)
+_sig("mi355_comm_create_external", c_vp, [ALLREDUCE_FN, ALLGATHER_FN, c_vp])
+_sig("mi355_llama_set_comm", ctypes.c_int, [c_vp, c_vp])
 _sig("mi355_comm_destroy", None, [c_vp])
 _sig("mi355_comm_all_reduce", ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i64])
 _sig("mi355_comm_all_gather", ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64])

@@ -75,6 +75,31 @@ bool rccl_load() {
 }
 enum { NCCL_FLOAT32 = 7, NCCL_SUM = 0 };
 
+// What every mi355_comm_* handle points to: an RCCL communicator created here, or collectives supplied by the host
+// (the reference's Rust side owns its nccl `Comm`; a host that already has one -- or a test running two ranks on one
+// GPU over gloo -- plugs its own all-reduce / all-gather in instead of handing us a second communicator).
+struct Comm {
+    void* nccl = nullptr;
+    mi355_allreduce_fn ar = nullptr;
+    mi355_allgather_fn ag = nullptr;
+    void* user = nullptr;
+};
+int nccl_dtype_of(int dt) { return dt == MI355_DTYPE_F32 ? 7 : (dt == MI355_DTYPE_F16 ? 6 : (dt == MI355_DTYPE_BF16 ? 9 : -1)); }
+int comm_all_reduce(Comm* c, void* buf, int64_t count, int dtype, int64_t stream) {
+    if (!c) return (int)hipErrorNotInitialized;
+    if (c->ar) return c->ar(c->user, buf, count, dtype, stream);
+    const int dt = nccl_dtype_of(dtype);
+    if (!c->nccl || dt < 0) return (int)hipErrorInvalidValue;
+    return g_rccl.all_reduce(buf, buf, (size_t)count, dt, NCCL_SUM, c->nccl, reinterpret_cast<hipStream_t>(stream)) == 0 ? 0 : (int)hipErrorUnknown;
+}
+int comm_all_gather(Comm* c, const void* send, void* recv, int64_t count, int dtype, int64_t stream) {
+    if (!c) return (int)hipErrorNotInitialized;
+    if (c->ag) return c->ag(c->user, send, recv, count, dtype, stream);
+    const int dt = nccl_dtype_of(dtype);
+    if (!c->nccl || dt < 0) return (int)hipErrorInvalidValue;
+    return g_rccl.all_gather(send, recv, (size_t)count, dt, c->nccl, reinterpret_cast<hipStream_t>(stream)) == 0 ? 0 : (int)hipErrorUnknown;
+}
+
 struct QW {
     void* tiles = nullptr;
     int type = 0, n_rows = 0, k = 0;
@@ -125,7 +150,8 @@ struct Model {
     int w_batch = 0, w_max_blocks = 0, w_ctx_cap = 0;     // shape of the last EAGER step (kernel attrs warmed)
     bool use_graph = true;
     // tensor parallel
-    void* comm = nullptr;           // ncclComm_t
+    Comm* comm = nullptr;           // mi355_comm_* handle (owned when created by mi355_llama_init_comm)
+    bool comm_owned = false;
     bool use_comm = false;          // tp_world > 1, or forced (single-rank plumbing test: MI355_FORCE_COMM=1)
     float* logits_local = nullptr;  // [B, vocab/W]
     float* logits_gather = nullptr; // [W, B, vocab/W]
@@ -203,8 +229,7 @@ int all_reduce_xs(Model* m, float* xs, int B, int64_t st) {
     // C1/C2: all-reduce(sum) of [B, hidden] after o_proj / down_proj (distributed.rs:696-711).  The reference
     // sends bf16 (attention.rs:1005-1009); we keep the f32 residual stream on the wire (decode messages are
     // latency-bound: 16 KiB at B=1).
-    return g_rccl.all_reduce(xs, xs, (size_t)B * m->cfg.hidden, NCCL_FLOAT32, NCCL_SUM, m->comm,
-                             reinterpret_cast<hipStream_t>(st)) == 0 ? 0 : (int)hipErrorUnknown;
+    return comm_all_reduce(m->comm, xs, (int64_t)B * m->cfg.hidden, MI355_DTYPE_F32, st);
 }
 
 enum { PART_QKV = 0, PART_ATTN = 1, PART_WO = 2, PART_GATEUP = 3, PART_DOWN = 4, PART_HEAD = 5, PART_EMBED = 6 };
@@ -229,8 +254,7 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
         RCHECK(mi355_qmatmul_fused(&d, st));
         if (!m->comm) return (int)hipErrorNotInitialized;
         const size_t cnt = (size_t)B * m->output.n_rows;
-        if (g_rccl.all_gather(m->logits_local, m->logits_gather, cnt, NCCL_FLOAT32, m->comm,
-                              reinterpret_cast<hipStream_t>(st)) != 0) return (int)hipErrorUnknown;
+        RCHECK(comm_all_gather(m->comm, m->logits_local, m->logits_gather, (int64_t)cnt, MI355_DTYPE_F32, st));
         hipLaunchKernelGGL(gather_transpose_kernel, dim3(512), dim3(256), 0, reinterpret_cast<hipStream_t>(st), logits,
                            m->logits_gather, c.tp_world, B, m->output.n_rows);
         return (int)hipGetLastError();
@@ -479,7 +503,7 @@ extern "C" void mi355_llama_destroy(void* mp) {
                     m->pa_tmp, m->pa_max, m->pa_sum, m->kv_slab, m->d_tokens, m->d_positions, m->d_slots,
                     m->d_ctx, m->d_bt, m->logits_local, m->logits_gather, m->p_xs, m->p_q, m->p_attn, m->p_h,
                     m->moe_ids, m->moe_w, m->moe_y, m->p_moe_ids, m->p_moe_w, m->p_moe_y};
-    if (m->comm && g_rccl.destroy) (void)g_rccl.destroy(m->comm);
+    if (m->comm && m->comm_owned) mi355_comm_destroy(m->comm);
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete m;
 }
@@ -696,7 +720,8 @@ static int record_step(Model* m, int64_t stream) {
                           m->cur_ctx_cap, m->logits, stream));
     // greedy sample, then prepare the next step's inputs on the device
     uint32_t* next = reinterpret_cast<uint32_t*>(m->q);   // scratch: q is dead after the last layer
-    RCHECK(mi355_argmax_f32(next, m->logits, B, m->output.n_rows, stream));
+    // under TP the lm_head holds vocab / world rows; the gathered logits row is world x that
+    RCHECK(mi355_argmax_f32(next, m->logits, B, m->output.n_rows * (m->use_comm ? m->cfg.tp_world : 1), stream));
     hipLaunchKernelGGL(advance_kernel, dim3((B + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
                        m->d_tokens, next, m->d_positions, m->d_slots, m->d_ctx, m->d_bt, m->cur_max_blocks,
                        m->cfg.block_size, B);
@@ -880,32 +905,54 @@ extern "C" int mi355_comm_unique_id(void* out128) {
 extern "C" int mi355_llama_init_comm(void* mp, const void* id128) {
     Model* m = static_cast<Model*>(mp);
     if (!m || !id128) return (int)hipErrorInvalidValue;
-    if (!rccl_load()) return (int)hipErrorSharedObjectInitFailed;
-    NcclId id;
-    memcpy(&id, id128, sizeof(id));
-    return g_rccl.init_rank(&m->comm, m->cfg.tp_world, id, m->cfg.tp_rank) == 0 ? 0 : (int)hipErrorUnknown;
+    void* c = mi355_comm_create(id128, m->cfg.tp_rank, m->cfg.tp_world);
+    if (!c) return (int)hipErrorSharedObjectInitFailed;
+    if (m->comm && m->comm_owned) mi355_comm_destroy(m->comm);
+    m->comm = static_cast<Comm*>(c);
+    m->comm_owned = true;
+    return 0;
+}
+// attach a communicator the caller owns (mi355_comm_create / mi355_comm_create_external)
+extern "C" int mi355_llama_set_comm(void* mp, void* comm) {
+    Model* m = static_cast<Model*>(mp);
+    if (!m) return (int)hipErrorInvalidValue;
+    if (m->comm && m->comm_owned) mi355_comm_destroy(m->comm);
+    m->comm = static_cast<Comm*>(comm);
+    m->comm_owned = false;
+    return 0;
 }
 
-// ---- generic communicator handle (the reference's `Comm`, one per process: pipeline.rs:805-812) for the other host
-// layers: create from the 128-byte unique id, in-stream all-reduce(sum) / all-gather, dtype = MI355_DTYPE_F32 / BF16 / F16
-static int nccl_dtype_of(int dt) { return dt == MI355_DTYPE_F32 ? 7 : (dt == MI355_DTYPE_F16 ? 6 : (dt == MI355_DTYPE_BF16 ? 9 : -1)); }
+// ---- generic communicator handle (the reference's `Comm`, one per process: pipeline.rs:805-812) for the host layers:
+// create from the 128-byte unique id, in-stream all-reduce(sum) / all-gather, dtype = MI355_DTYPE_F32 / BF16 / F16
 extern "C" void* mi355_comm_create(const void* id128, int32_t rank, int32_t world) {
     if (!id128 || world < 1 || rank < 0 || rank >= world || !rccl_load()) return nullptr;
     NcclId id;
     memcpy(&id, id128, sizeof(id));
-    void* comm = nullptr;
-    return g_rccl.init_rank(&comm, world, id, rank) == 0 ? comm : nullptr;
+    void* nccl = nullptr;
+    if (g_rccl.init_rank(&nccl, world, id, rank) != 0) return nullptr;
+    Comm* c = new Comm();
+    c->nccl = nccl;
+    return c;
 }
-extern "C" void mi355_comm_destroy(void* comm) { if (comm && g_rccl.destroy) (void)g_rccl.destroy(comm); }
+extern "C" void* mi355_comm_create_external(mi355_allreduce_fn all_reduce, mi355_allgather_fn all_gather, void* user) {
+    if (!all_reduce || !all_gather) return nullptr;
+    Comm* c = new Comm();
+    c->ar = all_reduce; c->ag = all_gather; c->user = user;
+    return c;
+}
+extern "C" void mi355_comm_destroy(void* comm) {
+    Comm* c = static_cast<Comm*>(comm);
+    if (!c) return;
+    if (c->nccl && g_rccl.destroy) (void)g_rccl.destroy(c->nccl);
+    delete c;
+}
 extern "C" int mi355_comm_all_reduce(void* comm, void* buf, int64_t count, int32_t dtype, int64_t stream) {
-    const int dt = nccl_dtype_of(dtype);
-    if (!comm || dt < 0) return (int)hipErrorInvalidValue;
-    return g_rccl.all_reduce(buf, buf, (size_t)count, dt, NCCL_SUM, comm, reinterpret_cast<hipStream_t>(stream)) == 0 ? 0 : (int)hipErrorUnknown;
+    if (!comm || nccl_dtype_of(dtype) < 0) return (int)hipErrorInvalidValue;
+    return comm_all_reduce(static_cast<Comm*>(comm), buf, count, dtype, stream);
 }
 extern "C" int mi355_comm_all_gather(void* comm, const void* send, void* recv, int64_t count, int32_t dtype, int64_t stream) {
-    const int dt = nccl_dtype_of(dtype);
-    if (!comm || dt < 0) return (int)hipErrorInvalidValue;
-    return g_rccl.all_gather(send, recv, (size_t)count, dt, comm, reinterpret_cast<hipStream_t>(stream)) == 0 ? 0 : (int)hipErrorUnknown;
+    if (!comm || nccl_dtype_of(dtype) < 0) return (int)hipErrorInvalidValue;
+    return comm_all_gather(static_cast<Comm*>(comm), send, recv, count, dtype, stream);
 }
 
 // ---- per-part launch for measurement: runs launch group `part` of layer `layer` on the static step inputs

@@ -58,6 +58,11 @@ class DenseLlama:
         _check(lib.mi355_dense_set_comm(self.h, self.comm), "dense_set_comm")
         return bytes(buf)
 
+    def set_comm(self, handle):
+        """attach a communicator the caller owns (mi355_comm_create / tp.TorchDistComm().handle); not destroyed here"""
+        _check(lib.mi355_dense_set_comm(self.h, handle), "dense_set_comm")
+        self.comm_borrowed = handle
+
     def set_rope_tables(self, cos, sin):
         """replace the default RoPE tables: f32 [n >= max_seq, rotary_dim/2]"""
         cos, sin = np.ascontiguousarray(cos, np.float32), np.ascontiguousarray(sin, np.float32)
@@ -165,7 +170,8 @@ class DenseLlama:
         cu = None
         if is_prefill:
             cu = torch.from_numpy(np.asarray(meta["cu_seqlens_q"]).astype(np.int64).astype(np.int32)).to(dev)
-        logits = torch.empty((n, self.cfg.vocab * (self.tp_world if self.comm else 1)), dtype=torch.float32, device=dev)
+        logits = torch.empty((n, self.cfg.vocab * (self.tp_world if (self.comm or getattr(self, 'comm_borrowed', None)) else 1)),
+                             dtype=torch.float32, device=dev)
         st = torch.cuda.current_stream().cuda_stream if stream is None else stream
         _check(lib.mi355_dense_forward(self.h, tok.data_ptr(), pos.data_ptr(), slots.data_ptr(), bt.data_ptr(),
                                        ctx.data_ptr(), cu.data_ptr() if cu is not None else None, n, T,

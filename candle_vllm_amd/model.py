@@ -194,6 +194,10 @@ class GGUFLLaMa:
         buf = np.ascontiguousarray(t.cpu().numpy())
         _check(lib.mi355_llama_init_comm(self.h, buf.ctypes.data), "init_comm")
 
+    def set_comm(self, handle):
+        """attach a communicator the caller owns (mi355_comm_create / tp.TorchDistComm().handle)"""
+        _check(lib.mi355_llama_set_comm(self.h, handle), "set_comm")
+
     def set_rope_tables(self, cos, sin):
         """replace the default RoPE tables (e.g. llama3 / yarn scaling built by `ops.rope_tables`): f32 [n >= max_seq, D/2]"""
         cos, sin = np.ascontiguousarray(cos, np.float32), np.ascontiguousarray(sin, np.float32)

@@ -21,6 +21,17 @@ def kv_head_shard(total_kv_heads, rank, world):
     return 1, rank // (world // total_kv_heads), total_kv_heads
 
 
+VOCAB_PADDING_SIZE = 64
+
+
+def pad_vocab_size(vocab_size, world_size):
+    """distributed.rs:1446-1452: the vocabulary a vocab-parallel lm_head is padded to (zero rows; the gathered logits
+    are narrowed back to vocab_size, :1661-1664).  Every BASELINE model's vocabulary is already a fixed point."""
+    padded = (vocab_size + VOCAB_PADDING_SIZE - 1) // VOCAB_PADDING_SIZE * VOCAB_PADDING_SIZE
+    per_rank = (padded + world_size - 1) // world_size * world_size
+    return (per_rank + VOCAB_PADDING_SIZE - 1) // VOCAB_PADDING_SIZE * VOCAB_PADDING_SIZE
+
+
 def _rows(tw, rank, world):
     t, b = tw
     n = b.shape[0]
@@ -133,3 +144,82 @@ def shard_dense_weights(W, cfg, rank, world):
             nl["bv"] = _dense_out(lw["bv"], kv_rank, kv_world)
         out["layers"].append(nl)
     return out
+
+
+# ---- host-supplied collectives (mi355_comm_create_external) over torch.distributed ---------------------------------
+class TorchDistComm:
+    """A communicator whose all-reduce / all-gather are done by the HOST through a torch.distributed process group --
+    what a host that already owns its communicator plugs in instead of a second RCCL one.  With the gloo backend the
+    payload is staged through host memory, which lets two ranks share ONE GPU: the multi-rank host logic of the
+    library (shard shapes, residual placement, vocab-parallel gather) then runs on a single-GPU box."""
+
+    _ESIZE = {0: 4, 1: 2, 2: 2}                      # MI355_DTYPE_F32 / F16 / BF16
+
+    def __init__(self, group=None):
+        import ctypes
+        import torch
+        import torch.distributed as dist
+        from ._lib import lib, ALLREDUCE_FN, ALLGATHER_FN
+        self._torch, self._dist, self._group = torch, dist, group
+        self._hip = ctypes.cdll.LoadLibrary("libamdhip64.so")
+        self._ar = ALLREDUCE_FN(self._all_reduce)      # keep the callbacks alive as long as the handle
+        self._ag = ALLGATHER_FN(self._all_gather)
+        self.handle = lib.mi355_comm_create_external(self._ar, self._ag, None)
+        if not self.handle:
+            raise RuntimeError("mi355_comm_create_external failed")
+
+    def _d2h(self, ptr, nbytes):
+        import ctypes
+        host = np.empty(nbytes, np.uint8)
+        self._torch.cuda.synchronize()
+        if self._hip.hipMemcpy(ctypes.c_void_p(host.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(nbytes), 2) != 0:
+            raise RuntimeError("hipMemcpy D2H failed")
+        return host
+
+    def _h2d(self, ptr, host):
+        import ctypes
+        if self._hip.hipMemcpy(ctypes.c_void_p(ptr), ctypes.c_void_p(host.ctypes.data), ctypes.c_size_t(host.nbytes), 1) != 0:
+            raise RuntimeError("hipMemcpy H2D failed")
+
+    @staticmethod
+    def _to_f32(raw, dtype):
+        if dtype == 0:
+            return raw.view(np.float32).copy()
+        if dtype == 1:
+            return raw.view(np.float16).astype(np.float32)
+        return (raw.view(np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+    @staticmethod
+    def _from_f32(vals, dtype):
+        if dtype == 0:
+            return vals.astype(np.float32).view(np.uint8)
+        if dtype == 1:
+            return vals.astype(np.float16).view(np.uint8)
+        u = np.ascontiguousarray(vals, np.float32).view(np.uint32)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16).view(np.uint8)      # RNE, as the device sum rounds
+
+    def _all_reduce(self, user, buf, count, dtype, stream):
+        try:
+            vals = self._to_f32(self._d2h(buf, count * self._ESIZE[dtype]), dtype)
+            t = self._torch.from_numpy(vals)
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
+            self._h2d(buf, np.ascontiguousarray(self._from_f32(t.numpy(), dtype)))
+            return 0
+        except Exception:                             # never unwind through the C frames
+            return 999
+
+    def _all_gather(self, user, send, recv, count, dtype, stream):
+        try:
+            raw = self._torch.from_numpy(self._d2h(send, count * self._ESIZE[dtype]))
+            outs = [self._torch.empty_like(raw) for _ in range(self._dist.get_world_size(self._group))]
+            self._dist.all_gather(outs, raw, group=self._group)
+            self._h2d(recv, np.ascontiguousarray(np.concatenate([o.numpy() for o in outs])))
+            return 0
+        except Exception:
+            return 999
+
+    def close(self):
+        from ._lib import lib
+        if self.handle:
+            lib.mi355_comm_destroy(self.handle)
+            self.handle = None

@@ -367,6 +367,7 @@ float* mi355_llama_logits_ptr(void* model);
  * launcher ships to every rank -> mi355_llama_init_comm on every rank (cudarc Comm::from_rank, pipeline.rs:805-812) */
 int mi355_comm_unique_id(void* out128);
 int mi355_llama_init_comm(void* model, const void* id128);
+int mi355_llama_set_comm(void* model, void* comm);          /* borrowed mi355_comm_* handle instead of init_comm */
 /* replace the default RoPE tables (built at create from rope_theta) by scaled ones: HOST f32 [n_positions >= max_seq, head_dim/2] */
 int mi355_llama_set_rope_tables(void* model, const float* cos_host, const float* sin_host, int32_t n_positions);
 /* measurement hook: one launch group of the step on the static inputs (part 0 qkv, 1 attention, 2 wo,
@@ -376,6 +377,11 @@ int mi355_llama_run_part(void* model, int32_t layer, int32_t part, int64_t strea
 /* generic communicator (the reference's per-process nccl `Comm`, pipeline.rs:805-812; collectives of
  * distributed.rs:547-654,1335-1446): RCCL bound by dlopen; id128 from mi355_comm_unique_id on rank 0 */
 void* mi355_comm_create(const void* id128, int32_t rank, int32_t world);
+/* ... or collectives the HOST supplies (it already owns a communicator, as the reference's Rust side does: both run in
+ * stream order on `stream`; all_reduce is sum, in place; dtype = MI355_DTYPE_*; return 0 on success) */
+typedef int (*mi355_allreduce_fn)(void* user, void* buf, int64_t count, int32_t dtype, int64_t stream);
+typedef int (*mi355_allgather_fn)(void* user, const void* send, void* recv, int64_t count_per_rank, int32_t dtype, int64_t stream);
+void* mi355_comm_create_external(mi355_allreduce_fn all_reduce, mi355_allgather_fn all_gather, void* user);
 void mi355_comm_destroy(void* comm);
 int mi355_comm_all_reduce(void* comm, void* buf, int64_t count, int32_t dtype, int64_t stream);   /* sum, in place */
 int mi355_comm_all_gather(void* comm, const void* send, void* recv, int64_t count, int32_t dtype, int64_t stream);

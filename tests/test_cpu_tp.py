@@ -187,3 +187,11 @@ def test_dense_shard_plan_gptq_shapes():
     assert np.array_equal(np.concatenate([l0["w1"]["qweight"], l1["w1"]["qweight"]], 1), W["layers"][0]["w1"]["qweight"])
     with pytest.raises(ValueError):
         tp.shard_dense_weights(W, cfg, 0, 4)          # 256/4 = 64 rows < group 128
+
+
+def test_pad_vocab_size_formula():
+    from candle_vllm_amd import tp
+    # BASELINE vocabularies are fixed points for their TP degrees (no padded rows to add)
+    assert tp.pad_vocab_size(128256, 8) == 128256 and tp.pad_vocab_size(152064, 2) == 152064 and tp.pad_vocab_size(32000, 8) == 32000
+    assert tp.pad_vocab_size(50257, 4) == 50304 and tp.pad_vocab_size(50304, 8) == 50304       # distributed.rs:1446-1452
+    assert tp.pad_vocab_size(100, 3) == 192
