@@ -436,7 +436,8 @@ extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
     alloc((void**)&m->q, (size_t)B * H * D * 2);
     alloc((void**)&m->attn, (size_t)B * H * D * 2);
     const int KE = cfg->n_expert > 1 ? (cfg->n_expert_used > 0 ? cfg->n_expert_used : 1) : 1;
-    if (cfg->n_expert > 1 && (cfg->n_expert_used < 1 || cfg->n_expert_used > cfg->n_expert || m->cfg.tp_world > 1)) { delete m; return nullptr; }
+    // MoE under TP: experts and router are replicated on every rank (quantized_llama.rs:344-365), attention is sharded
+    if (cfg->n_expert > 1 && (cfg->n_expert_used < 1 || cfg->n_expert_used > cfg->n_expert)) { delete m; return nullptr; }
     alloc((void**)&m->h, (size_t)B * KE * cfg->intermediate * 4);
     if (cfg->n_expert > 1) {
         alloc((void**)&m->moe_ids, (size_t)B * KE * 4);

@@ -57,7 +57,7 @@ def shard_config(cfg, rank, world):
     local = copy.copy(cfg)
     local.n_heads = cfg.n_heads // world
     local.n_kv_heads = kv_head_shard(cfg.n_kv_heads, rank, world)[0]
-    local.intermediate = cfg.intermediate // world
+    local.intermediate = cfg.intermediate if getattr(cfg, "n_expert", 0) else cfg.intermediate // world   # MoE: replicated
     local.vocab = cfg.vocab // world
     return local
 
@@ -69,14 +69,18 @@ def shard_weights(W, cfg, rank, world):
     out = {"tok_embd": W["tok_embd"], "output_norm": W["output_norm"], "output": _rows(W["output"], rank, world),
            "layers": []}
     for lw in W["layers"]:
-        out["layers"].append({
-            "attn_norm": lw["attn_norm"], "ffn_norm": lw["ffn_norm"],
-            "wq": _rows(lw["wq"], rank, world),
-            "wk": _rows(lw["wk"], kv_rank, kv_world), "wv": _rows(lw["wv"], kv_rank, kv_world),
-            "wo": _cols(lw["wo"], rank, world),
-            "w1": _rows(lw["w1"], rank, world), "w3": _rows(lw["w3"], rank, world),
-            "w2": _cols(lw["w2"], rank, world),
-        })
+        nl = {"attn_norm": lw["attn_norm"], "ffn_norm": lw["ffn_norm"],
+              "wq": _rows(lw["wq"], rank, world),
+              "wk": _rows(lw["wk"], kv_rank, kv_world), "wv": _rows(lw["wv"], kv_rank, kv_world),
+              "wo": _cols(lw["wo"], rank, world)}
+        if "experts" in lw:
+            # Mixtral GGUF: router and experts are loaded whole on every rank (quantized_llama.rs:344-365) -- the
+            # MoE block is replicated, attention and the lm_head carry the parallelism
+            nl["gate_inp"], nl["experts"] = lw["gate_inp"], lw["experts"]
+        else:
+            nl.update({"w1": _rows(lw["w1"], rank, world), "w3": _rows(lw["w3"], rank, world),
+                       "w2": _cols(lw["w2"], rank, world)})
+        out["layers"].append(nl)
     return out
 
 

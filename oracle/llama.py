@@ -209,12 +209,14 @@ class OracleLlama:
             xs = attn + xs
             x = ops.rms_norm(xs, lw["ffn_norm"], c.rms_eps)
             if "experts" in lw:
+                # experts are loaded UNSHARDED on every rank (`get_no_shape`, all_reduce: None --
+                # quantized_llama.rs:344-365): the MoE block is replicated, only attention / lm_head are parallel
                 mlp = moe_forward(x, lw, self.moe_top_k, self.o2)
             else:
                 h = ops.silu_mul(_qmm(x, lw["w1"], self.o2), _qmm(x, lw["w3"], self.o2))
                 mlp = _qmm(h, lw["w2"], self.o2)
-            if self.comm is not None:
-                mlp = self.comm.all_reduce(mlp)                        # C2 (quantized_llama.rs:38-42)
+                if self.comm is not None:
+                    mlp = self.comm.all_reduce(mlp)                    # C2 (quantized_llama.rs:38-42)
             xs = mlp + xs
             if trace is not None:
                 trace.append(xs.copy())

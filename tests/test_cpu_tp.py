@@ -36,21 +36,25 @@ class GlooComm:
         return [o.numpy() for o in outs]
 
 
-def _case():
+def _case(moe=False):
     cfg = llama.LlamaConfig.tiny(hidden=512, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=1024, vocab=512)
-    W = llama.make_weights(cfg, seed=99)
+    if moe:
+        cfg.n_expert, cfg.n_expert_used = 4, 2
+        W = llama.make_moe_weights(cfg, 4, seed=99)
+    else:
+        W = llama.make_weights(cfg, seed=99)
     rng = np.random.default_rng(5)
     seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 21)], "block_table": [2, 5]},
             {"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 9)], "block_table": [1]}]
     return cfg, W, seqs
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, moe=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from candle_vllm_amd import tp
-    cfg, W, seqs = _case()
+    cfg, W, seqs = _case(moe)
     lcfg = tp.shard_config(cfg, rank, world)
     lW = tp.shard_weights(W, cfg, rank, world)
     m = llama.OracleLlama(lcfg, lW, comm=GlooComm())
@@ -65,14 +69,15 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_tp2_oracle_equals_unsharded():
+@pytest.mark.parametrize("moe", [False, True])
+def test_tp2_oracle_equals_unsharded(moe):
     import importlib.util
     if importlib.util.find_spec("candle_vllm_amd") is None:
         pytest.skip("package not importable")
     # importing candle_vllm_amd needs the built library (symbol check); build on demand
     import __graft_entry__ as ge
     ge.build()
-    cfg, W, seqs = _case()
+    cfg, W, seqs = _case(moe)
     ref_m = llama.OracleLlama(cfg, W)
     cache = ref_m.new_cache(8)
     pre = ref_m.forward(O.prepare_prompt(seqs, cfg.block_size), cache, is_prefill=True)
@@ -82,7 +87,7 @@ def test_tp2_oracle_equals_unsharded():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, moe)) for r in range(2)]
     for p in procs:
         p.start()
     got_pre, got_dec = q.get(timeout=120)

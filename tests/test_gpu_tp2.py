@@ -27,22 +27,26 @@ def _free_port():
     return p
 
 
-def _gguf_case():
+def _gguf_case(moe=False):
     cfg = llama.LlamaConfig.tiny(hidden=512, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=1024, vocab=512)
-    W = llama.make_weights(cfg, seed=99)
+    if moe:                                              # Mixtral shape: experts replicated, attention sharded
+        cfg.n_expert, cfg.n_expert_used = 4, 2
+        W = llama.make_moe_weights(cfg, 4, seed=99)
+    else:
+        W = llama.make_weights(cfg, seed=99)
     rng = np.random.default_rng(5)
     seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 21)], "block_table": [2, 5]},
             {"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 9)], "block_table": [1]}]
     return cfg, W, seqs
 
 
-def _gguf_worker(rank, world, port, q):
+def _gguf_worker(rank, world, port, q, moe=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from candle_vllm_amd import model as M, tp
-    cfg, W, seqs = _gguf_case()
+    cfg, W, seqs = _gguf_case(moe)
     comm = tp.TorchDistComm()
     gm = M.GGUFLLaMa(cfg, max_batch=2, kv_layout=M.KV_PAGED, tp_rank=rank, tp_world=world)
     gm.load_oracle_weights(tp.shard_weights(W, cfg, rank, world))
@@ -71,10 +75,11 @@ def _gguf_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_gguf_tp2_two_ranks_on_one_gpu_equal_the_unsharded_model(lib):
+@pytest.mark.parametrize("moe", [False, True])
+def test_gguf_tp2_two_ranks_on_one_gpu_equal_the_unsharded_model(lib, moe):
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a visible MI355X")
-    cfg, W, seqs = _gguf_case()
+    cfg, W, seqs = _gguf_case(moe)
     orc = llama.OracleLlama(cfg, W, flash_layout=False)
     cache = orc.new_cache(8)
     pre = orc.forward(O.prepare_prompt(seqs, cfg.block_size), cache, is_prefill=True)
@@ -95,7 +100,7 @@ def test_gguf_tp2_two_ranks_on_one_gpu_equal_the_unsharded_model(lib):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gguf_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_gguf_worker, args=(r, 2, port, q, moe)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}
