@@ -26,10 +26,13 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
-// two f32 -> packed bf16x2 (lo in bits 0-15), round-to-nearest-even in hardware (gfx950 v_cvt_pk_bf16_f32)
+// two f32 -> packed bf16x2 (lo in bits 0-15), round-to-nearest-even in hardware (gfx950 v_cvt_pk_bf16_f32).
+// The write happens inside inline asm, and hipcc pads no wait states between an asm-written VGPR and an MFMA that
+// takes it as an operand in the next instructions (observed: wrong sums on the first m-tile of a wide launch), so the
+// two wait states that pair needs are part of the string.
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
     uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
 __device__ __forceinline__ float f16_bits_to_f32(uint16_t h) {

@@ -875,6 +875,65 @@ __device__ __forceinline__ void wide_q4k(const TileRegs& w, const uint8_t* __res
     }
 }
 
+// Second-generation image (qmg_prep_entry): the Q4_K minimum and "+128" offset terms are NOT applied per sub-block in
+// VALU (4 FMAs per MFMA and token group) but by two K=16 MFMAs per m-tile against the sub-block sums staged as an A
+// fragment:  T1 = sum_j m_j S_j,  T2 = sum_j sc_j S_j  ->  y -= dmin*T1 + 128*d*T2.   Per 2304-B unit at 32 tokens:
+// 256 -> 128 + 32 FMAs.
+__device__ __forceinline__ uint2 bytes4_to_bf16x4(uint32_t w) {
+    // integers < 256 are exact in bf16 = the upper half of their f32: plain bit operations.  (Not cvt_pk_bf16: that is
+    // an inline-asm VALU write, and hipcc pads no wait states between an asm-written VGPR and an MFMA that reads it as an
+    // operand right away -- measured as wrong sums on the first m-tile only.)
+    const float f0 = (float)(w & 0xFF), f1 = (float)((w >> 8) & 0xFF), f2 = (float)((w >> 16) & 0xFF), f3 = (float)(w >> 24);
+    return make_uint2((__float_as_uint(f0) >> 16) | (__float_as_uint(f1) & 0xFFFF0000u),
+                      (__float_as_uint(f2) >> 16) | (__float_as_uint(f3) & 0xFFFF0000u));
+}
+template <int MT>
+__device__ __forceinline__ void wide_q4k2(const TileRegs& w, const uint8_t* __restrict__ L, int lane, float (&y)[MT][4]) {
+    const int m = lane & 15, kg = lane >> 4;
+    const uint8_t* sfrag = L + (size_t)32 * MT * 16 * 16;           // [MT][kg 4][row 16][4 bf16]
+    const float d = f16_bits_to_f32((uint16_t)(w.a.x & 0xFFFF));
+    const float dmin = f16_bits_to_f32((uint16_t)(w.a.x >> 16));
+    const uint32_t s0 = w.a.y, s1 = w.a.z, s2 = w.a.w;
+    const uint32_t scl = s0 & 0x3F3F3F3Fu, mnl = s1 & 0x3F3F3F3Fu;
+    const uint32_t sch = (s2 & 0x0F0F0F0Fu) | ((s0 >> 2) & 0x30303030u);
+    const uint32_t mnh = ((s2 >> 4) & 0x0F0F0F0Fu) | ((s1 >> 2) & 0x30303030u);
+    // B fragments of the two small MFMAs: k = 4kg + e  <->  j = 4(kg & 1) + e  (both pieces of S use the same values)
+    const uint2 mb = bytes4_to_bf16x4((kg & 1) ? mnh : mnl), sb = bytes4_to_bf16x4((kg & 1) ? sch : scl);
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    uint32_t nib = 0x000F000Fu;
+    asm volatile("" : "+v"(nib));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float dsc = d * (float)(((j < 4 ? scl : sch) >> (8 * (j & 3))) & 0xFF);
+        const int p = j >> 2, pr = (j >> 1) & 1, sh = (j & 1) * 4;
+        const uint4 qs = p ? w.c : w.b;
+        const uint32_t w0 = pr ? qs.z : qs.x, w1 = pr ? qs.w : qs.y;
+        uint4 bw;
+        bw.x = ((w0 >> sh) & nib) | BF16_128;
+        bw.y = ((w0 >> (sh + 8)) & nib) | BF16_128;
+        bw.z = ((w1 >> sh) & nib) | BF16_128;
+        bw.w = ((w1 >> (sh + 8)) & nib) | BF16_128;
+        const uint8_t* abase = L + ((size_t)(4 * j + kg) * (MT * 16) + m) * 16;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const uint4 aw = *reinterpret_cast<const uint4*>(abase + (size_t)mt * 16 * 16);
+            const f32x4_t acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw),
+                                                                        __builtin_bit_cast(bf16x8_t, bw), zero, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) y[mt][v] = fmaf(dsc, acc[v], y[mt][v]);
+        }
+    }
+    const float nd128 = -128.f * d, ndmin = -dmin;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const uint2 sa = *reinterpret_cast<const uint2*>(sfrag + ((size_t)(mt * 4 + kg) * 16 + m) * 8);
+        const f32x4_t t1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, sa), __builtin_bit_cast(s16x4_t, mb), zero, 0, 0, 0);
+        const f32x4_t t2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, sa), __builtin_bit_cast(s16x4_t, sb), zero, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) y[mt][v] = fmaf(ndmin, t1[v], fmaf(nd128, t2[v], y[mt][v]));
+    }
+}
+
 template <int MT, bool PIN = true>
 __device__ __forceinline__ void wide_q6k(const TileRegs& w, const uint8_t* __restrict__ L, int lane, float (&y)[MT][4]) {
     constexpr int BP = MT * 8;
@@ -1098,8 +1157,7 @@ __device__ __forceinline__ void qmg_prep_entry(uint8_t* __restrict__ img, float*
                                                const int kb, const int b, const int El) {
     const int BP = MT * 8;
     uint8_t* kbase = img + (size_t)kb * kbb;
-    float* xs32 = reinterpret_cast<float*>(kbase + (size_t)32 * MT * 16 * 16);
-    float* xs16 = xs32 + 8 * 2 * BP;
+    float* xs16 = reinterpret_cast<float*>(kbase + (size_t)32 * MT * 16 * 16) + 8 * 2 * BP;   // after the 512*MT-byte S-fragment planes
     const int mt = b >> 3, m = b & 7;
     const int k = kb * 256 + El * 8;
     float ss = 0.f;
@@ -1130,8 +1188,16 @@ __device__ __forceinline__ void qmg_prep_entry(uint8_t* __restrict__ img, float*
         xs16[((El >> 1) * 2 + 1) * BP + b] = l16;
     }
     if ((El & 3) == 0) {
-        xs32[((El >> 2) * 2 + 0) * BP + b] = h32;
-        xs32[((El >> 2) * 2 + 1) * BP + b] = l32;
+        // sub-block sums as the A operand of a K=16 MFMA (Q4_K minimum / offset terms, wide_q4k2): per m-tile
+        // [kg 4][row 16][4 bf16], k = 8*piece + j with piece 0 = bf16(S), piece 1 = bf16(S - piece 0) (S to 2^-17, like x);
+        // rows 0..7 = sums of the hi plane of the tile's 8 tokens, rows 8..15 = sums of the lo plane
+        const int j = El >> 2;
+        uint8_t* sfrag = kbase + (size_t)32 * MT * 16 * 16 + (size_t)mt * 512;
+        const uint16_t hh = f32_to_bf16(h32), lh = f32_to_bf16(l32);
+        const uint16_t hl = f32_to_bf16(h32 - bf16_to_f32(hh)), ll = f32_to_bf16(l32 - bf16_to_f32(lh));
+        auto at = [&](int piece, int row) { return reinterpret_cast<uint16_t*>(sfrag + ((size_t)(2 * piece + (j >> 2)) * 16 + row) * 8) + (j & 3); };
+        *at(0, m) = hh; *at(1, m) = hl;
+        *at(0, 8 + m) = lh; *at(1, 8 + m) = ll;
     }
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) ss += __shfl_xor(ss, o, 64);
@@ -1223,7 +1289,7 @@ __global__ void __launch_bounds__(512, 4) qmm_gemm_kernel(const QmmArgs a, const
         // the next tile streams in while this one is unpacked and multiplied (counted vmcnt: no DMA in this wave)
         TileRegs nxt = load_tile<WT>(wtype, more ? wbase + (size_t)(kb + 1) * wtb : wbase, more ? lane : 0);
         if (a.dbg == 1) { y[0][0][0] += __uint_as_float(cur.a.x ^ cur.b.y ^ cur.c.z); }
-        else if (wtype == MI355_GGML_Q4_K) wide_q4k<MT, WT == 0>(cur, Lc, lane, y[0]);   // pin the schedule only in the mixed build
+        else if (wtype == MI355_GGML_Q4_K) wide_q4k2<MT>(cur, Lc, lane, y[0]);
         else wide_q6k<MT, WT == 0>(cur, Lc, lane, y[0]);
         cur = nxt;
         __syncthreads();                                              // everyone is done with Lc; the loader filled the other buffer
