@@ -1,0 +1,92 @@
+"""The whole hot path as the reference's engine loop drives it (llm_engine.rs execute_scheduled_batch): the C++ scheduler
+picks a prompt or a decode step, the block manager builds the step inputs, the GPU model runs the step, greedy tokens are
+appended, finished sequences are freed -- continuous batching with staggered arrivals and chunked prefill.  Every
+sequence must end up with exactly the tokens the ORACLE generates for it ALONE: batching, chunking and block placement
+must not change a result."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import llama                               # noqa: E402
+from oracle import ops as O                            # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_alone(orc, cfg, prompt, n_new):
+    nblk = -(-(len(prompt) + n_new + 1) // cfg.block_size)
+    cache = orc.new_cache(nblk + 1)
+    seq = {"tokens": list(prompt), "block_table": list(range(1, nblk + 1))}
+    lg = orc.forward(O.prepare_prompt([seq], cfg.block_size), cache, is_prefill=True)
+    out = []
+    for _ in range(n_new):
+        t = int(lg[0].argmax())
+        out.append(t)
+        seq["tokens"].append(t)
+        lg = orc.forward(O.prepare_decode([seq], cfg.block_size), cache)
+    return out
+
+
+@pytest.mark.parametrize("chunk,layout,nblk", [(0, "paged", 48), (24, "paged", 48), (24, "flash", 48), (0, "paged", 14)])
+def test_continuous_batching_engine_loop_matches_per_sequence_oracle(lib, chunk, layout, nblk):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from candle_vllm_amd import model as M
+    from candle_vllm_amd import block_engine as be
+    cfg = llama.LlamaConfig.tiny()
+    W = llama.make_weights(cfg, seed=2024)
+    flash = layout == "flash"
+    orc = llama.OracleLlama(cfg, W, flash_layout=flash)
+    rng = np.random.default_rng(606)
+    NSEQ = 7                                            # nblk = 14: the pool runs dry -> preemption by recompute (mod.rs:303-330)
+    prompts = [[int(t) for t in rng.integers(0, cfg.vocab, int(n))] for n in rng.integers(5, 60, NSEQ)]
+    n_new = [int(n) for n in rng.integers(3, 12, NSEQ)]
+    arrivals = sorted(int(a) for a in rng.integers(0, 12, NSEQ))
+    want = [_oracle_alone(orc, cfg, p, n) for p, n in zip(prompts, n_new)]
+
+    sched = be.Scheduler(block_size=cfg.block_size, num_gpu_blocks=nblk, num_cpu_blocks=8, max_num_parallel_reqs=8,
+                         max_num_batched_tokens=96, prefill_chunk_size=chunk)
+    eng = sched.block_engine
+    gm = M.GGUFLLaMa(cfg, max_batch=8, kv_layout=M.KV_FLASH if flash else M.KV_PAGED)
+    gm.load_oracle_weights(W)
+    gm.alloc_kv_cache(nblk)
+    seqs, got, done = {}, {i: [] for i in range(NSEQ)}, set()
+    next_id, step, prompt_steps, decode_steps, max_batch_seen, preempted = 0, 0, 0, 0, 0, 0
+    while len(done) < NSEQ and step < 400:
+        while next_id < NSEQ and arrivals[next_id] <= step:
+            seqs[next_id] = eng.new_sequence(next_id, prompts[next_id])
+            sched.add_sequence(next_id, [seqs[next_id]])
+            next_id += 1
+        out = sched.schedule(now_ms=step * 50)
+        preempted += len(sched.take_pending_runner_releases())
+        group = [seqs[g] for g in out.scheduled]
+        if group:
+            if out.is_prompt:
+                prompt_steps += 1
+                meta = eng.prepare_prompt(group, chunk=chunk)
+                logits = gm.forward_prefill(meta).cpu().numpy()
+                sampled = sched.filter_prefill_finished(out.scheduled) if chunk else list(out.scheduled)
+            else:
+                decode_steps += 1
+                max_batch_seen = max(max_batch_seen, len(group))
+                meta = eng.prepare_decode(group)
+                logits = gm.forward_decode(meta).cpu().numpy()
+                sampled = list(out.scheduled)
+            for row, gid in enumerate(out.scheduled):
+                if gid not in sampled or gid in done:
+                    continue
+                tok = int(logits[row].argmax())
+                got[gid].append(tok)
+                seqs[gid].add_token(tok)
+                if len(got[gid]) >= n_new[gid]:
+                    sched.set_finished(gid)
+                    done.add(gid)
+            sched.free_finished_sequence_groups()
+        step += 1
+    assert len(done) == NSEQ, (len(done), step)
+    assert prompt_steps >= 2 and decode_steps >= 2 and max_batch_seen >= 3      # the batch really was mixed and ragged
+    assert (preempted > 0) == (nblk < 20), preempted                            # the small pool did preempt, the large one did not
+    assert eng.get_num_free_blocks() == nblk and not sched.has_unfinished_sequences()
+    for i in range(NSEQ):
+        assert got[i] == want[i], (i, got[i], want[i])
