@@ -204,7 +204,7 @@ class GGUFLLaMa:
         _check(lib.mi355_llama_set_rope_tables(self.h, cos.ctypes.data, sin.ctypes.data, cos.shape[0]), "set_rope_tables")
 
     # ------------------------------------------------------------------ measurement
-    def dominant_kernel_roofline(self, stream, peak_gbs, reps=3):
+    def dominant_kernel_roofline(self, stream, peak_gbs, reps=7):
         """HIP-event timing of every launch group of the decode step (eager, on the step's own stream, weights of
         all layers in turn so each launch streams from HBM).  Returns the `roofline` object of the group that
         takes the most time, plus the per-group table."""
@@ -226,7 +226,7 @@ class GGUFLLaMa:
                 evs.append((e0, e1))
             torch.cuda.synchronize()
             us = sorted(a.elapsed_time(b) * 1e3 / L for a, b in evs[1:])
-            avg = float(np.mean(us))
+            avg = float(us[len(us) // 2])                     # median sweep: robust against a clock ramp in the first sweeps
             nbytes = kv_bytes if part == 1 else float(np.mean([self.part_bytes[(l, part)] for l in range(L)]))
             rows[part] = {"kernel": names[part], "avg_us": round(avg, 2), "median_us": round(us[len(us) // 2], 2),
                           "bytes": int(nbytes), "GBs": round(nbytes / avg / 1e3, 1), "launches_per_step": L}
@@ -246,7 +246,7 @@ class GGUFLLaMa:
                 "frac": round(r["GBs"] / peak_gbs, 4), "traffic": traffic, "avg_us": r["avg_us"],
                 "algorithmic_bytes_per_launch": r["bytes"],
                 "timing": "one hipEvent pair around the launches of all %d layers back to back on the step stream "
-                          "(each streams its own weights from HBM), / %d, %d sweeps" % (L, L, reps),
+                          "(each streams its own weights from HBM), / %d = average launch duration of a sweep; median of %d sweeps" % (L, L, reps),
                 "groups": [rows[p] for p in sorted(rows)]}
 
     # ------------------------------------------------------------------ KV cache (CacheEngine)
