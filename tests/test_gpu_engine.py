@@ -90,3 +90,89 @@ def test_continuous_batching_engine_loop_matches_per_sequence_oracle(lib, chunk,
     assert eng.get_num_free_blocks() == nblk and not sched.has_unfinished_sequences()
     for i in range(NSEQ):
         assert got[i] == want[i], (i, got[i], want[i])
+
+
+def test_engine_loop_with_swap_preemption(lib):
+    """Prefix cache on -> preemption swaps a sequence's KV blocks to the host (mod.rs:725-755) and back after the
+    cooling period; the engine executes the scheduler's block ops the way `execute_scheduler_ops` does
+    (llm_engine.rs:1357-1400: swap_in, swap_out, copy, then finalize) with `mi355_swap_blocks` on every layer's K
+    and V.  A swapped-and-restored sequence must still generate exactly the oracle's tokens."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    import ctypes
+    from candle_vllm_amd import model as M
+    from candle_vllm_amd import block_engine as be
+    from candle_vllm_amd import ops as cvo
+    cfg = llama.LlamaConfig.tiny()
+    W = llama.make_weights(cfg, seed=2025)
+    orc = llama.OracleLlama(cfg, W, flash_layout=False)
+    rng = np.random.default_rng(707)
+    NSEQ, nblk, ncpu = 5, 10, 24
+    prompts = [[int(t) for t in rng.integers(0, cfg.vocab, int(n))] for n in rng.integers(20, 40, NSEQ)]
+    n_new = [int(n) for n in rng.integers(14, 22, NSEQ)]
+    want = [_oracle_alone(orc, cfg, p, n) for p, n in zip(prompts, n_new)]
+    sched = be.Scheduler(block_size=cfg.block_size, num_gpu_blocks=nblk, num_cpu_blocks=ncpu, max_num_parallel_reqs=8,
+                         max_num_batched_tokens=256, prefill_chunk_size=0, prefix_cache_enabled=True, max_cached_blocks=2)
+    eng = sched.block_engine
+    gm = M.GGUFLLaMa(cfg, max_batch=8, kv_layout=M.KV_PAGED)
+    gm.load_oracle_weights(W)
+    gm.alloc_kv_cache(nblk)
+    block_bytes = cfg.n_kv_heads * cfg.head_dim * cfg.block_size * 2
+    cpu_cache = torch.zeros((cfg.n_layers, 2, ncpu, block_bytes), dtype=torch.uint8).pin_memory()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def swap(mapping, to_host):
+        if not mapping:
+            return
+        flat = []
+        for s, d in mapping.items():
+            flat += [int(s), int(d)]
+        arr = (ctypes.c_int64 * len(flat))(*flat)
+        for l in range(cfg.n_layers):
+            for which in (0, 1):                                   # K then V (cache_engine.rs:352-358)
+                dev_ptr = M.lib.mi355_llama_kv_ptr(gm.h, l, which)
+                host_ptr = cpu_cache[l, which].data_ptr()
+                src, dst = (dev_ptr, host_ptr) if to_host else (host_ptr, dev_ptr)
+                rc = M.lib.mi355_swap_blocks(src, dst, ctypes.cast(arr, ctypes.c_void_p), len(flat) // 2, block_bytes,
+                                             cvo.SWAP_D2H if to_host else cvo.SWAP_H2D, st)
+                assert rc == 0
+        torch.cuda.synchronize()
+
+    seqs = {i: eng.new_sequence(i, prompts[i]) for i in range(NSEQ)}
+    for i in range(NSEQ):
+        sched.add_sequence(i, [seqs[i]])
+    got, done = {i: [] for i in range(NSEQ)}, set()
+    swapped_out, swapped_in, step = 0, 0, 0
+    while len(done) < NSEQ and step < 600:
+        out = sched.schedule(now_ms=step * 200)                    # 200 ms per step: the 300 ms cooling passes in 2 steps
+        sched.take_pending_runner_releases()
+        swap(out.blocks_to_swap_in, to_host=False)                 # execute_scheduler_ops order: in, out, copy
+        swap(out.blocks_to_swap_out, to_host=True)
+        assert not out.blocks_to_copy
+        for g in out.swap_in_groups:
+            eng.finalize_swap_in(g)
+        for g in out.swap_out_groups:
+            eng.finalize_swap_out(g)
+        swapped_out += len(out.swap_out_groups)
+        swapped_in += len(out.swap_in_groups)
+        group = [seqs[g] for g in out.scheduled]
+        if group:
+            if out.is_prompt:
+                logits = gm.forward_prefill(eng.prepare_prompt(group)).cpu().numpy()
+            else:
+                logits = gm.forward_decode(eng.prepare_decode(group)).cpu().numpy()
+            for row, gid in enumerate(out.scheduled):
+                if gid in done:
+                    continue
+                tok = int(logits[row].argmax())
+                got[gid].append(tok)
+                seqs[gid].add_token(tok)
+                if len(got[gid]) >= n_new[gid]:
+                    sched.set_finished(gid)
+                    done.add(gid)
+            sched.free_finished_sequence_groups()
+        step += 1
+    assert len(done) == NSEQ, (len(done), step)
+    assert swapped_out > 0 and swapped_in == swapped_out, (swapped_out, swapped_in)
+    for i in range(NSEQ):
+        assert got[i] == want[i], (i, got[i], want[i])
