@@ -176,3 +176,55 @@ def test_engine_loop_with_swap_preemption(lib):
     assert swapped_out > 0 and swapped_in == swapped_out, (swapped_out, swapped_in)
     for i in range(NSEQ):
         assert got[i] == want[i], (i, got[i], want[i])
+
+
+def test_engine_loop_prefix_cache_hit_reuses_kv_blocks(lib):
+    """Prefix cache: a finished sequence leaves its full blocks in the cache (hash chain over token blocks); a later
+    prompt with the same first 32 tokens is allocated ON those blocks, only its remaining tokens are computed (prefill
+    with a cached prefix, K4 through the block table) -- and it must still produce the oracle's tokens."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from candle_vllm_amd import model as M
+    from candle_vllm_amd import block_engine as be
+    cfg = llama.LlamaConfig.tiny()
+    W = llama.make_weights(cfg, seed=2026)
+    orc = llama.OracleLlama(cfg, W, flash_layout=False)
+    rng = np.random.default_rng(808)
+    shared = [int(t) for t in rng.integers(0, cfg.vocab, 2 * cfg.block_size)]
+    prompts = [shared + [int(t) for t in rng.integers(0, cfg.vocab, 9)],
+               shared + [int(t) for t in rng.integers(0, cfg.vocab, 13)]]
+    n_new = [6, 7]
+    want = [_oracle_alone(orc, cfg, p, n) for p, n in zip(prompts, n_new)]
+    sched = be.Scheduler(block_size=cfg.block_size, num_gpu_blocks=24, num_cpu_blocks=8, max_num_parallel_reqs=4,
+                         max_num_batched_tokens=256, prefill_chunk_size=0, prefix_cache_enabled=True, max_cached_blocks=8)
+    eng = sched.block_engine
+    gm = M.GGUFLLaMa(cfg, max_batch=4, kv_layout=M.KV_PAGED)
+    gm.load_oracle_weights(W)
+    gm.alloc_kv_cache(24)
+    got = {}
+    computed_prompt_tokens = []
+    for gid in (0, 1):                                              # one after the other: the second arrives when the first is done
+        seq = eng.new_sequence(gid, prompts[gid])
+        sched.add_sequence(gid, [seq])
+        got[gid] = []
+        for step in range(64):
+            out = sched.schedule(now_ms=1000 * gid + 50 * step)
+            if not out.scheduled:
+                continue
+            if out.is_prompt:
+                meta = eng.prepare_prompt([seq])
+                computed_prompt_tokens.append(len(meta["input_ids"]))
+                logits = gm.forward_prefill(meta).cpu().numpy()
+            else:
+                logits = gm.forward_decode(eng.prepare_decode([seq])).cpu().numpy()
+            tok = int(logits[0].argmax())
+            got[gid].append(tok)
+            seq.add_token(tok)
+            if len(got[gid]) >= n_new[gid]:
+                sched.set_finished(gid)
+                sched.free_finished_sequence_groups()
+                break
+    assert got[0] == want[0] and got[1] == want[1], (got, want)
+    assert computed_prompt_tokens[0] == len(prompts[0])
+    assert computed_prompt_tokens[1] == len(prompts[1]) - 2 * cfg.block_size     # the shared two blocks were NOT recomputed
+    assert eng.prefix_cache_blocks() > 0
