@@ -78,7 +78,7 @@ class GGUFLLaMa:
         self.local_kv_heads = max(cfg.n_kv_heads // tp_world, 1)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:           # `lib` is already gone at interpreter shutdown
             lib.mi355_llama_destroy(self.h)
             self.h = None
 

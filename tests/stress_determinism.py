@@ -36,3 +36,30 @@ for flash in (True, False):
                     d = np.abs(got - ref)
                     print("  MISMATCH it", it, "rows", np.unique(np.nonzero(d)[0]).tolist(), "max", d.max(), flush=True)
         print(f"flash={flash} nseq={nseq}: {bad} / 300 differ", flush=True)
+
+# ---- wide (9..32 token) chained path + workgroup-merged attention partitions: batch 12, contexts up to 600 tokens
+B = 12
+ctxs = [int(c) for c in rng.integers(100, 600, B)]
+nblk = [-(-(c + 1) // cfg.block_size) for c in ctxs]
+seqs, nxt = [], 1
+for c, n in zip(ctxs, nblk):
+    seqs.append({"tokens": [int(t) for t in rng.integers(0, cfg.vocab, c)], "block_table": list(range(nxt, nxt + n))})
+    nxt += n
+big = llama.LlamaConfig.tiny(max_seq=1024)
+gm = M.GGUFLLaMa(big, max_batch=B, max_blocks_per_seq=max(nblk) + 1, kv_layout=M.KV_PAGED)
+gm.load_oracle_weights(W)
+gm.alloc_kv_cache(nxt + 1)
+ks, vs = O.kv_cache_shapes(nxt + 1, cfg.block_size, cfg.n_kv_heads, cfg.head_dim, 2, False)
+kc = O.f32_to_bf16_bits(rng.normal(0, 1, ks).astype(np.float32))
+vc = O.f32_to_bf16_bits(rng.normal(0, 1, vs).astype(np.float32))
+for l in range(cfg.n_layers):
+    gm.kv_upload(l, kc, vc)
+meta = O.prepare_decode(seqs, cfg.block_size)
+ref = gm.forward_decode(meta).cpu().numpy()
+bad = 0
+for it in range(300):
+    got = gm.forward_decode(meta).cpu().numpy()
+    if not np.array_equal(got, ref):
+        bad += 1
+print(f"batch {B} wide+chained+merged-attention: {bad} / 300 runs differ (max ctx {max(ctxs)})", flush=True)
+assert bad == 0
