@@ -1312,13 +1312,7 @@ __global__ void __launch_bounds__(512, 4) qmm_gemm_kernel(const QmmArgs a, const
 // partial sums -> epilogue; one thread per (token, concatenated padded row)
 // returns the f32 value written to a.out for (token b, out column = the chain's k index), 0 when nothing was written
 __device__ __forceinline__ float qmm_epilogue_one(const QmmArgs& a, const float* __restrict__ part, const int ldp, const int ks,
-                                                  const int BP, const float* __restrict__ ssp, const int prow, const int b) {
-    float inv = 1.f;                                               // deferred RMSNorm scale of this token
-    if (a.norm_w) {
-        float ss = 0.f;
-        for (int kb = 0; kb < (a.K >> 8); ++kb) ss += ssp[(size_t)kb * BP + b];
-        inv = rsqrtf(ss / (float)a.K + a.eps);
-    }
+                                                  const int BP, const float inv, const int prow, const int b) {
     int sg = 0, lrow = prow;
     while (sg + 1 < a.nseg && lrow >= a.seg[sg].n_tiles * 16) { lrow -= a.seg[sg].n_tiles * 16; ++sg; }
     if (lrow >= a.seg[sg].n_rows) return 0.f;
@@ -1390,8 +1384,23 @@ __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, cons
                                                            const QmgChainOut ch) {
     const int prow = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
+    // deferred RMSNorm scale of this workgroup's token: the per-k-block partial sums are read by the lanes of one wave
+    // in parallel (one L2 round trip) -- a per-thread loop over up to 56 k-blocks was most of this kernel's time
+    __shared__ float sm_inv;
+    float inv = 1.f;
+    if (a.norm_w && ssp) {
+        if (threadIdx.x < 64) {
+            float ss = 0.f;
+            if (b < a.B)
+                for (int kb = threadIdx.x; kb < (a.K >> 8); kb += 64) ss += ssp[(size_t)kb * BP + b];
+            ss = wave_sum(ss);
+            if (threadIdx.x == 0) sm_inv = rsqrtf(ss / (float)a.K + a.eps);
+        }
+        __syncthreads();
+        inv = sm_inv;
+    }
     float o = 0.f;
-    if (prow < ldp && b < a.B) o = qmm_epilogue_one(a, part, ldp, ks, BP, ssp, prow, b);
+    if (prow < ldp && b < a.B) o = qmm_epilogue_one(a, part, ldp, ks, BP, inv, prow, b);
     if (!ch.img) return;
     const int kb = blockIdx.x;
     if (kb * 256 >= ch.K) return;                                    // uniform: e.g. the `up` half of the gate/up rows
