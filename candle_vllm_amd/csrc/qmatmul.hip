@@ -1208,7 +1208,9 @@ template <int MT>
 __global__ void __launch_bounds__(256) qmm_prep2_kernel(uint8_t* __restrict__ img, float* __restrict__ ssp, const QmmArgs a, const size_t kbb) {
     constexpr int BP = MT * 8;
     const int kb = blockIdx.x;
-    for (int e = threadIdx.x; e < BP * 32; e += blockDim.x) {       // 32 consecutive lanes = the 32 entries of one row
+    // grid = (k-blocks, m-tiles): one workgroup = the 8 token rows of one m-tile (a single pass: the launch is a chain
+    // of one load and one store latency, so it must not loop)
+    for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < BP * 32; e += blockDim.x * gridDim.y) {   // 32 consecutive lanes = the 32 entries of one row
         const int b = e >> 5, El = e & 31;
         const bool live = b < a.B;
         float v[8];
@@ -1469,7 +1471,7 @@ static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
     }
     uint8_t* img = g_qmg_imgs[cur];
     float* ssp = reinterpret_cast<float*>(img + kbb * nkb);                 // [nkb][MT*8] after the image
-    if (!chained) hipLaunchKernelGGL((qmm_prep2_kernel<MT>), dim3(nkb), dim3(256), 0, st, img, ssp, a, kbb);
+    if (!chained) hipLaunchKernelGGL((qmm_prep2_kernel<MT>), dim3(nkb, MT), dim3(256), 0, st, img, ssp, a, kbb);
     // one GEMM launch per run of same-type segments: the type-specialised builds need no schedule pinning and do not
     // spill (the mixed build did); each run writes its own columns of the partial-sum buffer
     for (int s0 = 0, slot_base = 0; s0 < a.nseg;) {
