@@ -13,7 +13,11 @@
  *     verbatim so the Rust `extern "C"` block binds unchanged;
  *   - `mi355_*` entry points return an int status (0 = ok, otherwise a hipError_t value) because the
  *     Python/C++ harness has no other error channel; a Rust binding may ignore it.
- *   - no torch / candle types anywhere in this file.
+ *   - no torch / candle types anywhere in this file;
+ *   - threading: one caller thread per process drives the device, as in the reference (one engine thread per rank bound
+ *     to its GPU, llm_engine.rs:1406-1414; all kernels on that device's single non-default stream, lib.rs:109).  The
+ *     library keeps grow-only device scratch (split-K partial sums, staged activation images, arrival counters) per
+ *     PROCESS: calls are not re-entrant across host threads, and launches that use the scratch must be stream-ordered.
  */
 #ifndef MI355_VLLM_H
 #define MI355_VLLM_H
