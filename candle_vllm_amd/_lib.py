@@ -215,6 +215,7 @@ _sig("mi355_dense_set_gptq", ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp, c_i3
 _sig("mi355_dense_set_comm", ctypes.c_int, [c_vp, c_vp])
 _sig("mi355_dense_set_rope_tables", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32])
 _sig("mi355_llama_set_rope_tables", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32])
+_sig("mi355_abi_struct_size", c_i64, [c_i32])
 _sig("mi355_rope_table_len", c_i32, [c_vp, c_i32, c_i32])
 _sig("mi355_rope_tables", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, ctypes.c_double, c_vp, c_i32, c_i32])
 _sig("mi355_comm_create", c_vp, [c_vp, c_i32, c_i32])
@@ -241,3 +242,10 @@ _sig("mi355_gguf_find", c_i32, [c_vp, ctypes.c_char_p])
 _sig("mi355_gguf_tensor_info", c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp])
 _sig("mi355_gguf_tensor_data", c_vp, [c_vp, c_i32])
 _sig("mi355_llama_load_gguf", ctypes.c_int, [ctypes.c_char_p] + [c_i32] * 5 + [c_vp, c_vp])
+
+
+# the hand-written ctypes mirrors must have the layout the library was built with
+for _id, _cls in ((0, QmmDesc), (1, LlamaConfig), (2, DenseConfig), (3, RopeScaling)):
+    if lib.mi355_abi_struct_size(_id) != ctypes.sizeof(_cls):
+        raise ImportError(f"{_cls.__name__}: ctypes mirror is {ctypes.sizeof(_cls)} bytes, the library expects "
+                          f"{lib.mi355_abi_struct_size(_id)} (include/mi355_vllm.h changed?)")

@@ -130,3 +130,14 @@ extern "C" int mi355_rope_tables(float* cos_out, float* sin_out, int32_t rotary_
     }
     return 1;
 }
+
+// ABI guard: struct sizes as this build of the header sees them (hand-written mirrors compare against it)
+extern "C" int64_t mi355_abi_struct_size(int32_t which) {
+    switch (which) {
+        case 0: return (int64_t)sizeof(mi355_qmm_desc);
+        case 1: return (int64_t)sizeof(mi355_llama_config);
+        case 2: return (int64_t)sizeof(mi355_dense_config);
+        case 3: return (int64_t)sizeof(mi355_rope_scaling);
+        default: return -1;
+    }
+}

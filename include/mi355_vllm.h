@@ -566,6 +566,10 @@ const void* mi355_gguf_tensor_data(void* gguf, int32_t i);
 int mi355_llama_load_gguf(const char* path, int32_t max_batch, int32_t max_blocks_per_seq, int32_t block_size,
                           int32_t kv_layout, int32_t max_seq, void** model_out, mi355_llama_config* cfg_out);
 
+/* ABI guard for bindings that mirror the structs by hand (ctypes, a Rust #[repr(C)]): sizeof of
+ * 0 = mi355_qmm_desc, 1 = mi355_llama_config, 2 = mi355_dense_config, 3 = mi355_rope_scaling; -1 for an unknown id */
+int64_t mi355_abi_struct_size(int32_t which);
+
 #ifdef __cplusplus
 }
 #endif
