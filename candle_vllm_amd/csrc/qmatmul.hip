@@ -740,140 +740,13 @@ __global__ void __launch_bounds__(512) qmm_moe_kernel(const QmmArgs a_in) {
 }
 
 // ================================================================================================
-// Wide-batch variant (9..32 tokens per launch): every weight byte is still read once.  GEMM-style: the 8 waves
-// of a workgroup own different row tiles and sweep K together, sharing one LDS image of the activations per
-// k-block (double-buffered, one barrier per k-block).  The image (hi/lo bf16 fragments + sub-block sums, with
-// the RMSNorm already applied) is produced once per launch by `qmm_prep_kernel`, so staging is a plain copy.
-//   image of k-block kb:  ximg [32 entries][MT*16 rows][16 B] | xs32 [8][2][MT*8] f32 | xs16 [16][2][MT*8] f32
+// Wide path (9..32 tokens per launch): every weight byte is still read once.  GEMM-style: the consumer waves of a
+// workgroup own different row tiles and sweep K together, sharing one LDS image of the activations per k-block
+// (double-buffered, one barrier per k-block).  The image (hi/lo bf16 fragments + sub-block sums, RMSNorm weight already
+// applied) is produced by `qmg_prep_entry` -- in the staging launch or in the previous mat-mul's epilogue.
+//   image of k-block kb:  ximg [32 entries][MT*16 rows][16 B] | S fragments [MT][4][16][4 bf16] | xs16 [16][2][MT*8] f32
 //   rows of M-tile mt: mt*16 + m, m<8 = hi(batch 8mt+m), m>=8 = lo(batch 8mt+m-8)
 #define QMW_MAXMT 4
-static inline size_t qmw_kb_bytes(int MT) { return (size_t)MT * 8 * 1216; }
-
-template <int MT>
-__global__ void __launch_bounds__(256) qmm_prep_kernel(uint8_t* __restrict__ img, const QmmArgs a, const size_t kbb) {
-    constexpr int BP = MT * 8;
-    __shared__ float red[16];
-    const int b = blockIdx.x;                        // one workgroup per (padded) batch row
-    const int nkb = a.K >> 8;
-    const bool live = b < a.B;
-    float inv = 1.f;
-    if (a.norm_w) {
-        float ss = 0.f;
-        if (live)
-            for (int k = threadIdx.x * 4; k < a.K; k += blockDim.x * 4) {
-                float v[4];
-                if (a.x_dtype == MI355_DTYPE_BF16) {
-                    const uint2 t = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(a.x) + (size_t)b * a.ldx + k);
-                    v[0] = bf16lo_to_f32(t.x); v[1] = bf16hi_to_f32(t.x); v[2] = bf16lo_to_f32(t.y); v[3] = bf16hi_to_f32(t.y);
-                } else {
-                    const float4 t = *reinterpret_cast<const float4*>(static_cast<const float*>(a.x) + (size_t)b * a.ldx + k);
-                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-                }
-                ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-            }
-        ss = block_sum(ss, red);
-        inv = rsqrtf(ss / (float)a.K + a.eps);
-    }
-    const int mt = b >> 3, m = b & 7;
-    for (int e = threadIdx.x; e < nkb * 32; e += blockDim.x) {      // entry = 8 consecutive elements
-        const int kb = e >> 5, El = e & 31;
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = 0.f;
-        if (live) {
-            const int k = e * 8;
-            if (a.x_dtype == MI355_DTYPE_BF16) {
-                const uint4 w = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(a.x) + (size_t)b * a.ldx + k);
-                v[0] = bf16lo_to_f32(w.x); v[1] = bf16hi_to_f32(w.x); v[2] = bf16lo_to_f32(w.y); v[3] = bf16hi_to_f32(w.y);
-                v[4] = bf16lo_to_f32(w.z); v[5] = bf16hi_to_f32(w.z); v[6] = bf16lo_to_f32(w.w); v[7] = bf16hi_to_f32(w.w);
-            } else {
-                const float* xp = static_cast<const float*>(a.x) + (size_t)b * a.ldx + k;
-                const float4 v0 = *reinterpret_cast<const float4*>(xp), v1 = *reinterpret_cast<const float4*>(xp + 4);
-                v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-            }
-            if (a.norm_w) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = v[i] * inv * a.norm_w[k + i];
-            }
-        }
-        const uint32_t h02 = cvt_pk_bf16(v[0], v[2]), h13 = cvt_pk_bf16(v[1], v[3]);
-        const uint32_t h46 = cvt_pk_bf16(v[4], v[6]), h57 = cvt_pk_bf16(v[5], v[7]);
-        const float hf[8] = {bf16lo_to_f32(h02), bf16lo_to_f32(h13), bf16hi_to_f32(h02), bf16hi_to_f32(h13),
-                             bf16lo_to_f32(h46), bf16lo_to_f32(h57), bf16hi_to_f32(h46), bf16hi_to_f32(h57)};
-        const uint32_t l02 = cvt_pk_bf16(v[0] - hf[0], v[2] - hf[2]), l13 = cvt_pk_bf16(v[1] - hf[1], v[3] - hf[3]);
-        const uint32_t l46 = cvt_pk_bf16(v[4] - hf[4], v[6] - hf[6]), l57 = cvt_pk_bf16(v[5] - hf[5], v[7] - hf[7]);
-        float hsum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) hsum += hf[i];
-        const float lsum = (bf16lo_to_f32(l02) + bf16hi_to_f32(l02)) + (bf16lo_to_f32(l13) + bf16hi_to_f32(l13)) +
-                           (bf16lo_to_f32(l46) + bf16hi_to_f32(l46)) + (bf16lo_to_f32(l57) + bf16hi_to_f32(l57));
-        uint8_t* kbase = img + (size_t)kb * kbb;
-        uint8_t* ent = kbase + ((size_t)El * (MT * 16) + mt * 16) * 16;
-        *reinterpret_cast<uint4*>(ent + (size_t)m * 16) = make_uint4(h02, h13, h46, h57);
-        *reinterpret_cast<uint4*>(ent + (size_t)(8 + m) * 16) = make_uint4(l02, l13, l46, l57);
-        // 16- / 32-element sums: the lanes of a quad hold consecutive entries of this row
-        const float h16 = hsum + __shfl_xor(hsum, 1, 64), l16 = lsum + __shfl_xor(lsum, 1, 64);
-        const float h32 = h16 + __shfl_xor(h16, 2, 64), l32 = l16 + __shfl_xor(l16, 2, 64);
-        float* xs32 = reinterpret_cast<float*>(kbase + (size_t)32 * MT * 16 * 16);
-        float* xs16 = xs32 + 8 * 2 * BP;
-        if ((El & 1) == 0) {
-            xs16[((El >> 1) * 2 + 0) * BP + b] = h16;
-            xs16[((El >> 1) * 2 + 1) * BP + b] = l16;
-        }
-        if ((El & 3) == 0) {
-            xs32[((El >> 2) * 2 + 0) * BP + b] = h32;
-            xs32[((El >> 2) * 2 + 1) * BP + b] = l32;
-        }
-    }
-}
-
-template <int MT, bool PIN = true>
-__device__ __forceinline__ void wide_q4k(const TileRegs& w, const uint8_t* __restrict__ L, int lane, float (&y)[MT][4]) {
-    constexpr int BP = MT * 8;
-    const int m = lane & 15, kg = lane >> 4;
-    const float* xs32 = reinterpret_cast<const float*>(L + (size_t)32 * MT * 16 * 16);
-    const float d = f16_bits_to_f32((uint16_t)(w.a.x & 0xFFFF));
-    const float dmin = f16_bits_to_f32((uint16_t)(w.a.x >> 16));
-    const uint32_t s0 = w.a.y, s1 = w.a.z, s2 = w.a.w;
-    const uint32_t scl = s0 & 0x3F3F3F3Fu, mnl = s1 & 0x3F3F3F3Fu;
-    const uint32_t sch = (s2 & 0x0F0F0F0Fu) | ((s0 >> 2) & 0x30303030u);
-    const uint32_t mnh = ((s2 >> 4) & 0x0F0F0F0Fu) | ((s1 >> 2) & 0x30303030u);
-    const float d128 = d * 128.f;
-    uint32_t nib = 0x000F000Fu;
-    asm volatile("" : "+v"(nib));
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float sa = (float)(((j < 4 ? scl : sch) >> (8 * (j & 3))) & 0xFF);
-        const float ma = (float)(((j < 4 ? mnl : mnh) >> (8 * (j & 3))) & 0xFF);
-        const float dsc = d * sa, cj = fmaf(dmin, ma, d128 * sa);
-        const int p = j >> 2, pr = (j >> 1) & 1, sh = (j & 1) * 4;
-        const uint4 qs = p ? w.c : w.b;
-        const uint32_t w0 = pr ? qs.z : qs.x, w1 = pr ? qs.w : qs.y;
-        uint4 bw;
-        bw.x = ((w0 >> sh) & nib) | BF16_128;
-        bw.y = ((w0 >> (sh + 8)) & nib) | BF16_128;
-        bw.z = ((w1 >> sh) & nib) | BF16_128;
-        bw.w = ((w1 >> (sh + 8)) & nib) | BF16_128;
-        const uint8_t* abase = L + ((size_t)(4 * j + kg) * (MT * 16) + m) * 16;
-        const float* xsj = xs32 + ((size_t)j * 2 + (kg >> 1)) * BP + 4 * (kg & 1);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const uint4 aw = *reinterpret_cast<const uint4*>(abase + (size_t)mt * 16 * 16);
-            const float4 xsv = *reinterpret_cast<const float4*>(xsj + 8 * mt);
-            const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
-            const f32x4_t acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw),
-                                                                        __builtin_bit_cast(bf16x8_t, bw), zero, 0, 0, 0);
-            y[mt][0] = fmaf(dsc, acc[0], fmaf(-cj, xsv.x, y[mt][0]));
-            y[mt][1] = fmaf(dsc, acc[1], fmaf(-cj, xsv.y, y[mt][1]));
-            y[mt][2] = fmaf(dsc, acc[2], fmaf(-cj, xsv.z, y[mt][2]));
-            y[mt][3] = fmaf(dsc, acc[3], fmaf(-cj, xsv.w, y[mt][3]));
-        }
-        if (PIN) {
-            asm volatile("" ::: "memory");          // one sub-block at a time: no hoisting of the next LDS reads,
-            __builtin_amdgcn_sched_barrier(0);      // keeps the live set small (no spills)
-        }
-    }
-}
 
 // Second-generation image (qmg_prep_entry): the Q4_K minimum and "+128" offset terms are NOT applied per sub-block in
 // VALU (4 FMAs per MFMA and token group) but by two K=16 MFMAs per m-tile against the sub-block sums staged as an A
@@ -986,161 +859,10 @@ __device__ __forceinline__ void wide_q6k(const TileRegs& w, const uint8_t* __res
     }
 }
 
-// grid = ceil(tiles / (NW*R)) workgroups of NW waves; wave w owns R consecutive tile slots and all of K.
-template <int MT, int R, int WT, int NW>
-__global__ void __launch_bounds__(64 * NW) qmm_wide_kernel(const QmmArgs a, const uint8_t* __restrict__ img) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nkb = a.K >> 8;
-    const size_t kbb = (size_t)MT * 8 * 1216;
-    const int n_slots = a.paired ? 2 * a.seg[0].n_tiles : a.seg[0].n_tiles + (a.nseg > 1 ? a.seg[1].n_tiles : 0) +
-                                                         (a.nseg > 2 ? a.seg[2].n_tiles : 0);
-    // slot -> (segment, tile): paired launches interleave gate/up (slot 2t = gate tile t, 2t+1 = up tile t)
-    int segi[R], tile[R];
-    bool have[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        int slot = (blockIdx.x * NW + wave) * R + r;
-        have[r] = slot < n_slots;
-        if (!have[r]) slot = 0;
-        if (a.paired) { segi[r] = slot & 1; tile[r] = slot >> 1; }
-        else {
-            int t = slot, s = 0;
-            while (s + 1 < a.nseg && t >= a.seg[s].n_tiles) { t -= a.seg[s].n_tiles; ++s; }
-            segi[r] = s; tile[r] = t;
-        }
-    }
-    const uint8_t* wbase[R];
-    int wtype[R], wtb[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        wtype[r] = WT ? WT : a.seg[segi[r]].type;
-        wtb[r] = (wtype[r] == MI355_GGML_Q4_K) ? Q4K_TILE : Q6K_TILE;
-        wbase[r] = a.seg[segi[r]].w + (size_t)tile[r] * nkb * wtb[r];
-    }
-    float y[R][MT][4];
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) y[r][mt][v] = 0.f;
-
-    // split-K over gridDim.y (only with the in-place residual epilogue: partial sums are atomically added)
-    const int kb_per = (nkb + gridDim.y - 1) / gridDim.y;
-    const int kb_lo = blockIdx.y * kb_per, kb_hi = min(nkb, kb_lo + kb_per);
-    if (kb_lo >= kb_hi) return;
-    // ---- prologue: first k-block of the image -> LDS buffer ; first weights
-    const int nvec = (int)(kbb / 16);                               // 16-B vectors per k-block image
-    for (int i = threadIdx.x; i < nvec; i += blockDim.x)
-        reinterpret_cast<uint4*>(smem + (size_t)(kb_lo & 1) * kbb)[i] = reinterpret_cast<const uint4*>(img + (size_t)kb_lo * kbb)[i];
-    TileRegs cur[R], nxt[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) cur[r] = load_tile<WT>(wtype[r], wbase[r] + (size_t)kb_lo * wtb[r], lane);
-    __syncthreads();
-    constexpr int XV = (MT * 8 * 1216 / 16 + 64 * NW - 1) / (64 * NW);   // image vectors per thread
-    for (int kb = kb_lo; kb < kb_hi; ++kb) {
-        const uint8_t* Lc = smem + (size_t)(kb & 1) * kbb;
-        uint8_t* Ln = smem + (size_t)((kb + 1) & 1) * kbb;
-        const bool more = kb + 1 < kb_hi;
-        // next k-block: weights into the ring, image into registers (written to LDS after the compute)
-        uint4 xv[XV];
-#pragma unroll
-        for (int i = 0; i < XV; ++i) {
-            const int idx = threadIdx.x + i * blockDim.x;
-            xv[i] = (more && idx < nvec) ? reinterpret_cast<const uint4*>(img + (size_t)(kb + 1) * kbb)[idx] : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            nxt[r] = load_tile<WT>(wtype[r], more ? wbase[r] + (size_t)(kb + 1) * wtb[r] : wbase[r], more ? lane : 0);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (wtype[r] == MI355_GGML_Q4_K) wide_q4k<MT>(cur[r], Lc, lane, y[r]);
-            else wide_q6k<MT>(cur[r], Lc, lane, y[r]);
-        }
-#pragma unroll
-        for (int i = 0; i < XV; ++i) {
-            const int idx = threadIdx.x + i * blockDim.x;
-            if (more && idx < nvec) reinterpret_cast<uint4*>(Ln)[idx] = xv[i];
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) cur[r] = nxt[r];
-        __syncthreads();
-    }
-
-    // ---- epilogue (per wave; no cross-wave reduction: a wave owns all of K for its tiles)
-    const int kg = lane >> 4, rr = lane & 15;
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) y[r][mt][v] += __shfl_xor(y[r][mt][v], 32, 64);   // hi + lo
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const QmmSeg& sg = a.seg[segi[r]];
-        const int lrow = tile[r] * 16 + rr;
-        const int orow = sg.row0 + lrow;
-        const bool row_ok = have[r] && lrow < sg.n_rows;
-        if (a.epi == MI355_EPI_SILU_MUL && (r & 1)) continue;       // up tiles are consumed with their gate tile
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int b = 8 * mt + 4 * kg + v;
-                float val = y[r][mt][v];
-                float partner = __shfl_xor(val, 1, 64);              // row rr^1 of the same tile (RoPE pair)
-                if (kg >= 2 || b >= a.B || !row_ok) continue;
-                if (a.bias) { val += a.bias[orow]; partner += a.bias[orow ^ 1]; }
-                if (a.epi == MI355_EPI_STORE) {
-                    a.out[(size_t)b * a.ldo + orow] = val;
-                } else if (a.epi == MI355_EPI_RESID) {
-                    if (gridDim.y > 1) {                             // split-K: out aliases resid, accumulate in place
-                        if (a.bias && blockIdx.y != 0) val -= a.bias[orow];
-                        atomicAdd(a.out + (size_t)b * a.ldo + orow, val);
-                    } else {
-                        a.out[(size_t)b * a.ldo + orow] = a.resid[(size_t)b * a.ldo + orow] + val;
-                    }
-                } else if (a.epi == MI355_EPI_SILU_MUL) {
-                    float up = y[(r + 1 < R) ? r + 1 : r][mt][v];
-                    if (a.bias) up += a.bias[a.seg[1].row0 + lrow];
-                    a.out[(size_t)b * a.ldo + lrow] = silu_f(val) * up;
-                } else if (a.epi == MI355_EPI_QKV_ROPE_CACHE) {
-                    const int D = a.D, d = lrow % D, hh = lrow / D;
-                    float o = val;
-                    if (segi[r] < 2 && d < a.rot) {
-                        const int64_t pos = a.positions[b];
-                        const float c = a.cos_t[pos * (a.rot >> 1) + (d >> 1)], sn = a.sin_t[pos * (a.rot >> 1) + (d >> 1)];
-                        o = (d & 1) ? (partner * sn + val * c) : (val * c - partner * sn);
-                    }
-                    const uint16_t ob = f32_to_bf16(o);
-                    if (segi[r] == 0) {
-                        a.q_out[(size_t)b * a.Hq * D + lrow] = ob;
-                    } else {
-                        const int64_t slot = a.slot_mapping[b];
-                        if (slot >= 0) {
-                            uint16_t* cache = (segi[r] == 1) ? a.kcache : a.vcache;
-                            if (a.kv_layout == MI355_KV_FLASH) {
-                                cache[(slot * a.Hkv + hh) * D + d] = ob;
-                            } else {
-                                const int64_t blk = slot / a.block_size, off = slot % a.block_size;
-                                if (segi[r] == 1)
-                                    cache[((((blk * a.Hkv + hh) * (D / 8) + d / 8) * a.block_size + off) * 8) + d % 8] = ob;
-                                else
-                                    cache[((blk * a.Hkv + hh) * D + d) * (int64_t)a.block_size + off] = ob;
-                            }
-                        }
-                    }
-                }
-            }
-    }
-}
-
-
 // ================================================================================================
-// Wide path, second generation: GEMM and epilogue split.  The first generation (above) keeps one wave on a row tile
-// for ALL of K with the epilogue fused, which caps the grid at tiles/NW workgroups and runs 1-2 waves per SIMD at
-// ~200 VGPRs: latency-bound (0.9 TB/s on gate/up at 32 tokens).  Here the GEMM kernel also splits K across
+// GEMM and epilogue are split.  (A first generation kept one wave on a row tile for ALL of K with the epilogue fused,
+// which capped the grid at tiles/NW workgroups and ran 1-2 waves per SIMD at ~200 VGPRs: latency-bound, 0.9 TB/s on
+// gate/up at 32 tokens; removed.)  The GEMM kernel splits K across
 // gridDim.y so that every launch has >= ~2048 waves, stays under 128 VGPRs (4 waves per SIMD, two 8-wave workgroups
 // per CU), stages the activation image global -> LDS by DMA (no staging registers), and writes f32 partial sums
 // [ks][token][row]; a small second kernel adds the partials and applies the epilogue (deterministic: no atomics).
@@ -1669,65 +1391,17 @@ static int qmp_launch(const QmmArgs& a0, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-static uint8_t* g_qmw_img = nullptr;
-static size_t g_qmw_img_bytes = 0;
-
-template <int MT, int R, int WT>
-static int qmw_launch(const QmmArgs& a, int n_slots, hipStream_t st) {
-    const int nkb = a.K / 256;
-    const size_t kbb = qmw_kb_bytes(MT), need = kbb * nkb;
-    if (need > g_qmw_img_bytes) {             // grow-only workspace; the host layer's eager warm-up step sizes it
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return (int)hipErrorStreamCaptureUnsupported;
-        if (g_qmw_img) { (void)hipDeviceSynchronize(); (void)hipFree(g_qmw_img); g_qmw_img = nullptr; g_qmw_img_bytes = 0; }
-        const size_t cap = need * 2;
-        hipError_t e = hipMalloc((void**)&g_qmw_img, cap);
-        if (e != hipSuccess) return (int)e;
-        g_qmw_img_bytes = cap;
-    }
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)qmm_wide_kernel<MT, R, WT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)qmm_wide_kernel<MT, R, WT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((qmm_prep_kernel<MT>), dim3(MT * 8), dim3(256), 0, st, g_qmw_img, a, kbb);
-    // 8 waves per workgroup share one image copy; 4 when that is needed to put a workgroup on every CU;
-    // narrow outputs with the in-place residual epilogue additionally split K (atomic accumulation)
-    if ((n_slots + 8 * R - 1) / (8 * R) >= 256) {
-        hipLaunchKernelGGL((qmm_wide_kernel<MT, R, WT, 8>), dim3((n_slots + 8 * R - 1) / (8 * R)), dim3(512), 2 * kbb, st, a, g_qmw_img);
-    } else {
-        const int nx = (n_slots + 4 * R - 1) / (4 * R);
-        int ks = 1;
-        if (a.epi == MI355_EPI_RESID && a.out == a.resid)
-            while (nx * ks < 256 && nkb / (ks * 2) >= 4) ks *= 2;
-        hipLaunchKernelGGL((qmm_wide_kernel<MT, R, WT, 4>), dim3(nx, ks), dim3(256), 2 * kbb, st, a, g_qmw_img);
-    }
-    return (int)hipGetLastError();
-}
-
-template <int MT>
-static int qmw_launch_mt(const QmmArgs& a, int wt, hipStream_t st) {
-    (void)wt;   // the type-generic instantiation (runtime tile type) is the one hipcc allocates without spills
-    const int n_slots = a.paired ? 2 * a.seg[0].n_tiles : a.seg[0].n_tiles + (a.nseg > 1 ? a.seg[1].n_tiles : 0) +
-                                                         (a.nseg > 2 ? a.seg[2].n_tiles : 0);
-    if (a.paired) return qmw_launch<MT, 2, 0>(a, n_slots, st);      // gate/up pairs must sit in one wave
-    return qmw_launch<MT, 1, 0>(a, n_slots, st);
-}
-
 // ------------------------------------------------------------------------------------------------ launcher
 void mi355_pa_set_fused(int v);
 void mi355_pa_set_wpb(int v);
 extern "C" void mi355_host_set_partition_override(int v);
 static int g_tune_nw = 0, g_tune_r = 0, g_tune_dbg = 0;   // 0 = heuristic; mi355_set_tuning (experiments only)
 static int g_tune_prefill_gemm = 1;                        // 0 = always stream the quantised weights (experiments)
-static int g_tune_wide = 2;                                // wide path generation (1 = fused single-pass, 2 = split GEMM + epilogue)
 extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     if (key == 0) g_tune_nw = value;
     else if (key == 1) g_tune_r = value;
     else if (key == 2) g_tune_dbg = value;
     else if (key == 3) mi355_pa_set_fused(value);
-    else if (key == 4) g_tune_wide = value;
     else if (key == 5) mi355_host_set_partition_override(value);
     else if (key == 6) g_tune_prefill_gemm = value;
     else if (key == 8) mi355_pa_set_wpb(value);
@@ -1876,13 +1550,9 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
             a.positions = pos0 ? pos0 + b0 : nullptr;
             a.slot_mapping = slot0 ? slot0 + b0 : nullptr;
             int rcw;
-            if (g_tune_wide == 2 || a.kv_layout == MI355_KV_PAGED_FP8) {
-                if (bn <= 16) rcw = qmg_launch<2>(a, st);
-                else if (bn <= 24) rcw = qmg_launch<3>(a, st);
-                else rcw = qmg_launch<4>(a, st);
-            } else if (bn <= 16) rcw = qmw_launch_mt<2>(a, wt, st);
-            else if (bn <= 24) rcw = qmw_launch_mt<3>(a, wt, st);
-            else rcw = qmw_launch_mt<4>(a, wt, st);
+            if (bn <= 16) rcw = qmg_launch<2>(a, st);
+            else if (bn <= 24) rcw = qmg_launch<3>(a, st);
+            else rcw = qmg_launch<4>(a, st);
             if (rcw) return rcw;
             b0 += bn;
             continue;

@@ -232,7 +232,10 @@ int mi355_moe_route(int32_t* expert_ids, float* weights, const float* x, const f
  * adds into ys (the residual stream), else overwrites */
 int mi355_moe_combine(float* ys, const float* y_pairs, const float* weights, int32_t num_tokens, int32_t hidden,
                       int32_t top_k, int32_t accumulate, int64_t stream);
-/* experiment knob (0: waves per workgroup, 1: row tiles per workgroup; value 0 = heuristic) */
+/* experiment knobs, never needed for correct results (value 0 = default unless noted): 0 waves per workgroup,
+ * 1 row tiles per workgroup, 2 probe modes of the mat-vec (1 stream only, 3 no staging, 4 no epilogue), 3 fused attention
+ * merge (0 off, 1 auto, 2 always), 5 attention partition override, 6 prompt-step GEMM (1 on), 8 attention waves per
+ * workgroup (1 | 4), 9 chained wide launches (1 on) */
 void mi355_set_tuning(int32_t key, int32_t value);
 
 /* ---------------------------------------------------------------------------------------------
