@@ -744,7 +744,7 @@ __global__ void __launch_bounds__(512) qmm_moe_kernel(const QmmArgs a_in) {
 // workgroup own different row tiles and sweep K together, sharing one LDS image of the activations per k-block
 // (double-buffered, one barrier per k-block).  The image (hi/lo bf16 fragments + sub-block sums, RMSNorm weight already
 // applied) is produced by `qmg_prep_entry` -- in the staging launch or in the previous mat-mul's epilogue.
-//   image of k-block kb:  ximg [32 entries][MT*16 rows][16 B] | S fragments [MT][4][16][4 bf16] | xs16 [16][2][MT*8] f32
+//   image of k-block kb:  ximg [32 entries][MT*16 rows][16 B] | S32 fragments [MT][4][16][4 bf16] | S16 fragments [MT][4][16][8 bf16]
 //   rows of M-tile mt: mt*16 + m, m<8 = hi(batch 8mt+m), m>=8 = lo(batch 8mt+m-8)
 #define QMW_MAXMT 4
 
@@ -807,14 +807,32 @@ __device__ __forceinline__ void wide_q4k2(const TileRegs& w, const uint8_t* __re
     }
 }
 
-template <int MT, bool PIN = true>
+// Q6_K on the wide path: the "-32 +128" code offset (160) is removed by ONE K=32 MFMA per m-tile against the staged
+// 16-element sub-block sums, T = sum_s sc_s S_s  ->  y -= 160 d T, instead of 4 FMAs per MFMA and token group.
+__device__ __forceinline__ uint32_t i8pair_to_bf16x2(uint32_t w, int lo_shift) {
+    const float f0 = (float)(int)(int8_t)((w >> lo_shift) & 0xFF), f1 = (float)(int)(int8_t)((w >> (lo_shift + 8)) & 0xFF);
+    return (__float_as_uint(f0) >> 16) | (__float_as_uint(f1) & 0xFFFF0000u);      // |integers| <= 128: exact in bf16
+}
+template <int MT>
 __device__ __forceinline__ void wide_q6k(const TileRegs& w, const uint8_t* __restrict__ L, int lane, float (&y)[MT][4]) {
-    constexpr int BP = MT * 8;
     const int m = lane & 15, kg = lane >> 4;
-    const float* xs16 = reinterpret_cast<const float*>(L + (size_t)32 * MT * 16 * 16) + 8 * 2 * BP;
+    const uint8_t* sf16 = L + (size_t)32 * MT * 16 * 16 + (size_t)MT * 512;     // [MT][kg 4][row 16][8 bf16]
     const float d = f16_bits_to_f32((uint16_t)(w.e & 0xFFFF));
     const uint32_t scw[4] = {w.a.x, w.a.y, w.a.z, w.a.w};
     const uint32_t qhw[4] = {w.d.x, w.d.y, w.d.z, w.d.w};
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    {   // B fragment of the offset MFMA: k = 8kg + e  <->  sub-block s = 8(kg & 1) + e (both pieces of S use the same scales)
+        const uint32_t s_lo = (kg & 1) ? scw[2] : scw[0], s_hi = (kg & 1) ? scw[3] : scw[1];
+        const uint4 sb = make_uint4(i8pair_to_bf16x2(s_lo, 0), i8pair_to_bf16x2(s_lo, 16), i8pair_to_bf16x2(s_hi, 0), i8pair_to_bf16x2(s_hi, 16));
+        const float nd160 = -160.f * d;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const uint4 sa = *reinterpret_cast<const uint4*>(sf16 + ((size_t)(mt * 4 + kg) * 16 + m) * 16);
+            const f32x4_t t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, sa), __builtin_bit_cast(bf16x8_t, sb), zero, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) y[mt][v] = fmaf(nd160, t[v], y[mt][v]);
+        }
+    }
     uint32_t bmask = 0x00FF00FFu;
     asm volatile("" : "+v"(bmask));
 #pragma unroll
@@ -835,24 +853,15 @@ __device__ __forceinline__ void wide_q6k(const TileRegs& w, const uint8_t* __res
                 bw.x = (t[tt] & bmask) | BF16_128;
                 bw.y = ((t[tt] >> 8) & bmask) | BF16_128;
                 const int sc8 = (int)(int8_t)((scw[s >> 2] >> (8 * (s & 3))) & 0xFF);
-                const float dsc = d * (float)sc8, c160 = -160.f * dsc;
+                const float dsc = d * (float)sc8;
                 const uint8_t* abase = L + ((size_t)(2 * s + (kg >> 1)) * (MT * 16) + m) * 16 + (kg & 1) * 8;
-                const float* xsj = xs16 + ((size_t)s * 2 + (kg >> 1)) * BP + 4 * (kg & 1);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const uint2 aw = *reinterpret_cast<const uint2*>(abase + (size_t)mt * 16 * 16);
-                    const float4 xsv = *reinterpret_cast<const float4*>(xsj + 8 * mt);
-                    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
                     const f32x4_t acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, aw),
                                                                                   __builtin_bit_cast(s16x4_t, bw), zero, 0, 0, 0);
-                    y[mt][0] = fmaf(dsc, acc[0], fmaf(c160, xsv.x, y[mt][0]));
-                    y[mt][1] = fmaf(dsc, acc[1], fmaf(c160, xsv.y, y[mt][1]));
-                    y[mt][2] = fmaf(dsc, acc[2], fmaf(c160, xsv.z, y[mt][2]));
-                    y[mt][3] = fmaf(dsc, acc[3], fmaf(c160, xsv.w, y[mt][3]));
-                }
-                if (PIN) {
-                    asm volatile("" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) y[mt][v] = fmaf(dsc, acc[v], y[mt][v]);
                 }
             }
         }
@@ -879,7 +888,6 @@ __device__ __forceinline__ void qmg_prep_entry(uint8_t* __restrict__ img, float*
                                                const int kb, const int b, const int El) {
     const int BP = MT * 8;
     uint8_t* kbase = img + (size_t)kb * kbb;
-    float* xs16 = reinterpret_cast<float*>(kbase + (size_t)32 * MT * 16 * 16) + 8 * 2 * BP;   // after the 512*MT-byte S-fragment planes
     const int mt = b >> 3, m = b & 7;
     const int k = kb * 256 + El * 8;
     float ss = 0.f;
@@ -906,8 +914,15 @@ __device__ __forceinline__ void qmg_prep_entry(uint8_t* __restrict__ img, float*
     const float h16 = hsum + __shfl_xor(hsum, 1, 64), l16 = lsum + __shfl_xor(lsum, 1, 64);
     const float h32 = h16 + __shfl_xor(h16, 2, 64), l32 = l16 + __shfl_xor(l16, 2, 64);
     if ((El & 1) == 0) {
-        xs16[((El >> 1) * 2 + 0) * BP + b] = h16;
-        xs16[((El >> 1) * 2 + 1) * BP + b] = l16;
+        // 16-element sub-block sums (Q6_K) as the A operand of a K=32 MFMA: per m-tile [kg 4][row 16][8 bf16],
+        // k = 16*piece + s (piece 0 = bf16(S), piece 1 = bf16(S - piece 0)), rows as below
+        const int s16 = El >> 1;
+        uint8_t* sf16 = kbase + (size_t)32 * MT * 16 * 16 + (size_t)MT * 512 + (size_t)mt * 1024;
+        const uint16_t hh = f32_to_bf16(h16), lh = f32_to_bf16(l16);
+        const uint16_t hl = f32_to_bf16(h16 - bf16_to_f32(hh)), ll = f32_to_bf16(l16 - bf16_to_f32(lh));
+        auto at16 = [&](int piece, int row) { return reinterpret_cast<uint16_t*>(sf16 + ((size_t)(2 * piece + (s16 >> 3)) * 16 + row) * 16) + (s16 & 7); };
+        *at16(0, m) = hh; *at16(1, m) = hl;
+        *at16(0, 8 + m) = lh; *at16(1, 8 + m) = ll;
     }
     if ((El & 3) == 0) {
         // sub-block sums as the A operand of a K=16 MFMA (Q4_K minimum / offset terms, wide_q4k2): per m-tile
@@ -1014,7 +1029,7 @@ __global__ void __launch_bounds__(512, 4) qmm_gemm_kernel(const QmmArgs a, const
         TileRegs nxt = load_tile<WT>(wtype, more ? wbase + (size_t)(kb + 1) * wtb : wbase, more ? lane : 0);
         if (a.dbg == 1) { y[0][0][0] += __uint_as_float(cur.a.x ^ cur.b.y ^ cur.c.z); }
         else if (wtype == MI355_GGML_Q4_K) wide_q4k2<MT>(cur, Lc, lane, y[0]);
-        else wide_q6k<MT, WT == 0>(cur, Lc, lane, y[0]);
+        else wide_q6k<MT>(cur, Lc, lane, y[0]);
         cur = nxt;
         __syncthreads();                                              // everyone is done with Lc; the loader filled the other buffer
     }
