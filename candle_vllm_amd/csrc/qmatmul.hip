@@ -1161,6 +1161,7 @@ static int g_qmg_cur = 0;
 struct QmgChainState { bool valid; const void* x; int B, K, MT, buf; const float* norm_w; hipStream_t st; };
 static QmgChainState g_qmg_chain = {false, nullptr, 0, 0, 0, 0, nullptr, nullptr};
 static int g_tune_chain = 1;                                  // mi355_set_tuning(9, 0): never chain (A/B experiments)
+static int g_tune_ks_target = 1024;                           // mi355_set_tuning(10, n): split K until a launch has n row-tile x k-split slots
 static float* g_qmg_part = nullptr;
 static size_t g_qmg_part_bytes = 0;
 
@@ -1184,9 +1185,11 @@ static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
     for (int s = 0; s < a.nseg; ++s) n_slots += a.seg[s].n_tiles;
     const int ldp = n_slots * 16;
     const size_t kbb = qmg_kb_bytes(MT);
-    // split K until the launch has >= 2048 waves (8 per CU), keeping >= 2 k-blocks per workgroup
+    // split K until the launch has >= 1024 (row tile, k-split) slots = 4 consumer waves per CU, keeping >= 2 k-blocks per
+    // workgroup.  (Measured at batch 32: targets 512 / 768 / 1024 / 1280 / 1536 / 2048 / 4096 -> 4081 / 4634 / 4835-4900 /
+    // 4737 / 4742 / 4686 / 4607 tok/s: less splitting = fewer partial sums for the epilogue and longer pipelines.)
     int ks = 1;
-    while (n_slots * ks < 2048 && nkb / (ks * 2) >= 2) ks *= 2;
+    while (n_slots * ks < g_tune_ks_target && nkb / (ks * 2) >= 2) ks *= 2;
     // activation image: staged by the previous launch's epilogue (chain) or by the prep kernel now
     const bool chained = g_qmg_chain.valid && g_qmg_chain.x == a.x && g_qmg_chain.B == a.B && g_qmg_chain.K == a.K &&
                          g_qmg_chain.MT == MT && g_qmg_chain.norm_w == a.norm_w && g_qmg_chain.st == st &&
@@ -1421,6 +1424,7 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     else if (key == 6) g_tune_prefill_gemm = value;
     else if (key == 8) mi355_pa_set_wpb(value);
     else if (key == 9) g_tune_chain = value;
+    else if (key == 10 && value > 0) g_tune_ks_target = value;
 }
 
 static size_t qmm_lds_bytes(int BT, int R, int NW) {
