@@ -330,7 +330,7 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
                                                    scale, 0.f, 1.f, 1.f, dt, stream));
             } else {
                 int ps = choose_partition(T, Hkv, max_context_len);
-                if (ps > 0) ps = ps <= 32 ? 32 : 64;   // MFMA kernel: 64-token partitions keep 4 waves/SIMD (128 VGPRs) and short rounds (+6 % at batch 32 vs 128)
+                if (ps > 0) ps = 32;   // MFMA kernel: 32-token partitions, 4 per workgroup (measured at batch 32: 32 -> 4937, 64 -> 4784, 128 -> ~4500 tok/s)
                 if (ps > 0 && (max_context_len + ps - 1) / ps > m->pa_cap_partitions) return (int)hipErrorInvalidValue;
                 DCHECK(mi355_paged_attention_fp8(m->attn, m->pa_sum, m->pa_max, m->pa_tmp, m->q, m->kcache[l], m->vcache[l],
                                                  block_tables, context_lens, T, H, Hkv, D, c.block_size, max_blocks,
@@ -345,7 +345,7 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
                                            max_blocks, scale, 0.f, c.kv_layout, dt, stream));
         } else {
             int ps = choose_partition(T, Hkv, max_context_len);
-            if (ps > 0 && c.kv_layout == MI355_KV_PAGED) ps = ps <= 32 ? 32 : 64;   // MFMA kernel: 64-token partitions keep 4 waves/SIMD (128 VGPRs) and short rounds (+6 % at batch 32 vs 128)
+            if (ps > 0 && c.kv_layout == MI355_KV_PAGED) ps = 32;   // MFMA kernel: 32-token partitions, 4 per workgroup (measured at batch 32: 32 -> 4937, 64 -> 4784, 128 -> ~4500 tok/s)
             if (ps > 0 && (max_context_len + ps - 1) / ps > m->pa_cap_partitions) return (int)hipErrorInvalidValue;
             if (ps == 0)
                 DCHECK(mi355_paged_attention_v1(m->attn, m->q, m->kcache[l], m->vcache[l], block_tables, context_lens, T, H,

@@ -312,7 +312,7 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
                                                in.max_seqlen_q, H, Hkv, D, c.block_size, in.max_blocks, scale, 0.f, 1.f, 1.f,
                                                MI355_DTYPE_BF16, st);
         int ps = choose_partition(B, Hkv, in.ctx_cap);
-        if (ps > 0) ps = ps <= 32 ? 32 : 64;   // MFMA kernel: 64-token partitions keep 4 waves/SIMD (128 VGPRs) and short rounds (+6 % at batch 32 vs 128)
+        if (ps > 0) ps = 32;   // MFMA kernel: 32-token partitions, 4 per workgroup (measured at batch 32: 32 -> 4937, 64 -> 4784, 128 -> ~4500 tok/s)
         if (ps > 0 && (in.ctx_cap + ps - 1) / ps > m->pa_cap_partitions) return (int)hipErrorInvalidValue;
         return mi355_paged_attention_fp8(in.attn, m->pa_sum, m->pa_max, m->pa_tmp, in.q, m->kcache[l], m->vcache[l], in.bt, in.ctx,
                                          B, H, Hkv, D, c.block_size, in.max_blocks, in.ctx_cap, ps, scale, 0.f, 1.f, 1.f, st);
@@ -326,7 +326,7 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
     if (part == PART_ATTN) {
         // --- paged attention over the cache (the new token's K/V are already in place)
         int ps = choose_partition(B, Hkv, in.ctx_cap);
-        if (ps > 0 && c.kv_layout == MI355_KV_PAGED) ps = ps <= 32 ? 32 : 64;   // MFMA kernel: 64-token partitions keep 4 waves/SIMD (128 VGPRs) and short rounds (+6 % at batch 32 vs 128)   // MFMA kernel sizes
+        if (ps > 0 && c.kv_layout == MI355_KV_PAGED) ps = 32;   // MFMA kernel: 32-token partitions, 4 per workgroup (measured at batch 32: 32 -> 4937, 64 -> 4784, 128 -> ~4500 tok/s)   // MFMA kernel sizes
         if (g_host_ps_override > 0 && ps > 0) ps = g_host_ps_override;
         const float scale = 1.0f / sqrtf((float)D);
         if (ps > 0 && (in.ctx_cap + ps - 1) / ps > m->pa_cap_partitions) return (int)hipErrorInvalidValue;
