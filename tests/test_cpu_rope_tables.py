@@ -61,3 +61,33 @@ def test_bad_arguments_are_rejected():
     assert lib.mi355_rope_tables(buf.ctypes.data, buf.ctypes.data, 7, 4, 1e4, None, 4, 0) != 0      # odd rotary dim
     sc.type = 9
     assert lib.mi355_rope_table_len(ctypes.byref(sc), 4, 0) == -1
+
+
+def test_rope_tables_match_committed_golden_rows():
+    """fixture made by tests/golden/make_golden_rope.py: pins the oracle AND the library's builder"""
+    import json
+    import os
+    import __graft_entry__ as ge
+    ge.build()
+    from candle_vllm_amd._lib import lib, RopeScaling
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rope_tables.json")))
+    for name, g in gold.items():
+        a = g["args"]
+        oc, osn = O.rope_tables_scaled(a["theta"], a["dim"], a["max_seq"], a["scaling"], a["mpe"])
+        sc = None
+        if a["scaling"] is not None:
+            sc = RopeScaling()
+            sc.type = TYPES[a["scaling"]["rope_type"]]
+            for k in ("factor", "low_freq_factor", "high_freq_factor", "original_max_position_embeddings", "alpha",
+                      "beta_fast", "beta_slow", "attn_factor", "extrapolation_factor"):
+                setattr(sc, k, float(a["scaling"].get(k, 0.0)))
+        scp = ctypes.byref(sc) if sc is not None else None
+        n = lib.mi355_rope_table_len(scp, a["max_seq"], a["mpe"])
+        assert n == g["n"] == oc.shape[0]
+        cos = np.empty((n, a["dim"] // 2), np.float32)
+        sin = np.empty_like(cos)
+        assert lib.mi355_rope_tables(cos.ctypes.data, sin.ctypes.data, a["dim"], n, a["theta"], scp, a["max_seq"], a["mpe"]) == 0
+        for r, gc, gs in zip(g["rows"], g["cos"], g["sin"]):
+            tol = max(4e-7, 1.2e-7 * n) * max(1.0, float(np.abs(np.asarray(gc)).max()))
+            assert np.abs(oc[r] - np.asarray(gc, np.float32)).max() <= 1e-7 and np.abs(osn[r] - np.asarray(gs, np.float32)).max() <= 1e-7
+            assert np.abs(cos[r] - np.asarray(gc, np.float32)).max() <= tol and np.abs(sin[r] - np.asarray(gs, np.float32)).max() <= tol
