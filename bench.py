@@ -236,8 +236,11 @@ def main():
     }
     if invalid:
         out["invalid"] = invalid
+    # every rank runs the per-launch-group timing: under TP the groups contain the all-reduce / all-gather, so a
+    # rank-0-only call would wait for its peers forever
+    roofline = gm.dominant_kernel_roofline(stream, HBM_PEAK_GBS)
     if rank == 0:
-        out["roofline"] = gm.dominant_kernel_roofline(stream, HBM_PEAK_GBS)
+        out["roofline"] = roofline
         if do_b32:
             out["batch32"] = bench_batch32(gm, cfg, args, perm, blocks_per_seq, stream, kv_per_tok)
             try:
