@@ -190,5 +190,44 @@ const void* mi355_gguf_tensor_data(void* h, int32_t i) {
     if (i < 0 || i >= (int)g->tensors.size()) return nullptr;
     return g->base + g->data_off + g->tensors[i].offset;
 }
+/* Tensor-parallel shard of tensor i as a raw byte range (no dequantisation): what `QVarBuilder::get_sharded` asks of
+ * candle's `Content::tensor_shard` (layers/quantized_var_builder.rs:135-183).  dim 0 = a contiguous range of rows
+ * (column-parallel weights, `shard(0, rank, W)`), dim 1 = the same block range of every row (row-parallel weights).
+ * Returns the shard's byte count (`out` may be NULL to size the buffer); -1 for a bad argument or a dimension that does
+ * not divide; -2 when a dim-1 shard would cut a quantisation block -- the reference then dequantises, narrows and
+ * re-quantises to Q8_0 (quantized_var_builder.rs:234-269), which changes the weights and is not built here;
+ * -3 when `out_cap` is too small. */
+int64_t mi355_gguf_tensor_shard(void* h, int32_t i, int32_t dim, int32_t rank, int32_t world, void* out, int64_t out_cap) {
+    Gguf* g = G(h);
+    if (!g || i < 0 || i >= (int)g->tensors.size() || world < 1 || rank < 0 || rank >= world) return -1;
+    const TInfo& t = g->tensors[i];
+    if (t.n_dims > 2 || dim < 0 || dim >= (int)t.n_dims) return -1;
+    uint64_t epb = 0, bpb = 0;
+    if (!type_layout(t.type, &epb, &bpb)) return -1;
+    const uint64_t cols = t.dims[0], rows = t.n_dims == 2 ? t.dims[1] : 1;      // GGUF stores the fastest dimension first
+    const uint64_t row_bytes = cols / epb * bpb;
+    const uint8_t* src = g->base + g->data_off + t.offset;
+    uint8_t* dst = static_cast<uint8_t*>(out);
+    const bool split_rows = t.n_dims == 2 && dim == 0;
+    if (split_rows) {
+        if (rows % (uint64_t)world) return -1;
+        const uint64_t n = rows / world * row_bytes;
+        if (dst) {
+            if (out_cap < (int64_t)n) return -3;
+            memcpy(dst, src + (uint64_t)rank * n, n);
+        }
+        return (int64_t)n;
+    }
+    // split along the fastest dimension (dim 1 of a matrix, dim 0 of a vector)
+    if (cols % (uint64_t)world) return -1;
+    const uint64_t c = cols / world;
+    if (c % epb) return -2;
+    const uint64_t seg = c / epb * bpb, n = seg * rows;
+    if (dst) {
+        if (out_cap < (int64_t)n) return -3;
+        for (uint64_t r = 0; r < rows; ++r) memcpy(dst + r * seg, src + r * row_bytes + (uint64_t)rank * seg, seg);
+    }
+    return (int64_t)n;
+}
 
 }  // extern "C"

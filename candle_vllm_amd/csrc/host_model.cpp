@@ -782,9 +782,16 @@ extern "C" float* mi355_llama_logits_ptr(void* mp) {
 }
 
 // ---- GGUFLLaMa::from_gguf (quantized_llama.rs:203-420) over the GGUF reader ------------------------------------
-extern "C" int mi355_llama_load_gguf(const char* path, int32_t max_batch, int32_t max_blocks_per_seq, int32_t block_size,
-                                     int32_t kv_layout, int32_t max_seq, void** model_out, mi355_llama_config* cfg_out) {
-    if (!path || !model_out) return (int)hipErrorInvalidValue;
+// tp_world > 1: every rank reads the same file and keeps its raw byte-range shard of each tensor, as
+// `get_sharded_no_shape` does (quantized_var_builder.rs:135-183,222-233): attn_q / ffn_gate / ffn_up / output on rows,
+// attn_k / attn_v on rows of the kv-head shard (`kv_head_shard`, distributed.rs:725-765: replicated groups when
+// Hkv < W), attn_output / ffn_down on k-blocks; token_embd, the norms and a Mixtral layer's router + experts are
+// loaded whole (quantized_llama.rs:262-268,344-365).  Shards that would need the reference's dequantise -> narrow ->
+// re-quantise fallback (k/W not a multiple of 256, a padded vocabulary) return hipErrorNotSupported.
+namespace {
+int load_gguf_impl(const char* path, int32_t max_batch, int32_t max_blocks_per_seq, int32_t block_size, int32_t kv_layout,
+                   int32_t max_seq, int32_t tp_rank, int32_t tp_world, void** model_out, mi355_llama_config* cfg_out) {
+    if (!path || !model_out || tp_world < 1 || tp_rank < 0 || tp_rank >= tp_world) return (int)hipErrorInvalidValue;
     *model_out = nullptr;
     void* g = mi355_gguf_open(path);
     if (!g) return (int)hipErrorFileNotFound;
@@ -827,18 +834,40 @@ extern "C" int mi355_llama_load_gguf(const char* path, int32_t max_batch, int32_
     cfg.vocab = (int32_t)vocab;
     cfg.max_seq = (max_seq > 0 && (uint64_t)max_seq < ctx_len) ? max_seq : (int32_t)ctx_len;
     cfg.block_size = block_size; cfg.kv_layout = kv_layout; cfg.max_batch = max_batch; cfg.max_blocks_per_seq = max_blocks_per_seq;
-    cfg.rms_eps = (float)eps; cfg.rope_theta = (float)theta; cfg.tp_rank = 0; cfg.tp_world = 1;
+    cfg.rms_eps = (float)eps; cfg.rope_theta = (float)theta; cfg.tp_rank = tp_rank; cfg.tp_world = tp_world;
     cfg.n_expert = n_expert > 1 ? (int32_t)n_expert : 0; cfg.n_expert_used = n_expert > 1 ? (int32_t)n_expert_used : 0;
+    // shard plan of this rank (attention.rs:553-554, distributed.rs:725-765,1446-1452)
+    int kv_rank = tp_rank, kv_world = tp_world;
+    if (tp_world > 1) {
+        if (cfg.n_heads % tp_world) return (int)hipErrorInvalidValue;
+        if (cfg.n_kv_heads >= tp_world) {
+            if (cfg.n_kv_heads % tp_world) return (int)hipErrorInvalidValue;
+        } else {
+            if (tp_world % cfg.n_kv_heads) return (int)hipErrorInvalidValue;
+            kv_rank = tp_rank / (tp_world / cfg.n_kv_heads); kv_world = cfg.n_kv_heads;   // one replicated head per rank
+        }
+        const int64_t pad64 = (vocab + 63) / 64 * 64;
+        const int64_t padded = ((pad64 + tp_world - 1) / tp_world * tp_world + 63) / 64 * 64;
+        if (padded != vocab) return (int)hipErrorNotSupported;    // zero-row padding re-quantises the lm_head (distributed.rs:1601-1612)
+    }
     Model* m = static_cast<Model*>(mi355_llama_create(&cfg));
     if (!m) return (int)hipErrorInvalidValue;
     struct Guard { Model* m; bool keep = false; ~Guard() { if (!keep) mi355_llama_destroy(m); } } guard{m};
 
-    auto load_q = [&](const std::string& name, int layer, int which) -> int {
+    // dim < 0: the whole tensor; dim 0 / 1: this rank's row / k-block shard
+    auto load_q = [&](const std::string& name, int layer, int which, int dim = -1, int rank = 0, int world = 1) -> int {
         int64_t dd[4]; int32_t t; uint64_t n;
         const int i = info(name, dd, &t, &n);
         if (i < 0) return (int)hipErrorInvalidValue;
         if (t != MI355_GGML_Q4_K && t != MI355_GGML_Q6_K) return (int)hipErrorNotSupported;   // other ggml types: out of scope
-        return mi355_llama_set_qweight(m, layer, which, t, mi355_gguf_tensor_data(g, i), (int32_t)dd[0], (int32_t)dd[1]);
+        if (dim < 0 || world <= 1)
+            return mi355_llama_set_qweight(m, layer, which, t, mi355_gguf_tensor_data(g, i), (int32_t)dd[0], (int32_t)dd[1]);
+        const int64_t bytes = mi355_gguf_tensor_shard(g, i, dim, rank, world, nullptr, 0);
+        if (bytes < 0) return bytes == -2 ? (int)hipErrorNotSupported : (int)hipErrorInvalidValue;
+        std::vector<uint8_t> shard((size_t)bytes);
+        if (mi355_gguf_tensor_shard(g, i, dim, rank, world, shard.data(), bytes) != bytes) return (int)hipErrorInvalidValue;
+        const int32_t rows = (int32_t)(dim == 0 ? dd[0] / world : dd[0]), k = (int32_t)(dim == 1 ? dd[1] / world : dd[1]);
+        return mi355_llama_set_qweight(m, layer, which, t, shard.data(), rows, k);
     };
     auto load_f32 = [&](const std::string& name, int layer, int which) -> int {
         int64_t dd[4]; int32_t t; uint64_t n;
@@ -863,13 +892,14 @@ extern "C" int mi355_llama_load_gguf(const char* path, int32_t max_batch, int32_
         return (int)hipErrorNotSupported;
     }
     RCHECK(load_f32("output_norm.weight", -1, MI355_W_OUTPUT_NORM));
-    RCHECK(load_q(mi355_gguf_find(g, "output.weight") >= 0 ? "output.weight" : "token_embd.weight", -1, MI355_W_OUTPUT));
+    RCHECK(load_q(mi355_gguf_find(g, "output.weight") >= 0 ? "output.weight" : "token_embd.weight", -1, MI355_W_OUTPUT,
+                  0, tp_rank, tp_world));
     for (int l = 0; l < cfg.n_layers; ++l) {
         const std::string p = "blk." + std::to_string(l) + ".";
-        RCHECK(load_q(p + "attn_q.weight", l, MI355_W_WQ));
-        RCHECK(load_q(p + "attn_k.weight", l, MI355_W_WK));
-        RCHECK(load_q(p + "attn_v.weight", l, MI355_W_WV));
-        RCHECK(load_q(p + "attn_output.weight", l, MI355_W_WO));
+        RCHECK(load_q(p + "attn_q.weight", l, MI355_W_WQ, 0, tp_rank, tp_world));
+        RCHECK(load_q(p + "attn_k.weight", l, MI355_W_WK, 0, kv_rank, kv_world));
+        RCHECK(load_q(p + "attn_v.weight", l, MI355_W_WV, 0, kv_rank, kv_world));
+        RCHECK(load_q(p + "attn_output.weight", l, MI355_W_WO, 1, tp_rank, tp_world));
         if (cfg.n_expert > 1) {                               // quantized_llama.rs:347-365
             RCHECK(load_f32(p + "ffn_gate_inp.weight", l, MI355_W_GATE_INP));
             for (int e = 0; e < cfg.n_expert; ++e) {
@@ -883,9 +913,9 @@ extern "C" int mi355_llama_load_gguf(const char* path, int32_t max_batch, int32_
                 }
             }
         } else {
-            RCHECK(load_q(p + "ffn_gate.weight", l, MI355_W_W1));
-            RCHECK(load_q(p + "ffn_down.weight", l, MI355_W_W2));
-            RCHECK(load_q(p + "ffn_up.weight", l, MI355_W_W3));
+            RCHECK(load_q(p + "ffn_gate.weight", l, MI355_W_W1, 0, tp_rank, tp_world));
+            RCHECK(load_q(p + "ffn_down.weight", l, MI355_W_W2, 1, tp_rank, tp_world));
+            RCHECK(load_q(p + "ffn_up.weight", l, MI355_W_W3, 0, tp_rank, tp_world));
         }
         RCHECK(load_f32(p + "attn_norm.weight", l, MI355_W_ATTN_NORM));
         RCHECK(load_f32(p + "ffn_norm.weight", l, MI355_W_FFN_NORM));
@@ -894,6 +924,19 @@ extern "C" int mi355_llama_load_gguf(const char* path, int32_t max_batch, int32_
     *model_out = m;
     if (cfg_out) *cfg_out = cfg;
     return 0;
+}
+}  // namespace
+
+extern "C" int mi355_llama_load_gguf(const char* path, int32_t max_batch, int32_t max_blocks_per_seq, int32_t block_size,
+                                     int32_t kv_layout, int32_t max_seq, void** model_out, mi355_llama_config* cfg_out) {
+    return load_gguf_impl(path, max_batch, max_blocks_per_seq, block_size, kv_layout, max_seq, 0, 1, model_out, cfg_out);
+}
+
+extern "C" int mi355_llama_load_gguf_tp(const char* path, int32_t max_batch, int32_t max_blocks_per_seq, int32_t block_size,
+                                        int32_t kv_layout, int32_t max_seq, int32_t tp_rank, int32_t tp_world,
+                                        void** model_out, mi355_llama_config* cfg_out) {
+    return load_gguf_impl(path, max_batch, max_blocks_per_seq, block_size, kv_layout, max_seq, tp_rank, tp_world, model_out,
+                          cfg_out);
 }
 
 // ---- tensor-parallel communicator -----------------------------------------------------------------------------

@@ -83,15 +83,18 @@ class GGUFLLaMa:
             self.h = None
 
     @classmethod
-    def from_gguf(cls, path, max_batch=1, max_blocks_per_seq=64, block_size=64, kv_layout=KV_FLASH, max_seq=0):
+    def from_gguf(cls, path, max_batch=1, max_blocks_per_seq=64, block_size=64, kv_layout=KV_FLASH, max_seq=0,
+                  tp_rank=0, tp_world=1):
         """`GGUFLLaMa::from_gguf` (quantized_llama.rs:203-420): config from the file's metadata, all tensors loaded
-        by the C++ reader (mi355_llama_load_gguf)."""
+        by the C++ reader (mi355_llama_load_gguf); with tp_world > 1 every rank keeps its raw byte-range shard
+        (mi355_llama_load_gguf_tp) and needs `init_comm` / `set_comm` before the first step."""
         if not torch.cuda.is_available():
             raise RuntimeError("GGUFLLaMa needs the MI355X: there is no CPU fallback")
         h = ctypes.c_void_p(0)
         c = LlamaConfig()
-        _check(lib.mi355_llama_load_gguf(str(path).encode(), max_batch, max_blocks_per_seq, block_size, kv_layout,
-                                         max_seq, ctypes.addressof(h), ctypes.addressof(c)), "load_gguf")
+        _check(lib.mi355_llama_load_gguf_tp(str(path).encode(), max_batch, max_blocks_per_seq, block_size, kv_layout,
+                                            max_seq, tp_rank, tp_world, ctypes.addressof(h), ctypes.addressof(c)),
+               "load_gguf")
         self = cls.__new__(cls)
         from types import SimpleNamespace
         self.cfg = SimpleNamespace(hidden=c.hidden, n_layers=c.n_layers, n_heads=c.n_heads, n_kv_heads=c.n_kv_heads,
@@ -99,8 +102,8 @@ class GGUFLLaMa:
                                    block_size=c.block_size, rms_eps=c.rms_eps, rope_theta=c.rope_theta)
         self.c, self.h, self.kv_layout, self.max_batch = c, h.value, kv_layout, max_batch
         self._keep, self.weight_bytes, self.part_bytes = [], 0, {}
-        self.tp_rank, self.tp_world = 0, 1
-        self.local_heads, self.local_kv_heads = c.n_heads, c.n_kv_heads
+        self.tp_rank, self.tp_world = tp_rank, tp_world
+        self.local_heads, self.local_kv_heads = c.n_heads // tp_world, max(c.n_kv_heads // tp_world, 1)
         return self
 
     # ------------------------------------------------------------------ weights

@@ -564,10 +564,26 @@ int32_t mi355_gguf_find(void* gguf, const char* name);
 int32_t mi355_gguf_tensor_info(void* gguf, int32_t i, char* name, int32_t name_cap, int64_t* dims4, int32_t* n_dims,
                                int32_t* ggml_type, uint64_t* nbytes);
 const void* mi355_gguf_tensor_data(void* gguf, int32_t i);
+/* Tensor-parallel shard of tensor i as a raw byte range -- `QVarBuilder::get_sharded` over candle's
+ * `Content::tensor_shard` (quantized_var_builder.rs:135-183): dim 0 = rows [rank*R/W, (rank+1)*R/W) (contiguous),
+ * dim 1 = the same block range of every row.  Host only, no dequantisation.  Returns the shard's bytes (out == NULL
+ * sizes the buffer); -1 bad argument / dimension does not divide; -2 a dim-1 shard would cut a quantisation block (the
+ * reference's dequantise -> narrow -> re-quantise-to-Q8_0 fallback, :234-269, is not built); -3 out_cap too small. */
+int64_t mi355_gguf_tensor_shard(void* gguf, int32_t i, int32_t dim, int32_t rank, int32_t world, void* out, int64_t out_cap);
 /* GGUFLLaMa::from_gguf (quantized_llama.rs:203-420): config from the metadata, every tensor handed to the model
  * (matrices Q4_K / Q6_K re-tiled, token_embd dequantised on the device, norms F32).  *model_out = mi355_llama handle. */
 int mi355_llama_load_gguf(const char* path, int32_t max_batch, int32_t max_blocks_per_seq, int32_t block_size,
                           int32_t kv_layout, int32_t max_seq, void** model_out, mi355_llama_config* cfg_out);
+/* The same under tensor parallelism (quantized_llama.rs:316-371, attention.rs:790-848, distributed.rs:1574-1629): rank
+ * `tp_rank` of `tp_world` reads the file and keeps its shard -- attn_q / ffn_gate / ffn_up / output rows, attn_k / attn_v
+ * rows of `kv_head_shard` (replicated groups when Hkv < W), attn_output / ffn_down k-blocks; token_embd, norms and a
+ * Mixtral layer's router + experts whole.  cfg_out holds the GLOBAL dimensions plus tp_rank / tp_world; attach a
+ * communicator (mi355_llama_init_comm / mi355_llama_set_comm) before the first step.  hipErrorNotSupported when a shard
+ * would need the reference's re-quantisation fallback (k/W not a multiple of 256, or a vocabulary that
+ * `pad_vocab_size` would pad). */
+int mi355_llama_load_gguf_tp(const char* path, int32_t max_batch, int32_t max_blocks_per_seq, int32_t block_size,
+                             int32_t kv_layout, int32_t max_seq, int32_t tp_rank, int32_t tp_world, void** model_out,
+                             mi355_llama_config* cfg_out);
 
 /* ABI guard for bindings that mirror the structs by hand (ctypes, a Rust #[repr(C)]): sizeof of
  * 0 = mi355_qmm_desc, 1 = mi355_llama_config, 2 = mi355_dense_config, 3 = mi355_rope_scaling; -1 for an unknown id */
