@@ -91,3 +91,40 @@ def test_rope_tables_match_committed_golden_rows():
             tol = max(4e-7, 1.2e-7 * n) * max(1.0, float(np.abs(np.asarray(gc)).max()))
             assert np.abs(oc[r] - np.asarray(gc, np.float32)).max() <= 1e-7 and np.abs(osn[r] - np.asarray(gs, np.float32)).max() <= 1e-7
             assert np.abs(cos[r] - np.asarray(gc, np.float32)).max() <= tol and np.abs(sin[r] - np.asarray(gs, np.float32)).max() <= tol
+
+
+def test_rope_scaling_matches_huggingface_inverse_frequencies():
+    """third-party anchor (tests/golden/rope_hf.json, made by tests/golden/make_golden_rope_hf.py from transformers'
+    ROPE_INIT_FUNCTIONS): the oracle's restatement of the reference AND the library's builder must reproduce
+    cos/sin(position * inv_freq_HF) * attention_factor_HF for llama3 / linear / yarn.  Tolerance: the angle is formed in
+    f32 (position * inv_freq), so an entry may be off by the angle's rounding, angle * 2^-22, plus table rounding."""
+    import json
+    import os
+    import __graft_entry__ as ge
+    ge.build()
+    from candle_vllm_amd._lib import lib, RopeScaling
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rope_hf.json")))
+    for name, g in gold.items():
+        if name.startswith("_"):
+            continue
+        a = g["args"]
+        inv, att = np.asarray(g["inv_freq"], np.float64), float(g["attention_factor"])
+        oc, osn = O.rope_tables_scaled(a["theta"], a["dim"], a["max_seq"], a["scaling"], a["mpe"])
+        sc = RopeScaling()
+        sc.type = TYPES[a["scaling"]["rope_type"]]
+        for k in ("factor", "low_freq_factor", "high_freq_factor", "original_max_position_embeddings", "alpha",
+                  "beta_fast", "beta_slow", "attn_factor", "extrapolation_factor"):
+            setattr(sc, k, float(a["scaling"].get(k, 0.0)))
+        n = lib.mi355_rope_table_len(ctypes.byref(sc), a["max_seq"], a["mpe"])
+        assert n == oc.shape[0] and inv.shape[0] == a["dim"] // 2
+        cos = np.empty((n, a["dim"] // 2), np.float32)
+        sin = np.empty_like(cos)
+        assert lib.mi355_rope_tables(cos.ctypes.data, sin.ctypes.data, a["dim"], n, a["theta"], ctypes.byref(sc),
+                                     a["max_seq"], a["mpe"]) == 0
+        rows = sorted({0, 1, 17, a["max_seq"] // 2, a["max_seq"] - 1, n - 1})
+        for r in rows:
+            ang = r * inv
+            tol = att * (ang * 2.0 ** -22 + 2e-6)
+            for got_c, got_s, who in ((oc[r], osn[r], "oracle"), (cos[r], sin[r], "library")):
+                assert (np.abs(got_c - np.cos(ang) * att) <= tol).all(), (name, who, r, np.abs(got_c - np.cos(ang) * att).max())
+                assert (np.abs(got_s - np.sin(ang) * att) <= tol).all(), (name, who, r, np.abs(got_s - np.sin(ang) * att).max())
