@@ -399,8 +399,9 @@ def prefill_attention(q, k, v, scale, softcap=None, cached=0, rnd=None):
 def f32_to_e4m3fn(x):
     """f32 -> OCP e4m3fn bytes (uint8): RNE, saturate to +-448 (0x7E), NaN -> 0x7F."""
     x = np.asarray(x, np.float32)
+    isnan = np.isnan(x)
     sign = (np.signbit(x)).astype(np.uint8) << 7
-    a = np.minimum(np.abs(x.astype(np.float64)), 448.0)
+    a = np.minimum(np.abs(np.where(isnan, np.float32(0), x).astype(np.float64)), 448.0)   # NaN lanes are overwritten below
     out = np.zeros(x.shape, np.uint8)
     nz = a > 0
     e = np.floor(np.log2(a, where=nz, out=np.zeros_like(a)))
@@ -414,7 +415,7 @@ def f32_to_e4m3fn(x):
     normal = man >= 8
     bits = np.where(normal, ((e2 + 7).astype(np.int64) << 3) | (man - 8), man)
     out = np.where(nz, bits, 0).astype(np.uint8)
-    out = np.where(np.isnan(x), np.uint8(0x7F), out | sign)
+    out = np.where(isnan, np.uint8(0x7F), out | sign)
     return out.astype(np.uint8)
 
 
