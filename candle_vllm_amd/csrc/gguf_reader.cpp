@@ -35,8 +35,9 @@ struct Gguf {
 
 struct Cur {
     const uint8_t* p; const uint8_t* end; bool ok = true;
-    template <typename T> T rd() { T v{}; if (p + sizeof(T) > end) { ok = false; return v; } memcpy(&v, p, sizeof(T)); p += sizeof(T); return v; }
-    std::string str() { const uint64_t n = rd<uint64_t>(); if (!ok || p + n > end) { ok = false; return {}; } std::string s((const char*)p, n); p += n; return s; }
+    template <typename T> T rd() { T v{}; if (!ok || sizeof(T) > (size_t)(end - p)) { ok = false; return v; } memcpy(&v, p, sizeof(T)); p += sizeof(T); return v; }
+    // lengths come from the file: compare against the bytes that are left, never form p + n (it may wrap)
+    std::string str() { const uint64_t n = rd<uint64_t>(); if (!ok || n > (uint64_t)(end - p)) { ok = false; return {}; } std::string s((const char*)p, n); p += n; return s; }
 };
 
 // bytes of `n` elements of ggml type t (block formats: elements per block / bytes per block)
@@ -93,14 +94,19 @@ Gguf* G(void* p) { return static_cast<Gguf*>(p); }
 
 extern "C" {
 
-void* mi355_gguf_open(const char* path) {
+void mi355_gguf_close(void* h);
+
+static void* gguf_open_impl(const char* path) {
+    if (!path) return nullptr;
     Gguf* g = new Gguf();
+    struct Guard { Gguf* g; ~Guard() { if (g) mi355_gguf_close(g); } } guard{g};     // every early exit and every throw cleans up
     g->fd = open(path, O_RDONLY);
     struct stat st;
-    if (g->fd < 0 || fstat(g->fd, &st) != 0) { if (g->fd >= 0) close(g->fd); delete g; return nullptr; }
+    if (g->fd < 0 || fstat(g->fd, &st) != 0) return nullptr;
     g->size = (size_t)st.st_size;
+    if (g->size < 24) return nullptr;                                       // magic + version + two counts
     void* m = mmap(nullptr, g->size, PROT_READ, MAP_PRIVATE, g->fd, 0);
-    if (m == MAP_FAILED) { close(g->fd); delete g; return nullptr; }
+    if (m == MAP_FAILED) return nullptr;
     g->base = static_cast<const uint8_t*>(m);
     Cur c{g->base, g->base + g->size};
     const uint32_t magic = c.rd<uint32_t>();
@@ -126,23 +132,34 @@ void* mi355_gguf_open(const char* path) {
         uint64_t epb = 0, bpb = 0;
         ok = ok && c.ok && type_layout(t.type, &epb, &bpb);
         if (ok) {
+            // element and byte counts with overflow checks: the dims are untrusted, and every later slice trusts nbytes
             uint64_t n = 1;
-            for (uint32_t d = 0; d < t.n_dims; ++d) n *= t.dims[d];
-            ok = (t.dims[0] % epb) == 0;
-            t.nbytes = n / epb * bpb;
+            for (uint32_t d = 0; ok && d < t.n_dims; ++d) ok = !__builtin_mul_overflow(n, t.dims[d], &n);
+            ok = ok && (t.dims[0] % epb) == 0 && !__builtin_mul_overflow(n / epb, bpb, &t.nbytes);
+        }
+        if (ok) {
             g->index[t.name] = (int)g->tensors.size();
             g->tensors.push_back(t);
         }
     }
     if (ok) {
         auto al = g->kv.find("general.alignment");
-        if (al != g->kv.end() && al->second.u > 0) g->alignment = (uint32_t)al->second.u;
+        if (al != g->kv.end()) {
+            if (al->second.u == 0 || al->second.u > (1u << 20)) ok = false;      // a zero or absurd alignment is a broken file
+            else g->alignment = (uint32_t)al->second.u;
+        }
         const uint64_t pos = (uint64_t)(c.p - g->base);
         g->data_off = (pos + g->alignment - 1) / g->alignment * g->alignment;
-        for (auto& t : g->tensors) if (g->data_off + t.offset + t.nbytes > g->size) ok = false;
+        ok = ok && g->data_off <= g->size;
+        const uint64_t room = ok ? g->size - g->data_off : 0;
+        for (auto& t : g->tensors) if (t.offset > room || t.nbytes > room - t.offset) ok = false;
     }
-    if (!ok) { munmap(m, g->size); close(g->fd); delete g; return nullptr; }
+    if (!ok) return nullptr;
+    guard.g = nullptr;
     return g;
+}
+void* mi355_gguf_open(const char* path) {
+    try { return gguf_open_impl(path); } catch (...) { return nullptr; }      // bad_alloc / length_error never cross the C ABI
 }
 void mi355_gguf_close(void* h) {
     Gguf* g = G(h);
@@ -151,32 +168,35 @@ void mi355_gguf_close(void* h) {
     if (g->fd >= 0) close(g->fd);
     delete g;
 }
-int32_t mi355_gguf_version(void* h) { return (int32_t)G(h)->version; }
-int32_t mi355_gguf_n_tensors(void* h) { return (int32_t)G(h)->tensors.size(); }
+int32_t mi355_gguf_version(void* h) { return h ? (int32_t)G(h)->version : -1; }
+int32_t mi355_gguf_n_tensors(void* h) { return h ? (int32_t)G(h)->tensors.size() : -1; }
 /* metadata: returns 1 when the key exists with a compatible type */
 int32_t mi355_gguf_get_u64(void* h, const char* key, uint64_t* out) {
+    if (!h || !key || !out) return 0;
     auto it = G(h)->kv.find(key);
     if (it == G(h)->kv.end() || it->second.type == T_STRING || it->second.type == T_ARRAY || it->second.type == T_F32 || it->second.type == T_F64) return 0;
     *out = it->second.u; return 1;
 }
 int32_t mi355_gguf_get_f64(void* h, const char* key, double* out) {
+    if (!h || !key || !out) return 0;
     auto it = G(h)->kv.find(key);
     if (it == G(h)->kv.end() || (it->second.type != T_F32 && it->second.type != T_F64)) return 0;
     *out = it->second.f; return 1;
 }
 int32_t mi355_gguf_get_str(void* h, const char* key, char* out, int32_t cap) {
+    if (!h || !key) return -1;
     auto it = G(h)->kv.find(key);
     if (it == G(h)->kv.end() || it->second.type != T_STRING) return -1;
     const int n = (int)it->second.s.size();
     if (out && cap > 0) { const int k = n < cap - 1 ? n : cap - 1; memcpy(out, it->second.s.data(), k); out[k] = 0; }
     return n;
 }
-int32_t mi355_gguf_find(void* h, const char* name) { auto it = G(h)->index.find(name); return it == G(h)->index.end() ? -1 : it->second; }
+int32_t mi355_gguf_find(void* h, const char* name) { if (!h || !name) return -1; auto it = G(h)->index.find(name); return it == G(h)->index.end() ? -1 : it->second; }
 /* dims are returned slowest-first ([rows, cols] for a matrix, as candle reports shapes; GGUF stores fastest-first) */
 int32_t mi355_gguf_tensor_info(void* h, int32_t i, char* name, int32_t name_cap, int64_t* dims4, int32_t* n_dims, int32_t* ggml_type,
                                uint64_t* nbytes) {
     Gguf* g = G(h);
-    if (i < 0 || i >= (int)g->tensors.size()) return -1;
+    if (!g || i < 0 || i >= (int)g->tensors.size()) return -1;
     const TInfo& t = g->tensors[i];
     if (name && name_cap > 0) { const int k = (int)t.name.size() < name_cap - 1 ? (int)t.name.size() : name_cap - 1; memcpy(name, t.name.data(), k); name[k] = 0; }
     if (dims4) for (uint32_t d = 0; d < 4; ++d) dims4[d] = d < t.n_dims ? (int64_t)t.dims[t.n_dims - 1 - d] : 1;
@@ -187,7 +207,7 @@ int32_t mi355_gguf_tensor_info(void* h, int32_t i, char* name, int32_t name_cap,
 }
 const void* mi355_gguf_tensor_data(void* h, int32_t i) {
     Gguf* g = G(h);
-    if (i < 0 || i >= (int)g->tensors.size()) return nullptr;
+    if (!g || i < 0 || i >= (int)g->tensors.size()) return nullptr;
     return g->base + g->data_off + g->tensors[i].offset;
 }
 /* Tensor-parallel shard of tensor i as a raw byte range (no dequantisation): what `QVarBuilder::get_sharded` asks of

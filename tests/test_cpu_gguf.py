@@ -171,3 +171,98 @@ def test_load_gguf_tp_rejects_unshardable_files_before_touching_the_gpu(lib, tmp
     assert load(p2, 0, 2) == 1                                    # 3 kv heads over 2 ranks: neither split nor replicated
     with pytest.raises(ValueError):
         tp.kv_head_shard(3, 0, 2)
+
+
+def _walk(lib, g):
+    """touch everything the reader exposes for an opened file (under the sanitizer run this is the bounds check)"""
+    n = lib.mi355_gguf_n_tensors(g)
+    d4 = (ctypes.c_int64 * 4)()
+    nd, ty, nb = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_uint64(0)
+    name = ctypes.create_string_buffer(256)
+    total = 0
+    for i in range(n):
+        assert lib.mi355_gguf_tensor_info(g, i, name, 256, d4, ctypes.addressof(nd), ctypes.addressof(ty), ctypes.addressof(nb)) == 0
+        ptr = lib.mi355_gguf_tensor_data(g, i)
+        if nb.value:
+            raw = np.ctypeslib.as_array((ctypes.c_uint8 * nb.value).from_address(ptr))
+            total += int(raw[0]) + int(raw[-1])                     # first and last byte of the claimed range are mapped
+        for dim in (0, 1):
+            for world in (1, 2):
+                k = lib.mi355_gguf_tensor_shard(g, i, dim, world - 1, world, None, 0)
+                if k > 0:
+                    buf = np.empty(k, np.uint8)
+                    assert lib.mi355_gguf_tensor_shard(g, i, dim, world - 1, world, buf.ctypes.data, k) == k
+    return total
+
+
+def test_reader_survives_corrupted_and_hostile_files(lib, tmp_path):
+    """every length, count, dimension and offset in a GGUF file is untrusted: random byte corruption, truncation at
+    every region, and hand-made hostile headers (string length 2^64-1, dims whose product wraps, offsets past the end,
+    zero / absurd alignment) must be refused or read within bounds -- never crash, never read outside the mapping"""
+    import struct
+    cfg = llama.LlamaConfig.tiny()
+    W = llama.make_weights(cfg, seed=5)
+    good = os.path.join(tmp_path, "good.gguf")
+    GW.llama_to_gguf(good, cfg, W)
+    data = bytearray(open(good, "rb").read())
+    g = lib.mi355_gguf_open(good.encode())
+    assert g
+    _walk(lib, g)
+    lib.mi355_gguf_close(g)
+    header_end = data.find(b"blk.0.attn_q.weight")          # somewhere inside the tensor directory
+    assert header_end > 0
+    rng = np.random.default_rng(2024)
+    p = os.path.join(tmp_path, "fuzz.gguf")
+    opened = 0
+    for trial in range(300):
+        d = bytearray(data)
+        kind = trial % 3
+        if kind == 0:                                        # flip bytes in the header / directory
+            for _ in range(int(rng.integers(1, 6))):
+                d[int(rng.integers(0, header_end + 4096))] = int(rng.integers(0, 256))
+        elif kind == 1:                                      # overwrite an aligned u64 with an extreme value
+            off = int(rng.integers(1, (header_end + 4096) // 8)) * 8
+            extremes = [0, 1, 2**31, 2**32, 2**63, 2**64 - 1, len(data), len(data) + 1]
+            d[off:off + 8] = struct.pack("<Q", extremes[int(rng.integers(0, len(extremes)))])
+        else:                                                # truncate
+            d = d[: int(rng.integers(0, len(d)))]
+        open(p, "wb").write(bytes(d))
+        g = lib.mi355_gguf_open(p.encode())
+        if g:
+            opened += 1
+            _walk(lib, g)
+            lib.mi355_gguf_close(g)
+    assert opened < 300                                      # most corruptions must be caught
+
+    def header(n_tensors, n_kv, body):
+        return struct.pack("<IIQQ", 0x46554747, 3, n_tensors, n_kv) + body
+
+    def s(b):
+        return struct.pack("<Q", len(b)) + b
+    hostile = {
+        "string length 2^64-1": header(0, 1, struct.pack("<Q", 2**64 - 1) + b"abc"),
+        "kv count 2^40": header(0, 2**40, b""),
+        "tensor count past the file": header(5, 0, b""),
+        "dims whose product wraps": header(1, 0, s(b"t") + struct.pack("<IQQIQ", 2, 2**32, 2**32, 0, 0) + b"\0" * 64),
+        "bytes-per-block product wraps": header(1, 0, s(b"t") + struct.pack("<IQIQ", 1, 2**62, 0, 0) + b"\0" * 64),
+        "offset past the end": header(1, 0, s(b"t") + struct.pack("<IQIQ", 1, 8, 0, 2**40) + b"\0" * 64),
+        "offset + size wraps": header(1, 0, s(b"t") + struct.pack("<IQIQ", 1, 8, 0, 2**64 - 8) + b"\0" * 64),
+        "five dimensions": header(1, 0, s(b"t") + struct.pack("<I", 5) + b"\0" * 128),
+        "unknown ggml type": header(1, 0, s(b"t") + struct.pack("<IQIQ", 1, 32, 999, 0) + b"\0" * 64),
+        "zero alignment": header(0, 1, s(b"general.alignment") + struct.pack("<II", 4, 0)),
+        "alignment 2^32": header(0, 1, s(b"general.alignment") + struct.pack("<IQ", 10, 2**32)),
+        "array of 2^60 bytes": header(0, 1, s(b"a") + struct.pack("<IIQ", 9, 0, 2**60) + b"\1" * 16),
+        "nested array": header(0, 1, s(b"a") + struct.pack("<IIQIQ", 9, 9, 1, 0, 1) + b"\1"),
+        "unknown value type": header(0, 1, s(b"a") + struct.pack("<I", 77) + b"\0" * 16),
+        "too short": b"GGUF\x03",
+        "empty": b"",
+    }
+    for what, blob in hostile.items():
+        open(p, "wb").write(blob)
+        assert not lib.mi355_gguf_open(p.encode()), what
+    # accessors on a null handle answer instead of crashing
+    u = ctypes.c_uint64(0)
+    assert lib.mi355_gguf_find(None, b"x") == -1 and lib.mi355_gguf_get_u64(None, b"k", ctypes.addressof(u)) == 0
+    assert lib.mi355_gguf_n_tensors(None) == -1 and lib.mi355_gguf_tensor_shard(None, 0, 0, 0, 1, None, 0) == -1
+    assert not lib.mi355_gguf_tensor_data(None, 0) and not lib.mi355_gguf_open(None)
+    lib.mi355_gguf_close(None)
