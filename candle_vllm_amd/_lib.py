@@ -243,6 +243,7 @@ _sig("mi355_gguf_tensor_info", c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_v
 _sig("mi355_gguf_tensor_data", c_vp, [c_vp, c_i32])
 _sig("mi355_llama_load_gguf", ctypes.c_int, [ctypes.c_char_p] + [c_i32] * 5 + [c_vp, c_vp])
 _sig("mi355_llama_load_gguf_tp", ctypes.c_int, [ctypes.c_char_p] + [c_i32] * 7 + [c_vp, c_vp])
+_sig("mi355_llama_check_gguf", ctypes.c_int, [ctypes.c_char_p, c_i32, c_i32, c_vp])
 _sig("mi355_gguf_tensor_shard", ctypes.c_int64, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, ctypes.c_int64])
 
 

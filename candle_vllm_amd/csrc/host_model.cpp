@@ -790,9 +790,10 @@ extern "C" float* mi355_llama_logits_ptr(void* mp) {
 // re-quantise fallback (k/W not a multiple of 256, a padded vocabulary) return hipErrorNotSupported.
 namespace {
 int load_gguf_impl(const char* path, int32_t max_batch, int32_t max_blocks_per_seq, int32_t block_size, int32_t kv_layout,
-                   int32_t max_seq, int32_t tp_rank, int32_t tp_world, void** model_out, mi355_llama_config* cfg_out) {
-    if (!path || !model_out || tp_world < 1 || tp_rank < 0 || tp_rank >= tp_world) return (int)hipErrorInvalidValue;
-    *model_out = nullptr;
+                   int32_t max_seq, int32_t tp_rank, int32_t tp_world, void** model_out, mi355_llama_config* cfg_out,
+                   bool check_only = false) {
+    if (!path || (!model_out && !check_only) || tp_world < 1 || tp_rank < 0 || tp_rank >= tp_world) return (int)hipErrorInvalidValue;
+    if (model_out) *model_out = nullptr;
     void* g = mi355_gguf_open(path);
     if (!g) return (int)hipErrorFileNotFound;
     struct Closer { void* g; ~Closer() { mi355_gguf_close(g); } } closer{g};
@@ -808,7 +809,14 @@ int load_gguf_impl(const char* path, int32_t max_batch, int32_t max_blocks_per_s
     (void)u(key("expert_count"), &n_expert);
     uint64_t n_expert_used = 0;
     (void)u(key("expert_used_count"), &n_expert_used);
+    // metadata is untrusted: bound everything before it is narrowed to int32 or used as a divisor
+    const uint64_t lim = 1u << 30;
+    const bool sane = head_count && head_count <= lim && head_count_kv && head_count_kv <= lim && block_count &&
+                      block_count <= 4096 && embd && embd <= lim && ctx_len && ctx_len <= lim && n_expert <= 1024 &&
+                      (n_expert <= 1 || (n_expert_used >= 1 && n_expert_used <= n_expert));
+    if (!sane) return (int)hipErrorInvalidValue;
     if (!u(key("attention.key_length"), &key_len)) key_len = embd / head_count;
+    if (key_len == 0 || key_len > 4096) return (int)hipErrorInvalidValue;
     double eps = 0, theta = 10000.0;
     if (mi355_gguf_get_f64(g, key("attention.layer_norm_rms_epsilon").c_str(), &eps) != 1) return (int)hipErrorInvalidValue;
     (void)mi355_gguf_get_f64(g, key("rope.freq_base").c_str(), &theta);
@@ -827,6 +835,8 @@ int load_gguf_impl(const char* path, int32_t max_batch, int32_t max_blocks_per_s
     int64_t dff[4]; int32_t tff; uint64_t nbff;
     if (info(n_expert > 1 ? "blk.0.ffn_gate.0.weight" : "blk.0.ffn_gate.weight", dff, &tff, &nbff) < 0) return (int)hipErrorInvalidValue;
 
+    if (vocab <= 0 || vocab > (int64_t)lim || dff[0] <= 0 || dff[0] > (int64_t)lim) return (int)hipErrorInvalidValue;
+    if (ty != 0 && ty != MI355_GGML_Q4_K && ty != MI355_GGML_Q6_K) return (int)hipErrorNotSupported;   // token_embd: F32 or a k-quant we dequantise
     mi355_llama_config cfg;
     memset(&cfg, 0, sizeof(cfg));
     cfg.hidden = (int32_t)embd; cfg.n_layers = (int32_t)block_count; cfg.n_heads = (int32_t)head_count;
@@ -849,6 +859,61 @@ int load_gguf_impl(const char* path, int32_t max_batch, int32_t max_blocks_per_s
         const int64_t pad64 = (vocab + 63) / 64 * 64;
         const int64_t padded = ((pad64 + tp_world - 1) / tp_world * tp_world + 63) / 64 * 64;
         if (padded != vocab) return (int)hipErrorNotSupported;    // zero-row padding re-quantises the lm_head (distributed.rs:1601-1612)
+    }
+    // ---- the tensor table against the configuration, BEFORE anything is allocated on the device: a file whose shapes
+    // disagree with its own metadata would otherwise make the kernels read past a weight (the reference checks the
+    // same dims while building the layers, attention.rs:850-870).  Host only: testable without a GPU.
+    {
+        const int64_t hid = cfg.hidden, HD = (int64_t)cfg.n_heads * cfg.head_dim, KD = (int64_t)cfg.n_kv_heads * cfg.head_dim;
+        const int64_t I = cfg.intermediate;
+        if (cfg.hidden <= 0 || cfg.n_layers <= 0 || cfg.n_layers > 4096 || cfg.n_heads <= 0 || cfg.n_kv_heads <= 0 ||
+            cfg.head_dim <= 0 || I <= 0 || vocab <= 0 || (hid % 256) || cfg.n_expert > 1024)
+            return (int)hipErrorInvalidValue;
+        // dim < 0: loaded whole; else this rank keeps rows (0) / k-blocks (1) of a `world`-way split
+        auto expect_q = [&](const std::string& name, int64_t rows, int64_t cols, int dim, int world) -> int {
+            int64_t dd[4]; int32_t t; uint64_t n;
+            if (info(name, dd, &t, &n) < 0) return (int)hipErrorInvalidValue;
+            if (t != MI355_GGML_Q4_K && t != MI355_GGML_Q6_K) return (int)hipErrorNotSupported;
+            if (dd[0] != rows || dd[1] != cols || dd[2] != 1 || dd[3] != 1) return (int)hipErrorInvalidValue;
+            if (dim == 0 && world > 1) { if (rows % world) return (int)hipErrorInvalidValue; rows /= world; }
+            if (dim == 1 && world > 1) { if (cols % world) return (int)hipErrorInvalidValue; cols /= world; }
+            if (cols % 256) return dim == 1 && world > 1 ? (int)hipErrorNotSupported : (int)hipErrorInvalidValue;   // re-quantising fallback: not built
+            return rows % 16 ? (int)hipErrorInvalidValue : 0;
+        };
+        auto expect_f32 = [&](const std::string& name, int64_t elems) -> int {
+            int64_t dd[4]; int32_t t; uint64_t n;
+            if (info(name, dd, &t, &n) < 0 || t != 0) return (int)hipErrorInvalidValue;
+            return (int64_t)(n / 4) == elems ? 0 : (int)hipErrorInvalidValue;
+        };
+        if (d[0] != vocab || d[1] != hid || d[2] != 1 || d[3] != 1) return (int)hipErrorInvalidValue;      // token_embd
+        RCHECK(expect_f32("output_norm.weight", hid));
+        RCHECK(expect_q(mi355_gguf_find(g, "output.weight") >= 0 ? "output.weight" : "token_embd.weight", vocab, hid, 0, tp_world));
+        for (int l = 0; l < cfg.n_layers; ++l) {
+            const std::string p = "blk." + std::to_string(l) + ".";
+            RCHECK(expect_q(p + "attn_q.weight", HD, hid, 0, tp_world));
+            RCHECK(expect_q(p + "attn_k.weight", KD, hid, 0, kv_world));
+            RCHECK(expect_q(p + "attn_v.weight", KD, hid, 0, kv_world));
+            RCHECK(expect_q(p + "attn_output.weight", hid, HD, 1, tp_world));
+            RCHECK(expect_f32(p + "attn_norm.weight", hid));
+            RCHECK(expect_f32(p + "ffn_norm.weight", hid));
+            if (cfg.n_expert > 1) {
+                RCHECK(expect_f32(p + "ffn_gate_inp.weight", (int64_t)cfg.n_expert * hid));
+                for (int e = 0; e < cfg.n_expert; ++e) {
+                    const std::string es = std::to_string(e) + ".weight";
+                    RCHECK(expect_q(p + "ffn_gate." + es, I, hid, -1, 1));
+                    RCHECK(expect_q(p + "ffn_down." + es, hid, I, -1, 1));
+                    RCHECK(expect_q(p + "ffn_up." + es, I, hid, -1, 1));
+                }
+            } else {
+                RCHECK(expect_q(p + "ffn_gate.weight", I, hid, 0, tp_world));
+                RCHECK(expect_q(p + "ffn_down.weight", hid, I, 1, tp_world));
+                RCHECK(expect_q(p + "ffn_up.weight", I, hid, 0, tp_world));
+            }
+        }
+    }
+    if (check_only) {
+        if (cfg_out) *cfg_out = cfg;
+        return 0;
     }
     Model* m = static_cast<Model*>(mi355_llama_create(&cfg));
     if (!m) return (int)hipErrorInvalidValue;
@@ -930,6 +995,10 @@ int load_gguf_impl(const char* path, int32_t max_batch, int32_t max_blocks_per_s
 extern "C" int mi355_llama_load_gguf(const char* path, int32_t max_batch, int32_t max_blocks_per_seq, int32_t block_size,
                                      int32_t kv_layout, int32_t max_seq, void** model_out, mi355_llama_config* cfg_out) {
     return load_gguf_impl(path, max_batch, max_blocks_per_seq, block_size, kv_layout, max_seq, 0, 1, model_out, cfg_out);
+}
+
+extern "C" int mi355_llama_check_gguf(const char* path, int32_t tp_rank, int32_t tp_world, mi355_llama_config* cfg_out) {
+    return load_gguf_impl(path, 1, 1, 16, MI355_KV_PAGED, 0, tp_rank, tp_world, nullptr, cfg_out, true);
 }
 
 extern "C" int mi355_llama_load_gguf_tp(const char* path, int32_t max_batch, int32_t max_blocks_per_seq, int32_t block_size,

@@ -584,6 +584,13 @@ int mi355_llama_load_gguf(const char* path, int32_t max_batch, int32_t max_block
 int mi355_llama_load_gguf_tp(const char* path, int32_t max_batch, int32_t max_blocks_per_seq, int32_t block_size,
                              int32_t kv_layout, int32_t max_seq, int32_t tp_rank, int32_t tp_world, void** model_out,
                              mi355_llama_config* cfg_out);
+/* Host-only dry run of the loader (no device call): reads the metadata, checks every tensor the model needs against it
+ * (present, Q4_K / Q6_K or F32 where required, shapes [rows, cols] consistent with head counts / embedding length / feed
+ * forward length / vocabulary, tile- and block-aligned, shardable `tp_world` ways) and fills cfg_out with the GLOBAL
+ * dimensions.  0 = mi355_llama_load_gguf[_tp] will accept the file; hipErrorInvalidValue (1) = malformed / inconsistent;
+ * hipErrorNotSupported (801) = a format or shard this build does not serve (other ggml types, re-quantising shards).
+ * The loaders run the same checks before their first allocation. */
+int mi355_llama_check_gguf(const char* path, int32_t tp_rank, int32_t tp_world, mi355_llama_config* cfg_out);
 
 /* ABI guard for bindings that mirror the structs by hand (ctypes, a Rust #[repr(C)]): sizeof of
  * 0 = mi355_qmm_desc, 1 = mi355_llama_config, 2 = mi355_dense_config, 3 = mi355_rope_scaling; -1 for an unknown id */

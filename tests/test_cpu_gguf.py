@@ -266,3 +266,72 @@ def test_reader_survives_corrupted_and_hostile_files(lib, tmp_path):
     assert lib.mi355_gguf_n_tensors(None) == -1 and lib.mi355_gguf_tensor_shard(None, 0, 0, 0, 1, None, 0) == -1
     assert not lib.mi355_gguf_tensor_data(None, 0) and not lib.mi355_gguf_open(None)
     lib.mi355_gguf_close(None)
+
+
+def _check(lib, path, rank=0, world=1):
+    from candle_vllm_amd._lib import LlamaConfig
+    c = LlamaConfig()
+    rc = lib.mi355_llama_check_gguf(path.encode(), rank, world, ctypes.addressof(c))
+    return rc, c
+
+
+def test_check_gguf_accepts_good_files_and_reports_the_global_config(lib, tmp_path):
+    """host-only dry run of `GGUFLLaMa::from_gguf` (quantized_llama.rs:203-420): what the loader would build"""
+    cfg = llama.LlamaConfig.tiny(hidden=1024, n_heads=4, n_kv_heads=2, head_dim=256, intermediate=1024, vocab=512)
+    p = os.path.join(tmp_path, "ok.gguf")
+    GW.llama_to_gguf(p, cfg, llama.make_weights(cfg, seed=3))
+    for rank, world in ((0, 1), (0, 2), (1, 2), (3, 4)):           # world 4: 2 kv heads replicated on pairs of ranks
+        rc, c = _check(lib, p, rank, world)
+        assert rc == 0, (rank, world, rc)
+        assert (c.hidden, c.n_layers, c.n_heads, c.n_kv_heads, c.head_dim, c.intermediate, c.vocab) == \
+            (cfg.hidden, cfg.n_layers, cfg.n_heads, cfg.n_kv_heads, cfg.head_dim, cfg.intermediate, cfg.vocab)
+        assert (c.tp_rank, c.tp_world, c.n_expert) == (rank, world, 0)
+        assert abs(c.rope_theta - cfg.rope_theta) < 1e-3 * cfg.rope_theta and abs(c.rms_eps - cfg.rms_eps) < 1e-9
+    assert _check(lib, p, 0, 8)[0] == 1                            # 4 heads over 8 ranks
+    moe = llama.LlamaConfig.tiny()
+    moe.n_expert, moe.n_expert_used = 4, 2
+    p2 = os.path.join(tmp_path, "moe.gguf")
+    GW.llama_to_gguf(p2, moe, llama.make_moe_weights(moe, 4, seed=4))
+    rc, c = _check(lib, p2)
+    assert rc == 0 and (c.n_expert, c.n_expert_used, c.intermediate) == (4, 2, moe.intermediate)
+
+
+def test_check_gguf_refuses_inconsistent_files(lib, tmp_path):
+    """a file whose tensors disagree with its own metadata must be refused on the host (the kernels trust the shapes)"""
+    cfg = llama.LlamaConfig.tiny(hidden=512, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=768, vocab=512)
+    W = llama.make_weights(cfg, seed=6)
+    good = os.path.join(tmp_path, "g.gguf")
+    md, ts = GW.llama_to_gguf(good, cfg, W)
+    assert _check(lib, good)[0] == 0
+    assert _check(lib, good, 0, 2)[0] == 801                       # ffn_down: 768 / 2 = 384 columns cut a 256-block
+    p = os.path.join(tmp_path, "bad.gguf")
+
+    def variant(md2=None, drop=None, retype=None, reshape=None):
+        m = dict(md)
+        m.update(md2 or {})
+        t2 = []
+        for name, t, raw, dims in ts:
+            if name == drop:
+                continue
+            if name == retype:
+                t = 8                                              # Q8_0: a valid GGUF type this build does not serve
+                raw = raw[: (dims[0] * dims[1] // 32) * 34] if len(raw) >= (dims[0] * dims[1] // 32) * 34 else \
+                    np.zeros((dims[0] * dims[1] // 32) * 34, np.uint8)
+            if reshape and name == reshape[0]:
+                dims = reshape[1]
+            t2.append((name, t, raw, dims))
+        GW.write_gguf(p, m, t2)
+        return _check(lib, p)[0]
+    assert variant(md2={"llama.attention.head_count": 8}) == 1                     # attn_q has 4 * 128 rows, not 8 * 128
+    assert variant(md2={"llama.attention.head_count_kv": 4}) == 1
+    assert variant(md2={"llama.embedding_length": 1024}) == 1
+    assert variant(md2={"llama.block_count": cfg.n_layers + 1}) == 1               # a layer's tensors are missing
+    assert variant(md2={"llama.attention.head_count": 0}) == 1                     # would divide by zero
+    assert variant(md2={"llama.block_count": 2**31 - 1}) == 1
+    assert variant(drop="blk.1.ffn_up.weight") == 1
+    assert variant(drop="output_norm.weight") == 1
+    assert variant(retype="blk.0.attn_v.weight") == 801
+    q = next(x for x in ts if x[0] == "blk.0.attn_output.weight")
+    assert variant(reshape=("blk.0.attn_output.weight", [q[3][0] // 2, q[3][1] * 2])) == 1    # same bytes, wrong shape
+    assert lib.mi355_llama_check_gguf(None, 0, 1, None) == 1
+    assert lib.mi355_llama_check_gguf(os.path.join(tmp_path, "none.gguf").encode(), 0, 1, None) != 0
