@@ -1,0 +1,127 @@
+"""Error behaviour of the C ABI that is decided on the HOST, before any device call (so it runs without a GPU): empty
+inputs are no-ops that return 0 (the reference's ops accept zero-length batches), malformed arguments are refused with
+hipErrorInvalidValue (1) instead of launching a kernel that would read out of bounds, and constructors answer NULL.
+Calls that would reach the device are not made here -- those are the `-m gpu` tests."""
+import ctypes
+
+import pytest
+
+INVALID = 1
+BF16, F16, F32 = 2, 1, 0          # MI355_DTYPE_*
+KV_FLASH, KV_PAGED = 0, 1
+
+
+@pytest.fixture(scope="module")
+def L(lib):
+    from candle_vllm_amd import _lib
+    assert (_lib.lib.mi355_abi_struct_size(0)) > 0
+    return _lib
+
+
+def test_dtype_codes_match_the_header():
+    import os
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mi355_vllm.h")).read()
+    codes = {k: int(v) for k, v in re.findall(r"#define (MI355_DTYPE_\w+|MI355_KV_\w+) (\d+)", hdr)}
+    assert (codes["MI355_DTYPE_F32"], codes["MI355_DTYPE_F16"], codes["MI355_DTYPE_BF16"]) == (F32, F16, BF16)
+    assert (codes["MI355_KV_FLASH"], codes["MI355_KV_PAGED"]) == (KV_FLASH, KV_PAGED)
+
+
+def test_empty_inputs_are_no_ops(L):
+    lib = L.lib
+    assert lib.mi355_reshape_and_cache(None, None, None, None, None, 0, 8, 128, 64, 2, KV_PAGED, 0) == 0
+    assert lib.mi355_reshape_and_cache_fp8(None, None, None, None, None, 0, 8, 128, 64, KV_PAGED, 1.0, 1.0, 0) == 0
+    assert lib.mi355_swap_blocks(None, None, None, 0, 131072, 0, 0) == 0
+    assert lib.mi355_swap_blocks(None, None, None, 4, 0, 0, 0) == 0
+    # zero sequences: nothing to attend
+    assert lib.mi355_paged_attention_v1(None, None, None, None, None, None, 0, 32, 8, 128, 64, 8, 512, 0.088, 0.0,
+                                        KV_PAGED, BF16, 0) == 0
+
+
+def test_malformed_attention_arguments_are_refused(L):
+    lib = L.lib
+    one = ctypes.c_uint64(0)
+    p = ctypes.addressof(one)                                  # any non-null pointer: the call must fail before using it
+
+    def v1(H=32, Hkv=8, D=128, layout=KV_PAGED, dtype=BF16):
+        return lib.mi355_paged_attention_v1(p, p, p, p, p, p, 1, H, Hkv, D, 64, 8, 512, 0.088, 0.0, layout, dtype, 0)
+    assert v1(H=30) == INVALID                                 # query heads not a multiple of kv heads
+    assert v1(D=100) == INVALID and v1(D=512) == INVALID       # head size: multiple of 8, <= 256
+    assert v1(dtype=F32) == INVALID and v1(dtype=7) == INVALID
+
+    def v2(ps, tmp=p):
+        return lib.mi355_paged_attention_v2(p, tmp, tmp, tmp, p, p, p, p, p, 1, 32, 8, 128, 64, 8, 512, ps, 0.088, 0.0,
+                                            KV_PAGED, BF16, 0)
+    assert v2(0) == INVALID and v2(-32) == INVALID             # v2 needs a partition size
+    assert lib.mi355_paged_attention_v2(p, None, None, None, p, p, p, p, p, 1, 30, 8, 128, 64, 8, 512, 32, 0.088, 0.0,
+                                        KV_PAGED, BF16, 0) == INVALID
+    # fp8 cache: partitioned call without the partial buffers
+    assert lib.mi355_paged_attention_fp8(p, None, None, None, p, p, p, p, p, 1, 32, 8, 128, 64, 8, 512, 32, 0.088, 0.0,
+                                         1.0, 1.0, 0) == INVALID
+    # prefill: dtype, head grouping, missing k/v when there is no cache, missing tables when there is one
+    def pre(k=p, v=p, kc=None, vc=None, bt=None, cl=None, H=32, Hkv=8, D=128, dtype=BF16):
+        return lib.mi355_prefill_attention(p, p, k, v, kc, vc, bt, cl, p, 1, 16, H, Hkv, D, 64, 8, 0.088, 0.0, KV_PAGED, dtype, 0)
+    assert pre(dtype=F32) == INVALID and pre(H=30) == INVALID and pre(D=320) == INVALID
+    assert pre(k=None, v=None) == INVALID
+    assert pre(kc=p, vc=p, bt=None, cl=None) == INVALID
+
+
+def test_malformed_cache_and_elementwise_arguments_are_refused(L):
+    lib = L.lib
+    one = ctypes.c_uint64(0)
+    p = ctypes.addressof(one)
+    assert lib.mi355_reshape_and_cache(p, p, p, p, p, 1, 8, 128, 64, 3, KV_PAGED, 0) == INVALID      # element size
+    assert lib.mi355_reshape_and_cache(p, p, p, p, p, 1, 8, 100, 64, 2, KV_PAGED, 0) == INVALID      # D % x
+    assert lib.mi355_reshape_and_cache(p, p, p, p, p, 1, 8, 128, 64, 2, 9, 0) == INVALID             # layout code
+    assert lib.mi355_reshape_and_cache_fp8(p, p, p, p, p, 1, 8, 120, 64, KV_PAGED, 1.0, 1.0, 0) == INVALID
+    assert lib.mi355_swap_blocks(p, p, p, 1, 4096, 99, 0) == INVALID                                 # direction code
+    assert lib.mi355_rope_inplace(p, p, p, p, p, 1, 4, 2, 128, 0, 0, BF16, 0) == INVALID             # rotary_dim 0
+    assert lib.mi355_rope_inplace(p, p, p, p, p, 1, 4, 2, 128, 130, 0, BF16, 0) == INVALID           # > head_dim
+    assert lib.mi355_rope_inplace(p, p, p, p, p, 1, 4, 2, 128, 63, 0, BF16, 0) == INVALID            # odd
+    assert lib.mi355_argmax_f32(p, p, 1, 0, 0) == INVALID
+    assert lib.mi355_moe_route(p, p, p, p, 1e-5, p, 1, 4096, 8, 9, 0) == INVALID                     # top-k > experts
+    assert lib.mi355_moe_route(p, p, p, p, 1e-5, p, 1, 4096, 0, 1, 0) == INVALID
+
+
+def test_malformed_quantised_matmul_descriptors_are_refused(L):
+    lib = L.lib
+    one = ctypes.c_uint64(0)
+    p = ctypes.addressof(one)
+    assert lib.mi355_qmatmul_fused(None, 0) == INVALID
+    d = L.QmmDesc()
+    d.nseg = 0
+    assert lib.mi355_qmatmul_fused(ctypes.byref(d), 0) == INVALID
+    d.nseg = 4
+    assert lib.mi355_qmatmul_fused(ctypes.byref(d), 0) == INVALID
+    d = L.QmmDesc()
+    d.nseg, d.x_dtype = 1, F16                                  # activations are f32 or bf16
+    assert lib.mi355_qmatmul_fused(ctypes.byref(d), 0) == INVALID
+    d = L.QmmDesc()
+    d.nseg, d.x_dtype, d.epilogue = 1, F32, 1                   # MI355_EPI_RESID without a residual pointer
+    d.out = p
+    assert lib.mi355_qmatmul_fused(ctypes.byref(d), 0) == INVALID
+    d.epilogue, d.out = 0, None                                 # MI355_EPI_STORE without an output pointer
+    assert lib.mi355_qmatmul_fused(ctypes.byref(d), 0) == INVALID
+    # repack: sizes are host arithmetic
+    assert lib.mi355_qweight_repacked_size(12, 16, 256) == 2304 and lib.mi355_qweight_repacked_size(14, 16, 256) == 3360
+    assert lib.mi355_qweight_repacked_size(12, 16, 100) < 0 and lib.mi355_qweight_repacked_size(8, 16, 256) < 0
+    assert lib.mi355_qweight_repacked_size(12, 17, 256) == 2 * 2304        # rows are padded to whole 16-row tiles
+    assert lib.mi355_qweight_repack(p, p, 8, 16, 256) != 0
+
+
+def test_constructors_refuse_bad_configurations(L):
+    lib = L.lib
+    assert not lib.mi355_llama_create(None)
+    c = L.LlamaConfig()
+    assert not lib.mi355_llama_create(ctypes.byref(c))          # all zero
+    c.hidden, c.n_layers, c.n_heads, c.n_kv_heads, c.head_dim, c.max_batch, c.max_blocks_per_seq = 250, 1, 2, 2, 64, 1, 4
+    assert not lib.mi355_llama_create(ctypes.byref(c))          # hidden not a multiple of the 256-wide k-block
+    assert not lib.mi355_dense_create(None)
+    lib.mi355_llama_destroy(None)
+    lib.mi355_dense_destroy(None)
+    # communicator entry points on a null handle
+    one = ctypes.c_uint64(0)
+    assert lib.mi355_comm_all_reduce(None, ctypes.addressof(one), 1, F32, 0) != 0
+    assert lib.mi355_comm_all_gather(None, ctypes.addressof(one), ctypes.addressof(one), 1, F32, 0) != 0
+    lib.mi355_comm_destroy(None)
+    assert lib.mi355_llama_set_comm(None, None) != 0
