@@ -1024,9 +1024,15 @@ int32_t mi355_sched_schedule(void* sp, uint64_t now_ms) {
             const int64_t gid = s->swapped.front();
             Group& gr = s->g(gid);
             if (gr.has_swapped_time && now_ms - gr.swapped_ms < 300) break;          // SWAP_COOLING_PERIOD
-            if (mi355_be_can_swap_in(e, gr.seqs.data(), (int)gr.seqs.size()) != 1) {
-                e->evict_until_free(mi355_be_swap_in_required_blocks(e, gr.seqs.data(), (int)gr.seqs.size()));
-                if (mi355_be_can_swap_in(e, gr.seqs.data(), (int)gr.seqs.size()) != 1) break;
+            // room for the swapped blocks AND for the slot that is reserved right after the swap-in (mod.rs:395-396).
+            // The reference checks only the former (`can_swap_in_seq_group`, block_engine.rs:1214-1219); when the group
+            // then needs one more block than the pool has, its allocator unwraps an empty free list (:113-117) and
+            // panics.  Here the group stays swapped out until both fit (found by the block-pressure stress test).
+            int need = mi355_be_swap_in_required_blocks(e, gr.seqs.data(), (int)gr.seqs.size());
+            for (int64_t sid : gr.seqs) { Seq* q = find_seq(e, sid); if (q) need += blocks_missing_for_sequence(e, sid, *q); }
+            if (need > (int)e->gpu.free_ids.size()) {
+                e->evict_until_free(need);
+                if (need > (int)e->gpu.free_ids.size()) break;
             }
             s->swapped.pop_front();
             std::vector<int64_t> pairs(2 * 8192);

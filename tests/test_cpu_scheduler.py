@@ -181,3 +181,90 @@ def test_continuous_batching_simulation_32_sequences(be):
     assert len(done) == 32, (len(done), step)
     assert eng.get_num_free_blocks() == nblk and not s.has_unfinished_sequences()
     assert prompt_steps > 0 and decode_steps > 0
+
+
+@pytest.mark.parametrize("prefix_cache", [False, True])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_scheduler_stress_under_block_pressure(be, seed, prefix_cache):
+    """random arrivals, shared prompt prefixes, a pool far too small for the offered load (forces preemption by
+    recompute without the prefix cache, by swap with it), random aborts: whatever the interleaving,
+      * a decode step only schedules groups whose tables are entirely on the GPU, with one distinct slot each,
+      * a physical block belongs to two live sequences only if its reference count says so,
+      * every group reaches FINISHED / ABORTED / IGNORED (no starvation, no lost group),
+      * at the end every GPU block is free or held by the prefix cache, and every CPU block is free."""
+    rng = np.random.default_rng(1000 * seed + int(prefix_cache))
+    bs, nblk, ncpu, N = 8, 24, 48, 40
+    s = _mk(be, block_size=bs, num_gpu_blocks=nblk, num_cpu_blocks=ncpu, max_num_parallel_reqs=6,
+            max_num_batched_tokens=96, prefill_chunk_size=32, prefix_cache_enabled=prefix_cache,
+            max_cached_blocks=6 if prefix_cache else 0)
+    eng = s.block_engine
+    common = rng.integers(0, 50, 40).tolist()                         # shared system prompt: prefix-cache hits
+    seqs, target, terminal = {}, {}, set()
+    arrivals = sorted(rng.integers(0, 120, N).tolist())
+    next_id, step, now = 0, 0, 0
+    saw_swap = saw_recompute = 0
+    TERMINAL = (be.Scheduler.FINISHED, be.Scheduler.ABORTED, be.Scheduler.IGNORED)
+    while len(terminal) < N and step < 20000:
+        while next_id < N and arrivals[next_id] <= step:
+            n = int(rng.integers(4, 90))
+            toks = (common[: int(rng.integers(0, 41))] + rng.integers(0, 50, n).tolist())[:n]
+            if rng.random() < 0.05:
+                toks = rng.integers(0, 50, bs * nblk + 5).tolist()     # can never fit: must be IGNORED, not starve the queue
+            seqs[next_id] = eng.new_sequence(next_id, toks)
+            target[next_id] = len(toks) + int(rng.integers(1, 40))
+            s.add_sequence(next_id, [seqs[next_id]])
+            next_id += 1
+        now += 400                                                    # past the 300 ms swap-in cooling every step
+        out = s.schedule(now_ms=now)
+        for g in out.ignored_seq_groups:
+            terminal.add(g)
+        saw_recompute += len(s.take_pending_runner_releases())
+        saw_swap += len(out.swap_out_groups)
+        for g in out.swap_out_groups:                                 # execute_scheduler_ops: copies done, commit them
+            eng.finalize_swap_out(g)
+        for g in out.swap_in_groups:
+            eng.finalize_swap_in(g)
+        group = [seqs[g] for g in out.scheduled]
+        if out.is_prompt:
+            if group:
+                meta = eng.prepare_prompt(group, chunk=32)
+                assert int(meta["cu_seqlens_q"][-1]) <= 96
+            decoding = [seqs[g] for g in s.filter_prefill_finished(out.scheduled)]
+        else:
+            decoding = group
+            if group:
+                meta = eng.prepare_decode(group)
+                assert len(set(meta["slot_mapping"].tolist())) == len(group)
+                assert (np.asarray(meta["slot_mapping"]) >= 0).all()
+        owners = {}
+        for q in group:
+            t = eng.block_table(q)
+            assert all(b >= 0 for b in t), "a scheduled group still has swapped-out blocks"
+            for b in set(t):
+                owners[b] = owners.get(b, 0) + 1
+        for b, n in owners.items():
+            assert eng.refcount(b) >= n, (b, n, eng.refcount(b))
+        for q in decoding:
+            if q.id in terminal:
+                continue
+            q.add_token(int(rng.integers(0, 50)))
+            if q.get_len() >= target[q.id]:
+                s.set_finished(q.id)
+                terminal.add(q.id)
+        live = [g for g in range(next_id) if g not in terminal and s.status(g) not in TERMINAL]
+        if live and rng.random() < 0.02:                               # a client disconnects
+            victim = int(rng.choice(live))
+            assert s.abort_sequences([victim]) == 1
+            terminal.add(victim)
+        s.free_finished_sequence_groups()
+        step += 1
+    assert len(terminal) == N, (len(terminal), step, s.num_waiting(), s.num_running(), s.num_swapped())
+    for g in range(N):
+        assert s.status(g) in TERMINAL or s.status(g) < 0, (g, s.status(g))
+    assert not s.has_unfinished_sequences()
+    cached = eng.prefix_cache_blocks() if prefix_cache else 0
+    assert eng.get_num_free_blocks() + cached == nblk, (eng.get_num_free_blocks(), cached)
+    assert eng.get_num_free_cpu_blocks() == ncpu
+    assert saw_recompute + saw_swap > 0                                # the pool really was under pressure
+    if prefix_cache:
+        assert saw_swap > 0
