@@ -213,7 +213,7 @@ class BlockEngine:
         if mb < 0:
             raise RuntimeError(f"prepare_decode failed ({mb})")
         return {"input_ids": tok, "positions": pos, "slot_mapping": slot, "context_lens": ctx,
-                "block_tables": bt[: n * mb].reshape(n, mb).copy(), "max_context_len": int(ctx.max())}
+                "block_tables": bt[: n * mb].reshape(n, mb).copy(), "max_context_len": int(ctx.max()) if n else 0}
 
     def prepare_prompt(self, group, chunk=0, tok_cap=1 << 20):
         a, p, n = _ids([s.id for s in group])

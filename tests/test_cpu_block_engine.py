@@ -282,3 +282,52 @@ def test_input_preparation_matches_the_numpy_restatement(be):
     ref = O.prepare_prompt([{"tokens": p[:56], "block_table": eng2.block_table(s)}], bs, num_cached_tokens=[32])
     for k in ("input_ids", "positions", "slot_mapping", "context_lens", "cu_seqlens_q", "cu_seqlens_k"):
         assert np.array_equal(np.asarray(got[k], np.int64), np.asarray(ref[k], np.int64)), k
+
+
+def test_input_preparation_at_baseline_sizes_ragged_and_empty(be):
+    """a1 / a2 at BASELINE's full sizes: 32 sequences, ragged contexts U[256,4096] plus one of 5000 tokens (79 blocks of
+    64 -- the table width of SURVEY 8a), decode steps that cross a block boundary, a 1-sequence batch, and the empty
+    batch; bit-exact against oracle.ops (inputs.rs:376-454)."""
+    rng = np.random.default_rng(77)
+    bs = 64
+    lens = rng.integers(256, 4097, 32).tolist()
+    lens[7], lens[19], lens[30] = 5000, 4095, 64                   # widest table; one token short of a boundary; exactly one block
+    eng = be.BlockEngine(bs, sum(-(-(n + 8) // bs) for n in lens) + 4, 0, False, 0)
+    toks = {i: rng.integers(0, 128256, n).tolist() for i, n in enumerate(lens)}
+    seqs = [eng.new_sequence(i, toks[i]) for i in range(32)]
+    order = rng.permutation(32).tolist()                             # allocation order != batch order: tables interleave
+    for i in order:
+        eng.allocate([seqs[i]])
+
+    def snap(group):
+        return [{"tokens": toks[s.id][:s.get_len()], "block_table": eng.block_table(s)} for s in group]
+    got = eng.prepare_prompt(seqs)
+    ref = O.prepare_prompt(snap(seqs), bs)
+    for k in ("input_ids", "positions", "slot_mapping", "context_lens", "block_tables", "cu_seqlens_q", "cu_seqlens_k"):
+        assert np.array_equal(np.asarray(got[k], np.int64), np.asarray(ref[k], np.int64)), k
+    assert int(got["cu_seqlens_q"][-1]) == sum(lens) and np.asarray(got["block_tables"]).shape == (32, 79)
+    for step in range(3):                                            # 4095 -> 4096 -> 4097 crosses a block boundary
+        for s in seqs:
+            t = int(rng.integers(0, 128256))
+            s.add_token(t)
+            toks[s.id].append(t)
+            assert eng.append_token_slot_to_seq(s) is None
+        got = eng.prepare_decode(seqs)
+        ref = O.prepare_decode(snap(seqs), bs)
+        for k in ("input_ids", "positions", "slot_mapping", "context_lens", "block_tables"):
+            assert np.array_equal(np.asarray(got[k], np.int64), np.asarray(ref[k], np.int64)), (step, k)
+        assert len(set(np.asarray(got["slot_mapping"]).tolist())) == 32
+    one = [seqs[7]]
+    got, ref = eng.prepare_decode(one), O.prepare_decode(snap(one), bs)
+    for k in ("input_ids", "positions", "slot_mapping", "context_lens", "block_tables"):
+        assert np.array_equal(np.asarray(got[k], np.int64), np.asarray(ref[k], np.int64)), k
+    assert np.asarray(got["block_tables"]).shape == (1, 79)
+    # the empty batch: the reference unwraps max() of an empty list here (inputs.rs:441-444) and the oracle mirrors that;
+    # the C entry point answers "0 sequences, 0 table columns" instead of failing
+    empty = eng.prepare_decode([])
+    assert len(empty["input_ids"]) == 0 and len(empty["slot_mapping"]) == 0 and empty["block_tables"].size == 0
+    with pytest.raises(ValueError):
+        O.prepare_decode([], bs)
+    for s in seqs:
+        eng.free_sequence(s)
+    assert eng.get_num_free_blocks() == eng.get_num_blocks()
