@@ -200,3 +200,84 @@ def test_pad_vocab_size_formula():
     assert tp.pad_vocab_size(128256, 8) == 128256 and tp.pad_vocab_size(152064, 2) == 152064 and tp.pad_vocab_size(32000, 8) == 32000
     assert tp.pad_vocab_size(50257, 4) == 50304 and tp.pad_vocab_size(50304, 8) == 50304       # distributed.rs:1446-1452
     assert tp.pad_vocab_size(100, 3) == 192
+
+
+# ---- the C-level communicator with HOST-supplied collectives (mi355_comm_create_external), 2 ranks over gloo -------------
+def _ext_comm_worker(rank, world, port, q):
+    try:
+        import ctypes
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from candle_vllm_amd import tp
+        from candle_vllm_amd._lib import lib
+
+        class HostComm(tp.TorchDistComm):              # same callbacks, payload already in host memory (no GPU here)
+            def _d2h(self, ptr, nbytes):
+                return np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(ptr)).copy()
+
+            def _h2d(self, ptr, host):
+                ctypes.memmove(ptr, host.ctypes.data, host.nbytes)
+        comm = HostComm()
+        out = {}
+        # all-reduce (sum, in place) in the three wire dtypes
+        x = (np.arange(1000, dtype=np.float32) * 0.25 + rank * 1000.0)
+        buf = x.copy()
+        assert lib.mi355_comm_all_reduce(comm.handle, buf.ctypes.data, buf.size, 0, 0) == 0
+        out["f32"] = buf
+        h = (np.arange(512) * 0.5 + rank).astype(np.float16)
+        assert lib.mi355_comm_all_reduce(comm.handle, h.ctypes.data, h.size, 1, 0) == 0
+        out["f16"] = h.astype(np.float32)
+        b = ((np.arange(256, dtype=np.float32) + rank * 0.5).view(np.uint32) >> 16).astype(np.uint16)   # exact bf16 values
+        assert lib.mi355_comm_all_reduce(comm.handle, b.ctypes.data, b.size, 2, 0) == 0
+        out["bf16"] = (b.astype(np.uint32) << 16).view(np.float32)
+        # all-gather: [W, count] rank-major
+        send = np.full(7, float(rank + 1), np.float32)
+        recv = np.zeros(7 * world, np.float32)
+        assert lib.mi355_comm_all_gather(comm.handle, send.ctypes.data, recv.ctypes.data, send.size, 0, 0) == 0
+        out["gather"] = recv
+        # bad dtype code is refused before the callback runs; a failing callback surfaces as a non-zero status
+        assert lib.mi355_comm_all_reduce(comm.handle, buf.ctypes.data, buf.size, 9, 0) != 0
+        comm._dist = None                              # makes the callback raise inside -> it returns 999, never unwinds
+        assert lib.mi355_comm_all_reduce(comm.handle, buf.ctypes.data, buf.size, 0, 0) != 0
+        q.put((rank, "ok", out))
+        dist.barrier()
+        lib.mi355_comm_destroy(comm.handle)
+        dist.destroy_process_group()
+    except BaseException as e:
+        q.put((rank, "error", repr(e)))
+        raise
+
+
+def test_external_communicator_callbacks_two_ranks():
+    """`mi355_comm_create_external` + `mi355_comm_all_reduce / all_gather` (the entry points a host that owns its own
+    communicator binds): argument passing, dtype codes, in-place sum, rank-major gather, error propagation -- through the
+    same Python callbacks `test_gpu_tp2.py` uses, with the payload in host memory."""
+    import __graft_entry__ as ge
+    ge.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ext_comm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(2):
+            r = q.get(timeout=180)
+            assert r[1] == "ok", r
+            res[r[0]] = r[2]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    for rank in (0, 1):
+        o = res[rank]
+        assert np.array_equal(o["f32"], np.arange(1000, dtype=np.float32) * 0.5 + 1000.0)
+        assert np.array_equal(o["f16"], (np.arange(512) * 1.0 + 1.0).astype(np.float16).astype(np.float32))
+        want = (np.arange(256, dtype=np.float32) * 2 + 0.5)
+        u = want.view(np.uint32)
+        want_bf = (((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32) << 16).view(np.float32)
+        assert np.array_equal(o["bf16"], want_bf)
+        assert np.array_equal(o["gather"], np.repeat(np.array([1.0, 2.0], np.float32), 7))
