@@ -17,6 +17,9 @@ lib = M.lib
 cfg = llama3_8b()
 CTX, K, Wm = 4096, 64, 8
 # TUNES: ';'-separated settings, each "key=val,key=val" for mi355_set_tuning (keys not named are reset to 0)
+# defaults of the mi355_set_tuning keys (qmatmul.hip / paged_attention.hip): 0 NW, 1 R, 2 probe mode, 3 fused attention
+# merge, 5 partition override, 8 attention waves per workgroup, 9 launch chaining, 10 K-split target
+DEFAULTS = {0: 0, 1: 0, 2: 0, 3: 1, 5: 0, 8: 0, 9: 1, 10: 1024}
 modes = os.environ.get("TUNES", "0=0;0=4;0=8;1=1;1=2;1=4;0=4,1=4;0=4,1=1;0=0").split(";")
 batches = [int(x) for x in os.environ.get("PF_BATCHES", "1,32").split(",")]
 Bmax = max(batches)
@@ -36,8 +39,8 @@ for B in batches:
     bt = perm[: B * bps].reshape(B, bps).astype(np.uint32)
     for mode in modes:
         gm.set_graph(False); gm.set_graph(True)          # tuning is baked into a captured graph
-        for k in (0, 1):
-            lib.mi355_set_tuning(k, 0)
+        for k, v in DEFAULTS.items():                    # every knob back to its default before the mode's own settings
+            lib.mi355_set_tuning(k, v)
         for kv in mode.split(","):
             k, v = kv.split("=")
             lib.mi355_set_tuning(int(k), int(v))
@@ -54,8 +57,8 @@ for B in batches:
         dt = time.perf_counter() - t0
         out[f"B{B}_mode{mode}"] = round(B * K / dt, 1)
         print(f"B={B} mode={mode}: {B * K / dt:.1f} tok/s  {dt / K * 1e3:.3f} ms/step", flush=True)
-for k in (0, 1):
-    lib.mi355_set_tuning(k, 0)
+for k, v in DEFAULTS.items():
+    lib.mi355_set_tuning(k, v)
 if os.environ.get("NO_PROBE"):
     sys.exit(0)
 # hot vs cold: launch group `part` of ONE layer 32x (weights stay in the Infinity Cache) vs of 32 layers in turn

@@ -1,0 +1,23 @@
+#!/bin/bash
+# One gpurun call that opens a round: everything that has not run on hardware yet, then the judged artefacts.
+#   gpurun --timeout 1500 -- 'bash tools/round_start_gpu_call.sh'
+# Writes gpurun_out/round_start/{pytest.log,smoke.log,bench.json,parts.log,sweep_attn.log}.
+set -x
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/round_start
+mkdir -p $OUT
+cd $R
+# 1. the whole GPU suite, including tests that were written after the previous round's GPU minutes were spent
+MI355_RUN_UNVALIDATED=1 timeout 900 python -m pytest tests -m gpu -q -x > $OUT/pytest.log 2>&1
+tail -3 $OUT/pytest.log
+# 2. smoke + the judged bench line
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1
+tail -1 $OUT/smoke.log
+timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+head -c 600 $OUT/bench.json
+# 3. per-launch-group table at batch 1 (eager, hipEvents) -- where the step's time goes
+timeout 300 python tools/exp_parts.py > $OUT/parts.log 2>&1
+tail -4 $OUT/parts.log
+# 4. decode-attention knobs at batch 1 / 32: fused merge (3), partition override (5), waves per workgroup (8)
+TUNES="3=0;3=1;3=2;8=1;8=4;5=64;5=128;3=0,8=1" PF_BATCHES="1,32" NO_PROBE=1 timeout 600 python tools/exp_decode_sweep.py > $OUT/sweep_attn.log 2>&1
+grep "tok/s" $OUT/sweep_attn.log
