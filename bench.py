@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--ctx", type=int, default=4096, help="prompt tokens already in the KV cache")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--tp-graph", action="store_true",
+                    help="N > 1 only, opt-in: capture the tensor-parallel step (RCCL calls included) in a hipGraph "
+                         "(mi355_llama_set_graph(model, 2)); the default TP step is eager")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-batch32", action="store_true", help="skip the secondary batch-32 measurement")
@@ -187,7 +190,8 @@ def main():
     seq_lens = np.full(B, args.ctx + 1, np.uint32)            # prompt + the first generated token
     stream = torch.cuda.Stream()
     st = stream.cuda_stream
-    gm.set_graph(not args.no_graph and world == 1)
+    graph_mode = 2 if (args.tp_graph and world > 1) else (not args.no_graph and world == 1)
+    gm.set_graph(graph_mode)
     ctx_cap = args.ctx + K + Wm + 2
     gm.decode_begin(tokens, seq_lens, bt, ctx_cap=ctx_cap, stream=st)
 
@@ -227,7 +231,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: Llama-3-8B Q4_K_M GGUF shapes, greedy decode, "
                                f"batch={B}, prompt ctx {args.ctx} in paged KV (block 64), {K} decode steps",
                    "batch": B, "ctx_start": args.ctx + 1 + Wm, "ctx_end": args.ctx + Wm + K,
-                   "parallelism": f"tp{world}", "graph": bool(not args.no_graph and world == 1),
+                   "parallelism": f"tp{world}", "graph": bool(graph_mode),
                    "kv_layout": ("paged K[NB,Hkv,D/8,64,8] V[NB,Hkv,D,64] bf16" if args.kv_layout == "paged"
                                  else "flash [NB,64,Hkv,128] bf16")},
         "step": {"algorithmic_bytes": int(step_bytes), "achieved_GBs": round(achieved, 1),

@@ -149,6 +149,7 @@ struct Model {
     int g_batch = 0, g_max_blocks = 0, g_ctx_cap = 0;
     int w_batch = 0, w_max_blocks = 0, w_ctx_cap = 0;     // shape of the last EAGER step (kernel attrs warmed)
     bool use_graph = true;
+    bool graph_tp = false;          // set_graph(2): capture tensor-parallel steps too (RCCL calls inside the graph; opt-in)
     // tensor parallel
     Comm* comm = nullptr;           // mi355_comm_* handle (owned when created by mi355_llama_init_comm)
     bool comm_owned = false;
@@ -733,6 +734,7 @@ extern "C" int mi355_llama_set_graph(void* mp, int32_t enable) {
     Model* m = static_cast<Model*>(mp);
     if (!m) return (int)hipErrorInvalidValue;
     m->use_graph = enable != 0;
+    m->graph_tp = enable == 2;
     if (!m->use_graph) drop_graph(m);
     return 0;
 }
@@ -743,7 +745,10 @@ extern "C" int mi355_llama_decode_step(void* mp, int64_t stream) {
     Model* m = static_cast<Model*>(mp);
     if (!m || m->cur_batch < 1) return (int)hipErrorInvalidValue;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (!m->use_graph || stream == 0 || m->use_comm) return record_step(m, stream);   // TP: eager (RCCL in-stream)
+    // TP steps run eagerly (RCCL in-stream) unless the caller opted in with set_graph(2) AND the communicator is RCCL's
+    // own (host-supplied collectives stage through the host and cannot be captured)
+    const bool tp_eager = m->use_comm && !(m->graph_tp && m->comm && m->comm->nccl);
+    if (!m->use_graph || stream == 0 || tp_eager) return record_step(m, stream);
     if (m->w_batch != m->cur_batch || m->w_max_blocks != m->cur_max_blocks || m->w_ctx_cap != m->cur_ctx_cap) {
         // first step of a new shape runs eagerly: lazily-set kernel attributes and occupancy queries must not
         // happen inside a stream capture

@@ -354,7 +354,8 @@ class GGUFLLaMa:
         return out
 
     def set_graph(self, enable):
-        _check(lib.mi355_llama_set_graph(self.h, 1 if enable else 0), "set_graph")
+        """False / True, or 2 = capture tensor-parallel steps too (RCCL inside the graph; opt-in)"""
+        _check(lib.mi355_llama_set_graph(self.h, 2 if enable == 2 else (1 if enable else 0)), "set_graph")
 
     def logits_numpy(self, batch):
         """logits of the last decode_step (device buffer of the model) -> numpy f32 [batch, vocab]"""

@@ -366,6 +366,8 @@ int mi355_llama_forward_prefill(void* model, const uint32_t* tokens, const int64
 int mi355_llama_decode_begin(void* model, const uint32_t* tokens_host, const uint32_t* seq_lens_host,
                              const uint32_t* block_tables_host, int32_t batch, int32_t max_blocks, int32_t ctx_cap,
                              int64_t stream);
+/* enable: 0 = eager steps, 1 = hipGraph replay (default; tensor-parallel steps stay eager), 2 = also capture
+ * tensor-parallel steps with the RCCL calls inside the graph (opt-in, RCCL communicators only; not yet run on hardware) */
 int mi355_llama_set_graph(void* model, int32_t enable);
 int mi355_llama_decode_step(void* model, int64_t stream);
 int mi355_llama_decode_read_tokens(void* model, uint32_t* host_out, int64_t stream);

@@ -117,6 +117,43 @@ def test_rccl_plumbing_single_rank(lib, monkeypatch):
     assert _rel(got, ref) < 1e-3
 
 
+@pytest.mark.skipif(not os.environ.get("MI355_RUN_UNVALIDATED"),
+                    reason="set_graph(2) (RCCL calls captured in the decode graph) was written after this round's GPU "
+                           "minutes were spent: first hardware run is due next round")
+def test_tp_step_captured_in_a_graph_single_rank(lib, monkeypatch):
+    """opt-in `mi355_llama_set_graph(model, 2)`: the tensor-parallel decode step (in-stream all-reduce after wo / w2,
+    all-gather of the logits) captured in a hipGraph and replayed must give the tokens of the eager TP loop.  One rank:
+    the RCCL calls are real, their payload trivial -- this pins the capture mechanics on the one GPU we have."""
+    monkeypatch.setenv("MI355_FORCE_COMM", "1")
+    cfg, orc, gm, seqs, cache = _setup(lib, True)
+
+    class _Dist:
+        @staticmethod
+        def broadcast(t, src=0):
+            return None
+    gm.init_comm(_Dist)
+    steps = 6
+    for s, extra in zip(seqs, ([9], [5])):
+        s["block_table"] = s["block_table"] + extra
+    bt = np.zeros((2, 3), np.uint32)
+    for i, s in enumerate(seqs):
+        bt[i, :len(s["block_table"])] = s["block_table"]
+    toks0, lens0 = [s["tokens"][-1] for s in seqs], [len(s["tokens"]) for s in seqs]
+    stream = torch.cuda.Stream()
+    runs = {}
+    for mode in (0, 2):
+        for l, (kc, vc) in enumerate(cache):
+            gm.kv_upload(l, kc, vc)
+        gm.set_graph(mode)
+        gm.decode_begin(toks0, lens0, bt, ctx_cap=max(lens0) + steps, stream=stream.cuda_stream)
+        got = []
+        for _ in range(steps):
+            gm.decode_step(stream.cuda_stream)
+            got.append([int(t) for t in gm.read_tokens(stream.cuda_stream)])
+        runs[mode] = got
+    assert runs[2] == runs[0], runs
+
+
 @pytest.mark.parametrize("flash", [True, False])
 def test_prefill_step_matches_oracle_then_decodes(lib, flash):
     """prompt step on the GPU (K1 + K4 + quantised matmuls over T tokens) vs the oracle's prefill: last-token
