@@ -143,7 +143,57 @@ void orc_quantize_q8k(const float* x, int k, float* d, int8_t* q, int16_t* bsums
     }
 }
 
+/* The integer dot products below exist twice: a scalar statement (the definition) and an AVX2 statement of the SAME integer
+ * arithmetic (candle's CPU backend runs ggml-style AVX2 kernels for these, so a scalar-only port would understate the CPU
+ * baseline by an order of magnitude).  Integer sums are exact either way and the per-block float operations are identical,
+ * so both give bit-identical results; tests/test_cpu_oracle.py checks that. */
+#if defined(__AVX2__)
+#include <immintrin.h>
+static inline int32_t hsum_epi32(__m256i v) {
+    __m128i s = _mm_add_epi32(_mm256_castsi256_si128(v), _mm256_extracti128_si256(v, 1));
+    s = _mm_add_epi32(s, _mm_shuffle_epi32(s, 0x4E));
+    s = _mm_add_epi32(s, _mm_shuffle_epi32(s, 0xB1));
+    return _mm_cvtsi128_si32(s);
+}
+#endif
+
+float orc_vec_dot_q4k_q8k_scalar(const uint8_t* w, int nb, const float* xd, const int8_t* xq, const int16_t* xb);
+float orc_vec_dot_q6k_q8k_scalar(const uint8_t* w, int nb, const float* xd, const int8_t* xq);
+
 float orc_vec_dot_q4k_q8k(const uint8_t* w, int nb, const float* xd, const int8_t* xq, const int16_t* xb) {
+#if defined(__AVX2__)
+    const __m256i m4 = _mm256_set1_epi8(0xF);
+    float sumf = 0;
+    for (int i = 0; i < nb; ++i, w += Q4K_BYTES, xq += QK_K, xb += 16) {
+        uint16_t dh, mh;
+        memcpy(&dh, w, 2);
+        memcpy(&mh, w + 2, 2);
+        const float d = f16_to_f32(dh) * xd[i], dmin = f16_to_f32(mh) * xd[i];
+        const uint8_t* q4 = w + 16;
+        __m256i acc = _mm256_setzero_si256();
+        int32_t summ = 0;
+        for (int p = 0; p < 4; ++p) {                    /* 64 weights: low nibbles = sub-block 2p, high = 2p+1 */
+            uint8_t sc0, m0, sc1, m1;
+            scale_min_k4(2 * p, w + 4, &sc0, &m0);
+            scale_min_k4(2 * p + 1, w + 4, &sc1, &m1);
+            const __m256i q = _mm256_loadu_si256((const __m256i*)(q4 + 32 * p));
+            const __m256i lo = _mm256_and_si256(q, m4), hi = _mm256_and_si256(_mm256_srli_epi16(q, 4), m4);
+            const __m256i a = _mm256_loadu_si256((const __m256i*)(xq + 64 * p));
+            const __m256i b = _mm256_loadu_si256((const __m256i*)(xq + 64 * p + 32));
+            /* u8 x s8 pair sums fit s16 (<= 2*15*127); times the 6-bit scale in s32 lanes */
+            acc = _mm256_add_epi32(acc, _mm256_madd_epi16(_mm256_maddubs_epi16(lo, a), _mm256_set1_epi16(sc0)));
+            acc = _mm256_add_epi32(acc, _mm256_madd_epi16(_mm256_maddubs_epi16(hi, b), _mm256_set1_epi16(sc1)));
+            summ += (xb[4 * p] + xb[4 * p + 1]) * m0 + (xb[4 * p + 2] + xb[4 * p + 3]) * m1;
+        }
+        sumf += d * (float)hsum_epi32(acc) - dmin * (float)summ;
+    }
+    return sumf;
+#else
+    return orc_vec_dot_q4k_q8k_scalar(w, nb, xd, xq, xb);
+#endif
+}
+
+float orc_vec_dot_q4k_q8k_scalar(const uint8_t* w, int nb, const float* xd, const int8_t* xq, const int16_t* xb) {
     float sumf = 0;
     for (int i = 0; i < nb; ++i, w += Q4K_BYTES, xq += QK_K, xb += 16) {
         uint16_t dh, mh;
@@ -169,6 +219,45 @@ float orc_vec_dot_q4k_q8k(const uint8_t* w, int nb, const float* xd, const int8_
 }
 
 float orc_vec_dot_q6k_q8k(const uint8_t* w, int nb, const float* xd, const int8_t* xq) {
+#if defined(__AVX2__)
+    const __m256i m4 = _mm256_set1_epi8(0xF), m2 = _mm256_set1_epi8(3), m32 = _mm256_set1_epi8(32);
+    float sumf = 0;
+    for (int i = 0; i < nb; ++i, w += Q6K_BYTES, xq += QK_K) {
+        const uint8_t *ql = w, *qh = w + 128;
+        const int8_t* sc = (const int8_t*)(w + 192);
+        uint16_t dh;
+        memcpy(&dh, w + 208, 2);
+        const float d = f16_to_f32(dh) * xd[i];
+        __m256i acc = _mm256_setzero_si256();
+        const int8_t* q8 = xq;
+        for (int n = 0; n < 2; ++n) {
+            const __m256i la = _mm256_loadu_si256((const __m256i*)ql), lb = _mm256_loadu_si256((const __m256i*)(ql + 32));
+            const __m256i h = _mm256_loadu_si256((const __m256i*)qh);
+            /* the four 32-weight groups of this half, as unsigned 6-bit codes (the -32 is taken off below) */
+            __m256i q[4];
+            q[0] = _mm256_or_si256(_mm256_and_si256(la, m4), _mm256_slli_epi16(_mm256_and_si256(h, m2), 4));
+            q[1] = _mm256_or_si256(_mm256_and_si256(lb, m4), _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(h, 2), m2), 4));
+            q[2] = _mm256_or_si256(_mm256_and_si256(_mm256_srli_epi16(la, 4), m4), _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(h, 4), m2), 4));
+            q[3] = _mm256_or_si256(_mm256_and_si256(_mm256_srli_epi16(lb, 4), m4), _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(h, 6), m2), 4));
+            for (int g = 0; g < 4; ++g) {
+                const __m256i a = _mm256_loadu_si256((const __m256i*)(q8 + 32 * g));
+                /* sum (q - 32) * a  =  sum q*a - 32 * sum a, pairwise in s16 (|.| <= 2*63*127 + 2*32*127 < 32768) */
+                const __m256i p16 = _mm256_sub_epi16(_mm256_maddubs_epi16(q[g], a), _mm256_maddubs_epi16(m32, a));
+                /* scale index: 16 weights per scale -> s16 lanes 0..7 use sc[2g], lanes 8..15 use sc[2g+1] */
+                const __m256i scv = _mm256_set_m128i(_mm_set1_epi16(sc[2 * g + 1]), _mm_set1_epi16(sc[2 * g]));
+                acc = _mm256_add_epi32(acc, _mm256_madd_epi16(p16, scv));
+            }
+            ql += 64; qh += 32; sc += 8; q8 += 128;
+        }
+        sumf += d * (float)hsum_epi32(acc);
+    }
+    return sumf;
+#else
+    return orc_vec_dot_q6k_q8k_scalar(w, nb, xd, xq);
+#endif
+}
+
+float orc_vec_dot_q6k_q8k_scalar(const uint8_t* w, int nb, const float* xd, const int8_t* xq) {
     float sumf = 0;
     for (int i = 0; i < nb; ++i, w += Q6K_BYTES, xq += QK_K) {
         const uint8_t *ql = w, *qh = w + 128;

@@ -297,3 +297,40 @@ def test_stablelm_oracle_plumbing_decode_equals_prefill():
     fresh = m.new_cache(16)
     again = m.forward(O.prepare_prompt(seqs, cfg.block_size), fresh, is_prefill=True)
     assert np.array_equal(again, lg)
+
+
+def test_c_twin_avx2_dot_products_equal_the_scalar_definition_bit_for_bit():
+    """oracle/oracle.c states the Q4_K x Q8_K and Q6_K x Q8_K integer dots twice (scalar definition, AVX2 for the
+    cpu_baseline's speed): random and extreme blocks (all codes 15 / 63 with activations +-127, the saturation corner of
+    `maddubs`), identical float results"""
+    import ctypes
+    from oracle import cref
+    cref.build()
+    L = cref.lib()
+    vp, i32 = ctypes.c_void_p, ctypes.c_int32
+    for name, args in (("orc_vec_dot_q4k_q8k", [vp, i32, vp, vp, vp]), ("orc_vec_dot_q4k_q8k_scalar", [vp, i32, vp, vp, vp]),
+                       ("orc_vec_dot_q6k_q8k", [vp, i32, vp, vp]), ("orc_vec_dot_q6k_q8k_scalar", [vp, i32, vp, vp])):
+        getattr(L, name).argtypes, getattr(L, name).restype = args, ctypes.c_float
+    rng = np.random.default_rng(12)
+    nb = 6
+    for trial in range(60):
+        xq = rng.integers(-127, 128, nb * 256).astype(np.int8)
+        w4 = rng.integers(0, 256, nb * 144, dtype=np.uint8)
+        w6 = rng.integers(0, 256, nb * 210, dtype=np.uint8)
+        if trial % 5 == 0:                                          # extremes
+            sign = 1 if trial % 10 == 0 else -1
+            xq[:] = 127 * sign
+            w4[:] = 0xFF
+            w6[:] = 0xFF
+            w6.reshape(nb, 210)[:, 192:208] = 0x7F if trial % 3 == 0 else 0x80      # scales +127 / -128
+        for b in range(nb):                                         # finite f16 scales
+            w4[b * 144:b * 144 + 4] = np.frombuffer(np.asarray([0.013, 0.007], np.float16).tobytes(), np.uint8)
+            w6[b * 210 + 208:b * 210 + 210] = np.frombuffer(np.float16(0.011).tobytes(), np.uint8)
+        xd = rng.uniform(0.01, 0.1, nb).astype(np.float32)
+        xb = xq.astype(np.int32).reshape(-1, 16).sum(1).astype(np.int16)
+        a = L.orc_vec_dot_q4k_q8k(w4.ctypes.data, nb, xd.ctypes.data, xq.ctypes.data, xb.ctypes.data)
+        b_ = L.orc_vec_dot_q4k_q8k_scalar(w4.ctypes.data, nb, xd.ctypes.data, xq.ctypes.data, xb.ctypes.data)
+        assert np.float32(a).tobytes() == np.float32(b_).tobytes(), (trial, a, b_)
+        c = L.orc_vec_dot_q6k_q8k(w6.ctypes.data, nb, xd.ctypes.data, xq.ctypes.data)
+        d = L.orc_vec_dot_q6k_q8k_scalar(w6.ctypes.data, nb, xd.ctypes.data, xq.ctypes.data)
+        assert np.float32(c).tobytes() == np.float32(d).tobytes(), (trial, c, d)
