@@ -27,6 +27,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
 
 
+# OpenMP threads that spin while idle burn a CPU quota and can slow the C oracle's cpu_baseline by an order of magnitude
+# on hosts whose quota is below their visible CPU count; must be set before libgomp is loaded (torch, liboracle)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+
 def llama3_8b():
     from oracle.llama import LlamaConfig   # dataclass of dims only (no arithmetic)
     return LlamaConfig.llama3_8b()
@@ -75,18 +80,34 @@ def cpu_baseline(cfg, steps, ctx=64):
     table = list(range(nblk))
     toks = [int(t) for t in rng.integers(0, cfg.vocab, ctx)]
     from oracle import ops as O
-    times = []
-    for _ in range(steps):
+    # thread count: all hardware threads is not always the fastest (SMT siblings, a cgroup quota below the visible
+    # CPU count); try a few counts, one step each, then time `steps` steps at the best one
+    L = cref.lib()
+    nmax = int(L.orc_num_threads())
+    trial = {}
+
+    def one_step():
         meta = O.prepare_decode([{"tokens": toks, "block_table": table}], cfg.block_size)
         t1 = time.time()
         lg = m.decode(meta, cache, o2=True)
-        times.append(time.time() - t1)
+        dt = time.time() - t1
         toks.append(int(lg[0].argmax()))
-    best = min(times)
-    return {"value": round(1.0 / best, 4), "unit": "tokens/s", "cores": int(cref.lib().orc_num_threads()),
+        return dt
+    for n in sorted({nmax, max(1, nmax // 2), max(1, nmax // 4), max(1, nmax // 8)}, reverse=True):
+        L.orc_set_num_threads(n)
+        trial[n] = one_step()
+        if trial[n] > 20.0:                                   # keep the sample bounded on a slow host
+            break
+    nbest = min(trial, key=trial.get)
+    L.orc_set_num_threads(nbest)
+    times = [one_step() for _ in range(steps)]
+    best = min(times + [trial[nbest]])
+    return {"value": round(1.0 / best, 4), "unit": "tokens/s", "cores": nbest,
             "kind": "port",
             "sample": f"{steps} decode steps, batch 1, ctx {ctx}, full {cfg.n_layers}-layer Q4_K_M model, "
-                      f"candle-CPU-style Q8_K integer dot (oracle/oracle.c, OpenMP), best step; setup {setup:.1f}s"}
+                      f"candle-CPU-style Q8_K integer dot in AVX2 (oracle/oracle.c, OpenMP, passive wait), best step at the "
+                      f"best of the thread counts tried {({k: round(v, 3) for k, v in trial.items()})} s/step; "
+                      f"setup {setup:.1f}s"}
 
 
 def bench_batch32(gm, cfg, args, perm, blocks_per_seq, stream, kv_per_tok):

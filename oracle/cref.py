@@ -44,6 +44,7 @@ def lib():
         L.orc_llama_fill_random.restype = i32
         L.orc_llama_decode.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32]
         L.orc_num_threads.restype = i32
+        L.orc_set_num_threads.argtypes = [i32]
         _lib = L
     return _lib
 

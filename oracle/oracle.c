@@ -540,6 +540,15 @@ void orc_llama_decode(void* mp, const uint32_t* tokens, const int64_t* positions
     free(xs); free(xn); free(q); free(k); free(v); free(att); free(g); free(u); free(tmp);
 }
 
+/* bench.py's cpu_baseline picks the thread count that gives the fastest step on the host it runs on */
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
