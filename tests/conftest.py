@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# idle OpenMP threads that spin burn the CPU quota of a container whose quota is below its visible CPU count (the C
+# oracle's parallel loops then run 10-50x slower); must be in the environment before libgomp is loaded
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
