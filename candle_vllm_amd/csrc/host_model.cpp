@@ -822,6 +822,10 @@ int load_gguf_impl(const char* path, int32_t max_batch, int32_t max_blocks_per_s
     if (!sane) return (int)hipErrorInvalidValue;
     if (!u(key("attention.key_length"), &key_len)) key_len = embd / head_count;
     if (key_len == 0 || key_len > 4096) return (int)hipErrorInvalidValue;
+    // partial rotary (`rope.dimension_count` != head_dim -> partial_rotary_factor, quantized_llama.rs:289-298): the GGUF
+    // step here rotates the whole head; refuse rather than rotate the wrong dimensions
+    uint64_t rope_dim = 0;
+    if (u(key("rope.dimension_count"), &rope_dim) && rope_dim != key_len) return (int)hipErrorNotSupported;
     double eps = 0, theta = 10000.0;
     if (mi355_gguf_get_f64(g, key("attention.layer_norm_rms_epsilon").c_str(), &eps) != 1) return (int)hipErrorInvalidValue;
     (void)mi355_gguf_get_f64(g, key("rope.freq_base").c_str(), &theta);

@@ -331,6 +331,8 @@ def test_check_gguf_refuses_inconsistent_files(lib, tmp_path):
     assert variant(drop="blk.1.ffn_up.weight") == 1
     assert variant(drop="output_norm.weight") == 1
     assert variant(retype="blk.0.attn_v.weight") == 801
+    assert variant(md2={"llama.rope.dimension_count": cfg.head_dim}) == 0         # full rotary, stated explicitly
+    assert variant(md2={"llama.rope.dimension_count": cfg.head_dim // 2}) == 801  # partial rotary: not served by the GGUF step
     q = next(x for x in ts if x[0] == "blk.0.attn_output.weight")
     assert variant(reshape=("blk.0.attn_output.weight", [q[3][0] // 2, q[3][1] * 2])) == 1    # same bytes, wrong shape
     assert lib.mi355_llama_check_gguf(None, 0, 1, None) == 1
