@@ -905,6 +905,10 @@ int load_gguf_impl(const char* path, int32_t max_batch, int32_t max_blocks_per_s
             RCHECK(expect_q(p + "attn_output.weight", hid, HD, 1, tp_world));
             RCHECK(expect_f32(p + "attn_norm.weight", hid));
             RCHECK(expect_f32(p + "ffn_norm.weight", hid));
+            // tensors the reference's QuantizedAttention would use when present (qkv bias, per-head q/k norm:
+            // attention.rs:811-866) and this step does not apply: refuse instead of computing something else
+            for (const char* extra : {"attn_q.bias", "attn_k.bias", "attn_v.bias", "attn_q_norm.weight", "attn_k_norm.weight"})
+                if (mi355_gguf_find(g, (p + extra).c_str()) >= 0) return (int)hipErrorNotSupported;
             if (cfg.n_expert > 1) {
                 RCHECK(expect_f32(p + "ffn_gate_inp.weight", (int64_t)cfg.n_expert * hid));
                 for (int e = 0; e < cfg.n_expert; ++e) {

@@ -333,6 +333,10 @@ def test_check_gguf_refuses_inconsistent_files(lib, tmp_path):
     assert variant(retype="blk.0.attn_v.weight") == 801
     assert variant(md2={"llama.rope.dimension_count": cfg.head_dim}) == 0         # full rotary, stated explicitly
     assert variant(md2={"llama.rope.dimension_count": cfg.head_dim // 2}) == 801  # partial rotary: not served by the GGUF step
+    # a Qwen2-style file (qkv bias) or a q/k-norm file: the GGUF step would ignore those tensors -> refused
+    for extra in ("blk.1.attn_q.bias", "blk.0.attn_k_norm.weight"):
+        GW.write_gguf(p, md, ts + [(extra, 0, np.zeros(cfg.head_dim * 4, np.uint8), [cfg.head_dim])])
+        assert _check(lib, p)[0] == 801, extra
     q = next(x for x in ts if x[0] == "blk.0.attn_output.weight")
     assert variant(reshape=("blk.0.attn_output.weight", [q[3][0] // 2, q[3][1] * 2])) == 1    # same bytes, wrong shape
     assert lib.mi355_llama_check_gguf(None, 0, 1, None) == 1
