@@ -1130,4 +1130,35 @@ void mi355_sched_rollback_swap_out(void* sp, int64_t group_id) {
     mi355_be_rollback_swap_out(s->eng, group_id);
 }
 
+/* ---- cache budget: src/lib.rs:128-284,515-523 -------------------------------------------------------- */
+/* compute_kvcache_budget_bytes (lib.rs:515-523): round(free_bytes * fraction) with the f32 fraction widened to f64;
+ * -1 when the fraction is outside (0, 1] (the reference returns an error) */
+int64_t mi355_kvcache_budget_bytes(int64_t free_bytes, float fraction) {
+    if (!(0.0f < fraction && fraction <= 1.0f) || free_bytes < 0) return -1;
+    const double v = (double)free_bytes * (double)fraction;
+    return (int64_t)(v + 0.5);                                  /* f64::round for non-negative values */
+}
+/* get_cache_config (lib.rs:128-284), the non-MLA / non-TurboQuant arm: per_block = dsize * block_size * kv heads per
+ * shard * head_dim * layers * 2 (at least 1); num_gpu_blocks = mem_gpu_mb * 2^20 / per_block; CPU blocks: half the GPU
+ * blocks when mem_cpu_mb == 0, else the explicit budget -- and none at all when CPU swap is off (the reference ties
+ * that to its `cuda` feature, lib.rs:247-257).  kv heads per shard: global / shards, 1 when there are fewer heads than
+ * shards (:159-166).  Returns 0, or hipErrorInvalidValue (1) for non-positive dimensions. */
+int mi355_get_cache_config(int64_t mem_gpu_mb, int64_t mem_cpu_mb, int32_t block_size, int32_t num_kv_heads, int32_t head_dim,
+                           int32_t num_layers, int32_t dsize, int32_t num_shards, int32_t cpu_swap, int64_t* num_gpu_blocks,
+                           int64_t* num_cpu_blocks) {
+    if (mem_gpu_mb < 0 || mem_cpu_mb < 0 || block_size <= 0 || num_kv_heads <= 0 || head_dim <= 0 || dsize <= 0 ||
+        !num_gpu_blocks || !num_cpu_blocks || mem_gpu_mb > (INT64_MAX >> 20) || mem_cpu_mb > (INT64_MAX >> 20))
+        return 1;
+    const int64_t shards = num_shards > 1 ? num_shards : 1;
+    const int64_t heads = num_kv_heads < shards ? 1 : num_kv_heads / shards;
+    const int64_t layers = num_layers > 1 ? num_layers : 1;     /* kv_cache_num_layers().max(1) */
+    int64_t per_block = (int64_t)dsize * block_size * heads * head_dim * layers * 2;
+    if (per_block < 1) per_block = 1;
+    const int64_t gpu = mem_gpu_mb * (1 << 20) / per_block;
+    *num_gpu_blocks = gpu;
+    *num_cpu_blocks = cpu_swap ? (mem_cpu_mb == 0 ? gpu / 2 : mem_cpu_mb * (1 << 20) / per_block) : 0;
+    return 0;
+}
+
+
 }  // extern "C"

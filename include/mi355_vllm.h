@@ -551,6 +551,17 @@ int32_t mi355_sched_abort_sequences(void* sched, const int64_t* seq_ids, int32_t
 void mi355_sched_rollback_swap_in(void* sched, int64_t group_id);
 void mi355_sched_rollback_swap_out(void* sched, int64_t group_id);
 
+/* Cache budget: `compute_kvcache_budget_bytes` (src/lib.rs:515-523) and `get_cache_config`
+ * (src/lib.rs:128-284, the non-MLA / non-TurboQuant arm).  Host arithmetic only.
+ *   budget: round(free_bytes * fraction); -1 for a fraction outside (0, 1].
+ *   config: per_block = dsize * block_size * kv_heads_per_shard * head_dim * max(layers, 1) * 2;
+ *           num_gpu_blocks = mem_gpu_mb * 2^20 / per_block; num_cpu_blocks = cpu_swap ? (mem_cpu_mb == 0 ? gpu / 2 :
+ *           mem_cpu_mb * 2^20 / per_block) : 0; kv_heads_per_shard = heads < shards ? 1 : heads / shards. */
+int64_t mi355_kvcache_budget_bytes(int64_t free_bytes, float fraction);
+int mi355_get_cache_config(int64_t mem_gpu_mb, int64_t mem_cpu_mb, int32_t block_size, int32_t num_kv_heads, int32_t head_dim,
+                           int32_t num_layers, int32_t dsize, int32_t num_shards, int32_t cpu_swap, int64_t* num_gpu_blocks,
+                           int64_t* num_cpu_blocks);
+
 /* ---------------------------------------------------------------------------------------------
  * 7. GGUF file reader: src/backend/gguf.rs:48-102,623-712, quantized_var_builder.rs:27-58;
  *    keys and tensor names as GGUFLLaMa reads them (quantized_llama.rs:225-371).  mmap, zero copy.

@@ -331,3 +331,37 @@ def test_input_preparation_at_baseline_sizes_ragged_and_empty(be):
     for s in seqs:
         eng.free_sequence(s)
     assert eng.get_num_free_blocks() == eng.get_num_blocks()
+
+
+def test_cache_budget_matches_the_reference_tests_and_the_oracle(lib):
+    """a24: `compute_kvcache_budget_bytes` against the reference's own unit tests (src/lib.rs:773-785: 700 * 0.9 -> 630,
+    0 -> 0) and `get_cache_config` (src/lib.rs:128-284) against the oracle restatement and SURVEY 8a's worked number
+    (Llama-3-8B bf16, block 64: 8 MiB per block across 32 layers x (K+V))"""
+    import ctypes
+    assert lib.mi355_kvcache_budget_bytes(700, 0.9) == 630               # test_compute_kvcache_budget_bytes
+    assert lib.mi355_kvcache_budget_bytes(0, 0.9) == 0                   # ..._clamps_to_zero
+    assert lib.mi355_kvcache_budget_bytes(1000, 1.0) == 1000
+    for bad in (0.0, -0.5, 1.5, float("nan")):                           # "kv_fraction must be in (0, 1]"
+        assert lib.mi355_kvcache_budget_bytes(700, bad) == -1
+    # f32 fraction widened to f64, then round-half-away: 0.9f32 = 0.89999997..., 5 * 0.9f32 = 4.4999998 -> 4
+    assert lib.mi355_kvcache_budget_bytes(5, 0.9) == 4 and lib.mi355_kvcache_budget_bytes(15, 0.5) == 8
+
+    def cfg(mem_gpu, mem_cpu, bs, hkv, d, layers, dsize, shards, swap):
+        g, c = ctypes.c_int64(-1), ctypes.c_int64(-1)
+        rc = lib.mi355_get_cache_config(mem_gpu, mem_cpu, bs, hkv, d, layers, dsize, shards, swap, ctypes.addressof(g), ctypes.addressof(c))
+        return rc, g.value, c.value
+    assert cfg(16384, 0, 64, 8, 128, 32, 2, 1, 1) == (0, 2048, 1024)    # 16 GiB / 8 MiB; CPU default = half
+    assert cfg(16384, 4096, 64, 8, 128, 32, 2, 1, 1) == (0, 2048, 512)  # explicit CPU budget
+    assert cfg(16384, 4096, 64, 8, 128, 32, 2, 1, 0) == (0, 2048, 0)    # swap off: no CPU blocks
+    assert cfg(16384, 0, 64, 8, 128, 32, 1, 1, 1)[1] == 4096            # fp8 cache: 1-byte elements
+    assert cfg(16384, 0, 64, 8, 128, 32, 2, 8, 1)[1] == 16384           # TP 8: one kv head per rank
+    assert cfg(16384, 0, 64, 8, 128, 32, 2, 16, 1)[1] == 16384          # fewer heads than shards: still one head
+    assert cfg(100, 0, 64, 8, 128, 0, 2, 1, 1)[1] == cfg(100, 0, 64, 8, 128, 1, 2, 1, 1)[1]   # layers.max(1)
+    rng = np.random.default_rng(9)
+    for _ in range(200):
+        mem, bs = int(rng.integers(1, 200000)), int(rng.choice([16, 32, 64]))
+        hkv, d, layers = int(rng.choice([1, 2, 4, 8, 32])), int(rng.choice([64, 80, 128, 256])), int(rng.integers(1, 81))
+        dsize, shards = int(rng.choice([1, 2, 4])), int(rng.choice([1, 2, 4, 8]))
+        local = 1 if hkv < shards else hkv // shards
+        assert cfg(mem, 0, bs, hkv, d, layers, dsize, shards, 1)[1] == O.num_gpu_blocks(mem, dsize, bs, local, d, layers)
+    assert cfg(1, 0, 0, 8, 128, 32, 2, 1, 1)[0] == 1 and cfg(-1, 0, 64, 8, 128, 32, 2, 1, 1)[0] == 1
