@@ -245,6 +245,7 @@ _sig("mi355_llama_load_gguf", ctypes.c_int, [ctypes.c_char_p] + [c_i32] * 5 + [c
 _sig("mi355_llama_load_gguf_tp", ctypes.c_int, [ctypes.c_char_p] + [c_i32] * 7 + [c_vp, c_vp])
 _sig("mi355_llama_check_gguf", ctypes.c_int, [ctypes.c_char_p, c_i32, c_i32, c_vp])
 _sig("mi355_kvcache_budget_bytes", c_i64, [c_i64, c_f32])
+_sig("mi355_effective_max_seq_len", c_i64, [c_vp, c_i64])
 _sig("mi355_get_cache_config", ctypes.c_int, [c_i64, c_i64] + [c_i32] * 7 + [c_vp, c_vp])
 _sig("mi355_gguf_tensor_shard", ctypes.c_int64, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, ctypes.c_int64])
 

@@ -60,6 +60,16 @@ extern "C" int32_t mi355_rope_table_len(const mi355_rope_scaling* sc, int32_t ma
     return -1;
 }
 
+// Config::effective_max_seq_len (src/openai/models/mod.rs:663-702): the context length a yarn-scaled model serves,
+// max(base, round(original_max_position_embeddings * factor)) for factor > 1; every other scaling keeps the base.
+// `apply_runtime_rope_overrides(Some(f))` (:704-714) is this with {yarn, factor f, original = base}.
+extern "C" int64_t mi355_effective_max_seq_len(const mi355_rope_scaling* sc, int64_t base_max_position_embeddings) {
+    if (!sc || sc->type != MI355_ROPE_YARN || !(sc->factor > 1.0) || !(sc->original_max_position_embeddings > 0))
+        return base_max_position_embeddings;
+    const int64_t scaled = (int64_t)std::llround(sc->original_max_position_embeddings * sc->factor);
+    return scaled > base_max_position_embeddings ? scaled : base_max_position_embeddings;
+}
+
 extern "C" int mi355_rope_tables(float* cos_out, float* sin_out, int32_t rotary_dim, int32_t n_positions, double rope_theta,
                                  const mi355_rope_scaling* sc, int32_t max_seq_len, int32_t max_position_embeddings) {
     if (!cos_out || !sin_out || rotary_dim <= 0 || (rotary_dim & 1) || n_positions <= 0 || rope_theta <= 0) return 1;

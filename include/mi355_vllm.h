@@ -301,6 +301,9 @@ typedef struct mi355_rope_scaling {
 int32_t mi355_rope_table_len(const mi355_rope_scaling* sc, int32_t max_seq_len, int32_t max_position_embeddings);
 int mi355_rope_tables(float* cos_out_host, float* sin_out_host, int32_t rotary_dim, int32_t n_positions, double rope_theta,
                       const mi355_rope_scaling* sc /* NULL = default */, int32_t max_seq_len, int32_t max_position_embeddings);
+/* `Config::effective_max_seq_len` (src/openai/models/mod.rs:663-702): max(base, round(original * factor)) for yarn with
+ * factor > 1, the base otherwise -- the context length the KV cache and the tables above are sized for */
+int64_t mi355_effective_max_seq_len(const mi355_rope_scaling* sc, int64_t base_max_position_embeddings);
 
 /* ---------------------------------------------------------------------------------------------
  * 4. Host layer: the GGUF llama decode step (GGUFLLaMa::forward + CacheEngine + decode graph), C handles.

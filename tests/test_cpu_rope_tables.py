@@ -128,3 +128,28 @@ def test_rope_scaling_matches_huggingface_inverse_frequencies():
             for got_c, got_s, who in ((oc[r], osn[r], "oracle"), (cos[r], sin[r], "library")):
                 assert (np.abs(got_c - np.cos(ang) * att) <= tol).all(), (name, who, r, np.abs(got_c - np.cos(ang) * att).max())
                 assert (np.abs(got_s - np.sin(ang) * att) <= tol).all(), (name, who, r, np.abs(got_s - np.sin(ang) * att).max())
+
+
+def test_effective_max_seq_len_matches_the_reference_unit_tests():
+    """`Config::effective_max_seq_len` / `apply_runtime_rope_overrides` against the reference's own tests
+    (src/openai/models/mod.rs:889-918): yarn factor 4 over 262144 -> 1048576; runtime yarn factor 8 -> 2097152"""
+    import __graft_entry__ as ge
+    ge.build()
+    from candle_vllm_amd._lib import lib, RopeScaling
+    sc = RopeScaling()
+    sc.type, sc.factor, sc.original_max_position_embeddings = TYPES["yarn"], 4.0, 262144.0
+    assert lib.mi355_effective_max_seq_len(ctypes.addressof(sc), 262144) == 1_048_576      # test_effective_max_seq_len_scales_yarn_context
+    sc.factor = 8.0                                                                        # apply_runtime_rope_overrides(Some(8.0))
+    assert lib.mi355_effective_max_seq_len(ctypes.addressof(sc), 262144) == 2_097_152
+    # and the rules around them (:691-701): only yarn, only factor > 1, never below the base, absent original -> base
+    assert lib.mi355_effective_max_seq_len(None, 8192) == 8192
+    sc.factor = 1.0
+    assert lib.mi355_effective_max_seq_len(ctypes.addressof(sc), 262144) == 262144
+    sc.factor, sc.original_max_position_embeddings = 4.0, 1024.0
+    assert lib.mi355_effective_max_seq_len(ctypes.addressof(sc), 8192) == 8192
+    sc.original_max_position_embeddings = 0.0
+    assert lib.mi355_effective_max_seq_len(ctypes.addressof(sc), 8192) == 8192
+    sc.type, sc.factor, sc.original_max_position_embeddings = TYPES["llama3"], 8.0, 8192.0
+    assert lib.mi355_effective_max_seq_len(ctypes.addressof(sc), 131072) == 131072
+    sc.type, sc.factor, sc.original_max_position_embeddings = TYPES["yarn"], 2.5, 1001.0
+    assert lib.mi355_effective_max_seq_len(ctypes.addressof(sc), 100) == 2503                # round(2502.5) away from zero
