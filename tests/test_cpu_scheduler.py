@@ -268,3 +268,15 @@ def test_scheduler_stress_under_block_pressure(be, seed, prefix_cache):
     assert saw_recompute + saw_swap > 0                                # the pool really was under pressure
     if prefix_cache:
         assert saw_swap > 0
+
+
+def test_active_sequence_limit_is_at_least_one(be):
+    """the reference's own unit test (scheduler/mod.rs:59-62: `active_sequence_limit(0, None) == 1`): a parallel-request
+    limit of 0 still admits one sequence per prompt step instead of starving the queue"""
+    s = _mk(be, max_num_parallel_reqs=0)
+    a = s.block_engine.new_sequence(1, list(range(5)))
+    b = s.block_engine.new_sequence(2, list(range(5)))
+    s.add_sequence(1, [a])
+    s.add_sequence(2, [b])
+    out = s.schedule()
+    assert out.is_prompt and out.scheduled == [1] and s.num_waiting() == 1
