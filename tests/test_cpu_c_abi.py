@@ -54,3 +54,23 @@ def test_plain_c_program_links_and_agrees_with_the_library(lib, tmp_path):
     assert int(kv["repacked_bad"][0]) < 0
     assert kv["rope_len"] == ["4"] and kv["rope_rc"] == ["0"] and kv["rope_row0"] == ["1.0", "0.0"]
     assert kv["gguf_open_missing"] == ["1"]
+
+
+def test_every_entry_point_cites_the_reference_interface_it_replaces():
+    """the header is the drop-in boundary: every declared function carries (itself, or the section banner it sits under) a
+    reference citation of the form file.rs:line / file.py:line"""
+    import re
+    src = open(os.path.join(INC, "mi355_vllm.h")).read()
+    decl = re.compile(r"^\s*(?:(?:const )?void\*?|int|int32_t|int64_t|uint64_t|float\*)\s+(\w+)\s*\(", re.M)
+    cite = re.compile(r"\.(rs|py):\d+")
+    last_end, section_cited, missing, n = 0, False, [], 0
+    for m in decl.finditer(src):
+        n += 1
+        between = src[last_end:m.start()]
+        end = src.index(";", m.start()) + 1
+        if re.search(r"/\* -{20,}", between):
+            section_cited = bool(cite.search(between[between.rfind("/* ---"):]))
+        if not cite.search(between + src[m.start():end]) and not section_cited:
+            missing.append(m.group(1))
+        last_end = end
+    assert n > 150 and not missing, missing
