@@ -17,6 +17,7 @@ DT = "bf16"
 
 
 def R(a):
+    """candle rounds every op result to the model dtype: src/openai/models/llama.rs:46-63."""
     return G.round_dt(a, DT)
 
 
@@ -57,6 +58,7 @@ class DenseConfig:
 
 
 def make_weights(cfg, seed=4321, std=0.05):
+    """tensor set of src/openai/models/llama.rs:203-260 (synthetic values)."""
     rng = np.random.default_rng(seed)
     H, Hkv, D, hid, I = cfg.n_heads, cfg.n_kv_heads, cfg.head_dim, cfg.hidden, cfg.intermediate
 
@@ -108,7 +110,8 @@ def _lin(x, w, b=None):
 
 
 def rms_norm16(x, w, eps):
-    """candle rms_norm on 16-bit data: f32 internally, result rounded (layers/others.rs NormX)."""
+    """candle rms_norm on 16-bit data: f32 internally, result rounded (layers/others.rs NormX).
+    candle_nn::RmsNorm in the model dtype: src/openai/distributed.rs:1164-1205, src/openai/models/llama.rs:53-54."""
     x = np.asarray(x, np.float32)
     inv = 1.0 / np.sqrt((x.astype(np.float64) ** 2).mean(-1, keepdims=True) + eps)
     return R(x * inv * np.asarray(w, np.float32))
@@ -148,6 +151,7 @@ class OracleDenseLlama:
         return rms_norm16(x, w, self.cfg.rms_eps)
 
     def new_cache(self, num_blocks):
+        """src/scheduler/cache_engine.rs:298-341 (shapes), :304-311 for the fp8 cache."""
         c = self.cfg
         if c.kv_fp8:
             ks, vs = ops.kv_cache_shapes(num_blocks, c.block_size, c.n_kv_heads, c.head_dim, 1, False)
@@ -172,6 +176,7 @@ class OracleDenseLlama:
         return np.concatenate(ys, 0)
 
     def forward(self, meta, kv_caches, is_prefill=False):
+        """Llama::forward_inner src/openai/models/llama.rs:139-201 with Attention::forward_ext src/openai/models/layers/attention.rs:585-734."""
         c, W = self.cfg, self.W
         toks, pos = meta["input_ids"], meta["positions"]
         T = len(toks)

@@ -55,7 +55,7 @@ def dequantize_q4_k(blocks):
 
     w[64g + l]      = d*sc[2g]  *(qs[32g+l] & 0xF) - dmin*m[2g]
     w[64g + 32 + l] = d*sc[2g+1]*(qs[32g+l] >> 4)  - dmin*m[2g+1]
-    """
+    Format [EXT ggml k-quants, SURVEY.md App. C]; semantics fixed by the QMatMul::forward call sites src/openai/models/layers/attention.rs:920-922 and src/openai/models/quantized_llama.rs:33-37 (candle k_quants.rs is un-vendored)."""
     b = np.ascontiguousarray(blocks, dtype=np.uint8)
     assert b.shape[-1] == Q4_K_BLOCK_BYTES
     lead = b.shape[:-1]
@@ -78,7 +78,7 @@ def quantize_q4_k(w):
     A plain min/max quantiser producing VALID Q4_K blocks.  It is NOT ggml's
     search-based `quantize_row_q4_K` (make_qkx2_quants); the reference never quantises on the
     decode hot path (only ISQ / TP re-shard, out of scope), so only the *format* matters.
-    """
+    Format [EXT ggml k-quants, SURVEY.md App. C]; semantics fixed by the QMatMul::forward call sites src/openai/models/layers/attention.rs:920-922 and src/openai/models/quantized_llama.rs:33-37 (candle k_quants.rs is un-vendored)."""
     w = np.asarray(w, dtype=np.float32)
     K = w.shape[-1]
     assert K % QK_K == 0
@@ -133,7 +133,8 @@ def dequantize_q6_k(blocks):
 
 
 def quantize_q6_k(w):
-    """w: float [..., K] -> uint8 [..., K/256, 210]; plain absmax quantiser (valid format)."""
+    """w: float [..., K] -> uint8 [..., K/256, 210]; plain absmax quantiser (valid format).
+    Format [EXT ggml k-quants, SURVEY.md App. C]; semantics fixed by the QMatMul::forward call sites src/openai/models/layers/attention.rs:920-922 and src/openai/models/quantized_llama.rs:33-37 (candle k_quants.rs is un-vendored)."""
     w = np.asarray(w, dtype=np.float32)
     K = w.shape[-1]
     assert K % QK_K == 0
@@ -168,6 +169,7 @@ def quantize_q6_k(w):
 
 # --------------------------------------------------------------------------- Q8_0
 def dequantize_q8_0(blocks):
+    """Format [EXT ggml k-quants, SURVEY.md App. C]; semantics fixed by the QMatMul::forward call sites src/openai/models/layers/attention.rs:920-922 and src/openai/models/quantized_llama.rs:33-37 (candle k_quants.rs is un-vendored)."""
     b = np.ascontiguousarray(blocks, dtype=np.uint8)
     assert b.shape[-1] == Q8_0_BLOCK_BYTES
     lead = b.shape[:-1]
@@ -177,6 +179,7 @@ def dequantize_q8_0(blocks):
 
 
 def quantize_q8_0(w):
+    """Format [EXT ggml k-quants, SURVEY.md App. C]; semantics fixed by the QMatMul::forward call sites src/openai/models/layers/attention.rs:920-922 and src/openai/models/quantized_llama.rs:33-37 (candle k_quants.rs is un-vendored)."""
     w = np.asarray(w, np.float32)
     lead = w.shape[:-1]
     x = w.reshape(lead + (w.shape[-1] // 32, 32))
@@ -196,7 +199,7 @@ def quantize_q8_k(x):
 
     ggml quantize_row_q8_K: iscale = -128/max (signed max-abs element), q = min(127, round(iscale*x)),
     d = 1/iscale.  [EXT]
-    """
+    Format [EXT ggml k-quants, SURVEY.md App. C]; semantics fixed by the QMatMul::forward call sites src/openai/models/layers/attention.rs:920-922 and src/openai/models/quantized_llama.rs:33-37 (candle k_quants.rs is un-vendored)."""
     x = np.asarray(x, np.float32)
     lead = x.shape[:-1]
     xb = x.reshape(lead + (x.shape[-1] // QK_K, QK_K))
@@ -212,7 +215,8 @@ def quantize_q8_k(x):
 
 
 def vec_dot_q4k_q8k(blocks, xd, xq, xbsums):
-    """O2: rows of Q4_K blocks [N, nb, 144] . one Q8_K-quantised vector -> f32 [N]."""
+    """O2: rows of Q4_K blocks [N, nb, 144] . one Q8_K-quantised vector -> f32 [N].
+    Format [EXT ggml k-quants, SURVEY.md App. C]; semantics fixed by the QMatMul::forward call sites src/openai/models/layers/attention.rs:920-922 and src/openai/models/quantized_llama.rs:33-37 (candle k_quants.rs is un-vendored)."""
     b = np.ascontiguousarray(blocks, np.uint8)
     d = b[..., 0:2].copy().view(np.float16)[..., 0].astype(np.float32)
     dmin = b[..., 2:4].copy().view(np.float16)[..., 0].astype(np.float32)
@@ -229,6 +233,7 @@ def vec_dot_q4k_q8k(blocks, xd, xq, xbsums):
 
 
 def vec_dot_q6k_q8k(blocks, xd, xq):
+    """Format [EXT ggml k-quants, SURVEY.md App. C]; semantics fixed by the QMatMul::forward call sites src/openai/models/layers/attention.rs:920-922 and src/openai/models/quantized_llama.rs:33-37 (candle k_quants.rs is un-vendored)."""
     b = np.ascontiguousarray(blocks, np.uint8)
     lead = b.shape[:-1]
     ql = b[..., 0:128].reshape(lead + (2, 64))
@@ -253,6 +258,7 @@ BLOCK_BYTES = {GGML_Q4_K: Q4_K_BLOCK_BYTES, GGML_Q6_K: Q6_K_BLOCK_BYTES}
 
 
 def dequantize(blocks, ggml_type):
+    """Format [EXT ggml k-quants, SURVEY.md App. C]; semantics fixed by the QMatMul::forward call sites src/openai/models/layers/attention.rs:920-922 and src/openai/models/quantized_llama.rs:33-37 (candle k_quants.rs is un-vendored)."""
     if ggml_type == GGML_Q4_K:
         return dequantize_q4_k(blocks)
     if ggml_type == GGML_Q6_K:
@@ -263,6 +269,7 @@ def dequantize(blocks, ggml_type):
 
 
 def quantize(w, ggml_type):
+    """Format [EXT ggml k-quants, SURVEY.md App. C]; semantics fixed by the QMatMul::forward call sites src/openai/models/layers/attention.rs:920-922 and src/openai/models/quantized_llama.rs:33-37 (candle k_quants.rs is un-vendored)."""
     if ggml_type == GGML_Q4_K:
         return quantize_q4_k(w)
     if ggml_type == GGML_Q6_K:
@@ -273,13 +280,15 @@ def quantize(w, ggml_type):
 
 
 def qmatmul_o1(x, blocks, ggml_type):
-    """`QMatMul::forward(&x_f32)` semantics, oracle O1: y[T,N] = x[T,K] . dequant(W[N,K])^T in f64."""
+    """`QMatMul::forward(&x_f32)` semantics, oracle O1: y[T,N] = x[T,K] . dequant(W[N,K])^T in f64.
+    Format [EXT ggml k-quants, SURVEY.md App. C]; semantics fixed by the QMatMul::forward call sites src/openai/models/layers/attention.rs:920-922 and src/openai/models/quantized_llama.rs:33-37 (candle k_quants.rs is un-vendored)."""
     w = dequantize(blocks, ggml_type).astype(np.float64)           # [N, K]
     return (np.asarray(x, np.float64) @ w.T).astype(np.float32)
 
 
 def qmatmul_o2(x, blocks, ggml_type):
-    """candle-CPU-faithful (Q8_K activations, integer dot)."""
+    """candle-CPU-faithful (Q8_K activations, integer dot).
+    Format [EXT ggml k-quants, SURVEY.md App. C]; semantics fixed by the QMatMul::forward call sites src/openai/models/layers/attention.rs:920-922 and src/openai/models/quantized_llama.rs:33-37 (candle k_quants.rs is un-vendored)."""
     x = np.asarray(x, np.float32)
     out = []
     for t in range(x.shape[0]):

@@ -31,6 +31,7 @@ class LlamaConfig:
 
     @staticmethod
     def llama3_8b():
+        """dims read from GGUF metadata at src/openai/models/quantized_llama.rs:231-260 (public model-card values)."""
         return LlamaConfig()
 
     @staticmethod
@@ -148,6 +149,7 @@ class OracleLlama:
         self.scale = 1.0 / np.sqrt(float(cfg.head_dim))
 
     def new_cache(self, num_blocks):
+        """src/scheduler/cache_engine.rs:298-341."""
         c = self.cfg
         if self.kv_fp8:
             ks, vs = ops.kv_cache_shapes(num_blocks, c.block_size, c.n_kv_heads, c.head_dim, 1, False)

@@ -13,7 +13,8 @@ PAD_SLOT_ID = -1          # src/openai/pipelines/llm_engine.rs:94 (_PAD_SLOT_ID)
 
 # --------------------------------------------------------------------------- bf16 helpers
 def f32_to_bf16_bits(x):
-    """round-to-nearest-even f32 -> bf16 bit pattern (uint16); NaN preserved as quiet NaN."""
+    """round-to-nearest-even f32 -> bf16 bit pattern (uint16); NaN preserved as quiet NaN.
+    candle `to_dtype(BF16)` = round to nearest even [EXT half crate]; cast sites src/openai/models/layers/attention.rs:977-981."""
     u = np.ascontiguousarray(x, np.float32).view(np.uint32)
     rounding = np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))
     r = ((u + rounding) >> np.uint32(16)).astype(np.uint16)
@@ -24,10 +25,12 @@ def f32_to_bf16_bits(x):
 
 
 def bf16_bits_to_f32(b):
+    """inverse of the bf16 cast at src/openai/models/layers/attention.rs:977-981 (exact)."""
     return (np.ascontiguousarray(b, np.uint16).astype(np.uint32) << np.uint32(16)).view(np.float32)
 
 
 def round_bf16(x):
+    """the value a bf16 store keeps: src/openai/models/layers/attention.rs:977-981."""
     return bf16_bits_to_f32(f32_to_bf16_bits(x))
 
 
@@ -204,7 +207,8 @@ def reshape_and_cache(k, v, key_cache, value_cache, slot_mapping, flash_layout):
 
 
 def gather_kv(key_cache, value_cache, block_table, context_len, flash_layout):
-    """Collect [context_len, Hkv, D] K and V for one sequence through its block table."""
+    """Collect [context_len, Hkv, D] K and V for one sequence through its block table.
+    reads the cache layouts of src/scheduler/cache_engine.rs:298-341 through one sequence's block table (pipelines/inputs.rs:425-454)."""
     if flash_layout:
         bs = key_cache.shape[1]
     else:
@@ -420,6 +424,7 @@ def f32_to_e4m3fn(x):
 
 
 def e4m3fn_to_f32(b):
+    """OCP e4m3fn decode for the U8 cache of src/main.rs:263-267 (cache_engine.rs:304-311)."""
     b = np.asarray(b, np.uint8).astype(np.int64)
     s = np.where(b & 0x80, -1.0, 1.0)
     e = (b >> 3) & 0xF
@@ -430,13 +435,15 @@ def e4m3fn_to_f32(b):
 
 
 def reshape_and_cache_fp8(k_f32, v_f32, key_cache_u8, value_cache_u8, slot_mapping, flash_layout=False):
-    """k, v values [T,Hkv,D] (already rounded to the model dtype) -> e4m3fn bytes scattered like reshape_and_cache."""
+    """k, v values [T,Hkv,D] (already rounded to the model dtype) -> e4m3fn bytes scattered like reshape_and_cache.
+    K1 on the U8 cache: src/scheduler/cache_engine.rs:304-311, call site src/openai/models/layers/attention.rs:983-995 (is_fp8_keys :896)."""
     reshape_and_cache(f32_to_e4m3fn(k_f32), f32_to_e4m3fn(v_f32), key_cache_u8, value_cache_u8, slot_mapping, flash_layout)
 
 
 def fp8_cache_as_bf16_bits(key_cache_u8, value_cache_u8, flash_layout=False):
     """e4m3fn caches -> bf16-bit caches in the 2-byte layouts (every e4m3 value is exact in bf16), so the 16-bit
-    attention restatements apply unchanged.  PAGED K: [NB,Hkv,D/16,bs,16] -> [NB,Hkv,D/8,bs,8]."""
+    attention restatements apply unchanged.  PAGED K: [NB,Hkv,D/16,bs,16] -> [NB,Hkv,D/8,bs,8].
+    what the fp8 attention kernels read back: src/openai/models/layers/attention.rs:574,896."""
     kf = f32_to_bf16_bits(e4m3fn_to_f32(key_cache_u8))
     vf = f32_to_bf16_bits(e4m3fn_to_f32(value_cache_u8))
     if not flash_layout:
