@@ -887,7 +887,11 @@ int load_gguf_impl(const char* path, int32_t max_batch, int32_t max_blocks_per_s
             if (dim == 0 && world > 1) { if (rows % world) return (int)hipErrorInvalidValue; rows /= world; }
             if (dim == 1 && world > 1) { if (cols % world) return (int)hipErrorInvalidValue; cols /= world; }
             if (cols % 256) return dim == 1 && world > 1 ? (int)hipErrorNotSupported : (int)hipErrorInvalidValue;   // re-quantising fallback: not built
-            return rows % 16 ? (int)hipErrorInvalidValue : 0;
+            // whole 16-row tiles are required only where the fused QKV epilogue needs them (mi355_qmatmul_fused checks the
+            // same); everywhere else the last tile may be ragged (odd vocabularies)
+            const bool qkv = name.find("attn_q.") != std::string::npos || name.find("attn_k.") != std::string::npos ||
+                             name.find("attn_v.") != std::string::npos;
+            return (qkv && rows % 16) ? (int)hipErrorInvalidValue : 0;
         };
         auto expect_f32 = [&](const std::string& name, int64_t elems) -> int {
             int64_t dd[4]; int32_t t; uint64_t n;

@@ -288,6 +288,11 @@ def test_check_gguf_accepts_good_files_and_reports_the_global_config(lib, tmp_pa
         assert (c.tp_rank, c.tp_world, c.n_expert) == (rank, world, 0)
         assert abs(c.rope_theta - cfg.rope_theta) < 1e-3 * cfg.rope_theta and abs(c.rms_eps - cfg.rms_eps) < 1e-9
     assert _check(lib, p, 0, 8)[0] == 1                            # 4 heads over 8 ranks
+    odd = llama.LlamaConfig.tiny(hidden=256, n_heads=2, n_kv_heads=2, head_dim=128, intermediate=512, vocab=333)
+    p3 = os.path.join(tmp_path, "odd.gguf")
+    GW.llama_to_gguf(p3, odd, llama.make_weights(odd, seed=8))
+    rc, c = _check(lib, p3)
+    assert rc == 0 and c.vocab == 333                              # a vocabulary that is not a multiple of the 16-row tile
     moe = llama.LlamaConfig.tiny()
     moe.n_expert, moe.n_expert_used = 4, 2
     p2 = os.path.join(tmp_path, "moe.gguf")
