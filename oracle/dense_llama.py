@@ -129,13 +129,14 @@ def layer_norm16(x, w, b, eps):
 
 
 class OracleDenseLlama:
-    def __init__(self, cfg, W, flash_layout=True, comm=None):
+    def __init__(self, cfg, W, flash_layout=True, comm=None, rope_scaling=None, max_position_embeddings=0):
         """comm: None, or an object with all_reduce(np.ndarray)->np.ndarray and all_gather(np.ndarray)->list (tensor
         parallel; cfg / W are then this rank's shard).  The collectives run in the model dtype: the reduced sum is
         rounded (distributed.rs:696-711), the gathered logits are exact (distributed.rs:1637-1663)."""
         self.cfg, self.W, self.flash, self.comm = cfg, W, flash_layout, comm
         self.rot = cfg.rotary_dim or cfg.head_dim
-        self.cos, self.sin = ops.rope_tables(cfg.rope_theta, self.rot, cfg.max_seq)
+        # rope_scaling: the reference's `rope_scaling` dict (ScalingRotaryEmbedding::new, rotary_emb.rs:107-341)
+        self.cos, self.sin = ops.rope_tables_scaled(cfg.rope_theta, self.rot, cfg.max_seq, rope_scaling, max_position_embeddings)
         self.scale = 1.0 / np.sqrt(float(cfg.head_dim))
 
     def _row_lin(self, x, w, resid):

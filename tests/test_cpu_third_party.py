@@ -272,3 +272,29 @@ def test_gguf_moe_oracle_matches_huggingface_mixtral():
     orc = llama.OracleLlama(cfg, W, flash_layout=False)
     got = _oracle_prefill_then_decode(orc, cfg, tokens, 3)
     _check_against_hf(got, want, len(tokens) - 4, 1e-2)
+
+
+def test_llama3_rope_scaling_through_the_whole_model_matches_huggingface():
+    """Llama-3.1-style `rope_scaling` (llama3: factor 8, low 1, high 4) applied by the oracle's tables vs HF Llama with the
+    same `rope_parameters`; a short original context (16) makes the scaling bite at these positions -- without it the
+    two differ by O(1), which the last assert shows"""
+    tr = pytest.importorskip("transformers")
+    cfg = DL.DenseConfig.tiny()
+    W = DL.make_weights(cfg, seed=19)
+    scaling = {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+               "original_max_position_embeddings": 16}
+    rp = dict(scaling)
+    rp["rope_theta"] = cfg.rope_theta
+    hf = tr.LlamaForCausalLM(tr.LlamaConfig(
+        vocab_size=cfg.vocab, hidden_size=cfg.hidden, intermediate_size=cfg.intermediate, num_hidden_layers=cfg.n_layers,
+        num_attention_heads=cfg.n_heads, num_key_value_heads=cfg.n_kv_heads, head_dim=cfg.head_dim,
+        max_position_embeddings=cfg.max_seq, rms_norm_eps=cfg.rms_eps, tie_word_embeddings=False, rope_parameters=rp,
+        attn_implementation="eager"))
+    rng = np.random.default_rng(23)
+    tokens = [int(t) for t in rng.integers(0, cfg.vocab, 48)]
+    want = _hf_logits(hf.float(), _hf_state(W, cfg, False, False), tokens)
+    scaled = DL.OracleDenseLlama(cfg, W, flash_layout=False, rope_scaling=scaling, max_position_embeddings=cfg.max_seq)
+    got = _oracle_prefill_then_decode(scaled, cfg, tokens, 3)
+    _check_against_hf(got, want, len(tokens) - 4, 3e-2)
+    plain = _oracle_prefill_then_decode(DL.OracleDenseLlama(cfg, W, flash_layout=False), cfg, tokens, 3)
+    assert np.abs(plain - want[len(tokens) - 4:]).max() / np.abs(want).max() > 5e-2     # the scaling really matters here
