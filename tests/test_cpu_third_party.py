@@ -274,15 +274,18 @@ def test_gguf_moe_oracle_matches_huggingface_mixtral():
     _check_against_hf(got, want, len(tokens) - 4, 1e-2)
 
 
-def test_llama3_rope_scaling_through_the_whole_model_matches_huggingface():
-    """Llama-3.1-style `rope_scaling` (llama3: factor 8, low 1, high 4) applied by the oracle's tables vs HF Llama with the
-    same `rope_parameters`; a short original context (16) makes the scaling bite at these positions -- without it the
-    two differ by O(1), which the last assert shows"""
+@pytest.mark.parametrize("scaling", [
+    {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0, "original_max_position_embeddings": 16},
+    {"rope_type": "yarn", "factor": 4.0, "original_max_position_embeddings": 16, "beta_fast": 32.0, "beta_slow": 1.0},
+    {"rope_type": "linear", "factor": 4.0},
+], ids=["llama3", "yarn", "linear"])
+def test_rope_scaling_through_the_whole_model_matches_huggingface(scaling):
+    """`rope_scaling` (llama3 as in Llama-3.1, yarn with its attention factor on cos / sin, linear) applied by the oracle's
+    tables vs HF Llama with the same `rope_parameters`; a short original context (16) makes the scaling bite at these
+    positions -- without it the two differ by O(1), which the last assert shows"""
     tr = pytest.importorskip("transformers")
     cfg = DL.DenseConfig.tiny()
     W = DL.make_weights(cfg, seed=19)
-    scaling = {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
-               "original_max_position_embeddings": 16}
     rp = dict(scaling)
     rp["rope_theta"] = cfg.rope_theta
     hf = tr.LlamaForCausalLM(tr.LlamaConfig(
