@@ -628,6 +628,16 @@ int32_t mi355_be_swap_out(void* be, int64_t group_id, const int64_t* seq_ids, in
     std::unordered_map<int, int> map;                     // gpu id -> cpu id
     std::vector<std::pair<int, int>> order;
     Pending pend;
+    {   // every failure is detected BEFORE a table or a pool is touched (no half-swapped group)
+        std::unordered_set<int> need;
+        for (int i = 0; i < n; ++i) {
+            auto it = e->tables.find(seq_ids[i]);
+            if (it == e->tables.end()) return -1;
+            for (size_t k = pc[seq_ids[i]]; k < it->second.size(); ++k) need.insert(it->second[k]);
+        }
+        if (need.size() > e->cpu.free_ids.size()) return -2;
+        if ((int64_t)need.size() > (int64_t)cap) return -3;       // the caller's pair buffer is too small
+    }
     for (int i = 0; i < n; ++i) {
         auto it = e->tables.find(seq_ids[i]);
         if (it == e->tables.end()) return -1;
@@ -658,6 +668,12 @@ int32_t mi355_be_swap_in(void* be, int64_t group_id, const int64_t* seq_ids, int
     std::unordered_map<int, int> map;                     // cpu id -> gpu id
     std::vector<std::pair<int, int>> order;
     Pending pend;
+    {   // check everything before mutating, as in swap_out
+        const int32_t need = mi355_be_swap_in_required_blocks(be, seq_ids, n);
+        for (int i = 0; i < n; ++i) if (e->tables.find(seq_ids[i]) == e->tables.end()) return -1;
+        if (need > (int32_t)e->gpu.free_ids.size()) return -2;
+        if (need > cap) return -3;
+    }
     for (int i = 0; i < n; ++i) {
         auto it = e->tables.find(seq_ids[i]);
         if (it == e->tables.end()) return -1;
@@ -874,8 +890,10 @@ struct Sched {
             abort_group(gid);
             return;
         }
-        std::vector<int64_t> pairs(2 * 8192);
-        const int k = mi355_be_swap_out(eng, gid, gr.seqs.data(), (int)gr.seqs.size(), pairs.data(), 8192);
+        size_t nblk = 0;                                                        // upper bound of the pair count: every block of the group
+        for (int64_t sid : gr.seqs) { auto it = eng->tables.find(sid); if (it != eng->tables.end()) nblk += it->second.size(); }
+        std::vector<int64_t> pairs(2 * nblk + 2);
+        const int k = mi355_be_swap_out(eng, gid, gr.seqs.data(), (int)gr.seqs.size(), pairs.data(), (int32_t)nblk);
         for (int i = 0; i < k; ++i) { result[R_SWAP_OUT_PAIRS].push_back(pairs[2 * i]); result[R_SWAP_OUT_PAIRS].push_back(pairs[2 * i + 1]); }
         result[R_SWAP_OUT_GROUPS].push_back(gid);
         gr.has_swapped_time = true; gr.swapped_ms = now_ms;
@@ -1035,8 +1053,10 @@ int32_t mi355_sched_schedule(void* sp, uint64_t now_ms) {
                 if (need > (int)e->gpu.free_ids.size()) break;
             }
             s->swapped.pop_front();
-            std::vector<int64_t> pairs(2 * 8192);
-            const int k = mi355_be_swap_in(e, gid, gr.seqs.data(), (int)gr.seqs.size(), pairs.data(), 8192);
+            size_t nblk = 0;
+            for (int64_t sid : gr.seqs) { auto it = e->tables.find(sid); if (it != e->tables.end()) nblk += it->second.size(); }
+            std::vector<int64_t> pairs(2 * nblk + 2);
+            const int k = mi355_be_swap_in(e, gid, gr.seqs.data(), (int)gr.seqs.size(), pairs.data(), (int32_t)nblk);
             for (int i = 0; i < k; ++i) { s->result[R_SWAP_IN_PAIRS].push_back(pairs[2 * i]); s->result[R_SWAP_IN_PAIRS].push_back(pairs[2 * i + 1]); }
             s->result[R_SWAP_IN_GROUPS].push_back(gid);
             gr.has_swapped_time = false;

@@ -16,6 +16,7 @@
 // code (`marlin_permute_scales`, linear.rs:341-379; examples/convert_awq_marlin.py:72-115) and are un-permuted
 // by index arithmetic here.
 #include "common.h"
+#include "scratch.h"
 #include "../../include/mi355_vllm.h"
 #include <hip/hip_runtime.h>
 
@@ -316,20 +317,16 @@ __global__ void __launch_bounds__(256) dense_chain_kernel(uint16_t* __restrict__
     out[(size_t)t * ldo + row] = f2h<DT>(o);
 }
 
-static void* g_dense_ws = nullptr;
-static size_t g_dense_ws_bytes = 0;
 
 static int dense_prompt_gemm(const DenseArgs& a, int dt, hipStream_t st) {
     const bool direct = a.epi == MI355_EPI_STORE && !a.bias;                 // no chain: the GEMM writes `out` itself
     uint16_t* y = static_cast<uint16_t*>(a.out);
     if (!direct) {
         const size_t need = (size_t)a.T * a.N * 2;
-        if (need > g_dense_ws_bytes) {
-            if (g_dense_ws) { (void)hipDeviceSynchronize(); (void)hipFree(g_dense_ws); g_dense_ws = nullptr; g_dense_ws_bytes = 0; }
-            if (hipMalloc(&g_dense_ws, need * 2) != hipSuccess) return (int)hipErrorOutOfMemory;
-            g_dense_ws_bytes = need * 2;
-        }
-        y = static_cast<uint16_t*>(g_dense_ws);
+        void* ws = nullptr;                                                  // per (device, stream): scratch.cpp
+        const int wrc = mi355_scratch_get(&ws, MI355_SCR_DENSE_WS, need, st, false);
+        if (wrc) return wrc;
+        y = static_cast<uint16_t*>(ws);
     }
     const int rc = mi355_internal_gemm_rowmajor(y, dt, direct ? a.ldo : a.N, a.x, a.w, dt, a.T, a.N, a.K, st);
     if (rc || direct) return rc;

@@ -8,6 +8,7 @@
 //   silu_mul   candle_nn::ops::silu(w1) * w3   src/openai/models/quantized_llama.rs:33-37
 //   argmax     logits.argmax(-1) (first max)   src/openai/logits_processor.rs:92-95
 #include "common.h"
+#include "scratch.h"
 #include "../../include/mi355_vllm.h"
 
 // ------------------------------------------------------------------------------------------------ RMSNorm
@@ -231,7 +232,6 @@ extern "C" int mi355_embedding_f32(float* out, const float* table, const uint32_
 //          slot, so the scratch is self-cleaning and the pair is safe to replay from a hipGraph.
 #define ARGMAX_SPLIT 64
 #define ARGMAX_MAX_ROWS 4096
-static unsigned long long* g_argmax_slots = nullptr;
 
 __device__ __forceinline__ unsigned long long argmax_key(float v, uint32_t idx) {
     uint32_t u = __float_as_uint(v);
@@ -273,15 +273,11 @@ __global__ void argmax_stage2_kernel(uint32_t* __restrict__ out, unsigned long l
 extern "C" int mi355_argmax_f32(uint32_t* out, const float* logits, int32_t batch, int32_t vocab, int64_t stream) {
     if (batch <= 0) return 0;
     if (batch > ARGMAX_MAX_ROWS || vocab <= 0) return (int)hipErrorInvalidValue;
-    if (!g_argmax_slots) {                                  // first call (never inside a stream capture: the
-        hipError_t e = hipMalloc((void**)&g_argmax_slots, ARGMAX_MAX_ROWS * 8);   // host layer warms up eagerly)
-        if (e != hipSuccess) return (int)e;
-        e = hipMemset(g_argmax_slots, 0, ARGMAX_MAX_ROWS * 8);
-        if (e != hipSuccess) return (int)e;
-        e = hipDeviceSynchronize();     // the memset runs on the null stream; `stream` may be non-blocking
-        if (e != hipSuccess) return (int)e;
-    }
     hipStream_t st = to_stream(stream);
+    void* sl = nullptr;                                     // slots belong to (device, stream): scratch.cpp
+    const int src = mi355_scratch_get(&sl, MI355_SCR_ARGMAX, ARGMAX_MAX_ROWS * 8, st, true);
+    if (src) return src;
+    unsigned long long* g_argmax_slots = static_cast<unsigned long long*>(sl);
     hipLaunchKernelGGL(argmax_stage1_kernel, dim3(ARGMAX_SPLIT, batch), dim3(256), 0, st, g_argmax_slots, logits, vocab);
     hipLaunchKernelGGL(argmax_stage2_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, out, g_argmax_slots, batch);
     return (int)hipGetLastError();

@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -143,6 +144,7 @@ struct Model {
     uint32_t* d_ctx = nullptr;
     uint32_t* d_bt = nullptr;
     int cur_batch = 0, cur_max_blocks = 0, cur_ctx_cap = 0;
+    int cur_ctx_max = 0;            // host mirror of max(d_ctx): the device-side loop must stay inside ctx_cap / the block table / max_seq
     // hipGraph
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
@@ -184,6 +186,9 @@ __global__ void advance_kernel(uint32_t* tokens, const uint32_t* next_tokens, in
     ctx[b] = n;
     const int64_t pos = (int64_t)n - 1;
     positions[b] = pos;
+    // the step after the last reserved block has no slot (-1 = "do not write", as a padded slot): the host refuses to
+    // run that step, and this kernel never reads past the block-table row
+    if (pos / block_size >= max_blocks) { slots[b] = -1; return; }
     const int64_t blk = bt[(size_t)b * max_blocks + pos / block_size];
     slots[b] = blk * block_size + pos % block_size;
 }
@@ -315,6 +320,7 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
         int ps = choose_partition(B, Hkv, in.ctx_cap);
         if (ps > 0) ps = 32;   // MFMA kernel: 32-token partitions, 4 per workgroup (measured at batch 32: 32 -> 4937, 64 -> 4784, 128 -> ~4500 tok/s)
         if (ps > 0 && (in.ctx_cap + ps - 1) / ps > m->pa_cap_partitions) return (int)hipErrorInvalidValue;
+        if (in.ctx_cap > c.max_seq) return (int)hipErrorInvalidValue;
         return mi355_paged_attention_fp8(in.attn, m->pa_sum, m->pa_max, m->pa_tmp, in.q, m->kcache[l], m->vcache[l], in.bt, in.ctx,
                                          B, H, Hkv, D, c.block_size, in.max_blocks, in.ctx_cap, ps, scale, 0.f, 1.f, 1.f, st);
     }
@@ -422,9 +428,12 @@ extern "C" void mi355_host_set_partition_override(int v) { g_host_ps_override = 
 
 extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
     if (!cfg || cfg->hidden <= 0 || cfg->n_layers <= 0 || cfg->max_batch <= 0 || cfg->head_dim <= 0 ||
-        (cfg->hidden % 256) || cfg->max_blocks_per_seq <= 0)
+        (cfg->hidden % 256) || cfg->max_blocks_per_seq <= 0 || cfg->max_seq <= 0 || cfg->block_size <= 0 ||
+        cfg->n_heads <= 0 || cfg->n_kv_heads <= 0 || cfg->vocab <= 0 || cfg->intermediate <= 0)
         return nullptr;
-    Model* m = new Model();
+    Model* m = nullptr;
+    try {
+    m = new Model();
     m->cfg = *cfg;
     if (m->cfg.tp_world <= 0) { m->cfg.tp_world = 1; m->cfg.tp_rank = 0; }
     const char* force = getenv("MI355_FORCE_COMM");
@@ -471,6 +480,10 @@ extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
     }
     if (!ok) { mi355_llama_destroy(m); return nullptr; }
     return m;
+    } catch (...) {                                          // bad_alloc and friends must not cross the C boundary
+        if (m) mi355_llama_destroy(m);
+        return nullptr;
+    }
 }
 
 extern "C" int mi355_llama_set_rope_tables(void* mp, const float* cos_host, const float* sin_host, int32_t n_positions) {
@@ -479,10 +492,11 @@ extern "C" int mi355_llama_set_rope_tables(void* mp, const float* cos_host, cons
     const size_t bytes = (size_t)n_positions * (m->cfg.head_dim / 2) * 4;
     float *c = nullptr, *s = nullptr;
     HCHECK(hipMalloc((void**)&c, bytes));
-    HCHECK(hipMalloc((void**)&s, bytes));
-    HCHECK(hipMemcpy(c, cos_host, bytes, hipMemcpyHostToDevice));
-    HCHECK(hipMemcpy(s, sin_host, bytes, hipMemcpyHostToDevice));
-    HCHECK(hipDeviceSynchronize());
+    hipError_t e = hipMalloc((void**)&s, bytes);
+    if (e == hipSuccess) e = hipMemcpy(c, cos_host, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(s, sin_host, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { (void)hipFree(c); if (s) (void)hipFree(s); return (int)e; }
     drop_graph(m);                                                  // captured launches hold the old pointers
     (void)hipFree(m->cos_t); (void)hipFree(m->sin_t);
     m->cos_t = c; m->sin_t = s;
@@ -642,6 +656,7 @@ static int ensure_prefill_cap(Model* m, int T) {
     if (m->cfg.n_expert > 1) {
         void* oldm[] = {m->p_moe_ids, m->p_moe_w, m->p_moe_y};
         for (void* p : oldm) if (p) (void)hipFree(p);
+        m->p_moe_ids = nullptr; m->p_moe_w = nullptr; m->p_moe_y = nullptr;
         HCHECK(hipMalloc((void**)&m->p_moe_ids, (size_t)cap * KE * 4));
         HCHECK(hipMalloc((void**)&m->p_moe_w, (size_t)cap * KE * 4));
         HCHECK(hipMalloc((void**)&m->p_moe_y, (size_t)cap * KE * m->cfg.hidden * 4));
@@ -705,6 +720,10 @@ extern "C" int mi355_llama_decode_begin(void* mp, const uint32_t* tokens_host, c
         if (pos[b] / bs >= max_blocks) return (int)hipErrorInvalidValue;          // "Block table is too small"
         slot[b] = (int64_t)block_tables_host[(size_t)b * max_blocks + pos[b] / bs] * bs + pos[b] % bs;
     }
+    // the greedy loop advances the context on the device: everything it will index is checked here and in decode_step
+    int ctx_max = 0;
+    for (int b = 0; b < batch; ++b) ctx_max = std::max(ctx_max, (int)seq_lens_host[b]);
+    if (ctx_cap < ctx_max || ctx_cap > m->cfg.max_seq || ctx_max > max_blocks * bs) return (int)hipErrorInvalidValue;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipMemcpyAsync(m->d_tokens, tokens_host, (size_t)batch * 4, hipMemcpyHostToDevice, st));
     HCHECK(hipMemcpyAsync(m->d_ctx, seq_lens_host, (size_t)batch * 4, hipMemcpyHostToDevice, st));
@@ -712,7 +731,7 @@ extern "C" int mi355_llama_decode_begin(void* mp, const uint32_t* tokens_host, c
     HCHECK(hipMemcpyAsync(m->d_positions, pos.data(), (size_t)batch * 8, hipMemcpyHostToDevice, st));
     HCHECK(hipMemcpyAsync(m->d_slots, slot.data(), (size_t)batch * 8, hipMemcpyHostToDevice, st));
     HCHECK(hipStreamSynchronize(st));                     // host vectors go out of scope
-    m->cur_batch = batch; m->cur_max_blocks = max_blocks; m->cur_ctx_cap = ctx_cap;
+    m->cur_batch = batch; m->cur_max_blocks = max_blocks; m->cur_ctx_cap = ctx_cap; m->cur_ctx_max = ctx_max;
     return 0;
 }
 
@@ -745,6 +764,12 @@ extern "C" int mi355_llama_decode_step(void* mp, int64_t stream) {
     Model* m = static_cast<Model*>(mp);
     if (!m || m->cur_batch < 1) return (int)hipErrorInvalidValue;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // this step attends over cur_ctx_max tokens, then `advance_kernel` looks up the slot of position cur_ctx_max: both
+    // must stay inside the attention grid (ctx_cap), the block-table row and the RoPE tables
+    if (m->cur_ctx_max > m->cur_ctx_cap || m->cur_ctx_max > m->cfg.max_seq ||
+        (m->cur_ctx_max + m->cfg.block_size - 1) / m->cfg.block_size > m->cur_max_blocks)
+        return (int)hipErrorInvalidValue;
+    struct Bump { Model* m; ~Bump() { ++m->cur_ctx_max; } } bump{m};
     // TP steps run eagerly (RCCL in-stream) unless the caller opted in with set_graph(2) AND the communicator is RCCL's
     // own (host-supplied collectives stage through the host and cannot be captured)
     const bool tp_eager = m->use_comm && !(m->graph_tp && m->comm && m->comm->nccl);

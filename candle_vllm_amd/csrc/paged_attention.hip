@@ -16,6 +16,7 @@
 //   * lane-group states merge with ds_bpermute shuffles, wave states through 8.3 KB of LDS,
 //   * v2: partitions write (normalised out, max_logit, exp_sum); a tiny reduce kernel merges them.
 #include "common.h"
+#include "scratch.h"
 #include <type_traits>
 #include "../../include/mi355_vllm.h"
 
@@ -283,7 +284,7 @@ __global__ void __launch_bounds__(512) paged_attn_reduce_kernel(void* __restrict
     // statistics of every possible partition are fetched while context_lens is still in flight
     float ml0 = (threadIdx.x < max_partitions) ? max_logits[base + threadIdx.x] : -1e30f;
     const int ctx = (int)context_lens[b];
-    const int P = (ctx + partition_size - 1) / partition_size;
+    const int P = min((ctx + partition_size - 1) / partition_size, max_partitions);   // never beyond the launched partitions
     float M = -1e30f;
     for (int i = threadIdx.x; i < P; i += blockDim.x) {
         const float ml = (i == (int)threadIdx.x) ? ml0 : max_logits[base + i];
@@ -599,7 +600,9 @@ __global__ void __launch_bounds__(64 * WPB) paged_attn_mfma_kernel(const PAParam
     const int hk = blockIdx.x, b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int part = blockIdx.z * WPB + wave;
-    const int ctx = (int)p.context_lens[b];
+    // a context longer than the launch was sized for is truncated to the grid (the host layer refuses such a step): the
+    // partition count below must match the launched grid or the fused merge's ticket never completes
+    const int ctx = min((int)p.context_lens[b], p.max_partitions * p.partition_size);
     if (blockIdx.z * WPB * p.partition_size >= ctx) return;        // uniform for the workgroup
     const int t0 = part * p.partition_size;
     const bool live = t0 < ctx;
@@ -848,7 +851,6 @@ static int launch_flash(const PAParams& p, int B, int P, hipStream_t st) {
     return (int)hipErrorInvalidValue;
 }
 
-static unsigned* g_pa_arrive = nullptr;
 #define PA_ARRIVE_SLOTS 65536
 static int g_pa_fused = 1;                                          // mi355_set_tuning(3, 0) -> separate reduce launch
 static int g_pa_wpb = 0;                                            // mi355_set_tuning(8, 1 | 4): waves (partitions) per workgroup, 0 = auto
@@ -876,12 +878,11 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
         else wpb = (P >= 8 && p.partition_size <= 64) ? 4 : 1;
         // the in-kernel merge is one wave per (sequence, kv head): worth it only when there are many of them
         if (P > 1 && g_pa_fused && (int64_t)B * p.Hkv >= (g_pa_fused > 1 ? 1 : 64) && (int64_t)B * p.Hkv <= PA_ARRIVE_SLOTS) {
-            if (!g_pa_arrive) {                                     // first call (eager warm-up), never in a capture
-                if (hipMalloc((void**)&g_pa_arrive, PA_ARRIVE_SLOTS * 4) != hipSuccess) return (int)hipErrorOutOfMemory;
-                if (hipMemset(g_pa_arrive, 0, PA_ARRIVE_SLOTS * 4) != hipSuccess) return (int)hipErrorUnknown;
-                if (hipDeviceSynchronize() != hipSuccess) return (int)hipErrorUnknown;   // null-stream memset vs a non-blocking `stream`
-            }
-            p.arrive = g_pa_arrive;
+            // tickets belong to (device, stream): two streams never share a counter (scratch.cpp)
+            void* arr = nullptr;
+            const int arc = mi355_scratch_get(&arr, MI355_SCR_PA_ARRIVE, PA_ARRIVE_SLOTS * 4, st, true);
+            if (arc) return arc;
+            p.arrive = static_cast<unsigned*>(arr);
             fused = true;
         }
         rc = (p.D == 128) ? launch_mfma<4>(p, B, P, wpb, st) : launch_mfma<2>(p, B, P, wpb, st);

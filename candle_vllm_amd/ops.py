@@ -244,7 +244,12 @@ class PagedAttention:
         out = torch.empty_like(q)
         sc = float(softcapping) if softcapping else 0.0
         n = meta.cu_seqlens_q.shape[0] - 1
+        # per sequence, as the reference decides it (seqlen_k = cached + chunk whenever num_cached > 0, inputs.rs:132-143):
+        # ANY sequence with a cached prefix sends the whole batch through the cache path.  (max_seqlen_k > max_seqlen_q
+        # misses a mixed batch such as 16 cached + 16 new beside 64 fresh tokens.)
         use_cached = meta.max_seqlen_k > meta.max_seqlen_q
+        if not use_cached and meta.cu_seqlens_k is not None and meta.cu_seqlens_q is not None:
+            use_cached = not torch.equal(meta.cu_seqlens_k, meta.cu_seqlens_q)
         if use_cached:
             layout = kv_layout_of(key_cache)
             bs = key_cache.shape[1] if layout == KV_FLASH else key_cache.shape[3]

@@ -488,7 +488,9 @@ int32_t mi355_be_evict_prefix_cache_until_free(void* be, int32_t min_free);
 int32_t mi355_be_query_prefix_match_tokens(void* be, const uint32_t* tokens, int32_t n);
 int32_t mi355_be_fallback_to_full_prefill(void* be, int64_t seq_id);
 int32_t mi355_be_rebuild_with_cached_prefix(void* be, int64_t seq_id, int32_t cached_tokens);
-/* swap: pairs out = (src_block, dst_block) to hand to mi355_swap_blocks; returns the pair count */
+/* swap: pairs out = (src_block, dst_block) to hand to mi355_swap_blocks; returns the pair count, or < 0 with NOTHING
+ * changed: -1 unknown sequence, -2 not enough free blocks on the destination side, -3 `cap` pairs are not enough
+ * (cap = the group's total block count always is) */
 int32_t mi355_be_can_swap_out(void* be, const int64_t* seq_ids, int32_t n);
 int32_t mi355_be_swap_in_required_blocks(void* be, const int64_t* seq_ids, int32_t n);
 int32_t mi355_be_can_swap_in(void* be, const int64_t* seq_ids, int32_t n);

@@ -117,9 +117,6 @@ def test_rccl_plumbing_single_rank(lib, monkeypatch):
     assert _rel(got, ref) < 1e-3
 
 
-@pytest.mark.skipif(not os.environ.get("MI355_RUN_UNVALIDATED"),
-                    reason="set_graph(2) (RCCL calls captured in the decode graph) was written after this round's GPU "
-                           "minutes were spent: first hardware run is due next round")
 def test_tp_step_captured_in_a_graph_single_rank(lib, monkeypatch):
     """opt-in `mi355_llama_set_graph(model, 2)`: the tensor-parallel decode step (in-stream all-reduce after wo / w2,
     all-gather of the logits) captured in a hipGraph and replayed must give the tokens of the eager TP loop.  One rank:

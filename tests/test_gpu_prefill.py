@@ -118,3 +118,29 @@ def test_prefill_softcap_and_decode_consistency(cv):
     dm = cv.InputMetadata.from_oracle_meta(dmeta, "cuda")
     dec = host16(pa.decode(dev16(q[0][-1:], dt), kcd, vcd, dm), dt)
     assert np.abs(dec[0] - out2[-1]).max() <= TOL[dt]
+
+
+def test_prefill_mixed_batch_cached_and_fresh_with_equal_maxima(cv):
+    """a batch where max_seqlen_k == max_seqlen_q although ONE sequence has a cached prefix (16 cached + 16
+    new beside 64 fresh tokens).  The reference decides `use_cached_kv` per sequence (inputs.rs:132-143); the wrapper
+    must take the cache path, otherwise the cached prefix is silently dropped from the first sequence's attention."""
+    dt, H, Hkv, D, bs = "bf16", 8, 2, 128, 16
+    rng = np.random.default_rng(77)
+    lens, cached = [16, 64], [16, 0]
+    q, k_all, v_all, kc, vc, meta = make_case(rng, lens, cached, H, Hkv, D, bs, dt, False)
+    scale = 1.0 / np.sqrt(D)
+    pa = cv.PagedAttention(H, D, scale, Hkv)
+    im = cv.InputMetadata.from_oracle_meta(meta, "cuda", is_prefill=True)
+    assert im.max_seqlen_k == im.max_seqlen_q                      # the batch-level test cannot see the prefix
+    kcd = torch.from_numpy(kc.view(np.int16)).cuda().view(TD[dt])
+    vcd = torch.from_numpy(vc.view(np.int16)).cuda().view(TD[dt])
+    # the chunk's own k / v are handed over too (as the model does): the wrapper must still read the cache
+    knew = np.concatenate([k_all[i][cached[i]:] for i in range(2)])
+    vnew = np.concatenate([v_all[i][cached[i]:] for i in range(2)])
+    out = pa.prefill(dev16(np.concatenate(q), dt), dev16(knew, dt), dev16(vnew, dt), kcd, vcd, im)
+    got = host16(out, dt)
+    o = 0
+    for i, l in enumerate(lens):
+        ref = O.prefill_attention(q[i], k_all[i], v_all[i], scale, cached=cached[i], rnd=lambda a: G.round_dt(a, dt))
+        assert np.abs(got[o:o + l] - ref).max() <= TOL[dt] * max(1.0, np.abs(ref).max()), f"seq {i}"
+        o += l

@@ -222,9 +222,6 @@ def _gguf_file_worker(rank, world, port, q, path):
         raise
 
 
-@pytest.mark.skipif(not os.environ.get("MI355_RUN_UNVALIDATED"),
-                    reason="written after this round's GPU minutes were spent: first hardware run is due next round "
-                           "(the byte-range sharder underneath is covered on the CPU by tests/test_cpu_gguf.py)")
 def test_gguf_file_loader_tp2_equals_setter_shards(lib, tmp_path):
     """f3 'TP re-sharding': every rank opens the same GGUF file through `mi355_llama_load_gguf_tp` and keeps its raw
     byte-range shard (get_sharded_no_shape, quantized_var_builder.rs:222-233); the prompt-step logits must be
