@@ -99,6 +99,10 @@ _sig("gemm_half_q_half_alt", None, [c_vp] * 6 + [c_i32] * 4 + [c_i64])
 _sig("gptq_repack", None, [c_vp, c_vp, c_i32, c_i32, c_i64])
 _sig("awq_repack", None, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
 _sig("mi355_marlin_scale_pos", c_i32, [c_i32, c_i32])
+_sig("mi355_last_error", ctypes.c_int, [])
+_sig("mi355_clear_error", None, [])
+_sig("mi355_marlin_format_repack", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64])
+_sig("mi355_marlin_weight_perm", c_i32, [c_i32])
 _sig("mi355_marlin_zero_pos", c_i32, [c_i32])
 _sig("mi355_linear", ctypes.c_int, [c_vp] * 5 + [c_i32] * 5 + [c_i64])
 _sig("mi355_gptq_linear", ctypes.c_int, [c_vp] * 5 + [c_i32, c_i32, c_vp, c_vp] + [c_i32] * 6 + [c_i64])
@@ -133,6 +137,7 @@ _sig("mi355_llama_logits_ptr", c_vp, [c_vp])
 _sig("mi355_comm_unique_id", ctypes.c_int, [c_vp])
 _sig("mi355_llama_init_comm", ctypes.c_int, [c_vp, c_vp])
 _sig("mi355_llama_run_part", ctypes.c_int, [c_vp, c_i32, c_i32, c_i64])
+_sig("mi355_llama_act_ptr", c_vp, [c_vp, c_i32])
 
 
 # ---- host block manager (section 5 of the header): every entry point takes plain ints / pointers

@@ -382,12 +382,14 @@ __global__ void awq_repack_kernel(const uint32_t* __restrict__ in, uint32_t* __r
 // act-order GPTQ: every k has its own group g_idx[k], so the scale cannot be factored out of an MFMA chain; the
 // weights are dequantised to f16 (w = s * (q - (z+1)) rounded to f16, as a half-precision dequant kernel does)
 // and contracted on MFMA.  One workgroup per 16-column tile, its 4 waves split K.
-template <int MT>
+template <int MT, int BITS>
 __global__ void __launch_bounds__(256) exllama_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
                                                       const uint32_t* __restrict__ qz, const uint16_t* __restrict__ sc,
                                                       const int32_t* __restrict__ g_idx, uint16_t* __restrict__ out,
                                                       int T, int N, int K, int group_size) {
     __shared__ float red[4][MT][16][16];
+    constexpr int PF = 32 / BITS;                                   // codes per u32: 8 (4-bit) or 4 (8-bit, linear.rs:215-217)
+    constexpr uint32_t QM = (1u << BITS) - 1u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, kg = lane >> 4;
     const int col = blockIdx.x * 16 + r16;
@@ -396,14 +398,16 @@ __global__ void __launch_bounds__(256) exllama_kernel(const uint16_t* __restrict
     for (int mt = 0; mt < MT; ++mt) y[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     for (int k32 = wave; k32 < K / 32; k32 += 4) {
         const int k0 = k32 * 32 + 8 * kg;
-        const uint32_t w = qw[(size_t)(k0 >> 3) * N + col];
+        uint32_t w[8 / PF];                                         // the 8 consecutive k of this lane: 1 word (4-bit) / 2 words (8-bit)
+#pragma unroll
+        for (int u = 0; u < 8 / PF; ++u) w[u] = qw[(size_t)(k0 / PF + u) * N + col];
         f16x8_t bf;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int g = g_idx ? g_idx[k0 + i] : (k0 + i) / group_size;
             const float s = f16_bits_to_f32(sc[(size_t)g * N + col]);
-            const int z = (int)((qz[(size_t)g * (N / 8) + (col >> 3)] >> (4 * (col & 7))) & 0xF) + 1;
-            bf[i] = (_Float16)(s * (float)((int)((w >> (4 * i)) & 0xF) - z));
+            const int z = (int)((qz[(size_t)g * (N / PF) + col / PF] >> (BITS * (col % PF))) & QM) + 1;
+            bf[i] = (_Float16)(s * (float)((int)((w[i / PF] >> (BITS * (i % PF))) & QM) - z));
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -425,6 +429,41 @@ __global__ void __launch_bounds__(256) exllama_kernel(const uint16_t* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------ Marlin-format checkpoints
+// `checkpoint_format == "marlin"` (linear.rs:222-239,279-290): the file holds B [k/16, 2n] u32 already in the Marlin
+// tile order (IST-DASLab marlin `Layer.pack` [EXT]): codes (k, n) -> 16x16 tiles, tile-row major; every 1024
+// consecutive values of a tile row (4 tiles) permuted by `_perm`, then 8 values per word with the nibble
+// interleave [0,2,4,6,1,3,5,7].  The reference hands B to marlin_4bit_* without a repack; this path's mat-mul streams
+// the GPTQ layout qweight[k/8][n], so a Marlin-format B is un-permuted ONCE at load time.
+//   perm1(i)[4*blk + e] = 16*row_e(i) + i/4 + 8*blk,  row_e = {2(i%4), 2(i%4)+1, 2(i%4+4), 2(i%4+4)+1}
+//   perm = concat_i concat_j (perm1(i) + 256 j), then within every 8: [0,2,4,6,1,3,5,7]
+__device__ __forceinline__ int marlin_perm_at(int j) {              // j in [0,1024): source index inside the 1024 chunk
+    const int e8 = j & 7, grp = j >> 3;                             // 8-group; interleave picks element {0,2,4,6,1,3,5,7}[e8]
+    const int src8 = (e8 < 4) ? 2 * e8 : 2 * (e8 - 4) + 1;
+    const int q = grp * 8 + src8;                                   // index into the un-interleaved perm
+    const int i = q >> 5, jj = (q >> 3) & 3, t = q & 7;             // 32 entries per i: 4 (j) x 8 (perm1)
+    const int blk = t >> 2, e = t & 3;
+    const int r = (e < 2) ? 2 * (i & 3) + e : 2 * ((i & 3) + 4) + (e - 2);
+    return 16 * r + (i >> 2) + 8 * blk + 256 * jj;
+}
+__global__ void __launch_bounds__(256) marlin_to_gptq_kernel(const uint32_t* __restrict__ B, uint32_t* __restrict__ out, int K, int N) {
+    __shared__ uint16_t inv[1024];
+    for (int j = threadIdx.x; j < 1024; j += 256) inv[marlin_perm_at(j)] = (uint16_t)j;
+    __syncthreads();
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)(K / 8) * N) return;
+    const int n = (int)(idx % N), kr = (int)(idx / N);
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = 8 * kr + i;
+        const int src = (n >> 4) * 256 + (k & 15) * 16 + (n & 15);  // position inside tile row k/16 before the permutation
+        const int col = (src & ~1023) + inv[src & 1023];
+        o |= ((B[(size_t)(k >> 4) * (2 * N) + (col >> 3)] >> (4 * (col & 7))) & 0xFu) << (4 * i);
+    }
+    out[idx] = o;
+}
+
 // ------------------------------------------------------------------------------------------------ C ABI
 static int marlin_common(const void* in, const int32_t* qweight, const void* scales, const void* zeros, void* out,
                          int m, int k, int n, int group_size, int dt, int awq, int64_t stream) {
@@ -439,58 +478,114 @@ static int marlin_common(const void* in, const int32_t* qweight, const void* sca
     return dense_run(a, DW_GPTQ4, dt, (hipStream_t)stream);
 }
 
+template <int BITS>
+static void exllama_launch(const uint16_t* x, const uint32_t* qw, const uint32_t* qz, const uint16_t* sc, const int32_t* g_idx,
+                           uint16_t* o, int T, int n, int k, hipStream_t st) {
+    // without g_idx the whole of k is one group: the op does not pass group_size, and the reference always loads g_idx
+    // for gptq checkpoints (linear.rs:298-314)
+    if (T <= 16) hipLaunchKernelGGL((exllama_kernel<1, BITS>), dim3(n / 16), dim3(256), 0, st, x, qw, qz, sc, g_idx, o, T, n, k, k);
+    else hipLaunchKernelGGL((exllama_kernel<2, BITS>), dim3(n / 16), dim3(256), 0, st, x, qw, qz, sc, g_idx, o, T, n, k, k);
+}
 extern "C" {
 
+// The reference's FFI symbols return nothing.  A call this library cannot serve must not leave the caller with an
+// uninitialised output that looks like data: the failure is recorded (mi355_last_error) and the output is filled with
+// 0xFFFF (NaN in f16 and bf16) whenever its pointer and shape are usable.
+static void ffi_fail(int code, void* out, int64_t m, int64_t n, int64_t stream) {
+    mi355_note_error(code ? code : (int)hipErrorInvalidValue);
+    if (out && m > 0 && n > 0) (void)hipMemsetAsync(out, 0xFF, (size_t)m * n * 2, (hipStream_t)stream);
+}
+static void marlin_ffi(const void* in, const int32_t* qweight, const void* scales, const void* zeros, void* out, int m, int k, int n,
+                       int group_size, int dt, int awq, int64_t stream) {
+    if (m == 0) return;
+    if (!in || !qweight || !scales || !out || m < 0 || k <= 0 || n <= 0 || (k & 255) || (n & 15) || (awq && !zeros)) {
+        ffi_fail((int)hipErrorInvalidValue, out, m, n, stream);
+        return;
+    }
+    const int rc = marlin_common(in, qweight, scales, zeros, out, m, k, n, group_size, dt, awq, stream);
+    if (rc) ffi_fail(rc, out, m, n, stream);
+}
 void marlin_4bit_f16(const void* in, const int32_t* qweight, const void* scales, const void* zeros, const void* g_idx,
                      void* out, int32_t m, int32_t k, int32_t n, const void* workspace, int32_t group_size, int64_t stream) {
     (void)g_idx; (void)workspace;
-    marlin_common(in, qweight, scales, zeros, out, m, k, n, group_size, MI355_DTYPE_F16, 0, stream);
+    marlin_ffi(in, qweight, scales, zeros, out, m, k, n, group_size, MI355_DTYPE_F16, 0, stream);
 }
 void marlin_4bit_bf16(const void* in, const int32_t* qweight, const void* scales, const void* zeros, const void* g_idx,
                       void* out, int32_t m, int32_t k, int32_t n, const void* workspace, int32_t group_size, int64_t stream) {
     (void)g_idx; (void)workspace;
-    marlin_common(in, qweight, scales, zeros, out, m, k, n, group_size, MI355_DTYPE_BF16, 0, stream);
+    marlin_ffi(in, qweight, scales, zeros, out, m, k, n, group_size, MI355_DTYPE_BF16, 0, stream);
 }
 void marlin_awq_4bit_f16(const void* in, const int32_t* qweight, const void* scales, const void* zeros, const void* g_idx,
                          void* out, int32_t m, int32_t k, int32_t n, const void* workspace, int32_t group_size, int64_t stream) {
     (void)g_idx; (void)workspace;
-    marlin_common(in, qweight, scales, zeros, out, m, k, n, group_size, MI355_DTYPE_F16, 1, stream);
+    marlin_ffi(in, qweight, scales, zeros, out, m, k, n, group_size, MI355_DTYPE_F16, 1, stream);
 }
 void marlin_awq_4bit_bf16(const void* in, const int32_t* qweight, const void* scales, const void* zeros, const void* g_idx,
                           void* out, int32_t m, int32_t k, int32_t n, const void* workspace, int32_t group_size, int64_t stream) {
     (void)g_idx; (void)workspace;
-    marlin_common(in, qweight, scales, zeros, out, m, k, n, group_size, MI355_DTYPE_BF16, 1, stream);
+    marlin_ffi(in, qweight, scales, zeros, out, m, k, n, group_size, MI355_DTYPE_BF16, 1, stream);
 }
 
 void gemm_half_q_half_alt(const void* a, const uint32_t* b_q_weight, const uint32_t* b_gptq_qzeros, const void* b_gptq_scales,
                           const int32_t* b_g_idx, void* c, int32_t m, int32_t n, int32_t k, int32_t bit, int64_t stream) {
-    if (bit != 4 || (n & 15) || (k & 31)) return;
+    if (m == 0) return;
+    // the reference admits 4 | 8 bits on this arm (linear.rs:215-217) and forwards `bits` (gptq.rs:181-194)
+    if ((bit != 4 && bit != 8) || !a || !b_q_weight || !b_gptq_qzeros || !b_gptq_scales || !c || m < 0 || n <= 0 || k <= 0 ||
+        (n & 15) || (k & 31)) {
+        ffi_fail((int)hipErrorInvalidValue, c, m, n, stream);
+        return;
+    }
     hipStream_t st = (hipStream_t)stream;
-    // without g_idx the group is k / group_size; the op does not pass group_size, so g_idx is required by the
-    // reference for act-order checkpoints (linear.rs:298-314 always loads it for gptq)
-    const int gs = k;
     for (int t0 = 0; t0 < m; t0 += 32) {
         const int T = m - t0 < 32 ? m - t0 : 32;
         const uint16_t* x = static_cast<const uint16_t*>(a) + (size_t)t0 * k;
         uint16_t* o = static_cast<uint16_t*>(c) + (size_t)t0 * n;
-        if (T <= 16)
-            hipLaunchKernelGGL((exllama_kernel<1>), dim3(n / 16), dim3(256), 0, st, x, b_q_weight, b_gptq_qzeros,
-                               static_cast<const uint16_t*>(b_gptq_scales), b_g_idx, o, T, n, k, gs);
-        else
-            hipLaunchKernelGGL((exllama_kernel<2>), dim3(n / 16), dim3(256), 0, st, x, b_q_weight, b_gptq_qzeros,
-                               static_cast<const uint16_t*>(b_gptq_scales), b_g_idx, o, T, n, k, gs);
+        if (bit == 4) exllama_launch<4>(x, b_q_weight, b_gptq_qzeros, static_cast<const uint16_t*>(b_gptq_scales), b_g_idx, o, T, n, k, st);
+        else exllama_launch<8>(x, b_q_weight, b_gptq_qzeros, static_cast<const uint16_t*>(b_gptq_scales), b_g_idx, o, T, n, k, st);
     }
+    const int rc = (int)hipGetLastError();
+    if (rc) ffi_fail(rc, c, m, n, stream);
 }
 
 void gptq_repack(const void* in, void* out, int32_t k_packed, int32_t n, int64_t stream) {
     // our Marlin-slot layout is the checkpoint layout: [k/8][n] u32 (the [k/16, 2n] shape holds the same words)
-    hipMemcpyAsync(out, in, (size_t)k_packed * n * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (!in || !out || k_packed <= 0 || n <= 0) { mi355_note_error((int)hipErrorInvalidValue); return; }
+    const hipError_t e = hipMemcpyAsync(out, in, (size_t)k_packed * n * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) mi355_note_error((int)e);
 }
 void awq_repack(const void* in, void* out, int32_t k, int32_t n_packed, int32_t bits, int64_t stream) {
-    if (bits != 4 || (k & 7)) return;
+    if (bits != 4 || (k & 7) || !in || !out || k <= 0 || n_packed <= 0) {
+        // the output is a weight image, not activations: poison it as NaN-scaled codes cannot be expressed -- record and leave
+        mi355_note_error((int)hipErrorInvalidValue);
+        return;
+    }
     const size_t total = (size_t)(k / 8) * n_packed * 8;
     hipLaunchKernelGGL(awq_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        static_cast<const uint32_t*>(in), static_cast<uint32_t*>(out), k, n_packed);
+    const int rc = (int)hipGetLastError();
+    if (rc) mi355_note_error(rc);
+}
+
+/* Marlin-FORMAT checkpoint weight B [k/16, 2n] u32 -> the layout the marlin_* entry points stream ([k/8][n] u32).  The
+ * integration calls this once per tensor on the `marlin_format` branch of qlinear (linear.rs:279-290), where the reference
+ * passes B through untouched. */
+int mi355_marlin_format_repack(const void* in_B, void* out, int32_t k, int32_t n, int64_t stream) {
+    if (!in_B || !out || k <= 0 || n <= 0 || (k & 15) || (n & 63)) return (int)hipErrorInvalidValue;
+    const size_t total = (size_t)(k / 8) * n;
+    hipLaunchKernelGGL(marlin_to_gptq_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const uint32_t*>(in_B), static_cast<uint32_t*>(out), k, n);
+    return (int)hipGetLastError();
+}
+/* host statement of the same permutation (unit-tested on CPU against the numpy restatement of marlin's `_get_perms`) */
+int32_t mi355_marlin_weight_perm(int32_t j) {
+    if (j < 0 || j >= 1024) return -1;
+    const int e8 = j & 7, grp = j >> 3;
+    const int src8 = (e8 < 4) ? 2 * e8 : 2 * (e8 - 4) + 1;
+    const int q = grp * 8 + src8;
+    const int i = q >> 5, jj = (q >> 3) & 3, t = q & 7;
+    const int blk = t >> 2, e = t & 3;
+    const int r = (e < 2) ? 2 * (i & 3) + e : 2 * ((i & 3) + 4) + (e - 2);
+    return 16 * r + (i >> 2) + 8 * blk + 256 * jj;
 }
 
 /* host-side index arithmetic of the Marlin permutations (unit-tested on CPU against the reference's Python) */

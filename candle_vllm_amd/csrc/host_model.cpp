@@ -1113,8 +1113,15 @@ extern "C" int mi355_comm_all_gather(void* comm, const void* send, void* recv, i
 // ---- per-part launch for measurement: runs launch group `part` of layer `layer` on the static step inputs
 extern "C" int mi355_llama_run_part(void* mp, int32_t layer, int32_t part, int64_t stream) {
     Model* m = static_cast<Model*>(mp);
-    if (!m || m->cur_batch < 1 || layer < 0 || layer >= m->cfg.n_layers) return (int)hipErrorInvalidValue;
+    if (!m || m->cur_batch < 1 || part < PART_QKV || part > PART_EMBED) return (int)hipErrorInvalidValue;
+    if (part <= PART_DOWN && (layer < 0 || layer >= m->cfg.n_layers)) return (int)hipErrorInvalidValue;
     const StepIn in{m->d_tokens, m->d_positions, m->d_slots, m->d_bt, m->d_ctx, m->cur_batch, m->cur_max_blocks, m->cur_ctx_cap,
                     m->xs, m->q, m->attn, m->h, m->moe_ids, m->moe_w, m->moe_y, false, nullptr, 0, 0};
-    return run_part(m, layer, part, in, m->logits, stream);
+    return run_part(m, part <= PART_DOWN ? layer : 0, part, in, m->logits, stream);
+}
+
+extern "C" void* mi355_llama_act_ptr(void* mp, int32_t which) {
+    Model* m = static_cast<Model*>(mp);
+    if (!m) return nullptr;
+    return which == 0 ? (void*)m->xs : which == 1 ? (void*)m->q : which == 2 ? (void*)m->attn : which == 3 ? (void*)m->h : nullptr;
 }

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -51,6 +52,16 @@ int mi355_scratch_get(void** out, int key, size_t bytes, hipStream_t st, bool ze
     *out = p;
     return 0;
 }
+
+// Sticky error of the `void` entry points (the reference's FFI symbols return nothing, src/backend/gptq.rs:115-194,
+// cache.rs:127-162): the first failure since the last clear is kept until the host reads it.
+namespace { std::atomic<int> g_last_error{0}; }
+void mi355_note_error(int code) {
+    int expect = 0;
+    if (code) g_last_error.compare_exchange_strong(expect, code);
+}
+extern "C" int mi355_last_error(void) { return g_last_error.load(); }
+extern "C" void mi355_clear_error(void) { g_last_error.store(0); }
 
 extern "C" void mi355_scratch_release_all(void) {
     std::lock_guard<std::mutex> lock(g_mu);

@@ -19,3 +19,6 @@ enum {
 // when it is first created or grown.  Returns hipErrorStreamCaptureUnsupported when growth would be needed mid-capture.
 int mi355_scratch_get(void** out, int key, size_t bytes, hipStream_t st, bool zero_on_create);
 extern "C" void mi355_scratch_release_all(void);
+
+// void FFI entry points record their first failure here (mi355_last_error / mi355_clear_error in the header)
+void mi355_note_error(int code);

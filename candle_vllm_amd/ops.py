@@ -494,7 +494,7 @@ def gptq_matmul(x, qweight, scales, qzeros, g_idx, workspace, bits, group_size, 
     if marlin:
         k, n = qweight.shape[0] * 16, qweight.shape[1] // 2
     else:
-        k, n = qweight.shape[0] * 8, qweight.shape[1]
+        k, n = qweight.shape[0] * (32 // bits), qweight.shape[1]          # pack_factor = 32 / bits (gptq.rs:45-47)
     x2 = x.reshape(-1, k)
     m = x2.shape[0]
     out = torch.empty((m, n), dtype=x.dtype, device=x.device)
@@ -510,7 +510,20 @@ def gptq_matmul(x, qweight, scales, qzeros, g_idx, workspace, bits, group_size, 
         if qzeros is None or g_idx is None:
             raise RuntimeError("the exllama arm needs qzeros and g_idx")
         lib.gemm_half_q_half_alt(_dev(x2), _dev(qweight), zp, _dev(scales), gp, _dev(out), m, n, k, bits, _stream())
+    err = lib.mi355_last_error()                     # the FFI symbols are `void`: the library records what it refused
+    if err:
+        lib.mi355_clear_error()
+        raise RuntimeError(f"gptq_matmul refused by the device library (hipError {err}); the output was filled with NaN")
     return out.reshape(*x.shape[:-1], n)
+
+
+def marlin_format_repack(B):
+    """`checkpoint_format == "marlin"` (linear.rs:222-239,279-290): B [k/16, 2n] u32 in the Marlin tile order -> the
+    [k/16, 2n]-shaped weight image marlin_weight_repack would have produced (same consumer: gptq_matmul with a workspace)."""
+    k, n = B.shape[0] * 16, B.shape[1] // 2
+    out = torch.empty_like(B)
+    _check(lib.mi355_marlin_format_repack(_dev(B), _dev(out), k, n, _stream()), "marlin_format_repack")
+    return out
 
 
 class GPTQLinear:

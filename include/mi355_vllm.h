@@ -255,14 +255,30 @@ void marlin_awq_4bit_f16(const void* in, const int32_t* qweight, const void* sca
                          void* out, int32_t m, int32_t k, int32_t n, const void* workspace, int32_t group_size, int64_t stream);
 void marlin_awq_4bit_bf16(const void* in, const int32_t* qweight, const void* scales, const void* zeros, const void* g_idx,
                           void* out, int32_t m, int32_t k, int32_t n, const void* workspace, int32_t group_size, int64_t stream);
-/* exllama-style GPTQ (act-order), f16 only -- gptq.rs:181-197.  a [m,k] f16; b_q_weight [k/8,n] u32 (checkpoint
- * layout); qzeros [k/g, n/8] u32 (stored zero - 1); scales [k/g,n] f16; g_idx [k] (required); c [m,n] f16 */
+/* exllama-style GPTQ (act-order), f16 only -- gptq.rs:181-197.  bit = 4 | 8 (linear.rs:215-217), pack = 32 / bit:
+ * a [m,k] f16; b_q_weight [k/pack,n] u32 (checkpoint layout); qzeros [k/g, n/pack] u32 (stored zero - 1); scales [k/g,n]
+ * f16; g_idx [k] (required); c [m,n] f16.
+ * These symbols return nothing (the reference's signatures).  A call that cannot be served -- other bit widths, n % 16,
+ * k % 32 (marlin_*: k % 256), null pointers -- records its error code (mi355_last_error) and fills the 16-bit output
+ * with 0xFFFF (NaN), so a wrong configuration never reads as data. */
 void gemm_half_q_half_alt(const void* a, const uint32_t* b_q_weight, const uint32_t* b_gptq_qzeros, const void* b_gptq_scales,
                           const int32_t* b_g_idx, void* c, int32_t m, int32_t n, int32_t k, int32_t bit, int64_t stream);
 /* load-time repack -- gptq.rs:313-332.  gptq: in [k_packed = k/8, n] u32; awq: in [k, n_packed = n/8] u32
  * (AutoAWQ nibble order [0,2,4,6,1,3,5,7]); out: k*n/8 u32 in the layout the marlin_* entry points consume. */
 void gptq_repack(const void* in, void* out, int32_t k_packed, int32_t n, int64_t stream);
 void awq_repack(const void* in, void* out, int32_t k, int32_t n_packed, int32_t bits, int64_t stream);
+/* first error recorded by a `void` entry point (copy_blocks_*, marlin_*, gemm_half_q_half_alt, *_repack) since the last
+ * clear; 0 = none.  The reference bails in Rust around these calls (gptq.rs:196, linear.rs:215-217); a host that binds
+ * this library checks here instead. */
+int mi355_last_error(void);
+void mi355_clear_error(void);
+/* `checkpoint_format == "marlin"` (linear.rs:222-239,279-290; dims gptq.rs:46-49): the file's B [k/16, 2n] u32 is already in
+ * the Marlin tile order and the reference feeds it to marlin_4bit_* without a repack.  This library's marlin_* entry
+ * points stream the layout gptq_repack produces, so the integration converts B once at load time: out = k*n/8 u32,
+ * k % 16 == 0, n % 64 == 0.  `s` (scales) needs nothing: it is Marlin-permuted in both cases. */
+int mi355_marlin_format_repack(const void* in_B, void* out, int32_t k, int32_t n, int64_t stream);
+/* the weight permutation of one 1024-value chunk of a Marlin tile row (host helper; -1 outside [0, 1024)) */
+int32_t mi355_marlin_weight_perm(int32_t j);
 
 /* position of natural column n inside a Marlin-permuted scale row (grouped: group_size < k; else "single"),
  * and inside a Marlin zero-point row (nibble index) -- host helpers, used by the kernels' index arithmetic */
@@ -385,6 +401,10 @@ int mi355_llama_set_rope_tables(void* model, const float* cos_host, const float*
 /* measurement hook: one launch group of the step on the static inputs (part 0 qkv, 1 attention, 2 wo,
  * 3 gate/up, 4 down, 5 lm_head, 6 embedding) */
 int mi355_llama_run_part(void* model, int32_t layer, int32_t part, int64_t stream);
+/* parity hook: device pointer of one activation buffer of the decode step -- 0 = residual stream xs f32 [max_batch, hidden]
+ * (`layer_in` of quantized_llama.rs:438-475), 1 = q bf16, 2 = attention output bf16, 3 = MLP intermediate f32.  With
+ * mi355_llama_run_part a test can feed the oracle's layer input and compare one layer at a time at full geometry. */
+void* mi355_llama_act_ptr(void* model, int32_t which);
 
 /* generic communicator (the reference's per-process nccl `Comm`, pipeline.rs:805-812; collectives of
  * distributed.rs:547-654,1335-1446): RCCL bound by dlopen; id128 from mi355_comm_unique_id on rank 0 */

@@ -43,6 +43,13 @@ def lib():
         L.orc_llama_fill_random.argtypes = [vp, vp, ctypes.c_uint64]
         L.orc_llama_fill_random.restype = i32
         L.orc_llama_decode.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32]
+        L.orc_llama_get_qweight.restype = vp
+        L.orc_llama_get_qweight.argtypes = [vp, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+        L.orc_llama_set_trace.argtypes = [vp, vp]
+        L.orc_llama_set_fill_scale.argtypes = [f32]
+        L.orc_llama_set_attn_bf16.argtypes = [i32]
+        L.orc_llama_set_trace_parts.argtypes = [vp, vp, vp, vp, vp]
+        L.orc_llama_prefill.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
         L.orc_num_threads.restype = i32
         L.orc_set_num_threads.argtypes = [i32]
         _lib = L
@@ -54,7 +61,7 @@ def qmatmul(x, blocks, ggml_type, o2):
     b = np.ascontiguousarray(blocks, np.uint8)
     N, K, T = b.shape[0], b.shape[1] * 256, x.shape[0]
     y = np.empty((T, N), np.float32)
-    lib().orc_qmatmul(b.ctypes.data, ggml_type, N, K, x.ctypes.data, T, y.ctypes.data, 1 if o2 else 0)
+    lib().orc_qmatmul(b.ctypes.data, ggml_type, N, K, x.ctypes.data, T, y.ctypes.data, int(o2))
     return y
 
 
@@ -71,7 +78,9 @@ class CLlama:
     """C decode step over numpy-owned weights (oracle.llama.make_weights dict) or random weights."""
     _SLOT = {"wq": 0, "wk": 1, "wv": 2, "wo": 3, "w1": 4, "w2": 5, "w3": 6}
 
-    def __init__(self, cfg, W=None, types=None, seed=1):
+    def __init__(self, cfg, W=None, types=None, seed=1, fill_scale=1.0):
+        """fill_scale (random weights only): multiplies the super-block scales, i.e. the std of the dequantised weights
+        (1.0 = std ~0.04, the bench's synthetic weights; 0.2 = branch gain < 1 as in a trained checkpoint)"""
         self.cfg = cfg
         self.h = lib().orc_llama_create(ctypes.byref(make_cfg(cfg)))
         self._keep = []
@@ -96,7 +105,10 @@ class CLlama:
                     q(l, slot, lw[name])
         else:
             t = np.ascontiguousarray(types, np.int32)
-            if lib().orc_llama_fill_random(self.h, t.ctypes.data, seed) != 0:
+            lib().orc_llama_set_fill_scale(float(fill_scale))
+            rc = lib().orc_llama_fill_random(self.h, t.ctypes.data, seed)
+            lib().orc_llama_set_fill_scale(1.0)
+            if rc != 0:
                 raise MemoryError("oracle weights")
 
     def __del__(self):
@@ -104,8 +116,43 @@ class CLlama:
             lib().orc_llama_destroy(self.h)
             self.h = None
 
+    def set_f32(self, layer, which, a):
+        """which: 7 attn_norm, 8 ffn_norm; layer -1: 9 tok_embd [vocab, hidden], 10 output_norm (borrowed: kept alive here)"""
+        a = np.ascontiguousarray(a, np.float32)
+        self._keep.append(a)
+        lib().orc_llama_set_f32(self.h, layer, which, a.ctypes.data)
+
+    def qweight(self, layer, which):
+        """(pointer, ggml type, rows, cols) of one tensor's native GGUF blocks (layer -1: the output matrix)"""
+        t, n, k = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        p = lib().orc_llama_get_qweight(self.h, layer, which, ctypes.byref(t), ctypes.byref(n), ctypes.byref(k))
+        return p, t.value, n.value, k.value
+
+    def set_trace(self, trace):
+        """trace: f32 [n_layers+1, B, hidden] filled by the next decode() calls (None = off); kept alive here"""
+        self._trace = trace
+        lib().orc_llama_set_trace(self.h, None if trace is None else trace.ctypes.data)
+
+    def set_trace_parts(self, q=None, att=None, mid=None, h=None):
+        """f32 [L,B,H*D], [L,B,H*D], [L,B,hidden], [L,B,I] filled by the next decode() calls (all None = off)"""
+        self._trace_parts = (q, att, mid, h)
+        lib().orc_llama_set_trace_parts(self.h, *[None if a is None else a.ctypes.data for a in (q, att, mid, h)])
+
+    def prefill(self, tokens, positions, slots, kv_caches):
+        """one prompt step of ONE sequence without a cached prefix (O1f products); returns the last token's logits [vocab]"""
+        tok = np.ascontiguousarray(tokens, np.uint32)
+        pos = np.ascontiguousarray(positions, np.int64)
+        sl = np.ascontiguousarray(slots, np.int64)
+        L = len(kv_caches)
+        kp = (ctypes.c_void_p * L)(*[k.ctypes.data for k, _ in kv_caches])
+        vp = (ctypes.c_void_p * L)(*[v.ctypes.data for _, v in kv_caches])
+        logits = np.empty(self.cfg.vocab, np.float32)
+        lib().orc_llama_prefill(self.h, tok.ctypes.data, pos.ctypes.data, sl.ctypes.data, len(tok), kp, vp, logits.ctypes.data)
+        return logits
+
     def decode(self, meta, kv_caches, o2=False):
-        """kv_caches: list of (K,V) uint16 arrays in FLASH layout (modified in place)."""
+        """kv_caches: list of (K,V) uint16 arrays in FLASH layout (modified in place).  o2: False/0 = O1 (f64 dots),
+        True/1 = candle-CPU Q8_K integer dots, 2 = O1f (f32 blocked dots, for many-token steps)."""
         B = len(meta["input_ids"])
         tok = np.ascontiguousarray(meta["input_ids"], np.uint32)
         pos = np.ascontiguousarray(meta["positions"], np.int64)
@@ -117,5 +164,5 @@ class CLlama:
         vp = (ctypes.c_void_p * L)(*[v.ctypes.data for _, v in kv_caches])
         logits = np.empty((B, self.cfg.vocab), np.float32)
         lib().orc_llama_decode(self.h, tok.ctypes.data, pos.ctypes.data, slots.ctypes.data, bt.ctypes.data,
-                               ctx.ctypes.data, B, bt.shape[1], kp, vp, logits.ctypes.data, 1 if o2 else 0)
+                               ctx.ctypes.data, B, bt.shape[1], kp, vp, logits.ctypes.data, int(o2))
         return logits

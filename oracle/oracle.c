@@ -286,8 +286,10 @@ float orc_vec_dot_q6k_q8k_scalar(const uint8_t* w, int nb, const float* xd, cons
 
 /* y[T,N] = x[T,K] . dequant(W[N,K])^T.  o2 != 0: candle-CPU-faithful (Q8_K activations, integer dot);
  * o2 == 0: dequantise each row, accumulate in double (oracle O1). */
+static void qmatmul_o1f(const uint8_t* w, int type, int N, int K, const float* x, int T, float* y);
 void orc_qmatmul(const uint8_t* w, int type, int N, int K, const float* x, int T, float* y, int o2) {
     const int nb = K / QK_K, bb = type == T_Q4K ? Q4K_BYTES : Q6K_BYTES;
+    if (o2 == 2) { qmatmul_o1f(w, type, N, K, x, T, y); return; }
     if (o2) {
         float* xd = (float*)malloc((size_t)T * nb * 4);
         int8_t* xq = (int8_t*)malloc((size_t)T * K);
@@ -320,6 +322,59 @@ void orc_qmatmul(const uint8_t* w, int type, int N, int K, const float* x, int T
             }
             free(wr);
         }
+    }
+}
+
+/* O1f: the O1 definition (dequantise the row, dot with the f32 activations) with f32 accumulation in 8 (AVX2) or 1
+ * partial sums instead of one double, blocked 16 rows x all tokens so a many-token product (the full-size parity
+ * leg's batch-32 step and 2048-token prompt step, tests/fullsize_parity.py) finishes in seconds.  Differs from O1 by
+ * f32 summation noise only (~1e-6 relative, tests/test_cpu_oracle.py); same call sites as O1. */
+#define O1F_RB 16
+static void qmatmul_o1f(const uint8_t* w, int type, int N, int K, const float* x, int T, float* y) {
+    const int nb = K / QK_K, bb = type == T_Q4K ? Q4K_BYTES : Q6K_BYTES;
+#pragma omp parallel
+    {
+        float* wr = (float*)aligned_alloc(64, (size_t)O1F_RB * K * 4);
+#pragma omp for schedule(dynamic, 1)
+        for (int n0 = 0; n0 < N; n0 += O1F_RB) {
+            const int nr = N - n0 < O1F_RB ? N - n0 : O1F_RB;
+            for (int r = 0; r < nr; ++r) {
+                const uint8_t* row = w + (size_t)(n0 + r) * nb * bb;
+                if (type == T_Q4K) orc_dequantize_q4k(row, wr + (size_t)r * K, nb);
+                else orc_dequantize_q6k(row, wr + (size_t)r * K, nb);
+            }
+            for (int t = 0; t < T; ++t) {
+                const float* xr = x + (size_t)t * K;
+                int r = 0;
+#if defined(__AVX2__) && defined(__FMA__)
+                for (; r + 4 <= nr; r += 4) {
+                    const float *w0 = wr + (size_t)r * K, *w1 = w0 + K, *w2 = w1 + K, *w3 = w2 + K;
+                    __m256 a0 = _mm256_setzero_ps(), a1 = a0, a2 = a0, a3 = a0;
+                    for (int k = 0; k < K; k += 8) {
+                        const __m256 xv = _mm256_loadu_ps(xr + k);
+                        a0 = _mm256_fmadd_ps(xv, _mm256_load_ps(w0 + k), a0);
+                        a1 = _mm256_fmadd_ps(xv, _mm256_load_ps(w1 + k), a1);
+                        a2 = _mm256_fmadd_ps(xv, _mm256_load_ps(w2 + k), a2);
+                        a3 = _mm256_fmadd_ps(xv, _mm256_load_ps(w3 + k), a3);
+                    }
+                    __m256 acc[4] = {a0, a1, a2, a3};
+                    for (int j = 0; j < 4; ++j) {
+                        __m128 s = _mm_add_ps(_mm256_castps256_ps128(acc[j]), _mm256_extractf128_ps(acc[j], 1));
+                        s = _mm_add_ps(s, _mm_movehl_ps(s, s));
+                        s = _mm_add_ss(s, _mm_shuffle_ps(s, s, 1));
+                        y[(size_t)t * N + n0 + r + j] = _mm_cvtss_f32(s);
+                    }
+                }
+#endif
+                for (; r < nr; ++r) {
+                    const float* wv = wr + (size_t)r * K;
+                    float acc = 0;
+                    for (int k = 0; k < K; ++k) acc += xr[k] * wv[k];
+                    y[(size_t)t * N + n0 + r] = acc;
+                }
+            }
+        }
+        free(wr);
     }
 }
 
@@ -364,6 +419,8 @@ typedef struct {
     float *cosT, *sinT;
     uint8_t* owned;        /* random weights allocated by orc_llama_create_random */
     float* owned_f;
+    float* trace;          /* optional: the residual stream at every layer entry + after the last layer, [n_layers+1][B][hidden] */
+    float *tr_q, *tr_att, *tr_mid, *tr_h;   /* optional per-layer intermediates: [L][B][H*D] x2, [L][B][hidden], [L][B][I] */
 } orc_model;
 
 void* orc_llama_create(const orc_cfg* c) {
@@ -389,6 +446,16 @@ void orc_llama_destroy(void* mp) {
     if (!m) return;
     free(m->lw); free(m->norms); free(m->cosT); free(m->sinT); free(m->owned); free(m->owned_f); free(m);
 }
+/* decode steps record `layer_in` of every layer (quantized_llama.rs:438) and the final hidden state into `trace`
+ * ([n_layers+1][B][hidden], borrowed; NULL = off) so a test can compare the GPU path one layer at a time */
+void orc_llama_set_trace(void* mp, float* trace) { ((orc_model*)mp)->trace = trace; }
+/* ... and the values at the rounding points inside every layer: q after RoPE rounded to bf16 (attention.rs:977-981), the
+ * attention output rounded to bf16 (:995-1003), the stream after the attention residual (quantized_llama.rs:464) and the
+ * MLP intermediate silu(w1 x) * w3 x (:33-36) -- so each launch group can be checked from the oracle's own inputs */
+void orc_llama_set_trace_parts(void* mp, float* q, float* att, float* mid, float* h) {
+    orc_model* m = (orc_model*)mp;
+    m->tr_q = q; m->tr_att = att; m->tr_mid = mid; m->tr_h = h;
+}
 /* which: 0 wq 1 wk 2 wv 3 wo 4 w1 5 w2 6 w3 ; layer -1, which 11: output.  Pointers are borrowed. */
 void orc_llama_set_qweight(void* mp, int layer, int which, int type, const uint8_t* blocks, int n, int k) {
     orc_model* m = (orc_model*)mp;
@@ -406,13 +473,44 @@ static uint64_t xs64(uint64_t* s) { uint64_t x = *s; x ^= x << 13; x ^= x >> 7; 
 
 /* Random VALID weights (Q4_K_M-style type mixture decided by the caller through types[]) for the CPU
  * baseline timing: bytes from xorshift, f16 super-block scales set to sane constants. */
+/* attention arithmetic of orc_llama_decode: 0 = f32 scores / softmax / P.V, output rounded to bf16 (the oracle's parity
+ * target); 1 = what the reference's CPU path literally does with its bf16 q, k, v tensors (models/mod.rs:1288-1306): the
+ * score matmul returns bf16, `* scale` rounds again, softmax_last_dim writes bf16 probabilities, the P.V matmul returns
+ * bf16 [EXT candle CPU matmul / softmax: f32 inside, dtype of the tensor outside].  Used to measure how far the
+ * reference's own rounding points move the logits (tests/fullsize_parity.py). */
+static int g_attn_bf16 = 0;
+void orc_llama_set_attn_bf16(int on) { g_attn_bf16 = on; }
+static float g_fill_scale = 1.0f;   /* orc_llama_set_fill_scale: multiplies the super-block scales of the NEXT fill */
+void orc_llama_set_fill_scale(float s) { g_fill_scale = s > 0 ? s : 1.0f; }
+static uint16_t f32_to_f16(float f) {   /* round to nearest even, subnormals included (values here are tiny positives) */
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    int32_t e = (int32_t)((u >> 23) & 0xFF) - 127 + 15;
+    uint32_t m = u & 0x7FFFFFu;
+    if (e >= 31) return (uint16_t)(sign | 0x7C00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        m |= 0x800000u;
+        const int sh = 14 - e;
+        uint32_t r = m >> sh;
+        const uint32_t rem = m & ((1u << sh) - 1), half = 1u << (sh - 1);
+        if (rem > half || (rem == half && (r & 1))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = ((uint32_t)e << 10) | (m >> 13);
+    const uint32_t rem = m & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1))) ++r;
+    return (uint16_t)(sign | r);
+}
 static void fill_random(uint8_t* p, int type, int64_t nblocks, uint64_t* seed) {
     const int bb = type == T_Q4K ? Q4K_BYTES : Q6K_BYTES;
     uint64_t* q = (uint64_t*)p;
     const int64_t n8 = nblocks * bb / 8;
     for (int64_t i = 0; i < n8; ++i) q[i] = xs64(seed);
     for (int64_t i = n8 * 8; i < nblocks * bb; ++i) p[i] = (uint8_t)xs64(seed);
-    const uint16_t d4 = 0x0A8E /* 2e-4 */, dm4 = 0x1625 /* 1.5e-3 */, d6 = 0x00D2 /* 1.25e-5 */;
+    uint16_t d4 = 0x0A8E /* 2e-4 */, dm4 = 0x1625 /* 1.5e-3 */, d6 = 0x00D2 /* 1.25e-5 */;
+    if (g_fill_scale != 1.0f) { d4 = f32_to_f16(2e-4f * g_fill_scale); dm4 = f32_to_f16(1.5e-3f * g_fill_scale); d6 = f32_to_f16(1.25e-5f * g_fill_scale); }
     for (int64_t i = 0; i < nblocks; ++i) {
         if (type == T_Q4K) { memcpy(p + i * bb, &d4, 2); memcpy(p + i * bb + 2, &dm4, 2); }
         else memcpy(p + i * bb + 208, &d6, 2);
@@ -484,6 +582,7 @@ void orc_llama_decode(void* mp, const uint32_t* tokens, const int64_t* positions
     const float scale = 1.0f / sqrtf((float)D);
     for (int l = 0; l < c->n_layers; ++l) {
         const orc_qw* W = m->lw + (size_t)l * 7;
+        if (m->trace) memcpy(m->trace + (size_t)l * B * hid, xs, (size_t)B * hid * 4);
         orc_rms_norm(xs, m->norms[(size_t)l * 2], c->rms_eps, B, hid, xn);
         orc_qmatmul(W[0].w, W[0].type, W[0].n, W[0].k, xn, B, q, o2);
         orc_qmatmul(W[1].w, W[1].type, W[1].n, W[1].k, xn, B, k, o2);
@@ -510,7 +609,7 @@ void orc_llama_decode(void* mp, const uint32_t* tokens, const int64_t* positions
                     const uint16_t* kr = kcache[l] + ((blk * bs + t % bs) * Hkv + hk) * D;
                     float s = 0;
                     for (int d = 0; d < D; ++d) s += qb[d] * bf16_to_f32(kr[d]);
-                    sc[t] = s * scale;
+                    sc[t] = g_attn_bf16 ? round_bf16(round_bf16(s) * scale) : s * scale;
                     if (sc[t] > mx) mx = sc[t];
                 }
                 double den = 0;
@@ -520,23 +619,121 @@ void orc_llama_decode(void* mp, const uint32_t* tokens, const int64_t* positions
                 for (int t = 0; t < n; ++t) {
                     const size_t blk = bt[(size_t)b * max_blocks + t / bs];
                     const uint16_t* vr = vcache[l] + ((blk * bs + t % bs) * Hkv + hk) * D;
-                    const float p = (float)(sc[t] / den);
+                    float p = (float)(sc[t] / den);
+                    if (g_attn_bf16) p = round_bf16(p);
                     for (int d = 0; d < D; ++d) o[d] += p * bf16_to_f32(vr[d]);
                 }
                 for (int d = 0; d < D; ++d) o[d] = round_bf16(o[d]);
                 free(sc);
             }
+        if (m->tr_q) for (size_t i = 0; i < (size_t)B * H * D; ++i) m->tr_q[(size_t)l * B * H * D + i] = round_bf16(q[i]);
+        if (m->tr_att) memcpy(m->tr_att + (size_t)l * B * H * D, att, (size_t)B * H * D * 4);
         orc_qmatmul(W[3].w, W[3].type, W[3].n, W[3].k, att, B, tmp, o2);
         for (size_t i = 0; i < (size_t)B * hid; ++i) xs[i] += tmp[i];
+        if (m->tr_mid) memcpy(m->tr_mid + (size_t)l * B * hid, xs, (size_t)B * hid * 4);
         orc_rms_norm(xs, m->norms[(size_t)l * 2 + 1], c->rms_eps, B, hid, xn);
         orc_qmatmul(W[4].w, W[4].type, W[4].n, W[4].k, xn, B, g, o2);
         orc_qmatmul(W[6].w, W[6].type, W[6].n, W[6].k, xn, B, u, o2);
         for (size_t i = 0; i < (size_t)B * I; ++i) g[i] = g[i] / (1.f + expf(-g[i])) * u[i];
+        if (m->tr_h) memcpy(m->tr_h + (size_t)l * B * I, g, (size_t)B * I * 4);
         orc_qmatmul(W[5].w, W[5].type, W[5].n, W[5].k, g, B, tmp, o2);
         for (size_t i = 0; i < (size_t)B * hid; ++i) xs[i] += tmp[i];
     }
+    if (m->trace) memcpy(m->trace + (size_t)c->n_layers * B * hid, xs, (size_t)B * hid * 4);
     orc_rms_norm(xs, m->out_norm, c->rms_eps, B, hid, xn);
     orc_qmatmul(m->out.w, m->out.type, m->out.n, m->out.k, xn, B, logits, o2);
+    free(xs); free(xn); free(q); free(k); free(v); free(att); free(g); free(u); free(tmp);
+}
+
+/* Borrowed view of one weight tensor (native GGUF blocks) so a test can hand the SAME bytes to the GPU path.
+ * layer < 0: the output matrix. */
+const uint8_t* orc_llama_get_qweight(void* mp, int layer, int which, int* type, int* n, int* k) {
+    orc_model* m = (orc_model*)mp;
+    const orc_qw* q = layer < 0 ? &m->out : &m->lw[(size_t)layer * 7 + which];
+    *type = q->type; *n = q->n; *k = q->k;
+    return q->w;
+}
+
+/* One prompt step of ONE sequence of T tokens without a cached prefix (`is_prefill`, quantized_llama.rs:424-506 with
+ * the causal NaiveAttention of models/mod.rs:1288-1306 and the mask of layers/mask.rs:32-53): same op order and
+ * rounding points as orc_llama_decode / oracle/llama.py (q, k, v rounded to bf16 before attention, attention output
+ * rounded to bf16, f32 everywhere else), quantised products in O1f.  Writes the chunk's K/V into the flash-layout
+ * caches at `slots` and returns the LAST token's logits [vocab]. */
+void orc_llama_prefill(void* mp, const uint32_t* tokens, const int64_t* positions, const int64_t* slots, int T,
+                       uint16_t** kcache, uint16_t** vcache, float* logits) {
+    orc_model* m = (orc_model*)mp;
+    const orc_cfg* c = &m->c;
+    const int H = c->n_heads, Hkv = c->n_kv_heads, D = c->head_dim, hid = c->hidden, I = c->intermediate;
+    const int G = H / Hkv;
+    float* xs = (float*)malloc((size_t)T * hid * 4);
+    float* xn = (float*)malloc((size_t)T * hid * 4);
+    float* q = (float*)malloc((size_t)T * H * D * 4);
+    float* k = (float*)malloc((size_t)T * Hkv * D * 4);
+    float* v = (float*)malloc((size_t)T * Hkv * D * 4);
+    float* att = (float*)malloc((size_t)T * H * D * 4);
+    float* g = (float*)malloc((size_t)T * I * 4);
+    float* u = (float*)malloc((size_t)T * I * 4);
+    float* tmp = (float*)malloc((size_t)T * hid * 4);
+    for (int t = 0; t < T; ++t)
+        for (int i = 0; i < hid; ++i)
+            xs[(size_t)t * hid + i] = m->tok_embd ? m->tok_embd[(size_t)tokens[t] * hid + i]
+                                                  : 0.02f * sinf((float)(tokens[t] % 977) * 0.37f + (float)i * 0.011f);
+    const float scale = 1.0f / sqrtf((float)D);
+    for (int l = 0; l < c->n_layers; ++l) {
+        const orc_qw* W = m->lw + (size_t)l * 7;
+        orc_rms_norm(xs, m->norms[(size_t)l * 2], c->rms_eps, T, hid, xn);
+        orc_qmatmul(W[0].w, W[0].type, W[0].n, W[0].k, xn, T, q, 2);
+        orc_qmatmul(W[1].w, W[1].type, W[1].n, W[1].k, xn, T, k, 2);
+        orc_qmatmul(W[2].w, W[2].type, W[2].n, W[2].k, xn, T, v, 2);
+        orc_rope_i(q, m->cosT, m->sinT, positions, T, H, D);
+        orc_rope_i(k, m->cosT, m->sinT, positions, T, Hkv, D);
+        for (size_t i = 0; i < (size_t)T * H * D; ++i) q[i] = round_bf16(q[i]);
+        for (size_t i = 0; i < (size_t)T * Hkv * D; ++i) { k[i] = round_bf16(k[i]); v[i] = round_bf16(v[i]); }
+        for (int t = 0; t < T; ++t) {
+            if (slots[t] < 0) continue;
+            for (int i = 0; i < Hkv * D; ++i) {
+                kcache[l][(size_t)slots[t] * Hkv * D + i] = f32_to_bf16(k[(size_t)t * Hkv * D + i]);
+                vcache[l][(size_t)slots[t] * Hkv * D + i] = f32_to_bf16(v[(size_t)t * Hkv * D + i]);
+            }
+        }
+#pragma omp parallel for collapse(2) schedule(dynamic, 8)
+        for (int h = 0; h < H; ++h)
+            for (int t = 0; t < T; ++t) {
+                const int hk = h / G;
+                float* sc = (float*)malloc((size_t)(t + 1) * 4);
+                const float* qr = q + ((size_t)t * H + h) * D;
+                float mx = -1e30f;
+                for (int j = 0; j <= t; ++j) {                 /* causal: query t sees keys 0..t */
+                    const float* kr = k + ((size_t)j * Hkv + hk) * D;
+                    float s = 0;
+                    for (int d = 0; d < D; ++d) s += qr[d] * kr[d];
+                    sc[j] = s * scale;
+                    if (sc[j] > mx) mx = sc[j];
+                }
+                double den = 0;
+                for (int j = 0; j <= t; ++j) { sc[j] = expf(sc[j] - mx); den += sc[j]; }
+                float o[512];
+                for (int d = 0; d < D; ++d) o[d] = 0;
+                for (int j = 0; j <= t; ++j) {
+                    const float* vr = v + ((size_t)j * Hkv + hk) * D;
+                    const float p = (float)(sc[j] / den);
+                    for (int d = 0; d < D; ++d) o[d] += p * vr[d];
+                }
+                float* op = att + ((size_t)t * H + h) * D;
+                for (int d = 0; d < D; ++d) op[d] = round_bf16(o[d]);
+                free(sc);
+            }
+        orc_qmatmul(W[3].w, W[3].type, W[3].n, W[3].k, att, T, tmp, 2);
+        for (size_t i = 0; i < (size_t)T * hid; ++i) xs[i] += tmp[i];
+        orc_rms_norm(xs, m->norms[(size_t)l * 2 + 1], c->rms_eps, T, hid, xn);
+        orc_qmatmul(W[4].w, W[4].type, W[4].n, W[4].k, xn, T, g, 2);
+        orc_qmatmul(W[6].w, W[6].type, W[6].n, W[6].k, xn, T, u, 2);
+        for (size_t i = 0; i < (size_t)T * I; ++i) g[i] = g[i] / (1.f + expf(-g[i])) * u[i];
+        orc_qmatmul(W[5].w, W[5].type, W[5].n, W[5].k, g, T, tmp, 2);
+        for (size_t i = 0; i < (size_t)T * hid; ++i) xs[i] += tmp[i];
+    }
+    orc_rms_norm(xs + (size_t)(T - 1) * hid, m->out_norm, c->rms_eps, 1, hid, xn);
+    orc_qmatmul(m->out.w, m->out.type, m->out.n, m->out.k, xn, 1, logits, 0);
     free(xs); free(xn); free(q); free(k); free(v); free(att); free(g); free(u); free(tmp);
 }
 

@@ -61,6 +61,32 @@ def test_host_index_helpers_invert_the_permutations(lib, gold):
                 assert ((packed[g, p // 8] >> np.uint32(4 * (p % 8))) & 0xF) == zp[g, n]
 
 
+def test_marlin_format_weight_permutation(lib):
+    """the Marlin-format weight permutation: the library's closed form == the restated `_get_perms`; it is a permutation of
+    1024; pack -> (host statement of the device un-permute) recovers the GPTQ words bit for bit"""
+    perm = G.marlin_weight_perm()
+    assert sorted(perm.tolist()) == list(range(1024))
+    assert [lib.mi355_marlin_weight_perm(j) for j in range(1024)] == perm.tolist()
+    assert lib.mi355_marlin_weight_perm(-1) == -1 and lib.mi355_marlin_weight_perm(1024) == -1
+    # first entries by hand (i = 0: col 0, rows 0,1,8,9 of block 0 then block 1; interleave [0,2,4,6,1,3,5,7])
+    assert perm[:8].tolist() == [0, 128, 8, 136, 16, 144, 24, 152]
+    rng = np.random.default_rng(2)
+    K, N = 64, 128
+    q = rng.integers(0, 16, (K, N))
+    B = G.marlin_format_pack(q)
+    assert B.shape == (K // 16, 2 * N)
+    inv = np.argsort(perm)
+    out = np.zeros((K // 8, N), np.uint32)
+    for kr in range(K // 8):
+        for n in range(N):
+            for i in range(8):
+                k = 8 * kr + i
+                src = (n >> 4) * 256 + (k & 15) * 16 + (n & 15)
+                col = (src & ~1023) + int(inv[src & 1023])
+                out[kr, n] |= ((B[k >> 4, col >> 3] >> np.uint32(4 * (col & 7))) & np.uint32(0xF)) << np.uint32(4 * i)
+    assert (out == G.gptq_pack(q)).all()
+
+
 def test_dequant_and_linear_definitions():
     rng = np.random.default_rng(1)
     K, N, gs = 256, 32, 64

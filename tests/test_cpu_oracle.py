@@ -273,6 +273,41 @@ def test_c_oracle_decode_step_matches_numpy_llama():
     assert np.abs(got2 - ref).max() < 0.1 * np.abs(ref).max()
 
 
+def test_c_oracle_o1f_blocked_products_and_prompt_step_match_numpy_llama():
+    """The many-token arithmetic the full-size parity leg uses (tests/fullsize_parity.py): O1f (f32 blocked dots) equals O1
+    (f64 dots) to f32 summation noise, and the C prompt step (one sequence, causal) equals the numpy prompt step --
+    logits and the K/V it writes."""
+    from oracle import cref
+    cref.build()
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(37, 1024)).astype(np.float32)
+    for t in (kq.GGML_Q4_K, kq.GGML_Q6_K):
+        b = kq.quantize(rng.normal(0, 0.05, (45, 1024)).astype(np.float32), t)      # 45 rows: a ragged last row block
+        o1 = kq.qmatmul_o1(x, b, t)
+        assert np.abs(cref.qmatmul(x, b, t, o2=2) - o1).max() < 3e-6 * np.abs(o1).max()
+    cfg = llama.LlamaConfig.tiny()
+    W = llama.make_weights(cfg, seed=1234)
+    M = llama.OracleLlama(cfg, W)
+    seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 45)], "block_table": [5, 2, 9]}]
+    cache = M.new_cache(12)
+    meta = O.prepare_prompt(seqs, cfg.block_size)
+    ref = M.forward(meta, cache, is_prefill=True)[0]
+    c_cache = [(np.zeros_like(k), np.zeros_like(v)) for k, v in cache]
+    got = cref.CLlama(cfg, W).prefill(meta["input_ids"], meta["positions"], meta["slot_mapping"], c_cache)
+    assert np.abs(got - ref).max() < 2e-3 * np.abs(ref).max()      # bf16 rounding flips of q/k/v between f32 and f64 sums
+    assert int(got.argmax()) == int(ref.argmax())
+    for (k1, v1), (k2, v2) in zip(cache, c_cache):
+        assert np.abs(O.bf16_bits_to_f32(k1) - O.bf16_bits_to_f32(k2)).max() <= 2 ** -7 * np.abs(O.bf16_bits_to_f32(k1)).max()
+        assert np.abs(O.bf16_bits_to_f32(v1) - O.bf16_bits_to_f32(v2)).max() <= 2 ** -7 * np.abs(O.bf16_bits_to_f32(v1)).max()
+    # the accessor hands out the very bytes that were set
+    cm = cref.CLlama(cfg, W)
+    p, t, n, k = cm.qweight(1, 5)
+    import ctypes
+    blocks = np.ascontiguousarray(W["layers"][1]["w2"][1])
+    assert (t, n, k) == (W["layers"][1]["w2"][0], blocks.shape[0], blocks.shape[1] * 256)
+    assert ctypes.string_at(p, 64) == blocks.tobytes()[:64]
+
+
 def test_stablelm_oracle_plumbing_decode_equals_prefill():
     """BASELINE configs[0] (StableLM-3B bf16, CPU plumbing): the numpy restatement with LayerNorm + bias, head_dim 80,
     partial rotary (20 of 80 channels) and qkv bias runs a prompt step and greedy decode steps; a decode step equals

