@@ -33,8 +33,8 @@ os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 
 def llama3_8b():
-    from oracle.llama import LlamaConfig   # dataclass of dims only (no arithmetic)
-    return LlamaConfig.llama3_8b()
+    from candle_vllm_amd.model import ModelDims
+    return ModelDims.llama3_8b()
 
 
 def parse():
@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--kv-layout", choices=["flash", "paged"], default="paged",
                     help="paged = vLLM layout (reference default without flash-attn features; MFMA attention), "
                          "flash = [NB,bs,Hkv,D]")
+    ap.add_argument("--parity", choices=["off", "quick", "full"], default="quick",
+                    help="full-size check of the benchmarked geometry against the C oracle after the timed region "
+                         "(quick: batch 1; full: + batch 32 ragged and a 2048-token prompt step)")
     ap.add_argument("--layers", type=int, default=0, help="debug only: fewer layers (result marked invalid)")
     return ap.parse_args()
 
@@ -161,6 +164,43 @@ def bench_prefill(gm, cfg, perm, blocks_per_seq, T=2048):
             "useful_TFLOPs": round(useful, 1), "issued_TFLOPs_bf16": round(3 * useful, 1),
             "frac_of_2.5PF_dense_bf16": round(3 * useful / 2500.0, 3),
             "note": "hi/lo split = 3 bf16 GEMMs per matmul (rocBLAS) + dequant + prefill attention"}
+
+
+def parity_leg(mode):
+    """The benchmarked geometry (Llama-3-8B shapes, Q4_K_M, ctx 4096, block 64) against the C oracle built from the same
+    weight bytes (tests/fullsize_parity.py; the oracle is the CHECKER here, never the thing measured).  PARITY UNPINNED: the
+    oracle restates the reference's arithmetic, no reference-held vector exists for the float kernels."""
+    import gc
+    import torch
+    from tests.fullsize_parity import Pair, ragged_batch32
+    out = {"oracle": "O1 (unpinned)", "geometry": "Llama-3-8B Q4_K_M, ctx 4096 in paged KV (block 64), batch 1"
+                                                   + (" / 32 ragged / 2048-token prompt step" if mode == "full" else "")}
+    t0 = time.time()
+    pb = Pair(fill_scale=1.0)                                   # the bench's synthetic weight scale
+    g = pb.run_parts([4097], o2=0)
+    out["launch_groups_b1"] = {k: (round(v, 7) if isinstance(v, float) else v) for k, v in g.items() if k not in ("units", "oracle")}
+    out["launch_groups_units"] = g["units"]
+    if mode == "full":
+        g32 = pb.run_parts(ragged_batch32(np.random.default_rng(4321)), o2=2)
+        out["launch_groups_b32"] = {k: (round(v, 7) if isinstance(v, float) else v) for k, v in g32.items() if k not in ("units", "oracle")}
+    del pb
+    gc.collect(); torch.cuda.empty_cache()
+    pt = Pair(fill_scale=0.2)                                   # branch gain < 1, as in a trained checkpoint: end-to-end
+    e = pt.run_decode([4097], steps=3, o2=0, graph=True)
+    out.update({"max_rel_err": round(e["max_rel_err"], 6), "tokens_equal": bool(e["tokens_equal"]),
+                "reference_bf16_attention_spread": round(e["reference_bf16_attention_spread"], 6),
+                "end_to_end": "3 greedy steps, batch 1, hipGraph replay, logits vs O1; `reference_bf16_attention_spread` = the "
+                              "oracle with the reference's bf16 attention tensors (models/mod.rs:1288-1306) vs the f32-attention "
+                              "oracle on the same step: the floor under any end-to-end comparison through 32 layers"})
+    if mode == "full":
+        e32 = pt.run_decode(ragged_batch32(np.random.default_rng(4321)), steps=2, o2=2, graph=True)
+        out["batch32"] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in e32.items()}
+        pr = pt.run_prompt(2048)
+        out["prompt_step"] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in pr.items()}
+    del pt
+    gc.collect(); torch.cuda.empty_cache()
+    out["seconds"] = round(time.time() - t0, 1)
+    return out
 
 
 def main():
@@ -272,6 +312,11 @@ def main():
                 out["prefill"] = bench_prefill(gm, cfg, perm, blocks_per_seq)
             except Exception as e:                            # secondary number only
                 out["prefill"] = {"error": repr(e)}
+        if args.parity != "off" and world == 1 and not args.layers:
+            try:
+                out["parity"] = parity_leg(args.parity)
+            except Exception as e:                            # the checker must never sink the measured number
+                out["parity"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps)

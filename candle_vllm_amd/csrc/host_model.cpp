@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/mi355_vllm.h"
+#include "comm.h"
 
 #define HCHECK(expr)                                   \
     do {                                               \
@@ -34,72 +35,6 @@
     } while (0)
 
 namespace {
-
-// ---- RCCL through dlopen: the communicator lives beside the decode step (one process per GPU; the reference
-// creates one cudarc nccl `Comm` per process -- src/openai/pipelines/pipeline.rs:805-812, distributed.rs:547-654).
-// The library is resolved at run time so the .so still loads on a CPU-only box.
-struct NcclId { char internal[128]; };
-typedef int (*nccl_get_id_t)(NcclId*);
-typedef int (*nccl_init_rank_t)(void**, int, NcclId, int);
-typedef int (*nccl_allreduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
-typedef int (*nccl_allgather_t)(const void*, void*, size_t, int, void*, hipStream_t);
-typedef int (*nccl_destroy_t)(void*);
-struct Rccl {
-    void* h = nullptr;
-    nccl_get_id_t get_id = nullptr;
-    nccl_init_rank_t init_rank = nullptr;
-    nccl_allreduce_t all_reduce = nullptr;
-    nccl_allgather_t all_gather = nullptr;
-    nccl_destroy_t destroy = nullptr;
-};
-Rccl g_rccl;
-bool rccl_load() {
-    if (g_rccl.h) return true;
-    const char* env = getenv("MI355_RCCL_PATH");
-    const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-    void* h = nullptr;
-    for (int pass = 0; pass < 2 && !h; ++pass)            // pass 0: only a copy that is already loaded (torch's)
-        for (const char* n : names) {
-            if (!n) continue;
-            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
-            if (h) break;
-        }
-    if (!h) return false;
-    g_rccl.get_id = (nccl_get_id_t)dlsym(h, "ncclGetUniqueId");
-    g_rccl.init_rank = (nccl_init_rank_t)dlsym(h, "ncclCommInitRank");
-    g_rccl.all_reduce = (nccl_allreduce_t)dlsym(h, "ncclAllReduce");
-    g_rccl.all_gather = (nccl_allgather_t)dlsym(h, "ncclAllGather");
-    g_rccl.destroy = (nccl_destroy_t)dlsym(h, "ncclCommDestroy");
-    if (!g_rccl.get_id || !g_rccl.init_rank || !g_rccl.all_reduce || !g_rccl.all_gather) return false;
-    g_rccl.h = h;
-    return true;
-}
-enum { NCCL_FLOAT32 = 7, NCCL_SUM = 0 };
-
-// What every mi355_comm_* handle points to: an RCCL communicator created here, or collectives supplied by the host
-// (the reference's Rust side owns its nccl `Comm`; a host that already has one -- or a test running two ranks on one
-// GPU over gloo -- plugs its own all-reduce / all-gather in instead of handing us a second communicator).
-struct Comm {
-    void* nccl = nullptr;
-    mi355_allreduce_fn ar = nullptr;
-    mi355_allgather_fn ag = nullptr;
-    void* user = nullptr;
-};
-int nccl_dtype_of(int dt) { return dt == MI355_DTYPE_F32 ? 7 : (dt == MI355_DTYPE_F16 ? 6 : (dt == MI355_DTYPE_BF16 ? 9 : -1)); }
-int comm_all_reduce(Comm* c, void* buf, int64_t count, int dtype, int64_t stream) {
-    if (!c) return (int)hipErrorNotInitialized;
-    if (c->ar) return c->ar(c->user, buf, count, dtype, stream);
-    const int dt = nccl_dtype_of(dtype);
-    if (!c->nccl || dt < 0) return (int)hipErrorInvalidValue;
-    return g_rccl.all_reduce(buf, buf, (size_t)count, dt, NCCL_SUM, c->nccl, reinterpret_cast<hipStream_t>(stream)) == 0 ? 0 : (int)hipErrorUnknown;
-}
-int comm_all_gather(Comm* c, const void* send, void* recv, int64_t count, int dtype, int64_t stream) {
-    if (!c) return (int)hipErrorNotInitialized;
-    if (c->ag) return c->ag(c->user, send, recv, count, dtype, stream);
-    const int dt = nccl_dtype_of(dtype);
-    if (!c->nccl || dt < 0) return (int)hipErrorInvalidValue;
-    return g_rccl.all_gather(send, recv, (size_t)count, dt, c->nccl, reinterpret_cast<hipStream_t>(stream)) == 0 ? 0 : (int)hipErrorUnknown;
-}
 
 struct QW {
     void* tiles = nullptr;
@@ -1075,39 +1010,6 @@ extern "C" int mi355_llama_set_comm(void* mp, void* comm) {
     m->comm = static_cast<Comm*>(comm);
     m->comm_owned = false;
     return 0;
-}
-
-// ---- generic communicator handle (the reference's `Comm`, one per process: pipeline.rs:805-812) for the host layers:
-// create from the 128-byte unique id, in-stream all-reduce(sum) / all-gather, dtype = MI355_DTYPE_F32 / BF16 / F16
-extern "C" void* mi355_comm_create(const void* id128, int32_t rank, int32_t world) {
-    if (!id128 || world < 1 || rank < 0 || rank >= world || !rccl_load()) return nullptr;
-    NcclId id;
-    memcpy(&id, id128, sizeof(id));
-    void* nccl = nullptr;
-    if (g_rccl.init_rank(&nccl, world, id, rank) != 0) return nullptr;
-    Comm* c = new Comm();
-    c->nccl = nccl;
-    return c;
-}
-extern "C" void* mi355_comm_create_external(mi355_allreduce_fn all_reduce, mi355_allgather_fn all_gather, void* user) {
-    if (!all_reduce || !all_gather) return nullptr;
-    Comm* c = new Comm();
-    c->ar = all_reduce; c->ag = all_gather; c->user = user;
-    return c;
-}
-extern "C" void mi355_comm_destroy(void* comm) {
-    Comm* c = static_cast<Comm*>(comm);
-    if (!c) return;
-    if (c->nccl && g_rccl.destroy) (void)g_rccl.destroy(c->nccl);
-    delete c;
-}
-extern "C" int mi355_comm_all_reduce(void* comm, void* buf, int64_t count, int32_t dtype, int64_t stream) {
-    if (!comm || nccl_dtype_of(dtype) < 0) return (int)hipErrorInvalidValue;
-    return comm_all_reduce(static_cast<Comm*>(comm), buf, count, dtype, stream);
-}
-extern "C" int mi355_comm_all_gather(void* comm, const void* send, void* recv, int64_t count, int32_t dtype, int64_t stream) {
-    if (!comm || nccl_dtype_of(dtype) < 0) return (int)hipErrorInvalidValue;
-    return comm_all_gather(static_cast<Comm*>(comm), send, recv, count, dtype, stream);
 }
 
 // ---- per-part launch for measurement: runs launch group `part` of layer `layer` on the static step inputs

@@ -826,6 +826,8 @@ static int launch_mfma_w(const PAParams& p, int B, int P, hipStream_t st) {
 }
 template <int D32>
 static int launch_mfma(const PAParams& p, int B, int P, int wpb, hipStream_t st) {
+    if (wpb == 16) return launch_mfma_w<D32, 16>(p, B, P, st);
+    if (wpb == 8) return launch_mfma_w<D32, 8>(p, B, P, st);
     return wpb == 4 ? launch_mfma_w<D32, 4>(p, B, P, st) : launch_mfma_w<D32, 1>(p, B, P, st);
 }
 
@@ -874,7 +876,7 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
                (p.partition_size == 32 || p.partition_size == 64 || p.partition_size == 128)) {
         bool fused = false;
         // few sequences, many partitions: 4 partitions per workgroup, merged in LDS (4 x fewer partials to reduce)
-        if (g_pa_wpb > 0) wpb = (g_pa_wpb == 4 && p.partition_size <= 64) ? 4 : 1;
+        if (g_pa_wpb > 0) wpb = ((g_pa_wpb == 4 || g_pa_wpb == 8 || g_pa_wpb == 16) && p.partition_size <= 64) ? g_pa_wpb : 1;
         else wpb = (P >= 8 && p.partition_size <= 64) ? 4 : 1;
         // the in-kernel merge is one wave per (sequence, kv head): worth it only when there are many of them
         if (P > 1 && g_pa_fused && (int64_t)B * p.Hkv >= (g_pa_fused > 1 ? 1 : 64) && (int64_t)B * p.Hkv <= PA_ARRIVE_SLOTS) {

@@ -16,6 +16,21 @@ _SLOT = {"wq": W_WQ, "wk": W_WK, "wv": W_WV, "wo": W_WO, "w1": W_W1, "w2": W_W2,
 _TILE_BYTES = {GGML_Q4_K: 2304, GGML_Q6_K: 3360}
 
 
+class ModelDims:
+    """dims a GGUFLLaMa is created from (read from the GGUF metadata at quantized_llama.rs:231-260)"""
+
+    def __init__(self, hidden=4096, n_layers=32, n_heads=32, n_kv_heads=8, head_dim=128, intermediate=14336, vocab=128256,
+                 rms_eps=1e-5, rope_theta=500000.0, max_seq=8192, block_size=64):
+        self.hidden, self.n_layers, self.n_heads, self.n_kv_heads, self.head_dim = hidden, n_layers, n_heads, n_kv_heads, head_dim
+        self.intermediate, self.vocab, self.rms_eps, self.rope_theta = intermediate, vocab, rms_eps, rope_theta
+        self.max_seq, self.block_size = max_seq, block_size
+
+    @staticmethod
+    def llama3_8b():
+        """Llama-3-8B (public model-card values): BASELINE.json configs[1]"""
+        return ModelDims()
+
+
 def q4km_type_for(name, layer, n_layers):
     """llama.cpp Q4_K_M mixture [EXT]: output Q6_K; attn_v / ffn_down Q6_K on `use_more_bits` layers."""
     if name == "output":
@@ -235,18 +250,25 @@ class GGUFLLaMa:
                           "bytes": int(nbytes), "GBs": round(nbytes / avg / 1e3, 1), "launches_per_step": L}
         dom = max(rows, key=lambda p: rows[p]["avg_us"] * L)
         r = rows[dom]
-        traffic = None
-        try:        # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
-            import json, os
-            pmc = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                              "profiles", "r01_pmc_traffic.json")))
-            if dom == 3 and self._batch == 1 and self.tp_world == 1:
-                e = pmc["kernels"]["void qmm_kernel<1, 2, 12>(QmmArgs) wgs=896"]
-                traffic = int(e["fetch_bytes_corrected"] + e["WRITE_SIZE_KiB_avg"] * 1024)
+        # HBM bytes per launch of the dominant kernel: NOT measurable from inside this process (PMC counters need the
+        # rocprofv3 wrapper), so it is quoted from the committed PMC pass of this round -- with the commit that pass ran on --
+        # and only when that pass saw the same launch (same workgroup count = same geometry); otherwise null
+        traffic, traffic_source = None, None
+        try:
+            import glob, json, os
+            root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+            files = sorted(glob.glob(os.path.join(root, "r*_pmc_traffic.json")))
+            pmc = json.load(open(files[-1]))
+            d = pmc.get("dominant")
+            if d and dom == 3 and self._batch == 1 and self.tp_world == 1 and \
+                    abs(d["traffic_bytes_per_launch"] - r["bytes"]) < 0.25 * r["bytes"]:
+                traffic = int(d["traffic_bytes_per_launch"])
+                traffic_source = "%s @%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 correction)" % (
+                    "profiles/" + os.path.basename(files[-1]), pmc.get("commit", "unknown"))
         except Exception:
-            traffic = None
+            traffic, traffic_source = None, None
         return {"bound": "hbm", "kernel": r["kernel"], "achieved": r["GBs"], "peak": peak_gbs, "unit": "GB/s",
-                "frac": round(r["GBs"] / peak_gbs, 4), "traffic": traffic, "avg_us": r["avg_us"],
+                "frac": round(r["GBs"] / peak_gbs, 4), "traffic": traffic, "traffic_source": traffic_source, "avg_us": r["avg_us"],
                 "algorithmic_bytes_per_launch": r["bytes"],
                 "timing": "one hipEvent pair around the launches of all %d layers back to back on the step stream "
                           "(each streams its own weights from HBM), / %d = average launch duration of a sweep; median of %d sweeps" % (L, L, reps),

@@ -432,7 +432,10 @@ void* orc_llama_create(const orc_cfg* c) {
     m->cosT = (float*)malloc((size_t)c->max_seq * half * 4);
     m->sinT = (float*)malloc((size_t)c->max_seq * half * 4);
     for (int i = 0; i < half; ++i) {
-        const float inv = (float)(1.0 / pow((double)c->rope_theta, (double)(2 * i) / (double)c->head_dim));
+        /* calculate_default_inv_freq (rotary_emb.rs:14-19): base^(i/dim) in f64, cast to f32, reciprocal taken IN f32.  (A f64
+         * reciprocal differs by one f32 ulp for some i; at position 4096 that is half a milliradian on the fastest pairs --
+         * found by the full-size parity leg, tests/test_gpu_fullsize.py.) */
+        const float inv = 1.0f / (float)pow((double)c->rope_theta, (double)(2 * i) / (double)c->head_dim);
         for (int p = 0; p < c->max_seq; ++p) {
             const float th = (float)p * inv;
             m->cosT[(size_t)p * half + i] = (float)cos((double)th);

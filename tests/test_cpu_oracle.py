@@ -308,6 +308,37 @@ def test_c_oracle_o1f_blocked_products_and_prompt_step_match_numpy_llama():
     assert ctypes.string_at(p, 64) == blocks.tobytes()[:64]
 
 
+def test_c_oracle_rope_tables_follow_the_reference_at_long_positions():
+    """calculate_default_inv_freq (rotary_emb.rs:14-19) takes the reciprocal in f32; a f64 reciprocal differs by one f32 ulp
+    for 18 of Llama-3's 64 frequencies, which at position ~4096 is half a milliradian on the fastest pairs (found by the
+    full-size parity leg).  The C twin must agree with the numpy restatement at such positions."""
+    from oracle import cref
+    cref.build()
+    cfg = llama.LlamaConfig.tiny(max_seq=8192)
+    cfg.rope_theta, cfg.head_dim, cfg.n_heads, cfg.n_kv_heads, cfg.hidden = 500000.0, 128, 2, 1, 256
+    W = llama.make_weights(cfg, seed=77)
+    M = llama.OracleLlama(cfg, W)
+    rng = np.random.default_rng(3)
+    L = 4099
+    nblk = -(-L // cfg.block_size)
+    seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, L)], "block_table": list(range(1, nblk + 1))}]
+    cache = M.new_cache(nblk + 1)
+    for kc, vc in cache:                                          # a random prefix instead of a 4k-token prompt step
+        kc[...] = (rng.standard_normal(kc.shape).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        vc[...] = (rng.standard_normal(vc.shape).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    meta = O.prepare_decode(seqs, cfg.block_size)
+    c_cache = [(k.copy(), v.copy()) for k, v in cache]
+    ref = M.forward(meta, cache)
+    got = cref.CLlama(cfg, W).decode(meta, c_cache, o2=False)
+    assert np.abs(got - ref).max() < 2e-4 * np.abs(ref).max()
+    slot = int(meta["slot_mapping"][0])
+    for (k1, _), (k2, _) in zip(cache, c_cache):                 # the new token's rotated K: identical up to a bf16 flip
+        a = O.bf16_bits_to_f32(k1.reshape(-1, cfg.n_kv_heads * cfg.head_dim)[slot])
+        b = O.bf16_bits_to_f32(k2.reshape(-1, cfg.n_kv_heads * cfg.head_dim)[slot])
+        assert np.abs(a - b).max() <= 2 ** -7 * np.abs(a).max()
+        assert (a != b).mean() < 0.05
+
+
 def test_stablelm_oracle_plumbing_decode_equals_prefill():
     """BASELINE configs[0] (StableLM-3B bf16, CPU plumbing): the numpy restatement with LayerNorm + bias, head_dim 80,
     partial rotary (20 of 80 channels) and qkv bias runs a prompt step and greedy decode steps; a decode step equals

@@ -46,6 +46,10 @@ for B in batches:
             lib.mi355_set_tuning(int(k), int(v))
         tokens = rng.integers(0, cfg.vocab, B).astype(np.uint32)
         seq_lens = np.full(B, CTX + 1, np.uint32) if B == 1 else rng.integers(256, 4096, B).astype(np.uint32)
+        gm.set_graph(False)                              # one eager step per mode: scratch a mode needs is created outside a capture
+        gm.decode_begin(tokens, seq_lens, bt, ctx_cap=CTX + K + Wm + 2, stream=st)
+        gm.decode_step(st); gm.read_tokens(st)
+        gm.set_graph(True)
         gm.decode_begin(tokens, seq_lens, bt, ctx_cap=CTX + K + Wm + 2, stream=st)
         for _ in range(Wm):
             gm.decode_step(st); gm.read_tokens(st)

@@ -17,6 +17,11 @@ for k, cs in acc.items():
     res[k] = {"launches": max(len(v) for v in cs.values())}
     for c, v in cs.items():
         res[k][c] = round(sum(v) / len(v), 1)
-json.dump(res, open(out, "w"), indent=1)
+if len(sys.argv) > 3:
+    res = {"commit": sys.argv[3], "kernels": res}
+    json.dump(res, open(out, "w"), indent=1)
+    res = res["kernels"]
+else:
+    json.dump(res, open(out, "w"), indent=1)
 for k in sorted(res, key=lambda k: -res[k].get("SQ_WAVE_CYCLES", 0) * res[k]["launches"]):
     print(k, res[k])

@@ -1,6 +1,6 @@
-"""profiles/r01_pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE) of
+"""profiles/rNN_pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE) of
    python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-batch32 --no-graph
-usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json>
+usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> [commit]
 FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports 1/2 of a
 wide coalesced read -> fetch_bytes_corrected = 2 * FETCH_SIZE * 1024."""
 import csv
@@ -38,5 +38,14 @@ for k in sorted(fetch):
     w = sum(write[k]) / len(write[k]) if k in write else 0.0
     out["kernels"][k] = {"workgroups": wgs[k], "launches": len(fetch[k]), "FETCH_SIZE_KiB_avg": round(f, 1),
                          "fetch_bytes_corrected": int(2 * f * 1024), "WRITE_SIZE_KiB_avg": round(w, 1)}
+out["commit"] = sys.argv[4] if len(sys.argv) > 4 else "unknown"
+# the dominant launch group of the step = the mat-vec kernel that moves the most bytes per step (gate/up at batch 1):
+# recorded BY MEASUREMENT so that the bench needs no kernel name
+mv = {k: v for k, v in out["kernels"].items() if "qmm_kernel" in k and v["launches"] > 0}
+if mv:
+    dom = max(mv, key=lambda k: mv[k]["fetch_bytes_corrected"] * mv[k]["launches"])
+    e = mv[dom]
+    out["dominant"] = {"kernel": dom, "workgroups": e["workgroups"], "launches": e["launches"],
+                       "traffic_bytes_per_launch": int(e["fetch_bytes_corrected"] + e["WRITE_SIZE_KiB_avg"] * 1024)}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps(out["kernels"].get("void qmm_kernel<1, 2, 12>(QmmArgs) wgs=896"), indent=1))
+print(json.dumps(out.get("dominant"), indent=1))
