@@ -231,6 +231,13 @@ _sig("mi355_llama_set_comm", ctypes.c_int, [c_vp, c_vp])
 _sig("mi355_comm_destroy", None, [c_vp])
 _sig("mi355_comm_all_reduce", ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i64])
 _sig("mi355_comm_all_gather", ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64])
+_sig("mi355_llama_comm_handle", c_vp, [c_vp])
+_sig("mi355_comm_set_options", ctypes.c_int, [c_vp, c_i32, c_i32])
+_sig("mi355_comm_wire_bf16", ctypes.c_int, [c_vp])
+_sig("mi355_comm_all_reduce_residual", ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64])
+_sig("mi355_comm_p2p_export", ctypes.c_int, [c_vp, c_vp])
+_sig("mi355_comm_p2p_attach", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32])
+_sig("mi355_comm_p2p_error", ctypes.c_int, [c_vp])
 _sig("mi355_dense_alloc_kv_cache", ctypes.c_int, [c_vp, c_i32])
 _sig("mi355_dense_kv_ptr", c_vp, [c_vp, c_i32, c_i32])
 _sig("mi355_dense_forward", ctypes.c_int, [c_vp] * 7 + [c_i32] * 5 + [c_vp, c_i64])

@@ -91,6 +91,8 @@ struct Model {
     Comm* comm = nullptr;           // mi355_comm_* handle (owned when created by mi355_llama_init_comm)
     bool comm_owned = false;
     bool use_comm = false;          // tp_world > 1, or forced (single-rank plumbing test: MI355_FORCE_COMM=1)
+    float* tp_y = nullptr;          // [B, hidden] this rank's o_proj / down_proj partial in the reference's wire mode (bf16 all-reduce)
+    float* p_tp_y = nullptr;        // same for prompt steps (grow-only with the prefill workspace)
     float* logits_local = nullptr;  // [B, vocab/W]
     float* logits_gather = nullptr; // [W, B, vocab/W]
     // prefill workspace (grow-only, sized by the largest chunk seen): same roles as xs / q / attn / h
@@ -145,6 +147,7 @@ struct StepIn {
     // activation buffers of this step (decode: the model's static ones; prefill: the T-row workspace)
     float* xs; uint16_t* q; uint16_t* attn; float* h;
     int32_t* moe_ids; float* moe_w; float* moe_y;     // MoE scratch matching the buffers above
+    float* tp_y;                                      // [B, hidden] partial of o_proj / down_proj (reference wire mode)
     // prefill only (is_prefill): cu_seqlens_q [num_seqs+1], B = total tokens
     bool is_prefill; const uint32_t* cu_q; int num_seqs, max_seqlen_q;
 };
@@ -164,13 +167,18 @@ __global__ void gather_transpose_kernel(float* out, const float* in, int W, int 
     }
 }
 
-int all_reduce_xs(Model* m, float* xs, int B, int64_t st) {
+// C1/C2: all-reduce(sum) of [B, hidden] after o_proj / down_proj (distributed.rs:696-711).
+//   wire 0 (default): the f32 stream goes on the wire; rank 0's mat-mul epilogue already added the residual, so the sum is
+//                     the new stream (one rounding fewer than the reference; decode messages are latency-bound: 16 KiB at B=1)
+//   wire 1          : the reference's numerics -- every rank's partial `y` is rounded to bf16, summed in bf16, and the
+//                     result is added to the f32 residual (attention.rs:1003-1008, quantized_llama.rs:38-42)
+bool wire_bf16(const Model* m) { return m->use_comm && m->comm && m->comm->wire_bf16; }
+int all_reduce_xs(Model* m, float* xs, float* y, int B, int64_t st) {
     if (!m->use_comm) return 0;
     if (!m->comm) return (int)hipErrorNotInitialized;
-    // C1/C2: all-reduce(sum) of [B, hidden] after o_proj / down_proj (distributed.rs:696-711).  The reference
-    // sends bf16 (attention.rs:1005-1009); we keep the f32 residual stream on the wire (decode messages are
-    // latency-bound: 16 KiB at B=1).
-    return comm_all_reduce(m->comm, xs, (int64_t)B * m->cfg.hidden, MI355_DTYPE_F32, st);
+    const int64_t n = (int64_t)B * m->cfg.hidden;
+    if (m->comm->wire_bf16) return y ? comm_all_reduce_f32(m->comm, y, xs, n, st) : (int)hipErrorInvalidValue;
+    return comm_all_reduce_f32(m->comm, xs, nullptr, n, st);
 }
 
 enum { PART_QKV = 0, PART_ATTN = 1, PART_WO = 2, PART_GATEUP = 3, PART_DOWN = 4, PART_HEAD = 5, PART_EMBED = 6 };
@@ -287,10 +295,11 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
         d.w_tiles[0] = L.w[MI355_W_WO].tiles; d.ggml_type[0] = L.w[MI355_W_WO].type; d.n_rows[0] = L.w[MI355_W_WO].n_rows;
         d.x = in.attn; d.x_dtype = MI355_DTYPE_BF16; d.ldx = H * D; d.k = H * D; d.num_tokens = B;
         d.epilogue = lead ? MI355_EPI_RESID : MI355_EPI_STORE; d.out = in.xs; d.ldo = hid; d.residual = in.xs;
+        if (wire_bf16(m)) { d.epilogue = MI355_EPI_STORE; d.out = in.tp_y; d.residual = nullptr; }   // partial only; + residual after the sum
         // 9..32 tokens: the epilogue stages the gate/up launch's activation image (xs is final here unless TP reduces it)
         if (!m->use_comm && !moe) { d.chain_next = 1; d.chain_next_k = hid; d.chain_next_norm = L.ffn_norm; }
         RCHECK(mi355_qmatmul_fused(&d, st));
-        return all_reduce_xs(m, in.xs, B, st);
+        return all_reduce_xs(m, in.xs, in.tp_y, B, st);
     }
     if (part == PART_GATEUP) {
         // --- ffn_norm + w1|w3 + silu*mul              (quantized_llama.rs:33-37, 468)
@@ -309,12 +318,13 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
         d.w_tiles[0] = L.w[MI355_W_W2].tiles; d.ggml_type[0] = L.w[MI355_W_W2].type; d.n_rows[0] = L.w[MI355_W_W2].n_rows;
         d.x = in.h; d.x_dtype = MI355_DTYPE_F32; d.ldx = I; d.k = I; d.num_tokens = B;
         d.epilogue = lead ? MI355_EPI_RESID : MI355_EPI_STORE; d.out = in.xs; d.ldo = hid; d.residual = in.xs;
+        if (wire_bf16(m)) { d.epilogue = MI355_EPI_STORE; d.out = in.tp_y; d.residual = nullptr; }
         if (!m->use_comm) {                                         // -> next layer's QKV, or the lm_head
             d.chain_next = 1; d.chain_next_k = hid;
             d.chain_next_norm = (l + 1 < c.n_layers) ? m->layers[l + 1].attn_norm : m->output_norm;
         }
         RCHECK(mi355_qmatmul_fused(&d, st));
-        return all_reduce_xs(m, in.xs, B, st);
+        return all_reduce_xs(m, in.xs, in.tp_y, B, st);
     }
     return (int)hipErrorInvalidValue;
 }
@@ -327,7 +337,7 @@ int forward_decode(Model* m, const uint32_t* tokens, const int64_t* positions, c
     if (B < 1 || B > c.max_batch) return (int)hipErrorInvalidValue;
     if ((int)m->kcache.size() != c.n_layers) return (int)hipErrorInvalidValue;
     const StepIn in{tokens, positions, slots, bt, ctx, B, max_blocks, ctx_cap, m->xs, m->q, m->attn, m->h,
-                    m->moe_ids, m->moe_w, m->moe_y, false, nullptr, 0, 0};
+                    m->moe_ids, m->moe_w, m->moe_y, m->tp_y, false, nullptr, 0, 0};
     RCHECK(run_part(m, 0, PART_EMBED, in, logits, st));
     for (int l = 0; l < c.n_layers; ++l)
         for (int part = PART_QKV; part <= PART_DOWN; ++part) RCHECK(run_part(m, l, part, in, logits, st));
@@ -391,6 +401,7 @@ extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
     }
     alloc((void**)&m->logits, (size_t)B * cfg->vocab * 4);
     if (m->use_comm) {
+        alloc((void**)&m->tp_y, (size_t)B * cfg->hidden * 4);
         alloc((void**)&m->logits_local, (size_t)B * cfg->vocab * 4 / m->cfg.tp_world + 64);
         alloc((void**)&m->logits_gather, (size_t)B * cfg->vocab * 4 + 64 * m->cfg.tp_world);
     }
@@ -452,7 +463,7 @@ extern "C" void mi355_llama_destroy(void* mp) {
     free_qw(m->output);
     void* ptrs[] = {m->tok_embd, m->output_norm, m->cos_t, m->sin_t, m->xs, m->q, m->attn, m->h, m->logits,
                     m->pa_tmp, m->pa_max, m->pa_sum, m->kv_slab, m->d_tokens, m->d_positions, m->d_slots,
-                    m->d_ctx, m->d_bt, m->logits_local, m->logits_gather, m->p_xs, m->p_q, m->p_attn, m->p_h,
+                    m->d_ctx, m->d_bt, m->logits_local, m->logits_gather, m->tp_y, m->p_tp_y, m->p_xs, m->p_q, m->p_attn, m->p_h,
                     m->moe_ids, m->moe_w, m->moe_y, m->p_moe_ids, m->p_moe_w, m->p_moe_y};
     if (m->comm && m->comm_owned) mi355_comm_destroy(m->comm);
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -577,10 +588,10 @@ extern "C" int64_t mi355_llama_kv_bytes_per_tensor(void* mp) {
 
 static int ensure_prefill_cap(Model* m, int T) {
     if (T <= m->p_cap) return 0;
-    void* old[] = {m->p_xs, m->p_q, m->p_attn, m->p_h};
+    void* old[] = {m->p_xs, m->p_q, m->p_attn, m->p_h, m->p_tp_y};
     HCHECK(hipDeviceSynchronize());
     for (void* p : old) if (p) (void)hipFree(p);
-    m->p_xs = nullptr; m->p_q = nullptr; m->p_attn = nullptr; m->p_h = nullptr; m->p_cap = 0;
+    m->p_xs = nullptr; m->p_q = nullptr; m->p_attn = nullptr; m->p_h = nullptr; m->p_tp_y = nullptr; m->p_cap = 0;
     const int H = local_heads(m), D = m->cfg.head_dim;
     const int cap = (T + 255) / 256 * 256;
     HCHECK(hipMalloc((void**)&m->p_xs, (size_t)cap * m->cfg.hidden * 4));
@@ -588,6 +599,7 @@ static int ensure_prefill_cap(Model* m, int T) {
     HCHECK(hipMalloc((void**)&m->p_attn, (size_t)cap * H * D * 2));
     const int KE = m->cfg.n_expert > 1 ? m->cfg.n_expert_used : 1;
     HCHECK(hipMalloc((void**)&m->p_h, (size_t)cap * KE * m->cfg.intermediate * 4));
+    if (m->use_comm) HCHECK(hipMalloc((void**)&m->p_tp_y, (size_t)cap * m->cfg.hidden * 4));
     if (m->cfg.n_expert > 1) {
         void* oldm[] = {m->p_moe_ids, m->p_moe_w, m->p_moe_y};
         for (void* p : oldm) if (p) (void)hipFree(p);
@@ -614,7 +626,7 @@ extern "C" int mi355_llama_forward_prefill(void* mp, const uint32_t* tokens, con
     if ((int)m->kcache.size() != c.n_layers) return (int)hipErrorInvalidValue;
     RCHECK(ensure_prefill_cap(m, num_tokens));
     StepIn in{tokens, positions, slot_mapping, block_tables, context_lens, num_tokens, max_blocks, 0,
-              m->p_xs, m->p_q, m->p_attn, m->p_h, m->p_moe_ids, m->p_moe_w, m->p_moe_y, true, cu_seqlens_q, num_seqs, max_seqlen_q};
+              m->p_xs, m->p_q, m->p_attn, m->p_h, m->p_moe_ids, m->p_moe_w, m->p_moe_y, m->p_tp_y, true, cu_seqlens_q, num_seqs, max_seqlen_q};
     RCHECK(run_part(m, 0, PART_EMBED, in, logits, stream));
     for (int l = 0; l < c.n_layers; ++l)
         for (int part = PART_QKV; part <= PART_DOWN; ++part) RCHECK(run_part(m, l, part, in, logits, stream));
@@ -707,7 +719,10 @@ extern "C" int mi355_llama_decode_step(void* mp, int64_t stream) {
     struct Bump { Model* m; ~Bump() { ++m->cur_ctx_max; } } bump{m};
     // TP steps run eagerly (RCCL in-stream) unless the caller opted in with set_graph(2) AND the communicator is RCCL's
     // own (host-supplied collectives stage through the host and cannot be captured)
-    const bool tp_eager = m->use_comm && !(m->graph_tp && m->comm && m->comm->nccl);
+    // TP steps are captured like single-GPU ones when every collective of the step is device-native (RCCL on its side
+    // stream joins the capture as a fork / join; the one-shot peer kernel is an ordinary node whose sequence numbers live
+    // on the device).  Host-supplied collectives stage through the host and cannot be captured: those steps stay eager.
+    const bool tp_eager = m->use_comm && !(m->comm && m->comm->nccl);
     if (!m->use_graph || stream == 0 || tp_eager) return record_step(m, stream);
     if (m->w_batch != m->cur_batch || m->w_max_blocks != m->cur_max_blocks || m->w_ctx_cap != m->cur_ctx_cap) {
         // first step of a new shape runs eagerly: lazily-set kernel attributes and occupancy queries must not
@@ -988,10 +1003,6 @@ extern "C" int mi355_llama_load_gguf_tp(const char* path, int32_t max_batch, int
 // ---- tensor-parallel communicator -----------------------------------------------------------------------------
 // rank 0 makes the id (ncclGetUniqueId), the launcher ships the 128 bytes to the other ranks (the reference
 // passes it through the DAEMON_PAYLOAD env / TCP, communicator.rs:761-769,877), every rank calls init.
-extern "C" int mi355_comm_unique_id(void* out128) {
-    if (!rccl_load()) return (int)hipErrorSharedObjectInitFailed;
-    return g_rccl.get_id(static_cast<NcclId*>(out128)) == 0 ? 0 : (int)hipErrorUnknown;
-}
 extern "C" int mi355_llama_init_comm(void* mp, const void* id128) {
     Model* m = static_cast<Model*>(mp);
     if (!m || !id128) return (int)hipErrorInvalidValue;
@@ -1001,6 +1012,10 @@ extern "C" int mi355_llama_init_comm(void* mp, const void* id128) {
     m->comm = static_cast<Comm*>(c);
     m->comm_owned = true;
     return 0;
+}
+extern "C" void* mi355_llama_comm_handle(void* mp) {
+    Model* m = static_cast<Model*>(mp);
+    return m ? static_cast<void*>(m->comm) : nullptr;
 }
 // attach a communicator the caller owns (mi355_comm_create / mi355_comm_create_external)
 extern "C" int mi355_llama_set_comm(void* mp, void* comm) {
@@ -1018,7 +1033,7 @@ extern "C" int mi355_llama_run_part(void* mp, int32_t layer, int32_t part, int64
     if (!m || m->cur_batch < 1 || part < PART_QKV || part > PART_EMBED) return (int)hipErrorInvalidValue;
     if (part <= PART_DOWN && (layer < 0 || layer >= m->cfg.n_layers)) return (int)hipErrorInvalidValue;
     const StepIn in{m->d_tokens, m->d_positions, m->d_slots, m->d_bt, m->d_ctx, m->cur_batch, m->cur_max_blocks, m->cur_ctx_cap,
-                    m->xs, m->q, m->attn, m->h, m->moe_ids, m->moe_w, m->moe_y, false, nullptr, 0, 0};
+                    m->xs, m->q, m->attn, m->h, m->moe_ids, m->moe_w, m->moe_y, m->tp_y, false, nullptr, 0, 0};
     return run_part(m, part <= PART_DOWN ? layer : 0, part, in, m->logits, stream);
 }
 

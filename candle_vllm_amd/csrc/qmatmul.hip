@@ -1120,7 +1120,7 @@ struct QmgChainOut { uint8_t* img; float* ssp; const float* norm_w; int K, MT; s
 // and 32 threads build the 32 entries.
 __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, const float* __restrict__ part, const int ldp,
                                                            const int ks, const int BP, const float* __restrict__ ssp,
-                                                           const QmgChainOut ch) {
+                                                           const QmgChainOut ch, const float* __restrict__ rscale = nullptr) {
     const int prow = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     // deferred RMSNorm scale of this workgroup's token: the per-k-block partial sums are read by the lanes of one wave
@@ -1138,6 +1138,7 @@ __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, cons
         __syncthreads();
         inv = sm_inv;
     }
+    if (rscale && b < a.B) inv *= rscale[b];                          // prompt-step GEMM: per-token power-of-two scale of the f16 image
     float o = 0.f;
     if (prow < ldp && b < a.B) o = qmm_epilogue_one(a, part, ldp, ks, BP, inv, prow, b);
     if (!ch.img) return;
@@ -1369,6 +1370,61 @@ int mi355_internal_gemm_rowmajor(void* out, int out_dtype, int ldo, const void* 
 static void* g_qmp_ws = nullptr;
 static size_t g_qmp_ws_bytes = 0;
 
+#include "qmm_prefill.inc"
+
+// hand-written prompt-step GEMM (qmm_prefill.inc); returns hipErrorNotSupported for launches it does not cover (then the
+// caller keeps the library-GEMM path)
+static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
+    QmmArgs a = a0;
+    a.paired = 0;
+    for (int s = 0; s < a.nseg; ++s)
+        if (a.seg[s].type != MI355_GGML_Q4_K && a.seg[s].type != MI355_GGML_Q6_K) return (int)hipErrorNotSupported;
+    if (a.moe_expert || (a.K & 255)) return (int)hipErrorNotSupported;
+    int n_slots = 0;
+    for (int s = 0; s < a.nseg; ++s) n_slots += a.seg[s].n_tiles;
+    const int T = a.B, K = a.K, ldp = n_slots * 16, nkb = K >> 8;
+    const int Tpad = (T + QPG_BM - 1) / QPG_BM * QPG_BM;
+    const size_t xa_b = (size_t)K * Tpad * 4, sf_b = (size_t)nkb * Tpad * 32, rs_b = (size_t)Tpad * 4, c_b = (size_t)T * ldp * 4;
+    int rc = qmg_grow(&g_qmp_ws, &g_qmp_ws_bytes, xa_b + sf_b + 2 * rs_b + c_b + 4096, st);
+    if (rc) return rc;
+    uint8_t* base = static_cast<uint8_t*>(g_qmp_ws);
+    QpgImg im;
+    im.xa = base; im.sfrag = base + xa_b;
+    im.row_scale = reinterpret_cast<float*>(base + xa_b + sf_b);
+    im.row_inv = im.row_scale + Tpad;
+    im.Tpad = Tpad;
+    float* C = reinterpret_cast<float*>(base + xa_b + sf_b + 2 * rs_b);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_kernel<MI355_GGML_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(qpg_rowstat_kernel, dim3(Tpad), dim3(256), 0, st, a, im);
+    hipLaunchKernelGGL(qpg_prep_kernel, dim3(nkb, Tpad / 8), dim3(256), 0, st, a, im);
+    for (int s0 = 0, slot_base = 0; s0 < a.nseg;) {
+        int s1 = s0 + 1;
+        while (s1 < a.nseg && a.seg[s1].type == a.seg[s0].type) ++s1;
+        QmmArgs r = a;
+        r.nseg = s1 - s0;
+        int run_slots = 0;
+        for (int q = 0; q < r.nseg; ++q) { r.seg[q] = a.seg[s0 + q]; run_slots += r.seg[q].n_tiles; }
+        if (r.seg[0].type == MI355_GGML_Q4_K) {
+            const dim3 grid((run_slots + QPG_BN / 16 - 1) / (QPG_BN / 16), Tpad / QPG_BM);
+            hipLaunchKernelGGL((qpg_gemm_kernel<MI355_GGML_Q4_K>), grid, dim3(512), 64 * 1024, st, r, im, C, ldp, run_slots, slot_base);
+        } else {
+            const dim3 grid((run_slots + 3) / 4, Tpad / QPG_BM);       // Q6_K: 64 rows per workgroup (two exact operands per weight)
+            hipLaunchKernelGGL(qpg_gemm_q6k_kernel, grid, dim3(512), 64 * 1024, st, r, im, C, ldp, run_slots, slot_base);
+        }
+        slot_base += run_slots;
+        s0 = s1;
+    }
+    a.norm_w = nullptr;                                     // applied while the image was built
+    hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, T), dim3(256), 0, st, a, C, ldp, 1, T, (const float*)nullptr,
+                       QmgChainOut{nullptr, nullptr, nullptr, 0, 0, 0}, (const float*)im.row_scale);
+    return (int)hipGetLastError();
+}
+
 static int qmp_launch(const QmmArgs& a0, hipStream_t st) {
     QmmArgs a = a0;
     a.paired = 0;
@@ -1545,9 +1601,16 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
         a.B = 1;
         return qmm_launch_bt<1>(a, R, wt, n_wg, NW, st);
     }
-    if (a.B >= QMP_MIN_TOKENS && g_tune_prefill_gemm) {      // prompt step: dequantise once, library GEMM on the matrix cores
-        const int rcp = qmp_launch(a, st);
-        if (rcp != (int)hipErrorSharedObjectInitFailed) return rcp;     // no rocBLAS on this box: stream the weights instead
+    if (a.B >= QMP_MIN_TOKENS && g_tune_prefill_gemm) {
+        // prompt step: the hand-written quantised GEMM (qmm_prefill.inc).  mi355_set_tuning(6, 2) = the first-generation path
+        // (bf16 hi/lo weight image + three library GEMMs) for A/B runs; (6, 0) = stream the weights 32 tokens at a time.
+        if (g_tune_prefill_gemm != 2) {
+            const int rcq = qpg_launch(a, st);
+            if (rcq != (int)hipErrorNotSupported) return rcq;
+        } else {
+            const int rcp = qmp_launch(a, st);
+            if (rcp != (int)hipErrorSharedObjectInitFailed) return rcp;
+        }
     }
     const int B = a.B;
     const size_t xes = (a.x_dtype == MI355_DTYPE_BF16) ? 2 : 4;

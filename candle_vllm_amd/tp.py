@@ -222,6 +222,29 @@ class TorchDistComm:
         except Exception:
             return 999
 
+    def set_options(self, side_stream=1, wire_bf16=0):
+        """wire_bf16 = 1: the reference's all-reduce numerics (bf16 partials, bf16 sum, then + residual; attention.rs:1003-1008)"""
+        from ._lib import lib
+        if lib.mi355_comm_set_options(self.handle, int(side_stream), int(wire_bf16)) != 0:
+            raise RuntimeError("mi355_comm_set_options failed")
+
+    def attach_p2p(self):
+        """one-shot peer-to-peer all-reduce for decode-sized messages: every rank exports its region, the 64-byte IPC
+        handles travel through the process group (as the RCCL unique id does), every rank opens its peers' regions"""
+        import ctypes
+        from ._lib import lib
+        h = ctypes.create_string_buffer(64)
+        rc = lib.mi355_comm_p2p_export(self.handle, ctypes.addressof(h))
+        if rc != 0:
+            raise RuntimeError(f"mi355_comm_p2p_export failed with hipError {rc}")
+        world, rank = self._dist.get_world_size(self._group), self._dist.get_rank(self._group)
+        all_h = [None] * world
+        self._dist.all_gather_object(all_h, bytes(h.raw), group=self._group)
+        blob = ctypes.create_string_buffer(b"".join(all_h), 64 * world)
+        rc = lib.mi355_comm_p2p_attach(self.handle, ctypes.addressof(blob), rank, world)
+        if rc != 0:
+            raise RuntimeError(f"mi355_comm_p2p_attach failed with hipError {rc}")
+
     def close(self):
         from ._lib import lib
         if self.handle:

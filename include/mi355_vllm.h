@@ -385,8 +385,9 @@ int mi355_llama_forward_prefill(void* model, const uint32_t* tokens, const int64
 int mi355_llama_decode_begin(void* model, const uint32_t* tokens_host, const uint32_t* seq_lens_host,
                              const uint32_t* block_tables_host, int32_t batch, int32_t max_blocks, int32_t ctx_cap,
                              int64_t stream);
-/* enable: 0 = eager steps, 1 = hipGraph replay (default; tensor-parallel steps stay eager), 2 = also capture
- * tensor-parallel steps with the RCCL calls inside the graph (opt-in, RCCL communicators only; not yet run on hardware) */
+/* enable: 0 = eager steps, 1 (or 2) = hipGraph replay (default).  Tensor-parallel steps are captured too when the
+ * communicator is device-native (RCCL on its side stream joins the capture as a fork / join, the one-shot peer kernel is a
+ * plain node); with host-supplied collectives (mi355_comm_create_external) they stay eager. */
 int mi355_llama_set_graph(void* model, int32_t enable);
 int mi355_llama_decode_step(void* model, int64_t stream);
 int mi355_llama_decode_read_tokens(void* model, uint32_t* host_out, int64_t stream);
@@ -396,6 +397,7 @@ float* mi355_llama_logits_ptr(void* model);
 int mi355_comm_unique_id(void* out128);
 int mi355_llama_init_comm(void* model, const void* id128);
 int mi355_llama_set_comm(void* model, void* comm);          /* borrowed mi355_comm_* handle instead of init_comm */
+void* mi355_llama_comm_handle(void* model);                 /* the model's communicator (pipeline.rs:805-812), e.g. for mi355_comm_set_options */
 /* replace the default RoPE tables (built at create from rope_theta) by scaled ones: HOST f32 [n_positions >= max_seq, head_dim/2] */
 int mi355_llama_set_rope_tables(void* model, const float* cos_host, const float* sin_host, int32_t n_positions);
 /* measurement hook: one launch group of the step on the static inputs (part 0 qkv, 1 attention, 2 wo,
@@ -416,6 +418,26 @@ typedef int (*mi355_allgather_fn)(void* user, const void* send, void* recv, int6
 void* mi355_comm_create_external(mi355_allreduce_fn all_reduce, mi355_allgather_fn all_gather, void* user);
 void mi355_comm_destroy(void* comm);
 int mi355_comm_all_reduce(void* comm, void* buf, int64_t count, int32_t dtype, int64_t stream);   /* sum, in place */
+/* side_stream: 1 (default) = RCCL calls run on the communicator's own stream, fenced by events against `stream`
+ * (north_star; the reference's nccl ops run on the nccl stream, distributed.rs:547-654); 0 = in `stream`.
+ * wire_bf16: 0 (default) = the f32 residual stream on the wire, rank 0's partial carries the residual (one rounding fewer
+ * than the reference); 1 = the reference's numerics: every rank rounds its o_proj / down_proj partial to bf16, the sum is
+ * taken in bf16 and added to the f32 residual (attention.rs:1003-1008, quantized_llama.rs:38-42). */
+int mi355_comm_set_options(void* comm, int32_t side_stream, int32_t wire_bf16);
+int mi355_comm_wire_bf16(void* comm);
+/* resid[i] += sum over ranks of y[i] (f32, y is clobbered) with the communicator's wire numerics -- the call the GGUF host
+ * layer makes after o_proj / down_proj in wire mode 1 (attention.rs:1003-1008) */
+int mi355_comm_all_reduce_residual(void* comm, float* y, float* resid, int64_t count, int64_t stream);
+/* One-shot peer-to-peer all-reduce for decode-sized f32 messages (<= 256 KiB; SURVEY 2.4: C1/C2 are 8-256 KiB and
+ * latency-bound -- distributed.rs:547-654 runs them as ring all-reduces): every rank publishes its partial in a
+ * fine-grained region, every rank sums all partials in rank order (bit-identical on all ranks), one kernel, replayable in
+ * a hipGraph.  mi355_comm_p2p_export: allocate this rank's region, return its 64-byte IPC handle; the launcher gathers
+ * the world's handles (as it ships the RCCL unique id, pipeline.rs:805-812); mi355_comm_p2p_attach: open the peers'
+ * regions (handles = world x 64 bytes in rank order).  Works on RCCL and on host-supplied communicators; larger messages
+ * and all-gathers keep their transport.  mi355_comm_p2p_error: 1 after a wait that ran into its spin bound. */
+int mi355_comm_p2p_export(void* comm, void* handle_out64);
+int mi355_comm_p2p_attach(void* comm, const void* handles, int32_t rank, int32_t world);
+int mi355_comm_p2p_error(void* comm);
 int mi355_comm_all_gather(void* comm, const void* send, void* recv, int64_t count, int32_t dtype, int64_t stream);
 
 /* ---------------------------------------------------------------------------------------------

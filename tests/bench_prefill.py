@@ -21,7 +21,7 @@ def main():
     for T in (512, 2048, 4096):
         seqs = [{"tokens": rng.integers(0, cfg.vocab, T).tolist(), "block_table": list(range(1, 1 + -(-T // cfg.block_size)))}]
         meta = O.prepare_prompt(seqs, cfg.block_size)
-        for mode in (1, 0):
+        for mode in (1, 2, 0):                                   # 1 = hand-written quantised GEMM, 2 = library GEMMs (first generation), 0 = streaming
             if mode == 0 and T > 512:
                 continue
             M.lib.mi355_set_tuning(6, mode)

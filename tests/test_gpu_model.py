@@ -151,6 +151,57 @@ def test_tp_step_captured_in_a_graph_single_rank(lib, monkeypatch):
     assert runs[2] == runs[0], runs
 
 
+def test_rccl_side_stream_and_reference_wire_numerics_single_rank(lib, monkeypatch):
+    """RCCL on its side stream (event-fenced fork / join, also inside the captured graph) with the reference's wire numerics
+    (`mi355_comm_set_options(comm, 1, 1)`: bf16 partial -> bf16 all-reduce -> + f32 residual, attention.rs:1003-1008).  One
+    rank: the collective is real, and the oracle's communicator for that world is `bf16(x)`."""
+    monkeypatch.setenv("MI355_FORCE_COMM", "1")
+    cfg, orc, gm, seqs, cache = _setup(lib, True)
+
+    class _Dist:
+        @staticmethod
+        def broadcast(t, src=0):
+            return None
+    gm.init_comm(_Dist)
+    from candle_vllm_amd.model import lib as L
+    assert L.mi355_comm_set_options(L.mi355_llama_comm_handle(gm.h), 1, 1) == 0
+
+    class _Bf16World1:                                   # all_reduce over one rank in the reference's wire dtype
+        @staticmethod
+        def all_reduce(x):
+            return O.round_bf16(np.asarray(x, np.float32))
+
+        @staticmethod
+        def all_gather(x):
+            return [x]
+    orc.comm = _Bf16World1()
+    meta = O.prepare_decode(seqs, cfg.block_size)
+    ref = orc.forward(meta, [(k.copy(), v.copy()) for k, v in cache])
+    got = gm.forward_decode(meta).cpu().numpy()
+    assert _rel(got, ref) < 1e-3, _rel(got, ref)
+    # and the greedy loop: graph replay == eager, with the collectives inside the graph
+    steps = 5
+    for s, extra in zip(seqs, ([9], [5])):
+        s["block_table"] = s["block_table"] + extra
+    bt = np.zeros((2, 3), np.uint32)
+    for i, s in enumerate(seqs):
+        bt[i, :len(s["block_table"])] = s["block_table"]
+    toks0, lens0 = [s["tokens"][-1] for s in seqs], [len(s["tokens"]) for s in seqs]
+    stream = torch.cuda.Stream()
+    runs = {}
+    for mode in (0, 1):
+        for l, (kc, vc) in enumerate(cache):
+            gm.kv_upload(l, kc, vc)
+        gm.set_graph(mode)
+        gm.decode_begin(toks0, lens0, bt, ctx_cap=max(lens0) + steps, stream=stream.cuda_stream)
+        got = []
+        for _ in range(steps):
+            gm.decode_step(stream.cuda_stream)
+            got.append([int(t) for t in gm.read_tokens(stream.cuda_stream)])
+        runs[mode] = got
+    assert runs[1] == runs[0], runs
+
+
 @pytest.mark.parametrize("flash", [True, False])
 def test_prefill_step_matches_oracle_then_decodes(lib, flash):
     """prompt step on the GPU (K1 + K4 + quantised matmuls over T tokens) vs the oracle's prefill: last-token

@@ -40,7 +40,7 @@ def _gguf_case(moe=False):
     return cfg, W, seqs
 
 
-def _gguf_worker(rank, world, port, q, moe=False):
+def _gguf_worker(rank, world, port, q, moe=False, p2p=False, wire=0):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -48,6 +48,9 @@ def _gguf_worker(rank, world, port, q, moe=False):
     from candle_vllm_amd import model as M, tp
     cfg, W, seqs = _gguf_case(moe)
     comm = tp.TorchDistComm()
+    if p2p:
+        comm.attach_p2p()                                # decode-sized all-reduces: the one-shot peer kernel (IPC regions)
+    comm.set_options(1, wire)
     gm = M.GGUFLLaMa(cfg, max_batch=2, kv_layout=M.KV_PAGED, tp_rank=rank, tp_world=world)
     gm.load_oracle_weights(tp.shard_weights(W, cfg, rank, world))
     gm.alloc_kv_cache(8)
@@ -69,17 +72,81 @@ def _gguf_worker(rank, world, port, q, moe=False):
     for _ in range(3):
         gm.decode_step(stream.cuda_stream)
         toks.append([int(t) for t in gm.read_tokens(stream.cuda_stream)])
-    q.put((rank, pre, dec, toks))
+    q.put((rank, pre, dec, toks, M.lib.mi355_comm_p2p_error(comm.handle)))
     dist.barrier()
     comm.close()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("moe", [False, True])
-def test_gguf_tp2_two_ranks_on_one_gpu_equal_the_unsharded_model(lib, moe):
+class _LockstepComm:
+    """two oracle ranks in two threads of this process: all_reduce / all_gather meet at a barrier.  wire = 1: the
+    reference's all-reduce dtype -- every partial rounded to bf16, bf16 sum (attention.rs:1003-1008)"""
+
+    def __init__(self, world, wire):
+        import threading
+        self.world, self.wire = world, wire
+        self.slots = [None] * world
+        self.bar = threading.Barrier(world)
+
+    def view(self, rank):
+        outer = self
+
+        class _V:
+            def all_reduce(self, x):
+                outer.slots[rank] = np.asarray(x, np.float32)
+                outer.bar.wait()
+                parts = [O.round_bf16(p) if outer.wire else p for p in outer.slots]
+                tot = parts[0].copy()
+                for p in parts[1:]:
+                    tot = tot + p
+                if outer.wire:
+                    tot = O.round_bf16(tot)
+                outer.bar.wait()
+                return tot
+
+            def all_gather(self, x):
+                outer.slots[rank] = np.asarray(x)
+                outer.bar.wait()
+                out = [p.copy() for p in outer.slots]
+                outer.bar.wait()
+                return out
+        return _V()
+
+
+def _oracle_two_ranks(cfg, W, seqs, wire):
+    """the 2-rank ORACLE (shards of candle_vllm_amd/tp.py, collectives in the requested wire dtype): prompt step + one
+    decode step, as rank 0 sees them"""
+    import threading
+    from candle_vllm_amd import tp
+    lc = _LockstepComm(2, wire)
+    out = [None, None]
+
+    def run(rank):
+        orc = llama.OracleLlama(tp.shard_config(cfg, rank, 2), tp.shard_weights(W, cfg, rank, 2), flash_layout=False, comm=lc.view(rank))
+        cache = orc.new_cache(8)
+        sq = [{"tokens": list(s["tokens"]), "block_table": list(s["block_table"])} for s in seqs]
+        pre = orc.forward(O.prepare_prompt(sq, cfg.block_size), cache, is_prefill=True)
+        for s, row in zip(sq, pre):
+            s["tokens"].append(int(row.argmax()))
+        dec = orc.forward(O.prepare_decode(sq, cfg.block_size), cache)
+        out[rank] = (pre, dec)
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    return out[0]
+
+
+@pytest.mark.parametrize("moe,p2p,wire", [(False, False, 0), (True, False, 0), (False, True, 0), (False, True, 1), (False, False, 1)])
+def test_gguf_tp2_two_ranks_on_one_gpu_equal_the_unsharded_model(lib, moe, p2p, wire):
+    """p2p: the all-reduces of the step go through the one-shot peer kernel (two processes, one GPU, IPC-opened regions);
+    wire = 1: the reference's bf16 wire numerics (attention.rs:1003-1008) -- both against the UNSHARDED oracle (the bf16
+    wire rounds each partial once more: same 3e-3 band)"""
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a visible MI355X")
     cfg, W, seqs = _gguf_case(moe)
+    wire_ref = _oracle_two_ranks(cfg, W, seqs, 1) if wire else None    # the reference's numerics, restated on two oracle ranks
     orc = llama.OracleLlama(cfg, W, flash_layout=False)
     cache = orc.new_cache(8)
     pre = orc.forward(O.prepare_prompt(seqs, cfg.block_size), cache, is_prefill=True)
@@ -100,7 +167,7 @@ def test_gguf_tp2_two_ranks_on_one_gpu_equal_the_unsharded_model(lib, moe):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gguf_worker, args=(r, 2, port, q, moe)) for r in range(2)]
+    procs = [ctx.Process(target=_gguf_worker, args=(r, 2, port, q, moe, p2p, wire)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}
@@ -111,8 +178,17 @@ def test_gguf_tp2_two_ranks_on_one_gpu_equal_the_unsharded_model(lib, moe):
         p.join(timeout=120)
         assert p.exitcode == 0
     for rank in (0, 1):                                   # every rank ends up with the full logits
-        got_pre, got_dec, toks = res[rank]
+        got_pre, got_dec, toks, p2p_err = res[rank]
+        assert p2p_err == 0                               # no peer wait ran into its spin bound
         assert got_pre.shape == pre.shape and got_dec.shape == dec.shape
+        if wire:
+            # against the 2-rank oracle with the SAME wire numerics (the bf16 wire moves the logits by ~3.5e-3 of their
+            # scale away from the unsharded f32 model -- the reference's own TP runs carry that too)
+            rp, rd = wire_ref
+            assert np.abs(got_pre - rp).max() < 3e-3 * np.abs(rp).max()
+            assert np.abs(got_dec - rd).max() < 3e-3 * np.abs(rd).max()
+            assert np.abs(got_pre - pre).max() < 1e-2 * np.abs(pre).max()
+            continue
         assert np.abs(got_pre - pre).max() < 3e-3 * np.abs(pre).max()
         assert np.abs(got_dec - dec).max() < 3e-3 * np.abs(dec).max()
         assert toks == want, (rank, toks, want)
@@ -263,3 +339,94 @@ def test_gguf_file_loader_tp2_equals_setter_shards(lib, tmp_path):
         assert dims == (cfg.hidden, cfg.n_heads, cfg.n_kv_heads, cfg.intermediate, cfg.vocab, rank, 2)   # GLOBAL dims
         assert np.array_equal(from_file, from_setters)
         assert np.abs(from_file - ref).max() < 3e-3 * np.abs(ref).max()
+
+
+# ------------------------------------------------------------------------------------------------ one-shot peer all-reduce
+def _p2p_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from candle_vllm_amd import tp
+    from candle_vllm_amd._lib import lib
+    comm = tp.TorchDistComm()
+    comm.attach_p2p()
+    stream = torch.cuda.Stream()
+    st = stream.cuda_stream
+    out = {}
+    with torch.cuda.stream(stream):
+        # (a) plain in-place f32 sums of several sizes, several calls each (sequence numbers / both parities)
+        for n in (100, 4096, 5000, 16384, 65536):
+            for it in range(4):
+                x = torch.from_numpy(np.random.default_rng(1000 * n + 10 * it + rank).standard_normal(n).astype(np.float32)).cuda()
+                assert lib.mi355_comm_all_reduce(comm.handle, x.data_ptr(), n, 0, st) == 0
+                torch.cuda.synchronize()
+                out[("sum", n, it)] = x.cpu().numpy()
+        # (b) the same kernel replayed from a hipGraph (sequence numbers live on the device)
+        n = 4096
+        buf = torch.zeros(n, dtype=torch.float32, device="cuda")
+        src = [torch.from_numpy(np.random.default_rng(77 + 10 * it + rank).standard_normal(n).astype(np.float32)).cuda() for it in range(3)]
+        buf.copy_(src[0])
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            assert lib.mi355_comm_all_reduce(comm.handle, buf.data_ptr(), n, 0, torch.cuda.current_stream().cuda_stream) == 0
+        for it in range(3):
+            buf.copy_(src[it])
+            torch.cuda.synchronize()
+            dist.barrier()
+            g.replay()
+            torch.cuda.synchronize()
+            out[("graph", it)] = buf.cpu().numpy()
+        # (c) the reference's wire numerics: resid += bf16(sum_r bf16(y_r))
+        comm.set_options(1, 1)
+        n = 8192
+        y = torch.from_numpy(np.random.default_rng(500 + rank).standard_normal(n).astype(np.float32)).cuda()
+        resid = torch.from_numpy(np.random.default_rng(9).standard_normal(n).astype(np.float32)).cuda()
+        assert lib.mi355_comm_all_reduce_residual(comm.handle, y.data_ptr(), resid.data_ptr(), n, st) == 0
+        torch.cuda.synchronize()
+        out[("wire1",)] = resid.cpu().numpy()
+    q.put((rank, out, lib.mi355_comm_p2p_error(comm.handle)))
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+
+
+def test_one_shot_peer_all_reduce_two_processes_one_gpu(lib):
+    """The <= 256 KiB all-reduce of the decode step as ONE kernel per rank over IPC-opened peer regions (the transport
+    distributed.rs:547-654 runs as a ring): sums in rank order (bit-identical on both ranks), every size class, repeated
+    calls, hipGraph replay, and the reference's bf16 wire numerics (attention.rs:1003-1008) bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_p2p_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r = q.get(timeout=300)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][1] == 0 and res[1][1] == 0
+    for n in (100, 4096, 5000, 16384, 65536):
+        for it in range(4):
+            a = np.random.default_rng(1000 * n + 10 * it + 0).standard_normal(n).astype(np.float32)
+            b = np.random.default_rng(1000 * n + 10 * it + 1).standard_normal(n).astype(np.float32)
+            want = a + b                                        # f32 add in rank order
+            for rank in (0, 1):
+                assert np.array_equal(res[rank][0][("sum", n, it)], want), (n, it, rank)
+    for it in range(3):
+        want = np.random.default_rng(77 + 10 * it).standard_normal(4096).astype(np.float32) + \
+               np.random.default_rng(77 + 10 * it + 1).standard_normal(4096).astype(np.float32)
+        for rank in (0, 1):
+            assert np.array_equal(res[rank][0][("graph", it)], want), (it, rank)
+    y0 = np.random.default_rng(500).standard_normal(8192).astype(np.float32)
+    y1 = np.random.default_rng(501).standard_normal(8192).astype(np.float32)
+    resid = np.random.default_rng(9).standard_normal(8192).astype(np.float32)
+    want = resid + O.round_bf16(O.round_bf16(y0) + O.round_bf16(y1))
+    for rank in (0, 1):
+        assert np.array_equal(res[rank][0][("wire1",)], want), rank
