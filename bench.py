@@ -161,9 +161,12 @@ def bench_prefill(gm, cfg, perm, blocks_per_seq, T=2048):
     params = gm.weight_bytes_global / 0.5625                   # Q4_K: 0.5625 B per weight (Q6_K rows slightly under-counted)
     useful = 2.0 * params * T / dt / 1e12
     return {"value": round(T / dt, 1), "unit": "prompt tokens/s", "tokens": T, "ms": round(dt * 1e3, 2),
-            "useful_TFLOPs": round(useful, 1), "issued_TFLOPs_bf16": round(3 * useful, 1),
-            "frac_of_2.5PF_dense_bf16": round(3 * useful / 2500.0, 3),
-            "note": "hi/lo split = 3 bf16 GEMMs per matmul (rocBLAS) + dequant + prefill attention"}
+            "useful_TFLOPs": round(useful, 1), "issued_TFLOPs_f16": round(2 * useful, 1),
+            "frac_of_2.5PF_dense_f16_issued": round(2 * useful / 2500.0, 3),
+            "note": "hand-written quantised GEMM (csrc/qmm_prefill.inc): Q4_K/Q6_K unpacked in registers into f16 MFMA operands, "
+                    "no weight image in HBM, no library GEMM; activations f16 hi + lo = 2 MFMA passes (issued = 2 x useful; Q6_K "
+                    "tensors 4 passes); whole prompt step incl. prefill attention and epilogues.  MFMA-busy of the GEMM launches "
+                    "from rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES: profiles/r02_prefill_pmc_sq.json"}
 
 
 def parity_leg(mode):

@@ -1369,6 +1369,8 @@ int mi355_internal_gemm_rowmajor(void* out, int out_dtype, int ldo, const void* 
 
 static void* g_qmp_ws = nullptr;
 static size_t g_qmp_ws_bytes = 0;
+static int g_tune_qpg = 0;                                 // mi355_set_tuning(11, v): prompt-step GEMM variant (A/B runs)
+static int g_tune_dbg = 0;                                 // mi355_set_tuning(2, v): probe / ablation modes (experiments only)
 
 #include "qmm_prefill.inc"
 
@@ -1387,6 +1389,7 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
     const size_t xa_b = (size_t)K * Tpad * 4, sf_b = (size_t)nkb * Tpad * 32, rs_b = (size_t)Tpad * 4, c_b = (size_t)T * ldp * 4;
     int rc = qmg_grow(&g_qmp_ws, &g_qmp_ws_bytes, xa_b + sf_b + 2 * rs_b + c_b + 4096, st);
     if (rc) return rc;
+    a.dbg = g_tune_dbg;                                     // ablation bits of the prompt-step GEMM (experiments only)
     uint8_t* base = static_cast<uint8_t*>(g_qmp_ws);
     QpgImg im;
     im.xa = base; im.sfrag = base + xa_b;
@@ -1396,7 +1399,10 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
     float* C = reinterpret_cast<float*>(base + xa_b + sf_b + 2 * rs_b);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)qpg_gemm_kernel<MI355_GGML_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+#define QPG_ATTR(MTW, NTW, WM, WN, DEEP) (void)hipFuncSetAttribute((const void*)qpg_gemm_kernel<MI355_GGML_Q4_K, MTW, NTW, WM, WN, DEEP>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)
+        QPG_ATTR(2, 4, 4, 2, false); QPG_ATTR(2, 4, 2, 4, false); QPG_ATTR(2, 4, 1, 8, false); QPG_ATTR(4, 4, 1, 4, false);
+        QPG_ATTR(2, 4, 2, 4, true); QPG_ATTR(4, 2, 2, 4, false);
+#undef QPG_ATTR
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         attr_done = true;
     }
@@ -1410,11 +1416,22 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
         int run_slots = 0;
         for (int q = 0; q < r.nseg; ++q) { r.seg[q] = a.seg[s0 + q]; run_slots += r.seg[q].n_tiles; }
         if (r.seg[0].type == MI355_GGML_Q4_K) {
-            const dim3 grid((run_slots + QPG_BN / 16 - 1) / (QPG_BN / 16), Tpad / QPG_BM);
-            hipLaunchKernelGGL((qpg_gemm_kernel<MI355_GGML_Q4_K>), grid, dim3(512), 64 * 1024, st, r, im, C, ldp, run_slots, slot_base);
+            // variants (mi355_set_tuning(11, v)): wave tile (m-tiles x row tiles), wave grid, activation prefetch depth
+#define QPG_GO(MTW, NTW, WM, WN, DEEP) hipLaunchKernelGGL((qpg_gemm_kernel<MI355_GGML_Q4_K, MTW, NTW, WM, WN, DEEP>), \
+                dim3((run_slots + NTW * WN - 1) / (NTW * WN), Tpad / (16 * MTW * WM)), dim3(WM * WN * 64), 4 * (16 * MTW * WM) * QPG_ROWB, st, \
+                r, im, C, ldp, run_slots, slot_base)
+            switch (g_tune_qpg) {
+                case 1: QPG_GO(2, 4, 4, 2, false); break;              // 128 x 128, waves 32 x 64
+                case 2: QPG_GO(2, 4, 2, 4, false); break;              //  64 x 256, waves 32 x 64
+                case 3: QPG_GO(4, 2, 2, 4, false); break;              // 128 x 128, waves 64 x 32
+                case 4: QPG_GO(4, 4, 1, 4, false); break;              //  64 x 256, 4 waves of 64 x 64
+                case 5: QPG_GO(2, 4, 2, 4, true); break;               //  64 x 256, activations two chunks ahead
+                default: QPG_GO(2, 4, 1, 8, false); break;             //  32 x 512, waves 32 x 64: measured best (14.7 k tok/s at T = 2048, no spills)
+            }
+#undef QPG_GO
         } else {
-            const dim3 grid((run_slots + 3) / 4, Tpad / QPG_BM);       // Q6_K: 64 rows per workgroup (two exact operands per weight)
-            hipLaunchKernelGGL(qpg_gemm_q6k_kernel, grid, dim3(512), 64 * 1024, st, r, im, C, ldp, run_slots, slot_base);
+            const dim3 grid((run_slots + 15) / 16, Tpad / 32);         // Q6_K: 32 tokens x 256 rows per workgroup
+            hipLaunchKernelGGL(qpg_gemm_q6k_kernel, grid, dim3(512), 16 * 1024, st, r, im, C, ldp, run_slots, slot_base);
         }
         slot_base += run_slots;
         s0 = s1;
@@ -1469,7 +1486,7 @@ static int qmp_launch(const QmmArgs& a0, hipStream_t st) {
 void mi355_pa_set_fused(int v);
 void mi355_pa_set_wpb(int v);
 extern "C" void mi355_host_set_partition_override(int v);
-static int g_tune_nw = 0, g_tune_r = 0, g_tune_dbg = 0;   // 0 = heuristic; mi355_set_tuning (experiments only)
+static int g_tune_nw = 0, g_tune_r = 0;                   // 0 = heuristic; mi355_set_tuning (experiments only)
 static int g_tune_prefill_gemm = 1;                        // 0 = always stream the quantised weights (experiments)
 extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     if (key == 0) g_tune_nw = value;
@@ -1481,6 +1498,7 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     else if (key == 8) mi355_pa_set_wpb(value);
     else if (key == 9) g_tune_chain = value;
     else if (key == 10 && value > 0) g_tune_ks_target = value;
+    else if (key == 11) g_tune_qpg = value;
 }
 
 static size_t qmm_lds_bytes(int BT, int R, int NW) {

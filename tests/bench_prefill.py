@@ -18,19 +18,25 @@ def main():
     gm.load_synthetic()
     gm.alloc_kv_cache(160)
     rng = np.random.default_rng(0)
-    for T in (512, 2048, 4096):
+    for T in [int(t) for t in os.environ.get("PF_T", "512,2048,4096").split(",")]:
         seqs = [{"tokens": rng.integers(0, cfg.vocab, T).tolist(), "block_table": list(range(1, 1 + -(-T // cfg.block_size)))}]
         meta = O.prepare_prompt(seqs, cfg.block_size)
-        for mode in (1, 2, 0):                                   # 1 = hand-written quantised GEMM, 2 = library GEMMs (first generation), 0 = streaming
+        for mode in [int(m) for m in os.environ.get("PF_MODES", "1,2,0").split(",")]:   # 1 = hand-written quantised GEMM, 2 = library GEMMs (first generation), 0 = streaming
             if mode == 0 and T > 512:
                 continue
             M.lib.mi355_set_tuning(6, mode)
-            gm.forward_prefill(meta)
-            t0 = time.perf_counter()
-            gm.forward_prefill(meta)
-            dt = time.perf_counter() - t0
-            flops = 2.0 * (gm.weight_bytes / 0.5625) * T          # ~ 2 * params * tokens (Q4_K: 0.5625 B / weight)
-            print(f"prefill T={T:5d} gemm={mode}: {T / dt:9.1f} tok/s  {dt * 1e3:8.1f} ms  ~{flops / dt / 1e12:6.1f} TFLOP/s", flush=True)
+            for qv in ([int(v) for v in os.environ.get("PF_QPG", "0").split(",")] if mode == 1 else [0]):
+                M.lib.mi355_set_tuning(11, qv)
+                for dbg in ([int(v) for v in os.environ.get("PF_DBG", "0").split(",")] if mode == 1 else [0]):
+                    M.lib.mi355_set_tuning(2, dbg)
+                    gm.forward_prefill(meta)
+                    t0 = time.perf_counter()
+                    gm.forward_prefill(meta)
+                    dt = time.perf_counter() - t0
+                    flops = 2.0 * (gm.weight_bytes / 0.5625) * T          # ~ 2 * params * tokens (Q4_K: 0.5625 B / weight)
+                    print(f"prefill T={T:5d} gemm={mode} variant={qv} dbg={dbg}: {T / dt:9.1f} tok/s  {dt * 1e3:8.1f} ms  ~{flops / dt / 1e12:6.1f} TFLOP/s", flush=True)
+    M.lib.mi355_set_tuning(11, 0)
+    M.lib.mi355_set_tuning(2, 0)
     M.lib.mi355_set_tuning(6, 1)
 
 
