@@ -45,9 +45,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--ctx", type=int, default=4096, help="prompt tokens already in the KV cache")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--tp-graph", action="store_true",
-                    help="N > 1 only, opt-in: capture the tensor-parallel step (RCCL calls included) in a hipGraph "
-                         "(mi355_llama_set_graph(model, 2)); the default TP step is eager")
+    ap.add_argument("--tp-eager", action="store_true", help="N > 1 only: run tensor-parallel steps eagerly instead of from a hipGraph")
+    ap.add_argument("--p2p", action="store_true",
+                    help="N > 1 only, opt-in: decode-sized all-reduces through the one-shot peer-to-peer kernel (IPC regions; validated "
+                         "with two processes on one GPU, not yet over xGMI) instead of RCCL")
+    ap.add_argument("--wire-bf16", action="store_true", help="N > 1 only: the reference's all-reduce numerics (bf16 partials on the wire)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-batch32", action="store_true", help="skip the secondary batch-32 measurement")
@@ -58,6 +60,8 @@ def parse():
     ap.add_argument("--parity", choices=["off", "quick", "full"], default="quick",
                     help="full-size check of the benchmarked geometry against the C oracle after the timed region "
                          "(quick: batch 1; full: + batch 32 ragged and a 2048-token prompt step)")
+    ap.add_argument("--legs", default="all", help="secondary legs at BASELINE configs[2..4] shapes on one GPU (bench_legs.py): "
+                                                   "all | none | comma list of bf16_b32,gptq_qwen2,mixtral_fp8")
     ap.add_argument("--layers", type=int, default=0, help="debug only: fewer layers (result marked invalid)")
     return ap.parse_args()
 
@@ -241,7 +245,7 @@ def main():
     gm = M.GGUFLLaMa(cfg, max_batch=(B32 if do_b32 else B), max_blocks_per_seq=blocks_per_seq, kv_layout=kv_layout,
                      tp_rank=rank, tp_world=world)
     if world > 1:
-        gm.init_comm(dist)
+        gm.init_comm(dist, p2p=args.p2p, wire_bf16=args.wire_bf16)
     gm.load_synthetic(seed=1235, recipe="q4_k_m")
     gm.alloc_kv_cache(num_blocks)
     gm.kv_fill_random(seed=7 + rank)
@@ -254,7 +258,8 @@ def main():
     seq_lens = np.full(B, args.ctx + 1, np.uint32)            # prompt + the first generated token
     stream = torch.cuda.Stream()
     st = stream.cuda_stream
-    graph_mode = 2 if (args.tp_graph and world > 1) else (not args.no_graph and world == 1)
+    # TP steps are captured too (RCCL on its side stream joins the capture as a fork / join; --tp-eager keeps them eager)
+    graph_mode = (not args.no_graph) and not (world > 1 and args.tp_eager)
     gm.set_graph(graph_mode)
     ctx_cap = args.ctx + K + Wm + 2
     gm.decode_begin(tokens, seq_lens, bt, ctx_cap=ctx_cap, stream=st)
@@ -264,7 +269,15 @@ def main():
             gm.decode_step(st)
             gm.read_tokens(st)                                # greedy sample -> host every step, as the engine does
 
-    run(Wm)
+    try:
+        run(Wm)
+    except RuntimeError:
+        if world == 1 or not graph_mode:
+            raise
+        graph_mode = False                                    # capture of the collectives refused on this stack: eager TP steps
+        gm.set_graph(False)
+        gm.decode_begin(tokens, seq_lens, bt, ctx_cap=ctx_cap, stream=st)
+        run(Wm)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -296,6 +309,8 @@ def main():
                                f"batch={B}, prompt ctx {args.ctx} in paged KV (block 64), {K} decode steps",
                    "batch": B, "ctx_start": args.ctx + 1 + Wm, "ctx_end": args.ctx + Wm + K,
                    "parallelism": f"tp{world}", "graph": bool(graph_mode),
+                   **({"all_reduce": ("one-shot peer kernel" if args.p2p else "RCCL on a side stream"),
+                       "wire": ("bf16 (reference numerics)" if args.wire_bf16 else "f32")} if world > 1 else {}),
                    "kv_layout": ("paged K[NB,Hkv,D/8,64,8] V[NB,Hkv,D,64] bf16" if args.kv_layout == "paged"
                                  else "flash [NB,64,Hkv,128] bf16")},
         "step": {"algorithmic_bytes": int(step_bytes), "achieved_GBs": round(achieved, 1),
@@ -315,6 +330,13 @@ def main():
                 out["prefill"] = bench_prefill(gm, cfg, perm, blocks_per_seq)
             except Exception as e:                            # secondary number only
                 out["prefill"] = {"error": repr(e)}
+        if args.legs != "none" and world == 1 and not args.layers and B == 1:
+            import gc
+            del gm                                            # the legs build their own models
+            gc.collect(); torch.cuda.empty_cache()
+            import bench_legs
+            names = list(bench_legs.LEGS) if args.legs == "all" else [n for n in args.legs.split(",") if n in bench_legs.LEGS]
+            out["configs"] = bench_legs.run_legs(names)
         if args.parity != "off" and world == 1 and not args.layers:
             try:
                 out["parity"] = parity_leg(args.parity)

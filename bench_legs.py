@@ -1,0 +1,246 @@
+"""Secondary legs of bench.py: BASELINE.json configs[2..4] at their named shapes on ONE MI355X (the TP variants need the
+driver's multi-GPU run), each with algorithmic bytes, achieved GB/s, roofline fraction and hipGraph replay.
+
+  bf16_b32     configs[2]  Llama-3-8B bf16 safetensors host path, batch 32 ragged contexts U[256,4096]  (llama.rs:139-201)
+  gptq_qwen2   configs[3]  Qwen2-7B GPTQ 4-bit g128 (marlin_4bit arm), batch 1, ctx 4096               (qwen.rs:78-96)
+  mixtral_fp8  configs[4]  Mixtral-8x7B Q4_K GGUF, 8 experts top-2, fp8 KV cache, batch 1, ctx 4096    (quantized_llama.rs:56-123)
+Synthetic weights of the named architectures (no network for checkpoints).  A "step" = one greedy decode step of the whole
+model over the batch; inputs advance on the device (torch ops inside the captured graph for the 16-bit host layer, the
+library's own advance kernel for the GGUF one); every step reads its sampled tokens back, as the engine does."""
+import time
+from types import SimpleNamespace
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0
+
+
+def _dims(**kw):
+    d = dict(rms_eps=1e-5, max_seq=8192, block_size=64, qkv_bias=False, layer_norm=False, rotary_dim=0, kv_fp8=False)
+    d.update(kw)
+    return SimpleNamespace(**d)
+
+
+def llama3_8b_dense():
+    return _dims(hidden=4096, n_layers=32, n_heads=32, n_kv_heads=8, head_dim=128, intermediate=14336, vocab=128256, rope_theta=500000.0)
+
+
+def qwen2_7b():
+    """Qwen2-7B (public model card): hidden 3584, 28 layers, 28 heads, 4 kv heads, intermediate 18944, qkv bias"""
+    return _dims(hidden=3584, n_layers=28, n_heads=28, n_kv_heads=4, head_dim=128, intermediate=18944, vocab=152064,
+                 rope_theta=1000000.0, rms_eps=1e-6, qkv_bias=True)
+
+
+def _result(name, workload, B, steps, dt, weight_bytes, kv_bytes, extra=None):
+    step_bytes = weight_bytes + kv_bytes
+    gbs = step_bytes * steps / dt / 1e9
+    r = {"config": name, "workload": workload, "value": round(B * steps / dt, 1), "unit": "tokens/s", "batch": B, "steps": steps,
+         "ms_per_step": round(1e3 * dt / steps, 3), "algorithmic_bytes": int(step_bytes), "achieved_GBs": round(gbs, 1),
+         "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4), "roofline_tok_s_at_8TBs": round(B * HBM_PEAK_GBS * 1e9 / step_bytes, 1),
+         "graph": True}
+    if extra:
+        r.update(extra)
+    return r
+
+
+def _dense_graph_loop(gm, cfg, B, ctxs, steps, warmup, kv_elem):
+    """greedy decode loop of the 16-bit host layer replayed from ONE captured graph per step: the C++ layer's launches and the
+    next-step input preparation (prepare_decode, inputs.rs:389-423, as torch ops on the device)"""
+    import torch
+    bs = cfg.block_size
+    cap = int(max(ctxs)) + steps + warmup + 2
+    nblk = [-(-(int(c) + steps + warmup + 2) // bs) for c in ctxs]
+    maxb = max(nblk)
+    rng = np.random.default_rng(0)
+    ids = rng.permutation(sum(nblk))
+    bt_h = np.zeros((B, maxb), np.int32)
+    o = 0
+    for i, n in enumerate(nblk):
+        bt_h[i, :n] = ids[o:o + n]
+        o += n
+    dev = "cuda"
+    bt = torch.from_numpy(bt_h).to(dev)
+    tok = torch.randint(0, cfg.vocab, (B,), dtype=torch.int32, device=dev)
+    lens = torch.tensor(np.asarray(ctxs, np.int64), device=dev)
+    pos = lens - 1
+    slots = bt.long().gather(1, (pos // bs)[:, None])[:, 0] * bs + pos % bs
+    ctx = lens.to(torch.int32)
+    logits = torch.empty((B, cfg.vocab), dtype=torch.float32, device=dev)
+    host_tok = torch.empty((B,), dtype=torch.int32).pin_memory()
+    stream = torch.cuda.Stream()
+
+    def body(st):
+        gm.forward_device(tok, pos, slots, bt, ctx, cap, logits, st)
+        tok.copy_(logits.argmax(-1).to(torch.int32))
+        pos.add_(1)
+        ctx.add_(1)
+        slots.copy_(bt.long().gather(1, (pos // bs)[:, None])[:, 0] * bs + pos % bs)
+    with torch.cuda.stream(stream):
+        body(stream.cuda_stream)                                      # eager once: lazily-created scratch must not be born in a capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            body(torch.cuda.current_stream().cuda_stream)
+        for _ in range(warmup):
+            g.replay()
+            host_tok.copy_(tok, non_blocking=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+            host_tok.copy_(tok, non_blocking=False)                   # sampled tokens -> host every step
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    mean_ctx = float(np.mean(ctxs)) + 1 + warmup + (steps - 1) / 2.0
+    kv = B * (mean_ctx + 1) * 2 * cfg.n_layers * cfg.n_kv_heads * cfg.head_dim * kv_elem
+    return dt, kv
+
+
+def leg_bf16_b32(steps=16, warmup=3):
+    from candle_vllm_amd import dense_model as DM
+    cfg = llama3_8b_dense()
+    B = 32
+    ctxs = np.random.default_rng(4321).integers(256, 4097, B).tolist()
+    gm = DM.DenseLlama(cfg, max_batch=B, max_blocks_per_seq=80, kv_layout=DM.KV_PAGED)
+    gm.load_synthetic()
+    gm.alloc_kv_cache(B * 70 + 8)
+    dt, kv = _dense_graph_loop(gm, cfg, B, ctxs, steps, warmup, 2)
+    return _result("bf16_b32", "BASELINE configs[2]: Llama-3-8B bf16, batch 32, ragged contexts U[256,4096] in paged KV (block 64), "
+                   "16-bit host layer (dense_model.cpp)", B, steps, dt, gm.weight_bytes(), kv)
+
+
+def leg_gptq_qwen2(steps=32, warmup=4):
+    """Qwen2-7B GPTQ 4-bit, group 128: every projection through the marlin_4bit arm (checkpoint layout, Marlin-permuted scales
+    un-permuted by index arithmetic), lm_head / embedding 16-bit"""
+    import torch
+    from candle_vllm_amd import dense_model as DM
+    cfg = qwen2_7b()
+    gm = DM.DenseLlama(cfg, max_batch=1, max_blocks_per_seq=80, kv_layout=DM.KV_PAGED)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rng = np.random.default_rng(3)
+
+    def dev16(n, s=0.02, mean=0.0):
+        return (torch.randn(n, generator=g, device="cuda") * s + mean).to(torch.bfloat16)
+
+    def put(layer, name, t):
+        DM._check(DM.lib.mi355_dense_set_weight_dev(gm.h, layer, DM.W_SLOTS[name], t.data_ptr(), t.numel()), name)
+        torch.cuda.synchronize()
+    HD, KD, hid, I, group = cfg.n_heads * cfg.head_dim, cfg.n_kv_heads * cfg.head_dim, cfg.hidden, cfg.intermediate, 128
+    put(-1, "tok_embd", dev16(cfg.vocab * hid, 0.5)); put(-1, "output_norm", dev16(hid, 0.02, 1.0)); put(-1, "output", dev16(cfg.vocab * hid))
+    shapes = {"wq": (HD, hid), "wk": (KD, hid), "wv": (KD, hid), "wo": (hid, HD), "w1": (I, hid), "w3": (I, hid), "w2": (hid, I)}
+    packs = {}
+    wbytes = 2 * cfg.vocab * hid
+    for name, (n, k) in shapes.items():                               # one random packed tensor per shape, shared by the layers
+        if (n, k) not in packs:
+            packs[(n, k)] = (rng.integers(0, 2 ** 32, (k // 8, n), dtype=np.uint32),
+                             rng.uniform(0.002, 0.01, (k // group, n)).astype(np.float32))
+    for l in range(cfg.n_layers):
+        put(l, "attn_norm", dev16(hid, 0.02, 1.0)); put(l, "ffn_norm", dev16(hid, 0.02, 1.0))
+        put(l, "bq", dev16(HD)); put(l, "bk", dev16(KD)); put(l, "bv", dev16(KD))
+        for name, (n, k) in shapes.items():
+            qw, sc = packs[(n, k)]
+            gm.set_gptq(l, name, qw, sc, group)
+            wbytes += (k // 8) * n * 4 + (k // group) * n * 2
+    gm.alloc_kv_cache(80)
+    dt, kv = _dense_graph_loop(gm, cfg, 1, [4096], steps, warmup, 2)
+    return _result("gptq_qwen2", "BASELINE configs[3] on one GPU: Qwen2-7B GPTQ 4-bit (group 128, marlin_4bit arm), batch 1, ctx 4096 in "
+                   "paged KV (block 64); TP=2 needs the driver's multi-GPU run", 1, steps, dt, wbytes, kv)
+
+
+def leg_mixtral_fp8(steps=32, warmup=4):
+    """Mixtral-8x7B Q4_K GGUF shapes: device router + top-2 + expert mat-vecs + combine, fp8 (e4m3fn) KV cache"""
+    import ctypes
+    import torch
+    from candle_vllm_amd import model as M
+    cfg = M.ModelDims(hidden=4096, n_layers=32, n_heads=32, n_kv_heads=8, head_dim=128, intermediate=14336, vocab=32000,
+                      rope_theta=1000000.0, max_seq=8192, block_size=64)
+    cfg.n_expert, cfg.n_expert_used = 8, 2
+    K, Wm = steps, warmup
+    bps = -(-(4096 + K + Wm + 2) // cfg.block_size)
+    gm = M.GGUFLLaMa(cfg, max_batch=1, max_blocks_per_seq=bps, kv_layout=M.KV_PAGED_FP8)
+    lib = M.lib
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    rng = np.random.default_rng(5)
+    hid, I, H, Hkv, D = cfg.hidden, cfg.intermediate, cfg.n_heads, cfg.n_kv_heads, cfg.head_dim
+
+    def f32(layer, which, a):
+        a = np.ascontiguousarray(a, np.float32)
+        M._check(lib.mi355_llama_set_f32(gm.h, layer, which, a.ctypes.data, a.size), "set_f32")
+
+    def tiles(layer, which, n, k, t=M.GGML_Q4_K):
+        tl = M.random_tiles(t, n, k, "cuda", gen)
+        gm._keep.append(tl)
+        M._check(lib.mi355_llama_set_qweight_tiles(gm.h, layer, which, t, tl.data_ptr(), n, k), "set_tiles")
+        return (n // 16) * (k // 256) * (2304 if t == M.GGML_Q4_K else 3360)
+    emb = (torch.randn((cfg.vocab, hid), device="cuda", generator=gen) * 0.02).cpu().numpy()
+    f32(-1, M.W_TOK_EMBD, emb)
+    f32(-1, M.W_OUTPUT_NORM, 1.0 + rng.normal(0, 0.02, hid))
+    step_w = tiles(-1, M.W_OUTPUT, cfg.vocab, hid, M.GGML_Q6_K)
+    # one random expert per projection (native GGUF blocks on the host), shared by all experts and layers: the loader
+    # repacks and uploads every (layer, expert) copy, so the model is full size on the device
+    def native_q4k(n, k):
+        b = rng.integers(0, 256, (n, k // 256, 144), dtype=np.uint8)
+        b[:, :, 0:2] = np.array([2e-4], np.float16).view(np.uint8)
+        b[:, :, 2:4] = np.array([1.5e-3], np.float16).view(np.uint8)
+        return np.ascontiguousarray(b)
+    e_up, e_down = native_q4k(I, hid), native_q4k(hid, I)
+    for l in range(cfg.n_layers):
+        f32(l, M.W_ATTN_NORM, 1.0 + rng.normal(0, 0.02, hid))
+        f32(l, M.W_FFN_NORM, 1.0 + rng.normal(0, 0.02, hid))
+        f32(l, 12, rng.normal(0.0, 0.5, (cfg.n_expert, hid)))
+        step_w += tiles(l, M.W_WQ, H * D, hid) + tiles(l, M.W_WK, Hkv * D, hid) + tiles(l, M.W_WV, Hkv * D, hid) + tiles(l, M.W_WO, hid, H * D)
+        for e in range(cfg.n_expert):
+            for which, blk, n, k in ((M.W_W1, e_up, I, hid), (M.W_W3, e_up, I, hid), (M.W_W2, e_down, hid, I)):
+                M._check(lib.mi355_llama_set_moe_expert(gm.h, l, which, e, M.GGML_Q4_K, blk.ctypes.data, n, k), "set_moe_expert")
+        step_w += cfg.n_expert_used * 3 * I * (hid // 256) * 144      # a token touches top-2 of the 8 experts
+    num_blocks = bps + 8
+    gm.alloc_kv_cache(num_blocks)
+    n8 = lib.mi355_llama_kv_bytes_per_tensor(gm.h)
+    for l in range(cfg.n_layers):                                     # random e4m3 bytes (finite codes only)
+        for which in (0, 1):
+            t = torch.randint(0, 120, (n8,), dtype=torch.uint8, device="cuda", generator=gen)
+            M._check(lib.mi355_llama_kv_copy(gm.h, l, which, t.data_ptr(), n8, 1), "kv_copy")
+    perm = rng.permutation(num_blocks - 1) + 1
+    bt = perm[:bps].reshape(1, bps).astype(np.uint32)
+    stream = torch.cuda.Stream()
+    st = stream.cuda_stream
+    gm.set_graph(True)
+    gm.decode_begin(rng.integers(0, cfg.vocab, 1).astype(np.uint32), np.full(1, 4097, np.uint32), bt, ctx_cap=4096 + K + Wm + 2, stream=st)
+    for _ in range(Wm):
+        gm.decode_step(st); gm.read_tokens(st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        gm.decode_step(st); gm.read_tokens(st)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    mean_ctx = 4097 + Wm + (K - 1) / 2.0
+    kv = (mean_ctx + 1) * 2 * cfg.n_layers * Hkv * D * 1            # fp8: one byte per element
+    return _result("mixtral_fp8", "BASELINE configs[4] on one GPU: Mixtral-8x7B Q4_K GGUF shapes (8 experts, top-2, device router), fp8 "
+                   "e4m3 KV cache, batch 1, ctx 4096; TP=8 needs the driver's multi-GPU run", 1, K, dt, step_w, kv)
+
+
+LEGS = {"bf16_b32": leg_bf16_b32, "gptq_qwen2": leg_gptq_qwen2, "mixtral_fp8": leg_mixtral_fp8}
+
+
+def run_legs(names):
+    import gc
+    import torch
+    out = {}
+    for n in names:
+        t0 = time.time()
+        try:
+            out[n] = LEGS[n]()
+            out[n]["seconds"] = round(time.time() - t0, 1)
+        except Exception as e:                                        # a secondary leg must never sink the headline
+            out[n] = {"error": repr(e)}
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
+if __name__ == "__main__":
+    import json
+    import sys
+    names = sys.argv[1:] or list(LEGS)
+    print(json.dumps(run_legs(names)), flush=True)

@@ -202,8 +202,10 @@ class GGUFLLaMa:
         return self.weight_bytes * self.tp_world
 
     # ------------------------------------------------------------------ tensor parallel
-    def init_comm(self, dist):
-        """RCCL communicator for this rank: rank 0 draws the unique id, torch.distributed ships the 128 bytes."""
+    def init_comm(self, dist, p2p=False, wire_bf16=False):
+        """RCCL communicator for this rank: rank 0 draws the unique id, torch.distributed ships the 128 bytes.
+        p2p: also attach the one-shot peer-to-peer all-reduce (every rank's 64-byte IPC handle gathered through `dist`);
+        wire_bf16: the reference's all-reduce numerics (attention.rs:1003-1008)."""
         buf = np.zeros(128, np.uint8)
         if self.tp_rank == 0:
             _check(lib.mi355_comm_unique_id(buf.ctypes.data), "comm_unique_id")
@@ -211,6 +213,16 @@ class GGUFLLaMa:
         dist.broadcast(t, src=0)
         buf = np.ascontiguousarray(t.cpu().numpy())
         _check(lib.mi355_llama_init_comm(self.h, buf.ctypes.data), "init_comm")
+        comm = lib.mi355_llama_comm_handle(self.h)
+        if wire_bf16:
+            _check(lib.mi355_comm_set_options(comm, 1, 1), "comm_set_options")
+        if p2p:
+            h = ctypes.create_string_buffer(64)
+            _check(lib.mi355_comm_p2p_export(comm, ctypes.addressof(h)), "comm_p2p_export")
+            all_h = [None] * self.tp_world
+            dist.all_gather_object(all_h, bytes(h.raw))
+            blob = ctypes.create_string_buffer(b"".join(all_h), 64 * self.tp_world)
+            _check(lib.mi355_comm_p2p_attach(comm, ctypes.addressof(blob), self.tp_rank, self.tp_world), "comm_p2p_attach")
 
     def set_comm(self, handle):
         """attach a communicator the caller owns (mi355_comm_create / tp.TorchDistComm().handle)"""

@@ -46,7 +46,7 @@ def _fake_model_module(dist, calls):
                 dist.all_reduce(t)
                 assert int(t.item()) == self.tp_world
 
-        def init_comm(self, d):
+        def init_comm(self, d, p2p=False, wire_bf16=False):
             t = torch.full((128,), float(self.tp_rank == 0))
             d.broadcast(t, src=0)
             assert float(t.sum()) == 128.0
@@ -86,6 +86,9 @@ def _fake_model_module(dist, calls):
 
     m = types.ModuleType("candle_vllm_amd.model")
     m.GGUFLLaMa, m.lib, m.KV_PAGED, m.KV_FLASH = FakeGGUFLLaMa, FakeLib, 1, 0
+    real = types.SimpleNamespace(hidden=4096, n_layers=32, n_heads=32, n_kv_heads=8, head_dim=128, intermediate=14336, vocab=128256,
+                                 rms_eps=1e-5, rope_theta=500000.0, max_seq=8192, block_size=64)
+    m.ModelDims = types.SimpleNamespace(llama3_8b=lambda: real)
     return m
 
 
@@ -151,10 +154,11 @@ def test_bench_main_two_ranks_control_flow():
         assert key in j, key
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 2 and j["scaling"] == "strong"
     assert j["vs_baseline"] is None and j["higher_is_better"] is True and j["data"] == "synthetic"
-    assert j["config"]["parallelism"] == "tp2" and j["config"]["graph"] is False and "workload" in j["config"]
+    assert j["config"]["parallelism"] == "tp2" and j["config"]["graph"] is True and "workload" in j["config"]   # TP steps are captured by default
+    assert j["config"]["all_reduce"] == "RCCL on a side stream" and j["config"]["wire"] == "f32"
     assert "cpu_baseline" not in j and "batch32" not in j          # N = 1 legs
     assert j["value"] > 0 and abs(j["value"] - 1e3 / j["ms_per_step"]) / j["value"] < 1e-2      # batch 1: tokens/s = steps/s
     for calls in (calls0, calls1):
-        assert ("init_comm",) in calls and ("roofline",) in calls and ("graph", False) in calls
+        assert ("init_comm",) in calls and ("roofline",) in calls and ("graph", True) in calls
         assert calls.count(("step",)) == 5               # 2 warm-up + 3 timed, on every rank
     assert calls0[0] == ("create", 0, 2, 1) and calls1[0] == ("create", 1, 2, 1)
