@@ -50,6 +50,7 @@ def lib():
         L.orc_llama_set_attn_bf16.argtypes = [i32]
         L.orc_llama_set_trace_parts.argtypes = [vp, vp, vp, vp, vp]
         L.orc_llama_prefill.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
+        L.orc_bf16_gemv.argtypes = [vp, i32, i32, vp, vp]
         L.orc_num_threads.restype = i32
         L.orc_set_num_threads.argtypes = [i32]
         _lib = L
@@ -62,6 +63,15 @@ def qmatmul(x, blocks, ggml_type, o2):
     N, K, T = b.shape[0], b.shape[1] * 256, x.shape[0]
     y = np.empty((T, N), np.float32)
     lib().orc_qmatmul(b.ctypes.data, ggml_type, N, K, x.ctypes.data, T, y.ctypes.data, int(o2))
+    return y
+
+
+def bf16_gemv(w_bits, x):
+    """y = W . x with W [N,K] bf16 bit patterns (uint16), x f32 [K]; f32 accumulation (AVX2 + OpenMP)"""
+    w = np.ascontiguousarray(w_bits, np.uint16)
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty(w.shape[0], np.float32)
+    lib().orc_bf16_gemv(w.ctypes.data, w.shape[0], w.shape[1], x.ctypes.data, y.ctypes.data)
     return y
 
 

@@ -740,6 +740,34 @@ void orc_llama_prefill(void* mp, const uint32_t* tokens, const int64_t* position
     free(xs); free(xn); free(q); free(k); free(v); free(att); free(g); free(u); free(tmp);
 }
 
+/* y[N] = W[N,K] (bf16 bit patterns, row-major) . x[K] (f32), f32 accumulation: the mat-vec a 16-bit `Linear::forward`
+ * (src/openai/models/linear.rs:124-172) runs on candle's CPU backend for one decode token [EXT: candle converts bf16 to f32
+ * lanes and accumulates in f32].  Used by bench.py's configs[0] CPU baseline (StableLM-3B bf16 shapes, stable_lm.rs:158-212). */
+void orc_bf16_gemv(const uint16_t* w, int N, int K, const float* x, float* y) {
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; ++n) {
+        const uint16_t* r = w + (size_t)n * K;
+        float acc = 0.f;
+        int k = 0;
+#if defined(__AVX2__) && defined(__FMA__)
+        __m256 a0 = _mm256_setzero_ps(), a1 = _mm256_setzero_ps();
+        for (; k + 16 <= K; k += 16) {
+            const __m256i lo = _mm256_slli_epi32(_mm256_cvtepu16_epi32(_mm_loadu_si128((const __m128i*)(r + k))), 16);
+            const __m256i hi = _mm256_slli_epi32(_mm256_cvtepu16_epi32(_mm_loadu_si128((const __m128i*)(r + k + 8))), 16);
+            a0 = _mm256_fmadd_ps(_mm256_castsi256_ps(lo), _mm256_loadu_ps(x + k), a0);
+            a1 = _mm256_fmadd_ps(_mm256_castsi256_ps(hi), _mm256_loadu_ps(x + k + 8), a1);
+        }
+        a0 = _mm256_add_ps(a0, a1);
+        __m128 s = _mm_add_ps(_mm256_castps256_ps128(a0), _mm256_extractf128_ps(a0, 1));
+        s = _mm_add_ps(s, _mm_movehl_ps(s, s));
+        s = _mm_add_ss(s, _mm_shuffle_ps(s, s, 1));
+        acc = _mm_cvtss_f32(s);
+#endif
+        for (; k < K; ++k) acc += bf16_to_f32(r[k]) * x[k];
+        y[n] = acc;
+    }
+}
+
 /* bench.py's cpu_baseline picks the thread count that gives the fastest step on the host it runs on */
 void orc_set_num_threads(int n) {
 #ifdef _OPENMP
