@@ -20,15 +20,25 @@ __global__ void __launch_bounds__(256) moe_route_kernel(int32_t* __restrict__ id
         for (int i = threadIdx.x; i < hidden; i += blockDim.x) ss += xr[i] * xr[i];
         inv = rsqrtf(block_sum(ss, red) / (float)hidden + eps);
     }
-    for (int e = 0; e < E; ++e) {                               // E <= 256 experts, each a block-wide dot product
-        float acc = 0.f;
+    // router logits: one WAVE per expert (e = wave, wave + 4, ...), 16-byte loads, all of a lane's loads independent --
+    // the first version walked the experts one after the other through block-wide reductions (97 us per launch at
+    // Mixtral's 8 x 4096: a chain of dependent load latencies)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = wave; e < E; e += 4) {
         const float* g = gate + (size_t)e * hidden;
-        for (int i = threadIdx.x; i < hidden; i += blockDim.x) {
-            const float xv = norm_w ? xr[i] * inv * norm_w[i] : xr[i];
-            acc = fmaf(xv, g[i], acc);
+        float acc = 0.f;
+        if ((hidden & 3) == 0) {
+            for (int i = 4 * lane; i < hidden; i += 256) {
+                const float4 xv = *reinterpret_cast<const float4*>(xr + i), gv = *reinterpret_cast<const float4*>(g + i);
+                float4 nv = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (norm_w) nv = *reinterpret_cast<const float4*>(norm_w + i);
+                acc = fmaf(xv.x * inv * nv.x, gv.x, fmaf(xv.y * inv * nv.y, gv.y, fmaf(xv.z * inv * nv.z, gv.z, fmaf(xv.w * inv * nv.w, gv.w, acc))));
+            }
+        } else {
+            for (int i = lane; i < hidden; i += 64) acc = fmaf(norm_w ? xr[i] * inv * norm_w[i] : xr[i], g[i], acc);
         }
-        acc = block_sum(acc, red);
-        if (threadIdx.x == 0) s_logit[e] = acc;
+        acc = wave_sum(acc);
+        if (lane == 0) s_logit[e] = acc;
     }
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -17,13 +17,13 @@ cd /tmp && export TMPDIR=/tmp
 cd $R
 echo "$SHA" > $OUT/${RN}_commit.txt
 timeout 900 python bench.py > $OUT/${RN}_bench_default.json 2> $OUT/bench_default.err
-B1="python bench.py --no-batch32 --no-cpu-baseline --parity off"
+B1="python bench.py --no-batch32 --no-cpu-baseline --parity off --legs none"
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/rp_b1 --output-format csv -- $B1 > $OUT/${RN}_bench_b1_under_rocprof.json 2> $OUT/rp_b1.err
 (echo "# commit $SHA : rocprofv3 --kernel-trace --stats -- $B1"; cat $(find /tmp/rp_b1 -name "*kernel_stats.csv" | head -1)) > $OUT/${RN}_bench_b1_kernel_stats.csv
-B32="python bench.py --batch 32 --steps 16 --warmup 4 --no-cpu-baseline --no-batch32 --parity off"
+B32="python bench.py --batch 32 --steps 16 --warmup 4 --no-cpu-baseline --no-batch32 --parity off --legs none"
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/rp_b32 --output-format csv -- $B32 > $OUT/${RN}_bench_b32_under_rocprof.json 2> $OUT/rp_b32.err
 (echo "# commit $SHA : rocprofv3 --kernel-trace --stats -- $B32"; cat $(find /tmp/rp_b32 -name "*kernel_stats.csv" | head -1)) > $OUT/${RN}_bench_b32_kernel_stats.csv
-PMC="python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-batch32 --no-graph --parity off"
+PMC="python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-batch32 --no-graph --parity off --legs none"
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_f --output-format csv -- $PMC > $OUT/pmc_f.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_w --output-format csv -- $PMC > $OUT/pmc_w.log 2>&1
 python tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w $OUT/${RN}_pmc_traffic.json $SHA
@@ -33,3 +33,10 @@ head -c 1800 $OUT/${RN}_bench_default.json
 head -14 $OUT/${RN}_bench_b1_kernel_stats.csv | cut -c1-150
 head -10 $OUT/${RN}_bench_b32_kernel_stats.csv | cut -c1-150
 head -12 $OUT/pmc_sq_summary.txt | cut -c1-400
+# 6. prompt-step GEMM: kernel stats + MFMA-busy
+PF="python tests/bench_prefill.py"
+PF_T=2048 PF_MODES=1 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/rp_pf --output-format csv -- $PF > $OUT/pf_stats.log 2>&1
+(echo "# commit $SHA : PF_T=2048 PF_MODES=1 rocprofv3 --kernel-trace --stats -- $PF"; cat $(find /tmp/rp_pf -name "*kernel_stats.csv" | head -1)) > $OUT/${RN}_prefill_kernel_stats.csv
+PF_T=2048 PF_MODES=1 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d /tmp/pmc_pf --output-format csv -- $PF > $OUT/pf_pmc.log 2>&1
+python tools/pmc_summary.py /tmp/pmc_pf $OUT/${RN}_prefill_pmc_sq.json $SHA > $OUT/pf_pmc_summary.txt 2>&1
+grep prefill $OUT/pf_stats.log
