@@ -5,6 +5,7 @@
 // and kv counts, then kvs {string key, u32 type, value}, tensor infos {string name, u32 n_dims, u64 dims[] (fastest
 // first), u32 ggml type, u64 offset}, then padding to `general.alignment` (default 32) and the data section.  [EXT: the
 // published GGUF specification]
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -247,6 +248,85 @@ int64_t mi355_gguf_tensor_shard(void* h, int32_t i, int32_t dim, int32_t rank, i
         if (out_cap < (int64_t)n) return -3;
         for (uint64_t r = 0; r < rows; ++r) memcpy(dst + r * seg, src + r * row_bytes + (uint64_t)rank * seg, seg);
     }
+    return (int64_t)n;
+}
+
+/* The reference's fallback for a dim-1 shard that cuts a quantisation block (`get_sharded_no_shape`,
+ * layers/quantized_var_builder.rs:234-269): dequantise the WHOLE tensor to f16 (`dequantize_f16`: f32 arithmetic of the block
+ * format, one rounding to f16), narrow columns [rank*c, (rank+1)*c), re-quantise -- to Q8_0 when c is not a multiple of the
+ * source block (256), which is the only case that reaches this function here.  Q8_0 as ggml's `quantize_row_q8_0` [EXT]:
+ * d = amax / 127 in f32, q = roundf(x / d) with the UNROUNDED d, stored d rounded to f16.
+ * out: rows x (c / 32) blocks of 34 bytes.  Returns the byte count (out may be NULL); -1 bad argument / unsupported source
+ * type (Q4_K and Q6_K are restated here) / c % 32 != 0; -3 out_cap too small. */
+int64_t mi355_gguf_tensor_shard_q8_0(void* h, int32_t i, int32_t rank, int32_t world, void* out, int64_t out_cap) {
+#pragma clang fp contract(off)      // candle's dequantisation rounds the product and the difference separately (no fused multiply-add)
+    Gguf* g = G(h);
+    if (!g || i < 0 || i >= (int)g->tensors.size() || world < 1 || rank < 0 || rank >= world) return -1;
+    const TInfo& t = g->tensors[i];
+    if (t.n_dims != 2 || (t.type != 12 && t.type != 14)) return -1;
+    const uint64_t cols = t.dims[0], rows = t.dims[1];
+    if (cols % (uint64_t)world) return -1;
+    const uint64_t c = cols / world;
+    if (c % 32) return -1;
+    const uint64_t n = rows * (c / 32) * 34;
+    if (!out) return (int64_t)n;
+    if (out_cap < (int64_t)n) return -3;
+    const uint64_t bb = t.type == 12 ? 144 : 210, nb = cols / 256;
+    const uint8_t* src = g->base + g->data_off + t.offset;
+    uint8_t* dst = static_cast<uint8_t*>(out);
+    auto f16 = [](const uint8_t* p) { uint16_t u; memcpy(&u, p, 2); _Float16 v; memcpy(&v, &u, 2); return (float)v; };
+    try {
+        std::vector<float> row(cols);
+#pragma omp parallel for schedule(static) firstprivate(row)
+        for (int64_t r = 0; r < (int64_t)rows; ++r) {
+            const uint8_t* rp = src + (uint64_t)r * nb * bb;
+            for (uint64_t b = 0; b < nb; ++b) {                       // ggml dequantize_row_q4_K / q6_K, f32 arithmetic
+                const uint8_t* blk = rp + b * bb;
+                float* y = row.data() + b * 256;
+                if (t.type == 12) {
+                    const float d = f16(blk), dmin = f16(blk + 2);
+                    const uint8_t* sc = blk + 4;
+                    const uint8_t* q = blk + 16;
+                    int is = 0;
+                    for (int j = 0; j < 256; j += 64, q += 32, is += 2) {
+                        uint8_t s1, m1, s2, m2;
+                        auto sm = [&](int jj, uint8_t& S, uint8_t& M) {
+                            if (jj < 4) { S = sc[jj] & 63; M = sc[jj + 4] & 63; }
+                            else { S = (sc[jj + 4] & 0xF) | ((sc[jj - 4] >> 6) << 4); M = (sc[jj + 4] >> 4) | ((sc[jj] >> 6) << 4); }
+                        };
+                        sm(is, s1, m1); sm(is + 1, s2, m2);
+                        const float d1 = d * s1, mm1 = dmin * m1, d2 = d * s2, mm2 = dmin * m2;
+                        for (int l = 0; l < 32; ++l) y[j + l] = d1 * (q[l] & 0xF) - mm1;
+                        for (int l = 0; l < 32; ++l) y[j + 32 + l] = d2 * (q[l] >> 4) - mm2;
+                    }
+                } else {
+                    const uint8_t *ql = blk, *qh = blk + 128;
+                    const int8_t* sc = reinterpret_cast<const int8_t*>(blk + 192);
+                    const float d = f16(blk + 208);
+                    for (int nh = 0; nh < 2; ++nh, y += 128, ql += 64, qh += 32, sc += 8)
+                        for (int l = 0; l < 32; ++l) {
+                            const int isx = l / 16;
+                            const int q1 = (int)((ql[l] & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32;
+                            const int q2 = (int)((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32;
+                            const int q3 = (int)((ql[l] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32;
+                            const int q4 = (int)((ql[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32;
+                            y[l] = d * sc[isx] * q1; y[l + 32] = d * sc[isx + 2] * q2;
+                            y[l + 64] = d * sc[isx + 4] * q3; y[l + 96] = d * sc[isx + 6] * q4;
+                        }
+                }
+            }
+            uint8_t* orow = dst + (uint64_t)r * (c / 32) * 34;
+            const float* x = row.data() + (uint64_t)rank * c;
+            for (uint64_t b = 0; b < c / 32; ++b) {
+                float v[32], amax = 0.f;
+                for (int j = 0; j < 32; ++j) { v[j] = (float)(_Float16)x[b * 32 + j]; amax = fmaxf(amax, fabsf(v[j])); }   // dequantize_f16: one rounding
+                const float d = amax / 127.f, id = d != 0.f ? 1.f / d : 0.f;
+                const _Float16 dh = (_Float16)d;
+                memcpy(orow + b * 34, &dh, 2);
+                for (int j = 0; j < 32; ++j) orow[b * 34 + 2 + j] = (uint8_t)(int8_t)roundf(v[j] * id);
+            }
+        }
+    } catch (...) { return -1; }
     return (int64_t)n;
 }
 

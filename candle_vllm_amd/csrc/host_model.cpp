@@ -475,6 +475,17 @@ extern "C" int mi355_llama_set_qweight(void* mp, int32_t layer, int32_t which, i
     Model* m = static_cast<Model*>(mp);
     QW* slot = m ? qw_slot(m, layer, which) : nullptr;
     if (!slot) return (int)hipErrorInvalidValue;
+    if (ggml_type == MI355_GGML_Q8_0) {
+        // a re-quantised tensor-parallel shard (quantized_var_builder.rs:234-269): native Q8_0 blocks, used as they are; only
+        // the row-parallel projections can need it (o_proj / down_proj: plain epilogues, no fused norm)
+        if ((which != MI355_W_WO && which != MI355_W_W2) || n_rows <= 0 || k <= 0 || (k % 32) || !native_host) return (int)hipErrorInvalidValue;
+        const size_t nb = (size_t)n_rows * (k / 32) * 34;
+        void* dev8 = nullptr;
+        HCHECK(hipMalloc(&dev8, nb));
+        HCHECK(hipMemcpy(dev8, native_host, nb, hipMemcpyHostToDevice));
+        drop_graph(m);
+        return set_qw(*slot, ggml_type, dev8, n_rows, k, true);
+    }
     const int64_t n = mi355_qweight_repacked_size(ggml_type, n_rows, k);
     if (n < 0) return (int)hipErrorInvalidValue;
     std::vector<uint8_t> tiles((size_t)n);
@@ -861,7 +872,11 @@ int load_gguf_impl(const char* path, int32_t max_batch, int32_t max_blocks_per_s
             if (dd[0] != rows || dd[1] != cols || dd[2] != 1 || dd[3] != 1) return (int)hipErrorInvalidValue;
             if (dim == 0 && world > 1) { if (rows % world) return (int)hipErrorInvalidValue; rows /= world; }
             if (dim == 1 && world > 1) { if (cols % world) return (int)hipErrorInvalidValue; cols /= world; }
-            if (cols % 256) return dim == 1 && world > 1 ? (int)hipErrorNotSupported : (int)hipErrorInvalidValue;   // re-quantising fallback: not built
+            if (cols % 256) {
+                // a dim-1 shard that cuts a k-quant block is re-quantised to Q8_0 (quantized_var_builder.rs:234-269): 32-wide blocks
+                if (dim == 1 && world > 1) return (cols % 32) ? (int)hipErrorNotSupported : 0;
+                return (int)hipErrorInvalidValue;
+            }
             // whole 16-row tiles are required only where the fused QKV epilogue needs them (mi355_qmatmul_fused checks the
             // same); everywhere else the last tile may be ragged (odd vocabularies)
             const bool qkv = name.find("attn_q.") != std::string::npos || name.find("attn_k.") != std::string::npos ||
@@ -920,6 +935,15 @@ int load_gguf_impl(const char* path, int32_t max_batch, int32_t max_blocks_per_s
         if (dim < 0 || world <= 1)
             return mi355_llama_set_qweight(m, layer, which, t, mi355_gguf_tensor_data(g, i), (int32_t)dd[0], (int32_t)dd[1]);
         const int64_t bytes = mi355_gguf_tensor_shard(g, i, dim, rank, world, nullptr, 0);
+        if (bytes == -2 && dim == 1 && (which == MI355_W_WO || which == MI355_W_W2)) {
+            // the shard cuts a k-quant block: the reference's dequantise -> narrow -> re-quantise-to-Q8_0 fallback
+            // (quantized_var_builder.rs:234-269)
+            const int64_t b8 = mi355_gguf_tensor_shard_q8_0(g, i, rank, world, nullptr, 0);
+            if (b8 < 0) return (int)hipErrorNotSupported;
+            std::vector<uint8_t> shard8((size_t)b8);
+            if (mi355_gguf_tensor_shard_q8_0(g, i, rank, world, shard8.data(), b8) != b8) return (int)hipErrorInvalidValue;
+            return mi355_llama_set_qweight(m, layer, which, MI355_GGML_Q8_0, shard8.data(), (int32_t)dd[0], (int32_t)(dd[1] / world));
+        }
         if (bytes < 0) return bytes == -2 ? (int)hipErrorNotSupported : (int)hipErrorInvalidValue;
         std::vector<uint8_t> shard((size_t)bytes);
         if (mi355_gguf_tensor_shard(g, i, dim, rank, world, shard.data(), bytes) != bytes) return (int)hipErrorInvalidValue;

@@ -1579,7 +1579,65 @@ static int qmm_launch_bt(QmmArgs& a, int R, int wt, int n_wg, int NW, hipStream_
 }
 
 // Run one fused quantised mat-mul over batch rows [0,B) in M-tiles of 8 batch entries.
+// ================================================================================================
+// Q8_0 arm: tensor-parallel shards the reference re-quantises (dim-1 shards that cut a 256-wide k-quant block are
+// dequantised, narrowed and re-quantised to Q8_0 -- layers/quantized_var_builder.rs:234-269).  Native blocks
+// [rows][K/32][f16 d | 32 x i8], no repack; one wave per output row and up to 8 tokens, lanes stride over the blocks.
+// A fallback for odd shapes (o_proj / down_proj of a model whose k / W is not a multiple of 256), not a tuned path.
+__global__ void __launch_bounds__(64) q8_0_matmul_kernel(const QmmArgs a) {
+    const int row = blockIdx.x, t0 = blockIdx.y * 8, lane = threadIdx.x;
+    const int nt = min(8, a.B - t0), nblk = a.K / 32;
+    const uint8_t* wr = a.seg[0].w + (size_t)row * nblk * 34;
+    float acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = 0.f;
+    for (int b = lane; b < nblk; b += 64) {
+        const uint16_t* p16 = reinterpret_cast<const uint16_t*>(wr + (size_t)b * 34);      // 34-byte blocks: 2-byte aligned
+        const float d = f16_bits_to_f32(p16[0]);
+        float w[32];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint16_t u = p16[1 + j];
+            w[2 * j] = d * (float)(int8_t)(u & 0xFF);
+            w[2 * j + 1] = d * (float)(int8_t)(u >> 8);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (t >= nt) break;
+            float s = 0.f;
+            if (a.x_dtype == MI355_DTYPE_BF16) {
+                const uint16_t* xp = static_cast<const uint16_t*>(a.x) + (size_t)(t0 + t) * a.ldx + (size_t)b * 32;
+#pragma unroll
+                for (int j = 0; j < 32; ++j) s = fmaf(bf16_to_f32(xp[j]), w[j], s);
+            } else {
+                const float* xp = static_cast<const float*>(a.x) + (size_t)(t0 + t) * a.ldx + (size_t)b * 32;
+#pragma unroll
+                for (int j = 0; j < 32; ++j) s = fmaf(xp[j], w[j], s);
+            }
+            acc[t] += s;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (t >= nt) break;
+        float v = wave_sum(acc[t]);
+        if (lane == 0) {
+            if (a.bias) v += a.bias[row];
+            const size_t o = (size_t)(t0 + t) * a.ldo + row;
+            a.out[o] = (a.epi == MI355_EPI_RESID) ? a.resid[o] + v : v;
+        }
+    }
+}
+static int q8_0_launch(const QmmArgs& a, hipStream_t st) {
+    if (a.nseg != 1 || a.norm_w || a.moe_expert || (a.epi != MI355_EPI_STORE && a.epi != MI355_EPI_RESID) || (a.K % 32) || a.K <= 0)
+        return (int)hipErrorInvalidValue;
+    if (a.B == 0) return 0;
+    hipLaunchKernelGGL(q8_0_matmul_kernel, dim3(a.seg[0].n_rows, (a.B + 7) / 8), dim3(64), 0, st, a);
+    return (int)hipGetLastError();
+}
+
 int mi355_qmm_launch(QmmArgs a, int64_t stream) {
+    if (a.nseg >= 1 && a.seg[0].type == MI355_GGML_Q8_0) return q8_0_launch(a, to_stream(stream));
     if (a.K <= 0 || (a.K % 256) || a.B < 0 || a.nseg < 1 || a.nseg > 3) return (int)hipErrorInvalidValue;
     if (a.B == 0) return 0;
     for (int s = 0; s < a.nseg; ++s)

@@ -365,9 +365,13 @@ class QMatMul:
     def __init__(self, blocks_native: np.ndarray, ggml_type: int, device):
         self.ggml_type = ggml_type
         self.n = blocks_native.shape[0]
-        self.k = blocks_native.shape[1] * 256
         self.native = torch.from_numpy(np.ascontiguousarray(blocks_native)).to(device)
-        self.tiles = torch.from_numpy(repack_qweight(blocks_native, ggml_type, self.n, self.k)).to(device)
+        if ggml_type == 8:                                  # GGML_Q8_0: a re-quantised TP shard, native 34-byte blocks, no repack
+            self.k = blocks_native.shape[1] * 32
+            self.tiles = self.native
+        else:
+            self.k = blocks_native.shape[1] * 256
+            self.tiles = torch.from_numpy(repack_qweight(blocks_native, ggml_type, self.n, self.k)).to(device)
 
     def forward(self, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         if x.dtype != torch.float32:

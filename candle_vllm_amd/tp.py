@@ -41,11 +41,17 @@ def _rows(tw, rank, world):
     return (t, np.ascontiguousarray(b[rank * c:(rank + 1) * c]))
 
 
-def _cols(tw, rank, world):
+def _cols(tw, rank, world, requant=None):
+    """column (k) shard: a k-block range when the blocks divide; else the reference's fallback -- dequantise, narrow,
+    re-quantise to Q8_0 (quantized_var_builder.rs:234-269) -- through `requant(blocks, type, rank, world)`, which the caller
+    supplies (the test-side restatement oracle.kquants.requantize_shard_q8_0; the product does it in
+    mi355_gguf_tensor_shard_q8_0 when it loads a file)"""
     t, b = tw
     nb = b.shape[1]
     if nb % world:
-        raise ValueError("column shard is not k-block aligned (Q8_0 re-quantisation fallback not built)")
+        if requant is None or (nb * 256) % (32 * world):
+            raise ValueError("column shard is not k-block aligned and no re-quantiser was supplied")
+        return (8, requant(b, t, rank, world))                       # GGML_Q8_0
     c = nb // world
     return (t, np.ascontiguousarray(b[:, rank * c:(rank + 1) * c]))
 
@@ -62,7 +68,7 @@ def shard_config(cfg, rank, world):
     return local
 
 
-def shard_weights(W, cfg, rank, world):
+def shard_weights(W, cfg, rank, world, requant=None):
     """W: oracle.llama.make_weights dict (global) -> this rank's dict.  tok_embd and the norm vectors are
     replicated."""
     _, kv_rank, kv_world = kv_head_shard(cfg.n_kv_heads, rank, world)
@@ -72,14 +78,14 @@ def shard_weights(W, cfg, rank, world):
         nl = {"attn_norm": lw["attn_norm"], "ffn_norm": lw["ffn_norm"],
               "wq": _rows(lw["wq"], rank, world),
               "wk": _rows(lw["wk"], kv_rank, kv_world), "wv": _rows(lw["wv"], kv_rank, kv_world),
-              "wo": _cols(lw["wo"], rank, world)}
+              "wo": _cols(lw["wo"], rank, world, requant)}
         if "experts" in lw:
             # Mixtral GGUF: router and experts are loaded whole on every rank (quantized_llama.rs:344-365) -- the
             # MoE block is replicated, attention and the lm_head carry the parallelism
             nl["gate_inp"], nl["experts"] = lw["gate_inp"], lw["experts"]
         else:
             nl.update({"w1": _rows(lw["w1"], rank, world), "w3": _rows(lw["w3"], rank, world),
-                       "w2": _cols(lw["w2"], rank, world)})
+                       "w2": _cols(lw["w2"], rank, world, requant)})
         out["layers"].append(nl)
     return out
 

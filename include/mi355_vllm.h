@@ -39,6 +39,7 @@ extern "C" {
 /* ggml tensor type ids (GGUF) */
 #define MI355_GGML_Q4_K 12
 #define MI355_GGML_Q6_K 14
+#define MI355_GGML_Q8_0 8      /* TP shards the reference re-quantises (quantized_var_builder.rs:234-269); native blocks, no repack */
 /* swap directions */
 #define MI355_SWAP_H2D 0
 #define MI355_SWAP_D2H 1
@@ -628,8 +629,12 @@ const void* mi355_gguf_tensor_data(void* gguf, int32_t i);
  * `Content::tensor_shard` (quantized_var_builder.rs:135-183): dim 0 = rows [rank*R/W, (rank+1)*R/W) (contiguous),
  * dim 1 = the same block range of every row.  Host only, no dequantisation.  Returns the shard's bytes (out == NULL
  * sizes the buffer); -1 bad argument / dimension does not divide; -2 a dim-1 shard would cut a quantisation block (the
- * reference's dequantise -> narrow -> re-quantise-to-Q8_0 fallback, :234-269, is not built); -3 out_cap too small. */
+ * reference's dequantise -> narrow -> re-quantise fallback, :234-269, is mi355_gguf_tensor_shard_q8_0 below); -3 out_cap too small. */
 int64_t mi355_gguf_tensor_shard(void* gguf, int32_t i, int32_t dim, int32_t rank, int32_t world, void* out, int64_t out_cap);
+/* the fallback of `get_sharded_no_shape` (quantized_var_builder.rs:234-269) for a dim-1 shard that cuts a quantisation block:
+ * dequantise to f16, narrow to this rank's columns, re-quantise to Q8_0 (f16 d, 32 x i8 per 34-byte block); the mat-mul of such
+ * a tensor goes through the Q8_0 arm of mi355_qmatmul_fused (MI355_GGML_Q8_0, native blocks, no repack).  Q4_K / Q6_K sources */
+int64_t mi355_gguf_tensor_shard_q8_0(void* gguf, int32_t tensor, int32_t rank, int32_t world, void* out, int64_t out_cap);
 /* GGUFLLaMa::from_gguf (quantized_llama.rs:203-420): config from the metadata, every tensor handed to the model
  * (matrices Q4_K / Q6_K re-tiled, token_embd dequantised on the device, norms F32).  *model_out = mi355_llama handle. */
 int mi355_llama_load_gguf(const char* path, int32_t max_batch, int32_t max_blocks_per_seq, int32_t block_size,

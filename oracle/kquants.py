@@ -193,6 +193,32 @@ def quantize_q8_0(w):
     return out
 
 
+def quantize_q8_0_ggml(w):
+    """ggml `quantize_row_q8_0` [EXT] as candle's `BlockQ8_0::from_float` runs it when a tensor-parallel shard is re-quantised
+    (layers/quantized_var_builder.rs:234-269): d = amax / 127 in f32, q = roundf(x * (1/d)) with the UNROUNDED d (half away
+    from zero), the stored d rounded to f16."""
+    w = np.asarray(w, np.float32)
+    lead = w.shape[:-1]
+    x = w.reshape(lead + (w.shape[-1] // 32, 32))
+    d = (np.abs(x).max(-1) / np.float32(127.0)).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        idv = np.where(d != 0, np.float32(1.0) / d, np.float32(0.0)).astype(np.float32)
+    v = (x * idv[..., None]).astype(np.float32)
+    q = (np.sign(v) * np.floor(np.abs(v) + np.float32(0.5))).astype(np.int8)          # roundf
+    out = np.zeros(lead + (x.shape[-2], Q8_0_BLOCK_BYTES), np.uint8)
+    out[..., 0:2] = d.astype(np.float16)[..., None].view(np.uint8)
+    out[..., 2:34] = q.view(np.uint8)
+    return out
+
+
+def requantize_shard_q8_0(blocks, ggml_type, rank, world):
+    """`get_sharded_no_shape`'s fallback (quantized_var_builder.rs:234-269) for a dim-1 shard that cuts a k-quant block:
+    dequantize_f16 (f32 arithmetic, one rounding to f16) -> narrow to this rank's columns -> Q8_0.  blocks [N, K/256, bytes]."""
+    w = dequantize(blocks, ggml_type).astype(np.float16).astype(np.float32)
+    c = w.shape[-1] // world
+    return quantize_q8_0_ggml(np.ascontiguousarray(w[:, rank * c:(rank + 1) * c]))
+
+
 # --------------------------------------------------------------------------- Q8_K (CPU activation format, oracle O2)
 def quantize_q8_k(x):
     """x: f32 [..., K] -> (d f32 [..., nb], q int8 [..., nb, 256], bsums int16 [..., nb, 16]).

@@ -147,6 +147,49 @@ def test_tensor_shard_error_codes(lib, tmp_path):
         lib.mi355_gguf_close(g)
 
 
+def test_requantised_shard_equals_the_restated_fallback_bit_for_bit(lib, tmp_path):
+    """a dim-1 shard that cuts a k-quant block: `get_sharded_no_shape`'s fallback (quantized_var_builder.rs:234-269) --
+    dequantize_f16 -> narrow -> Q8_0 -- as the loader does it on the host (mi355_gguf_tensor_shard_q8_0) against the numpy
+    restatement, byte for byte; Q4_K and Q6_K sources; and the shard plan of candle_vllm_amd/tp.py uses the same bytes"""
+    from candle_vllm_amd import tp
+    cfg = llama.LlamaConfig.tiny(hidden=256, n_heads=6, n_kv_heads=2, head_dim=128, intermediate=768, vocab=384)
+    W = llama.make_weights(cfg, seed=5)                            # wo [256, 768], w2 [256, 768]: 384 columns per rank of 2
+    path = os.path.join(tmp_path, "q8.gguf")
+    GW.llama_to_gguf(path, cfg, W)
+    g = lib.mi355_gguf_open(path.encode())
+    assert g
+    try:
+        seen = set()
+        for l in range(cfg.n_layers):
+            for name, key in (("attn_output", "wo"), ("ffn_down", "w2")):
+                i = lib.mi355_gguf_find(g, f"blk.{l}.{name}.weight".encode())
+                t, blocks = W["layers"][l][key]
+                seen.add(t)
+                assert lib.mi355_gguf_tensor_shard(g, i, 1, 0, 2, None, 0) == -2
+                for rank in (0, 1):
+                    n = lib.mi355_gguf_tensor_shard_q8_0(g, i, rank, 2, None, 0)
+                    assert n == 256 * (384 // 32) * 34
+                    out = np.empty(n, np.uint8)
+                    assert lib.mi355_gguf_tensor_shard_q8_0(g, i, rank, 2, out.ctypes.data, n) == n
+                    want = kq.requantize_shard_q8_0(blocks, t, rank, 2)
+                    assert np.array_equal(out.reshape(want.shape), want), (l, name, rank)
+                    st, sb = tp._cols((t, blocks), rank, 2, kq.requantize_shard_q8_0)
+                    assert st == kq.GGML_Q8_0 and np.array_equal(sb, want)
+                assert lib.mi355_gguf_tensor_shard_q8_0(g, i, 0, 2, out.ctypes.data, n - 1) == -3
+        assert seen == {kq.GGML_Q4_K, kq.GGML_Q6_K}                 # the Q4_K_M mixture puts both types on these tensors
+        i_q = lib.mi355_gguf_find(g, b"blk.0.attn_q.weight")
+        assert lib.mi355_gguf_tensor_shard_q8_0(g, i_q, 2, 2, None, 0) == -1       # rank out of range
+        i_norm = lib.mi355_gguf_find(g, b"blk.0.attn_norm.weight")
+        assert lib.mi355_gguf_tensor_shard_q8_0(g, i_norm, 0, 2, None, 0) == -1    # not a quantised matrix
+    finally:
+        lib.mi355_gguf_close(g)
+    # ggml's rounding: half away from zero with the UNROUNDED scale
+    x = np.zeros((1, 32), np.float32)
+    x[0, 0], x[0, 1], x[0, 2] = 127.0, 0.5, -2.5
+    q = kq.quantize_q8_0_ggml(x)[0, 0, 2:].view(np.int8)
+    assert q[0] == 127 and q[1] == 1 and q[2] == -3
+
+
 def test_load_gguf_tp_rejects_unshardable_files_before_touching_the_gpu(lib, tmp_path):
     """the shard-plan checks of `mi355_llama_load_gguf_tp` run on the host, ahead of any device call: heads that do
     not divide (attention.rs:553-554), kv heads that neither divide nor replicate (distributed.rs:744-760), a
@@ -308,7 +351,11 @@ def test_check_gguf_refuses_inconsistent_files(lib, tmp_path):
     good = os.path.join(tmp_path, "g.gguf")
     md, ts = GW.llama_to_gguf(good, cfg, W)
     assert _check(lib, good)[0] == 0
-    assert _check(lib, good, 0, 2)[0] == 801                       # ffn_down: 768 / 2 = 384 columns cut a 256-block
+    assert _check(lib, good, 0, 2)[0] == 0                         # ffn_down: 768 / 2 = 384 columns cut a 256-block: the Q8_0 fallback
+    cfg5 = llama.LlamaConfig.tiny(hidden=512, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=1280, vocab=512)
+    five = os.path.join(tmp_path, "five.gguf")
+    GW.llama_to_gguf(five, cfg5, llama.make_weights(cfg5, seed=6))
+    assert _check(lib, five, 0, 5)[0] != 0                         # 4 heads over 5 ranks
     p = os.path.join(tmp_path, "bad.gguf")
 
     def variant(md2=None, drop=None, retype=None, reshape=None):

@@ -288,6 +288,25 @@ def test_qmatmul_vs_oracle(cv, t, T, N, K):
     assert rel_err(got, mm.forward_ref(dev(x)).cpu().numpy()) < 1e-4       # MFMA path == simple kernel
 
 
+@pytest.mark.parametrize("T,N,K", [(1, 64, 384), (5, 40, 1792), (20, 256, 96)])
+def test_q8_0_arm_of_requantised_tp_shards(cv, T, N, K):
+    """Q8_0 (the dtype a tensor-parallel shard is re-quantised to when it cuts a k-quant block, quantized_var_builder.rs:
+    234-269): K only needs to be a multiple of 32; plain store + bias, and the residual epilogue with bf16 activations (o_proj)"""
+    rng = np.random.default_rng(40 + T + N)
+    blocks = kq.quantize_q8_0_ggml(rng.normal(0, 0.05, (N, K)).astype(np.float32))
+    x = rng.normal(0, 1, (T, K)).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    mm = cv.QMatMul(blocks, kq.GGML_Q8_0, "cuda")
+    ref = kq.qmatmul_o1(x, blocks, kq.GGML_Q8_0)
+    assert rel_err(mm.forward(dev(x)).cpu().numpy(), ref) < 1e-5
+    assert rel_err(mm.forward(dev(x), dev(bias)).cpu().numpy(), ref + bias) < 1e-5
+    xb = O.round_bf16(x)
+    resid = rng.normal(size=(T, N)).astype(np.float32)
+    out = dev(resid.copy())
+    cv.qmatmul_fused([mm], dev(xb, torch.bfloat16), epilogue=cv.EPI_RESID, out=out, residual=out)
+    assert rel_err(out.cpu().numpy(), resid + kq.qmatmul_o1(xb, blocks, kq.GGML_Q8_0)) < 1e-5
+
+
 def test_qmatmul_random_bytes_all_code_points(cv):
     """Blocks of random BYTES (every nibble / 6-bit scale pattern), sane f16 d/dmin: exercises the unpack."""
     rng = np.random.default_rng(13)

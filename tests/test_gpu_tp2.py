@@ -268,7 +268,18 @@ def test_dense_tp2_two_ranks_on_one_gpu(lib, gptq):
     assert np.array_equal(res[0][0], res[1][0])
 
 
-def _gguf_file_worker(rank, world, port, q, path):
+def _unaligned_case():
+    """H = 6 heads over 2 ranks -> 3 local heads: o_proj shard = 384 columns, down_proj shard = 384 columns: both cut a 256-wide
+    k-quant block -> the reference's Q8_0 re-quantising fallback (quantized_var_builder.rs:234-269)"""
+    cfg = llama.LlamaConfig.tiny(hidden=512, n_heads=6, n_kv_heads=2, head_dim=128, intermediate=768, vocab=512)
+    W = llama.make_weights(cfg, seed=77)
+    rng = np.random.default_rng(6)
+    seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 21)], "block_table": [2, 5]},
+            {"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 9)], "block_table": [1]}]
+    return cfg, W, seqs
+
+
+def _gguf_file_worker(rank, world, port, q, path, unaligned=False):
     try:
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
         import torch.distributed as dist
@@ -276,14 +287,14 @@ def _gguf_file_worker(rank, world, port, q, path):
         torch.cuda.set_device(0)
         from candle_vllm_amd import model as M, tp
         from oracle import kquants as kq
-        cfg, W, seqs = _gguf_case(False)
+        cfg, W, seqs = _unaligned_case() if unaligned else _gguf_case(False)
         W = dict(W)
         W["tok_embd"] = kq.dequantize_q6_k(kq.quantize(W["tok_embd"], kq.GGML_Q6_K)).reshape(cfg.vocab, cfg.hidden).astype(np.float32)
         # both models are built before the first collective, so a loader error cannot leave the peer waiting
         a = M.GGUFLLaMa.from_gguf(path, max_batch=2, max_blocks_per_seq=16, block_size=cfg.block_size,
                                   kv_layout=M.KV_PAGED, tp_rank=rank, tp_world=world)
         b = M.GGUFLLaMa(cfg, max_batch=2, max_blocks_per_seq=16, kv_layout=M.KV_PAGED, tp_rank=rank, tp_world=world)
-        b.load_oracle_weights(tp.shard_weights(W, cfg, rank, world))
+        b.load_oracle_weights(tp.shard_weights(W, cfg, rank, world, kq.requantize_shard_q8_0))
         dims = (a.c.hidden, a.c.n_heads, a.c.n_kv_heads, a.c.intermediate, a.c.vocab, a.c.tp_rank, a.c.tp_world)
         comm = tp.TorchDistComm()
         meta = O.prepare_prompt(seqs, cfg.block_size)
@@ -342,6 +353,61 @@ def test_gguf_file_loader_tp2_equals_setter_shards(lib, tmp_path):
         assert dims == (cfg.hidden, cfg.n_heads, cfg.n_kv_heads, cfg.intermediate, cfg.vocab, rank, 2)   # GLOBAL dims
         assert np.array_equal(from_file, from_setters)
         assert np.abs(from_file - ref).max() < 3e-3 * np.abs(ref).max()
+
+
+def test_gguf_file_loader_tp2_requantises_unaligned_shards_to_q8_0(lib, tmp_path):
+    """`get_sharded_no_shape`'s fallback (quantized_var_builder.rs:234-269) on the device: o_proj / down_proj shards of 384
+    columns are dequantised, narrowed and re-quantised to Q8_0 by the loader and multiplied by the Q8_0 arm.  The loaded
+    model is bit-identical to the one whose shards the test cut itself (same bytes, checked on the CPU in
+    test_cpu_gguf.py) and agrees with the 2-rank ORACLE over the same re-quantised shards."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    import threading
+    from candle_vllm_amd import tp
+    from oracle import gguf_writer as GW
+    from oracle import kquants as kq
+    cfg, W, seqs = _unaligned_case()
+    W = dict(W)
+    W["tok_embd"] = kq.dequantize_q6_k(kq.quantize(W["tok_embd"], kq.GGML_Q6_K)).reshape(cfg.vocab, cfg.hidden).astype(np.float32)
+    path = os.path.join(tmp_path, "q8.gguf")
+    GW.llama_to_gguf(path, cfg, W)
+    lc = _LockstepComm(2, 0)
+    refs = [None, None]
+
+    def run(rank):
+        orc = llama.OracleLlama(tp.shard_config(cfg, rank, 2), tp.shard_weights(W, cfg, rank, 2, kq.requantize_shard_q8_0),
+                                flash_layout=False, comm=lc.view(rank))
+        refs[rank] = orc.forward(O.prepare_prompt(seqs, cfg.block_size), orc.new_cache(8), is_prefill=True)
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gguf_file_worker, args=(r, 2, port, q, path, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res, err = {}, None
+    try:
+        for _ in range(2):
+            r = q.get(timeout=300)
+            if r[1] == "error":
+                err = r
+                break
+            res[r[0]] = r[2:]
+    finally:
+        for p in procs:
+            p.join(timeout=5 if err else 120)
+            if p.is_alive():
+                p.terminate()                              # this test's own children only
+    assert err is None, err
+    for rank in (0, 1):
+        dims, from_file, from_setters = res[rank]
+        assert dims == (cfg.hidden, cfg.n_heads, cfg.n_kv_heads, cfg.intermediate, cfg.vocab, rank, 2)
+        assert np.array_equal(from_file, from_setters)
+        assert np.abs(from_file - refs[0]).max() < 3e-3 * np.abs(refs[0]).max()
 
 
 # ------------------------------------------------------------------------------------------------ one-shot peer all-reduce
