@@ -101,6 +101,9 @@ struct Model {
     // MoE routing scratch (sized for the decode batch; prompt steps use their own, below)
     int32_t* moe_ids = nullptr; float* moe_w = nullptr; float* moe_y = nullptr;
     int32_t* p_moe_ids = nullptr; float* p_moe_w = nullptr; float* p_moe_y = nullptr;
+    // grouped experts on prompt steps: gathered rows in expert order + the permutation and its inverse
+    float* p_moe_xg = nullptr; int32_t* p_moe_perm = nullptr; int32_t* p_moe_inv = nullptr;
+    bool moe_grouped_done = false;  // this layer's MlpOrMoe ran grouped inside the gate/up part: the down part has nothing left to do
 };
 
 int g_host_ps_override = 0;     // experiments: mi355_set_tuning(5, partition_size)
@@ -215,6 +218,53 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
         // --- MlpOrMoe::forward (quantized_llama.rs:56-123) without the host round trip
         const int K = c.n_expert_used, pairs = B * K;
         if (!L.gate_inp || !L.eslab[0] || !L.eslab[1] || !L.eslab[2]) return (int)hipErrorInvalidValue;
+        if (part == PART_DOWN && m->moe_grouped_done) { m->moe_grouped_done = false; return 0; }
+        if (part == PART_GATEUP && in.is_prefill && B >= 16 && m->p_moe_xg) {
+            // ---- grouped experts (prompt steps): route on the device, sort the (token, slot) pairs by expert on the host --
+            // the reference pulls the routing to the host as well (`to_vec2`, quantized_llama.rs:70) -- then every selected
+            // expert streams ONCE over all of its tokens (gate/up with the fused norm + SiLU*mul, down), and one kernel adds the
+            // weighted expert outputs to the residual (quantized_llama.rs:93-119, 470).  The per-pair path below reads an
+            // expert once per pair: exact, but a 2048-token prompt would stream each expert hundreds of times.
+            RCHECK(mi355_moe_route(in.moe_ids, in.moe_w, in.xs, L.ffn_norm, c.rms_eps, L.gate_inp, B, hid, c.n_expert, K, st));
+            std::vector<int32_t> ids((size_t)pairs), perm((size_t)pairs), inv((size_t)pairs);
+            HCHECK(hipMemcpyAsync(ids.data(), in.moe_ids, (size_t)pairs * 4, hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(st)));
+            HCHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(st)));
+            std::vector<int> count(c.n_expert + 1, 0);
+            for (int p = 0; p < pairs; ++p) {
+                if (ids[p] < 0 || ids[p] >= c.n_expert) return (int)hipErrorInvalidValue;
+                ++count[ids[p] + 1];
+            }
+            for (int e = 0; e < c.n_expert; ++e) count[e + 1] += count[e];           // offsets
+            std::vector<int> fill(count.begin(), count.end() - 1);
+            for (int p = 0; p < pairs; ++p) { const int pos = fill[ids[p]]++; perm[pos] = p; inv[p] = pos; }   // stable: token order inside an expert
+            HCHECK(hipMemcpyAsync(m->p_moe_perm, perm.data(), (size_t)pairs * 4, hipMemcpyHostToDevice, reinterpret_cast<hipStream_t>(st)));
+            HCHECK(hipMemcpyAsync(m->p_moe_inv, inv.data(), (size_t)pairs * 4, hipMemcpyHostToDevice, reinterpret_cast<hipStream_t>(st)));
+            RCHECK(mi355_moe_gather(m->p_moe_xg, in.xs, m->p_moe_perm, pairs, K, hid, st));
+            for (int e = 0; e < c.n_expert; ++e) {
+                const int off = count[e], n_e = count[e + 1] - count[e];
+                if (n_e == 0) continue;
+                mi355_qmm_desc g;
+                memset(&g, 0, sizeof(g));
+                g.nseg = 2;
+                g.w_tiles[0] = L.eslab[0] + (size_t)e * L.estride[0]; g.ggml_type[0] = L.etype[0]; g.n_rows[0] = L.erows[0];
+                g.w_tiles[1] = L.eslab[2] + (size_t)e * L.estride[2]; g.ggml_type[1] = L.etype[2]; g.n_rows[1] = L.erows[2];
+                g.x = m->p_moe_xg + (size_t)off * hid; g.x_dtype = MI355_DTYPE_F32; g.ldx = hid; g.k = hid; g.num_tokens = n_e;
+                g.norm_weight = L.ffn_norm; g.norm_eps = c.rms_eps;
+                g.epilogue = MI355_EPI_SILU_MUL; g.out = in.h + (size_t)off * I; g.ldo = I;
+                RCHECK(mi355_qmatmul_fused(&g, st));
+                mi355_qmm_desc dn;
+                memset(&dn, 0, sizeof(dn));
+                dn.nseg = 1;
+                dn.w_tiles[0] = L.eslab[1] + (size_t)e * L.estride[1]; dn.ggml_type[0] = L.etype[1]; dn.n_rows[0] = L.erows[1];
+                dn.x = in.h + (size_t)off * I; dn.x_dtype = MI355_DTYPE_F32; dn.ldx = I; dn.k = I; dn.num_tokens = n_e;
+                dn.epilogue = MI355_EPI_STORE; dn.out = in.moe_y + (size_t)off * hid; dn.ldo = hid;
+                RCHECK(mi355_qmatmul_fused(&dn, st));
+            }
+            RCHECK(mi355_moe_scatter_combine(in.xs, in.moe_y, in.moe_w, m->p_moe_inv, B, hid, K, st));
+            HCHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(st)));          // perm / inv leave scope with this call
+            m->moe_grouped_done = true;
+            return 0;
+        }
         if (part == PART_GATEUP) {
             RCHECK(mi355_moe_route(in.moe_ids, in.moe_w, in.xs, L.ffn_norm, c.rms_eps, L.gate_inp, B, hid, c.n_expert, K, st));
             d.nseg = 2;
@@ -463,7 +513,7 @@ extern "C" void mi355_llama_destroy(void* mp) {
     free_qw(m->output);
     void* ptrs[] = {m->tok_embd, m->output_norm, m->cos_t, m->sin_t, m->xs, m->q, m->attn, m->h, m->logits,
                     m->pa_tmp, m->pa_max, m->pa_sum, m->kv_slab, m->d_tokens, m->d_positions, m->d_slots,
-                    m->d_ctx, m->d_bt, m->logits_local, m->logits_gather, m->tp_y, m->p_tp_y, m->p_xs, m->p_q, m->p_attn, m->p_h,
+                    m->d_ctx, m->d_bt, m->logits_local, m->logits_gather, m->tp_y, m->p_tp_y, m->p_moe_xg, m->p_moe_perm, m->p_moe_inv, m->p_xs, m->p_q, m->p_attn, m->p_h,
                     m->moe_ids, m->moe_w, m->moe_y, m->p_moe_ids, m->p_moe_w, m->p_moe_y};
     if (m->comm && m->comm_owned) mi355_comm_destroy(m->comm);
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -612,9 +662,13 @@ static int ensure_prefill_cap(Model* m, int T) {
     HCHECK(hipMalloc((void**)&m->p_h, (size_t)cap * KE * m->cfg.intermediate * 4));
     if (m->use_comm) HCHECK(hipMalloc((void**)&m->p_tp_y, (size_t)cap * m->cfg.hidden * 4));
     if (m->cfg.n_expert > 1) {
-        void* oldm[] = {m->p_moe_ids, m->p_moe_w, m->p_moe_y};
+        void* oldm[] = {m->p_moe_ids, m->p_moe_w, m->p_moe_y, m->p_moe_xg, m->p_moe_perm, m->p_moe_inv};
         for (void* p : oldm) if (p) (void)hipFree(p);
         m->p_moe_ids = nullptr; m->p_moe_w = nullptr; m->p_moe_y = nullptr;
+        m->p_moe_xg = nullptr; m->p_moe_perm = nullptr; m->p_moe_inv = nullptr;
+        HCHECK(hipMalloc((void**)&m->p_moe_xg, (size_t)cap * KE * m->cfg.hidden * 4));
+        HCHECK(hipMalloc((void**)&m->p_moe_perm, (size_t)cap * KE * 4));
+        HCHECK(hipMalloc((void**)&m->p_moe_inv, (size_t)cap * KE * 4));
         HCHECK(hipMalloc((void**)&m->p_moe_ids, (size_t)cap * KE * 4));
         HCHECK(hipMalloc((void**)&m->p_moe_w, (size_t)cap * KE * 4));
         HCHECK(hipMalloc((void**)&m->p_moe_y, (size_t)cap * KE * m->cfg.hidden * 4));

@@ -73,6 +73,41 @@ __global__ void __launch_bounds__(256) moe_combine_kernel(float* __restrict__ ys
     ys[(size_t)t * hidden + i] = acc;
 }
 
+// ---- grouped experts (prompt steps / large batches): the (token, slot) pairs sorted by expert, so that every selected
+// expert is streamed ONCE per step over all of its tokens -- what the reference's host-routed loop does per expert with
+// index_select / index_add (quantized_llama.rs:93-119; layers/moe.rs:746-810)
+__global__ void __launch_bounds__(256) moe_gather_kernel(float* __restrict__ dst, const float* __restrict__ src, const int32_t* __restrict__ perm,
+                                                         int K, int hidden) {
+    const int p = blockIdx.y;                                          // position in expert order
+    const int t = perm[p] / K;                                         // pair index = token * K + slot
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i < hidden) *reinterpret_cast<float4*>(dst + (size_t)p * hidden + i) = *reinterpret_cast<const float4*>(src + (size_t)t * hidden + i);
+}
+__global__ void __launch_bounds__(256) moe_scatter_combine_kernel(float* __restrict__ ys, const float* __restrict__ yg, const float* __restrict__ wts,
+                                                                  const int32_t* __restrict__ inv, int hidden, int K) {
+    const int t = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hidden) return;
+    float acc = ys[(size_t)t * hidden + i];                            // residual (quantized_llama.rs:470)
+    for (int j = 0; j < K; ++j) acc = fmaf(wts[(size_t)t * K + j], yg[(size_t)inv[t * K + j] * hidden + i], acc);
+    ys[(size_t)t * hidden + i] = acc;
+}
+extern "C" int mi355_moe_gather(float* dst, const float* src, const int32_t* perm, int32_t num_pairs, int32_t top_k, int32_t hidden,
+                                int64_t stream) {
+    if (num_pairs <= 0) return 0;
+    if (!dst || !src || !perm || top_k < 1 || hidden <= 0 || (hidden & 3)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(moe_gather_kernel, dim3((hidden / 4 + 255) / 256, num_pairs), dim3(256), 0, to_stream(stream), dst, src, perm, top_k, hidden);
+    return (int)hipGetLastError();
+}
+extern "C" int mi355_moe_scatter_combine(float* ys, const float* y_sorted, const float* weights, const int32_t* inv, int32_t num_tokens,
+                                         int32_t hidden, int32_t top_k, int64_t stream) {
+    if (num_tokens <= 0) return 0;
+    if (!ys || !y_sorted || !weights || !inv || top_k < 1 || hidden <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(moe_scatter_combine_kernel, dim3((hidden + 255) / 256, num_tokens), dim3(256), 0, to_stream(stream), ys, y_sorted,
+                       weights, inv, hidden, top_k);
+    return (int)hipGetLastError();
+}
+
 extern "C" int mi355_moe_route(int32_t* expert_ids, float* weights, const float* x, const float* norm_weight, float norm_eps,
                                const float* gate_inp, int32_t num_tokens, int32_t hidden, int32_t n_expert, int32_t top_k,
                                int64_t stream) {

@@ -21,8 +21,12 @@
 //     K, partial sums meet in LDS, and the epilogue fuses bias/residual (K-free adds), SiLU*mul (K9),
 //     interleaved RoPE + bf16 cast + paged-cache scatter (K7 + K1).
 #include "common.h"
+#include "scratch.h"
 #include "../../include/mi355_vllm.h"
 #include <string.h>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #define Q4K_BLOCK 144
 #define Q6K_BLOCK 210
@@ -1155,27 +1159,23 @@ __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, cons
     }
 }
 
-static uint8_t* g_qmg_imgs[2] = {nullptr, nullptr};           // two images: an epilogue stages the next one while its own ssp is live
-static size_t g_qmg_img_bytes[2] = {0, 0};
-static int g_qmg_cur = 0;
+// Scratch of the wide / prompt paths (activation images, split-K partials, the prompt-step workspace) belongs to the
+// (device, stream) that launches: two models on two streams never share an image, growing a buffer never frees memory a
+// captured graph still replays from (scratch.cpp).  The chain hint is per (device, stream) too.
 // image staged by the last chained epilogue: valid for exactly the next wide launch if it consumes the same activations
 struct QmgChainState { bool valid; const void* x; int B, K, MT, buf; const float* norm_w; hipStream_t st; };
-static QmgChainState g_qmg_chain = {false, nullptr, 0, 0, 0, 0, nullptr, nullptr};
+struct QmgStream { int cur = 0; QmgChainState chain = {false, nullptr, 0, 0, 0, 0, nullptr, nullptr}; };
+static std::mutex g_qmg_mu;
+static std::map<std::pair<int, hipStream_t>, QmgStream> g_qmg_streams;
+static QmgStream& qmg_stream(hipStream_t st) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_qmg_mu);
+    return g_qmg_streams[std::make_pair(dev, st)];              // std::map: the reference stays valid across later inserts
+}
 static int g_tune_chain = 1;                                  // mi355_set_tuning(9, 0): never chain (A/B experiments)
 static int g_tune_ks_target = 1024;                           // mi355_set_tuning(10, n): split K until a launch has n row-tile x k-split slots
-static float* g_qmg_part = nullptr;
-static size_t g_qmg_part_bytes = 0;
-
-static int qmg_grow(void** p, size_t* have, size_t need, hipStream_t st) {
-    if (need <= *have) return 0;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return (int)hipErrorStreamCaptureUnsupported;
-    if (*p) { (void)hipDeviceSynchronize(); (void)hipFree(*p); *p = nullptr; *have = 0; }
-    const hipError_t e = hipMalloc(p, need * 2);
-    if (e != hipSuccess) return (int)e;
-    *have = need * 2;
-    return 0;
-}
+static inline int qmg_buf(void** p, int key, size_t need, hipStream_t st) { return mi355_scratch_get(p, key, need, st, false); }
 
 template <int MT>
 static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
@@ -1192,25 +1192,28 @@ static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
     int ks = 1;
     while (n_slots * ks < g_tune_ks_target && nkb / (ks * 2) >= 2) ks *= 2;
     // activation image: staged by the previous launch's epilogue (chain) or by the prep kernel now
-    const bool chained = g_qmg_chain.valid && g_qmg_chain.x == a.x && g_qmg_chain.B == a.B && g_qmg_chain.K == a.K &&
-                         g_qmg_chain.MT == MT && g_qmg_chain.norm_w == a.norm_w && g_qmg_chain.st == st &&
+    QmgStream& qs = qmg_stream(st);
+    const bool chained = qs.chain.valid && qs.chain.x == a.x && qs.chain.B == a.B && qs.chain.K == a.K &&
+                         qs.chain.MT == MT && qs.chain.norm_w == a.norm_w && qs.chain.st == st &&
                          a.x_dtype == MI355_DTYPE_F32 && a.ldx == a.K;
-    g_qmg_chain.valid = false;
-    const int cur = chained ? g_qmg_chain.buf : g_qmg_cur;
+    qs.chain.valid = false;
+    const int cur = chained ? qs.chain.buf : qs.cur;
     int rc = 0;
-    if (!chained) {
-        rc = qmg_grow((void**)&g_qmg_imgs[cur], &g_qmg_img_bytes[cur], kbb * nkb + (size_t)nkb * MT * 8 * sizeof(float), st);
-        if (rc) return rc;
-    }
-    rc = qmg_grow((void**)&g_qmg_part, &g_qmg_part_bytes, (size_t)ks * MT * 8 * ldp * sizeof(float), st);
+    void* imgp = nullptr;
+    // (a chained image was sized by the epilogue that staged it: the same request returns the same buffer)
+    rc = qmg_buf(&imgp, cur ? MI355_SCR_QMM_IMG1 : MI355_SCR_QMM_IMG0, kbb * nkb + (size_t)nkb * MT * 8 * sizeof(float), st);
     if (rc) return rc;
+    void* partp = nullptr;
+    rc = qmg_buf(&partp, MI355_SCR_QMM_PART, (size_t)ks * MT * 8 * ldp * sizeof(float), st);
+    if (rc) return rc;
+    float* const part = static_cast<float*>(partp);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)qmm_gemm_kernel<MT, MI355_GGML_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qmm_gemm_kernel<MT, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    uint8_t* img = g_qmg_imgs[cur];
+    uint8_t* img = static_cast<uint8_t*>(imgp);
     float* ssp = reinterpret_cast<float*>(img + kbb * nkb);                 // [nkb][MT*8] after the image
     if (!chained) hipLaunchKernelGGL((qmm_prep2_kernel<MT>), dim3(nkb, MT), dim3(256), 0, st, img, ssp, a, kbb);
     // one GEMM launch per run of same-type segments: the type-specialised builds need no schedule pinning and do not
@@ -1224,9 +1227,9 @@ static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
         for (int q = 0; q < r.nseg; ++q) { r.seg[q] = a.seg[s0 + q]; run_slots += r.seg[q].n_tiles; }
         const dim3 ggrid((run_slots + QMG_NC - 1) / QMG_NC, ks);
         if (r.seg[0].type == MI355_GGML_Q4_K)
-            hipLaunchKernelGGL((qmm_gemm_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), 2 * kbb, st, r, img, g_qmg_part, ldp, run_slots, slot_base);
+            hipLaunchKernelGGL((qmm_gemm_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), 2 * kbb, st, r, img, part, ldp, run_slots, slot_base);
         else
-            hipLaunchKernelGGL((qmm_gemm_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, r, img, g_qmg_part, ldp, run_slots, slot_base);
+            hipLaunchKernelGGL((qmm_gemm_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, r, img, part, ldp, run_slots, slot_base);
         slot_base += run_slots;
         s0 = s1;
     }
@@ -1237,13 +1240,15 @@ static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
                       (a.epi == MI355_EPI_SILU_MUL ? a.seg[0].n_rows == a.next_k : (a.nseg == 1 && a.seg[0].n_rows == a.next_k));
     if (want) {
         const int other = cur ^ 1, nkb2 = a.next_k / 256;
-        rc = qmg_grow((void**)&g_qmg_imgs[other], &g_qmg_img_bytes[other], kbb * nkb2 + (size_t)nkb2 * MT * 8 * sizeof(float), st);
+        void* onext = nullptr;
+        rc = qmg_buf(&onext, other ? MI355_SCR_QMM_IMG1 : MI355_SCR_QMM_IMG0, kbb * nkb2 + (size_t)nkb2 * MT * 8 * sizeof(float), st);
         if (rc) return rc;
-        ch = QmgChainOut{g_qmg_imgs[other], reinterpret_cast<float*>(g_qmg_imgs[other] + kbb * nkb2), a.next_norm_w, a.next_k, MT, kbb};
-        g_qmg_chain = QmgChainState{true, a.out, a.B, a.next_k, MT, other, a.next_norm_w, st};
+        uint8_t* oimg = static_cast<uint8_t*>(onext);
+        ch = QmgChainOut{oimg, reinterpret_cast<float*>(oimg + kbb * nkb2), a.next_norm_w, a.next_k, MT, kbb};
+        qs.chain = QmgChainState{true, a.out, a.B, a.next_k, MT, other, a.next_norm_w, st};
     }
-    g_qmg_cur = cur;
-    hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, want ? MT * 8 : a.B), dim3(256), 0, st, a, g_qmg_part, ldp, ks,
+    qs.cur = cur;
+    hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, want ? MT * 8 : a.B), dim3(256), 0, st, a, part, ldp, ks,
                        MT * 8, ssp, ch);
     return (int)hipGetLastError();
 }
@@ -1367,8 +1372,6 @@ int mi355_internal_gemm_rowmajor(void* out, int out_dtype, int ldo, const void* 
     return rc == 0 ? 0 : (int)hipErrorUnknown;
 }
 
-static void* g_qmp_ws = nullptr;
-static size_t g_qmp_ws_bytes = 0;
 static int g_tune_qpg = 0;                                 // mi355_set_tuning(11, v): prompt-step GEMM variant (A/B runs)
 static int g_tune_dbg = 0;                                 // mi355_set_tuning(2, v): probe / ablation modes (experiments only)
 
@@ -1387,10 +1390,11 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
     const int T = a.B, K = a.K, ldp = n_slots * 16, nkb = K >> 8;
     const int Tpad = (T + QPG_BM - 1) / QPG_BM * QPG_BM;
     const size_t xa_b = (size_t)K * Tpad * 4, sf_b = (size_t)nkb * Tpad * 32, rs_b = (size_t)Tpad * 4, c_b = (size_t)T * ldp * 4;
-    int rc = qmg_grow(&g_qmp_ws, &g_qmp_ws_bytes, xa_b + sf_b + 2 * rs_b + c_b + 4096, st);
+    void* ws = nullptr;
+    int rc = qmg_buf(&ws, MI355_SCR_QMP_WS, xa_b + sf_b + 2 * rs_b + c_b + 4096, st);
     if (rc) return rc;
     a.dbg = g_tune_dbg;                                     // ablation bits of the prompt-step GEMM (experiments only)
-    uint8_t* base = static_cast<uint8_t*>(g_qmp_ws);
+    uint8_t* base = static_cast<uint8_t*>(ws);
     QpgImg im;
     im.xa = base; im.sfrag = base + xa_b;
     im.row_scale = reinterpret_cast<float*>(base + xa_b + sf_b);
@@ -1451,13 +1455,14 @@ static int qmp_launch(const QmmArgs& a0, hipStream_t st) {
     const int T = a.B, K = a.K, ldp = n_slots * 16;
     // workspace: w_hi, w_lo [ldp, K] bf16 | x_hi, x_lo [T, K] bf16 | C [T, ldp] f32
     const size_t wb = (size_t)ldp * K * 2, xb = (size_t)T * K * 2, cb = (size_t)T * ldp * 4;
-    int rc = qmg_grow(&g_qmp_ws, &g_qmp_ws_bytes, 2 * wb + 2 * xb + cb + 1024, st);
+    void* ws = nullptr;
+    int rc = qmg_buf(&ws, MI355_SCR_QMP_WS, 2 * wb + 2 * xb + cb + 1024, st);
     if (rc) return rc;
-    uint16_t* w_hi = static_cast<uint16_t*>(g_qmp_ws);
-    uint16_t* w_lo = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(g_qmp_ws) + wb);
-    uint16_t* x_hi = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(g_qmp_ws) + 2 * wb);
-    uint16_t* x_lo = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(g_qmp_ws) + 2 * wb + xb);
-    float* C = reinterpret_cast<float*>(static_cast<uint8_t*>(g_qmp_ws) + 2 * wb + 2 * xb);
+    uint16_t* w_hi = static_cast<uint16_t*>(ws);
+    uint16_t* w_lo = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(ws) + wb);
+    uint16_t* x_hi = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(ws) + 2 * wb);
+    uint16_t* x_lo = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(ws) + 2 * wb + xb);
+    float* C = reinterpret_cast<float*>(static_cast<uint8_t*>(ws) + 2 * wb + 2 * xb);
     int row0 = 0;
     for (int s = 0; s < a.nseg; ++s) {                     // concatenated padded row space, as the epilogue expects
         hipLaunchKernelGGL(qmp_dequant_kernel, dim3(K >> 8, a.seg[s].n_tiles), dim3(256), 0, st, w_hi + (size_t)row0 * K,

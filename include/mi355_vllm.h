@@ -233,6 +233,12 @@ int mi355_moe_route(int32_t* expert_ids, float* weights, const float* x, const f
  * adds into ys (the residual stream), else overwrites */
 int mi355_moe_combine(float* ys, const float* y_pairs, const float* weights, int32_t num_tokens, int32_t hidden,
                       int32_t top_k, int32_t accumulate, int64_t stream);
+/* grouped experts for prompt steps / large batches (the reference's per-expert index_select -> expert -> index_add loop,
+ * quantized_llama.rs:93-119; layers/moe.rs:746-810): `perm` = the (token * top_k + slot) pair indices sorted by expert,
+ * `inv` = its inverse.  gather: dst[p] = src[perm[p] / top_k] (f32 rows); scatter_combine: ys[t] += sum_j w[t,j] * y_sorted[inv[t*top_k+j]] */
+int mi355_moe_gather(float* dst, const float* src, const int32_t* perm, int32_t num_pairs, int32_t top_k, int32_t hidden, int64_t stream);
+int mi355_moe_scatter_combine(float* ys, const float* y_sorted, const float* weights, const int32_t* inv, int32_t num_tokens,
+                              int32_t hidden, int32_t top_k, int64_t stream);
 /* experiment knobs, never needed for correct results (value 0 = default unless noted): 0 waves per workgroup,
  * 1 row tiles per workgroup, 2 probe modes of the mat-vec (1 stream only, 3 no staging, 4 no epilogue), 3 fused attention
  * merge (0 off, 1 auto, 2 always), 5 attention partition override, 6 prompt-step GEMM (1 on), 8 attention waves per

@@ -319,6 +319,41 @@ def test_model_loaded_from_gguf_file_equals_setter_path(lib, tmp_path):
     assert np.array_equal(c.forward_prefill(meta).cpu().numpy(), d.forward_prefill(meta).cpu().numpy())
 
 
+def test_moe_prompt_step_grouped_experts(lib):
+    """a 150-token prompt on the Mixtral-shaped tiny model: the (token, slot) pairs are sorted by expert and every selected
+    expert runs ONCE over its ~75 tokens (grouped path: gather -> gate/up + SiLU*mul -> down -> weighted scatter-add,
+    quantized_llama.rs:93-119; layers/moe.rs:746-810) -- groups of this size cross the decode, wide and prompt-step mat-mul
+    paths -- vs the oracle's per-token MlpOrMoe restatement; then a chunk of 5 tokens (per-pair path) on top of it"""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from candle_vllm_amd import model as M
+    cfg = llama.LlamaConfig.tiny()
+    cfg.n_expert, cfg.n_expert_used = 4, 2
+    W = llama.make_moe_weights(cfg, 4, seed=79)
+    orc = llama.OracleLlama(cfg, W, flash_layout=True)
+    rng = np.random.default_rng(23)
+    seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 150)], "block_table": list(range(1, 11))}]
+    cache = orc.new_cache(16)
+    meta = O.prepare_prompt(seqs, cfg.block_size)
+    ref = orc.forward(meta, cache, is_prefill=True)
+    gm = M.GGUFLLaMa(cfg, max_batch=4, kv_layout=M.KV_FLASH)
+    gm.load_oracle_weights(W)
+    gm.alloc_kv_cache(16)
+    got = gm.forward_prefill(meta).cpu().numpy()
+    assert _rel(got, ref) < 3e-3, _rel(got, ref)
+    assert int(got[0].argmax()) == int(ref[0].argmax())
+    for l, (kc, vc) in enumerate(cache):                          # the cache both sides wrote: bf16 rounding noise only
+        gk, gv = gm.kv_download(l)
+        fk = O.bf16_bits_to_f32(kc)[1:11]
+        assert np.abs(O.bf16_bits_to_f32(gk)[1:11] - fk).max() <= 2 ** -6 * np.abs(fk).max()
+    seqs[0]["tokens"].append(int(ref[0].argmax()))
+    dmeta = O.prepare_decode(seqs, cfg.block_size)
+    dref = orc.forward(dmeta, cache)
+    dgot = gm.forward_decode(dmeta).cpu().numpy()
+    assert _rel(dgot, dref) < 3e-3
+    assert int(dgot[0].argmax()) == int(dref[0].argmax())
+
+
 def test_moe_model_prompt_and_graph_decode(lib):
     """Mixtral-shaped tiny model (4 experts, top-2): prompt step and greedy decode (eager and hipGraph replay -- the
     routing never leaves the device) vs the oracle's MlpOrMoe restatement (quantized_llama.rs:56-123)."""
