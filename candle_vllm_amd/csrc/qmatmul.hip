@@ -1373,6 +1373,7 @@ int mi355_internal_gemm_rowmajor(void* out, int out_dtype, int ldo, const void* 
 }
 
 static int g_tune_qpg = 0;                                 // mi355_set_tuning(11, v): prompt-step GEMM variant (A/B runs)
+static int g_tune_qpg_min = 96;                            // mi355_set_tuning(12, n): fewest tokens that take the prompt-step GEMM (QMP_MIN_TOKENS)
 static int g_tune_dbg = 0;                                 // mi355_set_tuning(2, v): probe / ablation modes (experiments only)
 
 #include "qmm_prefill.inc"
@@ -1405,7 +1406,7 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
     if (!attr_done) {
 #define QPG_ATTR(MTW, NTW, WM, WN, DEEP) (void)hipFuncSetAttribute((const void*)qpg_gemm_kernel<MI355_GGML_Q4_K, MTW, NTW, WM, WN, DEEP>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)
         QPG_ATTR(2, 4, 4, 2, false); QPG_ATTR(2, 4, 2, 4, false); QPG_ATTR(2, 4, 1, 8, false); QPG_ATTR(4, 4, 1, 4, false);
-        QPG_ATTR(2, 4, 2, 4, true); QPG_ATTR(4, 2, 2, 4, false);
+        QPG_ATTR(2, 4, 2, 4, true); QPG_ATTR(4, 2, 2, 4, false); QPG_ATTR(2, 4, 1, 8, true);
 #undef QPG_ATTR
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         attr_done = true;
@@ -1422,7 +1423,7 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
         if (r.seg[0].type == MI355_GGML_Q4_K) {
             // variants (mi355_set_tuning(11, v)): wave tile (m-tiles x row tiles), wave grid, activation prefetch depth
 #define QPG_GO(MTW, NTW, WM, WN, DEEP) hipLaunchKernelGGL((qpg_gemm_kernel<MI355_GGML_Q4_K, MTW, NTW, WM, WN, DEEP>), \
-                dim3((run_slots + NTW * WN - 1) / (NTW * WN), Tpad / (16 * MTW * WM)), dim3(WM * WN * 64), 4 * (16 * MTW * WM) * QPG_ROWB, st, \
+                dim3(Tpad / (16 * MTW * WM), (run_slots + NTW * WN - 1) / (NTW * WN)), dim3(WM * WN * 64), 4 * (16 * MTW * WM) * QPG_ROWB, st, \
                 r, im, C, ldp, run_slots, slot_base)
             switch (g_tune_qpg) {
                 case 1: QPG_GO(2, 4, 4, 2, false); break;              // 128 x 128, waves 32 x 64
@@ -1430,11 +1431,12 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
                 case 3: QPG_GO(4, 2, 2, 4, false); break;              // 128 x 128, waves 64 x 32
                 case 4: QPG_GO(4, 4, 1, 4, false); break;              //  64 x 256, 4 waves of 64 x 64
                 case 5: QPG_GO(2, 4, 2, 4, true); break;               //  64 x 256, activations two chunks ahead
+                case 7: QPG_GO(2, 4, 1, 8, true); break;               //  32 x 512, activations two chunks ahead
                 default: QPG_GO(2, 4, 1, 8, false); break;             //  32 x 512, waves 32 x 64: measured best (14.7 k tok/s at T = 2048, no spills)
             }
 #undef QPG_GO
         } else {
-            const dim3 grid((run_slots + 15) / 16, Tpad / 32);         // Q6_K: 32 tokens x 256 rows per workgroup
+            const dim3 grid(Tpad / 32, (run_slots + 15) / 16);         // Q6_K: 32 tokens x 256 rows per workgroup; token blocks fastest
             hipLaunchKernelGGL(qpg_gemm_q6k_kernel, grid, dim3(512), 16 * 1024, st, r, im, C, ldp, run_slots, slot_base);
         }
         slot_base += run_slots;
@@ -1504,6 +1506,7 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     else if (key == 9) g_tune_chain = value;
     else if (key == 10 && value > 0) g_tune_ks_target = value;
     else if (key == 11) g_tune_qpg = value;
+    else if (key == 12 && value > 0) g_tune_qpg_min = value;
 }
 
 static size_t qmm_lds_bytes(int BT, int R, int NW) {
@@ -1682,7 +1685,7 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
         a.B = 1;
         return qmm_launch_bt<1>(a, R, wt, n_wg, NW, st);
     }
-    if (a.B >= QMP_MIN_TOKENS && g_tune_prefill_gemm) {
+    if (a.B >= g_tune_qpg_min && g_tune_prefill_gemm) {
         // prompt step: the hand-written quantised GEMM (qmm_prefill.inc).  mi355_set_tuning(6, 2) = the first-generation path
         // (bf16 hi/lo weight image + three library GEMMs) for A/B runs; (6, 0) = stream the weights 32 tokens at a time.
         if (g_tune_prefill_gemm != 2) {
