@@ -979,9 +979,11 @@ __global__ void __launch_bounds__(256) qmm_prep2_kernel(uint8_t* __restrict__ im
 // front of the next use of ANY loaded register, which serialised load -> wait -> compute in the first version
 // (measured: 36 of 45 us of the gate/up GEMM were the load/barrier skeleton).  One barrier per k-block.
 #define QMG_NC 7
-template <int MT, int WT>
-__global__ void __launch_bounds__(512, 4) qmm_gemm_kernel(const QmmArgs a, const uint8_t* __restrict__ img, float* __restrict__ part,
-                                                          const int ldp, const int n_slots, const int slot_base) {
+// segments [s0, s1) of `a` (all of type WT when WT != 0) = row-tile slots [0, n_slots) of this run, workgroup bx of the run;
+// NC consumer waves + one loader wave per workgroup
+template <int MT, int WT, int NC = QMG_NC>
+__device__ __forceinline__ void qmm_gemm_body(const QmmArgs& a, const uint8_t* __restrict__ img, float* __restrict__ part, const int ldp,
+                                              const int s0, const int s1, const int n_slots, const int slot_base, const int bx) {
     extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
     constexpr int BP = MT * 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -991,7 +993,7 @@ __global__ void __launch_bounds__(512, 4) qmm_gemm_kernel(const QmmArgs a, const
     const int kb_lo = blockIdx.y * kb_per, kb_hi = min(nkb, kb_lo + kb_per);
     if (kb_lo >= kb_hi) return;                                       // uniform for the workgroup
 
-    if (wave == QMG_NC) {
+    if (wave == NC) {
         // ---------------- loader wave: the image of k-block kb+1 lands while the consumers work on kb
         const int nchunk = (int)(kbb >> 10);                          // 1 KiB = one wave-wide 16-B DMA
         auto dma_kb = [&](int kb, int buf) {
@@ -1011,11 +1013,11 @@ __global__ void __launch_bounds__(512, 4) qmm_gemm_kernel(const QmmArgs a, const
         return;
     }
     // ---------------- consumer waves
-    int slot = blockIdx.x * QMG_NC + wave;
+    int slot = bx * NC + wave;
     const bool have = slot < n_slots;
     if (!have) slot = 0;
-    int t = slot, sg = 0;
-    while (sg + 1 < a.nseg && t >= a.seg[sg].n_tiles) { t -= a.seg[sg].n_tiles; ++sg; }
+    int t = slot, sg = s0;
+    while (sg + 1 < s1 && t >= a.seg[sg].n_tiles) { t -= a.seg[sg].n_tiles; ++sg; }
     const int wtype = WT ? WT : a.seg[sg].type;                       // WT != 0: every tile of the launch has that type
     const int wtb = (wtype == MI355_GGML_Q4_K) ? Q4K_TILE : Q6K_TILE;
     const uint8_t* wbase = a.seg[sg].w + (size_t)t * nkb * wtb;
@@ -1050,6 +1052,31 @@ __global__ void __launch_bounds__(512, 4) qmm_gemm_kernel(const QmmArgs a, const
 #pragma unroll
             for (int v = 0; v < 4; ++v) pp[(size_t)(8 * mt + 4 * kg + v) * ldp] = y[0][mt][v];
     }
+}
+template <int MT, int WT>
+__global__ void __launch_bounds__(512, 4) qmm_gemm_kernel(const QmmArgs a, const uint8_t* __restrict__ img, float* __restrict__ part,
+                                                          const int ldp, const int n_slots, const int slot_base) {
+    qmm_gemm_body<MT, WT>(a, img, part, ldp, 0, a.nseg, n_slots, slot_base, (int)blockIdx.x);
+}
+// 15 consumers + the loader: twice the waves on one shared image per CU (the image DMA is 2.4x the weight bytes, so a
+// second workgroup per CU is not the way to more waves).  Measured +7 % on gate/up only; kept as a tuning option.
+#define QMG_NC_WIDE 15
+template <int MT, int WT>
+__global__ void __launch_bounds__(1024) qmm_gemm16_kernel(const QmmArgs a, const uint8_t* __restrict__ img, float* __restrict__ part,
+                                                          const int ldp, const int n_slots, const int slot_base) {
+    qmm_gemm_body<MT, WT, QMG_NC_WIDE>(a, img, part, ldp, 0, a.nseg, n_slots, slot_base, (int)blockIdx.x);
+}
+// two runs of segments in ONE launch (q, k in Q4_K + v in Q6_K: the v run alone is 10 workgroups x 13 us): the first nwg0
+// workgroups take run 0 with the WTA body, the rest run 1 with the WTB body -- a uniform branch between two specialised
+// bodies, not the per-wave type dispatch of a mixed build.  (At the 128-VGPR bound of the single-run kernels the two inlined
+// bodies spill 39 dwords and the launch is as slow as the two it replaces; such launches have < 256 workgroups, so the
+// second workgroup per CU that bound buys is never used.)
+template <int MT, int WTA, int WTB>
+__global__ void __launch_bounds__(512, 2) qmm_gemm2_kernel(const QmmArgs a, const uint8_t* __restrict__ img, float* __restrict__ part,
+                                                           const int ldp, const int s_split, const int slots0, const int slots1) {
+    const int nwg0 = (slots0 + QMG_NC - 1) / QMG_NC;
+    if ((int)blockIdx.x < nwg0) qmm_gemm_body<MT, WTA>(a, img, part, ldp, 0, s_split, slots0, 0, (int)blockIdx.x);
+    else qmm_gemm_body<MT, WTB>(a, img, part, ldp, s_split, a.nseg, slots1, slots0, (int)blockIdx.x - nwg0);
 }
 
 // partial sums -> epilogue; one thread per (token, concatenated padded row)
@@ -1174,6 +1201,8 @@ static QmgStream& qmg_stream(hipStream_t st) {
     return g_qmg_streams[std::make_pair(dev, st)];              // std::map: the reference stays valid across later inserts
 }
 static int g_tune_chain = 1;                                  // mi355_set_tuning(9, 0): never chain (A/B experiments)
+static int g_tune_wide16 = 0;                                 // mi355_set_tuning(15, n): launches of >= n (row tile x k-block) units use 16-wave workgroups
+static int g_tune_merge = 1;                                  // mi355_set_tuning(14, 0): one launch per run of same-type segments (A/B)
 static int g_tune_ks_target = 1024;                           // mi355_set_tuning(10, n): split K until a launch has n row-tile x k-split slots
 static inline int qmg_buf(void** p, int key, size_t need, hipStream_t st) { return mi355_scratch_get(p, key, need, st, false); }
 
@@ -1189,8 +1218,11 @@ static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
     // split K until the launch has >= 1024 (row tile, k-split) slots = 4 consumer waves per CU, keeping >= 2 k-blocks per
     // workgroup.  (Measured at batch 32: targets 512 / 768 / 1024 / 1280 / 1536 / 2048 / 4096 -> 4081 / 4634 / 4835-4900 /
     // 4737 / 4742 / 4686 / 4607 tok/s: less splitting = fewer partial sums for the epilogue and longer pipelines.)
+    const bool wide16 = g_tune_wide16 > 0 && (int64_t)n_slots * nkb >= g_tune_wide16;
+    const int NCq = wide16 ? QMG_NC_WIDE : QMG_NC;
     int ks = 1;
-    while (n_slots * ks < g_tune_ks_target && nkb / (ks * 2) >= 2) ks *= 2;
+    if (wide16) { while ((n_slots + NCq - 1) / NCq * ks < 200 && nkb / (ks * 2) >= 4) ks *= 2; }
+    else { while (n_slots * ks < g_tune_ks_target && nkb / (ks * 2) >= 2) ks *= 2; }
     // activation image: staged by the previous launch's epilogue (chain) or by the prep kernel now
     QmgStream& qs = qmg_stream(st);
     const bool chained = qs.chain.valid && qs.chain.x == a.x && qs.chain.B == a.B && qs.chain.K == a.K &&
@@ -1211,6 +1243,9 @@ static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)qmm_gemm_kernel<MT, MI355_GGML_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qmm_gemm_kernel<MT, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qmm_gemm2_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qmm_gemm16_kernel<MT, MI355_GGML_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qmm_gemm16_kernel<MT, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     uint8_t* img = static_cast<uint8_t*>(imgp);
@@ -1218,15 +1253,28 @@ static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
     if (!chained) hipLaunchKernelGGL((qmm_prep2_kernel<MT>), dim3(nkb, MT), dim3(256), 0, st, img, ssp, a, kbb);
     // one GEMM launch per run of same-type segments: the type-specialised builds need no schedule pinning and do not
     // spill (the mixed build did); each run writes its own columns of the partial-sum buffer
-    for (int s0 = 0, slot_base = 0; s0 < a.nseg;) {
+    int s_split = 0, slots0 = 0;                                     // exactly one Q4_K run followed by one Q6_K run: one launch
+    while (s_split < a.nseg && a.seg[s_split].type == MI355_GGML_Q4_K) slots0 += a.seg[s_split++].n_tiles;
+    bool two_runs = g_tune_merge && !wide16 && s_split > 0 && s_split < a.nseg;
+    for (int q = s_split; q < a.nseg; ++q) two_runs = two_runs && a.seg[q].type == MI355_GGML_Q6_K;
+    if (two_runs) {
+        const int slots1 = n_slots - slots0;
+        const dim3 ggrid((slots0 + QMG_NC - 1) / QMG_NC + (slots1 + QMG_NC - 1) / QMG_NC, ks);
+        hipLaunchKernelGGL((qmm_gemm2_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, a, img, part, ldp, s_split, slots0, slots1);
+    }
+    for (int s0 = 0, slot_base = 0; s0 < a.nseg && !two_runs;) {
         int s1 = s0 + 1;
         while (s1 < a.nseg && a.seg[s1].type == a.seg[s0].type) ++s1;
         QmmArgs r = a;
         r.nseg = s1 - s0;
         int run_slots = 0;
         for (int q = 0; q < r.nseg; ++q) { r.seg[q] = a.seg[s0 + q]; run_slots += r.seg[q].n_tiles; }
-        const dim3 ggrid((run_slots + QMG_NC - 1) / QMG_NC, ks);
-        if (r.seg[0].type == MI355_GGML_Q4_K)
+        const dim3 ggrid((run_slots + NCq - 1) / NCq, ks);
+        if (wide16 && r.seg[0].type == MI355_GGML_Q4_K)
+            hipLaunchKernelGGL((qmm_gemm16_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(1024), 2 * kbb, st, r, img, part, ldp, run_slots, slot_base);
+        else if (wide16)
+            hipLaunchKernelGGL((qmm_gemm16_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(1024), 2 * kbb, st, r, img, part, ldp, run_slots, slot_base);
+        else if (r.seg[0].type == MI355_GGML_Q4_K)
             hipLaunchKernelGGL((qmm_gemm_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), 2 * kbb, st, r, img, part, ldp, run_slots, slot_base);
         else
             hipLaunchKernelGGL((qmm_gemm_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, r, img, part, ldp, run_slots, slot_base);
@@ -1499,6 +1547,8 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     if (key == 0) g_tune_nw = value;
     else if (key == 1) g_tune_r = value;
     else if (key == 2) g_tune_dbg = value;
+    else if (key == 14) g_tune_merge = value;
+    else if (key == 15) g_tune_wide16 = value;
     else if (key == 3) mi355_pa_set_fused(value);
     else if (key == 5) mi355_host_set_partition_override(value);
     else if (key == 6) g_tune_prefill_gemm = value;
