@@ -764,55 +764,77 @@ __device__ __forceinline__ uint2 bytes4_to_bf16x4(uint32_t w) {
     return make_uint2((__float_as_uint(f0) >> 16) | (__float_as_uint(f1) & 0xFFFF0000u),
                       (__float_as_uint(f2) >> 16) | (__float_as_uint(f3) & 0xFFFF0000u));
 }
+// Third-generation wide operands: the image is f16 (hi = f16(x / 16), lo = f16(x / 16 - hi): 22 mantissa bits, range
+// 1e6) so that the B operand can carry the 6-bit sub-block scale EXACTLY: f16(1024 + q) is `0x6400 | q`, one packed
+// fma(1024 + q, sc, -1024 sc) = sc q (<= 945 < 2048: exact).  The eight sub-blocks of a k-block then chain in the MFMA
+// accumulator and the super-block scale is applied once:  y += 16 d acc - 16 dmin sum_j m_j S_j.  Per 2304-B unit at 32
+// tokens the VALU work drops from ~300 to ~170 instructions (the launch was VALU-issue-bound: 8.6 M VALU instructions per
+// gate/up launch = 14 us of a SIMD's issue slots out of 32 us, with the scale FMAs chained behind every MFMA).
+typedef _Float16 qmg_h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 qmg_h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 qmg_h8 __attribute__((ext_vector_type(8)));
+#define QMG_XSCALE 0.0625f          // image = x / 16 ...
+#define QMG_XUNSCALE 16.0f          // ... folded back into d / dmin
+#define QMG_LOSCALE 2048.0f         // lo plane = (x / 16 - hi) * 2^11 ...
+#define QMG_LOUNSCALE (1.0f / 2048.0f)   // ... folded back when the hi and lo rows of the result meet
 template <int MT>
 __device__ __forceinline__ void wide_q4k2(const TileRegs& w, const uint8_t* __restrict__ L, int lane, float (&y)[MT][4]) {
     const int m = lane & 15, kg = lane >> 4;
     const uint8_t* sfrag = L + (size_t)32 * MT * 16 * 16;           // [MT][kg 4][row 16][4 bf16]
-    const float d = f16_bits_to_f32((uint16_t)(w.a.x & 0xFFFF));
-    const float dmin = f16_bits_to_f32((uint16_t)(w.a.x >> 16));
+    const float d = QMG_XUNSCALE * f16_bits_to_f32((uint16_t)(w.a.x & 0xFFFF));
+    const float ndmin = -QMG_XUNSCALE * f16_bits_to_f32((uint16_t)(w.a.x >> 16));
     const uint32_t s0 = w.a.y, s1 = w.a.z, s2 = w.a.w;
     const uint32_t scl = s0 & 0x3F3F3F3Fu, mnl = s1 & 0x3F3F3F3Fu;
     const uint32_t sch = (s2 & 0x0F0F0F0Fu) | ((s0 >> 2) & 0x30303030u);
     const uint32_t mnh = ((s2 >> 4) & 0x0F0F0F0Fu) | ((s1 >> 2) & 0x30303030u);
-    // B fragments of the two small MFMAs: k = 4kg + e  <->  j = 4(kg & 1) + e  (both pieces of S use the same values)
-    const uint2 mb = bytes4_to_bf16x4((kg & 1) ? mnh : mnl), sb = bytes4_to_bf16x4((kg & 1) ? sch : scl);
-    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
-    uint32_t nib = 0x000F000Fu;
-    asm volatile("" : "+v"(nib));
+    // B fragment of the minimum term: k = 4kg + e  <->  j = 4(kg & 1) + e  (both pieces of S use the same values)
+    const uint2 mb = bytes4_to_bf16x4((kg & 1) ? mnh : mnl);
+    uint32_t nib = 0x000F000Fu, c1024 = 0x64006400u;
+    asm volatile("" : "+v"(nib), "+v"(c1024));                       // in VGPRs: "(w >> s) & nib | c1024" is one v_and_or_b32
+    const qmg_h2 k1024 = {(_Float16)1024.f, (_Float16)1024.f}, kneg = {(_Float16)(-1024.f), (_Float16)(-1024.f)};
+    // the eight scales as f16 pairs: 1024 + sc is 0x6400 | sc, minus 1024 in one packed add
+    qmg_h2 scp[4];                                                    // (sc0,sc2) (sc1,sc3) (sc4,sc6) (sc5,sc7)
+    scp[0] = __builtin_bit_cast(qmg_h2, (scl & 0x00FF00FFu) | c1024) - k1024;
+    scp[1] = __builtin_bit_cast(qmg_h2, ((scl >> 8) & 0x00FF00FFu) | c1024) - k1024;
+    scp[2] = __builtin_bit_cast(qmg_h2, (sch & 0x00FF00FFu) | c1024) - k1024;
+    scp[3] = __builtin_bit_cast(qmg_h2, ((sch >> 8) & 0x00FF00FFu) | c1024) - k1024;
+    f32x4_t acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float dsc = d * (float)(((j < 4 ? scl : sch) >> (8 * (j & 3))) & 0xFF);
+        const qmg_h2 pr2 = scp[2 * (j >> 2) + (j & 1)];               // holds sc_j in half (j >> 1) & 1
+        const _Float16 sj = ((j >> 1) & 1) ? pr2[1] : pr2[0];
+        const qmg_h2 S = {sj, sj}, OFF = S * kneg;
         const int p = j >> 2, pr = (j >> 1) & 1, sh = (j & 1) * 4;
         const uint4 qs = p ? w.c : w.b;
         const uint32_t w0 = pr ? qs.z : qs.x, w1 = pr ? qs.w : qs.y;
-        uint4 bw;
-        bw.x = ((w0 >> sh) & nib) | BF16_128;
-        bw.y = ((w0 >> (sh + 8)) & nib) | BF16_128;
-        bw.z = ((w1 >> sh) & nib) | BF16_128;
-        bw.w = ((w1 >> (sh + 8)) & nib) | BF16_128;
+        const qmg_h2 r0 = __builtin_elementwise_fma(__builtin_bit_cast(qmg_h2, ((w0 >> sh) & nib) | c1024), S, OFF);
+        const qmg_h2 r1 = __builtin_elementwise_fma(__builtin_bit_cast(qmg_h2, ((w0 >> (sh + 8)) & nib) | c1024), S, OFF);
+        const qmg_h2 r2 = __builtin_elementwise_fma(__builtin_bit_cast(qmg_h2, ((w1 >> sh) & nib) | c1024), S, OFF);
+        const qmg_h2 r3 = __builtin_elementwise_fma(__builtin_bit_cast(qmg_h2, ((w1 >> (sh + 8)) & nib) | c1024), S, OFF);
+        const qmg_h8 bw = {r0[0], r0[1], r1[0], r1[1], r2[0], r2[1], r3[0], r3[1]};
         const uint8_t* abase = L + ((size_t)(4 * j + kg) * (MT * 16) + m) * 16;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const uint4 aw = *reinterpret_cast<const uint4*>(abase + (size_t)mt * 16 * 16);
-            const f32x4_t acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw),
-                                                                        __builtin_bit_cast(bf16x8_t, bw), zero, 0, 0, 0);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) y[mt][v] = fmaf(dsc, acc[v], y[mt][v]);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(qmg_h8, aw), bw, acc[mt], 0, 0, 0);
         }
     }
-    const float nd128 = -128.f * d, ndmin = -dmin;
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const uint2 sa = *reinterpret_cast<const uint2*>(sfrag + ((size_t)(mt * 4 + kg) * 16 + m) * 8);
         const f32x4_t t1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, sa), __builtin_bit_cast(s16x4_t, mb), zero, 0, 0, 0);
-        const f32x4_t t2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, sa), __builtin_bit_cast(s16x4_t, sb), zero, 0, 0, 0);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) y[mt][v] = fmaf(ndmin, t1[v], fmaf(nd128, t2[v], y[mt][v]));
+        for (int v = 0; v < 4; ++v) y[mt][v] = fmaf(ndmin, t1[v], fmaf(d, acc[mt][v], y[mt][v]));
     }
 }
 
-// Q6_K on the wide path: the "-32 +128" code offset (160) is removed by ONE K=32 MFMA per m-tile against the staged
-// 16-element sub-block sums, T = sum_s sc_s S_s  ->  y -= 160 d T, instead of 4 FMAs per MFMA and token group.
+// Q6_K on the wide path: the code rides in mantissa bits 9..4 of f16 64.0 (`0x5400 | c << 4` = 64 + c), the "-32 +64"
+// offset (96) is removed by ONE K=32 MFMA per m-tile against the staged 16-element sub-block sums, T = sum_s sc_s S_s
+// ->  y -= 96 d T.  (The int8 scale times the 6-bit code does not fit f16's 11 bits, so the scale stays a VALU FMA per
+// sub-block here.)
 __device__ __forceinline__ uint32_t i8pair_to_bf16x2(uint32_t w, int lo_shift) {
     const float f0 = (float)(int)(int8_t)((w >> lo_shift) & 0xFF), f1 = (float)(int)(int8_t)((w >> (lo_shift + 8)) & 0xFF);
     return (__float_as_uint(f0) >> 16) | (__float_as_uint(f1) & 0xFFFF0000u);      // |integers| <= 128: exact in bf16
@@ -821,24 +843,24 @@ template <int MT>
 __device__ __forceinline__ void wide_q6k(const TileRegs& w, const uint8_t* __restrict__ L, int lane, float (&y)[MT][4]) {
     const int m = lane & 15, kg = lane >> 4;
     const uint8_t* sf16 = L + (size_t)32 * MT * 16 * 16 + (size_t)MT * 512;     // [MT][kg 4][row 16][8 bf16]
-    const float d = f16_bits_to_f32((uint16_t)(w.e & 0xFFFF));
+    const float d = QMG_XUNSCALE * f16_bits_to_f32((uint16_t)(w.e & 0xFFFF));
     const uint32_t scw[4] = {w.a.x, w.a.y, w.a.z, w.a.w};
     const uint32_t qhw[4] = {w.d.x, w.d.y, w.d.z, w.d.w};
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
     {   // B fragment of the offset MFMA: k = 8kg + e  <->  sub-block s = 8(kg & 1) + e (both pieces of S use the same scales)
         const uint32_t s_lo = (kg & 1) ? scw[2] : scw[0], s_hi = (kg & 1) ? scw[3] : scw[1];
         const uint4 sb = make_uint4(i8pair_to_bf16x2(s_lo, 0), i8pair_to_bf16x2(s_lo, 16), i8pair_to_bf16x2(s_hi, 0), i8pair_to_bf16x2(s_hi, 16));
-        const float nd160 = -160.f * d;
+        const float nd96 = -96.f * d;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const uint4 sa = *reinterpret_cast<const uint4*>(sf16 + ((size_t)(mt * 4 + kg) * 16 + m) * 16);
             const f32x4_t t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, sa), __builtin_bit_cast(bf16x8_t, sb), zero, 0, 0, 0);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) y[mt][v] = fmaf(nd160, t[v], y[mt][v]);
+            for (int v = 0; v < 4; ++v) y[mt][v] = fmaf(nd96, t[v], y[mt][v]);
         }
     }
-    uint32_t bmask = 0x00FF00FFu;
-    asm volatile("" : "+v"(bmask));
+    uint32_t cmask = 0x03F003F0u, c64 = 0x54005400u;
+    asm volatile("" : "+v"(cmask), "+v"(c64));
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const uint4 ql = n ? w.c : w.b;
@@ -854,16 +876,15 @@ __device__ __forceinline__ void wide_q6k(const TileRegs& w, const uint8_t* __res
             for (int tt = 0; tt < 4; ++tt) {
                 const int s = 8 * n + 2 * tt + is;
                 uint2 bw;
-                bw.x = (t[tt] & bmask) | BF16_128;
-                bw.y = ((t[tt] >> 8) & bmask) | BF16_128;
+                bw.x = ((t[tt] << 4) & cmask) | c64;                  // elements (b0, b2): 64 + c
+                bw.y = ((t[tt] >> 4) & cmask) | c64;                  // elements (b1, b3)
                 const int sc8 = (int)(int8_t)((scw[s >> 2] >> (8 * (s & 3))) & 0xFF);
                 const float dsc = d * (float)sc8;
                 const uint8_t* abase = L + ((size_t)(2 * s + (kg >> 1)) * (MT * 16) + m) * 16 + (kg & 1) * 8;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const uint2 aw = *reinterpret_cast<const uint2*>(abase + (size_t)mt * 16 * 16);
-                    const f32x4_t acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, aw),
-                                                                                  __builtin_bit_cast(s16x4_t, bw), zero, 0, 0, 0);
+                    const f32x4_t acc = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(qmg_h4, aw), __builtin_bit_cast(qmg_h4, bw), zero, 0, 0, 0);
 #pragma unroll
                     for (int v = 0; v < 4; ++v) y[mt][v] = fmaf(dsc, acc[v], y[mt][v]);
                 }
@@ -890,6 +911,9 @@ static inline size_t qmg_kb_bytes(int MT) { return (((size_t)MT * 8 * 1216) + 10
 __device__ __forceinline__ void qmg_prep_entry(uint8_t* __restrict__ img, float* __restrict__ ssp, float (&v)[8], const bool live,
                                                const float* __restrict__ norm_w, const int MT, const size_t kbb,
                                                const int kb, const int b, const int El) {
+    // the two call sites (staging kernel, chained epilogue) must produce the same bits from the same values: no
+    // compiler-chosen fused multiply-adds in the sums below (a contraction picked differently per kernel = 1 ulp of 1/rms)
+#pragma clang fp contract(off)
     const int BP = MT * 8;
     uint8_t* kbase = img + (size_t)kb * kbb;
     const int mt = b >> 3, m = b & 7;
@@ -901,17 +925,29 @@ __device__ __forceinline__ void qmg_prep_entry(uint8_t* __restrict__ img, float*
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] *= norm_w[k + i];
     }
-    const uint32_t h02 = cvt_pk_bf16(v[0], v[2]), h13 = cvt_pk_bf16(v[1], v[3]);
-    const uint32_t h46 = cvt_pk_bf16(v[4], v[6]), h57 = cvt_pk_bf16(v[5], v[7]);
-    const float hf[8] = {bf16lo_to_f32(h02), bf16lo_to_f32(h13), bf16hi_to_f32(h02), bf16hi_to_f32(h13),
-                         bf16lo_to_f32(h46), bf16lo_to_f32(h57), bf16hi_to_f32(h46), bf16hi_to_f32(h57)};
-    const uint32_t l02 = cvt_pk_bf16(v[0] - hf[0], v[2] - hf[2]), l13 = cvt_pk_bf16(v[1] - hf[1], v[3] - hf[3]);
-    const uint32_t l46 = cvt_pk_bf16(v[4] - hf[4], v[6] - hf[6]), l57 = cvt_pk_bf16(v[5] - hf[5], v[7] - hf[7]);
+    // f16 hi / lo of x / 16 (element order {0,2,1,3,4,6,5,7} inside the 8-group, as the B operands unpack)
+    auto pk = [](float a0, float a1) {
+        const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+        return (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+    };
+    auto lo16 = [](uint32_t w2) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w2 & 0xFFFF)); };
+    auto hi16 = [](uint32_t w2) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w2 >> 16)); };
+    float xs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xs[i] = fminf(fmaxf(v[i] * QMG_XSCALE, -65504.f), 65504.f);
+    // no f16 denormals on either plane: a value below f16's smallest normal goes to the (scaled) lo plane entirely
+    auto nz = [](float t) { return fabsf(t) < 6.103515625e-05f ? 0.f : t; };
+    const uint32_t h02 = pk(nz(xs[0]), nz(xs[2])), h13 = pk(nz(xs[1]), nz(xs[3]));
+    const uint32_t h46 = pk(nz(xs[4]), nz(xs[6])), h57 = pk(nz(xs[5]), nz(xs[7]));
+    const float hf[8] = {lo16(h02), lo16(h13), hi16(h02), hi16(h13), lo16(h46), lo16(h57), hi16(h46), hi16(h57)};
+    // the lo plane is stored times 2^11 (the residual of an f16 rounding is 2^-11 of the value: unscaled it would sit in
+    // f16's denormal range for every |x| < 2); the GEMM folds 2^-11 back into the lo rows of its result
+    const uint32_t l02 = pk((xs[0] - hf[0]) * QMG_LOSCALE, (xs[2] - hf[2]) * QMG_LOSCALE), l13 = pk((xs[1] - hf[1]) * QMG_LOSCALE, (xs[3] - hf[3]) * QMG_LOSCALE);
+    const uint32_t l46 = pk((xs[4] - hf[4]) * QMG_LOSCALE, (xs[6] - hf[6]) * QMG_LOSCALE), l57 = pk((xs[5] - hf[5]) * QMG_LOSCALE, (xs[7] - hf[7]) * QMG_LOSCALE);
     float hsum = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) hsum += hf[i];
-    const float lsum = (bf16lo_to_f32(l02) + bf16hi_to_f32(l02)) + (bf16lo_to_f32(l13) + bf16hi_to_f32(l13)) +
-                       (bf16lo_to_f32(l46) + bf16hi_to_f32(l46)) + (bf16lo_to_f32(l57) + bf16hi_to_f32(l57));
+    const float lsum = (lo16(l02) + hi16(l02)) + (lo16(l13) + hi16(l13)) + (lo16(l46) + hi16(l46)) + (lo16(l57) + hi16(l57));
     uint8_t* ent = kbase + ((size_t)El * (MT * 16) + mt * 16) * 16;
     *reinterpret_cast<uint4*>(ent + (size_t)m * 16) = make_uint4(h02, h13, h46, h57);
     *reinterpret_cast<uint4*>(ent + (size_t)(8 + m) * 16) = make_uint4(l02, l13, l46, l57);
@@ -1044,7 +1080,10 @@ __device__ __forceinline__ void qmm_gemm_body(const QmmArgs& a, const uint8_t* _
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) y[0][mt][v] += __shfl_xor(y[0][mt][v], 32, 64);
+        for (int v = 0; v < 4; ++v) {
+            const float yy = kg >= 2 ? y[0][mt][v] * QMG_LOUNSCALE : y[0][mt][v];     // MFMA rows 8..15 = the lo plane
+            y[0][mt][v] = yy + __shfl_xor(yy, 32, 64);
+        }
     if (have && kg < 2) {
         float* pp = part + (size_t)blockIdx.y * BP * ldp + (size_t)(slot_base + slot) * 16 + rr;
 #pragma unroll

@@ -1,0 +1,7 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/call_s
+mkdir -p $OUT
+cd $R
+timeout 200 python tools/exp_chain_det.py 2>&1 | tail -6
+timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py tests/test_gpu_engine.py tests/test_gpu_prefill.py -q -m gpu > $OUT/pytest.log 2>&1; grep -E "passed|failed|Error|error" $OUT/pytest.log | tail -5
