@@ -251,6 +251,46 @@ int64_t mi355_gguf_tensor_shard(void* h, int32_t i, int32_t dim, int32_t rank, i
     return (int64_t)n;
 }
 
+// IEEE binary16 <-> binary32 in plain integer arithmetic (round to nearest even, subnormals kept): the host side must not
+// depend on a compiler's _Float16 (g++ has none in C++ mode; the sanitizer build uses g++)
+static inline float half_bits_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1Fu, man = h & 0x3FFu;
+    uint32_t u;
+    if (exp == 0) {
+        if (man == 0) { u = sign; }
+        else {                                                    // subnormal: normalise
+            int e = -1;
+            uint32_t m = man;
+            do { ++e; m <<= 1; } while (!(m & 0x400u));
+            u = sign | ((uint32_t)(127 - 15 - e) << 23) | ((m & 0x3FFu) << 13);
+        }
+    } else if (exp == 31) { u = sign | 0x7F800000u | (man << 13); }
+    else { u = sign | ((exp + 112u) << 23) | (man << 13); }
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline uint16_t float_to_half_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7FFFFFFFu;
+    if (u >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | (u > 0x7F800000u ? 0x200u : 0u));   // inf / nan
+    if (u >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);                                        // rounds to inf (>= 65520)
+    if (u < 0x33000001u) return (uint16_t)sign;                                                     // <= 2^-25: rounds to zero
+    const int e = (int)(u >> 23) - 127;
+    uint32_t man = (u & 0x7FFFFFu) | 0x800000u;
+    int shift = e < -14 ? 13 + (-14 - e) : 13;                                                      // subnormal results lose more bits
+    uint32_t hm = man >> shift;
+    const uint32_t rem = man & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (hm & 1u))) ++hm;
+    const uint32_t he = e < -14 ? 0u : (uint32_t)(e + 15);
+    // hm carries the implicit bit for normal results: (he << 10) + (hm - 0x400) == ((he - 1) << 10) + hm; a mantissa carry rolls into the exponent
+    const uint32_t out = e < -14 ? hm : (((he - 1u) << 10) + hm);
+    return (uint16_t)(sign | out);
+}
+
+
 /* The reference's fallback for a dim-1 shard that cuts a quantisation block (`get_sharded_no_shape`,
  * layers/quantized_var_builder.rs:234-269): dequantise the WHOLE tensor to f16 (`dequantize_f16`: f32 arithmetic of the block
  * format, one rounding to f16), narrow columns [rank*c, (rank+1)*c), re-quantise -- to Q8_0 when c is not a multiple of the
@@ -274,7 +314,7 @@ int64_t mi355_gguf_tensor_shard_q8_0(void* h, int32_t i, int32_t rank, int32_t w
     const uint64_t bb = t.type == 12 ? 144 : 210, nb = cols / 256;
     const uint8_t* src = g->base + g->data_off + t.offset;
     uint8_t* dst = static_cast<uint8_t*>(out);
-    auto f16 = [](const uint8_t* p) { uint16_t u; memcpy(&u, p, 2); _Float16 v; memcpy(&v, &u, 2); return (float)v; };
+    auto f16 = [](const uint8_t* p) { uint16_t u; memcpy(&u, p, 2); return half_bits_to_float(u); };
     try {
         std::vector<float> row(cols);
 #pragma omp parallel for schedule(static) firstprivate(row)
@@ -319,9 +359,9 @@ int64_t mi355_gguf_tensor_shard_q8_0(void* h, int32_t i, int32_t rank, int32_t w
             const float* x = row.data() + (uint64_t)rank * c;
             for (uint64_t b = 0; b < c / 32; ++b) {
                 float v[32], amax = 0.f;
-                for (int j = 0; j < 32; ++j) { v[j] = (float)(_Float16)x[b * 32 + j]; amax = fmaxf(amax, fabsf(v[j])); }   // dequantize_f16: one rounding
+                for (int j = 0; j < 32; ++j) { v[j] = half_bits_to_float(float_to_half_bits(x[b * 32 + j])); amax = fmaxf(amax, fabsf(v[j])); }   // dequantize_f16: one rounding
                 const float d = amax / 127.f, id = d != 0.f ? 1.f / d : 0.f;
-                const _Float16 dh = (_Float16)d;
+                const uint16_t dh = float_to_half_bits(d);
                 memcpy(orow + b * 34, &dh, 2);
                 for (int j = 0; j < 32; ++j) orow[b * 34 + 2 + j] = (uint8_t)(int8_t)roundf(v[j] * id);
             }

@@ -577,8 +577,19 @@ __device__ __forceinline__ void qmm_epilogue(const QmmArgs& a, const float* red,
     }
 }
 
+// experiments only (dbg 7): per-wave timestamps [workgroup][wave 16][4] = entry, main loop done, past the barrier, exit
+__device__ unsigned long long* g_qmm_ts = nullptr;
+extern "C" int mi355_debug_set_timestamps(void* dev_ptr) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_qmm_ts), &dev_ptr, sizeof(dev_ptr));
+}
+__device__ __forceinline__ void qmm_stamp(const QmmArgs& a, int i) {
+    if (a.dbg == 7 && (threadIdx.x & 63) == 0 && g_qmm_ts)
+        g_qmm_ts[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 4 + i] = wall_clock64();
+}
+
 template <int BT, int R, int WT>
 __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
+    qmm_stamp(a, 0);
     constexpr int NV = BT < 4 ? BT : 4;
     constexpr int PF = (R > QMM_PF_MIN) ? R : QMM_PF_MIN;
     constexpr int PFK = PF / R;                                  // ring depth in k-blocks
@@ -650,14 +661,14 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
         for (int q = 0; q < PFK; ++q) {
             const int kbi = kbi0 + q;
             const bool active = kbi < n_my_kb;                    // wave-uniform
-            if (active && a.dbg < 3) stage_kblock3<BT>(a, xr[q], ximg, lane, ss);
+            if (active && (a.dbg < 3 || a.dbg == 7)) stage_kblock3<BT>(a, xr[q], ximg, lane, ss);
             const int kbn = wave + NW * (kbi + PFK);
-            if (a.dbg < 3) xr[q] = load_x<BT>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp);
+            if (a.dbg < 3 || a.dbg == 7) xr[q] = load_x<BT>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp);
             const bool ok = kbi + PFK < n_my_kb;
             if constexpr (WT != 0) {
                 // every tile of the launch has one type: the R tiles of this k-block share C_in and the A fragments
                 if (active) {
-                    if (a.dbg >= 1) {
+                    if (a.dbg >= 1 && a.dbg != 7) {
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
                             const TileRegs& t = buf[q * R + r];
@@ -681,7 +692,7 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
                 for (int r = 0; r < R; ++r) {
                     const int s = q * R + r;
                     if (active) {
-                        if (a.dbg >= 1) {
+                        if (a.dbg >= 1 && a.dbg != 7) {
                             y[r][0] += __uint_as_float((buf[s].a.x ^ buf[s].b.x ^ buf[s].c.x ^ buf[s].d.x ^ buf[s].b.w ^ buf[s].c.w) & 0x3FFFFFu);
                         } else if (wtype[r] == MI355_GGML_Q4_K) {
                             compute3_q4k<BT, NV, 1>(&buf[s], ximg, lane, &y[r]);
@@ -702,6 +713,7 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
         if (t == 1.2345e-30f) a.out[0] = t;
         return;
     }
+    qmm_stamp(a, 1);
     // ---- hi + lo, then cross-wave reduction in LDS.  After the xor-32 add, lanes 0..31 hold batch 4*kg+v.
     const int kg = lane >> 4, row = lane & 15;
 #pragma unroll
@@ -720,14 +732,14 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
         }
     }
     __syncthreads();
+    qmm_stamp(a, 2);
 
     qmm_epilogue<BT, R>(a, red, red_ss, NW, segi, tile, ep);
+    qmm_stamp(a, 3);
 }
 
 template <int BT, int R, int WT>
 __global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) { qmm_body<BT, R, WT>(a); }
-
-
 // MoE variant (decode-shaped, BT = 1): blockIdx.y = (token, slot) pair.  The adjusted descriptor is a private copy
 // -- kept out of the dense kernel, where the kernel arguments must stay scalar loads from the kernarg segment.
 template <int R, int WT>
