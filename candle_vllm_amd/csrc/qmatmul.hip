@@ -760,7 +760,7 @@ __global__ void __launch_bounds__(512) qmm_moe_kernel(const QmmArgs a_in) {
 // workgroup own different row tiles and sweep K together, sharing one LDS image of the activations per k-block
 // (double-buffered, one barrier per k-block).  The image (hi/lo bf16 fragments + sub-block sums, RMSNorm weight already
 // applied) is produced by `qmg_prep_entry` -- in the staging launch or in the previous mat-mul's epilogue.
-//   image of k-block kb:  ximg [32 entries][MT*16 rows][16 B] | S32 fragments [MT][4][16][4 bf16] | S16 fragments [MT][4][16][8 bf16]
+//   image of k-block kb:  ximg [32 entries][MT*16 rows][16 B] | S32 fragments [MT][4][16][4 bf16]   (1088 B per token row)
 //   rows of M-tile mt: mt*16 + m, m<8 = hi(batch 8mt+m), m>=8 = lo(batch 8mt+m-8)
 #define QMW_MAXMT 4
 
@@ -843,66 +843,82 @@ __device__ __forceinline__ void wide_q4k2(const TileRegs& w, const uint8_t* __re
     }
 }
 
-// Q6_K on the wide path: the code rides in mantissa bits 9..4 of f16 64.0 (`0x5400 | c << 4` = 64 + c), the "-32 +64"
-// offset (96) is removed by ONE K=32 MFMA per m-tile against the staged 16-element sub-block sums, T = sum_s sc_s S_s
-// ->  y -= 96 d T.  (The int8 scale times the 6-bit code does not fit f16's 11 bits, so the scale stays a VALU FMA per
-// sub-block here.)
-__device__ __forceinline__ uint32_t i8pair_to_bf16x2(uint32_t w, int lo_shift) {
-    const float f0 = (float)(int)(int8_t)((w >> lo_shift) & 0xFF), f1 = (float)(int)(int8_t)((w >> (lo_shift + 8)) & 0xFF);
-    return (__float_as_uint(f0) >> 16) | (__float_as_uint(f1) & 0xFFFF0000u);      // |integers| <= 128: exact in bf16
-}
+// Q6_K on the wide path.  The int8 sub-block scale times the 6-bit code (|sc (c - 32)| <= 4064) does not fit f16's 11
+// bits, so the scale is split sc = 2 sh + sl (sh = sc >> 1, sl = sc & 1): |sh (c - 32)| <= 2048 and sl (c - 32) are exact.
+// The code rides in mantissa bits 9..4 of f16 64.0 (`0x5400 | c << 4` = 64 + c): one packed fma(64 + c, sh, -96 sh) =
+// sh (c - 32) per part, two MFMA chains per k-block (hi part, lo part) and ONE scaling at the end, y += 16 d (2 acc_h +
+// acc_l) -- instead of a scale FMA per sub-block, m-tile and output (469 -> ~280 VALU per 3360-B tile at 32 tokens; the
+// MFMA count doubles, the matrix pipe was 23 % busy).  A K=32 MFMA spans the two 16-element sub-blocks 2p, 2p+1.
 template <int MT>
 __device__ __forceinline__ void wide_q6k(const TileRegs& w, const uint8_t* __restrict__ L, int lane, float (&y)[MT][4]) {
     const int m = lane & 15, kg = lane >> 4;
-    const uint8_t* sf16 = L + (size_t)32 * MT * 16 * 16 + (size_t)MT * 512;     // [MT][kg 4][row 16][8 bf16]
     const float d = QMG_XUNSCALE * f16_bits_to_f32((uint16_t)(w.e & 0xFFFF));
     const uint32_t scw[4] = {w.a.x, w.a.y, w.a.z, w.a.w};
     const uint32_t qhw[4] = {w.d.x, w.d.y, w.d.z, w.d.w};
-    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
-    {   // B fragment of the offset MFMA: k = 8kg + e  <->  sub-block s = 8(kg & 1) + e (both pieces of S use the same scales)
-        const uint32_t s_lo = (kg & 1) ? scw[2] : scw[0], s_hi = (kg & 1) ? scw[3] : scw[1];
-        const uint4 sb = make_uint4(i8pair_to_bf16x2(s_lo, 0), i8pair_to_bf16x2(s_lo, 16), i8pair_to_bf16x2(s_hi, 0), i8pair_to_bf16x2(s_hi, 16));
-        const float nd96 = -96.f * d;
+    uint32_t cmask = 0x03F003F0u, c64 = 0x54005400u, c1024 = 0x64006400u, bmask = 0x00FF00FFu;
+    asm volatile("" : "+v"(cmask), "+v"(c64), "+v"(c1024), "+v"(bmask));
+    const qmg_h2 k1088 = {(_Float16)1088.f, (_Float16)1088.f}, k1024 = {(_Float16)1024.f, (_Float16)1024.f};
+    const qmg_h2 kn96 = {(_Float16)(-96.f), (_Float16)(-96.f)};
+    // scale parts of the 16 sub-blocks as f16 pairs: word q holds sub-blocks 4q..4q+3; [q][0] = (s0, s2), [q][1] = (s1, s3)
+    qmg_h2 SH[4][2], SL[4][2];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const uint4 sa = *reinterpret_cast<const uint4*>(sf16 + ((size_t)(mt * 4 + kg) * 16 + m) * 16);
-            const f32x4_t t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, sa), __builtin_bit_cast(bf16x8_t, sb), zero, 0, 0, 0);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) y[mt][v] = fmaf(nd96, t[v], y[mt][v]);
-        }
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t uh = ((scw[q] ^ 0x80808080u) >> 1) & 0x7F7F7F7Fu;      // bytes sh + 64
+        const uint32_t ul = scw[q] & 0x01010101u;                              // bytes sl
+        SH[q][0] = __builtin_bit_cast(qmg_h2, (uh & bmask) | c1024) - k1088;
+        SH[q][1] = __builtin_bit_cast(qmg_h2, ((uh >> 8) & bmask) | c1024) - k1088;
+        SL[q][0] = __builtin_bit_cast(qmg_h2, (ul & bmask) | c1024) - k1024;
+        SL[q][1] = __builtin_bit_cast(qmg_h2, ((ul >> 8) & bmask) | c1024) - k1024;
     }
-    uint32_t cmask = 0x03F003F0u, c64 = 0x54005400u;
-    asm volatile("" : "+v"(cmask), "+v"(c64));
+    f32x4_t acch[MT], accl[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { acch[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; accl[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const uint4 ql = n ? w.c : w.b;
+        uint32_t t[2][4];
 #pragma unroll
         for (int is = 0; is < 2; ++is) {
             const uint32_t a = is ? ql.z : ql.x, b = is ? ql.w : ql.y, h = qhw[2 * n + is];
-            uint32_t t[4];
-            t[0] = (a & 0x0F0F0F0Fu) | ((h << 4) & 0x30303030u);
-            t[1] = (b & 0x0F0F0F0Fu) | ((h << 2) & 0x30303030u);
-            t[2] = ((a >> 4) & 0x0F0F0F0Fu) | (h & 0x30303030u);
-            t[3] = ((b >> 4) & 0x0F0F0F0Fu) | ((h >> 2) & 0x30303030u);
+            t[is][0] = (a & 0x0F0F0F0Fu) | ((h << 4) & 0x30303030u);
+            t[is][1] = (b & 0x0F0F0F0Fu) | ((h << 2) & 0x30303030u);
+            t[is][2] = ((a >> 4) & 0x0F0F0F0Fu) | (h & 0x30303030u);
+            t[is][3] = ((b >> 4) & 0x0F0F0F0Fu) | ((h >> 2) & 0x30303030u);
+        }
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const int s = 8 * n + 2 * tt + is;
-                uint2 bw;
-                bw.x = ((t[tt] << 4) & cmask) | c64;                  // elements (b0, b2): 64 + c
-                bw.y = ((t[tt] >> 4) & cmask) | c64;                  // elements (b1, b3)
-                const int sc8 = (int)(int8_t)((scw[s >> 2] >> (8 * (s & 3))) & 0xFF);
-                const float dsc = d * (float)sc8;
-                const uint8_t* abase = L + ((size_t)(2 * s + (kg >> 1)) * (MT * 16) + m) * 16 + (kg & 1) * 8;
+        for (int tt = 0; tt < 4; ++tt) {
+            qmg_h2 bh[4], bl[4];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const uint2 aw = *reinterpret_cast<const uint2*>(abase + (size_t)mt * 16 * 16);
-                    const f32x4_t acc = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(qmg_h4, aw), __builtin_bit_cast(qmg_h4, bw), zero, 0, 0, 0);
+            for (int is = 0; is < 2; ++is) {
+                const int s = 8 * n + 2 * tt + is;                    // 16-element sub-block 0..15
+                const qmg_h2 ph = SH[s >> 2][s & 1], pl = SL[s >> 2][s & 1];
+                const _Float16 sh = ((s >> 1) & 1) ? ph[1] : ph[0], sl = ((s >> 1) & 1) ? pl[1] : pl[0];
+                const qmg_h2 Sh = {sh, sh}, Sl = {sl, sl}, Oh = Sh * kn96, Ol = Sl * kn96;
+                const qmg_h2 c02 = __builtin_bit_cast(qmg_h2, ((t[is][tt] << 4) & cmask) | c64);     // elements (b0, b2): 64 + c
+                const qmg_h2 c13 = __builtin_bit_cast(qmg_h2, ((t[is][tt] >> 4) & cmask) | c64);     // elements (b1, b3)
+                bh[2 * is] = __builtin_elementwise_fma(c02, Sh, Oh); bh[2 * is + 1] = __builtin_elementwise_fma(c13, Sh, Oh);
+                bl[2 * is] = __builtin_elementwise_fma(c02, Sl, Ol); bl[2 * is + 1] = __builtin_elementwise_fma(c13, Sl, Ol);
+            }
+            const qmg_h8 Bh = {bh[0][0], bh[0][1], bh[1][0], bh[1][1], bh[2][0], bh[2][1], bh[3][0], bh[3][1]};
+            const qmg_h8 Bl = {bl[0][0], bl[0][1], bl[1][0], bl[1][1], bl[2][0], bl[2][1], bl[3][0], bl[3][1]};
+            // A: elements 4kg..4kg+3 of sub-block 2p (entry 2 s0 + (kg >> 1), half kg & 1) and the same of sub-block 2p + 1
+            const int s0 = 8 * n + 2 * tt;
+            const uint8_t* abase = L + ((size_t)(2 * s0 + (kg >> 1)) * (MT * 16) + m) * 16 + (kg & 1) * 8;
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) y[mt][v] = fmaf(dsc, acc[v], y[mt][v]);
-                }
+            for (int mt = 0; mt < MT; ++mt) {
+                const uint2 a0 = *reinterpret_cast<const uint2*>(abase + (size_t)mt * 16 * 16);
+                const uint2 a1 = *reinterpret_cast<const uint2*>(abase + (size_t)mt * 16 * 16 + (size_t)2 * (MT * 16) * 16);
+                const qmg_h8 A = __builtin_bit_cast(qmg_h8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+                acch[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, Bh, acch[mt], 0, 0, 0);
+                accl[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, Bl, accl[mt], 0, 0, 0);
             }
         }
     }
+    const float d2 = 2.f * d;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) y[mt][v] = fmaf(d2, acch[mt][v], fmaf(d, accl[mt][v], y[mt][v]));
 }
 
 // ================================================================================================
@@ -912,7 +928,7 @@ __device__ __forceinline__ void wide_q6k(const TileRegs& w, const uint8_t* __res
 // gridDim.y so that every launch has >= ~2048 waves, stays under 128 VGPRs (4 waves per SIMD, two 8-wave workgroups
 // per CU), stages the activation image global -> LDS by DMA (no staging registers), and writes f32 partial sums
 // [ks][token][row]; a small second kernel adds the partials and applies the epilogue (deterministic: no atomics).
-static inline size_t qmg_kb_bytes(int MT) { return (((size_t)MT * 8 * 1216) + 1023) / 1024 * 1024; }
+static inline size_t qmg_kb_bytes(int MT) { return (((size_t)MT * 8 * 1088) + 1023) / 1024 * 1024; }
 
 
 // image + per-k-block sum of squares in ONE pass: grid = k-blocks, a workgroup builds k-block kb for every token
@@ -964,18 +980,7 @@ __device__ __forceinline__ void qmg_prep_entry(uint8_t* __restrict__ img, float*
     *reinterpret_cast<uint4*>(ent + (size_t)m * 16) = make_uint4(h02, h13, h46, h57);
     *reinterpret_cast<uint4*>(ent + (size_t)(8 + m) * 16) = make_uint4(l02, l13, l46, l57);
     const float h16 = hsum + __shfl_xor(hsum, 1, 64), l16 = lsum + __shfl_xor(lsum, 1, 64);
-    const float h32 = h16 + __shfl_xor(h16, 2, 64), l32 = l16 + __shfl_xor(l16, 2, 64);
-    if ((El & 1) == 0) {
-        // 16-element sub-block sums (Q6_K) as the A operand of a K=32 MFMA: per m-tile [kg 4][row 16][8 bf16],
-        // k = 16*piece + s (piece 0 = bf16(S), piece 1 = bf16(S - piece 0)), rows as below
-        const int s16 = El >> 1;
-        uint8_t* sf16 = kbase + (size_t)32 * MT * 16 * 16 + (size_t)MT * 512 + (size_t)mt * 1024;
-        const uint16_t hh = f32_to_bf16(h16), lh = f32_to_bf16(l16);
-        const uint16_t hl = f32_to_bf16(h16 - bf16_to_f32(hh)), ll = f32_to_bf16(l16 - bf16_to_f32(lh));
-        auto at16 = [&](int piece, int row) { return reinterpret_cast<uint16_t*>(sf16 + ((size_t)(2 * piece + (s16 >> 3)) * 16 + row) * 16) + (s16 & 7); };
-        *at16(0, m) = hh; *at16(1, m) = hl;
-        *at16(0, 8 + m) = lh; *at16(1, 8 + m) = ll;
-    }
+    const float h32 = h16 + __shfl_xor(h16, 2, 64), l32 = l16 + __shfl_xor(l16, 2, 64);       // 32-element sub-block sums
     if ((El & 3) == 0) {
         // sub-block sums as the A operand of a K=16 MFMA (Q4_K minimum / offset terms, wide_q4k2): per m-tile
         // [kg 4][row 16][4 bf16], k = 8*piece + j with piece 0 = bf16(S), piece 1 = bf16(S - piece 0) (S to 2^-17, like x);
@@ -1036,7 +1041,7 @@ __device__ __forceinline__ void qmm_gemm_body(const QmmArgs& a, const uint8_t* _
     constexpr int BP = MT * 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nkb = a.K >> 8;
-    const size_t kbb = (((size_t)MT * 8 * 1216) + 1023) / 1024 * 1024;
+    const size_t kbb = (((size_t)MT * 8 * 1088) + 1023) / 1024 * 1024;
     const int kb_per = (nkb + gridDim.y - 1) / gridDim.y;
     const int kb_lo = blockIdx.y * kb_per, kb_hi = min(nkb, kb_lo + kb_per);
     if (kb_lo >= kb_hi) return;                                       // uniform for the workgroup
@@ -1254,6 +1259,7 @@ static QmgStream& qmg_stream(hipStream_t st) {
 static int g_tune_chain = 1;                                  // mi355_set_tuning(9, 0): never chain (A/B experiments)
 static int g_tune_wide16 = 0;                                 // mi355_set_tuning(15, n): launches of >= n (row tile x k-block) units use 16-wave workgroups
 static int g_tune_merge = 1;                                  // mi355_set_tuning(14, 0): one launch per run of same-type segments (A/B)
+static int g_tune_ks_minkb = 2;                               // mi355_set_tuning(17, n): fewest k-blocks a k-split keeps per workgroup
 static int g_tune_ks_target = 1024;                           // mi355_set_tuning(10, n): split K until a launch has n row-tile x k-split slots
 static inline int qmg_buf(void** p, int key, size_t need, hipStream_t st) { return mi355_scratch_get(p, key, need, st, false); }
 
@@ -1273,7 +1279,8 @@ static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
     const int NCq = wide16 ? QMG_NC_WIDE : QMG_NC;
     int ks = 1;
     if (wide16) { while ((n_slots + NCq - 1) / NCq * ks < 200 && nkb / (ks * 2) >= 4) ks *= 2; }
-    else { while (n_slots * ks < g_tune_ks_target && nkb / (ks * 2) >= 2) ks *= 2; }
+    else if (g_tune_ks_target > 0) { while (n_slots * ks < g_tune_ks_target && nkb / (ks * 2) >= g_tune_ks_minkb) ks *= 2; }
+    else { while ((n_slots + QMG_NC - 1) / QMG_NC * ks < -g_tune_ks_target && nkb / (ks * 2) >= g_tune_ks_minkb) ks *= 2; }
     // activation image: staged by the previous launch's epilogue (chain) or by the prep kernel now
     QmgStream& qs = qmg_stream(st);
     const bool chained = qs.chain.valid && qs.chain.x == a.x && qs.chain.B == a.B && qs.chain.K == a.K &&
@@ -1605,7 +1612,8 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     else if (key == 6) g_tune_prefill_gemm = value;
     else if (key == 8) mi355_pa_set_wpb(value);
     else if (key == 9) g_tune_chain = value;
-    else if (key == 10 && value > 0) g_tune_ks_target = value;
+    else if (key == 10 && value != 0) g_tune_ks_target = value;     // > 0: (row tile x k-split) slots, < 0: workgroups
+    else if (key == 17 && value > 0) g_tune_ks_minkb = value;
     else if (key == 11) g_tune_qpg = value;
     else if (key == 12 && value > 0) g_tune_qpg_min = value;
 }
