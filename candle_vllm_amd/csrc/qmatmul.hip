@@ -1135,41 +1135,56 @@ __global__ void __launch_bounds__(512, 2) qmm_gemm2_kernel(const QmmArgs a, cons
     else qmm_gemm_body<MT, WTB>(a, img, part, ldp, s_split, a.nseg, slots1, slots0, (int)blockIdx.x - nwg0);
 }
 
-// partial sums -> epilogue; one thread per (token, concatenated padded row)
+// partial sums -> epilogue; one thread per (token, concatenated padded row).  Two phases, so that every load that does not
+// depend on the deferred 1/rms factor (the k-split partial sums of the thread's row and of its partner row, the residual,
+// the bias) is in flight BEFORE the workgroup reduces the sum of squares -- one memory round trip instead of two.
+struct QmgEpiRow { int sg, lrow, orow; bool live, has_aux; float s_main, s_aux, b_main, b_aux, resid; };
+__device__ __forceinline__ QmgEpiRow qmm_epilogue_load(const QmmArgs& a, const float* __restrict__ part, const int ldp, const int ks,
+                                                       const int BP, const int prow, const int b) {
+    QmgEpiRow e;
+    e.sg = 0; e.lrow = prow;
+    while (e.sg + 1 < a.nseg && e.lrow >= a.seg[e.sg].n_tiles * 16) { e.lrow -= a.seg[e.sg].n_tiles * 16; ++e.sg; }
+    e.live = e.lrow < a.seg[e.sg].n_rows;
+    e.orow = a.seg[e.sg].row0 + e.lrow;
+    e.has_aux = false; e.s_main = e.s_aux = e.b_main = e.b_aux = e.resid = 0.f;
+    if (!e.live) return e;
+    int aux = 0, aux_orow = 0;
+    if (a.epi == MI355_EPI_SILU_MUL) {                                // gate rows drive; up = same row of segment 1
+        if (e.sg != 0) { e.live = false; return e; }
+        e.has_aux = true; aux = a.seg[0].n_tiles * 16 + e.lrow; aux_orow = a.seg[1].row0 + e.lrow;
+    } else if (a.epi == MI355_EPI_QKV_ROPE_CACHE) {
+        if (e.sg < 2 && (e.lrow % a.D) < a.rot) { e.has_aux = true; aux = prow ^ 1; aux_orow = e.orow ^ 1; }
+    }
+    for (int k = 0; k < ks; ++k) {
+        e.s_main += part[((size_t)k * BP + b) * ldp + prow];
+        if (e.has_aux) e.s_aux += part[((size_t)k * BP + b) * ldp + aux];
+    }
+    if (a.bias) { e.b_main = a.bias[e.orow]; if (e.has_aux) e.b_aux = a.bias[aux_orow]; }
+    if (a.epi == MI355_EPI_RESID) e.resid = a.resid[(size_t)b * a.ldo + e.orow];
+    return e;
+}
 // returns the f32 value written to a.out for (token b, out column = the chain's k index), 0 when nothing was written
-__device__ __forceinline__ float qmm_epilogue_one(const QmmArgs& a, const float* __restrict__ part, const int ldp, const int ks,
-                                                  const int BP, const float inv, const int prow, const int b) {
-    int sg = 0, lrow = prow;
-    while (sg + 1 < a.nseg && lrow >= a.seg[sg].n_tiles * 16) { lrow -= a.seg[sg].n_tiles * 16; ++sg; }
-    if (lrow >= a.seg[sg].n_rows) return 0.f;
-    auto total = [&](int pr) {
-        float s = 0.f;
-        for (int k = 0; k < ks; ++k) s += part[((size_t)k * BP + b) * ldp + pr];
-        return s * inv;
-    };
-    const int orow = a.seg[sg].row0 + lrow;
-    float val = total(prow);
-    if (a.bias) val += a.bias[orow];
+__device__ __forceinline__ float qmm_epilogue_apply(const QmmArgs& a, const QmgEpiRow& e, const float inv, const int b) {
+    if (!e.live) return 0.f;
+    const int sg = e.sg, lrow = e.lrow, orow = e.orow;
+    const float val = e.s_main * inv + e.b_main;
     if (a.epi == MI355_EPI_STORE) {
         a.out[(size_t)b * a.ldo + orow] = val;
         return val;
     } else if (a.epi == MI355_EPI_RESID) {
-        const float o = a.resid[(size_t)b * a.ldo + orow] + val;
+        const float o = e.resid + val;
         a.out[(size_t)b * a.ldo + orow] = o;
         return o;
     } else if (a.epi == MI355_EPI_SILU_MUL) {
-        if (sg != 0) return 0.f;                                      // gate rows drive; up = same row of segment 1
-        float up = total(a.seg[0].n_tiles * 16 + lrow);
-        if (a.bias) up += a.bias[a.seg[1].row0 + lrow];
+        const float up = e.s_aux * inv + e.b_aux;
         const float o = silu_f(val) * up;
         a.out[(size_t)b * a.ldo + lrow] = o;
         return o;
     } else if (a.epi == MI355_EPI_QKV_ROPE_CACHE) {
         const int D = a.D, d = lrow % D, hh = lrow / D;
         float o = val;
-        if (sg < 2 && d < a.rot) {
-            float partner = total(prow ^ 1);
-            if (a.bias) partner += a.bias[orow ^ 1];
+        if (e.has_aux) {
+            const float partner = e.s_aux * inv + e.b_aux;
             const int64_t pos = a.positions[b];
             const float c = a.cos_t[pos * (a.rot >> 1) + (d >> 1)], sn = a.sin_t[pos * (a.rot >> 1) + (d >> 1)];
             o = (d & 1) ? (partner * sn + val * c) : (val * c - partner * sn);
@@ -1214,6 +1229,10 @@ __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, cons
     // in parallel (one L2 round trip) -- a per-thread loop over up to 56 k-blocks was most of this kernel's time
     __shared__ float sm_inv;
     float inv = 1.f;
+    QmgEpiRow er;
+    er.live = false;
+    const bool mine = prow < ldp && b < a.B;
+    if (mine) er = qmm_epilogue_load(a, part, ldp, ks, BP, prow, b);
     if (a.norm_w && ssp) {
         if (threadIdx.x < 64) {
             float ss = 0.f;
@@ -1227,7 +1246,7 @@ __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, cons
     }
     if (rscale && b < a.B) inv *= rscale[b];                          // prompt-step GEMM: per-token power-of-two scale of the f16 image
     float o = 0.f;
-    if (prow < ldp && b < a.B) o = qmm_epilogue_one(a, part, ldp, ks, BP, inv, prow, b);
+    if (mine) o = qmm_epilogue_apply(a, er, inv, b);
     if (!ch.img) return;
     const int kb = blockIdx.x;
     if (kb * 256 >= ch.K) return;                                    // uniform: e.g. the `up` half of the gate/up rows
