@@ -40,3 +40,19 @@ PF_T=2048 PF_MODES=1 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/rp_pf 
 PF_T=2048 PF_MODES=1 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d /tmp/pmc_pf --output-format csv -- $PF > $OUT/pf_pmc.log 2>&1
 python tools/pmc_summary.py /tmp/pmc_pf $OUT/${RN}_prefill_pmc_sq.json $SHA > $OUT/pf_pmc_summary.txt 2>&1
 grep prefill $OUT/pf_stats.log
+# 7. ragged batch-32 step: durations per (kernel, grid) from a kernel trace
+B32_STEPS=6 timeout 300 rocprofv3 --kernel-trace -d /tmp/rp_b32r --output-format csv -- python tools/exp_b32.py > $OUT/b32_ragged.log 2>&1
+(echo "# commit $SHA : B32_STEPS=6 rocprofv3 --kernel-trace -- python tools/exp_b32.py ; tools/trace_groups.py (mean / min us per launch shape)"; grep -o "'value': [0-9.]*" $OUT/b32_ragged.log; python tools/trace_groups.py $(find /tmp/rp_b32r -name "*kernel_trace.csv" | head -1) | grep -v "at::native") > $OUT/${RN}_b32_ragged_launch_groups.txt
+# 8. SQ counters of the wide GEMM at batch 32 (two --pmc passes)
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+           "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA"; do
+  i=$((i+1))
+  B32_STEPS=3 timeout 300 rocprofv3 --kernel-trace --pmc $set -d /tmp/pmc_b32_$i --output-format csv -- python tools/exp_b32.py > $OUT/pmc_b32_$i.log 2>&1
+  python tools/pmc_summary.py /tmp/pmc_b32_$i $OUT/${RN}_pmc_sq_b32_set$i.json $SHA > /dev/null 2>&1
+done
+# 9. micro-benchmarks: bare weight stream of the wide GEMM; per-wave timelines of the single-token launches
+[ -x tools/probe_wide_stream.bin ] || hipcc --offload-arch=gfx950 -O3 tools/probe_wide_stream.hip -o tools/probe_wide_stream.bin
+(echo "# commit $SHA : tools/probe_wide_stream.bin"; timeout 120 tools/probe_wide_stream.bin) > $OUT/${RN}_probe_wide_stream.txt 2>&1
+(echo "# commit $SHA : python tools/exp_wave_times.py (us since the first wave's entry; 100 MHz clock)"; timeout 300 python tools/exp_wave_times.py 2>&1 | grep -v amdgpu.ids) > $OUT/${RN}_b1_wave_times.txt
+head -12 $OUT/${RN}_b32_ragged_launch_groups.txt | cut -c1-170
