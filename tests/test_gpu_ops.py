@@ -324,6 +324,27 @@ def test_qmatmul_random_bytes_all_code_points(cv):
         assert rel_err(mm.forward(dev(x)).cpu().numpy(), kq.qmatmul_o1(x, blocks, t)) < 1e-4
 
 
+@pytest.mark.parametrize("t", [kq.GGML_Q4_K, kq.GGML_Q6_K])
+def test_wide_path_activation_range(cv, t):
+    """The 9..32-token path stages activations as f16 hi + lo of x/16 (lo scaled by 2^11, no denormals): outliers of 3e4
+    and 8e5 next to entries of 1e-5, and a uniformly small input, keep the f32-activation accuracy; beyond 1.05e6 the
+    result is NaN (never a plausible wrong number)."""
+    rng = np.random.default_rng(21)
+    N, K, B = 64, 1024, 16
+    blocks = kq.quantize(rng.normal(0, 0.05, (N, K)).astype(np.float32), t)
+    mm = cv.QMatMul(blocks, t, "cuda")
+    x = rng.normal(size=(B, K)).astype(np.float32)
+    x[:, 5] = 3.0e4
+    x[3, 7] = -8.0e5
+    x[:, 100:200] *= 1e-5
+    assert rel_err(mm.forward(dev(x)).cpu().numpy(), kq.qmatmul_o1(x, blocks, t)) < 1e-4
+    x = (rng.normal(size=(B, K)) * 1e-2).astype(np.float32)
+    assert rel_err(mm.forward(dev(x)).cpu().numpy(), kq.qmatmul_o1(x, blocks, t)) < 1e-4
+    x[2, 9] = 2.0e6
+    y = mm.forward(dev(x)).cpu().numpy()
+    assert np.isnan(y[2]).all() and np.isfinite(np.delete(y, 2, axis=0)).all()
+
+
 @pytest.mark.parametrize("B", [3, 12, 32, 130])
 def test_fused_norm_qkv_rope_cache(cv, B):
     """[RMSNorm -> wq,wk,wv -> interleaved RoPE -> bf16 -> q_out / paged cache] == composition of oracles
