@@ -661,14 +661,14 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
         for (int q = 0; q < PFK; ++q) {
             const int kbi = kbi0 + q;
             const bool active = kbi < n_my_kb;                    // wave-uniform
-            if (active && (a.dbg < 3 || a.dbg == 7)) stage_kblock3<BT>(a, xr[q], ximg, lane, ss);
+            if (active && (a.dbg < 3 || a.dbg == 7 || a.dbg == 5)) stage_kblock3<BT>(a, xr[q], ximg, lane, ss);
             const int kbn = wave + NW * (kbi + PFK);
-            if (a.dbg < 3 || a.dbg == 7) xr[q] = load_x<BT>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp);
+            if (a.dbg < 3 || a.dbg == 7 || a.dbg == 5) xr[q] = load_x<BT>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp);
             const bool ok = kbi + PFK < n_my_kb;
             if constexpr (WT != 0) {
                 // every tile of the launch has one type: the R tiles of this k-block share C_in and the A fragments
                 if (active) {
-                    if (a.dbg >= 1 && a.dbg != 7) {
+                    if (a.dbg >= 1 && a.dbg != 7 && a.dbg != 5) {
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
                             const TileRegs& t = buf[q * R + r];
@@ -686,13 +686,13 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
                 }
 #pragma unroll
                 for (int r = 0; r < R; ++r)
-                    buf[q * R + r] = load_tile<WT>(wtype[r], ok ? wbase[r] + (size_t)kbn * wtb[r] : wbase[r], ok ? lane : 0);
+                    if (a.dbg != 5) buf[q * R + r] = load_tile<WT>(wtype[r], ok ? wbase[r] + (size_t)kbn * wtb[r] : wbase[r], ok ? lane : 0);   // probe 5: no weight stream after the first ring fill
             } else {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int s = q * R + r;
                     if (active) {
-                        if (a.dbg >= 1 && a.dbg != 7) {
+                        if (a.dbg >= 1 && a.dbg != 7 && a.dbg != 5) {
                             y[r][0] += __uint_as_float((buf[s].a.x ^ buf[s].b.x ^ buf[s].c.x ^ buf[s].d.x ^ buf[s].b.w ^ buf[s].c.w) & 0x3FFFFFu);
                         } else if (wtype[r] == MI355_GGML_Q4_K) {
                             compute3_q4k<BT, NV, 1>(&buf[s], ximg, lane, &y[r]);
@@ -740,6 +740,245 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
 
 template <int BT, int R, int WT>
 __global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) { qmm_body<BT, R, WT>(a); }
+// ================================================================================================
+// EXPERIMENT (mi355_set_tuning(18, 1), single-token launches only): the reference CPU path's own activation format.
+// candle's CPU mat-vec quantises x to Q8_K (per 256-block: iscale = -128 / max, q = round(iscale x) <= 127, d = 1 / iscale,
+// sums per 16) and takes INTEGER dot products with the 4/6-bit codes: sumf += (d_w d_x) sum_j sc_j (q4 . q8)_j
+// - (dmin d_x) sum_j m_j bsum_j   [candle-core k_quants vec_dot_q4k_q8k / vec_dot_q6k_q8k; restated in oracle/oracle.c, O2].
+// On the matrix core that is `v_mfma_i32_16x16x32_i8` straight on the masked nibbles (no hi/lo planes, no code-to-float
+// trick): ~75 VALU + 8 MFMA per Q4_K tile and k-block instead of 160 + 12.  The result equals O2 (the reference CPU's
+// numbers) to f32 summation order, not O1; everything else of the launch (work split, weight ring, cross-wave reduction,
+// fused epilogues, deferred RMSNorm -- the quantisation is scale-invariant) is qmm_body's.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+#define Q8W_BYTES 352                 // per token and wave: 256 codes + 16 sums of 16 (i32) + d (f32) + pad
+
+__device__ __forceinline__ void stage_q8k(const QmmArgs& a, const XRegs<1>& xr, uint8_t* xq, int lane, float (&ss)[1]) {
+    float v[4];
+    if (a.x_dtype == MI355_DTYPE_BF16) {
+        v[0] = bf16lo_to_f32(xr.v[0].x); v[1] = bf16hi_to_f32(xr.v[0].x);
+        v[2] = bf16lo_to_f32(xr.v[0].y); v[3] = bf16hi_to_f32(xr.v[0].y);
+    } else {
+        v[0] = __uint_as_float(xr.v[0].x); v[1] = __uint_as_float(xr.v[0].y);
+        v[2] = __uint_as_float(xr.v[0].z); v[3] = __uint_as_float(xr.v[0].w);
+    }
+    if (a.norm_w) {
+        ss[0] = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], ss[0]))));
+        v[0] *= xr.nw.x; v[1] *= xr.nw.y; v[2] *= xr.nw.z; v[3] *= xr.nw.w;
+    }
+    const float am = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    const float amax = wave_max(am);
+    // the signed value of largest magnitude, FIRST occurrence (quantize_row_q8_K keeps `max` at the first strict maximum)
+    int li = -1;
+#pragma unroll
+    for (int i = 3; i >= 0; --i) if (fabsf(v[i]) == amax) li = i;
+    const unsigned long long cand = __ballot(li >= 0);
+    const int first = __ffsll((long long)cand) - 1;
+    const float mine = li == 0 ? v[0] : (li == 1 ? v[1] : (li == 2 ? v[2] : v[3]));
+    const float mx = __shfl(mine, first, 64);
+    uint32_t packed = 0;
+    int s4 = 0;
+    float dx = 0.f;
+    if (amax != 0.f) {
+        const float iscale = -128.f / mx;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int q = (int)rintf(iscale * v[i]);
+            q = q > 127 ? 127 : q;
+            s4 += q;
+            packed |= ((uint32_t)q & 0xFFu) << (8 * i);
+        }
+        dx = 1.f / iscale;
+    }
+    *reinterpret_cast<uint32_t*>(xq + 4 * lane) = packed;
+    s4 += __shfl_xor(s4, 1, 64);
+    s4 += __shfl_xor(s4, 2, 64);
+    if ((lane & 3) == 0) reinterpret_cast<int*>(xq + 256)[lane >> 2] = s4;
+    if (lane == 0) *reinterpret_cast<float*>(xq + 320) = dx;
+}
+
+// RR tiles of one k-block against the wave's staged token; y[r][0] accumulates in every lane of kg == 0 (row = lane & 15)
+template <int RR>
+__device__ __forceinline__ void compute_q4k_i8(const TileRegs* w, const uint8_t* xq, int lane, float (*y)[1]) {
+    const int kg = lane >> 4;
+    long A[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) A[j] = *reinterpret_cast<const long*>(xq + 32 * j + 8 * kg);      // k = 32 j + 8 kg .. +7
+    const int4 b0 = *reinterpret_cast<const int4*>(xq + 256), b1 = *reinterpret_cast<const int4*>(xq + 272);
+    const int4 b2 = *reinterpret_cast<const int4*>(xq + 288), b3 = *reinterpret_cast<const int4*>(xq + 304);
+    const int bs32[8] = {b0.x + b0.y, b0.z + b0.w, b1.x + b1.y, b1.z + b1.w, b2.x + b2.y, b2.z + b2.w, b3.x + b3.y, b3.z + b3.w};
+    const float dx = *reinterpret_cast<const float*>(xq + 320);
+    uint32_t nibs = 0x0F0F0F0Fu;
+    asm volatile("" : "+v"(nibs));
+    const i32x4_t zero = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        const float d = f16_bits_to_f32((uint16_t)(w[r].a.x & 0xFFFF)) * dx;
+        const float dmin = f16_bits_to_f32((uint16_t)(w[r].a.x >> 16)) * dx;
+        const uint32_t s0 = w[r].a.y, s1 = w[r].a.z, s2 = w[r].a.w;
+        const uint32_t scl = s0 & 0x3F3F3F3Fu, mnl = s1 & 0x3F3F3F3Fu;
+        const uint32_t sch = (s2 & 0x0F0F0F0Fu) | ((s0 >> 2) & 0x30303030u);
+        const uint32_t mnh = ((s2 >> 4) & 0x0F0F0F0Fu) | ((s1 >> 2) & 0x30303030u);
+        int sumi = 0, summ = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int p = j >> 2, pr = (j >> 1) & 1, sh = (j & 1) * 4;
+            const uint4 qs = p ? w[r].c : w[r].b;
+            const uint32_t w0 = pr ? qs.z : qs.x, w1 = pr ? qs.w : qs.y;
+            const uint32_t q0 = (w0 >> sh) & nibs, q1 = (w1 >> sh) & nibs;                         // 8 codes, k order
+            const long B = (long)(((unsigned long long)q1 << 32) | q0);
+            const i32x4_t acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[j], B, zero, 0, 0, 0);
+            const int sc = (int)((((j < 4) ? scl : sch) >> (8 * (j & 3))) & 0xFF);
+            const int mn = (int)((((j < 4) ? mnl : mnh) >> (8 * (j & 3))) & 0xFF);
+            sumi += __mul24(sc, acc[0]);                         // |acc| <= 32 * 15 * 128 < 2^23: full-rate 24-bit multiplies
+            summ += __mul24(mn, bs32[j]);
+        }
+        y[r][0] += d * (float)sumi - dmin * (float)summ;
+    }
+}
+
+template <int RR>
+__device__ __forceinline__ void compute_q6k_i8(const TileRegs* w, const uint8_t* xq, int lane, float (*y)[1]) {
+    const int kg = lane >> 4;
+    // A of the pair of 16-element sub-blocks (2p, 2p+1): elements 4kg..4kg+3 of each
+    long A[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const uint32_t lo = *reinterpret_cast<const uint32_t*>(xq + 32 * p + 4 * kg);
+        const uint32_t hi = *reinterpret_cast<const uint32_t*>(xq + 32 * p + 16 + 4 * kg);
+        A[p] = (long)(((unsigned long long)hi << 32) | lo);
+    }
+    const int4 b0 = *reinterpret_cast<const int4*>(xq + 256), b1 = *reinterpret_cast<const int4*>(xq + 272);
+    const int4 b2 = *reinterpret_cast<const int4*>(xq + 288), b3 = *reinterpret_cast<const int4*>(xq + 304);
+    const int bs16[16] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+    const float dx = *reinterpret_cast<const float*>(xq + 320);
+    const i32x4_t zero = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        const float d = f16_bits_to_f32((uint16_t)(w[r].e & 0xFFFF)) * dx;
+        const uint32_t scw[4] = {w[r].a.x, w[r].a.y, w[r].a.z, w[r].a.w};
+        const uint32_t qhw[4] = {w[r].d.x, w[r].d.y, w[r].d.z, w[r].d.w};
+        int sumi = 0, corr = 0;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const uint4 ql = n ? w[r].c : w[r].b;
+            uint32_t t[2][4];
+#pragma unroll
+            for (int is = 0; is < 2; ++is) {
+                const uint32_t qa = is ? ql.z : ql.x, qb = is ? ql.w : ql.y, h = qhw[2 * n + is];
+                t[is][0] = (qa & 0x0F0F0F0Fu) | ((h << 4) & 0x30303030u);
+                t[is][1] = (qb & 0x0F0F0F0Fu) | ((h << 2) & 0x30303030u);
+                t[is][2] = ((qa >> 4) & 0x0F0F0F0Fu) | (h & 0x30303030u);
+                t[is][3] = ((qb >> 4) & 0x0F0F0F0Fu) | ((h >> 2) & 0x30303030u);
+            }
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int s0i = 8 * n + 2 * tt, p = 4 * n + tt;
+                // the codes 0..63 are valid int8; the "- 32" comes back through the sums of 16:  sum (c - 32) q8 = sum c q8 - 32 bsum
+                const long B0 = (long)(unsigned long long)t[0][tt];                               // sub-block 2p only (upper k half zero)
+                const long B1 = (long)((unsigned long long)t[1][tt] << 32);                      // sub-block 2p + 1 only
+                const i32x4_t a0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[p], B0, zero, 0, 0, 0);
+                const i32x4_t a1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[p], B1, zero, 0, 0, 0);
+                const int sc0 = (int)(int8_t)((scw[s0i >> 2] >> (8 * (s0i & 3))) & 0xFF);
+                const int sc1 = (int)(int8_t)((scw[(s0i + 1) >> 2] >> (8 * ((s0i + 1) & 3))) & 0xFF);
+                sumi += __mul24(sc0, a0[0]) + __mul24(sc1, a1[0]);
+                corr += __mul24(sc0, bs16[s0i]) + __mul24(sc1, bs16[s0i + 1]);
+            }
+        }
+        y[r][0] += d * (float)(sumi - 32 * corr);
+    }
+}
+
+template <int R, int WT>
+__device__ __forceinline__ void qmm_body_q8(const QmmArgs& a) {
+    constexpr int BT = 1, NV = 1;
+    constexpr int PF = (R > QMM_PF_MIN) ? R : QMM_PF_MIN;
+    constexpr int PFK = PF / R;
+    static_assert(PF % R == 0, "ring depth must be a multiple of the tiles per workgroup");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
+    const int nkb = a.K >> 8;
+    int segi[R], tile[R];
+    if (a.paired) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { segi[r] = r & 1; tile[r] = blockIdx.x * (R / 2 > 0 ? R / 2 : 1) + (r >> 1); }
+    } else {
+        int t = blockIdx.x * R, s = 0;
+        while (s + 1 < a.nseg && t >= a.seg[s].n_tiles) { t -= a.seg[s].n_tiles; ++s; }
+#pragma unroll
+        for (int r = 0; r < R; ++r) { segi[r] = s; tile[r] = t + r; }
+    }
+    const uint8_t* wbase[R];
+    int wtype[R], wtb[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        wtype[r] = WT ? WT : a.seg[segi[r]].type;
+        wtb[r] = (wtype[r] == MI355_GGML_Q4_K) ? Q4K_TILE : Q6K_TILE;
+        wbase[r] = a.seg[segi[r]].w + (size_t)tile[r] * nkb * wtb[r];
+    }
+    const float* nwp = a.norm_w ? a.norm_w : reinterpret_cast<const float*>(a.seg[0].w);
+    constexpr int XW = 32 * 2 * BT * 16;                          // same carve-up as qmm_body (the launcher sizes LDS for it)
+    static_assert(Q8W_BYTES <= XW, "the Q8_K image must fit the per-wave activation scratch");
+    uint8_t* xq = smem + (size_t)wave * XW;
+    float* red = reinterpret_cast<float*>(smem + (size_t)NW * XW);
+    float* red_ss = red + (size_t)NW * R * BT * 16;
+    float y[R][NV];
+#pragma unroll
+    for (int r = 0; r < R; ++r) y[r][0] = 0.f;
+    float ss[BT] = {0.f};
+    EpiPre ep;
+    epi_pre_early<BT, R>(a, segi, tile, ep);
+    const int n_my_kb = (nkb > wave) ? (nkb - wave + NW - 1) / NW : 0;
+    const int kb_last = n_my_kb > 0 ? wave + NW * (n_my_kb - 1) : 0;
+    XRegs<BT> xr[PFK];
+    TileRegs buf[PF];
+#pragma unroll
+    for (int q = 0; q < PFK; ++q) {
+        const int kb = wave + NW * q;
+        xr[q] = load_x<BT>(a, kb <= kb_last ? kb : kb_last, lane, nwp);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool ok = q < n_my_kb;
+            buf[q * R + r] = load_tile<WT>(wtype[r], ok ? wbase[r] + (size_t)kb * wtb[r] : wbase[r], ok ? lane : 0);
+        }
+    }
+    epi_pre_late(a, ep);
+    for (int kbi0 = 0; kbi0 < n_my_kb; kbi0 += PFK) {
+#pragma unroll
+        for (int q = 0; q < PFK; ++q) {
+            const int kbi = kbi0 + q;
+            const bool active = kbi < n_my_kb;
+            if (active) stage_q8k(a, xr[q], xq, lane, ss);
+            // the sums and d are written by single lanes and read by all: without a wave-scope fence the compiler may hoist
+            // another lane's read above the store it never executes itself (seen: lane 0 right, lanes 1..15 stale)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            const int kbn = wave + NW * (kbi + PFK);
+            xr[q] = load_x<BT>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp);
+            const bool ok = kbi + PFK < n_my_kb;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int s = q * R + r;
+                if (active) {
+                    if (wtype[r] == MI355_GGML_Q4_K) compute_q4k_i8<1>(&buf[s], xq, lane, &y[r]);
+                    else compute_q6k_i8<1>(&buf[s], xq, lane, &y[r]);
+                }
+                buf[s] = load_tile<WT>(wtype[r], ok ? wbase[r] + (size_t)kbn * wtb[r] : wbase[r], ok ? lane : 0);
+            }
+        }
+    }
+    const int kg = lane >> 4, row = lane & 15;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (kg == 0) red[(((size_t)wave * R + r) * BT + 0) * 16 + row] = y[r][0];
+    if (a.norm_w) {
+        const float t = wave_sum(ss[0]);
+        if (lane == 0) red_ss[wave * BT] = t;
+    }
+    __syncthreads();
+    qmm_epilogue<BT, R>(a, red, red_ss, NW, segi, tile, ep);
+}
+template <int R, int WT>
+__global__ void __launch_bounds__(512) qmm_q8_kernel(const QmmArgs a) { qmm_body_q8<R, WT>(a); }
+
 // MoE variant (decode-shaped, BT = 1): blockIdx.y = (token, slot) pair.  The adjusted descriptor is a private copy
 // -- kept out of the dense kernel, where the kernel arguments must stay scalar loads from the kernarg segment.
 template <int R, int WT>
@@ -1618,6 +1857,7 @@ static int qmp_launch(const QmmArgs& a0, hipStream_t st) {
 void mi355_pa_set_fused(int v);
 void mi355_pa_set_wpb(int v);
 extern "C" void mi355_host_set_partition_override(int v);
+static int g_tune_actq8 = 0;                               // mi355_set_tuning(18, 1): EXPERIMENT, single-token launches quantise x to Q8_K (reference CPU numerics, O2)
 static int g_tune_nw = 0, g_tune_r = 0;                   // 0 = heuristic; mi355_set_tuning (experiments only)
 static int g_tune_prefill_gemm = 1;                        // 0 = always stream the quantised weights (experiments)
 extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
@@ -1626,6 +1866,7 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     else if (key == 2) g_tune_dbg = value;
     else if (key == 14) g_tune_merge = value;
     else if (key == 15) g_tune_wide16 = value;
+    else if (key == 18) g_tune_actq8 = value;
     else if (key == 3) mi355_pa_set_fused(value);
     else if (key == 5) mi355_host_set_partition_override(value);
     else if (key == 6) g_tune_prefill_gemm = value;
@@ -1695,6 +1936,17 @@ static int qmm_launch_btrw(QmmArgs& a, int n_wg, int NW, hipStream_t st) {
             return (int)hipErrorInvalidValue;
         }
     } else {
+        if constexpr (BT == 1) {
+            if (g_tune_actq8) {
+                static bool q8_attr_done = false;
+                if (!q8_attr_done) {
+                    (void)hipFuncSetAttribute((const void*)qmm_q8_kernel<R, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    q8_attr_done = true;
+                }
+                hipLaunchKernelGGL((qmm_q8_kernel<R, WT>), dim3(n_wg), dim3(64 * NW), shm, st, a);
+                return (int)hipGetLastError();
+            }
+        }
         hipLaunchKernelGGL((qmm_kernel<BT, R, WT>), dim3(n_wg), dim3(64 * NW), shm, st, a);
     }
     return (int)hipGetLastError();

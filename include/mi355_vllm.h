@@ -244,7 +244,9 @@ int mi355_moe_scatter_combine(float* ys, const float* y_sorted, const float* wei
  * merge (0 off, 1 auto, 2 always), 5 attention partition override, 6 prompt-step GEMM (1 on, 2 library GEMM), 8 attention
  * waves per workgroup (1 | 4 | 8 | 16), 9 chained wide launches (1 on), 10 split-K slot target of the wide path, 11 / 12
  * prompt-step GEMM variant / minimum tokens, 14 one launch for a Q4_K + Q6_K pair of runs (1 on), 15 16-wave workgroups
- * on the wide path for launches of >= n units (0 off); probe mode 7 = per-wave timestamps (below) */
+ * on the wide path for launches of >= n units (0 off), 17 fewest k-blocks per k-split, 18 EXPERIMENT: single-token launches
+ * quantise x to Q8_K and take integer dot products (the reference CPU's numerics, oracle O2; default 0 = f32-accurate
+ * activations, oracle O1); probe mode 7 = per-wave timestamps (below) */
 void mi355_set_tuning(int32_t key, int32_t value);
 /* experiments only: device buffer of uint64 [workgroup][16 waves][4] that the 1..8-token mat-vec fills with wall-clock
  * stamps (entry, main loop done, past the barrier, exit) while probe mode 7 is set; NULL switches it off */

@@ -19,7 +19,7 @@ CTX, K, Wm = 4096, 64, 8
 # TUNES: ';'-separated settings, each "key=val,key=val" for mi355_set_tuning (keys not named are reset to 0)
 # defaults of the mi355_set_tuning keys (qmatmul.hip / paged_attention.hip): 0 NW, 1 R, 2 probe mode, 3 fused attention
 # merge, 5 partition override, 8 attention waves per workgroup, 9 launch chaining, 10 K-split target
-DEFAULTS = {0: 0, 1: 0, 2: 0, 3: 1, 5: 0, 8: 0, 9: 1, 10: 1024, 14: 1, 15: 0, 17: 2}
+DEFAULTS = {0: 0, 1: 0, 2: 0, 3: 1, 5: 0, 8: 0, 9: 1, 10: 1024, 14: 1, 15: 0, 17: 2, 18: 0}
 modes = os.environ.get("TUNES", "0=0;0=4;0=8;1=1;1=2;1=4;0=4,1=4;0=4,1=1;0=0").split(";")
 batches = [int(x) for x in os.environ.get("PF_BATCHES", "1,32").split(",")]
 Bmax = max(batches)
