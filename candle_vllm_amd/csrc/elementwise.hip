@@ -48,10 +48,59 @@ __global__ void __launch_bounds__(256) rms_norm_kernel(T* __restrict__ out, cons
         st_from_f32<T>(orow, i, ld_as_f32<T>(xr, i) * inv * ld_as_f32<WT>(w, i));
 }
 
+// bf16 rows up to 8192 wide (the decode step of the 16-bit host layers: one row = one workgroup = a chain of memory round
+// trips): x AND the weight are requested up front as 16-byte pieces and stay in registers, so the launch is one round trip
+// instead of three (measured on the Qwen2-7B GPTQ leg: 11.3 us per call with the generic kernel, two calls per layer).
+__global__ void __launch_bounds__(256) rms_norm_bf16_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ x,
+                                                            const uint16_t* __restrict__ w, int hidden, float eps) {
+    __shared__ float red[16];
+    const int64_t row = blockIdx.x;
+    const uint4* x4 = reinterpret_cast<const uint4*>(x + row * hidden);
+    const uint4* w4 = reinterpret_cast<const uint4*>(w);
+    uint4* o4 = reinterpret_cast<uint4*>(out + row * hidden);
+    const int n8 = hidden >> 3;
+    uint4 xv[4], wv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int i = threadIdx.x + c * 256;
+        xv[c] = i < n8 ? x4[i] : make_uint4(0, 0, 0, 0);
+        wv[c] = i < n8 ? w4[i] : make_uint4(0, 0, 0, 0);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t u[4] = {xv[c].x, xv[c].y, xv[c].z, xv[c].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = bf16lo_to_f32(u[e]), b = bf16hi_to_f32(u[e]);
+            ss += a * a + b * b;
+        }
+    }
+    ss = block_sum(ss, red);
+    const float inv = rsqrtf(ss / (float)hidden + eps);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int i = threadIdx.x + c * 256;
+        if (i >= n8) continue;
+        const uint32_t u[4] = {xv[c].x, xv[c].y, xv[c].z, xv[c].w}, g[4] = {wv[c].x, wv[c].y, wv[c].z, wv[c].w};
+        uint32_t r[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            r[e] = pack_bf16x2(bf16lo_to_f32(u[e]) * inv * bf16lo_to_f32(g[e]), bf16hi_to_f32(u[e]) * inv * bf16hi_to_f32(g[e]));
+        o4[i] = make_uint4(r[0], r[1], r[2], r[3]);
+    }
+}
+
 extern "C" int mi355_rms_norm(void* out, const void* x, const void* w, int32_t num_tokens, int32_t hidden,
                               float eps, int32_t dtype, int32_t w_dtype, int64_t stream) {
     if (num_tokens <= 0) return 0;
     hipStream_t st = to_stream(stream);
+    if (dtype == MI355_DTYPE_BF16 && w_dtype == MI355_DTYPE_BF16 && (hidden & 7) == 0 && hidden <= 8192 &&
+        ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {
+        hipLaunchKernelGGL(rms_norm_bf16_kernel, dim3(num_tokens), dim3(256), 0, st, (uint16_t*)out, (const uint16_t*)x,
+                           (const uint16_t*)w, hidden, eps);
+        return (int)hipGetLastError();
+    }
     if (dtype == MI355_DTYPE_F32 && w_dtype == MI355_DTYPE_F32)
         hipLaunchKernelGGL((rms_norm_kernel<float, float>), dim3(num_tokens), dim3(256), 0, st, (float*)out,
                            (const float*)x, (const float*)w, hidden, eps);
