@@ -1921,7 +1921,8 @@ static int qmm_launch_btrw(QmmArgs& a, int n_wg, int NW, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)qmm_kernel<BT, R, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    if (NW <= 0) NW = qmm_pick_nw<BT, R, WT>(n_wg, a.K / 256);
+    // (token, slot) pairs of a mixture-of-experts launch are workgroups too: all of them should be resident at once
+    if (NW <= 0) NW = qmm_pick_nw<BT, R, WT>(n_wg * (a.moe_expert ? a.moe_pairs : 1), a.K / 256);
     const size_t shm = qmm_lds_bytes(BT, R, NW);
     if (shm > 160 * 1024) return (int)hipErrorInvalidValue;
     if (a.moe_expert) {

@@ -3,9 +3,9 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/call_w
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $R
-timeout 900 python -m pytest tests/test_gpu_dense_model.py tests/test_gpu_linear.py tests/test_gpu_ops.py -q -m gpu -k "not q8k" 2>&1 | grep -E "passed|failed" | tail -3
+
 timeout 400 rocprofv3 --kernel-trace -d /tmp/rp_w --output-format csv -- python bench.py --steps 4 --warmup 1 --no-batch32 --no-cpu-baseline --parity off --legs ${LEGS:-gptq_qwen2} > $OUT/bench.json 2>/dev/null
-python tools/trace_groups.py $(find /tmp/rp_w -name "*kernel_trace.csv" | head -1) | grep -E "dense_kernel|exllama|paged|rms|rope|silu|cache|add|embed|argmax" | head -24
+python tools/trace_groups.py $(find /tmp/rp_w -name "*kernel_trace.csv" | head -1) | grep -v "at::native" | head -22
 python - <<'P'
 import json
 d=json.loads(open('gpurun_out/call_w/bench.json').read().strip().splitlines()[-1])
