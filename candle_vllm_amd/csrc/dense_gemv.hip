@@ -90,14 +90,14 @@ __device__ __forceinline__ float zero_point(const DenseArgs& a, int g, int col) 
 // k-blocks; MT = ceil(T/16) M tiles.  GJ (4-bit only) = 32-wide k runs per quantisation group inside a k-block
 // (group 32/64/128/>=256 -> 1/2/4/8): the MFMA chain runs over a whole group and the scale is applied once.
 template <int DT, int WTYPE, int MT, int R, int GJ>
-__global__ void __launch_bounds__(512) dense_kernel(const DenseArgs a) {
+__device__ __forceinline__ void dense_body(const DenseArgs& a, const int bx) {
     extern __shared__ __attribute__((aligned(16))) float dg_red[];   // [NW][R][MT][16 m][16 rows]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
     const int r16 = lane & 15, kg = lane >> 4;
     const int nkb = a.K >> 8;
     int row0[R];
-    row0[0] = blockIdx.x * 16;
-    if (R == 2) row0[R - 1] = a.pair_offset + blockIdx.x * 16;
+    row0[0] = bx * 16;
+    if (R == 2) row0[R - 1] = a.pair_offset + bx * 16;
     const uint16_t* x16 = static_cast<const uint16_t*>(a.x);
 
     f32x4_t y[R][MT];
@@ -237,6 +237,18 @@ __global__ void __launch_bounds__(512) dense_kernel(const DenseArgs a) {
         static_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + row] = f2h<DT>(o);
     }
 }
+template <int DT, int WTYPE, int MT, int R, int GJ>
+__global__ void __launch_bounds__(512) dense_kernel(const DenseArgs a) { dense_body<DT, WTYPE, MT, R, GJ>(a, (int)blockIdx.x); }
+// q, k and v projections of one attention block in ONE launch (same x, k, tokens and weight format; three outputs): the k and
+// v launches of a grouped-query model are 32 workgroups of 6 us each (Qwen2-7B: 2 of the 3 launches for 1/8 of the bytes).
+// The workgroup index selects the matrix -- a uniform branch in front of one body.
+template <int DT, int WTYPE, int MT, int GJ>
+__global__ void __launch_bounds__(512) dense3_kernel(const DenseArgs a0, const DenseArgs a1, const DenseArgs a2, const int t0, const int t1) {
+    const int bx = (int)blockIdx.x;
+    if (bx < t0) dense_body<DT, WTYPE, MT, 1, GJ>(a0, bx);
+    else if (bx < t0 + t1) dense_body<DT, WTYPE, MT, 1, GJ>(a1, bx - t0);
+    else dense_body<DT, WTYPE, MT, 1, GJ>(a2, bx - t0 - t1);
+}
 
 // ------------------------------------------------------------------------------------------------ launch
 template <int DT, int WTYPE, int MT, int R>
@@ -282,6 +294,34 @@ static int dense_launch_dt(const DenseArgs& a, hipStream_t st) {
     }
     switch (mt) { case 1: DG_CASE(1, 1); case 2: DG_CASE(2, 1); case 3: DG_CASE(3, 1); default: DG_CASE(4, 1); }
 #undef DG_CASE
+}
+
+template <int DT, int WTYPE>
+static int dense3_launch_dt(const DenseArgs (&a)[3], hipStream_t st) {
+    const int mt = (a[0].T + 15) / 16;
+    int gj = 8;
+    if (WTYPE == DW_GPTQ4) {
+        const int g = a[0].group_size;
+        if (g >= 256) { if (g % 256) return -2; }
+        else if (g == 128) gj = 4;
+        else if (g == 64) gj = 2;
+        else if (g == 32) gj = 1;
+        else return -2;
+    }
+    const int t0 = a[0].N / 16, t1 = a[1].N / 16, t2 = a[2].N / 16, tiles = t0 + t1 + t2;
+    const int nkb = a[0].K >> 8;
+    int nw = 8;
+    while (nw > 1 && (nw > nkb || (size_t)tiles * nw > 256 * 32)) nw >>= 1;
+    if (mt >= 3 && nw > 4) nw = 4;
+    const size_t lds = (size_t)nw * mt * 256 * sizeof(float);
+    dim3 grid(tiles), block(nw * 64);
+#define DG3(MT_, GJ_) hipLaunchKernelGGL((dense3_kernel<DT, WTYPE, MT_, GJ_>), grid, block, lds, st, a[0], a[1], a[2], t0, t1)
+#define DG3_MT(GJ_) switch (mt) { case 1: DG3(1, GJ_); break; case 2: DG3(2, GJ_); break; case 3: DG3(3, GJ_); break; default: DG3(4, GJ_); break; }
+    if (WTYPE == DW_DENSE) { DG3_MT(8) }
+    else switch (gj) { case 1: DG3_MT(1) break; case 2: DG3_MT(2) break; case 4: DG3_MT(4) break; default: DG3_MT(8) break; }
+#undef DG3_MT
+#undef DG3
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 static int dense_dispatch(const DenseArgs& a, int wtype, int dt, hipStream_t st) {
@@ -619,6 +659,32 @@ int mi355_gptq_linear(void* out, const void* x, const void* qweight, const void*
     if (epilogue == MI355_EPI_SILU_MUL) { a.pair_offset = n / 2; a.ldo = n / 2; } else a.ldo = n;
     if (epilogue == MI355_EPI_RESID && !residual) return -2;
     return dense_run(a, DW_GPTQ4, dtype, (hipStream_t)stream);
+}
+
+/* q, k, v projections (plain store epilogue, optional bias) in one launch; returns -4 when the shapes do not qualify
+ * (the caller then issues three mi355_linear / mi355_gptq_linear calls).  Internal to the host layer (dense_model.cpp). */
+int mi355_internal_linear3(void* const* outs, const void* x, const void* const* ws, const void* const* scales,
+                           const void* const* biases, const int32_t* ns, int32_t num_tokens, int32_t k, int32_t group_size,
+                           int32_t is_gptq, int32_t dtype, int64_t stream) {
+    if (num_tokens < 1 || num_tokens > 64 || (k & 255)) return -4;
+    DenseArgs a[3];
+    for (int i = 0; i < 3; ++i) {
+        if (!ws[i] || !outs[i] || ns[i] <= 0 || (ns[i] & 15)) return -4;
+        a[i] = DenseArgs{};
+        a[i].w = ws[i]; a[i].ldw = k; a[i].x = x; a[i].ldx = k; a[i].T = num_tokens; a[i].K = k; a[i].N = ns[i];
+        a[i].bias = biases ? biases[i] : nullptr; a[i].epi = MI355_EPI_STORE; a[i].out = outs[i]; a[i].ldo = ns[i];
+        if (is_gptq) {
+            a[i].scales = scales[i]; a[i].qzeros = nullptr; a[i].zmode = MI355_ZERO_SYM8;
+            a[i].group_size = (group_size <= 0 || group_size > k) ? k : group_size;
+            a[i].sperm = SP_NONE;
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MI355_DTYPE_BF16)
+        return is_gptq ? dense3_launch_dt<MI355_DTYPE_BF16, DW_GPTQ4>(a, st) : dense3_launch_dt<MI355_DTYPE_BF16, DW_DENSE>(a, st);
+    if (dtype == MI355_DTYPE_F16)
+        return is_gptq ? dense3_launch_dt<MI355_DTYPE_F16, DW_GPTQ4>(a, st) : dense3_launch_dt<MI355_DTYPE_F16, DW_DENSE>(a, st);
+    return -4;
 }
 
 }  // extern "C"

@@ -15,6 +15,15 @@
 #include "../../include/mi355_vllm.h"
 #include "common.h"
 
+extern "C" int mi355_internal_rope_cache(void* q, void* k, const void* v, void* key_cache, void* value_cache, const float* cos_t,
+                                         const float* sin_t, const int64_t* positions, const int64_t* slot_mapping,
+                                         int32_t num_tokens, int32_t num_heads, int32_t num_kv_heads, int32_t head_dim,
+                                         int32_t rotary_dim, int32_t is_rope_i, int32_t block_size, int32_t layout, int32_t dtype,
+                                         int64_t stream);
+extern "C" int mi355_internal_linear3(void* const* outs, const void* x, const void* const* ws, const void* const* scales,
+                                      const void* const* biases, const int32_t* ns, int32_t num_tokens, int32_t k,
+                                      int32_t group_size, int32_t is_gptq, int32_t dtype, int64_t stream);
+
 namespace {
 
 #define DCHECK(expr) do { const int rc_ = (expr); if (rc_ != 0) return rc_; } while (0)
@@ -314,10 +323,35 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
         // x = rms_1(xs)                                                     llama.rs:53-54
         DCHECK(norm(m, m->xn, m->xs, L.attn_norm, L.attn_norm_b, T, stream));
         // q,k,v projections (+bias)                                          attention.rs:597-607
+        int rc3 = -4;
+        {   // one launch for the three projections when they share the weight format (decode-sized steps)
+            const QLin &gq = L.gq[MI355_W_WQ], &gk = L.gq[MI355_W_WK], &gv = L.gq[MI355_W_WV];
+            const bool all_q = gq.qw && gk.qw && gv.qw && gq.group == gk.group && gq.group == gv.group;
+            const bool all_d = !gq.qw && !gk.qw && !gv.qw && L.wq && L.wk && L.wv;
+            if (T <= 64 && (all_q || all_d)) {
+                void* outs[3] = {m->q, m->k, m->v};
+                const void* ws[3] = {all_q ? (const void*)gq.qw : L.wq, all_q ? (const void*)gk.qw : L.wk, all_q ? (const void*)gv.qw : L.wv};
+                const void* sc[3] = {gq.scales, gk.scales, gv.scales};
+                const void* bs[3] = {L.bq, L.bk, L.bv};
+                const int32_t ns[3] = {H * D, Hkv * D, Hkv * D};
+                rc3 = mi355_internal_linear3(outs, m->xn, ws, sc, bs, ns, T, hid, gq.group, all_q ? 1 : 0, m->cfg.dtype, stream);
+                if (rc3 != 0 && rc3 != -4) return rc3;
+            }
+        }
+        if (rc3 != 0) {
         DCHECK(linear(m, L.wq, L.gq[MI355_W_WQ], m->q, m->xn, L.bq, nullptr, T, H * D, hid, MI355_EPI_STORE, stream));
         DCHECK(linear(m, L.wk, L.gq[MI355_W_WK], m->k, m->xn, L.bk, nullptr, T, Hkv * D, hid, MI355_EPI_STORE, stream));
         DCHECK(linear(m, L.wv, L.gq[MI355_W_WV], m->v, m->xn, L.bv, nullptr, T, Hkv * D, hid, MI355_EPI_STORE, stream));
+        }
         // q,k -> f32 -> rope -> model dtype                                  attention.rs:644-690
+        // (decode steps without an fp8 cache: RoPE and the cache write share one launch)
+        int rc_rc = -4;
+        if (!c.kv_fp8 && !prefill)
+            rc_rc = mi355_internal_rope_cache(m->q, m->k, m->v, m->kcache[l], m->vcache[l], m->cos_t, m->sin_t, positions, slot_mapping,
+                                              T, H, Hkv, D, c.rotary_dim, c.rope_interleaved, c.block_size, c.kv_layout, dt, stream);
+        if (rc_rc != 0 && rc_rc != -4) return rc_rc;
+        const bool fused_rc = rc_rc == 0;
+        if (!fused_rc)
         DCHECK(mi355_rope_inplace(m->q, m->k, m->cos_t, m->sin_t, positions, T, H, Hkv, D, c.rotary_dim, c.rope_interleaved, dt, stream));
         // PagedAttention::forward: cache write, then prefill / decode attention   attention.rs:707-719
         if (c.kv_fp8) {
@@ -337,6 +371,7 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
                                                  max_context_len, ps, scale, 0.f, 1.f, 1.f, stream));
             }
         } else {
+        if (!fused_rc)
         DCHECK(mi355_reshape_and_cache(m->k, m->v, m->kcache[l], m->vcache[l], slot_mapping, T, Hkv, D, c.block_size, 2,
                                        c.kv_layout, stream));
         if (prefill) {

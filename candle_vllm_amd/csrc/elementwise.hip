@@ -197,6 +197,69 @@ extern "C" int mi355_rope_inplace(void* q, void* k, const float* cos_t, const fl
     return (int)hipGetLastError();
 }
 
+// RoPE of q and k in place AND the cache write of the rotated k and of v, one launch (16-bit data, bf16 cache, both cache
+// layouts): in a decode step the two separate launches are 5 us each for a few KB.  Same arithmetic and rounding points as
+// rope_kernel followed by reshape_and_cache (q, k stay rotated in place; padded slots skip the cache).
+__global__ void __launch_bounds__(256) rope_cache_bf16_kernel(uint16_t* __restrict__ q, uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+                                                              uint16_t* __restrict__ kc, uint16_t* __restrict__ vc,
+                                                              const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                              const int64_t* __restrict__ positions, const int64_t* __restrict__ slot_mapping,
+                                                              int H, int Hkv, int D, int rot, int is_rope_i, int bs, int flash) {
+    const int t = blockIdx.x;
+    const int64_t pos = positions[t], slot = slot_mapping[t];
+    const int half = rot >> 1;
+    const float* c = cosT + pos * half;
+    const float* s = sinT + pos * half;
+    const int64_t blk = slot >= 0 ? slot / bs : 0;
+    const int off = slot >= 0 ? (int)(slot % bs) : 0;
+    auto kidx = [&](int h, int d) -> int64_t {
+        return flash ? (slot * Hkv + h) * D + d : ((((blk * Hkv + h) * (D / 8) + d / 8) * bs + off) * 8) + d % 8;
+    };
+    auto vidx = [&](int h, int d) -> int64_t {
+        return flash ? (slot * Hkv + h) * D + d : ((blk * Hkv + h) * D + d) * (int64_t)bs + off;
+    };
+    const int npairs = (H + Hkv) * half;
+    for (int i = threadIdx.x; i < npairs; i += blockDim.x) {
+        const int h = i / half, j = i % half;
+        const bool isq = h < H;
+        uint16_t* base = isq ? q + ((int64_t)t * H + h) * D : k + ((int64_t)t * Hkv + (h - H)) * D;
+        const int i0 = is_rope_i ? 2 * j : j;
+        const int i1 = is_rope_i ? 2 * j + 1 : j + half;
+        const float x0 = bf16_to_f32(base[i0]), x1 = bf16_to_f32(base[i1]);
+        const float cc = c[j], sn = s[j];
+        const uint16_t r0 = f32_to_bf16(x0 * cc - x1 * sn), r1 = f32_to_bf16(x0 * sn + x1 * cc);
+        base[i0] = r0; base[i1] = r1;
+        if (!isq && slot >= 0) { kc[kidx(h - H, i0)] = r0; kc[kidx(h - H, i1)] = r1; }
+    }
+    if (slot < 0) return;
+    // the dimensions RoPE leaves alone (partial rotary), and v
+    const int nrest = Hkv * (D - rot);
+    for (int i = threadIdx.x; i < nrest; i += blockDim.x) {
+        const int h = i / (D - rot), d = rot + i % (D - rot);
+        kc[kidx(h, d)] = k[((int64_t)t * Hkv + h) * D + d];
+    }
+    const int nv = Hkv * D;
+    for (int i = threadIdx.x; i < nv; i += blockDim.x) {
+        const int h = i / D, d = i % D;
+        vc[vidx(h, d)] = v[(int64_t)t * nv + i];
+    }
+}
+/* internal to the 16-bit host layer (dense_model.cpp); -4 = shapes this kernel does not take (caller uses the two launches) */
+extern "C" int mi355_internal_rope_cache(void* q, void* k, const void* v, void* key_cache, void* value_cache, const float* cos_t,
+                                         const float* sin_t, const int64_t* positions, const int64_t* slot_mapping,
+                                         int32_t num_tokens, int32_t num_heads, int32_t num_kv_heads, int32_t head_dim,
+                                         int32_t rotary_dim, int32_t is_rope_i, int32_t block_size, int32_t layout, int32_t dtype,
+                                         int64_t stream) {
+    if (num_tokens <= 0) return 0;
+    if (dtype != MI355_DTYPE_BF16 || rotary_dim <= 0 || rotary_dim > head_dim || (rotary_dim & 1) || (head_dim & 7) ||
+        (layout != MI355_KV_FLASH && layout != MI355_KV_PAGED))
+        return -4;
+    hipLaunchKernelGGL(rope_cache_bf16_kernel, dim3(num_tokens), dim3(256), 0, to_stream(stream), (uint16_t*)q, (uint16_t*)k,
+                       (const uint16_t*)v, (uint16_t*)key_cache, (uint16_t*)value_cache, cos_t, sin_t, positions, slot_mapping,
+                       num_heads, num_kv_heads, head_dim, rotary_dim, is_rope_i, block_size, layout == MI355_KV_FLASH ? 1 : 0);
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ SiLU * mul, add, casts
 template <typename T>
 __global__ void __launch_bounds__(256) silu_mul_kernel(T* __restrict__ out, const T* __restrict__ g,
