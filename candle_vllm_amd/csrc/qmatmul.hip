@@ -213,6 +213,13 @@ struct QmmArgs {
 };
 
 struct TileRegs { uint4 a, b, c, d; uint32_t e; };
+// Probe / ablation modes (mi355_set_tuning(2, v)) are compiled into -DMI355_QMM_PROBES builds only (tools/ build their own
+// library): a guarded load or branch in a hot loop costs the production kernels measurable time.
+#ifdef MI355_QMM_PROBES
+#define QMM_DBG(a) ((a).dbg)
+#else
+#define QMM_DBG(a) 0
+#endif
 typedef const void __attribute__((address_space(1)))* qmg_gptr_t;
 typedef void __attribute__((address_space(3)))* qmg_lptr_t;
 
@@ -577,19 +584,28 @@ __device__ __forceinline__ void qmm_epilogue(const QmmArgs& a, const float* red,
     }
 }
 
-// experiments only (dbg 7): per-wave timestamps [workgroup][wave 16][4] = entry, main loop done, past the barrier, exit
+// experiments only (probe mode 7): per-wave timestamps [workgroup][wave 16][4] = entry, main loop done, past the barrier, exit.
+// The hooks are compiled in ONLY with -DMI355_QMM_TIMESTAMPS (tools/exp_wave_times.py builds its own library): four dead
+// scalar branches in the single-token kernel measured 463 vs 485 tok/s at batch 1.
 __device__ unsigned long long* g_qmm_ts = nullptr;
 extern "C" int mi355_debug_set_timestamps(void* dev_ptr) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_qmm_ts), &dev_ptr, sizeof(dev_ptr));
 }
+#ifdef MI355_QMM_TIMESTAMPS
 __device__ __forceinline__ void qmm_stamp(const QmmArgs& a, int i) {
     if (a.dbg == 7 && (threadIdx.x & 63) == 0 && g_qmm_ts)
         g_qmm_ts[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 4 + i] = wall_clock64();
 }
+#else
+#define qmm_stamp(a, i) ((void)0)
+#endif
 
 template <int BT, int R, int WT>
 __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
     qmm_stamp(a, 0);
+    // probe modes of this kernel exist only in -DMI355_QMM_PROBES builds (tools/): every guarded load or branch in the hot
+    // loop costs the production kernel measurable time
+    const int dbg = QMM_DBG(a);
     constexpr int NV = BT < 4 ? BT : 4;
     constexpr int PF = (R > QMM_PF_MIN) ? R : QMM_PF_MIN;
     constexpr int PFK = PF / R;                                  // ring depth in k-blocks
@@ -661,14 +677,14 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
         for (int q = 0; q < PFK; ++q) {
             const int kbi = kbi0 + q;
             const bool active = kbi < n_my_kb;                    // wave-uniform
-            if (active && (a.dbg < 3 || a.dbg == 7 || a.dbg == 5)) stage_kblock3<BT>(a, xr[q], ximg, lane, ss);
+            if (active && (dbg < 3 || dbg == 7)) stage_kblock3<BT>(a, xr[q], ximg, lane, ss);
             const int kbn = wave + NW * (kbi + PFK);
-            if (a.dbg < 3 || a.dbg == 7 || a.dbg == 5) xr[q] = load_x<BT>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp);
+            if (dbg < 3 || dbg == 7) xr[q] = load_x<BT>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp);
             const bool ok = kbi + PFK < n_my_kb;
             if constexpr (WT != 0) {
                 // every tile of the launch has one type: the R tiles of this k-block share C_in and the A fragments
                 if (active) {
-                    if (a.dbg >= 1 && a.dbg != 7 && a.dbg != 5) {
+                    if (dbg >= 1 && dbg != 7) {
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
                             const TileRegs& t = buf[q * R + r];
@@ -686,13 +702,13 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
                 }
 #pragma unroll
                 for (int r = 0; r < R; ++r)
-                    if (a.dbg != 5) buf[q * R + r] = load_tile<WT>(wtype[r], ok ? wbase[r] + (size_t)kbn * wtb[r] : wbase[r], ok ? lane : 0);   // probe 5: no weight stream after the first ring fill
+                    buf[q * R + r] = load_tile<WT>(wtype[r], ok ? wbase[r] + (size_t)kbn * wtb[r] : wbase[r], ok ? lane : 0);   // unconditional: a guarded load here costs the counted vmcnt waits (measured -7 % at batch 1)
             } else {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int s = q * R + r;
                     if (active) {
-                        if (a.dbg >= 1 && a.dbg != 7 && a.dbg != 5) {
+                        if (dbg >= 1 && dbg != 7) {
                             y[r][0] += __uint_as_float((buf[s].a.x ^ buf[s].b.x ^ buf[s].c.x ^ buf[s].d.x ^ buf[s].b.w ^ buf[s].c.w) & 0x3FFFFFu);
                         } else if (wtype[r] == MI355_GGML_Q4_K) {
                             compute3_q4k<BT, NV, 1>(&buf[s], ximg, lane, &y[r]);
@@ -706,7 +722,7 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
         }
     }
 
-    if (a.dbg == 4) {                                              // probe: weight stream only, no reduction / epilogue
+    if (dbg == 4) {                                              // probe: weight stream only, no reduction / epilogue
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < R; ++r) t += y[r][0];
@@ -1298,7 +1314,7 @@ __device__ __forceinline__ void qmm_gemm_body(const QmmArgs& a, const uint8_t* _
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int kb = kb_lo; kb < kb_hi; ++kb) {
-            if (kb + 1 < kb_hi && a.dbg != 2) dma_kb(kb + 1, (kb + 1) & 1);
+            if (kb + 1 < kb_hi && QMM_DBG(a) != 2) dma_kb(kb + 1, (kb + 1) & 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
@@ -1325,7 +1341,7 @@ __device__ __forceinline__ void qmm_gemm_body(const QmmArgs& a, const uint8_t* _
         const bool more = kb + 1 < kb_hi;
         // the next tile streams in while this one is unpacked and multiplied (counted vmcnt: no DMA in this wave)
         TileRegs nxt = load_tile<WT>(wtype, more ? wbase + (size_t)(kb + 1) * wtb : wbase, more ? lane : 0);
-        if (a.dbg == 1) { y[0][0][0] += __uint_as_float(cur.a.x ^ cur.b.y ^ cur.c.z); }
+        if (QMM_DBG(a) == 1) { y[0][0][0] += __uint_as_float(cur.a.x ^ cur.b.y ^ cur.c.z); }
         else if (wtype == MI355_GGML_Q4_K) wide_q4k2<MT>(cur, Lc, lane, y[0]);
         else wide_q6k<MT>(cur, Lc, lane, y[0]);
         cur = nxt;

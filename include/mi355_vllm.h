@@ -240,7 +240,8 @@ int mi355_moe_gather(float* dst, const float* src, const int32_t* perm, int32_t 
 int mi355_moe_scatter_combine(float* ys, const float* y_sorted, const float* weights, const int32_t* inv, int32_t num_tokens,
                               int32_t hidden, int32_t top_k, int64_t stream);
 /* experiment knobs, never needed for correct results (value 0 = default unless noted): 0 waves per workgroup,
- * 1 row tiles per workgroup, 2 probe modes of the mat-vec (1 stream only, 3 no staging, 4 no epilogue), 3 fused attention
+ * 1 row tiles per workgroup, 2 probe modes of the mat-vec (1 stream only, 3 no staging, 4 no epilogue; compiled into
+ * -DMI355_QMM_PROBES builds only, tools/build_probe_lib.sh -- the production kernels carry no probe code), 3 fused attention
  * merge (0 off, 1 auto, 2 always), 5 attention partition override, 6 prompt-step GEMM (1 on, 2 library GEMM), 8 attention
  * waves per workgroup (1 | 4 | 8 | 16), 9 chained wide launches (1 on), 10 split-K slot target of the wide path, 11 / 12
  * prompt-step GEMM variant / minimum tokens, 14 one launch for a Q4_K + Q6_K pair of runs (1 on), 15 16-wave workgroups
@@ -249,7 +250,7 @@ int mi355_moe_scatter_combine(float* ys, const float* y_sorted, const float* wei
  * activations, oracle O1); probe mode 7 = per-wave timestamps (below) */
 void mi355_set_tuning(int32_t key, int32_t value);
 /* experiments only: device buffer of uint64 [workgroup][16 waves][4] that the 1..8-token mat-vec fills with wall-clock
- * stamps (entry, main loop done, past the barrier, exit) while probe mode 7 is set; NULL switches it off */
+ * stamps (entry, main loop done, past the barrier, exit) while probe mode 7 is set (probe builds only); NULL switches it off */
 int mi355_debug_set_timestamps(void* dev_ptr);
 
 /* ---------------------------------------------------------------------------------------------

@@ -19,7 +19,7 @@ bt = (np.arange(bps) + 1).reshape(1, bps).astype(np.uint32)
 gm.set_graph(False)
 gm.decode_begin(np.array([5], np.uint32), np.full(1, CTX + 1, np.uint32), bt, ctx_cap=CTX + 16, stream=st)
 gm.decode_step(st); torch.cuda.synchronize()
-modes = [int(x) for x in os.environ.get("DBG", "0,1,5,3,4").split(",")]
+modes = [int(x) for x in os.environ.get("DBG", "0,1,3,4").split(",")]
 for part, name in ((0, "qkv"), (2, "wo"), (3, "gateup"), (4, "down")):
     row = []
     for dbg in modes:

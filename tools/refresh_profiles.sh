@@ -54,5 +54,5 @@ done
 # 9. micro-benchmarks: bare weight stream of the wide GEMM; per-wave timelines of the single-token launches
 [ -x tools/probe_wide_stream.bin ] || hipcc --offload-arch=gfx950 -O3 tools/probe_wide_stream.hip -o tools/probe_wide_stream.bin
 (echo "# commit $SHA : tools/probe_wide_stream.bin"; timeout 120 tools/probe_wide_stream.bin) > $OUT/${RN}_probe_wide_stream.txt 2>&1
-(echo "# commit $SHA : python tools/exp_wave_times.py (us since the first wave's entry; 100 MHz clock)"; timeout 300 python tools/exp_wave_times.py 2>&1 | grep -v amdgpu.ids) > $OUT/${RN}_b1_wave_times.txt
+(echo "# commit $SHA : MI355_LIB_PATH=build_probe/libmi355vllm_probes.so python tools/exp_wave_times.py (probe build: tools/build_probe_lib.sh; us since the first wave's entry; 100 MHz clock)"; MI355_LIB_PATH=$R/build_probe/libmi355vllm_probes.so timeout 300 python tools/exp_wave_times.py 2>&1 | grep -v amdgpu.ids) > $OUT/${RN}_b1_wave_times.txt
 head -12 $OUT/${RN}_b32_ragged_launch_groups.txt | cut -c1-170
