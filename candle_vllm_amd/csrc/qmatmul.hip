@@ -276,14 +276,16 @@ struct XRegs {
     float4 nw;        // RMSNorm weight of the 4 elements (1 when no norm is fused)
 };
 
-template <int BT>
+// XB: 1 = x is bf16, 0 = f32 (the single-launch kernels are built for both: a run-time branch around the activation loads
+// of the hot loop measured 2.3 % of the batch-1 step), -1 = decide at run time
+template <int BT, int XB = -1>
 __device__ __forceinline__ XRegs<BT> load_x(const QmmArgs& a, int kb, int lane, const float* nwp) {
     XRegs<BT> r;
     const size_t k = (size_t)kb * 256 + 4 * lane;
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
         const int bb = b < a.B ? b : a.B - 1;                     // padded rows re-read the last row (zeroed later)
-        if (a.x_dtype == MI355_DTYPE_BF16) {
+        if (XB < 0 ? a.x_dtype == MI355_DTYPE_BF16 : XB == 1) {
             const uint2 t = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(a.x) + (size_t)bb * a.ldx + k);
             r.v[b] = make_uint4(t.x, t.y, 0, 0);
         } else {
@@ -303,13 +305,13 @@ __device__ __forceinline__ XRegs<BT> load_x(const QmmArgs& a, int kb, int lane, 
 //     -> no shuffle reductions and no sum arrays in the staging step, no per-sub-block offset FMAs;
 //   * d and dmin are applied once per tile (sum_j sc_j*P_j and sum_j m_j*S_j are formed first);
 //   * tiles of one k-block that share a type are computed together so C_in and the A fragments are shared.
-template <int BT>
+template <int BT, int XB = -1>
 __device__ __forceinline__ void stage_kblock3(const QmmArgs& a, const XRegs<BT>& xr, uint8_t* ximg, int lane, float (&ss)[BT]) {
     const int E = lane >> 1, half = lane & 1;
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
         float v[4];
-        if (a.x_dtype == MI355_DTYPE_BF16) {
+        if (XB < 0 ? a.x_dtype == MI355_DTYPE_BF16 : XB == 1) {
             v[0] = bf16lo_to_f32(xr.v[b].x); v[1] = bf16hi_to_f32(xr.v[b].x);
             v[2] = bf16lo_to_f32(xr.v[b].y); v[3] = bf16hi_to_f32(xr.v[b].y);
         } else {
@@ -600,7 +602,7 @@ __device__ __forceinline__ void qmm_stamp(const QmmArgs& a, int i) {
 #define qmm_stamp(a, i) ((void)0)
 #endif
 
-template <int BT, int R, int WT>
+template <int BT, int R, int WT, int XB>
 __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
     qmm_stamp(a, 0);
     // probe modes of this kernel exist only in -DMI355_QMM_PROBES builds (tools/): every guarded load or branch in the hot
@@ -662,7 +664,7 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
 #pragma unroll
     for (int q = 0; q < PFK; ++q) {
         const int kb = wave + NW * q;
-        xr[q] = load_x<BT>(a, kb <= kb_last ? kb : kb_last, lane, nwp);
+        xr[q] = load_x<BT, XB>(a, kb <= kb_last ? kb : kb_last, lane, nwp);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const bool ok = q < n_my_kb;
@@ -677,9 +679,9 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
         for (int q = 0; q < PFK; ++q) {
             const int kbi = kbi0 + q;
             const bool active = kbi < n_my_kb;                    // wave-uniform
-            if (active && (dbg < 3 || dbg == 7)) stage_kblock3<BT>(a, xr[q], ximg, lane, ss);
+            if (active && (dbg < 3 || dbg == 7)) stage_kblock3<BT, XB>(a, xr[q], ximg, lane, ss);
             const int kbn = wave + NW * (kbi + PFK);
-            if (dbg < 3 || dbg == 7) xr[q] = load_x<BT>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp);
+            if (dbg < 3 || dbg == 7) xr[q] = load_x<BT, XB>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp);
             const bool ok = kbi + PFK < n_my_kb;
             if constexpr (WT != 0) {
                 // every tile of the launch has one type: the R tiles of this k-block share C_in and the A fragments
@@ -754,8 +756,8 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
     qmm_stamp(a, 3);
 }
 
-template <int BT, int R, int WT>
-__global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) { qmm_body<BT, R, WT>(a); }
+template <int BT, int R, int WT, int XB>
+__global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) { qmm_body<BT, R, WT, XB>(a); }
 // ================================================================================================
 // EXPERIMENT (mi355_set_tuning(18, 1), single-token launches only): the reference CPU path's own activation format.
 // candle's CPU mat-vec quantises x to Q8_K (per 256-block: iscale = -128 / max, q = round(iscale x) <= 127, d = 1 / iscale,
@@ -1007,7 +1009,7 @@ __global__ void __launch_bounds__(512) qmm_moe_kernel(const QmmArgs a_in) {
     const size_t xes = (a.x_dtype == MI355_DTYPE_BF16) ? 2 : 4;
     a.x = static_cast<const uint8_t*>(a.x) + (size_t)(pair / a.moe_xdiv) * a.ldx * xes;
     a.out += (size_t)pair * a.ldo;
-    qmm_body<1, R, WT>(a);
+    qmm_body<1, R, WT, -1>(a);
 }
 
 // ================================================================================================
@@ -1918,7 +1920,7 @@ static int qmm_pick_nw(int n_wg, int nkb) {
         if (nw > nkb) continue;
         if (blocks_per_cu[i] < 0) {
             int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)qmm_kernel<BT, R, WT>, 64 * nw,
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)qmm_kernel<BT, R, WT, 0>, 64 * nw,
                                                              qmm_lds_bytes(BT, R, nw)) != hipSuccess || nb < 1) nb = 1;
             blocks_per_cu[i] = nb;
         }
@@ -1934,7 +1936,8 @@ static int qmm_launch_btrw(QmmArgs& a, int n_wg, int NW, hipStream_t st) {
     a.kch = 0;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)qmm_kernel<BT, R, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qmm_kernel<BT, R, WT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qmm_kernel<BT, R, WT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     // (token, slot) pairs of a mixture-of-experts launch are workgroups too: all of them should be resident at once
@@ -1964,7 +1967,8 @@ static int qmm_launch_btrw(QmmArgs& a, int n_wg, int NW, hipStream_t st) {
                 return (int)hipGetLastError();
             }
         }
-        hipLaunchKernelGGL((qmm_kernel<BT, R, WT>), dim3(n_wg), dim3(64 * NW), shm, st, a);
+        if (a.x_dtype == MI355_DTYPE_BF16) hipLaunchKernelGGL((qmm_kernel<BT, R, WT, 1>), dim3(n_wg), dim3(64 * NW), shm, st, a);
+        else hipLaunchKernelGGL((qmm_kernel<BT, R, WT, 0>), dim3(n_wg), dim3(64 * NW), shm, st, a);
     }
     return (int)hipGetLastError();
 }
