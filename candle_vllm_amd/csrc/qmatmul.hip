@@ -278,13 +278,15 @@ struct XRegs {
 
 // XB: 1 = x is bf16, 0 = f32 (the single-launch kernels are built for both: a run-time branch around the activation loads
 // of the hot loop measured 2.3 % of the batch-1 step), -1 = decide at run time
-template <int BT, int XB = -1>
+// NRM: 1 = an RMSNorm weight is fused, 0 = none (no weight load, no sum of squares), -1 = decide at run time -- the same reason
+// (the branch in the staging step measured 1.4 % of the batch-1 step)
+template <int BT, int XB = -1, int NRM = -1>
 __device__ __forceinline__ XRegs<BT> load_x(const QmmArgs& a, int kb, int lane, const float* nwp) {
     XRegs<BT> r;
     const size_t k = (size_t)kb * 256 + 4 * lane;
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
-        const int bb = b < a.B ? b : a.B - 1;                     // padded rows re-read the last row (zeroed later)
+        const int bb = (BT == 1 || b < a.B) ? b : a.B - 1;        // padded rows re-read the last row (zeroed later)
         if (XB < 0 ? a.x_dtype == MI355_DTYPE_BF16 : XB == 1) {
             const uint2 t = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(a.x) + (size_t)bb * a.ldx + k);
             r.v[b] = make_uint4(t.x, t.y, 0, 0);
@@ -292,7 +294,8 @@ __device__ __forceinline__ XRegs<BT> load_x(const QmmArgs& a, int kb, int lane, 
             r.v[b] = *reinterpret_cast<const uint4*>(static_cast<const float*>(a.x) + (size_t)bb * a.ldx + k);
         }
     }
-    r.nw = *reinterpret_cast<const float4*>(nwp + k);
+    if (NRM != 0) r.nw = *reinterpret_cast<const float4*>(nwp + k);
+    else r.nw = make_float4(1.f, 1.f, 1.f, 1.f);
     return r;
 }
 
@@ -305,7 +308,7 @@ __device__ __forceinline__ XRegs<BT> load_x(const QmmArgs& a, int kb, int lane, 
 //     -> no shuffle reductions and no sum arrays in the staging step, no per-sub-block offset FMAs;
 //   * d and dmin are applied once per tile (sum_j sc_j*P_j and sum_j m_j*S_j are formed first);
 //   * tiles of one k-block that share a type are computed together so C_in and the A fragments are shared.
-template <int BT, int XB = -1>
+template <int BT, int XB = -1, int NRM = -1>
 __device__ __forceinline__ void stage_kblock3(const QmmArgs& a, const XRegs<BT>& xr, uint8_t* ximg, int lane, float (&ss)[BT]) {
     const int E = lane >> 1, half = lane & 1;
 #pragma unroll
@@ -318,8 +321,8 @@ __device__ __forceinline__ void stage_kblock3(const QmmArgs& a, const XRegs<BT>&
             v[0] = __uint_as_float(xr.v[b].x); v[1] = __uint_as_float(xr.v[b].y);
             v[2] = __uint_as_float(xr.v[b].z); v[3] = __uint_as_float(xr.v[b].w);
         }
-        if (b >= a.B) { v[0] = v[1] = v[2] = v[3] = 0.f; }
-        if (a.norm_w) {
+        if (BT > 1 && b >= a.B) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+        if (NRM < 0 ? a.norm_w != nullptr : NRM == 1) {
             ss[b] = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], ss[b]))));
             v[0] *= xr.nw.x; v[1] *= xr.nw.y; v[2] *= xr.nw.z; v[3] *= xr.nw.w;
         }
@@ -602,7 +605,7 @@ __device__ __forceinline__ void qmm_stamp(const QmmArgs& a, int i) {
 #define qmm_stamp(a, i) ((void)0)
 #endif
 
-template <int BT, int R, int WT, int XB>
+template <int BT, int R, int WT, int XB, int NRM>
 __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
     qmm_stamp(a, 0);
     // probe modes of this kernel exist only in -DMI355_QMM_PROBES builds (tools/): every guarded load or branch in the hot
@@ -664,7 +667,7 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
 #pragma unroll
     for (int q = 0; q < PFK; ++q) {
         const int kb = wave + NW * q;
-        xr[q] = load_x<BT, XB>(a, kb <= kb_last ? kb : kb_last, lane, nwp);
+        xr[q] = load_x<BT, XB, NRM>(a, kb <= kb_last ? kb : kb_last, lane, nwp);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const bool ok = q < n_my_kb;
@@ -679,9 +682,9 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
         for (int q = 0; q < PFK; ++q) {
             const int kbi = kbi0 + q;
             const bool active = kbi < n_my_kb;                    // wave-uniform
-            if (active && (dbg < 3 || dbg == 7)) stage_kblock3<BT, XB>(a, xr[q], ximg, lane, ss);
+            if (active && (dbg < 3 || dbg == 7)) stage_kblock3<BT, XB, NRM>(a, xr[q], ximg, lane, ss);
             const int kbn = wave + NW * (kbi + PFK);
-            if (dbg < 3 || dbg == 7) xr[q] = load_x<BT, XB>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp);
+            if (dbg < 3 || dbg == 7) xr[q] = load_x<BT, XB, NRM>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp);
             const bool ok = kbi + PFK < n_my_kb;
             if constexpr (WT != 0) {
                 // every tile of the launch has one type: the R tiles of this k-block share C_in and the A fragments
@@ -756,8 +759,8 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
     qmm_stamp(a, 3);
 }
 
-template <int BT, int R, int WT, int XB>
-__global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) { qmm_body<BT, R, WT, XB>(a); }
+template <int BT, int R, int WT, int XB, int NRM>
+__global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) { qmm_body<BT, R, WT, XB, NRM>(a); }
 // ================================================================================================
 // EXPERIMENT (mi355_set_tuning(18, 1), single-token launches only): the reference CPU path's own activation format.
 // candle's CPU mat-vec quantises x to Q8_K (per 256-block: iscale = -128 / max, q = round(iscale x) <= 127, d = 1 / iscale,
@@ -1009,7 +1012,7 @@ __global__ void __launch_bounds__(512) qmm_moe_kernel(const QmmArgs a_in) {
     const size_t xes = (a.x_dtype == MI355_DTYPE_BF16) ? 2 : 4;
     a.x = static_cast<const uint8_t*>(a.x) + (size_t)(pair / a.moe_xdiv) * a.ldx * xes;
     a.out += (size_t)pair * a.ldo;
-    qmm_body<1, R, WT, -1>(a);
+    qmm_body<1, R, WT, -1, -1>(a);
 }
 
 // ================================================================================================
@@ -1920,7 +1923,7 @@ static int qmm_pick_nw(int n_wg, int nkb) {
         if (nw > nkb) continue;
         if (blocks_per_cu[i] < 0) {
             int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)qmm_kernel<BT, R, WT, 0>, 64 * nw,
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)qmm_kernel<BT, R, WT, 0, 1>, 64 * nw,
                                                              qmm_lds_bytes(BT, R, nw)) != hipSuccess || nb < 1) nb = 1;
             blocks_per_cu[i] = nb;
         }
@@ -1936,8 +1939,10 @@ static int qmm_launch_btrw(QmmArgs& a, int n_wg, int NW, hipStream_t st) {
     a.kch = 0;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)qmm_kernel<BT, R, WT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)qmm_kernel<BT, R, WT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qmm_kernel<BT, R, WT, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qmm_kernel<BT, R, WT, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qmm_kernel<BT, R, WT, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qmm_kernel<BT, R, WT, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     // (token, slot) pairs of a mixture-of-experts launch are workgroups too: all of them should be resident at once
@@ -1967,8 +1972,11 @@ static int qmm_launch_btrw(QmmArgs& a, int n_wg, int NW, hipStream_t st) {
                 return (int)hipGetLastError();
             }
         }
-        if (a.x_dtype == MI355_DTYPE_BF16) hipLaunchKernelGGL((qmm_kernel<BT, R, WT, 1>), dim3(n_wg), dim3(64 * NW), shm, st, a);
-        else hipLaunchKernelGGL((qmm_kernel<BT, R, WT, 0>), dim3(n_wg), dim3(64 * NW), shm, st, a);
+        const bool xb = a.x_dtype == MI355_DTYPE_BF16, nrm = a.norm_w != nullptr;
+        if (xb && nrm) hipLaunchKernelGGL((qmm_kernel<BT, R, WT, 1, 1>), dim3(n_wg), dim3(64 * NW), shm, st, a);
+        else if (xb) hipLaunchKernelGGL((qmm_kernel<BT, R, WT, 1, 0>), dim3(n_wg), dim3(64 * NW), shm, st, a);
+        else if (nrm) hipLaunchKernelGGL((qmm_kernel<BT, R, WT, 0, 1>), dim3(n_wg), dim3(64 * NW), shm, st, a);
+        else hipLaunchKernelGGL((qmm_kernel<BT, R, WT, 0, 0>), dim3(n_wg), dim3(64 * NW), shm, st, a);
     }
     return (int)hipGetLastError();
 }
