@@ -2074,7 +2074,11 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
     } else {
         R = 1;
         if (div2 && total_tiles / 2 >= 1024) R = 2;
-        if (div4 && total_tiles / 4 >= 1024) R = 4;
+        // four Q6_K tiles per workgroup need more than the register file (256 VGPRs + spills once the body is branch-free):
+        // lm_head of Llama-3-8B 108 us with R = 4, 74 us with R = 2
+        bool any_q6 = false;
+        for (int s = 0; s < a.nseg; ++s) any_q6 = any_q6 || a.seg[s].type == MI355_GGML_Q6_K;
+        if (div4 && total_tiles / 4 >= 1024 && !any_q6) R = 4;
     }
     if (g_tune_r > 0 && !(a.paired && g_tune_r == 1)) {
         if (g_tune_r == 4 && (a.paired ? a.seg[0].n_tiles % 2 == 0 : div4)) R = 4;
