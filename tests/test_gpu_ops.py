@@ -523,6 +523,31 @@ def test_moe_route_experts_combine(cv, T):
     assert rel_err(ys.cpu().numpy(), ref) < 1e-3
 
 
+@pytest.mark.parametrize("hid,E,K", [(4096, 8, 2), (2048, 4, 2), (1024, 16, 4), (8192, 2, 1), (4096, 1, 1), (3072, 8, 2), (4096, 6, 2)])
+def test_moe_router_wide_kernel_and_fallback(cv, hid, E, K):
+    """Router at model-sized hidden: 1..16 experts (a power of two) with hidden % 1024 == 0 take the 16-wave kernel whose loads
+    all leave in one round trip; 3072 x 8 (slice not a multiple of 256) and 6 experts take the generic kernel.  Expert ids bit
+    for bit, renormalised weights to 1e-5, with and without the fused RMSNorm."""
+    from oracle import llama as L
+    rng = np.random.default_rng(hid + E)
+    T = 5
+    x = rng.normal(0, 1, (T, hid)).astype(np.float32)
+    nw = (1.0 + rng.normal(0, 0.05, hid)).astype(np.float32)
+    gate = rng.normal(0, 0.5, (E, hid)).astype(np.float32)
+    st = torch.cuda.current_stream().cuda_stream
+    for use_norm in (True, False):
+        xin = O.rms_norm(x, nw, 1e-5) if use_norm else x
+        ids_ref, w_ref = L.moe_route(xin, gate, K)
+        ids = torch.full((T, K), -1, dtype=torch.int32, device="cuda")
+        wts = torch.zeros((T, K), dtype=torch.float32, device="cuda")
+        nwd = dev(nw)
+        assert cv.lib.mi355_moe_route(ids.data_ptr(), wts.data_ptr(), dev(x).data_ptr(), nwd.data_ptr() if use_norm else None, 1e-5,
+                                      dev(gate).data_ptr(), T, hid, E, K, st) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(ids.cpu().numpy(), ids_ref)
+        assert np.abs(wts.cpu().numpy() - w_ref).max() < 1e-5
+
+
 @pytest.mark.parametrize("bs,ctx", [(64, [4100, 37, 520]), (16, [1000, 259])])
 def test_paged_attention_workgroup_merge_equals_one_wave_per_partition(cv, bs, ctx):
     """4 partitions per workgroup merged in LDS (few sequences, long contexts) vs one wave per partition: same
