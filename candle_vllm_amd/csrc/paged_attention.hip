@@ -876,10 +876,13 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
                (p.partition_size == 32 || p.partition_size == 64 || p.partition_size == 128)) {
         bool fused = false;
         // few sequences, many partitions: 4 partitions per workgroup, merged in LDS (4 x fewer partials to reduce)
+        // one sequence with a long context (batch-1 decode): 8 partitions per workgroup and the merge in the last arriver --
+        // measured +1 % on the whole step in three sessions (507 -> 512 tok/s); at 2..8 sequences it is noise, so the rule stops there
+        const bool lone = (int64_t)B * p.Hkv <= 8 && P >= 32 && p.partition_size <= 64 && g_pa_fused == 1 && g_pa_wpb == 0;
         if (g_pa_wpb > 0) wpb = ((g_pa_wpb == 4 || g_pa_wpb == 8 || g_pa_wpb == 16) && p.partition_size <= 64) ? g_pa_wpb : 1;
-        else wpb = (P >= 8 && p.partition_size <= 64) ? 4 : 1;
+        else wpb = lone ? 8 : ((P >= 8 && p.partition_size <= 64) ? 4 : 1);
         // the in-kernel merge is one wave per (sequence, kv head): worth it only when there are many of them
-        if (P > 1 && g_pa_fused && (int64_t)B * p.Hkv >= (g_pa_fused > 1 ? 1 : 64) && (int64_t)B * p.Hkv <= PA_ARRIVE_SLOTS) {
+        if (P > 1 && g_pa_fused && ((int64_t)B * p.Hkv >= (g_pa_fused > 1 ? 1 : 64) || lone) && (int64_t)B * p.Hkv <= PA_ARRIVE_SLOTS) {
             // tickets belong to (device, stream): two streams never share a counter (scratch.cpp)
             void* arr = nullptr;
             const int arc = mi355_scratch_get(&arr, MI355_SCR_PA_ARRIVE, PA_ARRIVE_SLOTS * 4, st, true);
