@@ -1018,16 +1018,15 @@ __global__ void __launch_bounds__(512) qmm_moe_kernel(const QmmArgs a_in) {
 // ================================================================================================
 // Wide path (9..32 tokens per launch): every weight byte is still read once.  GEMM-style: the consumer waves of a
 // workgroup own different row tiles and sweep K together, sharing one LDS image of the activations per k-block
-// (double-buffered, one barrier per k-block).  The image (hi/lo bf16 fragments + sub-block sums, RMSNorm weight already
-// applied) is produced by `qmg_prep_entry` -- in the staging launch or in the previous mat-mul's epilogue.
+// (double-buffered, one barrier per k-block).  The image (f16 hi / lo fragments of x / 16, lo scaled by 2^11, + the bf16
+// pieces of the 32-element sub-block sums; RMSNorm weight already applied) is produced by `qmg_prep_entry` -- in the staging launch or in the previous mat-mul's epilogue.
 //   image of k-block kb:  ximg [32 entries][MT*16 rows][16 B] | S32 fragments [MT][4][16][4 bf16]   (1088 B per token row)
 //   rows of M-tile mt: mt*16 + m, m<8 = hi(batch 8mt+m), m>=8 = lo(batch 8mt+m-8)
 #define QMW_MAXMT 4
 
-// Second-generation image (qmg_prep_entry): the Q4_K minimum and "+128" offset terms are NOT applied per sub-block in
-// VALU (4 FMAs per MFMA and token group) but by two K=16 MFMAs per m-tile against the sub-block sums staged as an A
-// fragment:  T1 = sum_j m_j S_j,  T2 = sum_j sc_j S_j  ->  y -= dmin*T1 + 128*d*T2.   Per 2304-B unit at 32 tokens:
-// 256 -> 128 + 32 FMAs.
+// The Q4_K minimum term is NOT applied per sub-block in VALU but by one K=16 MFMA per m-tile against the sub-block sums
+// staged as an A fragment (bf16 hi / lo pieces of S):  T1 = sum_j m_j S_j  ->  y -= dmin * T1.  (The second generation also
+// needed T2 = sum_j sc_j S_j for the "+128" of its bf16 code trick; the f16 operands of the third carry no offset.)
 __device__ __forceinline__ uint2 bytes4_to_bf16x4(uint32_t w) {
     // integers < 256 are exact in bf16 = the upper half of their f32: plain bit operations.  (Not cvt_pk_bf16: that is
     // an inline-asm VALU write, and hipcc pads no wait states between an asm-written VGPR and an MFMA that reads it as an
@@ -1194,7 +1193,7 @@ static inline size_t qmg_kb_bytes(int MT) { return (((size_t)MT * 8 * 1088) + 10
 // image + per-k-block sum of squares in ONE pass: grid = k-blocks, a workgroup builds k-block kb for every token
 // row.  The RMSNorm weight is applied here, the 1/rms factor (a per-token scalar) is applied by the epilogue kernel
 // from the per-k-block partial sums ssp[kb][row] -- no second pass over x, no atomics.
-// one image entry (8 consecutive elements El of k-block kb, token row b): hi/lo bf16 fragments, sub-block sums, and the
+// one image entry (8 consecutive elements El of k-block kb, token row b): f16 hi / lo fragments, sub-block sums, and the
 // sum of squares of the row's k-block (reduced over the 32 consecutive lanes that hold its 32 entries)
 __device__ __forceinline__ void qmg_prep_entry(uint8_t* __restrict__ img, float* __restrict__ ssp, float (&v)[8], const bool live,
                                                const float* __restrict__ norm_w, const int MT, const size_t kbb,
