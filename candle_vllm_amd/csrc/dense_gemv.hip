@@ -165,7 +165,8 @@ __device__ __forceinline__ void dense_body(const DenseArgs& a, const int bx) {
                 }
 #pragma unroll
             for (int gq = 0; gq < 8 / GJ; ++gq) {
-                const int g = (kb * 256 + 32 * GJ * gq) / a.group_size;
+                // groups of 32 / 64 / 128 are exactly GJ runs wide: no run-time division in the loop (GJ == 8: groups of >= 256)
+                const int g = GJ < 8 ? kb * (8 / GJ) + gq : (kb * 256) / a.group_size;
                 // row sums of x over the group (every column of a ones-MFMA result holds it)
                 f32x4_t xs[MT];
 #pragma unroll
