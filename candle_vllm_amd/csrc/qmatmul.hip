@@ -773,16 +773,17 @@ __global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) { qmm_body<BT
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 #define Q8W_BYTES 352                 // per token and wave: 256 codes + 16 sums of 16 (i32) + d (f32) + pad
 
+template <int XB, int NRM>
 __device__ __forceinline__ void stage_q8k(const QmmArgs& a, const XRegs<1>& xr, uint8_t* xq, int lane, float (&ss)[1]) {
     float v[4];
-    if (a.x_dtype == MI355_DTYPE_BF16) {
+    if (XB == 1) {
         v[0] = bf16lo_to_f32(xr.v[0].x); v[1] = bf16hi_to_f32(xr.v[0].x);
         v[2] = bf16lo_to_f32(xr.v[0].y); v[3] = bf16hi_to_f32(xr.v[0].y);
     } else {
         v[0] = __uint_as_float(xr.v[0].x); v[1] = __uint_as_float(xr.v[0].y);
         v[2] = __uint_as_float(xr.v[0].z); v[3] = __uint_as_float(xr.v[0].w);
     }
-    if (a.norm_w) {
+    if (NRM == 1) {
         ss[0] = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], ss[0]))));
         v[0] *= xr.nw.x; v[1] *= xr.nw.y; v[2] *= xr.nw.z; v[3] *= xr.nw.w;
     }
@@ -909,7 +910,7 @@ __device__ __forceinline__ void compute_q6k_i8(const TileRegs* w, const uint8_t*
     }
 }
 
-template <int R, int WT>
+template <int R, int WT, int XB, int NRM>
 __device__ __forceinline__ void qmm_body_q8(const QmmArgs& a) {
     constexpr int BT = 1, NV = 1;
     constexpr int PF = (R > QMM_PF_MIN) ? R : QMM_PF_MIN;
@@ -955,7 +956,7 @@ __device__ __forceinline__ void qmm_body_q8(const QmmArgs& a) {
 #pragma unroll
     for (int q = 0; q < PFK; ++q) {
         const int kb = wave + NW * q;
-        xr[q] = load_x<BT>(a, kb <= kb_last ? kb : kb_last, lane, nwp);
+        xr[q] = load_x<BT, XB, NRM>(a, kb <= kb_last ? kb : kb_last, lane, nwp);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const bool ok = q < n_my_kb;
@@ -968,12 +969,12 @@ __device__ __forceinline__ void qmm_body_q8(const QmmArgs& a) {
         for (int q = 0; q < PFK; ++q) {
             const int kbi = kbi0 + q;
             const bool active = kbi < n_my_kb;
-            if (active) stage_q8k(a, xr[q], xq, lane, ss);
+            if (active) stage_q8k<XB, NRM>(a, xr[q], xq, lane, ss);
             // the sums and d are written by single lanes and read by all: without a wave-scope fence the compiler may hoist
             // another lane's read above the store it never executes itself (seen: lane 0 right, lanes 1..15 stale)
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             const int kbn = wave + NW * (kbi + PFK);
-            xr[q] = load_x<BT>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp);
+            xr[q] = load_x<BT, XB, NRM>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp);
             const bool ok = kbi + PFK < n_my_kb;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -997,8 +998,8 @@ __device__ __forceinline__ void qmm_body_q8(const QmmArgs& a) {
     __syncthreads();
     qmm_epilogue<BT, R>(a, red, red_ss, NW, segi, tile, ep);
 }
-template <int R, int WT>
-__global__ void __launch_bounds__(512) qmm_q8_kernel(const QmmArgs a) { qmm_body_q8<R, WT>(a); }
+template <int R, int WT, int XB, int NRM>
+__global__ void __launch_bounds__(512) qmm_q8_kernel(const QmmArgs a) { qmm_body_q8<R, WT, XB, NRM>(a); }
 
 // MoE variant (decode-shaped, BT = 1): blockIdx.y = (token, slot) pair.  The adjusted descriptor is a private copy
 // -- kept out of the dense kernel, where the kernel arguments must stay scalar loads from the kernarg segment.
@@ -1962,12 +1963,12 @@ static int qmm_launch_btrw(QmmArgs& a, int n_wg, int NW, hipStream_t st) {
     } else {
         if constexpr (BT == 1) {
             if (g_tune_actq8) {
-                static bool q8_attr_done = false;
-                if (!q8_attr_done) {
-                    (void)hipFuncSetAttribute((const void*)qmm_q8_kernel<R, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    q8_attr_done = true;
-                }
-                hipLaunchKernelGGL((qmm_q8_kernel<R, WT>), dim3(n_wg), dim3(64 * NW), shm, st, a);
+                const bool xb8 = a.x_dtype == MI355_DTYPE_BF16, nrm8 = a.norm_w != nullptr;
+#define Q8_GO(XB_, NRM_) do { \
+                    (void)hipFuncSetAttribute((const void*)qmm_q8_kernel<R, WT, XB_, NRM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                    hipLaunchKernelGGL((qmm_q8_kernel<R, WT, XB_, NRM_>), dim3(n_wg), dim3(64 * NW), shm, st, a); } while (0)
+                if (xb8 && nrm8) Q8_GO(1, 1); else if (xb8) Q8_GO(1, 0); else if (nrm8) Q8_GO(0, 1); else Q8_GO(0, 0);
+#undef Q8_GO
                 return (int)hipGetLastError();
             }
         }
