@@ -92,6 +92,7 @@ _sig("mi355_qmatmul", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i3
 _sig("mi355_qmatmul_fused", ctypes.c_int, [ctypes.POINTER(QmmDesc), c_i64])
 _sig("mi355_set_tuning", None, [c_i32, c_i32])
 _sig("mi355_debug_set_timestamps", ctypes.c_int, [c_vp])
+_sig("mi355_qmv_error", ctypes.c_int, [ctypes.POINTER(ctypes.c_int32), c_i32])
 _sig("mi355_moe_route", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64])
 _sig("mi355_moe_combine", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64])
 _sig("mi355_moe_gather", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])

@@ -109,8 +109,10 @@ struct OneShotArgs {
 #define P2P_SPIN_LIMIT (1 << 22)
 __global__ void __launch_bounds__(1024) oneshot_allreduce_kernel(const OneShotArgs a) {
     __shared__ uint32_t s_seq;
+    __shared__ int s_lost;
     const int g = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) {
+        s_lost = 0;
         // the call counter lives in this rank's own region: a captured graph replays with fresh sequence numbers
         const uint32_t s = __hip_atomic_load(&a.local->ctr[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;
         __hip_atomic_store(&a.local->ctr[g], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -142,15 +144,21 @@ __global__ void __launch_bounds__(1024) oneshot_allreduce_kernel(const OneShotAr
             __builtin_amdgcn_s_sleep(2);
             if (++spins > P2P_SPIN_LIMIT) {                           // bounded: a lost peer is an error, never a hang
                 __hip_atomic_store(&a.local->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                s_lost = 1;
                 break;
             }
         }
     }
     __syncthreads();
+    // a peer that missed the spin bound makes this call's sum meaningless: poison the outputs (NaN travels to the logits and
+    // the sampled token of every rank that was waiting) instead of adding stale slices -- never a plausible wrong number; the
+    // sticky error word is read by mi355_llama_read_tokens / mi355_comm_p2p_error
+    const bool lost = s_lost != 0;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int64_t i = base + tid + 1024 * j;
         if (i >= a.count) continue;
+        if (lost) { a.out[i] = __uint_as_float(0x7FC00000u); continue; }
         float acc = 0.f;
         for (int r = 0; r < a.world; ++r)
             acc += (r == a.rank) ? v[j] : __hip_atomic_load(&a.peer[r]->stage[par][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -266,9 +274,10 @@ extern "C" int mi355_comm_p2p_export(void* comm, void* handle_out64) {
     if (!c->local) {
         void* p = nullptr;
         // fine-grained (system-coherent) memory: peers poll the flags and read the slices while the kernel runs
+        // (no coarse-grained fallback: on plain hipMalloc memory the system-scope flag / slice protocol is not guaranteed to be
+        // visible to a peer while the kernel runs -- the export fails and the caller keeps RCCL)
         hipError_t e = hipExtMallocWithFlags(&p, sizeof(P2PRegion), hipDeviceMallocFinegrained);
-        if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&p, sizeof(P2PRegion)); }
-        if (e != hipSuccess) return (int)e;
+        if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
         e = hipMemset(p, 0, sizeof(P2PRegion));
         if (e != hipSuccess) { (void)hipFree(p); return (int)e; }
         CCHECK(hipDeviceSynchronize());

@@ -817,7 +817,13 @@ extern "C" int mi355_llama_decode_read_tokens(void* mp, uint32_t* host_out, int6
     if (!m || m->cur_batch < 1) return (int)hipErrorInvalidValue;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipMemcpyAsync(host_out, m->d_tokens, (size_t)m->cur_batch * 4, hipMemcpyDeviceToHost, st));
+    // the one-shot peer all-reduce's sticky error word rides along in the same synchronisation: a peer that missed the spin
+    // bound poisoned that step's activations with NaN (comm.hip), and the tokens read here must not be used
+    uint32_t p2p_err = 0;
+    const bool p2p = m->use_comm && m->comm && m->comm->p2p && m->comm->local;
+    if (p2p) HCHECK(hipMemcpyAsync(&p2p_err, &m->comm->local->err, 4, hipMemcpyDeviceToHost, st));
     HCHECK(hipStreamSynchronize(st));
+    if (p2p && p2p_err != 0) return (int)hipErrorPeerAccessNotEnabled;   // "a peer was not there": the step is invalid on this rank
     return 0;
 }
 

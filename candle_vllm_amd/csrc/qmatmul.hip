@@ -1535,6 +1535,9 @@ static QmgStream& qmg_stream(hipStream_t st) {
     std::lock_guard<std::mutex> lock(g_qmg_mu);
     return g_qmg_streams[std::make_pair(dev, st)];              // std::map: the reference stays valid across later inserts
 }
+static int g_tune_qmv = 0;                                    // mi355_set_tuning(20, 1): single-token launches take the LDS-DMA engine (qmv_engine.inc) one by one -- measured slower than qmm_kernel per launch (fixed cost), faster chained
+static int g_tune_qmv_nc = 8;                                 // mi355_set_tuning(21, n): consumer waves per workgroup of the engine (1..15)
+static int g_tune_qmv_ring = 0;                               // mi355_set_tuning(22, 64): the engine never takes the 128 KiB ring (A/B)
 static int g_tune_chain = 1;                                  // mi355_set_tuning(9, 0): never chain (A/B experiments)
 static int g_tune_wide16 = 0;                                 // mi355_set_tuning(15, n): launches of >= n (row tile x k-block) units use 16-wave workgroups
 static int g_tune_merge = 1;                                  // mi355_set_tuning(14, 0): one launch per run of same-type segments (A/B)
@@ -1897,6 +1900,9 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     else if (key == 17 && value > 0) g_tune_ks_minkb = value;
     else if (key == 11) g_tune_qpg = value;
     else if (key == 12 && value > 0) g_tune_qpg_min = value;
+    else if (key == 20) g_tune_qmv = value;
+    else if (key == 21 && value > 0) g_tune_qmv_nc = value;
+    else if (key == 22) g_tune_qmv_ring = value;
 }
 
 static size_t qmm_lds_bytes(int BT, int R, int NW) {
@@ -1905,6 +1911,8 @@ static size_t qmm_lds_bytes(int BT, int R, int NW) {
 }
 
 static int g_num_cus = 0;
+
+#include "qmv_engine.inc"
 
 // Waves per workgroup: the largest NW in {8,4,2,1} for which every workgroup of the launch is resident at
 // once (no second dispatch round => no tail), judged by the occupancy the runtime reports for this variant.
@@ -2144,7 +2152,10 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
         a.positions = pos0 ? pos0 + b0 : nullptr;
         a.slot_mapping = slot0 ? slot0 + b0 : nullptr;
         int rc;
-        if (bn == 1) rc = qmm_launch_bt<1>(a, R, wt, n_wg, NW, st);
+        if (bn == 1) {
+            rc = qmv_launch(a, wt, st);                       // LDS-DMA loader / consumer engine (qmv_engine.inc)
+            if (rc == (int)hipErrorNotSupported) rc = qmm_launch_bt<1>(a, R, wt, n_wg, NW, st);
+        }
         else if (bn == 2) rc = qmm_launch_bt<2>(a, R, wt, n_wg, NW, st);
         else if (bn <= 4) rc = qmm_launch_bt<4>(a, R, wt, n_wg, NW, st);
         else rc = qmm_launch_bt<8>(a, R, wt, n_wg, NW, st);

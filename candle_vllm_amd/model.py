@@ -131,7 +131,10 @@ class GGUFLLaMa:
         def qw(layer, which, tw):
             t, blocks = tw
             b = np.ascontiguousarray(blocks)
-            _check(lib.mi355_llama_set_qweight(self.h, layer, which, t, b.ctypes.data, b.shape[0], b.shape[1] * 256),
+            # blocks [N, k / per, block bytes]: a k-quant super-block holds 256 weights, a re-quantised Q8_0 shard's block 32
+            # (tp.shard_weights(..., requant); ADVICE r2: `* 256` for every type read 8x the host buffer)
+            per = 32 if int(t) == 8 else 256
+            _check(lib.mi355_llama_set_qweight(self.h, layer, which, t, b.ctypes.data, b.shape[0], b.shape[1] * per),
                    "set_qweight")
             self.weight_bytes += b.size
         f32(-1, W_TOK_EMBD, W["tok_embd"])

@@ -252,6 +252,11 @@ void mi355_set_tuning(int32_t key, int32_t value);
 /* experiments only: device buffer of uint64 [workgroup][16 waves][4] that the 1..8-token mat-vec fills with wall-clock
  * stamps (entry, main loop done, past the barrier, exit) while probe mode 7 is set (probe builds only); NULL switches it off */
 int mi355_debug_set_timestamps(void* dev_ptr);
+/* Single-token launches run on the LDS-DMA loader / consumer engine (csrc/qmv_engine.inc; tuning keys 20 on / off, 21 consumer
+ * waves, 22 = 64 forbids the 128-KiB ring).  Its in-workgroup waits are bounded: a wait that gave up leaves a sticky device
+ * word (1 consumer waited for data, 2 loader waited for ring space, 3 consumer waited for the activation image) and the
+ * launch's outputs are then garbage.  Reads the word into *out_host (synchronising copy) and clears it when reset != 0. */
+int mi355_qmv_error(int32_t* out_host, int32_t reset);
 
 /* ---------------------------------------------------------------------------------------------
  * 3b. Safetensors path: dense 16-bit and GPTQ/AWQ/Marlin 4-bit linears (decode-shaped, any num_tokens).
