@@ -325,6 +325,13 @@ def main():
     st = stream.cuda_stream
     # TP steps are captured too (RCCL on its side stream joins the capture as a fork / join; --tp-eager keeps them eager)
     graph_mode = (not args.no_graph) and not (world > 1 and args.tp_eager)
+    if world > 1 and graph_mode:
+        # every rank tests LOCALLY whether this stack captures the communicator's all-reduce (capture + instantiate, nothing
+        # is launched), then the ranks agree: one rank falling back to eager steps alone would leave its peers inside a
+        # collective
+        flag = torch.tensor([1 if gm.comm_capture_ok(st) else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        graph_mode = bool(int(flag.item()))
     gm.set_graph(graph_mode)
     ctx_cap = args.ctx + K + Wm + 2
     gm.decode_begin(tokens, seq_lens, bt, ctx_cap=ctx_cap, stream=st)
@@ -334,15 +341,7 @@ def main():
             gm.decode_step(st)
             gm.read_tokens(st)                                # greedy sample -> host every step, as the engine does
 
-    try:
-        run(Wm)
-    except RuntimeError:
-        if world == 1 or not graph_mode:
-            raise
-        graph_mode = False                                    # capture of the collectives refused on this stack: eager TP steps
-        gm.set_graph(False)
-        gm.decode_begin(tokens, seq_lens, bt, ctx_cap=ctx_cap, stream=st)
-        run(Wm)
+    run(Wm)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -93,6 +93,8 @@ _sig("mi355_qmatmul_fused", ctypes.c_int, [ctypes.POINTER(QmmDesc), c_i64])
 _sig("mi355_set_tuning", None, [c_i32, c_i32])
 _sig("mi355_debug_set_timestamps", ctypes.c_int, [c_vp])
 _sig("mi355_qmv_error", ctypes.c_int, [ctypes.POINTER(ctypes.c_int32), c_i32])
+_sig("mi355_qmv_chain_sync_bytes", ctypes.c_int, [])
+_sig("mi355_qmatmul_chain", ctypes.c_int, [ctypes.POINTER(QmmDesc), c_i32, c_vp, c_i64])
 _sig("mi355_moe_route", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64])
 _sig("mi355_moe_combine", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64])
 _sig("mi355_moe_gather", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
@@ -242,6 +244,7 @@ _sig("mi355_comm_all_reduce_residual", ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c
 _sig("mi355_comm_p2p_export", ctypes.c_int, [c_vp, c_vp])
 _sig("mi355_comm_p2p_attach", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32])
 _sig("mi355_comm_p2p_error", ctypes.c_int, [c_vp])
+_sig("mi355_comm_capture_probe", ctypes.c_int, [c_vp, c_i64])
 _sig("mi355_dense_alloc_kv_cache", ctypes.c_int, [c_vp, c_i32])
 _sig("mi355_dense_kv_ptr", c_vp, [c_vp, c_i32, c_i32])
 _sig("mi355_dense_forward", ctypes.c_int, [c_vp] * 7 + [c_i32] * 5 + [c_vp, c_i64])

@@ -894,6 +894,14 @@ struct Sched {
         for (int64_t sid : gr.seqs) { auto it = eng->tables.find(sid); if (it != eng->tables.end()) nblk += it->second.size(); }
         std::vector<int64_t> pairs(2 * nblk + 2);
         const int k = mi355_be_swap_out(eng, gid, gr.seqs.data(), (int)gr.seqs.size(), pairs.data(), (int32_t)nblk);
+        if (k < 0) {
+            // the swap was refused by its up-front checks (nothing moved): the group must not be recorded as
+            // swapped out.  Fall back the way `can_swap_out == false` does: recompute a single sequence, abort a larger group.
+            if (gr.seqs.size() == 1) { preempt_by_recompute(gid); return; }
+            request_release(gr);
+            abort_group(gid);
+            return;
+        }
         for (int i = 0; i < k; ++i) { result[R_SWAP_OUT_PAIRS].push_back(pairs[2 * i]); result[R_SWAP_OUT_PAIRS].push_back(pairs[2 * i + 1]); }
         result[R_SWAP_OUT_GROUPS].push_back(gid);
         gr.has_swapped_time = true; gr.swapped_ms = now_ms;
@@ -1057,6 +1065,7 @@ int32_t mi355_sched_schedule(void* sp, uint64_t now_ms) {
             for (int64_t sid : gr.seqs) { auto it = e->tables.find(sid); if (it != e->tables.end()) nblk += it->second.size(); }
             std::vector<int64_t> pairs(2 * nblk + 2);
             const int k = mi355_be_swap_in(e, gid, gr.seqs.data(), (int)gr.seqs.size(), pairs.data(), (int32_t)nblk);
+            if (k < 0) { s->swapped.push_front(gid); break; }                        // refused, nothing moved: the group stays swapped out, first in line
             for (int i = 0; i < k; ++i) { s->result[R_SWAP_IN_PAIRS].push_back(pairs[2 * i]); s->result[R_SWAP_IN_PAIRS].push_back(pairs[2 * i + 1]); }
             s->result[R_SWAP_IN_GROUPS].push_back(gid);
             gr.has_swapped_time = false;

@@ -312,6 +312,37 @@ extern "C" int mi355_comm_p2p_error(void* comm) {
     return (int)e;
 }
 
+// Can this stack capture the communicator's all-reduce in a hipGraph?  Captures one 64-element all-reduce on `stream`,
+// instantiates the graph and destroys it WITHOUT launching: nothing runs on the wire, so a rank can test locally and the ranks
+// agree on graph / eager steps before the first real step (a per-rank fallback after a failed first step would leave its
+// peers inside a collective).  0 = capturable.
+extern "C" int mi355_comm_capture_probe(void* comm, int64_t stream) {
+    Comm* c = static_cast<Comm*>(comm);
+    if (!c || stream == 0) return (int)hipErrorInvalidValue;
+    if (c->ar && !c->p2p) return (int)hipErrorNotSupported;       // host-supplied collectives are host calls: never captured
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    void* buf = nullptr;
+    CCHECK(hipMalloc(&buf, 64 * sizeof(float)));
+    (void)hipMemsetAsync(buf, 0, 64 * sizeof(float), st);
+    (void)hipStreamSynchronize(st);
+    int rc = (int)hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    hipGraph_t g = nullptr;
+    if (rc == 0) {
+        rc = comm_all_reduce(c, buf, 64, MI355_DTYPE_F32, stream);
+        const int erc = (int)hipStreamEndCapture(st, &g);         // always close the capture, also after a refused enqueue
+        if (rc == 0) rc = erc;
+    }
+    if (rc == 0 && g) {
+        hipGraphExec_t ge = nullptr;
+        rc = (int)hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        if (ge) (void)hipGraphExecDestroy(ge);
+    }
+    if (g) (void)hipGraphDestroy(g);
+    if (rc) (void)hipGetLastError();
+    (void)hipFree(buf);
+    return rc;
+}
+
 extern "C" int mi355_comm_all_reduce(void* comm, void* buf, int64_t count, int32_t dtype, int64_t stream) {
     if (!comm || nccl_dtype_of(dtype) < 0) return (int)hipErrorInvalidValue;
     return comm_all_reduce(static_cast<Comm*>(comm), buf, count, dtype, stream);

@@ -94,6 +94,7 @@ struct Model {
     float* tp_y = nullptr;          // [B, hidden] this rank's o_proj / down_proj partial in the reference's wire mode (bf16 all-reduce)
     float* p_tp_y = nullptr;        // same for prompt steps (grow-only with the prefill workspace)
     float* logits_local = nullptr;  // [B, vocab/W]
+    void* chain_sync = nullptr;     // arrival counters of the chained single-token launches (qmv_chain.inc), zeroed once
     float* logits_gather = nullptr; // [W, B, vocab/W]
     // prefill workspace (grow-only, sized by the largest chunk seen): same roles as xs / q / attn / h
     float* p_xs = nullptr; uint16_t* p_q = nullptr; uint16_t* p_attn = nullptr; float* p_h = nullptr;
@@ -186,6 +187,66 @@ int all_reduce_xs(Model* m, float* xs, float* y, int B, int64_t st) {
 
 enum { PART_QKV = 0, PART_ATTN = 1, PART_WO = 2, PART_GATEUP = 3, PART_DOWN = 4, PART_HEAD = 5, PART_EMBED = 6 };
 
+// The mat-mul descriptor of one dense (non-MoE) launch group, exactly as run_part issues it -- shared with the chained
+// single-token step (run_chain), which hands four of them to ONE persistent launch.
+void dense_desc(Model* m, int l, int part, const StepIn& in, float* logits, mi355_qmm_desc& d) {
+    const mi355_llama_config& c = m->cfg;
+    const int H = local_heads(m), Hkv = local_kv_heads(m), D = c.head_dim, hid = c.hidden, B = in.B;
+    const bool lead = c.tp_rank == 0;
+    memset(&d, 0, sizeof(d));
+    if (part == PART_HEAD) {
+        d.nseg = 1;
+        d.w_tiles[0] = m->output.tiles; d.ggml_type[0] = m->output.type; d.n_rows[0] = m->output.n_rows;
+        d.x = in.xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
+        d.norm_weight = m->output_norm; d.norm_eps = c.rms_eps;
+        d.epilogue = MI355_EPI_STORE; d.ldo = m->output.n_rows;
+        d.out = m->use_comm ? m->logits_local : logits;
+        return;
+    }
+    Layer& L = m->layers[l];
+    const int I = L.w[MI355_W_W1].n_rows;
+    if (part == PART_QKV) {
+        d.nseg = 3;
+        const int qkv[3] = {MI355_W_WQ, MI355_W_WK, MI355_W_WV};
+        for (int s = 0; s < 3; ++s) {
+            d.w_tiles[s] = L.w[qkv[s]].tiles; d.ggml_type[s] = L.w[qkv[s]].type; d.n_rows[s] = L.w[qkv[s]].n_rows;
+        }
+        d.x = in.xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
+        d.norm_weight = L.attn_norm; d.norm_eps = c.rms_eps;
+        d.epilogue = MI355_EPI_QKV_ROPE_CACHE;
+        d.cos_table = m->cos_t; d.sin_table = m->sin_t; d.positions = in.positions; d.slot_mapping = in.slots;
+        d.q_out = in.q; d.key_cache = m->kcache[l]; d.value_cache = m->vcache[l];
+        d.num_heads = H; d.num_kv_heads = Hkv; d.head_dim = D; d.rotary_dim = D;
+        d.block_size = c.block_size; d.kv_layout = c.kv_layout;
+    } else if (part == PART_WO) {
+        d.nseg = 1;
+        d.w_tiles[0] = L.w[MI355_W_WO].tiles; d.ggml_type[0] = L.w[MI355_W_WO].type; d.n_rows[0] = L.w[MI355_W_WO].n_rows;
+        d.x = in.attn; d.x_dtype = MI355_DTYPE_BF16; d.ldx = H * D; d.k = H * D; d.num_tokens = B;
+        d.epilogue = lead ? MI355_EPI_RESID : MI355_EPI_STORE; d.out = in.xs; d.ldo = hid; d.residual = in.xs;
+        if (wire_bf16(m)) { d.epilogue = MI355_EPI_STORE; d.out = in.tp_y; d.residual = nullptr; }   // partial only; + residual after the sum
+        // 9..32 tokens: the epilogue stages the gate/up launch's activation image (xs is final here unless TP reduces it)
+        if (!m->use_comm && c.n_expert <= 1) { d.chain_next = 1; d.chain_next_k = hid; d.chain_next_norm = L.ffn_norm; }
+    } else if (part == PART_GATEUP) {
+        d.nseg = 2;
+        d.w_tiles[0] = L.w[MI355_W_W1].tiles; d.ggml_type[0] = L.w[MI355_W_W1].type; d.n_rows[0] = L.w[MI355_W_W1].n_rows;
+        d.w_tiles[1] = L.w[MI355_W_W3].tiles; d.ggml_type[1] = L.w[MI355_W_W3].type; d.n_rows[1] = L.w[MI355_W_W3].n_rows;
+        d.x = in.xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
+        d.norm_weight = L.ffn_norm; d.norm_eps = c.rms_eps;
+        d.epilogue = MI355_EPI_SILU_MUL; d.out = in.h; d.ldo = I;
+        d.chain_next = 1; d.chain_next_k = I; d.chain_next_norm = nullptr;          // -> w2
+    } else if (part == PART_DOWN) {
+        d.nseg = 1;
+        d.w_tiles[0] = L.w[MI355_W_W2].tiles; d.ggml_type[0] = L.w[MI355_W_W2].type; d.n_rows[0] = L.w[MI355_W_W2].n_rows;
+        d.x = in.h; d.x_dtype = MI355_DTYPE_F32; d.ldx = I; d.k = I; d.num_tokens = B;
+        d.epilogue = lead ? MI355_EPI_RESID : MI355_EPI_STORE; d.out = in.xs; d.ldo = hid; d.residual = in.xs;
+        if (wire_bf16(m)) { d.epilogue = MI355_EPI_STORE; d.out = in.tp_y; d.residual = nullptr; }
+        if (!m->use_comm) {                                         // -> next layer's QKV, or the lm_head
+            d.chain_next = 1; d.chain_next_k = hid;
+            d.chain_next_norm = (l + 1 < c.n_layers) ? m->layers[l + 1].attn_norm : m->output_norm;
+        }
+    }
+}
+
 // one launch group of the step; `l` = layer (ignored for EMBED / HEAD)
 int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t st) {
     const mi355_llama_config& c = m->cfg;
@@ -196,14 +257,9 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
     if (part == PART_EMBED) return mi355_embedding_f32(in.xs, m->tok_embd, in.tokens, B, hid, st);
     if (part == PART_HEAD) {
         // --- output_norm + lm_head -> logits f32       (quantized_llama.rs:500-505; vocab-parallel under TP)
-        d.nseg = 1;
-        d.w_tiles[0] = m->output.tiles; d.ggml_type[0] = m->output.type; d.n_rows[0] = m->output.n_rows;
-        d.x = in.xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
-        d.norm_weight = m->output_norm; d.norm_eps = c.rms_eps;
-        d.epilogue = MI355_EPI_STORE; d.ldo = m->output.n_rows;
-        if (!m->use_comm) { d.out = logits; return mi355_qmatmul_fused(&d, st); }
-        d.out = m->logits_local;
+        dense_desc(m, 0, PART_HEAD, in, logits, d);
         RCHECK(mi355_qmatmul_fused(&d, st));
+        if (!m->use_comm) return 0;
         if (!m->comm) return (int)hipErrorNotInitialized;
         const size_t cnt = (size_t)B * m->output.n_rows;
         RCHECK(comm_all_gather(m->comm, m->logits_local, m->logits_gather, (int64_t)cnt, MI355_DTYPE_F32, st));
@@ -289,18 +345,7 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
     }
     if (part == PART_QKV) {
         // --- attention_norm + wq|wk|wv + interleaved RoPE + bf16 cast + cache scatter
-        d.nseg = 3;
-        const int qkv[3] = {MI355_W_WQ, MI355_W_WK, MI355_W_WV};
-        for (int s = 0; s < 3; ++s) {
-            d.w_tiles[s] = L.w[qkv[s]].tiles; d.ggml_type[s] = L.w[qkv[s]].type; d.n_rows[s] = L.w[qkv[s]].n_rows;
-        }
-        d.x = in.xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
-        d.norm_weight = L.attn_norm; d.norm_eps = c.rms_eps;
-        d.epilogue = MI355_EPI_QKV_ROPE_CACHE;
-        d.cos_table = m->cos_t; d.sin_table = m->sin_t; d.positions = in.positions; d.slot_mapping = in.slots;
-        d.q_out = in.q; d.key_cache = m->kcache[l]; d.value_cache = m->vcache[l];
-        d.num_heads = H; d.num_kv_heads = Hkv; d.head_dim = D; d.rotary_dim = D;
-        d.block_size = c.block_size; d.kv_layout = c.kv_layout;
+        dense_desc(m, l, PART_QKV, in, logits, d);
         return mi355_qmatmul_fused(&d, st);
     }
     if (part == PART_ATTN && c.kv_layout == MI355_KV_PAGED_FP8) {
@@ -339,44 +384,35 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
                                         in.bt, in.ctx, B, H, Hkv, D, c.block_size, in.max_blocks, in.ctx_cap, ps,
                                         scale, 0.f, c.kv_layout, MI355_DTYPE_BF16, st);
     }
-    if (part == PART_WO) {
+    if (part == PART_WO || part == PART_DOWN) {
         // --- wo(y.to_dtype(F32)) + residual (+ all-reduce)   (attention.rs:1004-1009, quantized_llama.rs:464)
-        d.nseg = 1;
-        d.w_tiles[0] = L.w[MI355_W_WO].tiles; d.ggml_type[0] = L.w[MI355_W_WO].type; d.n_rows[0] = L.w[MI355_W_WO].n_rows;
-        d.x = in.attn; d.x_dtype = MI355_DTYPE_BF16; d.ldx = H * D; d.k = H * D; d.num_tokens = B;
-        d.epilogue = lead ? MI355_EPI_RESID : MI355_EPI_STORE; d.out = in.xs; d.ldo = hid; d.residual = in.xs;
-        if (wire_bf16(m)) { d.epilogue = MI355_EPI_STORE; d.out = in.tp_y; d.residual = nullptr; }   // partial only; + residual after the sum
-        // 9..32 tokens: the epilogue stages the gate/up launch's activation image (xs is final here unless TP reduces it)
-        if (!m->use_comm && !moe) { d.chain_next = 1; d.chain_next_k = hid; d.chain_next_norm = L.ffn_norm; }
+        // --- w2 + residual (+ all-reduce)                     (quantized_llama.rs:37-42, 470)
+        dense_desc(m, l, part, in, logits, d);
         RCHECK(mi355_qmatmul_fused(&d, st));
         return all_reduce_xs(m, in.xs, in.tp_y, B, st);
     }
     if (part == PART_GATEUP) {
         // --- ffn_norm + w1|w3 + silu*mul              (quantized_llama.rs:33-37, 468)
-        d.nseg = 2;
-        d.w_tiles[0] = L.w[MI355_W_W1].tiles; d.ggml_type[0] = L.w[MI355_W_W1].type; d.n_rows[0] = L.w[MI355_W_W1].n_rows;
-        d.w_tiles[1] = L.w[MI355_W_W3].tiles; d.ggml_type[1] = L.w[MI355_W_W3].type; d.n_rows[1] = L.w[MI355_W_W3].n_rows;
-        d.x = in.xs; d.x_dtype = MI355_DTYPE_F32; d.ldx = hid; d.k = hid; d.num_tokens = B;
-        d.norm_weight = L.ffn_norm; d.norm_eps = c.rms_eps;
-        d.epilogue = MI355_EPI_SILU_MUL; d.out = in.h; d.ldo = I;
-        d.chain_next = 1; d.chain_next_k = I; d.chain_next_norm = nullptr;          // -> w2
+        dense_desc(m, l, PART_GATEUP, in, logits, d);
         return mi355_qmatmul_fused(&d, st);
     }
-    if (part == PART_DOWN) {
-        // --- w2 + residual (+ all-reduce)             (quantized_llama.rs:37-42, 470)
-        d.nseg = 1;
-        d.w_tiles[0] = L.w[MI355_W_W2].tiles; d.ggml_type[0] = L.w[MI355_W_W2].type; d.n_rows[0] = L.w[MI355_W_W2].n_rows;
-        d.x = in.h; d.x_dtype = MI355_DTYPE_F32; d.ldx = I; d.k = I; d.num_tokens = B;
-        d.epilogue = lead ? MI355_EPI_RESID : MI355_EPI_STORE; d.out = in.xs; d.ldo = hid; d.residual = in.xs;
-        if (wire_bf16(m)) { d.epilogue = MI355_EPI_STORE; d.out = in.tp_y; d.residual = nullptr; }
-        if (!m->use_comm) {                                         // -> next layer's QKV, or the lm_head
-            d.chain_next = 1; d.chain_next_k = hid;
-            d.chain_next_norm = (l + 1 < c.n_layers) ? m->layers[l + 1].attn_norm : m->output_norm;
-        }
-        RCHECK(mi355_qmatmul_fused(&d, st));
-        return all_reduce_xs(m, in.xs, in.tp_y, B, st);
-    }
     return (int)hipErrorInvalidValue;
+}
+
+// Single token, one GPU, dense MLP: the four mat-vecs between two attention calls -- wo + residual, ffn_norm + gate/up +
+// silu*mul, down + residual, then the NEXT layer's attn_norm + q|k|v + RoPE + cache write (or output_norm + lm_head after
+// the last layer) -- run as ONE persistent launch (csrc/qmv_chain.inc).  Returns hipErrorNotSupported when the chain does
+// not apply; the caller then issues the launch groups one by one.
+int run_chain(Model* m, int l, const StepIn& in, float* logits, int64_t st) {
+    const mi355_llama_config& c = m->cfg;
+    if (in.B != 1 || in.is_prefill || m->use_comm || c.n_expert > 1 || !m->chain_sync) return (int)hipErrorNotSupported;
+    mi355_qmm_desc d[4];
+    dense_desc(m, l, PART_WO, in, logits, d[0]);
+    dense_desc(m, l, PART_GATEUP, in, logits, d[1]);
+    dense_desc(m, l, PART_DOWN, in, logits, d[2]);
+    if (l + 1 < c.n_layers) dense_desc(m, l + 1, PART_QKV, in, logits, d[3]);
+    else dense_desc(m, 0, PART_HEAD, in, logits, d[3]);
+    return mi355_qmatmul_chain(d, 4, m->chain_sync, st);
 }
 
 // one decode step over device-resident inputs (everything enqueued on `st`)
@@ -389,8 +425,24 @@ int forward_decode(Model* m, const uint32_t* tokens, const int64_t* positions, c
     const StepIn in{tokens, positions, slots, bt, ctx, B, max_blocks, ctx_cap, m->xs, m->q, m->attn, m->h,
                     m->moe_ids, m->moe_w, m->moe_y, m->tp_y, false, nullptr, 0, 0};
     RCHECK(run_part(m, 0, PART_EMBED, in, logits, st));
-    for (int l = 0; l < c.n_layers; ++l)
-        for (int part = PART_QKV; part <= PART_DOWN; ++part) RCHECK(run_part(m, l, part, in, logits, st));
+    // single token: embed, q|k|v of layer 0, then per layer [attention, ONE persistent launch for wo -> gate/up -> down ->
+    // the next layer's q|k|v (the lm_head after the last layer)]; any step the chain does not cover falls back group by group
+    bool qkv_done = false, head_done = false;
+    for (int l = 0; l < c.n_layers; ++l) {
+        if (!qkv_done) RCHECK(run_part(m, l, PART_QKV, in, logits, st));
+        RCHECK(run_part(m, l, PART_ATTN, in, logits, st));
+        const int rc = run_chain(m, l, in, logits, st);
+        if (rc == 0) {
+            qkv_done = true;
+            head_done = l + 1 == c.n_layers;
+        } else if (rc == (int)hipErrorNotSupported) {
+            qkv_done = false;
+            for (int part = PART_WO; part <= PART_DOWN; ++part) RCHECK(run_part(m, l, part, in, logits, st));
+        } else {
+            return rc;
+        }
+    }
+    if (head_done) return 0;
     return run_part(m, 0, PART_HEAD, in, logits, st);
 }
 
@@ -455,6 +507,8 @@ extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
         alloc((void**)&m->logits_local, (size_t)B * cfg->vocab * 4 / m->cfg.tp_world + 64);
         alloc((void**)&m->logits_gather, (size_t)B * cfg->vocab * 4 + 64 * m->cfg.tp_world);
     }
+    alloc(&m->chain_sync, (size_t)mi355_qmv_chain_sync_bytes());
+    if (m->chain_sync && hipMemset(m->chain_sync, 0, (size_t)mi355_qmv_chain_sync_bytes()) != hipSuccess) ok = false;
     m->pa_cap_partitions = (cfg->max_seq + 31) / 32 + 1;   // v2 partitions are >= 32 tokens (choose_partition)
     alloc((void**)&m->pa_tmp, (size_t)B * H * m->pa_cap_partitions * D * 4);
     alloc((void**)&m->pa_max, (size_t)B * H * m->pa_cap_partitions * 4);
@@ -514,7 +568,7 @@ extern "C" void mi355_llama_destroy(void* mp) {
     void* ptrs[] = {m->tok_embd, m->output_norm, m->cos_t, m->sin_t, m->xs, m->q, m->attn, m->h, m->logits,
                     m->pa_tmp, m->pa_max, m->pa_sum, m->kv_slab, m->d_tokens, m->d_positions, m->d_slots,
                     m->d_ctx, m->d_bt, m->logits_local, m->logits_gather, m->tp_y, m->p_tp_y, m->p_moe_xg, m->p_moe_perm, m->p_moe_inv, m->p_xs, m->p_q, m->p_attn, m->p_h,
-                    m->moe_ids, m->moe_w, m->moe_y, m->p_moe_ids, m->p_moe_w, m->p_moe_y};
+                    m->moe_ids, m->moe_w, m->moe_y, m->p_moe_ids, m->p_moe_w, m->p_moe_y, m->chain_sync};
     if (m->comm && m->comm_owned) mi355_comm_destroy(m->comm);
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete m;

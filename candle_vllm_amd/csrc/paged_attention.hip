@@ -881,6 +881,12 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
         const bool lone = (int64_t)B * p.Hkv <= 8 && P >= 32 && p.partition_size <= 64 && g_pa_fused == 1 && g_pa_wpb == 0;
         if (g_pa_wpb > 0) wpb = ((g_pa_wpb == 4 || g_pa_wpb == 8 || g_pa_wpb == 16) && p.partition_size <= 64) ? g_pa_wpb : 1;
         else wpb = lone ? 8 : ((P >= 8 && p.partition_size <= 64) ? 4 : 1);
+        // launch_mfma_w needs WPB * G * (32 * D32 + 2) * 4 bytes of dynamic LDS and no larger-LDS attribute is set for it: with 16 query
+        // heads per kv head and D = 128 eight partitions per workgroup would ask for 66 560 B and the launch fails
+        {
+            const int G = p.H / p.Hkv, D32 = p.D / 32;
+            while (wpb > 1 && (size_t)wpb * G * (32 * D32 + 2) * 4 > 64 * 1024) wpb = wpb == 16 ? 8 : (wpb == 8 ? 4 : 1);
+        }
         // the in-kernel merge is one wave per (sequence, kv head): worth it only when there are many of them
         if (P > 1 && g_pa_fused && ((int64_t)B * p.Hkv >= (g_pa_fused > 1 ? 1 : 64) || lone) && (int64_t)B * p.Hkv <= PA_ARRIVE_SLOTS) {
             // tickets belong to (device, stream): two streams never share a counter (scratch.cpp)

@@ -761,6 +761,7 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
 
 template <int BT, int R, int WT, int XB, int NRM>
 __global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) { qmm_body<BT, R, WT, XB, NRM>(a); }
+#ifdef MI355_QMM_PROBES   // the Q8_K-activation experiment lives in probe builds only (tools/build_probe_lib.sh): it lost every A/B
 // ================================================================================================
 // EXPERIMENT (mi355_set_tuning(18, 1), single-token launches only): the reference CPU path's own activation format.
 // candle's CPU mat-vec quantises x to Q8_K (per 256-block: iscale = -128 / max, q = round(iscale x) <= 127, d = 1 / iscale,
@@ -1000,6 +1001,8 @@ __device__ __forceinline__ void qmm_body_q8(const QmmArgs& a) {
 }
 template <int R, int WT, int XB, int NRM>
 __global__ void __launch_bounds__(512) qmm_q8_kernel(const QmmArgs a) { qmm_body_q8<R, WT, XB, NRM>(a); }
+
+#endif  // MI355_QMM_PROBES
 
 // MoE variant (decode-shaped, BT = 1): blockIdx.y = (token, slot) pair.  The adjusted descriptor is a private copy
 // -- kept out of the dense kernel, where the kernel arguments must stay scalar loads from the kernarg segment.
@@ -1537,6 +1540,7 @@ static QmgStream& qmg_stream(hipStream_t st) {
 }
 static int g_tune_qmv = 0;                                    // mi355_set_tuning(20, 1): single-token launches take the LDS-DMA engine (qmv_engine.inc) one by one -- measured slower than qmm_kernel per launch (fixed cost), faster chained
 static int g_tune_qmv_nc = 8;                                 // mi355_set_tuning(21, n): consumer waves per workgroup of the engine (1..15)
+static int g_tune_chain_b1 = 0;                               // mi355_set_tuning(23, 1): probe builds: chain the single-token mat-vecs between two attention calls into one persistent launch
 static int g_tune_qmv_ring = 0;                               // mi355_set_tuning(22, 64): the engine never takes the 128 KiB ring (A/B)
 static int g_tune_chain = 1;                                  // mi355_set_tuning(9, 0): never chain (A/B experiments)
 static int g_tune_wide16 = 0;                                 // mi355_set_tuning(15, n): launches of >= n (row tile x k-block) units use 16-wave workgroups
@@ -1654,6 +1658,7 @@ static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
 #include <dlfcn.h>
 #define QMP_MIN_TOKENS 96
 
+#ifdef MI355_QMM_PROBES   // first-generation prompt path (bf16 hi/lo weight image + three library GEMMs): A/B in probe builds only
 __device__ __forceinline__ float dequant_tile(int type, const uint8_t* __restrict__ t, int r, int i) {
     if (type == MI355_GGML_Q4_K) {
         const uint8_t* h = t + r * 16;
@@ -1722,6 +1727,8 @@ __global__ void __launch_bounds__(256) qmp_xsplit_kernel(uint16_t* __restrict__ 
         lo[(size_t)b * a.K + k] = f32_to_bf16(v - bf16_to_f32(h));
     }
 }
+
+#endif  // MI355_QMM_PROBES
 
 struct QmpBlas {
     void* lib = nullptr; void* handle = nullptr;
@@ -1836,6 +1843,7 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+#ifdef MI355_QMM_PROBES
 static int qmp_launch(const QmmArgs& a0, hipStream_t st) {
     QmmArgs a = a0;
     a.paired = 0;
@@ -1877,6 +1885,8 @@ static int qmp_launch(const QmmArgs& a0, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+#endif  // MI355_QMM_PROBES
+
 // ------------------------------------------------------------------------------------------------ launcher
 void mi355_pa_set_fused(int v);
 void mi355_pa_set_wpb(int v);
@@ -1903,6 +1913,7 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     else if (key == 20) g_tune_qmv = value;
     else if (key == 21 && value > 0) g_tune_qmv_nc = value;
     else if (key == 22) g_tune_qmv_ring = value;
+    else if (key == 23) g_tune_chain_b1 = value;
 }
 
 static size_t qmm_lds_bytes(int BT, int R, int NW) {
@@ -1912,7 +1923,15 @@ static size_t qmm_lds_bytes(int BT, int R, int NW) {
 
 static int g_num_cus = 0;
 
+// The LDS-DMA loader / consumer engine for single-token launches and the chained persistent launch built on it are
+// EXPERIMENTS that lost their A/B on the MI355X ("what was tried for batch 1 in round 3"): they are
+// compiled into probe builds only (tools/build_probe_lib.sh); the product library keeps the entry points as refusals.
+#ifdef MI355_QMM_PROBES
 #include "qmv_engine.inc"
+#else
+static int qmv_launch(const QmmArgs&, int, hipStream_t) { return (int)hipErrorNotSupported; }
+extern "C" int mi355_qmv_error(int32_t* out_host, int32_t) { if (out_host) *out_host = 0; return 0; }
+#endif
 
 // Waves per workgroup: the largest NW in {8,4,2,1} for which every workgroup of the launch is resident at
 // once (no second dispatch round => no tail), judged by the occupancy the runtime reports for this variant.
@@ -1969,6 +1988,7 @@ static int qmm_launch_btrw(QmmArgs& a, int n_wg, int NW, hipStream_t st) {
             return (int)hipErrorInvalidValue;
         }
     } else {
+#ifdef MI355_QMM_PROBES
         if constexpr (BT == 1) {
             if (g_tune_actq8) {
                 const bool xb8 = a.x_dtype == MI355_DTYPE_BF16, nrm8 = a.norm_w != nullptr;
@@ -1980,6 +2000,7 @@ static int qmm_launch_btrw(QmmArgs& a, int n_wg, int NW, hipStream_t st) {
                 return (int)hipGetLastError();
             }
         }
+#endif
         const bool xb = a.x_dtype == MI355_DTYPE_BF16, nrm = a.norm_w != nullptr;
         if (xb && nrm) hipLaunchKernelGGL((qmm_kernel<BT, R, WT, 1, 1>), dim3(n_wg), dim3(64 * NW), shm, st, a);
         else if (xb) hipLaunchKernelGGL((qmm_kernel<BT, R, WT, 1, 0>), dim3(n_wg), dim3(64 * NW), shm, st, a);
@@ -2109,12 +2130,15 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
     if (a.B >= g_tune_qpg_min && g_tune_prefill_gemm) {
         // prompt step: the hand-written quantised GEMM (qmm_prefill.inc).  mi355_set_tuning(6, 2) = the first-generation path
         // (bf16 hi/lo weight image + three library GEMMs) for A/B runs; (6, 0) = stream the weights 32 tokens at a time.
-        if (g_tune_prefill_gemm != 2) {
-            const int rcq = qpg_launch(a, st);
-            if (rcq != (int)hipErrorNotSupported) return rcq;
-        } else {
+#ifdef MI355_QMM_PROBES
+        if (g_tune_prefill_gemm == 2) {
             const int rcp = qmp_launch(a, st);
             if (rcp != (int)hipErrorSharedObjectInitFailed) return rcp;
+        } else
+#endif
+        {
+            const int rcq = qpg_launch(a, st);
+            if (rcq != (int)hipErrorNotSupported) return rcq;
         }
     }
     const int B = a.B;
@@ -2177,9 +2201,9 @@ extern "C" int mi355_qmatmul(float* out, const float* x, const void* w_tiles, in
     return mi355_qmm_launch(a, stream);
 }
 
-extern "C" int mi355_qmatmul_fused(const mi355_qmm_desc* d, int64_t stream) {
+static int qmm_args_from_desc(const mi355_qmm_desc* d, QmmArgs& a) {
     if (!d) return (int)hipErrorInvalidValue;
-    QmmArgs a{};
+    a = QmmArgs{};
     a.nseg = d->nseg;
     if (d->nseg < 1 || d->nseg > 3) return (int)hipErrorInvalidValue;
     int row0 = 0;
@@ -2212,5 +2236,19 @@ extern "C" int mi355_qmatmul_fused(const mi355_qmm_desc* d, int64_t stream) {
     for (int s = 0; s < 3; ++s) a.moe_stride[s] = d->moe_expert_stride[s];
     a.chain_next = (d->chain_next && !d->moe_expert_ids && d->num_tokens > 8 && d->num_tokens <= 8 * QMW_MAXMT) ? 1 : 0;
     a.next_k = d->chain_next_k; a.next_norm_w = d->chain_next_norm;
+    return 0;
+}
+
+extern "C" int mi355_qmatmul_fused(const mi355_qmm_desc* d, int64_t stream) {
+    QmmArgs a{};
+    const int rc = qmm_args_from_desc(d, a);
+    if (rc) return rc;
     return mi355_qmm_launch(a, stream);
 }
+
+#ifdef MI355_QMM_PROBES
+#include "qmv_chain.inc"
+#else
+extern "C" int mi355_qmv_chain_sync_bytes(void) { return 256; }
+extern "C" int mi355_qmatmul_chain(const mi355_qmm_desc*, int32_t, void*, int64_t) { return (int)hipErrorNotSupported; }
+#endif

@@ -227,6 +227,10 @@ class GGUFLLaMa:
             blob = ctypes.create_string_buffer(b"".join(all_h), 64 * self.tp_world)
             _check(lib.mi355_comm_p2p_attach(comm, ctypes.addressof(blob), self.tp_rank, self.tp_world), "comm_p2p_attach")
 
+    def comm_capture_ok(self, stream):
+        """can this stack capture the communicator's all-reduce in a hipGraph?  (local test, nothing goes on the wire)"""
+        return lib.mi355_comm_capture_probe(lib.mi355_llama_comm_handle(self.h), stream) == 0
+
     def set_comm(self, handle):
         """attach a communicator the caller owns (mi355_comm_create / tp.TorchDistComm().handle)"""
         _check(lib.mi355_llama_set_comm(self.h, handle), "set_comm")

@@ -63,6 +63,18 @@ class InputMetadata:
     seqlens: Optional[List[int]] = None
     is_mla: bool = False
     is_mtp_verify: bool = False
+    use_cached_kv: Optional[bool] = None             # decided ONCE per step on the host (inputs.rs:132-143), not per layer call
+
+    def cached_prefix(self) -> bool:
+        """does any sequence of this prompt step have a cached prefix (seqlen_k = cached + chunk, inputs.rs:132-143)?  The
+        answer is computed once per step and kept: comparing the device tensors in every layer's call is a host
+        synchronisation per layer."""
+        if self.use_cached_kv is None:
+            uc = self.max_seqlen_k > self.max_seqlen_q
+            if not uc and self.cu_seqlens_k is not None and self.cu_seqlens_q is not None:
+                uc = not torch.equal(self.cu_seqlens_k, self.cu_seqlens_q)
+            self.use_cached_kv = bool(uc)
+        return self.use_cached_kv
 
     @staticmethod
     def from_oracle_meta(meta: dict, device, is_prefill=False):
@@ -76,7 +88,9 @@ class InputMetadata:
             max_context_len=int(meta["max_context_len"]),
             cu_seqlens_q=t(meta["cu_seqlens_q"].astype(np.int64), np.int32) if "cu_seqlens_q" in meta else None,
             cu_seqlens_k=t(meta["cu_seqlens_k"].astype(np.int64), np.int32) if "cu_seqlens_k" in meta else None,
-            max_seqlen_q=int(meta.get("max_seqlen_q", 0)), max_seqlen_k=int(meta.get("max_seqlen_k", 0)))
+            max_seqlen_q=int(meta.get("max_seqlen_q", 0)), max_seqlen_k=int(meta.get("max_seqlen_k", 0)),
+            use_cached_kv=(bool(np.any(np.asarray(meta["cu_seqlens_k"]) != np.asarray(meta["cu_seqlens_q"])))
+                           if ("cu_seqlens_k" in meta and "cu_seqlens_q" in meta) else None))
 
 
 # ----------------------------------------------------------------------------------------------- cache ops
@@ -247,9 +261,7 @@ class PagedAttention:
         # per sequence, as the reference decides it (seqlen_k = cached + chunk whenever num_cached > 0, inputs.rs:132-143):
         # ANY sequence with a cached prefix sends the whole batch through the cache path.  (max_seqlen_k > max_seqlen_q
         # misses a mixed batch such as 16 cached + 16 new beside 64 fresh tokens.)
-        use_cached = meta.max_seqlen_k > meta.max_seqlen_q
-        if not use_cached and meta.cu_seqlens_k is not None and meta.cu_seqlens_q is not None:
-            use_cached = not torch.equal(meta.cu_seqlens_k, meta.cu_seqlens_q)
+        use_cached = meta.cached_prefix()
         if use_cached:
             layout = kv_layout_of(key_cache)
             bs = key_cache.shape[1] if layout == KV_FLASH else key_cache.shape[3]

@@ -252,11 +252,23 @@ void mi355_set_tuning(int32_t key, int32_t value);
 /* experiments only: device buffer of uint64 [workgroup][16 waves][4] that the 1..8-token mat-vec fills with wall-clock
  * stamps (entry, main loop done, past the barrier, exit) while probe mode 7 is set (probe builds only); NULL switches it off */
 int mi355_debug_set_timestamps(void* dev_ptr);
-/* Single-token launches run on the LDS-DMA loader / consumer engine (csrc/qmv_engine.inc; tuning keys 20 on / off, 21 consumer
- * waves, 22 = 64 forbids the 128-KiB ring).  Its in-workgroup waits are bounded: a wait that gave up leaves a sticky device
- * word (1 consumer waited for data, 2 loader waited for ring space, 3 consumer waited for the activation image) and the
- * launch's outputs are then garbage.  Reads the word into *out_host (synchronising copy) and clears it when reset != 0. */
+/* EXPERIMENTS, compiled into probe builds only (-DMI355_QMM_PROBES, tools/build_probe_lib.sh); in the product library the
+ * three entry points below exist and refuse (hipErrorNotSupported / error word 0).
+ * Single-token launches on an LDS-DMA loader / consumer engine (csrc/qmv_engine.inc; tuning keys 20 on / off, 21 consumer
+ * waves, 22 ring KiB cap).  Its in-workgroup waits are bounded: a wait that gave up leaves a sticky device word (1 consumer
+ * waited for data, 2 loader for ring space, 3 / 4 consumer rendezvous, 5 a chain edge) and the launch's outputs are garbage.
+ * Reads the word into *out_host (synchronising copy) and clears it when reset != 0. */
 int mi355_qmv_error(int32_t* out_host, int32_t reset);
+/* A chain of n (<= 4) single-token launches in ONE persistent launch (csrc/qmv_chain.inc): descs[p + 1].x must be
+ * descs[p].out (f32, one token); only the last may carry MI355_EPI_QKV_ROPE_CACHE.  This is the decode step's
+ * wo + residual -> ffn_norm + gate/up + silu*mul -> down + residual -> next layer's attn_norm + q|k|v + RoPE + cache write
+ * (quantized_llama.rs:424-506), bit-identical to the four mi355_qmatmul_fused calls.  `sync` = mi355_qmv_chain_sync_bytes()
+ * bytes of device memory zeroed once (arrival counters, monotonic across launches and hipGraph replays).  The launch needs
+ * every CU of the device to itself (one resident workgroup per CU; the phase boundaries are grid-wide dependencies with
+ * bounded waits, mi355_qmv_error).  Returns hipErrorNotSupported (801) when the chain does not fit -- issue the calls one by
+ * one then.  Tuning key 23 = 1 switches chaining on (probe builds; measured slower than launch by launch). */
+int mi355_qmv_chain_sync_bytes(void);
+int mi355_qmatmul_chain(const mi355_qmm_desc* descs, int32_t n, void* sync, int64_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 3b. Safetensors path: dense 16-bit and GPTQ/AWQ/Marlin 4-bit linears (decode-shaped, any num_tokens).
@@ -458,6 +470,10 @@ int mi355_comm_all_reduce_residual(void* comm, float* y, float* resid, int64_t c
 int mi355_comm_p2p_export(void* comm, void* handle_out64);
 int mi355_comm_p2p_attach(void* comm, const void* handles, int32_t rank, int32_t world);
 int mi355_comm_p2p_error(void* comm);
+/* 0 when the communicator's all-reduce can be captured in a hipGraph on this stack: captures one small all-reduce on
+ * `stream`, instantiates and destroys the graph without launching it (nothing runs on the wire), so every rank can test
+ * locally and the ranks agree on captured / eager steps before the first real step. */
+int mi355_comm_capture_probe(void* comm, int64_t stream);
 int mi355_comm_all_gather(void* comm, const void* send, void* recv, int64_t count, int32_t dtype, int64_t stream);
 
 /* ---------------------------------------------------------------------------------------------

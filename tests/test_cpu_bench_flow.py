@@ -52,6 +52,10 @@ def _fake_model_module(dist, calls):
             assert float(t.sum()) == 128.0
             calls.append(("init_comm",))
 
+        def comm_capture_ok(self, stream):               # every rank tests locally, bench.py then takes the MIN over ranks
+            calls.append(("capture_probe",))
+            return True
+
         def load_synthetic(self, seed=0, recipe=""):
             calls.append(("load_synthetic", recipe))
 

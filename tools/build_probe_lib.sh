@@ -5,7 +5,7 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $R/build_probe
-cp $R/candle_vllm_amd/csrc/qmatmul.hip $R/candle_vllm_amd/csrc/qmatmul_probe_tmp.hip
+cp $R/candle_vllm_amd/csrc/qmatmul.hip $R/candle_vllm_amd/csrc/qmatmul_probe_tmp.hip   # (same directory: the .inc files resolve)
 trap "rm -f $R/candle_vllm_amd/csrc/qmatmul_probe_tmp.hip" EXIT
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fopenmp -Wno-unused-value -DMI355_QMM_PROBES -DMI355_QMM_TIMESTAMPS -I$R/include \
       -c $R/candle_vllm_amd/csrc/qmatmul_probe_tmp.hip -o $R/build_probe/qmatmul.o
