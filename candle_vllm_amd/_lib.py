@@ -247,6 +247,7 @@ _sig("mi355_comm_p2p_error", ctypes.c_int, [c_vp])
 _sig("mi355_comm_capture_probe", ctypes.c_int, [c_vp, c_i64])
 _sig("mi355_dense_alloc_kv_cache", ctypes.c_int, [c_vp, c_i32])
 _sig("mi355_dense_kv_ptr", c_vp, [c_vp, c_i32, c_i32])
+_sig("mi355_dense_set_layer_window", ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp])
 _sig("mi355_dense_forward", ctypes.c_int, [c_vp] * 7 + [c_i32] * 5 + [c_vp, c_i64])
 
 # ---- GGUF reader (section 7)

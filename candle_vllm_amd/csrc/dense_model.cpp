@@ -55,6 +55,10 @@ struct DModel {
     int num_blocks = 0;
     void* comm = nullptr;                 // borrowed communicator (tp_world > 1, or a 1-rank plumbing test)
     uint16_t* lg_gather = nullptr;        // [W, B, V/W]
+    // test hook (mi355_dense_set_layer_window): run layers [win_first, win_last] only, from a supplied residual stream
+    int win_first = -1, win_last = -1;
+    const void* win_in = nullptr;
+    void* win_out = nullptr;
 };
 
 // [W, B, Vl] -> [B, W*Vl]   (VocabParallelLinear: all-gather then un-interleave, distributed.rs:1637-1663)
@@ -293,6 +297,17 @@ int mi355_dense_alloc_kv_cache(void* mp, int32_t num_blocks) {
     m->num_blocks = num_blocks;
     return 0;
 }
+/* Test hook for the full-size parity legs (tests/fullsize_dense.py): the next mi355_dense_forward calls skip the embedding and
+ * the head, start from the 16-bit residual stream xs_in_dev [num_tokens, hidden], run layers first..last (inclusive) exactly as
+ * the whole forward runs them, and copy the stream after the last of them to xs_out_dev.  first < 0 switches the window off. */
+int mi355_dense_set_layer_window(void* mp, int32_t first, int32_t last, const void* xs_in_dev, void* xs_out_dev) {
+    DModel* m = static_cast<DModel*>(mp);
+    if (!m) return (int)hipErrorInvalidValue;
+    if (first < 0) { m->win_first = m->win_last = -1; m->win_in = nullptr; m->win_out = nullptr; return 0; }
+    if (last < first || last >= m->cfg.n_layers || !xs_in_dev || !xs_out_dev) return (int)hipErrorInvalidValue;
+    m->win_first = first; m->win_last = last; m->win_in = xs_in_dev; m->win_out = xs_out_dev;
+    return 0;
+}
 void* mi355_dense_kv_ptr(void* mp, int32_t layer, int32_t which) {
     DModel* m = static_cast<DModel*>(mp);
     if (!m || layer < 0 || layer >= (int)m->kcache.size()) return nullptr;
@@ -316,8 +331,10 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
     const int T = num_tokens, H = c.n_heads, Hkv = c.n_kv_heads, D = c.head_dim, hid = c.hidden, I = c.intermediate;
     const int dt = c.dtype;
     const float scale = 1.0f / sqrtf((float)D);
-    hipLaunchKernelGGL(embedding16_kernel, dim3(T), dim3(256), 0, st, m->xs, m->tok_embd, tokens, hid);
-    for (int l = 0; l < c.n_layers; ++l) {
+    const bool window = m->win_first >= 0;
+    if (window) DHIP(hipMemcpyAsync(m->xs, m->win_in, (size_t)T * hid * 2, hipMemcpyDeviceToDevice, st));
+    else hipLaunchKernelGGL(embedding16_kernel, dim3(T), dim3(256), 0, st, m->xs, m->tok_embd, tokens, hid);
+    for (int l = window ? m->win_first : 0; l <= (window ? m->win_last : c.n_layers - 1); ++l) {
         DLayer& L = m->layers[l];
         if (!L.attn_norm || !L.ffn_norm) return (int)hipErrorInvalidValue;
         // x = rms_1(xs)                                                     llama.rs:53-54
@@ -413,6 +430,10 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
         } else {
             DCHECK(linear(m, L.w2, L.gq[MI355_W_W2], m->xs, m->h, nullptr, m->xs, T, hid, I, MI355_EPI_RESID, stream));
         }
+    }
+    if (window) {                                                           // the residual stream after the window's last layer
+        DHIP(hipMemcpyAsync(m->win_out, m->xs, (size_t)T * hid * 2, hipMemcpyDeviceToDevice, st));
+        return 0;
     }
     const uint16_t* last = m->xs;
     if (prefill) {                                                          // llama.rs:190-194

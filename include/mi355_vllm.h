@@ -514,6 +514,10 @@ int mi355_dense_set_comm(void* model, void* comm);
 int mi355_dense_set_rope_tables(void* model, const float* cos_host, const float* sin_host, int32_t n_positions);   /* [n, rotary_dim/2] */
 int mi355_dense_alloc_kv_cache(void* model, int32_t num_blocks);
 void* mi355_dense_kv_ptr(void* model, int32_t layer, int32_t which);
+/* test hook (full-size parity legs): the following mi355_dense_forward calls run layers first..last only, from the 16-bit
+ * residual stream xs_in_dev [num_tokens, hidden], and copy the stream after layer `last` to xs_out_dev (no embedding, no
+ * head, `logits` untouched); first < 0 restores the whole forward */
+int mi355_dense_set_layer_window(void* model, int32_t first, int32_t last, const void* xs_in_dev, void* xs_out_dev);
 /* one step: prompt when cu_seqlens_q != NULL (flattened tokens), else decode (num_tokens == num_seqs);
  * DEVICE inputs as prepare_prompt / prepare_decode build them; logits f32 [num_seqs, vocab] */
 int mi355_dense_forward(void* model, const uint32_t* tokens, const int64_t* positions, const int64_t* slot_mapping,

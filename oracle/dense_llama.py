@@ -105,6 +105,8 @@ def quantize_gptq(W, group=128, seed=7):
 def _lin(x, w, b=None):
     """Linear::forward or the QLinear GPTQ arm (linear.rs:124-172 / 854-906)"""
     if isinstance(w, dict):
+        if "deq" not in w:                                              # full-size legs: dequantise on first use, keep (shared by the layers)
+            w["deq"] = G.gptq_dequant(G.gptq_unpack(w["qweight"]).astype(np.int64), w["scales"], None, w["group"])
         return G.gptq_linear(x, w["deq"], b, DT)
     return G.linear16(x, w, b, DT)
 
@@ -176,13 +178,16 @@ class OracleDenseLlama:
             ys.append(ops.prefill_attention(q[a:b], ops.bf16_bits_to_f32(kk), ops.bf16_bits_to_f32(vv), self.scale, cached=n - (b - a)))
         return np.concatenate(ys, 0)
 
-    def forward(self, meta, kv_caches, is_prefill=False):
-        """Llama::forward_inner src/openai/models/llama.rs:139-201 with Attention::forward_ext src/openai/models/layers/attention.rs:585-734."""
+    def forward(self, meta, kv_caches, is_prefill=False, trace=None):
+        """Llama::forward_inner src/openai/models/llama.rs:139-201 with Attention::forward_ext src/openai/models/layers/attention.rs:585-734.
+        trace: a list that receives the residual stream at every layer entry and after the last layer (full-size parity legs)."""
         c, W = self.cfg, self.W
         toks, pos = meta["input_ids"], meta["positions"]
         T = len(toks)
         xs = W["tok_embd"][toks].astype(np.float32)
         for l, lw in enumerate(W["layers"]):
+            if trace is not None:
+                trace.append(xs.copy())
             x = self._norm(xs, lw["attn_norm"], lw.get("attn_norm_b"))
             q = _lin(x, lw["wq"], lw.get("bq")).reshape(T, c.n_heads, c.head_dim)
             k = _lin(x, lw["wk"], lw.get("bk")).reshape(T, c.n_kv_heads, c.head_dim)
@@ -214,6 +219,8 @@ class OracleDenseLlama:
             gate, up = _lin(x, lw["w1"]), _lin(x, lw["w3"])
             h = G.silu_mul16(gate, up, DT)
             xs = self._row_lin(h, lw["w2"], xs)
+        if trace is not None:
+            trace.append(xs.copy())
         if is_prefill:
             xs = xs[np.asarray(meta["cu_seqlens_q"][1:], np.int64) - 1]
         xs = self._norm(xs, W["output_norm"], W.get("output_norm_b"))

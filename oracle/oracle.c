@@ -160,7 +160,105 @@ static inline int32_t hsum_epi32(__m256i v) {
 float orc_vec_dot_q4k_q8k_scalar(const uint8_t* w, int nb, const float* xd, const int8_t* xq, const int16_t* xb);
 float orc_vec_dot_q6k_q8k_scalar(const uint8_t* w, int nb, const float* xd, const int8_t* xq);
 
+/* A third statement of the same integer arithmetic for hosts with AVX-512 VNNI (the MI355X boxes' EPYC 9575F has it): the
+ * u8 x s8 products go through vpdpbusd (four products per s32 lane, exact) instead of vpmaddubsw + vpmaddwd.  Chosen at run
+ * time (`orc_isa`), bit-identical to the scalar definition like the AVX2 one (tests/test_cpu_oracle.py). */
+#if defined(__x86_64__) && defined(__GNUC__)
+#define ORC_HAVE_VNNI 1
+#include <immintrin.h>
+#define ORC_VNNI __attribute__((target("avx2,avx512f,avx512bw,avx512vl,avx512vnni")))
+static int g_force_isa = -1;                       /* -1 auto, 0 scalar/AVX2 build default, 1 VNNI (tests) */
+static int orc_use_vnni(void) {
+    static int have = -1;
+    if (have < 0) have = __builtin_cpu_supports("avx512vnni") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512bw");
+    if (g_force_isa == 0) return 0;
+    return have;
+}
+void orc_force_isa(int v) { g_force_isa = v; }
+const char* orc_isa(void) {
+    if (orc_use_vnni()) return "avx512-vnni (vpdpbusd, 256-bit)";
+#if defined(__AVX2__)
+    return "avx2";
+#else
+    return "scalar";
+#endif
+}
+ORC_VNNI static inline int32_t hsum_epi32_v(__m256i v) {
+    __m128i s = _mm_add_epi32(_mm256_castsi256_si128(v), _mm256_extracti128_si256(v, 1));
+    s = _mm_add_epi32(s, _mm_shuffle_epi32(s, 0x4E));
+    s = _mm_add_epi32(s, _mm_shuffle_epi32(s, 0xB1));
+    return _mm_cvtsi128_si32(s);
+}
+ORC_VNNI static float vec_dot_q4k_q8k_vnni(const uint8_t* w, int nb, const float* xd, const int8_t* xq, const int16_t* xb) {
+    const __m256i m4 = _mm256_set1_epi8(0xF);
+    float sumf = 0;
+    for (int i = 0; i < nb; ++i, w += Q4K_BYTES, xq += QK_K, xb += 16) {
+        uint16_t dh, mh;
+        memcpy(&dh, w, 2);
+        memcpy(&mh, w + 2, 2);
+        const float d = f16_to_f32(dh) * xd[i], dmin = f16_to_f32(mh) * xd[i];
+        const uint8_t* q4 = w + 16;
+        __m256i acc = _mm256_setzero_si256();
+        int32_t summ = 0;
+        for (int p = 0; p < 4; ++p) {
+            uint8_t sc0, m0, sc1, m1;
+            scale_min_k4(2 * p, w + 4, &sc0, &m0);
+            scale_min_k4(2 * p + 1, w + 4, &sc1, &m1);
+            const __m256i q = _mm256_loadu_si256((const __m256i*)(q4 + 32 * p));
+            const __m256i lo = _mm256_and_si256(q, m4), hi = _mm256_and_si256(_mm256_srli_epi16(q, 4), m4);
+            const __m256i a = _mm256_loadu_si256((const __m256i*)(xq + 64 * p));
+            const __m256i b = _mm256_loadu_si256((const __m256i*)(xq + 64 * p + 32));
+            const __m256i z = _mm256_setzero_si256();
+            acc = _mm256_add_epi32(acc, _mm256_mullo_epi32(_mm256_dpbusd_epi32(z, lo, a), _mm256_set1_epi32(sc0)));
+            acc = _mm256_add_epi32(acc, _mm256_mullo_epi32(_mm256_dpbusd_epi32(z, hi, b), _mm256_set1_epi32(sc1)));
+            summ += (xb[4 * p] + xb[4 * p + 1]) * m0 + (xb[4 * p + 2] + xb[4 * p + 3]) * m1;
+        }
+        sumf += d * (float)hsum_epi32_v(acc) - dmin * (float)summ;
+    }
+    return sumf;
+}
+ORC_VNNI static float vec_dot_q6k_q8k_vnni(const uint8_t* w, int nb, const float* xd, const int8_t* xq) {
+    const __m256i m4 = _mm256_set1_epi8(0xF), m2 = _mm256_set1_epi8(3), m32 = _mm256_set1_epi8(32);
+    float sumf = 0;
+    for (int i = 0; i < nb; ++i, w += Q6K_BYTES, xq += QK_K) {
+        const uint8_t *ql = w, *qh = w + 128;
+        const int8_t* sc = (const int8_t*)(w + 192);
+        uint16_t dh;
+        memcpy(&dh, w + 208, 2);
+        const float d = f16_to_f32(dh) * xd[i];
+        __m256i acc = _mm256_setzero_si256();
+        const int8_t* q8 = xq;
+        for (int n = 0; n < 2; ++n) {
+            const __m256i la = _mm256_loadu_si256((const __m256i*)ql), lb = _mm256_loadu_si256((const __m256i*)(ql + 32));
+            const __m256i h = _mm256_loadu_si256((const __m256i*)qh);
+            __m256i q[4];
+            q[0] = _mm256_or_si256(_mm256_and_si256(la, m4), _mm256_slli_epi16(_mm256_and_si256(h, m2), 4));
+            q[1] = _mm256_or_si256(_mm256_and_si256(lb, m4), _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(h, 2), m2), 4));
+            q[2] = _mm256_or_si256(_mm256_and_si256(_mm256_srli_epi16(la, 4), m4), _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(h, 4), m2), 4));
+            q[3] = _mm256_or_si256(_mm256_and_si256(_mm256_srli_epi16(lb, 4), m4), _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(h, 6), m2), 4));
+            for (int g = 0; g < 4; ++g) {
+                const __m256i a = _mm256_loadu_si256((const __m256i*)(q8 + 32 * g));
+                const __m256i z = _mm256_setzero_si256();
+                /* sum (q - 32) a = sum q a - 32 sum a, four products per s32 lane; lanes 0..3 belong to scale 2g, 4..7 to 2g+1 */
+                const __m256i p32 = _mm256_sub_epi32(_mm256_dpbusd_epi32(z, q[g], a), _mm256_dpbusd_epi32(z, m32, a));
+                const __m256i scv = _mm256_set_m128i(_mm_set1_epi32(sc[2 * g + 1]), _mm_set1_epi32(sc[2 * g]));
+                acc = _mm256_add_epi32(acc, _mm256_mullo_epi32(p32, scv));
+            }
+            ql += 64; qh += 32; sc += 8; q8 += 128;
+        }
+        sumf += d * (float)hsum_epi32_v(acc);
+    }
+    return sumf;
+}
+#else
+const char* orc_isa(void) { return "scalar"; }
+void orc_force_isa(int v) { (void)v; }
+#endif
+
 float orc_vec_dot_q4k_q8k(const uint8_t* w, int nb, const float* xd, const int8_t* xq, const int16_t* xb) {
+#ifdef ORC_HAVE_VNNI
+    if (orc_use_vnni()) return vec_dot_q4k_q8k_vnni(w, nb, xd, xq, xb);
+#endif
 #if defined(__AVX2__)
     const __m256i m4 = _mm256_set1_epi8(0xF);
     float sumf = 0;
@@ -219,6 +317,9 @@ float orc_vec_dot_q4k_q8k_scalar(const uint8_t* w, int nb, const float* xd, cons
 }
 
 float orc_vec_dot_q6k_q8k(const uint8_t* w, int nb, const float* xd, const int8_t* xq) {
+#ifdef ORC_HAVE_VNNI
+    if (orc_use_vnni()) return vec_dot_q6k_q8k_vnni(w, nb, xd, xq);
+#endif
 #if defined(__AVX2__)
     const __m256i m4 = _mm256_set1_epi8(0xF), m2 = _mm256_set1_epi8(3), m32 = _mm256_set1_epi8(32);
     float sumf = 0;

@@ -23,3 +23,9 @@ def lib():
     ge.build()
     import candle_vllm_amd
     return candle_vllm_amd.lib
+
+
+# tests of code that exists in probe builds only (tools/build_probe_lib.sh: -DMI355_QMM_PROBES) are collected only when such a
+# library is loaded:  MI355_LIB_PATH=build_probe/libmi355vllm_probes.so MI355_PROBE_BUILD=1 python -m pytest tests/probe -m gpu
+import os as _os
+collect_ignore_glob = [] if _os.environ.get("MI355_PROBE_BUILD") else ["probe/*"]

@@ -124,7 +124,7 @@ class Pair:
         gm.set_graph(bool(graph))
         gm.decode_begin([s["tokens"][-1] for s in seqs], [len(s["tokens"]) for s in seqs], bt,
                         ctx_cap=int(max(seq_lens)) + steps, stream=st)
-        worst, equal, tie, t_orc = 0.0, True, False, 0.0
+        worst, worst_b, equal, tie, t_orc, done = 0.0, 0.0, True, False, 0.0, 0
         for step in range(steps):
             gm.decode_step(st)
             got_tok = [int(t) for t in gm.read_tokens(st)]
@@ -144,6 +144,9 @@ class Pair:
             t_orc += time.time() - t0
             if step == 0:
                 spread = float((np.abs(other - ref).max(axis=1) / np.abs(ref).max(axis=1)).max())
+                # the GPU against the bf16-attention oracle itself (the faithful restatement of the reference's CPU path)
+                worst_b = float((np.abs(got - other).max(axis=1) / np.abs(other).max(axis=1)).max())
+            done += 1
             for b in range(B):
                 scale = float(np.abs(ref[b]).max())
                 err = float(np.abs(got[b] - ref[b]).max())
@@ -158,8 +161,9 @@ class Pair:
                 seqs[b]["tokens"].append(want)
             if tie or not equal:
                 break                                                  # the device loop fed its own token: stop in lockstep
-        return {"batch": B, "steps": step + 1, "ctx_max": int(max(seq_lens)), "graph": bool(graph),
-                "max_rel_err": worst, "tokens_equal": equal, "near_tie": tie, "reference_bf16_attention_spread": spread,
+        return {"batch": B, "steps": step + 1, "steps_compared": done, "ctx_max": int(max(seq_lens)), "graph": bool(graph),
+                "max_rel_err": worst, "max_rel_err_vs_bf16_attention": worst_b, "tokens_equal": bool(equal and not tie), "near_tie": tie,
+                "reference_bf16_attention_spread": spread,
                 "oracle": "O1 (unpinned)" if int(o2) == 0 else "O1f (unpinned)", "oracle_s_per_step": round(t_orc / (step + 1), 2)}
 
     # ------------------------------------------------------------------------------------------------ one layer at a time

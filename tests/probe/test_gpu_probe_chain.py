@@ -87,3 +87,33 @@ def test_chained_step_equals_launch_by_launch_tokens():
             assert np.abs(l0 - l1).max() <= 2e-3 * np.abs(l0).max()
     finally:
         lib.mi355_set_tuning(23, 0)
+
+
+def rel_err(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(np.asarray(b, np.float64)).max() + 1e-30))
+
+
+@pytest.mark.parametrize("t", [kq.GGML_Q4_K, kq.GGML_Q6_K])
+def test_q8k_activation_experiment_equals_the_reference_cpu_numbers(t):
+    """mi355_set_tuning(18, 1): single-token launches quantise x to Q8_K and take integer dots on the matrix core, i.e. the
+    arithmetic of candle's CPU mat-vec (oracle O2).  Equal to O2 to f32 summation order; O2 itself sits 5e-3..8e-3 away from
+    the exact product (O1), which the default path matches to 3e-6."""
+    _probe_or_skip()
+    from candle_vllm_amd import _lib
+    from candle_vllm_amd import ops as cv
+    rng = np.random.default_rng(23)
+    for N, K in ((64, 1024), (272, 4096), (48, 14336)):
+        blocks = kq.quantize(rng.normal(0, 0.05, (N, K)).astype(np.float32), t)
+        mm = cv.QMatMul(blocks, t, "cuda")
+        x = rng.normal(size=(1, K)).astype(np.float32)
+        o1, o2 = kq.qmatmul_o1(x, blocks, t), kq.qmatmul_o2(x, blocks, t)
+        try:
+            _lib.lib.mi355_set_tuning(18, 1)
+            y = mm.forward(torch.from_numpy(x).cuda()).cpu().numpy()
+        finally:
+            _lib.lib.mi355_set_tuning(18, 0)
+        assert rel_err(y, o2) < 1e-6, rel_err(y, o2)
+        assert rel_err(mm.forward(torch.from_numpy(x).cuda()).cpu().numpy(), o1) < 1e-5
+        assert 1e-3 < rel_err(o2, o1) < 3e-2
+
+

@@ -365,14 +365,20 @@ def test_stablelm_oracle_plumbing_decode_equals_prefill():
     assert np.array_equal(again, lg)
 
 
-def test_c_twin_avx2_dot_products_equal_the_scalar_definition_bit_for_bit():
-    """oracle/oracle.c states the Q4_K x Q8_K and Q6_K x Q8_K integer dots twice (scalar definition, AVX2 for the
-    cpu_baseline's speed): random and extreme blocks (all codes 15 / 63 with activations +-127, the saturation corner of
-    `maddubs`), identical float results"""
+@pytest.mark.parametrize("isa", ["avx2", "vnni"])
+def test_c_twin_avx2_dot_products_equal_the_scalar_definition_bit_for_bit(isa):
+    """oracle/oracle.c states the Q4_K x Q8_K and Q6_K x Q8_K integer dots three times (scalar definition; AVX2 and -- on hosts
+    that have it -- AVX-512 VNNI `vpdpbusd` for the cpu_baseline's speed): random and extreme blocks (all codes 15 / 63 with
+    activations +-127, the saturation corner of `maddubs`), identical float results"""
     import ctypes
     from oracle import cref
     cref.build()
     L = cref.lib()
+    L.orc_isa.restype = ctypes.c_char_p
+    L.orc_force_isa(0 if isa == "avx2" else -1)
+    if isa == "vnni" and b"vnni" not in L.orc_isa():
+        L.orc_force_isa(-1)
+        pytest.skip("this host has no AVX-512 VNNI")
     vp, i32 = ctypes.c_void_p, ctypes.c_int32
     for name, args in (("orc_vec_dot_q4k_q8k", [vp, i32, vp, vp, vp]), ("orc_vec_dot_q4k_q8k_scalar", [vp, i32, vp, vp, vp]),
                        ("orc_vec_dot_q6k_q8k", [vp, i32, vp, vp]), ("orc_vec_dot_q6k_q8k_scalar", [vp, i32, vp, vp])):
@@ -400,3 +406,4 @@ def test_c_twin_avx2_dot_products_equal_the_scalar_definition_bit_for_bit():
         c = L.orc_vec_dot_q6k_q8k(w6.ctypes.data, nb, xd.ctypes.data, xq.ctypes.data)
         d = L.orc_vec_dot_q6k_q8k_scalar(w6.ctypes.data, nb, xd.ctypes.data, xq.ctypes.data)
         assert np.float32(c).tobytes() == np.float32(d).tobytes(), (trial, c, d)
+    L.orc_force_isa(-1)

@@ -22,6 +22,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
+# bounds of the three legs added in round 3: about twice what the first run on the MI355X measured
+BF16_LAYER_EXCESS = 1e-2     # stream after ONE 16-bit layer from the oracle's stream: error beyond one bf16 ulp of the element, relative
+                             # to the row's largest value (measured 4.4e-3 at batch 32 / Llama-3-8B, 1.9e-3 Qwen2-7B GPTQ)
+BF16_E2E = 4e-2              # logits after 32 / 28 bf16-rounding layers (measured 2.0e-2 / 4.9e-3; the tiny tests of this path use 2e-2 after 2 layers)
+MOE_LAYER = 1e-3             # one Mixtral layer (e4m3 cache + routed experts), relative to what the layer adds (measured 2.3e-4, median 2.8e-5)
+MOE_E2E = 5e-3               # logits after 32 layers, two greedy steps (measured 1.9e-3)
+
 
 def _pair(lib, scale):
     if not torch.cuda.is_available():
@@ -71,13 +78,18 @@ def _layerwise_ok(r):
     assert r["lm_head_rel_err"] < 1e-4 and r["tokens_equal"], r
 
 
-def _end_to_end_ok(r, floor):
+def _end_to_end_ok(r, floor, min_steps):
     # BASELINE's bar is 1e-3 on the logits.  Through 32 layers that bar is below what the reference's OWN rounding points do
-    # to the logits (`reference_bf16_attention_spread`: the oracle with the reference's bf16 attention tensors vs the oracle
-    # with f32 attention, same weights, same step), so the end-to-end bound is that measured spread (x2) or `floor`,
-    # whichever is larger -- and the greedy tokens must agree.
-    assert r["max_rel_err"] < max(floor, 2.0 * r["reference_bf16_attention_spread"]), r
-    assert r["tokens_equal"], r
+    # to the logits (`reference_bf16_attention_spread`: the oracle with the reference's bf16 attention tensors -- the faithful
+    # restatement of its CPU path, models/mod.rs:1288-1306 -- vs the oracle with f32 attention, same weights, same step).  The
+    # end-to-end bound is ONE such spread (round 2 allowed two), measured in the same test, or `floor` if that is larger; the GPU
+    # is also compared with the bf16-attention oracle directly (`max_rel_err_vs_bf16_attention`, the same bound).  Greedy tokens
+    # must agree on every compared step; a near-tie stop is not "equal": the number of compared steps is asserted.
+    bound = max(floor, 1.0 * r["reference_bf16_attention_spread"])
+    assert r["max_rel_err"] < bound, r
+    assert r["max_rel_err_vs_bf16_attention"] < bound, r
+    assert r["tokens_equal"] and not r["near_tie"], r
+    assert r["steps_compared"] >= min_steps, r
 
 
 def test_every_layer_batch1_at_ctx_4096_bench_weights(pair_bench):
@@ -96,14 +108,14 @@ def test_every_layer_batch32_ragged_bench_weights(pair_bench):
 def test_batch1_graph_replay_at_ctx_4096(pair_trained):
     r = pair_trained.run_decode([4097], steps=3, o2=0, graph=True)
     print(r)
-    _end_to_end_ok(r, 1e-3)
+    _end_to_end_ok(r, 1e-3, 3)
 
 
 def test_batch32_ragged_chained_wide_path(pair_trained):
     from tests.fullsize_parity import ragged_batch32
     r = pair_trained.run_decode(ragged_batch32(np.random.default_rng(4321)), steps=2, o2=2, graph=True)
     print(r)
-    _end_to_end_ok(r, 1e-3)
+    _end_to_end_ok(r, 1e-3, 2)
 
 
 def test_prompt_step(pair_trained):
@@ -113,3 +125,46 @@ def test_prompt_step(pair_trained):
     assert r["max_rel_err"] < 3e-3, r
     assert r["tokens_equal"], r
     assert r["kv_max_rel_err"] <= 2 ** -6, r
+
+
+# ---- the other three timed geometries (bench_legs.py): BASELINE configs[2..4] at their benchmarked sizes
+def test_bf16_batch32_ragged_llama3_8b_every_layer_and_end_to_end(lib):
+    """configs[2]: the 16-bit host layer (dense_model.cpp) at Llama-3-8B size, 32 layers, batch 32 with ragged contexts up to
+    4097 tokens (llama.rs:139-201, attention.rs:585-734, mlp.rs:440-458, linear.rs:124-172)"""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from tests.fullsize_dense import DensePair, ragged_batch32
+    p = DensePair("bf16_b32", log=print, std=0.008)
+    r = p.run(ragged_batch32(np.random.default_rng(4321)))
+    print({k: v for k, v in r.items() if k != "per_layer"})
+    del p
+    assert r["worst_layer_excess"] < BF16_LAYER_EXCESS, r
+    assert r["logits_max_rel_err"] < BF16_E2E and r["tokens_equal"], r
+
+
+def test_gptq_qwen2_7b_batch1_ctx4096_every_layer_and_end_to_end(lib):
+    """configs[3] on one GPU: Qwen2-7B shapes, 28 layers, GPTQ 4-bit group 128 through the marlin_4bit arm, qkv bias, batch 1 at
+    context 4097 (qwen.rs:78-96, gptq.rs:26-204, linear.rs:845-906)"""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from tests.fullsize_dense import DensePair
+    p = DensePair("gptq_qwen2", log=print, std=0.004)
+    r = p.run([4097])
+    print({k: v for k, v in r.items() if k != "per_layer"})
+    del p
+    assert r["worst_layer_excess"] < BF16_LAYER_EXCESS, r
+    assert r["logits_max_rel_err"] < BF16_E2E and r["tokens_equal"], r
+
+
+def test_mixtral_8x7b_q4k_fp8_kv_batch1_ctx4096_every_layer_and_end_to_end(lib):
+    """configs[4] on one GPU: Mixtral-8x7B Q4_K shapes, 32 layers x 8 experts, device router + top-2, fp8 KV cache, batch 1 at
+    context 4097 (quantized_llama.rs:56-123, layers/moe.rs:746-810, attention.rs:574,896)"""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from tests.fullsize_moe import MoePair
+    p = MoePair(n_layers=32, scale=0.2, log=print)
+    r = p.run(ctx=4097, steps=2)
+    print(r)
+    del p
+    assert r["worst_layer_rel_err"] < MOE_LAYER and r["median_layer_rel_err"] < 1e-4 and r["lm_head_rel_err"] < 1e-4, r
+    assert r["logits_max_rel_err"] < MOE_E2E and r["tokens_equal"] and r["steps_compared"] == 2, r
