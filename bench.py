@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--kv-layout", choices=["flash", "paged"], default="paged",
                     help="paged = vLLM layout (reference default without flash-attn features; MFMA attention), "
                          "flash = [NB,bs,Hkv,D]")
-    ap.add_argument("--parity", choices=["off", "quick", "full"], default="quick",
+    ap.add_argument("--parity", choices=["off", "quick", "full"], default="full",
                     help="full-size check of the benchmarked geometry against the C oracle after the timed region "
                          "(quick: batch 1; full: + batch 32 ragged and a 2048-token prompt step)")
     ap.add_argument("--legs", default="all", help="secondary legs at BASELINE configs[2..4] shapes on one GPU (bench_legs.py): "
@@ -283,7 +283,8 @@ def parity_leg(mode):
     gc.collect(); torch.cuda.empty_cache()
     pt = Pair(fill_scale=0.2)                                   # branch gain < 1, as in a trained checkpoint: end-to-end
     e = pt.run_decode([4097], steps=3, o2=0, graph=True)
-    out.update({"max_rel_err": round(e["max_rel_err"], 6), "tokens_equal": bool(e["tokens_equal"]),
+    out.update({"max_rel_err": round(e["max_rel_err"], 6), "max_rel_err_vs_bf16_attention": round(e["max_rel_err_vs_bf16_attention"], 6),
+                "tokens_equal": bool(e["tokens_equal"]), "near_tie_tokens": int(e["near_tie_tokens"]), "steps_compared": int(e["steps_compared"]),
                 "reference_bf16_attention_spread": round(e["reference_bf16_attention_spread"], 6),
                 "end_to_end": "3 greedy steps, batch 1, hipGraph replay, logits vs O1; `reference_bf16_attention_spread` = the "
                               "oracle with the reference's bf16 attention tensors (models/mod.rs:1288-1306) vs the f32-attention "
@@ -424,7 +425,7 @@ def main():
             gc.collect(); torch.cuda.empty_cache()
             import bench_legs
             names = list(bench_legs.LEGS) if args.legs == "all" else [n for n in args.legs.split(",") if n in bench_legs.LEGS]
-            out["configs"] = bench_legs.run_legs(names)
+            out["configs"] = bench_legs.run_legs(names, parity=args.parity != "off")
         if args.parity != "off" and world == 1 and not args.layers:
             try:
                 out["parity"] = parity_leg(args.parity)

@@ -223,7 +223,23 @@ def leg_mixtral_fp8(steps=32, warmup=4):
 LEGS = {"bf16_b32": leg_bf16_b32, "gptq_qwen2": leg_gptq_qwen2, "mixtral_fp8": leg_mixtral_fp8}
 
 
-def run_legs(names):
+def leg_parity(name):
+    """The leg's geometry at its benchmarked size against the oracle (tests/fullsize_dense.py, tests/fullsize_moe.py: every
+    layer teacher-forced from the oracle's stream + one / two greedy steps end to end).  The oracle is the CHECKER here, run
+    after the timed region; PARITY UNPINNED (no reference-held vector exists for the float kernels)."""
+    if name == "mixtral_fp8":
+        from tests.fullsize_moe import MoePair
+        p = MoePair(n_layers=32, scale=0.2)
+        r = p.run(ctx=4097, steps=2)
+    else:
+        from tests.fullsize_dense import DensePair, ragged_batch32
+        p = DensePair(name, std=0.008 if name == "bf16_b32" else 0.004)
+        r = p.run(ragged_batch32(np.random.default_rng(4321)) if name == "bf16_b32" else [4097])
+    del p
+    return {k: (round(v, 7) if isinstance(v, float) else v) for k, v in r.items() if k not in ("per_layer", "units")}
+
+
+def run_legs(names, parity=True):
     import gc
     import torch
     out = {}
@@ -236,6 +252,15 @@ def run_legs(names):
             out[n] = {"error": repr(e)}
         gc.collect()
         torch.cuda.empty_cache()
+        if parity and "error" not in out[n]:
+            t1 = time.time()
+            try:
+                out[n]["parity"] = leg_parity(n)
+                out[n]["parity"]["seconds"] = round(time.time() - t1, 1)
+            except Exception as e:                                    # the checker must never sink the measured number
+                out[n]["parity"] = {"error": repr(e)}
+            gc.collect()
+            torch.cuda.empty_cache()
     return out
 
 

@@ -333,60 +333,164 @@ static int dense_dispatch(const DenseArgs& a, int wtype, int dt, hipStream_t st)
     return -2;
 }
 
-// ---- prompt steps (T >= 96, dense weights): the matmul is compute-bound -> library GEMM on the matrix cores (bf16 / f16
-// output rounded once from the f32 accumulator, exactly what candle's Linear does through the vendor BLAS), then one
-// elementwise kernel for candle's rounding chain (+bias, +residual, silu(gate)*up).
-int mi355_internal_gemm_rowmajor(void* out, int out_dtype, int ldo, const void* x, const void* w, int in_dtype, int T, int N, int K,
-                                 hipStream_t st);
-
-template <int DT>
-__global__ void __launch_bounds__(256) dense_chain_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ y, const uint16_t* __restrict__ bias,
-                                                          const uint16_t* __restrict__ resid, int N, int ldo, int epi, int pair_offset) {
-    const int t = blockIdx.y;
-    const int n_out = epi == MI355_EPI_SILU_MUL ? pair_offset : N;
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n_out) return;
-    float o = h2f<DT>(y[(size_t)t * N + row]);
-    if (bias) o = rnd<DT>(o + h2f<DT>(bias[row]));
-    if (epi == MI355_EPI_SILU_MUL) {
-        float u = h2f<DT>(y[(size_t)t * N + pair_offset + row]);
-        if (bias) u = rnd<DT>(u + h2f<DT>(bias[pair_offset + row]));
-        o = rnd<DT>(rnd<DT>(o / (1.f + __expf(-o))) * u);
-    } else if (epi == MI355_EPI_RESID) {
-        o = rnd<DT>(o + h2f<DT>(resid[(size_t)t * ldo + row]));
-    }
-    out[(size_t)t * ldo + row] = f2h<DT>(o);
+// ---- prompt steps (T >= 96, dense 16-bit weights): the matmul is compute-bound -> a hand-written MFMA GEMM
+// (`Linear::forward` on prompt chunks, linear.rs:124-172; packed gate_up of mlp.rs:324-352,440-458).  Both operands are
+// k-contiguous ("TN": x [T,K], W [N,K]), so a 16 x 16 x 32 A / B fragment is 16 contiguous bytes of a row:
+//   * workgroup tile 128 tokens x 128 weight rows, 4 waves as 2 x 2, wave tile 64 x 64 (4 x 4 accumulators), K in steps of 64;
+//   * both tiles go global -> LDS by DMA (`global_load_lds_dwordx4`, inline asm so that hipcc neither counts nor drains it:
+//     the DMA of K-step t+1 is in flight while step t is multiplied; one counted wait + one barrier per step), two LDS buffers;
+//   * LDS rows are 128 B (64 k): the 16-byte slot c of row r is stored at slot c ^ (r & 7) -- the swizzle is applied to the
+//     lane's GLOBAL source address (the DMA destination is lane-linear), fragment reads are conflict-free ds_read_b128;
+//   * candle's rounding chain in the epilogue, from the f32 accumulators: round to the dtype, + bias (rounded), then
+//     + residual (rounded) or silu(gate) rounded * up rounded -- no separate chain kernel, no f32 / 16-bit staging of y;
+//   * SILU_MUL: the B tile holds 64 gate rows and the 64 matching up rows (pair_offset apart in W), every wave owns both halves
+//     of its 32 output columns, so gate and up meet in registers.
+// rocBLAS is no longer used on this path (round 2 called rocblas_gemm_ex here).
+template <int NP>
+__device__ __forceinline__ void dgemm_dma(const uint8_t* gsrc_lane, uint32_t lds_dst) {
+    // NP x 1 KiB: lane l copies 16 B from its own source address (+ i * row_stride handled by the caller through separate calls)
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_dst) : "memory");
 }
 
+#define DG_BM 128
+#define DG_BN 128
+#define DG_BK 64
+template <int DT>
+__global__ void __launch_bounds__(256, 2) dense_gemm_kernel(const DenseArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];   // [2 buffers][A 16 KiB | B 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m16 = lane & 15, kg = lane >> 4;
+    const bool silu = a.epi == MI355_EPI_SILU_MUL;
+    // token tiles fastest: the workgroups that run together share their weight tile through L2
+    const int bm = blockIdx.x, bn = blockIdx.y;
+    const int t0 = bm * DG_BM;
+    const int n_cols = silu ? a.pair_offset : a.N;                      // output columns
+    const int c0 = bn * (silu ? 64 : DG_BN);                            // first output column of this tile
+    // weight row held by LDS B-row j
+    auto wrow = [&](int j) {
+        int n = silu ? (j < 64 ? c0 + j : a.pair_offset + c0 + (j - 64)) : c0 + j;
+        const int lim = silu ? (j < 64 ? a.pair_offset - 1 : a.N - 1) : a.N - 1;
+        return n > lim ? lim : n;                                       // clamped: columns beyond the matrix are computed and never stored
+    };
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)smem);
+    const uint8_t* xb = static_cast<const uint8_t*>(a.x);
+    const uint8_t* wb = static_cast<const uint8_t*>(a.w);
+    // staging: round r (0..3) covers LDS rows 32 r .. 32 r + 31; this thread's row / slot inside the round
+    const int srow = tid >> 3, sslot = tid & 7;
+    const uint8_t* asrc[4];
+    const uint8_t* bsrc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 32 * r + srow;
+        int t = t0 + row;
+        if (t > a.T - 1) t = a.T - 1;
+        asrc[r] = xb + ((size_t)t * a.ldx) * 2 + (size_t)((sslot ^ (row & 7)) * 16);
+        bsrc[r] = wb + ((size_t)wrow(row) * a.ldw) * 2 + (size_t)((sslot ^ (row & 7)) * 16);
+    }
+    auto stage = [&](int kt, int buf) {
+        const uint32_t base = lds0 + (uint32_t)buf * 32768u + (uint32_t)wave * 1024u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dgemm_dma<1>(asrc[r] + (size_t)kt * (DG_BK * 2), base + (uint32_t)r * 4096u);
+            dgemm_dma<1>(bsrc[r] + (size_t)kt * (DG_BK * 2), base + 16384u + (uint32_t)r * 4096u);
+        }
+    };
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // LDS byte offsets of this lane's fragments (without the K-step slot): A rows of the wave's four m-fragments, B rows of its
+    // four n-fragments (SILU_MUL: fragments 0, 1 = gate columns, 2, 3 = the same columns of up)
+    int arow[4], brow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) arow[i] = wr * 64 + i * 16 + m16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) brow[j] = silu ? ((j >> 1) * 64 + wc * 32 + (j & 1) * 16 + m16) : (wc * 64 + j * 16 + m16);
+    const int nkt = a.K / DG_BK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);                       // in flight while this step is multiplied
+        const uint8_t* A = smem + (size_t)buf * 32768;
+        const uint8_t* B = A + 16384;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            uint4 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const uint4*>(A + (size_t)arow[i] * 128 + (size_t)(((s2 * 4 + kg) ^ (arow[i] & 7)) * 16));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const uint4*>(B + (size_t)brow[j] * 128 + (size_t)(((s2 * 4 + kg) ^ (brow[j] & 7)) * 16));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma32<DT>(af[i], bf[j], acc[i][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the next tile has landed (this wave's share of it)
+        __syncthreads();                                                // ... everyone's; and everyone is done reading `buf`
+    }
+    // ---- epilogue: the lane holds tokens 4 kg + v of every m-fragment for column m16 of every n-fragment
+    const uint16_t* bias = static_cast<const uint16_t*>(a.bias);
+    const uint16_t* resid = static_cast<const uint16_t*>(a.resid);
+    uint16_t* out = static_cast<uint16_t*>(a.out);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int t = t0 + wr * 64 + i * 16 + 4 * kg + v;
+            if (t >= a.T) continue;
+            if (silu) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = c0 + wc * 32 + j * 16 + m16;
+                    if (col >= n_cols) continue;
+                    float g = rnd<DT>(acc[i][j][v]), u = rnd<DT>(acc[i][j + 2][v]);
+                    if (bias) { g = rnd<DT>(g + h2f<DT>(bias[col])); u = rnd<DT>(u + h2f<DT>(bias[a.pair_offset + col])); }
+                    out[(size_t)t * a.ldo + col] = f2h<DT>(rnd<DT>(rnd<DT>(g / (1.f + __expf(-g))) * u));      // silu(gate) * up (mlp.rs:457)
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = c0 + wc * 64 + j * 16 + m16;
+                    if (col >= n_cols) continue;
+                    float o = rnd<DT>(acc[i][j][v]);
+                    if (bias) o = rnd<DT>(o + h2f<DT>(bias[col]));
+                    if (a.epi == MI355_EPI_RESID) o = rnd<DT>(o + h2f<DT>(resid[(size_t)t * a.ldo + col]));
+                    out[(size_t)t * a.ldo + col] = f2h<DT>(o);
+                }
+            }
+        }
+}
 
 static int dense_prompt_gemm(const DenseArgs& a, int dt, hipStream_t st) {
-    const bool direct = a.epi == MI355_EPI_STORE && !a.bias;                 // no chain: the GEMM writes `out` itself
-    uint16_t* y = static_cast<uint16_t*>(a.out);
-    if (!direct) {
-        const size_t need = (size_t)a.T * a.N * 2;
-        void* ws = nullptr;                                                  // per (device, stream): scratch.cpp
-        const int wrc = mi355_scratch_get(&ws, MI355_SCR_DENSE_WS, need, st, false);
-        if (wrc) return wrc;
-        y = static_cast<uint16_t*>(ws);
+    if (a.K % DG_BK || a.T < 1 || a.N < 1) return (int)hipErrorNotSupported;
+    if ((a.ldx * 2) % 16 || (a.ldw * 2) % 16) return (int)hipErrorNotSupported;          // 16-byte DMA pieces
+    if (a.epi == MI355_EPI_SILU_MUL && (a.pair_offset <= 0 || a.N != 2 * a.pair_offset)) return (int)hipErrorNotSupported;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)dense_gemm_kernel<MI355_DTYPE_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)dense_gemm_kernel<MI355_DTYPE_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_done = true;
     }
-    const int rc = mi355_internal_gemm_rowmajor(y, dt, direct ? a.ldo : a.N, a.x, a.w, dt, a.T, a.N, a.K, st);
-    if (rc || direct) return rc;
-    const int n_out = a.epi == MI355_EPI_SILU_MUL ? a.pair_offset : a.N;
-    dim3 grid((n_out + 255) / 256, a.T);
-    if (dt == MI355_DTYPE_BF16)
-        hipLaunchKernelGGL((dense_chain_kernel<MI355_DTYPE_BF16>), grid, dim3(256), 0, st, static_cast<uint16_t*>(a.out), y,
-                           static_cast<const uint16_t*>(a.bias), static_cast<const uint16_t*>(a.resid), a.N, a.ldo, a.epi, a.pair_offset);
-    else
-        hipLaunchKernelGGL((dense_chain_kernel<MI355_DTYPE_F16>), grid, dim3(256), 0, st, static_cast<uint16_t*>(a.out), y,
-                           static_cast<const uint16_t*>(a.bias), static_cast<const uint16_t*>(a.resid), a.N, a.ldo, a.epi, a.pair_offset);
+    const int n_cols = a.epi == MI355_EPI_SILU_MUL ? a.pair_offset : a.N;
+    const int cols_per_wg = a.epi == MI355_EPI_SILU_MUL ? 64 : DG_BN;
+    const dim3 grid((a.T + DG_BM - 1) / DG_BM, (n_cols + cols_per_wg - 1) / cols_per_wg);
+    if (dt == MI355_DTYPE_BF16) hipLaunchKernelGGL((dense_gemm_kernel<MI355_DTYPE_BF16>), grid, dim3(256), 64 * 1024, st, a);
+    else if (dt == MI355_DTYPE_F16) hipLaunchKernelGGL((dense_gemm_kernel<MI355_DTYPE_F16>), grid, dim3(256), 64 * 1024, st, a);
+    else return (int)hipErrorNotSupported;
     return (int)hipGetLastError();
 }
 
 // SILU_MUL with more than 32 tokens, or any T > 64: run in token chunks
 static int dense_run(DenseArgs a, int wtype, int dt, hipStream_t st) {
-    if (wtype == DW_DENSE && a.T >= 96 && a.ldx == a.K && a.ldw == a.K) {
+    if (wtype == DW_DENSE && a.T >= 96) {
         const int rc = dense_prompt_gemm(a, dt, st);
-        if (rc != (int)hipErrorSharedObjectInitFailed) return rc;          // no rocBLAS: keep streaming in chunks
+        if (rc != (int)hipErrorNotSupported) return rc;                    // odd strides / K: keep streaming in token chunks
     }
     const int chunk = a.epi == MI355_EPI_SILU_MUL ? 32 : 64;
     const int T = a.T;

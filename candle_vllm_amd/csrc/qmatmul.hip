@@ -1398,6 +1398,8 @@ __global__ void __launch_bounds__(512, 2) qmm_gemm2_kernel(const QmmArgs a, cons
     else qmm_gemm_body<MT, WTB>(a, img, part, ldp, s_split, a.nseg, slots1, slots0, (int)blockIdx.x - nwg0);
 }
 
+#include "qmm_wide1.inc"
+
 // partial sums -> epilogue; one thread per (token, concatenated padded row).  Two phases, so that every load that does not
 // depend on the deferred 1/rms factor (the k-split partial sums of the thread's row and of its partner row, the residual,
 // the bias) is in flight BEFORE the workgroup reduces the sum of squares -- one memory round trip instead of two.
@@ -1478,7 +1480,7 @@ __device__ __forceinline__ float qmm_epilogue_apply(const QmmArgs& a, const QmgE
 }
 
 // chain target: where the epilogue stages the NEXT wide mat-mul's activation image (img == null: no chain)
-struct QmgChainOut { uint8_t* img; float* ssp; const float* norm_w; int K, MT; size_t kbb; };
+struct QmgChainOut { uint8_t* img; float* ssp; const float* norm_w; int K, MT; size_t kbb; int sp; };   // sp: 1 = single f16 plane (qmm_wide1.inc), MT then counts 16-token tiles
 
 // grid = (padded rows / 256, tokens).  With a chain target the y extent covers the PADDED token rows (MT*8) and every
 // workgroup = (token b, 256 consecutive output columns) = one (row, k-block) of the next image: the outputs meet in LDS
@@ -1520,7 +1522,8 @@ __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, cons
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = sm_o[threadIdx.x * 8 + i];
-        qmg_prep_entry(ch.img, ch.ssp, v, b < a.B, ch.norm_w, ch.MT, ch.kbb, kb, b, (int)threadIdx.x);
+        if (ch.sp) qw1_prep_entry(ch.img, ch.ssp, v, b < a.B, ch.norm_w, ch.MT, ch.kbb, kb, b, (int)threadIdx.x);
+        else qmg_prep_entry(ch.img, ch.ssp, v, b < a.B, ch.norm_w, ch.MT, ch.kbb, kb, b, (int)threadIdx.x);
     }
 }
 
@@ -1528,8 +1531,8 @@ __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, cons
 // (device, stream) that launches: two models on two streams never share an image, growing a buffer never frees memory a
 // captured graph still replays from (scratch.cpp).  The chain hint is per (device, stream) too.
 // image staged by the last chained epilogue: valid for exactly the next wide launch if it consumes the same activations
-struct QmgChainState { bool valid; const void* x; int B, K, MT, buf; const float* norm_w; hipStream_t st; };
-struct QmgStream { int cur = 0; QmgChainState chain = {false, nullptr, 0, 0, 0, 0, nullptr, nullptr}; };
+struct QmgChainState { bool valid; const void* x; int B, K, MT, buf; const float* norm_w; hipStream_t st; int sp; };
+struct QmgStream { int cur = 0; QmgChainState chain = {false, nullptr, 0, 0, 0, 0, nullptr, nullptr, 0}; };
 static std::mutex g_qmg_mu;
 static std::map<std::pair<int, hipStream_t>, QmgStream> g_qmg_streams;
 static QmgStream& qmg_stream(hipStream_t st) {
@@ -1540,6 +1543,7 @@ static QmgStream& qmg_stream(hipStream_t st) {
 }
 static int g_tune_qmv = 0;                                    // mi355_set_tuning(20, 1): single-token launches take the LDS-DMA engine (qmv_engine.inc) one by one -- measured slower than qmm_kernel per launch (fixed cost), faster chained
 static int g_tune_qmv_nc = 8;                                 // mi355_set_tuning(21, n): consumer waves per workgroup of the engine (1..15)
+static int g_tune_exact_act = 0;                              // mi355_set_tuning(24, 1): "exact" activations on the 9..32-token and prompt paths: f16 hi + lo planes (22 bits) instead of one f16 plane
 static int g_tune_chain_b1 = 0;                               // mi355_set_tuning(23, 1): probe builds: chain the single-token mat-vecs between two attention calls into one persistent launch
 static int g_tune_qmv_ring = 0;                               // mi355_set_tuning(22, 64): the engine never takes the 128 KiB ring (A/B)
 static int g_tune_chain = 1;                                  // mi355_set_tuning(9, 0): never chain (A/B experiments)
@@ -1570,7 +1574,7 @@ static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
     // activation image: staged by the previous launch's epilogue (chain) or by the prep kernel now
     QmgStream& qs = qmg_stream(st);
     const bool chained = qs.chain.valid && qs.chain.x == a.x && qs.chain.B == a.B && qs.chain.K == a.K &&
-                         qs.chain.MT == MT && qs.chain.norm_w == a.norm_w && qs.chain.st == st &&
+                         qs.chain.MT == MT && qs.chain.sp == 0 && qs.chain.norm_w == a.norm_w && qs.chain.st == st &&
                          a.x_dtype == MI355_DTYPE_F32 && a.ldx == a.K;
     qs.chain.valid = false;
     const int cur = chained ? qs.chain.buf : qs.cur;
@@ -1626,7 +1630,7 @@ static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
         s0 = s1;
     }
     // chain: this epilogue also stages the image of the next wide mat-mul (x = our out) into the other buffer
-    QmgChainOut ch{nullptr, nullptr, nullptr, 0, 0, 0};
+    QmgChainOut ch{nullptr, nullptr, nullptr, 0, 0, 0, 0};
     const bool want = g_tune_chain && a.chain_next && a.next_k > 0 && (a.next_k % 256) == 0 && a.ldo == a.next_k &&
                       (a.epi == MI355_EPI_RESID || a.epi == MI355_EPI_SILU_MUL || a.epi == MI355_EPI_STORE) &&
                       (a.epi == MI355_EPI_SILU_MUL ? a.seg[0].n_rows == a.next_k : (a.nseg == 1 && a.seg[0].n_rows == a.next_k));
@@ -1636,12 +1640,91 @@ static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
         rc = qmg_buf(&onext, other ? MI355_SCR_QMM_IMG1 : MI355_SCR_QMM_IMG0, kbb * nkb2 + (size_t)nkb2 * MT * 8 * sizeof(float), st);
         if (rc) return rc;
         uint8_t* oimg = static_cast<uint8_t*>(onext);
-        ch = QmgChainOut{oimg, reinterpret_cast<float*>(oimg + kbb * nkb2), a.next_norm_w, a.next_k, MT, kbb};
-        qs.chain = QmgChainState{true, a.out, a.B, a.next_k, MT, other, a.next_norm_w, st};
+        ch = QmgChainOut{oimg, reinterpret_cast<float*>(oimg + kbb * nkb2), a.next_norm_w, a.next_k, MT, kbb, 0};
+        qs.chain = QmgChainState{true, a.out, a.B, a.next_k, MT, other, a.next_norm_w, st, 0};
     }
     qs.cur = cur;
     hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, want ? MT * 8 : a.B), dim3(256), 0, st, a, part, ldp, ks,
                        MT * 8, ssp, ch);
+    return (int)hipGetLastError();
+}
+
+// single-plane launcher (qmm_wide1.inc): MT = m-tiles of 16 tokens (1: 9..16 tokens, 2: 17..32)
+template <int MT>
+static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
+    QmmArgs a = a0;
+    if (a.paired) a.paired = 0;
+    const int nkb = a.K / 256;
+    int n_slots = 0;
+    for (int s = 0; s < a.nseg; ++s) n_slots += a.seg[s].n_tiles;
+    const int ldp = n_slots * 16, BP = MT * 16;
+    const size_t kbb = qw1_kb_bytes(MT);
+    int ks = 1;
+    if (g_tune_ks_target > 0) { while (n_slots * ks < g_tune_ks_target && nkb / (ks * 2) >= g_tune_ks_minkb) ks *= 2; }
+    else { while ((n_slots + QMG_NC - 1) / QMG_NC * ks < -g_tune_ks_target && nkb / (ks * 2) >= g_tune_ks_minkb) ks *= 2; }
+    QmgStream& qs = qmg_stream(st);
+    const bool chained = qs.chain.valid && qs.chain.x == a.x && qs.chain.B == a.B && qs.chain.K == a.K &&
+                         qs.chain.MT == MT && qs.chain.sp == 1 && qs.chain.norm_w == a.norm_w && qs.chain.st == st &&
+                         a.x_dtype == MI355_DTYPE_F32 && a.ldx == a.K;
+    qs.chain.valid = false;
+    const int cur = chained ? qs.chain.buf : qs.cur;
+    int rc = 0;
+    void* imgp = nullptr;
+    rc = qmg_buf(&imgp, cur ? MI355_SCR_QMM_IMG1 : MI355_SCR_QMM_IMG0, kbb * nkb + (size_t)nkb * BP * sizeof(float), st);
+    if (rc) return rc;
+    void* partp = nullptr;
+    rc = qmg_buf(&partp, MI355_SCR_QMM_PART, (size_t)ks * BP * ldp * sizeof(float), st);
+    if (rc) return rc;
+    float* const part = static_cast<float*>(partp);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)qw1_gemm_kernel<MT, MI355_GGML_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qw1_gemm_kernel<MT, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qw1_gemm2_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    uint8_t* img = static_cast<uint8_t*>(imgp);
+    float* ssp = reinterpret_cast<float*>(img + kbb * nkb);                 // [nkb][BP] after the image
+    if (!chained) hipLaunchKernelGGL((qw1_prep_kernel<MT>), dim3(nkb, MT * 2), dim3(256), 0, st, img, ssp, a, kbb);
+    int s_split = 0, slots0 = 0;                                     // exactly one Q4_K run followed by one Q6_K run: one launch
+    while (s_split < a.nseg && a.seg[s_split].type == MI355_GGML_Q4_K) slots0 += a.seg[s_split++].n_tiles;
+    bool two_runs = g_tune_merge && s_split > 0 && s_split < a.nseg;
+    for (int q = s_split; q < a.nseg; ++q) two_runs = two_runs && a.seg[q].type == MI355_GGML_Q6_K;
+    if (two_runs) {
+        const int slots1 = n_slots - slots0;
+        const dim3 ggrid((slots0 + QMG_NC - 1) / QMG_NC + (slots1 + QMG_NC - 1) / QMG_NC, ks);
+        hipLaunchKernelGGL((qw1_gemm2_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, a, img, part, ldp, s_split, slots0, slots1);
+    }
+    for (int s0 = 0, slot_base = 0; s0 < a.nseg && !two_runs;) {
+        int s1 = s0 + 1;
+        while (s1 < a.nseg && a.seg[s1].type == a.seg[s0].type) ++s1;
+        QmmArgs r = a;
+        r.nseg = s1 - s0;
+        int run_slots = 0;
+        for (int q = 0; q < r.nseg; ++q) { r.seg[q] = a.seg[s0 + q]; run_slots += r.seg[q].n_tiles; }
+        const dim3 ggrid((run_slots + QMG_NC - 1) / QMG_NC, ks);
+        if (r.seg[0].type == MI355_GGML_Q4_K)
+            hipLaunchKernelGGL((qw1_gemm_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), 2 * kbb, st, r, img, part, ldp, run_slots, slot_base);
+        else
+            hipLaunchKernelGGL((qw1_gemm_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, r, img, part, ldp, run_slots, slot_base);
+        slot_base += run_slots;
+        s0 = s1;
+    }
+    QmgChainOut ch{nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    const bool want = g_tune_chain && a.chain_next && a.next_k > 0 && (a.next_k % 256) == 0 && a.ldo == a.next_k &&
+                      (a.epi == MI355_EPI_RESID || a.epi == MI355_EPI_SILU_MUL || a.epi == MI355_EPI_STORE) &&
+                      (a.epi == MI355_EPI_SILU_MUL ? a.seg[0].n_rows == a.next_k : (a.nseg == 1 && a.seg[0].n_rows == a.next_k));
+    if (want) {
+        const int other = cur ^ 1, nkb2 = a.next_k / 256;
+        void* onext = nullptr;
+        rc = qmg_buf(&onext, other ? MI355_SCR_QMM_IMG1 : MI355_SCR_QMM_IMG0, kbb * nkb2 + (size_t)nkb2 * BP * sizeof(float), st);
+        if (rc) return rc;
+        uint8_t* oimg = static_cast<uint8_t*>(onext);
+        ch = QmgChainOut{oimg, reinterpret_cast<float*>(oimg + kbb * nkb2), a.next_norm_w, a.next_k, MT, kbb, 1};
+        qs.chain = QmgChainState{true, a.out, a.B, a.next_k, MT, other, a.next_norm_w, st, 1};
+    }
+    qs.cur = cur;
+    hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, want ? BP : a.B), dim3(256), 0, st, a, part, ldp, ks, BP, ssp, ch);
     return (int)hipGetLastError();
 }
 
@@ -1730,6 +1813,7 @@ __global__ void __launch_bounds__(256) qmp_xsplit_kernel(uint16_t* __restrict__ 
 
 #endif  // MI355_QMM_PROBES
 
+#ifdef MI355_QMM_PROBES   // rocBLAS (dlopen) exists in probe builds only: the A/B partner of the hand-written prompt GEMMs
 struct QmpBlas {
     void* lib = nullptr; void* handle = nullptr;
     int (*create)(void**) = nullptr;
@@ -1767,6 +1851,8 @@ int mi355_internal_gemm_rowmajor(void* out, int out_dtype, int ldo, const void* 
     return rc == 0 ? 0 : (int)hipErrorUnknown;
 }
 
+#endif  // MI355_QMM_PROBES
+
 static int g_tune_qpg = 0;                                 // mi355_set_tuning(11, v): prompt-step GEMM variant (A/B runs)
 static int g_tune_qpg_min = 96;                            // mi355_set_tuning(12, n): fewest tokens that take the prompt-step GEMM (QMP_MIN_TOKENS)
 static int g_tune_dbg = 0;                                 // mi355_set_tuning(2, v): probe / ablation modes (experiments only)
@@ -1785,7 +1871,8 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
     for (int s = 0; s < a.nseg; ++s) n_slots += a.seg[s].n_tiles;
     const int T = a.B, K = a.K, ldp = n_slots * 16, nkb = K >> 8;
     const int Tpad = (T + QPG_BM - 1) / QPG_BM * QPG_BM;
-    const size_t xa_b = (size_t)K * Tpad * 4, sf_b = (size_t)nkb * Tpad * 32, rs_b = (size_t)Tpad * 4, c_b = (size_t)T * ldp * 4;
+    const int parts = g_tune_exact_act ? 2 : 1;             // activation planes of the f16 image (mi355_set_tuning(24, 1) = hi + lo)
+    const size_t xa_b = (size_t)K * Tpad * 2 * parts, sf_b = (size_t)nkb * Tpad * 32, rs_b = (size_t)Tpad * 4, c_b = (size_t)T * ldp * 4;
     void* ws = nullptr;
     int rc = qmg_buf(&ws, MI355_SCR_QMP_WS, xa_b + sf_b + 2 * rs_b + c_b + 4096, st);
     if (rc) return rc;
@@ -1796,14 +1883,17 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
     im.row_scale = reinterpret_cast<float*>(base + xa_b + sf_b);
     im.row_inv = im.row_scale + Tpad;
     im.Tpad = Tpad;
+    im.parts = parts;
     float* C = reinterpret_cast<float*>(base + xa_b + sf_b + 2 * rs_b);
     static bool attr_done = false;
     if (!attr_done) {
-#define QPG_ATTR(MTW, NTW, WM, WN, DEEP) (void)hipFuncSetAttribute((const void*)qpg_gemm_kernel<MI355_GGML_Q4_K, MTW, NTW, WM, WN, DEEP>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)
-        QPG_ATTR(2, 4, 4, 2, false); QPG_ATTR(2, 4, 2, 4, false); QPG_ATTR(2, 4, 1, 8, false); QPG_ATTR(4, 4, 1, 4, false);
-        QPG_ATTR(2, 4, 2, 4, true); QPG_ATTR(4, 2, 2, 4, false); QPG_ATTR(2, 4, 1, 8, true);
+#define QPG_ATTR(MTW, NTW, WM, WN, DEEP) \
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_kernel<MI355_GGML_Q4_K, MTW, NTW, WM, WN, DEEP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_kernel<MI355_GGML_Q4_K, MTW, NTW, WM, WN, DEEP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)
+        QPG_ATTR(2, 4, 1, 8, false); QPG_ATTR(4, 4, 1, 8, false); QPG_ATTR(4, 2, 1, 8, false); QPG_ATTR(2, 4, 2, 4, false);
 #undef QPG_ATTR
-        (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         attr_done = true;
     }
     hipLaunchKernelGGL(qpg_rowstat_kernel, dim3(Tpad), dim3(256), 0, st, a, im);
@@ -1816,30 +1906,30 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
         int run_slots = 0;
         for (int q = 0; q < r.nseg; ++q) { r.seg[q] = a.seg[s0 + q]; run_slots += r.seg[q].n_tiles; }
         if (r.seg[0].type == MI355_GGML_Q4_K) {
-            // variants (mi355_set_tuning(11, v)): wave tile (m-tiles x row tiles), wave grid, activation prefetch depth
-#define QPG_GO(MTW, NTW, WM, WN, DEEP) hipLaunchKernelGGL((qpg_gemm_kernel<MI355_GGML_Q4_K, MTW, NTW, WM, WN, DEEP>), \
-                dim3(Tpad / (16 * MTW * WM), (run_slots + NTW * WN - 1) / (NTW * WN)), dim3(WM * WN * 64), 4 * (16 * MTW * WM) * QPG_ROWB, st, \
-                r, im, C, ldp, run_slots, slot_base)
+            // variants (mi355_set_tuning(11, v)): wave tile (m-tiles x row tiles) and wave grid; PARTS = activation planes
+#define QPG_GO(MTW, NTW, WM, WN, DEEP) do { \
+                const dim3 g_(Tpad / (16 * MTW * WM), (run_slots + NTW * WN - 1) / (NTW * WN)), b_(WM * WN * 64); \
+                const size_t sh_ = (size_t)2 * parts * (16 * MTW * WM) * QPG_ROWB; \
+                if (parts == 1) hipLaunchKernelGGL((qpg_gemm_kernel<MI355_GGML_Q4_K, MTW, NTW, WM, WN, DEEP, 1>), g_, b_, sh_, st, r, im, C, ldp, run_slots, slot_base); \
+                else hipLaunchKernelGGL((qpg_gemm_kernel<MI355_GGML_Q4_K, MTW, NTW, WM, WN, DEEP, 2>), g_, b_, sh_, st, r, im, C, ldp, run_slots, slot_base); } while (0)
             switch (g_tune_qpg) {
-                case 1: QPG_GO(2, 4, 4, 2, false); break;              // 128 x 128, waves 32 x 64
-                case 2: QPG_GO(2, 4, 2, 4, false); break;              //  64 x 256, waves 32 x 64
-                case 3: QPG_GO(4, 2, 2, 4, false); break;              // 128 x 128, waves 64 x 32
-                case 4: QPG_GO(4, 4, 1, 4, false); break;              //  64 x 256, 4 waves of 64 x 64
-                case 5: QPG_GO(2, 4, 2, 4, true); break;               //  64 x 256, activations two chunks ahead
-                case 7: QPG_GO(2, 4, 1, 8, true); break;               //  32 x 512, activations two chunks ahead
-                default: QPG_GO(2, 4, 1, 8, false); break;             //  32 x 512, waves 32 x 64: measured best (14.7 k tok/s at T = 2048, no spills)
+                case 1: QPG_GO(4, 4, 1, 8, false); break;              //  64 x 512, waves 64 x 64
+                case 2: QPG_GO(4, 2, 1, 8, false); break;              //  64 x 256, waves 64 x 32
+                case 3: QPG_GO(2, 4, 2, 4, false); break;              //  64 x 256, waves 32 x 64
+                default: QPG_GO(2, 4, 1, 8, false); break;             //  32 x 512, waves 32 x 64: measured best in round 2 (hi + lo planes)
             }
 #undef QPG_GO
         } else {
             const dim3 grid(Tpad / 32, (run_slots + 15) / 16);         // Q6_K: 32 tokens x 256 rows per workgroup; token blocks fastest
-            hipLaunchKernelGGL(qpg_gemm_q6k_kernel, grid, dim3(512), 16 * 1024, st, r, im, C, ldp, run_slots, slot_base);
+            if (parts == 1) hipLaunchKernelGGL(qpg_gemm_q6k_kernel<1>, grid, dim3(512), 8 * 1024, st, r, im, C, ldp, run_slots, slot_base);
+            else hipLaunchKernelGGL(qpg_gemm_q6k_kernel<2>, grid, dim3(512), 16 * 1024, st, r, im, C, ldp, run_slots, slot_base);
         }
         slot_base += run_slots;
         s0 = s1;
     }
     a.norm_w = nullptr;                                     // applied while the image was built
     hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, T), dim3(256), 0, st, a, C, ldp, 1, T, (const float*)nullptr,
-                       QmgChainOut{nullptr, nullptr, nullptr, 0, 0, 0}, (const float*)im.row_scale);
+                       QmgChainOut{nullptr, nullptr, nullptr, 0, 0, 0, 0}, (const float*)im.row_scale);
     return (int)hipGetLastError();
 }
 
@@ -1881,7 +1971,7 @@ static int qmp_launch(const QmmArgs& a0, hipStream_t st) {
     }
     a.norm_w = nullptr;                                     // already applied to x
     hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, T), dim3(256), 0, st, a, C, ldp, 1, T, (const float*)nullptr,
-                       QmgChainOut{nullptr, nullptr, nullptr, 0, 0, 0});
+                       QmgChainOut{nullptr, nullptr, nullptr, 0, 0, 0, 0});
     return (int)hipGetLastError();
 }
 
@@ -1914,6 +2004,7 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     else if (key == 21 && value > 0) g_tune_qmv_nc = value;
     else if (key == 22) g_tune_qmv_ring = value;
     else if (key == 23) g_tune_chain_b1 = value;
+    else if (key == 24) g_tune_exact_act = value;
 }
 
 static size_t qmm_lds_bytes(int BT, int R, int NW) {
@@ -2161,7 +2252,8 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
             a.positions = pos0 ? pos0 + b0 : nullptr;
             a.slot_mapping = slot0 ? slot0 + b0 : nullptr;
             int rcw;
-            if (bn <= 16) rcw = qmg_launch<2>(a, st);
+            if (!g_tune_exact_act) rcw = bn <= 16 ? qw1_launch<1>(a, st) : qw1_launch<2>(a, st);   // one f16 plane, 16-token m-tiles (default)
+            else if (bn <= 16) rcw = qmg_launch<2>(a, st);                                          // hi + lo planes, 8-token m-tiles ("exact")
             else if (bn <= 24) rcw = qmg_launch<3>(a, st);
             else rcw = qmg_launch<4>(a, st);
             if (rcw) return rcw;

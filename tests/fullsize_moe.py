@@ -83,7 +83,7 @@ class MoePair:
             W["layers"].append(lw)
         self.W = W
         cref.build()
-        OL._qmm = lambda x, tw, o2: cref.qmatmul(np.ascontiguousarray(x, np.float32), tw[1], tw[0], 0)   # the C twin's O1 product
+        self._fast_qmm = lambda x, tw, o2: cref.qmatmul(np.ascontiguousarray(x, np.float32), tw[1], tw[0], 0)   # the C twin's O1 product
         self.orc = OL.OracleLlama(cfg, W, flash_layout=False)
         self.orc.kv_fp8 = True
         self.log(f"mixtral: weights in both models: {time.time() - t0:.1f}s")
@@ -104,6 +104,16 @@ class MoePair:
         self.log(f"mixtral: fp8 KV pool in both models: {time.time() - t0:.1f}s")
 
     def run(self, ctx=4097, steps=2):
+        # the oracle's mat-vecs go through the C twin for the duration of this run only (the module-level hook is restored: other
+        # tests in the same process use weight types the C product does not know, e.g. Q8_0 shards)
+        keep = OL._qmm
+        OL._qmm = self._fast_qmm
+        try:
+            return self._run(ctx, steps)
+        finally:
+            OL._qmm = keep
+
+    def _run(self, ctx, steps):
         cfg, gm, rng, M, torch = self.cfg, self.gm, self.rng, self.M, self.torch
         lib = M.lib
         bs, hid, NL = cfg.block_size, cfg.hidden, cfg.n_layers
@@ -152,7 +162,7 @@ class MoePair:
         gm.set_graph(True)
         gm.decode_begin([seqs[0]["tokens"][-1]], [ctx], bt, ctx_cap=ctx + steps, stream=st)
         cache1 = [(k.copy(), v.copy()) for k, v in self.cache]
-        worst, equal, tie, done = 0.0, True, False, 0
+        worst, equal, ties, done = 0.0, True, 0, 0
         for step in range(steps):
             gm.decode_step(st)
             tok = int(gm.read_tokens(st)[0])
@@ -167,10 +177,11 @@ class MoePair:
             if tok != want:
                 top2 = np.partition(r, -2)[-2:]
                 if float(top2[1] - top2[0]) <= 2.0 * err:
-                    tie = True
+                    ties += 1                                             # near tie: the oracle follows the GPU's token
+                    want = tok
                 else:
                     equal = False
-                break                                                     # the device loop fed its own token: stop in lockstep
+                    break
             seqs[0]["tokens"].append(want)
-        res.update({"steps_compared": done, "logits_max_rel_err": worst, "tokens_equal": bool(equal and not tie), "near_tie": bool(tie)})
+        res.update({"steps_compared": done, "logits_max_rel_err": worst, "tokens_equal": bool(equal), "near_tie_tokens": ties})
         return res

@@ -108,8 +108,9 @@ class Pair:
     # ------------------------------------------------------------------------------------------------ decode
     def run_decode(self, seq_lens, steps=2, o2=0, graph=True):
         """`steps` greedy decode steps of len(seq_lens) sequences whose first seq_len-1 tokens are already in the cache.
-        Returns a dict: max_rel_err (max over steps and sequences of max|got-ref| / max|ref| of that row), tokens_equal,
-        near_tie (a token mismatch where the oracle's own top-2 gap is below the error bound -- comparison stops there)."""
+        Returns a dict: max_rel_err (max over steps and sequences of max|got-ref| / max|ref| of that row), tokens_equal (no
+        mismatch outside a near tie), near_tie_tokens (mismatches where the oracle's own top-2 gap is below the error bound: the
+        oracle then follows the GPU's token and the comparison continues), steps_compared."""
         cfg, gm, rng = self.cfg, self.gm, self.rng
         B, bs = len(seq_lens), cfg.block_size
         self._next = 0                                                 # scenarios reuse the pool (both caches hold the same bytes)
@@ -124,7 +125,7 @@ class Pair:
         gm.set_graph(bool(graph))
         gm.decode_begin([s["tokens"][-1] for s in seqs], [len(s["tokens"]) for s in seqs], bt,
                         ctx_cap=int(max(seq_lens)) + steps, stream=st)
-        worst, worst_b, equal, tie, t_orc, done = 0.0, 0.0, True, False, 0.0, 0
+        worst, worst_b, equal, ties, t_orc, done = 0.0, 0.0, True, 0, 0.0, 0
         for step in range(steps):
             gm.decode_step(st)
             got_tok = [int(t) for t in gm.read_tokens(st)]
@@ -155,14 +156,17 @@ class Pair:
                 if got_tok[b] != want:
                     top2 = np.partition(ref[b], -2)[-2:]
                     if float(top2[1] - top2[0]) <= 2.0 * err:
-                        tie = True
+                        # a near tie (the oracle's own top-2 gap is inside the error bound) is not a mismatch; the device loop
+                        # has fed ITS token, so the oracle follows it for this sequence and the comparison goes on
+                        ties += 1
+                        want = got_tok[b]
                     else:
                         equal = False
                 seqs[b]["tokens"].append(want)
-            if tie or not equal:
-                break                                                  # the device loop fed its own token: stop in lockstep
+            if not equal:
+                break                                                  # a real mismatch: the two runs have diverged
         return {"batch": B, "steps": step + 1, "steps_compared": done, "ctx_max": int(max(seq_lens)), "graph": bool(graph),
-                "max_rel_err": worst, "max_rel_err_vs_bf16_attention": worst_b, "tokens_equal": bool(equal and not tie), "near_tie": tie,
+                "max_rel_err": worst, "max_rel_err_vs_bf16_attention": worst_b, "tokens_equal": bool(equal), "near_tie_tokens": ties,
                 "reference_bf16_attention_spread": spread,
                 "oracle": "O1 (unpinned)" if int(o2) == 0 else "O1f (unpinned)", "oracle_s_per_step": round(t_orc / (step + 1), 2)}
 

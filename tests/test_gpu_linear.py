@@ -51,7 +51,8 @@ def check_ulp(got, ref, dt, ulps=1.01, what="", mag=None):
 # ------------------------------------------------------------------------------------------------ K10 dense
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("T,N,K", [(1, 256, 512), (5, 48, 256), (16, 1024, 1024), (17, 64, 768), (33, 128, 512),
-                                   (64, 96, 256), (70, 32, 512), (128, 64, 512), (200, 48, 256)])   # >= 96: library GEMM path
+                                   (64, 96, 256), (70, 32, 512), (128, 64, 512), (200, 48, 256),
+                                   (256, 384, 1024), (300, 200, 576), (97, 130, 64)])   # >= 96 tokens: the hand-written 128 x 128 MFMA GEMM (ragged T / N tiles, one K step)
 def test_linear_matches_oracle(cv, dt, T, N, K):
     rng = np.random.default_rng(T * 1000 + N)
     x = G.round_dt(rng.normal(0, 1, (T, K)), dt)
@@ -68,10 +69,10 @@ def test_linear_matches_oracle(cv, dt, T, N, K):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
-@pytest.mark.parametrize("T", [1, 8, 32, 40, 130])
+@pytest.mark.parametrize("T", [1, 8, 32, 40, 130, 257])
 def test_linear_gate_up_silu(cv, dt, T):
     rng = np.random.default_rng(T)
-    K, I = 512, 192
+    K, I = (512, 192) if T != 257 else (1024, 328)              # 257 tokens: three token tiles, 5.1 column tiles of the prompt GEMM
     x = G.round_dt(rng.normal(0, 1, (T, K)), dt)
     w = G.round_dt(rng.normal(0, 0.06, (2 * I, K)), dt)          # packed [gate; up] (mlp.rs:324-352)
     lin = cv.Linear(dev16(w, dt))

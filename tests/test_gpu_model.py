@@ -469,7 +469,9 @@ def test_long_prompt_uses_the_gemm_path_and_matches(lib):
         outs.append(gm.forward_prefill(meta).cpu().numpy())
     M.lib.mi355_set_tuning(6, 1)
     assert _rel(outs[0], ref) < 3e-3, _rel(outs[0], ref)
-    assert _rel(outs[0], outs[1]) < 2e-3
+    # both paths carry ONE f16 plane per activation since round 3 (own block scales each): two independent 11-bit roundings
+    # through the tiny model's two layers -- measured 2.7e-3 between them, each within 3e-3 of the oracle
+    assert _rel(outs[0], outs[1]) < 4e-3
     assert [int(r.argmax()) for r in outs[0]] == [int(r.argmax()) for r in ref]
 
 

@@ -36,6 +36,24 @@ def bf16_bits(t):
     return t.detach().view(torch.int16).cpu().numpy().view(np.uint16)
 
 
+
+# Per-op bounds against O1 (dequantise, f64 dot).  1..8 tokens: f32-accurate activations (bf16 hi + lo): 1e-4.  9..32 tokens
+# and prompt steps: ONE f16 plane per activation with a power-of-two scale per token and k-block (qmm_wide1.inc,
+# qmm_prefill.inc) -- 11 significant bits, measured 1.8e-4 .. 3.3e-4 on these shapes, bound 5e-4 (north_star's bar: 1e-3).
+# mi355_set_tuning(24, 1) brings the hi + lo planes back ("exact" activations): 1e-4 there as well.
+NARROW_TOL, WIDE_TOL = 1e-4, 5e-4
+
+
+class exact_activations:
+    def __enter__(self):
+        from candle_vllm_amd import _lib
+        _lib.lib.mi355_set_tuning(24, 1)
+
+    def __exit__(self, *a):
+        from candle_vllm_amd import _lib
+        _lib.lib.mi355_set_tuning(24, 0)
+
+
 def rel_err(got, ref):
     return float(np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64)).max() /
                  max(1e-30, np.abs(np.asarray(ref, np.float64)).max()))
@@ -281,11 +299,14 @@ def test_qmatmul_vs_oracle(cv, t, T, N, K):
     mm = cv.QMatMul(blocks, t, "cuda")
     ref = kq.qmatmul_o1(x, blocks, t)
     got = mm.forward(dev(x)).cpu().numpy()
-    # hi/lo bf16 split carries 16 mantissa bits of x; fp32 accumulation.  Bar from BASELINE: 1e-3.
-    assert rel_err(got, ref) < 1e-4, rel_err(got, ref)
+    tol = NARROW_TOL if T <= 8 else WIDE_TOL                              # bar from BASELINE: 1e-3
+    assert rel_err(got, ref) < tol, rel_err(got, ref)
     got_b = mm.forward(dev(x), dev(bias)).cpu().numpy()
-    assert rel_err(got_b, ref + bias) < 1e-4
-    assert rel_err(got, mm.forward_ref(dev(x)).cpu().numpy()) < 1e-4       # MFMA path == simple kernel
+    assert rel_err(got_b, ref + bias) < tol
+    assert rel_err(got, mm.forward_ref(dev(x)).cpu().numpy()) < tol        # MFMA path == simple kernel
+    if T > 8:
+        with exact_activations():                                          # hi + lo planes: f32-accurate activations again
+            assert rel_err(mm.forward(dev(x)).cpu().numpy(), ref) < NARROW_TOL
 
 
 @pytest.mark.parametrize("T,N,K", [(1, 64, 384), (5, 40, 1792), (20, 256, 96)])
@@ -326,9 +347,10 @@ def test_qmatmul_random_bytes_all_code_points(cv):
 
 @pytest.mark.parametrize("t", [kq.GGML_Q4_K, kq.GGML_Q6_K])
 def test_wide_path_activation_range(cv, t):
-    """The 9..32-token path stages activations as f16 hi + lo of x/16 (lo scaled by 2^11, no denormals): outliers of 3e4
-    and 8e5 next to entries of 1e-5, and a uniformly small input, keep the f32-activation accuracy; beyond 1.05e6 the
-    result is NaN (never a plausible wrong number)."""
+    """The 9..32-token path stages ONE f16 plane with a power-of-two scale per token and k-block: outliers of 3e4 / 8e5 / 2e6
+    next to entries of 1e-5, and a uniformly tiny input, keep the single-plane accuracy (the scale follows every k-block's own
+    magnitude); an infinite activation makes its row NaN, never a plausible wrong number.  "Exact" mode (hi + lo planes of
+    x / 16, generation three): f32-activation accuracy up to 1.05e6, NaN beyond."""
     rng = np.random.default_rng(21)
     N, K, B = 64, 1024, 16
     blocks = kq.quantize(rng.normal(0, 0.05, (N, K)).astype(np.float32), t)
@@ -337,12 +359,22 @@ def test_wide_path_activation_range(cv, t):
     x[:, 5] = 3.0e4
     x[3, 7] = -8.0e5
     x[:, 100:200] *= 1e-5
-    assert rel_err(mm.forward(dev(x)).cpu().numpy(), kq.qmatmul_o1(x, blocks, t)) < 1e-4
-    x = (rng.normal(size=(B, K)) * 1e-2).astype(np.float32)
-    assert rel_err(mm.forward(dev(x)).cpu().numpy(), kq.qmatmul_o1(x, blocks, t)) < 1e-4
-    x[2, 9] = 2.0e6
-    y = mm.forward(dev(x)).cpu().numpy()
-    assert np.isnan(y[2]).all() and np.isfinite(np.delete(y, 2, axis=0)).all()
+    x1 = x.copy()
+    assert rel_err(mm.forward(dev(x)).cpu().numpy(), kq.qmatmul_o1(x, blocks, t)) < WIDE_TOL
+    x[4, 300] = 2.0e6
+    assert rel_err(mm.forward(dev(x)).cpu().numpy(), kq.qmatmul_o1(x, blocks, t)) < WIDE_TOL
+    xs = (rng.normal(size=(B, K)) * 1e-7).astype(np.float32)
+    assert rel_err(mm.forward(dev(xs)).cpu().numpy(), kq.qmatmul_o1(xs, blocks, t)) < WIDE_TOL
+    xs[2, 9] = np.inf
+    y = mm.forward(dev(xs)).cpu().numpy()
+    assert (~np.isfinite(y[2])).all() and np.isfinite(np.delete(y, 2, axis=0)).all()      # NaN or +-inf, never a finite number
+    with exact_activations():
+        assert rel_err(mm.forward(dev(x1)).cpu().numpy(), kq.qmatmul_o1(x1, blocks, t)) < NARROW_TOL
+        x2 = (rng.normal(size=(B, K)) * 1e-2).astype(np.float32)
+        assert rel_err(mm.forward(dev(x2)).cpu().numpy(), kq.qmatmul_o1(x2, blocks, t)) < NARROW_TOL
+        x2[2, 9] = 2.0e6
+        y = mm.forward(dev(x2)).cpu().numpy()
+        assert np.isnan(y[2]).all() and np.isfinite(np.delete(y, 2, axis=0)).all()
 
 
 @pytest.mark.parametrize("B", [3, 12, 32, 130])
@@ -402,11 +434,12 @@ def test_fused_silu_pair_and_residual(cv, B):
     cv.qmatmul_fused([mg, mu], dev(x), epilogue=cv.EPI_SILU_MUL, out=h, norm_weight=dev(nw), norm_eps=1e-5)
     xn = O.rms_norm(x, nw, 1e-5)
     href = O.silu_mul(kq.qmatmul_o1(xn, wg, 12), kq.qmatmul_o1(xn, wu, 12))
-    assert rel_err(h.cpu().numpy(), href) < 1e-4
+    tol = NARROW_TOL if B <= 8 else 2 * WIDE_TOL                         # silu(g) * u multiplies two single-plane products
+    assert rel_err(h.cpu().numpy(), href) < tol
     res = dev(x.copy())
     cv.qmatmul_fused([md], h, epilogue=cv.EPI_RESID, out=res, residual=res)      # in place: x += W2 h
     ref = x + kq.qmatmul_o1(h.cpu().numpy(), wd, 14)
-    assert rel_err(res.cpu().numpy(), ref) < 1e-4
+    assert rel_err(res.cpu().numpy(), ref) < tol
 
 
 def test_paged_attention_fused_merge_is_stable(cv):
