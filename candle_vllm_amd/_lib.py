@@ -112,6 +112,10 @@ _sig("mi355_marlin_weight_perm", c_i32, [c_i32])
 _sig("mi355_marlin_zero_pos", c_i32, [c_i32])
 _sig("mi355_linear", ctypes.c_int, [c_vp] * 5 + [c_i32] * 5 + [c_i64])
 _sig("mi355_gptq_linear", ctypes.c_int, [c_vp] * 5 + [c_i32, c_i32, c_vp, c_vp] + [c_i32] * 6 + [c_i64])
+_sig("mi355_gptq_linear_tiled", ctypes.c_int, [c_vp] * 5 + [c_i32, c_i32, c_vp, c_vp] + [c_i32] * 6 + [c_i64])
+_sig("mi355_gptq_tile_repack", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
+_sig("mi355_gptq_tile_unpack", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64])
+_sig("mi355_gptq_tile_index", ctypes.c_int64, [c_i32] * 4)
 
 
 class LlamaConfig(ctypes.Structure):

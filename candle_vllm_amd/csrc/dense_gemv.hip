@@ -23,7 +23,16 @@
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int dg_u32x4 __attribute__((ext_vector_type(4)));
 
-enum { DW_DENSE = 0, DW_GPTQ4 = 1 };
+// DW_GPTQ4: checkpoint layout qweight[k/8][n] u32.  DW_GPTQ4T: the same words in 16-column x 256-k tiles (gptq_tile_index below):
+// one wave's share of a k-block is two contiguous 1 KiB runs (two dwordx4 loads per lane) instead of eight loads that each
+// touch four 64-byte segments a row apart -- what gptq_repack / awq_repack / mi355_marlin_format_repack produce at load time.
+enum { DW_DENSE = 0, DW_GPTQ4 = 1, DW_GPTQ4T = 2 };
+// word index of qweight[kr][n] (kr = k/8) in the tiled image: [tile n/16][k-block kr/32][half][lane = 16*(kr%4) + n%16][4]
+// holding rows kr = 32 kb + 4 (4 half + jj) + lane/16 -- the fragment order of dense_body's 4-bit arm
+__host__ __device__ __forceinline__ size_t gptq_tile_index(int kr, int n, int nkb) {
+    const int kb = kr >> 5, rem = kr & 31, j = rem >> 2, kg = rem & 3;
+    return ((((size_t)(n >> 4) * nkb + kb) * 2 + (j >> 2)) * 64 + kg * 16 + (n & 15)) * 4 + (j & 3);
+}
 enum { SP_NONE = 0, SP_GROUPED = 1, SP_SINGLE = 2 };
 
 struct DenseArgs {
@@ -123,9 +132,16 @@ __device__ __forceinline__ void dense_body(const DenseArgs& a, const int bx) {
         } else {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const uint32_t* qp = static_cast<const uint32_t*>(a.w) + (size_t)(kb * 32 + kg) * a.N + row0[r] + r16;
+                if constexpr (WTYPE == DW_GPTQ4T) {
+                    const dg_u32x4* tp = reinterpret_cast<const dg_u32x4*>(a.w) + ((size_t)(row0[r] >> 4) * nkb + kb) * 128 + lane;
+                    const dg_u32x4 v0 = __builtin_nontemporal_load(tp), v1 = __builtin_nontemporal_load(tp + 64);
+                    bw[r][0].x = v0.x; bw[r][1].x = v0.y; bw[r][2].x = v0.z; bw[r][3].x = v0.w;
+                    bw[r][4].x = v1.x; bw[r][5].x = v1.y; bw[r][6].x = v1.z; bw[r][7].x = v1.w;
+                } else {
+                    const uint32_t* qp = static_cast<const uint32_t*>(a.w) + (size_t)(kb * 32 + kg) * a.N + row0[r] + r16;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bw[r][j].x = __builtin_nontemporal_load(qp + (size_t)(4 * j) * a.N);
+                    for (int j = 0; j < 8; ++j) bw[r][j].x = __builtin_nontemporal_load(qp + (size_t)(4 * j) * a.N);
+                }
             }
         }
 #pragma unroll
@@ -276,7 +292,7 @@ static int dense_launch_dt(const DenseArgs& a, hipStream_t st) {
     const bool pair = a.epi == MI355_EPI_SILU_MUL;
     const int mt = (a.T + 15) / 16;
     int gj = 8;
-    if (WTYPE == DW_GPTQ4) {
+    if (WTYPE != DW_DENSE) {
         if (a.group_size >= 256) { if (a.group_size % 256) return -2; gj = 8; }
         else if (a.group_size == 128) gj = 4;
         else if (a.group_size == 64) gj = 2;
@@ -301,7 +317,7 @@ template <int DT, int WTYPE>
 static int dense3_launch_dt(const DenseArgs (&a)[3], hipStream_t st) {
     const int mt = (a[0].T + 15) / 16;
     int gj = 8;
-    if (WTYPE == DW_GPTQ4) {
+    if (WTYPE != DW_DENSE) {
         const int g = a[0].group_size;
         if (g >= 256) { if (g % 256) return -2; }
         else if (g == 128) gj = 4;
@@ -325,11 +341,15 @@ static int dense3_launch_dt(const DenseArgs (&a)[3], hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+template <int DT>
+static int dense_dispatch_dt(const DenseArgs& a, int wtype, hipStream_t st) {
+    if (wtype == DW_DENSE) return dense_launch_dt<DT, DW_DENSE>(a, st);
+    if (wtype == DW_GPTQ4T) return dense_launch_dt<DT, DW_GPTQ4T>(a, st);
+    return dense_launch_dt<DT, DW_GPTQ4>(a, st);
+}
 static int dense_dispatch(const DenseArgs& a, int wtype, int dt, hipStream_t st) {
-    if (dt == MI355_DTYPE_BF16)
-        return wtype == DW_DENSE ? dense_launch_dt<MI355_DTYPE_BF16, DW_DENSE>(a, st) : dense_launch_dt<MI355_DTYPE_BF16, DW_GPTQ4>(a, st);
-    if (dt == MI355_DTYPE_F16)
-        return wtype == DW_DENSE ? dense_launch_dt<MI355_DTYPE_F16, DW_DENSE>(a, st) : dense_launch_dt<MI355_DTYPE_F16, DW_GPTQ4>(a, st);
+    if (dt == MI355_DTYPE_BF16) return dense_dispatch_dt<MI355_DTYPE_BF16>(a, wtype, st);
+    if (dt == MI355_DTYPE_F16) return dense_dispatch_dt<MI355_DTYPE_F16>(a, wtype, st);
     return -2;
 }
 
@@ -508,9 +528,24 @@ static int dense_run(DenseArgs a, int wtype, int dt, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------ K15 repack
-__global__ void awq_repack_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int K, int NP) {
+// checkpoint layout [K/8][n_in] (columns [0, n_in)) -> tiles tile0 .. of the tiled image (gptq_tile_index); K % 256 == 0, n_in % 16 == 0
+__global__ void gptq_tile_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int K, int n_in, int tile0) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)(K / 8) * n_in) return;
+    const int n = (int)(idx % n_in), kr = (int)(idx / n_in);
+    out[gptq_tile_index(kr, n + 16 * tile0, K >> 8)] = in[idx];
+}
+// the inverse (tests / the exllama arm of a model that changes its mind): tiled image -> [K/8][N]
+__global__ void gptq_untile_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int K, int N) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)(K / 8) * N) return;
+    out[idx] = in[gptq_tile_index((int)(idx / N), (int)(idx % N), K >> 8)];
+}
+static inline bool gptq_tileable(int k, int n) { return k > 0 && n > 0 && !(k & 255) && !(n & 15); }
+
+__global__ void awq_repack_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int K, int NP, int tiled) {
     // in [K][NP] : nibble i of in[k][c] = code(k, 8c + {0,2,4,6,1,3,5,7}[i])   [EXT: AutoAWQ order_map]
-    // out [K/8][8 NP] : nibble i of out[kr][n] = code(8kr + i, n)
+    // out [K/8][8 NP] : nibble i of out[kr][n] = code(8kr + i, n), stored at gptq_tile_index(kr, n) when `tiled`
     const int N = NP * 8;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)(K / 8) * N) return;
@@ -520,7 +555,7 @@ __global__ void awq_repack_kernel(const uint32_t* __restrict__ in, uint32_t* __r
     uint32_t o = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) o |= ((in[(size_t)(8 * kr + i) * NP + (n >> 3)] >> (4 * pos)) & 0xFu) << (4 * i);
-    out[idx] = o;
+    out[tiled ? gptq_tile_index(kr, n, K >> 8) : idx] = o;
 }
 
 // ------------------------------------------------------------------------------------------------ K14 exllama
@@ -591,7 +626,7 @@ __device__ __forceinline__ int marlin_perm_at(int j) {              // j in [0,1
     const int r = (e < 2) ? 2 * (i & 3) + e : 2 * ((i & 3) + 4) + (e - 2);
     return 16 * r + (i >> 2) + 8 * blk + 256 * jj;
 }
-__global__ void __launch_bounds__(256) marlin_to_gptq_kernel(const uint32_t* __restrict__ B, uint32_t* __restrict__ out, int K, int N) {
+__global__ void __launch_bounds__(256) marlin_to_gptq_kernel(const uint32_t* __restrict__ B, uint32_t* __restrict__ out, int K, int N, int tiled) {
     __shared__ uint16_t inv[1024];
     for (int j = threadIdx.x; j < 1024; j += 256) inv[marlin_perm_at(j)] = (uint16_t)j;
     __syncthreads();
@@ -606,7 +641,7 @@ __global__ void __launch_bounds__(256) marlin_to_gptq_kernel(const uint32_t* __r
         const int col = (src & ~1023) + inv[src & 1023];
         o |= ((B[(size_t)(k >> 4) * (2 * N) + (col >> 3)] >> (4 * (col & 7))) & 0xFu) << (4 * i);
     }
-    out[idx] = o;
+    out[tiled ? gptq_tile_index(kr, n, K >> 8) : idx] = o;
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -620,7 +655,7 @@ static int marlin_common(const void* in, const int32_t* qweight, const void* sca
     a.zmode = awq ? MI355_ZERO_AWQ_MARLIN : MI355_ZERO_SYM8;
     a.x = in; a.ldx = k; a.T = m; a.N = n; a.K = k;
     a.out = out; a.ldo = n; a.epi = MI355_EPI_STORE;
-    return dense_run(a, DW_GPTQ4, dt, (hipStream_t)stream);
+    return dense_run(a, DW_GPTQ4T, dt, (hipStream_t)stream);          // the image gptq_repack / awq_repack / mi355_marlin_format_repack made
 }
 
 template <int BITS>
@@ -692,11 +727,37 @@ void gemm_half_q_half_alt(const void* a, const uint32_t* b_q_weight, const uint3
     if (rc) ffi_fail(rc, c, m, n, stream);
 }
 
+/* gptq_repack (marlin gptq_marlin_repack.cu's slot, linear.rs:845-853): checkpoint qweight [k/8][n] -> the weight image the
+ * marlin_* entry points stream.  Every shape those entry points accept (k % 256 == 0, n % 16 == 0) gets the 16 x 256 tile order
+ * (gptq_tile_index); any other shape is copied as is (marlin_* refuses it loudly either way).  in != out. */
 void gptq_repack(const void* in, void* out, int32_t k_packed, int32_t n, int64_t stream) {
-    // our Marlin-slot layout is the checkpoint layout: [k/8][n] u32 (the [k/16, 2n] shape holds the same words)
-    if (!in || !out || k_packed <= 0 || n <= 0) { mi355_note_error((int)hipErrorInvalidValue); return; }
+    if (!in || !out || k_packed <= 0 || n <= 0 || in == out) { mi355_note_error((int)hipErrorInvalidValue); return; }
+    if (gptq_tileable(k_packed * 8, n)) {
+        const size_t total = (size_t)k_packed * n;
+        hipLaunchKernelGGL(gptq_tile_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           static_cast<const uint32_t*>(in), static_cast<uint32_t*>(out), k_packed * 8, n, 0);
+        const int rc = (int)hipGetLastError();
+        if (rc) mi355_note_error(rc);
+        return;
+    }
     const hipError_t e = hipMemcpyAsync(out, in, (size_t)k_packed * n * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream);
     if (e != hipSuccess) mi355_note_error((int)e);
+}
+/* the tile order on its own: columns [0, n_in) of a checkpoint-layout tensor -> tiles tile0 .. of `out` (a tensor of any width
+ * >= 16 (tile0 + n_in / 16)): the host layer packs gate_proj and up_proj side by side this way.  And its inverse. */
+int mi355_gptq_tile_repack(const void* in, void* out, int32_t k, int32_t n_in, int32_t tile0, int64_t stream) {
+    if (!in || !out || in == out || !gptq_tileable(k, n_in) || tile0 < 0) return (int)hipErrorInvalidValue;
+    const size_t total = (size_t)(k / 8) * n_in;
+    hipLaunchKernelGGL(gptq_tile_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const uint32_t*>(in), static_cast<uint32_t*>(out), k, n_in, tile0);
+    return (int)hipGetLastError();
+}
+int mi355_gptq_tile_unpack(const void* in, void* out, int32_t k, int32_t n, int64_t stream) {
+    if (!in || !out || in == out || !gptq_tileable(k, n)) return (int)hipErrorInvalidValue;
+    const size_t total = (size_t)(k / 8) * n;
+    hipLaunchKernelGGL(gptq_untile_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const uint32_t*>(in), static_cast<uint32_t*>(out), k, n);
+    return (int)hipGetLastError();
 }
 void awq_repack(const void* in, void* out, int32_t k, int32_t n_packed, int32_t bits, int64_t stream) {
     if (bits != 4 || (k & 7) || !in || !out || k <= 0 || n_packed <= 0) {
@@ -706,7 +767,7 @@ void awq_repack(const void* in, void* out, int32_t k, int32_t n_packed, int32_t 
     }
     const size_t total = (size_t)(k / 8) * n_packed * 8;
     hipLaunchKernelGGL(awq_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       static_cast<const uint32_t*>(in), static_cast<uint32_t*>(out), k, n_packed);
+                       static_cast<const uint32_t*>(in), static_cast<uint32_t*>(out), k, n_packed, gptq_tileable(k, n_packed * 8) ? 1 : 0);
     const int rc = (int)hipGetLastError();
     if (rc) mi355_note_error(rc);
 }
@@ -718,8 +779,13 @@ int mi355_marlin_format_repack(const void* in_B, void* out, int32_t k, int32_t n
     if (!in_B || !out || k <= 0 || n <= 0 || (k & 15) || (n & 63)) return (int)hipErrorInvalidValue;
     const size_t total = (size_t)(k / 8) * n;
     hipLaunchKernelGGL(marlin_to_gptq_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       static_cast<const uint32_t*>(in_B), static_cast<uint32_t*>(out), k, n);
+                       static_cast<const uint32_t*>(in_B), static_cast<uint32_t*>(out), k, n, gptq_tileable(k, n) ? 1 : 0);
     return (int)hipGetLastError();
+}
+/* host statement of the tile order (unit-tested on CPU against oracle/gptq.py's gptq_tile); -1 for a shape that is not tiled */
+int64_t mi355_gptq_tile_index(int32_t kr, int32_t n, int32_t k, int32_t n_total) {
+    if (!gptq_tileable(k, n_total) || kr < 0 || kr >= k / 8 || n < 0 || n >= n_total) return -1;
+    return (int64_t)gptq_tile_index(kr, n, k >> 8);
 }
 /* host statement of the same permutation (unit-tested on CPU against the numpy restatement of marlin's `_get_perms`) */
 int32_t mi355_marlin_weight_perm(int32_t j) {
@@ -751,10 +817,10 @@ int mi355_linear(void* out, const void* x, const void* w, const void* bias, cons
     return dense_run(a, DW_DENSE, dtype, (hipStream_t)stream);
 }
 
-int mi355_gptq_linear(void* out, const void* x, const void* qweight, const void* scales, const void* qzeros,
-                      int32_t zero_mode, int32_t scales_permuted, const void* bias, const void* residual,
-                      int32_t num_tokens, int32_t n, int32_t k, int32_t group_size, int32_t dtype, int32_t epilogue,
-                      int64_t stream) {
+static int gptq_linear_impl(int wtype, void* out, const void* x, const void* qweight, const void* scales, const void* qzeros,
+                            int32_t zero_mode, int32_t scales_permuted, const void* bias, const void* residual,
+                            int32_t num_tokens, int32_t n, int32_t k, int32_t group_size, int32_t dtype, int32_t epilogue,
+                            int64_t stream) {
     DenseArgs a{};
     a.w = qweight; a.scales = scales; a.qzeros = static_cast<const uint32_t*>(qzeros); a.zmode = zero_mode;
     a.group_size = (group_size <= 0 || group_size > k) ? k : group_size;
@@ -763,7 +829,22 @@ int mi355_gptq_linear(void* out, const void* x, const void* qweight, const void*
     a.bias = bias; a.resid = residual; a.epi = epilogue; a.out = out;
     if (epilogue == MI355_EPI_SILU_MUL) { a.pair_offset = n / 2; a.ldo = n / 2; } else a.ldo = n;
     if (epilogue == MI355_EPI_RESID && !residual) return -2;
-    return dense_run(a, DW_GPTQ4, dtype, (hipStream_t)stream);
+    return dense_run(a, wtype, dtype, (hipStream_t)stream);
+}
+int mi355_gptq_linear(void* out, const void* x, const void* qweight, const void* scales, const void* qzeros,
+                      int32_t zero_mode, int32_t scales_permuted, const void* bias, const void* residual,
+                      int32_t num_tokens, int32_t n, int32_t k, int32_t group_size, int32_t dtype, int32_t epilogue,
+                      int64_t stream) {
+    return gptq_linear_impl(DW_GPTQ4, out, x, qweight, scales, qzeros, zero_mode, scales_permuted, bias, residual, num_tokens, n, k,
+                            group_size, dtype, epilogue, stream);
+}
+/* the same op over the TILED weight image (gptq_repack / mi355_gptq_tile_repack); scales and zero points as above */
+int mi355_gptq_linear_tiled(void* out, const void* x, const void* qweight_tiled, const void* scales, const void* qzeros,
+                            int32_t zero_mode, int32_t scales_permuted, const void* bias, const void* residual,
+                            int32_t num_tokens, int32_t n, int32_t k, int32_t group_size, int32_t dtype, int32_t epilogue,
+                            int64_t stream) {
+    return gptq_linear_impl(DW_GPTQ4T, out, x, qweight_tiled, scales, qzeros, zero_mode, scales_permuted, bias, residual, num_tokens,
+                            n, k, group_size, dtype, epilogue, stream);
 }
 
 /* q, k, v projections (plain store epilogue, optional bias) in one launch; returns -4 when the shapes do not qualify
@@ -786,9 +867,11 @@ int mi355_internal_linear3(void* const* outs, const void* x, const void* const* 
     }
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MI355_DTYPE_BF16)
-        return is_gptq ? dense3_launch_dt<MI355_DTYPE_BF16, DW_GPTQ4>(a, st) : dense3_launch_dt<MI355_DTYPE_BF16, DW_DENSE>(a, st);
+        return is_gptq == 2 ? dense3_launch_dt<MI355_DTYPE_BF16, DW_GPTQ4T>(a, st)
+               : is_gptq ? dense3_launch_dt<MI355_DTYPE_BF16, DW_GPTQ4>(a, st) : dense3_launch_dt<MI355_DTYPE_BF16, DW_DENSE>(a, st);
     if (dtype == MI355_DTYPE_F16)
-        return is_gptq ? dense3_launch_dt<MI355_DTYPE_F16, DW_GPTQ4>(a, st) : dense3_launch_dt<MI355_DTYPE_F16, DW_DENSE>(a, st);
+        return is_gptq == 2 ? dense3_launch_dt<MI355_DTYPE_F16, DW_GPTQ4T>(a, st)
+               : is_gptq ? dense3_launch_dt<MI355_DTYPE_F16, DW_GPTQ4>(a, st) : dense3_launch_dt<MI355_DTYPE_F16, DW_DENSE>(a, st);
     return -4;
 }
 

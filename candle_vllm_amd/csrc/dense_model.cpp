@@ -29,8 +29,9 @@ namespace {
 #define DCHECK(expr) do { const int rc_ = (expr); if (rc_ != 0) return rc_; } while (0)
 #define DHIP(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
 
-// GPTQ (4-bit, symmetric, group scales) variant of a projection: qweight [K/8, N] u32 + scales [K/g, N] 16-bit, both in
-// checkpoint layout (linear.rs:226-252); gate and up are concatenated along N for the fused silu*up epilogue.
+// GPTQ (4-bit, symmetric, group scales) variant of a projection: qweight (checkpoint [K/8, N] u32, linear.rs:226-252) re-ordered at
+// load time into 16-column x 256-k tiles (mi355_gptq_tile_repack) + scales [K/g, N] 16-bit in checkpoint layout; gate and up
+// are concatenated along N for the fused silu*up epilogue.
 struct QLin { uint32_t* qw = nullptr; uint16_t* scales = nullptr; int group = 0; };
 
 struct DLayer {
@@ -125,7 +126,7 @@ int norm(const DModel* m, uint16_t* out, const uint16_t* x, const uint16_t* w, c
 int linear(const DModel* m, const uint16_t* w, const QLin& g, void* out, const void* x, const void* bias, const void* resid,
            int T, int n, int k, int epi, int64_t stream) {
     if (g.qw)
-        return mi355_gptq_linear(out, x, g.qw, g.scales, nullptr, MI355_ZERO_SYM8, 0, bias, resid, T, n, k, g.group, m->cfg.dtype, epi, stream);
+        return mi355_gptq_linear_tiled(out, x, g.qw, g.scales, nullptr, MI355_ZERO_SYM8, 0, bias, resid, T, n, k, g.group, m->cfg.dtype, epi, stream);
     if (!w) return (int)hipErrorInvalidValue;
     return mi355_linear(out, x, w, bias, resid, T, n, k, m->cfg.dtype, epi, stream);
 }
@@ -253,7 +254,15 @@ int mi355_dense_set_gptq(void* mp, int32_t layer, int32_t which, const void* qwe
     q.group = g;
     if (!q.qw) DHIP(hipMalloc((void**)&q.qw, (size_t)(k / 8) * ntot * 4));
     if (!q.scales) DHIP(hipMalloc((void**)&q.scales, (size_t)(k / g) * ntot * 2));
-    DHIP(hipMemcpy2D(q.qw + col0, (size_t)ntot * 4, qweight_host, (size_t)n * 4, (size_t)n * 4, k / 8, hipMemcpyHostToDevice));
+    {   // checkpoint layout -> staging buffer -> tiles [col0 / 16, (col0 + n) / 16) of the tiled image
+        uint32_t* stage = nullptr;
+        DHIP(hipMalloc((void**)&stage, (size_t)(k / 8) * n * 4));
+        int rc = (int)hipMemcpy(stage, qweight_host, (size_t)(k / 8) * n * 4, hipMemcpyHostToDevice);
+        if (!rc) rc = mi355_gptq_tile_repack(stage, q.qw, k, n, col0 / 16, 0);
+        if (!rc) rc = (int)hipDeviceSynchronize();
+        (void)hipFree(stage);
+        if (rc) return rc;
+    }
     DHIP(hipMemcpy2D(q.scales + col0, (size_t)ntot * 2, scales_host, (size_t)n * 2, (size_t)n * 2, k / g, hipMemcpyHostToDevice));
     return 0;
 }
@@ -351,7 +360,7 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
                 const void* sc[3] = {gq.scales, gk.scales, gv.scales};
                 const void* bs[3] = {L.bq, L.bk, L.bv};
                 const int32_t ns[3] = {H * D, Hkv * D, Hkv * D};
-                rc3 = mi355_internal_linear3(outs, m->xn, ws, sc, bs, ns, T, hid, gq.group, all_q ? 1 : 0, m->cfg.dtype, stream);
+                rc3 = mi355_internal_linear3(outs, m->xn, ws, sc, bs, ns, T, hid, gq.group, all_q ? 2 : 0, m->cfg.dtype, stream);
                 if (rc3 != 0 && rc3 != -4) return rc3;
             }
         }

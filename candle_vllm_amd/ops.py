@@ -542,14 +542,30 @@ def marlin_format_repack(B):
     return out
 
 
-class GPTQLinear:
-    """QLinear GPTQ arm (linear.rs:854-906) with the decode epilogues fused; qweight in checkpoint layout
-    [k/8, n] (= our marlin-slot layout), scales natural or Marlin-permuted."""
+def gptq_tile_unpack(qw_tiled, k, n):
+    """the tiled weight image (marlin_weight_repack / marlin_format_repack output) back in checkpoint layout [k/8, n]"""
+    out = torch.empty((k // 8, n), dtype=qw_tiled.dtype, device=qw_tiled.device)
+    _check(lib.mi355_gptq_tile_unpack(_dev(qw_tiled), _dev(out), k, n, _stream()), "gptq_tile_unpack")
+    return out
 
-    def __init__(self, qweight, scales, group_size, qzeros=None, zero_mode=ZERO_SYM8, scales_permuted=False, bias=None):
-        self.qweight, self.scales, self.qzeros, self.bias = qweight, scales, qzeros, bias
+
+class GPTQLinear:
+    """QLinear GPTQ arm (linear.rs:854-906) with the decode epilogues fused; qweight in checkpoint layout [k/8, n], re-ordered
+    into the tiled image at construction when the shape allows (`tiled=None`: k % 256 == 0 and n % 16 == 0); scales natural or
+    Marlin-permuted."""
+
+    def __init__(self, qweight, scales, group_size, qzeros=None, zero_mode=ZERO_SYM8, scales_permuted=False, bias=None, tiled=None):
+        self.scales, self.qzeros, self.bias = scales, qzeros, bias
         self.group_size, self.zero_mode, self.scales_permuted = group_size, zero_mode, scales_permuted
         self.k, self.n = qweight.numel() * 8 // scales.shape[-1], scales.shape[-1]
+        if tiled is None:
+            tiled = self.k % 256 == 0 and self.n % 16 == 0
+        self.tiled = bool(tiled)
+        if self.tiled:
+            t = torch.empty_like(qweight)
+            _check(lib.mi355_gptq_tile_repack(_dev(qweight), _dev(t), self.k, self.n, 0, _stream()), "gptq_tile_repack")
+            qweight = t
+        self.qweight = qweight
 
     def forward(self, x, *, epilogue=EPI_STORE, residual=None, out=None):
         dt = _dt16(x)
@@ -558,12 +574,11 @@ class GPTQLinear:
         n_out = self.n // 2 if epilogue == EPI_SILU_MUL else self.n
         if out is None:
             out = torch.empty((T, n_out), dtype=x.dtype, device=x.device)
-        _check(lib.mi355_gptq_linear(_dev(out), _dev(x2), _dev(self.qweight), _dev(self.scales),
-                                     _dev(self.qzeros) if self.qzeros is not None else None, self.zero_mode,
-                                     1 if self.scales_permuted else 0,
-                                     _dev(self.bias) if self.bias is not None else None,
-                                     _dev(residual) if residual is not None else None, T, self.n, self.k,
-                                     self.group_size, dt, epilogue, _stream()), "gptq_linear")
+        fn = lib.mi355_gptq_linear_tiled if self.tiled else lib.mi355_gptq_linear
+        _check(fn(_dev(out), _dev(x2), _dev(self.qweight), _dev(self.scales),
+                  _dev(self.qzeros) if self.qzeros is not None else None, self.zero_mode, 1 if self.scales_permuted else 0,
+                  _dev(self.bias) if self.bias is not None else None, _dev(residual) if residual is not None else None,
+                  T, self.n, self.k, self.group_size, dt, epilogue, _stream()), "gptq_linear")
         return out
 
 

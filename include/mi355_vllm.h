@@ -331,6 +331,20 @@ int mi355_gptq_linear(void* out, const void* x, const void* qweight, const void*
                       int32_t zero_mode, int32_t scales_permuted, const void* bias, const void* residual,
                       int32_t num_tokens, int32_t n, int32_t k, int32_t group_size, int32_t dtype, int32_t epilogue,
                       int64_t stream);
+/* The same op over the TILED weight image: qweight re-ordered once at load time into 16-column x 256-k tiles, word (kr = k/8, n)
+ * at  ((((n/16) * (k/256) + kr/32) * 2 + (kr%32)/16) * 64 + 16 * (kr%4) + n%16) * 4 + ((kr%32)/4) % 4  -- one wave's share of a
+ * k-block is two contiguous 1 KiB runs.  This is the image gptq_repack / awq_repack / mi355_marlin_format_repack write and the
+ * marlin_* entry points read (the slot the reference fills with gptq_marlin_repack's output, linear.rs:845-853).
+ * mi355_gptq_tile_repack: columns [0, n_in) of a checkpoint-layout tensor [k/8][n_in] -> tiles tile0 .. of `out` (k % 256 == 0,
+ * n_in % 16 == 0, in != out); mi355_gptq_tile_unpack: the inverse over a whole [k/8][n] tensor. */
+int mi355_gptq_linear_tiled(void* out, const void* x, const void* qweight_tiled, const void* scales, const void* qzeros,
+                            int32_t zero_mode, int32_t scales_permuted, const void* bias, const void* residual,
+                            int32_t num_tokens, int32_t n, int32_t k, int32_t group_size, int32_t dtype, int32_t epilogue,
+                            int64_t stream);
+int mi355_gptq_tile_repack(const void* in, void* out, int32_t k, int32_t n_in, int32_t tile0, int64_t stream);
+int mi355_gptq_tile_unpack(const void* in, void* out, int32_t k, int32_t n, int64_t stream);
+/* host helper: word index of qweight[kr][n] inside the tiled image of a [k/8][n_total] tensor (-1 when the shape is not tiled) */
+int64_t mi355_gptq_tile_index(int32_t kr, int32_t n, int32_t k, int32_t n_total);
 
 /* RoPE cos/sin table builders (HOST): DefaultRotaryEmbedding::new / ScalingRotaryEmbedding::new
  * (layers/rotary_emb.rs:14-48,107-341,358-457) in the reference's f32 arithmetic.  Tables are f32

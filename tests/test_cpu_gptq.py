@@ -109,3 +109,21 @@ def test_dequant_and_linear_definitions():
     assert (G.round_dt(y, "bf16") == y).all()
     ref = (x.astype(np.float64) @ wd.astype(np.float64).T) + b
     assert np.abs(y - ref).max() <= 2 ** -7 * np.abs(ref).max()
+
+
+def test_gptq_tile_order_host_statement(lib):
+    """the 16-column x 256-k tile order of the marlin-slot weight image: the library's index function == the numpy statement
+    (oracle/gptq.py gptq_tile), a permutation of the words; shapes the marlin arm refuses are not tiled"""
+    rng = np.random.default_rng(9)
+    K, N = 512, 48
+    qw = rng.integers(0, 2 ** 32, (K // 8, N), dtype=np.uint32)
+    tiled = G.gptq_tile(qw)
+    idx = np.array([[lib.mi355_gptq_tile_index(kr, n, K, N) for n in range(N)] for kr in range(K // 8)])
+    assert sorted(idx.reshape(-1).tolist()) == list(range(qw.size))
+    assert (tiled[idx] == qw).all()
+    # one wave's share of a k-block: lane l of half h holds 4 consecutive words = rows 32 kb + 4 (4h + jj) + l / 16, column 16 tile + l % 16
+    assert lib.mi355_gptq_tile_index(0, 0, K, N) == 0 and lib.mi355_gptq_tile_index(4, 0, K, N) == 1
+    assert lib.mi355_gptq_tile_index(1, 0, K, N) == 16 * 4 and lib.mi355_gptq_tile_index(16, 0, K, N) == 256
+    assert lib.mi355_gptq_tile_index(32, 0, K, N) == 512 and lib.mi355_gptq_tile_index(0, 16, K, N) == 512 * (K // 256)
+    assert lib.mi355_gptq_tile_index(0, 0, 128, N) == -1 and lib.mi355_gptq_tile_index(0, 0, K, 40) == -1
+    assert lib.mi355_gptq_tile_index(K // 8, 0, K, N) == -1 and lib.mi355_gptq_tile_index(0, N, K, N) == -1

@@ -89,12 +89,28 @@ def test_repack_bit_exact(cv):
     K, N = 512, 128
     q = rng.integers(0, 16, (K, N))
     gq = G.gptq_pack(q)
+    tiled = G.gptq_tile(gq)                                       # numpy statement of the library's 16 x 256 tile order
     out = cv.marlin_weight_repack(dev_u32(gq), 4, False)
     assert tuple(out.shape) == (K // 16, 2 * N)                   # gptq.rs:291-297
-    assert (out.cpu().numpy().view(np.uint32).reshape(K // 8, N) == gq).all()
+    assert (out.cpu().numpy().view(np.uint32).reshape(-1) == tiled).all()
+    assert (cv.gptq_tile_unpack(out, K, N).cpu().numpy().view(np.uint32) == gq).all()      # and back: a permutation of words
     out2 = cv.marlin_weight_repack(dev_u32(G.awq_pack(q)), 4, True)
     assert tuple(out2.shape) == (K // 16, 2 * N)                  # gptq.rs:285-290
-    assert (out2.cpu().numpy().view(np.uint32).reshape(K // 8, N) == gq).all()
+    assert (out2.cpu().numpy().view(np.uint32).reshape(-1) == tiled).all()
+    # a shape the marlin arm does not take (k % 256 != 0) keeps the checkpoint layout
+    q3 = rng.integers(0, 16, (128, 32))
+    out3 = cv.marlin_weight_repack(dev_u32(G.gptq_pack(q3)), 4, False)
+    assert (out3.cpu().numpy().view(np.uint32).reshape(16, 32) == G.gptq_pack(q3)).all()
+    # columns [0, n) into tiles tile0 .. of a wider image (how the host layer packs gate_proj | up_proj)
+    from candle_vllm_amd import lib
+    wide = torch.zeros((K // 8) * 2 * N, dtype=torch.int32, device="cuda")
+    q4 = rng.integers(0, 16, (K, N))
+    parts = [dev_u32(gq), dev_u32(G.gptq_pack(q4))]
+    for part, t0 in zip(parts, (0, N // 16)):
+        assert lib.mi355_gptq_tile_repack(part.data_ptr(), wide.data_ptr(), K, N, t0, 0) == 0
+    torch.cuda.synchronize()
+    both = np.concatenate([gq, G.gptq_pack(q4)], axis=1)
+    assert (wide.cpu().numpy().view(np.uint32) == G.gptq_tile(both)).all()
 
 
 # ------------------------------------------------------------------------------------------------ K12 / K13 marlin
@@ -207,7 +223,10 @@ def test_marlin_format_checkpoint(cv, dt, T, N, K, gs):
     B = G.marlin_format_pack(q)
     assert B.shape == (K // 16, 2 * N)                            # linear.rs:226-231 (marlin_format dims)
     qw = cv.marlin_format_repack(dev_u32(B))
-    assert (qw.cpu().numpy().view(np.uint32).reshape(K // 8, N) == G.gptq_pack(q)).all()
+    if K % 256 == 0:
+        assert (qw.cpu().numpy().view(np.uint32).reshape(-1) == G.gptq_tile(G.gptq_pack(q))).all()
+    else:
+        assert (qw.cpu().numpy().view(np.uint32).reshape(K // 8, N) == G.gptq_pack(q)).all()
     x = G.round_dt(rng.normal(0, 1, (T, K)), dt)
     sp = G.marlin_permute_scales(s, K, N, gs)
     ws = torch.zeros(N, dtype=torch.int32, device="cuda")
