@@ -7,6 +7,7 @@ driver's multi-GPU run), each with algorithmic bytes, achieved GB/s, roofline fr
 Synthetic weights of the named architectures (no network for checkpoints).  A "step" = one greedy decode step of the whole
 model over the batch; inputs advance on the device (torch ops inside the captured graph for the 16-bit host layer, the
 library's own advance kernel for the GGUF one); every step reads its sampled tokens back, as the engine does."""
+import os
 import time
 from types import SimpleNamespace
 
@@ -267,5 +268,11 @@ def run_legs(names, parity=True):
 if __name__ == "__main__":
     import json
     import sys
-    names = sys.argv[1:] or list(LEGS)
-    print(json.dumps(run_legs(names)), flush=True)
+    args = sys.argv[1:]
+    for kv in os.environ.get("MI355_TUNING", "").split(","):          # experiments: MI355_TUNING=key:value,key:value
+        if ":" in kv:
+            from candle_vllm_amd import lib as _lib
+            _lib.mi355_set_tuning(int(kv.split(":")[0]), int(kv.split(":")[1]))
+    parity = "--no-parity" not in args
+    names = [a for a in args if not a.startswith("--")] or list(LEGS)
+    print(json.dumps(run_legs(names, parity=parity)), flush=True)

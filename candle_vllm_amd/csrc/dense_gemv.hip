@@ -50,6 +50,11 @@ struct DenseArgs {
     const void* resid;        // 16-bit [T][ldo] (EPI_RESID)
     int32_t epi;              // MI355_EPI_STORE / RESID / SILU_MUL
     int32_t pair_offset;      // SILU_MUL: rows of `up` start at pair_offset (packed gate_up weight, mlp.rs:324-352)
+    const void* norm_w;       // dense_small_kernel only: RmsNorm weight [K] (bf16) applied to x while it is staged, or null
+    float norm_eps;
+    const float* ss_in;       // with norm_w: [T][K/16] partial sums of squares of x's rows, left by the launch that produced x
+    int32_t dbg;              // experiments (tuning key 33)
+    float* ss_out;            // dense_small_kernel only: where this launch leaves [T][ldo/16] partial sums of squares of its output
 };
 
 template <int DT> __device__ __forceinline__ float h2f(uint16_t h) {
@@ -93,6 +98,24 @@ __device__ __forceinline__ float zero_point(const DenseArgs& a, int g, int col) 
     const int t = ((u & 1) << 2) | (u >> 1);            // argsort([0,2,4,6,1,3,5,7]) = [0,4,1,5,2,6,3,7]
     const int p2 = (p1 & ~7) + t;
     return (float)((a.qzeros[(size_t)g * (a.N / 8) + p2 / 8] >> (4 * (p2 & 7))) & 0xF);
+}
+
+// the rounding chain of one output element: y (and the `up` value u of a gate/up pair) -> the model dtype
+template <int DT>
+__device__ __forceinline__ float dense_epilogue(const DenseArgs& a, const int m, const int row, const float y, const float up) {
+    const uint16_t* b16 = static_cast<const uint16_t*>(a.bias);
+    // candle rounds the matmul result to the model dtype, then the bias add rounds again (linear.rs:124-172)
+    float o = rnd<DT>(y);
+    if (b16) o = rnd<DT>(o + h2f<DT>(b16[row]));
+    if (a.epi == MI355_EPI_SILU_MUL) {
+        float u = rnd<DT>(up);
+        if (b16) u = rnd<DT>(u + h2f<DT>(b16[a.pair_offset + row]));
+        o = rnd<DT>(rnd<DT>(o / (1.f + __expf(-o))) * u);               // silu(gate) * up (mlp.rs:457)
+    } else if (a.epi == MI355_EPI_RESID) {
+        o = rnd<DT>(o + h2f<DT>(static_cast<const uint16_t*>(a.resid)[(size_t)m * a.ldo + row]));
+    }
+    static_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + row] = f2h<DT>(o);
+    return o;
 }
 
 // One workgroup = R row tiles (R = 2 for the packed gate/up pair) x all of K; the waves split the 256-wide
@@ -239,19 +262,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs& a, const int bx) {
             for (int w = 0; w < NW; ++w) s += dg_red[((((size_t)w * R + r) * MT + (m >> 4)) * 16 + (m & 15)) * 16 + rr];
             val[r] = s;
         }
-        const int row = row0[0] + rr;
-        const uint16_t* b16 = static_cast<const uint16_t*>(a.bias);
-        // candle rounds the matmul result to the model dtype, then the bias add rounds again (linear.rs:124-172)
-        float o = rnd<DT>(val[0]);
-        if (b16) o = rnd<DT>(o + h2f<DT>(b16[row]));
-        if (a.epi == MI355_EPI_SILU_MUL) {
-            float u = rnd<DT>(val[R - 1]);
-            if (b16) u = rnd<DT>(u + h2f<DT>(b16[a.pair_offset + row]));
-            o = rnd<DT>(rnd<DT>(o / (1.f + __expf(-o))) * u);               // silu(gate) * up (mlp.rs:457)
-        } else if (a.epi == MI355_EPI_RESID) {
-            o = rnd<DT>(o + h2f<DT>(static_cast<const uint16_t*>(a.resid)[(size_t)m * a.ldo + row]));
-        }
-        static_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + row] = f2h<DT>(o);
+        dense_epilogue<DT>(a, m, row0[0] + rr, val[0], val[R - 1]);
     }
 }
 template <int DT, int WTYPE, int MT, int R, int GJ>
@@ -265,6 +276,255 @@ __global__ void __launch_bounds__(512) dense3_kernel(const DenseArgs a0, const D
     if (bx < t0) dense_body<DT, WTYPE, MT, 1, GJ>(a0, bx);
     else if (bx < t0 + t1) dense_body<DT, WTYPE, MT, 1, GJ>(a1, bx - t0);
     else dense_body<DT, WTYPE, MT, 1, GJ>(a2, bx - t0 - t1);
+}
+
+// ------------------------------------------------------------------------------------------------ 1..4 tokens x 4-bit weights
+// The decode step of a GPTQ / AWQ model at batch 1..4 is a chain of small weight streams (Qwen2-7B: 6 / 8 / 34 / 68 MB), each
+// against the launch floor (~4.5 us): what a launch reaches is (bytes in flight) / (memory latency), and what the step reaches is
+// mostly the NUMBER of launches.  dense_body asks for one k-block per wave at a time and its activation and scale loads queue
+// BEHIND the weight loads (VMEM returns in order).  Here:
+//   * every wave stages the activations of ITS k-blocks once, into its own LDS region -- already in the (x0,x4,x1,x5,..) order
+//     of the 4-bit code pairs -- one round trip together with the first weight loads, no workgroup barrier;
+//   * when `norm_w` is set the staging applies RmsNorm: inv = rsqrt(sum(x^2)/K + eps) comes from `ss_in`, per-tile partial sums of
+//     squares that the PRODUCER of the residual stream left behind in its epilogue (`ss_out`; fixed summation order on both
+//     sides) -- the two norm launches of a layer disappear without a second pass over x (measured first: every workgroup
+//     redoing the two-pass norm behind a barrier cost as much as the launches it saved);
+//   * every wave keeps D k-blocks of weights + the dwords holding their scales / zero points in flight (a register ring of D
+//     slots; the only VMEM instructions in the loop are the ring's loads, so the counted vmcnt waits leave D-1 slots outstanding).
+// Same arithmetic as dense_body's 4-bit arm (128+q / 1024+q codes, scale applied once per group, ones-MFMA row sums).
+// sum over the 64 lanes, the same value in every lane, without the LDS crossbar: four DPP row shifts leave each row's sum in its
+// lane 15, four v_readlane pick them up (__shfl_xor is ds_bpermute: six dependent LDS round trips per sum -- measured 6 us on the
+// 28 us gate/up launch when every wave reduced four tokens' partial sums that way)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    int x = __float_as_int(v);
+    x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true)));   // row_shr:1
+    x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true)));   // row_shr:2
+    x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true)));   // row_shr:4
+    x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true)));   // row_shr:8
+    return (__int_as_float(__builtin_amdgcn_readlane(x, 15)) + __int_as_float(__builtin_amdgcn_readlane(x, 31))) +
+           (__int_as_float(__builtin_amdgcn_readlane(x, 47)) + __int_as_float(__builtin_amdgcn_readlane(x, 63)));
+}
+constexpr int DS_X_BYTES_MAX = 40 * 1024;          // staged activations: T * K * 2 bytes (T = 1: K <= 20480)
+template <int DT, int WTYPE, int R, int GJ, int D, bool ZP, int NCH>
+__device__ __forceinline__ void dense_small_body(const DenseArgs& a, const int bx) {
+    static_assert(WTYPE != DW_DENSE, "4-bit weights only");
+    constexpr int NG = 8 / GJ;                     // quantisation groups per k-block (GJ == 8: one group of >= 256)
+    extern __shared__ __attribute__((aligned(16))) uint8_t ds_lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int nkb = a.K >> 8, T = a.T, K = a.K;
+    const int nmine = (nkb - wave + NW - 1) / NW;                  // NW <= nkb: every wave has at least one k-block
+    const int nmax = (nkb + NW - 1) / NW;
+    uint16_t* xw = reinterpret_cast<uint16_t*>(ds_lds) + (size_t)wave * nmax * T * 256;    // this wave's [nmine][T][256], pair order
+    float* red = reinterpret_cast<float*>(ds_lds + (size_t)NW * nmax * T * 512);           // [NW][R][4][16]
+    int row0[R];
+    row0[0] = bx * 16;
+    if (R == 2) row0[R - 1] = a.pair_offset + bx * 16;
+
+    // ---- activation (and norm) loads first, then the ring's first D slots
+    const uint16_t* x16 = static_cast<const uint16_t*>(a.x);
+    const uint16_t* nw16 = static_cast<const uint16_t*>(a.norm_w);
+    // entry f = i * T + t: 256 values = 32 lanes x 16 B, two entries per pass, NCH * 4 passes (the launch checks F <= NCH * 8).
+    // Everything below is straight-line code: a run-time loop around loads in front of the ring makes the compiler's wait-count
+    // pass give up on counted waits in the main loop (it drains the whole ring at the loop header).
+    const int F = nmine * T, half = lane >> 5, piece = lane & 31;
+    constexpr int SC = NCH * 4;
+    float inv[4] = {1.f, 1.f, 1.f, 1.f};
+    // (the wave-uniform `if`s keep clamped duplicate loads off the L2 -> CU path: unpredicated, a wave of the gate/up launch pulled
+    // 16 KB of partial sums, activations and norm weights for its 8 KB of weights)
+    f32x4_t ssp[4][2];
+    const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
+    if (nw16) {
+        const int ntp = K >> 4;                                          // the producer's tiles (<= 512: K <= 8192 when normed), 4 per lane and load
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                ssp[t][c] = z4;
+                if (t < T && 256 * c < ntp && !(a.dbg & 1))
+                    ssp[t][c] = *reinterpret_cast<const f32x4_t*>(a.ss_in + (size_t)t * ntp + min(4 * lane + 256 * c, ntp - 4));   // masked at use
+            }
+    }
+    uint4 xv[SC], gv[SC];
+#pragma unroll
+    for (int c = 0; c < SC; ++c) {
+        xv[c] = make_uint4(0, 0, 0, 0); gv[c] = xv[c];
+        if (2 * c < F) {
+            const int f = min(2 * c + half, F - 1), i = f / T, t = f - i * T;
+            const size_t k0 = (size_t)(wave + i * NW) * 256 + 8 * piece;
+            xv[c] = *reinterpret_cast<const uint4*>(x16 + (size_t)t * a.ldx + k0);
+            if (nw16 && !(a.dbg & 2)) gv[c] = *reinterpret_cast<const uint4*>(nw16 + k0);
+        }
+    }
+
+    // sc: the aligned DWORD that holds the 16-bit scale (extracted at use): 16-bit loads get packed two to a VGPR by the compiler
+    // right after they are issued -- a wait on the NEWEST loads of the ring, i.e. on all of it
+    struct Slot { uint32_t q[R][8]; uint32_t sc[R][NG]; uint32_t zw[R][NG]; };
+    int spos[R], zidx[R], zsh[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int col = row0[r] + r16;
+        spos[r] = marlin_scale_pos(col, a.sperm);
+        int zp = col;
+        if (a.zmode == MI355_ZERO_AWQ_MARLIN) {        // marlin zero points (convert_awq_marlin.py:72-91), as zero_point()
+            const int p1 = marlin_scale_pos(col, SP_GROUPED), u = p1 & 7;
+            zp = (p1 & ~7) + (((u & 1) << 2) | (u >> 1));
+        }
+        zidx[r] = zp >> 3; zsh[r] = 4 * (zp & 7);
+    }
+    const float zadd = a.zmode == MI355_ZERO_GPTQ_PLUS1 ? 1.f : 0.f;
+    const uint16_t* sc16 = static_cast<const uint16_t*>(a.scales);
+    auto issue = [&](Slot& sl, int kb) {
+        kb = min(kb, nkb - 1);                                    // past the end: a harmless re-load of the last block (L2 hit)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if constexpr (WTYPE == DW_GPTQ4T) {
+                const dg_u32x4* tp = reinterpret_cast<const dg_u32x4*>(a.w) + ((size_t)(row0[r] >> 4) * nkb + kb) * 128 + lane;
+                const dg_u32x4 v0 = __builtin_nontemporal_load(tp), v1 = __builtin_nontemporal_load(tp + 64);
+                sl.q[r][0] = v0.x; sl.q[r][1] = v0.y; sl.q[r][2] = v0.z; sl.q[r][3] = v0.w;
+                sl.q[r][4] = v1.x; sl.q[r][5] = v1.y; sl.q[r][6] = v1.z; sl.q[r][7] = v1.w;
+            } else {
+                const uint32_t* qp = static_cast<const uint32_t*>(a.w) + (size_t)(kb * 32 + kg) * a.N + row0[r] + r16;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sl.q[r][j] = __builtin_nontemporal_load(qp + (size_t)(4 * j) * a.N);
+            }
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) {
+                const int g = GJ < 8 ? kb * NG + gq : (kb * 256) / a.group_size;
+                sl.sc[r][gq] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sc16 + (size_t)g * a.N + (spos[r] & ~1)));
+                if constexpr (ZP) sl.zw[r][gq] = a.qzeros[(size_t)g * (a.N / 8) + zidx[r]];
+            }
+        }
+    };
+    Slot ring[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(ring[d], wave + d * NW);
+
+    // ---- activations -> this wave's LDS region (rms_norm_bf16_kernel's arithmetic, elementwise.hip, when normed)
+    if (nw16) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t >= T) break;
+            const int ntp = K >> 4;
+            const f32x4_t p0 = 4 * lane < ntp ? ssp[t][0] : z4, p1 = 4 * lane + 256 < ntp ? ssp[t][1] : z4;
+            float v = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]));
+            inv[t] = rsqrtf(wave_sum_dpp(v) / (float)K + a.norm_eps);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < SC; ++c) {
+        const int f = 2 * c + half;
+        if (f < F) {
+            uint4 v = xv[c];
+            if (nw16) {
+                const int t = f % T;
+                const float iv = t == 0 ? inv[0] : t == 1 ? inv[1] : t == 2 ? inv[2] : inv[3];
+                const uint32_t u[4] = {v.x, v.y, v.z, v.w}, gw[4] = {gv[c].x, gv[c].y, gv[c].z, gv[c].w};
+                uint32_t o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[e] = pack_bf16x2(bf16lo_to_f32(u[e]) * iv * bf16lo_to_f32(gw[e]), bf16hi_to_f32(u[e]) * iv * bf16hi_to_f32(gw[e]));
+                v = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+            uint4 pq;                                                        // code pairs (n_i, n_{i+4}): element order {0,4,1,5,2,6,3,7}
+            pq.x = __builtin_amdgcn_perm(v.z, v.x, 0x05040100u);
+            pq.y = __builtin_amdgcn_perm(v.z, v.x, 0x07060302u);
+            pq.z = __builtin_amdgcn_perm(v.w, v.y, 0x05040100u);
+            pq.w = __builtin_amdgcn_perm(v.w, v.y, 0x07060302u);
+            *reinterpret_cast<uint4*>(xw + (size_t)f * 256 + 8 * piece) = pq;
+        }
+    }
+
+    constexpr uint32_t KOFF = (DT == MI355_DTYPE_BF16) ? 0x43004300u : 0x64006400u;
+    constexpr float OFF = (DT == MI355_DTYPE_BF16) ? 128.f : 1024.f;
+    constexpr uint32_t ONE2 = (DT == MI355_DTYPE_BF16) ? 0x3F803F80u : 0x3C003C00u;
+    uint32_t nib = 0x000F000Fu;
+    asm volatile("" : "+v"(nib));
+    const uint4 ones = make_uint4(ONE2, ONE2, ONE2, ONE2);
+    const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t y[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) y[r] = zero4;
+    const uint16_t* xrow = xw + (size_t)min(r16, T - 1) * 256 + 8 * kg;
+
+    auto compute = [&](const Slot& sl, const int i) {
+        uint4 aw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) aw[j] = *reinterpret_cast<const uint4*>(xrow + (size_t)i * T * 256 + 32 * j);
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            f32x4_t xs = zero4;
+            if (!(a.dbg & 8)) {
+#pragma unroll
+            for (int jj = 0; jj < GJ; ++jj) xs = mfma32<DT>(aw[gq * GJ + jj], ones, xs);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float s = h2f<DT>((uint16_t)(sl.sc[r][gq] >> (16 * (spos[r] & 1))));
+                float z = 8.f;
+                if constexpr (ZP) z = (float)((sl.zw[r][gq] >> zsh[r]) & 0xFu) + zadd;
+                const float c = -(OFF + z) * s;
+                f32x4_t acc = zero4;
+#pragma unroll
+                for (int jj = 0; jj < GJ; ++jj) {
+                    const uint32_t w = sl.q[r][gq * GJ + jj];
+                    uint4 b;
+                    b.x = (w & nib) | KOFF;
+                    b.y = ((w >> 4) & nib) | KOFF;
+                    b.z = ((w >> 8) & nib) | KOFF;
+                    b.w = ((w >> 12) & nib) | KOFF;
+                    acc = mfma32<DT>(aw[gq * GJ + jj], b, acc);
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) y[r][v] += s * acc[v] + c * xs[v];
+            }
+        }
+    };
+    for (int i0 = 0; i0 < nmine; i0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int i = i0 + d;
+            if (i < nmine) compute(ring[d], i);
+            issue(ring[d], wave + (i + D) * NW);
+        }
+    }
+
+    // ---- cross-wave reduction: C layout lane (col = weight row r16, rows m = 4kg+v): tokens 0..3 sit in kg == 0
+    if (kg == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) red[((wave * R + r) * 4 + v) * 16 + r16] = y[r][v];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < T * 16) {
+        const int rr = threadIdx.x & 15, m = threadIdx.x >> 4;
+        float val[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float sum = 0.f;
+            for (int w = 0; w < NW; ++w) sum += red[((w * R + r) * 4 + m) * 16 + rr];
+            val[r] = sum;
+        }
+        const float o = dense_epilogue<DT>(a, m, row0[0] + rr, val[0], val[R - 1]);
+        if (a.ss_out) {                                                  // sum of squares of this tile's 16 outputs of token m (fixed order)
+            int q2 = __float_as_int(o * o);                            // row (16-lane) sum by DPP shifts: lane 15 of the row ends up with it
+            q2 = __float_as_int(__int_as_float(q2) + __int_as_float(__builtin_amdgcn_update_dpp(0, q2, 0x111, 0xf, 0xf, true)));
+            q2 = __float_as_int(__int_as_float(q2) + __int_as_float(__builtin_amdgcn_update_dpp(0, q2, 0x112, 0xf, 0xf, true)));
+            q2 = __float_as_int(__int_as_float(q2) + __int_as_float(__builtin_amdgcn_update_dpp(0, q2, 0x114, 0xf, 0xf, true)));
+            q2 = __float_as_int(__int_as_float(q2) + __int_as_float(__builtin_amdgcn_update_dpp(0, q2, 0x118, 0xf, 0xf, true)));
+            if (rr == 15) a.ss_out[(size_t)m * (a.ldo >> 4) + bx] = __int_as_float(q2);
+        }
+    }
+}
+template <int DT, int WTYPE, int R, int GJ, int D, bool ZP, int NCH>
+__global__ void __launch_bounds__(512) dense_small_kernel(const DenseArgs a) { dense_small_body<DT, WTYPE, R, GJ, D, ZP, NCH>(a, (int)blockIdx.x); }
+template <int DT, int WTYPE, int GJ, int D>
+__global__ void __launch_bounds__(512) dense_small3_kernel(const DenseArgs a0, const DenseArgs a1, const DenseArgs a2, const int t0, const int t1) {
+    const int bx = (int)blockIdx.x;
+    if (bx < t0) dense_small_body<DT, WTYPE, 1, GJ, D, false, 1>(a0, bx);
+    else if (bx < t0 + t1) dense_small_body<DT, WTYPE, 1, GJ, D, false, 1>(a1, bx - t0);
+    else dense_small_body<DT, WTYPE, 1, GJ, D, false, 1>(a2, bx - t0 - t1);
 }
 
 // ------------------------------------------------------------------------------------------------ launch
@@ -286,9 +546,94 @@ static int dense_launch_gj(const DenseArgs& a, int gj, int nw, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// ---- the 1..4-token launch of 4-bit weights (dense_small_kernel): -4 = this shape stays on dense_kernel
+static int g_tune_small_nw = 0;        // tuning key 30: waves per workgroup (0 = chosen from the k-blocks)
+static int g_tune_small_off = 0;       // tuning key 31: 1 = keep 1..4 tokens on dense_kernel (A/B measurements)
+static int g_tune_small_dbg = 0;
+static int g_tune_small_nonorm = 0;    // tuning key 32: 1 = never norm on the way in (the host layer launches the norm separately)
+void mi355_dense_set_small(int key, int v) { if (key == 30) g_tune_small_nw = v; else if (key == 31) g_tune_small_off = v; else if (key == 32) g_tune_small_nonorm = v; else if (key == 33) g_tune_small_dbg = v; }
+static inline int dense_small_gj(int group_size) {
+    if (group_size >= 256) return (group_size % 256) ? -1 : 8;
+    return group_size == 128 ? 4 : group_size == 64 ? 2 : group_size == 32 ? 1 : -1;
+}
+static inline int dense_small_nw(int nkb) {
+    if (g_tune_small_nw >= 1 && g_tune_small_nw <= 8 && g_tune_small_nw <= nkb) return g_tune_small_nw;
+    int best = 1, best_slots = 1 << 30;
+    for (int nw = nkb < 8 ? nkb : 8; nw >= 4 && nw >= 1; --nw) {                // fewest idle wave-slots, the larger workgroup on a tie
+        const int slots = (nkb + nw - 1) / nw * nw;
+        if (slots < best_slots) { best_slots = slots; best = nw; }
+    }
+    return nkb < 4 ? nkb : best;
+}
+// staging passes a wave needs: ceil(k-blocks per wave * T / 8); the kernel is built for 1 and 2
+static inline int dense_small_nch(const DenseArgs& a) {
+    const int nkb = a.K >> 8, nw = dense_small_nw(nkb);
+    return (((nkb + nw - 1) / nw) * a.T + 7) / 8;
+}
+static inline bool dense_small_ok(const DenseArgs& a, int dt) {
+    if (g_tune_small_off || a.T < 1 || a.T > 4 || (a.N & 15) || (a.K & 255) || (size_t)a.T * a.K * 2 > (size_t)DS_X_BYTES_MAX) return false;
+    if (a.norm_w && (dt != MI355_DTYPE_BF16 || g_tune_small_nonorm || !a.ss_in || a.K > 8192)) return false;
+    if (((uintptr_t)a.x & 15) || (a.ldx & 7)) return false;
+    return dense_small_gj(a.group_size) > 0 && dense_small_nch(a) <= 2;
+}
+template <int DT, int R, int D, bool ZP, int NCH>
+static int dense_small_launch_gj(const DenseArgs& a, int gj, hipStream_t st) {
+    const int tiles = (R == 2 ? a.pair_offset : a.N) / 16;
+    const int nw = dense_small_nw(a.K >> 8);
+    const size_t lds = (size_t)nw * (((a.K >> 8) + nw - 1) / nw) * a.T * 512 + (size_t)nw * R * 64 * sizeof(float);
+    dim3 grid(tiles), block(nw * 64);
+    const_cast<DenseArgs&>(a).dbg = g_tune_small_dbg;
+    switch (gj) {
+        case 1: hipLaunchKernelGGL((dense_small_kernel<DT, DW_GPTQ4T, R, 1, D, ZP, NCH>), grid, block, lds, st, a); break;
+        case 2: hipLaunchKernelGGL((dense_small_kernel<DT, DW_GPTQ4T, R, 2, D, ZP, NCH>), grid, block, lds, st, a); break;
+        case 4: hipLaunchKernelGGL((dense_small_kernel<DT, DW_GPTQ4T, R, 4, D, ZP, NCH>), grid, block, lds, st, a); break;
+        default: hipLaunchKernelGGL((dense_small_kernel<DT, DW_GPTQ4T, R, 8, D, ZP, NCH>), grid, block, lds, st, a); break;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+template <int DT, int R, int D, bool ZP>
+static int dense_small_launch_nch(const DenseArgs& a, int gj, hipStream_t st) {
+    return dense_small_nch(a) <= 1 ? dense_small_launch_gj<DT, R, D, ZP, 1>(a, gj, st) : dense_small_launch_gj<DT, R, D, ZP, 2>(a, gj, st);
+}
+// the tiled weight image only: the checkpoint layout (mi355_gptq_linear) stays on dense_kernel
+template <int DT, int WTYPE>
+static int dense_small_launch(const DenseArgs& a, hipStream_t st) {
+    if constexpr (WTYPE != DW_GPTQ4T) return -4;
+    else {
+        if (!dense_small_ok(a, DT)) return -4;
+        const int gj = dense_small_gj(a.group_size);
+        const bool zp = a.zmode != MI355_ZERO_SYM8 && a.qzeros;
+        if (a.epi == MI355_EPI_SILU_MUL)
+            return zp ? dense_small_launch_nch<DT, 2, 2, true>(a, gj, st) : dense_small_launch_nch<DT, 2, 2, false>(a, gj, st);
+        return zp ? dense_small_launch_nch<DT, 1, 4, true>(a, gj, st) : dense_small_launch_nch<DT, 1, 4, false>(a, gj, st);
+    }
+}
+template <int DT, int WTYPE>
+static int dense_small3_launch(const DenseArgs (&a)[3], hipStream_t st) {
+    if constexpr (WTYPE != DW_GPTQ4T) return -4;
+    else {
+        for (int i = 0; i < 3; ++i)
+            if (!dense_small_ok(a[i], DT) || a[i].zmode != MI355_ZERO_SYM8 || dense_small_nch(a[i]) != 1) return -4;
+        const int gj = dense_small_gj(a[0].group_size);
+        const int t0 = a[0].N / 16, t1 = a[1].N / 16, t2 = a[2].N / 16;
+        const int nw = dense_small_nw(a[0].K >> 8);
+        const size_t lds = (size_t)nw * (((a[0].K >> 8) + nw - 1) / nw) * a[0].T * 512 + (size_t)nw * 64 * sizeof(float);
+        dim3 grid(t0 + t1 + t2), block(nw * 64);
+#define DS3(GJ_) hipLaunchKernelGGL((dense_small3_kernel<DT, DW_GPTQ4T, GJ_, 4>), grid, block, lds, st, a[0], a[1], a[2], t0, t1)
+        switch (gj) { case 1: DS3(1); break; case 2: DS3(2); break; case 4: DS3(4); break; default: DS3(8); break; }
+#undef DS3
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+}
+
 template <int DT, int WTYPE>
 static int dense_launch_dt(const DenseArgs& a, hipStream_t st) {
     if (a.T < 1 || a.T > 64 || (a.N & 15) || (a.K & 255)) return -2;
+    {
+        const int rs = dense_small_launch<DT, WTYPE>(a, st);
+        if (rs != -4) return rs;
+        if (a.norm_w) return -4;                   // only the small kernel norms on the way in: the caller norms separately
+    }
     const bool pair = a.epi == MI355_EPI_SILU_MUL;
     const int mt = (a.T + 15) / 16;
     int gj = 8;
@@ -315,6 +660,11 @@ static int dense_launch_dt(const DenseArgs& a, hipStream_t st) {
 
 template <int DT, int WTYPE>
 static int dense3_launch_dt(const DenseArgs (&a)[3], hipStream_t st) {
+    {
+        const int rs = dense_small3_launch<DT, WTYPE>(a, st);
+        if (rs != -4) return rs;
+        if (a[0].norm_w) return -4;
+    }
     const int mt = (a[0].T + 15) / 16;
     int gj = 8;
     if (WTYPE != DW_DENSE) {
@@ -838,6 +1188,28 @@ int mi355_gptq_linear(void* out, const void* x, const void* qweight, const void*
     return gptq_linear_impl(DW_GPTQ4, out, x, qweight, scales, qzeros, zero_mode, scales_permuted, bias, residual, num_tokens, n, k,
                             group_size, dtype, epilogue, stream);
 }
+/* host layer only: the tiled sym-8 op on the 1..4-token kernel, with its two extras: RmsNorm(norm_w, eps) applied to x on the
+ * way in (inv from `ss_in`, the per-tile sums of squares the producer of x left behind) and `ss_out`, the same sums of this
+ * launch's own output rows for the next consumer.  -4 when the shape is not served by that kernel: the caller then norms
+ * separately, calls mi355_gptq_linear_tiled, and treats ss_out as not written. */
+int mi355_internal_gptq_small_linear(void* out, const void* x, const void* qweight_tiled, const void* scales, const void* bias,
+                                     const void* residual, const void* norm_w, float norm_eps, const float* ss_in, float* ss_out,
+                                     int32_t num_tokens, int32_t n, int32_t k, int32_t group_size, int32_t dtype, int32_t epilogue,
+                                     int64_t stream) {
+    if (num_tokens < 1 || num_tokens > 4 || (epilogue == MI355_EPI_RESID && !residual)) return -4;
+    DenseArgs a{};
+    a.w = qweight_tiled; a.scales = scales; a.zmode = MI355_ZERO_SYM8;
+    a.group_size = (group_size <= 0 || group_size > k) ? k : group_size;
+    a.sperm = SP_NONE;
+    a.x = x; a.ldx = k; a.T = num_tokens; a.K = k; a.N = n;
+    a.bias = bias; a.resid = residual; a.epi = epilogue; a.out = out;
+    a.norm_w = norm_w; a.norm_eps = norm_eps; a.ss_in = ss_in; a.ss_out = ss_out;
+    if (epilogue == MI355_EPI_SILU_MUL) { a.pair_offset = n / 2; a.ldo = n / 2; } else a.ldo = n;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MI355_DTYPE_BF16) return dense_small_launch<MI355_DTYPE_BF16, DW_GPTQ4T>(a, st);
+    if (dtype == MI355_DTYPE_F16) return dense_small_launch<MI355_DTYPE_F16, DW_GPTQ4T>(a, st);
+    return -4;
+}
 /* the same op over the TILED weight image (gptq_repack / mi355_gptq_tile_repack); scales and zero points as above */
 int mi355_gptq_linear_tiled(void* out, const void* x, const void* qweight_tiled, const void* scales, const void* qzeros,
                             int32_t zero_mode, int32_t scales_permuted, const void* bias, const void* residual,
@@ -848,10 +1220,12 @@ int mi355_gptq_linear_tiled(void* out, const void* x, const void* qweight_tiled,
 }
 
 /* q, k, v projections (plain store epilogue, optional bias) in one launch; returns -4 when the shapes do not qualify
- * (the caller then issues three mi355_linear / mi355_gptq_linear calls).  Internal to the host layer (dense_model.cpp). */
+ * (the caller then issues three mi355_linear / mi355_gptq_linear calls).  norm_w != NULL: x is the residual stream and the
+ * launch applies RmsNorm(norm_w, eps) on the way in, inv from the producer's sums of squares `ss_in` (1..4 tokens of 4-bit
+ * weights only; -4 otherwise and the caller norms separately).  Internal to the host layer (dense_model.cpp). */
 int mi355_internal_linear3(void* const* outs, const void* x, const void* const* ws, const void* const* scales,
                            const void* const* biases, const int32_t* ns, int32_t num_tokens, int32_t k, int32_t group_size,
-                           int32_t is_gptq, int32_t dtype, int64_t stream) {
+                           int32_t is_gptq, int32_t dtype, const void* norm_w, float norm_eps, const float* ss_in, int64_t stream) {
     if (num_tokens < 1 || num_tokens > 64 || (k & 255)) return -4;
     DenseArgs a[3];
     for (int i = 0; i < 3; ++i) {
@@ -859,6 +1233,7 @@ int mi355_internal_linear3(void* const* outs, const void* x, const void* const* 
         a[i] = DenseArgs{};
         a[i].w = ws[i]; a[i].ldw = k; a[i].x = x; a[i].ldx = k; a[i].T = num_tokens; a[i].K = k; a[i].N = ns[i];
         a[i].bias = biases ? biases[i] : nullptr; a[i].epi = MI355_EPI_STORE; a[i].out = outs[i]; a[i].ldo = ns[i];
+        a[i].norm_w = norm_w; a[i].norm_eps = norm_eps; a[i].ss_in = ss_in;
         if (is_gptq) {
             a[i].scales = scales[i]; a[i].qzeros = nullptr; a[i].zmode = MI355_ZERO_SYM8;
             a[i].group_size = (group_size <= 0 || group_size > k) ? k : group_size;

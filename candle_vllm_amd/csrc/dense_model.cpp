@@ -22,7 +22,12 @@ extern "C" int mi355_internal_rope_cache(void* q, void* k, const void* v, void* 
                                          int64_t stream);
 extern "C" int mi355_internal_linear3(void* const* outs, const void* x, const void* const* ws, const void* const* scales,
                                       const void* const* biases, const int32_t* ns, int32_t num_tokens, int32_t k,
-                                      int32_t group_size, int32_t is_gptq, int32_t dtype, int64_t stream);
+                                      int32_t group_size, int32_t is_gptq, int32_t dtype, const void* norm_w, float norm_eps,
+                                      const float* ss_in, int64_t stream);
+extern "C" int mi355_internal_gptq_small_linear(void* out, const void* x, const void* qweight_tiled, const void* scales, const void* bias,
+                                                const void* residual, const void* norm_w, float norm_eps, const float* ss_in, float* ss_out,
+                                                int32_t num_tokens, int32_t n, int32_t k, int32_t group_size, int32_t dtype,
+                                                int32_t epilogue, int64_t stream);
 
 namespace {
 
@@ -50,6 +55,8 @@ struct DModel {
     int cap = 0;
     uint16_t *xs = nullptr, *xn = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *attn = nullptr, *h = nullptr, *lg16 = nullptr;
     float *pa_tmp = nullptr, *pa_max = nullptr, *pa_sum = nullptr;
+    float* ss = nullptr;                  // [4][hidden / 16] sums of squares of the residual stream's rows, per 16-column tile: left by
+                                          // the 1..4-token 4-bit launch that wrote xs, read by the next one that norms it
     int pa_cap_partitions = 0;
     void* kv_slab = nullptr;
     std::vector<void*> kcache, vcache;
@@ -131,6 +138,19 @@ int linear(const DModel* m, const uint16_t* w, const QLin& g, void* out, const v
     return mi355_linear(out, x, w, bias, resid, T, n, k, m->cfg.dtype, epi, stream);
 }
 
+// xs += x . w^T (the residual epilogue of o_proj / down_proj).  With 4-bit weights and 1..4 tokens the launch also leaves the sums
+// of squares of the new xs rows in m->ss (*ss_valid), so the consumer's RmsNorm needs no launch of its own.
+int resid_linear(const DModel* m, const uint16_t* w, const QLin& g, const void* x, int T, int n, int k, bool* ss_valid, int64_t stream) {
+    *ss_valid = false;
+    if (g.qw && T <= 4 && m->cfg.norm_type == 0) {
+        const int rc = mi355_internal_gptq_small_linear(m->xs, x, g.qw, g.scales, nullptr, m->xs, nullptr, 0.f, nullptr, m->ss, T, n, k,
+                                                        g.group, m->cfg.dtype, MI355_EPI_RESID, stream);
+        if (rc == 0) { *ss_valid = true; return 0; }
+        if (rc != -4) return rc;
+    }
+    return linear(m, w, g, m->xs, x, nullptr, m->xs, T, n, k, MI355_EPI_RESID, stream);
+}
+
 int choose_partition(int batch, int kv_heads, int ctx_cap) {
     if (ctx_cap <= 256) return 0;
     int per_seq = (2048 + batch * kv_heads - 1) / (batch * kv_heads);
@@ -165,7 +185,8 @@ void* mi355_dense_create(const mi355_dense_config* cfg) {
     const size_t B = cfg->max_batch, H = cfg->n_heads;
     ok = ok && hipMalloc((void**)&m->pa_tmp, B * H * m->pa_cap_partitions * D * 4) == hipSuccess &&
          hipMalloc((void**)&m->pa_max, B * H * m->pa_cap_partitions * 4) == hipSuccess &&
-         hipMalloc((void**)&m->pa_sum, B * H * m->pa_cap_partitions * 4) == hipSuccess;
+         hipMalloc((void**)&m->pa_sum, B * H * m->pa_cap_partitions * 4) == hipSuccess &&
+         hipMalloc((void**)&m->ss, (size_t)4 * (cfg->hidden / 16) * 4) == hipSuccess;
     if (!ok) { mi355_dense_destroy(m); return nullptr; }
     return m;
 }
@@ -179,7 +200,7 @@ void mi355_dense_destroy(void* mp) {
         for (auto& g : L.gq) { if (g.qw) (void)hipFree(g.qw); if (g.scales) (void)hipFree(g.scales); }
     }
     void* ps[] = {m->tok_embd, m->output_norm, m->output_norm_b, m->output, m->cos_t, m->sin_t, m->xs, m->xn, m->q, m->k, m->v, m->attn,
-                  m->h, m->lg16, m->pa_tmp, m->pa_max, m->pa_sum, m->kv_slab, m->lg_gather};
+                  m->h, m->lg16, m->pa_tmp, m->pa_max, m->pa_sum, m->ss, m->kv_slab, m->lg_gather};
     for (void* p : ps) if (p) (void)hipFree(p);
     delete m;
 }
@@ -343,14 +364,16 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
     const bool window = m->win_first >= 0;
     if (window) DHIP(hipMemcpyAsync(m->xs, m->win_in, (size_t)T * hid * 2, hipMemcpyDeviceToDevice, st));
     else hipLaunchKernelGGL(embedding16_kernel, dim3(T), dim3(256), 0, st, m->xs, m->tok_embd, tokens, hid);
+    bool ss_valid = false;                    // m->ss holds the sums of squares of the current xs rows
     for (int l = window ? m->win_first : 0; l <= (window ? m->win_last : c.n_layers - 1); ++l) {
         DLayer& L = m->layers[l];
         if (!L.attn_norm || !L.ffn_norm) return (int)hipErrorInvalidValue;
-        // x = rms_1(xs)                                                     llama.rs:53-54
-        DCHECK(norm(m, m->xn, m->xs, L.attn_norm, L.attn_norm_b, T, stream));
-        // q,k,v projections (+bias)                                          attention.rs:597-607
+        // x = rms_1(xs) (llama.rs:53-54), then the q,k,v projections (+bias) (attention.rs:597-607)
+        // one launch for the three projections when they share the weight format (decode-sized steps); with 4-bit weights
+        // and 1..4 tokens that launch also applies the RmsNorm while it stages the activations (no norm launch)
         int rc3 = -4;
-        {   // one launch for the three projections when they share the weight format (decode-sized steps)
+        bool normed = false;
+        {
             const QLin &gq = L.gq[MI355_W_WQ], &gk = L.gq[MI355_W_WK], &gv = L.gq[MI355_W_WV];
             const bool all_q = gq.qw && gk.qw && gv.qw && gq.group == gk.group && gq.group == gv.group;
             const bool all_d = !gq.qw && !gk.qw && !gv.qw && L.wq && L.wk && L.wv;
@@ -360,10 +383,19 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
                 const void* sc[3] = {gq.scales, gk.scales, gv.scales};
                 const void* bs[3] = {L.bq, L.bk, L.bv};
                 const int32_t ns[3] = {H * D, Hkv * D, Hkv * D};
-                rc3 = mi355_internal_linear3(outs, m->xn, ws, sc, bs, ns, T, hid, gq.group, all_q ? 2 : 0, m->cfg.dtype, stream);
-                if (rc3 != 0 && rc3 != -4) return rc3;
+                if (all_q && ss_valid && c.norm_type == 0) {            // the producer of xs left its sums of squares: no norm launch
+                    rc3 = mi355_internal_linear3(outs, m->xs, ws, sc, bs, ns, T, hid, gq.group, 2, m->cfg.dtype, L.attn_norm, c.rms_eps, m->ss, stream);
+                    if (rc3 != 0 && rc3 != -4) return rc3;
+                }
+                if (rc3 != 0) {
+                    DCHECK(norm(m, m->xn, m->xs, L.attn_norm, L.attn_norm_b, T, stream));
+                    normed = true;
+                    rc3 = mi355_internal_linear3(outs, m->xn, ws, sc, bs, ns, T, hid, gq.group, all_q ? 2 : 0, m->cfg.dtype, nullptr, 0.f, nullptr, stream);
+                    if (rc3 != 0 && rc3 != -4) return rc3;
+                }
             }
         }
+        if (rc3 != 0 && !normed) DCHECK(norm(m, m->xn, m->xs, L.attn_norm, L.attn_norm_b, T, stream));
         if (rc3 != 0) {
         DCHECK(linear(m, L.wq, L.gq[MI355_W_WQ], m->q, m->xn, L.bq, nullptr, T, H * D, hid, MI355_EPI_STORE, stream));
         DCHECK(linear(m, L.wk, L.gq[MI355_W_WK], m->k, m->xn, L.bk, nullptr, T, Hkv * D, hid, MI355_EPI_STORE, stream));
@@ -427,17 +459,26 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
             DCHECK(mi355_comm_all_reduce(m->comm, m->xn, (int64_t)T * hid, dt, stream));
             hipLaunchKernelGGL(add16_kernel, dim3(add_grid), dim3(256), 0, st, m->xs, m->xn, (int64_t)T * hid, dt == MI355_DTYPE_BF16);
         } else {
-            DCHECK(linear(m, L.wo, L.gq[MI355_W_WO], m->xs, m->attn, nullptr, m->xs, T, hid, H * D, MI355_EPI_RESID, stream));
+            DCHECK(resid_linear(m, L.wo, L.gq[MI355_W_WO], m->attn, T, hid, H * D, &ss_valid, stream));
         }
         // xs = down(silu(gate) * up) + residual                              llama.rs:59-61, mlp.rs:440-458
+        int rc_gu = -4;
+        if (L.gq[MI355_W_W1].qw && ss_valid && c.norm_type == 0) {       // wo left the sums of squares of xs: the RmsNorm rides in the gate/up launch
+            const QLin& g = L.gq[MI355_W_W1];
+            rc_gu = mi355_internal_gptq_small_linear(m->h, m->xs, g.qw, g.scales, nullptr, nullptr, L.ffn_norm, c.rms_eps, m->ss, nullptr,
+                                                     T, 2 * I, hid, g.group, dt, MI355_EPI_SILU_MUL, stream);
+            if (rc_gu != 0 && rc_gu != -4) return rc_gu;
+        }
+        if (rc_gu != 0) {
         DCHECK(norm(m, m->xn, m->xs, L.ffn_norm, L.ffn_norm_b, T, stream));
         DCHECK(linear(m, L.gate_up, L.gq[MI355_W_W1], m->h, m->xn, nullptr, nullptr, T, 2 * I, hid, MI355_EPI_SILU_MUL, stream));
+        }
         if (tp) {
             DCHECK(linear(m, L.w2, L.gq[MI355_W_W2], m->xn, m->h, nullptr, nullptr, T, hid, I, MI355_EPI_STORE, stream));
             DCHECK(mi355_comm_all_reduce(m->comm, m->xn, (int64_t)T * hid, dt, stream));
             hipLaunchKernelGGL(add16_kernel, dim3(add_grid), dim3(256), 0, st, m->xs, m->xn, (int64_t)T * hid, dt == MI355_DTYPE_BF16);
         } else {
-            DCHECK(linear(m, L.w2, L.gq[MI355_W_W2], m->xs, m->h, nullptr, m->xs, T, hid, I, MI355_EPI_RESID, stream));
+            DCHECK(resid_linear(m, L.w2, L.gq[MI355_W_W2], m->h, T, hid, I, &ss_valid, stream));
         }
     }
     if (window) {                                                           // the residual stream after the window's last layer

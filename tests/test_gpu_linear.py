@@ -237,9 +237,11 @@ def test_marlin_format_checkpoint(cv, dt, T, N, K, gs):
 
 # ------------------------------------------------------------------------------------------------ fused GPTQ epilogues
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
-def test_gptq_linear_fused_epilogues(cv, dt):
+@pytest.mark.parametrize("T", [6, 1, 4])
+def test_gptq_linear_fused_epilogues(cv, dt, T):
+    """T = 6: the 16-token-tile kernel; T = 1, 4: the 1..4-token kernel (activations staged in LDS, weight ring)"""
     rng = np.random.default_rng(11)
-    T, K, I, gs = 6, 512, 128, 128
+    K, I, gs = 512, 128, 128
     q, s = _gptq_case(rng, K, 2 * I, gs, dt)
     x = G.round_dt(rng.normal(0, 1, (T, K)), dt)
     lin = cv.GPTQLinear(dev_u32(G.gptq_pack(q)), dev16(s, dt), gs)
@@ -253,3 +255,24 @@ def test_gptq_linear_fused_epilogues(cv, dt):
     y2 = host16(lin2.forward(dev16(x, dt), epilogue=cv.EPI_RESID, residual=dev16(res, dt)), dt)
     ref2 = G.round_dt(G.gptq_linear(x, G.gptq_dequant(q, s, z, gs), None, dt) + res, dt)
     check_ulp(y2, ref2, dt, what="gptq asym + resid", ulps=2.01, mag=G.gptq_linear(x, G.gptq_dequant(q, s, z, gs), None, dt))
+
+
+@pytest.mark.parametrize("tiled", [True, False])
+@pytest.mark.parametrize("T,N,K,gs", [(1, 256, 3584, 128), (2, 64, 3584, 64), (3, 64, 1792, 32), (1, 48, 18944, 128), (4, 32, 4864, 256)])
+def test_small_batch_4bit_kernel_shapes(cv, T, N, K, gs, tiled):
+    """the 1..4-token kernel at k-block counts that do not divide by 8 (Qwen2: 14 and 74), every group size, both weight
+    layouts, against the oracle -- and against the 16-token-tile kernel (tuning key 31) to the same bound"""
+    from candle_vllm_amd import lib
+    rng = np.random.default_rng(K + N + T)
+    q, s = _gptq_case(rng, K, N, gs, "bf16")
+    x = G.round_dt(rng.normal(0, 1, (T, K)), "bf16")
+    lin = cv.GPTQLinear(dev_u32(G.gptq_pack(q)), dev16(s, "bf16"), gs, tiled=tiled)
+    ref = G.gptq_linear(x, G.gptq_dequant(q, s, None, gs), None, "bf16")
+    y = host16(lin.forward(dev16(x, "bf16")), "bf16")
+    check_ulp(y, ref, "bf16", what="1..4-token kernel")
+    lib.mi355_set_tuning(31, 1)
+    try:
+        y0 = host16(lin.forward(dev16(x, "bf16")), "bf16")
+    finally:
+        lib.mi355_set_tuning(31, 0)
+    check_ulp(y0, ref, "bf16", what="16-token-tile kernel")
