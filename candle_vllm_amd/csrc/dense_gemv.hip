@@ -35,6 +35,13 @@ __host__ __device__ __forceinline__ size_t gptq_tile_index(int kr, int n, int nk
 }
 enum { SP_NONE = 0, SP_GROUPED = 1, SP_SINGLE = 2 };
 
+// attention.rs:644-719 after the projections: q,k -> f32 -> rope -> model dtype, then the cache write of k and v
+struct DenseRope {
+    const float* cos_t; const float* sin_t;         // [max_seq][head_dim / 2] f32
+    const int64_t* positions; const int64_t* slots; // [T]
+    uint16_t* kcache; uint16_t* vcache;             // this layer's bf16 cache
+    int32_t n_kv_heads, head_dim, block_size, flash;
+};
 struct DenseArgs {
     const void* w;            // DENSE: 16-bit [N][ldw] ; GPTQ4: u32 [K/8][N]
     int32_t ldw;
@@ -54,6 +61,8 @@ struct DenseArgs {
     float norm_eps;
     const float* ss_in;       // with norm_w: [T][K/16] partial sums of squares of x's rows, left by the launch that produced x
     int32_t dbg;              // experiments (tuning key 33)
+    // dense_small3r_kernel only (q / k / v of a decode step): RoPE and the KV-cache write in the projection's epilogue
+    int32_t rope_mode;        // 0 none; 1 = q (rotate, store); 2 = k (rotate, store, write the key cache); 3 = v (store, write the value cache)
     float* ss_out;            // dense_small_kernel only: where this launch leaves [T][ldo/16] partial sums of squares of its output
 };
 
@@ -306,7 +315,7 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 }
 constexpr int DS_X_BYTES_MAX = 40 * 1024;          // staged activations: T * K * 2 bytes (T = 1: K <= 20480)
 template <int DT, int WTYPE, int R, int GJ, int D, bool ZP, int NCH>
-__device__ __forceinline__ void dense_small_body(const DenseArgs& a, const int bx) {
+__device__ __forceinline__ void dense_small_body(const DenseArgs& a, const int bx, const DenseRope* rp = nullptr) {
     static_assert(WTYPE != DW_DENSE, "4-bit weights only");
     constexpr int NG = 8 / GJ;                     // quantisation groups per k-block (GJ == 8: one group of >= 256)
     extern __shared__ __attribute__((aligned(16))) uint8_t ds_lds[];
@@ -320,6 +329,11 @@ __device__ __forceinline__ void dense_small_body(const DenseArgs& a, const int b
     int row0[R];
     row0[0] = bx * 16;
     if (R == 2) row0[R - 1] = a.pair_offset + bx * 16;
+    if (R == 2 && rp) {                                            // RoPE pairs: rows (h, j) and (h, j + D/2) of one head
+        const int tph = rp->head_dim >> 5;                         // 16-row pair tiles per head
+        row0[0] = (bx / tph) * rp->head_dim + (bx % tph) * 16;
+        row0[R - 1] = row0[0] + (rp->head_dim >> 1);
+    }
 
     // ---- activation (and norm) loads first, then the ring's first D slots
     const uint16_t* x16 = static_cast<const uint16_t*>(a.x);
@@ -330,8 +344,9 @@ __device__ __forceinline__ void dense_small_body(const DenseArgs& a, const int b
     const int F = nmine * T, half = lane >> 5, piece = lane & 31;
     constexpr int SC = NCH * 4;
     float inv[4] = {1.f, 1.f, 1.f, 1.f};
-    // (the wave-uniform `if`s keep clamped duplicate loads off the L2 -> CU path: unpredicated, a wave of the gate/up launch pulled
-    // 16 KB of partial sums, activations and norm weights for its 8 KB of weights)
+    // Loads that have nothing to fetch (token >= T, pass beyond F) are still issued -- conditional loads make the wait-count pass
+    // drain everything -- but with every lane on the SAME 16 bytes: one 64-byte request instead of a KiB (unpredicated and
+    // clamped, a wave of the gate/up launch pulled 16 KB of partial sums, activations and norm weights for its 8 KB of weights).
     f32x4_t ssp[4][2];
     const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
     if (nw16) {
@@ -340,21 +355,18 @@ __device__ __forceinline__ void dense_small_body(const DenseArgs& a, const int b
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                ssp[t][c] = z4;
-                if (t < T && 256 * c < ntp && !(a.dbg & 1))
-                    ssp[t][c] = *reinterpret_cast<const f32x4_t*>(a.ss_in + (size_t)t * ntp + min(4 * lane + 256 * c, ntp - 4));   // masked at use
+                const bool ok = t < T && 256 * c < ntp && !(a.dbg & 1);
+                ssp[t][c] = *reinterpret_cast<const f32x4_t*>(a.ss_in + (ok ? (size_t)t * ntp + min(4 * lane + 256 * c, ntp - 4) : 0));   // masked at use
             }
     }
     uint4 xv[SC], gv[SC];
 #pragma unroll
     for (int c = 0; c < SC; ++c) {
-        xv[c] = make_uint4(0, 0, 0, 0); gv[c] = xv[c];
-        if (2 * c < F) {
-            const int f = min(2 * c + half, F - 1), i = f / T, t = f - i * T;
-            const size_t k0 = (size_t)(wave + i * NW) * 256 + 8 * piece;
-            xv[c] = *reinterpret_cast<const uint4*>(x16 + (size_t)t * a.ldx + k0);
-            if (nw16 && !(a.dbg & 2)) gv[c] = *reinterpret_cast<const uint4*>(nw16 + k0);
-        }
+        const bool ok = 2 * c < F;
+        const int f = min(2 * c + half, F - 1), i = f / T, t = f - i * T;
+        const size_t k0 = (size_t)(wave + i * NW) * 256 + 8 * piece;
+        xv[c] = *reinterpret_cast<const uint4*>(x16 + (ok ? (size_t)t * a.ldx + k0 : 0));
+        if (nw16) gv[c] = *reinterpret_cast<const uint4*>(nw16 + (ok ? k0 : 0));
     }
 
     // sc: the aligned DWORD that holds the 16-bit scale (extracted at use): 16-bit loads get packed two to a VGPR by the compiler
@@ -374,25 +386,28 @@ __device__ __forceinline__ void dense_small_body(const DenseArgs& a, const int b
     }
     const float zadd = a.zmode == MI355_ZERO_GPTQ_PLUS1 ? 1.f : 0.f;
     const uint16_t* sc16 = static_cast<const uint16_t*>(a.scales);
-    auto issue = [&](Slot& sl, int kb) {
-        kb = min(kb, nkb - 1);                                    // past the end: a harmless re-load of the last block (L2 hit)
+    // Past the wave's last k-block the slot is still loaded (conditional loads in the ring make the compiler's wait-count pass drain
+    // everything: measured), but every lane reads the SAME 16 bytes of the last block: one 64-byte request instead of a KiB.
+    auto issue = [&](Slot& sl, const int kb_in) {
+        const bool ok = kb_in < nkb;
+        const int kb = ok ? kb_in : nkb - 1, ln = ok ? lane : 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if constexpr (WTYPE == DW_GPTQ4T) {
-                const dg_u32x4* tp = reinterpret_cast<const dg_u32x4*>(a.w) + ((size_t)(row0[r] >> 4) * nkb + kb) * 128 + lane;
-                const dg_u32x4 v0 = __builtin_nontemporal_load(tp), v1 = __builtin_nontemporal_load(tp + 64);
+                const dg_u32x4* tp = reinterpret_cast<const dg_u32x4*>(a.w) + ((size_t)(row0[r] >> 4) * nkb + kb) * 128 + ln;
+                const dg_u32x4 v0 = __builtin_nontemporal_load(tp), v1 = __builtin_nontemporal_load(tp + (ok ? 64 : 0));
                 sl.q[r][0] = v0.x; sl.q[r][1] = v0.y; sl.q[r][2] = v0.z; sl.q[r][3] = v0.w;
                 sl.q[r][4] = v1.x; sl.q[r][5] = v1.y; sl.q[r][6] = v1.z; sl.q[r][7] = v1.w;
             } else {
-                const uint32_t* qp = static_cast<const uint32_t*>(a.w) + (size_t)(kb * 32 + kg) * a.N + row0[r] + r16;
+                const uint32_t* qp = static_cast<const uint32_t*>(a.w) + (size_t)(kb * 32 + (ok ? kg : 0)) * a.N + row0[r] + (ok ? r16 : 0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) sl.q[r][j] = __builtin_nontemporal_load(qp + (size_t)(4 * j) * a.N);
+                for (int j = 0; j < 8; ++j) sl.q[r][j] = __builtin_nontemporal_load(qp + (size_t)(ok ? 4 * j : 0) * a.N);
             }
 #pragma unroll
             for (int gq = 0; gq < NG; ++gq) {
                 const int g = GJ < 8 ? kb * NG + gq : (kb * 256) / a.group_size;
-                sl.sc[r][gq] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sc16 + (size_t)g * a.N + (spos[r] & ~1)));
-                if constexpr (ZP) sl.zw[r][gq] = a.qzeros[(size_t)g * (a.N / 8) + zidx[r]];
+                sl.sc[r][gq] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sc16 + (size_t)g * a.N + (ok ? (spos[r] & ~1) : 0)));
+                if constexpr (ZP) sl.zw[r][gq] = a.qzeros[(size_t)g * (a.N / 8) + (ok ? zidx[r] : 0)];
             }
         }
     };
@@ -406,7 +421,7 @@ __device__ __forceinline__ void dense_small_body(const DenseArgs& a, const int b
         for (int t = 0; t < 4; ++t) {
             if (t >= T) break;
             const int ntp = K >> 4;
-            const f32x4_t p0 = 4 * lane < ntp ? ssp[t][0] : z4, p1 = 4 * lane + 256 < ntp ? ssp[t][1] : z4;
+            const f32x4_t p0 = 4 * lane < ntp ? ssp[t][0] : z4, p1 = 4 * lane + 256 < ntp ? ssp[t][1] : z4;    // (t < T here)
             float v = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]));
             inv[t] = rsqrtf(wave_sum_dpp(v) / (float)K + a.norm_eps);
         }
@@ -506,6 +521,43 @@ __device__ __forceinline__ void dense_small_body(const DenseArgs& a, const int b
             for (int w = 0; w < NW; ++w) sum += red[((w * R + r) * 4 + m) * 16 + rr];
             val[r] = sum;
         }
+        if (rp) {
+            // q / k / v of a decode step: the rounding chain of the projection (+bias), then for q and k "f32 -> rope -> model
+            // dtype" (attention.rs:644-690; rope_cache_bf16_kernel's arithmetic), then the cache write of k / v (attention.rs:707-719)
+            const uint16_t* b16 = static_cast<const uint16_t*>(a.bias);
+            const int Dh = rp->head_dim, hf = Dh >> 1, bs = rp->block_size, Hkv = rp->n_kv_heads;
+            const int64_t slot = rp->slots[m];
+            const int64_t blk = slot >= 0 ? slot / bs : 0;
+            const int off = slot >= 0 ? (int)(slot % bs) : 0;
+            uint16_t* o16 = static_cast<uint16_t*>(a.out);
+            float o0 = rnd<DT>(val[0]);
+            if (b16) o0 = rnd<DT>(o0 + h2f<DT>(b16[row0[0] + rr]));
+            if (R == 2) {
+                float o1 = rnd<DT>(val[R - 1]);
+                if (b16) o1 = rnd<DT>(o1 + h2f<DT>(b16[row0[R - 1] + rr]));
+                const int h = row0[0] / Dh, j = row0[0] % Dh + rr;
+                const int64_t pos = rp->positions[m];
+                const float cc = rp->cos_t[pos * hf + j], sn = rp->sin_t[pos * hf + j];
+                const uint16_t r0 = f2h<DT>(o0 * cc - o1 * sn), r1 = f2h<DT>(o0 * sn + o1 * cc);
+                o16[(size_t)m * a.ldo + row0[0] + rr] = r0;
+                o16[(size_t)m * a.ldo + row0[R - 1] + rr] = r1;
+                if (a.rope_mode == 2 && slot >= 0) {
+                    const int d0 = j, d1 = j + hf;
+                    if (rp->flash) { rp->kcache[(slot * Hkv + h) * Dh + d0] = r0; rp->kcache[(slot * Hkv + h) * Dh + d1] = r1; }
+                    else {
+                        rp->kcache[((((blk * Hkv + h) * (Dh / 8) + d0 / 8) * bs + off) * 8) + d0 % 8] = r0;
+                        rp->kcache[((((blk * Hkv + h) * (Dh / 8) + d1 / 8) * bs + off) * 8) + d1 % 8] = r1;
+                    }
+                }
+            } else {
+                const uint16_t r0 = f2h<DT>(o0);
+                const int row = row0[0] + rr, h = row / Dh, d = row % Dh;
+                o16[(size_t)m * a.ldo + row] = r0;
+                if (a.rope_mode == 3 && slot >= 0)
+                    rp->vcache[rp->flash ? (slot * Hkv + h) * Dh + d : ((blk * Hkv + h) * Dh + d) * (int64_t)bs + off] = r0;
+            }
+            return;
+        }
         const float o = dense_epilogue<DT>(a, m, row0[0] + rr, val[0], val[R - 1]);
         if (a.ss_out) {                                                  // sum of squares of this tile's 16 outputs of token m (fixed order)
             int q2 = __float_as_int(o * o);                            // row (16-lane) sum by DPP shifts: lane 15 of the row ends up with it
@@ -525,6 +577,16 @@ __global__ void __launch_bounds__(512) dense_small3_kernel(const DenseArgs a0, c
     if (bx < t0) dense_small_body<DT, WTYPE, 1, GJ, D, false, 1>(a0, bx);
     else if (bx < t0 + t1) dense_small_body<DT, WTYPE, 1, GJ, D, false, 1>(a1, bx - t0);
     else dense_small_body<DT, WTYPE, 1, GJ, D, false, 1>(a2, bx - t0 - t1);
+}
+
+// q, k, v of a decode step with RoPE and the cache write in the epilogue: q and k as row-tile PAIRS (j, j + D/2) of one head
+template <int DT, int WTYPE, int GJ>
+__global__ void __launch_bounds__(512) dense_small3r_kernel(const DenseArgs a0, const DenseArgs a1, const DenseArgs a2, const int t0, const int t1,
+                                                            const DenseRope rp) {
+    const int bx = (int)blockIdx.x;
+    if (bx < t0) dense_small_body<DT, WTYPE, 2, GJ, 2, false, 1>(a0, bx, &rp);
+    else if (bx < t0 + t1) dense_small_body<DT, WTYPE, 2, GJ, 2, false, 1>(a1, bx - t0, &rp);
+    else dense_small_body<DT, WTYPE, 1, GJ, 4, false, 1>(a2, bx - t0 - t1, &rp);
 }
 
 // ------------------------------------------------------------------------------------------------ launch
@@ -550,8 +612,9 @@ static int dense_launch_gj(const DenseArgs& a, int gj, int nw, hipStream_t st) {
 static int g_tune_small_nw = 0;        // tuning key 30: waves per workgroup (0 = chosen from the k-blocks)
 static int g_tune_small_off = 0;       // tuning key 31: 1 = keep 1..4 tokens on dense_kernel (A/B measurements)
 static int g_tune_small_dbg = 0;
+static int g_tune_small_norope = 0;    // tuning key 34: 1 = RoPE and the cache write stay in their own launch
 static int g_tune_small_nonorm = 0;    // tuning key 32: 1 = never norm on the way in (the host layer launches the norm separately)
-void mi355_dense_set_small(int key, int v) { if (key == 30) g_tune_small_nw = v; else if (key == 31) g_tune_small_off = v; else if (key == 32) g_tune_small_nonorm = v; else if (key == 33) g_tune_small_dbg = v; }
+void mi355_dense_set_small(int key, int v) { if (key == 30) g_tune_small_nw = v; else if (key == 31) g_tune_small_off = v; else if (key == 32) g_tune_small_nonorm = v; else if (key == 33) g_tune_small_dbg = v; else if (key == 34) g_tune_small_norope = v; }
 static inline int dense_small_gj(int group_size) {
     if (group_size >= 256) return (group_size % 256) ? -1 : 8;
     return group_size == 128 ? 4 : group_size == 64 ? 2 : group_size == 32 ? 1 : -1;
@@ -609,14 +672,29 @@ static int dense_small_launch(const DenseArgs& a, hipStream_t st) {
     }
 }
 template <int DT, int WTYPE>
-static int dense_small3_launch(const DenseArgs (&a)[3], hipStream_t st) {
+static int dense_small3_launch(const DenseArgs (&a)[3], const DenseRope* rp, hipStream_t st) {
     if constexpr (WTYPE != DW_GPTQ4T) return -4;
     else {
         for (int i = 0; i < 3; ++i)
             if (!dense_small_ok(a[i], DT) || a[i].zmode != MI355_ZERO_SYM8 || dense_small_nch(a[i]) != 1) return -4;
         const int gj = dense_small_gj(a[0].group_size);
-        const int t0 = a[0].N / 16, t1 = a[1].N / 16, t2 = a[2].N / 16;
         const int nw = dense_small_nw(a[0].K >> 8);
+        if (rp) {
+            // RoPE + cache write in the epilogue: whole heads of an even, 32-divisible width (pairs of 16-row tiles half a head apart)
+            if (g_tune_small_norope || DT != MI355_DTYPE_BF16 || (rp->head_dim & 31) || a[0].N % rp->head_dim || a[1].N != rp->n_kv_heads * rp->head_dim ||
+                a[2].N != a[1].N)
+                return -4;
+            DenseArgs b[3] = {a[0], a[1], a[2]};
+            b[0].rope_mode = 1; b[1].rope_mode = 2; b[2].rope_mode = 3;
+            const int t0 = a[0].N / 32, t1 = a[1].N / 32, t2 = a[2].N / 16;
+            const size_t lds = (size_t)nw * (((a[0].K >> 8) + nw - 1) / nw) * a[0].T * 512 + (size_t)nw * 2 * 64 * sizeof(float);
+            dim3 grid(t0 + t1 + t2), block(nw * 64);
+#define DS3R(GJ_) hipLaunchKernelGGL((dense_small3r_kernel<DT, DW_GPTQ4T, GJ_>), grid, block, lds, st, b[0], b[1], b[2], t0, t1, *rp)
+            switch (gj) { case 1: DS3R(1); break; case 2: DS3R(2); break; case 4: DS3R(4); break; default: DS3R(8); break; }
+#undef DS3R
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        }
+        const int t0 = a[0].N / 16, t1 = a[1].N / 16, t2 = a[2].N / 16;
         const size_t lds = (size_t)nw * (((a[0].K >> 8) + nw - 1) / nw) * a[0].T * 512 + (size_t)nw * 64 * sizeof(float);
         dim3 grid(t0 + t1 + t2), block(nw * 64);
 #define DS3(GJ_) hipLaunchKernelGGL((dense_small3_kernel<DT, DW_GPTQ4T, GJ_, 4>), grid, block, lds, st, a[0], a[1], a[2], t0, t1)
@@ -659,11 +737,11 @@ static int dense_launch_dt(const DenseArgs& a, hipStream_t st) {
 }
 
 template <int DT, int WTYPE>
-static int dense3_launch_dt(const DenseArgs (&a)[3], hipStream_t st) {
+static int dense3_launch_dt(const DenseArgs (&a)[3], const DenseRope* rp, hipStream_t st) {
     {
-        const int rs = dense_small3_launch<DT, WTYPE>(a, st);
+        const int rs = dense_small3_launch<DT, WTYPE>(a, rp, st);
         if (rs != -4) return rs;
-        if (a[0].norm_w) return -4;
+        if (a[0].norm_w || rp) return -4;          // only the 1..4-token kernel norms on the way in / ropes on the way out
     }
     const int mt = (a[0].T + 15) / 16;
     int gj = 8;
@@ -1222,11 +1300,15 @@ int mi355_gptq_linear_tiled(void* out, const void* x, const void* qweight_tiled,
 /* q, k, v projections (plain store epilogue, optional bias) in one launch; returns -4 when the shapes do not qualify
  * (the caller then issues three mi355_linear / mi355_gptq_linear calls).  norm_w != NULL: x is the residual stream and the
  * launch applies RmsNorm(norm_w, eps) on the way in, inv from the producer's sums of squares `ss_in` (1..4 tokens of 4-bit
- * weights only; -4 otherwise and the caller norms separately).  Internal to the host layer (dense_model.cpp). */
+ * weights only; -4 otherwise and the caller norms separately).  rope != NULL (a DenseRope): the launch also rotates q and k
+ * and writes k and v into the layer's bf16 cache -- the work of mi355_internal_rope_cache -- in its epilogue (same kernel only;
+ * -4 otherwise and the caller keeps the separate launch).  Internal to the host layer (dense_model.cpp). */
 int mi355_internal_linear3(void* const* outs, const void* x, const void* const* ws, const void* const* scales,
                            const void* const* biases, const int32_t* ns, int32_t num_tokens, int32_t k, int32_t group_size,
-                           int32_t is_gptq, int32_t dtype, const void* norm_w, float norm_eps, const float* ss_in, int64_t stream) {
+                           int32_t is_gptq, int32_t dtype, const void* norm_w, float norm_eps, const float* ss_in, const void* rope,
+                           int64_t stream) {
     if (num_tokens < 1 || num_tokens > 64 || (k & 255)) return -4;
+    const DenseRope* rp = static_cast<const DenseRope*>(rope);
     DenseArgs a[3];
     for (int i = 0; i < 3; ++i) {
         if (!ws[i] || !outs[i] || ns[i] <= 0 || (ns[i] & 15)) return -4;
@@ -1242,11 +1324,11 @@ int mi355_internal_linear3(void* const* outs, const void* x, const void* const* 
     }
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MI355_DTYPE_BF16)
-        return is_gptq == 2 ? dense3_launch_dt<MI355_DTYPE_BF16, DW_GPTQ4T>(a, st)
-               : is_gptq ? dense3_launch_dt<MI355_DTYPE_BF16, DW_GPTQ4>(a, st) : dense3_launch_dt<MI355_DTYPE_BF16, DW_DENSE>(a, st);
+        return is_gptq == 2 ? dense3_launch_dt<MI355_DTYPE_BF16, DW_GPTQ4T>(a, rp, st)
+               : is_gptq ? dense3_launch_dt<MI355_DTYPE_BF16, DW_GPTQ4>(a, rp, st) : dense3_launch_dt<MI355_DTYPE_BF16, DW_DENSE>(a, rp, st);
     if (dtype == MI355_DTYPE_F16)
-        return is_gptq == 2 ? dense3_launch_dt<MI355_DTYPE_F16, DW_GPTQ4T>(a, st)
-               : is_gptq ? dense3_launch_dt<MI355_DTYPE_F16, DW_GPTQ4>(a, st) : dense3_launch_dt<MI355_DTYPE_F16, DW_DENSE>(a, st);
+        return is_gptq == 2 ? dense3_launch_dt<MI355_DTYPE_F16, DW_GPTQ4T>(a, rp, st)
+               : is_gptq ? dense3_launch_dt<MI355_DTYPE_F16, DW_GPTQ4>(a, rp, st) : dense3_launch_dt<MI355_DTYPE_F16, DW_DENSE>(a, rp, st);
     return -4;
 }
 

@@ -23,7 +23,14 @@ extern "C" int mi355_internal_rope_cache(void* q, void* k, const void* v, void* 
 extern "C" int mi355_internal_linear3(void* const* outs, const void* x, const void* const* ws, const void* const* scales,
                                       const void* const* biases, const int32_t* ns, int32_t num_tokens, int32_t k,
                                       int32_t group_size, int32_t is_gptq, int32_t dtype, const void* norm_w, float norm_eps,
-                                      const float* ss_in, int64_t stream);
+                                      const float* ss_in, const void* rope, int64_t stream);
+// mirror of dense_gemv.hip's DenseRope: RoPE + KV-cache write in the epilogue of the q/k/v launch
+struct DenseRope {
+    const float* cos_t; const float* sin_t;
+    const int64_t* positions; const int64_t* slots;
+    uint16_t* kcache; uint16_t* vcache;
+    int32_t n_kv_heads, head_dim, block_size, flash;
+};
 extern "C" int mi355_internal_gptq_small_linear(void* out, const void* x, const void* qweight_tiled, const void* scales, const void* bias,
                                                 const void* residual, const void* norm_w, float norm_eps, const float* ss_in, float* ss_out,
                                                 int32_t num_tokens, int32_t n, int32_t k, int32_t group_size, int32_t dtype,
@@ -372,7 +379,7 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
         // one launch for the three projections when they share the weight format (decode-sized steps); with 4-bit weights
         // and 1..4 tokens that launch also applies the RmsNorm while it stages the activations (no norm launch)
         int rc3 = -4;
-        bool normed = false;
+        bool normed = false, roped = false;
         {
             const QLin &gq = L.gq[MI355_W_WQ], &gk = L.gq[MI355_W_WK], &gv = L.gq[MI355_W_WV];
             const bool all_q = gq.qw && gk.qw && gv.qw && gq.group == gk.group && gq.group == gv.group;
@@ -383,15 +390,28 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
                 const void* sc[3] = {gq.scales, gk.scales, gv.scales};
                 const void* bs[3] = {L.bq, L.bk, L.bv};
                 const int32_t ns[3] = {H * D, Hkv * D, Hkv * D};
+                // a decode step of 4-bit weights on a bf16 cache with full, non-interleaved rotary: RoPE and the cache write ride in the
+                // q/k/v launch's epilogue (-4 from the launch = not this shape: the launch is repeated without them)
+                DenseRope rp{m->cos_t, m->sin_t, positions, slot_mapping, (uint16_t*)m->kcache[l], (uint16_t*)m->vcache[l], Hkv, D,
+                             c.block_size, c.kv_layout == MI355_KV_FLASH ? 1 : 0};
+                const bool rope_ok = all_q && T <= 4 && !prefill && !c.kv_fp8 && c.rotary_dim == D && !c.rope_interleaved;
                 if (all_q && ss_valid && c.norm_type == 0) {            // the producer of xs left its sums of squares: no norm launch
-                    rc3 = mi355_internal_linear3(outs, m->xs, ws, sc, bs, ns, T, hid, gq.group, 2, m->cfg.dtype, L.attn_norm, c.rms_eps, m->ss, stream);
-                    if (rc3 != 0 && rc3 != -4) return rc3;
+                    for (int pass = rope_ok ? 0 : 1; pass < 2 && rc3 != 0; ++pass) {
+                        rc3 = mi355_internal_linear3(outs, m->xs, ws, sc, bs, ns, T, hid, gq.group, 2, m->cfg.dtype, L.attn_norm, c.rms_eps, m->ss,
+                                                     pass == 0 ? &rp : nullptr, stream);
+                        if (rc3 != 0 && rc3 != -4) return rc3;
+                        roped = rc3 == 0 && pass == 0;
+                    }
                 }
                 if (rc3 != 0) {
                     DCHECK(norm(m, m->xn, m->xs, L.attn_norm, L.attn_norm_b, T, stream));
                     normed = true;
-                    rc3 = mi355_internal_linear3(outs, m->xn, ws, sc, bs, ns, T, hid, gq.group, all_q ? 2 : 0, m->cfg.dtype, nullptr, 0.f, nullptr, stream);
-                    if (rc3 != 0 && rc3 != -4) return rc3;
+                    for (int pass = rope_ok ? 0 : 1; pass < 2 && rc3 != 0; ++pass) {
+                        rc3 = mi355_internal_linear3(outs, m->xn, ws, sc, bs, ns, T, hid, gq.group, all_q ? 2 : 0, m->cfg.dtype, nullptr, 0.f, nullptr,
+                                                     pass == 0 ? &rp : nullptr, stream);
+                        if (rc3 != 0 && rc3 != -4) return rc3;
+                        roped = rc3 == 0 && pass == 0;
+                    }
                 }
             }
         }
@@ -403,8 +423,8 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
         }
         // q,k -> f32 -> rope -> model dtype                                  attention.rs:644-690
         // (decode steps without an fp8 cache: RoPE and the cache write share one launch)
-        int rc_rc = -4;
-        if (!c.kv_fp8 && !prefill)
+        int rc_rc = roped ? 0 : -4;
+        if (!roped && !c.kv_fp8 && !prefill)
             rc_rc = mi355_internal_rope_cache(m->q, m->k, m->v, m->kcache[l], m->vcache[l], m->cos_t, m->sin_t, positions, slot_mapping,
                                               T, H, Hkv, D, c.rotary_dim, c.rope_interleaved, c.block_size, c.kv_layout, dt, stream);
         if (rc_rc != 0 && rc_rc != -4) return rc_rc;

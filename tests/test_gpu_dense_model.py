@@ -107,24 +107,30 @@ def test_stablelm_shape_prompt_then_decode(lib, flash):
         assert [int(r.argmax()) for r in got] == [int(r.argmax()) for r in ref]
 
 
-def test_qwen2_gptq_shape_prompt_then_decode(lib):
-    """BASELINE config 4 shape, tiny: every projection GPTQ 4-bit sym group 128 (QLinear GPTQ arm) + qkv bias."""
+@pytest.mark.parametrize("flash", [False, True])
+def test_qwen2_gptq_shape_prompt_then_decode(lib, flash):
+    """BASELINE config 4 shape, tiny: every projection GPTQ 4-bit sym group 128 (QLinear GPTQ arm) + qkv bias.  The decode steps
+    (2 tokens) run the 1..4-token launches: RmsNorm from the producer's sums of squares, RoPE + cache write (both cache layouts)
+    in the q/k/v epilogue -- and once more with those folded launches switched off (tuning keys 32, 34), to the same bound."""
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a visible MI355X")
     from candle_vllm_amd import dense_model as M
     cfg = DL.DenseConfig.tiny(qkv_bias=True)
     W = DL.quantize_gptq(DL.make_weights(cfg), group=128)
-    orc = DL.OracleDenseLlama(cfg, W, flash_layout=False)
+    orc = DL.OracleDenseLlama(cfg, W, flash_layout=flash)
     rng = np.random.default_rng(21)
     seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 29)], "block_table": [3, 7]},
             {"tokens": [int(t) for t in rng.integers(0, cfg.vocab, 7)], "block_table": [1]}]
     cache = orc.new_cache(16)
     meta = O.prepare_prompt(seqs, cfg.block_size)
     ref = orc.forward(meta, cache, is_prefill=True)
-    gm = M.DenseLlama(cfg, max_batch=4, kv_layout=M.KV_PAGED)
-    gm.load_oracle_weights(W)
-    gm.alloc_kv_cache(16)
+    gm = M.DenseLlama(cfg, max_batch=4, kv_layout=M.KV_FLASH if flash else M.KV_PAGED)
+    gm2 = M.DenseLlama(cfg, max_batch=4, kv_layout=M.KV_FLASH if flash else M.KV_PAGED)      # the same steps, launch by launch
+    for g in (gm, gm2):
+        g.load_oracle_weights(W)
+        g.alloc_kv_cache(16)
     got = gm.forward(meta, is_prefill=True).cpu().numpy()
+    gm2.forward(meta, is_prefill=True)
     assert _rel(got, ref) < 2e-2, _rel(got, ref)
     assert [int(r.argmax()) for r in got] == [int(r.argmax()) for r in ref]
     for step in range(2):
@@ -133,7 +139,13 @@ def test_qwen2_gptq_shape_prompt_then_decode(lib):
         dmeta = O.prepare_decode(seqs, cfg.block_size)
         ref = orc.forward(dmeta, cache)
         got = gm.forward(dmeta).cpu().numpy()
+        M.lib.mi355_set_tuning(32, 1); M.lib.mi355_set_tuning(34, 1)
+        try:
+            got2 = gm2.forward(dmeta).cpu().numpy()
+        finally:
+            M.lib.mi355_set_tuning(32, 0); M.lib.mi355_set_tuning(34, 0)
         assert _rel(got, ref) < 2e-2, (step, _rel(got, ref))
+        assert _rel(got2, ref) < 2e-2, (step, _rel(got2, ref))
         assert [int(r.argmax()) for r in got] == [int(r.argmax()) for r in ref]
 
 
