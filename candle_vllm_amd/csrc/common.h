@@ -62,6 +62,27 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// The same two reductions without the LDS crossbar (every __shfl_xor above is a ds_bpermute: six dependent LDS round trips per
+// call): four DPP row shifts leave each 16-lane row's result in its lane 15, four v_readlane pick them up.  ALL 64 lanes must be
+// active.  The result is wave-uniform.  (Summation order differs from wave_sum's butterfly.)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    int x = __float_as_int(v);
+    x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true)));   // row_shr:1
+    x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true)));   // row_shr:2
+    x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true)));   // row_shr:4
+    x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true)));   // row_shr:8
+    return (__int_as_float(__builtin_amdgcn_readlane(x, 15)) + __int_as_float(__builtin_amdgcn_readlane(x, 31))) +
+           (__int_as_float(__builtin_amdgcn_readlane(x, 47)) + __int_as_float(__builtin_amdgcn_readlane(x, 63)));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    int x = __float_as_int(v);                                     // lanes without a source keep their own value (old = x, no bound_ctrl)
+    x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x111, 0xf, 0xf, false))));
+    x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x112, 0xf, 0xf, false))));
+    x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xf, false))));
+    x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x118, 0xf, 0xf, false))));
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(x, 15)), __int_as_float(__builtin_amdgcn_readlane(x, 31))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(x, 47)), __int_as_float(__builtin_amdgcn_readlane(x, 63))));
+}
 // reduce over lane groups of width W (power of two <= 64); result valid in every lane of the group
 template <int W>
 __device__ __forceinline__ float group_sum(float v) {

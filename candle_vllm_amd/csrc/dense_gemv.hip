@@ -301,18 +301,8 @@ __global__ void __launch_bounds__(512) dense3_kernel(const DenseArgs a0, const D
 //   * every wave keeps D k-blocks of weights + the dwords holding their scales / zero points in flight (a register ring of D
 //     slots; the only VMEM instructions in the loop are the ring's loads, so the counted vmcnt waits leave D-1 slots outstanding).
 // Same arithmetic as dense_body's 4-bit arm (128+q / 1024+q codes, scale applied once per group, ones-MFMA row sums).
-// sum over the 64 lanes, the same value in every lane, without the LDS crossbar: four DPP row shifts leave each row's sum in its
-// lane 15, four v_readlane pick them up (__shfl_xor is ds_bpermute: six dependent LDS round trips per sum -- measured 6 us on the
-// 28 us gate/up launch when every wave reduced four tokens' partial sums that way)
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-    int x = __float_as_int(v);
-    x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true)));   // row_shr:1
-    x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true)));   // row_shr:2
-    x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true)));   // row_shr:4
-    x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true)));   // row_shr:8
-    return (__int_as_float(__builtin_amdgcn_readlane(x, 15)) + __int_as_float(__builtin_amdgcn_readlane(x, 31))) +
-           (__int_as_float(__builtin_amdgcn_readlane(x, 47)) + __int_as_float(__builtin_amdgcn_readlane(x, 63)));
-}
+// (wave_sum_dpp, common.h: __shfl_xor reductions measured 6 us on the 28 us gate/up launch when every wave reduced four tokens'
+// partial sums that way)
 constexpr int DS_X_BYTES_MAX = 40 * 1024;          // staged activations: T * K * 2 bytes (T = 1: K <= 20480)
 template <int DT, int WTYPE, int R, int GJ, int D, bool ZP, int NCH>
 __device__ __forceinline__ void dense_small_body(const DenseArgs& a, const int bx, const DenseRope* rp = nullptr) {
@@ -610,23 +600,29 @@ static int dense_launch_gj(const DenseArgs& a, int gj, int nw, hipStream_t st) {
 
 // ---- the 1..4-token launch of 4-bit weights (dense_small_kernel): -4 = this shape stays on dense_kernel
 static int g_tune_small_nw = 0;        // tuning key 30: waves per workgroup (0 = chosen from the k-blocks)
+static int g_tune_small_nw_big = 0;    // tuning key 35: the same for K > 8192
 static int g_tune_small_off = 0;       // tuning key 31: 1 = keep 1..4 tokens on dense_kernel (A/B measurements)
 static int g_tune_small_dbg = 0;
 static int g_tune_small_norope = 0;    // tuning key 34: 1 = RoPE and the cache write stay in their own launch
 static int g_tune_small_nonorm = 0;    // tuning key 32: 1 = never norm on the way in (the host layer launches the norm separately)
-void mi355_dense_set_small(int key, int v) { if (key == 30) g_tune_small_nw = v; else if (key == 31) g_tune_small_off = v; else if (key == 32) g_tune_small_nonorm = v; else if (key == 33) g_tune_small_dbg = v; else if (key == 34) g_tune_small_norope = v; }
+void mi355_dense_set_small(int key, int v) { if (key == 30) g_tune_small_nw = v; else if (key == 31) g_tune_small_off = v; else if (key == 32) g_tune_small_nonorm = v; else if (key == 33) g_tune_small_dbg = v; else if (key == 34) g_tune_small_norope = v; else if (key == 35) g_tune_small_nw_big = v; }
 static inline int dense_small_gj(int group_size) {
     if (group_size >= 256) return (group_size % 256) ? -1 : 8;
     return group_size == 128 ? 4 : group_size == 64 ? 2 : group_size == 32 ? 1 : -1;
 }
 static inline int dense_small_nw(int nkb) {
-    if (g_tune_small_nw >= 1 && g_tune_small_nw <= 8 && g_tune_small_nw <= nkb) return g_tune_small_nw;
+    if (g_tune_small_nw >= 1 && g_tune_small_nw <= 8 && g_tune_small_nw <= nkb && nkb <= 32) return g_tune_small_nw;   // experiments: hidden-sized K only
+    if (g_tune_small_nw_big >= 1 && g_tune_small_nw_big <= 8 && nkb > 32) return g_tune_small_nw_big;
+    if (nkb < 4) return nkb;
+    // hidden-sized K (<= 16 k-blocks: 4096): four waves -- more, smaller workgroups per CU balance the launch better than more
+    // waves on fewer (Qwen2-7B gate/up, 1184 workgroups: 19.5 us with 2..4 waves, 22.3 us with 7; q/k/v and wo within 0.4 us)
+    if (nkb <= 16) return 4;
     int best = 1, best_slots = 1 << 30;
-    for (int nw = nkb < 8 ? nkb : 8; nw >= 4 && nw >= 1; --nw) {                // fewest idle wave-slots, the larger workgroup on a tie
+    for (int nw = 8; nw >= 4; --nw) {                               // fewest idle wave-slots, the larger workgroup on a tie
         const int slots = (nkb + nw - 1) / nw * nw;
         if (slots < best_slots) { best_slots = slots; best = nw; }
     }
-    return nkb < 4 ? nkb : best;
+    return best;
 }
 // staging passes a wave needs: ceil(k-blocks per wave * T / 8); the kernel is built for 1 and 2
 static inline int dense_small_nch(const DenseArgs& a) {

@@ -676,31 +676,71 @@ __global__ void __launch_bounds__(64 * WPB) paged_attn_mfma_kernel(const PAParam
         if ((int)sm_t[0] != Pg - 1) return;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (threadIdx.x == 0) __hip_atomic_store(p.arrive + (int64_t)b * p.Hkv + hk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        constexpr int DL2 = D / 64, MU2 = 8;
+        // one wave per query head; ONE round trip per 32 partials: lane q holds (exp_sum, max_logit) of partial q, every lane its
+        // D/64 channels of all 32 -- everything is requested before anything is used (the first form walked the partials 8 at a
+        // time, a memory round trip each: 3 us of serial tail behind a 6 us attention at 16 partials per head, 5 us at 32)
+        constexpr int DL2 = D / 64, MU2 = 32;
         for (int g = wave; g < G; g += WPB) {
             const int64_t pi0 = ((int64_t)b * p.H + hk * G + g) * p.max_partitions;
             float M = -1e30f;
-            for (int q = lane; q < Pg; q += 64) M = fmaxf(M, p.max_logits[pi0 + q]);
-            M = wave_max(M);
             float accv[DL2], den = 0.f;
 #pragma unroll
             for (int e = 0; e < DL2; ++e) accv[e] = 0.f;
-            for (int q0 = 0; q0 < Pg; q0 += MU2) {
-                float tv[MU2][DL2], es[MU2], ml[MU2];
+            if (Pg <= 64) {
+                const float ml_q = lane < Pg ? p.max_logits[pi0 + lane] : -1e30f;
+                const float es_q = lane < Pg ? p.exp_sums[pi0 + lane] : 0.f;
+                float tv[MU2][DL2];
 #pragma unroll
                 for (int u = 0; u < MU2; ++u) {
-                    const int q = (q0 + u < Pg) ? q0 + u : Pg - 1;
-                    es[u] = p.exp_sums[pi0 + q];
-                    ml[u] = p.max_logits[pi0 + q];
+                    const int q = u < Pg ? u : Pg - 1;
 #pragma unroll
                     for (int e = 0; e < DL2; ++e) tv[u][e] = p.tmp_out[(pi0 + q) * D + lane * DL2 + e];
                 }
+                M = wave_max_dpp(ml_q);
+                const float wl = es_q * __expf(ml_q - M);          // 0 beyond Pg (es_q = 0)
+                den = wave_sum_dpp(wl);
+                const int wbits = __float_as_int(wl);
 #pragma unroll
                 for (int u = 0; u < MU2; ++u) {
-                    const float wq = (q0 + u < Pg) ? es[u] * __expf(ml[u] - M) : 0.f;
-                    den += wq;
+                    const float wq = __int_as_float(__builtin_amdgcn_readlane(wbits, u));
 #pragma unroll
                     for (int e = 0; e < DL2; ++e) accv[e] = fmaf(tv[u][e], wq, accv[e]);
+                }
+                for (int q0 = MU2; q0 < Pg; q0 += MU2) {           // 33..64 partials: one more round trip
+#pragma unroll
+                    for (int u = 0; u < MU2; ++u) {
+                        const int q = q0 + u < Pg ? q0 + u : Pg - 1;
+#pragma unroll
+                        for (int e = 0; e < DL2; ++e) tv[u][e] = p.tmp_out[(pi0 + q) * D + lane * DL2 + e];
+                    }
+#pragma unroll
+                    for (int u = 0; u < MU2; ++u) {
+                        const float wq = __int_as_float(__builtin_amdgcn_readlane(wbits, q0 + u));
+#pragma unroll
+                        for (int e = 0; e < DL2; ++e) accv[e] = fmaf(tv[u][e], wq, accv[e]);
+                    }
+                }
+            } else {
+                for (int q = lane; q < Pg; q += 64) M = fmaxf(M, p.max_logits[pi0 + q]);
+                M = wave_max(M);
+                constexpr int MU3 = 8;
+                for (int q0 = 0; q0 < Pg; q0 += MU3) {
+                    float tv[MU3][DL2], es[MU3], ml[MU3];
+#pragma unroll
+                    for (int u = 0; u < MU3; ++u) {
+                        const int q = (q0 + u < Pg) ? q0 + u : Pg - 1;
+                        es[u] = p.exp_sums[pi0 + q];
+                        ml[u] = p.max_logits[pi0 + q];
+#pragma unroll
+                        for (int e = 0; e < DL2; ++e) tv[u][e] = p.tmp_out[(pi0 + q) * D + lane * DL2 + e];
+                    }
+#pragma unroll
+                    for (int u = 0; u < MU3; ++u) {
+                        const float wq = (q0 + u < Pg) ? es[u] * __expf(ml[u] - M) : 0.f;
+                        den += wq;
+#pragma unroll
+                        for (int e = 0; e < DL2; ++e) accv[e] = fmaf(tv[u][e], wq, accv[e]);
+                    }
                 }
             }
             const float inv = den > 0.f ? 1.f / den : 0.f;

@@ -559,7 +559,7 @@ def test_moe_router_wide_kernel_and_fallback(cv, hid, E, K):
         assert np.abs(wts.cpu().numpy() - w_ref).max() < 1e-5
 
 
-@pytest.mark.parametrize("bs,ctx", [(64, [4100, 37, 520]), (16, [1000, 259])])
+@pytest.mark.parametrize("bs,ctx", [(64, [4100, 37, 520]), (16, [1000, 259]), (64, [9000, 300])])
 def test_paged_attention_workgroup_merge_equals_one_wave_per_partition(cv, bs, ctx):
     """4 partitions per workgroup merged in LDS (few sequences, long contexts) vs one wave per partition: same
     partition arithmetic, different merge tree -> equal to accumulation noise, both within 1 bf16 ulp of the oracle."""
@@ -574,7 +574,7 @@ def test_paged_attention_workgroup_merge_equals_one_wave_per_partition(cv, bs, c
     tol = 2 ** -7 * np.abs(oracle).max() + 1e-6
     outs = {}
     try:
-        for wpb in (1, 4):
+        for wpb in (1, 4, 8, 16):                                     # partials per head in the fused merge: <= 32, 33..64, > 64
             cv.lib.mi355_set_tuning(8, wpb)
             for ps in (32, 64):
                 for fused in (0, 2):
