@@ -280,18 +280,26 @@ struct XRegs {
 // of the hot loop measured 2.3 % of the batch-1 step), -1 = decide at run time
 // NRM: 1 = an RMSNorm weight is fused, 0 = none (no weight load, no sum of squares), -1 = decide at run time -- the same reason
 // (the branch in the staging step measured 1.4 % of the batch-1 step)
+// what a (token, slot) pair of a mixture-of-experts launch adds to the descriptor's pointers: wave-uniform values next to the
+// kernarg descriptor, applied under `if constexpr (MOE)` only: with the offsets always present (zeros in the dense kernels) the
+// dense Q4_K f32-x kernel came out of hipcc producing NaN at several wave counts (tools/dbg_nan.py) although its ISA differed
+// from the good one by a handful of scalar instructions -- the dense kernels are kept byte-identical to what was validated.  The first form of qmm_moe_kernel patched a private
+// COPY of the descriptor instead: 312 bytes of scratch per lane, every argument a scratch load -- the expert mat-vecs ran at
+// 2.0-2.3 TB/s where the dense ones reach 3.5-3.9.
+struct QmmPairOff { size_t w0, w1, w2; size_t x_bytes; size_t out; };
 template <int BT, int XB = -1, int NRM = -1>
-__device__ __forceinline__ XRegs<BT> load_x(const QmmArgs& a, int kb, int lane, const float* nwp) {
+__device__ __forceinline__ XRegs<BT> load_x(const QmmArgs& a, int kb, int lane, const float* nwp, const size_t x_bytes = 0) {
+    const uint8_t* xb0 = static_cast<const uint8_t*>(a.x) + x_bytes;
     XRegs<BT> r;
     const size_t k = (size_t)kb * 256 + 4 * lane;
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
         const int bb = (BT == 1 || b < a.B) ? b : a.B - 1;        // padded rows re-read the last row (zeroed later)
         if (XB < 0 ? a.x_dtype == MI355_DTYPE_BF16 : XB == 1) {
-            const uint2 t = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(a.x) + (size_t)bb * a.ldx + k);
+            const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(xb0) + (size_t)bb * a.ldx + k);
             r.v[b] = make_uint4(t.x, t.y, 0, 0);
         } else {
-            r.v[b] = *reinterpret_cast<const uint4*>(static_cast<const float*>(a.x) + (size_t)bb * a.ldx + k);
+            r.v[b] = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(xb0) + (size_t)bb * a.ldx + k);
         }
     }
     if (NRM != 0) r.nw = *reinterpret_cast<const float4*>(nwp + k);
@@ -507,7 +515,8 @@ __device__ __forceinline__ void epi_pre_late(const QmmArgs& a, EpiPre& ep) {
 // red: [NW][R][BT][16] partial sums of the NW compute waves, red_ss: [NW][BT] partial sum x^2 (fused RMSNorm)
 template <int BT, int R>
 __device__ __forceinline__ void qmm_epilogue(const QmmArgs& a, const float* red, const float* red_ss, const int NW,
-                                             const int (&segi)[R], const int (&tile)[R], const EpiPre& ep) {
+                                             const int (&segi)[R], const int (&tile)[R], const EpiPre& ep, const size_t out_off = 0) {
+    float* const aout = a.out + out_off;
     // ---- epilogue: thread -> (slot r, batch b, row rr)
     constexpr int NOUT = R * BT * 16;
     const int nout = NOUT;
@@ -537,15 +546,15 @@ __device__ __forceinline__ void qmm_epilogue(const QmmArgs& a, const float* red,
             if (r & 1) continue;                                   // even slot = gate, odd slot = up of the same rows
             float g = sum_of(r, rr), up = sum_of(r + 1, rr);
             if (a.bias) { g += a.bias[orow]; up += a.bias[a.seg[1].row0 + lrow]; }
-            a.out[(size_t)b * a.ldo + lrow] = silu_f(g) * up;
+            aout[(size_t)b * a.ldo + lrow] = silu_f(g) * up;
             continue;
         }
         float val = sum_of(r, rr);
         if (a.bias) val += a.bias[orow];
         if (a.epi == MI355_EPI_STORE) {
-            a.out[(size_t)b * a.ldo + orow] = val;
+            aout[(size_t)b * a.ldo + orow] = val;
         } else if (a.epi == MI355_EPI_RESID) {
-            a.out[(size_t)b * a.ldo + orow] = (pre ? ep.f0 : a.resid[(size_t)b * a.ldo + orow]) + val;
+            aout[(size_t)b * a.ldo + orow] = (pre ? ep.f0 : a.resid[(size_t)b * a.ldo + orow]) + val;
         } else if (a.epi == MI355_EPI_QKV_ROPE_CACHE) {
             // segment 0 = q, 1 = k, 2 = v ; interleaved RoPE on (even,odd) channel pairs of q and k
             const int D = a.D, d = lrow % D, hh = lrow / D;
@@ -605,8 +614,8 @@ __device__ __forceinline__ void qmm_stamp(const QmmArgs& a, int i) {
 #define qmm_stamp(a, i) ((void)0)
 #endif
 
-template <int BT, int R, int WT, int XB, int NRM>
-__device__ __forceinline__ void qmm_body(const QmmArgs& a) {
+template <int BT, int R, int WT, int XB, int NRM, bool MOE = false>
+__device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po = QmmPairOff{0, 0, 0, 0, 0}) {
     qmm_stamp(a, 0);
     // probe modes of this kernel exist only in -DMI355_QMM_PROBES builds (tools/): every guarded load or branch in the hot
     // loop costs the production kernel measurable time
@@ -637,6 +646,7 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
         wtype[r] = WT ? WT : a.seg[segi[r]].type;
         wtb[r] = (wtype[r] == MI355_GGML_Q4_K) ? Q4K_TILE : Q6K_TILE;
         wbase[r] = a.seg[segi[r]].w + (size_t)tile[r] * nkb * wtb[r];
+        if constexpr (MOE) wbase[r] += (segi[r] == 0 ? po.w0 : segi[r] == 1 ? po.w1 : po.w2);
     }
     // RMSNorm weights, or any readable K floats when no norm is fused (keeps the load count static)
     const float* nwp = a.norm_w ? a.norm_w : reinterpret_cast<const float*>(a.seg[0].w);
@@ -667,7 +677,7 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
 #pragma unroll
     for (int q = 0; q < PFK; ++q) {
         const int kb = wave + NW * q;
-        xr[q] = load_x<BT, XB, NRM>(a, kb <= kb_last ? kb : kb_last, lane, nwp);
+        xr[q] = load_x<BT, XB, NRM>(a, kb <= kb_last ? kb : kb_last, lane, nwp, MOE ? po.x_bytes : 0);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const bool ok = q < n_my_kb;
@@ -684,7 +694,7 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
             const bool active = kbi < n_my_kb;                    // wave-uniform
             if (active && (dbg < 3 || dbg == 7)) stage_kblock3<BT, XB, NRM>(a, xr[q], ximg, lane, ss);
             const int kbn = wave + NW * (kbi + PFK);
-            if (dbg < 3 || dbg == 7) xr[q] = load_x<BT, XB, NRM>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp);
+            if (dbg < 3 || dbg == 7) xr[q] = load_x<BT, XB, NRM>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp, MOE ? po.x_bytes : 0);
             const bool ok = kbi + PFK < n_my_kb;
             if constexpr (WT != 0) {
                 // every tile of the launch has one type: the R tiles of this k-block share C_in and the A fragments
@@ -755,7 +765,7 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a) {
     __syncthreads();
     qmm_stamp(a, 2);
 
-    qmm_epilogue<BT, R>(a, red, red_ss, NW, segi, tile, ep);
+    qmm_epilogue<BT, R>(a, red, red_ss, NW, segi, tile, ep, MOE ? po.out : 0);
     qmm_stamp(a, 3);
 }
 
@@ -1006,17 +1016,14 @@ __global__ void __launch_bounds__(512) qmm_q8_kernel(const QmmArgs a) { qmm_body
 
 // MoE variant (decode-shaped, BT = 1): blockIdx.y = (token, slot) pair.  The adjusted descriptor is a private copy
 // -- kept out of the dense kernel, where the kernel arguments must stay scalar loads from the kernarg segment.
-template <int R, int WT>
-__global__ void __launch_bounds__(512) qmm_moe_kernel(const QmmArgs a_in) {
-    QmmArgs a = a_in;
+template <int R, int WT, int XB, int NRM>
+__global__ void __launch_bounds__(512) qmm_moe_kernel(const QmmArgs a) {
     const int pair = blockIdx.y;
-    const int64_t e = a.moe_expert[pair];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) a.seg[s].w += e * a.moe_stride[s];
+    const size_t e = (size_t)a.moe_expert[pair];
     const size_t xes = (a.x_dtype == MI355_DTYPE_BF16) ? 2 : 4;
-    a.x = static_cast<const uint8_t*>(a.x) + (size_t)(pair / a.moe_xdiv) * a.ldx * xes;
-    a.out += (size_t)pair * a.ldo;
-    qmm_body<1, R, WT, -1, -1>(a);
+    const QmmPairOff po = {e * (size_t)a.moe_stride[0], e * (size_t)a.moe_stride[1], e * (size_t)a.moe_stride[2],
+                           (size_t)(pair / a.moe_xdiv) * a.ldx * xes, (size_t)pair * a.ldo};
+    qmm_body<1, R, WT, XB, NRM, true>(a, po);
 }
 
 // ================================================================================================
@@ -2073,10 +2080,18 @@ static int qmm_launch_btrw(QmmArgs& a, int n_wg, int NW, hipStream_t st) {
         if constexpr (BT == 1) {
             static bool moe_attr_done = false;
             if (!moe_attr_done) {
-                (void)hipFuncSetAttribute((const void*)qmm_moe_kernel<R, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)qmm_moe_kernel<R, WT, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)qmm_moe_kernel<R, WT, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)qmm_moe_kernel<R, WT, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)qmm_moe_kernel<R, WT, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 moe_attr_done = true;
             }
-            hipLaunchKernelGGL((qmm_moe_kernel<R, WT>), dim3(n_wg, a.moe_pairs), dim3(64 * NW), shm, st, a);
+            const bool xb = a.x_dtype == MI355_DTYPE_BF16, nrm = a.norm_w != nullptr;
+            const dim3 mgrid(n_wg, a.moe_pairs), mblock(64 * NW);
+            if (xb && nrm) hipLaunchKernelGGL((qmm_moe_kernel<R, WT, 1, 1>), mgrid, mblock, shm, st, a);
+            else if (xb) hipLaunchKernelGGL((qmm_moe_kernel<R, WT, 1, 0>), mgrid, mblock, shm, st, a);
+            else if (nrm) hipLaunchKernelGGL((qmm_moe_kernel<R, WT, 0, 1>), mgrid, mblock, shm, st, a);
+            else hipLaunchKernelGGL((qmm_moe_kernel<R, WT, 0, 0>), mgrid, mblock, shm, st, a);
         } else {
             return (int)hipErrorInvalidValue;
         }
