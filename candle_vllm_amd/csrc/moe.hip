@@ -145,7 +145,11 @@ __global__ void __launch_bounds__(1024) moe_route16_kernel(int32_t* __restrict__
         if (c0 == 0 && norm_w) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) ss += xq[j].x * xq[j].x + xq[j].y * xq[j].y + xq[j].z * xq[j].z + xq[j].w * xq[j].w;
-            ss = block_sum(ss, red);                                  // (hidden <= 8192: the two pieces above are the whole row)
+            // (hidden <= 8192: the two pieces above are the whole row); DPP sums: every ds_bpermute of wave_sum is an LDS round trip
+            ss = wave_sum_dpp(ss);
+            if (lane == 0) red[wave] = ss;
+            __syncthreads();
+            ss = wave_sum_dpp(lane < 16 ? red[lane] : 0.f);
         }
         const float inv = norm_w ? rsqrtf(ss / (float)hidden + eps) : 1.f;
 #pragma unroll
@@ -153,7 +157,7 @@ __global__ void __launch_bounds__(1024) moe_route16_kernel(int32_t* __restrict__
             acc = fmaf(xv[u].x * inv * nv[u].x, gv[u].x, fmaf(xv[u].y * inv * nv[u].y, gv[u].y,
                   fmaf(xv[u].z * inv * nv[u].z, gv[u].z, fmaf(xv[u].w * inv * nv[u].w, gv[u].w, acc))));
     }
-    acc = wave_sum(acc);
+    acc = wave_sum_dpp(acc);
     if (lane == 0) s_part[wave] = acc;
     __syncthreads();
     if (threadIdx.x < (unsigned)E) {
