@@ -287,6 +287,118 @@ __global__ void __launch_bounds__(512) dense3_kernel(const DenseArgs a0, const D
     else dense_body<DT, WTYPE, MT, 1, GJ>(a2, bx - t0 - t1);
 }
 
+// ------------------------------------------------------------------------------------------------ 5..64 tokens x 16-bit weights, many row tiles
+// dense_body gives a workgroup ONE row tile (or gate/up pair) and lets its waves split K: every wave then fetches its own copy of
+// the activations of its k-blocks -- at 32 tokens 16 KB of x (from L2) for every 8 KB of weights, and all of a k-block's loads are
+// requested, waited for and consumed before the next k-block's go out (measured on BASELINE configs[2], Llama-3-8B bf16 at batch
+// 32: gate/up 235 MB in 86.7 us = 2.7 TB/s, lm_head 2.7 TB/s).  Here the waves of a workgroup own DIFFERENT row tiles and sweep K
+// together:
+//   * one image of the activations per k-block in LDS, staged once by all threads and shared by the NW tiles (rows padded to
+//     528 B: the 16 rows of an A-fragment read land on 16 different bank quads), double-buffered, one barrier per k-block;
+//   * every wave keeps TWO k-blocks of its tile's weights in flight (a 2-slot register ring; the activations of the next
+//     k-block are requested in between, so the counted vmcnt waits never drain the ring);
+//   * a wave owns all of K for its tile: no cross-wave reduction, the epilogue runs out of the accumulators.
+// Taken when the launch has enough row tiles for that shape (gate/up, lm_head); the few-tile projections (wo, down, q/k/v) keep
+// the K-split of dense_body.
+constexpr int DWD_LDX = 264;                        // 16-bit elements per staged row: 256 + 8 pad
+template <int DT, int MT, int R, int NW>
+__global__ void __launch_bounds__(64 * NW) dense_wide_kernel(const DenseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t dwd_x[];          // [2][MT * 16][DWD_LDX]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int nkb = a.K >> 8, T = a.T;
+    // every workgroup starts its sweep at a different k-block: in step, all waves of the launch would ask for the same 512-byte column
+    // of rows 8 KB apart (the order of the f32 sum changes with the workgroup, not from run to run)
+    const int rot = a.dbg == 64 ? 0 : (int)((blockIdx.x * 7u) % (unsigned)nkb);
+#define DWD_KB(KB_) (((KB_) + rot) % nkb)
+    const int ntiles = (R == 2 ? a.pair_offset : a.N) >> 4;
+    const int tile = min((int)blockIdx.x * NW + wave, ntiles - 1);            // a surplus wave shadows the last tile (stores skipped)
+    const bool live = (int)blockIdx.x * NW + wave < ntiles;
+    int row0[R];
+    row0[0] = tile * 16;
+    if (R == 2) row0[R - 1] = a.pair_offset + tile * 16;
+    const uint16_t* x16 = static_cast<const uint16_t*>(a.x);
+    const uint16_t* wrow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wrow[r] = static_cast<const uint16_t*>(a.w) + (size_t)(row0[r] + r16) * a.ldw + 8 * kg;
+
+    // ---- staging: MT * 512 pieces of 16 B per k-block over NW * 64 threads (piece p: row p / 32, 16-byte column p % 32)
+    constexpr int XP = MT * 8 / NW;
+    static_assert(XP >= 1 && XP * NW == MT * 8, "pieces must divide evenly");
+    const int xcol = threadIdx.x & 31, xrow0 = threadIdx.x >> 5;             // piece i of this thread: row xrow0 + 2 NW i
+    const uint16_t* xsrc[XP];
+#pragma unroll
+    for (int i = 0; i < XP; ++i) xsrc[i] = x16 + (size_t)min(xrow0 + 2 * NW * i, T - 1) * a.ldx + 8 * xcol;
+    uint16_t* const xdst = dwd_x + (size_t)xrow0 * DWD_LDX + 8 * xcol;
+    uint4 xr[XP];
+#define DWD_X_LOAD(KB_) _Pragma("unroll") for (int i_ = 0; i_ < XP; ++i_) xr[i_] = *reinterpret_cast<const uint4*>(xsrc[i_] + (size_t)DWD_KB(KB_) * 256)
+#define DWD_X_STORE(BUF_) _Pragma("unroll") for (int i_ = 0; i_ < XP; ++i_) \
+        *reinterpret_cast<uint4*>(xdst + ((size_t)(BUF_) * MT * 16 + 2 * NW * i_) * DWD_LDX) = xr[i_]
+    uint4 bw[2][R][8];
+    // past the end: one 16-byte request per instruction (see dense_small_body)
+#define DWD_W_LOAD(SLOT_, KB_) do { \
+        const bool ok_ = (KB_) < nkb; \
+        const size_t koff_ = ok_ ? (size_t)DWD_KB(KB_) * 256 : 0; \
+        _Pragma("unroll") for (int r_ = 0; r_ < R; ++r_) { \
+            const uint16_t* wp_ = (ok_ ? wrow[r_] : static_cast<const uint16_t*>(a.w)) + koff_; \
+            _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) { \
+                const dg_u32x4 v_ = __builtin_nontemporal_load(reinterpret_cast<const dg_u32x4*>(wp_ + (ok_ ? 32 * j_ : 0))); \
+                bw[SLOT_][r_][j_] = make_uint4(v_.x, v_.y, v_.z, v_.w); \
+            } \
+        } } while (0)
+    DWD_X_LOAD(0);
+    DWD_W_LOAD(0, 0);
+    DWD_W_LOAD(1, 1);
+    f32x4_t y[R][MT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) y[r][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    DWD_X_STORE(0);
+    __syncthreads();
+
+#define DWD_COMPUTE(SLOT_, BUF_) do { \
+        const uint16_t* xb_ = dwd_x + ((size_t)(BUF_) * MT * 16 + r16) * DWD_LDX + 8 * kg; \
+        _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) { \
+            uint4 aw_[MT]; \
+            _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) aw_[mt_] = *reinterpret_cast<const uint4*>(xb_ + (size_t)mt_ * 16 * DWD_LDX + 32 * j_); \
+            _Pragma("unroll") for (int r_ = 0; r_ < R; ++r_) \
+                _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) y[r_][mt_] = mfma32<DT>(aw_[mt_], bw[SLOT_][r_][j_], y[r_][mt_]); \
+        } } while (0)
+    for (int kb0 = 0; kb0 < nkb; kb0 += 2) {
+        // slot 0
+        {
+            const int kb = kb0;
+            DWD_X_LOAD(min(kb + 1, nkb - 1));                                // next k-block's activations ride between the ring's loads
+            DWD_COMPUTE(0, 0);
+            DWD_W_LOAD(0, kb + 2);
+            DWD_X_STORE(1);
+            __syncthreads();
+        }
+        if (kb0 + 1 < nkb) {                                                 // workgroup-uniform
+            const int kb = kb0 + 1;
+            DWD_X_LOAD(min(kb + 1, nkb - 1));
+            DWD_COMPUTE(1, 1);
+            DWD_W_LOAD(1, kb + 2);
+            DWD_X_STORE(0);
+            __syncthreads();
+        }
+    }
+#undef DWD_X_LOAD
+#undef DWD_X_STORE
+#undef DWD_W_LOAD
+#undef DWD_COMPUTE
+#undef DWD_KB
+    if (!live) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int m = mt * 16 + 4 * kg + v;
+            if (m < T) dense_epilogue<DT>(a, m, row0[0] + r16, y[0][mt][v], y[R - 1][mt][v]);
+        }
+}
+
 // ------------------------------------------------------------------------------------------------ 1..4 tokens x 4-bit weights
 // The decode step of a GPTQ / AWQ model at batch 1..4 is a chain of small weight streams (Qwen2-7B: 6 / 8 / 34 / 68 MB), each
 // against the launch floor (~4.5 us): what a launch reaches is (bytes in flight) / (memory latency), and what the step reaches is
@@ -599,13 +711,16 @@ static int dense_launch_gj(const DenseArgs& a, int gj, int nw, hipStream_t st) {
 }
 
 // ---- the 1..4-token launch of 4-bit weights (dense_small_kernel): -4 = this shape stays on dense_kernel
+static int g_tune_gemm_min_t = 96;     // tuning key 36: tokens from which a 16-bit projection takes the 128 x 128 MFMA GEMM
+static int g_tune_wide_nw = 4;         // tuning key 38: waves (row tiles) per workgroup of dense_wide_kernel: 2 | 4
+static int g_tune_wide_off = 0;        // tuning key 37: 1 = 16-bit launches with many row tiles stay on dense_kernel (A/B)
 static int g_tune_small_nw = 0;        // tuning key 30: waves per workgroup (0 = chosen from the k-blocks)
 static int g_tune_small_nw_big = 0;    // tuning key 35: the same for K > 8192
 static int g_tune_small_off = 0;       // tuning key 31: 1 = keep 1..4 tokens on dense_kernel (A/B measurements)
 static int g_tune_small_dbg = 0;
 static int g_tune_small_norope = 0;    // tuning key 34: 1 = RoPE and the cache write stay in their own launch
 static int g_tune_small_nonorm = 0;    // tuning key 32: 1 = never norm on the way in (the host layer launches the norm separately)
-void mi355_dense_set_small(int key, int v) { if (key == 30) g_tune_small_nw = v; else if (key == 31) g_tune_small_off = v; else if (key == 32) g_tune_small_nonorm = v; else if (key == 33) g_tune_small_dbg = v; else if (key == 34) g_tune_small_norope = v; else if (key == 35) g_tune_small_nw_big = v; }
+void mi355_dense_set_small(int key, int v) { if (key == 30) g_tune_small_nw = v; else if (key == 31) g_tune_small_off = v; else if (key == 32) g_tune_small_nonorm = v; else if (key == 33) g_tune_small_dbg = v; else if (key == 34) g_tune_small_norope = v; else if (key == 35) g_tune_small_nw_big = v; else if (key == 36 && v > 0) g_tune_gemm_min_t = v; else if (key == 37) g_tune_wide_off = v; else if (key == 38) g_tune_wide_nw = v; }
 static inline int dense_small_gj(int group_size) {
     if (group_size >= 256) return (group_size % 256) ? -1 : 8;
     return group_size == 128 ? 4 : group_size == 64 ? 2 : group_size == 32 ? 1 : -1;
@@ -710,6 +825,27 @@ static int dense_launch_dt(const DenseArgs& a, hipStream_t st) {
     }
     const bool pair = a.epi == MI355_EPI_SILU_MUL;
     const int mt = (a.T + 15) / 16;
+    if constexpr (WTYPE == DW_DENSE) {
+        // enough row tiles for one tile (or gate/up pair) per wave on every CU: the LDS-shared-activation sweep
+        const int wtiles = (pair ? a.pair_offset : a.N) / 16;
+        if (!g_tune_wide_off && a.T > 4 && wtiles >= 4 * 192 && (!pair || mt <= 2) && !((uintptr_t)a.x & 15) && !(a.ldx & 7) &&
+            !((uintptr_t)a.w & 15) && !(a.ldw & 7)) {
+            const_cast<DenseArgs&>(a).dbg = g_tune_small_dbg;
+            const int nwv = g_tune_wide_nw == 2 ? 2 : 4;
+            const dim3 grid((wtiles + nwv - 1) / nwv), block(64 * nwv);
+            const size_t lds = (size_t)2 * mt * 16 * DWD_LDX * 2;
+#define DWD_GO2(MT_, R_, NW_) do { \
+                static bool attr = false; \
+                if (!attr) { (void)hipFuncSetAttribute((const void*)dense_wide_kernel<DT, MT_, R_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
+                hipLaunchKernelGGL((dense_wide_kernel<DT, MT_, R_, NW_>), grid, block, lds, st, a); } while (0)
+#define DWD_GO(MT_, R_) do { if (nwv == 2) DWD_GO2(MT_, R_, 2); else DWD_GO2(MT_, R_, 4); } while (0)
+            if (pair) { if (mt == 1) DWD_GO(1, 2); else DWD_GO(2, 2); }
+            else switch (mt) { case 1: DWD_GO(1, 1); break; case 2: DWD_GO(2, 1); break; case 3: DWD_GO(3, 1); break; default: DWD_GO(4, 1); break; }
+#undef DWD_GO2
+#undef DWD_GO
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        }
+    }
     int gj = 8;
     if (WTYPE != DW_DENSE) {
         if (a.group_size >= 256) { if (a.group_size % 256) return -2; gj = 8; }
@@ -932,7 +1068,7 @@ static int dense_prompt_gemm(const DenseArgs& a, int dt, hipStream_t st) {
 
 // SILU_MUL with more than 32 tokens, or any T > 64: run in token chunks
 static int dense_run(DenseArgs a, int wtype, int dt, hipStream_t st) {
-    if (wtype == DW_DENSE && a.T >= 96) {
+    if (wtype == DW_DENSE && a.T >= g_tune_gemm_min_t) {
         const int rc = dense_prompt_gemm(a, dt, st);
         if (rc != (int)hipErrorNotSupported) return rc;                    // odd strides / K: keep streaming in token chunks
     }

@@ -2013,7 +2013,7 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     else if (key == 22) g_tune_qmv_ring = value;
     else if (key == 23) g_tune_chain_b1 = value;
     else if (key == 24) g_tune_exact_act = value;
-    else if (key >= 30 && key <= 35) mi355_dense_set_small(key, value);
+    else if (key >= 30 && key <= 38) mi355_dense_set_small(key, value);
 }
 
 static size_t qmm_lds_bytes(int BT, int R, int NW) {

@@ -276,3 +276,32 @@ def test_small_batch_4bit_kernel_shapes(cv, T, N, K, gs, tiled):
     finally:
         lib.mi355_set_tuning(31, 0)
     check_ulp(y0, ref, "bf16", what="16-token-tile kernel")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("T,N,K,pair", [(32, 12304, 512, False), (9, 12288, 256, False), (64, 12320, 768, False), (48, 12288, 512, False),
+                                        (32, 12304, 512, True), (5, 12288, 256, True), (20, 12320, 768, True)])
+def test_wide_16bit_kernel_many_row_tiles(cv, dt, T, N, K, pair):
+    """5..64 tokens against >= 768 row tiles (gate/up, lm_head shapes): the LDS-shared-activation kernel (one row tile or gate/up
+    pair per wave, 2-slot weight ring; a tile count that is not a multiple of 4 leaves surplus waves), against the oracle -- and
+    the K-split kernel on the same inputs (tuning key 37) to the same bound"""
+    from candle_vllm_amd import lib
+    rng = np.random.default_rng(T * 31 + N + K)
+    x = G.round_dt(rng.normal(0, 1, (T, K)), dt)
+    if pair:
+        w = G.round_dt(rng.normal(0, 0.06, (2 * N, K)), dt)
+        gu = G.linear16(x, w, None, dt)
+        ref, mag, ulps = G.silu_mul16(gu[:, :N], gu[:, N:], dt), None, 3.0
+    else:
+        w = G.round_dt(rng.normal(0, 0.05, (N, K)), dt)
+        ref, mag, ulps = G.linear16(x, w, None, dt), None, 1.01
+    lin = cv.Linear(dev16(w, dt))
+    kw = {"epilogue": cv.EPI_SILU_MUL} if pair else {}
+    y = host16(lin.forward(dev16(x, dt), **kw), dt)
+    check_ulp(y, ref, dt, ulps=ulps, what="wide 16-bit kernel", mag=mag)
+    lib.mi355_set_tuning(37, 1)
+    try:
+        y0 = host16(lin.forward(dev16(x, dt), **kw), dt)
+    finally:
+        lib.mi355_set_tuning(37, 0)
+    check_ulp(y0, ref, dt, ulps=ulps, what="K-split kernel", mag=mag)
