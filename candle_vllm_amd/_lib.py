@@ -98,6 +98,8 @@ _sig("mi355_qmatmul_chain", ctypes.c_int, [ctypes.POINTER(QmmDesc), c_i32, c_vp,
 _sig("mi355_moe_route", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64])
 _sig("mi355_moe_combine", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64])
 _sig("mi355_moe_gather", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
+_sig("mi355_moe_group", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
+_sig("mi355_moe_gather_pos", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
 _sig("mi355_moe_scatter_combine", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
 for _n in ("marlin_4bit_f16", "marlin_4bit_bf16", "marlin_awq_4bit_f16", "marlin_awq_4bit_bf16"):
     _sig(_n, None, [c_vp] * 6 + [c_i32] * 3 + [c_vp, c_i32, c_i64])

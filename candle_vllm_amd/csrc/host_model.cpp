@@ -104,9 +104,14 @@ struct Model {
     int32_t* p_moe_ids = nullptr; float* p_moe_w = nullptr; float* p_moe_y = nullptr;
     // grouped experts on prompt steps: gathered rows in expert order + the permutation and its inverse
     float* p_moe_xg = nullptr; int32_t* p_moe_perm = nullptr; int32_t* p_moe_inv = nullptr;
+    // decode steps with many (token, slot) pairs: experts grouped on the device, `g_cap` rows per expert (host_model.cpp run_part)
+    float* g_moe_xg = nullptr; float* g_moe_h = nullptr; float* g_moe_yg = nullptr; int32_t* g_moe_pos = nullptr; int g_cap = 0;
     bool moe_grouped_done = false;  // this layer's MlpOrMoe ran grouped inside the gate/up part: the down part has nothing left to do
 };
 
+// per-pair expert mat-vecs read an expert once per pair; grouped, every expert is read once per 32-row chunk of its `pairs` rows
+int g_moe_group = 1;            // tuning key 41: 0 = decode steps never group (A/B)
+inline bool moe_group_pays(int pairs, int n_expert) { return pairs > n_expert * ((pairs + 31) / 32); }
 int g_host_ps_override = 0;     // experiments: mi355_set_tuning(5, partition_size)
 
 int local_heads(const Model* m) { return m->cfg.n_heads / (m->cfg.tp_world > 0 ? m->cfg.tp_world : 1); }
@@ -321,6 +326,39 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
             m->moe_grouped_done = true;
             return 0;
         }
+        if (part == PART_GATEUP && !in.is_prefill && g_moe_group && m->g_moe_xg && pairs <= m->g_cap && moe_group_pays(pairs, c.n_expert)) {
+            // ---- grouped experts, decided on the device (decode steps with many pairs; graph-safe: no host round trip, fixed launch
+            // shapes): route, give every pair a row in its expert's block of `cap` rows (stable), gather, then EVERY expert streams
+            // once per 32-row chunk over its whole block (rows past its count hold stale finite values that nobody reads back), and
+            // one kernel adds the weighted rows to the residual.  Per pair (below) a batch-32 Mixtral step reads 64 experts per
+            // layer; here 8 experts x 2 chunks.
+            const int cap = ((pairs + 31) / 32) * 32 <= m->g_cap ? ((pairs + 31) / 32) * 32 : m->g_cap;   // rows every expert's GEMM runs over
+            RCHECK(mi355_moe_route(in.moe_ids, in.moe_w, in.xs, L.ffn_norm, c.rms_eps, L.gate_inp, B, hid, c.n_expert, K, st));
+            RCHECK(mi355_moe_group(m->g_moe_pos, in.moe_ids, pairs, c.n_expert, m->g_cap, st));
+            RCHECK(mi355_moe_gather_pos(m->g_moe_xg, in.xs, m->g_moe_pos, pairs, K, hid, st));
+            for (int e = 0; e < c.n_expert; ++e) {
+                const size_t off = (size_t)e * m->g_cap;
+                mi355_qmm_desc g;
+                memset(&g, 0, sizeof(g));
+                g.nseg = 2;
+                g.w_tiles[0] = L.eslab[0] + (size_t)e * L.estride[0]; g.ggml_type[0] = L.etype[0]; g.n_rows[0] = L.erows[0];
+                g.w_tiles[1] = L.eslab[2] + (size_t)e * L.estride[2]; g.ggml_type[1] = L.etype[2]; g.n_rows[1] = L.erows[2];
+                g.x = m->g_moe_xg + off * hid; g.x_dtype = MI355_DTYPE_F32; g.ldx = hid; g.k = hid; g.num_tokens = cap;
+                g.norm_weight = L.ffn_norm; g.norm_eps = c.rms_eps;
+                g.epilogue = MI355_EPI_SILU_MUL; g.out = m->g_moe_h + off * I; g.ldo = I;
+                RCHECK(mi355_qmatmul_fused(&g, st));
+                mi355_qmm_desc dn;
+                memset(&dn, 0, sizeof(dn));
+                dn.nseg = 1;
+                dn.w_tiles[0] = L.eslab[1] + (size_t)e * L.estride[1]; dn.ggml_type[0] = L.etype[1]; dn.n_rows[0] = L.erows[1];
+                dn.x = m->g_moe_h + off * I; dn.x_dtype = MI355_DTYPE_F32; dn.ldx = I; dn.k = I; dn.num_tokens = cap;
+                dn.epilogue = MI355_EPI_STORE; dn.out = m->g_moe_yg + off * hid; dn.ldo = hid;
+                RCHECK(mi355_qmatmul_fused(&dn, st));
+            }
+            RCHECK(mi355_moe_scatter_combine(in.xs, m->g_moe_yg, in.moe_w, m->g_moe_pos, B, hid, K, st));
+            m->moe_grouped_done = true;
+            return 0;
+        }
         if (part == PART_GATEUP) {
             RCHECK(mi355_moe_route(in.moe_ids, in.moe_w, in.xs, L.ffn_norm, c.rms_eps, L.gate_inp, B, hid, c.n_expert, K, st));
             d.nseg = 2;
@@ -472,6 +510,7 @@ void drop_graph(Model* m) {
 }  // namespace
 
 extern "C" void mi355_host_set_partition_override(int v) { g_host_ps_override = v; }
+extern "C" void mi355_host_set_moe_group(int v) { g_moe_group = v; }
 
 extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
     if (!cfg || cfg->hidden <= 0 || cfg->n_layers <= 0 || cfg->max_batch <= 0 || cfg->head_dim <= 0 ||
@@ -500,6 +539,15 @@ extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
         alloc((void**)&m->moe_ids, (size_t)B * KE * 4);
         alloc((void**)&m->moe_w, (size_t)B * KE * 4);
         alloc((void**)&m->moe_y, (size_t)B * KE * cfg->hidden * 4);
+        if (moe_group_pays(B * KE, cfg->n_expert)) {          // device-grouped decode: every expert owns B * KE rows of these
+            m->g_cap = B * KE;
+            const size_t rows = (size_t)cfg->n_expert * m->g_cap;
+            alloc((void**)&m->g_moe_xg, rows * cfg->hidden * 4);
+            alloc((void**)&m->g_moe_h, rows * cfg->intermediate * 4);
+            alloc((void**)&m->g_moe_yg, rows * cfg->hidden * 4);
+            alloc((void**)&m->g_moe_pos, (size_t)B * KE * 4);
+            if (m->g_moe_xg) (void)hipMemset(m->g_moe_xg, 0, rows * cfg->hidden * 4);      // rows no pair lands in: finite from the start
+        }
     }
     alloc((void**)&m->logits, (size_t)B * cfg->vocab * 4);
     if (m->use_comm) {
@@ -568,7 +616,7 @@ extern "C" void mi355_llama_destroy(void* mp) {
     void* ptrs[] = {m->tok_embd, m->output_norm, m->cos_t, m->sin_t, m->xs, m->q, m->attn, m->h, m->logits,
                     m->pa_tmp, m->pa_max, m->pa_sum, m->kv_slab, m->d_tokens, m->d_positions, m->d_slots,
                     m->d_ctx, m->d_bt, m->logits_local, m->logits_gather, m->tp_y, m->p_tp_y, m->p_moe_xg, m->p_moe_perm, m->p_moe_inv, m->p_xs, m->p_q, m->p_attn, m->p_h,
-                    m->moe_ids, m->moe_w, m->moe_y, m->p_moe_ids, m->p_moe_w, m->p_moe_y, m->chain_sync};
+                    m->moe_ids, m->moe_w, m->moe_y, m->p_moe_ids, m->p_moe_w, m->p_moe_y, m->chain_sync, m->g_moe_xg, m->g_moe_h, m->g_moe_yg, m->g_moe_pos};
     if (m->comm && m->comm_owned) mi355_comm_destroy(m->comm);
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete m;

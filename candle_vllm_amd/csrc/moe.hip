@@ -92,6 +92,38 @@ __global__ void __launch_bounds__(256) moe_scatter_combine_kernel(float* __restr
     for (int j = 0; j < K; ++j) acc = fmaf(wts[(size_t)t * K + j], yg[(size_t)inv[t * K + j] * hidden + i], acc);
     ys[(size_t)t * hidden + i] = acc;
 }
+// ---- the same grouping decided ON THE DEVICE (decode steps inside a captured graph: no host round trip, fixed launch shapes).
+// Every expert owns `cap` rows of the gathered buffers (cap >= the step's pair count: any routing fits); pair p lands in row
+// pos[p] = ids[p] * cap + (number of earlier pairs of the same expert) -- stable, token order inside an expert.  Rows past an
+// expert's count are never written and never read back: the expert GEMMs run over all cap rows (rows are independent), the
+// combine reads only pos[].
+__global__ void __launch_bounds__(256) moe_group_kernel(int32_t* __restrict__ pos, const int32_t* __restrict__ ids, int pairs, int n_expert, int cap) {
+    for (int p = threadIdx.x; p < pairs; p += blockDim.x) {
+        const int e = ids[p];
+        int before = 0;
+        for (int q = 0; q < p; ++q) before += ids[q] == e ? 1 : 0;
+        pos[p] = (e >= 0 && e < n_expert) ? e * cap + before : 0;
+    }
+}
+__global__ void __launch_bounds__(256) moe_gather_pos_kernel(float* __restrict__ dst, const float* __restrict__ src, const int32_t* __restrict__ pos,
+                                                             int K, int hidden) {
+    const int p = blockIdx.y;                                          // pair index = token * K + slot
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i < hidden) *reinterpret_cast<float4*>(dst + (size_t)pos[p] * hidden + i) = *reinterpret_cast<const float4*>(src + (size_t)(p / K) * hidden + i);
+}
+extern "C" int mi355_moe_group(int32_t* pos, const int32_t* expert_ids, int32_t num_pairs, int32_t n_expert, int32_t cap, int64_t stream) {
+    if (num_pairs <= 0) return 0;
+    if (!pos || !expert_ids || n_expert < 1 || cap < num_pairs || num_pairs > 4096) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(moe_group_kernel, dim3(1), dim3(256), 0, to_stream(stream), pos, expert_ids, num_pairs, n_expert, cap);
+    return (int)hipGetLastError();
+}
+extern "C" int mi355_moe_gather_pos(float* dst, const float* src, const int32_t* pos, int32_t num_pairs, int32_t top_k, int32_t hidden,
+                                    int64_t stream) {
+    if (num_pairs <= 0) return 0;
+    if (!dst || !src || !pos || top_k < 1 || hidden <= 0 || (hidden & 3)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(moe_gather_pos_kernel, dim3((hidden / 4 + 255) / 256, num_pairs), dim3(256), 0, to_stream(stream), dst, src, pos, top_k, hidden);
+    return (int)hipGetLastError();
+}
 extern "C" int mi355_moe_gather(float* dst, const float* src, const int32_t* perm, int32_t num_pairs, int32_t top_k, int32_t hidden,
                                 int64_t stream) {
     if (num_pairs <= 0) return 0;

@@ -236,6 +236,13 @@ int mi355_moe_combine(float* ys, const float* y_pairs, const float* weights, int
 /* grouped experts for prompt steps / large batches (the reference's per-expert index_select -> expert -> index_add loop,
  * quantized_llama.rs:93-119; layers/moe.rs:746-810): `perm` = the (token * top_k + slot) pair indices sorted by expert,
  * `inv` = its inverse.  gather: dst[p] = src[perm[p] / top_k] (f32 rows); scatter_combine: ys[t] += sum_j w[t,j] * y_sorted[inv[t*top_k+j]] */
+/* The same grouping decided on the device, for decode steps inside a captured graph (no host round trip, fixed launch shapes):
+ * every expert owns `cap` rows (cap >= num_pairs) of the gathered buffers; mi355_moe_group writes pos[p] = expert_ids[p] * cap +
+ * (earlier pairs of the same expert); mi355_moe_gather_pos copies token p / top_k into row pos[p]; the expert GEMMs then run over
+ * all cap rows of every expert (rows are independent; unwritten rows are never read back) and mi355_moe_scatter_combine(inv = pos)
+ * adds the weighted rows to the residual -- quantized_llama.rs:93-119 without `to_vec2`. */
+int mi355_moe_group(int32_t* pos, const int32_t* expert_ids, int32_t num_pairs, int32_t n_expert, int32_t cap, int64_t stream);
+int mi355_moe_gather_pos(float* dst, const float* src, const int32_t* pos, int32_t num_pairs, int32_t top_k, int32_t hidden, int64_t stream);
 int mi355_moe_gather(float* dst, const float* src, const int32_t* perm, int32_t num_pairs, int32_t top_k, int32_t hidden, int64_t stream);
 int mi355_moe_scatter_combine(float* ys, const float* y_sorted, const float* weights, const int32_t* inv, int32_t num_tokens,
                               int32_t hidden, int32_t top_k, int64_t stream);

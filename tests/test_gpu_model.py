@@ -535,3 +535,53 @@ def test_llama3_rope_scaling_tables_through_the_model(lib):
     got = gm.forward_decode(meta).cpu().numpy()
     assert _rel(got, ref) < 1e-3, _rel(got, ref)
     assert _rel(got, base) > 1e-3                                   # not the default tables
+
+
+@pytest.mark.parametrize("B", [12, 33])
+def test_moe_decode_experts_grouped_on_the_device(lib, B):
+    """A decode step with many (token, slot) pairs: the pairs are grouped by expert ON THE DEVICE (mi355_moe_group: every expert
+    owns `cap` rows, stable order, no host round trip -- graph-safe) and every expert streams once per 32-row chunk; against the
+    oracle's MlpOrMoe restatement (quantized_llama.rs:56-123) and against the per-pair path (tuning key 41 = 0): same routing,
+    same tokens, logits equal to accumulation noise (B = 12: the 1-8-token per-pair kernels vs the wide path; 33 -> 66 pairs, 3 chunks)."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from candle_vllm_amd import model as M
+    cfg = llama.LlamaConfig.tiny()
+    cfg.n_expert, cfg.n_expert_used = 4, 2
+    W = llama.make_moe_weights(cfg, 4, seed=78)
+    orc = llama.OracleLlama(cfg, W, flash_layout=False)
+    rng = np.random.default_rng(13)
+    seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, int(n))], "block_table": [2 * i + 1, 2 * i + 2]}
+            for i, n in enumerate(rng.integers(3, 2 * cfg.block_size - 4, B))]
+    cache = orc.new_cache(2 * B + 2)
+    lg = orc.forward(O.prepare_prompt(seqs, cfg.block_size), cache, is_prefill=True)
+    for s, row in zip(seqs, lg):
+        s["tokens"].append(int(row.argmax()))
+    gm = M.GGUFLLaMa(cfg, max_batch=B, kv_layout=M.KV_PAGED)
+    gm.load_oracle_weights(W)
+    gm.alloc_kv_cache(2 * B + 2)
+    meta = O.prepare_decode(seqs, cfg.block_size)
+    ref = orc.forward(meta, [(k.copy(), v.copy()) for k, v in cache])
+    outs = {}
+    try:
+        for grouped in (1, 0):
+            for l, (kc, vc) in enumerate(cache):
+                gm.kv_upload(l, kc, vc)
+            M.lib.mi355_set_tuning(41, grouped)
+            outs[grouped] = gm.forward_decode(meta).cpu().numpy()
+    finally:
+        M.lib.mi355_set_tuning(41, 1)
+    # the MoE prompt step's bound (test_moe_model_prompt_and_graph_decode): a near-tie in the router's softmax moves the mixing
+    # weights of this tiny model by more than the mat-muls' own error (measured 1.1e-3 .. 1.5e-3 on both paths)
+    for g, bound in ((0, 3e-3), (1, 3e-3)):
+        assert _rel(outs[g], ref) < bound, (g, _rel(outs[g], ref))
+        assert [int(r.argmax()) for r in outs[g]] == [int(r.argmax()) for r in ref]
+    assert _rel(outs[1], outs[0]) < 3e-3
+    # the grouping itself, bit for bit: pos[p] = e * cap + rank of p among the pairs of e
+    ids = rng.integers(0, 4, 2 * B).astype(np.int32)
+    d_ids = torch.from_numpy(ids).cuda()
+    pos = torch.zeros(2 * B, dtype=torch.int32, device="cuda")
+    assert M.lib.mi355_moe_group(pos.data_ptr(), d_ids.data_ptr(), 2 * B, 4, 2 * B, 0) == 0
+    torch.cuda.synchronize()
+    want = [int(e) * 2 * B + int((ids[:p] == e).sum()) for p, e in enumerate(ids)]
+    assert pos.cpu().tolist() == want
