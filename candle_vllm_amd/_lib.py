@@ -46,6 +46,7 @@ class QmmDesc(ctypes.Structure):
         ("block_size", c_i32), ("kv_layout", c_i32),
         ("moe_expert_ids", c_vp), ("moe_pairs", c_i32), ("moe_x_div", c_i32), ("moe_expert_stride", c_i64 * 3),
         ("chain_next", c_i32), ("chain_next_k", c_i32), ("chain_next_norm", c_vp),
+        ("rows_dev", c_vp), ("rows_min", c_i32),
     ]
 
 
@@ -98,7 +99,7 @@ _sig("mi355_qmatmul_chain", ctypes.c_int, [ctypes.POINTER(QmmDesc), c_i32, c_vp,
 _sig("mi355_moe_route", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64])
 _sig("mi355_moe_combine", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64])
 _sig("mi355_moe_gather", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
-_sig("mi355_moe_group", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
+_sig("mi355_moe_group", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
 _sig("mi355_moe_gather_pos", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
 _sig("mi355_moe_scatter_combine", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
 for _n in ("marlin_4bit_f16", "marlin_4bit_bf16", "marlin_awq_4bit_f16", "marlin_awq_4bit_bf16"):

@@ -105,7 +105,7 @@ struct Model {
     // grouped experts on prompt steps: gathered rows in expert order + the permutation and its inverse
     float* p_moe_xg = nullptr; int32_t* p_moe_perm = nullptr; int32_t* p_moe_inv = nullptr;
     // decode steps with many (token, slot) pairs: experts grouped on the device, `g_cap` rows per expert (host_model.cpp run_part)
-    float* g_moe_xg = nullptr; float* g_moe_h = nullptr; float* g_moe_yg = nullptr; int32_t* g_moe_pos = nullptr; int g_cap = 0;
+    float* g_moe_xg = nullptr; float* g_moe_h = nullptr; float* g_moe_yg = nullptr; int32_t* g_moe_pos = nullptr; int32_t* g_moe_cnt = nullptr; int g_cap = 0;
     bool moe_grouped_done = false;  // this layer's MlpOrMoe ran grouped inside the gate/up part: the down part has nothing left to do
 };
 
@@ -332,28 +332,34 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
             // once per 32-row chunk over its whole block (rows past its count hold stale finite values that nobody reads back), and
             // one kernel adds the weighted rows to the residual.  Per pair (below) a batch-32 Mixtral step reads 64 experts per
             // layer; here 8 experts x 2 chunks.
-            const int cap = ((pairs + 31) / 32) * 32 <= m->g_cap ? ((pairs + 31) / 32) * 32 : m->g_cap;   // rows every expert's GEMM runs over
             RCHECK(mi355_moe_route(in.moe_ids, in.moe_w, in.xs, L.ffn_norm, c.rms_eps, L.gate_inp, B, hid, c.n_expert, K, st));
-            RCHECK(mi355_moe_group(m->g_moe_pos, in.moe_ids, pairs, c.n_expert, m->g_cap, st));
+            RCHECK(mi355_moe_group(m->g_moe_pos, m->g_moe_cnt, in.moe_ids, pairs, c.n_expert, m->g_cap, st));
             RCHECK(mi355_moe_gather_pos(m->g_moe_xg, in.xs, m->g_moe_pos, pairs, K, hid, st));
             for (int e = 0; e < c.n_expert; ++e) {
-                const size_t off = (size_t)e * m->g_cap;
-                mi355_qmm_desc g;
-                memset(&g, 0, sizeof(g));
-                g.nseg = 2;
-                g.w_tiles[0] = L.eslab[0] + (size_t)e * L.estride[0]; g.ggml_type[0] = L.etype[0]; g.n_rows[0] = L.erows[0];
-                g.w_tiles[1] = L.eslab[2] + (size_t)e * L.estride[2]; g.ggml_type[1] = L.etype[2]; g.n_rows[1] = L.erows[2];
-                g.x = m->g_moe_xg + off * hid; g.x_dtype = MI355_DTYPE_F32; g.ldx = hid; g.k = hid; g.num_tokens = cap;
-                g.norm_weight = L.ffn_norm; g.norm_eps = c.rms_eps;
-                g.epilogue = MI355_EPI_SILU_MUL; g.out = m->g_moe_h + off * I; g.ldo = I;
-                RCHECK(mi355_qmatmul_fused(&g, st));
-                mi355_qmm_desc dn;
-                memset(&dn, 0, sizeof(dn));
-                dn.nseg = 1;
-                dn.w_tiles[0] = L.eslab[1] + (size_t)e * L.estride[1]; dn.ggml_type[0] = L.etype[1]; dn.n_rows[0] = L.erows[1];
-                dn.x = m->g_moe_h + off * I; dn.x_dtype = MI355_DTYPE_F32; dn.ldx = I; dn.k = I; dn.num_tokens = cap;
-                dn.epilogue = MI355_EPI_STORE; dn.out = m->g_moe_yg + off * hid; dn.ldo = hid;
-                RCHECK(mi355_qmatmul_fused(&dn, st));
+                // one fixed-shape launch group per 32-row chunk of the expert's block; a chunk no pair landed in (the expert's count,
+                // on the device, <= its first row) falls through every kernel of its launches
+                for (int r0 = 0; r0 < pairs; r0 += 32) {
+                    const int rows = 32;                              // (the gate is built into the 9..32-token launches)
+                    const size_t off = (size_t)e * m->g_cap + r0;
+                    mi355_qmm_desc g;
+                    memset(&g, 0, sizeof(g));
+                    g.nseg = 2;
+                    g.w_tiles[0] = L.eslab[0] + (size_t)e * L.estride[0]; g.ggml_type[0] = L.etype[0]; g.n_rows[0] = L.erows[0];
+                    g.w_tiles[1] = L.eslab[2] + (size_t)e * L.estride[2]; g.ggml_type[1] = L.etype[2]; g.n_rows[1] = L.erows[2];
+                    g.x = m->g_moe_xg + off * hid; g.x_dtype = MI355_DTYPE_F32; g.ldx = hid; g.k = hid; g.num_tokens = rows;
+                    g.norm_weight = L.ffn_norm; g.norm_eps = c.rms_eps;
+                    g.epilogue = MI355_EPI_SILU_MUL; g.out = m->g_moe_h + off * I; g.ldo = I;
+                    g.rows_dev = m->g_moe_cnt + e; g.rows_min = r0;
+                    RCHECK(mi355_qmatmul_fused(&g, st));
+                    mi355_qmm_desc dn;
+                    memset(&dn, 0, sizeof(dn));
+                    dn.nseg = 1;
+                    dn.w_tiles[0] = L.eslab[1] + (size_t)e * L.estride[1]; dn.ggml_type[0] = L.etype[1]; dn.n_rows[0] = L.erows[1];
+                    dn.x = m->g_moe_h + off * I; dn.x_dtype = MI355_DTYPE_F32; dn.ldx = I; dn.k = I; dn.num_tokens = rows;
+                    dn.epilogue = MI355_EPI_STORE; dn.out = m->g_moe_yg + off * hid; dn.ldo = hid;
+                    dn.rows_dev = m->g_moe_cnt + e; dn.rows_min = r0;
+                    RCHECK(mi355_qmatmul_fused(&dn, st));
+                }
             }
             RCHECK(mi355_moe_scatter_combine(in.xs, m->g_moe_yg, in.moe_w, m->g_moe_pos, B, hid, K, st));
             m->moe_grouped_done = true;
@@ -540,12 +546,13 @@ extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
         alloc((void**)&m->moe_w, (size_t)B * KE * 4);
         alloc((void**)&m->moe_y, (size_t)B * KE * cfg->hidden * 4);
         if (moe_group_pays(B * KE, cfg->n_expert)) {          // device-grouped decode: every expert owns B * KE rows of these
-            m->g_cap = B * KE;
+            m->g_cap = (B * KE + 31) / 32 * 32;                // whole 32-row chunks: the launch shape of every (expert, chunk)
             const size_t rows = (size_t)cfg->n_expert * m->g_cap;
             alloc((void**)&m->g_moe_xg, rows * cfg->hidden * 4);
             alloc((void**)&m->g_moe_h, rows * cfg->intermediate * 4);
             alloc((void**)&m->g_moe_yg, rows * cfg->hidden * 4);
-            alloc((void**)&m->g_moe_pos, (size_t)B * KE * 4);
+            alloc((void**)&m->g_moe_pos, (size_t)m->g_cap * 4);
+            alloc((void**)&m->g_moe_cnt, (size_t)cfg->n_expert * 4);
             if (m->g_moe_xg) (void)hipMemset(m->g_moe_xg, 0, rows * cfg->hidden * 4);      // rows no pair lands in: finite from the start
         }
     }
@@ -616,7 +623,7 @@ extern "C" void mi355_llama_destroy(void* mp) {
     void* ptrs[] = {m->tok_embd, m->output_norm, m->cos_t, m->sin_t, m->xs, m->q, m->attn, m->h, m->logits,
                     m->pa_tmp, m->pa_max, m->pa_sum, m->kv_slab, m->d_tokens, m->d_positions, m->d_slots,
                     m->d_ctx, m->d_bt, m->logits_local, m->logits_gather, m->tp_y, m->p_tp_y, m->p_moe_xg, m->p_moe_perm, m->p_moe_inv, m->p_xs, m->p_q, m->p_attn, m->p_h,
-                    m->moe_ids, m->moe_w, m->moe_y, m->p_moe_ids, m->p_moe_w, m->p_moe_y, m->chain_sync, m->g_moe_xg, m->g_moe_h, m->g_moe_yg, m->g_moe_pos};
+                    m->moe_ids, m->moe_w, m->moe_y, m->p_moe_ids, m->p_moe_w, m->p_moe_y, m->chain_sync, m->g_moe_xg, m->g_moe_h, m->g_moe_yg, m->g_moe_pos, m->g_moe_cnt};
     if (m->comm && m->comm_owned) mi355_comm_destroy(m->comm);
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete m;

@@ -97,7 +97,14 @@ __global__ void __launch_bounds__(256) moe_scatter_combine_kernel(float* __restr
 // pos[p] = ids[p] * cap + (number of earlier pairs of the same expert) -- stable, token order inside an expert.  Rows past an
 // expert's count are never written and never read back: the expert GEMMs run over all cap rows (rows are independent), the
 // combine reads only pos[].
-__global__ void __launch_bounds__(256) moe_group_kernel(int32_t* __restrict__ pos, const int32_t* __restrict__ ids, int pairs, int n_expert, int cap) {
+__global__ void __launch_bounds__(256) moe_group_kernel(int32_t* __restrict__ pos, int32_t* __restrict__ counts, const int32_t* __restrict__ ids,
+                                                        int pairs, int n_expert, int cap) {
+    if (counts)
+        for (int e = threadIdx.x; e < n_expert; e += blockDim.x) {
+            int n = 0;
+            for (int q = 0; q < pairs; ++q) n += ids[q] == e ? 1 : 0;
+            counts[e] = n;
+        }
     for (int p = threadIdx.x; p < pairs; p += blockDim.x) {
         const int e = ids[p];
         int before = 0;
@@ -111,10 +118,11 @@ __global__ void __launch_bounds__(256) moe_gather_pos_kernel(float* __restrict__
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i < hidden) *reinterpret_cast<float4*>(dst + (size_t)pos[p] * hidden + i) = *reinterpret_cast<const float4*>(src + (size_t)(p / K) * hidden + i);
 }
-extern "C" int mi355_moe_group(int32_t* pos, const int32_t* expert_ids, int32_t num_pairs, int32_t n_expert, int32_t cap, int64_t stream) {
+extern "C" int mi355_moe_group(int32_t* pos, int32_t* counts, const int32_t* expert_ids, int32_t num_pairs, int32_t n_expert, int32_t cap,
+                               int64_t stream) {
     if (num_pairs <= 0) return 0;
     if (!pos || !expert_ids || n_expert < 1 || cap < num_pairs || num_pairs > 4096) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(moe_group_kernel, dim3(1), dim3(256), 0, to_stream(stream), pos, expert_ids, num_pairs, n_expert, cap);
+    hipLaunchKernelGGL(moe_group_kernel, dim3(1), dim3(256), 0, to_stream(stream), pos, counts, expert_ids, num_pairs, n_expert, cap);
     return (int)hipGetLastError();
 }
 extern "C" int mi355_moe_gather_pos(float* dst, const float* src, const int32_t* pos, int32_t num_pairs, int32_t top_k, int32_t hidden,

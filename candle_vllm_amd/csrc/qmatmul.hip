@@ -209,6 +209,7 @@ struct QmmArgs {
     // id is read from device memory and selects the weight slab, its x row is pair / moe_xdiv, its out row is pair
     const int32_t* moe_expert;
     int32_t moe_pairs, moe_xdiv;
+    const int32_t* rows_dev; int32_t rows_min;   // wide path: no-op unless *rows_dev > rows_min (mi355_qmm_desc)
     int64_t moe_stride[3];    // bytes between consecutive experts of each segment
 };
 
@@ -1495,6 +1496,7 @@ struct QmgChainOut { uint8_t* img; float* ssp; const float* norm_w; int K, MT; s
 __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, const float* __restrict__ part, const int ldp,
                                                            const int ks, const int BP, const float* __restrict__ ssp,
                                                            const QmgChainOut ch, const float* __restrict__ rscale = nullptr) {
+    if (a.rows_dev && *a.rows_dev <= a.rows_min) return;
     const int prow = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     // deferred RMSNorm scale of this workgroup's token: the per-k-block partial sums are read by the lanes of one wave
@@ -2344,6 +2346,7 @@ static int qmm_args_from_desc(const mi355_qmm_desc* d, QmmArgs& a) {
     if ((a.epi == MI355_EPI_STORE || a.epi == MI355_EPI_RESID || a.epi == MI355_EPI_SILU_MUL) && !a.out)
         return (int)hipErrorInvalidValue;
     a.moe_expert = d->moe_expert_ids; a.moe_pairs = d->moe_pairs; a.moe_xdiv = d->moe_x_div;
+    a.rows_dev = d->rows_dev; a.rows_min = d->rows_min;
     for (int s = 0; s < 3; ++s) a.moe_stride[s] = d->moe_expert_stride[s];
     a.chain_next = (d->chain_next && !d->moe_expert_ids && d->num_tokens > 8 && d->num_tokens <= 8 * QMW_MAXMT) ? 1 : 0;
     a.next_k = d->chain_next_k; a.next_norm_w = d->chain_next_norm;

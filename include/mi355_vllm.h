@@ -220,6 +220,10 @@ typedef struct mi355_qmm_desc {
      * arguments match (it silently stages itself when they do not). */
     int32_t chain_next, chain_next_k;
     const float* chain_next_norm;
+    /* device-side gate (NULL = off; 9..32-token launches only): the launch is a no-op unless *rows_dev > rows_min -- a
+     * graph-captured MoE step launches one fixed-shape chunk per (expert, 32 rows) and the chunks no pair landed in fall through */
+    const int32_t* rows_dev;
+    int32_t rows_min;
 } mi355_qmm_desc;
 int mi355_qmatmul_fused(const mi355_qmm_desc* desc, int64_t stream);
 /* MoE routing on the device (MlpOrMoe::forward, quantized_llama.rs:56-123, without the host round trip):
@@ -238,10 +242,10 @@ int mi355_moe_combine(float* ys, const float* y_pairs, const float* weights, int
  * `inv` = its inverse.  gather: dst[p] = src[perm[p] / top_k] (f32 rows); scatter_combine: ys[t] += sum_j w[t,j] * y_sorted[inv[t*top_k+j]] */
 /* The same grouping decided on the device, for decode steps inside a captured graph (no host round trip, fixed launch shapes):
  * every expert owns `cap` rows (cap >= num_pairs) of the gathered buffers; mi355_moe_group writes pos[p] = expert_ids[p] * cap +
- * (earlier pairs of the same expert); mi355_moe_gather_pos copies token p / top_k into row pos[p]; the expert GEMMs then run over
+ * (earlier pairs of the same expert) and, when counts != NULL, the pairs per expert (the rows_dev gate of mi355_qmm_desc); mi355_moe_gather_pos copies token p / top_k into row pos[p]; the expert GEMMs then run over
  * all cap rows of every expert (rows are independent; unwritten rows are never read back) and mi355_moe_scatter_combine(inv = pos)
  * adds the weighted rows to the residual -- quantized_llama.rs:93-119 without `to_vec2`. */
-int mi355_moe_group(int32_t* pos, const int32_t* expert_ids, int32_t num_pairs, int32_t n_expert, int32_t cap, int64_t stream);
+int mi355_moe_group(int32_t* pos, int32_t* counts, const int32_t* expert_ids, int32_t num_pairs, int32_t n_expert, int32_t cap, int64_t stream);
 int mi355_moe_gather_pos(float* dst, const float* src, const int32_t* pos, int32_t num_pairs, int32_t top_k, int32_t hidden, int64_t stream);
 int mi355_moe_gather(float* dst, const float* src, const int32_t* perm, int32_t num_pairs, int32_t top_k, int32_t hidden, int64_t stream);
 int mi355_moe_scatter_combine(float* ys, const float* y_sorted, const float* weights, const int32_t* inv, int32_t num_tokens,

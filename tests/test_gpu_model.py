@@ -581,7 +581,9 @@ def test_moe_decode_experts_grouped_on_the_device(lib, B):
     ids = rng.integers(0, 4, 2 * B).astype(np.int32)
     d_ids = torch.from_numpy(ids).cuda()
     pos = torch.zeros(2 * B, dtype=torch.int32, device="cuda")
-    assert M.lib.mi355_moe_group(pos.data_ptr(), d_ids.data_ptr(), 2 * B, 4, 2 * B, 0) == 0
+    cnt = torch.zeros(4, dtype=torch.int32, device="cuda")
+    assert M.lib.mi355_moe_group(pos.data_ptr(), cnt.data_ptr(), d_ids.data_ptr(), 2 * B, 4, 2 * B, 0) == 0
     torch.cuda.synchronize()
     want = [int(e) * 2 * B + int((ids[:p] == e).sum()) for p, e in enumerate(ids)]
     assert pos.cpu().tolist() == want
+    assert cnt.cpu().tolist() == [int((ids == e).sum()) for e in range(4)]
