@@ -114,6 +114,9 @@ _sig("mi355_marlin_format_repack", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i6
 _sig("mi355_marlin_weight_perm", c_i32, [c_i32])
 _sig("mi355_marlin_zero_pos", c_i32, [c_i32])
 _sig("mi355_linear", ctypes.c_int, [c_vp] * 5 + [c_i32] * 5 + [c_i64])
+_sig("mi355_linear_tiled", ctypes.c_int, [c_vp] * 5 + [c_i32] * 5 + [c_i64])
+_sig("mi355_dense_tile_repack", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i64])
+_sig("mi355_dense_tile_index", ctypes.c_int64, [c_i32] * 4)
 _sig("mi355_gptq_linear", ctypes.c_int, [c_vp] * 5 + [c_i32, c_i32, c_vp, c_vp] + [c_i32] * 6 + [c_i64])
 _sig("mi355_gptq_linear_tiled", ctypes.c_int, [c_vp] * 5 + [c_i32, c_i32, c_vp, c_vp] + [c_i32] * 6 + [c_i64])
 _sig("mi355_gptq_tile_repack", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])

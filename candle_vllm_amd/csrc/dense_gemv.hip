@@ -33,6 +33,13 @@ __host__ __device__ __forceinline__ size_t gptq_tile_index(int kr, int n, int nk
     const int kb = kr >> 5, rem = kr & 31, j = rem >> 2, kg = rem & 3;
     return ((((size_t)(n >> 4) * nkb + kb) * 2 + (j >> 2)) * 64 + kg * 16 + (n & 15)) * 4 + (j & 3);
 }
+// 16-bit weights [N][K] in the same 16-row x 256-k tiles (element index): [tile n/16][k-block k/256][j = (k%256)/32][lane = 16*((k%32)/8) + n%16][k%8]
+// -- fragment j of a (tile, k-block) is 1 KiB contiguous, the whole (tile, k-block) 8 KiB; a row-major row tile is sixteen 512-byte
+// pieces 2 K bytes apart, and a wave instruction touches 16 rows x 64 B of it (measured: 3.9 TB/s at best from that pattern)
+__host__ __device__ __forceinline__ size_t dense_tile_index(int n, int k, int nkb) {
+    const int kb = k >> 8, kk = k & 255, j = kk >> 5, kg = (kk & 31) >> 3, e = kk & 7;
+    return (((((size_t)(n >> 4) * nkb + kb) * 8 + j) * 64 + kg * 16 + (n & 15)) << 3) + e;
+}
 enum { SP_NONE = 0, SP_GROUPED = 1, SP_SINGLE = 2 };
 
 // attention.rs:644-719 after the projections: q,k -> f32 -> rope -> model dtype, then the cache write of k and v
@@ -43,8 +50,9 @@ struct DenseRope {
     int32_t n_kv_heads, head_dim, block_size, flash;
 };
 struct DenseArgs {
-    const void* w;            // DENSE: 16-bit [N][ldw] ; GPTQ4: u32 [K/8][N]
+    const void* w;            // DENSE: 16-bit [N][ldw] (wtiled: the 16 x 256 tile image, dense_tile_index) ; GPTQ4: u32 [K/8][N]
     int32_t ldw;
+    int32_t wtiled;           // DENSE only: 1 = w is the tiled image (N % 16 == 0, K % 256 == 0; ldw unused)
     const void* scales;       // GPTQ4: 16-bit [K/g][N]
     const uint32_t* qzeros;   // packed zero points [K/g][N/8] or null
     int32_t zmode, sperm;     // MI355_ZERO_* ; SP_*
@@ -154,10 +162,13 @@ __device__ __forceinline__ void dense_body(const DenseArgs& a, const int bx) {
         if constexpr (WTYPE == DW_DENSE) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const uint16_t* wp = static_cast<const uint16_t*>(a.w) + (size_t)(row0[r] + r16) * a.ldw + (size_t)kb * 256 + 8 * kg;
+                // row-major: row r16 of the tile, 32 j + 8 kg inside the k-block; tiled: fragment j is 64 lanes x 16 B contiguous
+                const uint16_t* wp = a.wtiled ? static_cast<const uint16_t*>(a.w) + ((((size_t)(row0[r] >> 4) * nkb + kb) * 8) * 64 + lane) * 8
+                                              : static_cast<const uint16_t*>(a.w) + (size_t)(row0[r] + r16) * a.ldw + (size_t)kb * 256 + 8 * kg;
+                const int jstride = a.wtiled ? 512 : 32;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const dg_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const dg_u32x4*>(wp + 32 * j));
+                    const dg_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const dg_u32x4*>(wp + (size_t)j * jstride));
                     bw[r][j] = make_uint4(v.x, v.y, v.z, v.w);
                 }
             }
@@ -320,7 +331,10 @@ __global__ void __launch_bounds__(64 * NW) dense_wide_kernel(const DenseArgs a) 
     const uint16_t* x16 = static_cast<const uint16_t*>(a.x);
     const uint16_t* wrow[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) wrow[r] = static_cast<const uint16_t*>(a.w) + (size_t)(row0[r] + r16) * a.ldw + 8 * kg;
+    for (int r = 0; r < R; ++r)
+        wrow[r] = a.wtiled ? static_cast<const uint16_t*>(a.w) + (((size_t)(row0[r] >> 4) * nkb) * 512 + lane) * 8
+                           : static_cast<const uint16_t*>(a.w) + (size_t)(row0[r] + r16) * a.ldw + 8 * kg;
+    const int wkstride = a.wtiled ? 4096 : 256, wjstride = a.wtiled ? 512 : 32;      // elements per k-block / per fragment
 
     // ---- staging: MT * 512 pieces of 16 B per k-block over NW * 64 threads (piece p: row p / 32, 16-byte column p % 32)
     constexpr int XP = MT * 8 / NW;
@@ -338,11 +352,11 @@ __global__ void __launch_bounds__(64 * NW) dense_wide_kernel(const DenseArgs a) 
     // past the end: one 16-byte request per instruction (see dense_small_body)
 #define DWD_W_LOAD(SLOT_, KB_) do { \
         const bool ok_ = (KB_) < nkb; \
-        const size_t koff_ = ok_ ? (size_t)DWD_KB(KB_) * 256 : 0; \
+        const size_t koff_ = ok_ ? (size_t)DWD_KB(KB_) * wkstride : 0; \
         _Pragma("unroll") for (int r_ = 0; r_ < R; ++r_) { \
             const uint16_t* wp_ = (ok_ ? wrow[r_] : static_cast<const uint16_t*>(a.w)) + koff_; \
             _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) { \
-                const dg_u32x4 v_ = __builtin_nontemporal_load(reinterpret_cast<const dg_u32x4*>(wp_ + (ok_ ? 32 * j_ : 0))); \
+                const dg_u32x4 v_ = __builtin_nontemporal_load(reinterpret_cast<const dg_u32x4*>(wp_ + (ok_ ? wjstride * j_ : 0))); \
                 bw[SLOT_][r_][j_] = make_uint4(v_.x, v_.y, v_.z, v_.w); \
             } \
         } } while (0)
@@ -829,7 +843,7 @@ static int dense_launch_dt(const DenseArgs& a, hipStream_t st) {
         // enough row tiles for one tile (or gate/up pair) per wave on every CU: the LDS-shared-activation sweep
         const int wtiles = (pair ? a.pair_offset : a.N) / 16;
         if (!g_tune_wide_off && a.T > 4 && wtiles >= 4 * 192 && (!pair || mt <= 2) && !((uintptr_t)a.x & 15) && !(a.ldx & 7) &&
-            !((uintptr_t)a.w & 15) && !(a.ldw & 7)) {
+            !((uintptr_t)a.w & 15) && (a.wtiled || !(a.ldw & 7))) {
             const_cast<DenseArgs&>(a).dbg = g_tune_small_dbg;
             const int nwv = g_tune_wide_nw == 2 ? 2 : 4;
             const dim3 grid((wtiles + nwv - 1) / nwv), block(64 * nwv);
@@ -968,14 +982,25 @@ __global__ void __launch_bounds__(256, 2) dense_gemm_kernel(const DenseArgs a) {
         int t = t0 + row;
         if (t > a.T - 1) t = a.T - 1;
         asrc[r] = xb + ((size_t)t * a.ldx) * 2 + (size_t)((sslot ^ (row & 7)) * 16);
-        bsrc[r] = wb + ((size_t)wrow(row) * a.ldw) * 2 + (size_t)((sslot ^ (row & 7)) * 16);
+        if (a.wtiled) {
+            // the tiled image IS the fragment order: the B tile in LDS is a verbatim copy -- [n-tile 8][fragment 2][lane 64][16 B] --
+            // and every DMA instruction of a wave copies one contiguous KiB (piece p = 4 r + wave: n-tile p / 2, fragment p % 2 of
+            // this K step; 2 KiB per (n-tile, K step)).  (A first version kept the row-major LDS layout and gathered 16-byte chunks:
+            // 64 separate requests per instruction, prompt step 40.2 k -> 36.9 k tok/s.)
+            const int p = 4 * r + wave;
+            const int n = wrow(16 * (p >> 1));
+            bsrc[r] = wb + (((((size_t)(n >> 4) * (a.K >> 8)) * 8 + (p & 1)) * 64 + lane) << 4);
+        } else {
+            bsrc[r] = wb + ((size_t)wrow(row) * a.ldw) * 2 + (size_t)((sslot ^ (row & 7)) * 16);
+        }
     }
+    const size_t bstep = a.wtiled ? 2048 : DG_BK * 2;                   // bytes per K step on the weight side
     auto stage = [&](int kt, int buf) {
         const uint32_t base = lds0 + (uint32_t)buf * 32768u + (uint32_t)wave * 1024u;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             dgemm_dma<1>(asrc[r] + (size_t)kt * (DG_BK * 2), base + (uint32_t)r * 4096u);
-            dgemm_dma<1>(bsrc[r] + (size_t)kt * (DG_BK * 2), base + 16384u + (uint32_t)r * 4096u);
+            dgemm_dma<1>(bsrc[r] + (size_t)kt * bstep, base + 16384u + (uint32_t)r * 4096u);
         }
     };
     f32x4_t acc[4][4];
@@ -1005,7 +1030,9 @@ __global__ void __launch_bounds__(256, 2) dense_gemm_kernel(const DenseArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const uint4*>(A + (size_t)arow[i] * 128 + (size_t)(((s2 * 4 + kg) ^ (arow[i] & 7)) * 16));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const uint4*>(B + (size_t)brow[j] * 128 + (size_t)(((s2 * 4 + kg) ^ (brow[j] & 7)) * 16));
+            for (int j = 0; j < 4; ++j)
+                bf[j] = a.wtiled ? *reinterpret_cast<const uint4*>(B + (size_t)((((brow[j] >> 4) * 2 + s2) * 64 + kg * 16 + m16) * 16))
+                                 : *reinterpret_cast<const uint4*>(B + (size_t)brow[j] * 128 + (size_t)(((s2 * 4 + kg) ^ (brow[j] & 7)) * 16));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1049,7 +1076,7 @@ __global__ void __launch_bounds__(256, 2) dense_gemm_kernel(const DenseArgs a) {
 
 static int dense_prompt_gemm(const DenseArgs& a, int dt, hipStream_t st) {
     if (a.K % DG_BK || a.T < 1 || a.N < 1) return (int)hipErrorNotSupported;
-    if ((a.ldx * 2) % 16 || (a.ldw * 2) % 16) return (int)hipErrorNotSupported;          // 16-byte DMA pieces
+    if ((a.ldx * 2) % 16 || (!a.wtiled && (a.ldw * 2) % 16)) return (int)hipErrorNotSupported;          // 16-byte DMA pieces
     if (a.epi == MI355_EPI_SILU_MUL && (a.pair_offset <= 0 || a.N != 2 * a.pair_offset)) return (int)hipErrorNotSupported;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1088,6 +1115,17 @@ static int dense_run(DenseArgs a, int wtype, int dt, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------ K15 repack
+// 16-bit [N][ld_in] row-major -> the tiled image (dense_tile_index): one thread per 16-byte chunk of the output
+__global__ void __launch_bounds__(256) dense_tile_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int N, int K, int64_t ld_in) {
+    const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;                 // chunk index = (((tile * nkb + kb) * 8 + j) * 64 + lane)
+    const int nkb = K >> 8;
+    if (o >= (size_t)(N >> 4) * nkb * 512) return;
+    const int lane = (int)(o & 63), j = (int)((o >> 6) & 7);
+    const size_t tk = o >> 9;
+    const int kb = (int)(tk % nkb), tile = (int)(tk / nkb);
+    const int n = tile * 16 + (lane & 15), k = kb * 256 + j * 32 + (lane >> 4) * 8;
+    *reinterpret_cast<uint4*>(out + o * 8) = *reinterpret_cast<const uint4*>(in + (size_t)n * ld_in + k);
+}
 // checkpoint layout [K/8][n_in] (columns [0, n_in)) -> tiles tile0 .. of the tiled image (gptq_tile_index); K % 256 == 0, n_in % 16 == 0
 __global__ void gptq_tile_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int K, int n_in, int tile0) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1367,6 +1405,36 @@ int32_t mi355_marlin_zero_pos(int32_t n) {
     return (p1 & ~7) + (((u & 1) << 2) | (u >> 1));
 }
 
+/* 16-bit weights [n][k] (row stride ld_in elements) -> the 16-row x 256-k tile image mi355_linear_tiled streams; in != out */
+int mi355_dense_tile_repack(const void* in, void* out, int32_t n, int32_t k, int64_t ld_in, int64_t stream) {
+    if (!in || !out || in == out || n <= 0 || k <= 0 || (n & 15) || (k & 255) || ld_in < k || (ld_in & 7) || ((uintptr_t)in & 15) || ((uintptr_t)out & 15))
+        return (int)hipErrorInvalidValue;
+    const size_t chunks = (size_t)(n >> 4) * (k >> 8) * 512;
+    hipLaunchKernelGGL(dense_tile_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const uint16_t*>(in), static_cast<uint16_t*>(out), n, k, ld_in);
+    return (int)hipGetLastError();
+}
+/* host statement of the tile order (element index of w[n][k]; -1 for a shape that is not tiled) */
+int64_t mi355_dense_tile_index(int32_t n_row, int32_t k_col, int32_t n, int32_t k) {
+    if (n <= 0 || k <= 0 || (n & 15) || (k & 255) || n_row < 0 || n_row >= n || k_col < 0 || k_col >= k) return -1;
+    return (int64_t)dense_tile_index(n_row, k_col, k >> 8);
+}
+static int linear_impl(int tiled, void* out, const void* x, const void* w, const void* bias, const void* residual, int32_t num_tokens,
+                       int32_t n, int32_t k, int32_t dtype, int32_t epilogue, int64_t stream) {
+    if (tiled && ((n & 15) || (k & 255))) return -2;
+    DenseArgs a{};
+    a.w = w; a.ldw = k; a.wtiled = tiled;
+    a.x = x; a.ldx = k; a.T = num_tokens; a.K = k; a.N = n;
+    a.bias = bias; a.resid = residual; a.epi = epilogue; a.out = out;
+    if (epilogue == MI355_EPI_SILU_MUL) { a.pair_offset = n / 2; a.ldo = n / 2; } else a.ldo = n;
+    if (epilogue == MI355_EPI_RESID && !residual) return -2;
+    return dense_run(a, DW_DENSE, dtype, (hipStream_t)stream);
+}
+/* `Linear::forward` over the tiled weight image (mi355_dense_tile_repack); everything else as mi355_linear */
+int mi355_linear_tiled(void* out, const void* x, const void* w_tiled, const void* bias, const void* residual, int32_t num_tokens,
+                       int32_t n, int32_t k, int32_t dtype, int32_t epilogue, int64_t stream) {
+    return linear_impl(1, out, x, w_tiled, bias, residual, num_tokens, n, k, dtype, epilogue, stream);
+}
 int mi355_linear(void* out, const void* x, const void* w, const void* bias, const void* residual, int32_t num_tokens,
                  int32_t n, int32_t k, int32_t dtype, int32_t epilogue, int64_t stream) {
     DenseArgs a{};
@@ -1445,10 +1513,10 @@ int mi355_internal_linear3(void* const* outs, const void* x, const void* const* 
     for (int i = 0; i < 3; ++i) {
         if (!ws[i] || !outs[i] || ns[i] <= 0 || (ns[i] & 15)) return -4;
         a[i] = DenseArgs{};
-        a[i].w = ws[i]; a[i].ldw = k; a[i].x = x; a[i].ldx = k; a[i].T = num_tokens; a[i].K = k; a[i].N = ns[i];
+        a[i].w = ws[i]; a[i].ldw = k; a[i].wtiled = is_gptq == 3 ? 1 : 0; a[i].x = x; a[i].ldx = k; a[i].T = num_tokens; a[i].K = k; a[i].N = ns[i];
         a[i].bias = biases ? biases[i] : nullptr; a[i].epi = MI355_EPI_STORE; a[i].out = outs[i]; a[i].ldo = ns[i];
         a[i].norm_w = norm_w; a[i].norm_eps = norm_eps; a[i].ss_in = ss_in;
-        if (is_gptq) {
+        if (is_gptq == 1 || is_gptq == 2) {
             a[i].scales = scales[i]; a[i].qzeros = nullptr; a[i].zmode = MI355_ZERO_SYM8;
             a[i].group_size = (group_size <= 0 || group_size > k) ? k : group_size;
             a[i].sperm = SP_NONE;
@@ -1457,10 +1525,10 @@ int mi355_internal_linear3(void* const* outs, const void* x, const void* const* 
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MI355_DTYPE_BF16)
         return is_gptq == 2 ? dense3_launch_dt<MI355_DTYPE_BF16, DW_GPTQ4T>(a, rp, st)
-               : is_gptq ? dense3_launch_dt<MI355_DTYPE_BF16, DW_GPTQ4>(a, rp, st) : dense3_launch_dt<MI355_DTYPE_BF16, DW_DENSE>(a, rp, st);
+               : is_gptq == 1 ? dense3_launch_dt<MI355_DTYPE_BF16, DW_GPTQ4>(a, rp, st) : dense3_launch_dt<MI355_DTYPE_BF16, DW_DENSE>(a, rp, st);
     if (dtype == MI355_DTYPE_F16)
         return is_gptq == 2 ? dense3_launch_dt<MI355_DTYPE_F16, DW_GPTQ4T>(a, rp, st)
-               : is_gptq ? dense3_launch_dt<MI355_DTYPE_F16, DW_GPTQ4>(a, rp, st) : dense3_launch_dt<MI355_DTYPE_F16, DW_DENSE>(a, rp, st);
+               : is_gptq == 1 ? dense3_launch_dt<MI355_DTYPE_F16, DW_GPTQ4>(a, rp, st) : dense3_launch_dt<MI355_DTYPE_F16, DW_DENSE>(a, rp, st);
     return -4;
 }
 

@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstring>
 #include <algorithm>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/mi355_vllm.h"
@@ -37,6 +38,7 @@ extern "C" int mi355_internal_gptq_small_linear(void* out, const void* x, const 
                                                 int32_t epilogue, int64_t stream);
 
 namespace {
+int g_dense_tile = 1;          // tuning key 42: 0 = the 16-bit host layer keeps its projections row-major (A/B; read at the first step)
 
 #define DCHECK(expr) do { const int rc_ = (expr); if (rc_ != 0) return rc_; } while (0)
 #define DHIP(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -62,6 +64,9 @@ struct DModel {
     int cap = 0;
     uint16_t *xs = nullptr, *xn = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *attn = nullptr, *h = nullptr, *lg16 = nullptr;
     float *pa_tmp = nullptr, *pa_max = nullptr, *pa_sum = nullptr;
+    // 16-bit projections re-ordered into 16-row x 256-k tiles (mi355_dense_tile_repack) before the first step: the pointers in here
+    std::unordered_set<const void*> tiled;
+    bool finalized = false;
     float* ss = nullptr;                  // [4][hidden / 16] sums of squares of the residual stream's rows, per 16-column tile: left by
                                           // the 1..4-token 4-bit launch that wrote xs, read by the next one that norms it
     int pa_cap_partitions = 0;
@@ -142,7 +147,41 @@ int linear(const DModel* m, const uint16_t* w, const QLin& g, void* out, const v
     if (g.qw)
         return mi355_gptq_linear_tiled(out, x, g.qw, g.scales, nullptr, MI355_ZERO_SYM8, 0, bias, resid, T, n, k, g.group, m->cfg.dtype, epi, stream);
     if (!w) return (int)hipErrorInvalidValue;
+    if (m->tiled.count(w)) return mi355_linear_tiled(out, x, w, bias, resid, T, n, k, m->cfg.dtype, epi, stream);
     return mi355_linear(out, x, w, bias, resid, T, n, k, m->cfg.dtype, epi, stream);
+}
+
+// Before the first step: every 16-bit projection whose shape allows it (n % 16 == 0, k % 256 == 0) is re-ordered into the tile
+// image the streaming kernels and the prompt GEMM read as contiguous KiB (row-major rows bound the weight stream at 3.9 TB/s:
+// DESIGN.md section 4).  q, k and v together or not at all (they share one launch).  Weights are frozen from here on.
+int tile_one(DModel* m, uint16_t** w, int n, int k) {
+    if (!*w || m->tiled.count(*w) || (n & 15) || (k & 255)) return 0;
+    uint16_t* t = nullptr;
+    DHIP(hipMalloc((void**)&t, (size_t)n * k * 2));
+    int rc = mi355_dense_tile_repack(*w, t, n, k, k, 0);
+    if (!rc) rc = (int)hipDeviceSynchronize();
+    if (rc) { (void)hipFree(t); return rc; }
+    (void)hipFree(*w);
+    *w = t;
+    m->tiled.insert(t);
+    return 0;
+}
+int finalize_weights(DModel* m) {
+    if (m->finalized) return 0;
+    const mi355_dense_config& c = m->cfg;
+    const int hid = c.hidden, HD = c.n_heads * c.head_dim, KD = c.n_kv_heads * c.head_dim, I = c.intermediate;
+    if (!g_dense_tile) { m->finalized = true; return 0; }
+    for (auto& L : m->layers) {
+        if (L.wq && L.wk && L.wv && !(HD & 15) && !(KD & 15) && !(hid & 255)) {
+            DCHECK(tile_one(m, &L.wq, HD, hid)); DCHECK(tile_one(m, &L.wk, KD, hid)); DCHECK(tile_one(m, &L.wv, KD, hid));
+        }
+        DCHECK(tile_one(m, &L.wo, hid, HD));
+        DCHECK(tile_one(m, &L.gate_up, 2 * I, hid));
+        DCHECK(tile_one(m, &L.w2, hid, I));
+    }
+    DCHECK(tile_one(m, &m->output, c.vocab, hid));
+    m->finalized = true;
+    return 0;
 }
 
 // xs += x . w^T (the residual epilogue of o_proj / down_proj).  With 4-bit weights and 1..4 tokens the launch also leaves the sums
@@ -171,6 +210,8 @@ int choose_partition(int batch, int kv_heads, int ctx_cap) {
 }  // namespace
 
 extern "C" {
+
+void mi355_dense_set_tile(int v) { g_dense_tile = v; }
 
 void* mi355_dense_create(const mi355_dense_config* cfg) {
     if (!cfg || cfg->hidden <= 0 || (cfg->hidden % 256) || (cfg->intermediate % 256) || cfg->n_layers <= 0 ||
@@ -258,6 +299,7 @@ static int dense_set_weight_impl(void* mp, int32_t layer, int32_t which, const v
         }
     }
     if (n_elems != expect) return (int)hipErrorInvalidValue;
+    if (*slot && m->tiled.count(*slot)) return (int)hipErrorInvalidValue;      // re-ordered at the first step: weights are frozen
     if (total == 0) total = expect;
     if (!*slot) DHIP(hipMalloc((void**)slot, (size_t)total * 2));
     DHIP(hipMemcpy(*slot + offset, host, (size_t)n_elems * 2, kind));
@@ -364,6 +406,7 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
     const bool prefill = cu_seqlens_q != nullptr;
     if (!prefill && num_tokens != num_seqs) return (int)hipErrorInvalidValue;
     DCHECK(ensure_cap(m, num_tokens));
+    DCHECK(finalize_weights(m));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int T = num_tokens, H = c.n_heads, Hkv = c.n_kv_heads, D = c.head_dim, hid = c.hidden, I = c.intermediate;
     const int dt = c.dtype;
@@ -407,7 +450,7 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
                     DCHECK(norm(m, m->xn, m->xs, L.attn_norm, L.attn_norm_b, T, stream));
                     normed = true;
                     for (int pass = rope_ok ? 0 : 1; pass < 2 && rc3 != 0; ++pass) {
-                        rc3 = mi355_internal_linear3(outs, m->xn, ws, sc, bs, ns, T, hid, gq.group, all_q ? 2 : 0, m->cfg.dtype, nullptr, 0.f, nullptr,
+                        rc3 = mi355_internal_linear3(outs, m->xn, ws, sc, bs, ns, T, hid, gq.group, all_q ? 2 : (m->tiled.count(L.wq) ? 3 : 0), m->cfg.dtype, nullptr, 0.f, nullptr,
                                                      pass == 0 ? &rp : nullptr, stream);
                         if (rc3 != 0 && rc3 != -4) return rc3;
                         roped = rc3 == 0 && pass == 0;
@@ -514,12 +557,12 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
     DCHECK(norm(m, m->xn, last, m->output_norm, m->output_norm_b, num_seqs, stream));
     if (m->comm) {                                                          // VocabParallelLinear (distributed.rs:1632-1667)
         const int W = c.tp_world > 1 ? c.tp_world : 1;
-        DCHECK(mi355_linear(m->lg16, m->xn, m->output, nullptr, nullptr, num_seqs, c.vocab, hid, dt, MI355_EPI_STORE, stream));
+        DCHECK(linear(m, m->output, QLin{}, m->lg16, m->xn, nullptr, nullptr, num_seqs, c.vocab, hid, MI355_EPI_STORE, stream));
         DCHECK(mi355_comm_all_gather(m->comm, m->lg16, m->lg_gather, (int64_t)num_seqs * c.vocab, dt, stream));
         hipLaunchKernelGGL(gather_transpose16_kernel, dim3(512), dim3(256), 0, st, m->lg16, m->lg_gather, W, num_seqs, c.vocab);
         return mi355_cast(logits, m->lg16, (int64_t)num_seqs * c.vocab * W, dt, MI355_DTYPE_F32, stream);
     }
-    DCHECK(mi355_linear(m->lg16, m->xn, m->output, nullptr, nullptr, num_seqs, c.vocab, hid, dt, MI355_EPI_STORE, stream));
+    DCHECK(linear(m, m->output, QLin{}, m->lg16, m->xn, nullptr, nullptr, num_seqs, c.vocab, hid, MI355_EPI_STORE, stream));
     return mi355_cast(logits, m->lg16, (int64_t)num_seqs * c.vocab, dt, MI355_DTYPE_F32, stream);
 }
 

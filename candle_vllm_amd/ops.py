@@ -461,9 +461,17 @@ class Linear:
     """`Linear` of src/openai/models/linear.rs:64-172: y = x.W^T (+b), weight [out, in] as stored in the checkpoint.
     epilogue (decode fusions): EPI_STORE, EPI_RESID (y + residual), EPI_SILU_MUL (packed gate_up, mlp.rs:324-352)."""
 
-    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
-        self.weight, self.bias = weight, bias
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, tiled: bool = False):
+        """tiled=True: keep the weight as the 16-row x 256-k tile image (mi355_dense_tile_repack; n % 16 == 0, k % 256 == 0), as the
+        16-bit host layer does with its projections"""
+        self.bias = bias
         self.n, self.k = weight.shape
+        self.tiled = bool(tiled)
+        if self.tiled:
+            t = torch.empty_like(weight)
+            _check(lib.mi355_dense_tile_repack(_dev(weight), _dev(t), self.n, self.k, self.k, _stream()), "dense_tile_repack")
+            weight = t
+        self.weight = weight
 
     def forward(self, x, *, epilogue=EPI_STORE, residual=None, out=None):
         dt = _dt16(x)
@@ -474,9 +482,9 @@ class Linear:
         n_out = self.n // 2 if epilogue == EPI_SILU_MUL else self.n
         if out is None:
             out = torch.empty((T, n_out), dtype=x.dtype, device=x.device)
-        _check(lib.mi355_linear(_dev(out), _dev(x2), _dev(self.weight), _dev(self.bias) if self.bias is not None else None,
-                                _dev(residual) if residual is not None else None, T, self.n, self.k, dt, epilogue,
-                                _stream()), "linear")
+        fn = lib.mi355_linear_tiled if self.tiled else lib.mi355_linear
+        _check(fn(_dev(out), _dev(x2), _dev(self.weight), _dev(self.bias) if self.bias is not None else None,
+                  _dev(residual) if residual is not None else None, T, self.n, self.k, dt, epilogue, _stream()), "linear")
         return out
 
 

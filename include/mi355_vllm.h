@@ -337,6 +337,15 @@ int32_t mi355_marlin_zero_pos(int32_t n);
  * silu(gate)*up with candle's per-op rounding).  Every op result is rounded to `dtype` as candle does. */
 int mi355_linear(void* out, const void* x, const void* w, const void* bias, const void* residual, int32_t num_tokens,
                  int32_t n, int32_t k, int32_t dtype, int32_t epilogue, int64_t stream);
+/* The same op over the TILED weight image: w [n][k] re-ordered once at load time into 16-row x 256-k tiles, element (n, k) at
+ *   ((((n/16) * (k_total/256) + k/256) * 8 + (k%256)/32) * 64 + 16 * ((k%32)/8) + n%16) * 8 + k%8
+ * -- the MFMA fragment order: fragment j of a (tile, k-block) is 1 KiB contiguous (a row-major tile is sixteen 512-byte pieces
+ * 2 k bytes apart; measured bound of that pattern: 3.9 TB/s).  n % 16 == 0, k % 256 == 0.  The host layer (mi355_dense_*) keeps
+ * its 16-bit projections in this form.  mi355_dense_tile_repack: device to device, in != out, row stride ld_in elements. */
+int mi355_linear_tiled(void* out, const void* x, const void* w_tiled, const void* bias, const void* residual, int32_t num_tokens,
+                       int32_t n, int32_t k, int32_t dtype, int32_t epilogue, int64_t stream);
+int mi355_dense_tile_repack(const void* in, void* out, int32_t n, int32_t k, int64_t ld_in, int64_t stream);
+int64_t mi355_dense_tile_index(int32_t n_row, int32_t k_col, int32_t n, int32_t k);
 /* `QLinear::forward` GPTQ arm (linear.rs:854-906) with the same fused epilogues; qweight [k/8, n] u32. */
 int mi355_gptq_linear(void* out, const void* x, const void* qweight, const void* scales, const void* qzeros,
                       int32_t zero_mode, int32_t scales_permuted, const void* bias, const void* residual,

@@ -127,3 +127,21 @@ def test_gptq_tile_order_host_statement(lib):
     assert lib.mi355_gptq_tile_index(32, 0, K, N) == 512 and lib.mi355_gptq_tile_index(0, 16, K, N) == 512 * (K // 256)
     assert lib.mi355_gptq_tile_index(0, 0, 128, N) == -1 and lib.mi355_gptq_tile_index(0, 0, K, 40) == -1
     assert lib.mi355_gptq_tile_index(K // 8, 0, K, N) == -1 and lib.mi355_gptq_tile_index(0, N, K, N) == -1
+
+
+def test_dense_tile_order_host_statement(lib):
+    """the 16-row x 256-k tile order of the 16-bit host layer's projections: the library's index function == the numpy
+    statement (oracle/gptq.py dense_tile), a permutation of the elements; other shapes are not tiled"""
+    N, K = 48, 512
+    w = np.arange(N * K, dtype=np.uint32).reshape(N, K)
+    tiled = G.dense_tile(w)
+    rng = np.random.default_rng(3)
+    for n, k in [(0, 0), (0, 7), (0, 8), (1, 0), (0, 32), (0, 256), (16, 0), (47, 511)] + [(int(a), int(b)) for a, b in zip(rng.integers(0, N, 200), rng.integers(0, K, 200))]:
+        assert tiled[lib.mi355_dense_tile_index(n, k, N, K)] == w[n, k]
+    assert sorted(tiled.tolist()) == list(range(N * K))
+    # fragment j of a (tile, k-block): 64 lanes x 8 elements contiguous; lane = 16 * k-group + row
+    assert lib.mi355_dense_tile_index(1, 0, N, K) == 8 and lib.mi355_dense_tile_index(0, 8, N, K) == 128
+    assert lib.mi355_dense_tile_index(0, 32, N, K) == 512 and lib.mi355_dense_tile_index(0, 256, N, K) == 4096
+    assert lib.mi355_dense_tile_index(16, 0, N, K) == 4096 * (K // 256)
+    assert lib.mi355_dense_tile_index(0, 0, 40, K) == -1 and lib.mi355_dense_tile_index(0, 0, N, 128) == -1
+    assert lib.mi355_dense_tile_index(N, 0, N, K) == -1 and lib.mi355_dense_tile_index(0, K, N, K) == -1

@@ -305,3 +305,39 @@ def test_wide_16bit_kernel_many_row_tiles(cv, dt, T, N, K, pair):
     finally:
         lib.mi355_set_tuning(37, 0)
     check_ulp(y0, ref, dt, ulps=ulps, what="K-split kernel", mag=mag)
+
+
+def test_dense_tile_repack_bit_exact(cv):
+    from candle_vllm_amd import lib
+    rng = np.random.default_rng(8)
+    N, K = 64, 768
+    w = rng.integers(0, 2 ** 16, (N, K), dtype=np.uint16)
+    d_in = torch.from_numpy(w.view(np.int16)).cuda()
+    d_out = torch.zeros_like(d_in)
+    assert lib.mi355_dense_tile_repack(d_in.data_ptr(), d_out.data_ptr(), N, K, K, 0) == 0
+    torch.cuda.synchronize()
+    assert (d_out.cpu().numpy().view(np.uint16).reshape(-1) == G.dense_tile(w)).all()
+    assert lib.mi355_dense_tile_repack(d_in.data_ptr(), d_out.data_ptr(), 40, K, K, 0) != 0      # n % 16
+    assert lib.mi355_dense_tile_repack(d_in.data_ptr(), d_out.data_ptr(), N, 128, 128, 0) != 0    # k % 256
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("T,N,K,pair", [(1, 64, 512, False), (8, 128, 256, False), (33, 96, 768, False), (64, 32, 512, False),
+                                        (32, 12304, 512, False), (20, 12320, 256, True), (3, 96, 512, True),
+                                        (130, 208, 512, False), (257, 336, 1024, True), (97, 144, 256, False)])
+def test_linear_over_the_tiled_weight_image(cv, dt, T, N, K, pair):
+    """mi355_linear_tiled through all three 16-bit kernels (K-split streaming kernel, LDS-shared-activation kernel at >= 768 row tiles,
+    128 x 128 MFMA GEMM from 96 tokens) == the oracle == the row-major result to the same bound"""
+    rng = np.random.default_rng(T * 7 + N + K)
+    x = G.round_dt(rng.normal(0, 1, (T, K)), dt)
+    if pair:
+        w = G.round_dt(rng.normal(0, 0.06, (2 * N, K)), dt)
+        gu = G.linear16(x, w, None, dt)
+        ref, ulps, kw = G.silu_mul16(gu[:, :N], gu[:, N:], dt), 3.0, {"epilogue": cv.EPI_SILU_MUL}
+    else:
+        w = G.round_dt(rng.normal(0, 0.05, (N, K)), dt)
+        ref, ulps, kw = G.linear16(x, w, None, dt), 1.01, {}
+    for tiled in (True, False):
+        lin = cv.Linear(dev16(w, dt), tiled=tiled)
+        y = host16(lin.forward(dev16(x, dt), **kw), dt)
+        check_ulp(y, ref, dt, ulps=ulps, what=f"linear tiled={tiled}")
