@@ -108,6 +108,7 @@ _sig("gemm_half_q_half_alt", None, [c_vp] * 6 + [c_i32] * 4 + [c_i64])
 _sig("gptq_repack", None, [c_vp, c_vp, c_i32, c_i32, c_i64])
 _sig("awq_repack", None, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
 _sig("mi355_marlin_scale_pos", c_i32, [c_i32, c_i32])
+_sig("mi355_get_tuning", c_i32, [c_i32])
 _sig("mi355_last_error", ctypes.c_int, [])
 _sig("mi355_clear_error", None, [])
 _sig("mi355_marlin_format_repack", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64])

@@ -1996,7 +1996,16 @@ extern "C" void mi355_dense_set_tile(int v);
 static int g_tune_actq8 = 0;                               // mi355_set_tuning(18, 1): EXPERIMENT, single-token launches quantise x to Q8_K (reference CPU numerics, O2)
 static int g_tune_nw = 0, g_tune_r = 0;                   // 0 = heuristic; mi355_set_tuning (experiments only)
 static int g_tune_prefill_gemm = 1;                        // 0 = always stream the quantised weights (experiments)
+// what every key currently holds (INT32_MIN: never set = the default): lets a caller restore exactly what it found
+// (candle_vllm_amd.tuning(key, value) is the scoped form the tests use)
+static int32_t g_tune_shadow[64];
+static bool g_tune_shadow_set[64];
+extern "C" int32_t mi355_get_tuning(int32_t key) {
+    if (key < 0 || key >= 64 || !g_tune_shadow_set[key]) return INT32_MIN;
+    return g_tune_shadow[key];
+}
 extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
+    if (key >= 0 && key < 64) { g_tune_shadow[key] = value; g_tune_shadow_set[key] = true; }
     if (key == 0) g_tune_nw = value;
     else if (key == 1) g_tune_r = value;
     else if (key == 2) g_tune_dbg = value;

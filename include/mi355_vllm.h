@@ -258,8 +258,16 @@ int mi355_moe_scatter_combine(float* ys, const float* y_sorted, const float* wei
  * prompt-step GEMM variant / minimum tokens, 14 one launch for a Q4_K + Q6_K pair of runs (1 on), 15 16-wave workgroups
  * on the wide path for launches of >= n units (0 off), 17 fewest k-blocks per k-split, 18 EXPERIMENT: single-token launches
  * quantise x to Q8_K and take integer dot products (the reference CPU's numerics, oracle O2; default 0 = f32-accurate
- * activations, oracle O1); probe mode 7 = per-wave timestamps (below) */
+ * activations, oracle O1); probe mode 7 = per-wave timestamps (below); 20-23 the LDS-DMA engine / chained launch experiments (probe
+ * builds); 24 "exact" activations on the 9..32-token and prompt paths (f16 hi + lo planes instead of one plane); 30 / 35 waves per
+ * workgroup of the 1..4-token 4-bit kernel (hidden-sized K / long K), 31 that kernel off, 32 no norm on the way in, 34 RoPE and
+ * cache write in their own launch, 36 tokens from which 16-bit projections take the MFMA GEMM (96), 37 the LDS-shared-activation
+ * 16-bit kernel off, 38 its waves per workgroup (2 | 4), 41 MoE decode grouping on the device (1 on), 42 16-bit host layer keeps its
+ * projections in tiles (1 on; read at the first step).  A/B switches for measurements and tests: no product path depends on a
+ * non-default value.  mi355_get_tuning returns what a key was last set to (INT32_MIN: never set), so a caller can restore what it
+ * found instead of assuming the default. */
 void mi355_set_tuning(int32_t key, int32_t value);
+int32_t mi355_get_tuning(int32_t key);
 /* experiments only: device buffer of uint64 [workgroup][16 waves][4] that the 1..8-token mat-vec fills with wall-clock
  * stamps (entry, main loop done, past the barrier, exit) while probe mode 7 is set (probe builds only); NULL switches it off */
 int mi355_debug_set_timestamps(void* dev_ptr);

@@ -282,8 +282,8 @@ class Pair:
             return float((excess.max(axis=1) / np.abs(ref2).max(axis=1)).max())
         slots = np.asarray(meta["slot_mapping"], np.int64)
         worst = {"q_excess": 0.0, "kv_excess": 0.0, "q_flip_frac": 0.0, "attn": 0.0, "wo": 0.0, "gate_up": 0.0, "down": 0.0}
-        lib.mi355_set_tuning(9, 0)
-        try:
+        from candle_vllm_amd import tuning
+        with tuning(9, 0):
             for l in range(NL):
                 up(p_xs, tr_xs[l]); run(l, 0)
                 q_got = O.bf16_bits_to_f32(down(p_q, (B, HD), np.uint16))
@@ -312,8 +312,6 @@ class Pair:
                 out = down(p_xs, (B, hid), np.float32)
                 add = np.abs(tr_xs[l + 1] - tr_mid[l]).max(axis=1)
                 worst["down"] = max(worst["down"], float((np.abs(out - tr_xs[l + 1]).max(axis=1) / add).max()))
-        finally:
-            lib.mi355_set_tuning(9, 1)
         worst.update({"batch": B, "ctx_max": int(max(seq_lens)), "oracle": "O1 (unpinned)" if int(o2) == 0 else "O1f (unpinned)",
                       "units": "q/kv_excess: error beyond one bf16 ulp of the element, relative to the row's largest value; attn: bf16 "
                                "ulps of the row's largest output; wo/gate_up/down: relative to what the group adds / produces"})

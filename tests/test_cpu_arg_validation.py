@@ -125,3 +125,24 @@ def test_constructors_refuse_bad_configurations(L):
     assert lib.mi355_comm_all_gather(None, ctypes.addressof(one), ctypes.addressof(one), 1, F32, 0) != 0
     lib.mi355_comm_destroy(None)
     assert lib.mi355_llama_set_comm(None, None) != 0
+
+
+def test_scoped_tuning_restores_what_it_found(lib):
+    """candle_vllm_amd.tuning(key, value): the key holds the value inside the block and what it held before afterwards, also when
+    the block raises (the A/B switches are process-global state of the library)"""
+    from candle_vllm_amd import tuning
+    assert lib.mi355_get_tuning(63) == -2 ** 31                   # never set
+    with tuning(63, 5):
+        assert lib.mi355_get_tuning(63) == 5
+        with tuning(63, 7):
+            assert lib.mi355_get_tuning(63) == 7
+        assert lib.mi355_get_tuning(63) == 5
+    assert lib.mi355_get_tuning(63) == 0                          # default of an unlisted key
+    try:
+        with tuning(41, 0):
+            assert lib.mi355_get_tuning(41) == 0
+            raise ValueError
+    except ValueError:
+        pass
+    assert lib.mi355_get_tuning(41) == 1                          # restored to its (non-zero) default
+    assert lib.mi355_get_tuning(-1) == -2 ** 31 and lib.mi355_get_tuning(64) == -2 ** 31

@@ -139,11 +139,9 @@ def test_qwen2_gptq_shape_prompt_then_decode(lib, flash):
         dmeta = O.prepare_decode(seqs, cfg.block_size)
         ref = orc.forward(dmeta, cache)
         got = gm.forward(dmeta).cpu().numpy()
-        M.lib.mi355_set_tuning(32, 1); M.lib.mi355_set_tuning(34, 1)
-        try:
+        from candle_vllm_amd import tuning
+        with tuning(32, 1), tuning(34, 1):
             got2 = gm2.forward(dmeta).cpu().numpy()
-        finally:
-            M.lib.mi355_set_tuning(32, 0); M.lib.mi355_set_tuning(34, 0)
         assert _rel(got, ref) < 2e-2, (step, _rel(got, ref))
         assert _rel(got2, ref) < 2e-2, (step, _rel(got2, ref))
         assert [int(r.argmax()) for r in got] == [int(r.argmax()) for r in ref]

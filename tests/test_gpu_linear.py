@@ -270,11 +270,9 @@ def test_small_batch_4bit_kernel_shapes(cv, T, N, K, gs, tiled):
     ref = G.gptq_linear(x, G.gptq_dequant(q, s, None, gs), None, "bf16")
     y = host16(lin.forward(dev16(x, "bf16")), "bf16")
     check_ulp(y, ref, "bf16", what="1..4-token kernel")
-    lib.mi355_set_tuning(31, 1)
-    try:
+    from candle_vllm_amd import tuning
+    with tuning(31, 1):
         y0 = host16(lin.forward(dev16(x, "bf16")), "bf16")
-    finally:
-        lib.mi355_set_tuning(31, 0)
     check_ulp(y0, ref, "bf16", what="16-token-tile kernel")
 
 
@@ -299,11 +297,9 @@ def test_wide_16bit_kernel_many_row_tiles(cv, dt, T, N, K, pair):
     kw = {"epilogue": cv.EPI_SILU_MUL} if pair else {}
     y = host16(lin.forward(dev16(x, dt), **kw), dt)
     check_ulp(y, ref, dt, ulps=ulps, what="wide 16-bit kernel", mag=mag)
-    lib.mi355_set_tuning(37, 1)
-    try:
+    from candle_vllm_amd import tuning
+    with tuning(37, 1):
         y0 = host16(lin.forward(dev16(x, dt), **kw), dt)
-    finally:
-        lib.mi355_set_tuning(37, 0)
     check_ulp(y0, ref, dt, ulps=ulps, what="K-split kernel", mag=mag)
 
 

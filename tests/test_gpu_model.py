@@ -461,13 +461,13 @@ def test_long_prompt_uses_the_gemm_path_and_matches(lib):
     meta = O.prepare_prompt(seqs, cfg.block_size)
     ref = orc.forward(meta, orc.new_cache(16), is_prefill=True)
     outs = []
+    from candle_vllm_amd import tuning
     for use_gemm in (1, 0):
-        M.lib.mi355_set_tuning(6, use_gemm)
         gm = M.GGUFLLaMa(cfg, max_batch=4, kv_layout=M.KV_PAGED)
         gm.load_oracle_weights(W)
         gm.alloc_kv_cache(16)
-        outs.append(gm.forward_prefill(meta).cpu().numpy())
-    M.lib.mi355_set_tuning(6, 1)
+        with tuning(6, use_gemm):
+            outs.append(gm.forward_prefill(meta).cpu().numpy())
     assert _rel(outs[0], ref) < 3e-3, _rel(outs[0], ref)
     # both paths carry ONE f16 plane per activation since round 3 (own block scales each): two independent 11-bit roundings
     # through the tiny model's two layers -- measured 2.7e-3 between them, each within 3e-3 of the oracle
@@ -498,14 +498,12 @@ def test_batch12_decode_wide_path_chained_equals_unchained_equals_oracle(lib):
     meta = O.prepare_decode(seqs, cfg.block_size)
     ref = orc.forward(meta, [(k.copy(), v.copy()) for k, v in cache])
     outs = {}
-    try:
-        for chain in (1, 0):
-            for l, (kc, vc) in enumerate(cache):
-                gm.kv_upload(l, kc, vc)
-            M.lib.mi355_set_tuning(9, chain)
+    from candle_vllm_amd import tuning
+    for chain in (1, 0):
+        for l, (kc, vc) in enumerate(cache):
+            gm.kv_upload(l, kc, vc)
+        with tuning(9, chain):
             outs[chain] = gm.forward_decode(meta).cpu().numpy()
-    finally:
-        M.lib.mi355_set_tuning(9, 1)
     assert np.array_equal(outs[1], outs[0])
     assert _rel(outs[1], ref) < 1e-3, _rel(outs[1], ref)
     assert [int(r.argmax()) for r in outs[1]] == [int(r.argmax()) for r in ref]
@@ -563,14 +561,12 @@ def test_moe_decode_experts_grouped_on_the_device(lib, B):
     meta = O.prepare_decode(seqs, cfg.block_size)
     ref = orc.forward(meta, [(k.copy(), v.copy()) for k, v in cache])
     outs = {}
-    try:
-        for grouped in (1, 0):
-            for l, (kc, vc) in enumerate(cache):
-                gm.kv_upload(l, kc, vc)
-            M.lib.mi355_set_tuning(41, grouped)
+    from candle_vllm_amd import tuning
+    for grouped in (1, 0):
+        for l, (kc, vc) in enumerate(cache):
+            gm.kv_upload(l, kc, vc)
+        with tuning(41, grouped):
             outs[grouped] = gm.forward_decode(meta).cpu().numpy()
-    finally:
-        M.lib.mi355_set_tuning(41, 1)
     # the MoE prompt step's bound (test_moe_model_prompt_and_graph_decode): a near-tie in the router's softmax moves the mixing
     # weights of this tiny model by more than the mat-muls' own error (measured 1.1e-3 .. 1.5e-3 on both paths)
     for g, bound in ((0, 3e-3), (1, 3e-3)):

@@ -44,14 +44,9 @@ def bf16_bits(t):
 NARROW_TOL, WIDE_TOL = 1e-4, 5e-4
 
 
-class exact_activations:
-    def __enter__(self):
-        from candle_vllm_amd import _lib
-        _lib.lib.mi355_set_tuning(24, 1)
-
-    def __exit__(self, *a):
-        from candle_vllm_amd import _lib
-        _lib.lib.mi355_set_tuning(24, 0)
+def exact_activations():
+    from candle_vllm_amd import tuning
+    return tuning(24, 1)
 
 
 def rel_err(got, ref):
@@ -453,21 +448,20 @@ def test_paged_attention_fused_merge_is_stable(cv):
     meta = cv.InputMetadata(False, dev(np.zeros(len(ctx), np.int64)), dev(bt.astype(np.int32)), dev(cl.astype(np.int32)),
                             max_context_len=max(ctx))
     qd, kcd, vcd = dev(q, torch.bfloat16), bf16_dev(kc), bf16_dev(vc)
-    cv.lib.mi355_set_tuning(3, 0)
-    ref = pa.decode(qd, kcd, vcd, meta, None, partition_size=64).float().cpu().numpy()
-    cv.lib.mi355_set_tuning(3, 2)                                  # 2 = force the fused merge for any batch
+    from candle_vllm_amd import tuning
+    with tuning(3, 0):
+        ref = pa.decode(qd, kcd, vcd, meta, None, partition_size=64).float().cpu().numpy()
     tol = 2 ** -7 * np.abs(ref).max()
     for i in range(30):
         qi = torch.roll(qd, i, 0) if i % 3 == 0 else qd            # vary the data now and then
-        got = pa.decode(qi, kcd, vcd, meta, None, partition_size=(32, 64, 128)[i % 3]).float().cpu().numpy()
+        with tuning(3, 2):                                         # 2 = force the fused merge for any batch
+            got = pa.decode(qi, kcd, vcd, meta, None, partition_size=(32, 64, 128)[i % 3]).float().cpu().numpy()
         if i % 3 == 0:
-            cv.lib.mi355_set_tuning(3, 0)
-            want = pa.decode(qi, kcd, vcd, meta, None, partition_size=64).float().cpu().numpy()
-            cv.lib.mi355_set_tuning(3, 2)
+            with tuning(3, 0):
+                want = pa.decode(qi, kcd, vcd, meta, None, partition_size=64).float().cpu().numpy()
         else:
             want = ref
         assert np.abs(got - want).max() <= tol, i
-    cv.lib.mi355_set_tuning(3, 1)
     oracle = O.paged_attention_decode(q, kc, vc, bt, cl, 1 / np.sqrt(D), False)
     assert np.abs(ref - oracle).max() <= tol
 
@@ -573,16 +567,12 @@ def test_paged_attention_workgroup_merge_equals_one_wave_per_partition(cv, bs, c
     oracle = O.paged_attention_decode(q, kc, vc, bt, cl, 1 / np.sqrt(D), False)
     tol = 2 ** -7 * np.abs(oracle).max() + 1e-6
     outs = {}
-    try:
-        for wpb in (1, 4, 8, 16):                                     # partials per head in the fused merge: <= 32, 33..64, > 64
-            cv.lib.mi355_set_tuning(8, wpb)
-            for ps in (32, 64):
-                for fused in (0, 2):
-                    cv.lib.mi355_set_tuning(3, fused)
+    from candle_vllm_amd import tuning
+    for wpb in (1, 4, 8, 16):                                         # partials per head in the fused merge: <= 32, 33..64, > 64
+        for ps in (32, 64):
+            for fused in (0, 2):
+                with tuning(8, wpb), tuning(3, fused):
                     got = pa.decode(qd, kcd, vcd, meta, None, partition_size=ps).float().cpu().numpy()
-                    assert np.abs(got - oracle).max() <= tol, (wpb, ps, fused, np.abs(got - oracle).max())
-                    outs[(wpb, ps, fused)] = got
-    finally:
-        cv.lib.mi355_set_tuning(8, 0)
-        cv.lib.mi355_set_tuning(3, 1)
+                assert np.abs(got - oracle).max() <= tol, (wpb, ps, fused, np.abs(got - oracle).max())
+                outs[(wpb, ps, fused)] = got
     assert np.abs(outs[(4, 32, 0)] - outs[(1, 32, 0)]).max() <= tol

@@ -8,7 +8,7 @@
 #   4. two --pmc passes (FETCH_SIZE, WRITE_SIZE)         -> rNN_pmc_traffic.json   (tools/pmc_traffic.py)
 #   5. one --pmc pass of the SQ busy counters            -> rNN_pmc_sq_b1.json     (MFMA-busy / VALU-busy of every kernel)
 set -x
-RN=${ROUND_TAG:-r02}
+RN=${ROUND_TAG:-r03}
 R=${GRAFT_REPO_ROOT:-$PWD}
 SHA=$(cat $R/COMMIT_SHA 2>/dev/null || echo unknown)
 OUT=$R/gpurun_out/prof
@@ -51,6 +51,14 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INS
   B32_STEPS=3 timeout 300 rocprofv3 --kernel-trace --pmc $set -d /tmp/pmc_b32_$i --output-format csv -- python tools/exp_b32.py > $OUT/pmc_b32_$i.log 2>&1
   python tools/pmc_summary.py /tmp/pmc_b32_$i $OUT/${RN}_pmc_sq_b32_set$i.json $SHA > /dev/null 2>&1
 done
+# 8b. kernel stats of the secondary legs (bench_legs.py)
+for leg in bf16_b32 gptq_qwen2 mixtral_fp8 mixtral_fp8_b32; do
+  rm -rf /tmp/rp_leg_$leg
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/rp_leg_$leg --output-format csv -- python bench_legs.py $leg --no-parity > $OUT/leg_$leg.log 2>&1
+  f=$(find /tmp/rp_leg_$leg -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && (echo "# commit $SHA : rocprofv3 --kernel-trace --stats -- python bench_legs.py $leg --no-parity ; $(tail -1 $OUT/leg_$leg.log | cut -c1-60) ... value $(tail -1 $OUT/leg_$leg.log | grep -o '"value": [0-9.]*' | head -1)"; head -16 "$f") > $OUT/${RN}_leg_${leg}_kernel_stats.csv
+done
+[ -n "$SKIP_MICRO" ] && { head -12 $OUT/${RN}_b32_ragged_launch_groups.txt | cut -c1-170; exit 0; }
 # 9. micro-benchmarks: bare weight stream of the wide GEMM; per-wave timelines of the single-token launches
 [ -x tools/probe_wide_stream.bin ] || hipcc --offload-arch=gfx950 -O3 tools/probe_wide_stream.hip -o tools/probe_wide_stream.bin
 (echo "# commit $SHA : tools/probe_wide_stream.bin"; timeout 120 tools/probe_wide_stream.bin) > $OUT/${RN}_probe_wide_stream.txt 2>&1
