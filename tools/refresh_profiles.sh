@@ -56,7 +56,7 @@ for leg in bf16_b32 gptq_qwen2 mixtral_fp8 mixtral_fp8_b32; do
   rm -rf /tmp/rp_leg_$leg
   timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/rp_leg_$leg --output-format csv -- python bench_legs.py $leg --no-parity > $OUT/leg_$leg.log 2>&1
   f=$(find /tmp/rp_leg_$leg -name "*kernel_stats.csv" | head -1)
-  [ -n "$f" ] && (echo "# commit $SHA : rocprofv3 --kernel-trace --stats -- python bench_legs.py $leg --no-parity ; $(tail -1 $OUT/leg_$leg.log | cut -c1-60) ... value $(tail -1 $OUT/leg_$leg.log | grep -o '"value": [0-9.]*' | head -1)"; head -16 "$f") > $OUT/${RN}_leg_${leg}_kernel_stats.csv
+  [ -n "$f" ] && (echo "# commit $SHA : rocprofv3 --kernel-trace --stats -- python bench_legs.py $leg --no-parity ; $(grep '^{' $OUT/leg_$leg.log | tail -1 | grep -o '"value": [0-9.]*' | head -1) under rocprofv3"; head -16 "$f") > $OUT/${RN}_leg_${leg}_kernel_stats.csv
 done
 [ -n "$SKIP_MICRO" ] && { head -12 $OUT/${RN}_b32_ragged_launch_groups.txt | cut -c1-170; exit 0; }
 # 9. micro-benchmarks: bare weight stream of the wide GEMM; per-wave timelines of the single-token launches
