@@ -350,6 +350,7 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
                     g.norm_weight = L.ffn_norm; g.norm_eps = c.rms_eps;
                     g.epilogue = MI355_EPI_SILU_MUL; g.out = m->g_moe_h + off * I; g.ldo = I;
                     g.rows_dev = m->g_moe_cnt + e; g.rows_min = r0;
+                    g.chain_next = 1; g.chain_next_k = I; g.chain_next_norm = nullptr;   // its epilogue stages the down launch's image (same gate)
                     RCHECK(mi355_qmatmul_fused(&g, st));
                     mi355_qmm_desc dn;
                     memset(&dn, 0, sizeof(dn));
