@@ -20,7 +20,7 @@
 
 typedef _Float16 pf_f16x8_t __attribute__((ext_vector_type(8)));
 
-enum { SRC_CONTIG = 0, SRC_FLASH = 1, SRC_PAGED = 2 };
+enum { SRC_CONTIG = 0, SRC_FLASH = 1, SRC_PAGED = 2, SRC_PAGED8 = 3 };   // PAGED8: e4m3fn cache, K [NB, Hkv, D/16, bs, 16], V [NB, Hkv, D, bs]
 
 struct PrefillParams {
     void* out;                 // [T, H, D]
@@ -65,8 +65,29 @@ __device__ __forceinline__ const uint4* row_chunk(const PrefillParams& p, const 
     }
 }
 
+// 4 e4m3fn bytes -> 4 bf16 (exact: 3 mantissa bits)
+__device__ __forceinline__ uint2 pf_fp8x4_to_bf16x4(uint32_t w) {
+    typedef float pf_f32x2 __attribute__((ext_vector_type(2)));
+    const pf_f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
+    return make_uint2(cvt_pk_bf16(a.x, a.y), cvt_pk_bf16(b.x, b.y));
+}
+// the 8 values d0 .. d0 + 7 of key j as an MFMA fragment (d0 % 8 == 0)
+template <int SRC, int D>
+__device__ __forceinline__ uint4 k_frag(const PrefillParams& p, const uint32_t* bt, int q_begin, int hk, int j, int d0) {
+    if constexpr (SRC == SRC_PAGED8) {
+        const size_t blk = bt[j / p.block_size];
+        const uint8_t* b8 = static_cast<const uint8_t*>(p.k) + (((blk * p.Hkv + hk) * (D / 16) + d0 / 16) * p.block_size + j % p.block_size) * 16 + (d0 & 8);
+        const uint2 raw = *reinterpret_cast<const uint2*>(b8);
+        const uint2 lo = pf_fp8x4_to_bf16x4(raw.x), hi = pf_fp8x4_to_bf16x4(raw.y);
+        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+    } else {
+        return *row_chunk<SRC, D>(p, p.k, bt, q_begin, hk, j, d0);
+    }
+}
+
 template <int DT, int D, int SRC>
 __global__ void __launch_bounds__(256) prefill_attn_kernel(const PrefillParams p) {
+    static_assert(SRC != SRC_PAGED8 || DT == MI355_DTYPE_BF16, "e4m3 is exact in bf16 only");
     constexpr int NC = D / 32;     // 32-wide d chunks (QK contraction, V row loads)
     constexpr int NDT = D / 16;    // 16-wide d tiles of O
     const int seq = blockIdx.z, h = blockIdx.y;
@@ -122,11 +143,33 @@ __global__ void __launch_bounds__(256) prefill_attn_kernel(const PrefillParams p
         for (int kt = 0; kt < 2; ++kt) {
             const int j = min(j0 + 16 * kt + r16, ctx - 1);
 #pragma unroll
-            for (int c = 0; c < NC; ++c) kf[kt][c] = *row_chunk<SRC, D>(p, p.k, bt, q_begin, hk, j, 32 * c + 8 * kg);
+            for (int c = 0; c < NC; ++c) kf[kt][c] = k_frag<SRC, D>(p, bt, q_begin, hk, j, 32 * c + 8 * kg);
         }
         // ---- V^T fragments (A operand of PV: lane = d r16 of d tile, k = keys {4kg..4kg+3} of kt 0 and of kt 1)
         uint4 vt[NDT];
-        if constexpr (SRC == SRC_PAGED) {
+        if constexpr (SRC == SRC_PAGED8) {
+            const uint8_t* vb = static_cast<const uint8_t*>(p.v);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                uint32_t w[4];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    const int jv = j0 + 16 * kt + 4 * kg;                        // 4 consecutive keys, same block: 4 bytes
+                    const int jc = min(jv, ctx - 1);
+                    const size_t blk = bt[jc / p.block_size];
+                    uint32_t raw = *reinterpret_cast<const uint32_t*>(vb + ((blk * p.Hkv + hk) * D + 16 * dt + r16) * p.block_size + (jv % p.block_size));
+                    if (jv + 3 >= ctx) {      // bytes past the context: zero them (0x00 = +0.0 in e4m3)
+                        if (jv + 0 >= ctx) raw &= 0xFFFFFF00u;
+                        if (jv + 1 >= ctx) raw &= 0xFFFF00FFu;
+                        if (jv + 2 >= ctx) raw &= 0xFF00FFFFu;
+                        if (jv + 3 >= ctx) raw &= 0x00FFFFFFu;
+                    }
+                    const uint2 t = pf_fp8x4_to_bf16x4(raw);
+                    w[2 * kt] = t.x; w[2 * kt + 1] = t.y;
+                }
+                vt[dt] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        } else if constexpr (SRC == SRC_PAGED) {
             const uint16_t* vb = static_cast<const uint16_t*>(p.v);
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
@@ -227,7 +270,7 @@ __global__ void __launch_bounds__(256) prefill_attn_kernel(const PrefillParams p
     for (int s = 0; s < 2; ++s) {
         const int ql = qw0 + 16 * s + r16;
         if (ql >= qlen) continue;
-        const float inv = 1.f / l_run[s];
+        const float inv = (SRC == SRC_PAGED8 ? p.v_scale : 1.f) / l_run[s];
         uint16_t* op = out16 + ((size_t)(q_begin + ql) * p.H + h) * D + 4 * kg;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
@@ -347,7 +390,10 @@ extern "C" int mi355_prefill_attention(void* out, const void* q, const void* k, 
 }
 
 // prefill over an fp8 (e4m3fn) KV cache (PAGED layout, K x = 16): every key -- cached prefix and the current chunk,
-// already written by mi355_reshape_and_cache_fp8 -- is read from the cache.  Generic kernel (correctness path).
+// already written by mi355_reshape_and_cache_fp8 -- is read from the cache.  MFMA flash kernel for head sizes 64 / 128 (round 3;
+// attention.rs:574,896), the generic kernel otherwise (and as the A/B: tuning key 43).
+static int g_pf_fp8_generic = 0;
+void mi355_prefill_set_fp8_generic(int v) { g_pf_fp8_generic = v; }
 extern "C" int mi355_prefill_attention_fp8(void* out, const void* q, const void* key_cache, const void* value_cache,
                                            const uint32_t* block_tables, const uint32_t* context_lens,
                                            const uint32_t* cu_seqlens_q, int32_t num_seqs, int32_t max_seqlen_q,
@@ -363,6 +409,16 @@ extern "C" int mi355_prefill_attention_fp8(void* out, const void* q, const void*
     p.H = num_heads; p.Hkv = num_kv_heads; p.block_size = block_size; p.max_blocks = max_blocks_per_seq;
     p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f; p.softcap = softcap > 0.f ? softcap : 0.f;
     p.kv8 = 1; p.k_scale = k_scale; p.v_scale = v_scale;
+    if ((head_dim == 64 || head_dim == 128) && block_size % 16 == 0 && !g_pf_fp8_generic) {
+        // the MFMA flash kernel over the e4m3 cache: bytes converted to bf16 fragments on the way in (exact), k_scale folded into the
+        // logit scale, v_scale into the normalisation
+        PrefillParams q8 = p;
+        q8.scale = scale * k_scale; q8.scale_log2 = scale * k_scale * 1.4426950408889634f;
+        dim3 grid8((max_seqlen_q + 127) / 128, num_heads, num_seqs);
+        if (head_dim == 128) hipLaunchKernelGGL((prefill_attn_kernel<MI355_DTYPE_BF16, 128, SRC_PAGED8>), grid8, dim3(256), 0, (hipStream_t)stream, q8);
+        else hipLaunchKernelGGL((prefill_attn_kernel<MI355_DTYPE_BF16, 64, SRC_PAGED8>), grid8, dim3(256), 0, (hipStream_t)stream, q8);
+        return (int)hipGetLastError();
+    }
     dim3 grid(max_seqlen_q, num_heads, num_seqs);
     hipLaunchKernelGGL((prefill_attn_generic_kernel<MI355_DTYPE_BF16>), grid, dim3(64), 0, (hipStream_t)stream, p, head_dim, SRC_PAGED);
     return (int)hipGetLastError();

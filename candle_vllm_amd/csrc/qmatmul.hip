@@ -1993,6 +1993,7 @@ void mi355_dense_set_small(int key, int v);
 extern "C" void mi355_host_set_partition_override(int v);
 extern "C" void mi355_host_set_moe_group(int v);
 extern "C" void mi355_dense_set_tile(int v);
+void mi355_prefill_set_fp8_generic(int v);
 static int g_tune_actq8 = 0;                               // mi355_set_tuning(18, 1): EXPERIMENT, single-token launches quantise x to Q8_K (reference CPU numerics, O2)
 static int g_tune_nw = 0, g_tune_r = 0;                   // 0 = heuristic; mi355_set_tuning (experiments only)
 static int g_tune_prefill_gemm = 1;                        // 0 = always stream the quantised weights (experiments)
@@ -2029,6 +2030,7 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     else if (key >= 30 && key <= 38) mi355_dense_set_small(key, value);
     else if (key == 41) mi355_host_set_moe_group(value);
     else if (key == 42) mi355_dense_set_tile(value);
+    else if (key == 43) mi355_prefill_set_fp8_generic(value);
 }
 
 static size_t qmm_lds_bytes(int BT, int R, int NW) {

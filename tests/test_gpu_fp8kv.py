@@ -94,10 +94,14 @@ def test_decode_attention_over_fp8_cache(cv, H, Hkv, D, bs, ctxs, ps):
     assert np.abs(got - ref).max() <= 2e-2 * max(1.0, np.abs(ref).max())     # bf16 P and output rounding
 
 
-def test_prefill_over_fp8_cache(cv):
+@pytest.mark.parametrize("generic", [0, 1])
+@pytest.mark.parametrize("H,Hkv,D,bs,lens,cached", [(4, 2, 64, 16, [37, 20], [0, 24]), (8, 2, 128, 64, [150, 33, 5], [0, 70, 129])])
+def test_prefill_over_fp8_cache(cv, H, Hkv, D, bs, lens, cached, generic):
+    """prefill over the e4m3 cache (attention.rs:574,896): the MFMA flash kernel (bytes -> bf16 fragments on the way in; several
+    128-query tiles, cached prefixes that cross blocks) and the generic kernel (tuning key 43) against the oracle on the
+    e4m3-rounded K / V, same bound"""
+    from candle_vllm_amd import tuning
     rng = np.random.default_rng(9)
-    H, Hkv, D, bs = 4, 2, 64, 16
-    lens, cached = [37, 20], [0, 24]
     pa = cv.PagedAttention(H, D, 1.0 / np.sqrt(D), Hkv, fp8_kvcache=True)
     ctx = [c + l for c, l in zip(cached, lens)]
     nblk = [-(-c // bs) for c in ctx]
@@ -120,9 +124,10 @@ def test_prefill_over_fp8_cache(cv):
     im = cv.InputMetadata.from_oracle_meta(meta, "cuda", is_prefill=True)
     q = [O.round_bf16(rng.normal(0, 1, (l, H, D)).astype(np.float32)) for l in lens]
     kcd, vcd = torch.from_numpy(kc).cuda(), torch.from_numpy(vc).cuda()
-    kn = np.concatenate([k_all[b][cached[b]:] for b in range(2)])
-    vn = np.concatenate([v_all[b][cached[b]:] for b in range(2)])
-    out = bf16_host(pa.forward(bf16_dev(np.concatenate(q)), bf16_dev(kn), bf16_dev(vn), None, kcd, vcd, im))
+    kn = np.concatenate([k_all[b][cached[b]:] for b in range(len(lens))])
+    vn = np.concatenate([v_all[b][cached[b]:] for b in range(len(lens))])
+    with tuning(43, generic):
+        out = bf16_host(pa.forward(bf16_dev(np.concatenate(q)), bf16_dev(kn), bf16_dev(vn), None, kcd, vcd, im))
     O.reshape_and_cache_fp8(kn, vn, kc, vc, meta["slot_mapping"], False)
     assert np.array_equal(kcd.cpu().numpy(), kc)
     o = 0
