@@ -726,6 +726,7 @@ static int dense_launch_gj(const DenseArgs& a, int gj, int nw, hipStream_t st) {
 
 // ---- the 1..4-token launch of 4-bit weights (dense_small_kernel): -4 = this shape stays on dense_kernel
 static int g_tune_gemm_min_t = 96;     // tuning key 36: tokens from which a 16-bit projection takes the 128 x 128 MFMA GEMM
+static int g_tune_gptq_gemm_off = 0;   // tuning key 39: 1 = 4-bit prompt steps run the decode kernel in 64-token chunks (A/B)
 static int g_tune_wide_nw = 4;         // tuning key 38: waves (row tiles) per workgroup of dense_wide_kernel: 2 | 4
 static int g_tune_wide_off = 0;        // tuning key 37: 1 = 16-bit launches with many row tiles stay on dense_kernel (A/B)
 static int g_tune_small_nw = 0;        // tuning key 30: waves per workgroup (0 = chosen from the k-blocks)
@@ -734,7 +735,7 @@ static int g_tune_small_off = 0;       // tuning key 31: 1 = keep 1..4 tokens on
 static int g_tune_small_dbg = 0;
 static int g_tune_small_norope = 0;    // tuning key 34: 1 = RoPE and the cache write stay in their own launch
 static int g_tune_small_nonorm = 0;    // tuning key 32: 1 = never norm on the way in (the host layer launches the norm separately)
-void mi355_dense_set_small(int key, int v) { if (key == 30) g_tune_small_nw = v; else if (key == 31) g_tune_small_off = v; else if (key == 32) g_tune_small_nonorm = v; else if (key == 33) g_tune_small_dbg = v; else if (key == 34) g_tune_small_norope = v; else if (key == 35) g_tune_small_nw_big = v; else if (key == 36 && v > 0) g_tune_gemm_min_t = v; else if (key == 37) g_tune_wide_off = v; else if (key == 38) g_tune_wide_nw = v; }
+void mi355_dense_set_small(int key, int v) { if (key == 30) g_tune_small_nw = v; else if (key == 31) g_tune_small_off = v; else if (key == 32) g_tune_small_nonorm = v; else if (key == 33) g_tune_small_dbg = v; else if (key == 34) g_tune_small_norope = v; else if (key == 35) g_tune_small_nw_big = v; else if (key == 36 && v > 0) g_tune_gemm_min_t = v; else if (key == 37) g_tune_wide_off = v; else if (key == 38) g_tune_wide_nw = v; else if (key == 39) g_tune_gptq_gemm_off = v; }
 static inline int dense_small_gj(int group_size) {
     if (group_size >= 256) return (group_size % 256) ? -1 : 8;
     return group_size == 128 ? 4 : group_size == 64 ? 2 : group_size == 32 ? 1 : -1;
@@ -1074,6 +1075,234 @@ __global__ void __launch_bounds__(256, 2) dense_gemm_kernel(const DenseArgs a) {
         }
 }
 
+// ---- prompt steps over the tiled 4-bit image: ONE pass over the weights instead of T / 64 passes of the decode
+// kernel.  Same 128 x 128 workgroup tile and the same activation staging (LDS-DMA, swizzled, double buffer) as dense_gemm_kernel; the
+// weights never touch LDS: word j of a lane in the tiled image holds exactly the 8 codes of its B fragment of MFMA step j (that is
+// what the tile order is), so a wave fetches one dwordx4 per n-fragment and 128 k and unpacks it in registers (128+q / 1024+q by one
+// AND-OR, code pairs (q_i, q_i+4): the A fragment is permuted to match on its way out of LDS).  The accumulators run over one
+// quantisation group (a multiple of 64 k); at its end  y += s_g (acc - (OFF + z) xsum_g)  with the per-token group sums of x from a
+// ones-MFMA (as the decode kernels) and (scale, zero point) from a panel staged in LDS once per workgroup: inside the K loop the only
+// global traffic is the activation DMA and the weight ring -- a load that hipcc can see next to the invisible DMA makes it wait for
+// everything (first version: scales and a pre-computed xsum array fetched at every group end, 2.1-2.4 us per K step, 214-306 TFLOP/s).
+#define GG_NF 2
+static_assert(GG_NF == 2, "the counted wait in gptq_gemm_kernel leaves GG_NF loads in flight");
+template <int DT, int GPK>
+__global__ void __launch_bounds__(256) gptq_gemm_kernel(const DenseArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];   // [3 buffers][A 16 KiB]: the DMA runs two K steps ahead
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m16 = lane & 15, kg = lane >> 4;
+    const bool silu = a.epi == MI355_EPI_SILU_MUL;
+    const int bm = blockIdx.x, bn = blockIdx.y;
+    const int t0 = bm * DG_BM;
+    const int n_cols = silu ? a.pair_offset : a.N;
+    // 128 tokens x 64 columns per workgroup (SILU_MUL: 32 gate + the same 32 up columns): 4 m-fragments x 2 n-fragments per wave --
+    // with 4 n-fragments the group accumulators, the running sums and the weight ring need more than 256 VGPRs
+    const int c0 = bn * (silu ? 32 : 64);
+    const int nkb = a.K >> 8, gs = a.group_size;
+    // n-fragment j of this wave: first column (clamped to the matrix: columns beyond it are computed and never stored)
+    int fcol[GG_NF];
+#pragma unroll
+    for (int j = 0; j < GG_NF; ++j) {
+        int n = silu ? ((j ? a.pair_offset : 0) + c0 + wc * 16) : (c0 + wc * 32 + j * 16);
+        const int lim = silu ? ((j ? a.N : a.pair_offset) - 16) : a.N - 16;
+        fcol[j] = n > lim ? lim : n;
+    }
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)smem);
+    const uint8_t* xb = static_cast<const uint8_t*>(a.x);
+    const int srow = tid >> 3, sslot = tid & 7;
+    const uint8_t* asrc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 32 * r + srow;
+        int t = t0 + row;
+        if (t > a.T - 1) t = a.T - 1;
+        asrc[r] = xb + ((size_t)t * a.ldx) * 2 + (size_t)((sslot ^ (row & 7)) * 16);
+    }
+    // ---- (scale, zero point) panel of this workgroup's 64 columns, all groups: u32 = zero point (f32 bits >> 16, an exact small
+    // integer) << 16 | scale bits; panel[g][wave-column wc][fragment j][m16]
+    uint32_t* panel = reinterpret_cast<uint32_t*>(smem + 3 * 16384);
+    {
+        const int ng = a.K / gs;
+        const uint16_t* sc16p = static_cast<const uint16_t*>(a.scales);
+        for (int e = tid; e < ng * 64; e += 256) {
+            const int g = e >> 6, lc = e & 63, pwc = lc >> 5, pj = (lc >> 4) & 1, pm = lc & 15;
+            int n = silu ? ((pj ? a.pair_offset : 0) + c0 + pwc * 16) : (c0 + pwc * 32 + pj * 16);
+            const int lim = silu ? ((pj ? a.N : a.pair_offset) - 16) : a.N - 16;
+            const int col = (n > lim ? lim : n) + pm;
+            const uint32_t sb = sc16p[(size_t)g * a.N + marlin_scale_pos(col, a.sperm)];
+            const float z = zero_point(a, g, col);
+            panel[e] = (__float_as_uint(z) & 0xFFFF0000u) | sb;
+        }
+    }
+    auto stage = [&](int kt, int buf) {
+        const uint32_t base = lds0 + (uint32_t)buf * 16384u + (uint32_t)wave * 1024u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dgemm_dma<1>(asrc[r] + (size_t)kt * (DG_BK * 2), base + (uint32_t)r * 4096u);
+    };
+    // weights: one dwordx4 per n-fragment and 128 k: [tile][k-block][half][lane][4 words]
+    const dg_u32x4* wbase[GG_NF];
+#pragma unroll
+    for (int j = 0; j < GG_NF; ++j) wbase[j] = reinterpret_cast<const dg_u32x4*>(a.w) + ((size_t)(fcol[j] >> 4) * nkb * 2) * 64 + lane;
+    dg_u32x4 wq[2][GG_NF];
+    auto wload = [&](int slot, int h128) {                               // h128 = index of the 128-k half (2 per k-block)
+#pragma unroll
+        for (int j = 0; j < GG_NF; ++j) wq[slot][j] = __builtin_nontemporal_load(wbase[j] + (size_t)h128 * 64);
+    };
+    constexpr uint32_t KOFF = (DT == MI355_DTYPE_BF16) ? 0x43004300u : 0x64006400u;
+    constexpr float OFF = (DT == MI355_DTYPE_BF16) ? 128.f : 1024.f;
+    uint32_t nib = 0x000F000Fu;
+    asm volatile("" : "+v"(nib));
+    constexpr uint32_t ONE2 = (DT == MI355_DTYPE_BF16) ? 0x3F803F80u : 0x3C003C00u;
+    const uint4 ones = make_uint4(ONE2, ONE2, ONE2, ONE2);
+    f32x4_t xs[4];                                                       // group sums of x per token (every column of a ones-MFMA holds them)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc[4][GG_NF], y[4][GG_NF];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < GG_NF; ++j) { acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; y[i][j] = acc[i][j]; }
+    int arow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) arow[i] = wr * 64 + i * 16 + m16;
+    const int nkt = a.K / DG_BK;
+    const int nh = a.K >> 7;
+    // A K step is 16 MFMAs per wave -- far less than a memory round trip -- so the activation tiles run TWO steps ahead through three
+    // buffers and the end-of-step wait is counted: only the tile of the NEXT step has to have landed (measured with a two-buffer,
+    // wait-for-everything loop: 2.4 us per K step, 214-306 TFLOP/s)
+    stage(0, 0);
+    if (nkt > 1) stage(1, 1);
+    wload(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // One k-block (256 k = 4 K steps = 2 weight halves) per iteration of the run-time loop, its four steps unrolled: buffer, ring slot
+    // and word indices are compile-time (a run-time slot index put the weight ring into scratch), and so is the position of the
+    // per-group update (GPK = K steps per group: 1 / 2 / 4; 0 = whole k-blocks, the update sits behind a loop over the group's
+    // k-blocks).  With the update under a run-time condition inside one flat loop hipcc parked y in the accumulation registers and
+    // moved 200 registers per K step back and forth (v_accvgpr_read / write: as many issue cycles as the MFMAs).
+    auto update = [&](const int g) {
+#pragma unroll
+        for (int j = 0; j < GG_NF; ++j) {
+            const uint32_t pz = panel[g * 64 + wc * 32 + j * 16 + m16];
+            const float sg = h2f<DT>((uint16_t)(pz & 0xFFFF));
+            const float cg = -(OFF + __uint_as_float(pz & 0xFFFF0000u)) * sg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) y[i][j][v] += sg * acc[i][j][v] + cg * xs[i][v];
+                acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    };
+#define GG_STEP(S_) do { \
+        constexpr int s_ = (S_); \
+        const int kt = 4 * kb + s_; \
+        const bool snext = kt + 2 < nkt; \
+        if (snext) stage(kt + 2, (kt + 2) % 3); \
+        constexpr bool wstep = !(s_ & 1); \
+        const bool wnext = wstep && 2 * kb + (s_ >> 1) + 1 < nh; \
+        if (wnext) wload(((s_ >> 1) & 1) ^ 1, 2 * kb + (s_ >> 1) + 1); \
+        const uint8_t* A = smem + (size_t)(kt % 3) * 16384; \
+        _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) { \
+            uint4 af[4]; \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) { \
+                const uint4 v = *reinterpret_cast<const uint4*>(A + (size_t)arow[i] * 128 + (size_t)(((s2 * 4 + kg) ^ (arow[i] & 7)) * 16)); \
+                af[i].x = __builtin_amdgcn_perm(v.z, v.x, 0x05040100u); \
+                af[i].y = __builtin_amdgcn_perm(v.z, v.x, 0x07060302u); \
+                af[i].z = __builtin_amdgcn_perm(v.w, v.y, 0x05040100u); \
+                af[i].w = __builtin_amdgcn_perm(v.w, v.y, 0x07060302u); \
+                xs[i] = mfma32<DT>(af[i], ones, xs[i]); \
+            } \
+            _Pragma("unroll") for (int j = 0; j < GG_NF; ++j) { \
+                const dg_u32x4 wv = wq[(s_ >> 1) & 1][j]; \
+                const uint32_t w = ((s_ & 1) * 2 + s2) == 0 ? wv.x : ((s_ & 1) * 2 + s2) == 1 ? wv.y : ((s_ & 1) * 2 + s2) == 2 ? wv.z : wv.w; \
+                uint4 b; \
+                b.x = (w & nib) | KOFF; b.y = ((w >> 4) & nib) | KOFF; b.z = ((w >> 8) & nib) | KOFF; b.w = ((w >> 12) & nib) | KOFF; \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[i][j] = mfma32<DT>(af[i], b, acc[i][j]); \
+            } \
+        } \
+        /* the tile of step kt + 1 (DMA issued one step ago) must have landed; younger than it: the weight loads of the previous step \
+           (odd steps) or of this one (even steps), and this step's DMA */ \
+        { \
+            const int younger = (snext ? 4 : 0) + ((wstep ? wnext : wprev) ? GG_NF : 0); \
+            if (younger >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
+            else if (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); \
+            else if (younger == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        } \
+        wprev = wnext; \
+        __syncthreads(); \
+        if constexpr (GPK == 1 || (GPK == 2 && (s_ & 1)) || (GPK == 4 && s_ == 3)) update(kt / (GPK ? GPK : 1)); \
+    } while (0)
+    bool wprev = false;
+    if constexpr (GPK != 0) {
+        for (int kb = 0; kb < nkb; ++kb) { GG_STEP(0); GG_STEP(1); GG_STEP(2); GG_STEP(3); }
+    } else {
+        const int kb_per_group = gs >> 8;
+        for (int g = 0; g < nkb / kb_per_group; ++g) {
+            for (int kbi = 0; kbi < kb_per_group; ++kbi) { const int kb = g * kb_per_group + kbi; GG_STEP(0); GG_STEP(1); GG_STEP(2); GG_STEP(3); }
+            update(g);
+        }
+    }
+#undef GG_STEP
+    // ---- epilogue (as dense_gemm_kernel): the lane holds tokens 4 kg + v of every m-fragment for column m16 of every n-fragment
+    const uint16_t* bias = static_cast<const uint16_t*>(a.bias);
+    const uint16_t* resid = static_cast<const uint16_t*>(a.resid);
+    uint16_t* out = static_cast<uint16_t*>(a.out);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int t = t0 + wr * 64 + i * 16 + 4 * kg + v;
+            if (t >= a.T) continue;
+            if (silu) {
+                const int col = c0 + wc * 16 + m16;
+                if (col < n_cols) {
+                    float g = rnd<DT>(y[i][0][v]), u = rnd<DT>(y[i][1][v]);
+                    if (bias) { g = rnd<DT>(g + h2f<DT>(bias[col])); u = rnd<DT>(u + h2f<DT>(bias[a.pair_offset + col])); }
+                    out[(size_t)t * a.ldo + col] = f2h<DT>(rnd<DT>(rnd<DT>(g / (1.f + __expf(-g))) * u));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < GG_NF; ++j) {
+                    const int col = c0 + wc * 32 + j * 16 + m16;
+                    if (col >= n_cols) continue;
+                    float o = rnd<DT>(y[i][j][v]);
+                    if (bias) o = rnd<DT>(o + h2f<DT>(bias[col]));
+                    if (a.epi == MI355_EPI_RESID) o = rnd<DT>(o + h2f<DT>(resid[(size_t)t * a.ldo + col]));
+                    out[(size_t)t * a.ldo + col] = f2h<DT>(o);
+                }
+            }
+        }
+}
+static int gptq_prompt_gemm(const DenseArgs& a, int dt, hipStream_t st) {
+    const int gs = a.group_size;
+    if (g_tune_gptq_gemm_off || (a.K & 255) || (a.N & 15) || a.T < 4 || gs < 64 || (gs % 64) || (a.K % gs)) return (int)hipErrorNotSupported;
+    if ((a.ldx * 2) % 16 || ((uintptr_t)a.x & 15)) return (int)hipErrorNotSupported;
+    if (a.epi == MI355_EPI_SILU_MUL && (a.pair_offset <= 0 || a.N != 2 * a.pair_offset || (a.pair_offset & 15))) return (int)hipErrorNotSupported;
+    const int n_cols = a.epi == MI355_EPI_SILU_MUL ? a.pair_offset : a.N;
+    const int cols_per_wg = a.epi == MI355_EPI_SILU_MUL ? 32 : 64;
+    const dim3 grid((a.T + DG_BM - 1) / DG_BM, (n_cols + cols_per_wg - 1) / cols_per_wg);
+    const size_t lds = 3 * 16384 + (size_t)(a.K / gs) * 64 * sizeof(uint32_t);
+    if (lds > 152 * 1024) return (int)hipErrorNotSupported;
+    const int gpk = gs == 64 ? 1 : gs == 128 ? 2 : gs == 256 ? 4 : 0;
+    if (gpk == 0 && (gs % 256)) return (int)hipErrorNotSupported;
+#define GG_GO(DT_, GPK_) do { \
+        static bool attr_ = false; \
+        if (!attr_) { (void)hipFuncSetAttribute((const void*)gptq_gemm_kernel<DT_, GPK_>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); attr_ = true; } \
+        hipLaunchKernelGGL((gptq_gemm_kernel<DT_, GPK_>), grid, dim3(256), lds, st, a); } while (0)
+#define GG_DT(DT_) do { if (gpk == 1) GG_GO(DT_, 1); else if (gpk == 2) GG_GO(DT_, 2); else if (gpk == 4) GG_GO(DT_, 4); else GG_GO(DT_, 0); } while (0)
+    if (dt == MI355_DTYPE_BF16) GG_DT(MI355_DTYPE_BF16);
+    else if (dt == MI355_DTYPE_F16) GG_DT(MI355_DTYPE_F16);
+#undef GG_DT
+#undef GG_GO
+    else return (int)hipErrorNotSupported;
+    return (int)hipGetLastError();
+}
+
 static int dense_prompt_gemm(const DenseArgs& a, int dt, hipStream_t st) {
     if (a.K % DG_BK || a.T < 1 || a.N < 1) return (int)hipErrorNotSupported;
     if ((a.ldx * 2) % 16 || (!a.wtiled && (a.ldw * 2) % 16)) return (int)hipErrorNotSupported;          // 16-byte DMA pieces
@@ -1098,6 +1327,10 @@ static int dense_run(DenseArgs a, int wtype, int dt, hipStream_t st) {
     if (wtype == DW_DENSE && a.T >= g_tune_gemm_min_t) {
         const int rc = dense_prompt_gemm(a, dt, st);
         if (rc != (int)hipErrorNotSupported) return rc;                    // odd strides / K: keep streaming in token chunks
+    }
+    if (wtype == DW_GPTQ4T && a.T >= g_tune_gemm_min_t) {
+        const int rc = gptq_prompt_gemm(a, dt, st);
+        if (rc != (int)hipErrorNotSupported) return rc;                    // groups of 32, odd strides: token chunks of the decode kernel
     }
     const int chunk = a.epi == MI355_EPI_SILU_MUL ? 32 : 64;
     const int T = a.T;

@@ -2027,7 +2027,7 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     else if (key == 22) g_tune_qmv_ring = value;
     else if (key == 23) g_tune_chain_b1 = value;
     else if (key == 24) g_tune_exact_act = value;
-    else if (key >= 30 && key <= 38) mi355_dense_set_small(key, value);
+    else if (key >= 30 && key <= 39) mi355_dense_set_small(key, value);
     else if (key == 41) mi355_host_set_moe_group(value);
     else if (key == 42) mi355_dense_set_tile(value);
     else if (key == 43) mi355_prefill_set_fp8_generic(value);

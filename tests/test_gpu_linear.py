@@ -337,3 +337,39 @@ def test_linear_over_the_tiled_weight_image(cv, dt, T, N, K, pair):
         lin = cv.Linear(dev16(w, dt), tiled=tiled)
         y = host16(lin.forward(dev16(x, dt), **kw), dt)
         check_ulp(y, ref, dt, ulps=ulps, what=f"linear tiled={tiled}")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("T,N,K,gs,mode", [(96, 64, 256, 64, "sym"), (130, 208, 512, 128, "sym"), (257, 96, 1024, 256, "sym"),
+                                           (200, 48, 512, -1, "sym"), (128, 80, 768, 128, "zp"), (161, 144, 512, 128, "silu"),
+                                           (97, 32, 256, 128, "resid")])
+def test_gptq_prompt_gemm_one_pass(cv, dt, T, N, K, gs, mode):
+    """>= 96 tokens over the tiled 4-bit image: the one-pass MFMA GEMM (weights unpacked in registers, per-group scale / offset with
+    the prep launch's group sums of x; ragged token and column tiles, groups of 64 / 128 / 256 / whole K, zero points, the fused
+    epilogues) == the oracle == the decode kernel in 64-token chunks (tuning key 39) to the same bound"""
+    from candle_vllm_amd import tuning
+    rng = np.random.default_rng(T + N + K)
+    pair = mode == "silu"
+    Nw = 2 * N if pair else N
+    q, s = _gptq_case(rng, K, Nw, gs, dt)
+    x = G.round_dt(rng.normal(0, 1, (T, K)), dt)
+    z = rng.integers(1, 17, ((1 if gs == -1 else K // gs), Nw)) if mode == "zp" else None
+    kw = {}
+    if z is not None:
+        kw = {"qzeros": dev_u32(G.gptq_pack_zeros(z)), "zero_mode": cv.ZERO_GPTQ_PLUS1}
+    lin = cv.GPTQLinear(dev_u32(G.gptq_pack(q)), dev16(s, dt), gs if gs > 0 else K, **kw)
+    assert lin.tiled
+    lin_ref = G.gptq_linear(x, G.gptq_dequant(q, s, z, gs), None, dt)
+    fkw, ulps, mag = {}, 1.01, None
+    if pair:
+        ref, fkw, ulps = G.silu_mul16(lin_ref[:, :N], lin_ref[:, N:], dt), {"epilogue": cv.EPI_SILU_MUL}, 3.0
+    elif mode == "resid":
+        res = G.round_dt(rng.normal(0, 1, (T, N)), dt)
+        ref, fkw, ulps, mag = G.round_dt(lin_ref + res, dt), {"epilogue": cv.EPI_RESID, "residual": dev16(res, dt)}, 2.01, lin_ref
+    else:
+        ref = lin_ref
+    y = host16(lin.forward(dev16(x, dt), **fkw), dt)
+    check_ulp(y, ref, dt, ulps=ulps, what="gptq prompt GEMM", mag=mag)
+    with tuning(39, 1):
+        y0 = host16(lin.forward(dev16(x, dt), **fkw), dt)
+    check_ulp(y0, ref, dt, ulps=ulps, what="decode kernel in chunks", mag=mag)
