@@ -68,7 +68,6 @@ struct DenseArgs {
     const void* norm_w;       // dense_small_kernel only: RmsNorm weight [K] (bf16) applied to x while it is staged, or null
     float norm_eps;
     const float* ss_in;       // with norm_w: [T][K/16] partial sums of squares of x's rows, left by the launch that produced x
-    int32_t dbg;              // experiments (tuning key 33)
     // dense_small3r_kernel only (q / k / v of a decode step): RoPE and the KV-cache write in the projection's epilogue
     int32_t rope_mode;        // 0 none; 1 = q (rotate, store); 2 = k (rotate, store, write the key cache); 3 = v (store, write the value cache)
     float* ss_out;            // dense_small_kernel only: where this launch leaves [T][ldo/16] partial sums of squares of its output
@@ -325,7 +324,7 @@ __global__ void __launch_bounds__(64 * NW) dense_wide_kernel(const DenseArgs a) 
     const int nkb = a.K >> 8, T = a.T;
     // every workgroup starts its sweep at a different k-block: in step, all waves of the launch would ask for the same 512-byte column
     // of rows 8 KB apart (the order of the f32 sum changes with the workgroup, not from run to run)
-    const int rot = a.dbg == 64 ? 0 : (int)((blockIdx.x * 7u) % (unsigned)nkb);
+    const int rot = (int)((blockIdx.x * 7u) % (unsigned)nkb);
 #define DWD_KB(KB_) (((KB_) + rot) % nkb)
     const int ntiles = (R == 2 ? a.pair_offset : a.N) >> 4;
     const int tile = min((int)blockIdx.x * NW + wave, ntiles - 1);            // a surplus wave shadows the last tile (stores skipped)
@@ -476,7 +475,7 @@ __device__ __forceinline__ void dense_small_body(const DenseArgs& a, const int b
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const bool ok = t < T && 256 * c < ntp && !(a.dbg & 1);
+                const bool ok = t < T && 256 * c < ntp;
                 ssp[t][c] = *reinterpret_cast<const f32x4_t*>(a.ss_in + (ok ? (size_t)t * ntp + min(4 * lane + 256 * c, ntp - 4) : 0));   // masked at use
             }
     }
@@ -590,10 +589,8 @@ __device__ __forceinline__ void dense_small_body(const DenseArgs& a, const int b
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq) {
             f32x4_t xs = zero4;
-            if (!(a.dbg & 8)) {
 #pragma unroll
             for (int jj = 0; jj < GJ; ++jj) xs = mfma32<DT>(aw[gq * GJ + jj], ones, xs);
-            }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float s = h2f<DT>((uint16_t)(sl.sc[r][gq] >> (16 * (spos[r] & 1))));
@@ -737,10 +734,9 @@ static int g_tune_wide_off = 0;        // tuning key 37: 1 = 16-bit launches wit
 static int g_tune_small_nw = 0;        // tuning key 30: waves per workgroup (0 = chosen from the k-blocks)
 static int g_tune_small_nw_big = 0;    // tuning key 35: the same for K > 8192
 static int g_tune_small_off = 0;       // tuning key 31: 1 = keep 1..4 tokens on dense_kernel (A/B measurements)
-static int g_tune_small_dbg = 0;
 static int g_tune_small_norope = 0;    // tuning key 34: 1 = RoPE and the cache write stay in their own launch
 static int g_tune_small_nonorm = 0;    // tuning key 32: 1 = never norm on the way in (the host layer launches the norm separately)
-void mi355_dense_set_small(int key, int v) { if (key == 30) g_tune_small_nw = v; else if (key == 31) g_tune_small_off = v; else if (key == 32) g_tune_small_nonorm = v; else if (key == 33) g_tune_small_dbg = v; else if (key == 34) g_tune_small_norope = v; else if (key == 35) g_tune_small_nw_big = v; else if (key == 36 && v > 0) g_tune_gemm_min_t = v; else if (key == 37) g_tune_wide_off = v; else if (key == 38) g_tune_wide_nw = v; else if (key == 39) g_tune_gptq_gemm_off = v; }
+void mi355_dense_set_small(int key, int v) { if (key == 30) g_tune_small_nw = v; else if (key == 31) g_tune_small_off = v; else if (key == 32) g_tune_small_nonorm = v; else if (key == 34) g_tune_small_norope = v; else if (key == 35) g_tune_small_nw_big = v; else if (key == 36 && v > 0) g_tune_gemm_min_t = v; else if (key == 37) g_tune_wide_off = v; else if (key == 38) g_tune_wide_nw = v; else if (key == 39) g_tune_gptq_gemm_off = v; }
 static inline int dense_small_gj(int group_size) {
     if (group_size >= 256) return (group_size % 256) ? -1 : 8;
     return group_size == 128 ? 4 : group_size == 64 ? 2 : group_size == 32 ? 1 : -1;
@@ -776,7 +772,6 @@ static int dense_small_launch_gj(const DenseArgs& a, int gj, hipStream_t st) {
     const int nw = dense_small_nw(a.K >> 8);
     const size_t lds = (size_t)nw * (((a.K >> 8) + nw - 1) / nw) * a.T * 512 + (size_t)nw * R * 64 * sizeof(float);
     dim3 grid(tiles), block(nw * 64);
-    const_cast<DenseArgs&>(a).dbg = g_tune_small_dbg;
     switch (gj) {
         case 1: hipLaunchKernelGGL((dense_small_kernel<DT, DW_GPTQ4T, R, 1, D, ZP, NCH>), grid, block, lds, st, a); break;
         case 2: hipLaunchKernelGGL((dense_small_kernel<DT, DW_GPTQ4T, R, 2, D, ZP, NCH>), grid, block, lds, st, a); break;
@@ -850,8 +845,7 @@ static int dense_launch_dt(const DenseArgs& a, hipStream_t st) {
         const int wtiles = (pair ? a.pair_offset : a.N) / 16;
         if (!g_tune_wide_off && a.T > 4 && wtiles >= 4 * 192 && (!pair || mt <= 2) && !((uintptr_t)a.x & 15) && !(a.ldx & 7) &&
             !((uintptr_t)a.w & 15) && (a.wtiled || !(a.ldw & 7))) {
-            const_cast<DenseArgs&>(a).dbg = g_tune_small_dbg;
-            const int nwv = g_tune_wide_nw == 2 ? 2 : 4;
+                    const int nwv = g_tune_wide_nw == 2 ? 2 : 4;
             const dim3 grid((wtiles + nwv - 1) / nwv), block(64 * nwv);
             const size_t lds = (size_t)2 * mt * 16 * DWD_LDX * 2;
 #define DWD_GO2(MT_, R_, NW_) do { \
