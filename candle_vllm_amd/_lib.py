@@ -280,6 +280,7 @@ _sig("mi355_effective_max_seq_len", c_i64, [c_vp, c_i64])
 _sig("mi355_get_cache_config", ctypes.c_int, [c_i64, c_i64] + [c_i32] * 7 + [c_vp, c_vp])
 _sig("mi355_gguf_tensor_shard", ctypes.c_int64, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, ctypes.c_int64])
 _sig("mi355_gguf_tensor_shard_q8_0", ctypes.c_int64, [c_vp, c_i32, c_i32, c_i32, c_vp, ctypes.c_int64])
+_sig("mi355_gguf_tensor_rows_padded", ctypes.c_int64, [c_vp, c_i32, ctypes.c_int64, ctypes.c_int64, c_vp, ctypes.c_int64])
 
 
 # the hand-written ctypes mirrors must have the layout the library was built with

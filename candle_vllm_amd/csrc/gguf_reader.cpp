@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -248,6 +249,30 @@ int64_t mi355_gguf_tensor_shard(void* h, int32_t i, int32_t dim, int32_t rank, i
         if (out_cap < (int64_t)n) return -3;
         for (uint64_t r = 0; r < rows; ++r) memcpy(dst + r * seg, src + r * row_bytes + (uint64_t)rank * seg, seg);
     }
+    return (int64_t)n;
+}
+
+/* rows [row0, row0 + n_rows) of a 2-D tensor in the file's own block format; rows beyond the tensor come out as ZERO blocks (all bytes
+ * zero: d = dmin = 0 in Q4_K / Q6_K / Q8_0, i.e. rows of 0.0) -- the vocab-parallel lm_head of a padded vocabulary (VocabParallelLinear,
+ * distributed.rs:1596-1616).  Returns the byte count (out == NULL: size query); -1 bad arguments / type, -3 out_cap too small. */
+int64_t mi355_gguf_tensor_rows_padded(void* h, int32_t i, int64_t row0, int64_t n_rows, void* out, int64_t out_cap) {
+    Gguf* g = G(h);
+    if (!g || i < 0 || i >= (int)g->tensors.size() || row0 < 0 || n_rows <= 0) return -1;
+    const TInfo& t = g->tensors[i];
+    if (t.n_dims != 2) return -1;
+    uint64_t epb = 0, bpb = 0;
+    if (!type_layout(t.type, &epb, &bpb)) return -1;
+    const uint64_t cols = t.dims[0], rows = t.dims[1];
+    if (cols % epb) return -1;
+    const uint64_t row_bytes = cols / epb * bpb;
+    if ((uint64_t)n_rows > (uint64_t)INT64_MAX / (row_bytes ? row_bytes : 1)) return -1;
+    const uint64_t n = (uint64_t)n_rows * row_bytes;
+    if (!out) return (int64_t)n;
+    if (out_cap < (int64_t)n) return -3;
+    const uint64_t have = (uint64_t)row0 < rows ? std::min<uint64_t>((uint64_t)n_rows, rows - (uint64_t)row0) : 0;
+    uint8_t* dst = static_cast<uint8_t*>(out);
+    if (have) memcpy(dst, g->base + g->data_off + t.offset + (uint64_t)row0 * row_bytes, have * row_bytes);
+    memset(dst + have * row_bytes, 0, (size_t)(n - have * row_bytes));
     return (int64_t)n;
 }
 

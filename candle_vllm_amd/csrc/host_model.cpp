@@ -167,13 +167,20 @@ __global__ void select_last_rows_kernel(float* dst, const float* src, const uint
     for (int i = threadIdx.x; i < hidden; i += blockDim.x) dst[(size_t)blockIdx.x * hidden + i] = src[row * hidden + i];
 }
 
-// [W, B, Vl] -> [B, W*Vl]   (VocabParallelLinear: all-gather then un-interleave, distributed.rs:1637-1663)
-__global__ void gather_transpose_kernel(float* out, const float* in, int W, int B, int Vl) {
+// [W, B, Vl] -> [B, V]   (VocabParallelLinear: all-gather, un-interleave, narrow to the real vocabulary V <= W * Vl -- the columns
+// beyond it are the zero rows of a padded vocabulary, distributed.rs:1637-1663)
+__global__ void gather_transpose_kernel(float* out, const float* in, int W, int B, int Vl, int V) {
     const int64_t n = (int64_t)W * B * Vl;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int v = (int)(i % Vl), b = (int)((i / Vl) % B), w = (int)(i / ((int64_t)Vl * B));
-        out[((int64_t)b * W + w) * Vl + v] = in[i];
+        const int64_t col = (int64_t)w * Vl + v;
+        if (col < V) out[(int64_t)b * V + col] = in[i];
     }
+}
+// distributed.rs:1446-1452
+inline int64_t pad_vocab(int64_t vocab, int world) {
+    const int64_t p64 = (vocab + 63) / 64 * 64;
+    return ((p64 + world - 1) / world * world + 63) / 64 * 64;
 }
 
 // C1/C2: all-reduce(sum) of [B, hidden] after o_proj / down_proj (distributed.rs:696-711).
@@ -266,10 +273,13 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
         RCHECK(mi355_qmatmul_fused(&d, st));
         if (!m->use_comm) return 0;
         if (!m->comm) return (int)hipErrorNotInitialized;
+        // every rank holds pad_vocab / world rows (zero rows beyond the real vocabulary): the gathered row is narrowed to c.vocab
+        if ((int64_t)m->output.n_rows * c.tp_world < c.vocab || (int64_t)m->output.n_rows * c.tp_world > pad_vocab(c.vocab, c.tp_world))
+            return (int)hipErrorInvalidValue;
         const size_t cnt = (size_t)B * m->output.n_rows;
         RCHECK(comm_all_gather(m->comm, m->logits_local, m->logits_gather, (int64_t)cnt, MI355_DTYPE_F32, st));
         hipLaunchKernelGGL(gather_transpose_kernel, dim3(512), dim3(256), 0, reinterpret_cast<hipStream_t>(st), logits,
-                           m->logits_gather, c.tp_world, B, m->output.n_rows);
+                           m->logits_gather, c.tp_world, B, m->output.n_rows, c.vocab);
         return (int)hipGetLastError();
     }
     Layer& L = m->layers[l];
@@ -560,8 +570,9 @@ extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
     alloc((void**)&m->logits, (size_t)B * cfg->vocab * 4);
     if (m->use_comm) {
         alloc((void**)&m->tp_y, (size_t)B * cfg->hidden * 4);
-        alloc((void**)&m->logits_local, (size_t)B * cfg->vocab * 4 / m->cfg.tp_world + 64);
-        alloc((void**)&m->logits_gather, (size_t)B * cfg->vocab * 4 + 64 * m->cfg.tp_world);
+        const size_t padded = (size_t)pad_vocab(cfg->vocab, m->cfg.tp_world);              // the lm_head shards may carry zero rows
+        alloc((void**)&m->logits_local, (size_t)B * padded * 4 / m->cfg.tp_world + 64);
+        alloc((void**)&m->logits_gather, (size_t)B * padded * 4 + 64 * m->cfg.tp_world);
     }
     alloc(&m->chain_sync, (size_t)mi355_qmv_chain_sync_bytes());
     if (m->chain_sync && hipMemset(m->chain_sync, 0, (size_t)mi355_qmv_chain_sync_bytes()) != hipSuccess) ok = false;
@@ -863,8 +874,8 @@ static int record_step(Model* m, int64_t stream) {
                           m->cur_ctx_cap, m->logits, stream));
     // greedy sample, then prepare the next step's inputs on the device
     uint32_t* next = reinterpret_cast<uint32_t*>(m->q);   // scratch: q is dead after the last layer
-    // under TP the lm_head holds vocab / world rows; the gathered logits row is world x that
-    RCHECK(mi355_argmax_f32(next, m->logits, B, m->output.n_rows * (m->use_comm ? m->cfg.tp_world : 1), stream));
+    // under TP the lm_head holds pad_vocab / world rows; the gathered logits row is narrowed to the real vocabulary
+    RCHECK(mi355_argmax_f32(next, m->logits, B, m->use_comm ? m->cfg.vocab : m->output.n_rows, stream));
     hipLaunchKernelGGL(advance_kernel, dim3((B + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
                        m->d_tokens, next, m->d_positions, m->d_slots, m->d_ctx, m->d_bt, m->cur_max_blocks,
                        m->cfg.block_size, B);
@@ -947,8 +958,9 @@ extern "C" float* mi355_llama_logits_ptr(void* mp) {
 // `get_sharded_no_shape` does (quantized_var_builder.rs:135-183,222-233): attn_q / ffn_gate / ffn_up / output on rows,
 // attn_k / attn_v on rows of the kv-head shard (`kv_head_shard`, distributed.rs:725-765: replicated groups when
 // Hkv < W), attn_output / ffn_down on k-blocks; token_embd, the norms and a Mixtral layer's router + experts are
-// loaded whole (quantized_llama.rs:262-268,344-365).  Shards that would need the reference's dequantise -> narrow ->
-// re-quantise fallback (k/W not a multiple of 256, a padded vocabulary) return hipErrorNotSupported.
+// loaded whole (quantized_llama.rs:262-268,344-365).  o_proj / down_proj shards that cut a k-block take the reference's
+// dequantise -> narrow -> re-quantise (Q8_0) fallback; the lm_head of a vocabulary `pad_vocab_size` pads keeps its own blocks
+// and gets all-zero blocks for the rows beyond the vocabulary (VocabParallelLinear, distributed.rs:1596-1616).
 namespace {
 int load_gguf_impl(const char* path, int32_t max_batch, int32_t max_blocks_per_seq, int32_t block_size, int32_t kv_layout,
                    int32_t max_seq, int32_t tp_rank, int32_t tp_world, void** model_out, mi355_llama_config* cfg_out,
@@ -1021,9 +1033,8 @@ int load_gguf_impl(const char* path, int32_t max_batch, int32_t max_blocks_per_s
             if (tp_world % cfg.n_kv_heads) return (int)hipErrorInvalidValue;
             kv_rank = tp_rank / (tp_world / cfg.n_kv_heads); kv_world = cfg.n_kv_heads;   // one replicated head per rank
         }
-        const int64_t pad64 = (vocab + 63) / 64 * 64;
-        const int64_t padded = ((pad64 + tp_world - 1) / tp_world * tp_world + 63) / 64 * 64;
-        if (padded != vocab) return (int)hipErrorNotSupported;    // zero-row padding re-quantises the lm_head (distributed.rs:1601-1612)
+        // a vocabulary that is not a fixed point of pad_vocab_size gets zero rows in the lm_head shards (below); the gathered logits
+        // are narrowed back (run_part, PART_HEAD)
     }
     // ---- the tensor table against the configuration, BEFORE anything is allocated on the device: a file whose shapes
     // disagree with its own metadata would otherwise make the kernels read past a weight (the reference checks the
@@ -1060,7 +1071,8 @@ int load_gguf_impl(const char* path, int32_t max_batch, int32_t max_blocks_per_s
         };
         if (d[0] != vocab || d[1] != hid || d[2] != 1 || d[3] != 1) return (int)hipErrorInvalidValue;      // token_embd
         RCHECK(expect_f32("output_norm.weight", hid));
-        RCHECK(expect_q(mi355_gguf_find(g, "output.weight") >= 0 ? "output.weight" : "token_embd.weight", vocab, hid, 0, tp_world));
+        // (the lm_head is sharded by rows of the PADDED vocabulary: any row count works, the shards carry zero rows)
+        RCHECK(expect_q(mi355_gguf_find(g, "output.weight") >= 0 ? "output.weight" : "token_embd.weight", vocab, hid, -1, 1));
         for (int l = 0; l < cfg.n_layers; ++l) {
             const std::string p = "blk." + std::to_string(l) + ".";
             RCHECK(expect_q(p + "attn_q.weight", HD, hid, 0, tp_world));
@@ -1143,8 +1155,24 @@ int load_gguf_impl(const char* path, int32_t max_batch, int32_t max_blocks_per_s
         return (int)hipErrorNotSupported;
     }
     RCHECK(load_f32("output_norm.weight", -1, MI355_W_OUTPUT_NORM));
-    RCHECK(load_q(mi355_gguf_find(g, "output.weight") >= 0 ? "output.weight" : "token_embd.weight", -1, MI355_W_OUTPUT,
-                  0, tp_rank, tp_world));
+    {   // vocab-parallel lm_head: rows [rank * local, (rank + 1) * local) of the vocabulary padded to pad_vocab_size, zero rows beyond
+        // the real one (VocabParallelLinear, distributed.rs:1596-1616; layout note in DESIGN.md section 7)
+        const std::string name = mi355_gguf_find(g, "output.weight") >= 0 ? "output.weight" : "token_embd.weight";
+        if (tp_world <= 1) {
+            RCHECK(load_q(name, -1, MI355_W_OUTPUT));
+        } else {
+            int64_t dd[4]; int32_t t; uint64_t n;
+            const int i = info(name, dd, &t, &n);
+            if (i < 0) return (int)hipErrorInvalidValue;
+            if (t != MI355_GGML_Q4_K && t != MI355_GGML_Q6_K) return (int)hipErrorNotSupported;
+            const int64_t local = pad_vocab(vocab, tp_world) / tp_world;
+            const int64_t bytes = mi355_gguf_tensor_rows_padded(g, i, (int64_t)tp_rank * local, local, nullptr, 0);
+            if (bytes < 0) return (int)hipErrorInvalidValue;
+            std::vector<uint8_t> shard((size_t)bytes);
+            if (mi355_gguf_tensor_rows_padded(g, i, (int64_t)tp_rank * local, local, shard.data(), bytes) != bytes) return (int)hipErrorInvalidValue;
+            RCHECK(mi355_llama_set_qweight(m, -1, MI355_W_OUTPUT, t, shard.data(), (int32_t)local, (int32_t)dd[1]));
+        }
+    }
     for (int l = 0; l < cfg.n_layers; ++l) {
         const std::string p = "blk." + std::to_string(l) + ".";
         RCHECK(load_q(p + "attn_q.weight", l, MI355_W_WQ, 0, tp_rank, tp_world));

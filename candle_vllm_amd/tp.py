@@ -32,6 +32,27 @@ def pad_vocab_size(vocab_size, world_size):
     return (per_rank + VOCAB_PADDING_SIZE - 1) // VOCAB_PADDING_SIZE * VOCAB_PADDING_SIZE
 
 
+def _zero_blocks(t, n_rows, nb):
+    """all-zero quantised rows: d (and dmin) = 0 and every code 0 dequantise to 0.0 in Q4_K, Q6_K and Q8_0 alike"""
+    width = {12: 144, 14: 210, 8: 34}[t]
+    return np.zeros((n_rows, nb, width), np.uint8)
+
+
+def _rows_padded(tw, rank, world, vocab):
+    """vocab-parallel lm_head (VocabParallelLinear, distributed.rs:1570-1630): the vocabulary is padded to pad_vocab_size, rank r
+    owns rows [r * local, (r + 1) * local) of the padded matrix, the rows beyond the real vocabulary are ZERO rows, and the gathered
+    logits are narrowed back to the real vocabulary.  (When the vocabulary does not divide, the reference's loader itself splits
+    vocab // world rows per rank BEFORE padding, so that every rank's zero rows end up in front of the next rank's real rows and the
+    narrowed logits are shifted -- DESIGN.md section 7; this is the intended layout: logits == the unsharded model's.)"""
+    t, b = tw
+    local = pad_vocab_size(vocab, world) // world
+    lo, hi = rank * local, min((rank + 1) * local, vocab)
+    real = b[lo:hi] if hi > lo else b[:0]
+    if real.shape[0] == local:
+        return (t, np.ascontiguousarray(real))
+    return (t, np.ascontiguousarray(np.concatenate([real, _zero_blocks(t, local - real.shape[0], b.shape[1])], axis=0)))
+
+
 def _rows(tw, rank, world):
     t, b = tw
     n = b.shape[0]
@@ -64,7 +85,8 @@ def shard_config(cfg, rank, world):
     local.n_heads = cfg.n_heads // world
     local.n_kv_heads = kv_head_shard(cfg.n_kv_heads, rank, world)[0]
     local.intermediate = cfg.intermediate if getattr(cfg, "n_expert", 0) else cfg.intermediate // world   # MoE: replicated
-    local.vocab = cfg.vocab // world
+    local.vocab = pad_vocab_size(cfg.vocab, world) // world          # rows of this rank's lm_head shard (zero rows included)
+    local.vocab_total = cfg.vocab                                    # what the gathered logits are narrowed to
     return local
 
 
@@ -72,7 +94,7 @@ def shard_weights(W, cfg, rank, world, requant=None):
     """W: oracle.llama.make_weights dict (global) -> this rank's dict.  tok_embd and the norm vectors are
     replicated."""
     _, kv_rank, kv_world = kv_head_shard(cfg.n_kv_heads, rank, world)
-    out = {"tok_embd": W["tok_embd"], "output_norm": W["output_norm"], "output": _rows(W["output"], rank, world),
+    out = {"tok_embd": W["tok_embd"], "output_norm": W["output_norm"], "output": _rows_padded(W["output"], rank, world, cfg.vocab),
            "layers": []}
     for lw in W["layers"]:
         nl = {"attn_norm": lw["attn_norm"], "ffn_norm": lw["ffn_norm"],

@@ -716,6 +716,9 @@ int64_t mi355_gguf_tensor_shard(void* gguf, int32_t i, int32_t dim, int32_t rank
  * dequantise to f16, narrow to this rank's columns, re-quantise to Q8_0 (f16 d, 32 x i8 per 34-byte block); the mat-mul of such
  * a tensor goes through the Q8_0 arm of mi355_qmatmul_fused (MI355_GGML_Q8_0, native blocks, no repack).  Q4_K / Q6_K sources */
 int64_t mi355_gguf_tensor_shard_q8_0(void* gguf, int32_t tensor, int32_t rank, int32_t world, void* out, int64_t out_cap);
+/* rows [row0, row0 + n_rows) of a 2-D tensor in the file's block format; rows beyond the tensor are ZERO blocks (rows of 0.0): the
+ * vocab-parallel lm_head shard of a padded vocabulary (distributed.rs:1596-1616).  Byte count (out == NULL: size query), -1 / -3 as above. */
+int64_t mi355_gguf_tensor_rows_padded(void* gguf, int32_t tensor, int64_t row0, int64_t n_rows, void* out, int64_t out_cap);
 /* GGUFLLaMa::from_gguf (quantized_llama.rs:203-420): config from the metadata, every tensor handed to the model
  * (matrices Q4_K / Q6_K re-tiled, token_embd dequantised on the device, norms F32).  *model_out = mi355_llama handle. */
 int mi355_llama_load_gguf(const char* path, int32_t max_batch, int32_t max_blocks_per_seq, int32_t block_size,

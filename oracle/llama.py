@@ -229,4 +229,7 @@ class OracleLlama:
         logits = _qmm(xs, W["output"], self.o2)
         if self.comm is not None:                                      # C3: vocab-parallel all-gather
             logits = np.concatenate(self.comm.all_gather(logits), axis=-1)
+            total = getattr(self.cfg, "vocab_total", None)             # padded vocabulary: narrow back (distributed.rs:1657-1660)
+            if total is not None and logits.shape[-1] > total:
+                logits = logits[..., :total]
         return logits

@@ -192,8 +192,8 @@ def test_requantised_shard_equals_the_restated_fallback_bit_for_bit(lib, tmp_pat
 
 def test_load_gguf_tp_rejects_unshardable_files_before_touching_the_gpu(lib, tmp_path):
     """the shard-plan checks of `mi355_llama_load_gguf_tp` run on the host, ahead of any device call: heads that do
-    not divide (attention.rs:553-554), kv heads that neither divide nor replicate (distributed.rs:744-760), a
-    vocabulary `pad_vocab_size` would pad (needs the re-quantising fallback: hipErrorNotSupported = 801)"""
+    not divide (attention.rs:553-554), kv heads that neither divide nor replicate (distributed.rs:744-760).  (A
+    vocabulary `pad_vocab_size` pads is NOT refused: its lm_head shards carry zero rows -- the reader test below.)"""
     from candle_vllm_amd import tp
     from candle_vllm_amd._lib import LlamaConfig
     h, c = ctypes.c_void_p(0), LlamaConfig()
@@ -205,7 +205,6 @@ def test_load_gguf_tp_rejects_unshardable_files_before_touching_the_gpu(lib, tmp
     p1 = os.path.join(tmp_path, "v336.gguf")
     GW.llama_to_gguf(p1, cfg, llama.make_weights(cfg, seed=1))
     assert tp.pad_vocab_size(336, 2) != 336
-    assert load(p1, 0, 2) == 801 and not h.value
     assert load(p1, 2, 2) == 1 and load(p1, 0, 0) == 1            # rank / world out of range
     assert load(p1, 0, 3) == 1                                    # 2 heads over 3 ranks
     cfg = llama.LlamaConfig.tiny(hidden=768, n_heads=6, n_kv_heads=3, head_dim=128, intermediate=512, vocab=384)
@@ -214,6 +213,43 @@ def test_load_gguf_tp_rejects_unshardable_files_before_touching_the_gpu(lib, tmp
     assert load(p2, 0, 2) == 1                                    # 3 kv heads over 2 ranks: neither split nor replicated
     with pytest.raises(ValueError):
         tp.kv_head_shard(3, 0, 2)
+
+
+def test_reader_rows_padded_gives_the_padded_vocabulary_shards(lib, tmp_path):
+    """`mi355_gguf_tensor_rows_padded`: the vocab-parallel lm_head shard of a vocabulary `pad_vocab_size` pads (336 -> 384 over two
+    ranks): the file's own blocks for the real rows, all-zero blocks beyond them -- the same shards candle_vllm_amd/tp.py cuts"""
+    from candle_vllm_amd import tp
+    cfg = llama.LlamaConfig.tiny(hidden=256, n_heads=2, n_kv_heads=2, head_dim=128, intermediate=512, vocab=336)
+    W = llama.make_weights(cfg, seed=1)
+    path = os.path.join(tmp_path, "v336.gguf")
+    GW.llama_to_gguf(path, cfg, W)
+    g = lib.mi355_gguf_open(path.encode())
+    assert g
+    try:
+        i = lib.mi355_gguf_find(g, b"output.weight")
+        assert i >= 0
+        local = tp.pad_vocab_size(336, 2) // 2
+        assert local == 192
+        for rank in range(2):
+            want = tp._rows_padded(W["output"], rank, 2, 336)[1]
+            n = lib.mi355_gguf_tensor_rows_padded(g, i, rank * local, local, None, 0)
+            assert n == want.nbytes
+            buf = np.full(n, 0xAB, np.uint8)
+            assert lib.mi355_gguf_tensor_rows_padded(g, i, rank * local, local, buf.ctypes.data, n) == n
+            assert np.array_equal(buf, want.reshape(-1))
+            assert lib.mi355_gguf_tensor_rows_padded(g, i, rank * local, local, buf.ctypes.data, n - 1) == -3
+        assert not np.frombuffer(tp._rows_padded(W["output"], 1, 2, 336)[1][336 - 192:].tobytes(), np.uint8).any()
+        # a window wholly beyond the tensor: zero blocks only; bad arguments
+        n = lib.mi355_gguf_tensor_rows_padded(g, i, 1000, 4, None, 0)
+        buf = np.full(n, 0xAB, np.uint8)
+        assert lib.mi355_gguf_tensor_rows_padded(g, i, 1000, 4, buf.ctypes.data, n) == n and not buf.any()
+        assert lib.mi355_gguf_tensor_rows_padded(g, i, -1, 4, None, 0) == -1
+        assert lib.mi355_gguf_tensor_rows_padded(g, i, 0, 0, None, 0) == -1
+        assert lib.mi355_gguf_tensor_rows_padded(g, lib.mi355_gguf_n_tensors(g), 0, 4, None, 0) == -1
+        j = lib.mi355_gguf_find(g, b"output_norm.weight")                      # 1-D tensor
+        assert lib.mi355_gguf_tensor_rows_padded(g, j, 0, 4, None, 0) == -1
+    finally:
+        lib.mi355_gguf_close(g)
 
 
 def _walk(lib, g):

@@ -36,8 +36,8 @@ class GlooComm:
         return [o.numpy() for o in outs]
 
 
-def _case(moe=False):
-    cfg = llama.LlamaConfig.tiny(hidden=512, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=1024, vocab=512)
+def _case(moe=False, vocab=512):
+    cfg = llama.LlamaConfig.tiny(hidden=512, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=1024, vocab=vocab)
     if moe:
         cfg.n_expert, cfg.n_expert_used = 4, 2
         W = llama.make_moe_weights(cfg, 4, seed=99)
@@ -49,12 +49,12 @@ def _case(moe=False):
     return cfg, W, seqs
 
 
-def _worker(rank, world, port, q, moe=False):
+def _worker(rank, world, port, q, moe=False, vocab=512):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from candle_vllm_amd import tp
-    cfg, W, seqs = _case(moe)
+    cfg, W, seqs = _case(moe, vocab)
     lcfg = tp.shard_config(cfg, rank, world)
     lW = tp.shard_weights(W, cfg, rank, world)
     m = llama.OracleLlama(lcfg, lW, comm=GlooComm())
@@ -69,15 +69,17 @@ def _worker(rank, world, port, q, moe=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("moe", [False, True])
-def test_tp2_oracle_equals_unsharded(moe):
+@pytest.mark.parametrize("moe,vocab", [(False, 512), (True, 512), (False, 500)])
+def test_tp2_oracle_equals_unsharded(moe, vocab):
+    """vocab = 500: not a fixed point of pad_vocab_size (-> 512): rank 1's lm_head shard carries 12 zero rows and the gathered
+    logits are narrowed back to 500 columns (VocabParallelLinear, distributed.rs:1596-1616,1657-1660)"""
     import importlib.util
     if importlib.util.find_spec("candle_vllm_amd") is None:
         pytest.skip("package not importable")
     # importing candle_vllm_amd needs the built library (symbol check); build on demand
     import __graft_entry__ as ge
     ge.build()
-    cfg, W, seqs = _case(moe)
+    cfg, W, seqs = _case(moe, vocab)
     ref_m = llama.OracleLlama(cfg, W)
     cache = ref_m.new_cache(8)
     pre = ref_m.forward(O.prepare_prompt(seqs, cfg.block_size), cache, is_prefill=True)
@@ -87,10 +89,11 @@ def test_tp2_oracle_equals_unsharded(moe):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, moe)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, moe, vocab)) for r in range(2)]
     for p in procs:
         p.start()
     got_pre, got_dec = q.get(timeout=120)
+    assert got_pre.shape == pre.shape and got_dec.shape == dec.shape and pre.shape[-1] == vocab
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -192,6 +195,29 @@ def test_dense_shard_plan_gptq_shapes():
     assert np.array_equal(np.concatenate([l0["w1"]["qweight"], l1["w1"]["qweight"]], 1), W["layers"][0]["w1"]["qweight"])
     with pytest.raises(ValueError):
         tp.shard_dense_weights(W, cfg, 0, 4)          # 256/4 = 64 rows < group 128
+
+
+def test_padded_vocabulary_shards_carry_zero_rows():
+    """the lm_head shard of a vocabulary pad_vocab_size pads: rows [rank * local, (rank + 1) * local) of the padded matrix, the
+    original blocks verbatim, all-zero blocks (= rows of 0.0 in every k-quant) beyond the real vocabulary"""
+    from candle_vllm_amd import tp
+    cfg = llama.LlamaConfig.tiny(hidden=512, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=1024, vocab=785)   # -> 832 / 2 ranks
+    W = llama.make_weights(cfg, seed=3)
+    t, blocks = W["output"]
+    assert tp.pad_vocab_size(cfg.vocab, 2) == 832
+    got = [tp.shard_weights(W, cfg, r, 2)["output"] for r in range(2)]
+    cat = np.concatenate([b for _, b in got], axis=0)
+    assert all(tt == t and b.shape[0] == 416 for tt, b in got) and cat.shape[0] == 832
+    assert np.array_equal(cat[:785], blocks) and not cat[785:].any()
+    lc = tp.shard_config(cfg, 1, 2)
+    assert (lc.vocab, lc.vocab_total) == (416, 785)
+    # a rank wholly beyond the real vocabulary holds zero rows only
+    assert tp.pad_vocab_size(100, 8) == 128
+    small = (t, blocks[:100])
+    last = tp._rows_padded(small, 7, 8, 100)[1]
+    assert last.shape[0] == 16 and not last.any()
+    six = tp._rows_padded(small, 6, 8, 100)[1]
+    assert np.array_equal(six[:4], blocks[96:100]) and not six[4:].any()    # rows 96..99 are real
 
 
 def test_pad_vocab_size_formula():

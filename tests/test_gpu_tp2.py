@@ -27,8 +27,8 @@ def _free_port():
     return p
 
 
-def _gguf_case(moe=False):
-    cfg = llama.LlamaConfig.tiny(hidden=512, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=1024, vocab=512)
+def _gguf_case(moe=False, vocab=512):
+    cfg = llama.LlamaConfig.tiny(hidden=512, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=1024, vocab=vocab)
     if moe:                                              # Mixtral shape: experts replicated, attention sharded
         cfg.n_expert, cfg.n_expert_used = 4, 2
         W = llama.make_moe_weights(cfg, 4, seed=99)
@@ -40,13 +40,13 @@ def _gguf_case(moe=False):
     return cfg, W, seqs
 
 
-def _gguf_worker(rank, world, port, q, moe=False, p2p=False, wire=0):
+def _gguf_worker(rank, world, port, q, moe=False, p2p=False, wire=0, vocab=512):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from candle_vllm_amd import model as M, tp
-    cfg, W, seqs = _gguf_case(moe)
+    cfg, W, seqs = _gguf_case(moe, vocab)
     comm = tp.TorchDistComm()
     if p2p:
         comm.attach_p2p()                                # decode-sized all-reduces: the one-shot peer kernel (IPC regions)
@@ -138,14 +138,17 @@ def _oracle_two_ranks(cfg, W, seqs, wire):
     return out[0]
 
 
-@pytest.mark.parametrize("moe,p2p,wire", [(False, False, 0), (True, False, 0), (False, True, 0), (False, True, 1), (False, False, 1)])
-def test_gguf_tp2_two_ranks_on_one_gpu_equal_the_unsharded_model(lib, moe, p2p, wire):
+@pytest.mark.parametrize("moe,p2p,wire,vocab", [(False, False, 0, 512), (True, False, 0, 512), (False, True, 0, 512), (False, True, 1, 512),
+                                                 (False, False, 1, 512), (False, False, 0, 500), (False, True, 0, 785)])
+def test_gguf_tp2_two_ranks_on_one_gpu_equal_the_unsharded_model(lib, moe, p2p, wire, vocab):
     """p2p: the all-reduces of the step go through the one-shot peer kernel (two processes, one GPU, IPC-opened regions);
     wire = 1: the reference's bf16 wire numerics (attention.rs:1003-1008) -- both against the UNSHARDED oracle (the bf16
-    wire rounds each partial once more: same 3e-3 band)"""
+    wire rounds each partial once more: same 3e-3 band).  vocab = 500 / 785: vocabularies `pad_vocab_size` pads (a GPT-2-style
+    50257 in small: odd, -> 512 / 832): the lm_head shards carry zero rows, the gathered logits are narrowed back and the greedy
+    loop samples over the real vocabulary only (VocabParallelLinear, distributed.rs:1448-1454,1596-1616,1657-1660)"""
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a visible MI355X")
-    cfg, W, seqs = _gguf_case(moe)
+    cfg, W, seqs = _gguf_case(moe, vocab)
     wire_ref = _oracle_two_ranks(cfg, W, seqs, 1) if wire else None    # the reference's numerics, restated on two oracle ranks
     orc = llama.OracleLlama(cfg, W, flash_layout=False)
     cache = orc.new_cache(8)
@@ -167,7 +170,7 @@ def test_gguf_tp2_two_ranks_on_one_gpu_equal_the_unsharded_model(lib, moe, p2p, 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gguf_worker, args=(r, 2, port, q, moe, p2p, wire)) for r in range(2)]
+    procs = [ctx.Process(target=_gguf_worker, args=(r, 2, port, q, moe, p2p, wire, vocab)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}
@@ -180,7 +183,7 @@ def test_gguf_tp2_two_ranks_on_one_gpu_equal_the_unsharded_model(lib, moe, p2p, 
     for rank in (0, 1):                                   # every rank ends up with the full logits
         got_pre, got_dec, toks, p2p_err = res[rank]
         assert p2p_err == 0                               # no peer wait ran into its spin bound
-        assert got_pre.shape == pre.shape and got_dec.shape == dec.shape
+        assert got_pre.shape == pre.shape and got_dec.shape == dec.shape and pre.shape[-1] == vocab
         if wire:
             # The bf16 wire moves the logits ~3e-3 of their scale away from the unsharded f32 model (the 2-rank ORACLE with
             # the same wire: 2.97e-3), and which partials round up or down flips on 1e-6 differences between two correct
@@ -279,7 +282,7 @@ def _unaligned_case():
     return cfg, W, seqs
 
 
-def _gguf_file_worker(rank, world, port, q, path, unaligned=False):
+def _gguf_file_worker(rank, world, port, q, path, unaligned=False, vocab=512):
     try:
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
         import torch.distributed as dist
@@ -287,7 +290,7 @@ def _gguf_file_worker(rank, world, port, q, path, unaligned=False):
         torch.cuda.set_device(0)
         from candle_vllm_amd import model as M, tp
         from oracle import kquants as kq
-        cfg, W, seqs = _unaligned_case() if unaligned else _gguf_case(False)
+        cfg, W, seqs = _unaligned_case() if unaligned else _gguf_case(False, vocab)
         W = dict(W)
         W["tok_embd"] = kq.dequantize_q6_k(kq.quantize(W["tok_embd"], kq.GGML_Q6_K)).reshape(cfg.vocab, cfg.hidden).astype(np.float32)
         # both models are built before the first collective, so a loader error cannot leave the peer waiting
@@ -312,16 +315,17 @@ def _gguf_file_worker(rank, world, port, q, path, unaligned=False):
         raise
 
 
-def test_gguf_file_loader_tp2_equals_setter_shards(lib, tmp_path):
+@pytest.mark.parametrize("vocab", [512, 500])
+def test_gguf_file_loader_tp2_equals_setter_shards(lib, tmp_path, vocab):
     """f3 'TP re-sharding': every rank opens the same GGUF file through `mi355_llama_load_gguf_tp` and keeps its raw
     byte-range shard (get_sharded_no_shape, quantized_var_builder.rs:222-233); the prompt-step logits must be
     bit-identical to the model whose shards were cut by candle_vllm_amd/tp.py and handed over through the setters, and
-    agree with the unsharded oracle."""
+    agree with the unsharded oracle.  vocab = 500: the loader pads the lm_head shards with zero rows (-> 512)."""
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a visible MI355X")
     from oracle import gguf_writer as GW
     from oracle import kquants as kq
-    cfg, W, seqs = _gguf_case(False)
+    cfg, W, seqs = _gguf_case(False, vocab)
     W = dict(W)
     W["tok_embd"] = kq.dequantize_q6_k(kq.quantize(W["tok_embd"], kq.GGML_Q6_K)).reshape(cfg.vocab, cfg.hidden).astype(np.float32)
     path = os.path.join(tmp_path, "tp2.gguf")
@@ -331,7 +335,7 @@ def test_gguf_file_loader_tp2_equals_setter_shards(lib, tmp_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gguf_file_worker, args=(r, 2, port, q, path)) for r in range(2)]
+    procs = [ctx.Process(target=_gguf_file_worker, args=(r, 2, port, q, path, False, vocab)) for r in range(2)]
     for p in procs:
         p.start()
     res, err = {}, None
