@@ -43,7 +43,8 @@ def _rows_padded(tw, rank, world, vocab):
     owns rows [r * local, (r + 1) * local) of the padded matrix, the rows beyond the real vocabulary are ZERO rows, and the gathered
     logits are narrowed back to the real vocabulary.  (When the vocabulary does not divide, the reference's loader itself splits
     vocab // world rows per rank BEFORE padding, so that every rank's zero rows end up in front of the next rank's real rows and the
-    narrowed logits are shifted -- DESIGN.md section 7; this is the intended layout: logits == the unsharded model's.)"""
+    narrowed logits are shifted -- DESIGN.md section 7; this is the layout of VocabParallelLinear::from_weight_bias, distributed.rs:1534-1550:
+    pad the whole matrix, then narrow(rank * local, local): logits == the unsharded model's.)"""
     t, b = tw
     local = pad_vocab_size(vocab, world) // world
     lo, hi = rank * local, min((rank + 1) * local, vocab)

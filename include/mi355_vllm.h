@@ -727,9 +727,10 @@ int mi355_llama_load_gguf(const char* path, int32_t max_batch, int32_t max_block
  * `tp_rank` of `tp_world` reads the file and keeps its shard -- attn_q / ffn_gate / ffn_up / output rows, attn_k / attn_v
  * rows of `kv_head_shard` (replicated groups when Hkv < W), attn_output / ffn_down k-blocks; token_embd, norms and a
  * Mixtral layer's router + experts whole.  cfg_out holds the GLOBAL dimensions plus tp_rank / tp_world; attach a
- * communicator (mi355_llama_init_comm / mi355_llama_set_comm) before the first step.  hipErrorNotSupported when a shard
- * would need the reference's re-quantisation fallback (k/W not a multiple of 256, or a vocabulary that
- * `pad_vocab_size` would pad). */
+ * communicator (mi355_llama_init_comm / mi355_llama_set_comm) before the first step.  An attn_output / ffn_down shard that
+ * cuts a k-quant block is re-quantised to Q8_0 (quantized_var_builder.rs:234-269); a vocabulary `pad_vocab_size` pads
+ * (distributed.rs:1448-1454) gets zero rows: rank r holds rows [r * local, (r + 1) * local) of the padded matrix and the
+ * logits come back narrowed to the real vocabulary (= the unsharded model's). */
 int mi355_llama_load_gguf_tp(const char* path, int32_t max_batch, int32_t max_blocks_per_seq, int32_t block_size,
                              int32_t kv_layout, int32_t max_seq, int32_t tp_rank, int32_t tp_world, void** model_out,
                              mi355_llama_config* cfg_out);
