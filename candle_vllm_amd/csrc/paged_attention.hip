@@ -442,7 +442,6 @@ __device__ __forceinline__ void pa_mfma_partition(const PAParams& p, const int b
     const int c = lane & 15, kg = lane >> 4;
     const uint16_t* kc = static_cast<const uint16_t*>(p.kc);
     const uint16_t* vc = static_cast<const uint16_t*>(p.vc);
-    const uint32_t* bt = p.block_tables + (int64_t)b * p.max_blocks;
 
     // Token order inside a 32-token pair of tiles is chosen for the MEMORY side: tile A row 4g+v <-> token 8g+v, tile B
     // row 4g+v <-> token 8g+4+v.  Then (i) a lane's probabilities of tiles A and B are the 8 consecutive tokens
@@ -455,6 +454,10 @@ __device__ __forceinline__ void pa_mfma_partition(const PAParams& p, const int b
     static_assert(NT % 2 == 0, "tiles come in pairs");
     const bool bs_pow2 = (bs & (bs - 1)) == 0;
     const int bs_shift = __ffs(bs) - 1;
+    // (round 3 A/B on one box: the table entries requested once per wave ahead of the context length -- one relaxed atomic load,
+    // handed out by ds_bpermute as pa_mfma_chunk does -- ran the batch-32 step 1.5 % SLOWER, 5905 vs 5995 tok/s three times over,
+    // batch 1 unchanged: the compiler already issues these loads together, and the bpermute sits in front of every K / V address)
+    const uint32_t* bt = p.block_tables + (int64_t)b * p.max_blocks;
     auto locate = [&](int tok, int64_t& blk, int& off) {
         const int q = bs_pow2 ? (tok >> bs_shift) : (tok / bs);
         blk = (int64_t)bt[q];
@@ -590,6 +593,191 @@ __device__ __forceinline__ void pa_mfma_partition(const PAParams& p, const int b
     }
 }
 
+// The same arithmetic as a LOOP over the 32-token pairs of one wave's chunk [t0, t1) (256 / 512 tokens), for launches with many
+// sequences and long contexts (batch 32 at 4 k tokens: 32 768 one-partition waves lived 6.4 us each, 55 % of it parked behind the
+// block-table -> K/V dependent round trips, the store drain and the arrival ticket, and held 16 KB in flight for a third of that --
+// r03_pmc_sq_b32: SQ_WAIT_ANY 0.55 of SQ_WAVE_CYCLES, 6.4 of 16 possible waves resident per CU, 4.2 TB/s).  Here a wave
+//   * reads its chunk's block ids ONCE (one table entry per lane, handed out by ds_bpermute),
+//   * keeps one group of loads in flight while it computes on the other: V of pair i is requested before the QK^T of pair i, K of
+//     pair i + 1 before the P.V of pair i,
+//   * carries the running maximum and sum across pairs (online softmax: O and the sum are rescaled by exp(m_old - m_new) -- the
+//     column statistic of head 4kg+v comes from lane 4kg+v through ds_bpermute),
+//   * and pays Q, the in-workgroup merge, the partial store and the arrival ticket once per chunk instead of once per 32 tokens.
+// Same fragment placement, masking rules and outputs (unnormalised O, m, bf16-rounded sum) as pa_mfma_partition.
+template <int D32, bool KV8>
+__device__ __forceinline__ void pa_mfma_chunk(const PAParams& p, const int b, const int hk, const int t0, const int t1,
+                                              const int lane, const int btv, f32x4_t (&o)[2 * D32], float& m, float& lsum) {
+    constexpr int D = 32 * D32, NTD = D / 16;
+    const int G = p.H / p.Hkv, bs = p.block_size;
+    const int c = lane & 15, kg = lane >> 4;
+    const uint16_t* kc = static_cast<const uint16_t*>(p.kc);
+    const uint16_t* vc = static_cast<const uint16_t*>(p.vc);
+    const bool bs_pow2 = (bs & (bs - 1)) == 0;
+    const int bs_shift = __ffs(bs) - 1;
+    // block ids of the chunk: lane l of `btv` holds table entry t0 / bs + l (t0 is a multiple of the block size; the chunk has at
+    // most 64 blocks -- pa_dispatch checks both); only entries of valid tokens are used
+    auto locate = [&](int rel, int64_t& blk, int& off) {              // rel = token - t0
+        const int q = bs_pow2 ? (rel >> bs_shift) : (rel / bs);
+        blk = (int64_t)__builtin_amdgcn_ds_bpermute(4 * q, btv);
+        off = rel - q * bs;
+    };
+    uint4 qf[D32];
+#pragma unroll
+    for (int j = 0; j < D32; ++j) {
+        qf[j] = make_uint4(0, 0, 0, 0);
+        if (c < G)
+            qf[j] = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_stride +
+                                                    (int64_t)(hk * G + c) * D + 32 * j + 8 * kg);
+    }
+    typedef typename std::conditional<KV8, uint2, uint4>::type kraw_t;
+    typedef typename std::conditional<KV8, uint2, uint4>::type vraw_t;
+    kraw_t kf[2][D32];
+    vraw_t vraw[NTD];
+    const int krow_tok = 8 * (c >> 2) + (c & 3);                      // token of MFMA row c inside its pair (tile A; B: +4)
+    const int vq = lane & 3, vch = lane >> 2;                         // V load placement: 8-token chunk vq of channel 16nt + vch
+    const int np = (t1 - t0 + 31) >> 5;                               // pairs of this chunk (>= 1: the caller checked t0 < t1)
+    // K of pair ip.  Rows at or beyond t1 read the chunk's first token (masked below); tile B's row is 4 tokens further in
+    // the SAME block (block size % 8 == 0), allocated whenever tile A's token is valid.  `fetch` false (nothing left to
+    // prefetch): every lane reads the same 16 bytes -- one request instead of a predicated load, which would make the
+    // compiler drain the whole queue
+    auto issue_k = [&](int ip, bool fetch) {
+        int rel = 32 * ip + krow_tok;
+        if (!fetch || t0 + rel >= t1) rel = 0;
+        int64_t blk; int off;
+        locate(rel, blk, off);
+        const int f = fetch ? 1 : 0;
+        if constexpr (KV8) {
+            const uint8_t* kb = static_cast<const uint8_t*>(p.kc) + ((blk * p.Hkv + hk) * (D / 16)) * (int64_t)bs * 16 +
+                                (int64_t)f * (off * 16 + 8 * (kg & 1));
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int j = 0; j < D32; ++j)
+                    kf[it][j] = *reinterpret_cast<const uint2*>(kb + (int64_t)f * ((int64_t)(2 * j + (kg >> 1)) * bs * 16 + it * 64));
+        } else {
+            const uint16_t* kb = kc + ((blk * p.Hkv + hk) * (D / 8)) * (int64_t)bs * 8 + (int64_t)f * off * 8;
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int j = 0; j < D32; ++j)
+                    kf[it][j] = *reinterpret_cast<const uint4*>(kb + (int64_t)f * ((int64_t)(4 * j + kg) * bs * 8 + it * 32));
+        }
+    };
+    auto issue_v = [&](int ip) {
+        int rel = 32 * ip + 8 * vq;
+        if (t0 + rel >= t1) rel = 0;
+        int64_t blk; int off;
+        locate(rel, blk, off);                                        // 8 consecutive tokens never straddle a block
+        if constexpr (KV8) {
+            const uint8_t* vb = static_cast<const uint8_t*>(p.vc) + ((blk * p.Hkv + hk) * D + vch) * (int64_t)bs + off;
+#pragma unroll
+            for (int nt = 0; nt < NTD; ++nt) vraw[nt] = *reinterpret_cast<const uint2*>(vb + (int64_t)(16 * nt) * bs);
+        } else {
+            const uint16_t* vb = vc + ((blk * p.Hkv + hk) * D + vch) * (int64_t)bs + off;
+#pragma unroll
+            for (int nt = 0; nt < NTD; ++nt) vraw[nt] = *reinterpret_cast<const uint4*>(vb + (int64_t)(16 * nt) * bs);
+        }
+    };
+    const float qk_scale = KV8 ? p.scale * p.k_scale : p.scale;
+    const int src_lane4 = 4 * (4 * c + kg);                           // V: byte address of lane 4c+kg for ds_bpermute
+    float m_run = -1e30f, l_run = 0.f;                                // head c's running maximum (all four kg lanes), this lane's share of the sum
+#pragma unroll
+    for (int nt = 0; nt < NTD; ++nt) o[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    issue_k(0, true);
+    for (int ip = 0; ip < np; ++ip) {
+        issue_v(ip);
+        // ---- S^T = K . Q^T : lane (head c, rows 4kg+v); row 4kg+v of tile `it` is token 32ip + 8kg + 4it + v
+        float sc[2][4];
+        float mp = -1e30f;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < D32; ++j) {
+                uint4 ka;
+                if constexpr (KV8) { const uint2 lo = fp8x4_to_bf16x4(kf[it][j].x), hi = fp8x4_to_bf16x4(kf[it][j].y); ka = make_uint4(lo.x, lo.y, hi.x, hi.y); }
+                else ka = kf[it][j];
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ka),
+                                                              __builtin_bit_cast(bf16x8_t, qf[j]), acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) sc[it][v] = acc[v] * qk_scale;
+        }
+        // K of the next pair goes out as soon as this pair's K registers are free
+        issue_k(ip + 1 < np ? ip + 1 : 0, ip + 1 < np);
+        if (p.softcap > 0.f) {                                        // one uniform branch for the eight logits
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) sc[it][v] = tanhf(sc[it][v] / p.softcap) * p.softcap;
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int tokb = t0 + 32 * ip + 8 * kg + 4 * it;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                sc[it][v] = (tokb + v < t1) ? sc[it][v] : -1e30f;
+                mp = fmaxf(mp, sc[it][v]);
+            }
+        }
+        mp = fmaxf(mp, __shfl_xor(mp, 16, 64));
+        mp = fmaxf(mp, __shfl_xor(mp, 32, 64));
+        const float m_new = fmaxf(m_run, mp);                         // finite: every pair of the loop has a valid token
+        const float alpha = __expf(m_run - m_new);                    // first pair: exp(-1e30 - m) = 0
+        m_run = m_new;
+        uint2 pf[2];
+        float lp = 0.f;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int tokb = t0 + 32 * ip + 8 * kg + 4 * it;
+            float pr[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) pr[v] = (tokb + v < t1) ? __expf(sc[it][v] - m_new) : 0.f;
+            pf[it] = make_uint2(cvt_pk_bf16(pr[0], pr[1]), cvt_pk_bf16(pr[2], pr[3]));
+            // the normaliser must match what the MFMA sums: the bf16-rounded probabilities
+            lp += (bf16lo_to_f32(pf[it].x) + bf16hi_to_f32(pf[it].x)) + (bf16lo_to_f32(pf[it].y) + bf16hi_to_f32(pf[it].y));
+        }
+        l_run = fmaf(l_run, alpha, lp);
+        // ---- O = O * alpha + P . V : lane (channel 16nt + c, heads 4kg+v) -- head 4kg+v's alpha sits in lane 4kg+v
+        float av[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) av[v] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (4 * kg + v), __float_as_int(alpha)));
+        const uint4 pa = make_uint4(pf[0].x, pf[0].y, pf[1].x, pf[1].y);
+        // never multiply 0 by unwritten (maybe NaN) V: tokens at or beyond t1 are cleared in the B fragment (branch-free: the
+        // masks are all ones for every pair but the last)
+        const int tk = t0 + 32 * ip + 8 * kg;                         // first token of this lane's 8
+        uint32_t vmask[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            vmask[e] = (tk + 2 * e < t1 ? 0x0000FFFFu : 0u) | (tk + 2 * e + 1 < t1 ? 0xFFFF0000u : 0u);
+#pragma unroll
+        for (int nt = 0; nt < NTD; ++nt) {
+            uint4 vv;
+            if constexpr (KV8) {
+                const uint32_t r0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)vraw[nt].x);
+                const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)vraw[nt].y);
+                const uint2 lo = fp8x4_to_bf16x4(r0), hi = fp8x4_to_bf16x4(r1);
+                vv = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            } else {
+                vv.x = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)vraw[nt].x);
+                vv.y = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)vraw[nt].y);
+                vv.z = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)vraw[nt].z);
+                vv.w = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)vraw[nt].w);
+            }
+            vv.x &= vmask[0]; vv.y &= vmask[1]; vv.z &= vmask[2]; vv.w &= vmask[3];
+            f32x4_t on = o[nt];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) on[v] *= av[v];
+            o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pa),
+                                                            __builtin_bit_cast(bf16x8_t, vv), on, 0, 0, 0);
+        }
+    }
+    m = m_run;
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    lsum = l_run;
+}
+
 // WPB = waves per workgroup.  1: one partition per workgroup (many sequences: the grid is large anyway).  > 1: the
 // workgroup takes WPB consecutive partitions, one per wave, and merges them in LDS before anything goes to global
 // memory -- WPB x fewer partials for the reduce / fused merge, which is what bounds the step at batch 1 (129
@@ -602,9 +790,16 @@ __global__ void __launch_bounds__(64 * WPB) paged_attn_mfma_kernel(const PAParam
     const int part = blockIdx.z * WPB + wave;
     // a context longer than the launch was sized for is truncated to the grid (the host layer refuses such a step): the
     // partition count below must match the launched grid or the fused merge's ticket never completes
+    const int t0 = part * p.partition_size;
+    // looped chunks: the table entries of this wave's chunk go out before the context length is known -- lane l asks for entry
+    // t0 / bs + l (clamped to the row: entries beyond the context hold no block id and are never used).  A relaxed atomic load: a
+    // plain one is sunk below the context-length branch by the compiler, back into the dependent chain.
+    int btv = 0;
+    if constexpr (NT == 0)
+        btv = (int)__hip_atomic_load(p.block_tables + (int64_t)b * p.max_blocks + min(t0 / p.block_size + lane, p.max_blocks - 1),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     const int ctx = min((int)p.context_lens[b], p.max_partitions * p.partition_size);
     if (blockIdx.z * WPB * p.partition_size >= ctx) return;        // uniform for the workgroup
-    const int t0 = part * p.partition_size;
     const bool live = t0 < ctx;
     const int t1 = min(ctx, t0 + p.partition_size);
     const int G = p.H / p.Hkv;
@@ -614,7 +809,10 @@ __global__ void __launch_bounds__(64 * WPB) paged_attn_mfma_kernel(const PAParam
     float m = -1e30f, lsum = 0.f;
 #pragma unroll
     for (int nt = 0; nt < NTD; ++nt) o[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if (live) pa_mfma_partition<D32, NT, KV8>(p, b, hk, t0, t1, lane, o, m, lsum);
+    if (live) {
+        if constexpr (NT == 0) pa_mfma_chunk<D32, KV8>(p, b, hk, t0, t1, lane, btv, o, m, lsum);  // partition = a chunk of 32-token pairs, looped
+        else pa_mfma_partition<D32, NT, KV8>(p, b, hk, t0, t1, lane, o, m, lsum);
+    }
     const int group_tokens = p.partition_size * WPB;               // tokens behind one partial in tmp_out
     const int pslot = blockIdx.z;
     if constexpr (WPB > 1) {
@@ -851,6 +1049,15 @@ static int launch_mfma_w(const PAParams& p, int B, int P, hipStream_t st) {
     dim3 grid(p.Hkv, B, (P + WPB - 1) / WPB), block(64 * WPB);
     const int nt = p.partition_size / 16;
     const size_t shm = WPB > 1 ? (size_t)WPB * (p.H / p.Hkv) * (32 * D32 + 2) * sizeof(float) : 0;
+    if (p.partition_size >= 256) {                                  // chunks of 32-token pairs, looped inside the wave (NT = 0)
+        if constexpr (WPB == 1 || WPB == 4) {
+            if (p.kv8) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 0, true, WPB>), grid, block, shm, st, p);
+            else hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 0, false, WPB>), grid, block, shm, st, p);
+            return (int)hipGetLastError();
+        } else {
+            return (int)hipErrorInvalidValue;
+        }
+    }
     if (p.kv8) {
         if (nt == 2) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 2, true, WPB>), grid, block, shm, st, p);
         else if (nt == 4) hipLaunchKernelGGL((paged_attn_mfma_kernel<D32, 4, true, WPB>), grid, block, shm, st, p);
@@ -896,6 +1103,7 @@ static int launch_flash(const PAParams& p, int B, int P, hipStream_t st) {
 #define PA_ARRIVE_SLOTS 65536
 static int g_pa_fused = 1;                                          // mi355_set_tuning(3, 0) -> separate reduce launch
 static int g_pa_wpb = 0;                                            // mi355_set_tuning(8, 1 | 4): waves (partitions) per workgroup, 0 = auto
+static int g_pa_loop = 1;                                           // mi355_set_tuning(44, 0): partition sizes 256 / 512 go to the generic kernel again
 
 static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t stream) {
     if (B <= 0) return 0;
@@ -913,14 +1121,18 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
                                              : launch_flash<MI355_DTYPE_F16, false>(p, B, P, st);
     } else if (layout == MI355_KV_PAGED && dtype == MI355_DTYPE_BF16 && (p.D == 128 || p.D == 64) &&
                p.H / p.Hkv <= 16 && (p.block_size % 16) == 0 &&
-               (p.partition_size == 32 || p.partition_size == 64 || p.partition_size == 128)) {
+               (p.partition_size == 32 || p.partition_size == 64 || p.partition_size == 128 ||
+                (g_pa_loop && (p.partition_size == 256 || p.partition_size == 512) && p.partition_size % p.block_size == 0 &&
+                 p.partition_size / p.block_size <= 64))) {
         bool fused = false;
+        const bool loop = p.partition_size >= 256;                  // pa_mfma_chunk: one wave walks its chunk pair by pair
         // few sequences, many partitions: 4 partitions per workgroup, merged in LDS (4 x fewer partials to reduce)
         // one sequence with a long context (batch-1 decode): 8 partitions per workgroup and the merge in the last arriver --
         // measured +1 % on the whole step in three sessions (507 -> 512 tok/s); at 2..8 sequences it is noise, so the rule stops there
         const bool lone = (int64_t)B * p.Hkv <= 8 && P >= 32 && p.partition_size <= 64 && g_pa_fused == 1 && g_pa_wpb == 0;
         if (g_pa_wpb > 0) wpb = ((g_pa_wpb == 4 || g_pa_wpb == 8 || g_pa_wpb == 16) && p.partition_size <= 64) ? g_pa_wpb : 1;
         else wpb = lone ? 8 : ((P >= 8 && p.partition_size <= 64) ? 4 : 1);
+        if (loop) wpb = P > 1 ? 4 : 1;                              // four chunks per workgroup, merged in LDS
         // launch_mfma_w needs WPB * G * (32 * D32 + 2) * 4 bytes of dynamic LDS and no larger-LDS attribute is set for it: with 16 query
         // heads per kv head and D = 128 eight partitions per workgroup would ask for 66 560 B and the launch fails
         {
@@ -965,6 +1177,7 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
 
 void mi355_pa_set_fused(int v) { g_pa_fused = v; }
 void mi355_pa_set_wpb(int v) { g_pa_wpb = v; }
+void mi355_pa_set_loop(int v) { g_pa_loop = v; }
 
 // decode attention over an fp8 (e4m3fn) KV cache in the PAGED layout (K x = 16); partition_size 0 = one pass (v1)
 extern "C" int mi355_paged_attention_fp8(void* out, float* exp_sums, float* max_logits, float* tmp_out, const void* q,

@@ -1989,6 +1989,7 @@ static int qmp_launch(const QmmArgs& a0, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------ launcher
 void mi355_pa_set_fused(int v);
 void mi355_pa_set_wpb(int v);
+void mi355_pa_set_loop(int v);
 void mi355_dense_set_small(int key, int v);
 extern "C" void mi355_host_set_partition_override(int v);
 extern "C" void mi355_host_set_moe_group(int v);
@@ -2031,6 +2032,7 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     else if (key == 41) mi355_host_set_moe_group(value);
     else if (key == 42) mi355_dense_set_tile(value);
     else if (key == 43) mi355_prefill_set_fp8_generic(value);
+    else if (key == 44) mi355_pa_set_loop(value);
 }
 
 static size_t qmm_lds_bytes(int BT, int R, int NW) {

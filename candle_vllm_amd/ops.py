@@ -237,7 +237,8 @@ class PagedAttention:
             return out
         ps = choose_partition(T, self.num_kv_heads, meta.max_context_len) if partition_size is None else partition_size
         if ps:
-            ps = 32 if ps <= 32 else (64 if ps <= 64 else 128)
+            if not (ps in (256, 512) and ps % bs == 0):             # 256 / 512: chunks walked inside the wave (pa_mfma_chunk)
+                ps = 32 if ps <= 32 else (64 if ps <= 64 else 128)
             P = -(-meta.max_context_len // ps)
             tmp, mx, sm = self._workspace(T, P, q.device)
             _check(lib.mi355_paged_attention_fp8(_dev(out), _dev(sm), _dev(mx), _dev(tmp), _dev(q), _dev(key_cache),
@@ -288,6 +289,12 @@ class PagedAttention:
         ps = choose_partition(B, self.num_kv_heads, meta.max_context_len) if partition_size is None else partition_size
         if layout == KV_PAGED and ps == 0 and meta.max_context_len > 8192:
             ps = 4096
+        if (partition_size is None and ps and layout == KV_PAGED and q.dtype == torch.bfloat16 and D in (64, 128)
+                and H // self.num_kv_heads <= 16 and bs % 16 == 0):
+            # the MFMA kernel's shapes: 32-token partitions, several per workgroup -- the choice of the C++ step drivers
+            # (host_model.cpp / dense_model.cpp).  Any other size would fall to the generic kernel, 40x slower at 4 k contexts
+            # (tools/exp_attn_loop.py); an explicit partition_size is passed through (256 / 512: the looped chunks)
+            ps = 32
         if ps == 0:
             _check(lib.mi355_paged_attention_v1(_dev(out), _dev(q), _dev(key_cache), _dev(value_cache), _dev(bt),
                                                 _dev(cl), B, H, self.num_kv_heads, D, bs, bt.shape[1],

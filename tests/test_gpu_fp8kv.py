@@ -52,7 +52,8 @@ def test_e4m3_cache_write_is_bit_exact(cv):
 
 
 @pytest.mark.parametrize("H,Hkv,D,bs,ctxs,ps", [(8, 2, 128, 64, [300, 64, 129], None), (4, 4, 64, 16, [40, 7], 0),
-                                                (8, 2, 128, 16, [200, 33], 32), (4, 2, 80, 16, [50], 0)])
+                                                (8, 2, 128, 16, [200, 33], 32), (4, 2, 80, 16, [50], 0),
+                                                (8, 2, 128, 64, [700, 300, 64, 257], 256), (8, 2, 128, 16, [1100, 33], 512)])
 def test_decode_attention_over_fp8_cache(cv, H, Hkv, D, bs, ctxs, ps):
     if D % 16:
         pytest.skip("x = 16 layout needs head_dim % 16 == 0")

@@ -576,3 +576,56 @@ def test_paged_attention_workgroup_merge_equals_one_wave_per_partition(cv, bs, c
                 assert np.abs(got - oracle).max() <= tol, (wpb, ps, fused, np.abs(got - oracle).max())
                 outs[(wpb, ps, fused)] = got
     assert np.abs(outs[(4, 32, 0)] - outs[(1, 32, 0)]).max() <= tol
+
+
+@pytest.mark.parametrize("H,Hkv,D,bs,ctx", [
+    (32, 8, 128, 64, [4100, 37, 520, 256, 257, 1024]),   # llama-3 heads; chunk-boundary lengths, one sequence below a chunk
+    (32, 8, 128, 16, [1000, 259, 15]),                   # 16-token blocks: 16 / 32 table entries per chunk
+    (28, 4, 128, 32, [777, 2049]),                       # qwen2: GQA group of 7
+    (8, 2, 64, 16, [900, 300]),                          # head_dim 64
+    (32, 8, 128, 64, [9000, 300]),                       # > 32 partials per head at 256-token chunks
+])
+def test_paged_attention_looped_chunks_equal_the_oracle(cv, H, Hkv, D, bs, ctx):
+    """partition sizes 256 / 512 on the PAGED layout: one wave walks its chunk 32 tokens at a time (online softmax, K / V of the
+    next step in flight) -- against the oracle, with the separate reduce launch, the fused merge, and against the one-partition
+    waves (same bound: 1 bf16 ulp of the largest output)"""
+    from candle_vllm_amd import tuning
+    rng = np.random.default_rng(43)
+    q, kc, vc, bt, cl = _attn_case(rng, len(ctx), H, Hkv, D, bs, ctx, False)
+    pa = cv.PagedAttention(H, D, 1 / np.sqrt(D), Hkv)
+    meta = cv.InputMetadata(False, dev(np.zeros(len(ctx), np.int64)), dev(bt.astype(np.int32)), dev(cl.astype(np.int32)),
+                            max_context_len=max(ctx))
+    qd, kcd, vcd = dev(q, torch.bfloat16), bf16_dev(kc), bf16_dev(vc)
+    oracle = O.paged_attention_decode(q, kc, vc, bt, cl, 1 / np.sqrt(D), False)
+    tol = 2 ** -7 * np.abs(oracle).max() + 1e-6
+    for ps in (256, 512):
+        for fused in (0, 2):
+            with tuning(3, fused):
+                got = pa.decode(qd, kcd, vcd, meta, None, partition_size=ps).float().cpu().numpy()
+            assert np.isfinite(got).all()
+            assert np.abs(got - oracle).max() <= tol, (ps, fused, np.abs(got - oracle).max())
+    with tuning(44, 0):                                               # the generic kernel at the same partition size
+        old = pa.decode(qd, kcd, vcd, meta, None, partition_size=256).float().cpu().numpy()
+    assert np.abs(old - oracle).max() <= tol
+    # softcap through the loop
+    ref = O.paged_attention_decode(q, kc, vc, bt, cl, 1 / np.sqrt(D), False, softcap=20.0)
+    got = pa.decode(qd, kcd, vcd, meta, 20.0, partition_size=256).float().cpu().numpy()
+    assert np.abs(got - ref).max() <= 2 ** -7 * np.abs(ref).max() + 1e-6
+
+
+def test_paged_attention_looped_chunks_many_sequences(cv):
+    """the launch shape the loop is for: sequences x kv heads >= 64 (fused merge by default, four chunks per workgroup), ragged"""
+    rng = np.random.default_rng(44)
+    H, Hkv, D, bs = 32, 8, 128, 64
+    ctx = [int(c) for c in rng.integers(1, 1500, 12)] + [1024, 1025]
+    q, kc, vc, bt, cl = _attn_case(rng, len(ctx), H, Hkv, D, bs, ctx, False)
+    pa = cv.PagedAttention(H, D, 1 / np.sqrt(D), Hkv)
+    meta = cv.InputMetadata(False, dev(np.zeros(len(ctx), np.int64)), dev(bt.astype(np.int32)), dev(cl.astype(np.int32)),
+                            max_context_len=max(ctx))
+    qd, kcd, vcd = dev(q, torch.bfloat16), bf16_dev(kc), bf16_dev(vc)
+    oracle = O.paged_attention_decode(q, kc, vc, bt, cl, 1 / np.sqrt(D), False)
+    tol = 2 ** -7 * np.abs(oracle).max() + 1e-6
+    for ps in (256, 512):
+        for _ in range(3):                                            # the arrival counters must come back to zero
+            got = pa.decode(qd, kcd, vcd, meta, None, partition_size=ps).float().cpu().numpy()
+            assert np.abs(got - oracle).max() <= tol, (ps, np.abs(got - oracle).max())
