@@ -89,7 +89,10 @@ int mi355_reshape_and_cache(const void* k, const void* v, void* key_cache, void*
  * softcap <= 0 disables soft-capping.  v1 = one partition per sequence; v2 = context split into
  * partition_size-token partitions merged by a log-sum-exp reduce
  * (tmp_out f32 [num_seqs,num_heads,P,head_dim], exp_sums/max_logits f32 [num_seqs,num_heads,P],
- *  P = ceil(max_context_len/partition_size)). */
+ *  P = ceil(max_context_len/partition_size)).  On the PAGED layout (bf16, head_dim 64 / 128, <= 16 query heads per kv head,
+ *  block_size % 16 == 0) the MFMA kernel serves partition_size 32 / 64 / 128 (one wave per partition) and 256 / 512 (one wave
+ *  walks its chunk 32 tokens at a time; needs partition_size % block_size == 0); every other size runs the generic kernel,
+ *  which is far slower at long contexts -- the step drivers use 32. */
 int mi355_paged_attention_v1(void* out, const void* q, const void* key_cache, const void* value_cache,
                              const uint32_t* block_tables, const uint32_t* context_lens, int32_t num_seqs,
                              int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
@@ -263,7 +266,8 @@ int mi355_moe_scatter_combine(float* ys, const float* y_sorted, const float* wei
  * workgroup of the 1..4-token 4-bit kernel (hidden-sized K / long K), 31 that kernel off, 32 no norm on the way in, 34 RoPE and
  * cache write in their own launch, 36 tokens from which 16-bit projections take the MFMA GEMM (96), 37 the LDS-shared-activation
  * 16-bit kernel off, 38 its waves per workgroup (2 | 4), 41 MoE decode grouping on the device (1 on), 42 16-bit host layer keeps its
- * projections in tiles (1 on; read at the first step).  A/B switches for measurements and tests: no product path depends on a
+ * projections in tiles (1 on; read at the first step), 43 fp8-cache prefill on the generic kernel, 44 decode attention partition sizes
+ * 256 / 512 as looped chunks on the MFMA kernel (1 on; 0 = the generic kernel).  A/B switches for measurements and tests: no product path depends on a
  * non-default value.  mi355_get_tuning returns what a key was last set to (INT32_MIN: never set), so a caller can restore what it
  * found instead of assuming the default. */
 void mi355_set_tuning(int32_t key, int32_t value);
