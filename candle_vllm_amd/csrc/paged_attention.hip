@@ -1044,6 +1044,238 @@ __global__ void __launch_bounds__(64 * WPB) paged_attn_mfma_kernel(const PAParam
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// EXPERIMENT (tuning key 44 = 2; partition sizes 1024 / 2048, head_dim 128, bf16 cache): K / V through LDS by DMA.
+// Every register-staged form above tops out at 4.1-4.7 TB/s of K + V at batch 32 (profiles/r03_b32_attention_loop_probe.txt): the
+// raw fragments cost 64 VGPRs and 32 ds_bpermute per 32 tokens, and a 32-token step reads HALF of every 128-byte V row.  Here one
+// workgroup (4 waves, one per SIMD) walks a chunk in stages of 64 tokens -- with 64-token blocks a stage is two contiguous 16 KiB
+// slabs of the cache -- through a ring of R stage buffers:
+//   * every wave copies 8 KiB of the stage global -> LDS with `global_load_lds_dwordx4` (waves 0, 1: the 16 channel-group rows of K;
+//     waves 2, 3: the 128 channel rows of V), up to R - 1 stages ahead; one counted `s_waitcnt vmcnt` + one barrier per stage;
+//   * the DMA's per-lane SOURCE address carries the permutations, the destination is lane-linear: K's 16-byte token slots are
+//     stored in MFMA row order (slot 32 ip + 16 it + r <- token 32 ip + 8 (r >> 2) + (r & 3) + 4 it: the A fragment of a tile is 16
+//     consecutive slots of a row -- conflict-free ds_read_b128), V's eight 16-byte slots of a channel row are XOR-swizzled with
+//     (channel >> 1) & 7 (a b128 lane group then covers 16 different bank quads);
+//   * every wave computes the scores of ALL 64 tokens (16 MFMAs, identical in the four waves: the softmax statistics agree bit
+//     for bit without an exchange) and the P.V of ITS 32 channels (4 MFMAs; the B fragment is one ds_read_b128 of a V row);
+//   * online softmax across stages as in pa_mfma_chunk; partials go out once per chunk and are merged by the reduce launch.
+// Token order inside a 32-token pair, masks and outputs are those of pa_mfma_partition.
+// layout of one 64-token stage in LDS: K 16 KiB [16 channel groups][64 slots of 16 B], V 16 KiB [128 channels][8 slots of 16 B].
+// The same functions serve the kernel and the host-side check of the permutations (mi355_internal_pal_layout,
+// tests/test_cpu_c_abi.py): what the DMA writes where, and what every lane's fragment read finds there.
+__host__ __device__ inline int pal_k_slot_token(int slot) {           // token (0..63 of the stage) held by K slot `slot` of every row
+    return 32 * (slot >> 5) + 8 * ((slot & 15) >> 2) + (slot & 3) + 4 * ((slot >> 4) & 1);
+}
+__host__ __device__ inline int pal_v_swz(int ch, int slot) { return slot ^ ((ch >> 1) & 7); }   // LDS slot <-> row slot (an involution)
+__host__ __device__ inline int pal_k_read_off(int j, int kg, int ip, int it, int r) { return (4 * j + kg) * 1024 + (32 * ip + 16 * it + r) * 16; }
+__host__ __device__ inline int pal_v_read_off(int ch, int ip, int kg) { return 16384 + ch * 128 + pal_v_swz(ch, 4 * ip + kg) * 16; }
+// DMA piece q (0..31, 1 KiB each, lane-linear destination q * 1024 + lane * 16): the 16 bytes lane `lane` copies --
+// K (q < 16): channel group q, token pal_k_slot_token(lane); V: channel 8 (q - 16) + (lane >> 3), tokens 8 g .. 8 g + 7
+__host__ __device__ inline int pal_dma_row(int q, int lane) { return q < 16 ? q : 8 * (q - 16) + (lane >> 3); }
+__host__ __device__ inline int pal_dma_token(int q, int lane) {
+    return q < 16 ? pal_k_slot_token(lane) : 8 * pal_v_swz(8 * (q - 16) + (lane >> 3), lane & 7);
+}
+
+__device__ __forceinline__ void pa_dma16(const uint8_t* gsrc_lane, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_dst) : "memory");
+}
+
+template <int R>
+__global__ void __launch_bounds__(256, 1) paged_attn_lds_kernel(const PAParams p) {
+    constexpr int D = 128, D32 = 4;
+    constexpr uint32_t STAGE_B = 32768u;                              // K 16 KiB | V 16 KiB
+    extern __shared__ __attribute__((aligned(1024))) uint8_t pal_smem[];
+    const int hk = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int c = lane & 15, kg = lane >> 4;
+    const int G = p.H / p.Hkv, bs = p.block_size;
+    const int t0 = blockIdx.z * p.partition_size;
+    const int ctx = min((int)p.context_lens[b], p.max_partitions * p.partition_size);
+    if (t0 >= ctx) return;                                            // uniform for the workgroup
+    const int t1 = min(ctx, t0 + p.partition_size);
+    const int ns = (t1 - t0 + 63) >> 6;                               // stages of this chunk
+    const int bs_shift = __ffs(bs) - 1;                               // block size 16 / 32 / 64 (pa_dispatch)
+    // table entries of the chunk (at most 64: pa_dispatch), one per lane; only entries of valid tokens are used
+    const int nblk = (t1 - t0 + bs - 1) >> bs_shift;
+    const int btv = (int)p.block_tables[(int64_t)b * p.max_blocks + (t0 >> bs_shift) + min(lane, nblk - 1)];
+    uint4 qf[D32];
+#pragma unroll
+    for (int j = 0; j < D32; ++j) {
+        const int hq = hk * G + (c < G ? c : 0);
+        qf[j] = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_stride + (int64_t)hq * D + 32 * j + 8 * kg);
+        if (c >= G) qf[j] = make_uint4(0, 0, 0, 0);
+    }
+    // the compiler's own wait for these loads must come BEFORE the first DMA goes out: it knows nothing of the DMA queue, and a
+    // wait placed later would drain it
+    {
+        int sink = btv;
+        asm volatile("" : "+v"(sink), "+v"(qf[0].x), "+v"(qf[1].x), "+v"(qf[2].x), "+v"(qf[3].x));
+    }
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)pal_smem);
+    const uint8_t* kc8 = static_cast<const uint8_t*>(p.kc);
+    const uint8_t* vc8 = static_cast<const uint8_t*>(p.vc);
+    // ---- this wave's share of a stage: pieces 8 wave .. 8 wave + 7 (1 KiB each; 0..15 K, 16..31 V)
+    const int ktok = pal_dma_token(0, lane);                          // token of K slot `lane` (the same in all 16 rows)
+    auto issue = [&](int st) {
+        const uint32_t dst = lds0 + (uint32_t)(st % R) * STAGE_B + (uint32_t)wave * 8192u;
+        const int rel0 = 64 * st;                                     // first token of the stage, relative to t0 (valid: st < ns)
+        if (wave < 2) {
+            int rel = rel0 + ktok;
+            if (t0 + rel >= t1) rel = rel0;
+            const int q = rel >> bs_shift;
+            const int64_t blk = (int64_t)__builtin_amdgcn_ds_bpermute(4 * q, btv);
+            const int off = rel - (q << bs_shift);
+            // K [NB][Hkv][16 channel groups][bs][16 B]
+            const uint8_t* src = kc8 + ((blk * p.Hkv + hk) * 16 + 8 * wave) * (int64_t)bs * 16 + (int64_t)off * 16;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pa_dma16(src + (int64_t)i * bs * 16, dst + (uint32_t)i * 1024u);
+        } else {
+            // V [NB][Hkv][128 channels][bs][2 B]: piece i of this wave = piece q = 8 wave + i of the stage, channels 8 (q - 16) + (lane >> 3);
+            // LDS slot lane & 7 of a row takes the row's slot (lane & 7) ^ ((channel >> 1) & 7), which depends on i through its
+            // parity only: two source bases, then 8 channels (8 bs 2 bytes) further per piece
+            const uint8_t* srcp[2];
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                int rel = rel0 + pal_dma_token(8 * wave + par, lane);
+                if (t0 + rel >= t1) rel = rel0;
+                const int q = rel >> bs_shift;
+                const int64_t blk = (int64_t)__builtin_amdgcn_ds_bpermute(4 * q, btv);
+                const int off = rel - (q << bs_shift);
+                srcp[par] = vc8 + (((blk * p.Hkv + hk) * D + pal_dma_row(8 * wave + par, lane)) * (int64_t)bs + off) * 2;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pa_dma16(srcp[i & 1] + (int64_t)(8 * (i & ~1)) * bs * 2, dst + (uint32_t)i * 1024u);
+        }
+    };
+    const float qk_scale = p.scale;
+    float m_run = -1e30f, l_run = 0.f;
+    f32x4_t o[2];
+    o[0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    o[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < R - 1; ++st)
+        if (st < ns) issue(st);
+    for (int i = 0; i < ns; ++i) {
+        // stage i must have landed; younger than it in this wave's queue: the stages issued after it (8 DMA instructions each)
+        {
+            const int ahead = min(ns, i + R - 1) - (i + 1);
+            if (ahead >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                              // everyone's share of stage i; everyone is done with stage i - 1
+        if (i + R - 1 < ns) issue(i + R - 1);                         // into the buffer stage i - 1 used
+        const uint8_t* Kb = pal_smem + (size_t)(i % R) * STAGE_B;    // the stage: K at 0, V at 16384 (pal_*_read_off)
+        // ---- S^T = K . Q^T for the 64 tokens: tile (ip, it), lane (head c, rows 4kg+v) <-> token 32 ip + 8 kg + 4 it + v
+        float sc[2][2][4];
+        float mp = -1e30f;
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                uint4 ka[D32];
+#pragma unroll
+                for (int j = 0; j < D32; ++j)
+                    ka[j] = *reinterpret_cast<const uint4*>(Kb + pal_k_read_off(j, kg, ip, it, c));
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < D32; ++j)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ka[j]), __builtin_bit_cast(bf16x8_t, qf[j]), acc, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) sc[ip][it][v] = acc[v] * qk_scale;
+            }
+        if (p.softcap > 0.f) {
+#pragma unroll
+            for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) sc[ip][it][v] = tanhf(sc[ip][it][v] / p.softcap) * p.softcap;
+        }
+        const int tb = t0 + 64 * i;
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    sc[ip][it][v] = (tb + 32 * ip + 8 * kg + 4 * it + v < t1) ? sc[ip][it][v] : -1e30f;
+                    mp = fmaxf(mp, sc[ip][it][v]);
+                }
+        mp = fmaxf(mp, __shfl_xor(mp, 16, 64));
+        mp = fmaxf(mp, __shfl_xor(mp, 32, 64));
+        const float m_new = fmaxf(m_run, mp);                         // finite: every stage of the loop has a valid token
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        uint4 pa[2];
+        float lp = 0.f;
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip) {
+            uint32_t w[4];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                float pr[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) pr[v] = (tb + 32 * ip + 8 * kg + 4 * it + v < t1) ? __expf(sc[ip][it][v] - m_new) : 0.f;
+                w[2 * it] = cvt_pk_bf16(pr[0], pr[1]);
+                w[2 * it + 1] = cvt_pk_bf16(pr[2], pr[3]);
+                // the normaliser must match what the MFMA sums: the bf16-rounded probabilities
+                lp += (bf16lo_to_f32(w[2 * it]) + bf16hi_to_f32(w[2 * it])) + (bf16lo_to_f32(w[2 * it + 1]) + bf16hi_to_f32(w[2 * it + 1]));
+            }
+            pa[ip] = make_uint4(w[0], w[1], w[2], w[3]);              // tokens 32 ip + 8 kg .. + 7 of head c
+        }
+        l_run = fmaf(l_run, alpha, lp);
+        // ---- O = O * alpha + P . V for this wave's channels 32 wave .. 32 wave + 31: lane (channel 16 nt + c, heads 4kg+v)
+        float av[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) av[v] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (4 * kg + v), __float_as_int(alpha)));
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+            const int ch = 32 * wave + 16 * n2 + c;
+            f32x4_t on = o[n2];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) on[v] *= av[v];
+#pragma unroll
+            for (int ip = 0; ip < 2; ++ip) {
+                uint4 vv = *reinterpret_cast<const uint4*>(Kb + pal_v_read_off(ch, ip, kg));
+                // never multiply 0 by unwritten (maybe NaN) V: tokens at or beyond t1 are cleared
+                const int tk = tb + 32 * ip + 8 * kg;
+                vv.x &= (tk + 0 < t1 ? 0x0000FFFFu : 0u) | (tk + 1 < t1 ? 0xFFFF0000u : 0u);
+                vv.y &= (tk + 2 < t1 ? 0x0000FFFFu : 0u) | (tk + 3 < t1 ? 0xFFFF0000u : 0u);
+                vv.z &= (tk + 4 < t1 ? 0x0000FFFFu : 0u) | (tk + 5 < t1 ? 0xFFFF0000u : 0u);
+                vv.w &= (tk + 6 < t1 ? 0x0000FFFFu : 0u) | (tk + 7 < t1 ? 0xFFFF0000u : 0u);
+                on = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pa[ip]), __builtin_bit_cast(bf16x8_t, vv), on, 0, 0, 0);
+            }
+            o[n2] = on;
+        }
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    // ---- this wave's 32 channels of every head: rows (heads 4kg+v) need the column statistics of lane (4kg+v)
+    const int pslot = blockIdx.z;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int head = 4 * kg + v;
+        const float lh = __shfl(l_run, head, 64), mh = __shfl(m_run, head, 64);
+        if (head >= G) continue;
+        const int h = hk * G + head;
+        const float inv = lh > 0.f ? 1.f / lh : 0.f;
+        if (p.max_partitions > 1) {
+            const int64_t pi = ((int64_t)b * p.H + h) * p.max_partitions + pslot;
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2) p.tmp_out[pi * D + 32 * wave + 16 * n2 + c] = o[n2][v] * inv;
+            if (wave == 0 && c == 0) { p.max_logits[pi] = mh; p.exp_sums[pi] = lh; }
+        } else {
+            uint16_t* op = static_cast<uint16_t*>(p.out) + ((int64_t)b * p.H + h) * D;
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2) op[32 * wave + 16 * n2 + c] = f32_to_bf16(o[n2][v] * inv);
+        }
+    }
+}
+
 template <int D32, int WPB>
 static int launch_mfma_w(const PAParams& p, int B, int P, hipStream_t st) {
     dim3 grid(p.Hkv, B, (P + WPB - 1) / WPB), block(64 * WPB);
@@ -1103,7 +1335,7 @@ static int launch_flash(const PAParams& p, int B, int P, hipStream_t st) {
 #define PA_ARRIVE_SLOTS 65536
 static int g_pa_fused = 1;                                          // mi355_set_tuning(3, 0) -> separate reduce launch
 static int g_pa_wpb = 0;                                            // mi355_set_tuning(8, 1 | 4): waves (partitions) per workgroup, 0 = auto
-static int g_pa_loop = 1;                                           // mi355_set_tuning(44, 0): partition sizes 256 / 512 go to the generic kernel again
+static int g_pa_loop = 1;                                           // mi355_set_tuning(44, 0): partition sizes 256 / 512 go to the generic kernel again; 2: EXPERIMENT, 1024 / 2048 take the LDS-DMA kernel
 
 static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t stream) {
     if (B <= 0) return 0;
@@ -1119,6 +1351,18 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
         else
             rc = (dtype == MI355_DTYPE_BF16) ? launch_flash<MI355_DTYPE_BF16, false>(p, B, P, st)
                                              : launch_flash<MI355_DTYPE_F16, false>(p, B, P, st);
+    } else if (layout == MI355_KV_PAGED && dtype == MI355_DTYPE_BF16 && p.D == 128 && !p.kv8 && g_pa_loop == 2 && p.H / p.Hkv <= 16 &&
+               (p.block_size == 16 || p.block_size == 32 || p.block_size == 64) &&
+               (p.partition_size == 1024 || p.partition_size == 2048 || p.partition_size == 4096) && p.partition_size / p.block_size <= 64) {
+        // EXPERIMENT (tuning key 44 = 2): chunks of 64-token stages through an LDS ring filled by DMA; partials merged by the reduce launch
+        constexpr int PAL_R = 4;
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)paged_attn_lds_kernel<PAL_R>, hipFuncAttributeMaxDynamicSharedMemorySize, PAL_R * 32768);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((paged_attn_lds_kernel<PAL_R>), dim3(p.Hkv, B, P), dim3(256), PAL_R * 32768, st, p);
+        rc = (int)hipGetLastError();
     } else if (layout == MI355_KV_PAGED && dtype == MI355_DTYPE_BF16 && (p.D == 128 || p.D == 64) &&
                p.H / p.Hkv <= 16 && (p.block_size % 16) == 0 &&
                (p.partition_size == 32 || p.partition_size == 64 || p.partition_size == 128 ||
@@ -1173,6 +1417,19 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
         hipLaunchKernelGGL(paged_attn_reduce_kernel<MI355_DTYPE_F16>, rgrid, rblock, rshm, st, p.out, p.tmp_out,
                            p.max_logits, p.exp_sums, p.context_lens, p.H, p.D, p.partition_size * wpb, p.max_partitions);
     return (int)hipGetLastError();
+}
+
+// host-side view of the LDS stage layout of paged_attn_lds_kernel (tests only): what = 0 row (channel group / channel) and 1 first token
+// of the 16 bytes DMA piece a, lane b copies; 2 byte offset of the K fragment read (j, kg, ip, it, r) = (a, b, c, d, e); 3 of the V
+// fragment read (channel, ip, kg) = (a, b, c)
+extern "C" int32_t mi355_internal_pal_layout(int32_t what, int32_t a, int32_t b, int32_t c, int32_t d, int32_t e) {
+    switch (what) {
+    case 0: return pal_dma_row(a, b);
+    case 1: return pal_dma_token(a, b);
+    case 2: return pal_k_read_off(a, b, c, d, e);
+    case 3: return pal_v_read_off(a, b, c);
+    default: return -1;
+    }
 }
 
 void mi355_pa_set_fused(int v) { g_pa_fused = v; }

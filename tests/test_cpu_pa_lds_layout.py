@@ -1,0 +1,98 @@
+"""The permutations of the LDS-DMA decode-attention experiment (paged_attn_lds_kernel, tuning key 44 = 2), checked on the host: the kernel
+and this test call the SAME index functions (csrc/paged_attention.hip: pal_*; here through mi355_internal_pal_layout).  A 64-token stage
+is written into a byte image exactly as the 32 DMA pieces write it (lane-linear destination, permuted per-lane source), then every lane's
+fragment reads are taken from the image and compared with what the MFMA conventions of the kernel need:
+  * K tile (ip, it), A-operand row r, k-group kg, step j  ->  token 32 ip + 8 (r >> 2) + (r & 3) + 4 it, channels 32 j + 8 kg .. + 7
+    (score row 4 kg + v of the tile is then token 32 ip + 8 kg + 4 it + v: the mask / softmax indexing of the kernel);
+  * V pair ip, B-operand column = channel, k-group kg        ->  tokens 32 ip + 8 kg .. + 7 of that channel
+    (= the probabilities the lane packs into its A fragment: tile A rows 4 kg + v, tile B rows 4 kg + v);
+and the b128 lane groups of both reads are bank-conflict free (MI355X_MICROARCH.md: 64 banks of 4 B, groups of 16 lanes)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def pal():
+    import __graft_entry__ as ge
+    ge.build()
+    from candle_vllm_amd._lib import lib
+    f = lib.mi355_internal_pal_layout
+    f.restype = ctypes.c_int32
+    f.argtypes = [ctypes.c_int32] * 6
+    return lambda what, a=0, b=0, c=0, d=0, e=0: int(f(what, a, b, c, d, e))
+
+
+def _stage_image(pal):
+    """uint16 image [16384] of one stage; element value: K -> token * 128 + channel, V -> 0x4000 | (token * 128 + channel)"""
+    img = np.full(16384, 0xFFFF, np.uint16)
+    written = np.zeros(16384, bool)
+    for q in range(32):
+        for lane in range(64):
+            row, tok = pal(0, q, lane), pal(1, q, lane)
+            dst = (q * 1024 + lane * 16) // 2
+            if q < 16:        # 16 bytes = the 8 channels of channel group `row` of token `tok`
+                vals = [tok * 128 + 8 * row + e for e in range(8)]
+            else:             # 16 bytes = tokens tok .. tok + 7 of channel `row`
+                assert tok % 8 == 0 and 0 <= tok < 64 and 0 <= row < 128
+                vals = [0x4000 | ((tok + e) * 128 + row) for e in range(8)]
+            assert not written[dst:dst + 8].any()
+            img[dst:dst + 8] = vals
+            written[dst:dst + 8] = True
+    assert written.all()
+    return img
+
+
+def test_every_granule_of_the_stage_is_copied_exactly_once(pal):
+    img = _stage_image(pal)
+    k, v = img[:8192], img[8192:]
+    assert sorted(k.tolist()) == list(range(64 * 128))                       # every (token, channel) of K once
+    assert sorted((v & 0x3FFF).tolist()) == list(range(64 * 128)) and (v & 0x4000).all()
+    # the sources of one piece stay inside one 1 KiB K row / eight 128-byte V rows: full lines on the global side
+    for q in range(32):
+        rows = {pal(0, q, lane) for lane in range(64)}
+        assert len(rows) == (1 if q < 16 else 8)
+
+
+def test_fragment_reads_find_the_operands_the_mfma_conventions_need(pal):
+    img = _stage_image(pal)
+    for ip in range(2):
+        for it in range(2):
+            for j in range(4):
+                for kg in range(4):
+                    for r in range(16):
+                        off = pal(2, j, kg, ip, it, r)
+                        assert off % 16 == 0
+                        got = img[off // 2: off // 2 + 8]
+                        tok = 32 * ip + 8 * (r >> 2) + (r & 3) + 4 * it
+                        assert got.tolist() == [tok * 128 + 32 * j + 8 * kg + e for e in range(8)]
+    for ch in range(128):
+        for ip in range(2):
+            for kg in range(4):
+                off = pal(3, ch, ip, kg)
+                got = img[off // 2: off // 2 + 8]
+                assert got.tolist() == [0x4000 | ((32 * ip + 8 * kg + e) * 128 + ch) for e in range(8)]
+    # the probabilities a lane packs: tile A row 4 kg + v -> token 32 ip + 8 kg + v, tile B -> + 4: together tokens 8 kg .. 8 kg + 7
+    for kg in range(4):
+        rows_a = [32 * 0 + 8 * ((4 * kg + v) >> 2) + ((4 * kg + v) & 3) for v in range(4)]
+        assert rows_a == [8 * kg + v for v in range(4)]
+
+
+def test_b128_lane_groups_are_bank_conflict_free(pal):
+    groups = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
+              list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)), list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64))]
+
+    def quads(offs):            # the 4-bank quads (16 B) a group touches inside the 256-byte bank row
+        return sorted((o // 16) % 16 for o in offs)
+
+    for grp in groups:
+        for ip in range(2):
+            for it in range(2):
+                for j in range(4):
+                    offs = [pal(2, j, lane >> 4, ip, it, lane & 15) for lane in grp]
+                    assert quads(offs) == list(range(16)), ("K", ip, it, j)
+            for wave in range(4):
+                for n2 in range(2):
+                    offs = [pal(3, 32 * wave + 16 * n2 + (lane & 15), ip, lane >> 4) for lane in grp]
+                    assert quads(offs) == list(range(16)), ("V", ip, wave, n2)

@@ -1,6 +1,8 @@
 """GPU parity tests (run with -m gpu on the MI355X): every kernel of the hot path through the C ABI vs the
 CPU oracle on the same seeded inputs.  Index/byte ops are bit-exact; floating point ops carry their
 tolerance next to the assert."""
+import os
+
 import numpy as np
 import pytest
 
@@ -629,3 +631,29 @@ def test_paged_attention_looped_chunks_many_sequences(cv):
         for _ in range(3):                                            # the arrival counters must come back to zero
             got = pa.decode(qd, kcd, vcd, meta, None, partition_size=ps).float().cpu().numpy()
             assert np.abs(got - oracle).max() <= tol, (ps, np.abs(got - oracle).max())
+
+
+@pytest.mark.skipif(not os.environ.get("MI355_EXPERIMENTS"), reason="experiment kernels run on request (MI355_EXPERIMENTS=1)")
+@pytest.mark.parametrize("bs,ctx", [(64, [4100, 37, 520, 1024, 1025, 2048]), (16, [1000, 259, 15]), (32, [777, 2049])])
+def test_paged_attention_lds_dma_experiment(cv, bs, ctx):
+    """tuning key 44 = 2: partition sizes 1024 / 2048 through the LDS ring filled by DMA (paged_attn_lds_kernel) -- same bound as the
+    product kernels.  Not part of the default run: the kernel is an experiment of round 3."""
+    from candle_vllm_amd import tuning
+    rng = np.random.default_rng(45)
+    H, Hkv, D = 32, 8, 128
+    q, kc, vc, bt, cl = _attn_case(rng, len(ctx), H, Hkv, D, bs, ctx, False)
+    pa = cv.PagedAttention(H, D, 1 / np.sqrt(D), Hkv)
+    meta = cv.InputMetadata(False, dev(np.zeros(len(ctx), np.int64)), dev(bt.astype(np.int32)), dev(cl.astype(np.int32)),
+                            max_context_len=max(ctx))
+    qd, kcd, vcd = dev(q, torch.bfloat16), bf16_dev(kc), bf16_dev(vc)
+    oracle = O.paged_attention_decode(q, kc, vc, bt, cl, 1 / np.sqrt(D), False)
+    tol = 2 ** -7 * np.abs(oracle).max() + 1e-6
+    with tuning(44, 2):
+        for ps in (1024, 2048):
+            if ps // bs > 64:
+                continue
+            for _ in range(2):
+                got = pa.decode(qd, kcd, vcd, meta, None, partition_size=ps).float().cpu().numpy()
+                assert np.isfinite(got).all()
+                assert np.abs(got - oracle).max() <= tol, (ps, np.abs(got - oracle).max())
+

@@ -1,5 +1,6 @@
 """scratch: decode attention alone on the PAGED layout, batch 32 (uniform 4 k and ragged contexts): one-partition waves (32 / 64 tokens)
-against the looped chunks (256 / 512, pa_mfma_chunk) and the generic kernel at the same partition size (tuning key 44 = 0)"""
+against the looped chunks (256 / 512, pa_mfma_chunk), the LDS-DMA experiment (1024 / 2048, tuning key 44 = 2) and the generic kernel
+(tuning key 44 = 0)"""
 import os
 import sys
 
@@ -31,7 +32,8 @@ for name, ctx in (("uniform 4096", [4096] * B), ("ragged U[256,4096]", np.random
     kv_bytes = sum(ctx) * Hkv * D * 2 * 2
     ref = None
     for label, ps, loop in (("one-partition waves, 32", 32, 1), ("one-partition waves, 64", 64, 1), ("looped chunks, 256", 256, 1),
-                            ("looped chunks, 512", 512, 1), ("generic kernel, 256", 256, 0)):
+                            ("looped chunks, 512", 512, 1), ("LDS-DMA stages, 1024", 1024, 2), ("LDS-DMA stages, 2048", 2048, 2), ("LDS-DMA stages, 4096", 4096, 2),
+                            ("generic kernel, 256", 256, 0)):
         with tuning(44, loop):
             out = pa.decode(q, kc, vc, meta, None, partition_size=ps)
             torch.cuda.synchronize()
