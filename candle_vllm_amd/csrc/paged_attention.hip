@@ -1276,6 +1276,297 @@ __global__ void __launch_bounds__(256, 1) paged_attn_lds_kernel(const PAParams p
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// EXPERIMENT (tuning key 44 = 3, partition size 64): the LDS-DMA stages of paged_attn_lds_kernel as ONE balanced stream per workgroup.
+// Ragged batches starve the chunked form (670 chunks of 1024 tokens on 256 CUs: 2.6 rounds, every chunk pays its ring fill).  Here the
+// (sequence, 64-token stage) pairs of a kv head form one flat index space of S stages; workgroup w of the W per kv head (W x Hkv = one
+// per CU) takes the stages [S w / W, S (w + 1) / W) -- equal shares whatever the context lengths -- and walks them through ONE ring:
+// the DMA of the next sequence's first stages is in flight while the last stages of the current one are multiplied.  Every
+// (sequence, workgroup) pair that meets leaves a partial (normalised O, max, sum) in slot w; paged_attn_stream_reduce_kernel recomputes
+// the cuts and merges the workgroups that touched its sequence.
+//   * stages per sequence and their prefix sums live in a wave's lanes (lane = sequence, <= 64 sequences): locating a flat index is a
+//     ballot + popcount, no planning launch;
+//   * block-table entries are fetched by SCALAR loads (wave-uniform addresses) one stage ahead: they count on lgkmcnt, the vector
+//     memory counter stays the DMA's own (the partial stores that enter it only make a counted wait stricter: the wait counts DMA
+//     instructions alone);
+//   * Q of the (up to 4) sequences of the share is staged in LDS before the first DMA goes out.
+__host__ __device__ inline int64_t pas_cut(int64_t S, int W, int w) { return S * w / W; }
+
+template <int R>
+__global__ void __launch_bounds__(256, 1) paged_attn_stream_kernel(const PAParams p, const int B, const uint32_t* __restrict__ btab,
+                                                                    const uint32_t* __restrict__ clens) {
+    // (btab / clens = p.block_tables / p.context_lens once more, as __restrict__ kernel arguments: only then does the compiler know that
+    // the partial stores cannot clobber them and fetches the wave-uniform table entries with s_load -- through the struct it used
+    // vector loads, whose waits drained the DMA queue every stage)
+    constexpr int D = 128, D32 = 4, QSEG = 4;
+    constexpr uint32_t STAGE_B = 32768u;
+    extern __shared__ __attribute__((aligned(1024))) uint8_t pas_smem[];   // ring [R][32 KiB] | Q [QSEG][16 heads][128] bf16
+    const int w = blockIdx.x, W = gridDim.x, hk = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int c = lane & 15, kg = lane >> 4;
+    const int G = p.H / p.Hkv, bs = p.block_size;
+    const int bs_shift = __ffs(bs) - 1, E = 64 >> bs_shift;           // block size 16 / 32 / 64: 4 / 2 / 1 table entries per stage
+    // ---- lane = sequence: context length, stages, inclusive prefix of the stages
+    const int ctx_l = lane < B ? (int)clens[lane] : 0;
+    const int n_l = (ctx_l + 63) >> 6;
+    int pend = n_l;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(pend, o, 64);
+        if (lane >= o) pend += t;
+    }
+    const int S = __builtin_amdgcn_readlane(pend, 63);
+    const int f_lo0 = (int)pas_cut(S, W, w), f_hi0 = (int)pas_cut(S, W, w + 1);
+    if (f_lo0 >= f_hi0) return;                                       // uniform for the workgroup
+    // sequence of flat stage f = number of sequences that end at or before f (the prefix is non-decreasing)
+    auto seq_of = [&](int f) { return __builtin_amdgcn_readfirstlane((int)__popcll(__ballot(pend <= f))); };
+    uint8_t* qlds = pas_smem + (size_t)R * STAGE_B;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)pas_smem);
+    const uint8_t* kc8 = static_cast<const uint8_t*>(p.kc);
+    const uint8_t* vc8 = static_cast<const uint8_t*>(p.vc);
+    const int ktok = pal_dma_token(0, lane);
+    // The share is walked in runs of at most QSEG sequences (one run unless the batch is made of very short sequences): a run stages
+    // its Q rows in LDS and fills the ring anew -- inside a run there is no compiler-visible vector load, so no wait of the compiler's
+    // ever touches the DMA queue.
+    for (int f_lo = f_lo0; f_lo < f_hi0;) {
+    const int b0 = seq_of(f_lo);
+    const int f_hi = min(f_hi0, __builtin_amdgcn_readlane(pend, min(b0 + QSEG - 1, 63)));
+    const int ns = f_hi - f_lo;
+    // ---- Q of the run's sequences -> LDS (before any DMA of the run goes out)
+    {
+        __syncthreads();                                              // the previous run is done with the Q rows and the ring
+        const int b_last = seq_of(f_hi - 1);
+        const int nq = min(b_last - b0 + 1, QSEG);
+        const int row = (int)threadIdx.x >> 4, gs = (int)threadIdx.x & 15;
+        for (int sg = 0; sg < nq; ++sg) {
+            if (row < G) {
+                const uint4 v = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.q) + (int64_t)(b0 + sg) * p.q_stride +
+                                                                (int64_t)(hk * G + row) * D + 8 * gs);
+                *reinterpret_cast<uint4*>(qlds + ((size_t)(sg * 16 + row) * D + 8 * gs) * 2) = v;
+            }
+        }
+        __syncthreads();
+    }
+    // table entries of stage (b, s): E consecutive entries, clamped to the sequence's last block (tokens beyond the context are masked)
+    auto load_ent = [&](int f, int (&ent)[4]) {
+        const int bq = seq_of(f);
+        const int sq = f - (__builtin_amdgcn_readlane(pend, bq) - __builtin_amdgcn_readlane(n_l, bq));
+        const int nblk = (__builtin_amdgcn_readlane(ctx_l, bq) + bs - 1) >> bs_shift;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = min(sq * E + min(e, E - 1), nblk - 1);
+            ent[e] = (int)btab[(int64_t)bq * p.max_blocks + idx];
+        }
+    };
+    // this wave's share of flat stage f (ring slot i % R): as paged_attn_lds_kernel, the block ids come from `ent`
+    auto issue = [&](int i, int f, const int (&ent)[4]) {
+        const int bq = seq_of(f);
+        const int sq = f - (__builtin_amdgcn_readlane(pend, bq) - __builtin_amdgcn_readlane(n_l, bq));
+        const int t1q = __builtin_amdgcn_readlane(ctx_l, bq);
+        const uint32_t dst = lds0 + (uint32_t)(i % R) * STAGE_B + (uint32_t)wave * 8192u;
+        auto block_of = [&](int tok) {                                // tok: token of the stage (0..63)
+            const int e = tok >> bs_shift;
+            return (int64_t)(e == 0 ? ent[0] : (e == 1 ? ent[1] : (e == 2 ? ent[2] : ent[3])));
+        };
+        if (wave < 2) {
+            int tok = ktok;
+            if (64 * sq + tok >= t1q) tok = 0;
+            const int64_t blk = block_of(tok);
+            const int off = tok & (bs - 1);
+            const uint8_t* src = kc8 + ((blk * p.Hkv + hk) * 16 + 8 * wave) * (int64_t)bs * 16 + (int64_t)off * 16;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pa_dma16(src + (int64_t)q * bs * 16, dst + (uint32_t)q * 1024u);
+        } else {
+            const uint8_t* srcp[2];
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                int tok = pal_dma_token(8 * wave + par, lane);
+                if (64 * sq + tok >= t1q) tok = 0;
+                const int64_t blk = block_of(tok);
+                const int off = tok & (bs - 1);
+                srcp[par] = vc8 + (((blk * p.Hkv + hk) * D + pal_dma_row(8 * wave + par, lane)) * (int64_t)bs + off) * 2;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pa_dma16(srcp[q & 1] + (int64_t)(8 * (q & ~1)) * bs * 2, dst + (uint32_t)q * 1024u);
+        }
+    };
+    int ent[4];
+#pragma unroll
+    for (int st = 0; st < R - 1; ++st)
+        if (st < ns) { load_ent(f_lo + st, ent); issue(st, f_lo + st, ent); }
+    if (R - 1 < ns) load_ent(f_lo + R - 1, ent);                      // for the issue of the first iteration
+    const float qk_scale = p.scale;
+    float m_run = -1e30f, l_run = 0.f;
+    f32x4_t o[2];
+    uint4 qf[D32];
+    int b = -1, pst = 0, t1 = 0, pe = 0;                              // current sequence, its first flat stage, context length, end
+    for (int i = 0; i < ns; ++i) {
+        const int f = f_lo + i;
+        {
+            const int ahead = min(ns, i + R - 1) - (i + 1);
+            if (ahead >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                              // everyone's share of stage i; everyone is done with stage i - 1
+        if (i + R - 1 < ns) {
+            issue(i + R - 1, f + R - 1, ent);
+            if (i + R < ns) load_ent(f + R, ent);                     // scalar loads: in flight until the next iteration's issue
+        }
+        if (b < 0 || f >= pe) {                                       // first stage of a sequence (of this share)
+            b = seq_of(f);
+            pe = __builtin_amdgcn_readlane(pend, b);
+            pst = pe - __builtin_amdgcn_readlane(n_l, b);
+            t1 = __builtin_amdgcn_readlane(ctx_l, b);
+            m_run = -1e30f; l_run = 0.f;
+            o[0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            o[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            const int sg = b - b0;
+#pragma unroll
+            for (int j = 0; j < D32; ++j) {
+                qf[j] = *reinterpret_cast<const uint4*>(qlds + ((size_t)(sg * 16 + (c < G ? c : 0)) * D + 32 * j + 8 * kg) * 2);
+                if (c >= G) qf[j] = make_uint4(0, 0, 0, 0);
+            }
+        }
+        const int tb = 64 * (f - pst);                                // first token of the stage inside its sequence
+        const uint8_t* Kb = pas_smem + (size_t)(i % R) * STAGE_B;
+        float sc[2][2][4];
+        float mp = -1e30f;
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                uint4 ka[D32];
+#pragma unroll
+                for (int j = 0; j < D32; ++j) ka[j] = *reinterpret_cast<const uint4*>(Kb + pal_k_read_off(j, kg, ip, it, c));
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < D32; ++j)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ka[j]), __builtin_bit_cast(bf16x8_t, qf[j]), acc, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) sc[ip][it][v] = acc[v] * qk_scale;
+            }
+        if (p.softcap > 0.f) {
+#pragma unroll
+            for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) sc[ip][it][v] = tanhf(sc[ip][it][v] / p.softcap) * p.softcap;
+        }
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    sc[ip][it][v] = (tb + 32 * ip + 8 * kg + 4 * it + v < t1) ? sc[ip][it][v] : -1e30f;
+                    mp = fmaxf(mp, sc[ip][it][v]);
+                }
+        mp = fmaxf(mp, __shfl_xor(mp, 16, 64));
+        mp = fmaxf(mp, __shfl_xor(mp, 32, 64));
+        const float m_new = fmaxf(m_run, mp);
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        uint4 pa[2];
+        float lp = 0.f;
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip) {
+            uint32_t pw[4];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                float pr[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) pr[v] = (tb + 32 * ip + 8 * kg + 4 * it + v < t1) ? __expf(sc[ip][it][v] - m_new) : 0.f;
+                pw[2 * it] = cvt_pk_bf16(pr[0], pr[1]);
+                pw[2 * it + 1] = cvt_pk_bf16(pr[2], pr[3]);
+                lp += (bf16lo_to_f32(pw[2 * it]) + bf16hi_to_f32(pw[2 * it])) + (bf16lo_to_f32(pw[2 * it + 1]) + bf16hi_to_f32(pw[2 * it + 1]));
+            }
+            pa[ip] = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+        }
+        l_run = fmaf(l_run, alpha, lp);
+        float av[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) av[v] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (4 * kg + v), __float_as_int(alpha)));
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+            const int ch = 32 * wave + 16 * n2 + c;
+            f32x4_t on = o[n2];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) on[v] *= av[v];
+#pragma unroll
+            for (int ip = 0; ip < 2; ++ip) {
+                uint4 vv = *reinterpret_cast<const uint4*>(Kb + pal_v_read_off(ch, ip, kg));
+                const int tk = tb + 32 * ip + 8 * kg;
+                vv.x &= (tk + 0 < t1 ? 0x0000FFFFu : 0u) | (tk + 1 < t1 ? 0xFFFF0000u : 0u);
+                vv.y &= (tk + 2 < t1 ? 0x0000FFFFu : 0u) | (tk + 3 < t1 ? 0xFFFF0000u : 0u);
+                vv.z &= (tk + 4 < t1 ? 0x0000FFFFu : 0u) | (tk + 5 < t1 ? 0xFFFF0000u : 0u);
+                vv.w &= (tk + 6 < t1 ? 0x0000FFFFu : 0u) | (tk + 7 < t1 ? 0xFFFF0000u : 0u);
+                on = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pa[ip]), __builtin_bit_cast(bf16x8_t, vv), on, 0, 0, 0);
+            }
+            o[n2] = on;
+        }
+        if (f + 1 >= pe || i + 1 >= ns) {
+            // ---- last stage of this sequence in this share: the partial of (sequence b, workgroup w)
+            float lt = l_run + __shfl_xor(l_run, 16, 64);
+            lt += __shfl_xor(lt, 32, 64);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int head = 4 * kg + v;
+                const float lh = __shfl(lt, head, 64), mh = __shfl(m_run, head, 64);
+                if (head < G) {
+                    const int64_t pi = ((int64_t)b * p.H + hk * G + head) * p.max_partitions + w;
+                    const float inv = lh > 0.f ? 1.f / lh : 0.f;
+#pragma unroll
+                    for (int n2 = 0; n2 < 2; ++n2) p.tmp_out[pi * D + 32 * wave + 16 * n2 + c] = o[n2][v] * inv;
+                    if (wave == 0 && c == 0) { p.max_logits[pi] = mh; p.exp_sums[pi] = lh; }
+                }
+            }
+        }
+    }
+    f_lo = f_hi;
+    }                                                                 // runs
+}
+
+// merge of the stream kernel's partials: workgroup (h, b) recomputes the cuts, finds the workgroups whose share met sequence b and
+// combines their slots.  128 threads = the 128 channels.
+__global__ void __launch_bounds__(128) paged_attn_stream_reduce_kernel(void* __restrict__ out, const float* __restrict__ tmp_out,
+                                                                       const float* __restrict__ max_logits, const float* __restrict__ exp_sums,
+                                                                       const uint32_t* __restrict__ context_lens, const int B, const int H,
+                                                                       const int W, const int slots) {
+    constexpr int D = 128;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, d = threadIdx.x;
+    const int n_l = lane < B ? ((int)context_lens[lane] + 63) >> 6 : 0;
+    int pend = n_l;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(pend, o, 64);
+        if (lane >= o) pend += t;
+    }
+    const int S = __builtin_amdgcn_readlane(pend, 63);
+    const int pe = __builtin_amdgcn_readlane(pend, b), ps = pe - __builtin_amdgcn_readlane(n_l, b);
+    // lane = workgroup: does its share [cut(w), cut(w + 1)) meet [ps, pe)?
+    bool meets = false;
+    if (lane < W) {
+        const int lo = (int)pas_cut(S, W, lane), hi = (int)pas_cut(S, W, lane + 1);
+        meets = lo < hi && lo < pe && hi > ps;
+    }
+    uint64_t mask = __ballot(meets);
+    const int64_t base = ((int64_t)b * H + h) * slots;
+    float M = -1e30f;
+    for (uint64_t mm = mask; mm; mm &= mm - 1) M = fmaxf(M, max_logits[base + __ffsll((unsigned long long)mm) - 1]);
+    float den = 0.f, acc = 0.f;
+    for (uint64_t mm = mask; mm; mm &= mm - 1) {
+        const int wq = __ffsll((unsigned long long)mm) - 1;
+        const float wt = exp_sums[base + wq] * __expf(max_logits[base + wq] - M);
+        den += wt;
+        acc = fmaf(tmp_out[(base + wq) * D + d], wt, acc);
+    }
+    if (mask) static_cast<uint16_t*>(out)[((int64_t)b * H + h) * D + d] = f32_to_bf16(den > 0.f ? acc / den : 0.f);
+}
+
 template <int D32, int WPB>
 static int launch_mfma_w(const PAParams& p, int B, int P, hipStream_t st) {
     dim3 grid(p.Hkv, B, (P + WPB - 1) / WPB), block(64 * WPB);
@@ -1335,7 +1626,7 @@ static int launch_flash(const PAParams& p, int B, int P, hipStream_t st) {
 #define PA_ARRIVE_SLOTS 65536
 static int g_pa_fused = 1;                                          // mi355_set_tuning(3, 0) -> separate reduce launch
 static int g_pa_wpb = 0;                                            // mi355_set_tuning(8, 1 | 4): waves (partitions) per workgroup, 0 = auto
-static int g_pa_loop = 1;                                           // mi355_set_tuning(44, 0): partition sizes 256 / 512 go to the generic kernel again; 2: EXPERIMENT, 1024 / 2048 take the LDS-DMA kernel
+static int g_pa_loop = 1;                                           // mi355_set_tuning(44, 0): partition sizes 256 / 512 go to the generic kernel again; 2: EXPERIMENT, 1024 / 2048 / 4096 take the LDS-DMA kernel; 3: EXPERIMENT, 64 takes the balanced LDS-DMA stream
 
 static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t stream) {
     if (B <= 0) return 0;
@@ -1351,6 +1642,24 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
         else
             rc = (dtype == MI355_DTYPE_BF16) ? launch_flash<MI355_DTYPE_BF16, false>(p, B, P, st)
                                              : launch_flash<MI355_DTYPE_F16, false>(p, B, P, st);
+    } else if (layout == MI355_KV_PAGED && dtype == MI355_DTYPE_BF16 && p.D == 128 && !p.kv8 && g_pa_loop == 3 && p.H / p.Hkv <= 16 &&
+               (p.block_size == 16 || p.block_size == 32 || p.block_size == 64) && p.partition_size == 64 && P > 1 && B <= 64) {
+        // EXPERIMENT (tuning key 44 = 3): one balanced stream of 64-token stages per workgroup, W workgroups per kv head (one per CU)
+        constexpr int PAS_R = 4;
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)paged_attn_stream_kernel<PAS_R>, hipFuncAttributeMaxDynamicSharedMemorySize, PAS_R * 32768 + 16384);
+            attr_done = true;
+        }
+        int W = 256 / p.Hkv;
+        if (W < 1) W = 1;
+        if (W > 64) W = 64;
+        if (W > P) W = P;
+        hipLaunchKernelGGL((paged_attn_stream_kernel<PAS_R>), dim3(W, p.Hkv), dim3(256), PAS_R * 32768 + 16384, st, p, B, p.block_tables,
+                           p.context_lens);
+        hipLaunchKernelGGL(paged_attn_stream_reduce_kernel, dim3(p.H, B), dim3(128), 0, st, p.out, p.tmp_out, p.max_logits, p.exp_sums,
+                           p.context_lens, B, p.H, W, p.max_partitions);
+        return (int)hipGetLastError();
     } else if (layout == MI355_KV_PAGED && dtype == MI355_DTYPE_BF16 && p.D == 128 && !p.kv8 && g_pa_loop == 2 && p.H / p.Hkv <= 16 &&
                (p.block_size == 16 || p.block_size == 32 || p.block_size == 64) &&
                (p.partition_size == 1024 || p.partition_size == 2048 || p.partition_size == 4096) && p.partition_size / p.block_size <= 64) {
@@ -1421,13 +1730,14 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
 
 // host-side view of the LDS stage layout of paged_attn_lds_kernel (tests only): what = 0 row (channel group / channel) and 1 first token
 // of the 16 bytes DMA piece a, lane b copies; 2 byte offset of the K fragment read (j, kg, ip, it, r) = (a, b, c, d, e); 3 of the V
-// fragment read (channel, ip, kg) = (a, b, c)
+// fragment read (channel, ip, kg) = (a, b, c); 4 the stream kernel's cut (S, W, w) = (a, b, c)
 extern "C" int32_t mi355_internal_pal_layout(int32_t what, int32_t a, int32_t b, int32_t c, int32_t d, int32_t e) {
     switch (what) {
     case 0: return pal_dma_row(a, b);
     case 1: return pal_dma_token(a, b);
     case 2: return pal_k_read_off(a, b, c, d, e);
     case 3: return pal_v_read_off(a, b, c);
+    case 4: return (int32_t)pas_cut(a, b, c);                         // first flat stage of workgroup c of b, S = a stages in all
     default: return -1;
     }
 }

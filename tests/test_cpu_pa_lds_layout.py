@@ -96,3 +96,33 @@ def test_b128_lane_groups_are_bank_conflict_free(pal):
                 for n2 in range(2):
                     offs = [pal(3, 32 * wave + 16 * n2 + (lane & 15), ip, lane >> 4) for lane in grp]
                     assert quads(offs) == list(range(16)), ("V", ip, wave, n2)
+
+
+def test_stream_cuts_cover_every_stage_once_and_the_reduce_finds_the_workgroups(pal):
+    """paged_attn_stream_kernel: the (sequence, 64-token stage) pairs of a kv head form one flat index space, workgroup w takes
+    [cut(w), cut(w + 1)); the reduce kernel decides with the same cuts which workgroups left a partial for its sequence"""
+    rng = np.random.default_rng(7)
+    for trial in range(60):
+        B = int(rng.integers(1, 65))
+        W = int(rng.choice([1, 2, 7, 16, 32, 64]))
+        ctx = rng.integers(1, [65, 300, 4097][trial % 3], B)
+        n = (ctx + 63) // 64
+        pend = np.cumsum(n)
+        S = int(pend[-1])
+        cuts = [pal(4, S, W, w) for w in range(W + 1)]
+        assert cuts[0] == 0 and cuts[-1] == S and all(0 <= cuts[w + 1] - cuts[w] <= -(-S // W) for w in range(W))
+        assert max(cuts[w + 1] - cuts[w] for w in range(W)) - min(cuts[w + 1] - cuts[w] for w in range(W)) <= 1
+        owner = np.full(S, -1)
+        wrote = set()                                                  # (sequence, workgroup) partials
+        for w in range(W):
+            for f in range(cuts[w], cuts[w + 1]):
+                assert owner[f] == -1
+                owner[f] = w
+                b = int(np.searchsorted(pend, f, side="right"))       # = popcount(pend <= f)
+                wrote.add((b, w))
+        assert (owner >= 0).all()
+        for b in range(B):
+            ps, pe = int(pend[b] - n[b]), int(pend[b])
+            meets = {w for w in range(W) if cuts[w] < cuts[w + 1] and cuts[w] < pe and cuts[w + 1] > ps}
+            assert meets == {w for (bb, w) in wrote if bb == b} and meets
+

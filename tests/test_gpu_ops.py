@@ -657,3 +657,26 @@ def test_paged_attention_lds_dma_experiment(cv, bs, ctx):
                 assert np.isfinite(got).all()
                 assert np.abs(got - oracle).max() <= tol, (ps, np.abs(got - oracle).max())
 
+
+@pytest.mark.skipif(not os.environ.get("MI355_EXPERIMENTS"), reason="experiment kernels run on request (MI355_EXPERIMENTS=1)")
+@pytest.mark.parametrize("bs,ctx", [(64, [4100, 37, 520, 1024, 1025, 2048, 64, 65, 1]), (16, [1000, 259, 15]), (32, [777, 2049]),
+                                    (64, list(range(1, 41))), (16, [700] * 33 + [3, 64, 129])])
+def test_paged_attention_lds_dma_stream_experiment(cv, bs, ctx):
+    """tuning key 44 = 3: partition size 64 as one balanced stream of 64-token stages per workgroup (paged_attn_stream_kernel +
+    paged_attn_stream_reduce_kernel): shares that cut sequences anywhere, many short sequences per share, <= 64 sequences"""
+    from candle_vllm_amd import tuning
+    rng = np.random.default_rng(46)
+    H, Hkv, D = 32, 8, 128
+    q, kc, vc, bt, cl = _attn_case(rng, len(ctx), H, Hkv, D, bs, ctx, False)
+    pa = cv.PagedAttention(H, D, 1 / np.sqrt(D), Hkv)
+    meta = cv.InputMetadata(False, dev(np.zeros(len(ctx), np.int64)), dev(bt.astype(np.int32)), dev(cl.astype(np.int32)),
+                            max_context_len=max(ctx))
+    qd, kcd, vcd = dev(q, torch.bfloat16), bf16_dev(kc), bf16_dev(vc)
+    oracle = O.paged_attention_decode(q, kc, vc, bt, cl, 1 / np.sqrt(D), False)
+    tol = 2 ** -7 * np.abs(oracle).max() + 1e-6
+    with tuning(44, 3):
+        for _ in range(2):
+            got = pa.decode(qd, kcd, vcd, meta, None, partition_size=64).float().cpu().numpy()
+            assert np.isfinite(got).all()
+            assert np.abs(got - oracle).max() <= tol, np.abs(got - oracle).max()
+
