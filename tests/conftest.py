@@ -18,10 +18,16 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def lib():
-    """The HIP C-ABI library; built on demand (hipcc cross-compiles without a GPU)."""
+    """The HIP C-ABI library; built on demand (hipcc cross-compiles without a GPU).  MI355_TUNING="key:value,..." sets A/B switches for
+    the whole session before the first test (how a candidate default is run through the entire suite before it becomes one, e.g.
+    MI355_TUNING=44:3,5:64 = the balanced LDS-DMA attention stream wherever its shapes fit); tests that scope a key with
+    candle_vllm_amd.tuning() still get their own value inside the block and this one back afterwards."""
     import __graft_entry__ as ge
     ge.build()
     import candle_vllm_amd
+    for kv in filter(None, os.environ.get("MI355_TUNING", "").split(",")):
+        k, v = kv.split(":")
+        candle_vllm_amd.lib.mi355_set_tuning(int(k), int(v))
     return candle_vllm_amd.lib
 
 

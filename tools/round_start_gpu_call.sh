@@ -10,6 +10,13 @@ cd $R
 # 1. the whole GPU suite, including tests written after the previous round's GPU minutes were spent (TP loader from a GGUF file, TP step in a hipGraph)
 timeout 900 python -m pytest tests -m gpu -q -x > $OUT/pytest.log 2>&1
 tail -3 $OUT/pytest.log
+# 1b. the candidate default of round 3 through the same suite: the balanced LDS-DMA attention stream (tuning key 44 = 3) as the step
+#     drivers' choice (key 5 = 64-token partitions); its own tests need MI355_EXPERIMENTS=1.  Green here -> make it the default
+#     (host_model.cpp / dense_model.cpp: ps = 64 and g_pa_loop = 3 when sequences x kv heads >= 64), then re-run 1.
+MI355_EXPERIMENTS=1 MI355_TUNING=44:3,5:64 timeout 900 python -m pytest tests -m gpu -q > $OUT/pytest_stream.log 2>&1
+tail -3 $OUT/pytest_stream.log
+B32_STEPS=16 B32_B1=1 B32_AB="5=0,44=1;5=64,44=3;5=0,44=1;5=64,44=3" timeout 120 python tools/exp_b32.py 2>&1 | grep "tok/s" > $OUT/b32_stream.log
+cat $OUT/b32_stream.log
 # 2. smoke + the judged bench line
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1
 tail -1 $OUT/smoke.log
