@@ -15,6 +15,7 @@
 // One wave = 32 queries (2 sub-tiles) of one head; a workgroup = 4 waves = 128 consecutive queries (so the K/V
 // tiles they share hit L1/L2).  grid = (ceil(max_seqlen_q/128), heads, seqs): >> 256 workgroups for real prompts.
 #include "common.h"
+#include "pa_lds_layout.h"
 #include "../../include/mi355_vllm.h"
 #include <hip/hip_runtime.h>
 
@@ -339,6 +340,255 @@ __global__ void __launch_bounds__(64) prefill_attn_generic_kernel(const PrefillP
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// EXPERIMENT (tuning key 47 = 1; bf16, head_dim 128, keys from the PAGED cache, block size 16 / 32 / 64): prompt attention with K / V
+// through LDS by DMA.  prefill_attn_kernel above gives every wave its own K / V fragments straight from global memory: 128 queries of
+// ONE head per workgroup, so a 2048-token prompt reads every K / V tile 16 x 4 (GQA) times out of L2 -- 432 us per layer at
+// Llama-3-8B shapes, 79 TFLOP/s.  Here a workgroup is 64 queries x the (up to) four heads of a GQA group: wave w owns head w, the four
+// waves share every K / V byte through the stage ring of paged_attn_lds_kernel (64-token stages, global_load_lds_dwordx4 three stages
+// ahead, counted vmcnt, one barrier per stage, the same conflict-free layouts -- pa_lds_layout.h), and a wave has the whole register
+// file: Q (4 query tiles x 4 k-steps), K of the stage (16 fragments, read once for the four query tiles), O (4 x 8 accumulators).
+//   S^T = K . Q^T per (key tile, query tile): the lane owns ONE query per query tile -- running max / sum are per-lane scalars;
+//   O   = P . V  with P as the A operand (hi + lo bf16 pieces, as prefill_attn_kernel: the 1e-3 logit bound is against exact
+//         softmax) and the V row fragment as B: 192 MFMAs per wave and stage.
+// Causal masks only on the stages the diagonal crosses; exp2 domain and softcap as prefill_attn_kernel.
+template <int R>
+__global__ void __launch_bounds__(256, 1) prefill_attn_lds_kernel(const PrefillParams p, const uint32_t* __restrict__ btab,
+                                                                   const uint32_t* __restrict__ clens, const uint32_t* __restrict__ cuq) {
+    constexpr int D = 128, NC = 4, NDT = 8;
+    constexpr uint32_t STAGE_B = 32768u;
+    extern __shared__ __attribute__((aligned(1024))) uint8_t pfl_smem[];
+    const int qb = blockIdx.x, seq = blockIdx.z;
+    const int G = p.H / p.Hkv, HG = (G + 3) >> 2;                     // head groups of up to four query heads per kv head
+    const int hk = (int)blockIdx.y / HG, hg = (int)blockIdx.y % HG;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int c = lane & 15, kg = lane >> 4;
+    const int bs = p.block_size, bs_shift = __ffs(bs) - 1, E = 64 >> bs_shift;
+    const int q_begin = (int)cuq[seq], qlen = (int)cuq[seq + 1] - q_begin;
+    const int ctx = (int)clens[seq];
+    const int cached = ctx - qlen;
+    const int q0 = qb * 64;
+    if (q0 >= qlen) return;                                           // uniform for the workgroup
+    const int hw = 4 * hg + wave;
+    const bool active = hw < G;                                       // this wave has a head (all waves copy and meet at the barriers)
+    const int h = hk * G + (active ? hw : 0);
+    const int kend = min(ctx, cached + min(q0 + 64, qlen));           // keys this block can see (exclusive)
+    const int ns = (kend + 63) >> 6;
+    const int nblk = (ctx + bs - 1) >> bs_shift;
+    // ---- Q fragments (B operand: lane = query c of tile qt, k = d 32j + 8kg ..) and the query's position
+    uint4 qf[4][NC];
+    int pos[4];
+    const uint16_t* q16 = static_cast<const uint16_t*>(p.q);
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        const int ql = q0 + 16 * qt + c;
+        pos[qt] = cached + min(ql, qlen - 1);
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            qf[qt][j] = *reinterpret_cast<const uint4*>(q16 + ((size_t)(q_begin + min(ql, qlen - 1)) * p.H + h) * D + 32 * j + 8 * kg);
+            if (ql >= qlen || !active) qf[qt][j] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    // the compiler's wait for these loads must come before the first DMA goes out (it knows nothing of the DMA queue)
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) asm volatile("" : "+v"(qf[qt][0].x), "+v"(qf[qt][1].x), "+v"(qf[qt][2].x), "+v"(qf[qt][3].x));
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)pfl_smem);
+    const uint8_t* kc8 = static_cast<const uint8_t*>(p.k);
+    const uint8_t* vc8 = static_cast<const uint8_t*>(p.v);
+    const int ktok = pal_dma_token(0, lane);
+    auto load_ent = [&](int st, int (&ent)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = min(st * E + min(e, E - 1), nblk - 1);
+            ent[e] = (int)btab[(int64_t)seq * p.max_blocks + idx];
+        }
+    };
+    auto issue = [&](int st, const int (&ent)[4]) {
+        const uint32_t dst = lds0 + (uint32_t)(st % R) * STAGE_B + (uint32_t)wave * 8192u;
+        auto block_of = [&](int tok) {
+            const int e = tok >> bs_shift;
+            return (int64_t)(e == 0 ? ent[0] : (e == 1 ? ent[1] : (e == 2 ? ent[2] : ent[3])));
+        };
+        if (wave < 2) {
+            int tok = ktok;
+            if (64 * st + tok >= ctx) tok = 0;
+            const int64_t blk = block_of(tok);
+            const int off = tok & (bs - 1);
+            const uint8_t* src = kc8 + ((blk * p.Hkv + hk) * 16 + 8 * wave) * (int64_t)bs * 16 + (int64_t)off * 16;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pa_dma16(src + (int64_t)q * bs * 16, dst + (uint32_t)q * 1024u);
+        } else {
+            const uint8_t* srcp[2];
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                int tok = pal_dma_token(8 * wave + par, lane);
+                if (64 * st + tok >= ctx) tok = 0;
+                const int64_t blk = block_of(tok);
+                const int off = tok & (bs - 1);
+                srcp[par] = vc8 + (((blk * p.Hkv + hk) * D + pal_dma_row(8 * wave + par, lane)) * (int64_t)bs + off) * 2;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pa_dma16(srcp[q & 1] + (int64_t)(8 * (q & ~1)) * bs * 2, dst + (uint32_t)q * 1024u);
+        }
+    };
+    int ent[4];
+#pragma unroll
+    for (int st = 0; st < R - 1; ++st)
+        if (st < ns) { load_ent(st, ent); issue(st, ent); }
+    if (R - 1 < ns) load_ent(R - 1, ent);
+    float m_run[4], l_run[4];
+    f32x4_t o[4][NDT];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        m_run[qt] = -INFINITY; l_run[qt] = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NDT; ++nt) o[qt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int i = 0; i < ns; ++i) {
+        {
+            const int ahead = min(ns, i + R - 1) - (i + 1);
+            if (ahead >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (i + R - 1 < ns) {
+            issue(i + R - 1, ent);
+            if (i + R < ns) load_ent(i + R, ent);
+        }
+        if (!active) continue;                                        // uniform per wave; the barrier is at the top of the loop
+        const uint8_t* Kb = pfl_smem + (size_t)(i % R) * STAGE_B;
+        const int tb = 64 * i;
+        const bool diag = tb + 63 > cached + q0;                      // some query of the block does not see the whole stage
+        // ---- K fragments of the stage: tile (ip, it), k-step j
+        uint4 ka[2][2][NC];
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int j = 0; j < NC; ++j) ka[ip][it][j] = *reinterpret_cast<const uint4*>(Kb + pal_k_read_off(j, kg, ip, it, c));
+        uint4 pb[4][2], pl[4][2];                                     // P of query tile qt, pair ip: hi and lo bf16 pieces (A operands)
+        float alpha[4];
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            float x[2][2][4];
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < NC; ++j)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ka[ip][it][j]), __builtin_bit_cast(bf16x8_t, qf[qt][j]), acc, 0, 0, 0);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        float sv = acc[v];
+                        if (p.softcap > 0.f) sv = tanhf(sv * p.scale / p.softcap) * p.softcap * 1.4426950408889634f;
+                        else sv *= p.scale_log2;
+                        x[ip][it][v] = sv;
+                    }
+                }
+            if (diag) {
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+                    for (int it = 0; it < 2; ++it)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            x[ip][it][v] = (tb + 32 * ip + 8 * kg + 4 * it + v <= pos[qt]) ? x[ip][it][v] : -INFINITY;   // causal (j < ctx follows)
+            }
+#pragma unroll
+            for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) tmax = fmaxf(tmax, x[ip][it][v]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float m_new = fmaxf(m_run[qt], tmax);               // finite from the first stage on: key 0 is visible to every query
+            alpha[qt] = exp2f(m_run[qt] - m_new);
+            m_run[qt] = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int ip = 0; ip < 2; ++ip) {
+                float e8[8];
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { e8[4 * it + v] = exp2f(x[ip][it][v] - m_new); psum += e8[4 * it + v]; }
+                const uint4 hi = make_uint4(cvt_pk_bf16(e8[0], e8[1]), cvt_pk_bf16(e8[2], e8[3]), cvt_pk_bf16(e8[4], e8[5]), cvt_pk_bf16(e8[6], e8[7]));
+                float r8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t wv = (e & 1) ? ((&hi.x)[e >> 1] & 0xFFFF0000u) : ((&hi.x)[e >> 1] << 16);
+                    r8[e] = e8[e] - __uint_as_float(wv);
+                }
+                pb[qt][ip] = hi;
+                pl[qt][ip] = make_uint4(cvt_pk_bf16(r8[0], r8[1]), cvt_pk_bf16(r8[2], r8[3]), cvt_pk_bf16(r8[4], r8[5]), cvt_pk_bf16(r8[6], r8[7]));
+            }
+            l_run[qt] = fmaf(l_run[qt], alpha[qt], psum);             // this lane's share (keys 8kg.. of both pairs); summed over kg at the end
+        }
+        // ---- O = O * alpha + P . V : lane (channel 16 nt + c, queries 4kg+v of tile qt); query 4kg+v's alpha sits in lane 4kg+v
+        float av[4][4];
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) av[qt][v] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (4 * kg + v), __float_as_int(alpha[qt])));
+        uint32_t vm[2][4];                                            // keys at or beyond ctx hold arbitrary bits: cleared in the B fragment
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip) {
+            const int tk = tb + 32 * ip + 8 * kg;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vm[ip][e] = (tk + 2 * e < ctx ? 0x0000FFFFu : 0u) | (tk + 2 * e + 1 < ctx ? 0xFFFF0000u : 0u);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NDT; ++nt) {
+            uint4 vv[2];
+#pragma unroll
+            for (int ip = 0; ip < 2; ++ip) {
+                vv[ip] = *reinterpret_cast<const uint4*>(Kb + pal_v_read_off(16 * nt + c, ip, kg));
+                vv[ip].x &= vm[ip][0]; vv[ip].y &= vm[ip][1]; vv[ip].z &= vm[ip][2]; vv[ip].w &= vm[ip][3];
+            }
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                f32x4_t on = o[qt][nt];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) on[v] *= av[qt][v];
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip) {
+                    on = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pb[qt][ip]), __builtin_bit_cast(bf16x8_t, vv[ip]), on, 0, 0, 0);
+                    on = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pl[qt][ip]), __builtin_bit_cast(bf16x8_t, vv[ip]), on, 0, 0, 0);
+                }
+                o[qt][nt] = on;
+            }
+        }
+    }
+    if (!active) return;
+    // ---- epilogue: rows (queries 4kg+v of tile qt) need the sums of lane (4kg+v)
+    uint16_t* out16 = static_cast<uint16_t*>(p.out);
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        float lt = l_run[qt] + __shfl_xor(l_run[qt], 16);
+        lt += __shfl_xor(lt, 32);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float lq = __shfl(lt, 4 * kg + v);
+            const int ql = q0 + 16 * qt + 4 * kg + v;
+            if (ql >= qlen) continue;
+            const float inv = 1.f / lq;
+            uint16_t* op = out16 + ((size_t)(q_begin + ql) * p.H + h) * D + c;
+#pragma unroll
+            for (int nt = 0; nt < NDT; ++nt) op[16 * nt] = f32_to_bf16(o[qt][nt][v] * inv);
+        }
+    }
+}
+
+static int g_pf_lds = 0;                                             // mi355_set_tuning(47, 1): EXPERIMENT, prefill_attn_lds_kernel where its shapes fit
+void mi355_prefill_set_lds(int v) { g_pf_lds = v; }
+
 template <int DT, int D>
 static void prefill_launch_src(const PrefillParams& p, int src, dim3 grid, hipStream_t st) {
     switch (src) {
@@ -371,6 +621,20 @@ extern "C" int mi355_prefill_attention(void* out, const void* q, const void* k, 
     const int src = !cached ? SRC_CONTIG : (layout == MI355_KV_FLASH ? SRC_FLASH : SRC_PAGED);
     hipStream_t st = (hipStream_t)stream;
     const bool mfma_ok = (head_dim == 64 || head_dim == 128) && (src != SRC_PAGED || block_size % 16 == 0);
+    if (g_pf_lds && src == SRC_PAGED && dtype == MI355_DTYPE_BF16 && head_dim == 128 &&
+        (block_size == 16 || block_size == 32 || block_size == 64)) {
+        // EXPERIMENT (tuning key 47 = 1): 64 queries x the heads of a GQA group per workgroup, K / V through the LDS ring
+        constexpr int PFL_R = 4;
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)prefill_attn_lds_kernel<PFL_R>, hipFuncAttributeMaxDynamicSharedMemorySize, PFL_R * 32768);
+            attr_done = true;
+        }
+        const int G = num_heads / num_kv_heads;
+        dim3 grid((max_seqlen_q + 63) / 64, num_kv_heads * ((G + 3) / 4), num_seqs);
+        hipLaunchKernelGGL((prefill_attn_lds_kernel<PFL_R>), grid, dim3(256), PFL_R * 32768, st, p, block_tables, context_lens, cu_seqlens_q);
+        return (int)hipGetLastError();
+    }
     if (mfma_ok) {
         dim3 grid((max_seqlen_q + 127) / 128, num_heads, num_seqs);
         if (dtype == MI355_DTYPE_BF16) {

@@ -1995,6 +1995,7 @@ extern "C" void mi355_host_set_partition_override(int v);
 extern "C" void mi355_host_set_moe_group(int v);
 extern "C" void mi355_dense_set_tile(int v);
 void mi355_prefill_set_fp8_generic(int v);
+void mi355_prefill_set_lds(int v);
 static int g_tune_actq8 = 0;                               // mi355_set_tuning(18, 1): EXPERIMENT, single-token launches quantise x to Q8_K (reference CPU numerics, O2)
 static int g_tune_nw = 0, g_tune_r = 0;                   // 0 = heuristic; mi355_set_tuning (experiments only)
 static int g_tune_prefill_gemm = 1;                        // 0 = always stream the quantised weights (experiments)
@@ -2033,6 +2034,7 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     else if (key == 42) mi355_dense_set_tile(value);
     else if (key == 43) mi355_prefill_set_fp8_generic(value);
     else if (key == 44) mi355_pa_set_loop(value);
+    else if (key == 47) mi355_prefill_set_lds(value);
 }
 
 static size_t qmm_lds_bytes(int BT, int R, int NW) {

@@ -29,12 +29,16 @@ def main():
                 M.lib.mi355_set_tuning(11, qv)
                 for dbg in ([int(v) for v in os.environ.get("PF_DBG", "0").split(",")] if mode == 1 else [0]):
                     M.lib.mi355_set_tuning(2, dbg)
-                    gm.forward_prefill(meta)
-                    t0 = time.perf_counter()
-                    gm.forward_prefill(meta)
-                    dt = time.perf_counter() - t0
-                    flops = 2.0 * (gm.weight_bytes / 0.5625) * T          # ~ 2 * params * tokens (Q4_K: 0.5625 B / weight)
-                    print(f"prefill T={T:5d} gemm={mode} variant={qv} dbg={dbg}: {T / dt:9.1f} tok/s  {dt * 1e3:8.1f} ms  ~{flops / dt / 1e12:6.1f} TFLOP/s", flush=True)
+                    # PF_ATTN="0,1": A/B of the prompt attention on the same model (tuning key 47: 1 = the LDS-DMA experiment)
+                    for attn in [int(v) for v in os.environ.get("PF_ATTN", "0").split(",")]:
+                        M.lib.mi355_set_tuning(47, attn)
+                        gm.forward_prefill(meta)
+                        t0 = time.perf_counter()
+                        gm.forward_prefill(meta)
+                        dt = time.perf_counter() - t0
+                        flops = 2.0 * (gm.weight_bytes / 0.5625) * T          # ~ 2 * params * tokens (Q4_K: 0.5625 B / weight)
+                        print(f"prefill T={T:5d} gemm={mode} variant={qv} dbg={dbg} attn={attn}: {T / dt:9.1f} tok/s  {dt * 1e3:8.1f} ms  ~{flops / dt / 1e12:6.1f} TFLOP/s", flush=True)
+                    M.lib.mi355_set_tuning(47, 0)
     M.lib.mi355_set_tuning(11, 0)
     M.lib.mi355_set_tuning(2, 0)
     M.lib.mi355_set_tuning(6, 1)

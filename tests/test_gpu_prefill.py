@@ -1,6 +1,8 @@
 """GPU parity tests for K4 (prefill attention) through the C ABI vs the numpy oracle (softmax in f64).
 Tolerance: flash-attention arithmetic (P rounded to 16 bit, f32 accumulation) vs exact softmax -> 2e-2 of the
 output scale for bf16, 4e-3 for f16, stated next to the assert; the output itself is a 16-bit value."""
+import os
+
 import numpy as np
 import pytest
 
@@ -144,3 +146,37 @@ def test_prefill_mixed_batch_cached_and_fresh_with_equal_maxima(cv):
         ref = O.prefill_attention(q[i], k_all[i], v_all[i], scale, cached=cached[i], rnd=lambda a: G.round_dt(a, dt))
         assert np.abs(got[o:o + l] - ref).max() <= TOL[dt] * max(1.0, np.abs(ref).max()), f"seq {i}"
         o += l
+
+
+@pytest.mark.skipif(not os.environ.get("MI355_EXPERIMENTS"), reason="experiment kernels run on request (MI355_EXPERIMENTS=1)")
+@pytest.mark.parametrize("H,Hkv,bs", [(8, 2, 64), (32, 8, 16), (28, 4, 32), (4, 4, 64), (8, 1, 16)])
+def test_prefill_lds_dma_experiment(cv, H, Hkv, bs):
+    """tuning key 47 = 1: prompt attention with K / V through the LDS ring (prefill_attn_lds_kernel): 64 queries x the heads of a GQA
+    group per workgroup -- chunked prefill, prefix hit, fresh prompts, blocks that end inside a stage, GQA groups of 1 / 4 / 7 / 8
+    heads; against the oracle at the product kernel's bound AND against the product kernel itself (same hi + lo probabilities:
+    the two agree to accumulation noise)"""
+    from candle_vllm_amd import tuning
+    dt, D = "bf16", 128
+    rng = np.random.default_rng(H + bs)
+    lens, cached = [70, 3, 129, 64, 200, 1], [50, 0, 200, 64, 0, 300]
+    q, k_all, v_all, kc, vc, meta = make_case(rng, lens, cached, H, Hkv, D, bs, dt, False)
+    scale = 1.0 / np.sqrt(D)
+    pa = cv.PagedAttention(H, D, scale, Hkv)
+    im = cv.InputMetadata.from_oracle_meta(meta, "cuda", is_prefill=True)
+    kcd = torch.from_numpy(kc.view(np.int16)).cuda().view(TD[dt])
+    vcd = torch.from_numpy(vc.view(np.int16)).cuda().view(TD[dt])
+    qd = dev16(np.concatenate(q), dt)
+    base = host16(pa.prefill(qd, None, None, kcd, vcd, im), dt)
+    with tuning(47, 1):
+        got = host16(pa.prefill(qd, None, None, kcd, vcd, im), dt)
+        soft = host16(pa.prefill(qd, None, None, kcd, vcd, im, 30.0), dt)
+    soft_base = host16(pa.prefill(qd, None, None, kcd, vcd, im, 30.0), dt)
+    assert np.isfinite(got).all() and np.isfinite(soft).all()
+    o = 0
+    for i, l in enumerate(lens):
+        ref = O.prefill_attention(q[i], k_all[i], v_all[i], scale, cached=cached[i], rnd=lambda a: G.round_dt(a, dt))
+        assert np.abs(got[o:o + l] - ref).max() <= TOL[dt] * max(1.0, np.abs(ref).max()), f"seq {i}"
+        o += l
+    assert np.abs(got - base).max() <= 2 ** -7 * max(1.0, np.abs(base).max())        # one bf16 ulp of the largest output
+    assert np.abs(soft - soft_base).max() <= 2 ** -7 * max(1.0, np.abs(soft_base).max())
+
