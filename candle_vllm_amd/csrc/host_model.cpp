@@ -527,6 +527,7 @@ void drop_graph(Model* m) {
 }  // namespace
 
 extern "C" void mi355_host_set_partition_override(int v) { g_host_ps_override = v; }
+extern "C" int mi355_host_get_partition_override() { return g_host_ps_override; }   // the 16-bit driver honours the same switch
 extern "C" void mi355_host_set_moe_group(int v) { g_moe_group = v; }
 
 extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
