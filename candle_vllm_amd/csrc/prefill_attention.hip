@@ -484,13 +484,23 @@ __global__ void __launch_bounds__(256, 1) prefill_attn_lds_kernel(const PrefillP
                     for (int j = 0; j < NC; ++j)
                         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ka[ip][it][j]), __builtin_bit_cast(bf16x8_t, qf[qt][j]), acc, 0, 0, 0);
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        float sv = acc[v];
-                        if (p.softcap > 0.f) sv = tanhf(sv * p.scale / p.softcap) * p.softcap * 1.4426950408889634f;
-                        else sv *= p.scale_log2;
-                        x[ip][it][v] = sv;
-                    }
+                    for (int v = 0; v < 4; ++v) x[ip][it][v] = acc[v];
                 }
+            if (p.softcap > 0.f) {                                    // one uniform branch for the sixteen logits of the query tile
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+                    for (int it = 0; it < 2; ++it)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) x[ip][it][v] = tanhf(x[ip][it][v] * p.scale / p.softcap) * p.softcap * 1.4426950408889634f;
+            } else {
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+                    for (int it = 0; it < 2; ++it)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) x[ip][it][v] *= p.scale_log2;
+            }
             if (diag) {
 #pragma unroll
                 for (int ip = 0; ip < 2; ++ip)
