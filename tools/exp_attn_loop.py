@@ -32,7 +32,7 @@ for name, ctx in (("uniform 4096", [4096] * B), ("ragged U[256,4096]", np.random
     kv_bytes = sum(ctx) * Hkv * D * 2 * 2
     ref = None
     for label, ps, loop in (("one-partition waves, 32", 32, 1), ("one-partition waves, 64", 64, 1), ("looped chunks, 256", 256, 1),
-                            ("looped chunks, 512", 512, 1), ("LDS-DMA stages, 1024", 1024, 2), ("LDS-DMA stages, 2048", 2048, 2), ("LDS-DMA stages, 4096", 4096, 2), ("LDS-DMA balanced stream", 64, 3),
+                            ("looped chunks, 512", 512, 1), ("LDS-DMA stages, 1024", 1024, 2), ("LDS-DMA stages, 2048", 2048, 2), ("LDS-DMA stages, 4096", 4096, 2), ("LDS-DMA balanced stream", 64, 3), ("LDS-DMA balanced stream, fused merge", 64, 4),
                             ("generic kernel, 256", 256, 0)):
         with tuning(44, loop):
             out = pa.decode(q, kc, vc, meta, None, partition_size=ps)

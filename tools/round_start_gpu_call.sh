@@ -17,7 +17,7 @@ tail -3 $OUT/pytest.log
 #  drop 47:1 here and fix it on its own)
 MI355_EXPERIMENTS=1 MI355_TUNING=44:3,5:64,47:1 timeout 900 python -m pytest tests -m gpu -q > $OUT/pytest_stream.log 2>&1
 tail -3 $OUT/pytest_stream.log
-B32_STEPS=16 B32_B1=1 B32_AB="5=0,44=1;5=64,44=3;5=0,44=1;5=64,44=3" timeout 120 python tools/exp_b32.py 2>&1 | grep "tok/s" > $OUT/b32_stream.log
+B32_STEPS=16 B32_B1=1 B32_AB="5=0,44=1;5=64,44=3;5=64,44=4;5=0,44=1;5=64,44=3;5=64,44=4" timeout 120 python tools/exp_b32.py 2>&1 | grep "tok/s" > $OUT/b32_stream.log
 cat $OUT/b32_stream.log
 PF_T=2048 PF_MODES=1 PF_ATTN=0,1,0,1 timeout 200 python tests/bench_prefill.py 2>&1 | grep "tok/s" > $OUT/prefill_attn_ab.log
 cat $OUT/prefill_attn_ab.log
