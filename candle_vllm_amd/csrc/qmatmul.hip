@@ -1863,6 +1863,7 @@ int mi355_internal_gemm_rowmajor(void* out, int out_dtype, int ldo, const void* 
 #endif  // MI355_QMM_PROBES
 
 static int g_tune_qpg = 0;                                 // mi355_set_tuning(11, v): prompt-step GEMM variant (A/B runs)
+static int g_tune_qpg_fepi = 0;                            // mi355_set_tuning(48, 1): EXPERIMENT, prompt-step GEMM applies the epilogue itself (Q4_K launches; store / residual / SiLU * up)
 static int g_tune_qpg_min = 96;                            // mi355_set_tuning(12, n): fewest tokens that take the prompt-step GEMM (QMP_MIN_TOKENS)
 static int g_tune_dbg = 0;                                 // mi355_set_tuning(2, v): probe / ablation modes (experiments only)
 
@@ -1901,12 +1902,29 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)qpg_gemm_kernel<MI355_GGML_Q4_K, MTW, NTW, WM, WN, DEEP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)
         QPG_ATTR(2, 4, 1, 8, false); QPG_ATTR(4, 4, 1, 8, false); QPG_ATTR(4, 2, 1, 8, false); QPG_ATTR(2, 4, 2, 4, false);
 #undef QPG_ATTR
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_kernel<MI355_GGML_Q4_K, 2, 4, 1, 8, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         attr_done = true;
     }
     hipLaunchKernelGGL(qpg_rowstat_kernel, dim3(Tpad), dim3(256), 0, st, a, im);
     hipLaunchKernelGGL(qpg_prep_kernel, dim3(nkb, Tpad / 8), dim3(256), 0, st, a, im);
+    // EXPERIMENT (mi355_set_tuning(48, 1)): all segments Q4_K, one activation plane, the default wave tile, and an epilogue that is a
+    // store / residual add / SiLU * up over two equal segments -> the GEMM writes the outputs itself, no C buffer, no epilogue launch
+    {
+        bool all_q4 = true;
+        for (int s = 0; s < a.nseg; ++s) all_q4 = all_q4 && a.seg[s].type == MI355_GGML_Q4_K;
+        const bool epi_ok = a.epi == MI355_EPI_STORE || a.epi == MI355_EPI_RESID ||
+                            (a.epi == MI355_EPI_SILU_MUL && a.nseg == 2 && a.seg[0].n_tiles == a.seg[1].n_tiles && a.seg[0].n_rows == a.seg[1].n_rows);
+        if (g_tune_qpg_fepi && all_q4 && epi_ok && parts == 1 && g_tune_qpg == 0) {
+            QmmArgs r = a;
+            r.norm_w = nullptr;                                 // applied while the image was built
+            const dim3 g_(Tpad / 32, (n_slots + 31) / 32), b_(512);
+            const size_t sh_ = (size_t)2 * 32 * QPG_ROWB;
+            hipLaunchKernelGGL((qpg_gemm_kernel<MI355_GGML_Q4_K, 2, 4, 1, 8, false, 1, true>), g_, b_, sh_, st, r, im, C, ldp, n_slots, 0);
+            return (int)hipGetLastError();
+        }
+    }
     for (int s0 = 0, slot_base = 0; s0 < a.nseg;) {
         int s1 = s0 + 1;
         while (s1 < a.nseg && a.seg[s1].type == a.seg[s0].type) ++s1;
@@ -2035,6 +2053,7 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     else if (key == 43) mi355_prefill_set_fp8_generic(value);
     else if (key == 44) mi355_pa_set_loop(value);
     else if (key == 47) mi355_prefill_set_lds(value);
+    else if (key == 48) g_tune_qpg_fepi = value;
 }
 
 static size_t qmm_lds_bytes(int BT, int R, int NW) {

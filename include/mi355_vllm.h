@@ -269,7 +269,8 @@ int mi355_moe_scatter_combine(float* ys, const float* y_sorted, const float* wei
  * projections in tiles (1 on; read at the first step), 43 fp8-cache prefill on the generic kernel, 44 decode attention partition sizes
  * 256 / 512 as looped chunks on the MFMA kernel (1 on; 0 = the generic kernel; EXPERIMENTS: 2 = partition sizes 1024 / 2048 / 4096
  * through an LDS ring filled by DMA, 3 = partition size 64 as one balanced LDS-DMA stream per workgroup, 4 = the same with the merge in the last arriver), 47 EXPERIMENT: prompt
- * attention over the PAGED cache with K / V through the same LDS ring (1 on; bf16, head_dim 128).  A/B switches for measurements and tests: no product path depends on a
+ * attention over the PAGED cache with K / V through the same LDS ring (1 on; bf16, head_dim 128), 48 EXPERIMENT: Q4_K prompt-step
+ * launches apply store / residual / SiLU * up in the GEMM's store loop (1 on).  A/B switches for measurements and tests: no product path depends on a
  * non-default value.  mi355_get_tuning returns what a key was last set to (INT32_MIN: never set), so a caller can restore what it
  * found instead of assuming the default. */
 void mi355_set_tuning(int32_t key, int32_t value);

@@ -17,6 +17,9 @@ def main():
     gm = M.GGUFLLaMa(cfg, max_batch=4, max_blocks_per_seq=80, kv_layout=M.KV_PAGED)
     gm.load_synthetic()
     gm.alloc_kv_cache(160)
+    for kv in filter(None, os.environ.get("MI355_TUNING", "").split(",")):     # "key:value,..." for the whole run (e.g. 48:1)
+        k, v = kv.split(":")
+        M.lib.mi355_set_tuning(int(k), int(v))
     rng = np.random.default_rng(0)
     for T in [int(t) for t in os.environ.get("PF_T", "512,2048,4096").split(",")]:
         seqs = [{"tokens": rng.integers(0, cfg.vocab, T).tolist(), "block_table": list(range(1, 1 + -(-T // cfg.block_size)))}]

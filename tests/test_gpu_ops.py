@@ -681,3 +681,44 @@ def test_paged_attention_lds_dma_stream_experiment(cv, bs, ctx):
                 assert np.isfinite(got).all()
                 assert np.abs(got - oracle).max() <= tol, (key, np.abs(got - oracle).max())
 
+
+@pytest.mark.skipif(not os.environ.get("MI355_EXPERIMENTS"), reason="experiment kernels run on request (MI355_EXPERIMENTS=1)")
+@pytest.mark.parametrize("T,N,K", [(128, 96, 1024), (200, 40, 512), (300, 640, 2048), (97, 16, 256)])
+def test_prompt_gemm_fused_epilogue_experiment(cv, T, N, K):
+    """tuning key 48 = 1: Q4_K prompt-step launches apply store / bias / residual / SiLU * up in the GEMM's own store loop (no C buffer,
+    no epilogue launch) -- against the oracle at the prompt path's bound and against the unfused path (same arithmetic: 1e-6)"""
+    from candle_vllm_amd import tuning
+    rng = np.random.default_rng(48 + T + N)
+    t = kq.GGML_Q4_K
+    bg = kq.quantize(rng.normal(0, 0.05, (N, K)).astype(np.float32), t)
+    bu = kq.quantize(rng.normal(0, 0.05, (N, K)).astype(np.float32), t)
+    x = rng.normal(0, 1, (T, K)).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    resid = rng.normal(size=(T, N)).astype(np.float32)
+    nw = (1 + 0.1 * rng.normal(size=K)).astype(np.float32)
+    mg, mu = cv.QMatMul(bg, t, "cuda"), cv.QMatMul(bu, t, "cuda")
+    rg, ru = kq.qmatmul_o1(x, bg, t), kq.qmatmul_o1(x, bu, t)
+    xn = O.rms_norm(x, nw, 1e-5)
+    rgn, run_ = kq.qmatmul_o1(xn, bg, t), kq.qmatmul_o1(xn, bu, t)
+
+    def all_modes():
+        out = {}
+        out["store"] = mg.forward(dev(x)).cpu().numpy()
+        out["bias"] = mg.forward(dev(x), dev(bias)).cpu().numpy()
+        o = dev(resid.copy())
+        cv.qmatmul_fused([mg], dev(x), epilogue=cv.EPI_RESID, out=o, residual=o)
+        out["resid"] = o.cpu().numpy()
+        h = torch.empty((T, N), dtype=torch.float32, device="cuda")
+        cv.qmatmul_fused([mg, mu], dev(x), epilogue=cv.EPI_SILU_MUL, out=h, norm_weight=dev(nw), norm_eps=1e-5)
+        out["silu"] = h.cpu().numpy()
+        return out
+
+    base = all_modes()
+    with tuning(48, 1):
+        got = all_modes()
+    want = {"store": rg, "bias": rg + bias, "resid": resid + rg, "silu": rgn / (1 + np.exp(-rgn)) * run_}
+    for k in want:
+        assert np.isfinite(got[k]).all()
+        assert rel_err(got[k], want[k]) < WIDE_TOL, (k, rel_err(got[k], want[k]))
+        assert rel_err(got[k], base[k]) < 1e-5, (k, rel_err(got[k], base[k]))
+

@@ -15,11 +15,13 @@ tail -3 $OUT/pytest.log
 #     (host_model.cpp / dense_model.cpp: ps = 64 and g_pa_loop = 3 when sequences x kv heads >= 64), then re-run 1.
 # (47:1 = the LDS-DMA prompt attention, written blind at the end of round 3: its test is test_gpu_prefill.py -k lds_dma; if it fails,
 #  drop 47:1 here and fix it on its own)
-MI355_EXPERIMENTS=1 MI355_TUNING=44:3,5:64,47:1 timeout 900 python -m pytest tests -m gpu -q > $OUT/pytest_stream.log 2>&1
+#  48:1 = the prompt-step GEMM with the epilogue in its store loop, also written blind: test_gpu_ops.py -k fused_epilogue)
+MI355_EXPERIMENTS=1 MI355_TUNING=44:3,5:64,47:1,48:1 timeout 900 python -m pytest tests -m gpu -q > $OUT/pytest_stream.log 2>&1
 tail -3 $OUT/pytest_stream.log
 B32_STEPS=16 B32_B1=1 B32_AB="5=0,44=1;5=64,44=3;5=64,44=4;5=0,44=1;5=64,44=3;5=64,44=4" timeout 120 python tools/exp_b32.py 2>&1 | grep "tok/s" > $OUT/b32_stream.log
 cat $OUT/b32_stream.log
 PF_T=2048 PF_MODES=1 PF_ATTN=0,1,0,1 timeout 200 python tests/bench_prefill.py 2>&1 | grep "tok/s" > $OUT/prefill_attn_ab.log
+MI355_TUNING=48:1 PF_T=2048 PF_MODES=1 PF_ATTN=0,1 timeout 200 python tests/bench_prefill.py 2>&1 | grep "tok/s" >> $OUT/prefill_attn_ab.log   # + fused epilogue
 cat $OUT/prefill_attn_ab.log
 # 2. smoke + the judged bench line
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1
