@@ -189,6 +189,10 @@ class BlockEngine:
         """-> {cpu_block: gpu_block}"""
         return self._swap(lib.mi355_be_swap_in, group_id, group)
 
+    def test_refuse_swaps(self, n_out=0, n_in=0):
+        """test hook: the next n_out swap-outs / n_in swap-ins are refused before anything is touched"""
+        lib.mi355_be_test_refuse_swaps(self.h, n_out, n_in)
+
     def finalize_swap_out(self, gid):
         lib.mi355_be_finalize_swap_out(self.h, gid)
 

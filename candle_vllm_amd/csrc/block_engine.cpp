@@ -216,6 +216,7 @@ struct Engine {
     std::unordered_map<int64_t, std::vector<Blk>> tables;
     std::unordered_map<int64_t, Seq> seqs;
     std::unordered_map<int64_t, Pending> pending_out, pending_in;
+    int refuse_swap_out = 0, refuse_swap_in = 0;          // test hook (mi355_be_test_refuse_swaps): the next n swaps are refused up front
 
     int logical_blocks(const Seq& s) const { return (int)s.tokens.size() / block_size + 1; }     // sequence.rs:208-227
     int blocks_to_add_new_tok(const Seq& s) const { return (s.tokens.size() % block_size) == 0 ? 1 : 0; }
@@ -388,6 +389,11 @@ int32_t mi355_be_allocate(void* be, const int64_t* seq_ids, int32_t n, int32_t c
         s->num_cached = cached_tokens;
         const int end = e->prefill_chunk_tokens(*s, chunk) + cached_tokens;
         const int required = chunk == 0 ? e->logical_blocks(*s) : (end + e->block_size - 1) / e->block_size;
+        // `can_allocate` counted ceil(prefill_end / block_size) blocks (:348-349); an unchunked allocation takes the LOGICAL block
+        // count, one more when the token count is a multiple of the block size (sequence.rs:208-227).  With exactly the counted
+        // blocks free the reference unwraps an empty free list here (:113-117).  We first give the prefix cache's evictable
+        // blocks back (the matched blocks are pinned by the references taken above), and refuse only if that is not enough.
+        if (required - (int)table.size() > (int)e->gpu.free_ids.size()) e->evict_until_free(required - (int)table.size());
         if (required - (int)table.size() > (int)e->gpu.free_ids.size()) {
             for (Blk b : table) e->release(b);
             return -2;                                            /* the reference would panic on an empty free list */
@@ -628,6 +634,7 @@ int32_t mi355_be_swap_out(void* be, int64_t group_id, const int64_t* seq_ids, in
     std::unordered_map<int, int> map;                     // gpu id -> cpu id
     std::vector<std::pair<int, int>> order;
     Pending pend;
+    if (e->refuse_swap_out > 0) { --e->refuse_swap_out; return -4; }
     {   // every failure is detected BEFORE a table or a pool is touched (no half-swapped group)
         std::unordered_set<int> need;
         for (int i = 0; i < n; ++i) {
@@ -668,6 +675,7 @@ int32_t mi355_be_swap_in(void* be, int64_t group_id, const int64_t* seq_ids, int
     std::unordered_map<int, int> map;                     // cpu id -> gpu id
     std::vector<std::pair<int, int>> order;
     Pending pend;
+    if (e->refuse_swap_in > 0) { --e->refuse_swap_in; return -4; }
     {   // check everything before mutating, as in swap_out
         const int32_t need = mi355_be_swap_in_required_blocks(be, seq_ids, n);
         for (int i = 0; i < n; ++i) if (e->tables.find(seq_ids[i]) == e->tables.end()) return -1;
@@ -696,6 +704,9 @@ int32_t mi355_be_swap_in(void* be, int64_t group_id, const int64_t* seq_ids, int
     e->pending_in[group_id] = std::move(pend);
     return emit_pairs(order, pairs, cap);
 }
+// TEST HOOK: the next `n_out` calls of mi355_be_swap_out and the next `n_in` calls of mi355_be_swap_in return -4 before they
+// touch a table or a pool -- the only way to reach the scheduler's refused-swap branches once `can_swap_*` has said yes.
+void mi355_be_test_refuse_swaps(void* be, int32_t n_out, int32_t n_in) { E(be)->refuse_swap_out = n_out; E(be)->refuse_swap_in = n_in; }
 void mi355_be_finalize_swap_out(void* be, int64_t group_id) { E(be)->pending_out.erase(group_id); }
 void mi355_be_rollback_swap_out(void* be, int64_t group_id) {                                       // :1270-1295
     Engine* e = E(be);

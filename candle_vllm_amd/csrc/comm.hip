@@ -312,23 +312,36 @@ extern "C" int mi355_comm_p2p_error(void* comm) {
     return (int)e;
 }
 
-// Can this stack capture the communicator's all-reduce in a hipGraph?  Captures one 64-element all-reduce on `stream`,
-// instantiates the graph and destroys it WITHOUT launching: nothing runs on the wire, so a rank can test locally and the ranks
-// agree on graph / eager steps before the first real step (a per-rank fallback after a failed first step would leave its
-// peers inside a collective).  0 = capturable.
+// Can this stack capture EVERY collective flavour a TP step issues in a hipGraph?  Captures, on `stream`, a small f32 all-reduce
+// (the one-shot peer kernel when attached), a hidden-sized f32 all-reduce beyond the one-shot limit, a bf16 all-reduce (the
+// reference's wire numerics) and an all-gather (the vocab-parallel logits), instantiates the graph and destroys it WITHOUT
+// launching: nothing runs on the wire, so a rank can test locally and the ranks agree on graph / eager steps before the first real
+// step (a per-rank fallback after a failed first step would leave its peers inside a collective).  A communicator with
+// ANY host-supplied callback is refused outright: the logits all-gather (and every all-reduce beyond the one-shot limit) would be
+// a host call made during capture -- not replayed, i.e. stale logits on every replay.  0 = capturable.
 extern "C" int mi355_comm_capture_probe(void* comm, int64_t stream) {
     Comm* c = static_cast<Comm*>(comm);
     if (!c || stream == 0) return (int)hipErrorInvalidValue;
-    if (c->ar && !c->p2p) return (int)hipErrorNotSupported;       // host-supplied collectives are host calls: never captured
+    if (c->ar || c->ag) return (int)hipErrorNotSupported;         // host-supplied collectives are host calls: never captured
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    void* buf = nullptr;
-    CCHECK(hipMalloc(&buf, 64 * sizeof(float)));
-    (void)hipMemsetAsync(buf, 0, 64 * sizeof(float), st);
+    const int world = c->world > 0 ? c->world : 1;
+    const int64_t big = MI355_P2P_MAX_BYTES / 4 + 1024;           // f32 elements: past the one-shot kernel's limit
+    const size_t bytes = (size_t)big * sizeof(float) + (size_t)big * 2 + 256 * sizeof(float) * (size_t)(world + 1);
+    char* buf = nullptr;
+    CCHECK(hipMalloc(reinterpret_cast<void**>(&buf), bytes));
+    (void)hipMemsetAsync(buf, 0, bytes, st);
     (void)hipStreamSynchronize(st);
+    float* f_big = reinterpret_cast<float*>(buf);
+    uint16_t* h_big = reinterpret_cast<uint16_t*>(buf + (size_t)big * sizeof(float));
+    float* g_send = reinterpret_cast<float*>(buf + (size_t)big * sizeof(float) + (size_t)big * 2);
+    float* g_recv = g_send + 256;
     int rc = (int)hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
     hipGraph_t g = nullptr;
     if (rc == 0) {
-        rc = comm_all_reduce(c, buf, 64, MI355_DTYPE_F32, stream);
+        rc = comm_all_reduce(c, f_big, 64, MI355_DTYPE_F32, stream);
+        if (rc == 0) rc = comm_all_reduce(c, f_big, big, MI355_DTYPE_F32, stream);
+        if (rc == 0) rc = comm_all_reduce(c, h_big, big, MI355_DTYPE_BF16, stream);
+        if (rc == 0) rc = comm_all_gather(c, g_send, g_recv, 256, MI355_DTYPE_F32, stream);
         const int erc = (int)hipStreamEndCapture(st, &g);         // always close the capture, also after a refused enqueue
         if (rc == 0) rc = erc;
     }

@@ -519,9 +519,11 @@ int mi355_comm_all_reduce_residual(void* comm, float* y, float* resid, int64_t c
 int mi355_comm_p2p_export(void* comm, void* handle_out64);
 int mi355_comm_p2p_attach(void* comm, const void* handles, int32_t rank, int32_t world);
 int mi355_comm_p2p_error(void* comm);
-/* 0 when the communicator's all-reduce can be captured in a hipGraph on this stack: captures one small all-reduce on
- * `stream`, instantiates and destroys the graph without launching it (nothing runs on the wire), so every rank can test
- * locally and the ranks agree on captured / eager steps before the first real step. */
+/* 0 when EVERY collective flavour of a TP step can be captured in a hipGraph on this stack: captures a small and a
+ * hidden-sized f32 all-reduce, a bf16 all-reduce and an all-gather on `stream`, instantiates and destroys the graph without
+ * launching it (nothing runs on the wire), so every rank can test locally and the ranks agree on captured / eager steps
+ * before the first real step.  A communicator that holds any host-supplied callback is refused (hipErrorNotSupported): a
+ * host call made during capture is not replayed. */
 int mi355_comm_capture_probe(void* comm, int64_t stream);
 int mi355_comm_all_gather(void* comm, const void* send, void* recv, int64_t count, int32_t dtype, int64_t stream);
 
@@ -627,6 +629,8 @@ int32_t mi355_be_swap_in_required_blocks(void* be, const int64_t* seq_ids, int32
 int32_t mi355_be_can_swap_in(void* be, const int64_t* seq_ids, int32_t n);
 int32_t mi355_be_swap_out(void* be, int64_t group_id, const int64_t* seq_ids, int32_t n, int64_t* pairs, int32_t cap);
 int32_t mi355_be_swap_in(void* be, int64_t group_id, const int64_t* seq_ids, int32_t n, int64_t* pairs, int32_t cap);
+/* test hook: the next n_out swap_out calls / n_in swap_in calls are refused (-4) before anything is touched */
+void mi355_be_test_refuse_swaps(void* be, int32_t n_out, int32_t n_in);
 void mi355_be_finalize_swap_out(void* be, int64_t group_id);
 void mi355_be_rollback_swap_out(void* be, int64_t group_id);
 void mi355_be_finalize_swap_in(void* be, int64_t group_id);

@@ -121,6 +121,82 @@ def test_preemption_swaps_when_the_prefix_cache_is_on(be):
     assert all(c >= 0 for c in s.block_engine.block_table(a))
 
 
+def _table(eng, seq):
+    try:
+        return eng.block_table(seq)
+    except KeyError:                                                       # no table: the sequence holds no blocks
+        return []
+
+
+def _two_groups_about_to_collide(be, n_seqs_of_victim=1):
+    """two running groups on a 4-block pool (prefix cache on => preemption by swap), each about to need a third block"""
+    s = _mk(be, num_gpu_blocks=4 if n_seqs_of_victim == 1 else 6, num_cpu_blocks=8, prefix_cache_enabled=True, max_cached_blocks=2)
+    eng = s.block_engine
+    victim = [eng.new_sequence(10 + i, list(range(50 * i, 50 * i + 7))) for i in range(n_seqs_of_victim)]
+    other = eng.new_sequence(2, list(range(100, 107)))
+    s.add_sequence(1, victim)
+    s.add_sequence(2, [other])
+    s.schedule()
+    for q in victim + [other]:
+        q.add_token(5)
+    return s, eng, victim, other
+
+
+def test_refused_swap_out_falls_back_to_recompute_for_a_single_sequence(be):
+    """`mi355_be_swap_out` refusing AFTER `can_swap_out` said yes (block_engine.cpp preempt(): k < 0): nothing was moved, so the
+    group must not be recorded as swapped out -- a single sequence is recomputed (mod.rs:700-723), exactly as if the swap had
+    been impossible."""
+    s, eng, (a,), b = _two_groups_about_to_collide(be)
+    eng.test_refuse_swaps(n_out=1)
+    out = s.schedule(now_ms=1000)
+    assert out.scheduled == [2]
+    assert out.swap_out_groups == [] and out.blocks_to_swap_out == {}      # no copy was requested
+    assert s.status(1) == be.Scheduler.WAITING and s.num_swapped() == 0 and s.num_waiting() == 1
+    assert s.take_pending_runner_releases() == [10]                        # recompute releases the runner state of the sequence
+    assert _table(eng, a) == []                                            # its blocks went back to the pool
+    assert eng.get_num_free_cpu_blocks() == 8                              # and the CPU pool was never touched
+    # the hook is spent: the next collision swaps for real
+    s.set_finished(2)
+    s.free_finished_sequence_groups()
+    out = s.schedule(now_ms=1400)
+    assert out.is_prompt and out.scheduled == [1]                          # the recomputed group is prefilled again
+
+
+def test_refused_swap_out_aborts_a_multi_sequence_group(be):
+    """a group of several sequences cannot be recomputed (mod.rs:706-716): a refused swap aborts it and frees its blocks"""
+    s, eng, victim, b = _two_groups_about_to_collide(be, n_seqs_of_victim=2)
+    free_before = eng.get_num_free_blocks()
+    eng.test_refuse_swaps(n_out=1)
+    out = s.schedule(now_ms=1000)
+    assert out.swap_out_groups == [] and s.num_swapped() == 0
+    assert s.status(1) != be.Scheduler.SWAPPED
+    if s.status(1) != be.Scheduler.RUNNING:                                # the victim was preempted: it must be gone, not half-swapped
+        assert s.status(1) == be.Scheduler.ABORTED
+        assert all(_table(eng, q) == [] for q in victim)
+        assert eng.get_num_free_blocks() >= free_before
+        assert eng.get_num_free_cpu_blocks() == 8
+
+
+def test_refused_swap_in_keeps_the_group_swapped_and_first_in_line(be):
+    """`mi355_be_swap_in` refusing (schedule(): k < 0): the group stays SWAPPED at the head of the queue with its CPU blocks, no
+    copy is requested, and it comes back on the next step"""
+    s, eng, (a,), b = _two_groups_about_to_collide(be)
+    out = s.schedule(now_ms=1000)
+    assert out.swap_out_groups == [1]
+    eng.finalize_swap_out(1)
+    cpu_table = eng.block_table(a)
+    s.set_finished(2)
+    s.free_finished_sequence_groups()
+    eng.test_refuse_swaps(n_in=1)
+    out = s.schedule(now_ms=2000)                                          # past the cooling period: would swap in, but is refused
+    assert out.swap_in_groups == [] and out.blocks_to_swap_in == {} and out.scheduled == []
+    assert s.status(1) == be.Scheduler.SWAPPED and s.num_swapped() == 1 and s.num_running() == 0
+    assert eng.block_table(a) == cpu_table                                 # untouched
+    out = s.schedule(now_ms=2400)
+    assert out.swap_in_groups == [1] and out.scheduled == [1]
+    assert all(c >= 0 for c in eng.block_table(a))
+
+
 def test_abort_frees_blocks(be):
     s = _mk(be)
     a = s.block_engine.new_sequence(1, list(range(9)))
