@@ -37,6 +37,7 @@ extern "C" int mi355_internal_gptq_small_linear(void* out, const void* x, const 
                                                 int32_t num_tokens, int32_t n, int32_t k, int32_t group_size, int32_t dtype,
                                                 int32_t epilogue, int64_t stream);
 
+extern "C" int mi355_pa_stream_auto(int32_t num_seqs, int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size);   // paged_attention.hip
 extern "C" int mi355_host_get_partition_override();   // host_model.cpp: mi355_set_tuning(5, partition_size), experiments
 
 namespace {
@@ -504,6 +505,7 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
         } else {
             int ps = choose_partition(T, Hkv, max_context_len);
             if (ps > 0 && c.kv_layout == MI355_KV_PAGED) ps = 32;   // MFMA kernel: 32-token partitions, 4 per workgroup (measured at batch 32: 32 -> 4937, 64 -> 4784, 128 -> ~4500 tok/s)
+            if (ps > 0 && c.kv_layout == MI355_KV_PAGED && dt == MI355_DTYPE_BF16 && mi355_pa_stream_auto(T, H, Hkv, D, c.block_size)) ps = 64;   // the balanced LDS-DMA stream, as the GGUF driver
             if (ps > 0 && c.kv_layout == MI355_KV_PAGED && mi355_host_get_partition_override() > 0) ps = mi355_host_get_partition_override();   // experiments: mi355_set_tuning(5, n), as the GGUF driver
             if (ps > 0 && (max_context_len + ps - 1) / ps > m->pa_cap_partitions) return (int)hipErrorInvalidValue;
             if (ps == 0)

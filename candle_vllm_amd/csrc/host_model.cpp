@@ -112,6 +112,7 @@ struct Model {
 // per-pair expert mat-vecs read an expert once per pair; grouped, every expert is read once per 32-row chunk of its `pairs` rows
 int g_moe_group = 1;            // tuning key 41: 0 = decode steps never group (A/B)
 inline bool moe_group_pays(int pairs, int n_expert) { return pairs > n_expert * ((pairs + 31) / 32); }
+extern "C" int mi355_pa_stream_auto(int32_t num_seqs, int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size);   // paged_attention.hip
 int g_host_ps_override = 0;     // experiments: mi355_set_tuning(5, partition_size)
 
 int local_heads(const Model* m) { return m->cfg.n_heads / (m->cfg.tp_world > 0 ? m->cfg.tp_world : 1); }
@@ -426,7 +427,9 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
     if (part == PART_ATTN) {
         // --- paged attention over the cache (the new token's K/V are already in place)
         int ps = choose_partition(B, Hkv, in.ctx_cap);
-        if (ps > 0 && c.kv_layout == MI355_KV_PAGED) ps = 32;   // MFMA kernel: 32-token partitions, 4 per workgroup (measured at batch 32: 32 -> 4937, 64 -> 4784, 128 -> ~4500 tok/s)   // MFMA kernel sizes
+        if (ps > 0 && c.kv_layout == MI355_KV_PAGED) ps = 32;   // MFMA kernel: 32-token partitions, 4 per workgroup (measured at batch 32: 32 -> 4937, 64 -> 4784, 128 -> ~4500 tok/s)
+        // >= 64 (sequence, kv head) pairs: 64-token stages through the balanced LDS-DMA stream (round 4: 5987 -> 6177 tok/s at batch 32)
+        if (ps > 0 && c.kv_layout == MI355_KV_PAGED && mi355_pa_stream_auto(B, H, Hkv, D, c.block_size)) ps = 64;
         if (g_host_ps_override > 0 && ps > 0) ps = g_host_ps_override;
         const float scale = 1.0f / sqrtf((float)D);
         if (ps > 0 && (in.ctx_cap + ps - 1) / ps > m->pa_cap_partitions) return (int)hipErrorInvalidValue;

@@ -1256,7 +1256,8 @@ __global__ void __launch_bounds__(256, 1) paged_attn_lds_kernel(const PAParams p
 }
 
 // ------------------------------------------------------------------------------------------------
-// EXPERIMENT (tuning key 44 = 3, partition size 64): the LDS-DMA stages of paged_attn_lds_kernel as ONE balanced stream per workgroup.
+// Partition size 64 at >= 64 (sequence, kv head) pairs (round 4 default; validated by the whole GPU suite): the LDS-DMA stages of
+// paged_attn_lds_kernel as ONE balanced stream per workgroup.
 // Ragged batches starve the chunked form (670 chunks of 1024 tokens on 256 CUs: 2.6 rounds, every chunk pays its ring fill).  Here the
 // (sequence, 64-token stage) pairs of a kv head form one flat index space of S stages; workgroup w of the W per kv head (W x Hkv = one
 // per CU) takes the stages [S w / W, S (w + 1) / W) -- equal shares whatever the context lengths -- and walks them through ONE ring:
@@ -1271,7 +1272,7 @@ __global__ void __launch_bounds__(256, 1) paged_attn_lds_kernel(const PAParams p
 //   * Q of the (up to 4) sequences of the share is staged in LDS before the first DMA goes out.
 __host__ __device__ inline int64_t pas_cut(int64_t S, int W, int w) { return S * w / W; }
 
-template <int R, bool FUSED = false>
+template <int R>
 __global__ void __launch_bounds__(256, 1) paged_attn_stream_kernel(const PAParams p, const int B, const uint32_t* __restrict__ btab,
                                                                     const uint32_t* __restrict__ clens) {
     // (btab / clens = p.block_tables / p.context_lens once more, as __restrict__ kernel arguments: only then does the compiler know that
@@ -1497,68 +1498,17 @@ __global__ void __launch_bounds__(256, 1) paged_attn_stream_kernel(const PAParam
                 if (head < G) {
                     const int64_t pi = ((int64_t)b * p.H + hk * G + head) * p.max_partitions + w;
                     const float inv = lh > 0.f ? 1.f / lh : 0.f;
-                    if constexpr (FUSED) {                            // write-through stores: the hand-off below needs no release fence
 #pragma unroll
-                        for (int n2 = 0; n2 < 2; ++n2)
-                            __hip_atomic_store(p.tmp_out + pi * D + 32 * wave + 16 * n2 + c, o[n2][v] * inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (wave == 0 && c == 0) {
-                            __hip_atomic_store(p.max_logits + pi, mh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(p.exp_sums + pi, lh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    } else {
-#pragma unroll
-                        for (int n2 = 0; n2 < 2; ++n2) p.tmp_out[pi * D + 32 * wave + 16 * n2 + c] = o[n2][v] * inv;
-                        if (wave == 0 && c == 0) { p.max_logits[pi] = mh; p.exp_sums[pi] = lh; }
-                    }
+                    for (int n2 = 0; n2 < 2; ++n2) p.tmp_out[pi * D + 32 * wave + 16 * n2 + c] = o[n2][v] * inv;
+                    if (wave == 0 && c == 0) { p.max_logits[pi] = mh; p.exp_sums[pi] = lh; }
                 }
             }
         }
     }
     f_lo = f_hi;
     }                                                                 // runs
-    if constexpr (FUSED) {
-        // ---- fused merge (tuning key 44 = 4): every workgroup that met sequence b takes a ticket for (b, kv head) after its partials
-        // have drained; the last one merges the slots of the workgroups that met b (the cuts are recomputed as in
-        // paged_attn_stream_reduce_kernel) -- no reduce launch.  Placement-independent hand-off as in paged_attn_mfma_kernel:
-        // write-through payload, drained, one relaxed ticket, ONE agent-scope acquire in the last arriver.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        unsigned* sm_t = reinterpret_cast<unsigned*>(pas_smem);       // the ring is free now
-        const int b_first = seq_of(f_lo0), b_last = seq_of(f_hi0 - 1);
-        for (int bq = b_first; bq <= b_last; ++bq) {
-            const int pe_b = __builtin_amdgcn_readlane(pend, bq), ps_b = pe_b - __builtin_amdgcn_readlane(n_l, bq);
-            if (pe_b == ps_b) continue;                               // a sequence without stages left no partial (uniform)
-            bool meets = false;
-            if (lane < W) {
-                const int lo = (int)pas_cut(S, W, lane), hi = (int)pas_cut(S, W, lane + 1);
-                meets = lo < hi && lo < pe_b && hi > ps_b;
-            }
-            const uint64_t mask = __ballot(meets);
-            const int expect = (int)__popcll(mask);
-            __syncthreads();                                          // sm_t of the previous sequence has been read by everyone
-            if (threadIdx.x == 0)
-                sm_t[0] = __hip_atomic_fetch_add(p.arrive + (int64_t)bq * p.Hkv + hk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            if ((int)sm_t[0] != expect - 1) continue;                 // uniform: not the last arriver for this sequence
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (threadIdx.x == 0) __hip_atomic_store(p.arrive + (int64_t)bq * p.Hkv + hk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // 256 threads: head g = idx / 128, channel d = idx % 128
-            for (int idx = (int)threadIdx.x; idx < G * D; idx += 256) {
-                const int g = idx >> 7, d = idx & 127;
-                const int64_t base = ((int64_t)bq * p.H + hk * G + g) * p.max_partitions;
-                float M = -1e30f;
-                for (uint64_t mm = mask; mm; mm &= mm - 1) M = fmaxf(M, p.max_logits[base + __ffsll((unsigned long long)mm) - 1]);
-                float den = 0.f, acc = 0.f;
-                for (uint64_t mm = mask; mm; mm &= mm - 1) {
-                    const int wq = __ffsll((unsigned long long)mm) - 1;
-                    const float wt = p.exp_sums[base + wq] * __expf(p.max_logits[base + wq] - M);
-                    den += wt;
-                    acc = fmaf(p.tmp_out[(base + wq) * D + d], wt, acc);
-                }
-                static_cast<uint16_t*>(p.out)[((int64_t)bq * p.H + hk * G + g) * D + d] = f32_to_bf16(den > 0.f ? acc / den : 0.f);
-            }
-        }
-    }
+    // (A last-arriver merge in this kernel instead of the reduce launch was measured in round 4 and lost: ragged batch 32 5800 tok/s against
+    //  6177 with the reduce launch, profiles/r04_b32_stream_ab.txt -- the merge walks up to W slots per head behind the slowest share.)
 }
 
 // merge of the stream kernel's partials: workgroup (h, b) recomputes the cuts, finds the workgroups whose share met sequence b and
@@ -1658,7 +1608,22 @@ static int launch_flash(const PAParams& p, int B, int P, hipStream_t st) {
 #define PA_ARRIVE_SLOTS 65536
 static int g_pa_fused = 1;                                          // mi355_set_tuning(3, 0) -> separate reduce launch
 static int g_pa_wpb = 0;                                            // mi355_set_tuning(8, 1 | 4): waves (partitions) per workgroup, 0 = auto
-static int g_pa_loop = 1;                                           // mi355_set_tuning(44, 0): partition sizes 256 / 512 go to the generic kernel again; 2: EXPERIMENT, 1024 / 2048 / 4096 take the LDS-DMA kernel; 3: EXPERIMENT, 64 takes the balanced LDS-DMA stream; 4: the same with the merge in the last arriver
+// mi355_set_tuning(44, v) -- which kernel serves a partition size on the PAGED bf16 layout:
+//   1 (default): 256 / 512 -> one wave walks its chunk (pa_mfma_chunk); 64 -> the balanced LDS-DMA stream when the launch has >= 64
+//                (sequence, kv head) pairs (measured on the MI355X: ragged batch 32 +3.2 %, batch 1 -13 %: profiles/r04_b32_stream_ab.txt)
+//   0: neither (256 / 512 go to the generic kernel, 64 to the one-partition waves);  5: chunks, never the stream (A/B)
+//   3: the stream for every launch with partition size 64 (tests: small shapes);  2: + 1024 / 2048 / 4096 take the chunked LDS-DMA kernel
+static int g_pa_loop = 1;
+#define PA_STREAM_MIN_PAIRS 64
+static bool pa_stream_shape_ok(int B, int H, int Hkv, int D, int block_size) {
+    return D == 128 && Hkv > 0 && H % Hkv == 0 && H / Hkv <= 16 && (block_size == 16 || block_size == 32 || block_size == 64) && B <= 64;
+}
+// what the step drivers ask: does a decode launch of this shape take the stream (-> they pass partition size 64)?
+extern "C" int mi355_pa_stream_auto(int32_t num_seqs, int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size) {
+    if (!(g_pa_loop == 1 || g_pa_loop == 2 || g_pa_loop == 3)) return 0;
+    if (!pa_stream_shape_ok(num_seqs, num_heads, num_kv_heads, head_dim, block_size)) return 0;
+    return (g_pa_loop == 3 || (int64_t)num_seqs * num_kv_heads >= PA_STREAM_MIN_PAIRS) ? 1 : 0;
+}
 
 static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t stream) {
     if (B <= 0) return 0;
@@ -1674,9 +1639,9 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
         else
             rc = (dtype == MI355_DTYPE_BF16) ? launch_flash<MI355_DTYPE_BF16, false>(p, B, P, st)
                                              : launch_flash<MI355_DTYPE_F16, false>(p, B, P, st);
-    } else if (layout == MI355_KV_PAGED && dtype == MI355_DTYPE_BF16 && p.D == 128 && !p.kv8 && (g_pa_loop == 3 || g_pa_loop == 4) && p.H / p.Hkv <= 16 &&
-               (p.block_size == 16 || p.block_size == 32 || p.block_size == 64) && p.partition_size == 64 && P > 1 && B <= 64) {
-        // EXPERIMENT (tuning key 44 = 3): one balanced stream of 64-token stages per workgroup, W workgroups per kv head (one per CU)
+    } else if (layout == MI355_KV_PAGED && dtype == MI355_DTYPE_BF16 && !p.kv8 && p.partition_size == 64 && P > 1 &&
+               mi355_pa_stream_auto(B, p.H, p.Hkv, p.D, p.block_size)) {
+        // one balanced stream of 64-token stages per workgroup, W workgroups per kv head (one per CU); partials merged by the reduce launch
         constexpr int PAS_R = 4;
         static bool attr_done = false;
         if (!attr_done) {
@@ -1687,20 +1652,6 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
         if (W < 1) W = 1;
         if (W > 64) W = 64;
         if (W > P) W = P;
-        if (g_pa_loop == 4 && (int64_t)B * p.Hkv <= PA_ARRIVE_SLOTS) {      // EXPERIMENT: the last arriver merges, no reduce launch (not run on hardware yet)
-            static bool attr4_done = false;
-            if (!attr4_done) {
-                (void)hipFuncSetAttribute((const void*)paged_attn_stream_kernel<PAS_R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PAS_R * 32768 + 16384);
-                attr4_done = true;
-            }
-            void* arr = nullptr;
-            const int arc = mi355_scratch_get(&arr, MI355_SCR_PA_ARRIVE, PA_ARRIVE_SLOTS * 4, st, true);
-            if (arc) return arc;
-            p.arrive = static_cast<unsigned*>(arr);
-            hipLaunchKernelGGL((paged_attn_stream_kernel<PAS_R, true>), dim3(W, p.Hkv), dim3(256), PAS_R * 32768 + 16384, st, p, B,
-                               p.block_tables, p.context_lens);
-            return (int)hipGetLastError();
-        }
         hipLaunchKernelGGL((paged_attn_stream_kernel<PAS_R>), dim3(W, p.Hkv), dim3(256), PAS_R * 32768 + 16384, st, p, B, p.block_tables,
                            p.context_lens);
         hipLaunchKernelGGL(paged_attn_stream_reduce_kernel, dim3(p.H, B), dim3(128), 0, st, p.out, p.tmp_out, p.max_logits, p.exp_sums,

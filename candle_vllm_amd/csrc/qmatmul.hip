@@ -1670,7 +1670,17 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
     const size_t kbb = qw1_kb_bytes(MT);
     int ks = 1;
     if (g_tune_ks_target > 0) { while (n_slots * ks < g_tune_ks_target && nkb / (ks * 2) >= g_tune_ks_minkb) ks *= 2; }
-    else { while ((n_slots + QMG_NC - 1) / QMG_NC * ks < -g_tune_ks_target && nkb / (ks * 2) >= g_tune_ks_minkb) ks *= 2; }
+    else {
+        // workgroup target: the smallest split (any integer, not only powers of two) that puts >= |target| workgroups on the chip while
+        // every split keeps >= minkb k-blocks; e.g. the 256-tile down projection: 37 workgroups x 7 splits of 8 k-blocks = 259
+        const int n_wg = (n_slots + QMG_NC - 1) / QMG_NC;
+        int want = (-g_tune_ks_target + n_wg - 1) / n_wg;
+        const int ks_max = nkb / g_tune_ks_minkb > 1 ? nkb / g_tune_ks_minkb : 1;
+        if (want > ks_max) want = ks_max;
+        if (want < 1) want = 1;
+        const int kb_per = (nkb + want - 1) / want;
+        ks = (nkb + kb_per - 1) / kb_per;                                 // no empty split
+    }
     QmgStream& qs = qmg_stream(st);
     const bool chained = qs.chain.valid && qs.chain.x == a.x && qs.chain.B == a.B && qs.chain.K == a.K &&
                          qs.chain.MT == MT && qs.chain.sp == 1 && qs.chain.norm_w == a.norm_w && qs.chain.st == st &&
@@ -1863,7 +1873,7 @@ int mi355_internal_gemm_rowmajor(void* out, int out_dtype, int ldo, const void* 
 #endif  // MI355_QMM_PROBES
 
 static int g_tune_qpg = 0;                                 // mi355_set_tuning(11, v): prompt-step GEMM variant (A/B runs)
-static int g_tune_qpg_fepi = 0;                            // mi355_set_tuning(48, 1): EXPERIMENT, prompt-step GEMM applies the epilogue itself (Q4_K launches; store / residual / SiLU * up)
+static int g_tune_qpg_fepi = 1;                            // mi355_set_tuning(48, 0): A/B, separate epilogue launch.  Default: the prompt-step GEMM applies the epilogue itself (Q4_K launches; store / residual / SiLU * up; round 4: +7 % on the prompt step)
 static int g_tune_qpg_min = 96;                            // mi355_set_tuning(12, n): fewest tokens that take the prompt-step GEMM (QMP_MIN_TOKENS)
 static int g_tune_dbg = 0;                                 // mi355_set_tuning(2, v): probe / ablation modes (experiments only)
 

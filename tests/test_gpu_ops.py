@@ -633,11 +633,10 @@ def test_paged_attention_looped_chunks_many_sequences(cv):
             assert np.abs(got - oracle).max() <= tol, (ps, np.abs(got - oracle).max())
 
 
-@pytest.mark.skipif(not os.environ.get("MI355_EXPERIMENTS"), reason="experiment kernels run on request (MI355_EXPERIMENTS=1)")
 @pytest.mark.parametrize("bs,ctx", [(64, [4100, 37, 520, 1024, 1025, 2048]), (16, [1000, 259, 15]), (32, [777, 2049])])
-def test_paged_attention_lds_dma_experiment(cv, bs, ctx):
+def test_paged_attention_lds_dma_chunks(cv, bs, ctx):
     """tuning key 44 = 2: partition sizes 1024 / 2048 through the LDS ring filled by DMA (paged_attn_lds_kernel) -- same bound as the
-    product kernels.  Not part of the default run: the kernel is an experiment of round 3."""
+    product kernels.  An option for callers with uniform long contexts (5.7 TB/s there); the step drivers use the balanced stream."""
     from candle_vllm_amd import tuning
     rng = np.random.default_rng(45)
     H, Hkv, D = 32, 8, 128
@@ -658,12 +657,12 @@ def test_paged_attention_lds_dma_experiment(cv, bs, ctx):
                 assert np.abs(got - oracle).max() <= tol, (ps, np.abs(got - oracle).max())
 
 
-@pytest.mark.skipif(not os.environ.get("MI355_EXPERIMENTS"), reason="experiment kernels run on request (MI355_EXPERIMENTS=1)")
 @pytest.mark.parametrize("bs,ctx", [(64, [4100, 37, 520, 1024, 1025, 2048, 64, 65, 1]), (16, [1000, 259, 15]), (32, [777, 2049]),
                                     (64, list(range(1, 41))), (16, [700] * 33 + [3, 64, 129])])
-def test_paged_attention_lds_dma_stream_experiment(cv, bs, ctx):
-    """tuning key 44 = 3: partition size 64 as one balanced stream of 64-token stages per workgroup (paged_attn_stream_kernel +
-    paged_attn_stream_reduce_kernel): shares that cut sequences anywhere, many short sequences per share, <= 64 sequences"""
+def test_paged_attention_lds_dma_stream(cv, bs, ctx):
+    """partition size 64 as one balanced stream of 64-token stages per workgroup (paged_attn_stream_kernel +
+    paged_attn_stream_reduce_kernel; the step drivers' choice at >= 64 (sequence, kv head) pairs since round 4, tuning key 44 = 3 forces
+    it for the small cases here): shares that cut sequences anywhere, many short sequences per share, <= 64 sequences"""
     from candle_vllm_amd import tuning
     rng = np.random.default_rng(46)
     H, Hkv, D = 32, 8, 128
@@ -674,7 +673,7 @@ def test_paged_attention_lds_dma_stream_experiment(cv, bs, ctx):
     qd, kcd, vcd = dev(q, torch.bfloat16), bf16_dev(kc), bf16_dev(vc)
     oracle = O.paged_attention_decode(q, kc, vc, bt, cl, 1 / np.sqrt(D), False)
     tol = 2 ** -7 * np.abs(oracle).max() + 1e-6
-    for key in (3, 4):                                                # 4: the merge in the last arriver instead of the reduce launch
+    for key in (3, 1):                                                # 1 = the default: the stream only at >= 64 (sequence, kv head) pairs
         with tuning(44, key):
             for _ in range(3):                                        # (the arrival counters must come back to zero)
                 got = pa.decode(qd, kcd, vcd, meta, None, partition_size=64).float().cpu().numpy()
@@ -682,11 +681,11 @@ def test_paged_attention_lds_dma_stream_experiment(cv, bs, ctx):
                 assert np.abs(got - oracle).max() <= tol, (key, np.abs(got - oracle).max())
 
 
-@pytest.mark.skipif(not os.environ.get("MI355_EXPERIMENTS"), reason="experiment kernels run on request (MI355_EXPERIMENTS=1)")
 @pytest.mark.parametrize("T,N,K", [(128, 96, 1024), (200, 40, 512), (300, 640, 2048), (97, 16, 256)])
-def test_prompt_gemm_fused_epilogue_experiment(cv, T, N, K):
-    """tuning key 48 = 1: Q4_K prompt-step launches apply store / bias / residual / SiLU * up in the GEMM's own store loop (no C buffer,
-    no epilogue launch) -- against the oracle at the prompt path's bound and against the unfused path (same arithmetic: 1e-6)"""
+def test_prompt_gemm_fused_epilogue(cv, T, N, K):
+    """the default since round 4: Q4_K prompt-step launches apply store / bias / residual / SiLU * up in the GEMM's own store loop (no C
+    buffer, no epilogue launch) -- against the oracle at the prompt path's bound and against the unfused path (tuning key 48 = 0; same
+    arithmetic: 1e-6)"""
     from candle_vllm_amd import tuning
     rng = np.random.default_rng(48 + T + N)
     t = kq.GGML_Q4_K
@@ -713,9 +712,9 @@ def test_prompt_gemm_fused_epilogue_experiment(cv, T, N, K):
         out["silu"] = h.cpu().numpy()
         return out
 
-    base = all_modes()
-    with tuning(48, 1):
-        got = all_modes()
+    with tuning(48, 0):
+        base = all_modes()
+    got = all_modes()
     want = {"store": rg, "bias": rg + bias, "resid": resid + rg, "silu": rgn / (1 + np.exp(-rgn)) * run_}
     for k in want:
         assert np.isfinite(got[k]).all()
