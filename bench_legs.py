@@ -5,8 +5,8 @@ driver's multi-GPU run), each with algorithmic bytes, achieved GB/s, roofline fr
   gptq_qwen2   configs[3]  Qwen2-7B GPTQ 4-bit g128 (marlin_4bit arm), batch 1, ctx 4096               (qwen.rs:78-96)
   mixtral_fp8  configs[4]  Mixtral-8x7B Q4_K GGUF, 8 experts top-2, fp8 KV cache, batch 1, ctx 4096    (quantized_llama.rs:56-123)
 Synthetic weights of the named architectures (no network for checkpoints).  A "step" = one greedy decode step of the whole
-model over the batch; inputs advance on the device (torch ops inside the captured graph for the 16-bit host layer, the
-library's own advance kernel for the GGUF one); every step reads its sampled tokens back, as the engine does."""
+model over the batch through the library's own step drivers (mi355_llama_decode_* / mi355_dense_decode_*: forward, argmax and
+the device-side input advance in one captured hipGraph); every step reads its sampled tokens back, as the engine does."""
 import os
 import time
 from types import SimpleNamespace
@@ -45,8 +45,9 @@ def _result(name, workload, B, steps, dt, weight_bytes, kv_bytes, extra=None):
 
 
 def _dense_graph_loop(gm, cfg, B, ctxs, steps, warmup, kv_elem):
-    """greedy decode loop of the 16-bit host layer replayed from ONE captured graph per step: the C++ layer's launches and the
-    next-step input preparation (prepare_decode, inputs.rs:389-423, as torch ops on the device)"""
+    """greedy decode loop of the 16-bit host layer through the library's own step driver (mi355_dense_decode_begin / _step /
+    _read_tokens: forward, argmax and the next-step inputs are ONE captured hipGraph, no torch op inside the step -- graph.rs:471-661,
+    inputs.rs:389-423); every step reads its sampled tokens back, as the engine does"""
     import torch
     bs = cfg.block_size
     cap = int(max(ctxs)) + steps + warmup + 2
@@ -54,44 +55,26 @@ def _dense_graph_loop(gm, cfg, B, ctxs, steps, warmup, kv_elem):
     maxb = max(nblk)
     rng = np.random.default_rng(0)
     ids = rng.permutation(sum(nblk))
-    bt_h = np.zeros((B, maxb), np.int32)
+    bt_h = np.zeros((B, maxb), np.uint32)
     o = 0
     for i, n in enumerate(nblk):
         bt_h[i, :n] = ids[o:o + n]
         o += n
-    dev = "cuda"
-    bt = torch.from_numpy(bt_h).to(dev)
-    tok = torch.randint(0, cfg.vocab, (B,), dtype=torch.int32, device=dev)
-    lens = torch.tensor(np.asarray(ctxs, np.int64), device=dev)
-    pos = lens - 1
-    slots = bt.long().gather(1, (pos // bs)[:, None])[:, 0] * bs + pos % bs
-    ctx = lens.to(torch.int32)
-    logits = torch.empty((B, cfg.vocab), dtype=torch.float32, device=dev)
-    host_tok = torch.empty((B,), dtype=torch.int32).pin_memory()
+    tok = rng.integers(0, cfg.vocab, B).astype(np.uint32)
     stream = torch.cuda.Stream()
-
-    def body(st):
-        gm.forward_device(tok, pos, slots, bt, ctx, cap, logits, st)
-        tok.copy_(logits.argmax(-1).to(torch.int32))
-        pos.add_(1)
-        ctx.add_(1)
-        slots.copy_(bt.long().gather(1, (pos // bs)[:, None])[:, 0] * bs + pos % bs)
-    with torch.cuda.stream(stream):
-        body(stream.cuda_stream)                                      # eager once: lazily-created scratch must not be born in a capture
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=stream):
-            body(torch.cuda.current_stream().cuda_stream)
-        for _ in range(warmup):
-            g.replay()
-            host_tok.copy_(tok, non_blocking=False)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            g.replay()
-            host_tok.copy_(tok, non_blocking=False)                   # sampled tokens -> host every step
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+    st = stream.cuda_stream
+    gm.set_graph(True)
+    gm.decode_begin(tok, np.asarray(ctxs, np.uint32), bt_h, ctx_cap=cap, stream=st)
+    for _ in range(warmup):                                           # the first is eager, the second captures, the rest replay
+        gm.decode_step(st)
+        gm.read_tokens(st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gm.decode_step(st)
+        gm.read_tokens(st)                                            # sampled tokens -> host every step
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
     mean_ctx = float(np.mean(ctxs)) + 1 + warmup + (steps - 1) / 2.0
     kv = B * (mean_ctx + 1) * 2 * cfg.n_layers * cfg.n_kv_heads * cfg.head_dim * kv_elem
     return dt, kv

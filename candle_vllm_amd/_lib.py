@@ -192,6 +192,7 @@ for _n in ("mi355_be_finalize_swap_out", "mi355_be_rollback_swap_out", "mi355_be
            "mi355_be_rollback_swap_in"):
     _sig(_n, None, [c_vp, c_i64])
 _sig("mi355_be_test_refuse_swaps", None, [c_vp, c_i32, c_i32])
+_sig("mi355_internal_qw1_wgs_touching", c_i32, [c_i32, c_vp, c_vp, c_i32])
 _sig("mi355_pc_create", c_vp, [c_i32] * 4)
 _sig("mi355_pc_insert", c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32])
 _sig("mi355_pc_match", c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32])
@@ -261,6 +262,12 @@ _sig("mi355_dense_alloc_kv_cache", ctypes.c_int, [c_vp, c_i32])
 _sig("mi355_dense_kv_ptr", c_vp, [c_vp, c_i32, c_i32])
 _sig("mi355_dense_set_layer_window", ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp])
 _sig("mi355_dense_forward", ctypes.c_int, [c_vp] * 7 + [c_i32] * 5 + [c_vp, c_i64])
+_sig("mi355_dense_finalize", ctypes.c_int, [c_vp])
+_sig("mi355_dense_set_graph", ctypes.c_int, [c_vp, c_i32])
+_sig("mi355_dense_decode_begin", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
+_sig("mi355_dense_decode_step", ctypes.c_int, [c_vp, c_i64])
+_sig("mi355_dense_decode_read_tokens", ctypes.c_int, [c_vp, c_vp, c_i64])
+_sig("mi355_dense_logits_ptr", c_vp, [c_vp])
 
 # ---- GGUF reader (section 7)
 _sig("mi355_gguf_open", c_vp, [ctypes.c_char_p])

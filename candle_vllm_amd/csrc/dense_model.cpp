@@ -4,17 +4,25 @@
 // the model dtype exactly where candle rounds (the residual stream is 16-bit here, unlike the GGUF path).
 // Kernels: dense_gemv.hip (linears + fused residual / silu*up), elementwise.hip (rms_norm, rope on 16-bit data
 // = upcast-rotate-downcast), cache_kernels.hip (reshape_and_cache), paged_attention.hip / prefill_attention.hip.
-// Eager only (no graph capture, no tensor parallelism on this path yet).
+// Step driver (round 4): `mi355_dense_decode_begin / _step / _read_tokens` -- the greedy loop on static device buffers with the
+// device-side input advance and argmax of the GGUF layer, one hipGraph per (batch, table width, ctx bucket): what
+// src/backend/graph.rs:471-661,685-807 + pipelines/pipeline.rs:2091-2135 do for every model family.  Tensor parallel through
+// mi355_dense_set_comm (captured when the communicator is device-native).
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <algorithm>
+#include <array>
+#include <map>
+#include <set>
 #include <unordered_set>
 #include <vector>
 
 #include "../../include/mi355_vllm.h"
 #include "common.h"
+#include "comm.h"
+#include "step_inputs.h"
 
 extern "C" int mi355_internal_rope_cache(void* q, void* k, const void* v, void* key_cache, void* value_cache, const float* cos_t,
                                          const float* sin_t, const int64_t* positions, const int64_t* slot_mapping,
@@ -78,11 +86,31 @@ struct DModel {
     int num_blocks = 0;
     void* comm = nullptr;                 // borrowed communicator (tp_world > 1, or a 1-rank plumbing test)
     uint16_t* lg_gather = nullptr;        // [W, B, V/W]
+    // greedy decode loop on static device buffers (mi355_dense_decode_*): step inputs, sampled tokens, f32 logits
+    uint32_t *d_tokens = nullptr, *d_ctx = nullptr, *d_bt = nullptr, *d_next = nullptr;
+    int64_t *d_positions = nullptr, *d_slots = nullptr;
+    float* d_logits = nullptr;
+    int cur_batch = 0, cur_max_blocks = 0, cur_ctx_cap = 0, cur_ctx_max = 0;
+    // one hipGraph of the greedy step per (batch, table width, ctx bucket), as the GGUF layer keeps them (graph.rs:471-661)
+    struct StepGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; uint64_t used = 0; };
+    std::map<std::array<int, 3>, StepGraph> graphs;
+    std::set<std::array<int, 3>> warmed;                  // shapes whose first (EAGER) step ran
+    uint64_t graph_clock = 0;
+    bool use_graph = true;
     // test hook (mi355_dense_set_layer_window): run layers [win_first, win_last] only, from a supplied residual stream
     int win_first = -1, win_last = -1;
     const void* win_in = nullptr;
     void* win_out = nullptr;
 };
+
+// captured steps hold raw pointers: whatever re-allocates a buffer a step touches drops them first
+void dense_drop_graph(DModel* m) {
+    for (auto& kv : m->graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    m->graphs.clear();
+}
 
 // [W, B, Vl] -> [B, W*Vl]   (VocabParallelLinear: all-gather then un-interleave, distributed.rs:1637-1663)
 __global__ void gather_transpose16_kernel(uint16_t* out, const uint16_t* in, int W, int B, int Vl) {
@@ -116,6 +144,7 @@ __global__ void select_last_rows16_kernel(uint16_t* dst, const uint16_t* src, co
 int ensure_cap(DModel* m, int T) {
     if (T <= m->cap) return 0;
     DHIP(hipDeviceSynchronize());
+    dense_drop_graph(m);
     void* old[] = {m->xs, m->xn, m->q, m->k, m->v, m->attn, m->h, m->lg16};
     for (void* p : old) if (p) (void)hipFree(p);
     m->xs = m->xn = m->q = m->k = m->v = m->attn = m->h = m->lg16 = nullptr;
@@ -250,8 +279,13 @@ void mi355_dense_destroy(void* mp) {
         for (void* p : ps) if (p) (void)hipFree(p);
         for (auto& g : L.gq) { if (g.qw) (void)hipFree(g.qw); if (g.scales) (void)hipFree(g.scales); }
     }
+    for (auto& kv : m->graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
     void* ps[] = {m->tok_embd, m->output_norm, m->output_norm_b, m->output, m->cos_t, m->sin_t, m->xs, m->xn, m->q, m->k, m->v, m->attn,
-                  m->h, m->lg16, m->pa_tmp, m->pa_max, m->pa_sum, m->ss, m->kv_slab, m->lg_gather};
+                  m->h, m->lg16, m->pa_tmp, m->pa_max, m->pa_sum, m->ss, m->kv_slab, m->lg_gather, m->d_tokens, m->d_ctx, m->d_bt,
+                  m->d_next, m->d_positions, m->d_slots, m->d_logits};
     for (void* p : ps) if (p) (void)hipFree(p);
     delete m;
 }
@@ -302,7 +336,7 @@ static int dense_set_weight_impl(void* mp, int32_t layer, int32_t which, const v
         }
     }
     if (n_elems != expect) return (int)hipErrorInvalidValue;
-    if (*slot && m->tiled.count(*slot)) return (int)hipErrorInvalidValue;      // re-ordered at the first step: weights are frozen
+    if (m->finalized) return (int)hipErrorInvalidValue;      // mi355_dense_finalize / the first step froze the weights: every slot alike
     if (total == 0) total = expect;
     if (!*slot) DHIP(hipMalloc((void**)slot, (size_t)total * 2));
     DHIP(hipMemcpy(*slot + offset, host, (size_t)n_elems * 2, kind));
@@ -315,7 +349,7 @@ static int dense_set_weight_impl(void* mp, int32_t layer, int32_t which, const v
 int mi355_dense_set_gptq(void* mp, int32_t layer, int32_t which, const void* qweight_host, const void* scales_host,
                          int32_t n, int32_t k, int32_t group_size) {
     DModel* m = static_cast<DModel*>(mp);
-    if (!m || layer < 0 || layer >= m->cfg.n_layers || !qweight_host || !scales_host) return (int)hipErrorInvalidValue;
+    if (!m || layer < 0 || layer >= m->cfg.n_layers || !qweight_host || !scales_host || m->finalized) return (int)hipErrorInvalidValue;
     if (which < MI355_W_WQ || which > MI355_W_W3 || (k % 256) || (n % 16)) return (int)hipErrorInvalidValue;
     const int g = (group_size <= 0 || group_size > k) ? k : group_size;
     const int I = m->cfg.intermediate;
@@ -345,6 +379,7 @@ int mi355_dense_set_rope_tables(void* mp, const float* cos_host, const float* si
     if (!m || !cos_host || !sin_host || n_positions < m->cfg.max_seq) return (int)hipErrorInvalidValue;
     const size_t bytes = (size_t)n_positions * (m->cfg.rotary_dim / 2) * 4;
     float *c = nullptr, *s = nullptr;
+    dense_drop_graph(m);
     DHIP(hipMalloc((void**)&c, bytes));
     DHIP(hipMalloc((void**)&s, bytes));
     DHIP(hipMemcpy(c, cos_host, bytes, hipMemcpyHostToDevice));
@@ -358,6 +393,7 @@ int mi355_dense_set_rope_tables(void* mp, const float* cos_host, const float* si
 int mi355_dense_set_comm(void* mp, void* comm) {
     DModel* m = static_cast<DModel*>(mp);
     if (!m) return (int)hipErrorInvalidValue;
+    dense_drop_graph(m);
     m->comm = comm;
     return 0;
 }
@@ -367,6 +403,7 @@ int mi355_dense_alloc_kv_cache(void* mp, int32_t num_blocks) {
     if (!m || num_blocks <= 0) return (int)hipErrorInvalidValue;
     const mi355_dense_config& c = m->cfg;
     const size_t per = (size_t)num_blocks * c.block_size * c.n_kv_heads * c.head_dim * (c.kv_fp8 ? 1 : 2);
+    dense_drop_graph(m);
     if (m->kv_slab) { (void)hipFree(m->kv_slab); m->kv_slab = nullptr; }
     DHIP(hipMalloc(&m->kv_slab, per * 2 * c.n_layers));
     DHIP(hipMemset(m->kv_slab, 0, per * 2 * c.n_layers));
@@ -408,9 +445,15 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
     if ((int)m->kcache.size() != c.n_layers || !m->tok_embd || !m->output || !m->output_norm) return (int)hipErrorInvalidValue;
     const bool prefill = cu_seqlens_q != nullptr;
     if (!prefill && num_tokens != num_seqs) return (int)hipErrorInvalidValue;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (num_tokens > m->cap || !m->finalized) {
+        // growing the workspace and the one-off weight repack allocate, synchronise and free: never inside a stream capture
+        // (loaders call mi355_dense_finalize, the step driver finalizes in decode_begin)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream != 0 && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return (int)hipErrorStreamCaptureUnsupported;
+    }
     DCHECK(ensure_cap(m, num_tokens));
     DCHECK(finalize_weights(m));
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int T = num_tokens, H = c.n_heads, Hkv = c.n_kv_heads, D = c.head_dim, hid = c.hidden, I = c.intermediate;
     const int dt = c.dtype;
     const float scale = 1.0f / sqrtf((float)D);
@@ -570,5 +613,131 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
     DCHECK(linear(m, m->output, QLin{}, m->lg16, m->xn, nullptr, nullptr, num_seqs, c.vocab, hid, MI355_EPI_STORE, stream));
     return mi355_cast(logits, m->lg16, (int64_t)num_seqs * c.vocab, dt, MI355_DTYPE_F32, stream);
 }
+
+/* Freeze the weights: the one-off re-ordering of the 16-bit projections into tiles (mi355_dense_tile_repack) that the first forward
+ * would otherwise do.  Loaders call it once after the last set_weight; afterwards set_weight refuses EVERY projection slot. */
+int mi355_dense_finalize(void* mp) {
+    DModel* m = static_cast<DModel*>(mp);
+    if (!m) return (int)hipErrorInvalidValue;
+    return finalize_weights(m);
+}
+
+/* ---- greedy decode loop on static device buffers (graph replay): the GGUF layer's mi355_llama_decode_* for this host layer ---- */
+int mi355_dense_set_graph(void* mp, int32_t enable) {
+    DModel* m = static_cast<DModel*>(mp);
+    if (!m) return (int)hipErrorInvalidValue;
+    m->use_graph = enable != 0;
+    if (!m->use_graph) dense_drop_graph(m);
+    return 0;
+}
+int mi355_dense_decode_begin(void* mp, const uint32_t* tokens_host, const uint32_t* seq_lens_host, const uint32_t* block_tables_host,
+                             int32_t batch, int32_t max_blocks, int32_t ctx_cap, int64_t stream) {
+    DModel* m = static_cast<DModel*>(mp);
+    if (!m || !tokens_host || !seq_lens_host || !block_tables_host || batch < 1 || batch > m->cfg.max_batch || max_blocks < 1 ||
+        m->cfg.max_blocks_per_seq < 1 || max_blocks > m->cfg.max_blocks_per_seq)
+        return (int)hipErrorInvalidValue;
+    const mi355_dense_config& c = m->cfg;
+    const int bs = c.block_size, W = c.tp_world > 1 ? c.tp_world : 1;
+    std::vector<int64_t> pos(batch), slot(batch);
+    int ctx_max = 0;
+    for (int b = 0; b < batch; ++b) {
+        if (seq_lens_host[b] < 1) return (int)hipErrorInvalidValue;
+        pos[b] = (int64_t)seq_lens_host[b] - 1;
+        if (pos[b] / bs >= max_blocks) return (int)hipErrorInvalidValue;          // "Block table is too small"
+        slot[b] = (int64_t)block_tables_host[(size_t)b * max_blocks + pos[b] / bs] * bs + pos[b] % bs;
+        ctx_max = std::max(ctx_max, (int)seq_lens_host[b]);
+    }
+    if (ctx_cap < ctx_max || ctx_cap > c.max_seq || ctx_max > max_blocks * bs) return (int)hipErrorInvalidValue;
+    if (!m->d_tokens) {
+        const size_t B = c.max_batch;
+        DHIP(hipMalloc((void**)&m->d_tokens, B * 4)); DHIP(hipMalloc((void**)&m->d_ctx, B * 4)); DHIP(hipMalloc((void**)&m->d_next, B * 4));
+        DHIP(hipMalloc((void**)&m->d_bt, B * c.max_blocks_per_seq * 4));
+        DHIP(hipMalloc((void**)&m->d_positions, B * 8)); DHIP(hipMalloc((void**)&m->d_slots, B * 8));
+        DHIP(hipMalloc((void**)&m->d_logits, B * (size_t)c.vocab * W * 4));
+    }
+    DCHECK(ensure_cap(m, batch));                          // everything that allocates happens here, never inside a captured step
+    DCHECK(finalize_weights(m));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    DHIP(hipMemcpyAsync(m->d_tokens, tokens_host, (size_t)batch * 4, hipMemcpyHostToDevice, st));
+    DHIP(hipMemcpyAsync(m->d_ctx, seq_lens_host, (size_t)batch * 4, hipMemcpyHostToDevice, st));
+    DHIP(hipMemcpyAsync(m->d_bt, block_tables_host, (size_t)batch * max_blocks * 4, hipMemcpyHostToDevice, st));
+    DHIP(hipMemcpyAsync(m->d_positions, pos.data(), (size_t)batch * 8, hipMemcpyHostToDevice, st));
+    DHIP(hipMemcpyAsync(m->d_slots, slot.data(), (size_t)batch * 8, hipMemcpyHostToDevice, st));
+    DHIP(hipStreamSynchronize(st));                        // host vectors go out of scope
+    m->cur_batch = batch; m->cur_max_blocks = max_blocks; m->cur_ctx_cap = ctx_cap; m->cur_ctx_max = ctx_max;
+    return 0;
+}
+static int dense_record_step(DModel* m, int64_t stream) {
+    const int B = m->cur_batch, W = m->cfg.tp_world > 1 ? m->cfg.tp_world : 1;
+    DCHECK(mi355_dense_forward(m, m->d_tokens, m->d_positions, m->d_slots, m->d_bt, m->d_ctx, nullptr, B, B, 0, m->cur_max_blocks,
+                               m->cur_ctx_cap, m->d_logits, stream));
+    // greedy sample (`sample_argmax`, logits_processor.rs:92-95: first maximum), then the next step's inputs on the device
+    DCHECK(mi355_argmax_f32(m->d_next, m->d_logits, B, m->cfg.vocab * W, stream));
+    hipLaunchKernelGGL(advance_kernel, dim3((B + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), m->d_tokens, m->d_next,
+                       m->d_positions, m->d_slots, m->d_ctx, m->d_bt, m->cur_max_blocks, m->cfg.block_size, B);
+    return (int)hipGetLastError();
+}
+/* One greedy step: forward -> argmax -> next-step inputs; captured once per (batch, max_blocks, ctx_cap) and replayed. */
+int mi355_dense_decode_step(void* mp, int64_t stream) {
+    DModel* m = static_cast<DModel*>(mp);
+    if (!m || m->cur_batch < 1) return (int)hipErrorInvalidValue;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // this step attends over cur_ctx_max tokens, then advance_kernel looks up the slot of position cur_ctx_max: both must stay
+    // inside the attention grid (ctx_cap), the block-table row and the RoPE tables
+    if (m->cur_ctx_max > m->cur_ctx_cap || m->cur_ctx_max > m->cfg.max_seq ||
+        (m->cur_ctx_max + m->cfg.block_size - 1) / m->cfg.block_size > m->cur_max_blocks)
+        return (int)hipErrorInvalidValue;
+    struct Bump { DModel* m; ~Bump() { ++m->cur_ctx_max; } } bump{m};
+    // host-supplied collectives are host calls: such TP steps stay eager (a host call made during capture is not replayed)
+    const Comm* cm = static_cast<const Comm*>(m->comm);
+    const bool tp_eager = cm && (cm->ar || cm->ag || !cm->nccl);
+    if (!m->use_graph || stream == 0 || tp_eager) return dense_record_step(m, stream);
+    const std::array<int, 3> shape{m->cur_batch, m->cur_max_blocks, m->cur_ctx_cap};
+    if (!m->warmed.count(shape)) {
+        // the first step of a new shape runs eagerly: lazily-set kernel attributes and scratch growth must not happen inside a capture
+        m->warmed.insert(shape);
+        return dense_record_step(m, stream);
+    }
+    auto it = m->graphs.find(shape);
+    if (it == m->graphs.end()) {
+        if (m->graphs.size() >= 96) {                                 // evict the least recently replayed shape
+            auto lru = m->graphs.begin();
+            for (auto q = m->graphs.begin(); q != m->graphs.end(); ++q) if (q->second.used < lru->second.used) lru = q;
+            if (lru->second.exec) (void)hipGraphExecDestroy(lru->second.exec);
+            if (lru->second.graph) (void)hipGraphDestroy(lru->second.graph);
+            m->graphs.erase(lru);
+        }
+        DHIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        const int rc = dense_record_step(m, stream);
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(st, &g);
+        if (rc != 0) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) return (int)e;
+        DModel::StepGraph sg;
+        sg.graph = g;
+        const hipError_t ie = hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0);
+        if (ie != hipSuccess) { (void)hipGraphDestroy(g); return (int)ie; }
+        it = m->graphs.emplace(shape, sg).first;
+    }
+    it->second.used = ++m->graph_clock;
+    DHIP(hipGraphLaunch(it->second.exec, st));
+    return 0;
+}
+/* D2H of the tokens the last step sampled (= the inputs of the next step); synchronises the stream */
+int mi355_dense_decode_read_tokens(void* mp, uint32_t* host_out, int64_t stream) {
+    DModel* m = static_cast<DModel*>(mp);
+    if (!m || !host_out || m->cur_batch < 1) return (int)hipErrorInvalidValue;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    DHIP(hipMemcpyAsync(host_out, m->d_tokens, (size_t)m->cur_batch * 4, hipMemcpyDeviceToHost, st));
+    uint32_t p2p_err = 0;
+    const Comm* cm = static_cast<const Comm*>(m->comm);
+    const bool p2p = cm && cm->p2p && cm->local;
+    if (p2p) DHIP(hipMemcpyAsync(&p2p_err, &cm->local->err, 4, hipMemcpyDeviceToHost, st));
+    DHIP(hipStreamSynchronize(st));
+    if (p2p && p2p_err != 0) return (int)hipErrorPeerAccessNotEnabled;     // a peer missed the spin bound: the step is invalid on this rank
+    return 0;
+}
+/* f32 [batch, vocab (x tp_world)] logits of the last step of the loop (device pointer) */
+float* mi355_dense_logits_ptr(void* mp) { DModel* m = static_cast<DModel*>(mp); return m ? m->d_logits : nullptr; }
 
 }  // extern "C"

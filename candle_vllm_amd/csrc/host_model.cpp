@@ -17,11 +17,15 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <array>
+#include <map>
+#include <set>
 #include <string>
 #include <vector>
 
 #include "../../include/mi355_vllm.h"
 #include "comm.h"
+#include "step_inputs.h"
 
 #define HCHECK(expr)                                   \
     do {                                               \
@@ -80,11 +84,12 @@ struct Model {
     uint32_t* d_bt = nullptr;
     int cur_batch = 0, cur_max_blocks = 0, cur_ctx_cap = 0;
     int cur_ctx_max = 0;            // host mirror of max(d_ctx): the device-side loop must stay inside ctx_cap / the block table / max_seq
-    // hipGraph
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t gexec = nullptr;
-    int g_batch = 0, g_max_blocks = 0, g_ctx_cap = 0;
-    int w_batch = 0, w_max_blocks = 0, w_ctx_cap = 0;     // shape of the last EAGER step (kernel attrs warmed)
+    // hipGraphs of the greedy step, one per (batch, table width, ctx bucket) -- graph.rs:471-661 keeps one per batch size; a batch
+    // that shrinks and grows as requests finish and arrive (continuous batching) finds its graph again instead of re-capturing
+    struct StepGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; uint64_t used = 0; };
+    std::map<std::array<int, 3>, StepGraph> graphs;
+    std::set<std::array<int, 3>> warmed;                  // shapes whose first (EAGER) step ran: kernel attributes / scratch exist
+    uint64_t graph_clock = 0;
     bool use_graph = true;
     bool graph_tp = false;          // set_graph(2): capture tensor-parallel steps too (RCCL calls inside the graph; opt-in)
     // tensor parallel
@@ -120,24 +125,6 @@ int local_kv_heads(const Model* m) {
     const int w = m->cfg.tp_world > 0 ? m->cfg.tp_world : 1;
     const int l = m->cfg.n_kv_heads / w;
     return l > 0 ? l : 1;   // kv_head_shard: replicated when Hkv < W (distributed.rs:725-765)
-}
-
-// positions / slots for the NEXT step from the block table: prepare_decode restated on the device so that a
-// captured graph can run step after step without host input (inputs.rs:389-423).
-__global__ void advance_kernel(uint32_t* tokens, const uint32_t* next_tokens, int64_t* positions, int64_t* slots,
-                               uint32_t* ctx, const uint32_t* bt, int max_blocks, int block_size, int batch) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= batch) return;
-    tokens[b] = next_tokens[b];
-    const uint32_t n = ctx[b] + 1;              // sequence length after appending the sampled token
-    ctx[b] = n;
-    const int64_t pos = (int64_t)n - 1;
-    positions[b] = pos;
-    // the step after the last reserved block has no slot (-1 = "do not write", as a padded slot): the host refuses to
-    // run that step, and this kernel never reads past the block-table row
-    if (pos / block_size >= max_blocks) { slots[b] = -1; return; }
-    const int64_t blk = bt[(size_t)b * max_blocks + pos / block_size];
-    slots[b] = blk * block_size + pos % block_size;
 }
 
 // v2 partition = what ONE wave streams (32 tokens per wave-chunk for head_dim 128): aim at ~8 waves per CU
@@ -522,9 +509,13 @@ QW* qw_slot(Model* m, int layer, int which) {
     return &m->layers[layer].w[which];
 }
 
+#define MI355_MAX_STEP_GRAPHS 96
 void drop_graph(Model* m) {
-    if (m->gexec) { (void)hipGraphExecDestroy(m->gexec); m->gexec = nullptr; }
-    if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+    for (auto& kv : m->graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    m->graphs.clear();
 }
 
 }  // namespace
@@ -914,25 +905,36 @@ extern "C" int mi355_llama_decode_step(void* mp, int64_t stream) {
     // on the device).  Host-supplied collectives stage through the host and cannot be captured: those steps stay eager.
     const bool tp_eager = m->use_comm && !(m->comm && m->comm->nccl);
     if (!m->use_graph || stream == 0 || tp_eager) return record_step(m, stream);
-    if (m->w_batch != m->cur_batch || m->w_max_blocks != m->cur_max_blocks || m->w_ctx_cap != m->cur_ctx_cap) {
+    const std::array<int, 3> shape{m->cur_batch, m->cur_max_blocks, m->cur_ctx_cap};
+    if (!m->warmed.count(shape)) {
         // first step of a new shape runs eagerly: lazily-set kernel attributes and occupancy queries must not
         // happen inside a stream capture
-        m->w_batch = m->cur_batch; m->w_max_blocks = m->cur_max_blocks; m->w_ctx_cap = m->cur_ctx_cap;
+        m->warmed.insert(shape);
         return record_step(m, stream);
     }
-    if (!m->gexec || m->g_batch != m->cur_batch || m->g_max_blocks != m->cur_max_blocks || m->g_ctx_cap != m->cur_ctx_cap) {
-        drop_graph(m);
+    auto it = m->graphs.find(shape);
+    if (it == m->graphs.end()) {
+        if (m->graphs.size() >= MI355_MAX_STEP_GRAPHS) {              // evict the least recently replayed shape
+            auto lru = m->graphs.begin();
+            for (auto q = m->graphs.begin(); q != m->graphs.end(); ++q) if (q->second.used < lru->second.used) lru = q;
+            if (lru->second.exec) (void)hipGraphExecDestroy(lru->second.exec);
+            if (lru->second.graph) (void)hipGraphDestroy(lru->second.graph);
+            m->graphs.erase(lru);
+        }
         HCHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         const int rc = record_step(m, stream);
         hipGraph_t g = nullptr;
         const hipError_t e = hipStreamEndCapture(st, &g);
         if (rc != 0) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (e != hipSuccess) return (int)e;
-        m->graph = g;
-        HCHECK(hipGraphInstantiate(&m->gexec, m->graph, nullptr, nullptr, 0));
-        m->g_batch = m->cur_batch; m->g_max_blocks = m->cur_max_blocks; m->g_ctx_cap = m->cur_ctx_cap;
+        Model::StepGraph sg;
+        sg.graph = g;
+        const hipError_t ie = hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0);
+        if (ie != hipSuccess) { (void)hipGraphDestroy(g); return (int)ie; }
+        it = m->graphs.emplace(shape, sg).first;
     }
-    HCHECK(hipGraphLaunch(m->gexec, st));
+    it->second.used = ++m->graph_clock;
+    HCHECK(hipGraphLaunch(it->second.exec, st));
     return 0;
 }
 

@@ -1536,6 +1536,8 @@ __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, cons
     }
 }
 
+#include "qmm_wide1_gemm.inc"
+
 // Scratch of the wide / prompt paths (activation images, split-K partials, the prompt-step workspace) belongs to the
 // (device, stream) that launches: two models on two streams never share an image, growing a buffer never frees memory a
 // captured graph still replays from (scratch.cpp).  The chain hint is per (device, stream) too.
@@ -1560,6 +1562,7 @@ static int g_tune_wide16 = 0;                                 // mi355_set_tunin
 static int g_tune_merge = 1;                                  // mi355_set_tuning(14, 0): one launch per run of same-type segments (A/B)
 static int g_tune_ks_minkb = 2;                               // mi355_set_tuning(17, n): fewest k-blocks a k-split keeps per workgroup
 static int g_tune_ks_target = 1024;                           // mi355_set_tuning(10, n): split K until a launch has n row-tile x k-split slots
+static int g_tune_wide_fuse = 1;                              // mi355_set_tuning(49, 0): A/B, the 9..32-token path runs its split-K epilogue as a separate launch again
 static inline int qmg_buf(void** p, int key, size_t need, hipStream_t st) { return mi355_scratch_get(p, key, need, st, false); }
 
 template <int MT>
@@ -1658,7 +1661,7 @@ static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-// single-plane launcher (qmm_wide1.inc): MT = m-tiles of 16 tokens (1: 9..16 tokens, 2: 17..32)
+// single-plane launcher (qmm_wide1.inc, qmm_wide1_gemm.inc): MT = m-tiles of 16 tokens (1: 9..16 tokens, 2: 17..32)
 template <int MT>
 static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
     QmmArgs a = a0;
@@ -1678,8 +1681,11 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
         const int ks_max = nkb / g_tune_ks_minkb > 1 ? nkb / g_tune_ks_minkb : 1;
         if (want > ks_max) want = ks_max;
         if (want < 1) want = 1;
-        const int kb_per = (nkb + want - 1) / want;
-        ks = (nkb + kb_per - 1) / kb_per;                                 // no empty split
+        ks = want;
+    }
+    {   // no empty split: the kernels walk ceil(nkb / ks) k-blocks per split, and every split's partial sums are added up
+        const int kb_per = (nkb + ks - 1) / ks;
+        ks = (nkb + kb_per - 1) / kb_per;
     }
     QmgStream& qs = qmg_stream(st);
     const bool chained = qs.chain.valid && qs.chain.x == a.x && qs.chain.B == a.B && qs.chain.K == a.K &&
@@ -1704,31 +1710,7 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
     }
     uint8_t* img = static_cast<uint8_t*>(imgp);
     float* ssp = reinterpret_cast<float*>(img + kbb * nkb);                 // [nkb][BP] after the image
-    if (!chained) hipLaunchKernelGGL((qw1_prep_kernel<MT>), dim3(nkb, MT * 2), dim3(256), 0, st, img, ssp, a, kbb);
-    int s_split = 0, slots0 = 0;                                     // exactly one Q4_K run followed by one Q6_K run: one launch
-    while (s_split < a.nseg && a.seg[s_split].type == MI355_GGML_Q4_K) slots0 += a.seg[s_split++].n_tiles;
-    bool two_runs = g_tune_merge && s_split > 0 && s_split < a.nseg;
-    for (int q = s_split; q < a.nseg; ++q) two_runs = two_runs && a.seg[q].type == MI355_GGML_Q6_K;
-    if (two_runs) {
-        const int slots1 = n_slots - slots0;
-        const dim3 ggrid((slots0 + QMG_NC - 1) / QMG_NC + (slots1 + QMG_NC - 1) / QMG_NC, ks);
-        hipLaunchKernelGGL((qw1_gemm2_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, a, img, part, ldp, s_split, slots0, slots1);
-    }
-    for (int s0 = 0, slot_base = 0; s0 < a.nseg && !two_runs;) {
-        int s1 = s0 + 1;
-        while (s1 < a.nseg && a.seg[s1].type == a.seg[s0].type) ++s1;
-        QmmArgs r = a;
-        r.nseg = s1 - s0;
-        int run_slots = 0;
-        for (int q = 0; q < r.nseg; ++q) { r.seg[q] = a.seg[s0 + q]; run_slots += r.seg[q].n_tiles; }
-        const dim3 ggrid((run_slots + QMG_NC - 1) / QMG_NC, ks);
-        if (r.seg[0].type == MI355_GGML_Q4_K)
-            hipLaunchKernelGGL((qw1_gemm_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), 2 * kbb, st, r, img, part, ldp, run_slots, slot_base);
-        else
-            hipLaunchKernelGGL((qw1_gemm_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, r, img, part, ldp, run_slots, slot_base);
-        slot_base += run_slots;
-        s0 = s1;
-    }
+    // chain: the epilogue also stages the image of the next wide mat-mul (x = our out) into the other buffer
     QmgChainOut ch{nullptr, nullptr, nullptr, 0, 0, 0, 0};
     const bool want = g_tune_chain && a.chain_next && a.next_k > 0 && (a.next_k % 256) == 0 && a.ldo == a.next_k &&
                       (a.epi == MI355_EPI_RESID || a.epi == MI355_EPI_SILU_MUL || a.epi == MI355_EPI_STORE) &&
@@ -1740,10 +1722,61 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
         if (rc) return rc;
         uint8_t* oimg = static_cast<uint8_t*>(onext);
         ch = QmgChainOut{oimg, reinterpret_cast<float*>(oimg + kbb * nkb2), a.next_norm_w, a.next_k, MT, kbb, 1};
-        qs.chain = QmgChainState{true, a.out, a.B, a.next_k, MT, other, a.next_norm_w, st, 1};
     }
+    // the split-K epilogue inside the GEMM launches (qmm_wide1_gemm.inc): tickets per 256-column block of the output
+    QwFuse fz{};
+    fz.ticket = nullptr; fz.ssp = ssp; fz.ch = ch; fz.ks = ks; fz.n_runs = 0;
+    if (g_tune_wide_fuse) {
+        void* tk = nullptr;
+        rc = mi355_scratch_get(&tk, MI355_SCR_QMM_TICKET, 8192 * sizeof(unsigned), st, true);
+        if (rc) return rc;
+        if ((ldp + 255) / 256 <= 8192) fz.ticket = static_cast<unsigned*>(tk);
+    }
+    if (!chained) hipLaunchKernelGGL((qw1_prep_kernel<MT>), dim3(nkb, MT * 2), dim3(256), 0, st, img, ssp, a, kbb);
+    int s_split = 0, slots0 = 0;                                     // exactly one Q4_K run followed by one Q6_K run: one launch
+    while (s_split < a.nseg && a.seg[s_split].type == MI355_GGML_Q4_K) slots0 += a.seg[s_split++].n_tiles;
+    bool two_runs = g_tune_merge && s_split > 0 && s_split < a.nseg;
+    for (int q = s_split; q < a.nseg; ++q) two_runs = two_runs && a.seg[q].type == MI355_GGML_Q6_K;
+    // the runs of same-type segments = the launches (or launch halves): every workgroup needs all of them to count a block's arrivals
+    for (int s0 = 0, base = 0; s0 < a.nseg;) {
+        int s1 = s0 + 1, rs = a.seg[s0].n_tiles;
+        while (s1 < a.nseg && a.seg[s1].type == a.seg[s0].type) rs += a.seg[s1++].n_tiles;
+        fz.run_lo[fz.n_runs] = base; fz.run_hi[fz.n_runs] = base + rs; ++fz.n_runs;
+        base += rs;
+        s0 = s1;
+    }
+    if (two_runs) {
+        const int slots1 = n_slots - slots0;
+        const dim3 ggrid((slots0 + QMG_NC - 1) / QMG_NC + (slots1 + QMG_NC - 1) / QMG_NC, ks);
+        hipLaunchKernelGGL((qw1_gemm2_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, a, img, part, ldp, s_split, slots0, slots1, fz);
+    }
+    for (int s0 = 0, slot_base = 0; s0 < a.nseg && !two_runs;) {
+        int s1 = s0 + 1;
+        while (s1 < a.nseg && a.seg[s1].type == a.seg[s0].type) ++s1;
+        QmmArgs r = a;
+        r.nseg = s1 - s0;
+        int run_slots = 0;
+        for (int q = 0; q < r.nseg; ++q) { r.seg[q] = a.seg[s0 + q]; run_slots += r.seg[q].n_tiles; }
+        // (the in-launch epilogue walks ALL segments of the mat-mul: it gets the whole descriptor, the GEMM part its own run)
+        const dim3 ggrid((run_slots + QMG_NC - 1) / QMG_NC, ks);
+        if (fz.ticket && r.nseg != a.nseg) {
+            // a mat-mul of several launches: the kernel's segment walk starts at the run's first segment
+            QmmArgs full = a;
+            if (r.seg[0].type == MI355_GGML_Q4_K)
+                hipLaunchKernelGGL((qw1_gemm_run_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), 2 * kbb, st, full, img, part, ldp, run_slots, slot_base, s0, s1, fz);
+            else
+                hipLaunchKernelGGL((qw1_gemm_run_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, full, img, part, ldp, run_slots, slot_base, s0, s1, fz);
+        } else if (r.seg[0].type == MI355_GGML_Q4_K)
+            hipLaunchKernelGGL((qw1_gemm_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), 2 * kbb, st, r, img, part, ldp, run_slots, slot_base, fz);
+        else
+            hipLaunchKernelGGL((qw1_gemm_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, r, img, part, ldp, run_slots, slot_base, fz);
+        slot_base += run_slots;
+        s0 = s1;
+    }
+    if (want) qs.chain = QmgChainState{true, a.out, a.B, a.next_k, MT, cur ^ 1, a.next_norm_w, st, 1};
     qs.cur = cur;
-    hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, want ? BP : a.B), dim3(256), 0, st, a, part, ldp, ks, BP, ssp, ch);
+    if (!fz.ticket)
+        hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, want ? BP : a.B), dim3(256), 0, st, a, part, ldp, ks, BP, ssp, ch);
     return (int)hipGetLastError();
 }
 
@@ -2064,6 +2097,7 @@ extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
     else if (key == 44) mi355_pa_set_loop(value);
     else if (key == 47) mi355_prefill_set_lds(value);
     else if (key == 48) g_tune_qpg_fepi = value;
+    else if (key == 49) g_tune_wide_fuse = value;
 }
 
 static size_t qmm_lds_bytes(int BT, int R, int NW) {

@@ -181,6 +181,40 @@ class DenseLlama:
             torch.cuda.synchronize()
         return logits
 
+    # ---- greedy loop on static device buffers (hipGraph replay): mi355_dense_decode_* = the GGUF layer's decode_begin / step / read
+    def finalize(self):
+        """freeze the weights (tile re-ordering happens here, not inside the first step)"""
+        _check(lib.mi355_dense_finalize(self.h), "dense_finalize")
+
+    def set_graph(self, enable):
+        _check(lib.mi355_dense_set_graph(self.h, 1 if enable else 0), "dense_set_graph")
+
+    def decode_begin(self, tokens, seq_lens, block_tables, ctx_cap, stream=0):
+        tokens = np.ascontiguousarray(tokens, np.uint32)
+        seq_lens = np.ascontiguousarray(seq_lens, np.uint32)
+        bt = np.ascontiguousarray(block_tables, np.uint32)
+        _check(lib.mi355_dense_decode_begin(self.h, tokens.ctypes.data, seq_lens.ctypes.data, bt.ctypes.data, len(tokens), bt.shape[1],
+                                            int(ctx_cap), stream), "dense_decode_begin")
+        self._loop_batch = len(tokens)
+
+    def decode_step(self, stream=0):
+        _check(lib.mi355_dense_decode_step(self.h, stream), "dense_decode_step")
+
+    def read_tokens(self, stream=0):
+        out = np.zeros(self._loop_batch, np.uint32)
+        _check(lib.mi355_dense_decode_read_tokens(self.h, out.ctypes.data, stream), "dense_decode_read_tokens")
+        return out
+
+    def loop_logits(self):
+        """f32 [batch, vocab] logits of the loop's last step (a copy)"""
+        n = self._loop_batch * self.cfg.vocab * (self.tp_world if (self.comm or getattr(self, 'comm_borrowed', None)) else 1)
+        out = torch.empty(n, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        ctypes.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(lib.mi355_dense_logits_ptr(self.h)),
+                                                             ctypes.c_size_t(n * 4), 3)
+        torch.cuda.synchronize()
+        return out.view(self._loop_batch, -1)
+
     def forward_device(self, tok, pos, slots, bt, ctx, max_context_len, logits, stream):
         """decode step over device tensors that stay resident (bench loop)"""
         _check(lib.mi355_dense_forward(self.h, tok.data_ptr(), pos.data_ptr(), slots.data_ptr(), bt.data_ptr(),

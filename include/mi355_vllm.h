@@ -530,7 +530,8 @@ int mi355_comm_all_gather(void* comm, const void* send, void* recv, int64_t coun
 /* ---------------------------------------------------------------------------------------------
  * 4b. Host layer for 16-bit safetensors llama-family models (Llama / Qwen2 shapes): src/openai/models/llama.rs:
  *     39-201, layers/attention.rs:585-734, layers/mlp.rs:440-458.  Residual stream and every op result in the
- *     model dtype, rounded where candle rounds.  Eager, single GPU.
+ *     model dtype, rounded where candle rounds.  mi355_dense_forward is one eager step; mi355_dense_decode_* is the greedy loop on
+ *     static device buffers replayed from a hipGraph (backend/graph.rs:471-661,685-807, pipelines/pipeline.rs:2091-2135).
  * ------------------------------------------------------------------------------------------- */
 typedef struct mi355_dense_config {
     int32_t hidden, n_layers, n_heads, n_kv_heads, head_dim, intermediate, vocab;
@@ -575,6 +576,22 @@ int mi355_dense_forward(void* model, const uint32_t* tokens, const int64_t* posi
                         const uint32_t* block_tables, const uint32_t* context_lens, const uint32_t* cu_seqlens_q,
                         int32_t num_seqs, int32_t num_tokens, int32_t max_seqlen_q, int32_t max_blocks,
                         int32_t max_context_len, float* logits, int64_t stream);
+/* Freeze the weights: the one-off re-ordering of the 16-bit projections into 16-row x 256-k tiles, which allocates and
+ * synchronises (the first forward does it otherwise, and refuses to while its stream is capturing).  Call it from the loader
+ * after the last setter; from then on mi355_dense_set_weight* / _set_gptq refuse every slot. */
+int mi355_dense_finalize(void* model);
+/* Greedy decode loop, same contract as mi355_llama_decode_begin / _step / _read_tokens: tokens_host[b] = last token of
+ * sequence b, seq_lens_host[b] = its length including that token, block tables [batch, max_blocks] with every block of the
+ * steps to come reserved, ctx_cap = upper bound of the context length over those steps.  A step = forward -> argmax (first
+ * maximum, logits_processor.rs:92-95) -> next positions / slots / context lengths on the device; captured once per
+ * (batch, max_blocks, ctx_cap) and replayed.  Tensor-parallel steps are captured when the communicator is RCCL's own, and
+ * run eagerly with host-supplied collectives.  Needs cfg.max_blocks_per_seq >= max_blocks. */
+int mi355_dense_set_graph(void* model, int32_t enable);
+int mi355_dense_decode_begin(void* model, const uint32_t* tokens_host, const uint32_t* seq_lens_host,
+                             const uint32_t* block_tables_host, int32_t batch, int32_t max_blocks, int32_t ctx_cap, int64_t stream);
+int mi355_dense_decode_step(void* model, int64_t stream);
+int mi355_dense_decode_read_tokens(void* model, uint32_t* host_out, int64_t stream);
+float* mi355_dense_logits_ptr(void* model);   /* f32 [batch, vocab (x tp_world)] of the loop's last step */
 
 /* ---------------------------------------------------------------------------------------------
  * 5. Host block manager: BlockEngine + PrefixCache + Sequence bookkeeping + input preparation.

@@ -233,3 +233,69 @@ def test_tp_shard_through_rccl_communicator(lib, gptq):
     got = gm.forward(dmeta).cpu().numpy()
     assert _rel(got, ref) < 2e-2, _rel(got, ref)
     assert np.array_equal(got, gm2.forward(dmeta).cpu().numpy())
+
+
+@pytest.mark.parametrize("gptq,flash", [(False, False), (False, True), (True, False)])
+def test_dense_greedy_loop_graph_equals_eager_equals_oracle(lib, gptq, flash):
+    """mi355_dense_decode_begin / _step / _read_tokens (round 4; graph.rs:471-661, pipeline.rs:2091-2135 for every model family): the
+    greedy loop on static device buffers -- forward, argmax, device-side input advance -- replayed from a hipGraph.  The tokens of the
+    graph-replayed loop == the eager loop == the oracle's greedy continuation (prepare_decode restated on the host), over steps that
+    cross a block boundary; the loop's last logits are the eager forward's to the bit."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from candle_vllm_amd import dense_model as M
+    cfg = DL.DenseConfig.tiny(qkv_bias=gptq)
+    W = DL.make_weights(cfg)
+    if gptq:
+        W = DL.quantize_gptq(W, group=128)
+    orc = DL.OracleDenseLlama(cfg, W, flash_layout=flash)
+    rng = np.random.default_rng(11)
+    bs, steps = cfg.block_size, 6
+    lens = [2 * bs - 3, 5, bs + 1]                                   # the first sequence crosses into its third block inside the loop
+    seqs, nxt = [], 1
+    for n in lens:
+        nb = -(-(n + steps + 1) // bs)
+        seqs.append({"tokens": [int(t) for t in rng.integers(0, cfg.vocab, n)], "block_table": list(range(nxt, nxt + nb))})
+        nxt += nb
+    nblocks = nxt + 1
+    cache = orc.new_cache(nblocks)
+    lg = orc.forward(O.prepare_prompt(seqs, bs), cache, is_prefill=True)
+    for s, row in zip(seqs, lg):
+        s["tokens"].append(int(row.argmax()))
+    maxb = max(len(s["block_table"]) for s in seqs)
+    bt = np.zeros((len(seqs), maxb), np.uint32)
+    for i, s in enumerate(seqs):
+        bt[i, :len(s["block_table"])] = s["block_table"]
+    tok0 = np.array([s["tokens"][-1] for s in seqs], np.uint32)
+    len0 = np.array([len(s["tokens"]) for s in seqs], np.uint32)
+    cap = int(len0.max()) + steps + 1
+
+    def run(graph):
+        gm = M.DenseLlama(cfg, max_batch=4, max_blocks_per_seq=maxb, kv_layout=M.KV_FLASH if flash else M.KV_PAGED)
+        gm.load_oracle_weights(W)
+        gm.finalize()
+        gm.alloc_kv_cache(nblocks)
+        for l, (kc, vc) in enumerate(cache0):
+            gm.kv_upload(l, kc, vc)
+        stream = torch.cuda.Stream()
+        gm.set_graph(graph)
+        gm.decode_begin(tok0, len0, bt, ctx_cap=cap, stream=stream.cuda_stream)
+        toks = []
+        for _ in range(steps):
+            gm.decode_step(stream.cuda_stream)
+            toks.append(gm.read_tokens(stream.cuda_stream).tolist())
+        return toks, gm.loop_logits().cpu().numpy()
+
+    cache0 = [(k.copy(), v.copy()) for k, v in cache]               # both GPU runs start from the oracle's prompt cache
+    want = []
+    for _ in range(steps):
+        ref = orc.forward(O.prepare_decode(seqs, bs), cache)
+        for s, row in zip(seqs, ref):
+            s["tokens"].append(int(row.argmax()))
+        want.append([s["tokens"][-1] for s in seqs])
+    eager, lg_e = run(False)
+    graph, lg_g = run(True)
+    assert eager == graph
+    assert np.array_equal(lg_e, lg_g)                                # same kernels, same inputs: bit-identical
+    assert graph == want, (graph, want)
+    assert _rel(lg_g, ref) < 2e-2
