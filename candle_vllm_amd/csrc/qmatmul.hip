@@ -1562,7 +1562,7 @@ static int g_tune_wide16 = 0;                                 // mi355_set_tunin
 static int g_tune_merge = 1;                                  // mi355_set_tuning(14, 0): one launch per run of same-type segments (A/B)
 static int g_tune_ks_minkb = 2;                               // mi355_set_tuning(17, n): fewest k-blocks a k-split keeps per workgroup
 static int g_tune_ks_target = 1024;                           // mi355_set_tuning(10, n): split K until a launch has n row-tile x k-split slots
-static int g_tune_wide_fuse = 1;                              // mi355_set_tuning(49, 0): A/B, the 9..32-token path runs its split-K epilogue as a separate launch again
+static int g_tune_wide_fuse = 0;                              // mi355_set_tuning(49, 1), probe builds only: EXPERIMENT, the 9..32-token path runs its split-K epilogue inside the GEMM launches (lost its A/B: qmm_wide1_gemm.inc)
 static inline int qmg_buf(void** p, int key, size_t need, hipStream_t st) { return mi355_scratch_get(p, key, need, st, false); }
 
 template <int MT>
@@ -1726,7 +1726,7 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
     // the split-K epilogue inside the GEMM launches (qmm_wide1_gemm.inc): tickets per 256-column block of the output
     QwFuse fz{};
     fz.ticket = nullptr; fz.ssp = ssp; fz.ch = ch; fz.ks = ks; fz.n_runs = 0;
-    if (g_tune_wide_fuse) {
+    if (QW1_FUSE_BUILD && g_tune_wide_fuse) {
         void* tk = nullptr;
         rc = mi355_scratch_get(&tk, MI355_SCR_QMM_TICKET, 8192 * sizeof(unsigned), st, true);
         if (rc) return rc;
@@ -1759,6 +1759,7 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
         for (int q = 0; q < r.nseg; ++q) { r.seg[q] = a.seg[s0 + q]; run_slots += r.seg[q].n_tiles; }
         // (the in-launch epilogue walks ALL segments of the mat-mul: it gets the whole descriptor, the GEMM part its own run)
         const dim3 ggrid((run_slots + QMG_NC - 1) / QMG_NC, ks);
+#if QW1_FUSE_BUILD
         if (fz.ticket && r.nseg != a.nseg) {
             // a mat-mul of several launches: the kernel's segment walk starts at the run's first segment
             QmmArgs full = a;
@@ -1766,7 +1767,9 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
                 hipLaunchKernelGGL((qw1_gemm_run_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), 2 * kbb, st, full, img, part, ldp, run_slots, slot_base, s0, s1, fz);
             else
                 hipLaunchKernelGGL((qw1_gemm_run_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, full, img, part, ldp, run_slots, slot_base, s0, s1, fz);
-        } else if (r.seg[0].type == MI355_GGML_Q4_K)
+        } else
+#endif
+        if (r.seg[0].type == MI355_GGML_Q4_K)
             hipLaunchKernelGGL((qw1_gemm_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), 2 * kbb, st, r, img, part, ldp, run_slots, slot_base, fz);
         else
             hipLaunchKernelGGL((qw1_gemm_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, r, img, part, ldp, run_slots, slot_base, fz);

@@ -287,15 +287,21 @@ def test_dense_greedy_loop_graph_equals_eager_equals_oracle(lib, gptq, flash):
         return toks, gm.loop_logits().cpu().numpy()
 
     cache0 = [(k.copy(), v.copy()) for k, v in cache]               # both GPU runs start from the oracle's prompt cache
-    want = []
-    for _ in range(steps):
-        ref = orc.forward(O.prepare_decode(seqs, bs), cache)
-        for s, row in zip(seqs, ref):
-            s["tokens"].append(int(row.argmax()))
-        want.append([s["tokens"][-1] for s in seqs])
     eager, lg_e = run(False)
     graph, lg_g = run(True)
     assert eager == graph
     assert np.array_equal(lg_e, lg_g)                                # same kernels, same inputs: bit-identical
-    assert graph == want, (graph, want)
+    # the oracle's greedy continuation: it follows the GPU's token where the two disagree INSIDE a near tie (the oracle's own logits of
+    # the two candidates closer than the path's bound: 2e-2 of the logit scale) -- the device loop cannot be teacher-forced
+    exact = 0
+    for step in range(steps):
+        ref = orc.forward(O.prepare_decode(seqs, bs), cache)
+        for i, (s, row) in enumerate(zip(seqs, ref)):
+            t_gpu, t_ref = graph[step][i], int(row.argmax())
+            if t_gpu == t_ref:
+                exact += 1
+            else:
+                assert row[t_ref] - row[t_gpu] <= 2e-2 * np.abs(row).max(), (step, i, t_gpu, t_ref)
+            s["tokens"].append(t_gpu)
+    assert exact >= int(0.8 * steps * len(seqs)), exact
     assert _rel(lg_g, ref) < 2e-2

@@ -228,3 +228,40 @@ def test_engine_loop_prefix_cache_hit_reuses_kv_blocks(lib):
     assert computed_prompt_tokens[0] == len(prompts[0])
     assert computed_prompt_tokens[1] == len(prompts[1]) - 2 * cfg.block_size     # the shared two blocks were NOT recomputed
     assert eng.prefix_cache_blocks() > 0
+
+
+@pytest.mark.parametrize("chunk", [0, 24])
+def test_engine_module_graph_replayed_decode_steps_match_per_sequence_oracle(lib, chunk):
+    """candle_vllm_amd.engine.run_engine -- the loop bench_legs.py `engine_b32` times at Llama-3-8B size: decode steps go through the
+    library's step driver (decode_begin copies the step's inputs into the static buffers, ONE hipGraph replay per step, one graph per batch
+    size kept as the batch grows and shrinks), prompt steps are sampled on the device.  Staggered arrivals, chunked prefill; every request
+    must end with exactly the tokens the oracle generates for it alone, and the usage record must follow llm_engine.rs:984-1002."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from candle_vllm_amd import model as M
+    from candle_vllm_amd import block_engine as be
+    from candle_vllm_amd import engine as E
+    cfg = llama.LlamaConfig.tiny()
+    W = llama.make_weights(cfg, seed=2027)
+    orc = llama.OracleLlama(cfg, W, flash_layout=False)
+    rng = np.random.default_rng(909)
+    NSEQ, nblk = 9, 64
+    prompts = [[int(t) for t in rng.integers(0, cfg.vocab, int(n))] for n in rng.integers(5, 60, NSEQ)]
+    n_new = [int(n) for n in rng.integers(4, 14, NSEQ)]
+    arrivals = sorted(int(a) for a in rng.integers(0, 10, NSEQ))
+    want = [_oracle_alone(orc, cfg, p, n) for p, n in zip(prompts, n_new)]
+    sched = be.Scheduler(block_size=cfg.block_size, num_gpu_blocks=nblk, num_cpu_blocks=8, max_num_parallel_reqs=8,
+                         max_num_batched_tokens=96, prefill_chunk_size=chunk)
+    gm = M.GGUFLLaMa(cfg, max_batch=8, max_blocks_per_seq=8, kv_layout=M.KV_PAGED)
+    gm.load_oracle_weights(W)
+    gm.alloc_kv_cache(nblk)
+    reqs = [E.Request(i, prompts[i], n_new[i], arrivals[i]) for i in range(NSEQ)]
+    stream = torch.cuda.Stream()
+    stats = E.run_engine(gm, sched, reqs, chunk=chunk, stream=stream.cuda_stream, graph=True)
+    assert stats["finished"] == NSEQ and stats["max_batch"] >= 3 and stats["prompt_steps"] >= 2
+    assert len(stats["batch_hist"]) >= 3                                       # several batch sizes = several cached graphs
+    for i, r in enumerate(reqs):
+        assert r.tokens == want[i], (i, r.tokens, want[i])
+    u = E.usage_summary(reqs)
+    assert u["requests"] == NSEQ and u["completion_tokens"] == sum(n_new) and u["decode_throughput"] > 0
+    assert sched.block_engine.get_num_free_blocks() == nblk and not sched.has_unfinished_sequences()
