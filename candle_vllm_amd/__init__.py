@@ -6,7 +6,7 @@ from ._lib import lib, LIB_PATH  # noqa: F401
 import contextlib as _contextlib
 
 # defaults of the tuning keys whose default is not 0 (include/mi355_vllm.h): what `tuning` restores when a key was never set before
-_TUNING_DEFAULTS = {3: 1, 6: 1, 9: 1, 10: 1024, 12: 96, 14: 1, 17: 2, 21: 8, 36: 96, 38: 4, 41: 1, 42: 1, 44: 1, 47: 1, 48: 1}
+_TUNING_DEFAULTS = {3: 1, 6: 1, 9: 1, 10: 1024, 11: 2, 12: 96, 14: 1, 17: 2, 21: 8, 36: 96, 38: 4, 41: 1, 42: 1, 44: 1, 47: 1, 48: 1}
 
 
 @_contextlib.contextmanager

@@ -111,6 +111,7 @@ struct Model {
     float* p_moe_xg = nullptr; int32_t* p_moe_perm = nullptr; int32_t* p_moe_inv = nullptr;
     // decode steps with many (token, slot) pairs: experts grouped on the device, `g_cap` rows per expert (host_model.cpp run_part)
     float* g_moe_xg = nullptr; float* g_moe_h = nullptr; float* g_moe_yg = nullptr; int32_t* g_moe_pos = nullptr; int32_t* g_moe_cnt = nullptr; int g_cap = 0;
+    int attn_numerics = 0;          // parity mode (mi355_llama_set_attention_numerics): 1 = the reference CPU path's bf16 rounding points in decode attention
     bool moe_grouped_done = false;  // this layer's MlpOrMoe ran grouped inside the gate/up part: the down part has nothing left to do
 };
 
@@ -410,6 +411,12 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
         return mi355_prefill_attention(in.attn, in.q, nullptr, nullptr, m->kcache[l], m->vcache[l], in.bt, in.ctx,
                                        in.cu_q, in.num_seqs, in.max_seqlen_q, H, Hkv, D, c.block_size, in.max_blocks,
                                        1.0f / sqrtf((float)D), 0.f, c.kv_layout, MI355_DTYPE_BF16, st);
+    }
+    if (part == PART_ATTN && m->attn_numerics == 1) {
+        // parity mode: scores / probabilities / P.V rounded to bf16 where models/mod.rs:1288-1306 rounds them (tests only)
+        if (in.ctx_cap > c.max_seq) return (int)hipErrorInvalidValue;
+        return mi355_paged_attention_reference_numerics(in.attn, in.q, m->kcache[l], m->vcache[l], in.bt, in.ctx, B, H, Hkv, D,
+                                                        c.block_size, in.max_blocks, in.ctx_cap, 1.0f / sqrtf((float)D), c.kv_layout, st);
     }
     if (part == PART_ATTN) {
         // --- paged attention over the cache (the new token's K/V are already in place)
@@ -875,6 +882,17 @@ static int record_step(Model* m, int64_t stream) {
                        m->d_tokens, next, m->d_positions, m->d_slots, m->d_ctx, m->d_bt, m->cur_max_blocks,
                        m->cfg.block_size, B);
     return (int)hipGetLastError();
+}
+
+/* PARITY MODE switch (tests): 0 = the product attention kernels (f32 scores and probabilities), 1 = decode attention with the
+ * reference CPU path's bf16 rounding points (models/mod.rs:1288-1306) -- slow; fp8 caches and prompt steps keep their kernels. */
+extern "C" int mi355_llama_set_attention_numerics(void* mp, int32_t mode) {
+    Model* m = static_cast<Model*>(mp);
+    if (!m || mode < 0 || mode > 1) return (int)hipErrorInvalidValue;
+    if (mode == 1 && m->cfg.kv_layout == MI355_KV_PAGED_FP8) return (int)hipErrorNotSupported;
+    drop_graph(m);
+    m->attn_numerics = mode;
+    return 0;
 }
 
 extern "C" int mi355_llama_set_graph(void* mp, int32_t enable) {

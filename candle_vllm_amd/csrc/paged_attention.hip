@@ -1739,6 +1739,95 @@ extern "C" int32_t mi355_internal_pal_layout(int32_t what, int32_t a, int32_t b,
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// PARITY MODE (tests only; mi355_llama_set_attention_numerics(model, 1)): decode attention with the reference CPU path's own rounding
+// points -- `NaiveAttention::forward` on bf16 tensors (models/mod.rs:1288-1306): the score matmul returns bf16, `* scale` rounds to
+// bf16 again, softmax_last_dim returns bf16 probabilities, the P.V matmul accumulates in f32 and returns bf16 -- and the SAME
+// summation orders as oracle/oracle.c's bf16-attention mode (sequential over d for a score, over t for the denominator in f64 and for
+// every output channel), so that the two agree except where an f32 rounding difference happens to straddle a bf16 tie.  The product
+// kernels keep scores / probabilities in f32 (more accurate than the reference); through 32 layers the reference's bf16 points alone
+// move the logits by 1.7-3 %, so north_star's "within 1e-3 of the reference CPU logits" can only be checked in
+// this mode.  One workgroup per (head, sequence); slow by design (a thread walks whole rows).
+__global__ void __launch_bounds__(256) paged_attn_refnum_kernel(const PAParams p, const int flash) {
+#pragma clang fp contract(fast)
+    extern __shared__ float rn_sm[];                                  // [D] q | [n] scores -> probabilities
+    const int h = blockIdx.x, b = blockIdx.y, D = p.D, G = p.H / p.Hkv, hk = h / G, bs = p.block_size;
+    const int n = (int)p.context_lens[b];
+    float* qs = rn_sm;
+    float* sc = rn_sm + D;
+    __shared__ float red[256];
+    __shared__ double den_s;
+    const uint16_t* q = static_cast<const uint16_t*>(p.q) + (size_t)b * p.q_stride + (size_t)h * D;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) qs[d] = bf16_to_f32(q[d]);
+    __syncthreads();
+    const uint16_t* kc = static_cast<const uint16_t*>(p.kc);
+    const uint16_t* vc = static_cast<const uint16_t*>(p.vc);
+    float mx = -1e30f;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        const size_t blk = p.block_tables[(size_t)b * p.max_blocks + t / bs];
+        const int off = t % bs;
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) {
+            const size_t ki = flash ? ((blk * bs + off) * p.Hkv + hk) * D + d
+                                    : ((((blk * p.Hkv + hk) * (D / 8) + d / 8) * bs + off) * 8) + d % 8;
+            s = fmaf(qs[d], bf16_to_f32(kc[ki]), s);
+        }
+        const float v = bf16_to_f32(f32_to_bf16(bf16_to_f32(f32_to_bf16(s)) * p.scale));
+        sc[t] = v;
+        mx = fmaxf(mx, v);
+    }
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    mx = red[0];
+    for (int t = threadIdx.x; t < n; t += blockDim.x) sc[t] = expf(sc[t] - mx);
+    __syncthreads();
+    if (threadIdx.x == 0) {                                           // the oracle's order: sequential, f64
+        double den = 0.0;
+        for (int t = 0; t < n; ++t) den += (double)sc[t];
+        den_s = den;
+    }
+    __syncthreads();
+    const double den = den_s;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) sc[t] = bf16_to_f32(f32_to_bf16((float)((double)sc[t] / den)));
+    __syncthreads();
+    uint16_t* out = static_cast<uint16_t*>(p.out) + ((size_t)b * p.H + h) * D;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float o = 0.f;
+        for (int t = 0; t < n; ++t) {
+            const size_t blk = p.block_tables[(size_t)b * p.max_blocks + t / bs];
+            const int off = t % bs;
+            const size_t vi = flash ? ((blk * bs + off) * p.Hkv + hk) * D + d : ((blk * p.Hkv + hk) * D + d) * (size_t)bs + off;
+            o = fmaf(sc[t], bf16_to_f32(vc[vi]), o);
+        }
+        out[d] = f32_to_bf16(o);
+    }
+}
+extern "C" int mi355_paged_attention_reference_numerics(void* out, const void* q, const void* key_cache, const void* value_cache,
+                                                        const uint32_t* block_tables, const uint32_t* context_lens, int32_t num_seqs,
+                                                        int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                                                        int32_t max_blocks_per_seq, int32_t max_context_len, float scale, int32_t layout,
+                                                        int64_t stream) {
+    if (num_seqs <= 0) return 0;
+    if (!out || !q || !key_cache || !value_cache || !block_tables || !context_lens || num_kv_heads <= 0 || num_heads % num_kv_heads ||
+        (head_dim & 7) || head_dim > 256 || (layout != MI355_KV_PAGED && layout != MI355_KV_FLASH))
+        return (int)hipErrorInvalidValue;
+    const size_t shm = ((size_t)head_dim + (size_t)(max_context_len > 0 ? max_context_len : 1)) * sizeof(float);
+    if (shm > 150 * 1024) return (int)hipErrorInvalidValue;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)paged_attn_refnum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_done = true;
+    }
+    PAParams p{};
+    p.out = out; p.q = q; p.kc = key_cache; p.vc = value_cache; p.block_tables = block_tables; p.context_lens = context_lens;
+    p.H = num_heads; p.Hkv = num_kv_heads; p.D = head_dim; p.block_size = block_size; p.max_blocks = max_blocks_per_seq;
+    p.scale = scale; p.q_stride = (int64_t)num_heads * head_dim;
+    hipLaunchKernelGGL(paged_attn_refnum_kernel, dim3(num_heads, num_seqs), dim3(256), shm, to_stream(stream), p, layout == MI355_KV_FLASH ? 1 : 0);
+    return (int)hipGetLastError();
+}
+
 void mi355_pa_set_fused(int v) { g_pa_fused = v; }
 void mi355_pa_set_wpb(int v) { g_pa_wpb = v; }
 void mi355_pa_set_loop(int v) { g_pa_loop = v; }

@@ -1908,7 +1908,7 @@ int mi355_internal_gemm_rowmajor(void* out, int out_dtype, int ldo, const void* 
 
 #endif  // MI355_QMM_PROBES
 
-static int g_tune_qpg = 0;                                 // mi355_set_tuning(11, v): prompt-step GEMM variant (A/B runs)
+static int g_tune_qpg = 2;                                 // mi355_set_tuning(11, v): prompt-step GEMM workgroup tile: 2 (default since round 4) = 64 tokens x 256 rows, 0 = 32 x 512 (rounds 2-3), 1 / 3: A/B variants
 static int g_tune_qpg_fepi = 1;                            // mi355_set_tuning(48, 0): A/B, separate epilogue launch.  Default: the prompt-step GEMM applies the epilogue itself (Q4_K launches; store / residual / SiLU * up; round 4: +7 % on the prompt step)
 static int g_tune_qpg_min = 96;                            // mi355_set_tuning(12, n): fewest tokens that take the prompt-step GEMM (QMP_MIN_TOKENS)
 static int g_tune_dbg = 0;                                 // mi355_set_tuning(2, v): probe / ablation modes (experiments only)
@@ -1949,8 +1949,10 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
         QPG_ATTR(2, 4, 1, 8, false); QPG_ATTR(4, 4, 1, 8, false); QPG_ATTR(4, 2, 1, 8, false); QPG_ATTR(2, 4, 2, 4, false);
 #undef QPG_ATTR
         (void)hipFuncSetAttribute((const void*)qpg_gemm_kernel<MI355_GGML_Q4_K, 2, 4, 1, 8, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_kernel<MI355_GGML_Q4_K, 4, 2, 1, 8, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         attr_done = true;
     }
     hipLaunchKernelGGL(qpg_rowstat_kernel, dim3(Tpad), dim3(256), 0, st, a, im);
@@ -1962,12 +1964,18 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
         for (int s = 0; s < a.nseg; ++s) all_q4 = all_q4 && a.seg[s].type == MI355_GGML_Q4_K;
         const bool epi_ok = a.epi == MI355_EPI_STORE || a.epi == MI355_EPI_RESID ||
                             (a.epi == MI355_EPI_SILU_MUL && a.nseg == 2 && a.seg[0].n_tiles == a.seg[1].n_tiles && a.seg[0].n_rows == a.seg[1].n_rows);
-        if (g_tune_qpg_fepi && all_q4 && epi_ok && parts == 1 && g_tune_qpg == 0) {
+        if (g_tune_qpg_fepi && all_q4 && epi_ok && parts == 1 && (g_tune_qpg == 0 || g_tune_qpg == 2)) {
             QmmArgs r = a;
             r.norm_w = nullptr;                                 // applied while the image was built
-            const dim3 g_(Tpad / 32, (n_slots + 31) / 32), b_(512);
-            const size_t sh_ = (size_t)2 * 32 * QPG_ROWB;
-            hipLaunchKernelGGL((qpg_gemm_kernel<MI355_GGML_Q4_K, 2, 4, 1, 8, false, 1, true>), g_, b_, sh_, st, r, im, C, ldp, n_slots, 0);
+            if (g_tune_qpg == 2) {                              // 64 tokens x 256 rows per workgroup (waves 64 x 32): every unpacked weight meets 64 tokens
+                const dim3 g_(Tpad / 64, (n_slots + 15) / 16), b_(512);
+                const size_t sh_ = (size_t)2 * 64 * QPG_ROWB;
+                hipLaunchKernelGGL((qpg_gemm_kernel<MI355_GGML_Q4_K, 4, 2, 1, 8, false, 1, true>), g_, b_, sh_, st, r, im, C, ldp, n_slots, 0);
+            } else {
+                const dim3 g_(Tpad / 32, (n_slots + 31) / 32), b_(512);
+                const size_t sh_ = (size_t)2 * 32 * QPG_ROWB;
+                hipLaunchKernelGGL((qpg_gemm_kernel<MI355_GGML_Q4_K, 2, 4, 1, 8, false, 1, true>), g_, b_, sh_, st, r, im, C, ldp, n_slots, 0);
+            }
             return (int)hipGetLastError();
         }
     }
@@ -1989,13 +1997,18 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
                 case 1: QPG_GO(4, 4, 1, 8, false); break;              //  64 x 512, waves 64 x 64
                 case 2: QPG_GO(4, 2, 1, 8, false); break;              //  64 x 256, waves 64 x 32
                 case 3: QPG_GO(2, 4, 2, 4, false); break;              //  64 x 256, waves 32 x 64
-                default: QPG_GO(2, 4, 1, 8, false); break;             //  32 x 512, waves 32 x 64: measured best in round 2 (hi + lo planes)
+                default: QPG_GO(2, 4, 1, 8, false); break;             //  32 x 512, waves 32 x 64: measured best in round 2 (hi + lo planes); with one plane 64 x 256 wins (round 4: 25.7 k -> 27.0 k tok/s at T = 2048)
             }
 #undef QPG_GO
         } else {
-            const dim3 grid(Tpad / 32, (run_slots + 15) / 16);         // Q6_K: 32 tokens x 256 rows per workgroup; token blocks fastest
-            if (parts == 1) hipLaunchKernelGGL(qpg_gemm_q6k_kernel<1>, grid, dim3(512), 8 * 1024, st, r, im, C, ldp, run_slots, slot_base);
-            else hipLaunchKernelGGL(qpg_gemm_q6k_kernel<2>, grid, dim3(512), 16 * 1024, st, r, im, C, ldp, run_slots, slot_base);
+            if (parts == 1 && g_tune_qpg == 2) {                        // Q6_K: 64 tokens x 256 rows per workgroup; token blocks fastest
+                const dim3 grid(Tpad / 64, (run_slots + 15) / 16);
+                hipLaunchKernelGGL((qpg_gemm_q6k_kernel<1, 4>), grid, dim3(512), 16 * 1024, st, r, im, C, ldp, run_slots, slot_base);
+            } else {
+                const dim3 grid(Tpad / 32, (run_slots + 15) / 16);     // 32 tokens x 256 rows
+                if (parts == 1) hipLaunchKernelGGL((qpg_gemm_q6k_kernel<1, 2>), grid, dim3(512), 8 * 1024, st, r, im, C, ldp, run_slots, slot_base);
+                else hipLaunchKernelGGL((qpg_gemm_q6k_kernel<2, 2>), grid, dim3(512), 16 * 1024, st, r, im, C, ldp, run_slots, slot_base);
+            }
         }
         slot_base += run_slots;
         s0 = s1;

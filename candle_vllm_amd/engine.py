@@ -18,14 +18,16 @@ class Request:
     def __init__(self, rid, prompt, max_new, arrival_step=0):
         self.id, self.prompt, self.max_new, self.arrival_step = rid, list(prompt), int(max_new), int(arrival_step)
         self.tokens = []                     # generated
+        self.logits = []                     # traced runs: the f32 logits row behind every generated token
         self.t_arrive = self.t_first = self.t_done = None
         self.seq = None
 
 
-def run_engine(gm, sched, requests, chunk=0, bt_width=None, ctx_cap=None, stream=0, graph=True, max_steps=100000, swap=None):
+def run_engine(gm, sched, requests, chunk=0, bt_width=None, ctx_cap=None, stream=0, graph=True, max_steps=100000, swap=None, trace_ids=()):
     """drive `requests` to completion; returns a dict of counters.  gm: model.GGUFLLaMa; sched: block_engine.Scheduler.
     bt_width / ctx_cap: the fixed block-table width and context bucket of the captured decode graphs (default: the model's limits).
-    swap(mapping, to_host): optional executor of the scheduler's swap maps (cache_engine.rs:345-385)."""
+    swap(mapping, to_host): optional executor of the scheduler's swap maps (cache_engine.rs:345-385).
+    trace_ids: requests whose logits row is kept for every token they sample (Request.logits; parity runs, never timed runs)."""
     import torch
     from . import ops as cvo
     eng = sched.block_engine
@@ -63,6 +65,7 @@ def run_engine(gm, sched, requests, chunk=0, bt_width=None, ctx_cap=None, stream
             logits = gm.forward_prefill(meta)
             toks = cvo.argmax(logits).cpu().numpy()
             sampled = set(sched.filter_prefill_finished(out.scheduled)) if chunk else set(out.scheduled)
+            rows = {row: logits[row].cpu().numpy() for row, gid in enumerate(out.scheduled) if gid in trace_ids}
             stats["prompt_steps"] += 1
             stats["prompt_tokens"] += len(meta["input_ids"])
         else:
@@ -75,6 +78,10 @@ def run_engine(gm, sched, requests, chunk=0, bt_width=None, ctx_cap=None, stream
             gm.decode_step(stream)
             toks = gm.read_tokens(stream)
             sampled = set(out.scheduled)
+            rows = {}
+            if any(gid in trace_ids for gid in out.scheduled):
+                lg = gm.logits_numpy(B)
+                rows = {row: lg[row].copy() for row, gid in enumerate(out.scheduled) if gid in trace_ids}
             stats["decode_steps"] += 1
             stats["max_batch"] = max(stats["max_batch"], B)
             stats["batch_hist"][B] = stats["batch_hist"].get(B, 0) + 1
@@ -87,6 +94,8 @@ def run_engine(gm, sched, requests, chunk=0, bt_width=None, ctx_cap=None, stream
             if not r.tokens:
                 r.t_first = now
             r.tokens.append(tok)
+            if row in rows:
+                r.logits.append(rows[row])
             r.seq.add_token(tok)
             if len(r.tokens) >= r.max_new:
                 r.t_done = now

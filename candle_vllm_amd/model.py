@@ -394,6 +394,10 @@ class GGUFLLaMa:
         _check(lib.mi355_llama_decode_read_tokens(self.h, out.ctypes.data, stream), "read_tokens")
         return out
 
+    def set_attention_numerics(self, mode):
+        """parity mode (tests): 1 = decode attention with the reference CPU path's bf16 rounding points (models/mod.rs:1288-1306)"""
+        _check(lib.mi355_llama_set_attention_numerics(self.h, int(mode)), "set_attention_numerics")
+
     def set_graph(self, enable):
         """False / True, or 2 = capture tensor-parallel steps too (RCCL inside the graph; opt-in)"""
         _check(lib.mi355_llama_set_graph(self.h, 2 if enable == 2 else (1 if enable else 0)), "set_graph")

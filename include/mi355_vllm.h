@@ -126,6 +126,16 @@ int mi355_reshape_and_cache_fp8(const void* k, const void* v, void* key_cache, v
                                 const int64_t* slot_mapping, int32_t num_tokens, int32_t num_kv_heads,
                                 int32_t head_dim, int32_t block_size, int32_t layout, float k_scale, float v_scale,
                                 int64_t stream);
+/* PARITY MODE (tests): decode attention with the reference CPU path's rounding points -- `NaiveAttention::forward` on bf16
+ * tensors, models/mod.rs:1288-1306: bf16 scores, `* scale` in bf16, bf16 probabilities, f32-accumulated P.V returned as bf16 --
+ * and the oracle's summation orders.  bf16 q / cache / out, PAGED or FLASH layout; one workgroup per (head, sequence), slow by
+ * design.  The product kernels above keep scores and probabilities in f32.  mi355_llama_set_attention_numerics(model, 1) routes
+ * the GGUF host layer's decode steps through it. */
+int mi355_paged_attention_reference_numerics(void* out, const void* q, const void* key_cache, const void* value_cache,
+                                             const uint32_t* block_tables, const uint32_t* context_lens, int32_t num_seqs,
+                                             int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                                             int32_t max_blocks_per_seq, int32_t max_context_len, float scale, int32_t layout,
+                                             int64_t stream);
 /* partition_size 0 = one pass (v1; exp_sums / max_logits / tmp_out may be NULL), else v2 temporaries as above */
 int mi355_paged_attention_fp8(void* out, float* exp_sums, float* max_logits, float* tmp_out, const void* q,
                               const void* key_cache, const void* value_cache, const uint32_t* block_tables,
@@ -470,6 +480,8 @@ int mi355_llama_decode_begin(void* model, const uint32_t* tokens_host, const uin
  * communicator is device-native (RCCL on its side stream joins the capture as a fork / join, the one-shot peer kernel is a
  * plain node); with host-supplied collectives (mi355_comm_create_external) they stay eager. */
 int mi355_llama_set_graph(void* model, int32_t enable);
+/* parity mode of the decode attention: 0 = product kernels, 1 = mi355_paged_attention_reference_numerics (tests only) */
+int mi355_llama_set_attention_numerics(void* model, int32_t mode);
 int mi355_llama_decode_step(void* model, int64_t stream);
 int mi355_llama_decode_read_tokens(void* model, uint32_t* host_out, int64_t stream);
 float* mi355_llama_logits_ptr(void* model);

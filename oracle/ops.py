@@ -259,6 +259,36 @@ def paged_attention_decode(q, key_cache, value_cache, block_tables, context_lens
     return round_bf16(out)
 
 
+def paged_attention_decode_bf16_tensors(q, key_cache, value_cache, block_tables, context_lens, scale, flash_layout):
+    """The same attention with the reference CPU path's OWN rounding points (NaiveAttention::forward on bf16 tensors,
+    src/openai/models/mod.rs:1288-1306): `q.matmul(k^T)` returns bf16, `* scale` rounds to bf16 again, `softmax_last_dim`
+    returns bf16 probabilities (computed in f32 from the bf16 scores), `attn.matmul(v)` accumulates in f32 and returns bf16.
+    Summation in f32, in index order (what oracle.c's bf16-attention mode and the GPU's parity-mode kernel do)."""
+    B, H, D = q.shape
+    out = np.zeros((B, H, D), np.float32)
+    for b in range(B):
+        n = int(context_lens[b])
+        if n == 0:
+            continue
+        k, v = gather_kv(key_cache, value_cache, block_tables[b], n, flash_layout)
+        k = bf16_bits_to_f32(k)
+        v = bf16_bits_to_f32(v)
+        g = H // k.shape[1]
+        for h in range(H):
+            kh, vh, qh = k[:, h // g, :], v[:, h // g, :], q[b, h].astype(np.float32)
+            s = np.zeros(n, np.float32)
+            for d in range(D):                                         # index order, f32
+                s = s + kh[:, d] * qh[d]
+            s = round_bf16(round_bf16(s) * np.float32(scale))
+            e = np.exp((s - s.max()).astype(np.float32)).astype(np.float32)
+            p = round_bf16((e.astype(np.float64) / e.astype(np.float64).sum()).astype(np.float32))
+            o = np.zeros(D, np.float32)
+            for t in range(n):
+                o = o + p[t] * vh[t]
+            out[b, h] = round_bf16(o)
+    return out
+
+
 def copy_blocks(key_caches, value_caches, block_mapping_pairs):
     """src/backend/cache.rs:103-162: for every layer and every (src,dst) pair copy block src->dst
     of K and of V (dim 0 = block).  block_mapping_pairs: flat [src0,dst0,src1,dst1,...]."""

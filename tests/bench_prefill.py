@@ -28,12 +28,12 @@ def main():
             if mode == 0 and T > 512:
                 continue
             M.lib.mi355_set_tuning(6, mode)
-            for qv in ([int(v) for v in os.environ.get("PF_QPG", "0").split(",")] if mode == 1 else [0]):
+            for qv in ([int(v) for v in os.environ.get("PF_QPG", "2").split(",")] if mode == 1 else [0]):
                 M.lib.mi355_set_tuning(11, qv)
                 for dbg in ([int(v) for v in os.environ.get("PF_DBG", "0").split(",")] if mode == 1 else [0]):
                     M.lib.mi355_set_tuning(2, dbg)
-                    # PF_ATTN="0,1": A/B of the prompt attention on the same model (tuning key 47: 1 = the LDS-DMA experiment)
-                    for attn in [int(v) for v in os.environ.get("PF_ATTN", "0").split(",")]:
+                    # PF_ATTN="0,1": A/B of the prompt attention on the same model (tuning key 47: 1 = the LDS-ring kernel, the default; 0 = register-fed)
+                    for attn in [int(v) for v in os.environ.get("PF_ATTN", "1").split(",")]:
                         M.lib.mi355_set_tuning(47, attn)
                         gm.forward_prefill(meta)
                         t0 = time.perf_counter()
@@ -41,8 +41,8 @@ def main():
                         dt = time.perf_counter() - t0
                         flops = 2.0 * (gm.weight_bytes / 0.5625) * T          # ~ 2 * params * tokens (Q4_K: 0.5625 B / weight)
                         print(f"prefill T={T:5d} gemm={mode} variant={qv} dbg={dbg} attn={attn}: {T / dt:9.1f} tok/s  {dt * 1e3:8.1f} ms  ~{flops / dt / 1e12:6.1f} TFLOP/s", flush=True)
-                    M.lib.mi355_set_tuning(47, 0)
-    M.lib.mi355_set_tuning(11, 0)
+                    M.lib.mi355_set_tuning(47, 1)
+    M.lib.mi355_set_tuning(11, 2)
     M.lib.mi355_set_tuning(2, 0)
     M.lib.mi355_set_tuning(6, 1)
 

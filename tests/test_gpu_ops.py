@@ -721,3 +721,30 @@ def test_prompt_gemm_fused_epilogue(cv, T, N, K):
         assert rel_err(got[k], want[k]) < WIDE_TOL, (k, rel_err(got[k], want[k]))
         assert rel_err(got[k], base[k]) < 1e-5, (k, rel_err(got[k], base[k]))
 
+
+
+@pytest.mark.parametrize("flash", [False, True])
+def test_paged_attention_reference_numerics_mode(cv, lib, flash):
+    """PARITY MODE kernel (mi355_paged_attention_reference_numerics): the reference CPU path's bf16 rounding points -- bf16 scores, bf16
+    `* scale`, bf16 probabilities, bf16 output (models/mod.rs:1288-1306) -- against the numpy restatement with the same points.  The two
+    differ only where an f32 rounding difference (fused multiply-add vs multiply + add) straddles a bf16 tie: almost every element
+    bit-equal, none further than one bf16 ulp of the largest output; and it is NOT the product kernel (f32 scores): the modes differ."""
+    rng = np.random.default_rng(77)
+    H, Hkv, D, bs = 8, 2, 128, 16
+    ctx = [70, 1, 33, 257]
+    q, kc, vc, bt, cl = _attn_case(rng, len(ctx), H, Hkv, D, bs, ctx, flash)
+    scale = 1 / np.sqrt(D)
+    want = O.paged_attention_decode_bf16_tensors(O.round_bf16(q), kc, vc, bt, cl, scale, flash)
+    qd, kcd, vcd = dev(q, torch.bfloat16), bf16_dev(kc), bf16_dev(vc)
+    btd, cld = dev(bt.astype(np.int32)), dev(cl.astype(np.int32))
+    out = torch.empty((len(ctx), H, D), dtype=torch.bfloat16, device="cuda")
+    rc = lib.mi355_paged_attention_reference_numerics(out.data_ptr(), qd.data_ptr(), kcd.data_ptr(), vcd.data_ptr(), btd.data_ptr(),
+                                                      cld.data_ptr(), len(ctx), H, Hkv, D, bs, bt.shape[1], max(ctx), float(scale),
+                                                      cv.KV_FLASH if flash else cv.KV_PAGED, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    got = out.float().cpu().numpy()
+    ulp = 2.0 ** -8 * np.abs(want).max()
+    assert np.abs(got - want).max() <= ulp + 1e-9
+    assert (got == want).mean() > 0.98, (got == want).mean()
+    product = O.paged_attention_decode(O.round_bf16(q), kc, vc, bt, cl, scale, flash)
+    assert (want != product).mean() > 0.05                           # the bf16 points are visible: this is a different computation
