@@ -197,14 +197,22 @@ class Pair:
             gm.decode_begin([s["tokens"][-1] for s in seqs], [len(s["tokens"]) for s in seqs], bt,
                             ctx_cap=int(max(seq_lens)) + steps, stream=st)
             worst, equal, ties, done = 0.0, True, 0, 0
-            per_step = []
+            per_step, self_spread = [], None
             for step in range(steps):
                 gm.decode_step(st)
                 got_tok = [int(t) for t in gm.read_tokens(st)]
                 got = gm.logits_numpy(B)
                 meta = O.prepare_decode(seqs, bs)
                 meta["block_tables"] = bt
+                if step == 0 and B == 1:
+                    # How reproducible is the reference's arithmetic itself?  The SAME restatement with its mat-vecs summed in blocked f32
+                    # (O1f) instead of f64 (O1) -- ~1e-6 apart per product, what two thread counts of a CPU backend differ by -- run through
+                    # the same 32 layers with the same bf16 attention tensors: the distance of the two logit rows is the floor under ANY
+                    # end-to-end comparison with the reference CPU path (tools/exp_oracle_self_spread.py: 3.3e-3 at this geometry).
+                    alt = self.orc.decode(meta, self.cache, o2=2 if int(o2) == 0 else 0)
                 ref = self.orc.decode(meta, self.cache, o2=o2)
+                if step == 0 and B == 1:
+                    self_spread = float((np.abs(alt - ref).max(axis=1) / np.abs(ref).max(axis=1)).max())
                 done += 1
                 w = 0.0
                 for b in range(B):
@@ -228,6 +236,7 @@ class Pair:
             cref.lib().orc_llama_set_attn_bf16(0)
         return {"batch": B, "steps_compared": done, "ctx_max": int(max(seq_lens)), "graph": bool(graph), "max_rel_err": worst,
                 "per_step": [round(x, 7) for x in per_step], "tokens_equal": bool(equal), "near_tie_tokens": ties,
+                "oracle_self_spread_f64_vs_f32_dots": self_spread,
                 "mode": "reference-faithful attention numerics on both sides (models/mod.rs:1288-1306)",
                 "oracle": "O1 + bf16 attention tensors (unpinned)" if int(o2) == 0 else "O1f + bf16 attention tensors (unpinned)"}
 
