@@ -124,13 +124,13 @@ def leg_bf16_prompt(T=2048):
             "frac_of_2.5PF_dense_bf16": round(useful / 2500.0, 3)}
 
 
-def leg_gptq_qwen2(steps=32, warmup=4):
+def leg_gptq_qwen2(steps=32, warmup=4, B=1):
     """Qwen2-7B GPTQ 4-bit, group 128: every projection through the marlin_4bit arm (checkpoint layout, Marlin-permuted scales
     un-permuted by index arithmetic), lm_head / embedding 16-bit"""
     import torch
     from candle_vllm_amd import dense_model as DM
     cfg = qwen2_7b()
-    gm = DM.DenseLlama(cfg, max_batch=1, max_blocks_per_seq=80, kv_layout=DM.KV_PAGED)
+    gm = DM.DenseLlama(cfg, max_batch=B, max_blocks_per_seq=80, kv_layout=DM.KV_PAGED)
     g = torch.Generator(device="cuda").manual_seed(3)
     rng = np.random.default_rng(3)
 
@@ -156,22 +156,29 @@ def leg_gptq_qwen2(steps=32, warmup=4):
             qw, sc = packs[(n, k)]
             gm.set_gptq(l, name, qw, sc, group)
             wbytes += (k // 8) * n * 4 + (k // group) * n * 2
-    gm.alloc_kv_cache(80)
-    dt, kv = _dense_graph_loop(gm, cfg, 1, [4096], steps, warmup, 2)
+    ctxs = [4096] if B == 1 else np.random.default_rng(4321).integers(256, 4097, B).tolist()
+    gm.alloc_kv_cache(sum(-(-(int(c) + steps + warmup + 2) // cfg.block_size) for c in ctxs) + 8)
+    dt, kv = _dense_graph_loop(gm, cfg, B, ctxs, steps, warmup, 2)
+    if B > 1:
+        return _result(f"gptq_qwen2_b{B}", f"BASELINE configs[3] shapes at batch {B}: Qwen2-7B GPTQ 4-bit (group 128, marlin_4bit arm), ragged "
+                       "contexts U[256,4096] in paged KV (block 64): the 5..64-token kernels over the tiled 4-bit image", B, steps, dt, wbytes, kv)
     return _result("gptq_qwen2", "BASELINE configs[3] on one GPU: Qwen2-7B GPTQ 4-bit (group 128, marlin_4bit arm), batch 1, ctx 4096 in "
                    "paged KV (block 64); TP=2 needs the driver's multi-GPU run", 1, steps, dt, wbytes, kv)
 
 
-def leg_mixtral_fp8(steps=32, warmup=4, B=1):
-    """Mixtral-8x7B Q4_K GGUF shapes: device router + top-2 + expert mat-vecs + combine, fp8 (e4m3fn) KV cache"""
-    import ctypes
+def leg_gptq_qwen2_b32(steps=12, warmup=3):
+    return leg_gptq_qwen2(steps=steps, warmup=warmup, B=32)
+
+
+def _build_mixtral(B, bps, max_seq=8192, n_layers=32):
+    """Mixtral-8x7B Q4_K GGUF shapes on the device: device router + top-2 + experts, fp8 (e4m3fn) KV cache layout; one random expert per
+    projection (native GGUF blocks on the host) shared by all experts and layers -- the loader repacks and uploads every (layer, expert)
+    copy, so the model is full size on the device.  Returns (model, cfg, weight bytes a single token touches per step, rng, generator)."""
     import torch
     from candle_vllm_amd import model as M
-    cfg = M.ModelDims(hidden=4096, n_layers=32, n_heads=32, n_kv_heads=8, head_dim=128, intermediate=14336, vocab=32000,
-                      rope_theta=1000000.0, max_seq=8192, block_size=64)
+    cfg = M.ModelDims(hidden=4096, n_layers=n_layers, n_heads=32, n_kv_heads=8, head_dim=128, intermediate=14336, vocab=32000,
+                      rope_theta=1000000.0, max_seq=max_seq, block_size=64)
     cfg.n_expert, cfg.n_expert_used = 8, 2
-    K, Wm = steps, warmup
-    bps = -(-(4096 + K + Wm + 2) // cfg.block_size)
     gm = M.GGUFLLaMa(cfg, max_batch=B, max_blocks_per_seq=bps, kv_layout=M.KV_PAGED_FP8)
     lib = M.lib
     gen = torch.Generator(device="cuda").manual_seed(5)
@@ -191,8 +198,7 @@ def leg_mixtral_fp8(steps=32, warmup=4, B=1):
     f32(-1, M.W_TOK_EMBD, emb)
     f32(-1, M.W_OUTPUT_NORM, 1.0 + rng.normal(0, 0.02, hid))
     step_w = tiles(-1, M.W_OUTPUT, cfg.vocab, hid, M.GGML_Q6_K)
-    # one random expert per projection (native GGUF blocks on the host), shared by all experts and layers: the loader
-    # repacks and uploads every (layer, expert) copy, so the model is full size on the device
+
     def native_q4k(n, k):
         b = rng.integers(0, 256, (n, k // 256, 144), dtype=np.uint8)
         b[:, :, 0:2] = np.array([2e-4], np.float16).view(np.uint8)
@@ -208,6 +214,18 @@ def leg_mixtral_fp8(steps=32, warmup=4, B=1):
             for which, blk, n, k in ((M.W_W1, e_up, I, hid), (M.W_W3, e_up, I, hid), (M.W_W2, e_down, hid, I)):
                 M._check(lib.mi355_llama_set_moe_expert(gm.h, l, which, e, M.GGML_Q4_K, blk.ctypes.data, n, k), "set_moe_expert")
         step_w += cfg.n_expert_used * 3 * I * (hid // 256) * 144      # a token touches top-2 of the 8 experts
+    return gm, cfg, step_w, rng, gen
+
+
+def leg_mixtral_fp8(steps=32, warmup=4, B=1):
+    """Mixtral-8x7B Q4_K GGUF shapes: device router + top-2 + expert mat-vecs + combine, fp8 (e4m3fn) KV cache"""
+    import torch
+    from candle_vllm_amd import model as M
+    K, Wm = steps, warmup
+    bps = -(-(4096 + K + Wm + 2) // 64)
+    gm, cfg, step_w, rng, gen = _build_mixtral(B, bps)
+    lib = M.lib
+    hid, I, H, Hkv, D = cfg.hidden, cfg.intermediate, cfg.n_heads, cfg.n_kv_heads, cfg.head_dim
     ctxs = [4097] if B == 1 else np.random.default_rng(4321).integers(256, 4097, B).tolist()       # B > 1: ragged contexts as the bf16 leg
     nblk = [-(-(int(c_) + K + Wm + 2) // cfg.block_size) for c_ in ctxs]
     num_blocks = sum(nblk) + 8
@@ -269,7 +287,7 @@ def leg_engine_b32(n_req=32, new_lo=48, new_hi=80, parity_reqs=2):
     bps = -(-(4096 + new_hi + 2) // cfg.block_size)
     nblk = int(sum(-(-(int(p) + int(n) + 1) // cfg.block_size) for p, n in zip(plens, n_new))) + 64
     gm = M.GGUFLLaMa(cfg, max_batch=n_req, max_blocks_per_seq=bps, kv_layout=M.KV_PAGED)
-    gm.load_synthetic(seed=1235, recipe="q4_k_m")
+    gm.load_synthetic(seed=1235, recipe="q4_k_m", scale=0.2)      # branch gain < 1 as in a trained checkpoint: logits can be compared (timing is value-independent)
     gm.alloc_kv_cache(nblk)
     prompts = [rng.integers(0, cfg.vocab, int(p)).tolist() for p in plens]
 
@@ -343,8 +361,50 @@ def leg_engine_b32(n_req=32, new_lo=48, new_hi=80, parity_reqs=2):
     return r
 
 
-LEGS = {"bf16_b32": leg_bf16_b32, "gptq_qwen2": leg_gptq_qwen2, "mixtral_fp8": leg_mixtral_fp8, "bf16_prompt": leg_bf16_prompt, "mixtral_fp8_b32": leg_mixtral_fp8_b32, "engine_b32": leg_engine_b32}
-NO_PARITY_LEG = {"bf16_prompt", "mixtral_fp8_b32", "engine_b32"}   # covered by tests: test_gpu_linear.py (>= 96 tokens), test_gpu_dense_model.py; test_gpu_model.py (device-grouped experts)
+def leg_mixtral_prompt_16k(T=16384, chunk=8192):
+    """BASELINE configs[4] at its stated size on one GPU: Mixtral-8x7B Q4_K, fp8 KV cache, a 16 384-token prompt
+    prefilled in two 8192-token chunks (`prefill_chunk_size`, pipelines/inputs.rs:90-230, main.rs:635-638): the scheduler admits the
+    first chunk, re-queues the sequence, the second chunk attends over the first through the e4m3 cache (cached prefix) -- prompt tokens/s
+    over both steps.  Full-size parity of this path: tests/test_gpu_fullsize.py::test_mixtral_chunked_prefill_16k_one_layer_full_width."""
+    import torch
+    from candle_vllm_amd import block_engine as be
+    from candle_vllm_amd import ops as cvo
+    bps = -(-(T + 8) // 64)
+    gm, cfg, step_w, rng, gen = _build_mixtral(1, bps, max_seq=T + 64)
+    gm.alloc_kv_cache(bps + 4)
+    prompt = rng.integers(0, cfg.vocab, T).tolist()
+
+    def one_pass():
+        sched = be.Scheduler(block_size=cfg.block_size, num_gpu_blocks=bps + 4, num_cpu_blocks=0, max_num_parallel_reqs=1,
+                             max_num_batched_tokens=chunk, prefill_chunk_size=chunk)
+        eng = sched.block_engine
+        seq = eng.new_sequence(0, prompt)
+        sched.add_sequence(0, [seq])
+        steps, tok = [], None
+        while True:
+            out = sched.schedule()
+            assert out.is_prompt and out.scheduled == [0]
+            meta = eng.prepare_prompt([seq], chunk=chunk)
+            t0 = time.perf_counter()
+            lg = gm.forward_prefill(meta)
+            torch.cuda.synchronize()
+            steps.append((len(meta["input_ids"]), time.perf_counter() - t0))
+            if sched.filter_prefill_finished(out.scheduled):
+                tok = int(cvo.argmax(lg)[0])
+                break
+        return steps, tok
+    one_pass()                                                        # warm-up: workspaces of both chunk shapes
+    steps, tok = one_pass()
+    dt = sum(t for _, t in steps)
+    flops = 2.0 * (step_w - cfg.vocab * (cfg.hidden // 256) * 210) / 0.5625 * T   # projections + top-2 experts per token (Q4_K: 0.5625 B / weight); lm_head runs once
+    return {"config": "mixtral_prompt_16k", "workload": f"BASELINE configs[4] at size: Mixtral-8x7B Q4_K shapes, fp8 e4m3 KV cache, {T}-token prompt "
+            f"as {len(steps)} chunks of {chunk} tokens through the scheduler (cached-prefix prompt attention over the fp8 cache, experts grouped per chunk)",
+            "value": round(T / dt, 1), "unit": "prompt tokens/s", "tokens": T, "chunks": [[n, round(t * 1e3, 1)] for n, t in steps],
+            "ms": round(dt * 1e3, 1), "useful_TFLOPs": round(flops / dt / 1e12, 1), "first_token": tok}
+
+
+LEGS = {"bf16_b32": leg_bf16_b32, "gptq_qwen2": leg_gptq_qwen2, "mixtral_fp8": leg_mixtral_fp8, "bf16_prompt": leg_bf16_prompt, "mixtral_fp8_b32": leg_mixtral_fp8_b32, "gptq_qwen2_b32": leg_gptq_qwen2_b32, "engine_b32": leg_engine_b32, "mixtral_prompt_16k": leg_mixtral_prompt_16k}
+NO_PARITY_LEG = {"bf16_prompt", "mixtral_fp8_b32", "engine_b32", "mixtral_prompt_16k"}   # covered by tests: test_gpu_linear.py (>= 96 tokens), test_gpu_dense_model.py; test_gpu_model.py (device-grouped experts)
 
 
 def leg_parity(name):
@@ -357,8 +417,9 @@ def leg_parity(name):
         r = p.run(ctx=4097, steps=2)
     else:
         from tests.fullsize_dense import DensePair, ragged_batch32
-        p = DensePair(name, std=0.008 if name == "bf16_b32" else 0.004)
-        r = p.run(ragged_batch32(np.random.default_rng(4321)) if name == "bf16_b32" else [4097])
+        base = "gptq_qwen2" if name.startswith("gptq_qwen2") else name
+        p = DensePair(base, std=0.008 if base == "bf16_b32" else 0.004, max_batch=32 if name == "gptq_qwen2_b32" else None)
+        r = p.run(ragged_batch32(np.random.default_rng(4321)) if name in ("bf16_b32", "gptq_qwen2_b32") else [4097])
     del p
     return {k: (round(v, 7) if isinstance(v, float) else v) for k, v in r.items() if k not in ("per_layer", "units")}
 

@@ -158,8 +158,10 @@ class GGUFLLaMa:
             for name, slot in _SLOT.items():
                 qw(l, slot, lw[name])
 
-    def load_synthetic(self, seed=1235, recipe="q4_k_m"):
-        """Random-init weights of the configured architecture, generated on the GPU already in tile order."""
+    def load_synthetic(self, seed=1235, recipe="q4_k_m", scale=1.0):
+        """Random-init weights of the configured architecture, generated on the GPU already in tile order.  scale: std of the
+        projections relative to the default (1.0 = std ~0.04: every branch has gain >> 1 and the 32-layer stack amplifies rounding
+        noise chaotically -- fine for timing; 0.2 = branch gain < 1 as in a trained checkpoint, for comparisons of logits)"""
         cfg = self.cfg
         gen = torch.Generator(device="cuda")
         gen.manual_seed(seed)
@@ -179,7 +181,7 @@ class GGUFLLaMa:
         def qw(layer, which, name, n, k):
             t = q4km_type_for(name, layer, cfg.n_layers) if recipe == "q4_k_m" else \
                 (GGML_Q6_K if name == "output" else GGML_Q4_K)
-            tiles = random_tiles(t, n, k, "cuda", gen)
+            tiles = random_tiles(t, n, k, "cuda", gen, d_scale=0.0025 * scale)
             self._keep.append(tiles)
             _check(lib.mi355_llama_set_qweight_tiles(self.h, layer, which, t, tiles.data_ptr(), n, k), "set_tiles")
             nbytes = (n // 16) * (k // 256) * _TILE_BYTES[t]

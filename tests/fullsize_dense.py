@@ -33,7 +33,7 @@ def ragged_batch32(rng):
 
 
 class DensePair:
-    def __init__(self, kind, log=None, std=None, seed=77, num_blocks=448):
+    def __init__(self, kind, log=None, std=None, seed=77, num_blocks=448, max_batch=None):
         import torch
         from candle_vllm_amd import dense_model as DM
         self.torch, self.DM, self.kind = torch, DM, kind
@@ -47,6 +47,8 @@ class DensePair:
             self.max_batch, gptq = 1, True
         else:
             raise ValueError(kind)
+        if max_batch:
+            self.max_batch = int(max_batch)
         self.cfg = cfg
         # std: the bench's synthetic weights (0.02 dense; scales 0.002..0.01 GPTQ) make every branch's gain > 1 -- fine for the
         # per-layer checks, chaotic end to end; `std` scales them down to trained-checkpoint-like gains for the end-to-end checks

@@ -33,21 +33,21 @@ def _native(rng, ggml_type, n, k, scale):
 
 
 class MoePair:
-    def __init__(self, n_layers=32, scale=1.0, seed=31, log=None):
+    def __init__(self, n_layers=32, scale=1.0, seed=31, log=None, max_seq=8192, ctx_tokens=4096 + 16):
         import torch
         from candle_vllm_amd import model as M
         self.torch, self.M = torch, M
         self.log = log or (lambda *a: None)
         lib = M.lib
         cfg = OL.LlamaConfig(vocab=32000, hidden=4096, n_layers=n_layers, n_heads=32, n_kv_heads=8, head_dim=128, intermediate=14336,
-                             rms_eps=1e-5, rope_theta=1000000.0, max_seq=8192, block_size=64)
+                             rms_eps=1e-5, rope_theta=1000000.0, max_seq=max_seq, block_size=64)
         self.cfg = cfg
         gcfg = M.ModelDims(hidden=4096, n_layers=n_layers, n_heads=32, n_kv_heads=8, head_dim=128, intermediate=14336, vocab=32000,
-                           rope_theta=1000000.0, max_seq=8192, block_size=64)
+                           rope_theta=1000000.0, max_seq=max_seq, block_size=64)
         gcfg.n_expert, gcfg.n_expert_used = 8, 2
         rng = np.random.default_rng(seed)
         t0 = time.time()
-        self.bps = -(-(4096 + 16) // cfg.block_size)
+        self.bps = -(-ctx_tokens // cfg.block_size)
         gm = M.GGUFLLaMa(gcfg, max_batch=1, max_blocks_per_seq=self.bps, kv_layout=M.KV_PAGED_FP8)
         self.gm = gm
         hid, I, H, Hkv, D = cfg.hidden, cfg.intermediate, cfg.n_heads, cfg.n_kv_heads, cfg.head_dim
@@ -185,3 +185,75 @@ class MoePair:
             seqs[0]["tokens"].append(want)
         res.update({"steps_compared": done, "logits_max_rel_err": worst, "tokens_equal": bool(equal), "near_tie_tokens": ties})
         return res
+
+
+    # ------------------------------------------------------------------------------------------------ configs[4]: chunked prefill at size
+    def run_chunked_prompt(self, T=16384, chunk=8192):
+        """BASELINE configs[4]'s prompt: T tokens prefilled in chunks of `chunk` through the C++ scheduler (prefill_chunk_size,
+        pipelines/inputs.rs:90-230): every chunk after the first attends over its predecessors through the e4m3 cache (cached prefix).
+        For a ONE-layer model of full width the oracle needs only cheap pieces: q / k / v of all T tokens (one O1f product each), the
+        e4m3 cache bytes, and -- for the LAST token, whose logits the second chunk returns -- attention over all T keys, the routed
+        experts, the head.  Compared: the device cache bytes of the whole prompt (both chunks' writes) and the final logits."""
+        from candle_vllm_amd import block_engine as be
+        from oracle import llama as OL2
+        cfg, gm, M, rng = self.cfg, self.gm, self.M, self.rng
+        assert cfg.n_layers == 1, "the oracle restatement below is written for one layer"
+        bs, hid, H, Hkv, D = cfg.block_size, cfg.hidden, cfg.n_heads, cfg.n_kv_heads, cfg.head_dim
+        prompt = [int(t) for t in rng.integers(0, cfg.vocab, T)]
+        sched = be.Scheduler(block_size=bs, num_gpu_blocks=self.num_blocks, num_cpu_blocks=0, max_num_parallel_reqs=1,
+                             max_num_batched_tokens=chunk, prefill_chunk_size=chunk)
+        eng = sched.block_engine
+        seq = eng.new_sequence(0, prompt)
+        sched.add_sequence(0, [seq])
+        chunks, got, metas = [], None, []
+        while True:
+            out = sched.schedule()
+            assert out.is_prompt and out.scheduled == [0]
+            meta = eng.prepare_prompt([seq], chunk=chunk)
+            metas.append(meta)
+            lg = gm.forward_prefill(meta)
+            chunks.append(len(meta["input_ids"]))
+            if sched.filter_prefill_finished(out.scheduled):
+                got = lg.cpu().numpy()[0]
+                break
+        assert sum(chunks) == T and len(chunks) == -(-T // chunk), chunks
+        assert int(metas[-1]["context_lens"][0]) == T                  # the last chunk saw the whole prompt as its context
+        kc_dev, vc_dev = gm.kv_download_u8(0)
+        # ---- oracle, layer 0
+        t0 = time.time()
+        lw, W = self.W["layers"][0], self.W
+        qmm = lambda x, tw: cref.qmatmul(np.ascontiguousarray(x, np.float32), tw[1], tw[0], 2)      # O1f (f32 blocked dots)
+        xs = W["tok_embd"][np.asarray(prompt)].astype(np.float32)
+        x = O.rms_norm(xs, lw["attn_norm"], cfg.rms_eps)
+        cos, sin = O.rope_tables(cfg.rope_theta, D, cfg.max_seq)
+        pos = np.arange(T)
+        k = O.rope_apply(qmm(x, lw["wk"]).reshape(T, Hkv, D), cos, sin, pos, interleaved=True)
+        v = qmm(x, lw["wv"]).reshape(T, Hkv, D)
+        table = np.concatenate([m["block_tables"][0] for m in metas[-1:]])          # the full table of the sequence
+        slots = np.concatenate([m["slot_mapping"] for m in metas])
+        ks, vs = O.kv_cache_shapes(self.num_blocks, bs, Hkv, D, 1, False)
+        kc, vc = np.zeros(ks, np.uint8), np.zeros(vs, np.uint8)
+        O.reshape_and_cache_fp8(O.round_bf16(k), O.round_bf16(v), kc, vc, slots, False)
+        used = np.unique(table[: -(-T // bs)])
+        kq_eq = float((kc_dev[used] == kc[used]).mean())
+        vq_eq = float((vc_dev[used] == vc[used]).mean())
+        # an e4m3 byte differs where the prompt GEMM's 3e-4 moved a bf16 value across an fp8 rounding boundary: never by more than one code
+        kd = np.abs(O.e4m3fn_to_f32(kc_dev[used]) - O.e4m3fn_to_f32(kc[used]))
+        k_ulp = float((kd / np.maximum(np.abs(O.e4m3fn_to_f32(kc[used])), 2.0 ** -6)).max())
+        # the last token: attention over all T keys read back from the ORACLE's e4m3 cache
+        q_last = O.rope_apply(qmm(x[-1:], lw["wq"]).reshape(1, H, D), cos, sin, pos[-1:], interleaved=True)
+        kb, vb = O.fp8_cache_as_bf16_bits(kc, vc, False)
+        kk, vv = O.gather_kv(kb, vb, table, T, False)
+        y = O.prefill_attention(O.round_bf16(q_last), O.bf16_bits_to_f32(kk), O.bf16_bits_to_f32(vv), 1.0 / np.sqrt(float(D)), cached=T - 1)
+        x1 = qmm(y.reshape(1, H * D), lw["wo"]) + xs[-1:]
+        keep = OL2._qmm
+        OL2._qmm = lambda a, tw, o2: qmm(a, tw)
+        try:
+            x2 = OL2.moe_forward(O.rms_norm(x1, lw["ffn_norm"], cfg.rms_eps), lw, 2) + x1
+        finally:
+            OL2._qmm = keep
+        ref = qmm(O.rms_norm(x2, W["output_norm"], cfg.rms_eps), W["output"])[0]
+        err = float(np.abs(got - ref).max() / np.abs(ref).max())
+        return {"leg": "mixtral_chunked_prefill", "tokens": T, "chunks": chunks, "layers": 1, "logits_max_rel_err": err,
+                "tokens_equal": bool(int(got.argmax()) == int(ref.argmax())), "k_cache_bytes_equal": kq_eq, "v_cache_bytes_equal": vq_eq,
+                "k_cache_max_rel_diff": k_ulp, "oracle": "O1f (unpinned), fp8 KV", "oracle_s": round(time.time() - t0, 1)}

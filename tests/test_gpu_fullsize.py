@@ -219,3 +219,21 @@ def test_mixtral_8x7b_q4k_fp8_kv_batch1_ctx4096_every_layer_and_end_to_end(lib):
     del p
     assert r["worst_layer_rel_err"] < MOE_LAYER and r["median_layer_rel_err"] < 1e-4 and r["lm_head_rel_err"] < 1e-4, r
     assert r["logits_max_rel_err"] < MOE_E2E and r["tokens_equal"] and r["steps_compared"] == 2, r
+
+
+def test_mixtral_chunked_prefill_16k_one_layer_full_width(lib):
+    """configs[4] at its stated prompt size: a 16 384-token prompt in two 8192-token chunks through the scheduler,
+    Mixtral-8x7B width (hidden 4096, 8 experts of 14336, top-2 on the device), fp8 e4m3 KV cache, block 64 -- ONE layer, so that the
+    oracle is affordable (tests/fullsize_moe.py run_chunked_prompt): the e4m3 cache bytes of all 16 384 positions and the logits the
+    second chunk returns (prefill attention over a cached prefix of 8192 tokens in the fp8 cache, experts grouped per chunk)."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from tests.fullsize_moe import MoePair
+    p = MoePair(n_layers=1, scale=0.2, max_seq=16384 + 64, ctx_tokens=16384 + 64)
+    r = p.run_chunked_prompt(T=16384, chunk=8192)
+    print(r)
+    del p
+    assert r["chunks"] == [8192, 8192]
+    assert r["k_cache_bytes_equal"] > 0.99 and r["v_cache_bytes_equal"] > 0.99, r       # flips of one e4m3 code only
+    assert r["k_cache_max_rel_diff"] <= 0.13, r                                            # one e4m3 step: 2^-3 of the value
+    assert r["logits_max_rel_err"] < 3e-3 and r["tokens_equal"], r                       # the prompt path's bound (one f16 plane) through one layer
