@@ -263,11 +263,11 @@ def bench_prefill(gm, cfg, perm, blocks_per_seq, T=2048):
 
 
 def experiments_leg():
-    """Opt-in experiment kernels measured beside the product path, in a SEPARATE process (a fault there cannot touch the judged
-    numbers): the ragged batch-32 step with the balanced LDS-DMA attention stream (mi355_set_tuning(44, 3) + 64-token partitions,
-    DESIGN.md section 4) against the default on the same model, alternated.  Reported only -- `batch32` above is the product."""
+    """A/B of a product dispatch decision, in a SEPARATE process (a fault there cannot touch the judged numbers): the ragged batch-32 step
+    with the balanced LDS-DMA attention stream (the step drivers' choice at >= 64 (sequence, kv head) pairs since round 4; tuning key 44
+    = 1) against the one-partition MFMA waves it replaced (key 44 = 5), same model, alternated.  Reported only."""
     import subprocess
-    env = dict(os.environ, B32_STEPS="16", B32_AB="5=0,44=1;5=64,44=3;5=0,44=1;5=64,44=3")
+    env = dict(os.environ, B32_STEPS="16", B32_AB="44=1;44=5;44=1;44=5")
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exp_b32.py")], env=env, stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT, text=True, timeout=240)
@@ -275,10 +275,11 @@ def experiments_leg():
         return {"error": repr(e)}
     rows = [ln.split() for ln in r.stdout.splitlines() if "tok/s" in ln]
     try:
-        base = [float(x[1]) for x in rows if x[0] == "5=0,44=1"]
-        exp = [float(x[1]) for x in rows if x[0] == "5=64,44=3"]
-        return {"batch32_ragged_tok_s": {"product_default": base, "lds_dma_attention_stream": exp},
-                "note": "opt-in experiment (tuning key 44 = 3), separate process, same model, alternated; not the judged path",
+        base = [float(x[1]) for x in rows if x[0] == "44=1"]
+        exp = [float(x[1]) for x in rows if x[0] == "44=5"]
+        return {"batch32_ragged_tok_s": {"product_default_lds_dma_attention_stream": base, "one_partition_mfma_waves": exp},
+                "note": "A/B of the attention kernel choice at batch 32 (tuning key 44: 1 = default, 5 = never the stream), separate process, "
+                        "same model, alternated; `batch32` above is the product",
                 "rc": r.returncode}
     except Exception as e:
         return {"error": repr(e), "tail": r.stdout[-400:]}

@@ -5,17 +5,21 @@ from ._lib import lib, LIB_PATH  # noqa: F401
 
 import contextlib as _contextlib
 
-# defaults of the tuning keys whose default is not 0 (include/mi355_vllm.h): what `tuning` restores when a key was never set before
-_TUNING_DEFAULTS = {3: 1, 6: 1, 9: 1, 10: 1024, 11: 2, 12: 96, 14: 1, 17: 2, 21: 8, 36: 96, 38: 4, 41: 1, 42: 1, 44: 1, 47: 1, 48: 1}
+
+class TuningKeyUnavailable(RuntimeError):
+    """the key belongs to probe builds (tools/build_probe_lib.sh); the product library honours the ten keys of include/mi355_vllm.h"""
 
 
 @_contextlib.contextmanager
 def tuning(key, value):
-    """scoped `mi355_set_tuning`: the key holds `value` inside the block and what it held before (or its default) afterwards --
-    also when the block raises.  The A/B switches are process-global state of the library; tests use this form."""
+    """scoped `mi355_set_tuning`: the key holds `value` inside the block and what it held before afterwards -- also when the block
+    raises.  The A/B switches are process-global state of the library; tests use this form.  The library itself knows every product
+    key's live value (mi355_get_tuning), so nothing about defaults is restated here."""
+    if not lib.mi355_tuning_supported(key):
+        raise TuningKeyUnavailable(f"tuning key {key} is not honoured by this build of the library")
     prev = lib.mi355_get_tuning(key)
-    if prev == -2 ** 31:
-        prev = _TUNING_DEFAULTS.get(key, 0)
+    if prev == -2 ** 31:                                  # a probe-build key that was never set: its default is 0 / "heuristic"
+        prev = 0
     lib.mi355_set_tuning(key, value)
     try:
         yield

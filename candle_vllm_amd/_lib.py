@@ -191,8 +191,8 @@ for _n in ("mi355_be_swap_out", "mi355_be_swap_in"):
 for _n in ("mi355_be_finalize_swap_out", "mi355_be_rollback_swap_out", "mi355_be_finalize_swap_in",
            "mi355_be_rollback_swap_in"):
     _sig(_n, None, [c_vp, c_i64])
+_sig("mi355_tuning_supported", c_i32, [c_i32])
 _sig("mi355_be_test_refuse_swaps", None, [c_vp, c_i32, c_i32])
-_sig("mi355_internal_qw1_wgs_touching", c_i32, [c_i32, c_vp, c_vp, c_i32])
 _sig("mi355_pc_create", c_vp, [c_i32] * 4)
 _sig("mi355_pc_insert", c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32])
 _sig("mi355_pc_match", c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32])

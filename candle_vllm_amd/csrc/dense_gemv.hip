@@ -736,7 +736,20 @@ static int g_tune_small_nw_big = 0;    // tuning key 35: the same for K > 8192
 static int g_tune_small_off = 0;       // tuning key 31: 1 = keep 1..4 tokens on dense_kernel (A/B measurements)
 static int g_tune_small_norope = 0;    // tuning key 34: 1 = RoPE and the cache write stay in their own launch
 static int g_tune_small_nonorm = 0;    // tuning key 32: 1 = never norm on the way in (the host layer launches the norm separately)
-void mi355_dense_set_small(int key, int v) { if (key == 30) g_tune_small_nw = v; else if (key == 31) g_tune_small_off = v; else if (key == 32) g_tune_small_nonorm = v; else if (key == 34) g_tune_small_norope = v; else if (key == 35) g_tune_small_nw_big = v; else if (key == 36 && v > 0) g_tune_gemm_min_t = v; else if (key == 37) g_tune_wide_off = v; else if (key == 38) g_tune_wide_nw = v; else if (key == 39) g_tune_gptq_gemm_off = v; }
+// tuning key 30 (product): bit mask of folded launches switched OFF -- 1 = the 1..4-token 4-bit kernel, 2 = no norm on the way in,
+// 4 = RoPE and the cache write in their own launch, 8 = the LDS-shared-activation 16-bit kernel, 16 = the one-pass 4-bit prompt GEMM.
+// Probe builds: 33 / 35 waves per workgroup of the 1..4-token kernel (hidden-sized K / long K), 36 tokens from which 16-bit
+// projections take the MFMA GEMM, 38 waves per workgroup of the LDS-shared-activation kernel.
+void mi355_dense_set_small(int key, int v) {
+    if (key == 30) {
+        g_tune_small_off = v & 1; g_tune_small_nonorm = (v >> 1) & 1; g_tune_small_norope = (v >> 2) & 1;
+        g_tune_wide_off = (v >> 3) & 1; g_tune_gptq_gemm_off = (v >> 4) & 1;
+    }
+    else if (key == 33) g_tune_small_nw = v;
+    else if (key == 35) g_tune_small_nw_big = v;
+    else if (key == 36 && v > 0) g_tune_gemm_min_t = v;
+    else if (key == 38) g_tune_wide_nw = v;
+}
 static inline int dense_small_gj(int group_size) {
     if (group_size >= 256) return (group_size % 256) ? -1 : 8;
     return group_size == 128 ? 4 : group_size == 64 ? 2 : group_size == 32 ? 1 : -1;

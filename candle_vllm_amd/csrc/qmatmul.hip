@@ -2076,44 +2076,73 @@ void mi355_prefill_set_lds(int v);
 static int g_tune_actq8 = 0;                               // mi355_set_tuning(18, 1): EXPERIMENT, single-token launches quantise x to Q8_K (reference CPU numerics, O2)
 static int g_tune_nw = 0, g_tune_r = 0;                   // 0 = heuristic; mi355_set_tuning (experiments only)
 static int g_tune_prefill_gemm = 1;                        // 0 = always stream the quantised weights (experiments)
-// what every key currently holds (INT32_MIN: never set = the default): lets a caller restore exactly what it found
-// (candle_vllm_amd.tuning(key, value) is the scoped form the tests use)
+// ---- A/B switches.  The PRODUCT library honours exactly ten keys (documented in include/mi355_vllm.h; their defaults live in the table
+// below, which is applied through the same setters at load time, so `mi355_get_tuning` always returns the live value of a product key);
+// every other key belongs to probe builds (-DMI355_QMM_PROBES, tools/build_probe_lib.sh) and is ignored by the product library.
+void mi355_prefill_set_fp8_generic(int v);
+void mi355_prefill_set_lds(int v);
 static int32_t g_tune_shadow[64];
 static bool g_tune_shadow_set[64];
+static const int32_t kProductTuning[][2] = {{3, 1}, {5, 0}, {6, 1}, {9, 1}, {24, 0}, {30, 0}, {41, 1}, {44, 1}, {47, 1}, {48, 1}};
+static bool tuning_is_product_key(int32_t key) {
+    for (const auto& kv : kProductTuning) if (kv[0] == key) return true;
+    return false;
+}
+static void tuning_apply(int32_t key, int32_t value) {
+    if (key == 3) { mi355_pa_set_fused(value & 15); mi355_pa_set_wpb(value >> 4); }   // merge form | 16 x partitions per workgroup (0 = auto)
+    else if (key == 5) mi355_host_set_partition_override(value);
+    else if (key == 6) g_tune_prefill_gemm = value;
+    else if (key == 9) g_tune_chain = value;
+    else if (key == 24) g_tune_exact_act = value;
+    else if (key == 30) mi355_dense_set_small(30, value);           // bit mask of folded launches switched OFF (dense_gemv.hip)
+    else if (key == 41) mi355_host_set_moe_group(value);
+    else if (key == 44) mi355_pa_set_loop(value);
+    else if (key == 47) { mi355_prefill_set_lds(value & 1); mi355_prefill_set_fp8_generic((value >> 1) & 1); }
+    else if (key == 48) g_tune_qpg_fepi = value;
+#ifdef MI355_QMM_PROBES
+    else if (key == 0) g_tune_nw = value;
+    else if (key == 1) g_tune_r = value;
+    else if (key == 2) g_tune_dbg = value;
+    else if (key == 10 && value != 0) g_tune_ks_target = value;     // > 0: (row tile x k-split) slots, < 0: workgroups
+    else if (key == 11) g_tune_qpg = value;
+    else if (key == 12 && value > 0) g_tune_qpg_min = value;
+    else if (key == 14) g_tune_merge = value;
+    else if (key == 15) g_tune_wide16 = value;
+    else if (key == 17 && value > 0) g_tune_ks_minkb = value;
+    else if (key == 18) g_tune_actq8 = value;
+    else if (key == 20) g_tune_qmv = value;
+    else if (key == 21 && value > 0) g_tune_qmv_nc = value;
+    else if (key == 22) g_tune_qmv_ring = value;
+    else if (key == 23) g_tune_chain_b1 = value;
+    else if (key >= 33 && key <= 38) mi355_dense_set_small(key, value);
+    else if (key == 42) mi355_dense_set_tile(value);
+    else if (key == 49) g_tune_wide_fuse = value;
+#endif
+}
+namespace {
+struct TuningInit {
+    TuningInit() {
+        for (const auto& kv : kProductTuning) { tuning_apply(kv[0], kv[1]); g_tune_shadow[kv[0]] = kv[1]; g_tune_shadow_set[kv[0]] = true; }
+    }
+} g_tuning_init;
+}
+/* 1 when this build honours `key` (the ten product keys; every key in probe builds) */
+extern "C" int32_t mi355_tuning_supported(int32_t key) {
+    if (key < 0 || key >= 64) return 0;
+#ifdef MI355_QMM_PROBES
+    return 1;
+#else
+    return tuning_is_product_key(key) ? 1 : 0;
+#endif
+}
 extern "C" int32_t mi355_get_tuning(int32_t key) {
     if (key < 0 || key >= 64 || !g_tune_shadow_set[key]) return INT32_MIN;
     return g_tune_shadow[key];
 }
 extern "C" void mi355_set_tuning(int32_t key, int32_t value) {
-    if (key >= 0 && key < 64) { g_tune_shadow[key] = value; g_tune_shadow_set[key] = true; }
-    if (key == 0) g_tune_nw = value;
-    else if (key == 1) g_tune_r = value;
-    else if (key == 2) g_tune_dbg = value;
-    else if (key == 14) g_tune_merge = value;
-    else if (key == 15) g_tune_wide16 = value;
-    else if (key == 18) g_tune_actq8 = value;
-    else if (key == 3) mi355_pa_set_fused(value);
-    else if (key == 5) mi355_host_set_partition_override(value);
-    else if (key == 6) g_tune_prefill_gemm = value;
-    else if (key == 8) mi355_pa_set_wpb(value);
-    else if (key == 9) g_tune_chain = value;
-    else if (key == 10 && value != 0) g_tune_ks_target = value;     // > 0: (row tile x k-split) slots, < 0: workgroups
-    else if (key == 17 && value > 0) g_tune_ks_minkb = value;
-    else if (key == 11) g_tune_qpg = value;
-    else if (key == 12 && value > 0) g_tune_qpg_min = value;
-    else if (key == 20) g_tune_qmv = value;
-    else if (key == 21 && value > 0) g_tune_qmv_nc = value;
-    else if (key == 22) g_tune_qmv_ring = value;
-    else if (key == 23) g_tune_chain_b1 = value;
-    else if (key == 24) g_tune_exact_act = value;
-    else if (key >= 30 && key <= 39) mi355_dense_set_small(key, value);
-    else if (key == 41) mi355_host_set_moe_group(value);
-    else if (key == 42) mi355_dense_set_tile(value);
-    else if (key == 43) mi355_prefill_set_fp8_generic(value);
-    else if (key == 44) mi355_pa_set_loop(value);
-    else if (key == 47) mi355_prefill_set_lds(value);
-    else if (key == 48) g_tune_qpg_fepi = value;
-    else if (key == 49) g_tune_wide_fuse = value;
+    if (!mi355_tuning_supported(key)) return;                       // product build: a probe key is ignored (and stays "never set")
+    g_tune_shadow[key] = value; g_tune_shadow_set[key] = true;
+    tuning_apply(key, value);
 }
 
 static size_t qmm_lds_bytes(int BT, int R, int NW) {

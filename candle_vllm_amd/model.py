@@ -271,23 +271,31 @@ class GGUFLLaMa:
                           "bytes": int(nbytes), "GBs": round(nbytes / avg / 1e3, 1), "launches_per_step": L}
         dom = max(rows, key=lambda p: rows[p]["avg_us"] * L)
         r = rows[dom]
-        # HBM bytes per launch of the dominant kernel: NOT measurable from inside this process (PMC counters need the
-        # rocprofv3 wrapper), so it is quoted from the committed PMC pass of this round -- with the commit that pass ran on --
-        # and only when that pass saw the same launch (same workgroup count = same geometry); otherwise null
-        traffic, traffic_source = None, None
+        # HBM bytes per launch of the dominant kernel: NOT measurable from inside this process (PMC counters need the rocprofv3
+        # wrapper), so it is quoted from the committed PMC pass of this round -- only while the mat-mul sources still hash to what that
+        # pass was built from (tools/pmc_traffic.py `kernel_source_sha256`: a changed kernel makes the number stale -> null) and only
+        # when that pass saw the same launch (same geometry); the pass's commit rides along in `traffic_source`
+        traffic, traffic_source = None, "null: no PMC pass of these kernel sources under profiles/"
         try:
-            import glob, json, os
-            root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
-            files = sorted(glob.glob(os.path.join(root, "r*_pmc_traffic.json")))
-            pmc = json.load(open(files[-1]))
-            d = pmc.get("dominant")
-            if d and dom == 3 and self._batch == 1 and self.tp_world == 1 and \
-                    abs(d["traffic_bytes_per_launch"] - r["bytes"]) < 0.25 * r["bytes"]:
-                traffic = int(d["traffic_bytes_per_launch"])
-                traffic_source = "%s @%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 correction)" % (
-                    "profiles/" + os.path.basename(files[-1]), pmc.get("commit", "unknown"))
+            import glob, hashlib, json, os
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            csrc = os.path.join(root, "candle_vllm_amd", "csrc")
+            hh = hashlib.sha256()
+            for f in sorted(os.listdir(csrc)):
+                if f.startswith("qmatmul") or f.startswith("qmm_") or f == "common.h":
+                    hh.update(open(os.path.join(csrc, f), "rb").read())
+            for path in sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_traffic.json")), reverse=True):
+                pmc = json.load(open(path))
+                d = pmc.get("dominant")
+                if pmc.get("kernel_source_sha256") != hh.hexdigest() or not d:
+                    continue
+                if dom == 3 and self._batch == 1 and self.tp_world == 1 and abs(d["traffic_bytes_per_launch"] - r["bytes"]) < 0.25 * r["bytes"]:
+                    traffic = int(d["traffic_bytes_per_launch"])
+                    traffic_source = "profiles/%s @%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 correction; kernel sources unchanged since)" % (
+                        os.path.basename(path), pmc.get("commit", "unknown"))
+                break
         except Exception:
-            traffic, traffic_source = None, None
+            traffic = None
         return {"bound": "hbm", "kernel": r["kernel"], "achieved": r["GBs"], "peak": peak_gbs, "unit": "GB/s",
                 "frac": round(r["GBs"] / peak_gbs, 4), "traffic": traffic, "traffic_source": traffic_source, "avg_us": r["avg_us"],
                 "algorithmic_bytes_per_launch": r["bytes"],

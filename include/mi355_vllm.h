@@ -263,28 +263,29 @@ int mi355_moe_gather_pos(float* dst, const float* src, const int32_t* pos, int32
 int mi355_moe_gather(float* dst, const float* src, const int32_t* perm, int32_t num_pairs, int32_t top_k, int32_t hidden, int64_t stream);
 int mi355_moe_scatter_combine(float* ys, const float* y_sorted, const float* weights, const int32_t* inv, int32_t num_tokens,
                               int32_t hidden, int32_t top_k, int64_t stream);
-/* experiment knobs, never needed for correct results (value 0 = default unless noted): 0 waves per workgroup,
- * 1 row tiles per workgroup, 2 probe modes of the mat-vec (1 stream only, 3 no staging, 4 no epilogue; compiled into
- * -DMI355_QMM_PROBES builds only, tools/build_probe_lib.sh -- the production kernels carry no probe code), 3 fused attention
- * merge (0 off, 1 auto, 2 always), 5 attention partition override, 6 prompt-step GEMM (1 on, 2 library GEMM), 8 attention
- * waves per workgroup (1 | 4 | 8 | 16), 9 chained wide launches (1 on), 10 split-K slot target of the wide path, 11 / 12
- * prompt-step GEMM variant / minimum tokens, 14 one launch for a Q4_K + Q6_K pair of runs (1 on), 15 16-wave workgroups
- * on the wide path for launches of >= n units (0 off), 17 fewest k-blocks per k-split, 18 EXPERIMENT: single-token launches
- * quantise x to Q8_K and take integer dot products (the reference CPU's numerics, oracle O2; default 0 = f32-accurate
- * activations, oracle O1); probe mode 7 = per-wave timestamps (below); 20-23 the LDS-DMA engine / chained launch experiments (probe
- * builds); 24 "exact" activations on the 9..32-token and prompt paths (f16 hi + lo planes instead of one plane); 30 / 35 waves per
- * workgroup of the 1..4-token 4-bit kernel (hidden-sized K / long K), 31 that kernel off, 32 no norm on the way in, 34 RoPE and
- * cache write in their own launch, 36 tokens from which 16-bit projections take the MFMA GEMM (96), 37 the LDS-shared-activation
- * 16-bit kernel off, 38 its waves per workgroup (2 | 4), 41 MoE decode grouping on the device (1 on), 42 16-bit host layer keeps its
- * projections in tiles (1 on; read at the first step), 43 fp8-cache prefill on the generic kernel, 44 decode attention partition sizes
- * 256 / 512 as looped chunks on the MFMA kernel (1 on; 0 = the generic kernel; EXPERIMENTS: 2 = partition sizes 1024 / 2048 / 4096
- * through an LDS ring filled by DMA, 3 = partition size 64 as one balanced LDS-DMA stream per workgroup, 4 = the same with the merge in the last arriver), 47 EXPERIMENT: prompt
- * attention over the PAGED cache with K / V through the same LDS ring (1 on; bf16, head_dim 128), 48 EXPERIMENT: Q4_K prompt-step
- * launches apply store / residual / SiLU * up in the GEMM's store loop (1 on).  A/B switches for measurements and tests: no product path depends on a
- * non-default value.  mi355_get_tuning returns what a key was last set to (INT32_MIN: never set), so a caller can restore what it
- * found instead of assuming the default. */
+/* A/B switches (process-global; for measurements and for tests that drive an alternative kernel through the same entry point).
+ * No product path depends on a non-default value.  The PRODUCT library honours exactly these ten keys:
+ *    3  decode-attention partition merge: low 4 bits 0 = separate reduce launch, 1 = in the last arriver where it pays (default),
+ *       2 = always; bits 4.. = partitions per workgroup (0 = chosen per launch, else 1 | 4 | 8 | 16)
+ *    5  decode-attention partition size of the step drivers (0 = their own choice: 32, or 64 for the balanced stream)
+ *    6  prompt steps (>= 96 tokens) on the hand-written quantised GEMM (1, default) or streamed like decode batches (0)
+ *    9  chained wide launches: an epilogue stages the next mat-mul's activation image (1, default)
+ *   24  "exact" activations on the 9..32-token and prompt paths: f16 hi + lo planes instead of one f16 plane (0, default)
+ *   30  16-bit / GPTQ linears, bit mask of folded launches switched OFF: 1 the 1..4-token 4-bit kernel, 2 no RMSNorm on the way in,
+ *       4 RoPE + cache write in their own launch, 8 the LDS-shared-activation 16-bit kernel, 16 the one-pass 4-bit prompt GEMM
+ *   41  MoE decode steps group their (token, slot) pairs by expert on the device (1, default)
+ *   44  decode-attention kernel per partition size on the PAGED bf16 cache: 1 (default) = 256 / 512 as looped chunks, 64 as the
+ *       balanced LDS-DMA stream at >= 64 (sequence, kv head) pairs; 0 = neither; 5 = chunks only; 3 = the stream for every launch
+ *       with partition size 64; 2 = additionally 1024 / 2048 / 4096 through the chunked LDS-DMA kernel
+ *   47  prompt attention: bit 0 = K / V through the LDS ring (bf16 cache, head_dim 128; default 1), bit 1 = fp8 caches on the generic kernel
+ *   48  Q4_K prompt-step launches apply store / residual / SiLU * up in the GEMM's store loop (1, default)
+ * mi355_tuning_supported(key) = 1 for these; mi355_get_tuning returns their live value.  Every other key (0-2, 8, 10-23, 33-38, 42, 49:
+ * wave / tile / split geometry, ablation modes, the experiments that lost their A/B) exists in probe builds only
+ * (-DMI355_QMM_PROBES, tools/build_probe_lib.sh, listed next to their variables in csrc/); the product library ignores them
+ * (mi355_get_tuning: INT32_MIN). */
 void mi355_set_tuning(int32_t key, int32_t value);
 int32_t mi355_get_tuning(int32_t key);
+int32_t mi355_tuning_supported(int32_t key);
 /* experiments only: device buffer of uint64 [workgroup][16 waves][4] that the 1..8-token mat-vec fills with wall-clock
  * stamps (entry, main loop done, past the barrier, exit) while probe mode 7 is set (probe builds only); NULL switches it off */
 int mi355_debug_set_timestamps(void* dev_ptr);

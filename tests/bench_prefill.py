@@ -29,7 +29,7 @@ def main():
                 continue
             M.lib.mi355_set_tuning(6, mode)
             for qv in ([int(v) for v in os.environ.get("PF_QPG", "2").split(",")] if mode == 1 else [0]):
-                M.lib.mi355_set_tuning(11, qv)
+                M.lib.mi355_set_tuning(11, qv)                      # (probe builds: the product library ignores keys 11 and 2)
                 for dbg in ([int(v) for v in os.environ.get("PF_DBG", "0").split(",")] if mode == 1 else [0]):
                     M.lib.mi355_set_tuning(2, dbg)
                     # PF_ATTN="0,1": A/B of the prompt attention on the same model (tuning key 47: 1 = the LDS-ring kernel, the default; 0 = register-fed)

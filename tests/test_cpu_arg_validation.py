@@ -131,13 +131,25 @@ def test_scoped_tuning_restores_what_it_found(lib):
     """candle_vllm_amd.tuning(key, value): the key holds the value inside the block and what it held before afterwards, also when
     the block raises (the A/B switches are process-global state of the library)"""
     from candle_vllm_amd import tuning
-    assert lib.mi355_get_tuning(63) == -2 ** 31                   # never set
-    with tuning(63, 5):
-        assert lib.mi355_get_tuning(63) == 5
-        with tuning(63, 7):
-            assert lib.mi355_get_tuning(63) == 7
-        assert lib.mi355_get_tuning(63) == 5
-    assert lib.mi355_get_tuning(63) == 0                          # default of an unlisted key
+    from candle_vllm_amd import TuningKeyUnavailable
+    product = [3, 5, 6, 9, 24, 30, 41, 44, 47, 48]                # the ten keys of the product library (include/mi355_vllm.h)
+    defaults = {3: 1, 5: 0, 6: 1, 9: 1, 24: 0, 30: 0, 41: 1, 44: 1, 47: 1, 48: 1}
+    for k in range(64):
+        assert bool(lib.mi355_tuning_supported(k)) == (k in product), k      # (a probe build honours all 64: this suite runs the product)
+        if k in product:
+            assert lib.mi355_get_tuning(k) == defaults[k], k     # the library reports the live value of every product key
+    assert lib.mi355_get_tuning(63) == -2 ** 31                   # a probe-build key: never set ...
+    lib.mi355_set_tuning(63, 5)
+    assert lib.mi355_get_tuning(63) == -2 ** 31                   # ... and ignored by the product library
+    with pytest.raises(TuningKeyUnavailable):
+        with tuning(63, 5):
+            pass
+    with tuning(5, 64):
+        assert lib.mi355_get_tuning(5) == 64
+        with tuning(5, 128):
+            assert lib.mi355_get_tuning(5) == 128
+        assert lib.mi355_get_tuning(5) == 64
+    assert lib.mi355_get_tuning(5) == 0
     try:
         with tuning(41, 0):
             assert lib.mi355_get_tuning(41) == 0

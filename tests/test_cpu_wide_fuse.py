@@ -11,6 +11,13 @@ import pytest
 NC = 7                                                                # QMG_NC: consumer waves = row tiles per workgroup
 
 
+def _f(lib):
+    f = lib.mi355_internal_qw1_wgs_touching                          # internal symbol (not in the public header): typed here
+    f.restype = ctypes.c_int32
+    f.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
+    return f
+
+
 def _brute(runs, n_blocks):
     touch = np.zeros(n_blocks, np.int64)
     for lo, hi in runs:
@@ -35,7 +42,7 @@ def test_ticket_expectation_equals_brute_force(lib, seed):
         want = _brute(runs, n_blocks)
         lo = (ctypes.c_int32 * 3)(*[r[0] for r in runs] + [0] * (3 - n_runs))
         hi = (ctypes.c_int32 * 3)(*[r[1] for r in runs] + [0] * (3 - n_runs))
-        got = [lib.mi355_internal_qw1_wgs_touching(n_runs, ctypes.addressof(lo), ctypes.addressof(hi), b) for b in range(n_blocks)]
+        got = [_f(lib)(n_runs, ctypes.addressof(lo), ctypes.addressof(hi), b) for b in range(n_blocks)]
         assert got == want.tolist(), (runs, got, want.tolist())
         # every workgroup's own block range [tile_lo >> 4, (tile_hi - 1) >> 4] is what the brute force counted: each block is touched
         assert (want > 0).all()
@@ -47,6 +54,6 @@ def test_llama3_launch_shapes(lib):
         n_blocks = (runs[-1][1] * 16 + 255) // 256
         lo = (ctypes.c_int32 * 3)(*[r[0] for r in runs] + [0] * (3 - len(runs)))
         hi = (ctypes.c_int32 * 3)(*[r[1] for r in runs] + [0] * (3 - len(runs)))
-        got = [lib.mi355_internal_qw1_wgs_touching(len(runs), ctypes.addressof(lo), ctypes.addressof(hi), b) for b in range(n_blocks)]
+        got = [_f(lib)(len(runs), ctypes.addressof(lo), ctypes.addressof(hi), b) for b in range(n_blocks)]
         assert got == _brute(runs, n_blocks).tolist()
         assert max(got) <= 4 and min(got) >= 1                        # 16 tiles over 7-tile workgroups: 3 or 4 of them (fewer at a run's end)

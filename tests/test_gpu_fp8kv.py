@@ -127,7 +127,7 @@ def test_prefill_over_fp8_cache(cv, H, Hkv, D, bs, lens, cached, generic):
     kcd, vcd = torch.from_numpy(kc).cuda(), torch.from_numpy(vc).cuda()
     kn = np.concatenate([k_all[b][cached[b]:] for b in range(len(lens))])
     vn = np.concatenate([v_all[b][cached[b]:] for b in range(len(lens))])
-    with tuning(43, generic):
+    with tuning(47, 1 | (2 if generic else 0)):                  # key 47 bit 1: fp8-cache prompt attention on the generic kernel
         out = bf16_host(pa.forward(bf16_dev(np.concatenate(q)), bf16_dev(kn), bf16_dev(vn), None, kcd, vcd, im))
     O.reshape_and_cache_fp8(kn, vn, kc, vc, meta["slot_mapping"], False)
     assert np.array_equal(kcd.cpu().numpy(), kc)

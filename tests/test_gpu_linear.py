@@ -271,7 +271,7 @@ def test_small_batch_4bit_kernel_shapes(cv, T, N, K, gs, tiled):
     y = host16(lin.forward(dev16(x, "bf16")), "bf16")
     check_ulp(y, ref, "bf16", what="1..4-token kernel")
     from candle_vllm_amd import tuning
-    with tuning(31, 1):
+    with tuning(30, 1):                                           # key 30 bit 0: the 1..4-token kernel off
         y0 = host16(lin.forward(dev16(x, "bf16")), "bf16")
     check_ulp(y0, ref, "bf16", what="16-token-tile kernel")
 
@@ -298,7 +298,7 @@ def test_wide_16bit_kernel_many_row_tiles(cv, dt, T, N, K, pair):
     y = host16(lin.forward(dev16(x, dt), **kw), dt)
     check_ulp(y, ref, dt, ulps=ulps, what="wide 16-bit kernel", mag=mag)
     from candle_vllm_amd import tuning
-    with tuning(37, 1):
+    with tuning(30, 8):                                           # key 30 bit 3: the LDS-shared-activation kernel off
         y0 = host16(lin.forward(dev16(x, dt), **kw), dt)
     check_ulp(y0, ref, dt, ulps=ulps, what="K-split kernel", mag=mag)
 
@@ -370,6 +370,6 @@ def test_gptq_prompt_gemm_one_pass(cv, dt, T, N, K, gs, mode):
         ref = lin_ref
     y = host16(lin.forward(dev16(x, dt), **fkw), dt)
     check_ulp(y, ref, dt, ulps=ulps, what="gptq prompt GEMM", mag=mag)
-    with tuning(39, 1):
+    with tuning(30, 16):                                          # key 30 bit 4: the one-pass 4-bit prompt GEMM off
         y0 = host16(lin.forward(dev16(x, dt), **fkw), dt)
     check_ulp(y0, ref, dt, ulps=ulps, what="decode kernel in chunks", mag=mag)

@@ -573,7 +573,7 @@ def test_paged_attention_workgroup_merge_equals_one_wave_per_partition(cv, bs, c
     for wpb in (1, 4, 8, 16):                                         # partials per head in the fused merge: <= 32, 33..64, > 64
         for ps in (32, 64):
             for fused in (0, 2):
-                with tuning(8, wpb), tuning(3, fused):
+                with tuning(3, fused + 16 * wpb):                     # key 3 = merge form + 16 x partitions per workgroup
                     got = pa.decode(qd, kcd, vcd, meta, None, partition_size=ps).float().cpu().numpy()
                 assert np.abs(got - oracle).max() <= tol, (wpb, ps, fused, np.abs(got - oracle).max())
                 outs[(wpb, ps, fused)] = got

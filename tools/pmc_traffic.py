@@ -39,6 +39,14 @@ for k in sorted(fetch):
     out["kernels"][k] = {"workgroups": wgs[k], "launches": len(fetch[k]), "FETCH_SIZE_KiB_avg": round(f, 1),
                          "fetch_bytes_corrected": int(2 * f * 1024), "WRITE_SIZE_KiB_avg": round(w, 1)}
 out["commit"] = sys.argv[4] if len(sys.argv) > 4 else "unknown"
+# the counters describe the kernels AS BUILT FROM THESE SOURCES: bench.py quotes `dominant` only while the hash still matches
+import hashlib, os
+_csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "candle_vllm_amd", "csrc")
+_h = hashlib.sha256()
+for _f in sorted(os.listdir(_csrc)):
+    if _f.startswith("qmatmul") or _f.startswith("qmm_") or _f == "common.h":
+        _h.update(open(os.path.join(_csrc, _f), "rb").read())
+out["kernel_source_sha256"] = _h.hexdigest()
 # the dominant launch group of the step = the mat-vec kernel that moves the most bytes per step (gate/up at batch 1):
 # recorded BY MEASUREMENT so that the bench needs no kernel name
 mv = {k: v for k, v in out["kernels"].items() if "qmm_kernel" in k and v["launches"] > 0}
