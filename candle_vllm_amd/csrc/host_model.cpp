@@ -118,6 +118,18 @@ struct Model {
 // per-pair expert mat-vecs read an expert once per pair; grouped, every expert is read once per 32-row chunk of its `pairs` rows
 int g_moe_group = 1;            // tuning key 41: 0 = decode steps never group (A/B)
 inline bool moe_group_pays(int pairs, int n_expert) { return pairs > n_expert * ((pairs + 31) / 32); }
+extern "C" int mi355_internal_paged_attention_v2_partials(void* out, float* exp_sums, float* max_logits, float* tmp_out, const void* q,
+                                                          const void* key_cache, const void* value_cache, const uint32_t* block_tables,
+                                                          const uint32_t* context_lens, int32_t num_seqs, int32_t num_heads,
+                                                          int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                                                          int32_t max_blocks_per_seq, int32_t max_context_len, int32_t partition_size,
+                                                          float scale, float softcap, int32_t layout, int32_t dtype, int64_t stream,
+                                                          int32_t* w_out);                                                   // paged_attention.hip
+extern "C" int mi355_internal_pa_stream_reduce(void* out, const float* tmp_out, const float* max_logits, const float* exp_sums,
+                                               const uint32_t* context_lens, int32_t B, int32_t H, int32_t W, int32_t slots, int64_t stream);
+extern "C" int mi355_internal_pa_stream_reduce_to_image(void* out, const float* tmp_out, const float* max_logits, const float* exp_sums,
+                                                        const uint32_t* context_lens, int32_t B, int32_t H, int32_t W, int32_t slots,
+                                                        int64_t stream);                                                     // qmatmul.hip
 extern "C" int mi355_pa_stream_auto(int32_t num_seqs, int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size);   // paged_attention.hip
 int g_host_ps_override = 0;     // experiments: mi355_set_tuning(5, partition_size)
 
@@ -432,6 +444,19 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
             return mi355_paged_attention_v1(in.attn, in.q, m->kcache[l], m->vcache[l], in.bt, in.ctx, B, H, Hkv, D,
                                             c.block_size, in.max_blocks, in.ctx_cap, scale, 0.f, c.kv_layout,
                                             MI355_DTYPE_BF16, st);
+        if (ps == 64 && B >= 9 && B <= 32 && !(H & 1) && c.kv_layout == MI355_KV_PAGED && !m->use_comm) {
+            // the balanced stream at a batch whose wo runs on the 9..32-token path: the merge of the partials also stages wo's activation
+            // image (qmatmul.hip mi355_internal_pa_stream_reduce_to_image): one launch instead of merge + staging
+            int32_t w = 0;
+            RCHECK(mi355_internal_paged_attention_v2_partials(in.attn, m->pa_sum, m->pa_max, m->pa_tmp, in.q, m->kcache[l], m->vcache[l], in.bt,
+                                                              in.ctx, B, H, Hkv, D, c.block_size, in.max_blocks, in.ctx_cap, ps, scale, 0.f,
+                                                              c.kv_layout, MI355_DTYPE_BF16, st, &w));
+            if (w == 0) return 0;                                     // the launch did not take the stream: it is complete
+            const int max_partitions = (in.ctx_cap + ps - 1) / ps < 1 ? 1 : (in.ctx_cap + ps - 1) / ps;
+            const int rc = mi355_internal_pa_stream_reduce_to_image(in.attn, m->pa_tmp, m->pa_max, m->pa_sum, in.ctx, B, H, w, max_partitions, st);
+            if (rc != -4) return rc;
+            return mi355_internal_pa_stream_reduce(in.attn, m->pa_tmp, m->pa_max, m->pa_sum, in.ctx, B, H, w, max_partitions, st);
+        }
         return mi355_paged_attention_v2(in.attn, m->pa_sum, m->pa_max, m->pa_tmp, in.q, m->kcache[l], m->vcache[l],
                                         in.bt, in.ctx, B, H, Hkv, D, c.block_size, in.max_blocks, in.ctx_cap, ps,
                                         scale, 0.f, c.kv_layout, MI355_DTYPE_BF16, st);

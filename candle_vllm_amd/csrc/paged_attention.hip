@@ -1270,7 +1270,7 @@ __global__ void __launch_bounds__(256, 1) paged_attn_lds_kernel(const PAParams p
 //     memory counter stays the DMA's own (the partial stores that enter it only make a counted wait stricter: the wait counts DMA
 //     instructions alone);
 //   * Q of the (up to 4) sequences of the share is staged in LDS before the first DMA goes out.
-__host__ __device__ inline int64_t pas_cut(int64_t S, int W, int w) { return S * w / W; }
+#include "pa_stream_cut.h"
 
 template <int R>
 __global__ void __launch_bounds__(256, 1) paged_attn_stream_kernel(const PAParams p, const int B, const uint32_t* __restrict__ btab,
@@ -1615,6 +1615,9 @@ static int g_pa_wpb = 0;                                            // mi355_set
 //   3: the stream for every launch with partition size 64 (tests: small shapes);  2: + 1024 / 2048 / 4096 take the chunked LDS-DMA kernel
 static int g_pa_loop = 1;
 #define PA_STREAM_MIN_PAIRS 64
+// internal (host layer): the next v2 call that takes the stream leaves its partials unmerged and reports its workgroup count, so that the
+// merge can run fused with the staging of the next mat-mul's activation image (qmatmul.hip: mi355_internal_pa_stream_reduce_to_image)
+static thread_local int g_pa_stream_noreduce = 0, g_pa_stream_last_w = 0;
 static bool pa_stream_shape_ok(int B, int H, int Hkv, int D, int block_size) {
     return D == 128 && Hkv > 0 && H % Hkv == 0 && H / Hkv <= 16 && (block_size == 16 || block_size == 32 || block_size == 64) && B <= 64;
 }
@@ -1654,6 +1657,7 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
         if (W > P) W = P;
         hipLaunchKernelGGL((paged_attn_stream_kernel<PAS_R>), dim3(W, p.Hkv), dim3(256), PAS_R * 32768 + 16384, st, p, B, p.block_tables,
                            p.context_lens);
+        if (g_pa_stream_noreduce) { g_pa_stream_last_w = W; return (int)hipGetLastError(); }   // the caller merges (mi355_internal_pa_stream_partials)
         hipLaunchKernelGGL(paged_attn_stream_reduce_kernel, dim3(p.H, B), dim3(128), 0, st, p.out, p.tmp_out, p.max_logits, p.exp_sums,
                            p.context_lens, B, p.H, W, p.max_partitions);
         return (int)hipGetLastError();
@@ -1825,6 +1829,31 @@ extern "C" int mi355_paged_attention_reference_numerics(void* out, const void* q
     p.H = num_heads; p.Hkv = num_kv_heads; p.D = head_dim; p.block_size = block_size; p.max_blocks = max_blocks_per_seq;
     p.scale = scale; p.q_stride = (int64_t)num_heads * head_dim;
     hipLaunchKernelGGL(paged_attn_refnum_kernel, dim3(num_heads, num_seqs), dim3(256), shm, to_stream(stream), p, layout == MI355_KV_FLASH ? 1 : 0);
+    return (int)hipGetLastError();
+}
+
+/* decode attention through the balanced stream WITHOUT its merge launch: partials stay in tmp_out / max_logits / exp_sums (slot w of
+ * max_partitions per (sequence, head)); *w_out = workgroups per kv head (0: the launch did not take the stream and is complete). */
+extern "C" int mi355_internal_paged_attention_v2_partials(void* out, float* exp_sums, float* max_logits, float* tmp_out, const void* q,
+                                                          const void* key_cache, const void* value_cache, const uint32_t* block_tables,
+                                                          const uint32_t* context_lens, int32_t num_seqs, int32_t num_heads,
+                                                          int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                                                          int32_t max_blocks_per_seq, int32_t max_context_len, int32_t partition_size,
+                                                          float scale, float softcap, int32_t layout, int32_t dtype, int64_t stream,
+                                                          int32_t* w_out) {
+    g_pa_stream_noreduce = 1; g_pa_stream_last_w = 0;
+    const int rc = mi355_paged_attention_v2(out, exp_sums, max_logits, tmp_out, q, key_cache, value_cache, block_tables, context_lens, num_seqs,
+                                            num_heads, num_kv_heads, head_dim, block_size, max_blocks_per_seq, max_context_len, partition_size,
+                                            scale, softcap, layout, dtype, stream);
+    g_pa_stream_noreduce = 0;
+    if (w_out) *w_out = g_pa_stream_last_w;
+    return rc;
+}
+
+extern "C" int mi355_internal_pa_stream_reduce(void* out, const float* tmp_out, const float* max_logits, const float* exp_sums,
+                                               const uint32_t* context_lens, int32_t B, int32_t H, int32_t W, int32_t slots, int64_t stream) {
+    hipLaunchKernelGGL(paged_attn_stream_reduce_kernel, dim3(H, B), dim3(128), 0, to_stream(stream), out, tmp_out, max_logits, exp_sums,
+                       context_lens, B, H, W, slots);
     return (int)hipGetLastError();
 }
 

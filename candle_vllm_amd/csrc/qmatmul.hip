@@ -1542,7 +1542,7 @@ __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, cons
 // (device, stream) that launches: two models on two streams never share an image, growing a buffer never frees memory a
 // captured graph still replays from (scratch.cpp).  The chain hint is per (device, stream) too.
 // image staged by the last chained epilogue: valid for exactly the next wide launch if it consumes the same activations
-struct QmgChainState { bool valid; const void* x; int B, K, MT, buf; const float* norm_w; hipStream_t st; int sp; };
+struct QmgChainState { bool valid; const void* x; int B, K, MT, buf; const float* norm_w; hipStream_t st; int sp; int x_dtype = MI355_DTYPE_F32; };
 struct QmgStream { int cur = 0; QmgChainState chain = {false, nullptr, 0, 0, 0, 0, nullptr, nullptr, 0}; };
 static std::mutex g_qmg_mu;
 static std::map<std::pair<int, hipStream_t>, QmgStream> g_qmg_streams;
@@ -1690,7 +1690,7 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
     QmgStream& qs = qmg_stream(st);
     const bool chained = qs.chain.valid && qs.chain.x == a.x && qs.chain.B == a.B && qs.chain.K == a.K &&
                          qs.chain.MT == MT && qs.chain.sp == 1 && qs.chain.norm_w == a.norm_w && qs.chain.st == st &&
-                         a.x_dtype == MI355_DTYPE_F32 && a.ldx == a.K;
+                         a.x_dtype == qs.chain.x_dtype && a.ldx == a.K;
     qs.chain.valid = false;
     const int cur = chained ? qs.chain.buf : qs.cur;
     int rc = 0;
@@ -1780,6 +1780,97 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
     qs.cur = cur;
     if (!fz.ticket)
         hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, want ? BP : a.B), dim3(256), 0, st, a, part, ldp, ks, BP, ssp, ch);
+    return (int)hipGetLastError();
+}
+
+// ---- the merge of the balanced attention stream's partials, fused with the staging of the NEXT mat-mul's activation image (round 4).
+// At batch 9..32 the attention output feeds wo through the 9..32-token path, whose image (one f16 plane, block scale per token and
+// k-block) was built by a launch of its own (qw1_prep_kernel, 4.9 us per layer) right after the merge launch (4.7 us): a k-block = 256
+// columns = two heads of 128 channels, so a workgroup that merges two heads of one sequence holds exactly one image row.  Same merge
+// arithmetic as paged_attn_stream_reduce_kernel, same entry builder as the staging kernel on the bf16-rounded outputs: bit-identical
+// image, one launch and one boundary fewer per layer.
+#include "pa_stream_cut.h"
+template <int MT>
+__global__ void __launch_bounds__(256) pa_stream_reduce_img_kernel(uint16_t* __restrict__ out, const float* __restrict__ tmp_out,
+                                                                   const float* __restrict__ max_logits, const float* __restrict__ exp_sums,
+                                                                   const uint32_t* __restrict__ context_lens, const int B, const int H,
+                                                                   const int W, const int slots, uint8_t* __restrict__ img,
+                                                                   float* __restrict__ ssp, const size_t kbb) {
+    constexpr int D = 128;
+    const int kb = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, h = 2 * kb + (threadIdx.x >> 7), d = threadIdx.x & 127;
+    __shared__ float sm_o[256];
+    float v = 0.f;
+    if (b < B) {
+        const int n_l = lane < B ? ((int)context_lens[lane] + 63) >> 6 : 0;
+        int pend = n_l;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(pend, o, 64);
+            if (lane >= o) pend += t;
+        }
+        const int S = __builtin_amdgcn_readlane(pend, 63);
+        const int pe = __builtin_amdgcn_readlane(pend, b), ps = pe - __builtin_amdgcn_readlane(n_l, b);
+        bool meets = false;
+        if (lane < W) {
+            const int lo = (int)pas_cut(S, W, lane), hi = (int)pas_cut(S, W, lane + 1);
+            meets = lo < hi && lo < pe && hi > ps;
+        }
+        const uint64_t mask = __ballot(meets);
+        const int64_t base = ((int64_t)b * H + h) * slots;
+        float M = -1e30f;
+        for (uint64_t mm = mask; mm; mm &= mm - 1) M = fmaxf(M, max_logits[base + __ffsll((unsigned long long)mm) - 1]);
+        float den = 0.f, acc = 0.f;
+        for (uint64_t mm = mask; mm; mm &= mm - 1) {
+            const int wq = __ffsll((unsigned long long)mm) - 1;
+            const float wt = exp_sums[base + wq] * __expf(max_logits[base + wq] - M);
+            den += wt;
+            acc = fmaf(tmp_out[(base + wq) * D + d], wt, acc);
+        }
+        uint16_t ob = 0;
+        if (mask) {
+            ob = f32_to_bf16(den > 0.f ? acc / den : 0.f);
+            out[((int64_t)b * H + h) * D + d] = ob;
+        } else {
+            ob = out[((int64_t)b * H + h) * D + d];                     // a sequence without stages: the output row is left as it is
+        }
+        v = bf16_to_f32(ob);                                          // wo reads the bf16 tensor (attention.rs:997-1004)
+    }
+    sm_o[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float e8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e8[i] = sm_o[threadIdx.x * 8 + i];
+        qw1_prep_entry(img, ssp, e8, b < B, nullptr, MT, kbb, kb, b, (int)threadIdx.x);
+    }
+}
+/* host layers: merge the stream's partials (mi355_internal_paged_attention_v2_partials) into `out` bf16 [B, H, 128] AND stage the image of
+ * the wide mat-mul that reads `out` next on this stream (x = out, k = H * 128, no norm).  9 <= B <= 32, H even.  -4: not this shape. */
+extern "C" int mi355_internal_pa_stream_reduce_to_image(void* out, const float* tmp_out, const float* max_logits, const float* exp_sums,
+                                                        const uint32_t* context_lens, int32_t B, int32_t H, int32_t W, int32_t slots,
+                                                        int64_t stream) {
+    if (B < 9 || B > 32 || (H & 1) || W < 1 || W > 64 || g_tune_exact_act || !g_tune_chain) return -4;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int MT = B <= 16 ? 1 : 2, BP = MT * 16, K = H * 128, nkb = K / 256;
+    const size_t kbb = qw1_kb_bytes(MT);
+    QmgStream& qs = qmg_stream(st);
+    const int other = qs.cur ^ 1;
+    void* p = nullptr;
+    const int rc = qmg_buf(&p, other ? MI355_SCR_QMM_IMG1 : MI355_SCR_QMM_IMG0, kbb * nkb + (size_t)nkb * BP * sizeof(float), st);
+    if (rc) return rc;
+    uint8_t* img = static_cast<uint8_t*>(p);
+    float* ssp = reinterpret_cast<float*>(img + kbb * nkb);
+    const dim3 grid(H / 2, BP);
+    if (MT == 1)
+        hipLaunchKernelGGL((pa_stream_reduce_img_kernel<1>), grid, dim3(256), 0, st, static_cast<uint16_t*>(out), tmp_out, max_logits, exp_sums,
+                           context_lens, B, H, W, slots, img, ssp, kbb);
+    else
+        hipLaunchKernelGGL((pa_stream_reduce_img_kernel<2>), grid, dim3(256), 0, st, static_cast<uint16_t*>(out), tmp_out, max_logits, exp_sums,
+                           context_lens, B, H, W, slots, img, ssp, kbb);
+    QmgChainState cs{true, out, B, K, MT, other, nullptr, st, 1};
+    cs.x_dtype = MI355_DTYPE_BF16;
+    qs.chain = cs;
     return (int)hipGetLastError();
 }
 
