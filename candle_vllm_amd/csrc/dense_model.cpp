@@ -110,6 +110,7 @@ void dense_drop_graph(DModel* m) {
         if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
     }
     m->graphs.clear();
+    m->warmed.clear();
 }
 
 // [W, B, Vl] -> [B, W*Vl]   (VocabParallelLinear: all-gather then un-interleave, distributed.rs:1637-1663)
@@ -628,6 +629,7 @@ int mi355_dense_set_graph(void* mp, int32_t enable) {
     if (!m) return (int)hipErrorInvalidValue;
     m->use_graph = enable != 0;
     if (!m->use_graph) dense_drop_graph(m);
+    m->warmed.clear();
     return 0;
 }
 int mi355_dense_decode_begin(void* mp, const uint32_t* tokens_host, const uint32_t* seq_lens_host, const uint32_t* block_tables_host,

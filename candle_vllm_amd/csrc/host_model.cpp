@@ -548,6 +548,7 @@ void drop_graph(Model* m) {
         if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
     }
     m->graphs.clear();
+    m->warmed.clear();                                                // whatever invalidated the graphs may also change which kernels / scratch a step uses: warm again
 }
 
 }  // namespace
@@ -926,6 +927,7 @@ extern "C" int mi355_llama_set_graph(void* mp, int32_t enable) {
     m->use_graph = enable != 0;
     m->graph_tp = enable == 2;
     if (!m->use_graph) drop_graph(m);
+    m->warmed.clear();                                                // a (re-)enabled graph mode starts with an eager step per shape
     return 0;
 }
 

@@ -1,0 +1,15 @@
+#!/bin/bash
+set -x
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/r4c10
+mkdir -p $OUT
+cd $R
+timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py tests/test_gpu_fullsize.py -m gpu -q -k "wide or chain or moe or batch32 or faithful or tokens" > $OUT/pytest.log 2>&1
+tail -6 $OUT/pytest.log
+B32_STEPS=16 B32_AB="9=1;9=2;9=1;9=2;44=5" timeout 300 python tools/exp_b32.py 2>&1 | grep "tok/s" > $OUT/b32.log; cat $OUT/b32.log
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_b32
+B32_STEPS=6 timeout 200 rocprofv3 --kernel-trace -d /tmp/prof_b32 --output-format csv -- python $R/tools/exp_b32.py > /tmp/b32_trace.log 2>&1
+f=$(find /tmp/prof_b32 -name "*kernel_trace.csv" | head -1)
+python $R/tools/trace_groups.py "$f" | grep -v "at::native" > $OUT/b32_groups.txt 2>&1
+head -16 $OUT/b32_groups.txt
