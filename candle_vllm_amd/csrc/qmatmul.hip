@@ -1536,59 +1536,11 @@ __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, cons
     }
 }
 
-// The same epilogue with FOUR token rows per workgroup (round 4, the 9..32-token path): grid = (padded rows / 256, token rows / 4).  At
-// 32 tokens the one-row form launches 512-3584 workgroups whose whole work is a handful of loads and stores per thread: the launch is
-// bound by the rate at which workgroups start, not by bytes (5.7-8 us per launch, 27 us per layer at batch 32).  Four rows per workgroup:
-// a quarter of the workgroups, the partial sums of all four rows requested before the first dependent instruction, the four deferred
-// RMSNorm factors by the four waves in parallel, the four image rows of a chain by 128 threads.  Per-element arithmetic and its order
-// are those of qmm_epilogue_kernel (same functions): bit-identical results.
-__global__ void __launch_bounds__(256) qmm_epilogue4_kernel(const QmmArgs a, const float* __restrict__ part, const int ldp,
-                                                            const int ks, const int BP, const float* __restrict__ ssp,
-                                                            const QmgChainOut ch) {
-    if (a.rows_dev && *a.rows_dev <= a.rows_min) return;
-    constexpr int TPW = 4;
-    const int prow = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b0 = blockIdx.y * TPW;
-    __shared__ float sm_inv[TPW];
-    __shared__ float sm_o[TPW][256];
-    QmgEpiRow er[TPW];
-    bool mine[TPW];
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        er[i].live = false;
-        mine[i] = prow < ldp && b0 + i < a.B;
-        if (mine[i]) er[i] = qmm_epilogue_load(a, part, ldp, ks, BP, prow, b0 + i);
-    }
-    if (a.norm_w && ssp) {
-        const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, b = b0 + w;      // wave w <-> token row b0 + w
-        float ss = 0.f;
-        if (b < a.B)
-            for (int kb = lane; kb < (a.K >> 8); kb += 64) ss += ssp[(size_t)kb * BP + b];
-        ss = wave_sum(ss);
-        if (lane == 0) sm_inv[w] = rsqrtf(ss / (float)a.K + a.eps);
-        __syncthreads();
-    }
-    float o[TPW];
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const float inv = (a.norm_w && ssp) ? sm_inv[i] : 1.f;
-        o[i] = mine[i] ? qmm_epilogue_apply(a, er[i], inv, b0 + i) : 0.f;
-    }
-    if (!ch.img) return;
-    const int kb = blockIdx.x;
-    if (kb * 256 >= ch.K) return;                                    // uniform: e.g. the `up` half of the gate/up rows
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) sm_o[i][threadIdx.x] = o[i];
-    __syncthreads();
-    if (threadIdx.x < 32 * TPW) {
-        const int i = threadIdx.x >> 5, El = threadIdx.x & 31;
-        float v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = sm_o[i][El * 8 + q];
-        qw1_prep_entry(ch.img, ch.ssp, v, b0 + i < a.B, ch.norm_w, ch.MT, ch.kbb, kb, b0 + i, El);
-    }
-}
-
+// (Round 4 measured a form of this kernel with FOUR token rows per workgroup -- a quarter of the workgroups, all partial sums requested up
+//  front -- on the theory that 512-3584 tiny workgroups per launch are bound by the rate at which workgroups start: it LOST, 10.4 / 13.0 /
+//  9.1 us against 5.7 / 7.5 / 8.0 us for the wo | down, q|k|v and gate/up epilogues, the ragged batch-32 step 5690 against 6255 tok/s
+//  (profiles/r04_b32_epilogue_rows_ab.txt).  The epilogue is a chain of three dependent memory round trips; more rows per thread make
+//  the chain longer, more workgroups hide it.  Deleted.)
 #include "qmm_wide1_gemm.inc"
 
 // Scratch of the wide / prompt paths (activation images, split-K partials, the prompt-step workspace) belongs to the
@@ -1736,6 +1688,18 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
         if (want < 1) want = 1;
         ks = want;
     }
+    if (g_tune_ks_target > 0 && a.nseg == 1 && a.seg[0].type == MI355_GGML_Q6_K && nkb >= 32) {
+        // a Q6_K launch of long K (the down projection: 256 tiles x 56 k-blocks) is bound by its unpack arithmetic (411 VALU per tile and
+        // k-block, profiles/r03_pmc_sq_b32_set1.json), not by bytes: with the power-of-two split it runs 37 x 4 = 148 workgroups on 256
+        // CUs.  The smallest integer split that covers the chip: 37 x 7 = 259 workgroups of 8 k-blocks.
+        const int n_wg = (n_slots + QMG_NC - 1) / QMG_NC;
+        const int cus = 256;                                              // MI355X
+        if (n_wg * ks < cus) {
+            int want = (cus + n_wg - 1) / n_wg;
+            while (want > 1 && nkb / want < 4) --want;
+            if (want > ks) ks = want;
+        }
+    }
     {   // no empty split: the kernels walk ceil(nkb / ks) k-blocks per split, and every split's partial sums are added up
         const int kb_per = (nkb + ks - 1) / ks;
         ks = (nkb + kb_per - 1) / kb_per;
@@ -1831,12 +1795,8 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
     }
     if (want) qs.chain = QmgChainState{true, a.out, a.B, a.next_k, MT, cur ^ 1, a.next_norm_w, st, 1};
     qs.cur = cur;
-    if (!fz.ticket) {
-        if (g_tune_chain != 2)                                        // four token rows per workgroup (key 9 = 2: the one-row form, A/B)
-            hipLaunchKernelGGL(qmm_epilogue4_kernel, dim3((ldp + 255) / 256, ((want ? BP : a.B) + 3) / 4), dim3(256), 0, st, a, part, ldp, ks, BP, ssp, ch);
-        else
-            hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, want ? BP : a.B), dim3(256), 0, st, a, part, ldp, ks, BP, ssp, ch);
-    }
+    if (!fz.ticket)
+        hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, want ? BP : a.B), dim3(256), 0, st, a, part, ldp, ks, BP, ssp, ch);
     return (int)hipGetLastError();
 }
 
