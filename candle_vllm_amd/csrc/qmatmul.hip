@@ -1688,12 +1688,14 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
         if (want < 1) want = 1;
         ks = want;
     }
-    if (g_tune_ks_target > 0 && a.nseg == 1 && a.seg[0].type == MI355_GGML_Q6_K && nkb >= 32) {
-        // a Q6_K launch of long K (the down projection: 256 tiles x 56 k-blocks) is bound by its unpack arithmetic (411 VALU per tile and
-        // k-block, profiles/r03_pmc_sq_b32_set1.json), not by bytes: with the power-of-two split it runs 37 x 4 = 148 workgroups on 256
-        // CUs.  The smallest integer split that covers the chip: 37 x 7 = 259 workgroups of 8 k-blocks.
+    if (g_tune_ks_target > 0 && a.nseg == 1 && nkb >= 32 && a.seg[0].type == MI355_GGML_Q6_K) {
+        // a Q6_K launch of long K (the down projection: 256 tiles x 56 k-blocks) is bound by its unpack arithmetic and the latency of
+        // its own chain (411 VALU per tile and k-block, profiles/r03_pmc_sq_b32_set1.json), not by bytes: with the power-of-two split
+        // it runs 37 x 4 = 148 workgroups, ONE per CU on 58 % of the chip.  Measured (round 4, same box): 37 x 7 = 259 workgroups (every
+        // CU, still one each) 27.6 -> 28.5 us; 37 x 14 = 518 (two per CU: the second workgroup's waves fill the first's stalls) 23.8 us,
+        // the ragged batch-32 step 6239 -> 6327 tok/s.  The same split for the Q4_K down projection: -0.3 % (its chain is shorter).
         const int n_wg = (n_slots + QMG_NC - 1) / QMG_NC;
-        const int cus = 256;                                              // MI355X
+        const int cus = 512;                                              // MI355X: two workgroups per CU (see below)
         if (n_wg * ks < cus) {
             int want = (cus + n_wg - 1) / n_wg;
             while (want > 1 && nkb / want < 4) --want;
