@@ -404,7 +404,7 @@ def leg_mixtral_prompt_16k(T=16384, chunk=8192):
 
 
 LEGS = {"bf16_b32": leg_bf16_b32, "gptq_qwen2": leg_gptq_qwen2, "mixtral_fp8": leg_mixtral_fp8, "bf16_prompt": leg_bf16_prompt, "mixtral_fp8_b32": leg_mixtral_fp8_b32, "gptq_qwen2_b32": leg_gptq_qwen2_b32, "engine_b32": leg_engine_b32, "mixtral_prompt_16k": leg_mixtral_prompt_16k}
-NO_PARITY_LEG = {"bf16_prompt", "mixtral_fp8_b32", "engine_b32", "mixtral_prompt_16k"}   # covered by tests: test_gpu_linear.py (>= 96 tokens), test_gpu_dense_model.py; test_gpu_model.py (device-grouped experts)
+NO_PARITY_LEG = {"bf16_prompt", "engine_b32", "mixtral_prompt_16k"}    # bf16_prompt: test_gpu_linear.py (>= 96 tokens), test_gpu_dense_model.py; the other two carry / name their own parity   # covered by tests: test_gpu_linear.py (>= 96 tokens), test_gpu_dense_model.py; test_gpu_model.py (device-grouped experts)
 
 
 def leg_parity(name):
@@ -415,6 +415,11 @@ def leg_parity(name):
         from tests.fullsize_moe import MoePair
         p = MoePair(n_layers=32, scale=0.2)
         r = p.run(ctx=4097, steps=2)
+    elif name == "mixtral_fp8_b32":
+        from tests.fullsize_moe import MoePair
+        from tests.fullsize_dense import ragged_batch32
+        p = MoePair(n_layers=32, scale=0.2, max_batch=32, num_blocks=320)
+        r = p.run_batch(ragged_batch32(np.random.default_rng(4321)), steps=1)
     else:
         from tests.fullsize_dense import DensePair, ragged_batch32
         base = "gptq_qwen2" if name.startswith("gptq_qwen2") else name

@@ -33,7 +33,7 @@ def _native(rng, ggml_type, n, k, scale):
 
 
 class MoePair:
-    def __init__(self, n_layers=32, scale=1.0, seed=31, log=None, max_seq=8192, ctx_tokens=4096 + 16):
+    def __init__(self, n_layers=32, scale=1.0, seed=31, log=None, max_seq=8192, ctx_tokens=4096 + 16, max_batch=1, num_blocks=None):
         import torch
         from candle_vllm_amd import model as M
         self.torch, self.M = torch, M
@@ -48,7 +48,7 @@ class MoePair:
         rng = np.random.default_rng(seed)
         t0 = time.time()
         self.bps = -(-ctx_tokens // cfg.block_size)
-        gm = M.GGUFLLaMa(gcfg, max_batch=1, max_blocks_per_seq=self.bps, kv_layout=M.KV_PAGED_FP8)
+        gm = M.GGUFLLaMa(gcfg, max_batch=max_batch, max_blocks_per_seq=self.bps, kv_layout=M.KV_PAGED_FP8)
         self.gm = gm
         hid, I, H, Hkv, D = cfg.hidden, cfg.intermediate, cfg.n_heads, cfg.n_kv_heads, cfg.head_dim
 
@@ -88,7 +88,7 @@ class MoePair:
         self.orc.kv_fp8 = True
         self.log(f"mixtral: weights in both models: {time.time() - t0:.1f}s")
         t0 = time.time()
-        self.num_blocks = self.bps + 8
+        self.num_blocks = num_blocks or (self.bps + 8)
         gm.alloc_kv_cache(self.num_blocks)
         ks, vs = O.kv_cache_shapes(self.num_blocks, cfg.block_size, Hkv, D, 1, False)
         kb = rng.integers(0, 120, ks, dtype=np.uint8)                     # finite e4m3 codes
@@ -186,6 +186,60 @@ class MoePair:
         res.update({"steps_compared": done, "logits_max_rel_err": worst, "tokens_equal": bool(equal), "near_tie_tokens": ties})
         return res
 
+
+
+    # ------------------------------------------------------------------------------------------------ batch of ragged sequences
+    def run_batch(self, seq_lens, steps=1):
+        """the timed batch-32 geometry of bench_legs.py `mixtral_fp8_b32`: ragged contexts, the (token, slot) pairs grouped by expert on the
+        device, fp8 KV cache, hipGraph replay -- greedy steps end to end against OracleLlama (O1f products)."""
+        keep = OL._qmm
+        OL._qmm = lambda x, tw, o2: cref.qmatmul(np.ascontiguousarray(x, np.float32), tw[1], tw[0], 2)
+        try:
+            cfg, gm, rng = self.cfg, self.gm, self.rng
+            bs, B = cfg.block_size, len(seq_lens)
+            seqs, nxt = [], 1
+            for L in seq_lens:
+                n = -(-(int(L) + steps) // bs)
+                seqs.append({"tokens": [0] * (int(L) - 1) + [int(rng.integers(0, cfg.vocab))], "block_table": list(range(nxt, nxt + n))})
+                nxt += n
+            assert nxt <= self.num_blocks, (nxt, self.num_blocks)
+            bt = np.zeros((B, self.bps), np.uint32)
+            for i, q in enumerate(seqs):
+                bt[i, : len(q["block_table"])] = q["block_table"]
+            st = self.stream.cuda_stream
+            gm.set_graph(True)
+            gm.decode_begin([q["tokens"][-1] for q in seqs], [len(q["tokens"]) for q in seqs], bt, ctx_cap=int(max(seq_lens)) + steps, stream=st)
+            cache1 = [(k.copy(), v.copy()) for k, v in self.cache]
+            worst, equal, ties, done, t_orc = 0.0, True, 0, 0, 0.0
+            for step in range(steps):
+                gm.decode_step(st)
+                toks = [int(t) for t in gm.read_tokens(st)]
+                got = gm.logits_numpy(B)
+                meta = O.prepare_decode(seqs, bs)
+                meta["block_tables"] = bt
+                t0 = time.time()
+                ref = self.orc.forward(meta, cache1)
+                t_orc += time.time() - t0
+                done += 1
+                for b in range(B):
+                    err = float(np.abs(got[b] - ref[b]).max())
+                    worst = max(worst, err / float(np.abs(ref[b]).max()))
+                    want = int(ref[b].argmax())
+                    if toks[b] != want:
+                        top2 = np.partition(ref[b], -2)[-2:]
+                        if float(top2[1] - top2[0]) <= 2.0 * err:
+                            ties += 1
+                            want = toks[b]
+                        else:
+                            equal = False
+                    seqs[b]["tokens"].append(want)
+                if not equal:
+                    break
+            return {"leg": "mixtral_fp8_b32", "batch": B, "ctx_max": int(max(seq_lens)), "layers": cfg.n_layers, "steps_compared": done,
+                    "logits_max_rel_err": worst, "tokens_equal": bool(equal), "near_tie_tokens": ties,
+                    "oracle": "O1f (unpinned), fp8 KV, experts per token", "oracle_s_per_step": round(t_orc / max(done, 1), 1)}
+        finally:
+            OL._qmm = keep
 
     # ------------------------------------------------------------------------------------------------ configs[4]: chunked prefill at size
     def run_chunked_prompt(self, T=16384, chunk=8192):
