@@ -1753,6 +1753,23 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
         if ((ldp + 255) / 256 <= 8192) fz.ticket = static_cast<unsigned*>(tk);
     }
     if (!chained) hipLaunchKernelGGL((qw1_prep_kernel<MT>), dim3(nkb, MT * 2), dim3(256), 0, st, img, ssp, a, kbb);
+    // per-tile epilogue inside the GEMM launches (qmm_wide1_gemm.inc, TEPI): mat-muls that stage no image for a successor -- q|k|v (RoPE +
+    // cache write), the lm_head, unchained stores / residual adds.  Key 9 = 2 keeps the separate epilogue launch (A/B).
+    const bool tepi = !fz.ticket && !want && g_tune_chain != 2 && n_slots <= 8192 &&
+                      (a.epi == MI355_EPI_QKV_ROPE_CACHE || a.epi == MI355_EPI_STORE || a.epi == MI355_EPI_RESID);
+    if (tepi) {
+        void* tk = nullptr;
+        rc = mi355_scratch_get(&tk, MI355_SCR_QMM_TICKET, 8192 * sizeof(unsigned), st, true);
+        if (rc) return rc;
+        fz.tile_ticket = static_cast<unsigned*>(tk);
+        static bool tepi_attr = false;
+        if (!tepi_attr) {
+            (void)hipFuncSetAttribute((const void*)qw1_gemm_tepi_kernel<MT, MI355_GGML_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)qw1_gemm_tepi_kernel<MT, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)qw1_gemm2_tepi_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            tepi_attr = true;
+        }
+    }
     int s_split = 0, slots0 = 0;                                     // exactly one Q4_K run followed by one Q6_K run: one launch
     while (s_split < a.nseg && a.seg[s_split].type == MI355_GGML_Q4_K) slots0 += a.seg[s_split++].n_tiles;
     bool two_runs = g_tune_merge && s_split > 0 && s_split < a.nseg;
@@ -1768,7 +1785,8 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
     if (two_runs) {
         const int slots1 = n_slots - slots0;
         const dim3 ggrid((slots0 + QMG_NC - 1) / QMG_NC + (slots1 + QMG_NC - 1) / QMG_NC, ks);
-        hipLaunchKernelGGL((qw1_gemm2_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, a, img, part, ldp, s_split, slots0, slots1, fz);
+        if (tepi) hipLaunchKernelGGL((qw1_gemm2_tepi_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb + 256, st, a, img, part, ldp, s_split, slots0, slots1, fz);
+        else hipLaunchKernelGGL((qw1_gemm2_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, a, img, part, ldp, s_split, slots0, slots1, fz);
     }
     for (int s0 = 0, slot_base = 0; s0 < a.nseg && !two_runs;) {
         int s1 = s0 + 1;
@@ -1789,7 +1807,12 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
                 hipLaunchKernelGGL((qw1_gemm_run_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, full, img, part, ldp, run_slots, slot_base, s0, s1, fz);
         } else
 #endif
-        if (r.seg[0].type == MI355_GGML_Q4_K)
+        if (tepi) {                                                   // the whole descriptor: the epilogue needs every segment's rows
+            if (r.seg[0].type == MI355_GGML_Q4_K)
+                hipLaunchKernelGGL((qw1_gemm_tepi_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), 2 * kbb + 256, st, a, img, part, ldp, run_slots, slot_base, s0, s1, fz);
+            else
+                hipLaunchKernelGGL((qw1_gemm_tepi_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb + 256, st, a, img, part, ldp, run_slots, slot_base, s0, s1, fz);
+        } else if (r.seg[0].type == MI355_GGML_Q4_K)
             hipLaunchKernelGGL((qw1_gemm_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), 2 * kbb, st, r, img, part, ldp, run_slots, slot_base, fz);
         else
             hipLaunchKernelGGL((qw1_gemm_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, r, img, part, ldp, run_slots, slot_base, fz);
@@ -1798,7 +1821,7 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
     }
     if (want) qs.chain = QmgChainState{true, a.out, a.B, a.next_k, MT, cur ^ 1, a.next_norm_w, st, 1};
     qs.cur = cur;
-    if (!fz.ticket)
+    if (!fz.ticket && !tepi)
         hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, want ? BP : a.B), dim3(256), 0, st, a, part, ldp, ks, BP, ssp, ch);
     return (int)hipGetLastError();
 }

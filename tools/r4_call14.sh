@@ -1,0 +1,14 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/r4c14
+mkdir -p $OUT
+cd $R
+timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py tests/test_gpu_engine.py tests/test_gpu_tp2.py tests/test_gpu_fp8kv.py tests/test_gpu_fullsize.py -m gpu -q -k "not dense and not gptq and not bf16" > $OUT/pytest.log 2>&1
+tail -5 $OUT/pytest.log
+B32_STEPS=16 B32_AB="9=1;9=2;9=1;9=2" timeout 300 python tools/exp_b32.py 2>&1 | grep "tok/s" > $OUT/b32.log; cat $OUT/b32.log
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_b32
+B32_STEPS=6 timeout 200 rocprofv3 --kernel-trace -d /tmp/prof_b32 --output-format csv -- python $R/tools/exp_b32.py > /tmp/b32_trace.log 2>&1
+f=$(find /tmp/prof_b32 -name "*kernel_trace.csv" | head -1)
+python $R/tools/trace_groups.py "$f" | grep -v "at::native" > $OUT/b32_groups.txt 2>&1
+head -14 $OUT/b32_groups.txt
