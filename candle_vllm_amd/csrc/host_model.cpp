@@ -562,6 +562,10 @@ extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
         (cfg->hidden % 256) || cfg->max_blocks_per_seq <= 0 || cfg->max_seq <= 0 || cfg->block_size <= 0 ||
         cfg->n_heads <= 0 || cfg->n_kv_heads <= 0 || cfg->vocab <= 0 || cfg->intermediate <= 0)
         return nullptr;
+    // vocab-parallel lm_head: every rank holds pad_vocab / world rows.  pad_vocab_size rounds to 64 AFTER it rounded to the world size
+    // (distributed.rs:1446-1452), so for a world that does not divide 64 (3, 6, ...) the padded size may not divide: refused here, before
+    // a single weight is loaded, instead of at the first step
+    if (cfg->tp_world > 1 && pad_vocab(cfg->vocab, cfg->tp_world) % cfg->tp_world != 0) return nullptr;
     Model* m = nullptr;
     try {
     m = new Model();
@@ -586,7 +590,7 @@ extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
         alloc((void**)&m->moe_y, (size_t)B * KE * cfg->hidden * 4);
         if (moe_group_pays(B * KE, cfg->n_expert)) {          // device-grouped decode: every expert owns B * KE rows of these
             m->g_cap = (B * KE + 31) / 32 * 32;                // whole 32-row chunks: the launch shape of every (expert, chunk)
-            const size_t rows = (size_t)cfg->n_expert * m->g_cap;
+            const size_t rows = (size_t)cfg->n_expert * m->g_cap + 1;            // + the dump row of an out-of-range expert id (moe_group_kernel)
             alloc((void**)&m->g_moe_xg, rows * cfg->hidden * 4);
             alloc((void**)&m->g_moe_h, rows * cfg->intermediate * 4);
             alloc((void**)&m->g_moe_yg, rows * cfg->hidden * 4);
@@ -1216,6 +1220,7 @@ int load_gguf_impl(const char* path, int32_t max_batch, int32_t max_blocks_per_s
             const int i = info(name, dd, &t, &n);
             if (i < 0) return (int)hipErrorInvalidValue;
             if (t != MI355_GGML_Q4_K && t != MI355_GGML_Q6_K) return (int)hipErrorNotSupported;
+            if (pad_vocab(vocab, tp_world) % tp_world != 0) return (int)hipErrorInvalidValue;   // (also refused by mi355_llama_create)
             const int64_t local = pad_vocab(vocab, tp_world) / tp_world;
             const int64_t bytes = mi355_gguf_tensor_rows_padded(g, i, (int64_t)tp_rank * local, local, nullptr, 0);
             if (bytes < 0) return (int)hipErrorInvalidValue;

@@ -109,7 +109,9 @@ __global__ void __launch_bounds__(256) moe_group_kernel(int32_t* __restrict__ po
         const int e = ids[p];
         int before = 0;
         for (int q = 0; q < p; ++q) before += ids[q] == e ? 1 : 0;
-        pos[p] = (e >= 0 && e < n_expert) ? e * cap + before : 0;
+        // an id outside [0, n_expert) (a corrupted router output) gets the DUMP row n_expert * cap: no expert's block, never read by an
+        // expert GEMM, so it cannot collide with expert 0's first pair; callers size their row buffers (n_expert * cap + 1)
+        pos[p] = (e >= 0 && e < n_expert) ? e * cap + before : n_expert * cap;
     }
 }
 __global__ void __launch_bounds__(256) moe_gather_pos_kernel(float* __restrict__ dst, const float* __restrict__ src, const int32_t* __restrict__ pos,

@@ -46,6 +46,8 @@ def _rows_padded(tw, rank, world, vocab):
     narrowed logits are shifted -- DESIGN.md section 7; this is the layout of VocabParallelLinear::from_weight_bias, distributed.rs:1534-1550:
     pad the whole matrix, then narrow(rank * local, local): logits == the unsharded model's.)"""
     t, b = tw
+    if pad_vocab_size(vocab, world) % world:
+        raise ValueError(f"pad_vocab_size({vocab}, {world}) does not divide by the world size (a world that does not divide 64)")
     local = pad_vocab_size(vocab, world) // world
     lo, hi = rank * local, min((rank + 1) * local, vocab)
     real = b[lo:hi] if hi > lo else b[:0]
@@ -86,6 +88,8 @@ def shard_config(cfg, rank, world):
     local.n_heads = cfg.n_heads // world
     local.n_kv_heads = kv_head_shard(cfg.n_kv_heads, rank, world)[0]
     local.intermediate = cfg.intermediate if getattr(cfg, "n_expert", 0) else cfg.intermediate // world   # MoE: replicated
+    if pad_vocab_size(cfg.vocab, world) % world:
+        raise ValueError(f"pad_vocab_size({cfg.vocab}, {world}) does not divide by the world size (a world that does not divide 64)")
     local.vocab = pad_vocab_size(cfg.vocab, world) // world          # rows of this rank's lm_head shard (zero rows included)
     local.vocab_total = cfg.vocab                                    # what the gathered logits are narrowed to
     return local

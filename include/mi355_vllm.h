@@ -257,7 +257,8 @@ int mi355_moe_combine(float* ys, const float* y_pairs, const float* weights, int
  * every expert owns `cap` rows (cap >= num_pairs) of the gathered buffers; mi355_moe_group writes pos[p] = expert_ids[p] * cap +
  * (earlier pairs of the same expert) and, when counts != NULL, the pairs per expert (the rows_dev gate of mi355_qmm_desc); mi355_moe_gather_pos copies token p / top_k into row pos[p]; the expert GEMMs then run over
  * all cap rows of every expert (rows are independent; unwritten rows are never read back) and mi355_moe_scatter_combine(inv = pos)
- * adds the weighted rows to the residual -- quantized_llama.rs:93-119 without `to_vec2`. */
+ * adds the weighted rows to the residual -- quantized_llama.rs:93-119 without `to_vec2`.  An expert id outside [0, n_expert) is sent to
+ * the DUMP row n_expert * cap (size the row buffers n_expert * cap + 1): it joins no expert's block and is not counted. */
 int mi355_moe_group(int32_t* pos, int32_t* counts, const int32_t* expert_ids, int32_t num_pairs, int32_t n_expert, int32_t cap, int64_t stream);
 int mi355_moe_gather_pos(float* dst, const float* src, const int32_t* pos, int32_t num_pairs, int32_t top_k, int32_t hidden, int64_t stream);
 int mi355_moe_gather(float* dst, const float* src, const int32_t* perm, int32_t num_pairs, int32_t top_k, int32_t hidden, int64_t stream);
