@@ -1754,9 +1754,15 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
     }
     if (!chained) hipLaunchKernelGGL((qw1_prep_kernel<MT>), dim3(nkb, MT * 2), dim3(256), 0, st, img, ssp, a, kbb);
     // per-tile epilogue inside the GEMM launches (qmm_wide1_gemm.inc, TEPI): mat-muls that stage no image for a successor -- q|k|v (RoPE +
-    // cache write), the lm_head, unchained stores / residual adds.  Key 9 = 2 keeps the separate epilogue launch (A/B).
-    const bool tepi = !fz.ticket && !want && g_tune_chain != 2 && n_slots <= 8192 &&
-                      (a.epi == MI355_EPI_QKV_ROPE_CACHE || a.epi == MI355_EPI_STORE || a.epi == MI355_EPI_RESID);
+    // cache write), the lm_head, unchained stores / residual adds.
+    // EXPERIMENT, probe builds only (key 49 = 2): measured in round 4 and lost -- q|k|v 40.7 us against 12.7 + 7.5 us for GEMM + epilogue
+    // launch, the lm_head 158 against 125 + 10 us, the ragged batch-32 step 5336 against 6130 tok/s (profiles/r04_b32_tile_epilogue_ab.txt):
+    // a wave that applies RoPE + the cache write to its eight elements walks eight chains of dependent loads (position -> cos / sin ->
+    // slot -> store) one after the other, where the epilogue launch gives every element its own thread.
+    bool tepi = false;
+#if QW1_FUSE_BUILD
+    tepi = g_tune_wide_fuse == 2 && !fz.ticket && !want && n_slots <= 8192 &&
+           (a.epi == MI355_EPI_QKV_ROPE_CACHE || a.epi == MI355_EPI_STORE || a.epi == MI355_EPI_RESID);
     if (tepi) {
         void* tk = nullptr;
         rc = mi355_scratch_get(&tk, MI355_SCR_QMM_TICKET, 8192 * sizeof(unsigned), st, true);
@@ -1770,6 +1776,7 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
             tepi_attr = true;
         }
     }
+#endif
     int s_split = 0, slots0 = 0;                                     // exactly one Q4_K run followed by one Q6_K run: one launch
     while (s_split < a.nseg && a.seg[s_split].type == MI355_GGML_Q4_K) slots0 += a.seg[s_split++].n_tiles;
     bool two_runs = g_tune_merge && s_split > 0 && s_split < a.nseg;
@@ -1785,8 +1792,11 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
     if (two_runs) {
         const int slots1 = n_slots - slots0;
         const dim3 ggrid((slots0 + QMG_NC - 1) / QMG_NC + (slots1 + QMG_NC - 1) / QMG_NC, ks);
+#if QW1_FUSE_BUILD
         if (tepi) hipLaunchKernelGGL((qw1_gemm2_tepi_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb + 256, st, a, img, part, ldp, s_split, slots0, slots1, fz);
-        else hipLaunchKernelGGL((qw1_gemm2_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, a, img, part, ldp, s_split, slots0, slots1, fz);
+        else
+#endif
+        hipLaunchKernelGGL((qw1_gemm2_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, a, img, part, ldp, s_split, slots0, slots1, fz);
     }
     for (int s0 = 0, slot_base = 0; s0 < a.nseg && !two_runs;) {
         int s1 = s0 + 1;
@@ -1807,12 +1817,15 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
                 hipLaunchKernelGGL((qw1_gemm_run_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, full, img, part, ldp, run_slots, slot_base, s0, s1, fz);
         } else
 #endif
+#if QW1_FUSE_BUILD
         if (tepi) {                                                   // the whole descriptor: the epilogue needs every segment's rows
             if (r.seg[0].type == MI355_GGML_Q4_K)
                 hipLaunchKernelGGL((qw1_gemm_tepi_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), 2 * kbb + 256, st, a, img, part, ldp, run_slots, slot_base, s0, s1, fz);
             else
                 hipLaunchKernelGGL((qw1_gemm_tepi_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb + 256, st, a, img, part, ldp, run_slots, slot_base, s0, s1, fz);
-        } else if (r.seg[0].type == MI355_GGML_Q4_K)
+        } else
+#endif
+        if (r.seg[0].type == MI355_GGML_Q4_K)
             hipLaunchKernelGGL((qw1_gemm_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), 2 * kbb, st, r, img, part, ldp, run_slots, slot_base, fz);
         else
             hipLaunchKernelGGL((qw1_gemm_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, r, img, part, ldp, run_slots, slot_base, fz);

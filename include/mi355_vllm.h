@@ -270,8 +270,7 @@ int mi355_moe_scatter_combine(float* ys, const float* y_sorted, const float* wei
  *       2 = always; bits 4.. = partitions per workgroup (0 = chosen per launch, else 1 | 4 | 8 | 16)
  *    5  decode-attention partition size of the step drivers (0 = their own choice: 32, or 64 for the balanced stream)
  *    6  prompt steps (>= 96 tokens) on the hand-written quantised GEMM (1, default) or streamed like decode batches (0)
- *    9  9..32-token path: 1 (default) = an epilogue stages the next mat-mul's activation image, and mat-muls that stage none (q|k|v,
- *       lm_head) run their epilogue per row tile inside the GEMM launch; 2 = chained, every epilogue a launch of its own; 0 = neither
+ *    9  chained wide launches: an epilogue stages the next mat-mul's activation image (1, default)
  *   24  "exact" activations on the 9..32-token and prompt paths: f16 hi + lo planes instead of one f16 plane (0, default)
  *   30  16-bit / GPTQ linears, bit mask of folded launches switched OFF: 1 the 1..4-token 4-bit kernel, 2 no RMSNorm on the way in,
  *       4 RoPE + cache write in their own launch, 8 the LDS-shared-activation 16-bit kernel, 16 the one-pass 4-bit prompt GEMM

@@ -3,7 +3,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/r4c14
 mkdir -p $OUT
 cd $R
-timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py tests/test_gpu_engine.py tests/test_gpu_tp2.py tests/test_gpu_fp8kv.py tests/test_gpu_fullsize.py -m gpu -q -k "not dense and not gptq and not bf16" > $OUT/pytest.log 2>&1
+timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -m gpu -q -k "wide or chain or moe or tokens" > $OUT/pytest.log 2>&1
 tail -5 $OUT/pytest.log
 B32_STEPS=16 B32_AB="9=1;9=2;9=1;9=2" timeout 300 python tools/exp_b32.py 2>&1 | grep "tok/s" > $OUT/b32.log; cat $OUT/b32.log
 cd /tmp && export TMPDIR=/tmp
