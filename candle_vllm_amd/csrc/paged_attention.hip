@@ -1644,14 +1644,17 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
                                              : launch_flash<MI355_DTYPE_F16, false>(p, B, P, st);
     } else if (layout == MI355_KV_PAGED && dtype == MI355_DTYPE_BF16 && !p.kv8 && p.partition_size == 64 && P > 1 &&
                mi355_pa_stream_auto(B, p.H, p.Hkv, p.D, p.block_size)) {
-        // one balanced stream of 64-token stages per workgroup, W workgroups per kv head (one per CU); partials merged by the reduce launch
-        constexpr int PAS_R = 4;
+        // one balanced stream of 64-token stages per workgroup, W workgroups per kv head; partials merged by the reduce launch.
+        // TWO workgroups per CU (W x Hkv = 512) on a ring of two stages each (80 KiB of LDS): a workgroup is four waves, one per SIMD,
+        // and alone on its CU every wait of its chain is dead time -- measured (round 4, one box, alternated): ring of 4 / one workgroup
+        // per CU 6218 / 6238 tok/s, ring of 2 / two per CU 6361 / 6386 on the ragged batch-32 step
+        constexpr int PAS_R = 2;
         static bool attr_done = false;
         if (!attr_done) {
             (void)hipFuncSetAttribute((const void*)paged_attn_stream_kernel<PAS_R>, hipFuncAttributeMaxDynamicSharedMemorySize, PAS_R * 32768 + 16384);
             attr_done = true;
         }
-        int W = 256 / p.Hkv;
+        int W = 512 / p.Hkv;
         if (W < 1) W = 1;
         if (W > 64) W = 64;
         if (W > P) W = P;
