@@ -223,6 +223,12 @@ struct TileRegs { uint4 a, b, c, d; uint32_t e; };
 #endif
 typedef const void __attribute__((address_space(1)))* qmg_gptr_t;
 typedef void __attribute__((address_space(3)))* qmg_lptr_t;
+// one wave-wide 16-B LDS DMA (lane i lands at lds_dst + 16 i) the compiler does NOT track: the caller counts s_waitcnt vmcnt itself
+__device__ __forceinline__ void qmg_dma16(const uint8_t* gsrc_lane, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_dst) : "memory");
+}
 
 // WT = MI355_GGML_Q4_K / MI355_GGML_Q6_K when every tile of the launch has that type (3 resp. 5 loads per unit),
 // 0 for mixed launches: both types then issue 5 loads (Q4_K adds two same-line dummies) so that the number of
@@ -1793,10 +1799,10 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
         const int slots1 = n_slots - slots0;
         const dim3 ggrid((slots0 + QMG_NC - 1) / QMG_NC + (slots1 + QMG_NC - 1) / QMG_NC, ks);
 #if QW1_FUSE_BUILD
-        if (tepi) hipLaunchKernelGGL((qw1_gemm2_tepi_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb + 256, st, a, img, part, ldp, s_split, slots0, slots1, fz);
+        if (tepi) hipLaunchKernelGGL((qw1_gemm2_tepi_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>), ggrid, dim3(512), QW1_NB * qw1_stage_bytes(MT, true) + 256, st, a, img, part, ldp, s_split, slots0, slots1, fz);
         else
 #endif
-        hipLaunchKernelGGL((qw1_gemm2_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, a, img, part, ldp, s_split, slots0, slots1, fz);
+        hipLaunchKernelGGL((qw1_gemm2_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>), ggrid, dim3(512), QW1_NB * qw1_stage_bytes(MT, true), st, a, img, part, ldp, s_split, slots0, slots1, fz);
     }
     for (int s0 = 0, slot_base = 0; s0 < a.nseg && !two_runs;) {
         int s1 = s0 + 1;
@@ -1812,23 +1818,23 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
             // a mat-mul of several launches: the kernel's segment walk starts at the run's first segment
             QmmArgs full = a;
             if (r.seg[0].type == MI355_GGML_Q4_K)
-                hipLaunchKernelGGL((qw1_gemm_run_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), 2 * kbb, st, full, img, part, ldp, run_slots, slot_base, s0, s1, fz);
+                hipLaunchKernelGGL((qw1_gemm_run_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), QW1_NB * qw1_stage_bytes(MT, true), st, full, img, part, ldp, run_slots, slot_base, s0, s1, fz);
             else
-                hipLaunchKernelGGL((qw1_gemm_run_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, full, img, part, ldp, run_slots, slot_base, s0, s1, fz);
+                hipLaunchKernelGGL((qw1_gemm_run_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), QW1_NB * qw1_stage_bytes(MT, false), st, full, img, part, ldp, run_slots, slot_base, s0, s1, fz);
         } else
 #endif
 #if QW1_FUSE_BUILD
         if (tepi) {                                                   // the whole descriptor: the epilogue needs every segment's rows
             if (r.seg[0].type == MI355_GGML_Q4_K)
-                hipLaunchKernelGGL((qw1_gemm_tepi_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), 2 * kbb + 256, st, a, img, part, ldp, run_slots, slot_base, s0, s1, fz);
+                hipLaunchKernelGGL((qw1_gemm_tepi_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), QW1_NB * qw1_stage_bytes(MT, true) + 256, st, a, img, part, ldp, run_slots, slot_base, s0, s1, fz);
             else
-                hipLaunchKernelGGL((qw1_gemm_tepi_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb + 256, st, a, img, part, ldp, run_slots, slot_base, s0, s1, fz);
+                hipLaunchKernelGGL((qw1_gemm_tepi_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), QW1_NB * qw1_stage_bytes(MT, false) + 256, st, a, img, part, ldp, run_slots, slot_base, s0, s1, fz);
         } else
 #endif
         if (r.seg[0].type == MI355_GGML_Q4_K)
-            hipLaunchKernelGGL((qw1_gemm_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), 2 * kbb, st, r, img, part, ldp, run_slots, slot_base, fz);
+            hipLaunchKernelGGL((qw1_gemm_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), QW1_NB * qw1_stage_bytes(MT, true), st, r, img, part, ldp, run_slots, slot_base, fz);
         else
-            hipLaunchKernelGGL((qw1_gemm_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), 2 * kbb, st, r, img, part, ldp, run_slots, slot_base, fz);
+            hipLaunchKernelGGL((qw1_gemm_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), QW1_NB * qw1_stage_bytes(MT, false), st, r, img, part, ldp, run_slots, slot_base, fz);
         slot_base += run_slots;
         s0 = s1;
     }
@@ -2060,6 +2066,12 @@ static int g_tune_qpg_fepi = 1;                            // mi355_set_tuning(4
 static int g_tune_qpg_min = 96;                            // mi355_set_tuning(12, n): fewest tokens that take the prompt-step GEMM (QMP_MIN_TOKENS)
 static int g_tune_dbg = 0;                                 // mi355_set_tuning(2, v): probe / ablation modes (experiments only)
 
+// fewest tokens of a launch that take the 128-token tile of the LDS-fed prompt GEMM.  Measured (round 4, one box, Llama-3-8B Q4_K_M prompt
+// step, 64- vs 128-token tile): T = 512: 21.8 k vs 20.0 k tok/s (896 vs 448 workgroups on the widest launch: 3.5 vs 1.75 rounds of the 256
+// CUs), T = 2048: 34.6 k vs 37.3 k, T = 4096: 31.4 k vs 34.6 k
+#ifndef QPG_MTW8_MIN_TOKENS
+#define QPG_MTW8_MIN_TOKENS 1024
+#endif
 #include "qmm_prefill.inc"
 
 // hand-written prompt-step GEMM (qmm_prefill.inc); returns hipErrorNotSupported for launches it does not cover (then the
@@ -2097,9 +2109,13 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
 #undef QPG_ATTR
         (void)hipFuncSetAttribute((const void*)qpg_gemm_kernel<MI355_GGML_Q4_K, 2, 4, 1, 8, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_kernel<MI355_GGML_Q4_K, 4, 2, 1, 8, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_lds_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_lds_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_lds_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_lds_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     hipLaunchKernelGGL(qpg_rowstat_kernel, dim3(Tpad), dim3(256), 0, st, a, im);
@@ -2116,8 +2132,12 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
             r.norm_w = nullptr;                                 // applied while the image was built
             if (g_tune_qpg == 2) {                              // 64 tokens x 256 rows per workgroup (waves 64 x 32): every unpacked weight meets 64 tokens
                 const dim3 g_(Tpad / 64, (n_slots + 15) / 16), b_(512);
-                const size_t sh_ = (size_t)2 * 64 * QPG_ROWB;
-                hipLaunchKernelGGL((qpg_gemm_kernel<MI355_GGML_Q4_K, 4, 2, 1, 8, false, 1, true>), g_, b_, sh_, st, r, im, C, ldp, n_slots, 0);
+                if (T >= QPG_MTW8_MIN_TOKENS) {
+                    const dim3 g8(Tpad / 128, (n_slots + 15) / 16);
+                    hipLaunchKernelGGL((qpg_gemm_lds_kernel<true, 8>), g8, b_, (size_t)QpgLds<8>::BYTES, st, r, im, C, ldp, n_slots, 0);
+                } else {
+                    hipLaunchKernelGGL((qpg_gemm_lds_kernel<true, 4>), g_, b_, (size_t)QpgLds<4>::BYTES, st, r, im, C, ldp, n_slots, 0);
+                }
             } else {
                 const dim3 g_(Tpad / 32, (n_slots + 31) / 32), b_(512);
                 const size_t sh_ = (size_t)2 * 32 * QPG_ROWB;
@@ -2142,7 +2162,15 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
                 else hipLaunchKernelGGL((qpg_gemm_kernel<MI355_GGML_Q4_K, MTW, NTW, WM, WN, DEEP, 2>), g_, b_, sh_, st, r, im, C, ldp, run_slots, slot_base); } while (0)
             switch (g_tune_qpg) {
                 case 1: QPG_GO(4, 4, 1, 8, false); break;              //  64 x 512, waves 64 x 64
-                case 2: QPG_GO(4, 2, 1, 8, false); break;              //  64 x 256, waves 64 x 32
+                case 2:                                                 //  64 (128) x 256, waves 64 (128) x 32; one activation plane: image and weights through LDS by DMA
+                    if (parts == 1) {
+                        const dim3 g4(Tpad / 64, (run_slots + 15) / 16), g8(Tpad / 128, (run_slots + 15) / 16), b_(512);
+                        if (T >= QPG_MTW8_MIN_TOKENS) hipLaunchKernelGGL((qpg_gemm_lds_kernel<false, 8>), g8, b_, (size_t)QpgLds<8>::BYTES, st, r, im, C, ldp, run_slots, slot_base);
+                        else hipLaunchKernelGGL((qpg_gemm_lds_kernel<false, 4>), g4, b_, (size_t)QpgLds<4>::BYTES, st, r, im, C, ldp, run_slots, slot_base);
+                    } else {
+                        QPG_GO(4, 2, 1, 8, false);                      // hi + lo planes ("exact" activations): the register-fed form
+                    }
+                    break;
                 case 3: QPG_GO(2, 4, 2, 4, false); break;              //  64 x 256, waves 32 x 64
                 default: QPG_GO(2, 4, 1, 8, false); break;             //  32 x 512, waves 32 x 64: measured best in round 2 (hi + lo planes); with one plane 64 x 256 wins (round 4: 25.7 k -> 27.0 k tok/s at T = 2048)
             }
@@ -2150,7 +2178,7 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
         } else {
             if (parts == 1 && g_tune_qpg == 2) {                        // Q6_K: 64 tokens x 256 rows per workgroup; token blocks fastest
                 const dim3 grid(Tpad / 64, (run_slots + 15) / 16);
-                hipLaunchKernelGGL((qpg_gemm_q6k_kernel<1, 4>), grid, dim3(512), 16 * 1024, st, r, im, C, ldp, run_slots, slot_base);
+                hipLaunchKernelGGL(qpg_gemm_q6k_lds_kernel, grid, dim3(512), (size_t)QPG6_LDS_BYTES, st, r, im, C, ldp, run_slots, slot_base);
             } else {
                 const dim3 grid(Tpad / 32, (run_slots + 15) / 16);     // 32 tokens x 256 rows
                 if (parts == 1) hipLaunchKernelGGL((qpg_gemm_q6k_kernel<1, 2>), grid, dim3(512), 8 * 1024, st, r, im, C, ldp, run_slots, slot_base);
