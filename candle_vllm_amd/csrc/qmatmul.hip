@@ -2066,11 +2066,11 @@ static int g_tune_qpg_fepi = 1;                            // mi355_set_tuning(4
 static int g_tune_qpg_min = 96;                            // mi355_set_tuning(12, n): fewest tokens that take the prompt-step GEMM (QMP_MIN_TOKENS)
 static int g_tune_dbg = 0;                                 // mi355_set_tuning(2, v): probe / ablation modes (experiments only)
 
-// fewest tokens of a launch that take the 128-token tile of the LDS-fed prompt GEMM.  Measured (round 4, one box, Llama-3-8B Q4_K_M prompt
-// step, 64- vs 128-token tile): T = 512: 21.8 k vs 20.0 k tok/s (896 vs 448 workgroups on the widest launch: 3.5 vs 1.75 rounds of the 256
-// CUs), T = 2048: 34.6 k vs 37.3 k, T = 4096: 31.4 k vs 34.6 k
+// fewest tokens of a launch that take the 128-token tile of the LDS-fed prompt GEMM.  Measured (round 4, Llama-3-8B Q4_K_M prompt step, 64- vs
+// 128-token tile, same box per pair): T = 512: 21.8 k vs 20.0 k tok/s, T = 1024: 30.9 k vs 29.7 k (896 workgroups on the widest launch = 3.5
+// rounds of the 256 CUs against 7), T = 2048: 34.6 k vs 37.3 k, T = 4096: 31.4 k vs 34.6 k
 #ifndef QPG_MTW8_MIN_TOKENS
-#define QPG_MTW8_MIN_TOKENS 1024
+#define QPG_MTW8_MIN_TOKENS 2048
 #endif
 #include "qmm_prefill.inc"
 

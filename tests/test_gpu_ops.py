@@ -681,7 +681,7 @@ def test_paged_attention_lds_dma_stream(cv, bs, ctx):
                 assert np.abs(got - oracle).max() <= tol, (key, np.abs(got - oracle).max())
 
 
-@pytest.mark.parametrize("T,N,K", [(128, 96, 1024), (200, 40, 512), (300, 640, 2048), (97, 16, 256), (1100, 48, 512)])   # (>= 1024 tokens: the 128-token tile)
+@pytest.mark.parametrize("T,N,K", [(128, 96, 1024), (200, 40, 512), (300, 640, 2048), (97, 16, 256), (2100, 48, 512)])   # (>= 2048 tokens: the 128-token tile)
 def test_prompt_gemm_fused_epilogue(cv, T, N, K):
     """the default since round 4: Q4_K prompt-step launches apply store / bias / residual / SiLU * up in the GEMM's own store loop (no C
     buffer, no epilogue launch) -- against the oracle at the prompt path's bound and against the unfused path (tuning key 48 = 0; same
