@@ -1799,10 +1799,10 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
         const int slots1 = n_slots - slots0;
         const dim3 ggrid((slots0 + QMG_NC - 1) / QMG_NC + (slots1 + QMG_NC - 1) / QMG_NC, ks);
 #if QW1_FUSE_BUILD
-        if (tepi) hipLaunchKernelGGL((qw1_gemm2_tepi_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>), ggrid, dim3(512), QW1_NB * qw1_stage_bytes(MT, true) + 256, st, a, img, part, ldp, s_split, slots0, slots1, fz);
+        if (tepi) hipLaunchKernelGGL((qw1_gemm2_tepi_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>), ggrid, dim3(512), QW1_NB * kbb + 256, st, a, img, part, ldp, s_split, slots0, slots1, fz);
         else
 #endif
-        hipLaunchKernelGGL((qw1_gemm2_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>), ggrid, dim3(512), QW1_NB * qw1_stage_bytes(MT, true), st, a, img, part, ldp, s_split, slots0, slots1, fz);
+        hipLaunchKernelGGL((qw1_gemm2_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>), ggrid, dim3(512), QW1_NB * kbb, st, a, img, part, ldp, s_split, slots0, slots1, fz);
     }
     for (int s0 = 0, slot_base = 0; s0 < a.nseg && !two_runs;) {
         int s1 = s0 + 1;
@@ -1818,23 +1818,23 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
             // a mat-mul of several launches: the kernel's segment walk starts at the run's first segment
             QmmArgs full = a;
             if (r.seg[0].type == MI355_GGML_Q4_K)
-                hipLaunchKernelGGL((qw1_gemm_run_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), QW1_NB * qw1_stage_bytes(MT, true), st, full, img, part, ldp, run_slots, slot_base, s0, s1, fz);
+                hipLaunchKernelGGL((qw1_gemm_run_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), QW1_NB * kbb, st, full, img, part, ldp, run_slots, slot_base, s0, s1, fz);
             else
-                hipLaunchKernelGGL((qw1_gemm_run_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), QW1_NB * qw1_stage_bytes(MT, false), st, full, img, part, ldp, run_slots, slot_base, s0, s1, fz);
+                hipLaunchKernelGGL((qw1_gemm_run_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), QW1_NB * kbb, st, full, img, part, ldp, run_slots, slot_base, s0, s1, fz);
         } else
 #endif
 #if QW1_FUSE_BUILD
         if (tepi) {                                                   // the whole descriptor: the epilogue needs every segment's rows
             if (r.seg[0].type == MI355_GGML_Q4_K)
-                hipLaunchKernelGGL((qw1_gemm_tepi_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), QW1_NB * qw1_stage_bytes(MT, true) + 256, st, a, img, part, ldp, run_slots, slot_base, s0, s1, fz);
+                hipLaunchKernelGGL((qw1_gemm_tepi_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), QW1_NB * kbb + 256, st, a, img, part, ldp, run_slots, slot_base, s0, s1, fz);
             else
-                hipLaunchKernelGGL((qw1_gemm_tepi_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), QW1_NB * qw1_stage_bytes(MT, false) + 256, st, a, img, part, ldp, run_slots, slot_base, s0, s1, fz);
+                hipLaunchKernelGGL((qw1_gemm_tepi_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), QW1_NB * kbb + 256, st, a, img, part, ldp, run_slots, slot_base, s0, s1, fz);
         } else
 #endif
         if (r.seg[0].type == MI355_GGML_Q4_K)
-            hipLaunchKernelGGL((qw1_gemm_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), QW1_NB * qw1_stage_bytes(MT, true), st, r, img, part, ldp, run_slots, slot_base, fz);
+            hipLaunchKernelGGL((qw1_gemm_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), QW1_NB * kbb, st, r, img, part, ldp, run_slots, slot_base, fz);
         else
-            hipLaunchKernelGGL((qw1_gemm_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), QW1_NB * qw1_stage_bytes(MT, false), st, r, img, part, ldp, run_slots, slot_base, fz);
+            hipLaunchKernelGGL((qw1_gemm_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), QW1_NB * kbb, st, r, img, part, ldp, run_slots, slot_base, fz);
         slot_base += run_slots;
         s0 = s1;
     }

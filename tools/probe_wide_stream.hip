@@ -136,6 +136,72 @@ __global__ void __launch_bounds__(512, 4) product_like(const uint8_t* __restrict
     } else if (y[0][0] == 1.2345f) part[0] = y[1][1] + y[2][2] + y[3][3];
 }
 
+
+// round 4: the same skeleton with the image of the fourth generation (IKB = 18 KiB per k-block: one f16 plane) and a ring of NBUF stages
+// filled NBUF - 1 k-blocks ahead (counted vmcnt + a bare s_barrier in the loader: the fence of __syncthreads would drain the DMAs)
+template <int IKB, int NBUF, bool STORE, bool LDSREAD>
+__global__ void __launch_bounds__(512, 4) product_like2(const uint8_t* __restrict__ w, const uint8_t* __restrict__ img, float* __restrict__ part,
+                                                        int n_tiles, int ldp) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr size_t kbb = (size_t)IKB * 1024;
+    constexpr int LEAD = NBUF - 1;
+    const int kb_per = NKB / gridDim.y, kb_lo = blockIdx.y * kb_per, kb_hi = kb_lo + kb_per;
+    if (wave == 7) {
+        auto dma = [&](int kb, int buf) {
+            const uint8_t* src = img + (size_t)kb * kbb;
+            uint8_t* dst = smem + (size_t)buf * kbb;
+#pragma unroll
+            for (int c = 0; c < IKB; ++c)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)c * 1024 + lane * 16), (lptr_t)(dst + (size_t)c * 1024), 16, 0, 0);
+        };
+        for (int i = 0; i < LEAD; ++i) if (kb_lo + i < kb_hi) dma(kb_lo + i, i);
+        if (LEAD == 2 && kb_lo + 1 < kb_hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IKB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int bufn = LEAD % NBUF;
+        for (int kb = kb_lo; kb < kb_hi; ++kb) {
+            const bool req = kb + LEAD < kb_hi;
+            if (req) dma(kb + LEAD, bufn);
+            bufn = bufn + 1 == NBUF ? 0 : bufn + 1;
+            if (LEAD == 2 && req) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IKB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+    int slot = blockIdx.x * 7 + wave;
+    const bool have = slot < n_tiles;
+    if (!have) slot = 0;
+    const uint8_t* base = w + (size_t)slot * NKB * TILE_B;
+    float y[4][4];
+    for (int mt = 0; mt < 4; ++mt) for (int v = 0; v < 4; ++v) y[mt][v] = 0.f;
+    Tile cur = ld_tile<true, true>(base + (size_t)kb_lo * TILE_B, lane);
+    __syncthreads();
+    int buf = 0;
+    for (int kb = kb_lo; kb < kb_hi; ++kb) {
+        const bool more = kb + 1 < kb_hi;
+        Tile nxt = ld_tile<true, true>(more ? base + (size_t)(kb + 1) * TILE_B : base, more ? lane : 0);
+        y[0][0] += __uint_as_float(fold(cur) & 0x3fffffffu);
+        if (LDSREAD) {                                                 // the product reads 16 KB of the image per wave and k-block
+            const uint8_t* L = smem + (size_t)buf * kbb;
+            for (int j = 0; j < 16; ++j) {
+                const uint4 a4 = *reinterpret_cast<const uint4*>(L + (size_t)j * 1024 + lane * 16);
+                y[j & 3][(j >> 2) & 3] += __uint_as_float(a4.x & 0x3fffffffu);
+            }
+        }
+        buf = buf + 1 == NBUF ? 0 : buf + 1;
+        cur = nxt;
+        __syncthreads();
+    }
+    const int kg = lane >> 4, rr = lane & 15;
+    if (STORE && have && kg < 2) {
+        float* pp = part + (size_t)blockIdx.y * 32 * ldp + (size_t)slot * 16 + rr;
+        for (int mt = 0; mt < 4; ++mt)
+            for (int v = 0; v < 4; ++v) pp[(size_t)(8 * mt + 4 * kg + v) * ldp] = y[mt][v];
+    }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 int main() {
@@ -197,5 +263,15 @@ int main() {
     PROD("  + both", true, true, false, 1)
     PROD("  + both + 32 KB of LDS reads per wave and k-block", true, true, true, 1)
     PROD("  all, k split 2", true, true, true, 2)
+#define PROD2(name, IKB, NBUF, STORE, LDSREAD, KSPLIT) \
+    { CK(hipFuncSetAttribute((const void*)product_like2<IKB, NBUF, STORE, LDSREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      if (timeit(name, [&](uint8_t* b) { hipLaunchKernelGGL((product_like2<IKB, NBUF, STORE, LDSREAD>), dim3(NT / 7, KSPLIT), dim3(512), (size_t)NBUF * IKB * 1024, st, b, img, part, NT, NT * 16); })) return 1; }
+    PROD2("round 4 image (18 KB per k-block): DMA, double buffer", 18, 2, false, false, 1)
+    PROD2("  + stores + 16 KB of LDS reads per wave and k-block", 18, 2, true, true, 1)
+    PROD2("  three stages, two k-blocks ahead: DMA only", 18, 3, false, false, 1)
+    PROD2("  three stages + stores + LDS reads", 18, 3, true, true, 1)
+    PROD2("  38 KB image, three stages, DMA only", 38, 3, false, false, 1)
+    PROD2("  18 KB, double buffer, all, k split 2", 18, 2, true, true, 2)
+    PROD2("  18 KB, three stages, all, k split 2", 18, 3, true, true, 2)
     return 0;
 }
