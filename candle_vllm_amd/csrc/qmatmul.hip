@@ -2105,15 +2105,17 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
 #define QPG_ATTR(MTW, NTW, WM, WN, DEEP) \
         (void)hipFuncSetAttribute((const void*)qpg_gemm_kernel<MI355_GGML_Q4_K, MTW, NTW, WM, WN, DEEP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
         (void)hipFuncSetAttribute((const void*)qpg_gemm_kernel<MI355_GGML_Q4_K, MTW, NTW, WM, WN, DEEP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)
-        QPG_ATTR(2, 4, 1, 8, false); QPG_ATTR(4, 4, 1, 8, false); QPG_ATTR(4, 2, 1, 8, false); QPG_ATTR(2, 4, 2, 4, false);
-#undef QPG_ATTR
+        QPG_ATTR(4, 2, 1, 8, false);
+#ifdef MI355_QMM_PROBES
+        QPG_ATTR(2, 4, 1, 8, false); QPG_ATTR(4, 4, 1, 8, false); QPG_ATTR(2, 4, 2, 4, false);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_kernel<MI355_GGML_Q4_K, 2, 4, 1, 8, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute((const void*)qpg_gemm_kernel<MI355_GGML_Q4_K, 4, 2, 1, 8, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+#endif
+#undef QPG_ATTR
         (void)hipFuncSetAttribute((const void*)qpg_gemm_lds_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_lds_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_lds_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_lds_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
@@ -2139,9 +2141,11 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
                     hipLaunchKernelGGL((qpg_gemm_lds_kernel<true, 4>), g_, b_, (size_t)QpgLds<4>::BYTES, st, r, im, C, ldp, n_slots, 0);
                 }
             } else {
-                const dim3 g_(Tpad / 32, (n_slots + 31) / 32), b_(512);
+#ifdef MI355_QMM_PROBES
+                const dim3 g_(Tpad / 32, (n_slots + 31) / 32), b_(512);   // rounds 2-3: 32 x 512, register-fed
                 const size_t sh_ = (size_t)2 * 32 * QPG_ROWB;
                 hipLaunchKernelGGL((qpg_gemm_kernel<MI355_GGML_Q4_K, 2, 4, 1, 8, false, 1, true>), g_, b_, sh_, st, r, im, C, ldp, n_slots, 0);
+#endif
             }
             return (int)hipGetLastError();
         }
@@ -2161,8 +2165,12 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
                 if (parts == 1) hipLaunchKernelGGL((qpg_gemm_kernel<MI355_GGML_Q4_K, MTW, NTW, WM, WN, DEEP, 1>), g_, b_, sh_, st, r, im, C, ldp, run_slots, slot_base); \
                 else hipLaunchKernelGGL((qpg_gemm_kernel<MI355_GGML_Q4_K, MTW, NTW, WM, WN, DEEP, 2>), g_, b_, sh_, st, r, im, C, ldp, run_slots, slot_base); } while (0)
             switch (g_tune_qpg) {
+#ifdef MI355_QMM_PROBES
                 case 1: QPG_GO(4, 4, 1, 8, false); break;              //  64 x 512, waves 64 x 64
-                case 2:                                                 //  64 (128) x 256, waves 64 (128) x 32; one activation plane: image and weights through LDS by DMA
+                case 3: QPG_GO(2, 4, 2, 4, false); break;              //  64 x 256, waves 32 x 64
+                case 0: QPG_GO(2, 4, 1, 8, false); break;              //  32 x 512, waves 32 x 64: measured best in round 2 (hi + lo planes); with one plane 64 x 256 wins (round 4: 25.7 k -> 27.0 k tok/s at T = 2048)
+#endif
+                default:                                                //  64 (128) x 256, waves 64 (128) x 32; one activation plane: image and weights through LDS by DMA
                     if (parts == 1) {
                         const dim3 g4(Tpad / 64, (run_slots + 15) / 16), g8(Tpad / 128, (run_slots + 15) / 16), b_(512);
                         if (T >= QPG_MTW8_MIN_TOKENS) hipLaunchKernelGGL((qpg_gemm_lds_kernel<false, 8>), g8, b_, (size_t)QpgLds<8>::BYTES, st, r, im, C, ldp, run_slots, slot_base);
@@ -2171,8 +2179,6 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
                         QPG_GO(4, 2, 1, 8, false);                      // hi + lo planes ("exact" activations): the register-fed form
                     }
                     break;
-                case 3: QPG_GO(2, 4, 2, 4, false); break;              //  64 x 256, waves 32 x 64
-                default: QPG_GO(2, 4, 1, 8, false); break;             //  32 x 512, waves 32 x 64: measured best in round 2 (hi + lo planes); with one plane 64 x 256 wins (round 4: 25.7 k -> 27.0 k tok/s at T = 2048)
             }
 #undef QPG_GO
         } else {
@@ -2180,9 +2186,12 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
                 const dim3 grid(Tpad / 64, (run_slots + 15) / 16);
                 hipLaunchKernelGGL(qpg_gemm_q6k_lds_kernel, grid, dim3(512), (size_t)QPG6_LDS_BYTES, st, r, im, C, ldp, run_slots, slot_base);
             } else {
-                const dim3 grid(Tpad / 32, (run_slots + 15) / 16);     // 32 tokens x 256 rows
+                const dim3 grid(Tpad / 32, (run_slots + 15) / 16);     // 32 tokens x 256 rows, register-fed: hi + lo planes ("exact" activations)
+#ifdef MI355_QMM_PROBES
                 if (parts == 1) hipLaunchKernelGGL((qpg_gemm_q6k_kernel<1, 2>), grid, dim3(512), 8 * 1024, st, r, im, C, ldp, run_slots, slot_base);
-                else hipLaunchKernelGGL((qpg_gemm_q6k_kernel<2, 2>), grid, dim3(512), 16 * 1024, st, r, im, C, ldp, run_slots, slot_base);
+                else
+#endif
+                hipLaunchKernelGGL((qpg_gemm_q6k_kernel<2, 2>), grid, dim3(512), 16 * 1024, st, r, im, C, ldp, run_slots, slot_base);
             }
         }
         slot_base += run_slots;
