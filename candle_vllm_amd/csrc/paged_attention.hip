@@ -1272,7 +1272,14 @@ __global__ void __launch_bounds__(256, 1) paged_attn_lds_kernel(const PAParams p
 //   * Q of the (up to 4) sequences of the share is staged in LDS before the first DMA goes out.
 #include "pa_stream_cut.h"
 
-template <int R>
+// PAS_TS (build-time A/B): 1 = the waves of a workgroup split the TOKENS of a stage (round 4), 0 = they split the output channels
+#ifndef PAS_TS
+#define PAS_TS 1
+#endif
+#ifndef PAS_RING
+#define PAS_RING 3
+#endif
+template <int R, bool TS = false>
 __global__ void __launch_bounds__(256, 1) paged_attn_stream_kernel(const PAParams p, const int B, const uint32_t* __restrict__ btab,
                                                                     const uint32_t* __restrict__ clens) {
     // (btab / clens = p.block_tables / p.context_lens once more, as __restrict__ kernel arguments: only then does the compiler know that
@@ -1377,7 +1384,8 @@ __global__ void __launch_bounds__(256, 1) paged_attn_stream_kernel(const PAParam
     if (R - 1 < ns) load_ent(f_lo + R - 1, ent);                      // for the issue of the first iteration
     const float qk_scale = p.scale;
     float m_run = -1e30f, l_run = 0.f;
-    f32x4_t o[2];
+    constexpr int NO = TS ? 8 : 2;                                    // output tiles of 16 channels per wave
+    f32x4_t o[NO];
     uint4 qf[D32];
     int b = -1, pst = 0, t1 = 0, pe = 0;                              // current sequence, its first flat stage, context length, end
     for (int i = 0; i < ns; ++i) {
@@ -1400,8 +1408,8 @@ __global__ void __launch_bounds__(256, 1) paged_attn_stream_kernel(const PAParam
             pst = pe - __builtin_amdgcn_readlane(n_l, b);
             t1 = __builtin_amdgcn_readlane(ctx_l, b);
             m_run = -1e30f; l_run = 0.f;
-            o[0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            o[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int n2 = 0; n2 < NO; ++n2) o[n2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             const int sg = b - b0;
 #pragma unroll
             for (int j = 0; j < D32; ++j) {
@@ -1411,96 +1419,186 @@ __global__ void __launch_bounds__(256, 1) paged_attn_stream_kernel(const PAParam
         }
         const int tb = 64 * (f - pst);                                // first token of the stage inside its sequence
         const uint8_t* Kb = pas_smem + (size_t)(i % R) * STAGE_B;
-        float sc[2][2][4];
-        float mp = -1e30f;
+        if constexpr (TS) {
+            // ---- TOKEN SPLIT (round 4): wave w takes the 16 tokens of tile (ip, it) = (w >> 1, w & 1) of the stage for ALL 128 channels with
+            // its own running softmax state -- 4 QK MFMAs and 4 scores per lane instead of 16 and 16 in every one of the four waves (the
+            // channel split computes the whole stage's scores and probabilities in each wave: four times redundant), P.V as eight K = 16
+            // MFMAs on the lane's own four probabilities; the four states are merged through LDS once per (sequence, share).
+            const int ip = wave >> 1, it = wave & 1;
+            uint4 ka[D32];
 #pragma unroll
-        for (int ip = 0; ip < 2; ++ip)
+            for (int j = 0; j < D32; ++j) ka[j] = *reinterpret_cast<const uint4*>(Kb + pal_k_read_off(j, kg, ip, it, c));
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                uint4 ka[D32];
-#pragma unroll
-                for (int j = 0; j < D32; ++j) ka[j] = *reinterpret_cast<const uint4*>(Kb + pal_k_read_off(j, kg, ip, it, c));
-                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int j = 0; j < D32; ++j)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ka[j]), __builtin_bit_cast(bf16x8_t, qf[j]), acc, 0, 0, 0);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) sc[ip][it][v] = acc[v] * qk_scale;
-            }
-        if (p.softcap > 0.f) {
-#pragma unroll
-            for (int ip = 0; ip < 2; ++ip)
-#pragma unroll
-                for (int it = 0; it < 2; ++it)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) sc[ip][it][v] = tanhf(sc[ip][it][v] / p.softcap) * p.softcap;
-        }
-#pragma unroll
-        for (int ip = 0; ip < 2; ++ip)
-#pragma unroll
-            for (int it = 0; it < 2; ++it)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    sc[ip][it][v] = (tb + 32 * ip + 8 * kg + 4 * it + v < t1) ? sc[ip][it][v] : -1e30f;
-                    mp = fmaxf(mp, sc[ip][it][v]);
-                }
-        mp = fmaxf(mp, __shfl_xor(mp, 16, 64));
-        mp = fmaxf(mp, __shfl_xor(mp, 32, 64));
-        const float m_new = fmaxf(m_run, mp);
-        const float alpha = __expf(m_run - m_new);
-        m_run = m_new;
-        uint4 pa[2];
-        float lp = 0.f;
-#pragma unroll
-        for (int ip = 0; ip < 2; ++ip) {
-            uint32_t pw[4];
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                float pr[4];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) pr[v] = (tb + 32 * ip + 8 * kg + 4 * it + v < t1) ? __expf(sc[ip][it][v] - m_new) : 0.f;
-                pw[2 * it] = cvt_pk_bf16(pr[0], pr[1]);
-                pw[2 * it + 1] = cvt_pk_bf16(pr[2], pr[3]);
-                lp += (bf16lo_to_f32(pw[2 * it]) + bf16hi_to_f32(pw[2 * it])) + (bf16lo_to_f32(pw[2 * it + 1]) + bf16hi_to_f32(pw[2 * it + 1]));
-            }
-            pa[ip] = make_uint4(pw[0], pw[1], pw[2], pw[3]);
-        }
-        l_run = fmaf(l_run, alpha, lp);
-        float av[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) av[v] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (4 * kg + v), __float_as_int(alpha)));
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2) {
-            const int ch = 32 * wave + 16 * n2 + c;
-            f32x4_t on = o[n2];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) on[v] *= av[v];
-#pragma unroll
-            for (int ip = 0; ip < 2; ++ip) {
-                uint4 vv = *reinterpret_cast<const uint4*>(Kb + pal_v_read_off(ch, ip, kg));
-                const int tk = tb + 32 * ip + 8 * kg;
-                vv.x &= (tk + 0 < t1 ? 0x0000FFFFu : 0u) | (tk + 1 < t1 ? 0xFFFF0000u : 0u);
-                vv.y &= (tk + 2 < t1 ? 0x0000FFFFu : 0u) | (tk + 3 < t1 ? 0xFFFF0000u : 0u);
-                vv.z &= (tk + 4 < t1 ? 0x0000FFFFu : 0u) | (tk + 5 < t1 ? 0xFFFF0000u : 0u);
-                vv.w &= (tk + 6 < t1 ? 0x0000FFFFu : 0u) | (tk + 7 < t1 ? 0xFFFF0000u : 0u);
-                on = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pa[ip]), __builtin_bit_cast(bf16x8_t, vv), on, 0, 0, 0);
-            }
-            o[n2] = on;
-        }
-        if (f + 1 >= pe || i + 1 >= ns) {
-            // ---- last stage of this sequence in this share: the partial of (sequence b, workgroup w)
-            float lt = l_run + __shfl_xor(l_run, 16, 64);
-            lt += __shfl_xor(lt, 32, 64);
+            for (int j = 0; j < D32; ++j)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ka[j]), __builtin_bit_cast(bf16x8_t, qf[j]), acc, 0, 0, 0);
+            const int tk = tb + 32 * ip + 8 * kg + 4 * it;           // the lane's four tokens: tk .. tk + 3
+            float sc[4], mp = -1e30f;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int head = 4 * kg + v;
-                const float lh = __shfl(lt, head, 64), mh = __shfl(m_run, head, 64);
-                if (head < G) {
-                    const int64_t pi = ((int64_t)b * p.H + hk * G + head) * p.max_partitions + w;
-                    const float inv = lh > 0.f ? 1.f / lh : 0.f;
+                sc[v] = acc[v] * qk_scale;
+                if (p.softcap > 0.f) sc[v] = tanhf(sc[v] / p.softcap) * p.softcap;
+                sc[v] = (tk + v < t1) ? sc[v] : -1e30f;
+                mp = fmaxf(mp, sc[v]);
+            }
+            mp = fmaxf(mp, __shfl_xor(mp, 16, 64));
+            mp = fmaxf(mp, __shfl_xor(mp, 32, 64));
+            const float m_new = fmaxf(m_run, mp);
+            const float alpha = __expf(m_run - m_new);
+            m_run = m_new;
+            float pr[4];
 #pragma unroll
-                    for (int n2 = 0; n2 < 2; ++n2) p.tmp_out[pi * D + 32 * wave + 16 * n2 + c] = o[n2][v] * inv;
-                    if (wave == 0 && c == 0) { p.max_logits[pi] = mh; p.exp_sums[pi] = lh; }
+            for (int v = 0; v < 4; ++v) pr[v] = (tk + v < t1) ? __expf(sc[v] - m_new) : 0.f;
+            const uint32_t pw0 = cvt_pk_bf16(pr[0], pr[1]), pw1 = cvt_pk_bf16(pr[2], pr[3]);
+            const float lp = (bf16lo_to_f32(pw0) + bf16hi_to_f32(pw0)) + (bf16lo_to_f32(pw1) + bf16hi_to_f32(pw1));
+            l_run = fmaf(l_run, alpha, lp);
+            const uint2 pa2 = make_uint2(pw0, pw1);
+            float av[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) av[v] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (4 * kg + v), __float_as_int(alpha)));
+            const uint32_t vm0 = (tk + 0 < t1 ? 0x0000FFFFu : 0u) | (tk + 1 < t1 ? 0xFFFF0000u : 0u);
+            const uint32_t vm1 = (tk + 2 < t1 ? 0x0000FFFFu : 0u) | (tk + 3 < t1 ? 0xFFFF0000u : 0u);
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) {
+                const int ch = 16 * n2 + c;
+                f32x4_t on = o[n2];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) on[v] *= av[v];
+                uint2 vv = *reinterpret_cast<const uint2*>(Kb + pal_v_read_off(ch, ip, kg) + 8 * it);   // the lane's 4 tokens of channel ch
+                vv.x &= vm0; vv.y &= vm1;
+                o[n2] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, pa2), __builtin_bit_cast(s16x4_t, vv), on, 0, 0, 0);
+            }
+            if (f + 1 >= pe || i + 1 >= ns) {
+                // ---- last stage of this sequence in this share: merge the four waves' states, leave the partial of (sequence b, workgroup w).
+                // Scratch = this stage's ring slot (the next DMA into it goes out behind the next iteration's barrier).
+                float lt = l_run + __shfl_xor(l_run, 16, 64);
+                lt += __shfl_xor(lt, 32, 64);
+                __syncthreads();                                      // every wave is done reading the slot
+                float* stt = reinterpret_cast<float*>(pas_smem + (size_t)(i % R) * STAGE_B);   // [4 waves][16 heads][m, l]
+                float* ob = stt + 128;                                // [4 waves][G heads][128 channels]
+                if (kg == 0) { stt[(wave * 16 + c) * 2] = m_run; stt[(wave * 16 + c) * 2 + 1] = lt; }
+                __syncthreads();
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int head = 4 * kg + v;
+                    if (head < G) {
+                        float M = stt[head * 2];
+#pragma unroll
+                        for (int ww = 1; ww < 4; ++ww) M = fmaxf(M, stt[(ww * 16 + head) * 2]);
+                        const float fw = __expf(stt[(wave * 16 + head) * 2] - M);
+#pragma unroll
+                        for (int n2 = 0; n2 < 8; ++n2) ob[(size_t)(wave * G + head) * D + 16 * n2 + c] = o[n2][v] * fw;
+                    }
+                }
+                __syncthreads();
+                for (int idx = (int)threadIdx.x; idx < G * D; idx += 256) {
+                    const int head = idx >> 7, ch = idx & (D - 1);
+                    float M = stt[head * 2];
+#pragma unroll
+                    for (int ww = 1; ww < 4; ++ww) M = fmaxf(M, stt[(ww * 16 + head) * 2]);
+                    float L = 0.f, sum = 0.f;
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) {
+                        L = fmaf(stt[(ww * 16 + head) * 2 + 1], __expf(stt[(ww * 16 + head) * 2] - M), L);
+                        sum += ob[(size_t)(ww * G + head) * D + ch];
+                    }
+                    const int64_t pi = ((int64_t)b * p.H + hk * G + head) * p.max_partitions + w;
+                    p.tmp_out[pi * D + ch] = sum * (L > 0.f ? 1.f / L : 0.f);
+                    if (ch == 0) { p.max_logits[pi] = M; p.exp_sums[pi] = L; }
+                }
+            }
+        } else {
+            float sc[2][2][4];
+            float mp = -1e30f;
+    #pragma unroll
+            for (int ip = 0; ip < 2; ++ip)
+    #pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    uint4 ka[D32];
+    #pragma unroll
+                    for (int j = 0; j < D32; ++j) ka[j] = *reinterpret_cast<const uint4*>(Kb + pal_k_read_off(j, kg, ip, it, c));
+                    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                    for (int j = 0; j < D32; ++j)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ka[j]), __builtin_bit_cast(bf16x8_t, qf[j]), acc, 0, 0, 0);
+    #pragma unroll
+                    for (int v = 0; v < 4; ++v) sc[ip][it][v] = acc[v] * qk_scale;
+                }
+            if (p.softcap > 0.f) {
+    #pragma unroll
+                for (int ip = 0; ip < 2; ++ip)
+    #pragma unroll
+                    for (int it = 0; it < 2; ++it)
+    #pragma unroll
+                        for (int v = 0; v < 4; ++v) sc[ip][it][v] = tanhf(sc[ip][it][v] / p.softcap) * p.softcap;
+            }
+    #pragma unroll
+            for (int ip = 0; ip < 2; ++ip)
+    #pragma unroll
+                for (int it = 0; it < 2; ++it)
+    #pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        sc[ip][it][v] = (tb + 32 * ip + 8 * kg + 4 * it + v < t1) ? sc[ip][it][v] : -1e30f;
+                        mp = fmaxf(mp, sc[ip][it][v]);
+                    }
+            mp = fmaxf(mp, __shfl_xor(mp, 16, 64));
+            mp = fmaxf(mp, __shfl_xor(mp, 32, 64));
+            const float m_new = fmaxf(m_run, mp);
+            const float alpha = __expf(m_run - m_new);
+            m_run = m_new;
+            uint4 pa[2];
+            float lp = 0.f;
+    #pragma unroll
+            for (int ip = 0; ip < 2; ++ip) {
+                uint32_t pw[4];
+    #pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    float pr[4];
+    #pragma unroll
+                    for (int v = 0; v < 4; ++v) pr[v] = (tb + 32 * ip + 8 * kg + 4 * it + v < t1) ? __expf(sc[ip][it][v] - m_new) : 0.f;
+                    pw[2 * it] = cvt_pk_bf16(pr[0], pr[1]);
+                    pw[2 * it + 1] = cvt_pk_bf16(pr[2], pr[3]);
+                    lp += (bf16lo_to_f32(pw[2 * it]) + bf16hi_to_f32(pw[2 * it])) + (bf16lo_to_f32(pw[2 * it + 1]) + bf16hi_to_f32(pw[2 * it + 1]));
+                }
+                pa[ip] = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+            }
+            l_run = fmaf(l_run, alpha, lp);
+            float av[4];
+    #pragma unroll
+            for (int v = 0; v < 4; ++v) av[v] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (4 * kg + v), __float_as_int(alpha)));
+    #pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2) {
+                const int ch = 32 * wave + 16 * n2 + c;
+                f32x4_t on = o[n2];
+    #pragma unroll
+                for (int v = 0; v < 4; ++v) on[v] *= av[v];
+    #pragma unroll
+                for (int ip = 0; ip < 2; ++ip) {
+                    uint4 vv = *reinterpret_cast<const uint4*>(Kb + pal_v_read_off(ch, ip, kg));
+                    const int tk = tb + 32 * ip + 8 * kg;
+                    vv.x &= (tk + 0 < t1 ? 0x0000FFFFu : 0u) | (tk + 1 < t1 ? 0xFFFF0000u : 0u);
+                    vv.y &= (tk + 2 < t1 ? 0x0000FFFFu : 0u) | (tk + 3 < t1 ? 0xFFFF0000u : 0u);
+                    vv.z &= (tk + 4 < t1 ? 0x0000FFFFu : 0u) | (tk + 5 < t1 ? 0xFFFF0000u : 0u);
+                    vv.w &= (tk + 6 < t1 ? 0x0000FFFFu : 0u) | (tk + 7 < t1 ? 0xFFFF0000u : 0u);
+                    on = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pa[ip]), __builtin_bit_cast(bf16x8_t, vv), on, 0, 0, 0);
+                }
+                o[n2] = on;
+            }
+            if (f + 1 >= pe || i + 1 >= ns) {
+                // ---- last stage of this sequence in this share: the partial of (sequence b, workgroup w)
+                float lt = l_run + __shfl_xor(l_run, 16, 64);
+                lt += __shfl_xor(lt, 32, 64);
+    #pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int head = 4 * kg + v;
+                    const float lh = __shfl(lt, head, 64), mh = __shfl(m_run, head, 64);
+                    if (head < G) {
+                        const int64_t pi = ((int64_t)b * p.H + hk * G + head) * p.max_partitions + w;
+                        const float inv = lh > 0.f ? 1.f / lh : 0.f;
+    #pragma unroll
+                        for (int n2 = 0; n2 < 2; ++n2) p.tmp_out[pi * D + 32 * wave + 16 * n2 + c] = o[n2][v] * inv;
+                        if (wave == 0 && c == 0) { p.max_logits[pi] = mh; p.exp_sums[pi] = lh; }
+                    }
                 }
             }
         }
@@ -1645,20 +1743,21 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
     } else if (layout == MI355_KV_PAGED && dtype == MI355_DTYPE_BF16 && !p.kv8 && p.partition_size == 64 && P > 1 &&
                mi355_pa_stream_auto(B, p.H, p.Hkv, p.D, p.block_size)) {
         // one balanced stream of 64-token stages per workgroup, W workgroups per kv head; partials merged by the reduce launch.
-        // TWO workgroups per CU (W x Hkv = 512) on a ring of two stages each (80 KiB of LDS): a workgroup is four waves, one per SIMD,
-        // and alone on its CU every wait of its chain is dead time -- measured (round 4, one box, alternated): ring of 4 / one workgroup
-        // per CU 6218 / 6238 tok/s, ring of 2 / two per CU 6361 / 6386 on the ragged batch-32 step
-        constexpr int PAS_R = 2;
+        // Measured on the ragged batch-32 step (round 4, each pair alternated on one box; profiles/r04_b32_stream_ab.txt):
+        //   channel split, ring of 4, one workgroup per CU 6218 / 6238 tok/s  ->  ring of 2, two workgroups per CU 6361 / 6386
+        //   token split (the waves share a stage's tokens instead of its output channels), ring of 2, two per CU: the same (6332 vs 6335)
+        //   token split, ring of 3 / 4, one workgroup per CU: 6369 / 6360 against 6312 -- the default
+        constexpr int PAS_R = PAS_RING;
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)paged_attn_stream_kernel<PAS_R>, hipFuncAttributeMaxDynamicSharedMemorySize, PAS_R * 32768 + 16384);
+            (void)hipFuncSetAttribute((const void*)paged_attn_stream_kernel<PAS_R, PAS_TS != 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PAS_R * 32768 + 16384);
             attr_done = true;
         }
-        int W = 512 / p.Hkv;
+        int W = (PAS_RING <= 2 ? 512 : 256) / p.Hkv;                  // two workgroups per CU fit with a ring of two stages only
         if (W < 1) W = 1;
         if (W > 64) W = 64;
         if (W > P) W = P;
-        hipLaunchKernelGGL((paged_attn_stream_kernel<PAS_R>), dim3(W, p.Hkv), dim3(256), PAS_R * 32768 + 16384, st, p, B, p.block_tables,
+        hipLaunchKernelGGL((paged_attn_stream_kernel<PAS_R, PAS_TS != 0>), dim3(W, p.Hkv), dim3(256), PAS_R * 32768 + 16384, st, p, B, p.block_tables,
                            p.context_lens);
         if (g_pa_stream_noreduce) { g_pa_stream_last_w = W; return (int)hipGetLastError(); }   // the caller merges (mi355_internal_pa_stream_partials)
         hipLaunchKernelGGL(paged_attn_stream_reduce_kernel, dim3(p.H, B), dim3(128), 0, st, p.out, p.tmp_out, p.max_logits, p.exp_sums,
