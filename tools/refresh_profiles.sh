@@ -2,10 +2,10 @@
 # Regenerates the judged artefacts under profiles/ on the GPU box (run through gpurun; results land in gpurun_out/prof, copy
 # them to profiles/).  Every file carries the commit it was measured on: write it to ./COMMIT_SHA before the call
 #   git rev-parse --short HEAD > COMMIT_SHA && gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh'
+#   0. two --pmc passes (FETCH_SIZE, WRITE_SIZE)         -> rNN_pmc_traffic.json   (tools/pmc_traffic.py; copied into profiles/ for step 1)
 #   1. python bench.py                                   -> rNN_bench_default.json
 #   2. rocprofv3 --kernel-trace --stats -- bench (B=1)   -> rNN_bench_b1_kernel_stats.csv (+ the bench line under rocprof)
 #   3. rocprofv3 --kernel-trace --stats -- bench (B=32)  -> rNN_bench_b32_kernel_stats.csv
-#   4. two --pmc passes (FETCH_SIZE, WRITE_SIZE)         -> rNN_pmc_traffic.json   (tools/pmc_traffic.py)
 #   5. one --pmc pass of the SQ busy counters            -> rNN_pmc_sq_b1.json     (MFMA-busy / VALU-busy of every kernel)
 set -x
 RN=${ROUND_TAG:-r03}
@@ -16,6 +16,13 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
 echo "$SHA" > $OUT/${RN}_commit.txt
+# the two HBM-traffic passes FIRST, and their summary straight into profiles/ of this copy of the tree: bench.py quotes `roofline.traffic`
+# only from a pass whose `kernel_source_sha256` matches the sources it runs
+PMC="python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-batch32 --no-graph --parity off --legs none"
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_f --output-format csv -- $PMC > $OUT/pmc_f.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_w --output-format csv -- $PMC > $OUT/pmc_w.log 2>&1
+python tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w $OUT/${RN}_pmc_traffic.json $SHA
+cp $OUT/${RN}_pmc_traffic.json $R/profiles/${RN}_pmc_traffic.json
 timeout 900 python bench.py > $OUT/${RN}_bench_default.json 2> $OUT/bench_default.err
 B1="python bench.py --no-batch32 --no-cpu-baseline --parity off --legs none"
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/rp_b1 --output-format csv -- $B1 > $OUT/${RN}_bench_b1_under_rocprof.json 2> $OUT/rp_b1.err
@@ -23,10 +30,6 @@ timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/rp_b1 --output-format csv -
 B32="python bench.py --batch 32 --steps 16 --warmup 4 --no-cpu-baseline --no-batch32 --parity off --legs none"
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/rp_b32 --output-format csv -- $B32 > $OUT/${RN}_bench_b32_under_rocprof.json 2> $OUT/rp_b32.err
 (echo "# commit $SHA : rocprofv3 --kernel-trace --stats -- $B32"; cat $(find /tmp/rp_b32 -name "*kernel_stats.csv" | head -1)) > $OUT/${RN}_bench_b32_kernel_stats.csv
-PMC="python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-batch32 --no-graph --parity off --legs none"
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_f --output-format csv -- $PMC > $OUT/pmc_f.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_w --output-format csv -- $PMC > $OUT/pmc_w.log 2>&1
-python tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w $OUT/${RN}_pmc_traffic.json $SHA
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY -d /tmp/pmc_sq --output-format csv -- $PMC > $OUT/pmc_sq.log 2>&1
 python tools/pmc_summary.py /tmp/pmc_sq $OUT/${RN}_pmc_sq_b1.json $SHA > $OUT/pmc_sq_summary.txt 2>&1
 head -c 1800 $OUT/${RN}_bench_default.json
