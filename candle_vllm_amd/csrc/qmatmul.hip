@@ -2120,8 +2120,7 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL(qpg_rowstat_kernel, dim3(Tpad), dim3(256), 0, st, a, im);
-    hipLaunchKernelGGL(qpg_prep_kernel, dim3(nkb, Tpad / 8), dim3(256), 0, st, a, im);
+    hipLaunchKernelGGL(qpg_rowprep_kernel, dim3(Tpad), dim3(256), 0, st, a, im);          // row statistics + image, one launch (workgroup = token)
     // EXPERIMENT (mi355_set_tuning(48, 1)): all segments Q4_K, one activation plane, the default wave tile, and an epilogue that is a
     // store / residual add / SiLU * up over two equal segments -> the GEMM writes the outputs itself, no C buffer, no epilogue launch
     {
