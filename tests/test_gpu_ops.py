@@ -287,7 +287,8 @@ def test_dequantize_and_ref_kernel(cv, t):
 @pytest.mark.parametrize("t", [kq.GGML_Q4_K, kq.GGML_Q6_K])
 @pytest.mark.parametrize("T,N,K", [(1, 64, 256), (1, 4096, 4096), (1, 40, 512), (2, 48, 1024), (3, 128, 4096),
                                    (5, 32, 14336), (8, 256, 2048), (9, 64, 512), (32, 96, 4096),
-                                   (128, 96, 1024), (200, 40, 512)])      # >= 96 tokens: prompt-step GEMM path
+                                   (128, 96, 1024), (200, 40, 512),       # >= 96 tokens: prompt-step GEMM path (image and weights through LDS by DMA)
+                                   (300, 272, 256), (2100, 40, 256)])     # one k-block (the DMA rings are longer than the matrix); >= 2048 tokens: 128-token tile
 def test_qmatmul_vs_oracle(cv, t, T, N, K):
     rng = np.random.default_rng(12 + T + N)
     blocks = kq.quantize(rng.normal(0, 0.05, (N, K)).astype(np.float32), t)
