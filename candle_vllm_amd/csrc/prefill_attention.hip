@@ -97,7 +97,8 @@ __global__ void __launch_bounds__(256) prefill_attn_kernel(const PrefillParams p
     const int cached = ctx - qlen;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, kg = lane >> 4;
-    const int qw0 = blockIdx.x * 128 + wave * 32;          // first query (chunk-local) of this wave
+    // query blocks are handed out HEAVIEST FIRST (the last block of a prompt sees every key): the light ones fill in behind them
+    const int qw0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * 128 + wave * 32;          // first query (chunk-local) of this wave
     if (qw0 >= qlen) return;
     const int hk = h / (p.H / p.Hkv);
     const uint32_t* bt = p.block_tables ? p.block_tables + (size_t)seq * p.max_blocks : nullptr;
@@ -352,35 +353,37 @@ __global__ void __launch_bounds__(64) prefill_attn_generic_kernel(const PrefillP
 //   O   = P . V  with P as the A operand (hi + lo bf16 pieces, as prefill_attn_kernel: the 1e-3 logit bound is against exact
 //         softmax) and the V row fragment as B: 192 MFMAs per wave and stage.
 // Causal masks only on the stages the diagonal crosses; exp2 domain and softcap as prefill_attn_kernel.
-template <int R>
+template <int R, int QT = 4>
 __global__ void __launch_bounds__(256, 1) prefill_attn_lds_kernel(const PrefillParams p, const uint32_t* __restrict__ btab,
                                                                    const uint32_t* __restrict__ clens, const uint32_t* __restrict__ cuq) {
     constexpr int D = 128, NC = 4, NDT = 8;
     constexpr uint32_t STAGE_B = 32768u;
     extern __shared__ __attribute__((aligned(1024))) uint8_t pfl_smem[];
-    const int qb = blockIdx.x, seq = blockIdx.z;
+    // QT = query tiles of 16 per workgroup.  Grid: x = head group (fastest), y = query block, HEAVIEST FIRST (the last block of a prompt sees
+    // all its keys, the first one stage): with more workgroups than CUs the light blocks fill in behind the heavy ones
+    const int qb = (int)gridDim.y - 1 - (int)blockIdx.y, seq = blockIdx.z;
     const int G = p.H / p.Hkv, HG = (G + 3) >> 2;                     // head groups of up to four query heads per kv head
-    const int hk = (int)blockIdx.y / HG, hg = (int)blockIdx.y % HG;
+    const int hk = (int)blockIdx.x / HG, hg = (int)blockIdx.x % HG;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int c = lane & 15, kg = lane >> 4;
     const int bs = p.block_size, bs_shift = __ffs(bs) - 1, E = 64 >> bs_shift;
     const int q_begin = (int)cuq[seq], qlen = (int)cuq[seq + 1] - q_begin;
     const int ctx = (int)clens[seq];
     const int cached = ctx - qlen;
-    const int q0 = qb * 64;
+    const int q0 = qb * (16 * QT);
     if (q0 >= qlen) return;                                           // uniform for the workgroup
     const int hw = 4 * hg + wave;
     const bool active = hw < G;                                       // this wave has a head (all waves copy and meet at the barriers)
     const int h = hk * G + (active ? hw : 0);
-    const int kend = min(ctx, cached + min(q0 + 64, qlen));           // keys this block can see (exclusive)
+    const int kend = min(ctx, cached + min(q0 + 16 * QT, qlen));           // keys this block can see (exclusive)
     const int ns = (kend + 63) >> 6;
     const int nblk = (ctx + bs - 1) >> bs_shift;
     // ---- Q fragments (B operand: lane = query c of tile qt, k = d 32j + 8kg ..) and the query's position
-    uint4 qf[4][NC];
-    int pos[4];
+    uint4 qf[QT][NC];
+    int pos[QT];
     const uint16_t* q16 = static_cast<const uint16_t*>(p.q);
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         const int ql = q0 + 16 * qt + c;
         pos[qt] = cached + min(ql, qlen - 1);
 #pragma unroll
@@ -391,7 +394,7 @@ __global__ void __launch_bounds__(256, 1) prefill_attn_lds_kernel(const PrefillP
     }
     // the compiler's wait for these loads must come before the first DMA goes out (it knows nothing of the DMA queue)
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) asm volatile("" : "+v"(qf[qt][0].x), "+v"(qf[qt][1].x), "+v"(qf[qt][2].x), "+v"(qf[qt][3].x));
+    for (int qt = 0; qt < QT; ++qt) asm volatile("" : "+v"(qf[qt][0].x), "+v"(qf[qt][1].x), "+v"(qf[qt][2].x), "+v"(qf[qt][3].x));
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)pfl_smem);
     const uint8_t* kc8 = static_cast<const uint8_t*>(p.k);
     const uint8_t* vc8 = static_cast<const uint8_t*>(p.v);
@@ -436,10 +439,10 @@ __global__ void __launch_bounds__(256, 1) prefill_attn_lds_kernel(const PrefillP
     for (int st = 0; st < R - 1; ++st)
         if (st < ns) { load_ent(st, ent); issue(st, ent); }
     if (R - 1 < ns) load_ent(R - 1, ent);
-    float m_run[4], l_run[4];
-    f32x4_t o[4][NDT];
+    float m_run[QT], l_run[QT];
+    f32x4_t o[QT][NDT];
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         m_run[qt] = -INFINITY; l_run[qt] = 0.f;
 #pragma unroll
         for (int nt = 0; nt < NDT; ++nt) o[qt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -469,10 +472,10 @@ __global__ void __launch_bounds__(256, 1) prefill_attn_lds_kernel(const PrefillP
             for (int it = 0; it < 2; ++it)
 #pragma unroll
                 for (int j = 0; j < NC; ++j) ka[ip][it][j] = *reinterpret_cast<const uint4*>(Kb + pal_k_read_off(j, kg, ip, it, c));
-        uint4 pb[4][2], pl[4][2];                                     // P of query tile qt, pair ip: hi and lo bf16 pieces (A operands)
-        float alpha[4];
+        uint4 pb[QT][2], pl[QT][2];                                     // P of query tile qt, pair ip: hi and lo bf16 pieces (A operands)
+        float alpha[QT];
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             float x[2][2][4];
             float tmax = -INFINITY;
 #pragma unroll
@@ -542,9 +545,9 @@ __global__ void __launch_bounds__(256, 1) prefill_attn_lds_kernel(const PrefillP
             l_run[qt] = fmaf(l_run[qt], alpha[qt], psum);             // this lane's share (keys 8kg.. of both pairs); summed over kg at the end
         }
         // ---- O = O * alpha + P . V : lane (channel 16 nt + c, queries 4kg+v of tile qt); query 4kg+v's alpha sits in lane 4kg+v
-        float av[4][4];
+        float av[QT][4];
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt)
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
             for (int v = 0; v < 4; ++v) av[qt][v] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (4 * kg + v), __float_as_int(alpha[qt])));
         uint32_t vm[2][4];                                            // keys at or beyond ctx hold arbitrary bits: cleared in the B fragment
@@ -563,7 +566,7 @@ __global__ void __launch_bounds__(256, 1) prefill_attn_lds_kernel(const PrefillP
                 vv[ip].x &= vm[ip][0]; vv[ip].y &= vm[ip][1]; vv[ip].z &= vm[ip][2]; vv[ip].w &= vm[ip][3];
             }
 #pragma unroll
-            for (int qt = 0; qt < 4; ++qt) {
+            for (int qt = 0; qt < QT; ++qt) {
                 f32x4_t on = o[qt][nt];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) on[v] *= av[qt][v];
@@ -580,7 +583,7 @@ __global__ void __launch_bounds__(256, 1) prefill_attn_lds_kernel(const PrefillP
     // ---- epilogue: rows (queries 4kg+v of tile qt) need the sums of lane (4kg+v)
     uint16_t* out16 = static_cast<uint16_t*>(p.out);
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         float lt = l_run[qt] + __shfl_xor(l_run[qt], 16);
         lt += __shfl_xor(lt, 32);
 #pragma unroll
@@ -635,15 +638,25 @@ extern "C" int mi355_prefill_attention(void* out, const void* q, const void* k, 
         (block_size == 16 || block_size == 32 || block_size == 64)) {
         // round 4 default (first run on hardware in round 4: its tests green, prompt step 21.8 k -> 23.7 k tok/s at T = 2048): 64 queries x the
         // heads of a GQA group per workgroup, K / V through the LDS ring
-        constexpr int PFL_R = 4;
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)prefill_attn_lds_kernel<PFL_R>, hipFuncAttributeMaxDynamicSharedMemorySize, PFL_R * 32768);
+            (void)hipFuncSetAttribute((const void*)prefill_attn_lds_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+            (void)hipFuncSetAttribute((const void*)prefill_attn_lds_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768);
             attr_done = true;
         }
-        const int G = num_heads / num_kv_heads;
-        dim3 grid((max_seqlen_q + 63) / 64, num_kv_heads * ((G + 3) / 4), num_seqs);
-        hipLaunchKernelGGL((prefill_attn_lds_kernel<PFL_R>), grid, dim3(256), PFL_R * 32768, st, p, block_tables, context_lens, cu_seqlens_q);
+        const int G = num_heads / num_kv_heads, hgs = num_kv_heads * ((G + 3) / 4);
+        // 64 queries per workgroup when that still gives two workgroups per CU to hand out heaviest first; else 32 (ring of two stages).
+        // Measured (round 4, Llama-3-8B prompt step, one box): T = 2048 (256 workgroups of 64 queries = one round, the launch lasts as long
+        // as its heaviest block) 37.8 k -> 39.8 k tok/s with 32-query blocks; T = 4096 38.9 k either way -- and 34.7 k before the grid was
+        // ordered heaviest block first.
+        const int64_t nwg64 = (int64_t)((max_seqlen_q + 63) / 64) * hgs * num_seqs;
+        if (nwg64 >= 512) {
+            dim3 grid(hgs, (max_seqlen_q + 63) / 64, num_seqs);
+            hipLaunchKernelGGL((prefill_attn_lds_kernel<4, 4>), grid, dim3(256), 4 * 32768, st, p, block_tables, context_lens, cu_seqlens_q);
+        } else {
+            dim3 grid(hgs, (max_seqlen_q + 31) / 32, num_seqs);
+            hipLaunchKernelGGL((prefill_attn_lds_kernel<2, 2>), grid, dim3(256), 2 * 32768, st, p, block_tables, context_lens, cu_seqlens_q);
+        }
         return (int)hipGetLastError();
     }
     if (mfma_ok) {
