@@ -733,17 +733,19 @@ static int g_tune_wide_nw = 4;         // tuning key 38: waves (row tiles) per w
 static int g_tune_wide_off = 0;        // tuning key 37: 1 = 16-bit launches with many row tiles stay on dense_kernel (A/B)
 static int g_tune_small_nw = 0;        // tuning key 30: waves per workgroup (0 = chosen from the k-blocks)
 static int g_tune_small_nw_big = 0;    // tuning key 35: the same for K > 8192
+static int g_tune_gemm_tall = 0;       // tuning key 30 bit 32 (round 4; measured SLOWER, stays off: bf16 prompt step of Llama-3-8B 53.7 k -> 51.5 k tok/s): the 256-token tile of the 16-bit prompt GEMM where it fills the chip twice
 static int g_tune_small_off = 0;       // tuning key 31: 1 = keep 1..4 tokens on dense_kernel (A/B measurements)
 static int g_tune_small_norope = 0;    // tuning key 34: 1 = RoPE and the cache write stay in their own launch
 static int g_tune_small_nonorm = 0;    // tuning key 32: 1 = never norm on the way in (the host layer launches the norm separately)
 // tuning key 30 (product): bit mask of folded launches switched OFF -- 1 = the 1..4-token 4-bit kernel, 2 = no norm on the way in,
-// 4 = RoPE and the cache write in their own launch, 8 = the LDS-shared-activation 16-bit kernel, 16 = the one-pass 4-bit prompt GEMM.
+// 4 = RoPE and the cache write in their own launch, 8 = the LDS-shared-activation 16-bit kernel, 16 = the one-pass 4-bit prompt GEMM;
+// 32 (switches ON) = the 256-token tile of the 16-bit prompt GEMM where it fills the chip twice, 32 | 64 = wherever that GEMM runs (tests).
 // Probe builds: 33 / 35 waves per workgroup of the 1..4-token kernel (hidden-sized K / long K), 36 tokens from which 16-bit
 // projections take the MFMA GEMM, 38 waves per workgroup of the LDS-shared-activation kernel.
 void mi355_dense_set_small(int key, int v) {
     if (key == 30) {
         g_tune_small_off = v & 1; g_tune_small_nonorm = (v >> 1) & 1; g_tune_small_norope = (v >> 2) & 1;
-        g_tune_wide_off = (v >> 3) & 1; g_tune_gptq_gemm_off = (v >> 4) & 1;
+        g_tune_wide_off = (v >> 3) & 1; g_tune_gptq_gemm_off = (v >> 4) & 1; g_tune_gemm_tall = (v >> 5) & 3;
     }
     else if (key == 33) g_tune_small_nw = v;
     else if (key == 35) g_tune_small_nw_big = v;
@@ -964,16 +966,23 @@ __device__ __forceinline__ void dgemm_dma(const uint8_t* gsrc_lane, uint32_t lds
 #define DG_BM 128
 #define DG_BN 128
 #define DG_BK 64
-template <int DT>
-__global__ void __launch_bounds__(256, 2) dense_gemm_kernel(const DenseArgs a) {
-    extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];   // [2 buffers][A 16 KiB | B 16 KiB]
+// WR = wave rows: 2 = 128 tokens x 128 weight rows per workgroup (4 waves, two workgroups per CU), 4 = 256 x 128 (8 waves, one workgroup
+// per CU; round 4): at 128 x 128 the tile moves 32 KiB through L2 -> LDS per 2.1 MFLOP -- 15 B per kFLOP, ~10 TB/s at the measured 650
+// TFLOP/s, which is what the L2 -> CU path carried in every other measurement of this chip -- the taller tile moves 11.4.  Measured (round 4,
+// one box, alternated, T = 2048): 53.7 k tok/s with the 128 x 128 tile, 51.5 k with 256 x 128: L2 traffic is not what bounds it; the tall tile
+// stays a tested option (tuning key 30 bit 32; bit-identical outputs, tests/test_gpu_linear.py).
+template <int DT, int WR = 2>
+__global__ void __launch_bounds__(128 * WR, WR == 2 ? 2 : 1) dense_gemm_kernel(const DenseArgs a) {
+    constexpr int BM = 64 * WR, NTHR = 128 * WR, AROUNDS = BM / (NTHR / 8), BROUNDS = DG_BN / (NTHR / 8);   // rows per staging round = NTHR / 8
+    constexpr uint32_t A_BYTES = BM * 128u, STAGE = A_BYTES + 16384u;
+    extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];   // [2 buffers][A 16 / 32 KiB | B 16 KiB]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int m16 = lane & 15, kg = lane >> 4;
     const bool silu = a.epi == MI355_EPI_SILU_MUL;
     // token tiles fastest: the workgroups that run together share their weight tile through L2
     const int bm = blockIdx.x, bn = blockIdx.y;
-    const int t0 = bm * DG_BM;
+    const int t0 = bm * BM;
     const int n_cols = silu ? a.pair_offset : a.N;                      // output columns
     const int c0 = bn * (silu ? 64 : DG_BN);                            // first output column of this tile
     // weight row held by LDS B-row j
@@ -985,22 +994,28 @@ __global__ void __launch_bounds__(256, 2) dense_gemm_kernel(const DenseArgs a) {
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)smem);
     const uint8_t* xb = static_cast<const uint8_t*>(a.x);
     const uint8_t* wb = static_cast<const uint8_t*>(a.w);
-    // staging: round r (0..3) covers LDS rows 32 r .. 32 r + 31; this thread's row / slot inside the round
+    // staging: a round covers NTHR / 8 LDS rows (8 threads = the 8 slots of a row; one wave = 8 rows = 1 KiB); this thread's row / slot inside
+    // the round.  A takes AROUNDS rounds (BM rows), B BROUNDS (128 rows)
+    constexpr int RROWS = NTHR / 8, NWV = NTHR / 64;
     const int srow = tid >> 3, sslot = tid & 7;
-    const uint8_t* asrc[4];
-    const uint8_t* bsrc[4];
+    const uint8_t* asrc[AROUNDS];
+    const uint8_t* bsrc[BROUNDS];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 32 * r + srow;
+    for (int r = 0; r < AROUNDS; ++r) {
+        const int row = RROWS * r + srow;
         int t = t0 + row;
         if (t > a.T - 1) t = a.T - 1;
         asrc[r] = xb + ((size_t)t * a.ldx) * 2 + (size_t)((sslot ^ (row & 7)) * 16);
+    }
+#pragma unroll
+    for (int r = 0; r < BROUNDS; ++r) {
+        const int row = RROWS * r + srow;
         if (a.wtiled) {
             // the tiled image IS the fragment order: the B tile in LDS is a verbatim copy -- [n-tile 8][fragment 2][lane 64][16 B] --
-            // and every DMA instruction of a wave copies one contiguous KiB (piece p = 4 r + wave: n-tile p / 2, fragment p % 2 of
+            // and every DMA instruction of a wave copies one contiguous KiB (piece p = NWV r + wave: n-tile p / 2, fragment p % 2 of
             // this K step; 2 KiB per (n-tile, K step)).  (A first version kept the row-major LDS layout and gathered 16-byte chunks:
             // 64 separate requests per instruction, prompt step 40.2 k -> 36.9 k tok/s.)
-            const int p = 4 * r + wave;
+            const int p = NWV * r + wave;
             const int n = wrow(16 * (p >> 1));
             bsrc[r] = wb + (((((size_t)(n >> 4) * (a.K >> 8)) * 8 + (p & 1)) * 64 + lane) << 4);
         } else {
@@ -1009,12 +1024,11 @@ __global__ void __launch_bounds__(256, 2) dense_gemm_kernel(const DenseArgs a) {
     }
     const size_t bstep = a.wtiled ? 2048 : DG_BK * 2;                   // bytes per K step on the weight side
     auto stage = [&](int kt, int buf) {
-        const uint32_t base = lds0 + (uint32_t)buf * 32768u + (uint32_t)wave * 1024u;
+        const uint32_t base = lds0 + (uint32_t)buf * STAGE + (uint32_t)wave * 1024u;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            dgemm_dma<1>(asrc[r] + (size_t)kt * (DG_BK * 2), base + (uint32_t)r * 4096u);
-            dgemm_dma<1>(bsrc[r] + (size_t)kt * bstep, base + 16384u + (uint32_t)r * 4096u);
-        }
+        for (int r = 0; r < AROUNDS; ++r) dgemm_dma<1>(asrc[r] + (size_t)kt * (DG_BK * 2), base + (uint32_t)r * (uint32_t)(RROWS * 128));
+#pragma unroll
+        for (int r = 0; r < BROUNDS; ++r) dgemm_dma<1>(bsrc[r] + (size_t)kt * bstep, base + A_BYTES + (uint32_t)r * (uint32_t)(RROWS * 128));
     };
     f32x4_t acc[4][4];
 #pragma unroll
@@ -1035,8 +1049,8 @@ __global__ void __launch_bounds__(256, 2) dense_gemm_kernel(const DenseArgs a) {
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);                       // in flight while this step is multiplied
-        const uint8_t* A = smem + (size_t)buf * 32768;
-        const uint8_t* B = A + 16384;
+        const uint8_t* A = smem + (size_t)buf * STAGE;
+        const uint8_t* B = A + A_BYTES;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             uint4 af[4], bf[4];
@@ -1321,15 +1335,27 @@ static int dense_prompt_gemm(const DenseArgs& a, int dt, hipStream_t st) {
     if (a.epi == MI355_EPI_SILU_MUL && (a.pair_offset <= 0 || a.N != 2 * a.pair_offset)) return (int)hipErrorNotSupported;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)dense_gemm_kernel<MI355_DTYPE_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute((const void*)dense_gemm_kernel<MI355_DTYPE_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)dense_gemm_kernel<MI355_DTYPE_BF16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)dense_gemm_kernel<MI355_DTYPE_F16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)dense_gemm_kernel<MI355_DTYPE_BF16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)dense_gemm_kernel<MI355_DTYPE_F16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_done = true;
     }
     const int n_cols = a.epi == MI355_EPI_SILU_MUL ? a.pair_offset : a.N;
     const int cols_per_wg = a.epi == MI355_EPI_SILU_MUL ? 64 : DG_BN;
-    const dim3 grid((a.T + DG_BM - 1) / DG_BM, (n_cols + cols_per_wg - 1) / cols_per_wg);
-    if (dt == MI355_DTYPE_BF16) hipLaunchKernelGGL((dense_gemm_kernel<MI355_DTYPE_BF16>), grid, dim3(256), 64 * 1024, st, a);
-    else if (dt == MI355_DTYPE_F16) hipLaunchKernelGGL((dense_gemm_kernel<MI355_DTYPE_F16>), grid, dim3(256), 64 * 1024, st, a);
+    const int ncb = (n_cols + cols_per_wg - 1) / cols_per_wg;
+    // the 256-token tile (one 8-wave workgroup per CU) when it still fills the chip twice
+    const bool tall = g_tune_gemm_tall && ((g_tune_gemm_tall & 2) || (int64_t)((a.T + 255) / 256) * ncb >= 512);   // (bit 64 of key 30: wherever the GEMM runs -- tests)
+    if (tall) {
+        const dim3 grid((a.T + 255) / 256, ncb);
+        if (dt == MI355_DTYPE_BF16) hipLaunchKernelGGL((dense_gemm_kernel<MI355_DTYPE_BF16, 4>), grid, dim3(512), 96 * 1024, st, a);
+        else if (dt == MI355_DTYPE_F16) hipLaunchKernelGGL((dense_gemm_kernel<MI355_DTYPE_F16, 4>), grid, dim3(512), 96 * 1024, st, a);
+        else return (int)hipErrorNotSupported;
+        return (int)hipGetLastError();
+    }
+    const dim3 grid((a.T + DG_BM - 1) / DG_BM, ncb);
+    if (dt == MI355_DTYPE_BF16) hipLaunchKernelGGL((dense_gemm_kernel<MI355_DTYPE_BF16, 2>), grid, dim3(256), 64 * 1024, st, a);
+    else if (dt == MI355_DTYPE_F16) hipLaunchKernelGGL((dense_gemm_kernel<MI355_DTYPE_F16, 2>), grid, dim3(256), 64 * 1024, st, a);
     else return (int)hipErrorNotSupported;
     return (int)hipGetLastError();
 }

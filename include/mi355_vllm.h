@@ -273,7 +273,8 @@ int mi355_moe_scatter_combine(float* ys, const float* y_sorted, const float* wei
  *    9  chained wide launches: an epilogue stages the next mat-mul's activation image (1, default)
  *   24  "exact" activations on the 9..32-token and prompt paths: f16 hi + lo planes instead of one f16 plane (0, default)
  *   30  16-bit / GPTQ linears, bit mask of folded launches switched OFF: 1 the 1..4-token 4-bit kernel, 2 no RMSNorm on the way in,
- *       4 RoPE + cache write in their own launch, 8 the LDS-shared-activation 16-bit kernel, 16 the one-pass 4-bit prompt GEMM
+ *       4 RoPE + cache write in their own launch, 8 the LDS-shared-activation 16-bit kernel, 16 the one-pass 4-bit prompt GEMM;
+ *       32 switches ON the 256-token tile of the 16-bit prompt GEMM where it fills the chip twice (64 as well: wherever it runs)
  *   41  MoE decode steps group their (token, slot) pairs by expert on the device (1, default)
  *   44  decode-attention kernel per partition size on the PAGED bf16 cache: 1 (default) = 256 / 512 as looped chunks, 64 as the
  *       balanced LDS-DMA stream at >= 64 (sequence, kv head) pairs; 0 = neither; 5 = chunks only; 3 = the stream for every launch

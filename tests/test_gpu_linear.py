@@ -69,6 +69,37 @@ def test_linear_matches_oracle(cv, dt, T, N, K):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("T,N,K", [(256, 384, 1024), (300, 200, 576), (97, 130, 64), (700, 128, 256)])
+def test_linear_prompt_gemm_tall_tile(cv, dt, T, N, K):
+    """the 256 x 128 tile of the 16-bit prompt GEMM (8 waves, tuning key 30 bits 32 | 64 = wherever the GEMM runs): the same rounding chain as
+    the 128 x 128 tile -- bit for bit (same K order per output element) -- and within the op's bound of the oracle; plain, tiled-image and
+    SiLU * up launches, ragged token / column tiles"""
+    from candle_vllm_amd import tuning
+    rng = np.random.default_rng(T * 7 + N)
+    x = G.round_dt(rng.normal(0, 1, (T, K)), dt)
+    w = G.round_dt(rng.normal(0, 0.05, (N, K)), dt)
+    b = G.round_dt(rng.normal(0, 0.2, N), dt)
+    res = G.round_dt(rng.normal(0, 1, (T, N)), dt)
+    I = N // 2
+    lin, lin2 = cv.Linear(dev16(w, dt), dev16(b, dt)), cv.Linear(dev16(w, dt))
+
+    def run():
+        y = host16(lin.forward(dev16(x, dt)), dt)
+        y2 = host16(lin2.forward(dev16(x, dt), epilogue=cv.EPI_RESID, residual=dev16(res, dt)), dt)
+        y3 = host16(lin2.forward(dev16(x, dt), epilogue=cv.EPI_SILU_MUL), dt)
+        return y, y2, y3
+
+    base = run()
+    with tuning(30, 32 | 64):
+        tall = run()
+    for a_, b_ in zip(base, tall):
+        assert np.array_equal(np.asarray(a_), np.asarray(b_))
+    check_ulp(tall[0], G.linear16(x, w, b, dt), dt, what="linear+bias", ulps=2.01, mag=G.linear16(x, w, None, dt))
+    gu = G.linear16(x, w, None, dt)
+    check_ulp(tall[2], G.silu_mul16(gu[:, :I], gu[:, I:], dt), dt, ulps=3.0, what="silu(gate)*up")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("T", [1, 8, 32, 40, 130, 257])
 def test_linear_gate_up_silu(cv, dt, T):
     rng = np.random.default_rng(T)
