@@ -970,7 +970,9 @@ __device__ __forceinline__ void dgemm_dma(const uint8_t* gsrc_lane, uint32_t lds
 // per CU; round 4): at 128 x 128 the tile moves 32 KiB through L2 -> LDS per 2.1 MFLOP -- 15 B per kFLOP, ~10 TB/s at the measured 650
 // TFLOP/s, which is what the L2 -> CU path carried in every other measurement of this chip -- the taller tile moves 11.4.  Measured (round 4,
 // one box, alternated, T = 2048): 53.7 k tok/s with the 128 x 128 tile, 51.5 k with 256 x 128: L2 traffic is not what bounds it; the tall tile
-// stays a tested option (tuning key 30 bit 32; bit-identical outputs, tests/test_gpu_linear.py).
+// stays a tested option (tuning key 30 bit 32; bit-identical outputs, tests/test_gpu_linear.py).  A ring of three K steps behind counted
+// waits (one workgroup per CU then) was measured too and removed: 53.0 k -> 41.2 k at 128 x 128, 47.5 k at 256 x 128 -- this GEMM lives on its
+// two workgroups per CU, not on prefetch depth.
 template <int DT, int WR = 2>
 __global__ void __launch_bounds__(128 * WR, WR == 2 ? 2 : 1) dense_gemm_kernel(const DenseArgs a) {
     constexpr int BM = 64 * WR, NTHR = 128 * WR, AROUNDS = BM / (NTHR / 8), BROUNDS = DG_BN / (NTHR / 8);   // rows per staging round = NTHR / 8
