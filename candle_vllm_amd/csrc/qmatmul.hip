@@ -2066,12 +2066,6 @@ static int g_tune_qpg_fepi = 1;                            // mi355_set_tuning(4
 static int g_tune_qpg_min = 96;                            // mi355_set_tuning(12, n): fewest tokens that take the prompt-step GEMM (QMP_MIN_TOKENS)
 static int g_tune_dbg = 0;                                 // mi355_set_tuning(2, v): probe / ablation modes (experiments only)
 
-// fewest tokens of a launch that take the 128-token tile of the LDS-fed prompt GEMM.  Measured (round 4, Llama-3-8B Q4_K_M prompt step, 64- vs
-// 128-token tile, same box per pair): T = 512: 21.8 k vs 20.0 k tok/s, T = 1024: 30.9 k vs 29.7 k (896 workgroups on the widest launch = 3.5
-// rounds of the 256 CUs against 7), T = 2048: 34.6 k vs 37.3 k, T = 4096: 31.4 k vs 34.6 k
-#ifndef QPG_MTW8_MIN_TOKENS
-#define QPG_MTW8_MIN_TOKENS 2048
-#endif
 #include "qmm_prefill.inc"
 
 // hand-written prompt-step GEMM (qmm_prefill.inc); returns hipErrorNotSupported for launches it does not cover (then the
@@ -2112,10 +2106,8 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 #endif
 #undef QPG_ATTR
-        (void)hipFuncSetAttribute((const void*)qpg_gemm_lds_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)qpg_gemm_lds_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)qpg_gemm_lds_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)qpg_gemm_lds_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_lds2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_lds2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
@@ -2131,14 +2123,9 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
         if (g_tune_qpg_fepi && all_q4 && epi_ok && parts == 1 && (g_tune_qpg == 0 || g_tune_qpg == 2)) {
             QmmArgs r = a;
             r.norm_w = nullptr;                                 // applied while the image was built
-            if (g_tune_qpg == 2) {                              // 64 tokens x 256 rows per workgroup (waves 64 x 32): every unpacked weight meets 64 tokens
+            if (g_tune_qpg == 2) {                              // 64 tokens x 256 rows per workgroup (waves 64 x 32), two workgroups per CU
                 const dim3 g_(Tpad / 64, (n_slots + 15) / 16), b_(512);
-                if (T >= QPG_MTW8_MIN_TOKENS) {
-                    const dim3 g8(Tpad / 128, (n_slots + 15) / 16);
-                    hipLaunchKernelGGL((qpg_gemm_lds_kernel<true, 8>), g8, b_, (size_t)QpgLds<8>::BYTES, st, r, im, C, ldp, n_slots, 0);
-                } else {
-                    hipLaunchKernelGGL((qpg_gemm_lds_kernel<true, 4>), g_, b_, (size_t)QpgLds<4>::BYTES, st, r, im, C, ldp, n_slots, 0);
-                }
+                hipLaunchKernelGGL((qpg_gemm_lds2_kernel<true>), g_, b_, (size_t)QPG2_BYTES, st, r, im, C, ldp, n_slots, 0);
             } else {
 #ifdef MI355_QMM_PROBES
                 const dim3 g_(Tpad / 32, (n_slots + 31) / 32), b_(512);   // rounds 2-3: 32 x 512, register-fed
@@ -2169,11 +2156,10 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
                 case 3: QPG_GO(2, 4, 2, 4, false); break;              //  64 x 256, waves 32 x 64
                 case 0: QPG_GO(2, 4, 1, 8, false); break;              //  32 x 512, waves 32 x 64: measured best in round 2 (hi + lo planes); with one plane 64 x 256 wins (round 4: 25.7 k -> 27.0 k tok/s at T = 2048)
 #endif
-                default:                                                //  64 (128) x 256, waves 64 (128) x 32; one activation plane: image and weights through LDS by DMA
+                default:                                                //  64 x 256, waves 64 x 32, two workgroups per CU; one activation plane: image and weights through LDS by DMA
                     if (parts == 1) {
-                        const dim3 g4(Tpad / 64, (run_slots + 15) / 16), g8(Tpad / 128, (run_slots + 15) / 16), b_(512);
-                        if (T >= QPG_MTW8_MIN_TOKENS) hipLaunchKernelGGL((qpg_gemm_lds_kernel<false, 8>), g8, b_, (size_t)QpgLds<8>::BYTES, st, r, im, C, ldp, run_slots, slot_base);
-                        else hipLaunchKernelGGL((qpg_gemm_lds_kernel<false, 4>), g4, b_, (size_t)QpgLds<4>::BYTES, st, r, im, C, ldp, run_slots, slot_base);
+                        const dim3 g4(Tpad / 64, (run_slots + 15) / 16), b_(512);
+                        hipLaunchKernelGGL((qpg_gemm_lds2_kernel<false>), g4, b_, (size_t)QPG2_BYTES, st, r, im, C, ldp, run_slots, slot_base);
                     } else {
                         QPG_GO(4, 2, 1, 8, false);                      // hi + lo planes ("exact" activations): the register-fed form
                     }

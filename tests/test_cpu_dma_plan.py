@@ -1,4 +1,4 @@
-"""Host-side check of the hand-counted `s_waitcnt vmcnt(N)` of the LDS-fed prompt-step GEMMs (csrc/qmm_prefill.inc: qpg_gemm_lds_kernel,
+"""Host-side check of the hand-counted `s_waitcnt vmcnt(N)` of the LDS-fed prompt-step GEMMs (csrc/qmm_prefill.inc: qpg_gemm_lds2_kernel,
 qpg_gemm_q6k_lds_kernel).  Their loops issue ONLY LDS-DMA instructions, in a fixed order per wave, and wait by count in front of every
 chunk's barrier; the counts are exported by the library (`mi355_internal_qpg_dma_plan`: the constants the kernels are compiled with) and
 checked here against a model of the instruction stream:
@@ -71,7 +71,7 @@ def _simulate(plan, nkb):
     return slack
 
 
-@pytest.mark.parametrize("kind", [4, 8, 6])
+@pytest.mark.parametrize("kind", [6])
 def test_counted_waits_are_safe_and_tight(lib, kind):
     plan = _plan(lib, kind)
     lead, ring, xu, nw, n0, n1 = plan
@@ -85,6 +85,58 @@ def test_counted_waits_are_safe_and_tight(lib, kind):
 
 
 def test_plan_matches_the_documented_counts(lib):
-    assert _plan(lib, 4) == [4, 8, 1, 6, 3, 9]                        # 64-token tile: ring of 8, 4 ahead
-    assert _plan(lib, 8) == [3, 4, 2, 6, 4, 10]                       # 128-token tile: ring of 4, 3 ahead, two DMAs per wave and chunk
-    assert _plan(lib, 6) == [3, 4, 1, 8, 2, 10]                       # Q6_K
+    assert _plan(lib, 6) == [3, 4, 1, 8, 2, 10]                       # Q6_K: ring of 4 chunks, 3 ahead, eight weight DMAs per wave and k-block
+    assert _plan(lib, 2) == [3, 4, 1, 6, 1, 8]                        # Q4_K, two workgroups per CU (its own order: the test below)
+
+
+def _simulate_two_wg(plan, nkb):
+    """qpg_gemm_lds2_kernel: per wave and k-block  I P1 P1 | I | I H S P0 P0 | I  behind the barriers of chunks 0..3 (image 3 chunks ahead,
+    plane 1 of THIS k-block in chunk 0, headers / sums / plane 0 of the NEXT one in chunk 2); prologue  I(0) | I(1) H S P0 P0 | I(2)"""
+    lead, ring, xu, nw, ne, no = plan
+    assert (lead, ring, xu, nw) == (3, 4, 1, 6)
+    nchunk = 4 * nkb
+    issued, retired = [], 0
+
+    def put(kind, idx):
+        issued.append((kind, idx))
+
+    def wait(n):
+        nonlocal retired
+        retired = max(retired, len(issued) - n)
+
+    def landed(kind, idx):
+        pos = [i for i, op in enumerate(issued) if op == (kind, idx)]
+        assert pos, (kind, idx)
+        return max(pos) < retired
+
+    put("I", 0); put("I", 1); put("H", 0); put("S", 0); put("P0", 0); put("P0", 0); put("I", 2)
+    slack = []
+    for kb in range(nkb):
+        for c in range(4):
+            kc = 4 * kb + c
+            wait(ne if c % 2 == 0 else no)
+            need = [("I", kc)]
+            if c == 0:
+                need += [("H", kb), ("S", kb), ("P0", kb)]
+            if c == 2:
+                need += [("P1", kb)]
+            for kind, idx in need:
+                assert landed(kind, idx), (nkb, kb, c, kind)
+            newest = max(i for i, op in enumerate(issued) if op in need)
+            slack.append((len(issued) - 1 - newest) - (ne if c % 2 == 0 else no))
+            assert (kc + lead) % ring != kc % ring and (kc + lead) % ring not in {(kc + d) % ring for d in range(1, lead)}
+            put("I", kc + lead)                                       # (past the end the kernel re-reads the last chunk into the same free slot)
+            if c == 0:
+                put("P1", kb); put("P1", kb)                          # plane-1 region: last read (into registers) in chunk 2 of kb - 1
+            if c == 2:
+                put("H", kb + 1); put("S", kb + 1); put("P0", kb + 1); put("P0", kb + 1)   # plane-0 region: last read in chunk 0 of kb
+    return slack
+
+
+def test_two_workgroup_kernel_counted_waits(lib):
+    plan = _plan(lib, 2)
+    assert plan == [3, 4, 1, 6, 1, 8]
+    for nkb in (1, 2, 3, 16, 56):
+        slack = _simulate_two_wg(plan, nkb)
+        assert min(slack) >= 0 and min(slack) == 0, (nkb, slack[:12])
+    assert set(_simulate_two_wg(plan, 16)[8:]) == {0}

@@ -288,7 +288,7 @@ def test_dequantize_and_ref_kernel(cv, t):
 @pytest.mark.parametrize("T,N,K", [(1, 64, 256), (1, 4096, 4096), (1, 40, 512), (2, 48, 1024), (3, 128, 4096),
                                    (5, 32, 14336), (8, 256, 2048), (9, 64, 512), (32, 96, 4096),
                                    (128, 96, 1024), (200, 40, 512),       # >= 96 tokens: prompt-step GEMM path (image and weights through LDS by DMA)
-                                   (300, 272, 256), (2100, 40, 256)])     # one k-block (the DMA rings are longer than the matrix); >= 2048 tokens: 128-token tile
+                                   (300, 272, 256), (2100, 40, 256)])     # one k-block (the DMA rings are longer than the matrix); many token blocks
 def test_qmatmul_vs_oracle(cv, t, T, N, K):
     rng = np.random.default_rng(12 + T + N)
     blocks = kq.quantize(rng.normal(0, 0.05, (N, K)).astype(np.float32), t)
@@ -682,7 +682,7 @@ def test_paged_attention_lds_dma_stream(cv, bs, ctx):
                 assert np.abs(got - oracle).max() <= tol, (key, np.abs(got - oracle).max())
 
 
-@pytest.mark.parametrize("T,N,K", [(128, 96, 1024), (200, 40, 512), (300, 640, 2048), (97, 16, 256), (2100, 48, 512)])   # (>= 2048 tokens: the 128-token tile)
+@pytest.mark.parametrize("T,N,K", [(128, 96, 1024), (200, 40, 512), (300, 640, 2048), (97, 16, 256), (2100, 48, 512)])   # (many token blocks per row block)
 def test_prompt_gemm_fused_epilogue(cv, T, N, K):
     """the default since round 4: Q4_K prompt-step launches apply store / bias / residual / SiLU * up in the GEMM's own store loop (no C
     buffer, no epilogue launch) -- against the oracle at the prompt path's bound and against the unfused path (tuning key 48 = 0; same
