@@ -1474,8 +1474,11 @@ __global__ void __launch_bounds__(256, 1) paged_attn_stream_kernel(const PAParam
                 float lt = l_run + __shfl_xor(l_run, 16, 64);
                 lt += __shfl_xor(lt, 32, 64);
                 __syncthreads();                                      // every wave is done reading the slot
-                float* stt = reinterpret_cast<float*>(pas_smem + (size_t)(i % R) * STAGE_B);   // [4 waves][16 heads][m, l]
-                float* ob = stt + 128;                                // [4 waves][G heads][128 channels]
+                // (the four waves' (m, l) pairs used to sit in front of `ob` in the slot -- at G = 16 the slot's 32 KiB are
+                // exactly ob's 4 x 16 x 128 floats, and the last 512 B ran into the next slot's K / V in flight; they have their own array now)
+                __shared__ float pas_stt[128];                        // [4 waves][16 heads][m, l]
+                float* stt = pas_stt;
+                float* ob = reinterpret_cast<float*>(pas_smem + (size_t)(i % R) * STAGE_B);   // [4 waves][G heads][128 channels]: <= 32 KiB at G <= 16
                 if (kg == 0) { stt[(wave * 16 + c) * 2] = m_run; stt[(wave * 16 + c) * 2 + 1] = lt; }
                 __syncthreads();
 #pragma unroll
