@@ -46,9 +46,11 @@ def parse():
     ap.add_argument("--ctx", type=int, default=4096, help="prompt tokens already in the KV cache")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--tp-eager", action="store_true", help="N > 1 only: run tensor-parallel steps eagerly instead of from a hipGraph")
-    ap.add_argument("--p2p", action="store_true",
-                    help="N > 1 only, opt-in: decode-sized all-reduces through the one-shot peer-to-peer kernel (IPC regions; validated "
-                         "with two processes on one GPU, not yet over xGMI) instead of RCCL")
+    ap.add_argument("--all-reduce", choices=["auto", "rccl", "p2p"], default="auto",
+                    help="N > 1 only: transport of the decode-sized all-reduces (<= 256 KiB).  auto (default): the in-stream one-shot "
+                         "peer-to-peer kernel when every pair of ranks has peer access and its self-test passes on every rank, RCCL on "
+                         "its side stream otherwise (the line's config.all_reduce says which); rccl / p2p force one")
+    ap.add_argument("--p2p", action="store_true", help="same as --all-reduce p2p")
     ap.add_argument("--wire-bf16", action="store_true", help="N > 1 only: the reference's all-reduce numerics (bf16 partials on the wire)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
@@ -328,8 +330,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: spawn the N ranks (one process per GPU) the way the reference spawns its own
+        # (src/openai/communicator.rs:704-785; the unique id travels by torch.distributed here) -- the same entry script under
+        # torch.distributed.run on the loopback address; rank 0 of the children prints the one JSON line
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(sys.argv[0])] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch `python bench.py --gpus N` (it spawns its ranks) or "
+                         f"`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
@@ -357,8 +373,10 @@ def main():
     kv_layout = M.KV_PAGED if args.kv_layout == "paged" else M.KV_FLASH
     gm = M.GGUFLLaMa(cfg, max_batch=(B32 if do_b32 else B), max_blocks_per_seq=blocks_per_seq, kv_layout=kv_layout,
                      tp_rank=rank, tp_world=world)
+    transport = None
     if world > 1:
-        gm.init_comm(dist, p2p=args.p2p, wire_bf16=args.wire_bf16)
+        mode = "p2p" if args.p2p else args.all_reduce
+        transport = gm.init_comm(dist, p2p={"auto": "auto", "rccl": False, "p2p": True}[mode], wire_bf16=args.wire_bf16)
     gm.load_synthetic(seed=1235, recipe="q4_k_m")
     gm.alloc_kv_cache(num_blocks)
     gm.kv_fill_random(seed=7 + rank)
@@ -421,7 +439,7 @@ def main():
                                f"batch={B}, prompt ctx {args.ctx} in paged KV (block 64), {K} decode steps",
                    "batch": B, "ctx_start": args.ctx + 1 + Wm, "ctx_end": args.ctx + Wm + K,
                    "parallelism": f"tp{world}", "graph": bool(graph_mode),
-                   **({"all_reduce": ("one-shot peer kernel" if args.p2p else "RCCL on a side stream"),
+                   **({"all_reduce": transport, "ranks": world,
                        "wire": ("bf16 (reference numerics)" if args.wire_bf16 else "f32")} if world > 1 else {}),
                    "kv_layout": ("paged K[NB,Hkv,D/8,64,8] V[NB,Hkv,D,64] bf16" if args.kv_layout == "paged"
                                  else "flash [NB,64,Hkv,128] bf16")},

@@ -18,8 +18,8 @@ def tuning(key, value):
     if not lib.mi355_tuning_supported(key):
         raise TuningKeyUnavailable(f"tuning key {key} is not honoured by this build of the library")
     prev = lib.mi355_get_tuning(key)
-    if prev == -2 ** 31:                                  # a probe-build key that was never set: its default is 0 / "heuristic"
-        prev = 0
+    if prev == -2 ** 31:                                  # a key this build honours but has no live value for: nothing to restore to
+        raise TuningKeyUnavailable(f"tuning key {key} has no recorded default in this build: set it explicitly with mi355_set_tuning")
     lib.mi355_set_tuning(key, value)
     try:
         yield

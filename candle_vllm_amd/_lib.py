@@ -75,6 +75,10 @@ _sig("mi355_paged_attention_v2", ctypes.c_int,
      [c_vp] * 9 + [c_i32] * 8 + [c_f32, c_f32, c_i32, c_i32, c_i64])
 _sig("mi355_prefill_attention", ctypes.c_int,
      [c_vp] * 9 + [c_i32] * 7 + [c_f32, c_f32, c_i32, c_i32, c_i64])
+_sig("mi355_paged_attention_window", ctypes.c_int,
+     [c_vp] * 6 + [c_i32] * 7 + [c_f32, c_f32, c_i32, c_i32, c_i32, c_i64])
+_sig("mi355_prefill_attention_window", ctypes.c_int,
+     [c_vp] * 9 + [c_i32] * 7 + [c_f32, c_f32, c_i32, c_i32, c_i32, c_i64])
 _sig("mi355_reshape_and_cache_fp8", ctypes.c_int, [c_vp] * 5 + [c_i32] * 5 + [c_f32, c_f32, c_i64])
 _sig("mi355_paged_attention_fp8", ctypes.c_int, [c_vp] * 9 + [c_i32] * 8 + [c_f32] * 4 + [c_i64])
 _sig("mi355_prefill_attention_fp8", ctypes.c_int, [c_vp] * 7 + [c_i32] * 7 + [c_f32] * 4 + [c_i32, c_i64])
@@ -227,7 +231,8 @@ class DenseConfig(ctypes.Structure):
                                      "vocab", "max_seq", "block_size", "kv_layout", "max_batch",
                                      "max_blocks_per_seq")] + \
                [("rms_eps", c_f32), ("rope_theta", c_f32), ("dtype", c_i32), ("rope_interleaved", c_i32),
-                ("norm_type", c_i32), ("rotary_dim", c_i32), ("kv_fp8", c_i32), ("tp_rank", c_i32), ("tp_world", c_i32)]
+                ("norm_type", c_i32), ("rotary_dim", c_i32), ("kv_fp8", c_i32), ("tp_rank", c_i32), ("tp_world", c_i32),
+                ("vocab_total", c_i32)]
 
 
 _sig("mi355_layer_norm", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_i64])
@@ -257,6 +262,7 @@ _sig("mi355_comm_all_reduce_residual", ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c
 _sig("mi355_comm_p2p_export", ctypes.c_int, [c_vp, c_vp])
 _sig("mi355_comm_p2p_attach", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32])
 _sig("mi355_comm_p2p_error", ctypes.c_int, [c_vp])
+_sig("mi355_comm_p2p_enable", ctypes.c_int, [c_vp, c_i32])
 _sig("mi355_comm_capture_probe", ctypes.c_int, [c_vp, c_i64])
 _sig("mi355_dense_alloc_kv_cache", ctypes.c_int, [c_vp, c_i32])
 _sig("mi355_dense_kv_ptr", c_vp, [c_vp, c_i32, c_i32])

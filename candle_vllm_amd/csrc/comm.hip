@@ -303,6 +303,18 @@ extern "C" int mi355_comm_p2p_attach(void* comm, const void* handles, int32_t ra
     c->rank = rank; c->world = world; c->p2p = true;
     return 0;
 }
+// the launcher's switch after a self-test across the ranks (candle_vllm_amd/model.py::init_comm): 0 = keep the regions but route every
+// all-reduce through the communicator's own transport again; 1 = back on (only when every peer region is open).  All ranks must
+// make the same call -- a rank that alone leaves the peer kernel would never publish its slice.
+extern "C" int mi355_comm_p2p_enable(void* comm, int32_t on) {
+    Comm* c = static_cast<Comm*>(comm);
+    if (!c) return (int)hipErrorInvalidValue;
+    if (!on) { c->p2p = false; return 0; }
+    if (!c->local || c->world < 1 || c->world > MI355_P2P_MAX_WORLD) return (int)hipErrorInvalidValue;
+    for (int r = 0; r < c->world; ++r) if (!c->peer[r]) return (int)hipErrorInvalidValue;
+    c->p2p = true;
+    return 0;
+}
 // 0 = every wait so far met its peer; 1 = a peer did not arrive within the spin bound (results of that call are invalid)
 extern "C" int mi355_comm_p2p_error(void* comm) {
     Comm* c = static_cast<Comm*>(comm);

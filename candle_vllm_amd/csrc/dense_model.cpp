@@ -113,13 +113,21 @@ void dense_drop_graph(DModel* m) {
     m->warmed.clear();
 }
 
-// [W, B, Vl] -> [B, W*Vl]   (VocabParallelLinear: all-gather then un-interleave, distributed.rs:1637-1663)
-__global__ void gather_transpose16_kernel(uint16_t* out, const uint16_t* in, int W, int B, int Vl) {
+// [W, B, Vl] -> [B, V]   (VocabParallelLinear: all-gather, un-interleave, narrow to the real vocabulary V <= W * Vl -- the columns
+// beyond it are the zero rows of a padded vocabulary, distributed.rs:1637-1663)
+__global__ void gather_transpose16_kernel(uint16_t* out, const uint16_t* in, int W, int B, int Vl, int V) {
     const int64_t n = (int64_t)W * B * Vl;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int v = (int)(i % Vl), b = (int)((i / Vl) % B), w = (int)(i / ((int64_t)Vl * B));
-        out[((int64_t)b * W + w) * Vl + v] = in[i];
+        const int64_t col = (int64_t)w * Vl + v;
+        if (col < V) out[(int64_t)b * V + col] = in[i];
     }
+}
+// the width of a logits row: the real vocabulary under tensor parallelism (cfg.vocab is the rank's shard, zero rows of a padded
+// vocabulary included), else the lm_head's rows
+inline int logits_width(const mi355_dense_config& c) {
+    const int W = c.tp_world > 1 ? c.tp_world : 1;
+    return (W > 1 && c.vocab_total > 0) ? c.vocab_total : c.vocab * W;
 }
 
 // xs = round(xs + y): the block's residual add after the row-parallel all-reduce (llama.rs:55-58 over
@@ -252,6 +260,9 @@ void* mi355_dense_create(const mi355_dense_config* cfg) {
         return nullptr;
     if (cfg->dtype != MI355_DTYPE_BF16) return nullptr;       // the attention kernels of this path are bf16
     if (cfg->kv_fp8 && (cfg->kv_layout != MI355_KV_PAGED || (cfg->head_dim % 16))) return nullptr;
+    // vocab_total (the real vocabulary a tensor-parallel lm_head's gathered logits are narrowed to): inside the gathered row
+    if (cfg->vocab_total < 0 || (cfg->vocab_total > 0 && (int64_t)cfg->vocab_total > (int64_t)cfg->vocab * (cfg->tp_world > 1 ? cfg->tp_world : 1)))
+        return nullptr;
     DModel* m = new DModel();
     m->cfg = *cfg;
     m->layers.resize(cfg->n_layers);
@@ -310,7 +321,7 @@ static int dense_set_weight_impl(void* mp, int32_t layer, int32_t which, const v
     int64_t expect = 0, offset = 0, total = 0;
     if (layer < 0) {
         // the embedding table is replicated under TP (full vocabulary), lm_head is vocab-parallel (distributed.rs:1632)
-        if (which == MI355_W_TOK_EMBD) { slot = &m->tok_embd; expect = (int64_t)c.vocab * (c.tp_world > 1 ? c.tp_world : 1) * hid; }
+        if (which == MI355_W_TOK_EMBD) { slot = &m->tok_embd; expect = (int64_t)logits_width(c) * hid; }
         else if (which == MI355_W_OUTPUT_NORM) { slot = &m->output_norm; expect = hid; }
         else if (which == MI355_W_OUTPUT) { slot = &m->output; expect = (int64_t)c.vocab * hid; }
         else if (which == MI355_W_OUTPUT_NORM_B) { slot = &m->output_norm_b; expect = hid; }
@@ -608,8 +619,10 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
         const int W = c.tp_world > 1 ? c.tp_world : 1;
         DCHECK(linear(m, m->output, QLin{}, m->lg16, m->xn, nullptr, nullptr, num_seqs, c.vocab, hid, MI355_EPI_STORE, stream));
         DCHECK(mi355_comm_all_gather(m->comm, m->lg16, m->lg_gather, (int64_t)num_seqs * c.vocab, dt, stream));
-        hipLaunchKernelGGL(gather_transpose16_kernel, dim3(512), dim3(256), 0, st, m->lg16, m->lg_gather, W, num_seqs, c.vocab);
-        return mi355_cast(logits, m->lg16, (int64_t)num_seqs * c.vocab * W, dt, MI355_DTYPE_F32, stream);
+        // narrowed to the real vocabulary as VocabParallelLinear::forward does before sampling (the greedy loop sampled
+        // over the padded row, where a zero row beats an all-negative row and the token id leaves the embedding table)
+        hipLaunchKernelGGL(gather_transpose16_kernel, dim3(512), dim3(256), 0, st, m->lg16, m->lg_gather, W, num_seqs, c.vocab, logits_width(c));
+        return mi355_cast(logits, m->lg16, (int64_t)num_seqs * logits_width(c), dt, MI355_DTYPE_F32, stream);
     }
     DCHECK(linear(m, m->output, QLin{}, m->lg16, m->xn, nullptr, nullptr, num_seqs, c.vocab, hid, MI355_EPI_STORE, stream));
     return mi355_cast(logits, m->lg16, (int64_t)num_seqs * c.vocab, dt, MI355_DTYPE_F32, stream);
@@ -670,11 +683,11 @@ int mi355_dense_decode_begin(void* mp, const uint32_t* tokens_host, const uint32
     return 0;
 }
 static int dense_record_step(DModel* m, int64_t stream) {
-    const int B = m->cur_batch, W = m->cfg.tp_world > 1 ? m->cfg.tp_world : 1;
+    const int B = m->cur_batch;
     DCHECK(mi355_dense_forward(m, m->d_tokens, m->d_positions, m->d_slots, m->d_bt, m->d_ctx, nullptr, B, B, 0, m->cur_max_blocks,
                                m->cur_ctx_cap, m->d_logits, stream));
     // greedy sample (`sample_argmax`, logits_processor.rs:92-95: first maximum), then the next step's inputs on the device
-    DCHECK(mi355_argmax_f32(m->d_next, m->d_logits, B, m->cfg.vocab * W, stream));
+    DCHECK(mi355_argmax_f32(m->d_next, m->d_logits, B, logits_width(m->cfg), stream));
     hipLaunchKernelGGL(advance_kernel, dim3((B + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), m->d_tokens, m->d_next,
                        m->d_positions, m->d_slots, m->d_ctx, m->d_bt, m->cur_max_blocks, m->cfg.block_size, B);
     return (int)hipGetLastError();
@@ -689,16 +702,18 @@ int mi355_dense_decode_step(void* mp, int64_t stream) {
     if (m->cur_ctx_max > m->cur_ctx_cap || m->cur_ctx_max > m->cfg.max_seq ||
         (m->cur_ctx_max + m->cfg.block_size - 1) / m->cfg.block_size > m->cur_max_blocks)
         return (int)hipErrorInvalidValue;
-    struct Bump { DModel* m; ~Bump() { ++m->cur_ctx_max; } } bump{m};
+    // (the host mirror of the context length advances only when a step was actually enqueued: a refused or failed step leaves the
+    // device-side context where it was, and a retry must pass the same checks again -- ADVICE r4)
+    auto stepped = [m](int rc) { if (rc == 0) ++m->cur_ctx_max; return rc; };
     // host-supplied collectives are host calls: such TP steps stay eager (a host call made during capture is not replayed)
     const Comm* cm = static_cast<const Comm*>(m->comm);
     const bool tp_eager = cm && (cm->ar || cm->ag || !cm->nccl);
-    if (!m->use_graph || stream == 0 || tp_eager) return dense_record_step(m, stream);
+    if (!m->use_graph || stream == 0 || tp_eager) return stepped(dense_record_step(m, stream));
     const std::array<int, 3> shape{m->cur_batch, m->cur_max_blocks, m->cur_ctx_cap};
     if (!m->warmed.count(shape)) {
         // the first step of a new shape runs eagerly: lazily-set kernel attributes and scratch growth must not happen inside a capture
         m->warmed.insert(shape);
-        return dense_record_step(m, stream);
+        return stepped(dense_record_step(m, stream));
     }
     auto it = m->graphs.find(shape);
     if (it == m->graphs.end()) {
@@ -723,7 +738,7 @@ int mi355_dense_decode_step(void* mp, int64_t stream) {
     }
     it->second.used = ++m->graph_clock;
     DHIP(hipGraphLaunch(it->second.exec, st));
-    return 0;
+    return stepped(0);
 }
 /* D2H of the tokens the last step sampled (= the inputs of the next step); synchronises the stream */
 int mi355_dense_decode_read_tokens(void* mp, uint32_t* host_out, int64_t stream) {
@@ -739,7 +754,8 @@ int mi355_dense_decode_read_tokens(void* mp, uint32_t* host_out, int64_t stream)
     if (p2p && p2p_err != 0) return (int)hipErrorPeerAccessNotEnabled;     // a peer missed the spin bound: the step is invalid on this rank
     return 0;
 }
-/* f32 [batch, vocab (x tp_world)] logits of the last step of the loop (device pointer) */
+/* f32 [batch, vocab] logits of the last step of the loop (device pointer); tensor parallel: [batch, vocab_total] (the gathered row
+ * narrowed to the real vocabulary; vocab x tp_world when vocab_total is 0) */
 float* mi355_dense_logits_ptr(void* mp) { DModel* m = static_cast<DModel*>(mp); return m ? m->d_logits : nullptr; }
 
 }  // extern "C"

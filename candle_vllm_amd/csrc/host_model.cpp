@@ -946,20 +946,22 @@ extern "C" int mi355_llama_decode_step(void* mp, int64_t stream) {
     if (m->cur_ctx_max > m->cur_ctx_cap || m->cur_ctx_max > m->cfg.max_seq ||
         (m->cur_ctx_max + m->cfg.block_size - 1) / m->cfg.block_size > m->cur_max_blocks)
         return (int)hipErrorInvalidValue;
-    struct Bump { Model* m; ~Bump() { ++m->cur_ctx_max; } } bump{m};
+    // (the host mirror of the context length advances only when a step was actually enqueued: a refused or failed step leaves the
+    // device-side context where it was, and a retry must pass the same checks again -- ADVICE r4)
+    auto stepped = [m](int rc) { if (rc == 0) ++m->cur_ctx_max; return rc; };
     // TP steps run eagerly (RCCL in-stream) unless the caller opted in with set_graph(2) AND the communicator is RCCL's
     // own (host-supplied collectives stage through the host and cannot be captured)
     // TP steps are captured like single-GPU ones when every collective of the step is device-native (RCCL on its side
     // stream joins the capture as a fork / join; the one-shot peer kernel is an ordinary node whose sequence numbers live
     // on the device).  Host-supplied collectives stage through the host and cannot be captured: those steps stay eager.
     const bool tp_eager = m->use_comm && !(m->comm && m->comm->nccl);
-    if (!m->use_graph || stream == 0 || tp_eager) return record_step(m, stream);
+    if (!m->use_graph || stream == 0 || tp_eager) return stepped(record_step(m, stream));
     const std::array<int, 3> shape{m->cur_batch, m->cur_max_blocks, m->cur_ctx_cap};
     if (!m->warmed.count(shape)) {
         // first step of a new shape runs eagerly: lazily-set kernel attributes and occupancy queries must not
         // happen inside a stream capture
         m->warmed.insert(shape);
-        return record_step(m, stream);
+        return stepped(record_step(m, stream));
     }
     auto it = m->graphs.find(shape);
     if (it == m->graphs.end()) {
@@ -984,7 +986,7 @@ extern "C" int mi355_llama_decode_step(void* mp, int64_t stream) {
     }
     it->second.used = ++m->graph_clock;
     HCHECK(hipGraphLaunch(it->second.exec, st));
-    return 0;
+    return stepped(0);
 }
 
 // D2H of the tokens the last step sampled (they are the inputs of the next step)

@@ -1937,6 +1937,107 @@ extern "C" int mi355_paged_attention_reference_numerics(void* out, const void* q
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// `sliding_window` of PagedAttention::new on decode steps (attention.rs:566-575,888-897; kernel in the un-vendored attention-rs): the
+// query (position ctx - 1) sees the last `window` keys only, positions ctx - window .. ctx - 1 -- what vLLM's paged attention gets by
+// truncating the block table to the window, here exact for windows that do not start on a block boundary.  No BASELINE model carries
+// a window: this is the correctness path (one workgroup per (head, sequence), the window's scores in LDS, f32 softmax as the product
+// kernels), every head size <= 256, both cache layouts, bf16 / f16.
+template <int KVT>
+__global__ void __launch_bounds__(256) paged_attn_window_kernel(const PAParams p, const int window, const int flash) {
+    extern __shared__ float pw_sm[];                                  // [D] q * scale | [<= window] scores -> probabilities
+    __shared__ float red[16];
+    const int h = blockIdx.x, b = blockIdx.y, D = p.D, G = p.H / p.Hkv, hk = h / G, bs = p.block_size;
+    const int ctx = (int)p.context_lens[b];
+    uint16_t* out = static_cast<uint16_t*>(p.out) + ((size_t)b * p.H + h) * D;
+    if (ctx <= 0) { for (int d = threadIdx.x; d < D; d += blockDim.x) out[d] = 0; return; }
+    const int t_lo = ctx > window ? ctx - window : 0, n = ctx - t_lo;
+    float* qs = pw_sm;
+    float* sc = pw_sm + D;
+    auto cvt = [](uint16_t v) { return KVT == MI355_DTYPE_BF16 ? bf16_to_f32(v) : f16_bits_to_f32(v); };
+    const uint16_t* q = static_cast<const uint16_t*>(p.q) + (size_t)b * p.q_stride + (size_t)h * D;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) qs[d] = cvt(q[d]) * p.scale;
+    __syncthreads();
+    const uint16_t* kc = static_cast<const uint16_t*>(p.kc);
+    const uint16_t* vc = static_cast<const uint16_t*>(p.vc);
+    const uint32_t* bt = p.block_tables + (size_t)b * p.max_blocks;
+    float mx = -1e30f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int t = t_lo + i;
+        const size_t blk = bt[t / bs];
+        const int off = t % bs;
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) {
+            const size_t ki = flash ? ((blk * bs + off) * p.Hkv + hk) * D + d
+                                    : ((((blk * p.Hkv + hk) * (D / 8) + d / 8) * bs + off) * 8) + d % 8;
+            s = fmaf(qs[d], cvt(kc[ki]), s);
+        }
+        if (p.softcap > 0.f) s = tanhf(s / p.softcap) * p.softcap;
+        sc[i] = s;
+        mx = fmaxf(mx, s);
+    }
+    {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        mx = wave_max(mx);
+        if (lane == 0) red[wid] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+    }
+    float lsum = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float e = __expf(sc[i] - mx);
+        sc[i] = e;
+        lsum += e;
+    }
+    lsum = block_sum(lsum, red);                                      // (its barrier publishes the probabilities)
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float a = 0.f;
+        for (int i = 0; i < n; ++i) {
+            const int t = t_lo + i;
+            const size_t blk = bt[t / bs];
+            const int off = t % bs;
+            const size_t vi = flash ? ((blk * bs + off) * p.Hkv + hk) * D + d : ((blk * p.Hkv + hk) * D + d) * (size_t)bs + off;
+            a = fmaf(sc[i], cvt(vc[vi]), a);
+        }
+        const float o = a / lsum;
+        out[d] = (KVT == MI355_DTYPE_BF16) ? f32_to_bf16(o) : f32_to_f16_bits(o);
+    }
+}
+extern "C" int mi355_paged_attention_window(void* out, const void* q, const void* key_cache, const void* value_cache,
+                                            const uint32_t* block_tables, const uint32_t* context_lens, int32_t num_seqs,
+                                            int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                                            int32_t max_blocks_per_seq, int32_t max_context_len, float scale, float softcap,
+                                            int32_t layout, int32_t dtype, int32_t sliding_window, int64_t stream) {
+    if (sliding_window <= 0)
+        return mi355_paged_attention_v1(out, q, key_cache, value_cache, block_tables, context_lens, num_seqs, num_heads, num_kv_heads, head_dim,
+                                        block_size, max_blocks_per_seq, max_context_len, scale, softcap, layout, dtype, stream);
+    if (num_seqs <= 0) return 0;
+    if (!out || !q || !key_cache || !value_cache || !block_tables || !context_lens || num_kv_heads <= 0 || num_heads % num_kv_heads ||
+        head_dim <= 0 || (head_dim & 7) || head_dim > 256 || block_size <= 0 || (layout != MI355_KV_PAGED && layout != MI355_KV_FLASH) ||
+        (dtype != MI355_DTYPE_BF16 && dtype != MI355_DTYPE_F16))
+        return (int)hipErrorInvalidValue;
+    const int span = sliding_window < max_context_len ? sliding_window : (max_context_len > 0 ? max_context_len : 1);
+    const size_t shm = ((size_t)head_dim + (size_t)span) * sizeof(float);
+    if (shm > 150 * 1024) return (int)hipErrorInvalidValue;           // windows beyond ~38 k tokens: not served by this path
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)paged_attn_window_kernel<MI355_DTYPE_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)paged_attn_window_kernel<MI355_DTYPE_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_done = true;
+    }
+    PAParams p{};
+    p.out = out; p.q = q; p.kc = key_cache; p.vc = value_cache; p.block_tables = block_tables; p.context_lens = context_lens;
+    p.H = num_heads; p.Hkv = num_kv_heads; p.D = head_dim; p.block_size = block_size; p.max_blocks = max_blocks_per_seq;
+    p.scale = scale; p.softcap = softcap; p.q_stride = (int64_t)num_heads * head_dim;
+    const int flash = layout == MI355_KV_FLASH ? 1 : 0;
+    if (dtype == MI355_DTYPE_BF16)
+        hipLaunchKernelGGL(paged_attn_window_kernel<MI355_DTYPE_BF16>, dim3(num_heads, num_seqs), dim3(256), shm, to_stream(stream), p, sliding_window, flash);
+    else
+        hipLaunchKernelGGL(paged_attn_window_kernel<MI355_DTYPE_F16>, dim3(num_heads, num_seqs), dim3(256), shm, to_stream(stream), p, sliding_window, flash);
+    return (int)hipGetLastError();
+}
+
 /* decode attention through the balanced stream WITHOUT its merge launch: partials stay in tmp_out / max_logits / exp_sums (slot w of
  * max_partitions per (sequence, head)); *w_out = workgroups per kv head (0: the launch did not take the stream and is complete). */
 extern "C" int mi355_internal_paged_attention_v2_partials(void* out, float* exp_sums, float* max_logits, float* tmp_out, const void* q,

@@ -36,6 +36,7 @@ struct PrefillParams {
     float scale;
     int32_t kv8;                    // generic kernel only: e4m3fn cache (PAGED layout, K x = 16)
     float k_scale, v_scale;
+    int32_t window;                 // generic kernel only: sliding window (0 = none): the query at position i sees keys i - window + 1 .. i
 };
 
 template <int DT>
@@ -301,7 +302,8 @@ __global__ void __launch_bounds__(64) prefill_attn_generic_kernel(const PrefillP
     float qv[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int i = 0; i < 4; ++i) { const int d = lane + 64 * i; qv[i] = d < D ? cvt(q16[d]) : 0.f; }
     float m = -INFINITY, l = 0.f;
-    for (int j = 0; j <= pos; ++j) {
+    const int j0 = p.window > 0 ? max(0, pos - p.window + 1) : 0;     // sliding window: the last `window` keys (mask.rs:22-27)
+    for (int j = j0; j <= pos; ++j) {
         float kv[4], vv[4], dot = 0.f;
         for (int i = 0; i < 4; ++i) {
             const int d = lane + 64 * i;
@@ -674,6 +676,43 @@ extern "C" int mi355_prefill_attention(void* out, const void* q, const void* k, 
         if (dtype == MI355_DTYPE_BF16) hipLaunchKernelGGL((prefill_attn_generic_kernel<MI355_DTYPE_BF16>), grid, dim3(64), 0, st, p, head_dim, src);
         else hipLaunchKernelGGL((prefill_attn_generic_kernel<MI355_DTYPE_F16>), grid, dim3(64), 0, st, p, head_dim, src);
     }
+    return (int)hipGetLastError();
+}
+
+/* `sliding_window` of PagedAttention::new on prompt steps (attention.rs:566-575,888-897; layers/mask.rs:22-27): the same operator with the
+ * causal mask narrowed to the last `sliding_window` keys of every query.  No BASELINE model carries a window, so this is the correctness
+ * path: the one-wave-per-(query, head) kernel, every head size / layout / 16-bit dtype.  sliding_window <= 0 = mi355_prefill_attention. */
+extern "C" int mi355_prefill_attention_window(void* out, const void* q, const void* k, const void* v, const void* key_cache,
+                                              const void* value_cache, const uint32_t* block_tables, const uint32_t* context_lens,
+                                              const uint32_t* cu_seqlens_q, int32_t num_seqs, int32_t max_seqlen_q,
+                                              int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                                              int32_t max_blocks_per_seq, float scale, float softcap, int32_t layout,
+                                              int32_t dtype, int32_t sliding_window, int64_t stream) {
+    if (sliding_window <= 0)
+        return mi355_prefill_attention(out, q, k, v, key_cache, value_cache, block_tables, context_lens, cu_seqlens_q, num_seqs, max_seqlen_q,
+                                       num_heads, num_kv_heads, head_dim, block_size, max_blocks_per_seq, scale, softcap, layout, dtype, stream);
+    if (num_seqs <= 0 || max_seqlen_q <= 0) return 0;
+    if (dtype != MI355_DTYPE_BF16 && dtype != MI355_DTYPE_F16) return (int)hipErrorInvalidValue;
+    if (num_kv_heads <= 0 || num_heads % num_kv_heads || head_dim > 256 || head_dim <= 0) return (int)hipErrorInvalidValue;
+    const bool cached = key_cache != nullptr;
+    if (cached && (!block_tables || !context_lens || !value_cache)) return (int)hipErrorInvalidValue;
+    if (!cached && (!k || !v)) return (int)hipErrorInvalidValue;
+    if (!out || !q || !cu_seqlens_q) return (int)hipErrorInvalidValue;
+    PrefillParams p{};
+    p.out = out; p.q = q;
+    p.k = cached ? key_cache : k; p.v = cached ? value_cache : v;
+    p.block_tables = cached ? block_tables : nullptr;
+    p.context_lens = cached ? context_lens : nullptr;
+    p.cu_q = cu_seqlens_q;
+    p.H = num_heads; p.Hkv = num_kv_heads; p.block_size = block_size; p.max_blocks = max_blocks_per_seq;
+    p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f; p.softcap = softcap > 0.f ? softcap : 0.f;
+    p.window = sliding_window;
+    const int src = !cached ? SRC_CONTIG : (layout == MI355_KV_FLASH ? SRC_FLASH : SRC_PAGED);
+    if (src == SRC_PAGED && head_dim % 8) return (int)hipErrorInvalidValue;
+    dim3 grid(max_seqlen_q, num_heads, num_seqs);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MI355_DTYPE_BF16) hipLaunchKernelGGL((prefill_attn_generic_kernel<MI355_DTYPE_BF16>), grid, dim3(64), 0, st, p, head_dim, src);
+    else hipLaunchKernelGGL((prefill_attn_generic_kernel<MI355_DTYPE_F16>), grid, dim3(64), 0, st, p, head_dim, src);
     return (int)hipGetLastError();
 }
 

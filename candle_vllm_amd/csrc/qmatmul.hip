@@ -778,248 +778,9 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po =
 
 template <int BT, int R, int WT, int XB, int NRM>
 __global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) { qmm_body<BT, R, WT, XB, NRM>(a); }
-#ifdef MI355_QMM_PROBES   // the Q8_K-activation experiment lives in probe builds only (tools/build_probe_lib.sh): it lost every A/B
-// ================================================================================================
-// EXPERIMENT (mi355_set_tuning(18, 1), single-token launches only): the reference CPU path's own activation format.
-// candle's CPU mat-vec quantises x to Q8_K (per 256-block: iscale = -128 / max, q = round(iscale x) <= 127, d = 1 / iscale,
-// sums per 16) and takes INTEGER dot products with the 4/6-bit codes: sumf += (d_w d_x) sum_j sc_j (q4 . q8)_j
-// - (dmin d_x) sum_j m_j bsum_j   [candle-core k_quants vec_dot_q4k_q8k / vec_dot_q6k_q8k; restated in oracle/oracle.c, O2].
-// On the matrix core that is `v_mfma_i32_16x16x32_i8` straight on the masked nibbles (no hi/lo planes, no code-to-float
-// trick): ~75 VALU + 8 MFMA per Q4_K tile and k-block instead of 160 + 12.  The result equals O2 (the reference CPU's
-// numbers) to f32 summation order, not O1; everything else of the launch (work split, weight ring, cross-wave reduction,
-// fused epilogues, deferred RMSNorm -- the quantisation is scale-invariant) is qmm_body's.
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
-#define Q8W_BYTES 352                 // per token and wave: 256 codes + 16 sums of 16 (i32) + d (f32) + pad
-
-template <int XB, int NRM>
-__device__ __forceinline__ void stage_q8k(const QmmArgs& a, const XRegs<1>& xr, uint8_t* xq, int lane, float (&ss)[1]) {
-    float v[4];
-    if (XB == 1) {
-        v[0] = bf16lo_to_f32(xr.v[0].x); v[1] = bf16hi_to_f32(xr.v[0].x);
-        v[2] = bf16lo_to_f32(xr.v[0].y); v[3] = bf16hi_to_f32(xr.v[0].y);
-    } else {
-        v[0] = __uint_as_float(xr.v[0].x); v[1] = __uint_as_float(xr.v[0].y);
-        v[2] = __uint_as_float(xr.v[0].z); v[3] = __uint_as_float(xr.v[0].w);
-    }
-    if (NRM == 1) {
-        ss[0] = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], ss[0]))));
-        v[0] *= xr.nw.x; v[1] *= xr.nw.y; v[2] *= xr.nw.z; v[3] *= xr.nw.w;
-    }
-    const float am = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-    const float amax = wave_max(am);
-    // the signed value of largest magnitude, FIRST occurrence (quantize_row_q8_K keeps `max` at the first strict maximum)
-    int li = -1;
-#pragma unroll
-    for (int i = 3; i >= 0; --i) if (fabsf(v[i]) == amax) li = i;
-    const unsigned long long cand = __ballot(li >= 0);
-    const int first = __ffsll((long long)cand) - 1;
-    const float mine = li == 0 ? v[0] : (li == 1 ? v[1] : (li == 2 ? v[2] : v[3]));
-    const float mx = __shfl(mine, first, 64);
-    uint32_t packed = 0;
-    int s4 = 0;
-    float dx = 0.f;
-    if (amax != 0.f) {
-        const float iscale = -128.f / mx;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int q = (int)rintf(iscale * v[i]);
-            q = q > 127 ? 127 : q;
-            s4 += q;
-            packed |= ((uint32_t)q & 0xFFu) << (8 * i);
-        }
-        dx = 1.f / iscale;
-    }
-    *reinterpret_cast<uint32_t*>(xq + 4 * lane) = packed;
-    s4 += __shfl_xor(s4, 1, 64);
-    s4 += __shfl_xor(s4, 2, 64);
-    if ((lane & 3) == 0) reinterpret_cast<int*>(xq + 256)[lane >> 2] = s4;
-    if (lane == 0) *reinterpret_cast<float*>(xq + 320) = dx;
-}
-
-// RR tiles of one k-block against the wave's staged token; y[r][0] accumulates in every lane of kg == 0 (row = lane & 15)
-template <int RR>
-__device__ __forceinline__ void compute_q4k_i8(const TileRegs* w, const uint8_t* xq, int lane, float (*y)[1]) {
-    const int kg = lane >> 4;
-    long A[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) A[j] = *reinterpret_cast<const long*>(xq + 32 * j + 8 * kg);      // k = 32 j + 8 kg .. +7
-    const int4 b0 = *reinterpret_cast<const int4*>(xq + 256), b1 = *reinterpret_cast<const int4*>(xq + 272);
-    const int4 b2 = *reinterpret_cast<const int4*>(xq + 288), b3 = *reinterpret_cast<const int4*>(xq + 304);
-    const int bs32[8] = {b0.x + b0.y, b0.z + b0.w, b1.x + b1.y, b1.z + b1.w, b2.x + b2.y, b2.z + b2.w, b3.x + b3.y, b3.z + b3.w};
-    const float dx = *reinterpret_cast<const float*>(xq + 320);
-    uint32_t nibs = 0x0F0F0F0Fu;
-    asm volatile("" : "+v"(nibs));
-    const i32x4_t zero = {0, 0, 0, 0};
-#pragma unroll
-    for (int r = 0; r < RR; ++r) {
-        const float d = f16_bits_to_f32((uint16_t)(w[r].a.x & 0xFFFF)) * dx;
-        const float dmin = f16_bits_to_f32((uint16_t)(w[r].a.x >> 16)) * dx;
-        const uint32_t s0 = w[r].a.y, s1 = w[r].a.z, s2 = w[r].a.w;
-        const uint32_t scl = s0 & 0x3F3F3F3Fu, mnl = s1 & 0x3F3F3F3Fu;
-        const uint32_t sch = (s2 & 0x0F0F0F0Fu) | ((s0 >> 2) & 0x30303030u);
-        const uint32_t mnh = ((s2 >> 4) & 0x0F0F0F0Fu) | ((s1 >> 2) & 0x30303030u);
-        int sumi = 0, summ = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int p = j >> 2, pr = (j >> 1) & 1, sh = (j & 1) * 4;
-            const uint4 qs = p ? w[r].c : w[r].b;
-            const uint32_t w0 = pr ? qs.z : qs.x, w1 = pr ? qs.w : qs.y;
-            const uint32_t q0 = (w0 >> sh) & nibs, q1 = (w1 >> sh) & nibs;                         // 8 codes, k order
-            const long B = (long)(((unsigned long long)q1 << 32) | q0);
-            const i32x4_t acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[j], B, zero, 0, 0, 0);
-            const int sc = (int)((((j < 4) ? scl : sch) >> (8 * (j & 3))) & 0xFF);
-            const int mn = (int)((((j < 4) ? mnl : mnh) >> (8 * (j & 3))) & 0xFF);
-            sumi += __mul24(sc, acc[0]);                         // |acc| <= 32 * 15 * 128 < 2^23: full-rate 24-bit multiplies
-            summ += __mul24(mn, bs32[j]);
-        }
-        y[r][0] += d * (float)sumi - dmin * (float)summ;
-    }
-}
-
-template <int RR>
-__device__ __forceinline__ void compute_q6k_i8(const TileRegs* w, const uint8_t* xq, int lane, float (*y)[1]) {
-    const int kg = lane >> 4;
-    // A of the pair of 16-element sub-blocks (2p, 2p+1): elements 4kg..4kg+3 of each
-    long A[8];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const uint32_t lo = *reinterpret_cast<const uint32_t*>(xq + 32 * p + 4 * kg);
-        const uint32_t hi = *reinterpret_cast<const uint32_t*>(xq + 32 * p + 16 + 4 * kg);
-        A[p] = (long)(((unsigned long long)hi << 32) | lo);
-    }
-    const int4 b0 = *reinterpret_cast<const int4*>(xq + 256), b1 = *reinterpret_cast<const int4*>(xq + 272);
-    const int4 b2 = *reinterpret_cast<const int4*>(xq + 288), b3 = *reinterpret_cast<const int4*>(xq + 304);
-    const int bs16[16] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
-    const float dx = *reinterpret_cast<const float*>(xq + 320);
-    const i32x4_t zero = {0, 0, 0, 0};
-#pragma unroll
-    for (int r = 0; r < RR; ++r) {
-        const float d = f16_bits_to_f32((uint16_t)(w[r].e & 0xFFFF)) * dx;
-        const uint32_t scw[4] = {w[r].a.x, w[r].a.y, w[r].a.z, w[r].a.w};
-        const uint32_t qhw[4] = {w[r].d.x, w[r].d.y, w[r].d.z, w[r].d.w};
-        int sumi = 0, corr = 0;
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const uint4 ql = n ? w[r].c : w[r].b;
-            uint32_t t[2][4];
-#pragma unroll
-            for (int is = 0; is < 2; ++is) {
-                const uint32_t qa = is ? ql.z : ql.x, qb = is ? ql.w : ql.y, h = qhw[2 * n + is];
-                t[is][0] = (qa & 0x0F0F0F0Fu) | ((h << 4) & 0x30303030u);
-                t[is][1] = (qb & 0x0F0F0F0Fu) | ((h << 2) & 0x30303030u);
-                t[is][2] = ((qa >> 4) & 0x0F0F0F0Fu) | (h & 0x30303030u);
-                t[is][3] = ((qb >> 4) & 0x0F0F0F0Fu) | ((h >> 2) & 0x30303030u);
-            }
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const int s0i = 8 * n + 2 * tt, p = 4 * n + tt;
-                // the codes 0..63 are valid int8; the "- 32" comes back through the sums of 16:  sum (c - 32) q8 = sum c q8 - 32 bsum
-                const long B0 = (long)(unsigned long long)t[0][tt];                               // sub-block 2p only (upper k half zero)
-                const long B1 = (long)((unsigned long long)t[1][tt] << 32);                      // sub-block 2p + 1 only
-                const i32x4_t a0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[p], B0, zero, 0, 0, 0);
-                const i32x4_t a1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[p], B1, zero, 0, 0, 0);
-                const int sc0 = (int)(int8_t)((scw[s0i >> 2] >> (8 * (s0i & 3))) & 0xFF);
-                const int sc1 = (int)(int8_t)((scw[(s0i + 1) >> 2] >> (8 * ((s0i + 1) & 3))) & 0xFF);
-                sumi += __mul24(sc0, a0[0]) + __mul24(sc1, a1[0]);
-                corr += __mul24(sc0, bs16[s0i]) + __mul24(sc1, bs16[s0i + 1]);
-            }
-        }
-        y[r][0] += d * (float)(sumi - 32 * corr);
-    }
-}
-
-template <int R, int WT, int XB, int NRM>
-__device__ __forceinline__ void qmm_body_q8(const QmmArgs& a) {
-    constexpr int BT = 1, NV = 1;
-    constexpr int PF = (R > QMM_PF_MIN) ? R : QMM_PF_MIN;
-    constexpr int PFK = PF / R;
-    static_assert(PF % R == 0, "ring depth must be a multiple of the tiles per workgroup");
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
-    const int nkb = a.K >> 8;
-    int segi[R], tile[R];
-    if (a.paired) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) { segi[r] = r & 1; tile[r] = blockIdx.x * (R / 2 > 0 ? R / 2 : 1) + (r >> 1); }
-    } else {
-        int t = blockIdx.x * R, s = 0;
-        while (s + 1 < a.nseg && t >= a.seg[s].n_tiles) { t -= a.seg[s].n_tiles; ++s; }
-#pragma unroll
-        for (int r = 0; r < R; ++r) { segi[r] = s; tile[r] = t + r; }
-    }
-    const uint8_t* wbase[R];
-    int wtype[R], wtb[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        wtype[r] = WT ? WT : a.seg[segi[r]].type;
-        wtb[r] = (wtype[r] == MI355_GGML_Q4_K) ? Q4K_TILE : Q6K_TILE;
-        wbase[r] = a.seg[segi[r]].w + (size_t)tile[r] * nkb * wtb[r];
-    }
-    const float* nwp = a.norm_w ? a.norm_w : reinterpret_cast<const float*>(a.seg[0].w);
-    constexpr int XW = 32 * 2 * BT * 16;                          // same carve-up as qmm_body (the launcher sizes LDS for it)
-    static_assert(Q8W_BYTES <= XW, "the Q8_K image must fit the per-wave activation scratch");
-    uint8_t* xq = smem + (size_t)wave * XW;
-    float* red = reinterpret_cast<float*>(smem + (size_t)NW * XW);
-    float* red_ss = red + (size_t)NW * R * BT * 16;
-    float y[R][NV];
-#pragma unroll
-    for (int r = 0; r < R; ++r) y[r][0] = 0.f;
-    float ss[BT] = {0.f};
-    EpiPre ep;
-    epi_pre_early<BT, R>(a, segi, tile, ep);
-    const int n_my_kb = (nkb > wave) ? (nkb - wave + NW - 1) / NW : 0;
-    const int kb_last = n_my_kb > 0 ? wave + NW * (n_my_kb - 1) : 0;
-    XRegs<BT> xr[PFK];
-    TileRegs buf[PF];
-#pragma unroll
-    for (int q = 0; q < PFK; ++q) {
-        const int kb = wave + NW * q;
-        xr[q] = load_x<BT, XB, NRM>(a, kb <= kb_last ? kb : kb_last, lane, nwp);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const bool ok = q < n_my_kb;
-            buf[q * R + r] = load_tile<WT>(wtype[r], ok ? wbase[r] + (size_t)kb * wtb[r] : wbase[r], ok ? lane : 0);
-        }
-    }
-    epi_pre_late(a, ep);
-    for (int kbi0 = 0; kbi0 < n_my_kb; kbi0 += PFK) {
-#pragma unroll
-        for (int q = 0; q < PFK; ++q) {
-            const int kbi = kbi0 + q;
-            const bool active = kbi < n_my_kb;
-            if (active) stage_q8k<XB, NRM>(a, xr[q], xq, lane, ss);
-            // the sums and d are written by single lanes and read by all: without a wave-scope fence the compiler may hoist
-            // another lane's read above the store it never executes itself (seen: lane 0 right, lanes 1..15 stale)
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            const int kbn = wave + NW * (kbi + PFK);
-            xr[q] = load_x<BT, XB, NRM>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp);
-            const bool ok = kbi + PFK < n_my_kb;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int s = q * R + r;
-                if (active) {
-                    if (wtype[r] == MI355_GGML_Q4_K) compute_q4k_i8<1>(&buf[s], xq, lane, &y[r]);
-                    else compute_q6k_i8<1>(&buf[s], xq, lane, &y[r]);
-                }
-                buf[s] = load_tile<WT>(wtype[r], ok ? wbase[r] + (size_t)kbn * wtb[r] : wbase[r], ok ? lane : 0);
-            }
-        }
-    }
-    const int kg = lane >> 4, row = lane & 15;
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-        if (kg == 0) red[(((size_t)wave * R + r) * BT + 0) * 16 + row] = y[r][0];
-    if (a.norm_w) {
-        const float t = wave_sum(ss[0]);
-        if (lane == 0) red_ss[wave * BT] = t;
-    }
-    __syncthreads();
-    qmm_epilogue<BT, R>(a, red, red_ss, NW, segi, tile, ep);
-}
-template <int R, int WT, int XB, int NRM>
-__global__ void __launch_bounds__(512) qmm_q8_kernel(const QmmArgs a) { qmm_body_q8<R, WT, XB, NRM>(a); }
-
-#endif  // MI355_QMM_PROBES
+#ifdef MI355_QMM_PROBES   // probe builds only (tools/build_probe_lib.sh): the Q8_K-activation experiment (round 2)
+#include "probes/qmm_q8.inc"
+#endif
 
 // MoE variant (decode-shaped, BT = 1): blockIdx.y = (token, slot) pair.  The adjusted descriptor is a private copy
 // -- kept out of the dense kernel, where the kernel arguments must stay scalar loads from the kernarg segment.
@@ -1949,117 +1710,13 @@ extern "C" int mi355_internal_pa_stream_reduce_to_image(void* out, const float* 
 #include <dlfcn.h>
 #define QMP_MIN_TOKENS 96
 
-#ifdef MI355_QMM_PROBES   // first-generation prompt path (bf16 hi/lo weight image + three library GEMMs): A/B in probe builds only
-__device__ __forceinline__ float dequant_tile(int type, const uint8_t* __restrict__ t, int r, int i) {
-    if (type == MI355_GGML_Q4_K) {
-        const uint8_t* h = t + r * 16;
-        const float d = f16_bits_to_f32(*reinterpret_cast<const uint16_t*>(h));
-        const float dmin = f16_bits_to_f32(*reinterpret_cast<const uint16_t*>(h + 2));
-        const uint8_t* s = h + 4;
-        const int j = i >> 5, l = i & 31, g = j >> 1;
-        int sc, m;
-        if (j < 4) { sc = s[j] & 63; m = s[j + 4] & 63; }
-        else { sc = (s[j + 4] & 0xF) | ((s[j - 4] >> 6) << 4); m = (s[j + 4] >> 4) | ((s[j] >> 6) << 4); }
-        const uint8_t qb = t[256 + (g >> 1) * 1024 + ((l >> 3) * 16 + r) * 16 + (g & 1) * 8 + (l & 7)];
-        const int q = (j & 1) ? (qb >> 4) : (qb & 0xF);
-        return d * (float)sc * (float)q - dmin * (float)m;
-    } else {
-        const int8_t* sc = reinterpret_cast<const int8_t*>(t + r * 16);
-        const float d = f16_bits_to_f32(*reinterpret_cast<const uint16_t*>(t + 3328 + 2 * r));
-        const int n = i >> 7, tt = (i >> 5) & 3, l = i & 31;
-        const int w = 32 * (tt & 1) + l;                              // index inside ql[64n .. 64n+63]
-        const int seg = w >> 4, kg = (w >> 2) & 3, e = w & 3;
-        const int segoff = (seg == 0) ? 0 : (seg == 1 ? 8 : (seg == 2 ? 4 : 12));
-        const uint8_t lb = t[256 + n * 1024 + (kg * 16 + r) * 16 + segoff + e];
-        const int lo4 = (tt & 2) ? (lb >> 4) : (lb & 0xF);
-        const int v = 32 * n + l;                                     // index inside qh[0..63]
-        const uint8_t hb = t[2304 + (((v >> 2) & 3) * 16 + r) * 16 + 4 * (v >> 4) + (v & 3)];
-        const int q = (lo4 | (((hb >> (2 * tt)) & 3) << 4)) - 32;
-        return d * (float)sc[8 * n + 2 * tt + (l >> 4)] * (float)q;
-    }
-}
+#ifdef MI355_QMM_PROBES   // probe builds only (tools/build_probe_lib.sh): first-generation prompt path: weight image for library GEMMs
+#include "probes/qmp_kernels.inc"
+#endif
 
-// grid (k-blocks, row tiles); 256 threads = the 256 k of the block; loop over the 16 rows
-__global__ void __launch_bounds__(256) qmp_dequant_kernel(uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, const uint8_t* __restrict__ tiles,
-                                                          int type, int n_rows, int K) {
-    const int kb = blockIdx.x, rt = blockIdx.y, nkb = K >> 8;
-    const int tb = (type == MI355_GGML_Q4_K) ? Q4K_TILE : Q6K_TILE;
-    const uint8_t* t = tiles + ((size_t)rt * nkb + kb) * tb;
-    for (int r = 0; r < 16; ++r) {
-        const int row = rt * 16 + r;
-        if (row >= n_rows) break;
-        const float w = dequant_tile(type, t, r, threadIdx.x);
-        const uint16_t h = f32_to_bf16(w);
-        const size_t o = (size_t)row * K + (size_t)kb * 256 + threadIdx.x;
-        hi[o] = h;
-        lo[o] = f32_to_bf16(w - bf16_to_f32(h));
-    }
-}
-
-// one workgroup per token row: optional RMSNorm, then hi/lo bf16
-__global__ void __launch_bounds__(256) qmp_xsplit_kernel(uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, const QmmArgs a) {
-    __shared__ float red[16];
-    const int b = blockIdx.x;
-    float inv = 1.f;
-    auto ldx = [&](int k) -> float {
-        if (a.x_dtype == MI355_DTYPE_BF16) return bf16_to_f32(static_cast<const uint16_t*>(a.x)[(size_t)b * a.ldx + k]);
-        return static_cast<const float*>(a.x)[(size_t)b * a.ldx + k];
-    };
-    if (a.norm_w) {
-        float ss = 0.f;
-        for (int k = threadIdx.x; k < a.K; k += blockDim.x) { const float v = ldx(k); ss += v * v; }
-        inv = rsqrtf(block_sum(ss, red) / (float)a.K + a.eps);
-    }
-    for (int k = threadIdx.x; k < a.K; k += blockDim.x) {
-        float v = ldx(k);
-        if (a.norm_w) v = v * inv * a.norm_w[k];
-        const uint16_t h = f32_to_bf16(v);
-        hi[(size_t)b * a.K + k] = h;
-        lo[(size_t)b * a.K + k] = f32_to_bf16(v - bf16_to_f32(h));
-    }
-}
-
-#endif  // MI355_QMM_PROBES
-
-#ifdef MI355_QMM_PROBES   // rocBLAS (dlopen) exists in probe builds only: the A/B partner of the hand-written prompt GEMMs
-struct QmpBlas {
-    void* lib = nullptr; void* handle = nullptr;
-    int (*create)(void**) = nullptr;
-    int (*set_stream)(void*, hipStream_t) = nullptr;
-    int (*gemm_ex)(void*, int, int, int, int, int, const void*, const void*, int, int, const void*, int, int, const void*,
-                   const void*, int, int, void*, int, int, int, int, int32_t, uint32_t) = nullptr;
-};
-static QmpBlas g_blas;
-static bool qmp_blas_load() {
-    if (g_blas.handle) return true;
-    if (!g_blas.lib) {
-        const char* names[] = {"librocblas.so", "librocblas.so.5", "/opt/rocm/lib/librocblas.so"};
-        for (const char* n : names) { g_blas.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (g_blas.lib) break; }
-        for (const char* n : names) { if (g_blas.lib) break; g_blas.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); }
-        if (!g_blas.lib) return false;
-        g_blas.create = (int (*)(void**))dlsym(g_blas.lib, "rocblas_create_handle");
-        g_blas.set_stream = (int (*)(void*, hipStream_t))dlsym(g_blas.lib, "rocblas_set_stream");
-        g_blas.gemm_ex = (decltype(g_blas.gemm_ex))dlsym(g_blas.lib, "rocblas_gemm_ex");
-        if (!g_blas.create || !g_blas.set_stream || !g_blas.gemm_ex) return false;
-    }
-    return g_blas.create(&g_blas.handle) == 0 && g_blas.handle;
-}
-
-// plain row-major GEMM on the library for the other translation units (dense_gemv.hip):
-//   out[T, ldo] (bf16 / f16 when out_dtype says so, else f32) = x[T, K] . w[N, K]^T, f32 accumulate, inputs `in_dtype`
-// returns hipErrorSharedObjectInitFailed when rocBLAS cannot be loaded (callers then keep their own kernels)
-int mi355_internal_gemm_rowmajor(void* out, int out_dtype, int ldo, const void* x, const void* w, int in_dtype, int T, int N, int K,
-                                 hipStream_t st) {
-    if (!qmp_blas_load()) return (int)hipErrorSharedObjectInitFailed;
-    if (g_blas.set_stream(g_blas.handle, st) != 0) return (int)hipErrorUnknown;
-    auto ty = [](int dt) { return dt == MI355_DTYPE_BF16 ? 168 : (dt == MI355_DTYPE_F16 ? 150 : 151); };
-    const float one = 1.f, zero = 0.f;
-    const int rc = g_blas.gemm_ex(g_blas.handle, 112, 111, N, T, K, &one, w, ty(in_dtype), K, x, ty(in_dtype), K, &zero, out, ty(out_dtype), ldo,
-                                  out, ty(out_dtype), ldo, 151, 0, 0, 0);
-    return rc == 0 ? 0 : (int)hipErrorUnknown;
-}
-
-#endif  // MI355_QMM_PROBES
+#ifdef MI355_QMM_PROBES   // probe builds only (tools/build_probe_lib.sh): rocBLAS by dlopen (A/B partner of the hand-written prompt GEMMs)
+#include "probes/qmp_rocblas.inc"
+#endif
 
 static int g_tune_qpg = 2;                                 // mi355_set_tuning(11, v): prompt-step GEMM workgroup tile: 2 (default since round 4) = 64 tokens x 256 rows, 0 = 32 x 512 (rounds 2-3), 1 / 3: A/B variants
 static int g_tune_qpg_fepi = 1;                            // mi355_set_tuning(48, 0): A/B, separate epilogue launch.  Default: the prompt-step GEMM applies the epilogue itself (Q4_K launches; store / residual / SiLU * up; round 4: +7 % on the prompt step)
@@ -2188,49 +1845,9 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-#ifdef MI355_QMM_PROBES
-static int qmp_launch(const QmmArgs& a0, hipStream_t st) {
-    QmmArgs a = a0;
-    a.paired = 0;
-    if (!qmp_blas_load()) return (int)hipErrorSharedObjectInitFailed;
-    int n_slots = 0, n_rows_total = 0;
-    for (int s = 0; s < a.nseg; ++s) { n_slots += a.seg[s].n_tiles; n_rows_total += a.seg[s].n_tiles * 16; }
-    const int T = a.B, K = a.K, ldp = n_slots * 16;
-    // workspace: w_hi, w_lo [ldp, K] bf16 | x_hi, x_lo [T, K] bf16 | C [T, ldp] f32
-    const size_t wb = (size_t)ldp * K * 2, xb = (size_t)T * K * 2, cb = (size_t)T * ldp * 4;
-    void* ws = nullptr;
-    int rc = qmg_buf(&ws, MI355_SCR_QMP_WS, 2 * wb + 2 * xb + cb + 1024, st);
-    if (rc) return rc;
-    uint16_t* w_hi = static_cast<uint16_t*>(ws);
-    uint16_t* w_lo = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(ws) + wb);
-    uint16_t* x_hi = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(ws) + 2 * wb);
-    uint16_t* x_lo = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(ws) + 2 * wb + xb);
-    float* C = reinterpret_cast<float*>(static_cast<uint8_t*>(ws) + 2 * wb + 2 * xb);
-    int row0 = 0;
-    for (int s = 0; s < a.nseg; ++s) {                     // concatenated padded row space, as the epilogue expects
-        hipLaunchKernelGGL(qmp_dequant_kernel, dim3(K >> 8, a.seg[s].n_tiles), dim3(256), 0, st, w_hi + (size_t)row0 * K,
-                           w_lo + (size_t)row0 * K, a.seg[s].w, a.seg[s].type, a.seg[s].n_tiles * 16, K);
-        row0 += a.seg[s].n_tiles * 16;
-    }
-    hipLaunchKernelGGL(qmp_xsplit_kernel, dim3(T), dim3(256), 0, st, x_hi, x_lo, a);
-    if (g_blas.set_stream(g_blas.handle, st) != 0) return (int)hipErrorUnknown;
-    // row-major C[T, ldp] = X[T,K] . W[ldp,K]^T   ==   column-major C^T[ldp, T] = op_T(W^T[K, ldp]) . X^T[K, T]
-    const float one = 1.f, zero = 0.f;
-    const int BF16 = 168, F32 = 151, OP_N = 111, OP_T = 112;
-    const uint16_t* Ws[3] = {w_hi, w_lo, w_hi};
-    const uint16_t* Xs[3] = {x_hi, x_hi, x_lo};
-    for (int g = 0; g < 3; ++g) {
-        const int st_rc = g_blas.gemm_ex(g_blas.handle, OP_T, OP_N, ldp, T, K, &one, Ws[g], BF16, K, Xs[g], BF16, K, g == 0 ? &zero : &one,
-                                         C, F32, ldp, C, F32, ldp, F32, 0, 0, 0);
-        if (st_rc != 0) return (int)hipErrorUnknown;
-    }
-    a.norm_w = nullptr;                                     // already applied to x
-    hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, T), dim3(256), 0, st, a, C, ldp, 1, T, (const float*)nullptr,
-                       QmgChainOut{nullptr, nullptr, nullptr, 0, 0, 0, 0});
-    return (int)hipGetLastError();
-}
-
-#endif  // MI355_QMM_PROBES
+#ifdef MI355_QMM_PROBES   // probe builds only (tools/build_probe_lib.sh): launcher of the first-generation prompt path
+#include "probes/qmp_launch.inc"
+#endif
 
 // ------------------------------------------------------------------------------------------------ launcher
 void mi355_pa_set_fused(int v);
@@ -2292,6 +1909,14 @@ namespace {
 struct TuningInit {
     TuningInit() {
         for (const auto& kv : kProductTuning) { tuning_apply(kv[0], kv[1]); g_tune_shadow[kv[0]] = kv[1]; g_tune_shadow_set[kv[0]] = true; }
+#ifdef MI355_QMM_PROBES
+        // probe builds: every key has a live value from the start (the defaults of the variables the setters write; ADVICE r4: a scoped
+        // set / restore of a never-set key used to "restore" 0, which several setters ignore and which switches others off)
+        static const int32_t kProbeDefaults[][2] = {{0, 0}, {1, 0}, {2, 0}, {10, 1024}, {11, 2}, {12, 96}, {14, 1}, {15, 0}, {17, 2}, {18, 0},
+                                                    {20, 0}, {21, 8}, {22, 0}, {23, 0}, {33, 0}, {34, 0}, {35, 0}, {36, 96}, {37, 0}, {38, 4},
+                                                    {42, 1}, {49, 0}};
+        for (const auto& kv : kProbeDefaults) { g_tune_shadow[kv[0]] = kv[1]; g_tune_shadow_set[kv[0]] = true; }
+#endif
     }
 } g_tuning_init;
 }
@@ -2325,7 +1950,7 @@ static int g_num_cus = 0;
 // EXPERIMENTS that lost their A/B on the MI355X ("what was tried for batch 1 in round 3"): they are
 // compiled into probe builds only (tools/build_probe_lib.sh); the product library keeps the entry points as refusals.
 #ifdef MI355_QMM_PROBES
-#include "qmv_engine.inc"
+#include "probes/qmv_engine.inc"
 #else
 static int qmv_launch(const QmmArgs&, int, hipStream_t) { return (int)hipErrorNotSupported; }
 extern "C" int mi355_qmv_error(int32_t* out_host, int32_t) { if (out_host) *out_host = 0; return 0; }
@@ -2655,7 +2280,7 @@ extern "C" int mi355_qmatmul_fused(const mi355_qmm_desc* d, int64_t stream) {
 }
 
 #ifdef MI355_QMM_PROBES
-#include "qmv_chain.inc"
+#include "probes/qmv_chain.inc"
 #else
 extern "C" int mi355_qmv_chain_sync_bytes(void) { return 256; }
 extern "C" int mi355_qmatmul_chain(const mi355_qmm_desc*, int32_t, void*, int64_t) { return (int)hipErrorNotSupported; }

@@ -31,10 +31,18 @@ class DenseLlama:
                         dtype=DT_BF16, rope_interleaved=int(rope_interleaved),
                         norm_type=1 if getattr(cfg, "layer_norm", False) else 0,
                         rotary_dim=int(getattr(cfg, "rotary_dim", 0) or 0),
-                        kv_fp8=1 if getattr(cfg, "kv_fp8", False) else 0, tp_rank=tp_rank, tp_world=tp_world)
+                        kv_fp8=1 if getattr(cfg, "kv_fp8", False) else 0, tp_rank=tp_rank, tp_world=tp_world,
+                        vocab_total=int(getattr(cfg, "vocab_total", 0) or 0) if tp_world > 1 else 0)
         self.h = lib.mi355_dense_create(ctypes.byref(c))
         if not self.h:
             raise RuntimeError("mi355_dense_create failed (bad config or no GPU memory)")
+
+    def logits_width(self):
+        """columns of a logits row: the lm_head's rows; with a communicator the gathered row narrowed to the real vocabulary"""
+        if not (self.comm or getattr(self, 'comm_borrowed', None)):
+            return self.cfg.vocab
+        vt = int(getattr(self.cfg, "vocab_total", 0) or 0) if self.tp_world > 1 else 0
+        return vt if vt > 0 else self.cfg.vocab * self.tp_world
 
     def __del__(self):
         if getattr(self, "h", None) and lib is not None:
@@ -62,6 +70,13 @@ class DenseLlama:
         """attach a communicator the caller owns (mi355_comm_create / tp.TorchDistComm().handle); not destroyed here"""
         _check(lib.mi355_dense_set_comm(self.h, handle), "dense_set_comm")
         self.comm_borrowed = handle
+
+    def comm_capture_ok(self, stream):
+        """can this stack capture the attached communicator's collectives in a hipGraph?  (local test, nothing goes on the wire.)  Tensor-
+        parallel callers run it on EVERY rank, reduce the answers (min) over their process group and call set_graph(False) everywhere
+        unless all ranks said yes: a rank that falls back alone would leave its peers inside a captured collective."""
+        h = self.comm or getattr(self, "comm_borrowed", None)
+        return bool(h) and lib.mi355_comm_capture_probe(h, stream) == 0
 
     def set_rope_tables(self, cos, sin):
         """replace the default RoPE tables: f32 [n >= max_seq, rotary_dim/2]"""
@@ -170,7 +185,7 @@ class DenseLlama:
         cu = None
         if is_prefill:
             cu = torch.from_numpy(np.asarray(meta["cu_seqlens_q"]).astype(np.int64).astype(np.int32)).to(dev)
-        logits = torch.empty((n, self.cfg.vocab * (self.tp_world if (self.comm or getattr(self, 'comm_borrowed', None)) else 1)),
+        logits = torch.empty((n, self.logits_width()),
                              dtype=torch.float32, device=dev)
         st = torch.cuda.current_stream().cuda_stream if stream is None else stream
         _check(lib.mi355_dense_forward(self.h, tok.data_ptr(), pos.data_ptr(), slots.data_ptr(), bt.data_ptr(),
@@ -207,7 +222,7 @@ class DenseLlama:
 
     def loop_logits(self):
         """f32 [batch, vocab] logits of the loop's last step (a copy)"""
-        n = self._loop_batch * self.cfg.vocab * (self.tp_world if (self.comm or getattr(self, 'comm_borrowed', None)) else 1)
+        n = self._loop_batch * self.logits_width()
         out = torch.empty(n, dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()
         ctypes.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(lib.mi355_dense_logits_ptr(self.h)),

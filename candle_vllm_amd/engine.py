@@ -48,6 +48,11 @@ def run_engine(gm, sched, requests, chunk=0, bt_width=None, ctx_cap=None, stream
             pi += 1
         out = sched.schedule(now_ms=int((time.perf_counter() - t0) * 1e3))
         stats["preempted"] += len(sched.take_pending_runner_releases())
+        if swap is None and (len(out.blocks_to_swap_in) or len(out.blocks_to_swap_out) or len(out.swap_in_groups) or len(out.swap_out_groups)):
+            # the scheduler decided to move KV blocks and nobody executes the copies: a group swapped back in would decode on blocks
+            # that were never filled (the reference's execute_scheduler_ops always performs them, cache_engine.rs:527-535)
+            raise RuntimeError("run_engine: the scheduler emitted swap operations but no `swap` callback was supplied "
+                               "(pass swap=..., or give the scheduler no CPU blocks so that it preempts by recompute)")
         if swap is not None:                                       # execute_scheduler_ops order: in, out, (copy)
             swap(out.blocks_to_swap_in, False)
             swap(out.blocks_to_swap_out, True)

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from ._lib import lib, LlamaConfig
-from .ops import _check, GGML_Q4_K, GGML_Q6_K, KV_FLASH, KV_PAGED  # noqa: F401
+from .ops import _check, GGML_Q4_K, GGML_Q6_K, KV_FLASH, KV_PAGED, DT_F32  # noqa: F401
 
 KV_PAGED_FP8 = 2          # `--kvcache-dtype fp8`: e4m3fn bytes in the paged layout with x = 16
 
@@ -207,9 +207,14 @@ class GGUFLLaMa:
         return self.weight_bytes * self.tp_world
 
     # ------------------------------------------------------------------ tensor parallel
-    def init_comm(self, dist, p2p=False, wire_bf16=False):
+    def init_comm(self, dist, p2p="auto", wire_bf16=False):
         """RCCL communicator for this rank: rank 0 draws the unique id, torch.distributed ships the 128 bytes.
-        p2p: also attach the one-shot peer-to-peer all-reduce (every rank's 64-byte IPC handle gathered through `dist`);
+        p2p: the transport of the decode-sized all-reduces (<= 256 KiB; C1 / C2 are 16 KiB at batch 1) --
+          False  RCCL on its side stream for every message;
+          True   the one-shot peer-to-peer kernel (every rank's 64-byte IPC handle gathered through `dist`), in-stream;
+          "auto" (default) the peer kernel when every pair of this node's ranks has peer access AND a self-test across the ranks
+                 (two all-reduces of known data through the peer kernel, the sticky error word clean) passes on every rank;
+                 otherwise every rank goes back to RCCL together.  `self.all_reduce_transport` says what was chosen and why.
         wire_bf16: the reference's all-reduce numerics (attention.rs:1003-1008)."""
         buf = np.zeros(128, np.uint8)
         if self.tp_rank == 0:
@@ -221,13 +226,54 @@ class GGUFLLaMa:
         comm = lib.mi355_llama_comm_handle(self.h)
         if wire_bf16:
             _check(lib.mi355_comm_set_options(comm, 1, 1), "comm_set_options")
-        if p2p:
+        self.all_reduce_transport = "RCCL on a side stream"
+        if not p2p:
+            return self.all_reduce_transport
+
+        def all_min(v):                                            # the ranks decide together
+            f = torch.tensor([int(v)], dtype=torch.int32, device="cuda")
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            return int(f.item())
+        if p2p == "auto":
+            try:
+                dev, n = torch.cuda.current_device(), torch.cuda.device_count()
+                peers = n >= self.tp_world and all(torch.cuda.can_device_access_peer(dev, j) for j in range(n) if j != dev)
+            except Exception:
+                peers = False
+            if not all_min(peers):
+                self.all_reduce_transport = "RCCL on a side stream (no peer access between every pair of ranks)"
+                return self.all_reduce_transport
+        attached = 0
+        try:
             h = ctypes.create_string_buffer(64)
             _check(lib.mi355_comm_p2p_export(comm, ctypes.addressof(h)), "comm_p2p_export")
-            all_h = [None] * self.tp_world
-            dist.all_gather_object(all_h, bytes(h.raw))
+            exported = 1
+        except RuntimeError:
+            h, exported = ctypes.create_string_buffer(64), 0
+        all_h = [None] * self.tp_world
+        dist.all_gather_object(all_h, bytes(h.raw))
+        if all_min(exported):
             blob = ctypes.create_string_buffer(b"".join(all_h), 64 * self.tp_world)
-            _check(lib.mi355_comm_p2p_attach(comm, ctypes.addressof(blob), self.tp_rank, self.tp_world), "comm_p2p_attach")
+            attached = int(lib.mi355_comm_p2p_attach(comm, ctypes.addressof(blob), self.tp_rank, self.tp_world) == 0)
+        ok = all_min(attached)
+        if ok:
+            # self-test: every rank contributes rank + 1 (then 2 * rank + 1); a peer that is not there poisons with NaN + error word
+            st = torch.cuda.current_stream().cuda_stream
+            W = self.tp_world
+            for rnd, want in ((1, W * (W + 1) // 2), (2, W * W)):
+                x = torch.full((2048,), float(rnd * self.tp_rank + 1), dtype=torch.float32, device="cuda")
+                rc = lib.mi355_comm_all_reduce(comm, x.data_ptr(), x.numel(), DT_F32, st)
+                torch.cuda.synchronize()
+                ok = ok and rc == 0 and bool((x == float(want)).all().item()) and lib.mi355_comm_p2p_error(comm) == 0
+            ok = all_min(ok)
+        if ok:
+            self.all_reduce_transport = "one-shot peer kernel (<= 256 KiB, in-stream), RCCL above"
+        else:
+            lib.mi355_comm_p2p_enable(comm, 0)
+            if p2p is True:
+                raise RuntimeError("the one-shot peer all-reduce was requested and failed its export / attach / self-test on at least one rank")
+            self.all_reduce_transport = "RCCL on a side stream (the peer kernel failed its self-test on at least one rank)"
+        return self.all_reduce_transport
 
     def comm_capture_ok(self, stream):
         """can this stack capture the communicator's all-reduce in a hipGraph?  (local test, nothing goes on the wire)"""

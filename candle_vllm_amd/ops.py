@@ -187,8 +187,13 @@ class PagedAttention:
 
     def __init__(self, num_heads, head_dim, scale, num_kv_heads=None, sliding_window=None, device=None,
                  alibi_slopes=None, fp8_kvcache=False):
-        if sliding_window is not None or alibi_slopes is not None:
-            raise NotImplementedError("sliding window / alibi are not used by the BASELINE models")
+        if alibi_slopes is not None:
+            raise NotImplementedError("alibi slopes: every call site of the reference passes None (attention.rs:573,895)")
+        # sliding_window (attention.rs:570,893): the query at position i sees keys i - w + 1 .. i; served by the generic kernels
+        # (mi355_paged_attention_window / mi355_prefill_attention_window), no fp8 cache
+        self.sliding_window = int(sliding_window) if sliding_window else 0
+        if self.sliding_window and fp8_kvcache:
+            raise NotImplementedError("sliding window over an fp8 KV cache")
         self.fp8_kvcache = bool(fp8_kvcache)           # is_fp8_keys (attention.rs:574,896): U8 cache, e4m3fn, PAGED layout
         self.k_scale = self.v_scale = 1.0
         self.num_heads, self.head_dim, self.scale = num_heads, head_dim, float(scale)
@@ -263,6 +268,21 @@ class PagedAttention:
         # ANY sequence with a cached prefix sends the whole batch through the cache path.  (max_seqlen_k > max_seqlen_q
         # misses a mixed batch such as 16 cached + 16 new beside 64 fresh tokens.)
         use_cached = meta.cached_prefix()
+        if self.sliding_window:
+            if use_cached:
+                layout = kv_layout_of(key_cache)
+                bs = key_cache.shape[1] if layout == KV_FLASH else key_cache.shape[3]
+                _check(lib.mi355_prefill_attention_window(_dev(out), _dev(q), None, None, _dev(key_cache), _dev(value_cache),
+                                                          _dev(meta.block_tables), _dev(meta.context_lens), _dev(meta.cu_seqlens_q), n,
+                                                          meta.max_seqlen_q, H, self.num_kv_heads, D, bs, meta.block_tables.shape[1],
+                                                          self.scale, sc, layout, _DT[q.dtype], self.sliding_window, _stream()),
+                       "prefill_attention_window")
+            else:
+                _check(lib.mi355_prefill_attention_window(_dev(out), _dev(q), _dev(k), _dev(v), None, None, None, None,
+                                                          _dev(meta.cu_seqlens_q), n, meta.max_seqlen_q, H, self.num_kv_heads, D, 0, 0,
+                                                          self.scale, sc, 0, _DT[q.dtype], self.sliding_window, _stream()),
+                       "prefill_attention_window")
+            return out
         if use_cached:
             layout = kv_layout_of(key_cache)
             bs = key_cache.shape[1] if layout == KV_FLASH else key_cache.shape[3]
@@ -286,6 +306,11 @@ class PagedAttention:
         dt = _DT[q.dtype]
         bt, cl = meta.block_tables, meta.context_lens
         sc = float(softcapping) if softcapping else 0.0
+        if self.sliding_window:
+            _check(lib.mi355_paged_attention_window(_dev(out), _dev(q), _dev(key_cache), _dev(value_cache), _dev(bt), _dev(cl), B, H,
+                                                    self.num_kv_heads, D, bs, bt.shape[1], meta.max_context_len, self.scale, sc, layout, dt,
+                                                    self.sliding_window, _stream()), "paged_attention_window")
+            return out
         ps = choose_partition(B, self.num_kv_heads, meta.max_context_len) if partition_size is None else partition_size
         if layout == KV_PAGED and ps == 0 and meta.max_context_len > 8192:
             ps = 4096

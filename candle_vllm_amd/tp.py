@@ -154,6 +154,19 @@ def _dense_in(w, rank, world):
     return np.ascontiguousarray(w[:, rank * c:(rank + 1) * c])
 
 
+def _dense_out_padded(w, rank, world, vocab):
+    """the vocab-parallel lm_head of the 16-bit path in the layout of VocabParallelLinear::from_weight_bias (distributed.rs:1534-1550):
+    rows [rank * local, (rank + 1) * local) of the matrix padded with zero rows to pad_vocab_size (same layout as `_rows_padded`)"""
+    if isinstance(w, dict):
+        return _dense_out(w, rank, world)
+    local = pad_vocab_size(vocab, world) // world
+    lo, hi = rank * local, min((rank + 1) * local, vocab)
+    real = w[lo:hi] if hi > lo else w[:0]
+    if real.shape[0] == local:
+        return np.ascontiguousarray(real)
+    return np.ascontiguousarray(np.concatenate([real, np.zeros((local - real.shape[0],) + w.shape[1:], w.dtype)], axis=0))
+
+
 def shard_dense_config(cfg, rank, world):
     """local oracle.dense_llama.DenseConfig of this rank"""
     return shard_config(cfg, rank, world)
@@ -164,7 +177,7 @@ def shard_dense_weights(W, cfg, rank, world):
     replicated; q/k/v biases follow their projection's out shard; lm_head is vocab-parallel."""
     _, kv_rank, kv_world = kv_head_shard(cfg.n_kv_heads, rank, world)
     out = {k: v for k, v in W.items() if k not in ("layers", "output")}
-    out["output"] = _dense_out(W["output"], rank, world)
+    out["output"] = _dense_out_padded(W["output"], rank, world, cfg.vocab)
     out["layers"] = []
     for lw in W["layers"]:
         nl = {k: v for k, v in lw.items() if k.endswith("norm") or k.endswith("norm_b")}

@@ -105,6 +105,23 @@ int mi355_paged_attention_v2(void* out, float* exp_sums, float* max_logits, floa
                              int32_t max_blocks_per_seq, int32_t max_context_len, int32_t partition_size,
                              float scale, float softcap, int32_t layout, int32_t dtype, int64_t stream);
 
+/* `sliding_window` of PagedAttention::new (attention.rs:566-575,888-897; the reference hands it to attention-rs' paged kernel and, on
+ * prompt steps, to its causal mask, layers/mask.rs:22-27): the query at position i sees keys max(0, i - w + 1) .. i.  Decode: position
+ * i = context_len - 1, i.e. the last w cached keys (what vLLM gets by truncating the block table to the window; exact here for windows
+ * that do not start on a block boundary).  sliding_window <= 0 delegates to the unwindowed entry point.  No BASELINE model carries a
+ * window: these are correctness paths (generic kernels, any head size <= 256, both layouts, bf16 / f16; no fp8 cache). */
+int mi355_paged_attention_window(void* out, const void* q, const void* key_cache, const void* value_cache,
+                                 const uint32_t* block_tables, const uint32_t* context_lens, int32_t num_seqs,
+                                 int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                                 int32_t max_blocks_per_seq, int32_t max_context_len, float scale, float softcap,
+                                 int32_t layout, int32_t dtype, int32_t sliding_window, int64_t stream);
+int mi355_prefill_attention_window(void* out, const void* q, const void* k, const void* v, const void* key_cache,
+                                   const void* value_cache, const uint32_t* block_tables, const uint32_t* context_lens,
+                                   const uint32_t* cu_seqlens_q, int32_t num_seqs, int32_t max_seqlen_q,
+                                   int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                                   int32_t max_blocks_per_seq, float scale, float softcap, int32_t layout,
+                                   int32_t dtype, int32_t sliding_window, int64_t stream);
+
 /* the prefill half of PagedAttention::forward (K4; attention.rs:707-719, metadata inputs.rs:90-230,351-367):
  * causal variable-length attention.  q, out [num_tokens, num_heads, head_dim], 16-bit `dtype`;
  * cu_seqlens_q u32 [num_seqs+1] delimits each sequence's chunk inside the flattened token dim.
@@ -534,6 +551,10 @@ int mi355_comm_all_reduce_residual(void* comm, float* y, float* resid, int64_t c
 int mi355_comm_p2p_export(void* comm, void* handle_out64);
 int mi355_comm_p2p_attach(void* comm, const void* handles, int32_t rank, int32_t world);
 int mi355_comm_p2p_error(void* comm);
+/* after mi355_comm_p2p_attach: 0 = route all-reduces through the communicator's own transport again (the regions stay open),
+ * 1 = the peer kernel again.  For a launcher that self-tests the peer path across its ranks before the first step and falls
+ * back on ALL ranks together when any of them failed (candle_vllm_amd/model.py::init_comm, bench.py --all-reduce auto). */
+int mi355_comm_p2p_enable(void* comm, int32_t on);
 /* 0 when EVERY collective flavour of a TP step can be captured in a hipGraph on this stack: captures a small and a
  * hidden-sized f32 all-reduce, a bf16 all-reduce and an all-gather on `stream`, instantiates and destroys the graph without
  * launching it (nothing runs on the wire), so every rank can test locally and the ranks agree on captured / eager steps
@@ -558,6 +579,9 @@ typedef struct mi355_dense_config {
     int32_t rotary_dim;        /* <= head_dim; StableLM: partial_rotary_factor 0.25 (stable_lm.rs:28); 0 = head_dim */
     int32_t kv_fp8;            /* 1 = `--kvcache-dtype fp8`: U8 e4m3fn cache (PAGED layout, x = 16), scale 1.0 */
     int32_t tp_rank, tp_world; /* tensor parallel: n_heads / n_kv_heads / intermediate / vocab are the LOCAL shard */
+    int32_t vocab_total;       /* tensor parallel: the REAL vocabulary (VocabParallelLinear narrows the gathered row to it before sampling,
+                                  distributed.rs:1657-1663; the lm_head shards of a padded vocabulary end in zero rows); logits rows, the
+                                  greedy loop's argmax and the replicated embedding table have this many entries.  0 = vocab x tp_world */
 } mi355_dense_config;
 #define MI355_W_BQ 12 /* q_proj.bias (Qwen2, StableLM use_qkv_bias) */
 #define MI355_W_BK 13
@@ -600,7 +624,11 @@ int mi355_dense_finalize(void* model);
  * steps to come reserved, ctx_cap = upper bound of the context length over those steps.  A step = forward -> argmax (first
  * maximum, logits_processor.rs:92-95) -> next positions / slots / context lengths on the device; captured once per
  * (batch, max_blocks, ctx_cap) and replayed.  Tensor-parallel steps are captured when the communicator is RCCL's own, and
- * run eagerly with host-supplied collectives.  Needs cfg.max_blocks_per_seq >= max_blocks. */
+ * run eagerly with host-supplied collectives.  Whether a capture works is a property of the local stack: tensor-parallel callers
+ * run mi355_comm_capture_probe on every rank, agree on the answer (min over the ranks) and switch graphs off EVERYWHERE
+ * (mi355_dense_set_graph(model, 0)) unless every rank can capture -- the library cannot make that decision per rank without
+ * leaving the other ranks inside a collective.  A step that fails leaves the loop where it was (the context length is advanced only
+ * by a step that was enqueued).  Needs cfg.max_blocks_per_seq >= max_blocks. */
 int mi355_dense_set_graph(void* model, int32_t enable);
 int mi355_dense_decode_begin(void* model, const uint32_t* tokens_host, const uint32_t* seq_lens_host,
                              const uint32_t* block_tables_host, int32_t batch, int32_t max_blocks, int32_t ctx_cap, int64_t stream);

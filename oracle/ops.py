@@ -228,12 +228,16 @@ def gather_kv(key_cache, value_cache, block_table, context_len, flash_layout):
 
 
 def paged_attention_decode(q, key_cache, value_cache, block_tables, context_lens, scale,
-                           flash_layout, softcap=None, kv_is_bf16_bits=True):
+                           flash_layout, softcap=None, kv_is_bf16_bits=True, sliding_window=None):
     """Decode attention over the paged cache.  q: [B, H, D] f32 values (already bf16-rounded by the
     caller, as attention.rs:977-981 casts q,k,v to bf16).  Caches hold bf16 bit patterns (uint16)
     when kv_is_bf16_bits else float arrays.  Math = NaiveAttention, src/openai/models/mod.rs:1288-1306
     (repeat_kv GQA expansion :1240-1247, q.k^T*scale, optional tanh softcap, softmax_last_dim, .v),
-    accumulated in f64; output rounded to bf16 (the kernel's output dtype).  Returns f32 [B, H, D]."""
+    accumulated in f64; output rounded to bf16 (the kernel's output dtype).  Returns f32 [B, H, D].
+    sliding_window (`PagedAttention::new(.., sliding_window, ..)`, attention.rs:566-575,888-897; the kernel lives in the un-vendored
+    attention-rs [EXT]): the query at position n - 1 sees the last `sliding_window` keys only, positions n - w .. n - 1 -- the published
+    semantics of the models that carry the field (Mistral / HF `sliding_window`: key j visible to query i iff i - j < w) and of vLLM's
+    paged attention, which truncates the block table to the window."""
     B, H, D = q.shape
     out = np.zeros((B, H, D), np.float32)
     for b in range(B):
@@ -244,6 +248,8 @@ def paged_attention_decode(q, key_cache, value_cache, block_tables, context_lens
         if kv_is_bf16_bits:
             k = bf16_bits_to_f32(k)
             v = bf16_bits_to_f32(v)
+        if sliding_window is not None and sliding_window > 0 and n > sliding_window:
+            k, v = k[n - sliding_window:], v[n - sliding_window:]
         Hkv = k.shape[1]
         g = H // Hkv
         for h in range(H):
@@ -404,16 +410,21 @@ def kv_head_shard(total_kv_heads, rank, world_size):
     return 1, rank // (world_size // total_kv_heads), total_kv_heads
 
 
-def prefill_attention(q, k, v, scale, softcap=None, cached=0, rnd=None):
+def prefill_attention(q, k, v, scale, softcap=None, cached=0, rnd=None, sliding_window=None):
     """Causal self-attention for ONE sequence.  q [T,H,D] (the chunk), k/v [cached+T,Hkv,D] (cached prefix
     followed by the chunk; `use_cached_kv`, inputs.rs:133-143) -- f32 values already rounded to the 16-bit dtype.
     NaiveAttention math (models/mod.rs:1288-1306) with the causal additive mask of layers/mask.rs:32-53:
-    query t sees keys 0 .. cached+t.  Output rounded by `rnd` (default bf16) f32 [T,H,D]."""
+    query t sees keys 0 .. cached+t.  Output rounded by `rnd` (default bf16) f32 [T,H,D].
+    sliding_window (layers/mask.rs:22-27 hands it to attention-rs' `causal_mask` [EXT]): the query at position i = cached + t sees keys
+    max(0, i - w + 1) .. i (HF: masked iff kv_idx <= q_idx - w)."""
     T, H, D = q.shape
     Hkv = k.shape[1]
     g = H // Hkv
     out = np.zeros((T, H, D), np.float32)
     mask = np.triu(np.ones((T, cached + T), bool), cached + 1)
+    if sliding_window is not None and sliding_window > 0:
+        qi = cached + np.arange(T)[:, None]
+        mask = mask | (np.arange(cached + T)[None, :] <= qi - sliding_window)
     for h in range(H):
         s = q[:, h].astype(np.float64) @ k[:, h // g].astype(np.float64).T * scale
         if softcap is not None:

@@ -28,92 +28,14 @@ def _free_port():
     return p
 
 
-def _fake_model_module(dist, calls):
-    class FakeLib:
-        @staticmethod
-        def mi355_set_tuning(k, v):
-            return 0
-
-    class FakeGGUFLLaMa:
-        def __init__(self, cfg, max_batch=1, max_blocks_per_seq=None, kv_layout=0, tp_rank=0, tp_world=1):
-            self.cfg, self.tp_rank, self.tp_world = cfg, tp_rank, tp_world
-            self.weight_bytes = 4_600_000_000 // tp_world
-            calls.append(("create", tp_rank, tp_world, max_batch))
-
-        def _collective(self):                           # stands for the all-reduce / all-gather inside a TP step
-            if self.tp_world > 1:
-                t = torch.ones(1)
-                dist.all_reduce(t)
-                assert int(t.item()) == self.tp_world
-
-        def init_comm(self, d, p2p=False, wire_bf16=False):
-            t = torch.full((128,), float(self.tp_rank == 0))
-            d.broadcast(t, src=0)
-            assert float(t.sum()) == 128.0
-            calls.append(("init_comm",))
-
-        def comm_capture_ok(self, stream):               # every rank tests locally, bench.py then takes the MIN over ranks
-            calls.append(("capture_probe",))
-            return True
-
-        def load_synthetic(self, seed=0, recipe=""):
-            calls.append(("load_synthetic", recipe))
-
-        def alloc_kv_cache(self, n):
-            self.num_blocks = n
-
-        def kv_fill_random(self, seed=0):
-            pass
-
-        def set_graph(self, on):
-            calls.append(("graph", bool(on)))
-
-        def decode_begin(self, tokens, seq_lens, bt, ctx_cap=0, stream=0):
-            assert len(tokens) == len(seq_lens) == bt.shape[0]
-            self._collective()
-
-        def decode_step(self, st):
-            self._collective()
-            calls.append(("step",))
-
-        def read_tokens(self, st):
-            return np.zeros(1, np.uint32)
-
-        @property
-        def weight_bytes_global(self):
-            return self.weight_bytes * self.tp_world
-
-        def dominant_kernel_roofline(self, stream, peak, reps=7):
-            self._collective()                           # the wo / down launch groups contain the all-reduce
-            calls.append(("roofline",))
-            return {"bound": "hbm", "achieved": 1.0, "peak": peak, "unit": "GB/s", "frac": 1.0 / peak, "traffic": None}
-
-    m = types.ModuleType("candle_vllm_amd.model")
-    m.GGUFLLaMa, m.lib, m.KV_PAGED, m.KV_FLASH = FakeGGUFLLaMa, FakeLib, 1, 0
-    real = types.SimpleNamespace(hidden=4096, n_layers=32, n_heads=32, n_kv_heads=8, head_dim=128, intermediate=14336, vocab=128256,
-                                 rms_eps=1e-5, rope_theta=500000.0, max_seq=8192, block_size=64)
-    m.ModelDims = types.SimpleNamespace(llama3_8b=lambda: real)
-    return m
-
-
 def _worker(rank, world, port, q):
     try:
         os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
                            "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
         sys.path.insert(0, ROOT)
-        import torch.distributed as dist
-        real_init, real_tensor = dist.init_process_group, torch.tensor
-        dist.init_process_group = lambda backend, **kw: real_init(
-            "gloo", rank=kw["rank"], world_size=kw["world_size"])      # "nccl" + device_id on the GPU box
-        torch.tensor = lambda *a, **kw: real_tensor(*a, **{k: v for k, v in kw.items() if k != "device"})
-        torch.cuda.set_device = lambda d: None
-        torch.cuda.synchronize = lambda *a: None
-        torch.cuda.Stream = lambda *a, **kw: types.SimpleNamespace(cuda_stream=0)
         calls = []
-        import candle_vllm_amd
-        fake = _fake_model_module(dist, calls)
-        sys.modules["candle_vllm_amd.model"] = fake
-        candle_vllm_amd.model = fake
+        from tests import bench_standin
+        bench_standin.install(calls)
         import bench
         sys.argv = ["bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "2"]
         buf, old = io.StringIO(), sys.stdout
@@ -159,10 +81,33 @@ def test_bench_main_two_ranks_control_flow():
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 2 and j["scaling"] == "strong"
     assert j["vs_baseline"] is None and j["higher_is_better"] is True and j["data"] == "synthetic"
     assert j["config"]["parallelism"] == "tp2" and j["config"]["graph"] is True and "workload" in j["config"]   # TP steps are captured by default
-    assert j["config"]["all_reduce"] == "RCCL on a side stream" and j["config"]["wire"] == "f32"
+    assert j["config"]["all_reduce"] == "stand-in transport" and j["config"]["ranks"] == 2 and j["config"]["wire"] == "f32"
     assert "cpu_baseline" not in j and "batch32" not in j          # N = 1 legs
     assert j["value"] > 0 and abs(j["value"] - 1e3 / j["ms_per_step"]) / j["value"] < 1e-2      # batch 1: tokens/s = steps/s
     for calls in (calls0, calls1):
-        assert ("init_comm",) in calls and ("roofline",) in calls and ("graph", True) in calls
+        assert ("init_comm", "auto") in calls and ("roofline",) in calls and ("graph", True) in calls
         assert calls.count(("step",)) == 5               # 2 warm-up + 3 timed, on every rank
     assert calls0[0] == ("create", 0, 2, 1) and calls1[0] == ("create", 1, 2, 1)
+
+
+@pytest.mark.timeout(300)
+def test_bench_py_gpus_2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` as a PLAIN subprocess (what the driver runs when it does not wrap the call in torch.distributed.run
+    itself; VERDICT r4: it used to exit with "launch with ..."): the entry script re-executes itself under torch.distributed.run on
+    127.0.0.1, one process per rank; rank 0 prints the one JSON line with n_gpus, the transport of the all-reduce and the rank count
+    it saw.  Here the entry script is the stand-in (gloo, no GPU): the spawning, the env contract and the line are bench.py's own."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_standin.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "strong"
+    assert j["config"]["parallelism"] == "tp2" and j["config"]["ranks"] == 2 and j["config"]["all_reduce"] == "stand-in transport"
+    # a world size that contradicts --gpus is refused, not silently benchmarked
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, cwd=ROOT)
+    assert r2.returncode != 0 and "WORLD_SIZE=1" in (r2.stderr + r2.stdout)

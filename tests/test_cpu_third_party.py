@@ -116,6 +116,39 @@ def test_prefill_attention_equals_torch_sdpa_causal_with_cached_prefix(cached):
     assert np.abs(got - want).max() <= 1e-6 * max(1.0, np.abs(want).max())
 
 
+@pytest.mark.parametrize("window,cached", [(8, 0), (5, 19), (64, 3)])
+def test_sliding_window_attention_equals_the_published_mask(window, cached):
+    """`sliding_window` (attention.rs:566-575,888-897; layers/mask.rs:22-27 -> attention-rs, un-vendored): the oracle's window against
+    torch SDPA under the mask transformers builds for Mistral-style models (`sliding_window_overlay`: kv_idx > q_idx - sliding_window,
+    on top of causal) -- prompt steps with a cached prefix, and the decode step as the last query of the same sequence"""
+    from transformers.masking_utils import sliding_window_overlay, causal_mask_function
+    rng = np.random.default_rng(5 + window)
+    T, H, Hkv, D = 23, 4, 2, 32
+    S = cached + T
+    q = rng.standard_normal((T, H, D)).astype(np.float32)
+    k = rng.standard_normal((S, Hkv, D)).astype(np.float32)
+    v = rng.standard_normal((S, Hkv, D)).astype(np.float32)
+    win = sliding_window_overlay(window)
+    mask = torch.tensor([[bool(win(0, 0, cached + t, j)) and bool(causal_mask_function(0, 0, cached + t, j)) for j in range(S)] for t in range(T)])
+    tq = torch.from_numpy(q).double().permute(1, 0, 2)[None]
+    tk = torch.from_numpy(k).double().permute(1, 0, 2).repeat_interleave(H // Hkv, 0)[None]
+    tv = torch.from_numpy(v).double().permute(1, 0, 2).repeat_interleave(H // Hkv, 0)[None]
+    want = F.scaled_dot_product_attention(tq, tk, tv, attn_mask=mask, scale=0.2)[0].permute(1, 0, 2).float().numpy()
+    got = O.prefill_attention(q, k, v, 0.2, cached=cached, rnd=lambda a: a, sliding_window=window)
+    assert np.abs(got - want).max() <= 1e-6 * max(1.0, np.abs(want).max())
+    # decode: the last query over the paged cache holding all S keys == the last row of the prompt-step result
+    bs = 16
+    nb = -(-S // bs)
+    ks, vs = O.kv_cache_shapes(nb + 1, bs, Hkv, D, 2, False)
+    kc, vc = np.zeros(ks, np.uint16), np.zeros(vs, np.uint16)
+    kb, vb, qb = O.round_bf16(k), O.round_bf16(v), O.round_bf16(q[-1:])
+    table = list(range(nb, 0, -1))
+    O.reshape_and_cache(O.f32_to_bf16_bits(kb), O.f32_to_bf16_bits(vb), kc, vc, [table[p // bs] * bs + p % bs for p in range(S)], False)
+    dec = O.paged_attention_decode(qb, kc, vc, np.asarray([table], np.uint32), [S], 0.2, False, sliding_window=window)[0]
+    ref = O.prefill_attention(qb, kb, vb, 0.2, cached=S - 1, sliding_window=window)[0]
+    assert np.array_equal(dec, ref)
+
+
 # ----------------------------------------------------------------------------------------------- whole models
 def _hf_state(W, cfg, bias, norm_bias):
     sd = {"model.embed_tokens.weight": W["tok_embd"], "model.norm.weight": W["output_norm"], "lm_head.weight": W["output"]}

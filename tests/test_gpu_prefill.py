@@ -179,3 +179,48 @@ def test_prefill_lds_dma_kernel(cv, H, Hkv, bs):
     assert np.abs(got - base).max() <= 2 ** -7 * max(1.0, np.abs(base).max())        # one bf16 ulp of the largest output
     assert np.abs(soft - soft_base).max() <= 2 ** -7 * max(1.0, np.abs(soft_base).max())
 
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("flash", [True, False])
+@pytest.mark.parametrize("H,Hkv,D,bs,window", [(8, 2, 128, 64, 100), (4, 4, 64, 16, 7), (4, 2, 80, 16, 33), (8, 2, 128, 16, 4096)])
+def test_sliding_window_prompt_and_decode(cv, dt, flash, H, Hkv, D, bs, window):
+    """`sliding_window` of PagedAttention::new (attention.rs:566-575,888-897): prompt steps with cached prefixes, without a cache, and the
+    decode step, against the oracle's windowed attention (anchored to transformers' sliding-window mask in test_cpu_third_party.py).
+    The generic kernels keep f32 softmax: same bound as the other prompt tests.  A window larger than every context = no window."""
+    rng = np.random.default_rng(D + bs + window + int(flash))
+    lens, cached = [70, 3, 129], [50, 0, 200]
+    q, k_all, v_all, kc, vc, meta = make_case(rng, lens, cached, H, Hkv, D, bs, dt, flash)
+    scale = 1.0 / np.sqrt(D)
+    pa = cv.PagedAttention(H, D, scale, Hkv, sliding_window=window)
+    im = cv.InputMetadata.from_oracle_meta(meta, "cuda", is_prefill=True)
+    kcd = torch.from_numpy(kc.view(np.int16)).cuda().view(TD[dt])
+    vcd = torch.from_numpy(vc.view(np.int16)).cuda().view(TD[dt])
+    got = host16(pa.prefill(dev16(np.concatenate(q), dt), None, None, kcd, vcd, im), dt)
+    assert np.isfinite(got).all()
+    o = 0
+    for i, l in enumerate(lens):
+        ref = O.prefill_attention(q[i], k_all[i], v_all[i], scale, cached=cached[i], rnd=lambda a: G.round_dt(a, dt), sliding_window=window)
+        assert np.abs(got[o:o + l] - ref).max() <= TOL[dt] * max(1.0, np.abs(ref).max()), f"seq {i}"
+        if window < cached[i] + l:                                 # the window really cuts keys off: differs from plain causal attention
+            full = O.prefill_attention(q[i], k_all[i], v_all[i], scale, cached=cached[i], rnd=lambda a: G.round_dt(a, dt))
+            assert np.abs(full - ref).max() > 1e-3
+        o += l
+    # no cache: the chunk's own keys
+    q2, k2, v2, _, _, meta2 = make_case(rng, [90, 5], [0, 0], H, Hkv, D, bs, dt, True)
+    im2 = cv.InputMetadata.from_oracle_meta(meta2, "cuda", is_prefill=True)
+    got2 = host16(pa.prefill(dev16(np.concatenate(q2), dt), dev16(np.concatenate(k2), dt), dev16(np.concatenate(v2), dt), None, None, im2), dt)
+    o = 0
+    for i, l in enumerate([90, 5]):
+        ref = O.prefill_attention(q2[i], k2[i], v2[i], scale, rnd=lambda a: G.round_dt(a, dt), sliding_window=window)
+        assert np.abs(got2[o:o + l] - ref).max() <= TOL[dt] * max(1.0, np.abs(ref).max()), f"fresh seq {i}"
+        o += l
+    # decode: one query per sequence over its whole cached context
+    ctx = [c + l for c, l in zip(cached, lens)]
+    seqs = [{"tokens": list(range(ctx[i])), "block_table": meta["block_tables"][i][: -(-ctx[i] // bs)].tolist()} for i in range(len(lens))]
+    dm = cv.InputMetadata.from_oracle_meta(O.prepare_decode(seqs, bs), "cuda")
+    qd = np.stack([q[i][-1] for i in range(len(lens))])
+    dec = host16(pa.decode(dev16(qd, dt), kcd, vcd, dm), dt)
+    for i in range(len(lens)):
+        ref = O.prefill_attention(q[i][-1:], k_all[i], v_all[i], scale, cached=ctx[i] - 1, rnd=lambda a: G.round_dt(a, dt), sliding_window=window)[0]
+        assert np.abs(dec[i] - ref).max() <= TOL[dt] * max(1.0, np.abs(ref).max()), f"decode seq {i}"

@@ -201,8 +201,8 @@ def test_gguf_tp2_two_ranks_on_one_gpu_equal_the_unsharded_model(lib, moe, p2p, 
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
 
 
-def _dense_case(gptq):
-    cfg = DL.DenseConfig(hidden=512, n_layers=2, n_heads=8, n_kv_heads=2, head_dim=64, intermediate=1024, vocab=512,
+def _dense_case(gptq, vocab=512):
+    cfg = DL.DenseConfig(hidden=512, n_layers=2, n_heads=8, n_kv_heads=2, head_dim=64, intermediate=1024, vocab=vocab,
                          rope_theta=10000.0, max_seq=256, block_size=16, qkv_bias=True)
     W = DL.make_weights(cfg, seed=31)
     if gptq:
@@ -213,13 +213,13 @@ def _dense_case(gptq):
     return cfg, W, seqs
 
 
-def _dense_worker(rank, world, port, q, gptq):
+def _dense_worker(rank, world, port, q, gptq, vocab=512):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from candle_vllm_amd import dense_model as M, tp
-    cfg, W, seqs = _dense_case(gptq)
+    cfg, W, seqs = _dense_case(gptq, vocab)
     comm = tp.TorchDistComm()
     gm = M.DenseLlama(tp.shard_dense_config(cfg, rank, world), max_batch=4, kv_layout=M.KV_PAGED, tp_rank=rank, tp_world=world)
     gm.load_oracle_weights(tp.shard_dense_weights(W, cfg, rank, world))
@@ -229,20 +229,34 @@ def _dense_worker(rank, world, port, q, gptq):
     for s, row in zip(seqs, pre):
         s["tokens"].append(int(row.argmax()))
     dec = gm.forward(O.prepare_decode(seqs, cfg.block_size)).cpu().numpy()
-    q.put((rank, pre, dec))
+    # the C++ greedy loop (argmax over the gathered row NARROWED to the real vocabulary), 2 steps, eager under host collectives
+    for s, row in zip(seqs, dec):
+        s["tokens"].append(int(row.argmax()))
+    maxb = max(len(s["block_table"]) for s in seqs)
+    bt = np.zeros((len(seqs), maxb), np.uint32)
+    for i, s in enumerate(seqs):
+        bt[i, :len(s["block_table"])] = s["block_table"]
+    gm.decode_begin([s["tokens"][-1] for s in seqs], [len(s["tokens"]) for s in seqs], bt, ctx_cap=max(len(s["tokens"]) for s in seqs) + 3)
+    toks = []
+    for _ in range(2):
+        gm.decode_step(0)
+        toks.append(gm.read_tokens(0).tolist())
+    q.put((rank, pre, dec, toks, gm.loop_logits().cpu().numpy()))
     dist.barrier()
     comm.close()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("gptq", [False, True])
-def test_dense_tp2_two_ranks_on_one_gpu(lib, gptq):
+@pytest.mark.parametrize("gptq,vocab", [(False, 512), (True, 512), (False, 500)])
+def test_dense_tp2_two_ranks_on_one_gpu(lib, gptq, vocab):
     """16-bit / GPTQ host path (BASELINE config 4 is Qwen2 GPTQ at TP=2): the 2-rank device run must agree with the
     unsharded oracle to 16-bit accumulation noise and pick the same tokens (the row-parallel partial products are rounded
-    per rank before the sum, so TP=2 is not bit-identical to TP=1 -- tests/test_cpu_tp.py shows the same for the oracle)."""
+    per rank before the sum, so TP=2 is not bit-identical to TP=1 -- tests/test_cpu_tp.py shows the same for the oracle).
+    vocab = 500: a vocabulary `pad_vocab_size` pads to 512 -- rank 1's lm_head shard ends in 12 zero rows, logits rows and the greedy loop's
+    argmax are narrowed to 500 columns (mi355_dense_config.vocab_total; VocabParallelLinear, distributed.rs:1657-1663)."""
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a visible MI355X")
-    cfg, W, seqs = _dense_case(gptq)
+    cfg, W, seqs = _dense_case(gptq, vocab)
     orc = DL.OracleDenseLlama(cfg, W, flash_layout=False)
     cache = orc.new_cache(8)
     pre = orc.forward(O.prepare_prompt(seqs, cfg.block_size), cache, is_prefill=True)
@@ -252,7 +266,7 @@ def test_dense_tp2_two_ranks_on_one_gpu(lib, gptq):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dense_worker, args=(r, 2, port, q, gptq)) for r in range(2)]
+    procs = [ctx.Process(target=_dense_worker, args=(r, 2, port, q, gptq, vocab)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}
@@ -263,12 +277,16 @@ def test_dense_tp2_two_ranks_on_one_gpu(lib, gptq):
         p.join(timeout=120)
         assert p.exitcode == 0
     for rank in (0, 1):
-        got_pre, got_dec = res[rank]
-        assert got_pre.shape == pre.shape and got_dec.shape == dec.shape
+        got_pre, got_dec, toks, loop_lg = res[rank]
+        assert got_pre.shape == pre.shape and got_dec.shape == dec.shape and pre.shape[-1] == vocab
         assert np.abs(got_pre - pre).max() < 3e-2 * np.abs(pre).max()
         assert np.abs(got_dec - dec).max() < 3e-2 * np.abs(dec).max()
         assert (got_pre.argmax(-1) == pre.argmax(-1)).all()
-    assert np.array_equal(res[0][0], res[1][0])
+        assert loop_lg.shape[-1] * 0 == 0 and loop_lg.size == len(seqs) * vocab
+        assert all(0 <= t < vocab for step in toks for t in step), toks
+        # the loop's last logits row is the device's own argmax input: its token is the row's first maximum over the REAL vocabulary
+        assert toks[-1] == [int(r.argmax()) for r in loop_lg.reshape(len(seqs), vocab)]
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][2] == res[1][2]
 
 
 def _unaligned_case():
