@@ -69,6 +69,49 @@ def parse():
     return ap.parse_args()
 
 
+def host_cpus():
+    """what the host offers this process: sockets / physical cores / hardware threads from /proc/cpuinfo, the scheduler affinity, and the
+    cgroup CPU quota (v2 cpu.max, v1 cfs_quota) -- a quota below the visible thread count is what keeps an OpenMP baseline from scaling"""
+    d = {"hw_threads": os.cpu_count()}
+    try:
+        d["affinity"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    try:
+        phys, cores = set(), set()
+        pid = cid = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                pid = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                cid = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if pid is not None:
+                    phys.add(pid)
+                    cores.add((pid, cid))
+                pid = cid = None
+        d["sockets"], d["physical_cores"] = len(phys) or None, len(cores) or None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                d["model"] = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = "unlimited" if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = "unlimited" if q < 0 else round(q / per, 2)
+        except (OSError, ValueError):
+            pass
+    d["cgroup_cpu_quota"] = quota
+    return d
+
+
 def cpu_baseline(cfg, steps=8, ctx=4096):
     """C port of the reference's CPU arithmetic (Q8_K activations, integer dots in AVX-512 VNNI / AVX2, OpenMP over rows and
     attention heads) on the host cores: `steps` greedy decode steps of the same model at the SAME context as the GPU run
@@ -113,13 +156,17 @@ def cpu_baseline(cfg, steps=8, ctx=4096):
             break
     nbest = min(trial, key=trial.get)
     L.orc_set_num_threads(nbest)
+    ph = (ctypes.c_double * 3)()
+    L.orc_llama_phase_times(ph, 1)
     times = [one_step() for _ in range(steps)]
+    L.orc_llama_phase_times(ph, 1)
     mean = float(np.mean(times))
-    try:
-        phys = len({tuple(l.split(":")[1].split()) for l in open("/proc/cpuinfo") if l.startswith("core id") or l.startswith("physical id")})
-    except OSError:
-        phys = 0
     return {"value": round(1.0 / mean, 4), "unit": "tokens/s", "cores": nbest, "kind": "port",
+            "host": host_cpus(),
+            "phase_seconds_per_step": {"quantised_matvecs": round(ph[0] / steps, 4), "attention": round(ph[1] / steps, 4),
+                                       "norms_rope_residuals": round(ph[2] / steps, 4),
+                                       "outside_the_C_step (numpy argmax, ctypes)": round(mean - (ph[0] + ph[1] + ph[2]) / steps, 4)},
+            "thread_scaling_s_per_step": {str(k): round(v, 4) for k, v in sorted(trial.items())},
             "ctx": ctx, "steps": steps, "isa": L.orc_isa().decode(), "host_threads": nmax, "best_step_tok_s": round(1.0 / min(times), 4),
             "sample": f"{steps} greedy decode steps, batch 1, ctx {ctx} (the GPU run's workload), full {cfg.n_layers}-layer Q4_K_M model; "
                       f"candle-CPU-style Q8_K integer dots (oracle/oracle.c, OpenMP, passive wait); mean step at the best of the "
@@ -460,6 +507,14 @@ def main():
                 out["prefill"] = bench_prefill(gm, cfg, perm, blocks_per_seq)
             except Exception as e:                            # secondary number only
                 out["prefill"] = {"error": repr(e)}
+            # BASELINE's metric is "decode tokens/s @ batch=1,32 ...; achieved HBM GB/s vs peak": `value` is the batch-1 number, the
+            # batch-32 number and the prompt-step number ride in `config` so that a record which keeps only the contract keys holds them
+            out["config"]["batch32_tokens_per_s"] = out["batch32"]["value"]
+            out["config"]["batch32_frac_of_8TBs"] = round(out["batch32"]["achieved_GBs"] / HBM_PEAK_GBS, 4)
+            out["config"]["batch1_frac_of_8TBs"] = out["step"]["frac_of_8TBs"]
+            if "value" in out["prefill"]:
+                out["config"]["prompt_2048_tokens_per_s"] = out["prefill"]["value"]
+                out["config"]["prompt_2048_frac_of_dense_f16_peak"] = out["prefill"]["frac_of_2.5PF_dense_f16"]
         if args.legs != "none" and world == 1 and not args.layers and B == 1:
             import gc
             del gm                                            # the legs build their own models

@@ -269,6 +269,8 @@ _sig("mi355_dense_kv_ptr", c_vp, [c_vp, c_i32, c_i32])
 _sig("mi355_dense_set_layer_window", ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp])
 _sig("mi355_dense_forward", ctypes.c_int, [c_vp] * 7 + [c_i32] * 5 + [c_vp, c_i64])
 _sig("mi355_llama_set_attention_numerics", ctypes.c_int, [c_vp, c_i32])
+_sig("mi355_internal_qmm_set_exact", None, [c_i32])
+_sig("mi355_internal_qmm_get_exact", c_i32, [])
 _sig("mi355_paged_attention_reference_numerics", ctypes.c_int, [c_vp] * 6 + [c_i32] * 7 + [c_f32, c_i32, c_i64])
 _sig("mi355_dense_finalize", ctypes.c_int, [c_vp])
 _sig("mi355_dense_set_graph", ctypes.c_int, [c_vp, c_i32])

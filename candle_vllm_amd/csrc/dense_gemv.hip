@@ -735,6 +735,7 @@ static int g_tune_small_nw = 0;        // tuning key 30: waves per workgroup (0 
 static int g_tune_small_nw_big = 0;    // tuning key 35: the same for K > 8192
 static int g_tune_gemm_tall = 0;       // tuning key 30 bit 32 (round 4; measured SLOWER, stays off: bf16 prompt step of Llama-3-8B 53.7 k -> 51.5 k tok/s): the 256-token tile of the 16-bit prompt GEMM where it fills the chip twice
 static int g_tune_small_off = 0;       // tuning key 31: 1 = keep 1..4 tokens on dense_kernel (A/B measurements)
+static int g_tune_gptq_wide_off = 0;   // tuning key 30 bit 128: 1 = 5..64-token launches of tiled 4-bit weights stay on dense_kernel (A/B; round 5)
 static int g_tune_small_norope = 0;    // tuning key 34: 1 = RoPE and the cache write stay in their own launch
 static int g_tune_small_nonorm = 0;    // tuning key 32: 1 = never norm on the way in (the host layer launches the norm separately)
 // tuning key 30 (product): bit mask of folded launches switched OFF -- 1 = the 1..4-token 4-bit kernel, 2 = no norm on the way in,
@@ -746,6 +747,7 @@ void mi355_dense_set_small(int key, int v) {
     if (key == 30) {
         g_tune_small_off = v & 1; g_tune_small_nonorm = (v >> 1) & 1; g_tune_small_norope = (v >> 2) & 1;
         g_tune_wide_off = (v >> 3) & 1; g_tune_gptq_gemm_off = (v >> 4) & 1; g_tune_gemm_tall = (v >> 5) & 3;
+        g_tune_gptq_wide_off = (v >> 7) & 1;
     }
     else if (key == 33) g_tune_small_nw = v;
     else if (key == 35) g_tune_small_nw_big = v;
@@ -845,6 +847,7 @@ static int dense_small3_launch(const DenseArgs (&a)[3], const DenseRope* rp, hip
     }
 }
 
+#include "gptq_wide.inc"   // 5..64 tokens x tiled 4-bit weights: LDS-shared activations, split-K for few-tile launches
 template <int DT, int WTYPE>
 static int dense_launch_dt(const DenseArgs& a, hipStream_t st) {
     if (a.T < 1 || a.T > 64 || (a.N & 15) || (a.K & 255)) return -2;
@@ -855,6 +858,10 @@ static int dense_launch_dt(const DenseArgs& a, hipStream_t st) {
     }
     const bool pair = a.epi == MI355_EPI_SILU_MUL;
     const int mt = (a.T + 15) / 16;
+    if constexpr (WTYPE == DW_GPTQ4T) {
+        const int rw = gptq_wide_launch<DT>(a, st);
+        if (rw != -4) return rw;
+    }
     if constexpr (WTYPE == DW_DENSE) {
         // enough row tiles for one tile (or gate/up pair) per wave on every CU: the LDS-shared-activation sweep
         const int wtiles = (pair ? a.pair_offset : a.N) / 16;

@@ -916,12 +916,14 @@ static int record_step(Model* m, int64_t stream) {
 
 /* PARITY MODE switch (tests): 0 = the product attention kernels (f32 scores and probabilities), 1 = decode attention with the
  * reference CPU path's bf16 rounding points (models/mod.rs:1288-1306) -- slow; fp8 caches and prompt steps keep their kernels. */
+extern "C" void mi355_internal_qmm_set_exact(int32_t on);             // qmatmul.hip (qmm_exact.inc): process-wide, tests only
 extern "C" int mi355_llama_set_attention_numerics(void* mp, int32_t mode) {
     Model* m = static_cast<Model*>(mp);
-    if (!m || mode < 0 || mode > 1) return (int)hipErrorInvalidValue;
-    if (mode == 1 && m->cfg.kv_layout == MI355_KV_PAGED_FP8) return (int)hipErrorNotSupported;
+    if (!m || mode < 0 || mode > 2) return (int)hipErrorInvalidValue;
+    if (mode >= 1 && m->cfg.kv_layout == MI355_KV_PAGED_FP8) return (int)hipErrorNotSupported;
     drop_graph(m);
-    m->attn_numerics = mode;
+    m->attn_numerics = mode >= 1 ? 1 : 0;
+    mi355_internal_qmm_set_exact(mode == 2 ? 1 : 0);                  // 2: + every mat-vec of the step exact to f32 rounding
     return 0;
 }
 

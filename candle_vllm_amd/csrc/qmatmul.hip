@@ -778,6 +778,7 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po =
 
 template <int BT, int R, int WT, int XB, int NRM>
 __global__ void __launch_bounds__(512) qmm_kernel(const QmmArgs a) { qmm_body<BT, R, WT, XB, NRM>(a); }
+#include "qmm_exact.inc"   // parity mode (tests only): exact single-token mat-vecs behind the same fused epilogue
 #ifdef MI355_QMM_PROBES   // probe builds only (tools/build_probe_lib.sh): the Q8_K-activation experiment (round 2)
 #include "probes/qmm_q8.inc"
 #endif
@@ -2113,6 +2114,42 @@ static int q8_0_launch(const QmmArgs& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+// ---- parity mode 2 (tests only; kernel in qmm_exact.inc): switch + launcher
+static int g_qmm_exact = 0;
+extern "C" void mi355_internal_qmm_set_exact(int32_t on) {
+    g_qmm_exact = on ? 1 : 0;
+    // an exact launch stages no activation image for its successor: forget every chain hint, in both directions of the switch
+    std::lock_guard<std::mutex> lk(g_qmg_mu);
+    for (auto& kv : g_qmg_streams) kv.second.chain.valid = false;
+}
+extern "C" int32_t mi355_internal_qmm_get_exact(void) { return g_qmm_exact; }
+
+// one launch per token
+static int qmm_exact_launch(QmmArgs a, hipStream_t st) {
+    const int B = a.B;
+    const size_t xes = (a.x_dtype == MI355_DTYPE_BF16) ? 2 : 4;
+    const uint8_t* x0 = static_cast<const uint8_t*>(a.x);
+    float* out0 = a.out;
+    const float* resid0 = a.resid;
+    uint16_t* q0 = a.q_out;
+    const int64_t* pos0 = a.positions;
+    const int64_t* slot0 = a.slot_mapping;
+    int total_tiles = 0;
+    for (int s = 0; s < a.nseg; ++s) total_tiles += a.seg[s].n_tiles;
+    for (int b = 0; b < B; ++b) {
+        a.B = 1;
+        a.x = x0 + (size_t)b * a.ldx * xes;
+        a.out = out0 ? out0 + (size_t)b * a.ldo : nullptr;
+        a.resid = resid0 ? resid0 + (size_t)b * a.ldo : nullptr;
+        a.q_out = q0 ? q0 + (size_t)b * a.Hq * a.D : nullptr;
+        a.positions = pos0 ? pos0 + b : nullptr;
+        a.slot_mapping = slot0 ? slot0 + b : nullptr;
+        if (a.paired) hipLaunchKernelGGL((qmm_exact_kernel<2>), dim3(a.seg[0].n_tiles), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((qmm_exact_kernel<1>), dim3(total_tiles), dim3(256), 0, st, a);
+    }
+    return (int)hipGetLastError();
+}
+
 int mi355_qmm_launch(QmmArgs a, int64_t stream) {
     if (a.nseg >= 1 && a.seg[0].type == MI355_GGML_Q8_0) return q8_0_launch(a, to_stream(stream));
     if (a.K <= 0 || (a.K % 256) || a.B < 0 || a.nseg < 1 || a.nseg > 3) return (int)hipErrorInvalidValue;
@@ -2120,6 +2157,7 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
     for (int s = 0; s < a.nseg; ++s)
         if (a.seg[s].type != MI355_GGML_Q4_K && a.seg[s].type != MI355_GGML_Q6_K) return (int)hipErrorInvalidValue;
     if (a.paired && (a.nseg != 2 || a.seg[0].n_tiles != a.seg[1].n_tiles)) return (int)hipErrorInvalidValue;
+    if (g_qmm_exact && !a.moe_expert && !a.rows_dev) return qmm_exact_launch(a, to_stream(stream));   // parity mode 2 (tests only)
     int total_tiles = 0;
     bool div4 = true, div2 = true;
     for (int s = 0; s < a.nseg; ++s) {

@@ -500,8 +500,14 @@ int mi355_llama_decode_begin(void* model, const uint32_t* tokens_host, const uin
  * communicator is device-native (RCCL on its side stream joins the capture as a fork / join, the one-shot peer kernel is a
  * plain node); with host-supplied collectives (mi355_comm_create_external) they stay eager. */
 int mi355_llama_set_graph(void* model, int32_t enable);
-/* parity mode of the decode attention: 0 = product kernels, 1 = mi355_paged_attention_reference_numerics (tests only) */
+/* parity mode of the decode steps (tests only): 0 = product kernels, 1 = decode attention through
+ * mi355_paged_attention_reference_numerics, 2 = that AND every quantised mat-vec of the step exact to f32 rounding (weights dequantised
+ * as the oracle's O1, f64 sums, the product's own fused epilogues; csrc/qmm_exact.inc -- the switch behind it is process-wide:
+ * mi355_internal_qmm_set_exact).  Mode 2 exists to show that the end-to-end distance to the oracle is amplified per-product rounding
+ * noise: with it the distance falls to the oracle's own f64-vs-f32-sum self-spread. */
 int mi355_llama_set_attention_numerics(void* model, int32_t mode);
+void mi355_internal_qmm_set_exact(int32_t on);
+int32_t mi355_internal_qmm_get_exact(void);
 int mi355_llama_decode_step(void* model, int64_t stream);
 int mi355_llama_decode_read_tokens(void* model, uint32_t* host_out, int64_t stream);
 float* mi355_llama_logits_ptr(void* model);

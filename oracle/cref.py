@@ -53,6 +53,7 @@ def lib():
         L.orc_bf16_gemv.argtypes = [vp, i32, i32, vp, vp]
         L.orc_num_threads.restype = i32
         L.orc_set_num_threads.argtypes = [i32]
+        L.orc_llama_phase_times.argtypes = [vp, i32]
         _lib = L
     return _lib
 

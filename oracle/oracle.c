@@ -662,6 +662,16 @@ int orc_llama_fill_random(void* mp, const int32_t* types, uint64_t seed) {
     return 0;
 }
 
+/* where a decode step spends its wall time (seconds, accumulated over calls): [0] quantised mat-vecs, [1] attention, [2] the rest
+ * (norms, RoPE, cache write, residuals, SiLU) -- bench.py's cpu_baseline reports them (is the host baseline bound by a
+ * serial section or by a CPU quota?) */
+static double g_phase[3];
+static double orc_now(void) { return omp_get_wtime(); }
+void orc_llama_phase_times(double* out3, int reset) {
+    for (int i = 0; i < 3; ++i) { out3[i] = g_phase[i]; if (reset) g_phase[i] = 0; }
+}
+#define ORC_MM(...) do { const double t_ = orc_now(); orc_qmatmul(__VA_ARGS__); g_phase[0] += orc_now() - t_; } while (0)
+
 /* One decode step (flash KV layout [NB, bs, Hkv, D], bf16 bit patterns).  logits f32 [B, vocab]. */
 void orc_llama_decode(void* mp, const uint32_t* tokens, const int64_t* positions, const int64_t* slots,
                       const uint32_t* bt, const uint32_t* ctx, int B, int max_blocks, uint16_t** kcache,
@@ -684,13 +694,14 @@ void orc_llama_decode(void* mp, const uint32_t* tokens, const int64_t* positions
             xs[(size_t)b * hid + i] = m->tok_embd ? m->tok_embd[(size_t)tokens[b] * hid + i]
                                                   : 0.02f * sinf((float)(tokens[b] % 977) * 0.37f + (float)i * 0.011f);
     const float scale = 1.0f / sqrtf((float)D);
+    const double t_step = orc_now(), mm0 = g_phase[0], at0 = g_phase[1];
     for (int l = 0; l < c->n_layers; ++l) {
         const orc_qw* W = m->lw + (size_t)l * 7;
         if (m->trace) memcpy(m->trace + (size_t)l * B * hid, xs, (size_t)B * hid * 4);
         orc_rms_norm(xs, m->norms[(size_t)l * 2], c->rms_eps, B, hid, xn);
-        orc_qmatmul(W[0].w, W[0].type, W[0].n, W[0].k, xn, B, q, o2);
-        orc_qmatmul(W[1].w, W[1].type, W[1].n, W[1].k, xn, B, k, o2);
-        orc_qmatmul(W[2].w, W[2].type, W[2].n, W[2].k, xn, B, v, o2);
+        ORC_MM(W[0].w, W[0].type, W[0].n, W[0].k, xn, B, q, o2);
+        ORC_MM(W[1].w, W[1].type, W[1].n, W[1].k, xn, B, k, o2);
+        ORC_MM(W[2].w, W[2].type, W[2].n, W[2].k, xn, B, v, o2);
         orc_rope_i(q, m->cosT, m->sinT, positions, B, H, D);
         orc_rope_i(k, m->cosT, m->sinT, positions, B, Hkv, D);
         for (int b = 0; b < B; ++b) {                      /* cast to bf16 + cache write (attention.rs:977-995) */
@@ -700,6 +711,7 @@ void orc_llama_decode(void* mp, const uint32_t* tokens, const int64_t* positions
                 vcache[l][(size_t)slots[b] * Hkv * D + i] = f32_to_bf16(v[(size_t)b * Hkv * D + i]);
             }
         }
+        const double t_att = orc_now();
 #pragma omp parallel for collapse(2) schedule(static)
         for (int b = 0; b < B; ++b)
             for (int h = 0; h < H; ++h) {
@@ -712,6 +724,23 @@ void orc_llama_decode(void* mp, const uint32_t* tokens, const int64_t* positions
                     const size_t blk = bt[(size_t)b * max_blocks + t / bs];
                     const uint16_t* kr = kcache[l] + ((blk * bs + t % bs) * Hkv + hk) * D;
                     float s = 0;
+#if defined(__AVX2__) && defined(__FMA__)
+                    if (!g_attn_bf16 && (D & 7) == 0) {
+                        /* f32-attention mode (the parity target O1 and the timed cpu_baseline): eight partial sums -- a CPU backend's
+                         * matmul does not walk a 128-element dot through one dependent FMA chain (that chain alone was 60 % of the
+                         * baseline's step at ctx 4096).  The bf16-attention mode below keeps the index order that the GPU's
+                         * parity-mode kernel mirrors bit for bit. */
+                        __m256 acc = _mm256_setzero_ps();
+                        for (int d = 0; d < D; d += 8) {
+                            const __m256i kb = _mm256_slli_epi32(_mm256_cvtepu16_epi32(_mm_loadu_si128((const __m128i*)(kr + d))), 16);
+                            acc = _mm256_fmadd_ps(_mm256_loadu_ps(qb + d), _mm256_castsi256_ps(kb), acc);
+                        }
+                        __m128 r4 = _mm_add_ps(_mm256_castps256_ps128(acc), _mm256_extractf128_ps(acc, 1));
+                        r4 = _mm_add_ps(r4, _mm_movehl_ps(r4, r4));
+                        r4 = _mm_add_ss(r4, _mm_shuffle_ps(r4, r4, 1));
+                        s = _mm_cvtss_f32(r4);
+                    } else
+#endif
                     for (int d = 0; d < D; ++d) s += qb[d] * bf16_to_f32(kr[d]);
                     sc[t] = g_attn_bf16 ? round_bf16(round_bf16(s) * scale) : s * scale;
                     if (sc[t] > mx) mx = sc[t];
@@ -730,22 +759,24 @@ void orc_llama_decode(void* mp, const uint32_t* tokens, const int64_t* positions
                 for (int d = 0; d < D; ++d) o[d] = round_bf16(o[d]);
                 free(sc);
             }
+        g_phase[1] += orc_now() - t_att;
         if (m->tr_q) for (size_t i = 0; i < (size_t)B * H * D; ++i) m->tr_q[(size_t)l * B * H * D + i] = round_bf16(q[i]);
         if (m->tr_att) memcpy(m->tr_att + (size_t)l * B * H * D, att, (size_t)B * H * D * 4);
-        orc_qmatmul(W[3].w, W[3].type, W[3].n, W[3].k, att, B, tmp, o2);
+        ORC_MM(W[3].w, W[3].type, W[3].n, W[3].k, att, B, tmp, o2);
         for (size_t i = 0; i < (size_t)B * hid; ++i) xs[i] += tmp[i];
         if (m->tr_mid) memcpy(m->tr_mid + (size_t)l * B * hid, xs, (size_t)B * hid * 4);
         orc_rms_norm(xs, m->norms[(size_t)l * 2 + 1], c->rms_eps, B, hid, xn);
-        orc_qmatmul(W[4].w, W[4].type, W[4].n, W[4].k, xn, B, g, o2);
-        orc_qmatmul(W[6].w, W[6].type, W[6].n, W[6].k, xn, B, u, o2);
+        ORC_MM(W[4].w, W[4].type, W[4].n, W[4].k, xn, B, g, o2);
+        ORC_MM(W[6].w, W[6].type, W[6].n, W[6].k, xn, B, u, o2);
         for (size_t i = 0; i < (size_t)B * I; ++i) g[i] = g[i] / (1.f + expf(-g[i])) * u[i];
         if (m->tr_h) memcpy(m->tr_h + (size_t)l * B * I, g, (size_t)B * I * 4);
-        orc_qmatmul(W[5].w, W[5].type, W[5].n, W[5].k, g, B, tmp, o2);
+        ORC_MM(W[5].w, W[5].type, W[5].n, W[5].k, g, B, tmp, o2);
         for (size_t i = 0; i < (size_t)B * hid; ++i) xs[i] += tmp[i];
     }
     if (m->trace) memcpy(m->trace + (size_t)c->n_layers * B * hid, xs, (size_t)B * hid * 4);
     orc_rms_norm(xs, m->out_norm, c->rms_eps, B, hid, xn);
-    orc_qmatmul(m->out.w, m->out.type, m->out.n, m->out.k, xn, B, logits, o2);
+    ORC_MM(m->out.w, m->out.type, m->out.n, m->out.k, xn, B, logits, o2);
+    g_phase[2] += (orc_now() - t_step) - (g_phase[0] - mm0) - (g_phase[1] - at0);
     free(xs); free(xn); free(q); free(k); free(v); free(att); free(g); free(u); free(tmp);
 }
 

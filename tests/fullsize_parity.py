@@ -170,7 +170,7 @@ class Pair:
                 "reference_bf16_attention_spread": spread,
                 "oracle": "O1 (unpinned)" if int(o2) == 0 else "O1f (unpinned)", "oracle_s_per_step": round(t_orc / (step + 1), 2)}
 
-    def run_decode_faithful(self, seq_lens, steps=2, o2=0, graph=True):
+    def run_decode_faithful(self, seq_lens, steps=2, o2=0, graph=True, exact=False):
         """north_star's comparison itself: "within 1e-3 of the reference CPU logits".  The reference's CPU path rounds the attention
         scores, the scaled scores, the probabilities and P.V to bf16 (NaiveAttention::forward on bf16 tensors, models/mod.rs:1288-1306);
         through 32 layers those points alone move the logits by 1.7-3 % (run_decode's `reference_bf16_attention_spread`), so the
@@ -178,7 +178,9 @@ class Pair:
         rounds elsewhere.  Here BOTH sides take the reference's points: the GPU model in parity mode
         (mi355_llama_set_attention_numerics(1): mi355_paged_attention_reference_numerics, same summation orders as the oracle) against
         oracle.c's bf16-attention mode -- every other kernel of the step (quantised mat-muls, RMSNorm, RoPE, cache write, residuals,
-        lm_head, argmax) is the product's.  Returns the worst logit error relative to the row's largest logit."""
+        lm_head, argmax) is the product's.  Returns the worst logit error relative to the row's largest logit.
+        exact=True (parity mode 2, csrc/qmm_exact.inc): the step's mat-vecs exact to f32 rounding as well -- the run that shows
+        whether the product's distance is amplified per-product rounding noise (it then falls to the oracle's self-spread) or a bias."""
         cfg, gm, rng = self.cfg, self.gm, self.rng
         B, bs = len(seq_lens), cfg.block_size
         self._next = 0
@@ -190,7 +192,7 @@ class Pair:
         for i, s in enumerate(seqs):
             bt[i, : len(s["block_table"])] = s["block_table"]
         st = self.stream.cuda_stream
-        gm.set_attention_numerics(1)
+        gm.set_attention_numerics(2 if exact else 1)
         cref.lib().orc_llama_set_attn_bf16(1)
         try:
             gm.set_graph(bool(graph))
@@ -237,7 +239,7 @@ class Pair:
         return {"batch": B, "steps_compared": done, "ctx_max": int(max(seq_lens)), "graph": bool(graph), "max_rel_err": worst,
                 "per_step": [round(x, 7) for x in per_step], "tokens_equal": bool(equal), "near_tie_tokens": ties,
                 "oracle_self_spread_f64_vs_f32_dots": self_spread,
-                "mode": "reference-faithful attention numerics on both sides (models/mod.rs:1288-1306)",
+                "mode": "reference-faithful attention numerics on both sides (models/mod.rs:1288-1306)" + (" + exact mat-vecs (qmm_exact.inc)" if exact else ""),
                 "oracle": "O1 + bf16 attention tensors (unpinned)" if int(o2) == 0 else "O1f + bf16 attention tensors (unpinned)"}
 
     # ------------------------------------------------------------------------------------------------ one layer at a time

@@ -404,3 +404,41 @@ def test_gptq_prompt_gemm_one_pass(cv, dt, T, N, K, gs, mode):
     with tuning(30, 16):                                          # key 30 bit 4: the one-pass 4-bit prompt GEMM off
         y0 = host16(lin.forward(dev16(x, dt), **fkw), dt)
     check_ulp(y0, ref, dt, ulps=ulps, what="decode kernel in chunks", mag=mag)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("T,N,K,gs,mode", [(32, 1184, 3584, 128, "store"), (32, 3584, 3584, 128, "resid"), (9, 224, 2048, 64, "store"),
+                                           (48, 512, 4864, 256, "bias"), (17, 2 * 4736, 1792, 128, "silu"), (32, 2 * 608, 3584, 128, "silu"),
+                                           (5, 64, 18944, 128, "resid"), (33, 4096, 256, 128, "store")])
+def test_gptq_wide_kernel_5_to_48_tokens(cv, dt, T, N, K, gs, mode):
+    """round 5 (csrc/gptq_wide.inc): 5..48 tokens over the tiled 4-bit image with the activations shared through LDS -- many-tile launches
+    in one sweep (gate/up as pairs per wave, SiLU * up from the accumulators), few-tile launches split over K with the partial sums added
+    by the epilogue launch (Qwen2-7B's wo / down shapes: 14 and 74 k-blocks), a single k-block, ragged last workgroups.  Against the oracle
+    at the bound of the 16-token-tile kernel it replaces, and against that kernel itself (tuning key 30 bit 128)."""
+    from candle_vllm_amd import tuning
+    rng = np.random.default_rng(K + N + T)
+    q, s = _gptq_case(rng, K, N, gs, dt)
+    x = G.round_dt(rng.normal(0, 1, (T, K)), dt)
+    bias = G.round_dt(rng.normal(0, 1, N), dt) if mode == "bias" else None
+    lin = cv.GPTQLinear(dev_u32(G.gptq_pack(q)), dev16(s, dt), gs, bias=None if bias is None else dev16(bias, dt))
+    assert lin.tiled
+    full = G.gptq_linear(x, G.gptq_dequant(q, s, None, gs), bias, dt)
+    kw, ulps = {}, 1.0
+    if mode == "silu":
+        ref = G.silu_mul16(full[:, :N // 2], full[:, N // 2:], dt)
+        kw, ulps = dict(epilogue=cv.EPI_SILU_MUL), 3.0
+    elif mode == "resid":
+        res = G.round_dt(rng.normal(0, 1, (T, N)), dt)
+        ref = G.round_dt(full + res, dt)
+        kw, ulps = dict(epilogue=cv.EPI_RESID, residual=dev16(res, dt)), 2.01
+    else:
+        ref = full
+        if mode == "bias":
+            ulps = 2.01
+    magkw = {"mag": full} if mode == "resid" else ({"mag": G.gptq_linear(x, G.gptq_dequant(q, s, None, gs), None, dt)} if mode == "bias" else {})
+    y = host16(lin.forward(dev16(x, dt), **kw), dt)
+    check_ulp(y, ref, dt, ulps=ulps, what="gptq wide kernel", **magkw)
+    with tuning(30, 128):                                          # key 30 bit 128: the wide kernel off
+        y0 = host16(lin.forward(dev16(x, dt), **kw), dt)
+    check_ulp(y0, ref, dt, ulps=ulps, what="16-token-tile kernel", **magkw)
+    assert np.abs(y - y0).max() <= 3 * (2.0 ** -8 if dt == "bf16" else 2.0 ** -11) * max(1.0, np.abs(ref).max())

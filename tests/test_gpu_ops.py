@@ -752,3 +752,35 @@ def test_paged_attention_reference_numerics_mode(cv, lib, flash):
     assert (got == want).mean() > 0.98, (got == want).mean()
     product = O.paged_attention_decode(O.round_bf16(q), kc, vc, bt, cl, scale, flash)
     assert (want != product).mean() > 0.05                           # the bf16 points are visible: this is a different computation
+
+
+@pytest.mark.parametrize("t", [kq.GGML_Q4_K, kq.GGML_Q6_K])
+def test_exact_parity_mode_matvecs(cv, lib, t):
+    """parity mode 2 (csrc/qmm_exact.inc; tests only): every single-token mat-vec exact to f32 rounding behind the product's own fused
+    epilogues -- the tile decoder against the oracle's dequantisation of the NATIVE blocks, plain store, fused RMSNorm + SiLU * up, and
+    residual.  Bound 3e-7 of the output scale (f64 sums rounded once to f32; the product kernels: 1e-5)."""
+    rng = np.random.default_rng(77 + t)
+    N, K = 208, 1024                                               # 13 row tiles, 4 k-blocks
+    bg = kq.quantize(rng.normal(0, 0.05, (N, K)).astype(np.float32), t)
+    bu = kq.quantize(rng.normal(0, 0.05, (N, K)).astype(np.float32), t)
+    mg, mu = cv.QMatMul(bg, t, "cuda"), cv.QMatMul(bu, t, "cuda")
+    nw = (1 + 0.1 * rng.normal(size=K)).astype(np.float32)
+    lib.mi355_internal_qmm_set_exact(1)
+    try:
+        assert lib.mi355_internal_qmm_get_exact() == 1
+        for T in (1, 3):
+            x = rng.normal(0, 1, (T, K)).astype(np.float32)
+            got = mg.forward(dev(x)).cpu().numpy()
+            assert rel_err(got, kq.qmatmul_o1(x, bg, t)) < 3e-7
+            xn = O.rms_norm(x, nw, 1e-5)
+            rg, ru = kq.qmatmul_o1(xn, bg, t).astype(np.float64), kq.qmatmul_o1(xn, bu, t).astype(np.float64)
+            h = torch.empty((T, N), dtype=torch.float32, device="cuda")
+            cv.qmatmul_fused([mg, mu], dev(x), epilogue=cv.EPI_SILU_MUL, out=h, norm_weight=dev(nw), norm_eps=1e-5)
+            assert rel_err(h.cpu().numpy(), rg / (1 + np.exp(-rg)) * ru) < 2e-6      # (the oracle's rms_norm rounds x * w / rms to f32 first)
+            resid = rng.normal(size=(T, N)).astype(np.float32)
+            o = dev(resid.copy())
+            cv.qmatmul_fused([mg], dev(x), epilogue=cv.EPI_RESID, out=o, residual=o)
+            assert rel_err(o.cpu().numpy(), resid + kq.qmatmul_o1(x, bg, t)) < 3e-7
+    finally:
+        lib.mi355_internal_qmm_set_exact(0)
+    assert rel_err(mg.forward(dev(x)).cpu().numpy(), kq.qmatmul_o1(x, bg, t)) < 1e-4   # back on the product kernels
