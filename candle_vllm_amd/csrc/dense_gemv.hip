@@ -316,16 +316,21 @@ __global__ void __launch_bounds__(512) dense3_kernel(const DenseArgs a0, const D
 // Taken when the launch has enough row tiles for that shape (gate/up, lm_head); the few-tile projections (wo, down, q/k/v) keep
 // the K-split of dense_body.
 constexpr int DWD_LDX = 264;                        // 16-bit elements per staged row: 256 + 8 pad
+//   * round 5: few-tile launches with a long K (down: 256 tiles x 56 k-blocks at Llama-3-8B) split K ACROSS workgroups (gridDim.y, two
+//     workgroups per CU) and leave f32 partial sums [split][token][row] for gptq_wide_epilogue_kernel (split order: deterministic) --
+//     on dense_body they ran at 2.7 TB/s (one k-block per wave at a time, every wave its own activations).
 template <int DT, int MT, int R, int NW>
-__global__ void __launch_bounds__(64 * NW) dense_wide_kernel(const DenseArgs a) {
+__global__ void __launch_bounds__(64 * NW) dense_wide_kernel(const DenseArgs a, float* __restrict__ part, const int ldp, const int kb_per_split) {
     extern __shared__ __attribute__((aligned(16))) uint16_t dwd_x[];          // [2][MT * 16][DWD_LDX]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, kg = lane >> 4;
-    const int nkb = a.K >> 8, T = a.T;
+    const int nkb_all = a.K >> 8, T = a.T;
+    const int kb_lo = (int)blockIdx.y * kb_per_split, nkb = min(nkb_all, kb_lo + kb_per_split) - kb_lo;   // this workgroup's K range
+    if (nkb <= 0) return;
     // every workgroup starts its sweep at a different k-block: in step, all waves of the launch would ask for the same 512-byte column
     // of rows 8 KB apart (the order of the f32 sum changes with the workgroup, not from run to run)
     const int rot = (int)((blockIdx.x * 7u) % (unsigned)nkb);
-#define DWD_KB(KB_) (((KB_) + rot) % nkb)
+#define DWD_KB(KB_) (kb_lo + ((KB_) + rot) % nkb)
     const int ntiles = (R == 2 ? a.pair_offset : a.N) >> 4;
     const int tile = min((int)blockIdx.x * NW + wave, ntiles - 1);            // a surplus wave shadows the last tile (stores skipped)
     const bool live = (int)blockIdx.x * NW + wave < ntiles;
@@ -336,7 +341,7 @@ __global__ void __launch_bounds__(64 * NW) dense_wide_kernel(const DenseArgs a) 
     const uint16_t* wrow[R];
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        wrow[r] = a.wtiled ? static_cast<const uint16_t*>(a.w) + (((size_t)(row0[r] >> 4) * nkb) * 512 + lane) * 8
+        wrow[r] = a.wtiled ? static_cast<const uint16_t*>(a.w) + (((size_t)(row0[r] >> 4) * nkb_all) * 512 + lane) * 8
                            : static_cast<const uint16_t*>(a.w) + (size_t)(row0[r] + r16) * a.ldw + 8 * kg;
     const int wkstride = a.wtiled ? 4096 : 256, wjstride = a.wtiled ? 512 : 32;      // elements per k-block / per fragment
 
@@ -408,6 +413,16 @@ __global__ void __launch_bounds__(64 * NW) dense_wide_kernel(const DenseArgs a) 
 #undef DWD_COMPUTE
 #undef DWD_KB
     if (!live) return;
+    if (part) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    part[((size_t)blockIdx.y * (MT * 16) + mt * 16 + 4 * kg + v) * ldp + row0[r] + r16] = y[r][mt][v];
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -863,23 +878,55 @@ static int dense_launch_dt(const DenseArgs& a, hipStream_t st) {
         if (rw != -4) return rw;
     }
     if constexpr (WTYPE == DW_DENSE) {
-        // enough row tiles for one tile (or gate/up pair) per wave on every CU: the LDS-shared-activation sweep
+        // enough row tiles for one tile (or gate/up pair) per wave on every CU: the LDS-shared-activation sweep.  Round 5: ALSO the few-tile
+        // launches with a long K (down: 256 tiles x 56 k-blocks at Llama-3-8B), split over K until two workgroups sit on every CU; their
+        // partial sums meet in gptq_wide_epilogue_kernel (short-K few-tile launches -- wo, q / k / v -- keep dense_kernel: a sweep of 4
+        // k-blocks plus the epilogue launch is not faster than its one launch)
         const int wtiles = (pair ? a.pair_offset : a.N) / 16;
-        if (!g_tune_wide_off && a.T > 4 && wtiles >= 4 * 192 && (!pair || mt <= 2) && !((uintptr_t)a.x & 15) && !(a.ldx & 7) &&
+        const int nkb_w = a.K >> 8;
+        const bool many = wtiles >= 4 * 192, longk = !pair && nkb_w >= 32 && mt <= 3;
+        if (!g_tune_wide_off && a.T > 4 && (many || longk) && (!pair || mt <= 2) && !((uintptr_t)a.x & 15) && !(a.ldx & 7) &&
             !((uintptr_t)a.w & 15) && (a.wtiled || !(a.ldw & 7))) {
-                    const int nwv = g_tune_wide_nw == 2 ? 2 : 4;
-            const dim3 grid((wtiles + nwv - 1) / nwv), block(64 * nwv);
+            const int nwv = many ? (g_tune_wide_nw == 2 ? 2 : 4) : 4;
+            const int gx = (wtiles + nwv - 1) / nwv;
+            int ks = 1;
+            if (!many) {
+                if (g_num_cus_dg == 0) {
+                    int dev = 0;
+                    hipDeviceProp_t prop;
+                    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus_dg = prop.multiProcessorCount;
+                    if (g_num_cus_dg <= 0) g_num_cus_dg = 256;
+                }
+                ks = (2 * g_num_cus_dg + gx - 1) / gx;
+                if (ks > nkb_w / 4) ks = nkb_w / 4;
+                if (ks < 1) ks = 1;
+            }
+            const int kps = (nkb_w + ks - 1) / ks;
+            ks = (nkb_w + kps - 1) / kps;
+            float* part = nullptr;
+            const int tpad = mt * 16, ldp = a.N;
+            if (ks > 1) {
+                void* pp = nullptr;
+                if (mi355_scratch_get(&pp, MI355_SCR_GPTQ_WIDE, (size_t)ks * tpad * ldp * sizeof(float), st, false)) return -1;
+                part = static_cast<float*>(pp);
+            }
+            const dim3 grid(gx, ks), block(64 * nwv);
             const size_t lds = (size_t)2 * mt * 16 * DWD_LDX * 2;
 #define DWD_GO2(MT_, R_, NW_) do { \
                 static bool attr = false; \
                 if (!attr) { (void)hipFuncSetAttribute((const void*)dense_wide_kernel<DT, MT_, R_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
-                hipLaunchKernelGGL((dense_wide_kernel<DT, MT_, R_, NW_>), grid, block, lds, st, a); } while (0)
+                hipLaunchKernelGGL((dense_wide_kernel<DT, MT_, R_, NW_>), grid, block, lds, st, a, part, ldp, kps); } while (0)
 #define DWD_GO(MT_, R_) do { if (nwv == 2) DWD_GO2(MT_, R_, 2); else DWD_GO2(MT_, R_, 4); } while (0)
             if (pair) { if (mt == 1) DWD_GO(1, 2); else DWD_GO(2, 2); }
             else switch (mt) { case 1: DWD_GO(1, 1); break; case 2: DWD_GO(2, 1); break; case 3: DWD_GO(3, 1); break; default: DWD_GO(4, 1); break; }
 #undef DWD_GO2
 #undef DWD_GO
-            return hipGetLastError() == hipSuccess ? 0 : -1;
+            if (hipGetLastError() != hipSuccess) return -1;
+            if (ks > 1) {
+                hipLaunchKernelGGL((gptq_wide_epilogue_kernel<DT>), dim3((a.N + 255) / 256, a.T), dim3(256), 0, st, a, part, ldp, ks, tpad);
+                if (hipGetLastError() != hipSuccess) return -1;
+            }
+            return 0;
         }
     }
     int gj = 8;

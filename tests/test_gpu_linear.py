@@ -442,3 +442,22 @@ def test_gptq_wide_kernel_5_to_48_tokens(cv, dt, T, N, K, gs, mode):
         y0 = host16(lin.forward(dev16(x, dt), **kw), dt)
     check_ulp(y0, ref, dt, ulps=ulps, what="16-token-tile kernel", **magkw)
     assert np.abs(y - y0).max() <= 3 * (2.0 ** -8 if dt == "bf16" else 2.0 ** -11) * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("T,N,K,tiled", [(32, 256, 8192, True), (20, 336, 14336, True), (48, 64, 8448, False), (9, 4096, 8192, True)])
+def test_wide_16bit_kernel_few_tiles_long_k_split(cv, dt, T, N, K, tiled):
+    """round 5: few-tile 16-bit launches with a long K (down_proj of a batch-32 step: 256 tiles x 56 k-blocks at Llama-3-8B) take the
+    LDS-shared-activation sweep split over K across workgroups; the partial sums meet in the epilogue launch (split order), which applies
+    bias / residual and the rounding chain.  Against the oracle at the bound of the kernel it replaces, bias + residual included."""
+    rng = np.random.default_rng(T + N + K)
+    x = G.round_dt(rng.normal(0, 1, (T, K)), dt)
+    w = G.round_dt(rng.normal(0, 0.02, (N, K)), dt)
+    b = G.round_dt(rng.normal(0, 0.2, N), dt)
+    res = G.round_dt(rng.normal(0, 1, (T, N)), dt)
+    lin = cv.Linear(dev16(w, dt), dev16(b, dt), tiled=tiled)
+    y = host16(lin.forward(dev16(x, dt), epilogue=cv.EPI_RESID, residual=dev16(res, dt)), dt)
+    full = G.linear16(x, w, b, dt)
+    check_ulp(y, G.round_dt(full + res, dt), dt, what="split-K wide kernel + bias + residual", ulps=3.01, mag=np.maximum(np.abs(full), np.abs(G.linear16(x, w, None, dt))))
+    y2 = host16(cv.Linear(dev16(w, dt), tiled=tiled).forward(dev16(x, dt)), dt)
+    check_ulp(y2, G.linear16(x, w, None, dt), dt, what="split-K wide kernel")
