@@ -420,10 +420,24 @@ def main():
     kv_layout = M.KV_PAGED if args.kv_layout == "paged" else M.KV_FLASH
     gm = M.GGUFLLaMa(cfg, max_batch=(B32 if do_b32 else B), max_blocks_per_seq=blocks_per_seq, kv_layout=kv_layout,
                      tp_rank=rank, tp_world=world)
-    transport = None
+    transport, comm_fallback = None, None
     if world > 1:
         mode = "p2p" if args.p2p else args.all_reduce
-        transport = gm.init_comm(dist, p2p={"auto": "auto", "rccl": False, "p2p": True}[mode], wire_bf16=args.wire_bf16)
+        try:
+            transport, ok = gm.init_comm(dist, p2p={"auto": "auto", "rccl": False, "p2p": True}[mode], wire_bf16=args.wire_bf16), 1
+        except Exception as e:                                 # e.g. librccl not loadable through dlopen on this box
+            transport, ok = repr(e), 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not int(flag.item()):
+            # last resort, on EVERY rank together: host-supplied collectives staged through the host over a gloo group (eager steps, slow)
+            # -- the run still measures the sharded model and says so, instead of leaving the scaling record empty
+            from candle_vllm_amd import tp as _tp
+            comm_fallback = _tp.TorchDistComm(dist.new_group(backend="gloo"))
+            if args.wire_bf16:
+                comm_fallback.set_options(1, 1)
+            gm.set_comm(comm_fallback.handle)
+            transport = "FALLBACK host-staged collectives over gloo (the device communicator failed on at least one rank: " + transport[:160] + ")"
     gm.load_synthetic(seed=1235, recipe="q4_k_m")
     gm.alloc_kv_cache(num_blocks)
     gm.kv_fill_random(seed=7 + rank)
@@ -437,7 +451,7 @@ def main():
     stream = torch.cuda.Stream()
     st = stream.cuda_stream
     # TP steps are captured too (RCCL on its side stream joins the capture as a fork / join; --tp-eager keeps them eager)
-    graph_mode = (not args.no_graph) and not (world > 1 and args.tp_eager)
+    graph_mode = (not args.no_graph) and not (world > 1 and (args.tp_eager or comm_fallback is not None))
     if world > 1 and graph_mode:
         # every rank tests LOCALLY whether this stack captures the communicator's all-reduce (capture + instantiate, nothing
         # is launched), then the ranks agree: one rank falling back to eager steps alone would leave its peers inside a

@@ -55,7 +55,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INS
   python tools/pmc_summary.py /tmp/pmc_b32_$i $OUT/${RN}_pmc_sq_b32_set$i.json $SHA > /dev/null 2>&1
 done
 # 8b. kernel stats of the secondary legs (bench_legs.py)
-for leg in bf16_b32 gptq_qwen2 mixtral_fp8 mixtral_fp8_b32; do
+for leg in bf16_b32 gptq_qwen2 gptq_qwen2_b32 mixtral_fp8 mixtral_fp8_b32; do
   rm -rf /tmp/rp_leg_$leg
   timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/rp_leg_$leg --output-format csv -- python bench_legs.py $leg --no-parity > $OUT/leg_$leg.log 2>&1
   f=$(find /tmp/rp_leg_$leg -name "*kernel_stats.csv" | head -1)
