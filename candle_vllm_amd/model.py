@@ -227,7 +227,7 @@ class GGUFLLaMa:
         if wire_bf16:
             _check(lib.mi355_comm_set_options(comm, 1, 1), "comm_set_options")
         self.all_reduce_transport = "RCCL on a side stream"
-        if not p2p:
+        if not p2p or (p2p == "auto" and self.tp_world < 2):          # (a one-rank world has no peer to reach)
             return self.all_reduce_transport
 
         def all_min(v):                                            # the ranks decide together

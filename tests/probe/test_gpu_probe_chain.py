@@ -1,6 +1,6 @@
 """EXPERIMENTS in probe builds only (tools/build_probe_lib.sh; run with MI355_LIB_PATH=build_probe/libmi355vllm_probes.so
-MI355_PROBE_BUILD=1): the single-token mat-vec on the LDS-DMA loader / consumer engine (csrc/qmv_engine.inc) and the four
-mat-vecs between two attention calls chained into ONE persistent launch (csrc/qmv_chain.inc; quantized_llama.rs:424-506).
+MI355_PROBE_BUILD=1): the single-token mat-vec on the LDS-DMA loader / consumer engine (csrc/probes/qmv_engine.inc) and the four
+mat-vecs between two attention calls chained into ONE persistent launch (csrc/probes/qmv_chain.inc; quantized_llama.rs:424-506).
 Both measured slower than qmm_kernel launch by launch (profiles/r03_b1_*_probe.txt); what these tests pin is that they compute
 the same numbers without a hang: engine == qmm_kernel bit for bit on plain launches, chained greedy tokens == unchained."""
 import ctypes

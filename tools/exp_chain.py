@@ -1,4 +1,4 @@
-"""Batch-1 step with the four mat-vecs between two attention calls chained in one persistent launch (csrc/qmv_chain.inc,
+"""Batch-1 step with the four mat-vecs between two attention calls chained in one persistent launch (csrc/probes/qmv_chain.inc,
 tuning key 23) against the same step launch by launch: logits / tokens compared, then hipGraph-replayed step times and the
 chain's per-wave cycle accounting (probe mode 15)."""
 import ctypes

@@ -1,4 +1,4 @@
-"""Batch-1 mat-vec engine (csrc/qmv_engine.inc) against the register-ring kernel (qmm_kernel) at the Llama-3-8B Q4_K_M launch
+"""Batch-1 mat-vec engine (csrc/probes/qmv_engine.inc) against the register-ring kernel (qmm_kernel) at the Llama-3-8B Q4_K_M launch
 shapes: same inputs through both, outputs compared, then the hipEvent time of each launch group for a sweep of consumer-wave
 counts and ring sizes.   python tools/exp_qmv.py [NC list, default 4,6,8,11,15]"""
 import ctypes
