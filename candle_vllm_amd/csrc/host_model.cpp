@@ -117,7 +117,10 @@ struct Model {
 
 // per-pair expert mat-vecs read an expert once per pair; grouped, every expert is read once per 32-row chunk of its `pairs` rows
 int g_moe_group = 1;            // tuning key 41: 0 = decode steps never group (A/B)
-inline bool moe_group_pays(int pairs, int n_expert) { return pairs > n_expert * ((pairs + 31) / 32); }
+// (round 5: an expert receives at most ONE row per token -- a token's n_expert_used experts are distinct, layers/moe.rs top-k -- so its block
+// has `tokens` live rows at most and is walked in ceil(tokens / 32) chunks, not ceil(pairs / 32): at batch 32 the second chunk of every
+// expert was a launch group that could never be live -- 16 of the 34 GEMM launches of a Mixtral layer, each a no-op with its boundary)
+inline bool moe_group_pays(int pairs, int n_expert, int tokens) { return pairs > n_expert * ((tokens + 31) / 32); }
 extern "C" int mi355_internal_paged_attention_v2_partials(void* out, float* exp_sums, float* max_logits, float* tmp_out, const void* q,
                                                           const void* key_cache, const void* value_cache, const uint32_t* block_tables,
                                                           const uint32_t* context_lens, int32_t num_seqs, int32_t num_heads,
@@ -337,7 +340,7 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
             m->moe_grouped_done = true;
             return 0;
         }
-        if (part == PART_GATEUP && !in.is_prefill && g_moe_group && m->g_moe_xg && pairs <= m->g_cap && moe_group_pays(pairs, c.n_expert)) {
+        if (part == PART_GATEUP && !in.is_prefill && g_moe_group && m->g_moe_xg && pairs <= m->g_cap && moe_group_pays(pairs, c.n_expert, B)) {
             // ---- grouped experts, decided on the device (decode steps with many pairs; graph-safe: no host round trip, fixed launch
             // shapes): route, give every pair a row in its expert's block of `cap` rows (stable), gather, then EVERY expert streams
             // once per 32-row chunk over its whole block (rows past its count hold stale finite values that nobody reads back), and
@@ -349,7 +352,7 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
             for (int e = 0; e < c.n_expert; ++e) {
                 // one fixed-shape launch group per 32-row chunk of the expert's block; a chunk no pair landed in (the expert's count,
                 // on the device, <= its first row) falls through every kernel of its launches
-                for (int r0 = 0; r0 < pairs; r0 += 32) {
+                for (int r0 = 0; r0 < B; r0 += 32) {                 // an expert holds at most one row per token
                     const int rows = 32;                              // (the gate is built into the 9..32-token launches)
                     const size_t off = (size_t)e * m->g_cap + r0;
                     mi355_qmm_desc g;
@@ -588,7 +591,7 @@ extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
         alloc((void**)&m->moe_ids, (size_t)B * KE * 4);
         alloc((void**)&m->moe_w, (size_t)B * KE * 4);
         alloc((void**)&m->moe_y, (size_t)B * KE * cfg->hidden * 4);
-        if (moe_group_pays(B * KE, cfg->n_expert)) {          // device-grouped decode: every expert owns B * KE rows of these
+        if (moe_group_pays(B * KE, cfg->n_expert, B)) {          // device-grouped decode: every expert owns B * KE rows of these
             m->g_cap = (B * KE + 31) / 32 * 32;                // whole 32-row chunks: the launch shape of every (expert, chunk)
             const size_t rows = (size_t)cfg->n_expert * m->g_cap + 1;            // + the dump row of an out-of-range expert id (moe_group_kernel)
             alloc((void**)&m->g_moe_xg, rows * cfg->hidden * 4);
