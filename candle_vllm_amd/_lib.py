@@ -47,6 +47,7 @@ class QmmDesc(ctypes.Structure):
         ("moe_expert_ids", c_vp), ("moe_pairs", c_i32), ("moe_x_div", c_i32), ("moe_expert_stride", c_i64 * 3),
         ("chain_next", c_i32), ("chain_next_k", c_i32), ("chain_next_norm", c_vp),
         ("rows_dev", c_vp), ("rows_min", c_i32),
+        ("group_count", c_i32), ("group_x_stride", c_i64), ("group_out_stride", c_i64),
     ]
 
 

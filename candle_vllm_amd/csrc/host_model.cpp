@@ -116,7 +116,7 @@ struct Model {
 };
 
 // per-pair expert mat-vecs read an expert once per pair; grouped, every expert is read once per 32-row chunk of its `pairs` rows
-int g_moe_group = 1;            // tuning key 41: 0 = decode steps never group (A/B)
+int g_moe_group = 1;            // tuning key 41: 0 = decode steps never group, 2 = grouped with one launch group per expert (A/B)
 // (round 5: an expert receives at most ONE row per token -- a token's n_expert_used experts are distinct, layers/moe.rs top-k -- so its block
 // has `tokens` live rows at most and is walked in ceil(tokens / 32) chunks, not ceil(pairs / 32): at batch 32 the second chunk of every
 // expert was a launch group that could never be live -- 16 of the 34 GEMM launches of a Mixtral layer, each a no-op with its boundary)
@@ -349,9 +349,11 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
             RCHECK(mi355_moe_route(in.moe_ids, in.moe_w, in.xs, L.ffn_norm, c.rms_eps, L.gate_inp, B, hid, c.n_expert, K, st));
             RCHECK(mi355_moe_group(m->g_moe_pos, m->g_moe_cnt, in.moe_ids, pairs, c.n_expert, m->g_cap, st));
             RCHECK(mi355_moe_gather_pos(m->g_moe_xg, in.xs, m->g_moe_pos, pairs, K, hid, st));
-            for (int e = 0; e < c.n_expert; ++e) {
-                // one fixed-shape launch group per 32-row chunk of the expert's block; a chunk no pair landed in (the expert's count,
-                // on the device, <= its first row) falls through every kernel of its launches
+            // key 41 = 1: ALL experts in the z extent of one launch each (mi355_qmm_desc.group_count): 5 launches per chunk instead of 5 per
+            // (expert, chunk); = 2: one launch group per expert (A/B).  A chunk no pair landed in (the expert's count, on the device, <= its
+            // first row) falls through every kernel
+            const int n_grp = g_moe_group == 2 ? 1 : c.n_expert;
+            for (int e = 0; e < c.n_expert; e += n_grp) {
                 for (int r0 = 0; r0 < B; r0 += 32) {                 // an expert holds at most one row per token
                     const int rows = 32;                              // (the gate is built into the 9..32-token launches)
                     const size_t off = (size_t)e * m->g_cap + r0;
@@ -365,6 +367,10 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
                     g.epilogue = MI355_EPI_SILU_MUL; g.out = m->g_moe_h + off * I; g.ldo = I;
                     g.rows_dev = m->g_moe_cnt + e; g.rows_min = r0;
                     g.chain_next = 1; g.chain_next_k = I; g.chain_next_norm = nullptr;   // its epilogue stages the down launch's image (same gate)
+                    if (n_grp > 1) {
+                        g.group_count = n_grp; g.group_x_stride = (int64_t)m->g_cap * hid; g.group_out_stride = (int64_t)m->g_cap * I;
+                        g.moe_expert_stride[0] = L.estride[0]; g.moe_expert_stride[1] = L.estride[2];
+                    }
                     RCHECK(mi355_qmatmul_fused(&g, st));
                     mi355_qmm_desc dn;
                     memset(&dn, 0, sizeof(dn));
@@ -373,6 +379,10 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
                     dn.x = m->g_moe_h + off * I; dn.x_dtype = MI355_DTYPE_F32; dn.ldx = I; dn.k = I; dn.num_tokens = rows;
                     dn.epilogue = MI355_EPI_STORE; dn.out = m->g_moe_yg + off * hid; dn.ldo = hid;
                     dn.rows_dev = m->g_moe_cnt + e; dn.rows_min = r0;
+                    if (n_grp > 1) {
+                        dn.group_count = n_grp; dn.group_x_stride = (int64_t)m->g_cap * I; dn.group_out_stride = (int64_t)m->g_cap * hid;
+                        dn.moe_expert_stride[0] = L.estride[1];
+                    }
                     RCHECK(mi355_qmatmul_fused(&dn, st));
                 }
             }

@@ -211,6 +211,10 @@ struct QmmArgs {
     int32_t moe_pairs, moe_xdiv;
     const int32_t* rows_dev; int32_t rows_min;   // wide path: no-op unless *rows_dev > rows_min (mi355_qmm_desc)
     int64_t moe_stride[3];    // bytes between consecutive experts of each segment
+    // grouped launch (9..32-token path): grp_n independent mat-muls of these shapes; group e reads x + e * grp_x, weights + e *
+    // moe_stride[s], writes out + e * grp_out (elements), gated by rows_dev[e]
+    int32_t grp_n;
+    int64_t grp_x, grp_out;
 };
 
 struct TileRegs { uint4 a, b, c, d; uint32_t e; };
@@ -1205,12 +1209,13 @@ __device__ __forceinline__ QmgEpiRow qmm_epilogue_load(const QmmArgs& a, const f
     return e;
 }
 // returns the f32 value written to a.out for (token b, out column = the chain's k index), 0 when nothing was written
-__device__ __forceinline__ float qmm_epilogue_apply(const QmmArgs& a, const QmgEpiRow& e, const float inv, const int b) {
+// (ooff: elements between a.out and the output of the workgroup's group -- grouped launches; 0 otherwise)
+__device__ __forceinline__ float qmm_epilogue_apply(const QmmArgs& a, const QmgEpiRow& e, const float inv, const int b, const size_t ooff = 0) {
     if (!e.live) return 0.f;
     const int sg = e.sg, lrow = e.lrow, orow = e.orow;
     const float val = e.s_main * inv + e.b_main;
     if (a.epi == MI355_EPI_STORE) {
-        a.out[(size_t)b * a.ldo + orow] = val;
+        a.out[ooff + (size_t)b * a.ldo + orow] = val;
         return val;
     } else if (a.epi == MI355_EPI_RESID) {
         const float o = e.resid + val;
@@ -1219,7 +1224,7 @@ __device__ __forceinline__ float qmm_epilogue_apply(const QmmArgs& a, const QmgE
     } else if (a.epi == MI355_EPI_SILU_MUL) {
         const float up = e.s_aux * inv + e.b_aux;
         const float o = silu_f(val) * up;
-        a.out[(size_t)b * a.ldo + lrow] = o;
+        a.out[ooff + (size_t)b * a.ldo + lrow] = o;
         return o;
     } else if (a.epi == MI355_EPI_QKV_ROPE_CACHE) {
         const int D = a.D, d = lrow % D, hh = lrow / D;
@@ -1261,10 +1266,9 @@ struct QmgChainOut { uint8_t* img; float* ssp; const float* norm_w; int K, MT; s
 // grid = (padded rows / 256, tokens).  With a chain target the y extent covers the PADDED token rows (MT*8) and every
 // workgroup = (token b, 256 consecutive output columns) = one (row, k-block) of the next image: the outputs meet in LDS
 // and 32 threads build the 32 entries.
-__global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, const float* __restrict__ part, const int ldp,
-                                                           const int ks, const int BP, const float* __restrict__ ssp,
-                                                           const QmgChainOut ch, const float* __restrict__ rscale = nullptr) {
-    if (a.rows_dev && *a.rows_dev <= a.rows_min) return;
+__device__ __forceinline__ void qmm_epilogue_body(const QmmArgs& a, const float* __restrict__ part, const int ldp, const int ks, const int BP,
+                                                  const float* __restrict__ ssp, const QmgChainOut& ch, const float* __restrict__ rscale,
+                                                  const size_t ooff) {
     const int prow = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     // deferred RMSNorm scale of this workgroup's token: the per-k-block partial sums are read by the lanes of one wave
@@ -1288,7 +1292,7 @@ __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, cons
     }
     if (rscale && b < a.B) inv *= rscale[b];                          // prompt-step GEMM: per-token power-of-two scale of the f16 image
     float o = 0.f;
-    if (mine) o = qmm_epilogue_apply(a, er, inv, b);
+    if (mine) o = qmm_epilogue_apply(a, er, inv, b, ooff);
     if (!ch.img) return;
     const int kb = blockIdx.x;
     if (kb * 256 >= ch.K) return;                                    // uniform: e.g. the `up` half of the gate/up rows
@@ -1303,6 +1307,26 @@ __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, cons
         else qmg_prep_entry(ch.img, ch.ssp, v, b < a.B, ch.norm_w, ch.MT, ch.kbb, kb, b, (int)threadIdx.x);
     }
 }
+__global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, const float* __restrict__ part, const int ldp,
+                                                           const int ks, const int BP, const float* __restrict__ ssp,
+                                                           const QmgChainOut ch, const float* __restrict__ rscale = nullptr) {
+    if (a.rows_dev && *a.rows_dev <= a.rows_min) return;
+    qmm_epilogue_body(a, part, ldp, ks, BP, ssp, ch, rscale, 0);
+}
+// grouped launches (QwGroup, qmm_wide1.inc): blockIdx.z = the group (STORE / SILU_MUL epilogues: the experts of a layer)
+__global__ void __launch_bounds__(256) qmm_epilogue_grp_kernel(const QmmArgs a, const float* __restrict__ part, const int ldp,
+                                                               const int ks, const int BP, const float* __restrict__ ssp,
+                                                               const QmgChainOut ch0, const QwGroup g) {
+    const int e = blockIdx.z;
+    if (a.rows_dev && a.rows_dev[e] <= a.rows_min) return;
+    QmgChainOut ch = ch0;
+    if (ch.img) {
+        ch.img += (size_t)e * g.chimg;
+        ch.ssp = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(ch.ssp) + (size_t)e * g.chimg);
+    }
+    qmm_epilogue_body(a, part + (size_t)e * g.part, ldp, ks, BP,
+                      reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(ssp) + (size_t)e * g.img), ch, nullptr, (size_t)e * g.out);
+}
 
 // (Round 4 measured a form of this kernel with FOUR token rows per workgroup -- a quarter of the workgroups, all partial sums requested up
 //  front -- on the theory that 512-3584 tiny workgroups per launch are bound by the rate at which workgroups start: it LOST, 10.4 / 13.0 /
@@ -1315,7 +1339,8 @@ __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, cons
 // (device, stream) that launches: two models on two streams never share an image, growing a buffer never frees memory a
 // captured graph still replays from (scratch.cpp).  The chain hint is per (device, stream) too.
 // image staged by the last chained epilogue: valid for exactly the next wide launch if it consumes the same activations
-struct QmgChainState { bool valid; const void* x; int B, K, MT, buf; const float* norm_w; hipStream_t st; int sp; int x_dtype = MI355_DTYPE_F32; };
+struct QmgChainState { bool valid; const void* x; int B, K, MT, buf; const float* norm_w; hipStream_t st; int sp; int x_dtype = MI355_DTYPE_F32;
+                       int grp = 1; int64_t grp_stride = 0; };                    // grouped launch: groups and elements between their activations
 struct QmgStream { int cur = 0; QmgChainState chain = {false, nullptr, 0, 0, 0, 0, nullptr, nullptr, 0}; };
 static std::mutex g_qmg_mu;
 static std::map<std::pair<int, hipStream_t>, QmgStream> g_qmg_streams;
@@ -1334,6 +1359,7 @@ static int g_tune_chain = 1;                                  // mi355_set_tunin
 static int g_tune_wide16 = 0;                                 // mi355_set_tuning(15, n): launches of >= n (row tile x k-block) units use 16-wave workgroups
 static int g_tune_merge = 1;                                  // mi355_set_tuning(14, 0): one launch per run of same-type segments (A/B)
 static int g_tune_ks_minkb = 2;                               // mi355_set_tuning(17, n): fewest k-blocks a k-split keeps per workgroup
+static int g_tune_grp_ks_target = 4096;                       // mi355_set_tuning(16, n): the same for grouped launches (slots of all groups)
 static int g_tune_ks_target = 1024;                           // mi355_set_tuning(10, n): split K until a launch has n row-tile x k-split slots
 static int g_tune_wide_fuse = 0;                              // mi355_set_tuning(49, 1), probe builds only: EXPERIMENT, the 9..32-token path runs its split-K epilogue inside the GEMM launches (lost its A/B: qmm_wide1_gemm.inc)
 static inline int qmg_buf(void** p, int key, size_t need, hipStream_t st) { return mi355_scratch_get(p, key, need, st, false); }
@@ -1444,8 +1470,11 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
     for (int s = 0; s < a.nseg; ++s) n_slots += a.seg[s].n_tiles;
     const int ldp = n_slots * 16, BP = MT * 16;
     const size_t kbb = qw1_kb_bytes(MT);
+    // grouped launch: G mat-muls of these shapes in the z extent of every launch (the experts of a mixture-of-experts layer)
+    const int G = a.grp_n > 1 ? a.grp_n : 1;
     int ks = 1;
-    if (g_tune_ks_target > 0) { while (n_slots * ks < g_tune_ks_target && nkb / (ks * 2) >= g_tune_ks_minkb) ks *= 2; }
+    if (G > 1) { while ((int64_t)n_slots * G * ks < g_tune_grp_ks_target && nkb / (ks * 2) >= g_tune_ks_minkb) ks *= 2; }
+    else if (g_tune_ks_target > 0) { while (n_slots * ks < g_tune_ks_target && nkb / (ks * 2) >= g_tune_ks_minkb) ks *= 2; }
     else {
         // workgroup target: the smallest split (any integer, not only powers of two) that puts >= |target| workgroups on the chip while
         // every split keeps >= minkb k-blocks; e.g. the 256-tile down projection: 37 workgroups x 7 splits of 8 k-blocks = 259
@@ -1456,7 +1485,7 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
         if (want < 1) want = 1;
         ks = want;
     }
-    if (g_tune_ks_target > 0 && a.nseg == 1 && nkb >= 32 && a.seg[0].type == MI355_GGML_Q6_K) {
+    if (G == 1 && g_tune_ks_target > 0 && a.nseg == 1 && nkb >= 32 && a.seg[0].type == MI355_GGML_Q6_K) {
         // a Q6_K launch of long K (the down projection: 256 tiles x 56 k-blocks) is bound by its unpack arithmetic and the latency of
         // its own chain (411 VALU per tile and k-block, profiles/r03_pmc_sq_b32_set1.json), not by bytes: with the power-of-two split
         // it runs 37 x 4 = 148 workgroups, ONE per CU on 58 % of the chip.  Measured (round 4, same box): 37 x 7 = 259 workgroups (every
@@ -1478,15 +1507,18 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
     QmgStream& qs = qmg_stream(st);
     const bool chained = qs.chain.valid && qs.chain.x == a.x && qs.chain.B == a.B && qs.chain.K == a.K &&
                          qs.chain.MT == MT && qs.chain.sp == 1 && qs.chain.norm_w == a.norm_w && qs.chain.st == st &&
-                         a.x_dtype == qs.chain.x_dtype && a.ldx == a.K;
+                         a.x_dtype == qs.chain.x_dtype && a.ldx == a.K && qs.chain.grp == G &&
+                         (G == 1 || qs.chain.grp_stride == a.grp_x);
     qs.chain.valid = false;
     const int cur = chained ? qs.chain.buf : qs.cur;
     int rc = 0;
     void* imgp = nullptr;
-    rc = qmg_buf(&imgp, cur ? MI355_SCR_QMM_IMG1 : MI355_SCR_QMM_IMG0, kbb * nkb + (size_t)nkb * BP * sizeof(float), st);
+    // (a group's image + sum-of-squares partials, rounded to the DMA granule: group e's lie e * imgb bytes after group 0's)
+    const size_t imgb = (kbb * nkb + (size_t)nkb * BP * sizeof(float) + 1023) / 1024 * 1024;
+    rc = qmg_buf(&imgp, cur ? MI355_SCR_QMM_IMG1 : MI355_SCR_QMM_IMG0, G > 1 ? G * imgb : kbb * nkb + (size_t)nkb * BP * sizeof(float), st);
     if (rc) return rc;
     void* partp = nullptr;
-    rc = qmg_buf(&partp, MI355_SCR_QMM_PART, (size_t)ks * BP * ldp * sizeof(float), st);
+    rc = qmg_buf(&partp, MI355_SCR_QMM_PART, (size_t)G * ks * BP * ldp * sizeof(float), st);
     if (rc) return rc;
     float* const part = static_cast<float*>(partp);
     static bool attr_done = false;
@@ -1494,33 +1526,40 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)qw1_gemm_kernel<MT, MI355_GGML_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qw1_gemm_kernel<MT, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qw1_gemm2_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qw1_gemm_grp_kernel<MT, MI355_GGML_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qw1_gemm_grp_kernel<MT, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qw1_gemm2_grp_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     uint8_t* img = static_cast<uint8_t*>(imgp);
     float* ssp = reinterpret_cast<float*>(img + kbb * nkb);                 // [nkb][BP] after the image
     // chain: the epilogue also stages the image of the next wide mat-mul (x = our out) into the other buffer
     QmgChainOut ch{nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    size_t imgb2 = 0;
     const bool want = g_tune_chain && a.chain_next && a.next_k > 0 && (a.next_k % 256) == 0 && a.ldo == a.next_k &&
                       (a.epi == MI355_EPI_RESID || a.epi == MI355_EPI_SILU_MUL || a.epi == MI355_EPI_STORE) &&
                       (a.epi == MI355_EPI_SILU_MUL ? a.seg[0].n_rows == a.next_k : (a.nseg == 1 && a.seg[0].n_rows == a.next_k));
     if (want) {
         const int other = cur ^ 1, nkb2 = a.next_k / 256;
         void* onext = nullptr;
-        rc = qmg_buf(&onext, other ? MI355_SCR_QMM_IMG1 : MI355_SCR_QMM_IMG0, kbb * nkb2 + (size_t)nkb2 * BP * sizeof(float), st);
+        imgb2 = (kbb * nkb2 + (size_t)nkb2 * BP * sizeof(float) + 1023) / 1024 * 1024;
+        rc = qmg_buf(&onext, other ? MI355_SCR_QMM_IMG1 : MI355_SCR_QMM_IMG0, G > 1 ? G * imgb2 : kbb * nkb2 + (size_t)nkb2 * BP * sizeof(float), st);
         if (rc) return rc;
         uint8_t* oimg = static_cast<uint8_t*>(onext);
         ch = QmgChainOut{oimg, reinterpret_cast<float*>(oimg + kbb * nkb2), a.next_norm_w, a.next_k, MT, kbb, 1};
     }
+    const QwGroup grp{a.grp_x, a.grp_out, (int64_t)imgb, (int64_t)ks * BP * ldp, (int64_t)imgb2};
     // the split-K epilogue inside the GEMM launches (qmm_wide1_gemm.inc): tickets per 256-column block of the output
     QwFuse fz{};
     fz.ticket = nullptr; fz.ssp = ssp; fz.ch = ch; fz.ks = ks; fz.n_runs = 0;
-    if (QW1_FUSE_BUILD && g_tune_wide_fuse) {
+    if (QW1_FUSE_BUILD && g_tune_wide_fuse && G == 1) {
         void* tk = nullptr;
         rc = mi355_scratch_get(&tk, MI355_SCR_QMM_TICKET, 8192 * sizeof(unsigned), st, true);
         if (rc) return rc;
         if ((ldp + 255) / 256 <= 8192) fz.ticket = static_cast<unsigned*>(tk);
     }
-    if (!chained) hipLaunchKernelGGL((qw1_prep_kernel<MT>), dim3(nkb, MT * 2), dim3(256), 0, st, img, ssp, a, kbb);
+    if (!chained && G > 1) hipLaunchKernelGGL((qw1_prep_grp_kernel<MT>), dim3(nkb, MT * 2, G), dim3(256), 0, st, img, ssp, a, kbb, grp);
+    else if (!chained) hipLaunchKernelGGL((qw1_prep_kernel<MT>), dim3(nkb, MT * 2), dim3(256), 0, st, img, ssp, a, kbb);
     // per-tile epilogue inside the GEMM launches (qmm_wide1_gemm.inc, TEPI): mat-muls that stage no image for a successor -- q|k|v (RoPE +
     // cache write), the lm_head, unchained stores / residual adds.
     // EXPERIMENT, probe builds only (key 49 = 2): measured in round 4 and lost -- q|k|v 40.7 us against 12.7 + 7.5 us for GEMM + epilogue
@@ -1529,7 +1568,7 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
     // slot -> store) one after the other, where the epilogue launch gives every element its own thread.
     bool tepi = false;
 #if QW1_FUSE_BUILD
-    tepi = g_tune_wide_fuse == 2 && !fz.ticket && !want && n_slots <= 8192 &&
+    tepi = G == 1 && g_tune_wide_fuse == 2 && !fz.ticket && !want && n_slots <= 8192 &&
            (a.epi == MI355_EPI_QKV_ROPE_CACHE || a.epi == MI355_EPI_STORE || a.epi == MI355_EPI_RESID);
     if (tepi) {
         void* tk = nullptr;
@@ -1559,7 +1598,9 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
     }
     if (two_runs) {
         const int slots1 = n_slots - slots0;
-        const dim3 ggrid((slots0 + QMG_NC - 1) / QMG_NC + (slots1 + QMG_NC - 1) / QMG_NC, ks);
+        const dim3 ggrid((slots0 + QMG_NC - 1) / QMG_NC + (slots1 + QMG_NC - 1) / QMG_NC, ks, G);
+        if (G > 1) hipLaunchKernelGGL((qw1_gemm2_grp_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>), ggrid, dim3(512), QW1_NB * kbb, st, a, img, part, ldp, s_split, slots0, slots1, fz, grp);
+        else
 #if QW1_FUSE_BUILD
         if (tepi) hipLaunchKernelGGL((qw1_gemm2_tepi_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>), ggrid, dim3(512), QW1_NB * kbb + 256, st, a, img, part, ldp, s_split, slots0, slots1, fz);
         else
@@ -1572,9 +1613,15 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
         QmmArgs r = a;
         r.nseg = s1 - s0;
         int run_slots = 0;
-        for (int q = 0; q < r.nseg; ++q) { r.seg[q] = a.seg[s0 + q]; run_slots += r.seg[q].n_tiles; }
+        for (int q = 0; q < r.nseg; ++q) { r.seg[q] = a.seg[s0 + q]; r.moe_stride[q] = a.moe_stride[s0 + q]; run_slots += r.seg[q].n_tiles; }
         // (the in-launch epilogue walks ALL segments of the mat-mul: it gets the whole descriptor, the GEMM part its own run)
-        const dim3 ggrid((run_slots + QMG_NC - 1) / QMG_NC, ks);
+        const dim3 ggrid((run_slots + QMG_NC - 1) / QMG_NC, ks, G);
+        if (G > 1) {
+            if (r.seg[0].type == MI355_GGML_Q4_K)
+                hipLaunchKernelGGL((qw1_gemm_grp_kernel<MT, MI355_GGML_Q4_K>), ggrid, dim3(512), QW1_NB * kbb, st, r, img, part, ldp, run_slots, slot_base, fz, grp);
+            else
+                hipLaunchKernelGGL((qw1_gemm_grp_kernel<MT, MI355_GGML_Q6_K>), ggrid, dim3(512), QW1_NB * kbb, st, r, img, part, ldp, run_slots, slot_base, fz, grp);
+        } else
 #if QW1_FUSE_BUILD
         if (fz.ticket && r.nseg != a.nseg) {
             // a mat-mul of several launches: the kernel's segment walk starts at the run's first segment
@@ -1600,9 +1647,11 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
         slot_base += run_slots;
         s0 = s1;
     }
-    if (want) qs.chain = QmgChainState{true, a.out, a.B, a.next_k, MT, cur ^ 1, a.next_norm_w, st, 1};
+    if (want) { qs.chain = QmgChainState{true, a.out, a.B, a.next_k, MT, cur ^ 1, a.next_norm_w, st, 1}; qs.chain.grp = G; qs.chain.grp_stride = a.grp_out; }
     qs.cur = cur;
-    if (!fz.ticket && !tepi)
+    if (G > 1)
+        hipLaunchKernelGGL(qmm_epilogue_grp_kernel, dim3((ldp + 255) / 256, want ? BP : a.B, G), dim3(256), 0, st, a, part, ldp, ks, BP, ssp, ch, grp);
+    else if (!fz.ticket && !tepi)
         hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, want ? BP : a.B), dim3(256), 0, st, a, part, ldp, ks, BP, ssp, ch);
     return (int)hipGetLastError();
 }
@@ -1895,6 +1944,7 @@ static void tuning_apply(int32_t key, int32_t value) {
     else if (key == 12 && value > 0) g_tune_qpg_min = value;
     else if (key == 14) g_tune_merge = value;
     else if (key == 15) g_tune_wide16 = value;
+    else if (key == 16 && value > 0) g_tune_grp_ks_target = value;
     else if (key == 17 && value > 0) g_tune_ks_minkb = value;
     else if (key == 18) g_tune_actq8 = value;
     else if (key == 20) g_tune_qmv = value;
@@ -1913,7 +1963,7 @@ struct TuningInit {
 #ifdef MI355_QMM_PROBES
         // probe builds: every key has a live value from the start (the defaults of the variables the setters write; ADVICE r4: a scoped
         // set / restore of a never-set key used to "restore" 0, which several setters ignore and which switches others off)
-        static const int32_t kProbeDefaults[][2] = {{0, 0}, {1, 0}, {2, 0}, {10, 1024}, {11, 2}, {12, 96}, {14, 1}, {15, 0}, {17, 2}, {18, 0},
+        static const int32_t kProbeDefaults[][2] = {{0, 0}, {1, 0}, {2, 0}, {10, 1024}, {11, 2}, {12, 96}, {14, 1}, {15, 0}, {16, 4096}, {17, 2}, {18, 0},
                                                     {20, 0}, {21, 8}, {22, 0}, {23, 0}, {33, 0}, {34, 0}, {35, 0}, {36, 96}, {37, 0}, {38, 4},
                                                     {42, 1}, {49, 0}};
         for (const auto& kv : kProbeDefaults) { g_tune_shadow[kv[0]] = kv[1]; g_tune_shadow_set[kv[0]] = true; }
@@ -2157,6 +2207,27 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
     for (int s = 0; s < a.nseg; ++s)
         if (a.seg[s].type != MI355_GGML_Q4_K && a.seg[s].type != MI355_GGML_Q6_K) return (int)hipErrorInvalidValue;
     if (a.paired && (a.nseg != 2 || a.seg[0].n_tiles != a.seg[1].n_tiles)) return (int)hipErrorInvalidValue;
+    if (a.grp_n > 1) {
+        // grouped launch: grp_n mat-muls of these shapes.  The 9..32-token path runs them as the z extent of its launches; everything
+        // else (other token counts, the exact modes) runs them one after the other -- same results, the descriptor's meaning is the loop
+        if (a.moe_expert || a.bias || (a.epi != MI355_EPI_STORE && a.epi != MI355_EPI_SILU_MUL)) return (int)hipErrorInvalidValue;
+        const bool one_launch = a.B > 8 && a.B <= 8 * QMW_MAXMT && !g_tune_exact_act && !g_qmm_exact &&
+                                !(a.B >= g_tune_qpg_min && g_tune_prefill_gemm);
+        if (!one_launch) {
+            const size_t xes = (a.x_dtype == MI355_DTYPE_BF16) ? 2 : 4;
+            for (int e = 0; e < a.grp_n; ++e) {
+                QmmArgs r = a;
+                r.grp_n = 0; r.chain_next = 0;
+                for (int s = 0; s < a.nseg; ++s) r.seg[s].w = a.seg[s].w + (size_t)e * a.moe_stride[s];
+                r.x = static_cast<const uint8_t*>(a.x) + (size_t)e * a.grp_x * xes;
+                r.out = a.out + (size_t)e * a.grp_out;
+                if (a.rows_dev) r.rows_dev = a.rows_dev + e;
+                const int rc = mi355_qmm_launch(r, stream);
+                if (rc) return rc;
+            }
+            return 0;
+        }
+    }
     if (g_qmm_exact && !a.moe_expert && !a.rows_dev) return qmm_exact_launch(a, to_stream(stream));   // parity mode 2 (tests only)
     int total_tiles = 0;
     bool div4 = true, div2 = true;
@@ -2305,6 +2376,8 @@ static int qmm_args_from_desc(const mi355_qmm_desc* d, QmmArgs& a) {
     a.moe_expert = d->moe_expert_ids; a.moe_pairs = d->moe_pairs; a.moe_xdiv = d->moe_x_div;
     a.rows_dev = d->rows_dev; a.rows_min = d->rows_min;
     for (int s = 0; s < 3; ++s) a.moe_stride[s] = d->moe_expert_stride[s];
+    if (d->group_count < 0 || (d->group_count > 1 && (d->moe_expert_ids || d->group_x_stride < 0 || d->group_out_stride < 0))) return (int)hipErrorInvalidValue;
+    a.grp_n = d->group_count > 1 ? d->group_count : 0; a.grp_x = d->group_x_stride; a.grp_out = d->group_out_stride;
     a.chain_next = (d->chain_next && !d->moe_expert_ids && d->num_tokens > 8 && d->num_tokens <= 8 * QMW_MAXMT) ? 1 : 0;
     a.next_k = d->chain_next_k; a.next_norm_w = d->chain_next_norm;
     return 0;

@@ -254,6 +254,14 @@ typedef struct mi355_qmm_desc {
      * graph-captured MoE step launches one fixed-shape chunk per (expert, 32 rows) and the chunks no pair landed in fall through */
     const int32_t* rows_dev;
     int32_t rows_min;
+    /* grouped call (0 / 1 = off): group_count mat-muls of exactly these shapes in one call -- the experts of a mixture-of-experts layer
+     * over their blocks of gathered rows (mi355_moe_group).  Group e reads x + e * group_x_stride elements, the weights
+     * w_tiles[s] + e * moe_expert_stride[s] bytes, writes out + e * group_out_stride elements, and is gated by rows_dev[e] (rows_dev,
+     * when given, then holds group_count counts).  Epilogues STORE and SILU_MUL, no bias, not together with moe_expert_ids.  With 9..32
+     * tokens the groups are the z extent of ONE launch each of the staging, GEMM and epilogue kernels (and a chain hint stages all the
+     * groups' next images); any other token count runs the groups one after the other. */
+    int32_t group_count;
+    int64_t group_x_stride, group_out_stride;
 } mi355_qmm_desc;
 int mi355_qmatmul_fused(const mi355_qmm_desc* desc, int64_t stream);
 /* MoE routing on the device (MlpOrMoe::forward, quantized_llama.rs:56-123, without the host round trip):
@@ -292,7 +300,8 @@ int mi355_moe_scatter_combine(float* ys, const float* y_sorted, const float* wei
  *   30  16-bit / GPTQ linears, bit mask of folded launches switched OFF: 1 the 1..4-token 4-bit kernel, 2 no RMSNorm on the way in,
  *       4 RoPE + cache write in their own launch, 8 the LDS-shared-activation 16-bit kernel, 16 the one-pass 4-bit prompt GEMM;
  *       32 switches ON the 256-token tile of the 16-bit prompt GEMM where it fills the chip twice (64 as well: wherever it runs)
- *   41  MoE decode steps group their (token, slot) pairs by expert on the device (1, default)
+ *   41  MoE decode steps group their (token, slot) pairs by expert on the device: 1 (default) = all experts in the z extent of one
+ *       launch per kernel (mi355_qmm_desc.group_count); 2 = grouped, one launch group per expert; 0 = one mat-vec per pair
  *   44  decode-attention kernel per partition size on the PAGED bf16 cache: 1 (default) = 256 / 512 as looped chunks, 64 as the
  *       balanced LDS-DMA stream at >= 64 (sequence, kv head) pairs; 0 = neither; 5 = chunks only; 3 = the stream for every launch
  *       with partition size 64; 2 = additionally 1024 / 2048 / 4096 through the chunked LDS-DMA kernel

