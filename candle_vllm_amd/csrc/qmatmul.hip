@@ -1268,7 +1268,8 @@ struct QmgChainOut { uint8_t* img; float* ssp; const float* norm_w; int K, MT; s
 // and 32 threads build the 32 entries.
 __device__ __forceinline__ void qmm_epilogue_body(const QmmArgs& a, const float* __restrict__ part, const int ldp, const int ks, const int BP,
                                                   const float* __restrict__ ssp, const QmgChainOut& ch, const float* __restrict__ rscale,
-                                                  const size_t ooff) {
+                                                  const size_t ooff, const int nb) {
+    // (nb: live token rows -- a.B, or the row count of the workgroup's group; rows past it get zero entries in a chained image)
     const int prow = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     // deferred RMSNorm scale of this workgroup's token: the per-k-block partial sums are read by the lanes of one wave
@@ -1277,12 +1278,12 @@ __device__ __forceinline__ void qmm_epilogue_body(const QmmArgs& a, const float*
     float inv = 1.f;
     QmgEpiRow er;
     er.live = false;
-    const bool mine = prow < ldp && b < a.B;
+    const bool mine = prow < ldp && b < nb;
     if (mine) er = qmm_epilogue_load(a, part, ldp, ks, BP, prow, b);
     if (a.norm_w && ssp) {
         if (threadIdx.x < 64) {
             float ss = 0.f;
-            if (b < a.B)
+            if (b < nb)
                 for (int kb = threadIdx.x; kb < (a.K >> 8); kb += 64) ss += ssp[(size_t)kb * BP + b];
             ss = wave_sum(ss);
             if (threadIdx.x == 0) sm_inv = rsqrtf(ss / (float)a.K + a.eps);
@@ -1290,7 +1291,7 @@ __device__ __forceinline__ void qmm_epilogue_body(const QmmArgs& a, const float*
         __syncthreads();
         inv = sm_inv;
     }
-    if (rscale && b < a.B) inv *= rscale[b];                          // prompt-step GEMM: per-token power-of-two scale of the f16 image
+    if (rscale && b < nb) inv *= rscale[b];                          // prompt-step GEMM: per-token power-of-two scale of the f16 image
     float o = 0.f;
     if (mine) o = qmm_epilogue_apply(a, er, inv, b, ooff);
     if (!ch.img) return;
@@ -1303,29 +1304,31 @@ __device__ __forceinline__ void qmm_epilogue_body(const QmmArgs& a, const float*
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = sm_o[threadIdx.x * 8 + i];
-        if (ch.sp) qw1_prep_entry(ch.img, ch.ssp, v, b < a.B, ch.norm_w, ch.MT, ch.kbb, kb, b, (int)threadIdx.x);
-        else qmg_prep_entry(ch.img, ch.ssp, v, b < a.B, ch.norm_w, ch.MT, ch.kbb, kb, b, (int)threadIdx.x);
+        if (ch.sp) qw1_prep_entry(ch.img, ch.ssp, v, b < nb, ch.norm_w, ch.MT, ch.kbb, kb, b, (int)threadIdx.x);
+        else qmg_prep_entry(ch.img, ch.ssp, v, b < nb, ch.norm_w, ch.MT, ch.kbb, kb, b, (int)threadIdx.x);
     }
 }
 __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, const float* __restrict__ part, const int ldp,
                                                            const int ks, const int BP, const float* __restrict__ ssp,
                                                            const QmgChainOut ch, const float* __restrict__ rscale = nullptr) {
     if (a.rows_dev && *a.rows_dev <= a.rows_min) return;
-    qmm_epilogue_body(a, part, ldp, ks, BP, ssp, ch, rscale, 0);
+    qmm_epilogue_body(a, part, ldp, ks, BP, ssp, ch, rscale, 0, a.B);
 }
 // grouped launches (QwGroup, qmm_wide1.inc): blockIdx.z = the group (STORE / SILU_MUL epilogues: the experts of a layer)
 __global__ void __launch_bounds__(256) qmm_epilogue_grp_kernel(const QmmArgs a, const float* __restrict__ part, const int ldp,
                                                                const int ks, const int BP, const float* __restrict__ ssp,
                                                                const QmgChainOut ch0, const QwGroup g) {
     const int e = blockIdx.z;
-    if (a.rows_dev && a.rows_dev[e] <= a.rows_min) return;
+    const int nb = a.rows_dev ? min(a.B, a.rows_dev[e] - a.rows_min) : a.B;
+    if (nb <= 0) return;
+    if ((int)blockIdx.y >= nb && !ch0.img) return;
     QmgChainOut ch = ch0;
     if (ch.img) {
         ch.img += (size_t)e * g.chimg;
         ch.ssp = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(ch.ssp) + (size_t)e * g.chimg);
     }
     qmm_epilogue_body(a, part + (size_t)e * g.part, ldp, ks, BP,
-                      reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(ssp) + (size_t)e * g.img), ch, nullptr, (size_t)e * g.out);
+                      reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(ssp) + (size_t)e * g.img), ch, nullptr, (size_t)e * g.out, nb);
 }
 
 // (Round 4 measured a form of this kernel with FOUR token rows per workgroup -- a quarter of the workgroups, all partial sums requested up

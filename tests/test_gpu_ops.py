@@ -590,11 +590,14 @@ def test_grouped_expert_matmuls_one_launch_per_kernel(cv, rows, types):
         if not live:
             assert (h1[e] == 7.0).all() and (y1[e] == 9.0).all() and (h0[e] == 7.0).all()
             continue
-        # the same kernels on the same operands; only the K split of the down launch may differ (its target counts all groups' tiles)
-        assert np.array_equal(h1[e, :rows], h0[e, :rows]), e
-        assert rel_err(y1[e, :rows], y0[e, :rows]) < 2e-6, (e, rel_err(y1[e, :rows], y0[e, :rows]))
+        # the same kernels on the same operands; only the K split of the down launch may differ (its target counts all groups' tiles).
+        # The 9..32-row grouped launches stop at the expert's COUNT (rows past it are never read back by the caller: not written);
+        # the one-by-one calls and the 1..8-row loop compute all `rows` rows
+        nlive = min(n, rows) if rows > 8 else rows
+        assert np.array_equal(h1[e, :nlive], h0[e, :nlive]), e
+        assert rel_err(y1[e, :nlive], y0[e, :nlive]) < 2e-6, (e, rel_err(y1[e, :nlive], y0[e, :nlive]))
         assert (h1[e, rows:] == 7.0).all() and (y1[e, rows:] == 9.0).all()
-    # and against the dequantised weights on the host for one live expert (the pieces are tested on their own elsewhere)
+        assert (h1[e, nlive:rows] == 7.0).all() and (y1[e, nlive:rows] == 9.0).all()
     assert np.isfinite(y1[0, :rows]).all() and np.abs(y1[0, :rows]).max() > 0
 
 
