@@ -35,6 +35,15 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
     asm("v_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
+// RoPE rotation of one pair in f32, every product and sum rounded on its own (candle's rope on f32 values does not fuse a multiply
+// into the add; with fused multiply-adds the compiler picks a different association in every kernel it inlines this into, and the
+// same step run through two launch shapes stops being bit-identical)
+__device__ __forceinline__ void rope_rotate(const float x0, const float x1, const float c, const float s, float& r0, float& r1) {
+#pragma clang fp contract(off)
+    const float a = x0 * c, b = x1 * s, d = x0 * s, e = x1 * c;
+    r0 = a - b;
+    r1 = d + e;
+}
 __device__ __forceinline__ float f16_bits_to_f32(uint16_t h) {
     _Float16 v = __builtin_bit_cast(_Float16, h);
     return (float)v;

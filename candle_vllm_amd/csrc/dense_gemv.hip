@@ -137,8 +137,10 @@ __device__ __forceinline__ float dense_epilogue(const DenseArgs& a, const int m,
 // One workgroup = R row tiles (R = 2 for the packed gate/up pair) x all of K; the waves split the 256-wide
 // k-blocks; MT = ceil(T/16) M tiles.  GJ (4-bit only) = 32-wide k runs per quantisation group inside a k-block
 // (group 32/64/128/>=256 -> 1/2/4/8): the MFMA chain runs over a whole group and the scale is applied once.
+// rp (dense3r_kernel: q / k / v of a decode step of 5..32 tokens): RoPE and the cache write in the epilogue; q and k then run as row-tile
+// PAIRS (j, j + D/2) of one head, as in dense_small_body
 template <int DT, int WTYPE, int MT, int R, int GJ>
-__device__ __forceinline__ void dense_body(const DenseArgs& a, const int bx) {
+__device__ __forceinline__ void dense_body(const DenseArgs& a, const int bx, const DenseRope* rp = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float dg_red[];   // [NW][R][MT][16 m][16 rows]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
     const int r16 = lane & 15, kg = lane >> 4;
@@ -146,6 +148,11 @@ __device__ __forceinline__ void dense_body(const DenseArgs& a, const int bx) {
     int row0[R];
     row0[0] = bx * 16;
     if (R == 2) row0[R - 1] = a.pair_offset + bx * 16;
+    if (R == 2 && rp) {                                            // RoPE pairs: rows (h, j) and (h, j + D/2) of one head
+        const int tph = rp->head_dim >> 5;                         // 16-row pair tiles per head
+        row0[0] = (bx / tph) * rp->head_dim + (bx % tph) * 16;
+        row0[R - 1] = row0[0] + (rp->head_dim >> 1);
+    }
     const uint16_t* x16 = static_cast<const uint16_t*>(a.x);
 
     f32x4_t y[R][MT];
@@ -260,7 +267,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs& a, const int bx) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) y[r][mt][v] += s * acc[mt][v] + c * xs[mt][v];
+                        for (int v = 0; v < 4; ++v) y[r][mt][v] = fmaf(s, acc[mt][v], fmaf(c, xs[mt][v], y[r][mt][v]));   // (explicit: the same association in every instantiation)
                 }
             }
         }
@@ -286,6 +293,45 @@ __device__ __forceinline__ void dense_body(const DenseArgs& a, const int bx) {
             for (int w = 0; w < NW; ++w) s += dg_red[((((size_t)w * R + r) * MT + (m >> 4)) * 16 + (m & 15)) * 16 + rr];
             val[r] = s;
         }
+        if (rp) {
+            // the rounding chain of the projection (+bias), then for q and k "f32 -> rope -> model dtype" (attention.rs:644-690;
+            // rope_cache_bf16_kernel's arithmetic), then the cache write of k / v (attention.rs:707-719) -- dense_small_body's epilogue
+            const uint16_t* b16 = static_cast<const uint16_t*>(a.bias);
+            const int Dh = rp->head_dim, hf = Dh >> 1, bs = rp->block_size, Hkv = rp->n_kv_heads;
+            const int64_t slot = rp->slots[m];
+            const int64_t blk = slot >= 0 ? slot / bs : 0;
+            const int off = slot >= 0 ? (int)(slot % bs) : 0;
+            uint16_t* o16 = static_cast<uint16_t*>(a.out);
+            float o0 = rnd<DT>(val[0]);
+            if (b16) o0 = rnd<DT>(o0 + h2f<DT>(b16[row0[0] + rr]));
+            if (R == 2) {
+                float o1 = rnd<DT>(val[R - 1]);
+                if (b16) o1 = rnd<DT>(o1 + h2f<DT>(b16[row0[R - 1] + rr]));
+                const int h = row0[0] / Dh, j = row0[0] % Dh + rr;
+                const int64_t pos = rp->positions[m];
+                const float cc = rp->cos_t[pos * hf + j], sn = rp->sin_t[pos * hf + j];
+                float f0, f1;
+                rope_rotate(o0, o1, cc, sn, f0, f1);
+                const uint16_t r0 = f2h<DT>(f0), r1 = f2h<DT>(f1);
+                o16[(size_t)m * a.ldo + row0[0] + rr] = r0;
+                o16[(size_t)m * a.ldo + row0[R - 1] + rr] = r1;
+                if (a.rope_mode == 2 && slot >= 0) {
+                    const int d0 = j, d1 = j + hf;
+                    if (rp->flash) { rp->kcache[(slot * Hkv + h) * Dh + d0] = r0; rp->kcache[(slot * Hkv + h) * Dh + d1] = r1; }
+                    else {
+                        rp->kcache[((((blk * Hkv + h) * (Dh / 8) + d0 / 8) * bs + off) * 8) + d0 % 8] = r0;
+                        rp->kcache[((((blk * Hkv + h) * (Dh / 8) + d1 / 8) * bs + off) * 8) + d1 % 8] = r1;
+                    }
+                }
+            } else {
+                const uint16_t r0 = f2h<DT>(o0);
+                const int row = row0[0] + rr, h = row / Dh, d = row % Dh;
+                o16[(size_t)m * a.ldo + row] = r0;
+                if (a.rope_mode == 3 && slot >= 0)
+                    rp->vcache[rp->flash ? (slot * Hkv + h) * Dh + d : ((blk * Hkv + h) * Dh + d) * (int64_t)bs + off] = r0;
+            }
+            continue;
+        }
         dense_epilogue<DT>(a, m, row0[0] + rr, val[0], val[R - 1]);
     }
 }
@@ -300,6 +346,17 @@ __global__ void __launch_bounds__(512) dense3_kernel(const DenseArgs a0, const D
     if (bx < t0) dense_body<DT, WTYPE, MT, 1, GJ>(a0, bx);
     else if (bx < t0 + t1) dense_body<DT, WTYPE, MT, 1, GJ>(a1, bx - t0);
     else dense_body<DT, WTYPE, MT, 1, GJ>(a2, bx - t0 - t1);
+}
+
+// the same with RoPE and the cache write in the epilogue (decode steps of 5..32 tokens, bf16 cache, full non-interleaved rotary): q and k
+// as pairs of row tiles half a head apart (t0, t1 count PAIRS), v one tile per workgroup -- no rope_cache launch behind it
+template <int DT, int WTYPE, int MT, int GJ>
+__global__ void __launch_bounds__(512) dense3r_kernel(const DenseArgs a0, const DenseArgs a1, const DenseArgs a2, const int t0, const int t1,
+                                                      const DenseRope rp) {
+    const int bx = (int)blockIdx.x;
+    if (bx < t0) dense_body<DT, WTYPE, MT, 2, GJ>(a0, bx, &rp);
+    else if (bx < t0 + t1) dense_body<DT, WTYPE, MT, 2, GJ>(a1, bx - t0, &rp);
+    else dense_body<DT, WTYPE, MT, 1, GJ>(a2, bx - t0 - t1, &rp);
 }
 
 // ------------------------------------------------------------------------------------------------ 5..64 tokens x 16-bit weights, many row tiles
@@ -671,7 +728,9 @@ __device__ __forceinline__ void dense_small_body(const DenseArgs& a, const int b
                 const int h = row0[0] / Dh, j = row0[0] % Dh + rr;
                 const int64_t pos = rp->positions[m];
                 const float cc = rp->cos_t[pos * hf + j], sn = rp->sin_t[pos * hf + j];
-                const uint16_t r0 = f2h<DT>(o0 * cc - o1 * sn), r1 = f2h<DT>(o0 * sn + o1 * cc);
+                float f0, f1;
+                rope_rotate(o0, o1, cc, sn, f0, f1);
+                const uint16_t r0 = f2h<DT>(f0), r1 = f2h<DT>(f1);
                 o16[(size_t)m * a.ldo + row0[0] + rr] = r0;
                 o16[(size_t)m * a.ldo + row0[R - 1] + rr] = r1;
                 if (a.rope_mode == 2 && slot >= 0) {
@@ -956,9 +1015,15 @@ static int dense3_launch_dt(const DenseArgs (&a)[3], const DenseRope* rp, hipStr
     {
         const int rs = dense_small3_launch<DT, WTYPE>(a, rp, st);
         if (rs != -4) return rs;
-        if (a[0].norm_w || rp) return -4;          // only the 1..4-token kernel norms on the way in / ropes on the way out
+        if (a[0].norm_w) return -4;                // only the 1..4-token kernel norms on the way in
     }
     const int mt = (a[0].T + 15) / 16;
+    if (rp) {
+        // RoPE + cache write in the epilogue of the 5..32-token kernel: whole heads of an even, 32-divisible width, bf16
+        if (g_tune_small_norope || DT != MI355_DTYPE_BF16 || mt > 2 || (rp->head_dim & 31) || a[0].N % rp->head_dim ||
+            a[1].N != rp->n_kv_heads * rp->head_dim || a[2].N != a[1].N)
+            return -4;
+    }
     int gj = 8;
     if (WTYPE != DW_DENSE) {
         const int g = a[0].group_size;
@@ -973,6 +1038,20 @@ static int dense3_launch_dt(const DenseArgs (&a)[3], const DenseRope* rp, hipStr
     int nw = 8;
     while (nw > 1 && (nw > nkb || (size_t)tiles * nw > 256 * 32)) nw >>= 1;
     if (mt >= 3 && nw > 4) nw = 4;
+    if (rp) {
+        DenseArgs b[3] = {a[0], a[1], a[2]};
+        b[0].rope_mode = 1; b[1].rope_mode = 2; b[2].rope_mode = 3;
+        const int p0 = t0 / 2, p1 = t1 / 2;
+        const size_t ldr = (size_t)nw * 2 * mt * 256 * sizeof(float);
+        dim3 gridr(p0 + p1 + t2), block(nw * 64);
+#define DG3R(MT_, GJ_) hipLaunchKernelGGL((dense3r_kernel<DT, WTYPE, MT_, GJ_>), gridr, block, ldr, st, b[0], b[1], b[2], p0, p1, *rp)
+#define DG3R_MT(GJ_) if (mt == 1) DG3R(1, GJ_); else DG3R(2, GJ_);
+        if (WTYPE == DW_DENSE) { DG3R_MT(8) }
+        else switch (gj) { case 1: DG3R_MT(1) break; case 2: DG3R_MT(2) break; case 4: DG3R_MT(4) break; default: DG3R_MT(8) break; }
+#undef DG3R_MT
+#undef DG3R
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     const size_t lds = (size_t)nw * mt * 256 * sizeof(float);
     dim3 grid(tiles), block(nw * 64);
 #define DG3(MT_, GJ_) hipLaunchKernelGGL((dense3_kernel<DT, WTYPE, MT_, GJ_>), grid, block, lds, st, a[0], a[1], a[2], t0, t1)

@@ -495,7 +495,8 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
                 // q/k/v launch's epilogue (-4 from the launch = not this shape: the launch is repeated without them)
                 DenseRope rp{m->cos_t, m->sin_t, positions, slot_mapping, (uint16_t*)m->kcache[l], (uint16_t*)m->vcache[l], Hkv, D,
                              c.block_size, c.kv_layout == MI355_KV_FLASH ? 1 : 0};
-                const bool rope_ok = all_q && T <= 4 && !prefill && !c.kv_fp8 && c.rotary_dim == D && !c.rope_interleaved;
+                // (1..4 tokens: the 4-bit small kernel; 5..32 tokens: the row-tile-pair form of the batch kernel, 4-bit and 16-bit weights)
+                const bool rope_ok = (all_q ? T <= 32 : (T > 4 && T <= 32)) && !prefill && !c.kv_fp8 && c.rotary_dim == D && !c.rope_interleaved;
                 if (all_q && ss_valid && c.norm_type == 0) {            // the producer of xs left its sums of squares: no norm launch
                     for (int pass = rope_ok ? 0 : 1; pass < 2 && rc3 != 0; ++pass) {
                         rc3 = mi355_internal_linear3(outs, m->xs, ws, sc, bs, ns, T, hid, gq.group, 2, m->cfg.dtype, L.attn_norm, c.rms_eps, m->ss,

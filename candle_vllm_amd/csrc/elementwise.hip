@@ -173,8 +173,10 @@ __global__ void __launch_bounds__(256) rope_kernel(T* __restrict__ q, T* __restr
         const int i1 = is_rope_i ? 2 * j + 1 : j + half;
         const float x0 = ld_as_f32<T>(base, i0), x1 = ld_as_f32<T>(base, i1);
         const float cc = c[j], sn = s[j];
-        st_from_f32<T>(base, i0, x0 * cc - x1 * sn);
-        st_from_f32<T>(base, i1, x0 * sn + x1 * cc);
+        float f0, f1;
+        rope_rotate(x0, x1, cc, sn, f0, f1);
+        st_from_f32<T>(base, i0, f0);
+        st_from_f32<T>(base, i1, f1);
     }
 }
 
@@ -227,7 +229,9 @@ __global__ void __launch_bounds__(256) rope_cache_bf16_kernel(uint16_t* __restri
         const int i1 = is_rope_i ? 2 * j + 1 : j + half;
         const float x0 = bf16_to_f32(base[i0]), x1 = bf16_to_f32(base[i1]);
         const float cc = c[j], sn = s[j];
-        const uint16_t r0 = f32_to_bf16(x0 * cc - x1 * sn), r1 = f32_to_bf16(x0 * sn + x1 * cc);
+        float f0, f1;
+        rope_rotate(x0, x1, cc, sn, f0, f1);
+        const uint16_t r0 = f32_to_bf16(f0), r1 = f32_to_bf16(f1);
         base[i0] = r0; base[i1] = r1;
         if (!isq && slot >= 0) { kc[kidx(h - H, i0)] = r0; kc[kidx(h - H, i1)] = r1; }
     }

@@ -147,6 +147,49 @@ def test_qwen2_gptq_shape_prompt_then_decode(lib, flash):
         assert [int(r.argmax()) for r in got] == [int(r.argmax()) for r in ref]
 
 
+@pytest.mark.parametrize("quant,flash,B", [("gptq", False, 9), ("gptq", True, 32), ("bf16", False, 32), ("bf16", True, 12), ("gptq", False, 17)])
+def test_batch_decode_rope_and_cache_ride_in_the_qkv_launch(lib, quant, flash, B):
+    """Decode steps of 5..32 sequences: q / k / v run as ONE launch whose epilogue rotates q and k and writes k and v into the cache
+    (row-tile pairs half a head apart, dense3r_kernel) -- against the same steps with the projections, RoPE and the cache write in
+    their own launches (tuning key 30 bit 2): the same arithmetic in the same order, so logits AND cache contents agree bit for bit;
+    and against the oracle to the model bound.  4-bit (+ qkv bias) and 16-bit weights, both cache layouts, one and two token tiles."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from candle_vllm_amd import dense_model as M
+    from candle_vllm_amd import tuning
+    cfg = DL.DenseConfig.tiny(qkv_bias=(quant == "gptq"))
+    W = DL.make_weights(cfg)
+    if quant == "gptq":
+        W = DL.quantize_gptq(W, group=128)
+    orc = DL.OracleDenseLlama(cfg, W, flash_layout=flash)
+    rng = np.random.default_rng(40 + B)
+    seqs = [{"tokens": [int(t) for t in rng.integers(0, cfg.vocab, int(n))], "block_table": [2 * i + 1, 2 * i + 2]}
+            for i, n in enumerate(rng.integers(3, 2 * cfg.block_size - 4, B))]
+    cache = orc.new_cache(2 * B + 2)
+    meta = O.prepare_prompt(seqs, cfg.block_size)
+    ref = orc.forward(meta, cache, is_prefill=True)
+    layout = M.KV_FLASH if flash else M.KV_PAGED
+    gm, gm2 = M.DenseLlama(cfg, max_batch=B, kv_layout=layout), M.DenseLlama(cfg, max_batch=B, kv_layout=layout)
+    for g in (gm, gm2):
+        g.load_oracle_weights(W)
+        g.alloc_kv_cache(2 * B + 2)
+        g.forward(meta, is_prefill=True)
+    for step in range(2):
+        for s, row in zip(seqs, ref):
+            s["tokens"].append(int(row.argmax()))
+        dmeta = O.prepare_decode(seqs, cfg.block_size)
+        ref = orc.forward(dmeta, cache)
+        got = gm.forward(dmeta).cpu().numpy()
+        with tuning(30, 4):                                       # RoPE + cache write in their own launch, three projections as before
+            got2 = gm2.forward(dmeta).cpu().numpy()
+        assert _rel(got, ref) < 2e-2, (step, _rel(got, ref))
+        assert np.array_equal(got, got2), (step, _rel(got, got2))
+        for l in range(cfg.n_layers):
+            k1, v1 = gm.kv_download(l)
+            k2, v2 = gm2.kv_download(l)
+            assert np.array_equal(k1, k2) and np.array_equal(v1, v2), (step, l)
+
+
 def test_dense_llama_with_fp8_kv_cache(lib):
     """`--kvcache-dtype fp8` on the 16-bit host path: e4m3fn cache (PAGED, x = 16), decode through the MFMA fp8
     kernel / one-pass kernel, prompt step through the fp8 prefill kernel; oracle attends over the dequantised cache."""
