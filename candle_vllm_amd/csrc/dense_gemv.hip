@@ -19,6 +19,7 @@
 #include "scratch.h"
 #include "../../include/mi355_vllm.h"
 #include <hip/hip_runtime.h>
+#include <utility>
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int dg_u32x4 __attribute__((ext_vector_type(4)));
@@ -809,6 +810,7 @@ static int g_tune_small_nw = 0;        // tuning key 30: waves per workgroup (0 
 static int g_tune_small_nw_big = 0;    // tuning key 35: the same for K > 8192
 static int g_tune_gemm_tall = 0;       // tuning key 30 bit 32 (round 4; measured SLOWER, stays off: bf16 prompt step of Llama-3-8B 53.7 k -> 51.5 k tok/s): the 256-token tile of the 16-bit prompt GEMM where it fills the chip twice
 static int g_tune_small_off = 0;       // tuning key 31: 1 = keep 1..4 tokens on dense_kernel (A/B measurements)
+static int g_tune_gptq_wide_nosplit = 0;   // tuning key 30 bit 256: gate/up pairs of the 5..32-token 4-bit launches stay on one wave each (A/B)
 static int g_tune_gptq_wide_off = 0;   // tuning key 30 bit 128: 1 = 5..64-token launches of tiled 4-bit weights stay on dense_kernel (A/B; round 5)
 static int g_tune_small_norope = 0;    // tuning key 34: 1 = RoPE and the cache write stay in their own launch
 static int g_tune_small_nonorm = 0;    // tuning key 32: 1 = never norm on the way in (the host layer launches the norm separately)
@@ -822,6 +824,7 @@ void mi355_dense_set_small(int key, int v) {
         g_tune_small_off = v & 1; g_tune_small_nonorm = (v >> 1) & 1; g_tune_small_norope = (v >> 2) & 1;
         g_tune_wide_off = (v >> 3) & 1; g_tune_gptq_gemm_off = (v >> 4) & 1; g_tune_gemm_tall = (v >> 5) & 3;
         g_tune_gptq_wide_off = (v >> 7) & 1;
+        g_tune_gptq_wide_nosplit = (v >> 8) & 1;
     }
     else if (key == 33) g_tune_small_nw = v;
     else if (key == 35) g_tune_small_nw_big = v;
