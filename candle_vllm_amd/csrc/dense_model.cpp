@@ -545,6 +545,8 @@ int mi355_dense_forward(void* mp, const uint32_t* tokens, const int64_t* positio
             } else {
                 int ps = choose_partition(T, Hkv, max_context_len);
                 if (ps > 0) ps = 32;   // MFMA kernel: 32-token partitions, 4 per workgroup (measured at batch 32: 32 -> 4937, 64 -> 4784, 128 -> ~4500 tok/s)
+                if (ps > 0 && mi355_pa_stream_auto(T, H, Hkv, D, c.block_size)) ps = 64;   // the balanced LDS-DMA stream over the e4m3fn cache, as the GGUF driver
+                if (ps > 0 && mi355_host_get_partition_override() > 0) ps = mi355_host_get_partition_override();
                 if (ps > 0 && (max_context_len + ps - 1) / ps > m->pa_cap_partitions) return (int)hipErrorInvalidValue;
                 DCHECK(mi355_paged_attention_fp8(m->attn, m->pa_sum, m->pa_max, m->pa_tmp, m->q, m->kcache[l], m->vcache[l],
                                                  block_tables, context_lens, T, H, Hkv, D, c.block_size, max_blocks,

@@ -130,6 +130,12 @@ extern "C" int mi355_internal_paged_attention_v2_partials(void* out, float* exp_
                                                           int32_t* w_out);                                                   // paged_attention.hip
 extern "C" int mi355_internal_pa_stream_reduce(void* out, const float* tmp_out, const float* max_logits, const float* exp_sums,
                                                const uint32_t* context_lens, int32_t B, int32_t H, int32_t W, int32_t slots, int64_t stream);
+extern "C" int mi355_internal_paged_attention_fp8_partials(void* out, float* exp_sums, float* max_logits, float* tmp_out, const void* q,
+                                                           const void* key_cache, const void* value_cache, const uint32_t* block_tables,
+                                                           const uint32_t* context_lens, int32_t num_seqs, int32_t num_heads,
+                                                           int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                                                           int32_t max_blocks_per_seq, int32_t max_context_len, int32_t partition_size,
+                                                           float scale, float softcap, float k_scale, float v_scale, int64_t stream, int32_t* w_out);
 extern "C" int mi355_internal_pa_stream_reduce_to_image(void* out, const float* tmp_out, const float* max_logits, const float* exp_sums,
                                                         const uint32_t* context_lens, int32_t B, int32_t H, int32_t W, int32_t slots,
                                                         int64_t stream);                                                     // qmatmul.hip
@@ -426,8 +432,23 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
                                                MI355_DTYPE_BF16, st);
         int ps = choose_partition(B, Hkv, in.ctx_cap);
         if (ps > 0) ps = 32;   // MFMA kernel: 32-token partitions, 4 per workgroup (measured at batch 32: 32 -> 4937, 64 -> 4784, 128 -> ~4500 tok/s)
+        // >= 64 (sequence, kv head) pairs: the balanced LDS-DMA stream over the e4m3fn cache (round 5), as on the bf16 cache
+        if (ps > 0 && mi355_pa_stream_auto(B, H, Hkv, D, c.block_size)) ps = 64;
+        if (g_host_ps_override > 0 && ps > 0) ps = g_host_ps_override;
         if (ps > 0 && (in.ctx_cap + ps - 1) / ps > m->pa_cap_partitions) return (int)hipErrorInvalidValue;
         if (in.ctx_cap > c.max_seq) return (int)hipErrorInvalidValue;
+        if (ps == 64 && B >= 9 && B <= 32 && !(H & 1) && !m->use_comm) {
+            // as on the bf16 cache below: the merge of the stream's partials also stages wo's activation image
+            int32_t w = 0;
+            RCHECK(mi355_internal_paged_attention_fp8_partials(in.attn, m->pa_sum, m->pa_max, m->pa_tmp, in.q, m->kcache[l], m->vcache[l], in.bt,
+                                                               in.ctx, B, H, Hkv, D, c.block_size, in.max_blocks, in.ctx_cap, ps, scale, 0.f, 1.f, 1.f,
+                                                               st, &w));
+            if (w == 0) return 0;                                     // the launch did not take the stream: it is complete
+            const int max_partitions = (in.ctx_cap + ps - 1) / ps < 1 ? 1 : (in.ctx_cap + ps - 1) / ps;
+            const int rc = mi355_internal_pa_stream_reduce_to_image(in.attn, m->pa_tmp, m->pa_max, m->pa_sum, in.ctx, B, H, w, max_partitions, st);
+            if (rc != -4) return rc;
+            return mi355_internal_pa_stream_reduce(in.attn, m->pa_tmp, m->pa_max, m->pa_sum, in.ctx, B, H, w, max_partitions, st);
+        }
         return mi355_paged_attention_fp8(in.attn, m->pa_sum, m->pa_max, m->pa_tmp, in.q, m->kcache[l], m->vcache[l], in.bt, in.ctx,
                                          B, H, Hkv, D, c.block_size, in.max_blocks, in.ctx_cap, ps, scale, 0.f, 1.f, 1.f, st);
     }

@@ -1279,15 +1279,22 @@ __global__ void __launch_bounds__(256, 1) paged_attn_lds_kernel(const PAParams p
 #ifndef PAS_RING
 #define PAS_RING 3
 #endif
-template <int R, bool TS = false>
+// KV8 (`--kvcache-dtype fp8`, token split only): the cache holds e4m3fn bytes -- K [NB][Hkv][D/16][bs][16], V [NB][Hkv][D][bs] -- so a stage is
+// 16 KiB: K [8 channel groups][64 slots of 16 B = one token's 16 channels], V [128 channels][4 slots of 16 B = 16 tokens] (slot s of channel
+// ch holds row slot s ^ ((ch >> 2) & 3): the 4-byte fragment reads of a wave land on 64 different banks).  Same DMA engine, half the
+// requests; the lane's bytes become bf16 (exact: 3 mantissa bits) on their way into the MFMA operands; scores carry k_scale, the
+// partial's output v_scale (attention.rs:896, is_fp8_keys).
+template <int R, bool TS = false, bool KV8 = false>
 __global__ void __launch_bounds__(256, 1) paged_attn_stream_kernel(const PAParams p, const int B, const uint32_t* __restrict__ btab,
                                                                     const uint32_t* __restrict__ clens) {
     // (btab / clens = p.block_tables / p.context_lens once more, as __restrict__ kernel arguments: only then does the compiler know that
     // the partial stores cannot clobber them and fetches the wave-uniform table entries with s_load -- through the struct it used
     // vector loads, whose waits drained the DMA queue every stage)
     constexpr int D = 128, D32 = 4, QSEG = 4;
-    constexpr uint32_t STAGE_B = 32768u;
-    extern __shared__ __attribute__((aligned(1024))) uint8_t pas_smem[];   // ring [R][32 KiB] | Q [QSEG][16 heads][128] bf16
+    static_assert(!KV8 || TS, "the fp8 cache takes the token split");
+    constexpr uint32_t STAGE_B = KV8 ? 16384u : 32768u;
+    constexpr int NDMA = KV8 ? 4 : 8;                                 // DMA instructions per wave and stage
+    extern __shared__ __attribute__((aligned(1024))) uint8_t pas_smem[];   // ring [R][stage] | Q [QSEG][16 heads][128] bf16 (| KV8: 32 KiB merge scratch)
     const int w = blockIdx.x, W = gridDim.x, hk = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int c = lane & 15, kg = lane >> 4;
@@ -1350,11 +1357,32 @@ __global__ void __launch_bounds__(256, 1) paged_attn_stream_kernel(const PAParam
         const int bq = seq_of(f);
         const int sq = f - (__builtin_amdgcn_readlane(pend, bq) - __builtin_amdgcn_readlane(n_l, bq));
         const int t1q = __builtin_amdgcn_readlane(ctx_l, bq);
-        const uint32_t dst = lds0 + (uint32_t)(i % R) * STAGE_B + (uint32_t)wave * 8192u;
+        const uint32_t dst = lds0 + (uint32_t)(i % R) * STAGE_B + (uint32_t)wave * (STAGE_B / 4);
         auto block_of = [&](int tok) {                                // tok: token of the stage (0..63)
             const int e = tok >> bs_shift;
             return (int64_t)(e == 0 ? ent[0] : (e == 1 ? ent[1] : (e == 2 ? ent[2] : ent[3])));
         };
+        if constexpr (KV8) {
+            if (wave < 2) {                                           // K: channel groups 4 wave .. 4 wave + 3, lane = slot
+                int tok = ktok;
+                if (64 * sq + tok >= t1q) tok = 0;
+                const int64_t blk = block_of(tok);
+                const int off = tok & (bs - 1);
+                const uint8_t* src = kc8 + ((blk * p.Hkv + hk) * 8 + 4 * wave) * (int64_t)bs * 16 + (int64_t)off * 16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pa_dma16(src + (int64_t)q * bs * 16, dst + (uint32_t)q * 1024u);
+            } else {                                                  // V: piece q = channels 16 q' + (lane >> 2), LDS slot lane & 3
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ch = 16 * (4 * (wave - 2) + q) + (lane >> 2);
+                    int tok = 16 * ((lane & 3) ^ ((ch >> 2) & 3));
+                    if (64 * sq + tok >= t1q) tok = 0;
+                    const int64_t blk = block_of(tok);
+                    const int off = tok & (bs - 1);
+                    pa_dma16(vc8 + ((blk * p.Hkv + hk) * D + ch) * (int64_t)bs + off, dst + (uint32_t)q * 1024u);
+                }
+            }
+        } else
         if (wave < 2) {
             int tok = ktok;
             if (64 * sq + tok >= t1q) tok = 0;
@@ -1382,7 +1410,7 @@ __global__ void __launch_bounds__(256, 1) paged_attn_stream_kernel(const PAParam
     for (int st = 0; st < R - 1; ++st)
         if (st < ns) { load_ent(f_lo + st, ent); issue(st, f_lo + st, ent); }
     if (R - 1 < ns) load_ent(f_lo + R - 1, ent);                      // for the issue of the first iteration
-    const float qk_scale = p.scale;
+    const float qk_scale = KV8 ? p.scale * p.k_scale : p.scale;
     float m_run = -1e30f, l_run = 0.f;
     constexpr int NO = TS ? 8 : 2;                                    // output tiles of 16 channels per wave
     f32x4_t o[NO];
@@ -1392,9 +1420,9 @@ __global__ void __launch_bounds__(256, 1) paged_attn_stream_kernel(const PAParam
         const int f = f_lo + i;
         {
             const int ahead = min(ns, i + R - 1) - (i + 1);
-            if (ahead >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NDMA) : "memory");
+            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();                                              // everyone's share of stage i; everyone is done with stage i - 1
@@ -1426,8 +1454,21 @@ __global__ void __launch_bounds__(256, 1) paged_attn_stream_kernel(const PAParam
             // MFMAs on the lane's own four probabilities; the four states are merged through LDS once per (sequence, share).
             const int ip = wave >> 1, it = wave & 1;
             uint4 ka[D32];
+            if constexpr (KV8) {
+                // channels 32 j + 8 kg .. + 7 of the tile's token c: half (kg & 1) of the 16-byte slot of channel group 2 j + (kg >> 1)
+                uint2 k8[D32];
+#pragma unroll
+                for (int j = 0; j < D32; ++j)
+                    k8[j] = *reinterpret_cast<const uint2*>(Kb + (2 * j + (kg >> 1)) * 1024 + (32 * ip + 16 * it + c) * 16 + 8 * (kg & 1));
+#pragma unroll
+                for (int j = 0; j < D32; ++j) {
+                    const uint2 lo = fp8x4_to_bf16x4(k8[j].x), hi = fp8x4_to_bf16x4(k8[j].y);
+                    ka[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < D32; ++j) ka[j] = *reinterpret_cast<const uint4*>(Kb + pal_k_read_off(j, kg, ip, it, c));
+            }
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < D32; ++j)
@@ -1464,7 +1505,11 @@ __global__ void __launch_bounds__(256, 1) paged_attn_stream_kernel(const PAParam
                 f32x4_t on = o[n2];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) on[v] *= av[v];
-                uint2 vv = *reinterpret_cast<const uint2*>(Kb + pal_v_read_off(ch, ip, kg) + 8 * it);   // the lane's 4 tokens of channel ch
+                uint2 vv;
+                if constexpr (KV8)                                    // 4 bytes = the lane's 4 tokens: row slot 2 ip + (kg >> 1), byte 8 (kg & 1) + 4 it
+                    vv = fp8x4_to_bf16x4(*reinterpret_cast<const uint32_t*>(Kb + 8192 + ch * 64 + (((2 * ip + (kg >> 1)) ^ ((ch >> 2) & 3)) * 16) + 8 * (kg & 1) + 4 * it));
+                else
+                    vv = *reinterpret_cast<const uint2*>(Kb + pal_v_read_off(ch, ip, kg) + 8 * it);   // the lane's 4 tokens of channel ch
                 vv.x &= vm0; vv.y &= vm1;
                 o[n2] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, pa2), __builtin_bit_cast(s16x4_t, vv), on, 0, 0, 0);
             }
@@ -1478,7 +1523,8 @@ __global__ void __launch_bounds__(256, 1) paged_attn_stream_kernel(const PAParam
                 // exactly ob's 4 x 16 x 128 floats, and the last 512 B ran into the next slot's K / V in flight; they have their own array now)
                 __shared__ float pas_stt[128];                        // [4 waves][16 heads][m, l]
                 float* stt = pas_stt;
-                float* ob = reinterpret_cast<float*>(pas_smem + (size_t)(i % R) * STAGE_B);   // [4 waves][G heads][128 channels]: <= 32 KiB at G <= 16
+                // (KV8: a stage is 16 KiB -- the scratch has its own 32 KiB behind the Q rows)
+                float* ob = reinterpret_cast<float*>((KV8 && G > 8) ? pas_smem + (size_t)R * STAGE_B + 16384 : pas_smem + (size_t)(i % R) * STAGE_B);   // [4 waves][G heads][128 channels]: <= 32 KiB at G <= 16
                 if (kg == 0) { stt[(wave * 16 + c) * 2] = m_run; stt[(wave * 16 + c) * 2 + 1] = lt; }
                 __syncthreads();
 #pragma unroll
@@ -1506,7 +1552,7 @@ __global__ void __launch_bounds__(256, 1) paged_attn_stream_kernel(const PAParam
                         sum += ob[(size_t)(ww * G + head) * D + ch];
                     }
                     const int64_t pi = ((int64_t)b * p.H + hk * G + head) * p.max_partitions + w;
-                    p.tmp_out[pi * D + ch] = sum * (L > 0.f ? 1.f / L : 0.f);
+                    p.tmp_out[pi * D + ch] = sum * (L > 0.f ? 1.f / L : 0.f) * (KV8 ? p.v_scale : 1.f);
                     if (ch == 0) { p.max_logits[pi] = M; p.exp_sums[pi] = L; }
                 }
             }
@@ -1743,6 +1789,30 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
         else
             rc = (dtype == MI355_DTYPE_BF16) ? launch_flash<MI355_DTYPE_BF16, false>(p, B, P, st)
                                              : launch_flash<MI355_DTYPE_F16, false>(p, B, P, st);
+    } else if (layout == MI355_KV_PAGED && dtype == MI355_DTYPE_BF16 && p.kv8 && PAS_TS != 0 && p.partition_size == 64 && P > 1 &&
+               mi355_pa_stream_auto(B, p.H, p.Hkv, p.D, p.block_size)) {
+        // the e4m3fn cache through the same balanced stream (round 5): 16 KiB stages, a ring of 3; the merge scratch of > 8 query heads per
+        // kv head has its own 32 KiB (a stage is too small for it).  A stage of this kernel lasts as long as a bf16 stage of twice the bytes
+        // (1.8 us: the chain K read -> convert -> QK -> softmax shuffles -> P.V of one wave per SIMD, not the DMA: rings of 5 and 6 stages
+        // changed nothing), so TWO workgroups share a CU where their LDS fits (64 KiB each at <= 8 query heads per kv head).  Measured on the
+        // Mixtral-shaped batch-32 step, one box: 32-token MFMA partitions 8.03 ms, this stream one workgroup per CU 8.36, two 7.89.
+        constexpr int PAS_R8 = 3;
+        const int G = p.H / p.Hkv;
+        const size_t shm8 = (size_t)PAS_R8 * 16384 + 16384 + (G > 8 ? 32768 : 0);
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)paged_attn_stream_kernel<PAS_R8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PAS_R8 * 16384 + 16384 + 32768);
+            attr_done = true;
+        }
+        int W = (G > 8 ? 256 : 512) / p.Hkv;
+        if (W < 1) W = 1;
+        if (W > 64) W = 64;
+        if (W > P) W = P;
+        hipLaunchKernelGGL((paged_attn_stream_kernel<PAS_R8, true, true>), dim3(W, p.Hkv), dim3(256), shm8, st, p, B, p.block_tables, p.context_lens);
+        if (g_pa_stream_noreduce) { g_pa_stream_last_w = W; return (int)hipGetLastError(); }   // the caller merges
+        hipLaunchKernelGGL(paged_attn_stream_reduce_kernel, dim3(p.H, B), dim3(128), 0, st, p.out, p.tmp_out, p.max_logits, p.exp_sums,
+                           p.context_lens, B, p.H, W, p.max_partitions);
+        return (int)hipGetLastError();
     } else if (layout == MI355_KV_PAGED && dtype == MI355_DTYPE_BF16 && !p.kv8 && p.partition_size == 64 && P > 1 &&
                mi355_pa_stream_auto(B, p.H, p.Hkv, p.D, p.block_size)) {
         // one balanced stream of 64-token stages per workgroup, W workgroups per kv head; partials merged by the reduce launch.
@@ -2051,6 +2121,22 @@ extern "C" int mi355_internal_paged_attention_v2_partials(void* out, float* exp_
     const int rc = mi355_paged_attention_v2(out, exp_sums, max_logits, tmp_out, q, key_cache, value_cache, block_tables, context_lens, num_seqs,
                                             num_heads, num_kv_heads, head_dim, block_size, max_blocks_per_seq, max_context_len, partition_size,
                                             scale, softcap, layout, dtype, stream);
+    g_pa_stream_noreduce = 0;
+    if (w_out) *w_out = g_pa_stream_last_w;
+    return rc;
+}
+
+/* the same over the e4m3fn cache */
+extern "C" int mi355_internal_paged_attention_fp8_partials(void* out, float* exp_sums, float* max_logits, float* tmp_out, const void* q,
+                                                           const void* key_cache, const void* value_cache, const uint32_t* block_tables,
+                                                           const uint32_t* context_lens, int32_t num_seqs, int32_t num_heads,
+                                                           int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                                                           int32_t max_blocks_per_seq, int32_t max_context_len, int32_t partition_size,
+                                                           float scale, float softcap, float k_scale, float v_scale, int64_t stream, int32_t* w_out) {
+    g_pa_stream_noreduce = 1; g_pa_stream_last_w = 0;
+    const int rc = mi355_paged_attention_fp8(out, exp_sums, max_logits, tmp_out, q, key_cache, value_cache, block_tables, context_lens, num_seqs,
+                                             num_heads, num_kv_heads, head_dim, block_size, max_blocks_per_seq, max_context_len, partition_size,
+                                             scale, softcap, k_scale, v_scale, stream);
     g_pa_stream_noreduce = 0;
     if (w_out) *w_out = g_pa_stream_last_w;
     return rc;

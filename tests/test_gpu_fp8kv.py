@@ -55,9 +55,31 @@ def test_e4m3_cache_write_is_bit_exact(cv):
                                                 (8, 2, 128, 16, [200, 33], 32), (4, 2, 80, 16, [50], 0),
                                                 (8, 2, 128, 64, [700, 300, 64, 257], 256), (8, 2, 128, 16, [1100, 33], 512)])
 def test_decode_attention_over_fp8_cache(cv, H, Hkv, D, bs, ctxs, ps):
+    _decode_case(cv, H, Hkv, D, bs, ctxs, ps)
+
+
+@pytest.mark.parametrize("H,Hkv,bs,ctxs,force", [(8, 2, 64, [300, 64, 129, 700], True), (28, 4, 16, None, False), (16, 1, 32, [513, 64, 1, 90, 2000], True),
+                                                 (32, 8, 32, None, False), (6, 2, 16, [65, 127, 128, 129], True)])
+def test_decode_attention_over_fp8_cache_balanced_stream(cv, H, Hkv, bs, ctxs, force):
+    """round 5: >= 64 (sequence, kv head) pairs at partition size 64 stream the e4m3fn cache through the LDS-DMA ring in 16 KiB stages
+    (`paged_attn_stream_kernel<3, true, true>`): ragged contexts whose last stage is masked, 1..16 query heads per kv head, block sizes
+    16 / 32 / 64, stale NaN bytes in unused slots; small launches are forced onto it (tuning key 44 = 3).  Against the oracle over the
+    dequantised cache, and against the 32-token MFMA partitions (key 44 = 0) to the rounding of the bf16 output."""
+    from candle_vllm_amd import tuning
+    if ctxs is None:                                               # natural: 16 or 8 sequences x 4 or 8 kv heads = 64 pairs
+        rng = np.random.default_rng(H)
+        ctxs = [int(c) for c in rng.integers(1, 1500, 64 // Hkv)]
+    with tuning(44, 3 if force else 1):
+        got = _decode_case(cv, H, Hkv, 128, bs, ctxs, 64, seed=7)
+    with tuning(44, 0):
+        base = _decode_case(cv, H, Hkv, 128, bs, ctxs, 32, seed=7)
+    assert np.abs(got - base).max() <= 2.0 ** -7 * max(1.0, np.abs(base).max())
+
+
+def _decode_case(cv, H, Hkv, D, bs, ctxs, ps, seed=0):
     if D % 16:
         pytest.skip("x = 16 layout needs head_dim % 16 == 0")
-    rng = np.random.default_rng(D + bs + len(ctxs))
+    rng = np.random.default_rng(D + bs + len(ctxs) + seed)
     B = len(ctxs)
     nblk = [-(-c // bs) for c in ctxs]
     NB = sum(nblk) + 2
@@ -93,6 +115,7 @@ def test_decode_attention_over_fp8_cache(cv, H, Hkv, D, bs, ctxs, ps):
     got = bf16_host(out)
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() <= 2e-2 * max(1.0, np.abs(ref).max())     # bf16 P and output rounding
+    return got
 
 
 @pytest.mark.parametrize("generic", [0, 1])
