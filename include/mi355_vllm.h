@@ -299,7 +299,8 @@ int mi355_moe_scatter_combine(float* ys, const float* y_sorted, const float* wei
  *   24  "exact" activations on the 9..32-token and prompt paths: f16 hi + lo planes instead of one f16 plane (0, default)
  *   30  16-bit / GPTQ linears, bit mask of folded launches switched OFF: 1 the 1..4-token 4-bit kernel, 2 no RMSNorm on the way in,
  *       4 RoPE + cache write in their own launch, 8 the LDS-shared-activation 16-bit kernel, 16 the one-pass 4-bit prompt GEMM;
- *       32 switches ON the 256-token tile of the 16-bit prompt GEMM where it fills the chip twice (64 as well: wherever it runs)
+ *       32 switches ON the 256-token tile of the 16-bit prompt GEMM where it fills the chip twice (64 as well: wherever it runs);
+ *       128 the 5..48-token LDS-shared-activation 4-bit kernel, 256 its gate/up pairs split over two waves
  *   41  MoE decode steps group their (token, slot) pairs by expert on the device: 1 (default) = all experts in the z extent of one
  *       launch per kernel (mi355_qmm_desc.group_count); 2 = grouped, one launch group per expert; 0 = one mat-vec per pair
  *   44  decode-attention kernel per partition size on the PAGED bf16 cache: 1 (default) = 256 / 512 as looped chunks, 64 as the
