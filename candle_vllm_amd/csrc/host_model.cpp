@@ -136,6 +136,9 @@ extern "C" int mi355_internal_paged_attention_fp8_partials(void* out, float* exp
                                                            int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
                                                            int32_t max_blocks_per_seq, int32_t max_context_len, int32_t partition_size,
                                                            float scale, float softcap, float k_scale, float v_scale, int64_t stream, int32_t* w_out);
+extern "C" int mi355_internal_moe_stage_grouped(const float* xs, const int32_t* ids, int32_t pairs, int32_t top_k, int32_t n_expert, int32_t cap,
+                                                int32_t r0, int32_t rows, int32_t hidden, const float* norm_w, int32_t* pos_out,
+                                                int32_t* counts_out, const float* x_key, int64_t stream);             // qmatmul.hip
 extern "C" int mi355_internal_pa_stream_reduce_to_image(void* out, const float* tmp_out, const float* max_logits, const float* exp_sums,
                                                         const uint32_t* context_lens, int32_t B, int32_t H, int32_t W, int32_t slots,
                                                         int64_t stream);                                                     // qmatmul.hip
@@ -353,8 +356,19 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
             // one kernel adds the weighted rows to the residual.  Per pair (below) a batch-32 Mixtral step reads 64 experts per
             // layer; here 8 experts x 2 chunks.
             RCHECK(mi355_moe_route(in.moe_ids, in.moe_w, in.xs, L.ffn_norm, c.rms_eps, L.gate_inp, B, hid, c.n_expert, K, st));
-            RCHECK(mi355_moe_group(m->g_moe_pos, m->g_moe_cnt, in.moe_ids, pairs, c.n_expert, m->g_cap, st));
-            RCHECK(mi355_moe_gather_pos(m->g_moe_xg, in.xs, m->g_moe_pos, pairs, K, hid, st));
+            // grouping, row gather and image staging as ONE launch per chunk where the grouped call takes the one-launch path (key 41 = 1);
+            // otherwise (-4) the pairs are grouped and their rows gathered first
+            bool staged = false;
+            if (g_moe_group == 1) {
+                const int rs = mi355_internal_moe_stage_grouped(in.xs, in.moe_ids, pairs, K, c.n_expert, m->g_cap, 0, 32, hid, L.ffn_norm, m->g_moe_pos,
+                                                                m->g_moe_cnt, m->g_moe_xg, st);
+                if (rs != 0 && rs != -4) return rs;
+                staged = rs == 0;
+            }
+            if (!staged) {
+                RCHECK(mi355_moe_group(m->g_moe_pos, m->g_moe_cnt, in.moe_ids, pairs, c.n_expert, m->g_cap, st));
+                RCHECK(mi355_moe_gather_pos(m->g_moe_xg, in.xs, m->g_moe_pos, pairs, K, hid, st));
+            }
             // key 41 = 1: ALL experts in the z extent of one launch each (mi355_qmm_desc.group_count): 5 launches per chunk instead of 5 per
             // (expert, chunk); = 2: one launch group per expert (A/B).  A chunk no pair landed in (the expert's count, on the device, <= its
             // first row) falls through every kernel
@@ -363,6 +377,9 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
                 for (int r0 = 0; r0 < B; r0 += 32) {                 // an expert holds at most one row per token
                     const int rows = 32;                              // (the gate is built into the 9..32-token launches)
                     const size_t off = (size_t)e * m->g_cap + r0;
+                    if (staged && r0 > 0)                             // the next chunk's images (chunk 0's were staged above)
+                        RCHECK(mi355_internal_moe_stage_grouped(in.xs, in.moe_ids, pairs, K, c.n_expert, m->g_cap, r0, 32, hid, L.ffn_norm,
+                                                                m->g_moe_pos, m->g_moe_cnt, m->g_moe_xg + (size_t)r0 * hid, st));
                     mi355_qmm_desc g;
                     memset(&g, 0, sizeof(g));
                     g.nseg = 2;

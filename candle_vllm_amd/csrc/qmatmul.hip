@@ -2333,6 +2333,40 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
     return 0;
 }
 
+/* internal (host_model.cpp, grouped experts of a decode step): route ids -> the grouped activation images of the NEXT grouped
+ * mi355_qmatmul_fused call on this stream (x = x_key, `rows` tokens, k = hidden, the same norm weight, group_count = n_expert,
+ * group_x_stride = cap * hidden), which finds them through the chain state and skips its staging launch; also leaves pos[] and counts[]
+ * (mi355_moe_group's outputs).  -4: this configuration does not take the one-launch grouped path -- the caller groups and gathers. */
+extern "C" int mi355_internal_moe_stage_grouped(const float* xs, const int32_t* ids, int32_t pairs, int32_t top_k, int32_t n_expert, int32_t cap,
+                                                int32_t r0, int32_t rows, int32_t hidden, const float* norm_w, int32_t* pos_out,
+                                                int32_t* counts_out, const float* x_key, int64_t stream) {
+    if (!xs || !ids || !pos_out || !counts_out || pairs < 1 || top_k < 1 || n_expert < 2 || cap < pairs || (hidden % 256) || rows < 9 ||
+        rows > 8 * QMW_MAXMT)
+        return -4;
+    if (g_tune_exact_act || g_qmm_exact || (rows >= g_tune_qpg_min && g_tune_prefill_gemm)) return -4;
+    hipStream_t st = to_stream(stream);
+    const int MT = rows <= 16 ? 1 : 2, BP = MT * 16, nkb = hidden / 256;
+    const size_t kbb = qw1_kb_bytes(MT);
+    QmgStream& qs = qmg_stream(st);
+    qs.chain.valid = false;
+    const int cur = qs.cur;
+    const size_t imgb = (kbb * nkb + (size_t)nkb * BP * sizeof(float) + 1023) / 1024 * 1024;
+    void* imgp = nullptr;
+    const int rc = qmg_buf(&imgp, cur ? MI355_SCR_QMM_IMG1 : MI355_SCR_QMM_IMG0, (size_t)n_expert * imgb, st);
+    if (rc) return rc;
+    uint8_t* img = static_cast<uint8_t*>(imgp);
+    float* ssp = reinterpret_cast<float*>(img + kbb * nkb);
+    if (MT == 1)
+        hipLaunchKernelGGL((qw1_prep_moe_kernel<1>), dim3(nkb, 2, n_expert), dim3(256), 0, st, img, ssp, xs, ids, pairs, top_k, n_expert, cap, r0,
+                           hidden, norm_w, kbb, (int64_t)imgb, pos_out, counts_out);
+    else
+        hipLaunchKernelGGL((qw1_prep_moe_kernel<2>), dim3(nkb, 4, n_expert), dim3(256), 0, st, img, ssp, xs, ids, pairs, top_k, n_expert, cap, r0,
+                           hidden, norm_w, kbb, (int64_t)imgb, pos_out, counts_out);
+    qs.chain = QmgChainState{true, x_key, rows, hidden, MT, cur, norm_w, st, 1};
+    qs.chain.grp = n_expert; qs.chain.grp_stride = (int64_t)cap * hidden;
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ C ABI
 extern "C" int mi355_qmatmul(float* out, const float* x, const void* w_tiles, int32_t ggml_type, int32_t T,
                              int32_t N, int32_t K, const float* bias, int64_t stream) {
