@@ -139,6 +139,8 @@ extern "C" int mi355_internal_paged_attention_fp8_partials(void* out, float* exp
 extern "C" int mi355_internal_moe_stage_grouped(const float* xs, const int32_t* ids, int32_t pairs, int32_t top_k, int32_t n_expert, int32_t cap,
                                                 int32_t r0, int32_t rows, int32_t hidden, const float* norm_w, int32_t* pos_out,
                                                 int32_t* counts_out, const float* x_key, int64_t stream);             // qmatmul.hip
+extern "C" int mi355_internal_moe_scatter_combine_to_image(float* ys, const float* y_rows, const float* weights, const int32_t* inv, int32_t num_tokens,
+                                                           int32_t hidden, int32_t top_k, const float* next_norm_w, int64_t stream);   // qmatmul.hip
 extern "C" int mi355_internal_pa_stream_reduce_to_image(void* out, const float* tmp_out, const float* max_logits, const float* exp_sums,
                                                         const uint32_t* context_lens, int32_t B, int32_t H, int32_t W, int32_t slots,
                                                         int64_t stream);                                                     // qmatmul.hip
@@ -409,7 +411,14 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
                     RCHECK(mi355_qmatmul_fused(&dn, st));
                 }
             }
-            RCHECK(mi355_moe_scatter_combine(in.xs, m->g_moe_yg, in.moe_w, m->g_moe_pos, B, hid, K, st));
+            {   // + residual; where the next mat-mul reads xs on the 9..32-token path the same launch stages its activation image
+                int rs = -4;
+                if (!m->use_comm && g_moe_group == 1)
+                    rs = mi355_internal_moe_scatter_combine_to_image(in.xs, m->g_moe_yg, in.moe_w, m->g_moe_pos, B, hid, K,
+                                                                     (l + 1 < c.n_layers) ? m->layers[l + 1].attn_norm : m->output_norm, st);
+                if (rs == -4) rs = mi355_moe_scatter_combine(in.xs, m->g_moe_yg, in.moe_w, m->g_moe_pos, B, hid, K, st);
+                if (rs) return rs;
+            }
             m->moe_grouped_done = true;
             return 0;
         }

@@ -2367,6 +2367,51 @@ extern "C" int mi355_internal_moe_stage_grouped(const float* xs, const int32_t* 
     return (int)hipGetLastError();
 }
 
+// The weighted expert rows added to the residual stream (mi355_moe_scatter_combine's arithmetic, bit for bit) AND the activation image of
+// the next 9..32-token mat-mul that reads the residual stream (the next layer's q|k|v or the lm_head; its RMSNorm weight = next_norm_w):
+// workgroup (256 columns, token row) = one (row, k-block) of the image, as in the chained epilogue.  grid.y covers the padded rows.
+__global__ void __launch_bounds__(256) moe_scatter_combine_img_kernel(float* __restrict__ ys, const float* __restrict__ yg, const float* __restrict__ wts,
+                                                                      const int32_t* __restrict__ inv, const int hidden, const int K, const int B,
+                                                                      const QmgChainOut ch) {
+    const int t = blockIdx.y;
+    const int i = blockIdx.x * 256 + (int)threadIdx.x;
+    float acc = 0.f;
+    if (t < B) {
+        acc = ys[(size_t)t * hidden + i];                               // residual (quantized_llama.rs:470)
+        for (int j = 0; j < K; ++j) acc = fmaf(wts[(size_t)t * K + j], yg[(size_t)inv[t * K + j] * hidden + i], acc);
+        ys[(size_t)t * hidden + i] = acc;
+    }
+    __shared__ float sm_o[256];
+    sm_o[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = sm_o[threadIdx.x * 8 + q];
+        qw1_prep_entry(ch.img, ch.ssp, v, t < B, ch.norm_w, ch.MT, ch.kbb, (int)blockIdx.x, t, (int)threadIdx.x);
+    }
+}
+/* internal (host_model.cpp): -4 = this configuration does not chain (the caller runs mi355_moe_scatter_combine) */
+extern "C" int mi355_internal_moe_scatter_combine_to_image(float* ys, const float* y_rows, const float* weights, const int32_t* inv, int32_t num_tokens,
+                                                           int32_t hidden, int32_t top_k, const float* next_norm_w, int64_t stream) {
+    if (!ys || !y_rows || !weights || !inv || top_k < 1 || (hidden % 256) || num_tokens < 9 || num_tokens > 8 * QMW_MAXMT) return -4;
+    if (!g_tune_chain || g_tune_exact_act || g_qmm_exact || (num_tokens >= g_tune_qpg_min && g_tune_prefill_gemm)) return -4;
+    hipStream_t st = to_stream(stream);
+    const int MT = num_tokens <= 16 ? 1 : 2, BP = MT * 16, nkb = hidden / 256;
+    const size_t kbb = qw1_kb_bytes(MT);
+    QmgStream& qs = qmg_stream(st);
+    qs.chain.valid = false;
+    const int other = qs.cur ^ 1;
+    void* imgp = nullptr;
+    const int rc = qmg_buf(&imgp, other ? MI355_SCR_QMM_IMG1 : MI355_SCR_QMM_IMG0, kbb * nkb + (size_t)nkb * BP * sizeof(float), st);
+    if (rc) return rc;
+    uint8_t* img = static_cast<uint8_t*>(imgp);
+    const QmgChainOut ch{img, reinterpret_cast<float*>(img + kbb * nkb), next_norm_w, hidden, MT, kbb, 1};
+    hipLaunchKernelGGL(moe_scatter_combine_img_kernel, dim3(nkb, BP), dim3(256), 0, st, ys, y_rows, weights, inv, hidden, top_k, num_tokens, ch);
+    qs.chain = QmgChainState{true, ys, num_tokens, hidden, MT, other, next_norm_w, st, 1};
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ C ABI
 extern "C" int mi355_qmatmul(float* out, const float* x, const void* w_tiles, int32_t ggml_type, int32_t T,
                              int32_t N, int32_t K, const float* bias, int64_t stream) {
