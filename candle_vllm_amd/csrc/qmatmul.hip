@@ -1320,8 +1320,9 @@ __global__ void __launch_bounds__(256) qmm_epilogue_grp_kernel(const QmmArgs a, 
                                                                const QmgChainOut ch0, const QwGroup g) {
     const int e = blockIdx.z;
     const int nb = a.rows_dev ? min(a.B, a.rows_dev[e] - a.rows_min) : a.B;
-    if (nb <= 0) return;
-    if ((int)blockIdx.y >= nb && !ch0.img) return;
+    // rows past the group's count: nothing to sum, and no image entry either -- every kernel of the path keeps rows apart (a row of the
+    // next mat-mul's image only ever meets its own scale, sums and accumulators), so what the next launch finds there is never stored
+    if ((int)blockIdx.y >= nb) return;
     QmgChainOut ch = ch0;
     if (ch.img) {
         ch.img += (size_t)e * g.chimg;
