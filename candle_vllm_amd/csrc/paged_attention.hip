@@ -1281,7 +1281,8 @@ __global__ void __launch_bounds__(256, 1) paged_attn_lds_kernel(const PAParams p
 #endif
 // KV8 (`--kvcache-dtype fp8`, token split only): the cache holds e4m3fn bytes -- K [NB][Hkv][D/16][bs][16], V [NB][Hkv][D][bs] -- so a stage is
 // 16 KiB: K [8 channel groups][64 slots of 16 B = one token's 16 channels], V [128 channels][4 slots of 16 B = 16 tokens] (slot s of channel
-// ch holds row slot s ^ ((ch >> 2) & 3): the 4-byte fragment reads of a wave land on 64 different banks).  Same DMA engine, half the
+// ch holds row slot s ^ ((ch >> 2) & 3): the 4-byte fragment reads of a wave instruction hit each of their 32 reachable banks twice -- the
+// floor of this placement, pa_lds_layout.h / tests/test_cpu_pa_lds_layout.py).  Same DMA engine, half the
 // requests; the lane's bytes become bf16 (exact: 3 mantissa bits) on their way into the MFMA operands; scores carry k_scale, the
 // partial's output v_scale (attention.rs:896, is_fp8_keys).
 template <int R, bool TS = false, bool KV8 = false>
@@ -1374,8 +1375,8 @@ __global__ void __launch_bounds__(256, 1) paged_attn_stream_kernel(const PAParam
             } else {                                                  // V: piece q = channels 16 q' + (lane >> 2), LDS slot lane & 3
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int ch = 16 * (4 * (wave - 2) + q) + (lane >> 2);
-                    int tok = 16 * ((lane & 3) ^ ((ch >> 2) & 3));
+                    const int ch = pal8_dma_row(8 + 4 * (wave - 2) + q, lane);
+                    int tok = pal8_dma_token(8 + 4 * (wave - 2) + q, lane);
                     if (64 * sq + tok >= t1q) tok = 0;
                     const int64_t blk = block_of(tok);
                     const int off = tok & (bs - 1);
@@ -1459,7 +1460,7 @@ __global__ void __launch_bounds__(256, 1) paged_attn_stream_kernel(const PAParam
                 uint2 k8[D32];
 #pragma unroll
                 for (int j = 0; j < D32; ++j)
-                    k8[j] = *reinterpret_cast<const uint2*>(Kb + (2 * j + (kg >> 1)) * 1024 + (32 * ip + 16 * it + c) * 16 + 8 * (kg & 1));
+                    k8[j] = *reinterpret_cast<const uint2*>(Kb + pal8_k_read_off(j, kg, ip, it, c));
 #pragma unroll
                 for (int j = 0; j < D32; ++j) {
                     const uint2 lo = fp8x4_to_bf16x4(k8[j].x), hi = fp8x4_to_bf16x4(k8[j].y);
@@ -1507,7 +1508,7 @@ __global__ void __launch_bounds__(256, 1) paged_attn_stream_kernel(const PAParam
                 for (int v = 0; v < 4; ++v) on[v] *= av[v];
                 uint2 vv;
                 if constexpr (KV8)                                    // 4 bytes = the lane's 4 tokens: row slot 2 ip + (kg >> 1), byte 8 (kg & 1) + 4 it
-                    vv = fp8x4_to_bf16x4(*reinterpret_cast<const uint32_t*>(Kb + 8192 + ch * 64 + (((2 * ip + (kg >> 1)) ^ ((ch >> 2) & 3)) * 16) + 8 * (kg & 1) + 4 * it));
+                    vv = fp8x4_to_bf16x4(*reinterpret_cast<const uint32_t*>(Kb + pal8_v_read_off(ch, ip, kg, it)));
                 else
                     vv = *reinterpret_cast<const uint2*>(Kb + pal_v_read_off(ch, ip, kg) + 8 * it);   // the lane's 4 tokens of channel ch
                 vv.x &= vm0; vv.y &= vm1;
@@ -1906,7 +1907,7 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
 
 // host-side view of the LDS stage layout of paged_attn_lds_kernel (tests only): what = 0 row (channel group / channel) and 1 first token
 // of the 16 bytes DMA piece a, lane b copies; 2 byte offset of the K fragment read (j, kg, ip, it, r) = (a, b, c, d, e); 3 of the V
-// fragment read (channel, ip, kg) = (a, b, c); 4 the stream kernel's cut (S, W, w) = (a, b, c)
+// fragment read (channel, ip, kg) = (a, b, c); 4 the stream kernel's cut (S, W, w) = (a, b, c); 5..8 the same four views of the e4m3fn stage
 extern "C" int32_t mi355_internal_pal_layout(int32_t what, int32_t a, int32_t b, int32_t c, int32_t d, int32_t e) {
     switch (what) {
     case 0: return pal_dma_row(a, b);
@@ -1914,6 +1915,10 @@ extern "C" int32_t mi355_internal_pal_layout(int32_t what, int32_t a, int32_t b,
     case 2: return pal_k_read_off(a, b, c, d, e);
     case 3: return pal_v_read_off(a, b, c);
     case 4: return (int32_t)pas_cut(a, b, c);                         // first flat stage of workgroup c of b, S = a stages in all
+    case 5: return pal8_dma_row(a, b);                                // the e4m3fn stage (16 pieces): row / first token of piece a, lane b
+    case 6: return pal8_dma_token(a, b);
+    case 7: return pal8_k_read_off(a, b, c, d, e);                    // 8-byte K fragment read (j, kg, ip, it, r)
+    case 8: return pal8_v_read_off(a, b, c, d);                       // 4-byte V fragment read (channel, ip, kg, it)
     default: return -1;
     }
 }

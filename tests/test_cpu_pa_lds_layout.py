@@ -126,3 +126,66 @@ def test_stream_cuts_cover_every_stage_once_and_the_reduce_finds_the_workgroups(
             meets = {w for w in range(W) if cuts[w] < cuts[w + 1] and cuts[w] < pe and cuts[w + 1] > ps}
             assert meets == {w for (bb, w) in wrote if bb == b} and meets
 
+
+
+def _stage_image_fp8(pal):
+    """uint16 image [16384] of one e4m3fn stage, one element per BYTE; value: K -> token * 128 + channel, V -> 0x4000 | (token * 128 + channel)"""
+    img = np.full(16384, 0xFFFF, np.uint16)
+    written = np.zeros(16384, bool)
+    for q in range(16):
+        for lane in range(64):
+            row, tok = pal(5, q, lane), pal(6, q, lane)
+            dst = q * 1024 + lane * 16
+            if q < 8:         # 16 bytes = the 16 channels of channel group `row` of token `tok`
+                vals = [tok * 128 + 16 * row + e for e in range(16)]
+            else:             # 16 bytes = tokens tok .. tok + 15 of channel `row`
+                assert tok % 16 == 0 and 0 <= tok < 64 and 0 <= row < 128
+                vals = [0x4000 | ((tok + e) * 128 + row) for e in range(16)]
+            assert not written[dst:dst + 16].any()
+            img[dst:dst + 16] = vals
+            written[dst:dst + 16] = True
+    assert written.all()
+    return img
+
+
+def test_fp8_stage_every_granule_once_and_the_fragments_the_token_split_needs(pal):
+    """round 5, paged_attn_stream_kernel<.., KV8>: the 16 KiB stage of the e4m3fn cache -- written as the 16 DMA pieces write it, read back as
+    the lanes of the token split read it: K tile (ip, it), row r, k-group kg, step j -> 8 bytes = channels 32 j + 8 kg .. + 7 of token
+    32 ip + 8 (r >> 2) + (r & 3) + 4 it (the bf16 stage's token order: masks and softmax indexing are shared); V channel ch, tile (ip, it),
+    k-group kg -> 4 bytes = tokens 32 ip + 8 kg + 4 it .. + 3 (the lane's four probabilities)."""
+    img = _stage_image_fp8(pal)
+    k, v = img[:8192], img[8192:]
+    assert sorted(k.tolist()) == list(range(64 * 128))
+    assert sorted((v & 0x3FFF).tolist()) == list(range(64 * 128)) and (v & 0x4000).all()
+    for q in range(16):                                               # full lines on the global side: one K row / sixteen 64-byte V rows
+        assert len({pal(5, q, lane) for lane in range(64)}) == (1 if q < 8 else 16)
+    for ip in range(2):
+        for it in range(2):
+            for j in range(4):
+                for kg in range(4):
+                    for r in range(16):
+                        off = pal(7, j, kg, ip, it, r)
+                        assert off % 8 == 0
+                        tok = 32 * ip + 8 * (r >> 2) + (r & 3) + 4 * it
+                        assert img[off:off + 8].tolist() == [tok * 128 + 32 * j + 8 * kg + e for e in range(8)]
+            for ch in range(128):
+                for kg in range(4):
+                    off = pal(8, ch, ip, kg, it)
+                    assert off % 4 == 0
+                    assert img[off:off + 4].tolist() == [0x4000 | ((32 * ip + 8 * kg + 4 * it + e) * 128 + ch) for e in range(4)]
+
+
+def test_fp8_stage_fragment_reads_are_bank_conflict_free(pal):
+    """64 banks of 4 B.  The 4-byte V reads of a wave instruction (64 lanes: channel 16 n2 + (lane & 15), k-group lane >> 4) all carry the
+    wave's own `it`, which selects the even or the odd banks of a 16-byte slot: 32 banks at best, and the swizzle reaches that floor (every
+    bank of the 32 exactly twice -- two passes, what the 8-byte reads of the bf16 stage take as well; without the swizzle it is 8-way).
+    The 8-byte K reads are served 32 lanes at a time and each half covers 32 different bank pairs."""
+    for ip in range(2):
+        for it in range(2):
+            for n2 in range(8):
+                banks = [(pal(8, 16 * n2 + (lane & 15), ip, lane >> 4, it) // 4) % 64 for lane in range(64)]
+                assert sorted(banks) == sorted(2 * [b for b in range(64) if b % 2 == it % 2]), ("V", ip, it, n2)
+            for j in range(4):
+                for half in range(2):
+                    pairs = [(pal(7, j, lane >> 4, ip, it, lane & 15) // 8) % 32 for lane in range(32 * half, 32 * half + 32)]
+                    assert sorted(pairs) == list(range(32)), ("K", ip, it, j, half)
