@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--blocks", type=int, default=3, help="timed blocks of --steps steps each; the value is the median block")
+    ap.add_argument("--settle-steps", type=int, default=160, help="N > 1 only: untimed steps before the first block (every rank must run the "
+                                                                   "same number of steps, so the time criterion of N = 1 cannot be used)")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--ctx", type=int, default=4096, help="prompt tokens already in the KV cache")
     ap.add_argument("--no-graph", action="store_true")
@@ -266,20 +269,22 @@ def bench_batch32(gm, cfg, args, perm, blocks_per_seq, stream, kv_per_tok):
     bt = perm[: B * blocks_per_seq].reshape(B, blocks_per_seq).astype(np.uint32)
     tokens = rng.integers(0, cfg.vocab, B).astype(np.uint32)
     st = stream.cuda_stream
-    gm.decode_begin(tokens, seq_lens, bt, ctx_cap=int(seq_lens.max()) + K + Wm + 2, stream=st)
-    for _ in range(Wm):
+    import bench_timing
+
+    def reset():
+        gm.decode_begin(tokens, seq_lens, bt, ctx_cap=int(seq_lens.max()) + K + Wm + 2, stream=st)
+
+    def step():
         gm.decode_step(st)
         gm.read_tokens(st)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(K):
-        gm.decode_step(st)
-        gm.read_tokens(st)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    tb = bench_timing.timed_blocks(step, torch.cuda.synchronize, K, warmup=Wm, blocks=3, reset=reset, stats=gm.graph_stats)
+    dt = tb["median_s"]
     mean_ctx = float(seq_lens.mean()) + Wm + (K - 1) / 2.0
     step_bytes = gm.weight_bytes_global + B * (mean_ctx + 1) * kv_per_tok
     return {"value": round(B * K / dt, 1), "unit": "tokens/s", "batch": B, "steps": K, "ms_per_step": round(1e3 * dt / K, 3),
+            "value_min": round(B * K / tb["max_s"], 1), "value_max": round(B * K / tb["min_s"], 1), "value_is": "median of 3 blocks",
+            "blocks_ms_per_step": tb["blocks_ms_per_step"], "settle": tb["settle"],
+            "graph_captures_in_timed_region": tb["graph_captures_in_timed_region"],
             "mean_ctx": round(mean_ctx, 1), "algorithmic_bytes": int(step_bytes),
             "achieved_GBs": round(step_bytes * K / dt / 1e9, 1),
             "roofline_tok_s_at_8TBs": round(B * HBM_PEAK_GBS * 1e9 / step_bytes, 1)}
@@ -295,16 +300,24 @@ def bench_prefill(gm, cfg, perm, blocks_per_seq, T=2048):
     seq = eng.new_sequence(0, rng.integers(0, cfg.vocab, T).tolist())
     eng.allocate([seq])
     meta = eng.prepare_prompt([seq])
-    gm.forward_prefill(meta)                                   # warm-up (workspaces)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    gm.forward_prefill(meta)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    params = gm.weight_bytes_global / 0.5625                   # Q4_K: 0.5625 B per weight (Q6_K rows slightly under-counted)
-    useful = 2.0 * params * T / dt / 1e12
+    import bench_timing
+    tc = bench_timing.timed_calls(lambda: gm.forward_prefill(meta), torch.cuda.synchronize)      # settle by time, then >= 3 calls: median
+    dt = tc["median_s"]
+    # useful flops of the weight GEMMs: 2 x parameters x tokens from the SHAPES (Q4_K and Q6_K tensors alike: one multiply-add per
+    # weight and token), the lm_head on the LAST row only (host_model.cpp runs it on one token per sequence); causal attention counted
+    # separately (QK^T and PV over the lower triangle: 2 x 2 x T^2/2 x H x D per layer)
+    H, Hkv, D, hid, I = cfg.n_heads, cfg.n_kv_heads, cfg.head_dim, cfg.hidden, cfg.intermediate
+    layer_params = 2 * hid * H * D + 2 * hid * Hkv * D + 3 * hid * I
+    gemm_flops = 2.0 * (cfg.n_layers * layer_params * T + cfg.vocab * hid * 1)
+    attn_flops = cfg.n_layers * 2.0 * 2.0 * (T * (T + 1) / 2.0) * H * D
+    useful = gemm_flops / dt / 1e12
     return {"value": round(T / dt, 1), "unit": "prompt tokens/s", "tokens": T, "ms": round(dt * 1e3, 2),
+            "value_min": round(T / tc["max_s"], 1), "value_max": round(T / tc["min_s"], 1), "value_is": "median of %d calls" % len(tc["calls_ms"]),
+            "calls_ms": tc["calls_ms"], "settle": tc["settle"],
             "useful_TFLOPs": round(useful, 1), "frac_of_2.5PF_dense_f16": round(useful / 2500.0, 3),
+            "with_causal_attention_TFLOPs": round((gemm_flops + attn_flops) / dt / 1e12, 1),
+            "flops_counted": "2 x (32 layers x %.1f M projection weights x T + lm_head x 1 token); attention's %.1f TFLOP reported separately"
+                             % (layer_params / 1e6, attn_flops / 1e12),
             "note": "hand-written quantised GEMM (csrc/qmm_prefill.inc): Q4_K/Q6_K unpacked in registers into f16 MFMA operands, "
                     "no weight image in HBM, no library GEMM; activations ONE f16 plane with a power-of-two scale per (token, "
                     "k-block) = 1 MFMA pass (round 2: hi + lo planes, 2 passes; tuning key 24 restores them); whole prompt step "
@@ -399,9 +412,6 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    import __graft_entry__ as ge
-    if rank == 0 or not os.path.exists(ge.LIB):
-        pass
     from candle_vllm_amd import model as M
     for kv in filter(None, os.environ.get("MI355_TUNE", "").split(",")):    # experiments only: "key=value,..."
         k, v = kv.split("=")
@@ -461,27 +471,33 @@ def main():
         graph_mode = bool(int(flag.item()))
     gm.set_graph(graph_mode)
     ctx_cap = args.ctx + K + Wm + 2
-    gm.decode_begin(tokens, seq_lens, bt, ctx_cap=ctx_cap, stream=st)
 
-    def run(n):
-        for _ in range(n):
-            gm.decode_step(st)
-            gm.read_tokens(st)                                # greedy sample -> host every step, as the engine does
+    def reset():                                              # the greedy loop back at the benchmark's start state (same graph shape)
+        gm.decode_begin(tokens, seq_lens, bt, ctx_cap=ctx_cap, stream=st)
 
-    run(Wm)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(K)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
+    def step():
+        gm.decode_step(st)
+        gm.read_tokens(st)                                    # greedy sample -> host every step, as the engine does
+
+    def sync():                                               # the contract's bracket: barrier + device synchronisation
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def reduce_max(dt):
+        if world == 1:
+            return dt
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
+
+    # settle by time (fixed count under TP: every step holds collectives), then >= 3 blocks of: reset, W untimed warm-up steps, EXACTLY K
+    # timed steps between barrier + synchronize, max over ranks; `value` = the median block (bench_timing.py)
+    import bench_timing
+    tb = bench_timing.timed_blocks(step, sync, K, warmup=Wm, blocks=args.blocks, reset=reset, stats=gm.graph_stats,
+                                   fixed_settle_steps=(args.settle_steps if world > 1 else 0), reduce_max=reduce_max)
+    dt = tb["median_s"]
     tok_s = B * K / dt
 
     # ---- algorithmic bytes of one step: every weight byte once + live KV once (+ the write)
@@ -494,12 +510,17 @@ def main():
         "metric": "decode tokens/s (greedy), Llama-3-8B Q4_K GGUF",
         "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": round(1e3 * dt / K, 4), "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+        "scaling": "strong", "vs_baseline": None,
         "dtype": "q4_k/q6_k weights, f32 activations, bf16 KV+attention", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: Llama-3-8B Q4_K_M GGUF shapes, greedy decode, "
                                f"batch={B}, prompt ctx {args.ctx} in paged KV (block 64), {K} decode steps",
                    "batch": B, "ctx_start": args.ctx + 1 + Wm, "ctx_end": args.ctx + Wm + K,
                    "parallelism": f"tp{world}", "graph": bool(graph_mode),
+                   "timing": {"blocks_ms_per_step": tb["blocks_ms_per_step"], "value_is": "median block",
+                              "tokens_per_s_min": round(B * K / tb["max_s"], 2), "tokens_per_s_max": round(B * K / tb["min_s"], 2),
+                              "settle": tb["settle"], "graph_captures_in_timed_region": tb.get("graph_captures_in_timed_region"),
+                              "eager_steps_in_timed_region": tb.get("eager_steps_in_timed_region"),
+                              "graph_captures_total": tb.get("graph_captures_total")},
                    **({"all_reduce": transport, "ranks": world,
                        "wire": ("bf16 (reference numerics)" if args.wire_bf16 else "f32")} if world > 1 else {}),
                    "kv_layout": ("paged K[NB,Hkv,D/8,64,8] V[NB,Hkv,D,64] bf16" if args.kv_layout == "paged"
@@ -515,6 +536,11 @@ def main():
     roofline = gm.dominant_kernel_roofline(stream, HBM_PEAK_GBS)
     if rank == 0:
         out["roofline"] = roofline
+        # `roofline.frac` describes the DOMINANT launch (the best-behaved one of the step); the whole step's time-weighted fraction
+        # -- every algorithmic byte of the step over the step's time -- rides next to it, in `roofline` and in the contract's `config`
+        out["roofline"]["whole_step_frac"] = out["step"]["frac_of_8TBs"]
+        out["config"]["whole_step_frac_of_8TBs"] = out["step"]["frac_of_8TBs"]
+        out["config"]["dominant_launch_frac_of_8TBs"] = roofline["frac"]
         if do_b32:
             out["batch32"] = bench_batch32(gm, cfg, args, perm, blocks_per_seq, stream, kv_per_tok)
             try:

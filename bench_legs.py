@@ -32,13 +32,19 @@ def qwen2_7b():
                  rope_theta=1000000.0, rms_eps=1e-6, qkv_bias=True)
 
 
-def _result(name, workload, B, steps, dt, weight_bytes, kv_bytes, extra=None):
+def _result(name, workload, B, steps, tb, weight_bytes, kv_bytes, extra=None):
+    """tb: bench_timing.timed_blocks result -- `value` is the MEDIAN block of `steps` steps; min / max / every block ride along"""
+    dt = tb["median_s"]
     step_bytes = weight_bytes + kv_bytes
     gbs = step_bytes * steps / dt / 1e9
     r = {"config": name, "workload": workload, "value": round(B * steps / dt, 1), "unit": "tokens/s", "batch": B, "steps": steps,
          "ms_per_step": round(1e3 * dt / steps, 3), "algorithmic_bytes": int(step_bytes), "achieved_GBs": round(gbs, 1),
          "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4), "roofline_tok_s_at_8TBs": round(B * HBM_PEAK_GBS * 1e9 / step_bytes, 1),
-         "graph": True}
+         "graph": True, "value_is": "median of %d blocks" % len(tb["blocks_ms_per_step"]),
+         "value_min": round(B * steps / tb["max_s"], 1), "value_max": round(B * steps / tb["min_s"], 1),
+         "blocks_ms_per_step": tb["blocks_ms_per_step"], "settle": tb["settle"],
+         "graph_captures_in_timed_region": tb.get("graph_captures_in_timed_region"),
+         "eager_steps_in_timed_region": tb.get("eager_steps_in_timed_region")}
     if extra:
         r.update(extra)
     return r
@@ -64,20 +70,20 @@ def _dense_graph_loop(gm, cfg, B, ctxs, steps, warmup, kv_elem):
     stream = torch.cuda.Stream()
     st = stream.cuda_stream
     gm.set_graph(True)
-    gm.decode_begin(tok, np.asarray(ctxs, np.uint32), bt_h, ctx_cap=cap, stream=st)
-    for _ in range(warmup):                                           # the first is eager, the second captures, the rest replay
-        gm.decode_step(st)
-        gm.read_tokens(st)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    import bench_timing
+
+    def reset():
+        gm.decode_begin(tok, np.asarray(ctxs, np.uint32), bt_h, ctx_cap=cap, stream=st)
+
+    def step():
         gm.decode_step(st)
         gm.read_tokens(st)                                            # sampled tokens -> host every step
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    # settle by time (the first step of the shape is eager, the second captures, the rest replay), then 3 blocks of `steps` steps, each
+    # from the same start state behind `warmup` untimed steps
+    tb = bench_timing.timed_blocks(step, torch.cuda.synchronize, steps, warmup=warmup, blocks=3, reset=reset, stats=gm.graph_stats)
     mean_ctx = float(np.mean(ctxs)) + 1 + warmup + (steps - 1) / 2.0
     kv = B * (mean_ctx + 1) * 2 * cfg.n_layers * cfg.n_kv_heads * cfg.head_dim * kv_elem
-    return dt, kv
+    return tb, kv
 
 
 def leg_bf16_b32(steps=16, warmup=3):
@@ -88,9 +94,9 @@ def leg_bf16_b32(steps=16, warmup=3):
     gm = DM.DenseLlama(cfg, max_batch=B, max_blocks_per_seq=80, kv_layout=DM.KV_PAGED)
     gm.load_synthetic()
     gm.alloc_kv_cache(B * 70 + 8)
-    dt, kv = _dense_graph_loop(gm, cfg, B, ctxs, steps, warmup, 2)
+    tb, kv = _dense_graph_loop(gm, cfg, B, ctxs, steps, warmup, 2)
     return _result("bf16_b32", "BASELINE configs[2]: Llama-3-8B bf16, batch 32, ragged contexts U[256,4096] in paged KV (block 64), "
-                   "16-bit host layer (dense_model.cpp)", B, steps, dt, gm.weight_bytes(), kv)
+                   "16-bit host layer (dense_model.cpp)", B, steps, tb, gm.weight_bytes(), kv)
 
 
 def leg_bf16_prompt(T=2048):
@@ -109,19 +115,21 @@ def leg_bf16_prompt(T=2048):
     seq = eng.new_sequence(0, np.random.default_rng(99).integers(0, cfg.vocab, T).tolist())
     eng.allocate([seq])
     meta = eng.prepare_prompt([seq])
-    gm.forward(meta, is_prefill=True)                                 # warm-up (scratch buffers)
-    torch.cuda.synchronize()
-    reps = 3
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        gm.forward(meta, is_prefill=True, sync=False)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    params = gm.weight_bytes() / 2 - cfg.vocab * cfg.hidden           # projections + lm_head (the embedding is a gather; lm_head runs on the last token only)
-    useful = 2.0 * (params - cfg.vocab * cfg.hidden) * T / dt / 1e12
+    import bench_timing
+    tc = bench_timing.timed_calls(lambda: gm.forward(meta, is_prefill=True, sync=False), torch.cuda.synchronize)
+    dt = tc["median_s"]
+    # useful flops from the SHAPES: 2 x projection weights x T; the lm_head runs on the last row only (x 1 token); the embedding is a gather
+    H, Hkv, D, hid, I = cfg.n_heads, cfg.n_kv_heads, cfg.head_dim, cfg.hidden, cfg.intermediate
+    layer_params = 2 * hid * H * D + 2 * hid * Hkv * D + 3 * hid * I
+    gemm_flops = 2.0 * (cfg.n_layers * layer_params * T + cfg.vocab * hid * 1)
+    attn_flops = cfg.n_layers * 2.0 * 2.0 * (T * (T + 1) / 2.0) * H * D
+    useful = gemm_flops / dt / 1e12
     return {"config": "bf16_prompt", "workload": f"Llama-3-8B bf16, one prompt step of {T} tokens (16-bit host layer, own MFMA GEMM, no library GEMM)",
             "value": round(T / dt, 1), "unit": "prompt tokens/s", "tokens": T, "ms": round(dt * 1e3, 2), "useful_TFLOPs": round(useful, 1),
-            "frac_of_2.5PF_dense_bf16": round(useful / 2500.0, 3)}
+            "value_is": "median of %d calls" % len(tc["calls_ms"]), "value_min": round(T / tc["max_s"], 1), "value_max": round(T / tc["min_s"], 1),
+            "calls_ms": tc["calls_ms"], "settle": tc["settle"],
+            "frac_of_2.5PF_dense_bf16": round(useful / 2500.0, 3),
+            "with_causal_attention_TFLOPs": round((gemm_flops + attn_flops) / dt / 1e12, 1)}
 
 
 def leg_gptq_qwen2(steps=32, warmup=4, B=1):
@@ -158,12 +166,12 @@ def leg_gptq_qwen2(steps=32, warmup=4, B=1):
             wbytes += (k // 8) * n * 4 + (k // group) * n * 2
     ctxs = [4096] if B == 1 else np.random.default_rng(4321).integers(256, 4097, B).tolist()
     gm.alloc_kv_cache(sum(-(-(int(c) + steps + warmup + 2) // cfg.block_size) for c in ctxs) + 8)
-    dt, kv = _dense_graph_loop(gm, cfg, B, ctxs, steps, warmup, 2)
+    tb, kv = _dense_graph_loop(gm, cfg, B, ctxs, steps, warmup, 2)
     if B > 1:
         return _result(f"gptq_qwen2_b{B}", f"BASELINE configs[3] shapes at batch {B}: Qwen2-7B GPTQ 4-bit (group 128, marlin_4bit arm), ragged "
-                       "contexts U[256,4096] in paged KV (block 64): the 5..64-token kernels over the tiled 4-bit image", B, steps, dt, wbytes, kv)
+                       "contexts U[256,4096] in paged KV (block 64): the 5..64-token kernels over the tiled 4-bit image", B, steps, tb, wbytes, kv)
     return _result("gptq_qwen2", "BASELINE configs[3] on one GPU: Qwen2-7B GPTQ 4-bit (group 128, marlin_4bit arm), batch 1, ctx 4096 in "
-                   "paged KV (block 64); TP=2 needs the driver's multi-GPU run", 1, steps, dt, wbytes, kv)
+                   "paged KV (block 64); TP=2 needs the driver's multi-GPU run", 1, steps, tb, wbytes, kv)
 
 
 def leg_gptq_qwen2_b32(steps=12, warmup=3):
@@ -244,15 +252,15 @@ def leg_mixtral_fp8(steps=32, warmup=4, B=1):
     stream = torch.cuda.Stream()
     st = stream.cuda_stream
     gm.set_graph(True)
-    gm.decode_begin(rng.integers(0, cfg.vocab, B).astype(np.uint32), np.asarray(ctxs, np.uint32), bt, ctx_cap=4096 + K + Wm + 2, stream=st)
-    for _ in range(Wm):
+    import bench_timing
+    tok0 = rng.integers(0, cfg.vocab, B).astype(np.uint32)
+
+    def reset():
+        gm.decode_begin(tok0, np.asarray(ctxs, np.uint32), bt, ctx_cap=4096 + K + Wm + 2, stream=st)
+
+    def step():
         gm.decode_step(st); gm.read_tokens(st)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(K):
-        gm.decode_step(st); gm.read_tokens(st)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    tb = bench_timing.timed_blocks(step, torch.cuda.synchronize, K, warmup=Wm, blocks=3, reset=reset, stats=gm.graph_stats)
     mean_ctx = float(np.mean(ctxs)) + Wm + (K - 1) / 2.0
     kv = B * (mean_ctx + 1) * 2 * cfg.n_layers * Hkv * D * 1        # fp8: one byte per element
     if B > 1:
@@ -261,12 +269,12 @@ def leg_mixtral_fp8(steps=32, warmup=4, B=1):
         step_w += cfg.n_layers * (cfg.n_expert - cfg.n_expert_used) * 3 * I * (hid // 256) * 144
         return _result(f"mixtral_fp8_b{B}", f"Mixtral-8x7B Q4_K GGUF shapes (8 experts, top-2, device router), fp8 e4m3 KV cache, batch {B}, ragged "
                        "contexts U[256,4096]; (token, slot) pairs grouped by expert on the device (graph-safe), every expert streamed once per "
-                       "32-row chunk of its block", B, K, dt, step_w, kv)
+                       "32-row chunk of its block", B, K, tb, step_w, kv)
     return _result("mixtral_fp8", "BASELINE configs[4] on one GPU: Mixtral-8x7B Q4_K GGUF shapes (8 experts, top-2, device router), fp8 "
-                   "e4m3 KV cache, batch 1, ctx 4096; TP=8 needs the driver's multi-GPU run", 1, K, dt, step_w, kv)
+                   "e4m3 KV cache, batch 1, ctx 4096; TP=8 needs the driver's multi-GPU run", 1, K, tb, step_w, kv)
 
 
-def leg_mixtral_fp8_b32(steps=8, warmup=2):
+def leg_mixtral_fp8_b32(steps=16, warmup=3):
     return leg_mixtral_fp8(steps=steps, warmup=warmup, B=32)
 
 
@@ -303,9 +311,14 @@ def leg_engine_b32(n_req=32, new_lo=48, new_hi=80, parity_reqs=2):
     warm = make(range(n_req))
     E.run_engine(gm, sched(), warm, stream=stream.cuda_stream, graph=True)
     torch.cuda.synchronize()
-    reqs = make(range(n_req))
-    st = E.run_engine(gm, sched(), reqs, stream=stream.cuda_stream, graph=True)
-    torch.cuda.synchronize()
+    runs = []
+    for _ in range(3):                                                # three timed runs of the whole request set; the median one is reported
+        reqs_i = make(range(n_req))
+        st_i = E.run_engine(gm, sched(), reqs_i, stream=stream.cuda_stream, graph=True)
+        torch.cuda.synchronize()
+        runs.append((E.usage_summary(reqs_i)["decode_throughput"], reqs_i, st_i))
+    runs.sort(key=lambda t: t[0])
+    _, reqs, st = runs[1]
     u = E.usage_summary(reqs)
     dec_tokens = u["completion_tokens"] - n_req
     same_as_warm = sum(a.tokens == b.tokens for a, b in zip(warm, reqs))
@@ -318,7 +331,8 @@ def leg_engine_b32(n_req=32, new_lo=48, new_hi=80, parity_reqs=2):
          "requests": n_req, "prompt_tokens": u["prompt_tokens"], "completion_tokens": u["completion_tokens"],
          "prompt_steps": st["prompt_steps"], "decode_steps": st["decode_steps"], "max_batch": st["max_batch"], "preempted": st["preempted"],
          "mean_decode_batch": round(dec_tokens / max(st["decode_steps"], 1), 2), "graph": True,
-         "run_to_run_identical_requests": int(same_as_warm)}
+         "run_to_run_identical_requests": int(same_as_warm), "value_is": "median of 3 runs of the request set (after one warm-up run)",
+         "value_min": round(runs[0][0], 1), "value_max": round(runs[2][0], 1)}
     if parity_reqs:
         # batching invariance at full size: a third, untimed engine run keeps the logits row behind every token of two requests (the
         # shortest and the longest prompt); the SAME model then runs each of them alone (its own scheduler and blocks, batch 1: the
@@ -394,13 +408,16 @@ def leg_mixtral_prompt_16k(T=16384, chunk=8192):
                 break
         return steps, tok
     one_pass()                                                        # warm-up: workspaces of both chunk shapes
-    steps, tok = one_pass()
+    passes = sorted((one_pass() for _ in range(3)), key=lambda p_: sum(t for _, t in p_[0]))      # three timed passes, the median one is reported
+    steps, tok = passes[1]
     dt = sum(t for _, t in steps)
     flops = 2.0 * (step_w - cfg.vocab * (cfg.hidden // 256) * 210) / 0.5625 * T   # projections + top-2 experts per token (Q4_K: 0.5625 B / weight); lm_head runs once
     return {"config": "mixtral_prompt_16k", "workload": f"BASELINE configs[4] at size: Mixtral-8x7B Q4_K shapes, fp8 e4m3 KV cache, {T}-token prompt "
             f"as {len(steps)} chunks of {chunk} tokens through the scheduler (cached-prefix prompt attention over the fp8 cache, experts grouped per chunk)",
             "value": round(T / dt, 1), "unit": "prompt tokens/s", "tokens": T, "chunks": [[n, round(t * 1e3, 1)] for n, t in steps],
-            "ms": round(dt * 1e3, 1), "useful_TFLOPs": round(flops / dt / 1e12, 1), "first_token": tok}
+            "ms": round(dt * 1e3, 1), "useful_TFLOPs": round(flops / dt / 1e12, 1), "first_token": tok,
+            "value_is": "median of 3 passes (after one warm-up pass)",
+            "value_min": round(T / sum(t for _, t in passes[2][0]), 1), "value_max": round(T / sum(t for _, t in passes[0][0]), 1)}
 
 
 LEGS = {"bf16_b32": leg_bf16_b32, "gptq_qwen2": leg_gptq_qwen2, "mixtral_fp8": leg_mixtral_fp8, "bf16_prompt": leg_bf16_prompt, "mixtral_fp8_b32": leg_mixtral_fp8_b32, "gptq_qwen2_b32": leg_gptq_qwen2_b32, "engine_b32": leg_engine_b32, "mixtral_prompt_16k": leg_mixtral_prompt_16k}
@@ -419,7 +436,7 @@ def leg_parity(name):
         from tests.fullsize_moe import MoePair
         from tests.fullsize_dense import ragged_batch32
         p = MoePair(n_layers=32, scale=0.2, max_batch=32, num_blocks=320)
-        r = p.run_batch(ragged_batch32(np.random.default_rng(4321)), steps=1)
+        r = p.run_batch(ragged_batch32(np.random.default_rng(4321)), steps=1)      # asserted with per-layer + two steps: tests/test_gpu_fullsize.py
     else:
         from tests.fullsize_dense import DensePair, ragged_batch32
         base = "gptq_qwen2" if name.startswith("gptq_qwen2") else name

@@ -154,6 +154,8 @@ _sig("mi355_llama_forward_prefill", ctypes.c_int, [c_vp] * 7 + [c_i32] * 4 + [c_
 _sig("mi355_llama_decode_begin", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
 _sig("mi355_llama_set_graph", ctypes.c_int, [c_vp, c_i32])
 _sig("mi355_llama_decode_step", ctypes.c_int, [c_vp, c_i64])
+_sig("mi355_llama_graph_captures", c_i64, [c_vp])
+_sig("mi355_llama_eager_steps", c_i64, [c_vp])
 _sig("mi355_llama_decode_read_tokens", ctypes.c_int, [c_vp, c_vp, c_i64])
 _sig("mi355_llama_logits_ptr", c_vp, [c_vp])
 _sig("mi355_comm_unique_id", ctypes.c_int, [c_vp])
@@ -277,6 +279,8 @@ _sig("mi355_dense_finalize", ctypes.c_int, [c_vp])
 _sig("mi355_dense_set_graph", ctypes.c_int, [c_vp, c_i32])
 _sig("mi355_dense_decode_begin", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
 _sig("mi355_dense_decode_step", ctypes.c_int, [c_vp, c_i64])
+_sig("mi355_dense_graph_captures", c_i64, [c_vp])
+_sig("mi355_dense_eager_steps", c_i64, [c_vp])
 _sig("mi355_dense_decode_read_tokens", ctypes.c_int, [c_vp, c_vp, c_i64])
 _sig("mi355_dense_logits_ptr", c_vp, [c_vp])
 

@@ -96,6 +96,7 @@ struct DModel {
     std::map<std::array<int, 3>, StepGraph> graphs;
     std::set<std::array<int, 3>> warmed;                  // shapes whose first (EAGER) step ran
     uint64_t graph_clock = 0;
+    int64_t graph_captures = 0, eager_steps = 0;      // mi355_dense_graph_captures / _eager_steps
     bool use_graph = true;
     // test hook (mi355_dense_set_layer_window): run layers [win_first, win_last] only, from a supplied residual stream
     int win_first = -1, win_last = -1;
@@ -708,15 +709,16 @@ int mi355_dense_decode_step(void* mp, int64_t stream) {
     // (the host mirror of the context length advances only when a step was actually enqueued: a refused or failed step leaves the
     // device-side context where it was, and a retry must pass the same checks again -- ADVICE r4)
     auto stepped = [m](int rc) { if (rc == 0) ++m->cur_ctx_max; return rc; };
+    auto eager = [m, stream]() { ++m->eager_steps; return dense_record_step(m, stream); };
     // host-supplied collectives are host calls: such TP steps stay eager (a host call made during capture is not replayed)
     const Comm* cm = static_cast<const Comm*>(m->comm);
     const bool tp_eager = cm && (cm->ar || cm->ag || !cm->nccl);
-    if (!m->use_graph || stream == 0 || tp_eager) return stepped(dense_record_step(m, stream));
+    if (!m->use_graph || stream == 0 || tp_eager) return stepped(eager());
     const std::array<int, 3> shape{m->cur_batch, m->cur_max_blocks, m->cur_ctx_cap};
     if (!m->warmed.count(shape)) {
         // the first step of a new shape runs eagerly: lazily-set kernel attributes and scratch growth must not happen inside a capture
         m->warmed.insert(shape);
-        return stepped(dense_record_step(m, stream));
+        return stepped(eager());
     }
     auto it = m->graphs.find(shape);
     if (it == m->graphs.end()) {
@@ -738,10 +740,20 @@ int mi355_dense_decode_step(void* mp, int64_t stream) {
         const hipError_t ie = hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0);
         if (ie != hipSuccess) { (void)hipGraphDestroy(g); return (int)ie; }
         it = m->graphs.emplace(shape, sg).first;
+        ++m->graph_captures;
     }
     it->second.used = ++m->graph_clock;
     DHIP(hipGraphLaunch(it->second.exec, st));
     return stepped(0);
+}
+/* step graphs captured + instantiated so far / steps of the greedy loop that ran eagerly (see mi355_llama_graph_captures) */
+int64_t mi355_dense_graph_captures(void* mp) {
+    DModel* m = static_cast<DModel*>(mp);
+    return m ? m->graph_captures : -1;
+}
+int64_t mi355_dense_eager_steps(void* mp) {
+    DModel* m = static_cast<DModel*>(mp);
+    return m ? m->eager_steps : -1;
 }
 /* D2H of the tokens the last step sampled (= the inputs of the next step); synchronises the stream */
 int mi355_dense_decode_read_tokens(void* mp, uint32_t* host_out, int64_t stream) {

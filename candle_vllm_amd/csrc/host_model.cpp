@@ -90,6 +90,7 @@ struct Model {
     std::map<std::array<int, 3>, StepGraph> graphs;
     std::set<std::array<int, 3>> warmed;                  // shapes whose first (EAGER) step ran: kernel attributes / scratch exist
     uint64_t graph_clock = 0;
+    int64_t graph_captures = 0, eager_steps = 0;          // mi355_llama_graph_captures: a re-capture inside a timed region must be visible
     bool use_graph = true;
     bool graph_tp = false;          // set_graph(2): capture tensor-parallel steps too (RCCL calls inside the graph; opt-in)
     // tensor parallel
@@ -138,7 +139,9 @@ extern "C" int mi355_internal_paged_attention_fp8_partials(void* out, float* exp
                                                            float scale, float softcap, float k_scale, float v_scale, int64_t stream, int32_t* w_out);
 extern "C" int mi355_internal_moe_stage_grouped(const float* xs, const int32_t* ids, int32_t pairs, int32_t top_k, int32_t n_expert, int32_t cap,
                                                 int32_t r0, int32_t rows, int32_t hidden, const float* norm_w, int32_t* pos_out,
-                                                int32_t* counts_out, const float* x_key, int64_t stream);             // qmatmul.hip
+                                                int32_t* counts_out, const float* x_key, int32_t row_limit, int64_t stream);
+extern "C" int mi355_internal_moe_group_limited(int32_t* pos, int32_t* counts, const int32_t* expert_ids, int32_t num_pairs, int32_t n_expert,
+                                                int32_t cap, int32_t row_limit, int64_t stream);                       // moe.hip             // qmatmul.hip
 extern "C" int mi355_internal_moe_scatter_combine_to_image(float* ys, const float* y_rows, const float* weights, const int32_t* inv, int32_t num_tokens,
                                                            int32_t hidden, int32_t top_k, const float* next_norm_w, int64_t stream);   // qmatmul.hip
 extern "C" int mi355_internal_pa_stream_reduce_to_image(void* out, const float* tmp_out, const float* max_logits, const float* exp_sums,
@@ -361,14 +364,17 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
             // grouping, row gather and image staging as ONE launch per chunk where the grouped call takes the one-launch path (key 41 = 1);
             // otherwise (-4) the pairs are grouped and their rows gathered first
             bool staged = false;
+            // the chunk loop below computes rows [0, row_limit) of every expert's block: an expert holds at most one row per token (a token's
+            // experts are distinct); a rank beyond that -- a corrupted router output -- lands on the NaN dump row and the step fails loudly
+            const int row_limit = (B + 31) / 32 * 32;
             if (g_moe_group == 1) {
                 const int rs = mi355_internal_moe_stage_grouped(in.xs, in.moe_ids, pairs, K, c.n_expert, m->g_cap, 0, 32, hid, L.ffn_norm, m->g_moe_pos,
-                                                                m->g_moe_cnt, m->g_moe_xg, st);
+                                                                m->g_moe_cnt, m->g_moe_xg, row_limit, st);
                 if (rs != 0 && rs != -4) return rs;
                 staged = rs == 0;
             }
             if (!staged) {
-                RCHECK(mi355_moe_group(m->g_moe_pos, m->g_moe_cnt, in.moe_ids, pairs, c.n_expert, m->g_cap, st));
+                RCHECK(mi355_internal_moe_group_limited(m->g_moe_pos, m->g_moe_cnt, in.moe_ids, pairs, c.n_expert, m->g_cap, row_limit, st));
                 RCHECK(mi355_moe_gather_pos(m->g_moe_xg, in.xs, m->g_moe_pos, pairs, K, hid, st));
             }
             // key 41 = 1: ALL experts in the z extent of one launch each (mi355_qmm_desc.group_count): 5 launches per chunk instead of 5 per
@@ -381,7 +387,7 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
                     const size_t off = (size_t)e * m->g_cap + r0;
                     if (staged && r0 > 0)                             // the next chunk's images (chunk 0's were staged above)
                         RCHECK(mi355_internal_moe_stage_grouped(in.xs, in.moe_ids, pairs, K, c.n_expert, m->g_cap, r0, 32, hid, L.ffn_norm,
-                                                                m->g_moe_pos, m->g_moe_cnt, m->g_moe_xg + (size_t)r0 * hid, st));
+                                                                m->g_moe_pos, m->g_moe_cnt, m->g_moe_xg + (size_t)r0 * hid, row_limit, st));
                     mi355_qmm_desc g;
                     memset(&g, 0, sizeof(g));
                     g.nseg = 2;
@@ -657,6 +663,9 @@ extern "C" void* mi355_llama_create(const mi355_llama_config* cfg) {
             alloc((void**)&m->g_moe_pos, (size_t)m->g_cap * 4);
             alloc((void**)&m->g_moe_cnt, (size_t)cfg->n_expert * 4);
             if (m->g_moe_xg) (void)hipMemset(m->g_moe_xg, 0, rows * cfg->hidden * 4);      // rows no pair lands in: finite from the start
+            // the DUMP row of the expert outputs is NaN and no launch ever writes it: a pair that was sent there (expert id out of range, or
+            // a rank beyond the rows the chunk loop covers) poisons its token's logits instead of combining a row nobody computed
+            if (m->g_moe_yg) (void)hipMemset(m->g_moe_yg + (rows - 1) * cfg->hidden, 0xFF, (size_t)cfg->hidden * 4);
         }
     }
     alloc((void**)&m->logits, (size_t)B * cfg->vocab * 4);
@@ -1011,19 +1020,20 @@ extern "C" int mi355_llama_decode_step(void* mp, int64_t stream) {
     // (the host mirror of the context length advances only when a step was actually enqueued: a refused or failed step leaves the
     // device-side context where it was, and a retry must pass the same checks again -- ADVICE r4)
     auto stepped = [m](int rc) { if (rc == 0) ++m->cur_ctx_max; return rc; };
+    auto eager = [m, stream]() { ++m->eager_steps; return record_step(m, stream); };
     // TP steps run eagerly (RCCL in-stream) unless the caller opted in with set_graph(2) AND the communicator is RCCL's
     // own (host-supplied collectives stage through the host and cannot be captured)
     // TP steps are captured like single-GPU ones when every collective of the step is device-native (RCCL on its side
     // stream joins the capture as a fork / join; the one-shot peer kernel is an ordinary node whose sequence numbers live
     // on the device).  Host-supplied collectives stage through the host and cannot be captured: those steps stay eager.
     const bool tp_eager = m->use_comm && !(m->comm && m->comm->nccl);
-    if (!m->use_graph || stream == 0 || tp_eager) return stepped(record_step(m, stream));
+    if (!m->use_graph || stream == 0 || tp_eager) return stepped(eager());
     const std::array<int, 3> shape{m->cur_batch, m->cur_max_blocks, m->cur_ctx_cap};
     if (!m->warmed.count(shape)) {
         // first step of a new shape runs eagerly: lazily-set kernel attributes and occupancy queries must not
         // happen inside a stream capture
         m->warmed.insert(shape);
-        return stepped(record_step(m, stream));
+        return stepped(eager());
     }
     auto it = m->graphs.find(shape);
     if (it == m->graphs.end()) {
@@ -1045,10 +1055,22 @@ extern "C" int mi355_llama_decode_step(void* mp, int64_t stream) {
         const hipError_t ie = hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0);
         if (ie != hipSuccess) { (void)hipGraphDestroy(g); return (int)ie; }
         it = m->graphs.emplace(shape, sg).first;
+        ++m->graph_captures;
     }
     it->second.used = ++m->graph_clock;
     HCHECK(hipGraphLaunch(it->second.exec, st));
     return stepped(0);
+}
+
+// how many step graphs this model captured + instantiated so far / how many steps of the greedy loop ran eagerly: a bench that
+// brackets its timed region with these can show that no capture (tens of ms) and no eager step fell inside it
+extern "C" int64_t mi355_llama_graph_captures(void* mp) {
+    Model* m = static_cast<Model*>(mp);
+    return m ? m->graph_captures : -1;
+}
+extern "C" int64_t mi355_llama_eager_steps(void* mp) {
+    Model* m = static_cast<Model*>(mp);
+    return m ? m->eager_steps : -1;
 }
 
 // D2H of the tokens the last step sampled (they are the inputs of the next step)

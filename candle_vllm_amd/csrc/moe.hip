@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256) moe_scatter_combine_kernel(float* __restr
 // expert's count are never written and never read back: the expert GEMMs run over all cap rows (rows are independent), the
 // combine reads only pos[].
 __global__ void __launch_bounds__(256) moe_group_kernel(int32_t* __restrict__ pos, int32_t* __restrict__ counts, const int32_t* __restrict__ ids,
-                                                        int pairs, int n_expert, int cap) {
+                                                        int pairs, int n_expert, int cap, int row_limit) {
     if (counts)
         for (int e = threadIdx.x; e < n_expert; e += blockDim.x) {
             int n = 0;
@@ -111,7 +111,10 @@ __global__ void __launch_bounds__(256) moe_group_kernel(int32_t* __restrict__ po
         for (int q = 0; q < p; ++q) before += ids[q] == e ? 1 : 0;
         // an id outside [0, n_expert) (a corrupted router output) gets the DUMP row n_expert * cap: no expert's block, never read by an
         // expert GEMM, so it cannot collide with expert 0's first pair; callers size their row buffers (n_expert * cap + 1)
-        pos[p] = (e >= 0 && e < n_expert) ? e * cap + before : n_expert * cap;
+        // a rank at or beyond `row_limit` (the rows the caller's launches cover per expert: only possible when a token carries the same
+        // expert twice, i.e. a corrupted router output) goes to the DUMP row as well -- the host layer keeps that row NaN in the expert
+        // outputs, so such a step fails loudly instead of combining rows nobody computed
+        pos[p] = (e >= 0 && e < n_expert && before < row_limit) ? e * cap + before : n_expert * cap;
     }
 }
 __global__ void __launch_bounds__(256) moe_gather_pos_kernel(float* __restrict__ dst, const float* __restrict__ src, const int32_t* __restrict__ pos,
@@ -120,12 +123,17 @@ __global__ void __launch_bounds__(256) moe_gather_pos_kernel(float* __restrict__
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i < hidden) *reinterpret_cast<float4*>(dst + (size_t)pos[p] * hidden + i) = *reinterpret_cast<const float4*>(src + (size_t)(p / K) * hidden + i);
 }
+/* internal (host_model.cpp): mi355_moe_group with the number of rows per expert that the caller's launches will actually compute */
+extern "C" int mi355_internal_moe_group_limited(int32_t* pos, int32_t* counts, const int32_t* expert_ids, int32_t num_pairs, int32_t n_expert,
+                                                int32_t cap, int32_t row_limit, int64_t stream) {
+    if (num_pairs <= 0) return 0;
+    if (!pos || !expert_ids || n_expert < 1 || cap < num_pairs || num_pairs > 4096 || row_limit < 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(moe_group_kernel, dim3(1), dim3(256), 0, to_stream(stream), pos, counts, expert_ids, num_pairs, n_expert, cap, row_limit);
+    return (int)hipGetLastError();
+}
 extern "C" int mi355_moe_group(int32_t* pos, int32_t* counts, const int32_t* expert_ids, int32_t num_pairs, int32_t n_expert, int32_t cap,
                                int64_t stream) {
-    if (num_pairs <= 0) return 0;
-    if (!pos || !expert_ids || n_expert < 1 || cap < num_pairs || num_pairs > 4096) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(moe_group_kernel, dim3(1), dim3(256), 0, to_stream(stream), pos, counts, expert_ids, num_pairs, n_expert, cap);
-    return (int)hipGetLastError();
+    return mi355_internal_moe_group_limited(pos, counts, expert_ids, num_pairs, n_expert, cap, cap, stream);
 }
 extern "C" int mi355_moe_gather_pos(float* dst, const float* src, const int32_t* pos, int32_t num_pairs, int32_t top_k, int32_t hidden,
                                     int64_t stream) {

@@ -1344,7 +1344,11 @@ __global__ void __launch_bounds__(256) qmm_epilogue_grp_kernel(const QmmArgs a, 
 // captured graph still replays from (scratch.cpp).  The chain hint is per (device, stream) too.
 // image staged by the last chained epilogue: valid for exactly the next wide launch if it consumes the same activations
 struct QmgChainState { bool valid; const void* x; int B, K, MT, buf; const float* norm_w; hipStream_t st; int sp; int x_dtype = MI355_DTYPE_F32;
-                       int grp = 1; int64_t grp_stride = 0; };                    // grouped launch: groups and elements between their activations
+                       int grp = 1; int64_t grp_stride = 0;                       // grouped launch: groups and elements between their activations
+                       // the images were built WITHOUT their activations ever being written to `x` (mi355_internal_moe_stage_grouped: `x` is
+                       // only the key the consumer will present).  A launch that presents this key and cannot take the images must fail, it
+                       // must never stage from `x` (stale rows, silently wrong results -- ADVICE r5)
+                       bool prestaged = false; };
 struct QmgStream { int cur = 0; QmgChainState chain = {false, nullptr, 0, 0, 0, 0, nullptr, nullptr, 0}; };
 static std::mutex g_qmg_mu;
 static std::map<std::pair<int, hipStream_t>, QmgStream> g_qmg_streams;
@@ -1354,6 +1358,10 @@ static QmgStream& qmg_stream(hipStream_t st) {
     std::lock_guard<std::mutex> lock(g_qmg_mu);
     return g_qmg_streams[std::make_pair(dev, st)];              // std::map: the reference stays valid across later inserts
 }
+// ONE statement of "a grouped mat-mul of B token rows runs as the z extent of the 9..32-token launches" (mi355_qmm_launch takes that path,
+// mi355_internal_moe_stage_grouped builds images only for it, mi355_internal_moe_scatter_combine_to_image stages only for it): three hand
+// copies of this condition had to agree for the fused MoE staging to be correct.  Defined below the tuning switches.
+static bool qmg_wide_one_launch(int B);
 static int g_tune_qmv = 0;                                    // mi355_set_tuning(20, 1): single-token launches take the LDS-DMA engine (qmv_engine.inc) one by one -- measured slower than qmm_kernel per launch (fixed cost), faster chained
 static int g_tune_qmv_nc = 8;                                 // mi355_set_tuning(21, n): consumer waves per workgroup of the engine (1..15)
 static int g_tune_exact_act = 0;                              // mi355_set_tuning(24, 1): "exact" activations on the 9..32-token and prompt paths: f16 hi + lo planes (22 bits) instead of one f16 plane
@@ -1513,7 +1521,12 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
                          qs.chain.MT == MT && qs.chain.sp == 1 && qs.chain.norm_w == a.norm_w && qs.chain.st == st &&
                          a.x_dtype == qs.chain.x_dtype && a.ldx == a.K && qs.chain.grp == G &&
                          (G == 1 || qs.chain.grp_stride == a.grp_x);
+    const bool orphan = qs.chain.valid && qs.chain.prestaged && qs.chain.x == a.x && !chained;
     qs.chain.valid = false;
+    if (orphan) {                                                       // the images behind this key were staged for another launch shape,
+        mi355_note_error((int)hipErrorInvalidValue);                     // and `x` itself was never written: refuse instead of staging stale rows
+        return (int)hipErrorInvalidValue;
+    }
     const int cur = chained ? qs.chain.buf : qs.cur;
     int rc = 0;
     void* imgp = nullptr;
@@ -2204,7 +2217,21 @@ static int qmm_exact_launch(QmmArgs a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+static bool qmg_wide_one_launch(int B) {
+    return B > 8 && B <= 8 * QMW_MAXMT && !g_tune_exact_act && !g_qmm_exact && !(B >= g_tune_qpg_min && g_tune_prefill_gemm);
+}
+
 int mi355_qmm_launch(QmmArgs a, int64_t stream) {
+    {   // images staged WITHOUT backing activations (fused MoE staging) may only be consumed by the grouped 9..32-token launch they were
+        // built for; any other route would read rows nobody wrote.  qw1_launch checks the remaining fields (tile height, k, norm, groups)
+        QmgStream& qs0 = qmg_stream(to_stream(stream));
+        if (qs0.chain.valid && qs0.chain.prestaged && qs0.chain.x == a.x && qs0.chain.st == to_stream(stream) &&
+            !(a.grp_n > 1 && qmg_wide_one_launch(a.B) && a.nseg >= 1 && a.seg[0].type != MI355_GGML_Q8_0)) {
+            qs0.chain.valid = false;
+            mi355_note_error((int)hipErrorInvalidValue);
+            return (int)hipErrorInvalidValue;
+        }
+    }
     if (a.nseg >= 1 && a.seg[0].type == MI355_GGML_Q8_0) return q8_0_launch(a, to_stream(stream));
     if (a.K <= 0 || (a.K % 256) || a.B < 0 || a.nseg < 1 || a.nseg > 3) return (int)hipErrorInvalidValue;
     if (a.B == 0) return 0;
@@ -2215,8 +2242,7 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
         // grouped launch: grp_n mat-muls of these shapes.  The 9..32-token path runs them as the z extent of its launches; everything
         // else (other token counts, the exact modes) runs them one after the other -- same results, the descriptor's meaning is the loop
         if (a.moe_expert || a.bias || (a.epi != MI355_EPI_STORE && a.epi != MI355_EPI_SILU_MUL)) return (int)hipErrorInvalidValue;
-        const bool one_launch = a.B > 8 && a.B <= 8 * QMW_MAXMT && !g_tune_exact_act && !g_qmm_exact &&
-                                !(a.B >= g_tune_qpg_min && g_tune_prefill_gemm);
+        const bool one_launch = qmg_wide_one_launch(a.B);
         if (!one_launch) {
             const size_t xes = (a.x_dtype == MI355_DTYPE_BF16) ? 2 : 4;
             for (int e = 0; e < a.grp_n; ++e) {
@@ -2340,11 +2366,9 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
  * (mi355_moe_group's outputs).  -4: this configuration does not take the one-launch grouped path -- the caller groups and gathers. */
 extern "C" int mi355_internal_moe_stage_grouped(const float* xs, const int32_t* ids, int32_t pairs, int32_t top_k, int32_t n_expert, int32_t cap,
                                                 int32_t r0, int32_t rows, int32_t hidden, const float* norm_w, int32_t* pos_out,
-                                                int32_t* counts_out, const float* x_key, int64_t stream) {
-    if (!xs || !ids || !pos_out || !counts_out || pairs < 1 || top_k < 1 || n_expert < 2 || cap < pairs || (hidden % 256) || rows < 9 ||
-        rows > 8 * QMW_MAXMT)
-        return -4;
-    if (g_tune_exact_act || g_qmm_exact || (rows >= g_tune_qpg_min && g_tune_prefill_gemm)) return -4;
+                                                int32_t* counts_out, const float* x_key, int32_t row_limit, int64_t stream) {
+    if (!xs || !ids || !pos_out || !counts_out || pairs < 1 || top_k < 1 || n_expert < 2 || cap < pairs || (hidden % 256)) return -4;
+    if (!qmg_wide_one_launch(rows)) return -4;                          // the consumer's own path decision (shared helper)
     hipStream_t st = to_stream(stream);
     const int MT = rows <= 16 ? 1 : 2, BP = MT * 16, nkb = hidden / 256;
     const size_t kbb = qw1_kb_bytes(MT);
@@ -2359,12 +2383,13 @@ extern "C" int mi355_internal_moe_stage_grouped(const float* xs, const int32_t* 
     float* ssp = reinterpret_cast<float*>(img + kbb * nkb);
     if (MT == 1)
         hipLaunchKernelGGL((qw1_prep_moe_kernel<1>), dim3(nkb, 2, n_expert), dim3(256), 0, st, img, ssp, xs, ids, pairs, top_k, n_expert, cap, r0,
-                           hidden, norm_w, kbb, (int64_t)imgb, pos_out, counts_out);
+                           hidden, norm_w, kbb, (int64_t)imgb, pos_out, counts_out, row_limit > 0 ? row_limit : cap);
     else
         hipLaunchKernelGGL((qw1_prep_moe_kernel<2>), dim3(nkb, 4, n_expert), dim3(256), 0, st, img, ssp, xs, ids, pairs, top_k, n_expert, cap, r0,
-                           hidden, norm_w, kbb, (int64_t)imgb, pos_out, counts_out);
+                           hidden, norm_w, kbb, (int64_t)imgb, pos_out, counts_out, row_limit > 0 ? row_limit : cap);
     qs.chain = QmgChainState{true, x_key, rows, hidden, MT, cur, norm_w, st, 1};
     qs.chain.grp = n_expert; qs.chain.grp_stride = (int64_t)cap * hidden;
+    qs.chain.prestaged = true;                                          // no activations behind x_key: consume these images or fail
     return (int)hipGetLastError();
 }
 
@@ -2395,8 +2420,8 @@ __global__ void __launch_bounds__(256) moe_scatter_combine_img_kernel(float* __r
 /* internal (host_model.cpp): -4 = this configuration does not chain (the caller runs mi355_moe_scatter_combine) */
 extern "C" int mi355_internal_moe_scatter_combine_to_image(float* ys, const float* y_rows, const float* weights, const int32_t* inv, int32_t num_tokens,
                                                            int32_t hidden, int32_t top_k, const float* next_norm_w, int64_t stream) {
-    if (!ys || !y_rows || !weights || !inv || top_k < 1 || (hidden % 256) || num_tokens < 9 || num_tokens > 8 * QMW_MAXMT) return -4;
-    if (!g_tune_chain || g_tune_exact_act || g_qmm_exact || (num_tokens >= g_tune_qpg_min && g_tune_prefill_gemm)) return -4;
+    if (!ys || !y_rows || !weights || !inv || top_k < 1 || (hidden % 256)) return -4;
+    if (!g_tune_chain || !qmg_wide_one_launch(num_tokens)) return -4;
     hipStream_t st = to_stream(stream);
     const int MT = num_tokens <= 16 ? 1 : 2, BP = MT * 16, nkb = hidden / 256;
     const size_t kbb = qw1_kb_bytes(MT);

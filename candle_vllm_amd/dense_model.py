@@ -215,6 +215,10 @@ class DenseLlama:
     def decode_step(self, stream=0):
         _check(lib.mi355_dense_decode_step(self.h, stream), "dense_decode_step")
 
+    def graph_stats(self):
+        """(step graphs captured so far, steps of the greedy loop that ran eagerly): mi355_dense_graph_captures / _eager_steps"""
+        return int(lib.mi355_dense_graph_captures(self.h)), int(lib.mi355_dense_eager_steps(self.h))
+
     def read_tokens(self, stream=0):
         out = np.zeros(self._loop_batch, np.uint32)
         _check(lib.mi355_dense_decode_read_tokens(self.h, out.ctypes.data, stream), "dense_decode_read_tokens")

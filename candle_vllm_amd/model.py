@@ -450,6 +450,10 @@ class GGUFLLaMa:
         _check(lib.mi355_llama_decode_read_tokens(self.h, out.ctypes.data, stream), "read_tokens")
         return out
 
+    def graph_stats(self):
+        """(step graphs captured so far, steps of the greedy loop that ran eagerly): mi355_llama_graph_captures / _eager_steps"""
+        return int(lib.mi355_llama_graph_captures(self.h)), int(lib.mi355_llama_eager_steps(self.h))
+
     def set_attention_numerics(self, mode):
         """parity mode (tests): 1 = decode attention with the reference CPU path's bf16 rounding points (models/mod.rs:1288-1306)"""
         _check(lib.mi355_llama_set_attention_numerics(self.h, int(mode)), "set_attention_numerics")

@@ -519,6 +519,11 @@ int mi355_llama_set_attention_numerics(void* model, int32_t mode);
 void mi355_internal_qmm_set_exact(int32_t on);
 int32_t mi355_internal_qmm_get_exact(void);
 int mi355_llama_decode_step(void* model, int64_t stream);
+/* bookkeeping of the greedy loop for benchmarks: step graphs captured + instantiated so far, and steps that ran eagerly (the first
+ * step of every new (batch, max_blocks, ctx_cap) shape, every step with graphs off).  A timed region bracketed by these shows that no
+ * capture and no eager step fell inside it (graph.rs:471-661 captures at load; here the second step of a shape captures). */
+int64_t mi355_llama_graph_captures(void* model);
+int64_t mi355_llama_eager_steps(void* model);
 int mi355_llama_decode_read_tokens(void* model, uint32_t* host_out, int64_t stream);
 float* mi355_llama_logits_ptr(void* model);
 /* tensor parallel: RCCL communicator (one process per GPU).  rank 0: mi355_comm_unique_id -> 128 bytes that the
@@ -649,6 +654,8 @@ int mi355_dense_set_graph(void* model, int32_t enable);
 int mi355_dense_decode_begin(void* model, const uint32_t* tokens_host, const uint32_t* seq_lens_host,
                              const uint32_t* block_tables_host, int32_t batch, int32_t max_blocks, int32_t ctx_cap, int64_t stream);
 int mi355_dense_decode_step(void* model, int64_t stream);
+int64_t mi355_dense_graph_captures(void* model);   /* as mi355_llama_graph_captures / _eager_steps */
+int64_t mi355_dense_eager_steps(void* model);
 int mi355_dense_decode_read_tokens(void* model, uint32_t* host_out, int64_t stream);
 float* mi355_dense_logits_ptr(void* model);   /* f32 [batch, vocab (x tp_world)] of the loop's last step */
 

@@ -178,9 +178,10 @@ class OracleDenseLlama:
             ys.append(ops.prefill_attention(q[a:b], ops.bf16_bits_to_f32(kk), ops.bf16_bits_to_f32(vv), self.scale, cached=n - (b - a)))
         return np.concatenate(ys, 0)
 
-    def forward(self, meta, kv_caches, is_prefill=False, trace=None):
+    def forward(self, meta, kv_caches, is_prefill=False, trace=None, trace_mid=None):
         """Llama::forward_inner src/openai/models/llama.rs:139-201 with Attention::forward_ext src/openai/models/layers/attention.rs:585-734.
-        trace: a list that receives the residual stream at every layer entry and after the last layer (full-size parity legs)."""
+        trace: a list that receives the residual stream at every layer entry and after the last layer (full-size parity legs);
+        trace_mid: a list that receives the stream between the two branches of every layer (after o_proj + residual)."""
         c, W = self.cfg, self.W
         toks, pos = meta["input_ids"], meta["positions"]
         T = len(toks)
@@ -199,6 +200,8 @@ class OracleDenseLlama:
                 y = self._attend_fp8(meta, q, k, v, kc, vc, is_prefill)
                 y = y.reshape(T, c.n_heads * c.head_dim)
                 xs = self._row_lin(y, lw["wo"], xs)
+                if trace_mid is not None:
+                    trace_mid.append(xs.copy())
                 x = self._norm(xs, lw["ffn_norm"], lw.get("ffn_norm_b"))
                 gate, up = _lin(x, lw["w1"]), _lin(x, lw["w3"])
                 xs = self._row_lin(G.silu_mul16(gate, up, DT), lw["w2"], xs)
@@ -215,6 +218,8 @@ class OracleDenseLlama:
                 y = ops.paged_attention_decode(q, kc, vc, meta["block_tables"], meta["context_lens"], self.scale, self.flash)
             y = y.reshape(T, c.n_heads * c.head_dim)
             xs = self._row_lin(y, lw["wo"], xs)
+            if trace_mid is not None:
+                trace_mid.append(xs.copy())
             x = self._norm(xs, lw["ffn_norm"], lw.get("ffn_norm_b"))
             gate, up = _lin(x, lw["w1"]), _lin(x, lw["w3"])
             h = G.silu_mul16(gate, up, DT)

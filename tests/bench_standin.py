@@ -64,6 +64,9 @@ def _fake_model_module(dist, calls):
         def read_tokens(self, st):
             return np.zeros(1, np.uint32)
 
+        def graph_stats(self):
+            return (1, 1)
+
         @property
         def weight_bytes_global(self):
             return self.weight_bytes * self.tp_world

@@ -140,8 +140,8 @@ class DensePair:
         # writes its own into the device pool)
         got = gm.forward(meta).cpu().numpy()
         t0 = time.time()
-        trace = []
-        ref = self.orc.forward(meta, self.cache, trace=trace)
+        trace, mid = [], []
+        ref = self.orc.forward(meta, self.cache, trace=trace, trace_mid=mid)
         t_orc = time.time() - t0
         scale = np.abs(ref).max(axis=1)
         err = np.abs(got - ref).max(axis=1)
@@ -160,7 +160,7 @@ class DensePair:
         xin = torch.empty((B, hid), dtype=torch.int16, device="cuda")
         xout = torch.empty((B, hid), dtype=torch.int16, device="cuda")
         worst_excess, worst_layer, flips = 0.0, -1, 0.0
-        per_layer = []
+        per_layer, worst_ratio = [], 0.0
         try:
             for l in (range(cfg.n_layers) if layers is None else layers):
                 xin.copy_(torch.from_numpy(_bf16_bits(trace[l]).view(np.int16)).cuda())
@@ -174,11 +174,20 @@ class DensePair:
                 e = float((excess.max(axis=1) / np.abs(r).max(axis=1)).max())
                 per_layer.append(round(e, 6))
                 flips = max(flips, float((g != r).mean()))
+                # the bound of that excess, DERIVED from the oracle's own magnitudes in this layer: the stream is rounded to bf16 where
+                # o_proj returns (y1), at the first residual sum (m = x + y1), where down_proj returns (y2) and at the second sum (the
+                # element's own ulp, already subtracted above).  Two implementations that differ by f32 summation order alone can land
+                # on different sides of a tie at each of those sites, i.e. differ by at most one ulp = 2^-7 of THAT value; the three
+                # kicks add up in the worst case: excess_i <= 2^-7 (|y1_i| + |m_i| + |y2_i|), relative to the row's largest |r|.
+                y1, m_, y2 = mid[l] - trace[l], mid[l], r - mid[l]
+                bound = float(((2.0 ** -7 * (np.abs(y1) + np.abs(m_) + np.abs(y2))).max(axis=1) / np.abs(r).max(axis=1)).max())
+                worst_ratio = max(worst_ratio, e / bound)
                 if e > worst_excess:
                     worst_excess, worst_layer = e, l
         finally:
             DM._check(lib.mi355_dense_set_layer_window(gm.h, -1, -1, None, None), "layer_window off")
         res.update({"worst_layer_excess": worst_excess, "worst_layer": worst_layer, "max_flip_frac": flips, "per_layer": per_layer,
+                    "worst_excess_over_derived_bound": worst_ratio,
                     "units": "worst_layer_excess: error of the stream after a layer beyond one bf16 ulp of the element, relative to the row's largest "
                              "value; max_flip_frac: fraction of stream elements that differ at all (one-ulp flips)"})
         return res

@@ -189,7 +189,7 @@ class MoePair:
 
 
     # ------------------------------------------------------------------------------------------------ batch of ragged sequences
-    def run_batch(self, seq_lens, steps=1):
+    def run_batch(self, seq_lens, steps=1, per_layer=False):
         """the timed batch-32 geometry of bench_legs.py `mixtral_fp8_b32`: ragged contexts, the (token, slot) pairs grouped by expert on the
         device, fp8 KV cache, hipGraph replay -- greedy steps end to end against OracleLlama (O1f products)."""
         keep = OL._qmm
@@ -207,9 +207,45 @@ class MoePair:
             for i, q in enumerate(seqs):
                 bt[i, : len(q["block_table"])] = q["block_table"]
             st = self.stream.cuda_stream
+            first_ref, layer_res = None, {}
+            if per_layer:
+                # ---- every layer alone at the batch, teacher-forced from the oracle's stream (eager launches through mi355_llama_run_part:
+                # the grouped-expert launches, the fp8 attention stream, the chained images -- what the captured step runs).  The oracle
+                # forward that records the stream is also the reference of the first end-to-end step below (same inputs, same pool).
+                M, torch = self.M, self.torch
+                lib = M.lib
+                hip = ctypes.CDLL("libamdhip64.so")
+                hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+                hip.hipMemcpy.restype = ctypes.c_int
+                lib.mi355_llama_act_ptr.restype = ctypes.c_void_p
+                xs_ptr = lib.mi355_llama_act_ptr(gm.h, 0)
+                gm.set_graph(False)
+                gm.decode_begin([q["tokens"][-1] for q in seqs], [len(q["tokens"]) for q in seqs], bt, ctx_cap=int(max(seq_lens)) + steps, stream=st)
+                meta = O.prepare_decode(seqs, bs)
+                meta["block_tables"] = bt
+                cache0 = [(k.copy(), v.copy()) for k, v in self.cache]
+                trace = []
+                first_ref = self.orc.forward(meta, cache0, trace=trace)
+                x_in = [np.ascontiguousarray(self.W["tok_embd"][meta["input_ids"]], np.float32)] + trace[:-1]
+                got = np.empty((B, cfg.hidden), np.float32)
+                errs = []
+                for l in range(cfg.n_layers):
+                    xi = np.ascontiguousarray(x_in[l], np.float32)
+                    M._check(hip.hipMemcpy(xs_ptr, xi.ctypes.data, xi.nbytes, 1), "H2D")
+                    for part in range(5):
+                        M._check(lib.mi355_llama_run_part(gm.h, l, part, st), "run_part")
+                    torch.cuda.synchronize()
+                    M._check(hip.hipMemcpy(got.ctypes.data, xs_ptr, got.nbytes, 2), "D2H")
+                    added = np.abs(trace[l] - xi).max(axis=1)
+                    errs.append(float((np.abs(got - trace[l]).max(axis=1) / added).max()))
+                layer_res = {"worst_layer_rel_err": max(errs), "worst_layer": int(np.argmax(errs)), "median_layer_rel_err": float(np.median(errs))}
+                for l in range(cfg.n_layers):                              # the layer runs wrote K/V of the new token: restore the device pool
+                    for which, a in ((0, self.cache[l][0]), (1, self.cache[l][1])):
+                        M._check(lib.mi355_llama_kv_copy(gm.h, l, which, a.ctypes.data, a.nbytes, 1), "kv_copy")
             gm.set_graph(True)
             gm.decode_begin([q["tokens"][-1] for q in seqs], [len(q["tokens"]) for q in seqs], bt, ctx_cap=int(max(seq_lens)) + steps, stream=st)
-            cache1 = [(k.copy(), v.copy()) for k, v in self.cache]
+            # with per_layer the traced oracle forward above WAS step 0 (same inputs, same pool; it left the new token's K/V in cache0)
+            cache1 = cache0 if first_ref is not None else [(k.copy(), v.copy()) for k, v in self.cache]
             worst, equal, ties, done, t_orc = 0.0, True, 0, 0, 0.0
             for step in range(steps):
                 gm.decode_step(st)
@@ -218,7 +254,7 @@ class MoePair:
                 meta = O.prepare_decode(seqs, bs)
                 meta["block_tables"] = bt
                 t0 = time.time()
-                ref = self.orc.forward(meta, cache1)
+                ref = first_ref if (step == 0 and first_ref is not None) else self.orc.forward(meta, cache1)
                 t_orc += time.time() - t0
                 done += 1
                 for b in range(B):
@@ -235,9 +271,10 @@ class MoePair:
                     seqs[b]["tokens"].append(want)
                 if not equal:
                     break
-            return {"leg": "mixtral_fp8_b32", "batch": B, "ctx_max": int(max(seq_lens)), "layers": cfg.n_layers, "steps_compared": done,
+            layer_res.update({"leg": "mixtral_fp8_b32", "batch": B, "ctx_max": int(max(seq_lens)), "layers": cfg.n_layers, "steps_compared": done,
                     "logits_max_rel_err": worst, "tokens_equal": bool(equal), "near_tie_tokens": ties,
-                    "oracle": "O1f (unpinned), fp8 KV, experts per token", "oracle_s_per_step": round(t_orc / max(done, 1), 1)}
+                    "oracle": "O1f (unpinned), fp8 KV, experts per token", "oracle_s_per_step": round(t_orc / max(done, 1), 1)})
+            return layer_res
         finally:
             OL._qmm = keep
 

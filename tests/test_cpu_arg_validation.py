@@ -112,10 +112,10 @@ def test_malformed_quantised_matmul_descriptors_are_refused(L):
     assert lib.mi355_qmatmul_fused(ctypes.byref(d), 0) == INVALID
     # the fused MoE staging / scatter launches of the host layer say "not this configuration" (-4) before anything touches the device
     lib.mi355_internal_moe_stage_grouped.restype = ctypes.c_int
-    lib.mi355_internal_moe_stage_grouped.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 7 + [ctypes.c_void_p] * 4 + [ctypes.c_int64]
-    assert lib.mi355_internal_moe_stage_grouped(None, None, 64, 2, 8, 64, 0, 32, 4096, None, None, None, None, 0) == -4
-    assert lib.mi355_internal_moe_stage_grouped(p, p, 64, 2, 8, 32, 0, 32, 4096, None, p, p, p, 0) == -4          # cap < pairs
-    assert lib.mi355_internal_moe_stage_grouped(p, p, 64, 2, 8, 64, 0, 5, 4096, None, p, p, p, 0) == -4           # 5 rows: not the 9..32-token path
+    lib.mi355_internal_moe_stage_grouped.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 7 + [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int64]
+    assert lib.mi355_internal_moe_stage_grouped(None, None, 64, 2, 8, 64, 0, 32, 4096, None, None, None, None, 32, 0) == -4
+    assert lib.mi355_internal_moe_stage_grouped(p, p, 64, 2, 8, 32, 0, 32, 4096, None, p, p, p, 32, 0) == -4          # cap < pairs
+    assert lib.mi355_internal_moe_stage_grouped(p, p, 64, 2, 8, 64, 0, 5, 4096, None, p, p, p, 32, 0) == -4           # 5 rows: not the 9..32-token path
     lib.mi355_internal_moe_scatter_combine_to_image.restype = ctypes.c_int
     lib.mi355_internal_moe_scatter_combine_to_image.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32] * 3 + [ctypes.c_void_p, ctypes.c_int64]
     assert lib.mi355_internal_moe_scatter_combine_to_image(p, p, p, p, 4, 4096, 2, None, 0) == -4                 # 4 tokens

@@ -37,7 +37,7 @@ def _worker(rank, world, port, q):
         from tests import bench_standin
         bench_standin.install(calls)
         import bench
-        sys.argv = ["bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "2"]
+        sys.argv = ["bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "2", "--settle-steps", "4"]
         buf, old = io.StringIO(), sys.stdout
         sys.stdout = buf
         try:
@@ -86,7 +86,7 @@ def test_bench_main_two_ranks_control_flow():
     assert j["value"] > 0 and abs(j["value"] - 1e3 / j["ms_per_step"]) / j["value"] < 1e-2      # batch 1: tokens/s = steps/s
     for calls in (calls0, calls1):
         assert ("init_comm", "auto") in calls and ("roofline",) in calls and ("graph", True) in calls
-        assert calls.count(("step",)) == 5               # 2 warm-up + 3 timed, on every rank
+        assert calls.count(("step",)) == 4 + 3 * 5       # 4 settle steps, then 3 blocks of (2 warm-up + 3 timed), on every rank
     assert calls0[0] == ("create", 0, 2, 1) and calls1[0] == ("create", 1, 2, 1)
 
 
@@ -99,7 +99,7 @@ def test_bench_py_gpus_2_spawns_its_own_ranks():
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_standin.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_standin.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--settle-steps", "2"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

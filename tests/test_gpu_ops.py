@@ -1,6 +1,7 @@
 """GPU parity tests (run with -m gpu on the MI355X): every kernel of the hot path through the C ABI vs the
 CPU oracle on the same seeded inputs.  Index/byte ops are bit-exact; floating point ops carry their
 tolerance next to the assert."""
+import ctypes
 import os
 
 import numpy as np
@@ -599,6 +600,85 @@ def test_grouped_expert_matmuls_one_launch_per_kernel(cv, rows, types):
         assert (h1[e, rows:] == 7.0).all() and (y1[e, rows:] == 9.0).all()
         assert (h1[e, nlive:rows] == 7.0).all() and (y1[e, nlive:rows] == 9.0).all()
     assert np.isfinite(y1[0, :rows]).all() and np.abs(y1[0, :rows]).max() > 0
+
+
+def test_fused_moe_staging_is_consumed_or_refused(cv):
+    """mi355_internal_moe_stage_grouped builds the grouped images straight from the residual stream and never writes the
+    gathered rows behind its key pointer.  The grouped call that presents the key must either take those images or FAIL -- a path decision
+    that changed between staging and launch (here: tuning key 24 flipped, other row count, other k) used to stage silently from the
+    never-written rows.  Also: a pair whose rank lies beyond the rows the caller's launches cover goes to the dump row, not into a block."""
+    rng = np.random.default_rng(11)
+    hid, I, E, K, B = 512, 768, 4, 2, 16
+    cap = 32
+    st = torch.cuda.current_stream().cuda_stream
+    lib = cv.lib
+    lib.mi355_internal_moe_stage_grouped.restype = ctypes.c_int
+    lib.mi355_internal_moe_stage_grouped.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 7 + [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int64]
+    xs = dev(rng.normal(0, 1, (B, hid)).astype(np.float32))
+    nw = dev((1.0 + rng.normal(0, 0.05, hid)).astype(np.float32))
+    ids_h = np.stack([rng.permutation(E)[:K] for _ in range(B)]).astype(np.int32)
+    ids = torch.from_numpy(ids_h).cuda()
+    pos = torch.full((B * K,), -1, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(E, dtype=torch.int32, device="cuda")
+    xg = torch.full((E * cap + 1, hid), float("nan"), dtype=torch.float32, device="cuda")     # the key: NEVER written by the staging
+    w1 = torch.from_numpy(np.concatenate([cv.repack_qweight(kq.quantize(rng.normal(0, 0.05, (I, hid)).astype(np.float32), kq.GGML_Q4_K), kq.GGML_Q4_K, I, hid) for _ in range(E)])).cuda()
+    s1 = w1.numel() // E
+    h = torch.zeros((E * cap, I), dtype=torch.float32, device="cuda")
+
+    def stage(row_limit=32):
+        return lib.mi355_internal_moe_stage_grouped(xs.data_ptr(), ids.data_ptr(), B * K, K, E, cap, 0, 32, hid, nw.data_ptr(), pos.data_ptr(),
+                                                    cnt.data_ptr(), xg.data_ptr(), row_limit, st)
+
+    def desc(rows=32, k=hid):
+        g = cv.QmmDesc()
+        g.nseg = 2
+        g.w_tiles[0], g.w_tiles[1] = w1.data_ptr(), w1.data_ptr()
+        g.ggml_type[0] = g.ggml_type[1] = kq.GGML_Q4_K
+        g.n_rows[0] = g.n_rows[1] = I
+        g.x, g.x_dtype, g.ldx, g.k, g.num_tokens = xg.data_ptr(), cv.DT_F32, k, k, rows
+        g.norm_weight, g.norm_eps = nw.data_ptr(), 1e-5
+        g.epilogue, g.out, g.ldo = cv.EPI_SILU_MUL, h.data_ptr(), I
+        g.rows_dev, g.rows_min = cnt.data_ptr(), 0
+        g.group_count, g.group_x_stride, g.group_out_stride = E, cap * k, cap * I
+        g.moe_expert_stride[0] = g.moe_expert_stride[1] = s1
+        return g
+    # (1) the intended pairing: staged images are consumed, results finite although the key buffer holds NaN
+    assert stage() == 0
+    assert lib.mi355_qmatmul_fused(desc(), st) == 0
+    torch.cuda.synchronize()
+    n0 = int(cnt.cpu()[0])
+    assert n0 == int((ids_h == 0).sum()) and np.isfinite(h.cpu().numpy()[:n0]).all()
+    lib.mi355_clear_error()
+    try:
+        # (2) the path decision flips between staging and launch (key 24 = exact activations: the grouped call would loop over the experts)
+        assert stage() == 0
+        lib.mi355_set_tuning(24, 1)
+        assert lib.mi355_qmatmul_fused(desc(), st) != 0
+        lib.mi355_set_tuning(24, 0)
+        assert lib.mi355_last_error() != 0
+        lib.mi355_clear_error()
+        # (3) a launch of another tile height presents the key: refused inside the wide launcher
+        assert stage() == 0
+        assert lib.mi355_qmatmul_fused(desc(rows=16), st) != 0
+        # (4) a refused launch forgets the images: the same call again has no staged images and would read the key buffer -- allowed
+        # (an ordinary unstaged grouped call), which is why the refusal above must not be retried by callers; here it simply runs
+        assert lib.mi355_qmatmul_fused(desc(rows=16), st) == 0
+    finally:
+        lib.mi355_set_tuning(24, 0)
+        lib.mi355_clear_error()
+    # (5) ranks beyond the row limit go to the dump row E * cap
+    assert stage(row_limit=2) == 0
+    torch.cuda.synchronize()
+    p_h = pos.cpu().numpy().reshape(B, K)
+    seen = {e: 0 for e in range(E)}
+    for t in range(B):
+        for j in range(K):
+            e = int(ids_h[t, j])
+            want = e * cap + seen[e] if seen[e] < 2 else E * cap
+            assert int(p_h[t, j]) == want, (t, j, e, seen[e], p_h[t, j])
+            seen[e] += 1
+    lib.mi355_qmatmul_fused(desc(), st)                     # consume / drop the staged state
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("hid,E,K", [(4096, 8, 2), (2048, 4, 2), (1024, 16, 4), (8192, 2, 1), (4096, 1, 1), (3072, 8, 2), (4096, 6, 2)])
