@@ -783,8 +783,23 @@ __device__ __forceinline__ void pa_mfma_chunk(const PAParams& p, const int b, co
 // workgroup takes WPB consecutive partitions, one per wave, and merges them in LDS before anything goes to global
 // memory -- WPB x fewer partials for the reduce / fused merge, which is what bounds the step at batch 1 (129
 // partitions per head at 4 k context).
+// every field of the parameter block in ONE burst of scalar loads at wave entry (round 6; see qmm_kernarg_burst in qmatmul.hip): the
+// compiler loads a kernarg field in the block that first uses it, and this kernel's prologue was context_lens pointer -> wait -> the
+// context length -> wait -> arrive pointer -> wait -> the rest -> wait, four dependent scalar round trips in front of the first K request
+#ifndef PA_KARG_BURST
+#define PA_KARG_BURST 1
+#endif
+__device__ __forceinline__ void pa_kernarg_burst(const PAParams& p) {
+#if PA_KARG_BURST
+    asm volatile("" ::"s"(p.out), "s"(p.tmp_out), "s"(p.max_logits), "s"(p.exp_sums), "s"(p.q), "s"(p.kc), "s"(p.vc), "s"(p.block_tables),
+                 "s"(p.context_lens), "s"(p.H), "s"(p.Hkv), "s"(p.D), "s"(p.block_size), "s"(p.max_blocks), "s"(p.partition_size),
+                 "s"(p.max_partitions), "s"(p.scale), "s"(p.softcap), "s"(p.q_stride), "s"(p.arrive), "s"(p.kv8), "s"(p.k_scale), "s"(p.v_scale));
+#endif
+}
+
 template <int D32, int NT, bool KV8 = false, int WPB = 1>
 __global__ void __launch_bounds__(64 * WPB) paged_attn_mfma_kernel(const PAParams p) {
+    pa_kernarg_burst(p);
     constexpr int D = 32 * D32, NTD = D / 16;
     const int hk = blockIdx.x, b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -624,10 +624,52 @@ __device__ __forceinline__ void qmm_stamp(const QmmArgs& a, int i) {
 #else
 #define qmm_stamp(a, i) ((void)0)
 #endif
+// Round 6: the INSIDE of a single-token launch on a timeline (-DMI355_QMM_TIMELINE builds only, tools/exp_b1_timeline.py):
+// eight 100 MHz timestamps per wave, kept in registers and written once at exit (a store in the loop would join the counted vmcnt waits):
+//   0 wave entry   1 kernarg fields in SGPRs   2 every load of the prologue issued   3 first k-block staged (= x and norm weight arrived)
+//   4 first (k-block, tile) unit computed (= first weights arrived)   5 main loop done   6 past the workgroup barrier   7 epilogue stores issued
+#ifdef MI355_QMM_TIMELINE
+#define QMM_TL_DECL unsigned long long qtl[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define QMM_TL(i) do { qtl[i] = wall_clock64(); } while (0)
+#define QMM_TL_ONCE(i) do { if (qtl[i] == 0) qtl[i] = wall_clock64(); } while (0)
+#define QMM_TL_FLUSH() do { if ((threadIdx.x & 63) == 0 && g_qmm_ts) { \
+        unsigned long long* d_ = g_qmm_ts + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (threadIdx.x >> 6)) * 8; \
+        for (int i_ = 0; i_ < 8; ++i_) d_[i_] = qtl[i_]; } } while (0)
+#else
+#define QMM_TL_DECL ((void)0)
+#define QMM_TL(i) ((void)0)
+#define QMM_TL_ONCE(i) ((void)0)
+#define QMM_TL_FLUSH() ((void)0)
+#endif
+
+// Every descriptor field the single-token kernel touches, requested in ONE burst of scalar loads at wave entry (round 6).  Left to
+// itself hipcc loads a kernarg field in the basic block that first uses it: the prologue of qmm_kernel<1,1,...> was a chain of EIGHT
+// `s_load -> s_waitcnt lgkmcnt(0) -> branch` round trips (paired, nseg, the segment walk, the tile pointer, B, n_rows, epi, the positions
+// pointer, norm_w / K, the x pointer) before the first weight request left the wave -- at the start of a launch every one of them misses
+// the scalar cache (the kernarg lines are cold in this XCD's L2 as well), and 160 launches per step pay it.  One asm statement with all
+// fields as SGPR inputs makes every load dominate its uses, so the compiler issues them back to back behind a single wait and re-uses
+// the registers in the branches below (kernarg memory is invariant: the later a.field reads are the same values).
+#ifndef QMM_KARG_BURST
+#define QMM_KARG_BURST 1
+#endif
+__device__ __forceinline__ void qmm_kernarg_burst(const QmmArgs& a) {
+#if QMM_KARG_BURST
+    asm volatile("" ::"s"(a.seg[0].w), "s"(a.seg[1].w), "s"(a.seg[2].w), "s"(a.seg[0].n_tiles), "s"(a.seg[1].n_tiles), "s"(a.seg[2].n_tiles),
+                 "s"(a.seg[0].type), "s"(a.seg[1].type), "s"(a.seg[2].type), "s"(a.seg[0].n_rows), "s"(a.seg[1].n_rows), "s"(a.seg[2].n_rows),
+                 "s"(a.seg[0].row0), "s"(a.seg[1].row0), "s"(a.seg[2].row0), "s"(a.nseg), "s"(a.paired), "s"(a.x), "s"(a.ldx), "s"(a.K),
+                 "s"(a.B), "s"(a.norm_w), "s"(a.eps), "s"(a.epi), "s"(a.out), "s"(a.ldo), "s"(a.resid), "s"(a.bias), "s"((int)blockDim.x));
+    asm volatile("" ::"s"(a.cos_t), "s"(a.sin_t), "s"(a.positions), "s"(a.slot_mapping), "s"(a.q_out), "s"(a.kcache), "s"(a.vcache), "s"(a.Hq),
+                 "s"(a.Hkv), "s"(a.D), "s"(a.rot), "s"(a.block_size), "s"(a.kv_layout));
+#endif
+}
 
 template <int BT, int R, int WT, int XB, int NRM, bool MOE = false>
 __device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po = QmmPairOff{0, 0, 0, 0, 0}) {
     qmm_stamp(a, 0);
+    QMM_TL_DECL;
+    QMM_TL(0);
+    qmm_kernarg_burst(a);
+    QMM_TL(1);
     // probe modes of this kernel exist only in -DMI355_QMM_PROBES builds (tools/): every guarded load or branch in the hot
     // loop costs the production kernel measurable time
     const int dbg = QMM_DBG(a);
@@ -645,8 +687,18 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po =
 #pragma unroll
         for (int r = 0; r < R; ++r) { segi[r] = r & 1; tile[r] = blockIdx.x * (R / 2 > 0 ? R / 2 : 1) + (r >> 1); }
     } else {
+        // (the segment walk over values that are already in SGPRs: a loop over a.seg[s] re-loads from the kernarg segment with a
+        // run-time index, one dependent scalar round trip per segment in front of the first weight request)
         int t = blockIdx.x * R, s = 0;
+#if QMM_KARG_BURST
+        const int nt0 = a.seg[0].n_tiles, nt1 = a.seg[1].n_tiles;
+        if (a.nseg > 1 && t >= nt0) {
+            t -= nt0; s = 1;
+            if (a.nseg > 2 && t >= nt1) { t -= nt1; s = 2; }
+        }
+#else       // the round-1..5 form (A/B builds: -DQMM_KARG_BURST=0)
         while (s + 1 < a.nseg && t >= a.seg[s].n_tiles) { t -= a.seg[s].n_tiles; ++s; }
+#endif
 #pragma unroll
         for (int r = 0; r < R; ++r) { segi[r] = s; tile[r] = t + r; }      // launcher guarantees n_tiles % R == 0
     }
@@ -654,9 +706,15 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po =
     int wtype[R], wtb[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
+#if QMM_KARG_BURST
+        wtype[r] = WT ? WT : (segi[r] == 0 ? a.seg[0].type : segi[r] == 1 ? a.seg[1].type : a.seg[2].type);
+        wtb[r] = (wtype[r] == MI355_GGML_Q4_K) ? Q4K_TILE : Q6K_TILE;
+        wbase[r] = (segi[r] == 0 ? a.seg[0].w : segi[r] == 1 ? a.seg[1].w : a.seg[2].w) + (size_t)tile[r] * nkb * wtb[r];
+#else
         wtype[r] = WT ? WT : a.seg[segi[r]].type;
         wtb[r] = (wtype[r] == MI355_GGML_Q4_K) ? Q4K_TILE : Q6K_TILE;
         wbase[r] = a.seg[segi[r]].w + (size_t)tile[r] * nkb * wtb[r];
+#endif
         if constexpr (MOE) wbase[r] += (segi[r] == 0 ? po.w0 : segi[r] == 1 ? po.w1 : po.w2);
     }
     // RMSNorm weights, or any readable K floats when no norm is fused (keeps the load count static)
@@ -697,6 +755,7 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po =
     }
 
     epi_pre_late(a, ep);
+    QMM_TL(2);
 
     for (int kbi0 = 0; kbi0 < n_my_kb; kbi0 += PFK) {
 #pragma unroll
@@ -704,6 +763,7 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po =
             const int kbi = kbi0 + q;
             const bool active = kbi < n_my_kb;                    // wave-uniform
             if (active && (dbg < 3 || dbg == 7)) stage_kblock3<BT, XB, NRM>(a, xr[q], ximg, lane, ss);
+            QMM_TL_ONCE(3);
             const int kbn = wave + NW * (kbi + PFK);
             if (dbg < 3 || dbg == 7) xr[q] = load_x<BT, XB, NRM>(a, kbn <= kb_last ? kbn : kb_last, lane, nwp, MOE ? po.x_bytes : 0);
             const bool ok = kbi + PFK < n_my_kb;
@@ -723,6 +783,9 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po =
                         for (int r0 = 0; r0 < R; r0 += RJ) {
                             if (WT == MI355_GGML_Q4_K) compute3_q4k<BT, NV, RJ>(&buf[q * R + r0], ximg, lane, y + r0);
                             else compute3_q6k<BT, NV, RJ>(&buf[q * R + r0], ximg, lane, y + r0);
+#ifdef MI355_QMM_TIMELINE
+                            if (qtl[4] == 0) { asm volatile("" ::"v"(y[r0][0])); qtl[4] = wall_clock64(); }
+#endif
                         }
                     }
                 }
@@ -741,6 +804,9 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po =
                         } else {
                             compute3_q6k<BT, NV, 1>(&buf[s], ximg, lane, &y[r]);
                         }
+#ifdef MI355_QMM_TIMELINE
+                        if (qtl[4] == 0) { asm volatile("" ::"v"(y[r][0])); qtl[4] = wall_clock64(); }
+#endif
                     }
                     buf[s] = load_tile<WT>(wtype[r], ok ? wbase[r] + (size_t)kbn * wtb[r] : wbase[r], ok ? lane : 0);
                 }
@@ -756,6 +822,7 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po =
         return;
     }
     qmm_stamp(a, 1);
+    QMM_TL(5);
     // ---- hi + lo, then cross-wave reduction in LDS.  After the xor-32 add, lanes 0..31 hold batch 4*kg+v.
     const int kg = lane >> 4, row = lane & 15;
 #pragma unroll
@@ -775,9 +842,12 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po =
     }
     __syncthreads();
     qmm_stamp(a, 2);
+    QMM_TL(6);
 
     qmm_epilogue<BT, R>(a, red, red_ss, NW, segi, tile, ep, MOE ? po.out : 0);
     qmm_stamp(a, 3);
+    QMM_TL(7);
+    QMM_TL_FLUSH();
 }
 
 template <int BT, int R, int WT, int XB, int NRM>

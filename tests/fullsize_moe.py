@@ -232,6 +232,10 @@ class MoePair:
                 for l in range(cfg.n_layers):
                     xi = np.ascontiguousarray(x_in[l], np.float32)
                     M._check(hip.hipMemcpy(xs_ptr, xi.ctypes.data, xi.nbytes, 1), "H2D")
+                    # the previous layer's last launch staged THIS layer's q|k|v activation image from its own output (chain hint keyed by the
+                    # stream pointer): forget it, or the teacher-forced input just uploaded would never be read (first run of this test:
+                    # 3e-2 -- the accumulated distance of the GPU's own stream, not one layer's error)
+                    lib.mi355_internal_qmm_set_exact(0)
                     for part in range(5):
                         M._check(lib.mi355_llama_run_part(gm.h, l, part, st), "run_part")
                     torch.cuda.synchronize()

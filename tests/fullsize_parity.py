@@ -279,6 +279,7 @@ class Pair:
         for l in range(NL):
             x_in = np.ascontiguousarray(trace[l])
             M._check(hip.hipMemcpy(xs, x_in.ctypes.data, x_in.nbytes, 1), "hipMemcpy H2D")
+            lib.mi355_internal_qmm_set_exact(lib.mi355_internal_qmm_get_exact())    # forget the chain hint: the previous layer's epilogue staged this layer's q|k|v image from ITS output, not from the teacher-forced input
             for part in range(5):
                 M._check(lib.mi355_llama_run_part(gm.h, l, part, st), "run_part")
             self.torch.cuda.synchronize()

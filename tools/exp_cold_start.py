@@ -27,6 +27,18 @@ def clocks():
         return repr(e)
 
 
+def cpu_stat():
+    """cgroup CPU bandwidth counters: nr_throttled / throttled_usec grow when the process group used up its quota inside a period and was
+    frozen until the period ended (CFS bandwidth control)"""
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            d = dict(ln.split() for ln in open(path).read().splitlines())
+            return {k: int(v) for k, v in d.items() if "throttl" in k or k in ("nr_periods", "usage_usec")}
+        except (OSError, ValueError):
+            continue
+    return {}
+
+
 def series(tag, step, n):
     ts = []
     for _ in range(n):
@@ -90,12 +102,33 @@ def main():
     series("C (re-begun, same shape)", step, n)
     print("captures / eager steps:", gm.graph_stats(), flush=True)
     # the host side of an idle phase: a CPU-bound phase in THIS process (what the oracle check is), then replays
+    try:
+        print("cgroup cpu.max:", open("/sys/fs/cgroup/cpu.max").read().strip(), "| visible CPUs:", os.cpu_count(), flush=True)
+    except OSError:
+        pass
+    print("cpu.stat before the CPU-bound phase:", cpu_stat(), flush=True)
     t0 = time.time()
     x = np.random.default_rng(0).standard_normal((3000, 3000))
     while time.time() - t0 < min(idle, 20.0):
         x = x @ x.T / 3000.0
+    print("cpu.stat after the CPU-bound phase :", cpu_stat(), flush=True)
     begin()
+    t0 = time.perf_counter(); step(); dt1 = (time.perf_counter() - t0) * 1e3
+    print(f"first step after the CPU-bound phase: {dt1:.2f} ms; cpu.stat now:", cpu_stat(), flush=True)
     series("D (after a CPU-bound phase of this process)", step, n)
+    # the same with the BLAS / OpenMP pools parked first (threadpoolctl): if the stall is the quota, limiting the burst removes it
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=8):
+            t0 = time.time()
+            while time.time() - t0 < 8.0:
+                x = x @ x.T / 3000.0
+        print("cpu.stat after an 8-thread CPU phase:", cpu_stat(), flush=True)
+        begin()
+        t0 = time.perf_counter(); step(); dt2 = (time.perf_counter() - t0) * 1e3
+        print(f"first step after the 8-thread CPU phase: {dt2:.2f} ms", flush=True)
+    except Exception as e:
+        print("threadpoolctl leg skipped:", repr(e), flush=True)
 
 
 if __name__ == "__main__":
