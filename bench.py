@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--legs", default="all", help="secondary legs at BASELINE configs[2..4] shapes on one GPU (bench_legs.py): "
                                                    "all | none | comma list of bf16_b32,gptq_qwen2,mixtral_fp8")
     ap.add_argument("--layers", type=int, default=0, help="debug only: fewer layers (result marked invalid)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal of the N > 1 command on a one-GPU box: every rank on cuda:0 (gloo control plane, the one-shot peer kernel "
+                         "over IPC for the all-reduces, host-staged vocabulary gather); the line is marked invalid")
     return ap.parse_args()
 
 
@@ -385,6 +388,55 @@ def parity_leg(mode):
     return out
 
 
+def setup_comm(gm, M, dist, args, rank, world):
+    """The tensor-parallel communicator of this run, decided by ALL ranks together -> (transport string, fallback communicator or None).
+      1. local pre-flight (no collective inside): librccl loadable; not the same-device rehearsal (RCCL refuses two ranks on one GPU);
+         not the forced failure of the rehearsal test (MI355_BENCH_FAIL_COMM_RANK = a rank number).  Minimum over the ranks.
+      2. all ranks enter GGUFLLaMa.init_comm (RCCL + the `auto` choice of the decode-sized all-reduce); it raises on every rank or on none.
+      3. otherwise, on EVERY rank together: host-supplied collectives staged through the host over a gloo group (tp.TorchDistComm;
+         eager steps) -- and, unless the pre-flight failure was a forced one, the one-shot peer kernel over IPC for the all-reduces (C1 / C2)
+         with its self-test; the vocabulary gather (C3) stays host-staged.  The run still measures the sharded model and says what carried it.
+    The flags travel over a gloo control group of their own, so a failing device communicator cannot take the agreement down with it."""
+    import torch
+    ctl = dist.new_group(backend="gloo")
+    agree = lambda ok: bool(M.comm_all_min(dist, ok, group=ctl))
+    mode = "p2p" if args.p2p else args.all_reduce
+    fail_rank = os.environ.get("MI355_BENCH_FAIL_COMM_RANK", "")       # the rehearsal test's switch; every rank sees the same environment
+    why, forced = None, fail_rank != ""
+    if fail_rank == str(rank):
+        why = "forced failure of the device communicator on rank %s (MI355_BENCH_FAIL_COMM_RANK)" % fail_rank
+    elif args.same_device:
+        why = f"{world} ranks share one device: RCCL refuses duplicate GPUs"
+    else:
+        probe = np.zeros(128, np.uint8)
+        if M.lib.mi355_comm_unique_id(probe.ctypes.data) != 0:
+            why = "librccl could not be loaded / ncclGetUniqueId failed"
+    if agree(why is None):
+        try:
+            transport, ok = gm.init_comm(dist, p2p={"auto": "auto", "rccl": False, "p2p": True}[mode], wire_bf16=args.wire_bf16), True
+        except Exception as e:                                 # init_comm raises on every rank or on none
+            transport, ok = repr(e)[:200], False
+        if agree(ok):
+            return transport, None
+        why = "init_comm failed: " + transport
+    from candle_vllm_amd import tp as _tp
+    comm = _tp.TorchDistComm(ctl)
+    comm.set_options(1, 1 if args.wire_bf16 else 0)
+    peer = False
+    if not forced and mode != "rccl":
+        if agree(M.ranks_have_peer_access(dist, world, group=ctl) or args.same_device):
+            peer = M.comm_attach_p2p(dist, comm.handle, rank, world, group=ctl)
+            if not peer:
+                M.lib.mi355_comm_p2p_enable(comm.handle, 0)
+    gm.set_comm(comm.handle)
+    reasons = [None] * world
+    dist.all_gather_object(reasons, why, group=ctl)
+    reason = next((r for r in reasons if r and r.startswith("forced")), None) or next((r for r in reasons if r), "unknown")
+    transport = ("FALLBACK: " + ("one-shot peer kernel over IPC for the all-reduces (self-test passed on every rank), " if peer else "")
+                 + "host-staged collectives over gloo" + (" for the vocabulary gather" if peer else "") + " -- " + reason[:200])
+    return transport, comm
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -408,9 +460,14 @@ def main():
                          f"`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     import torch
     import torch.distributed as dist
+    if args.same_device:                                      # rehearsal: every rank on cuda:0 (RCCL refuses two ranks on one GPU: gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.same_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from candle_vllm_amd import model as M
     for kv in filter(None, os.environ.get("MI355_TUNE", "").split(",")):    # experiments only: "key=value,..."
@@ -422,6 +479,8 @@ def main():
     if args.layers:
         cfg.n_layers = args.layers
         invalid = "debug run with fewer layers"
+    if args.same_device and world > 1:
+        invalid = ((invalid + "; ") if invalid else "") + f"{world} ranks on ONE device: a rehearsal of the multi-GPU control flow, not a scaling measurement"
     B, K, Wm = args.batch, args.steps, args.warmup
     do_b32 = (not args.no_batch32) and world == 1 and B == 1
     B32 = 32
@@ -432,25 +491,10 @@ def main():
                      tp_rank=rank, tp_world=world)
     transport, comm_fallback = None, None
     if world > 1:
-        mode = "p2p" if args.p2p else args.all_reduce
-        try:
-            transport, ok = gm.init_comm(dist, p2p={"auto": "auto", "rccl": False, "p2p": True}[mode], wire_bf16=args.wire_bf16), 1
-        except Exception as e:                                 # e.g. librccl not loadable through dlopen on this box
-            transport, ok = repr(e), 0
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if not int(flag.item()):
-            # last resort, on EVERY rank together: host-supplied collectives staged through the host over a gloo group (eager steps, slow)
-            # -- the run still measures the sharded model and says so, instead of leaving the scaling record empty
-            from candle_vllm_amd import tp as _tp
-            comm_fallback = _tp.TorchDistComm(dist.new_group(backend="gloo"))
-            if args.wire_bf16:
-                comm_fallback.set_options(1, 1)
-            gm.set_comm(comm_fallback.handle)
-            transport = "FALLBACK host-staged collectives over gloo (the device communicator failed on at least one rank: " + transport[:160] + ")"
+        transport, comm_fallback = setup_comm(gm, M, dist, args, rank, world)
     gm.load_synthetic(seed=1235, recipe="q4_k_m")
     gm.alloc_kv_cache(num_blocks)
-    gm.kv_fill_random(seed=7 + rank)
+    gm.kv_fill_random(seed=7)                                 # (TP: every rank draws the global cache and keeps its kv-head group)
 
     # block tables: physical blocks in shuffled order (stresses the gather), identical on every rank
     rng = np.random.default_rng(1235)
@@ -466,9 +510,7 @@ def main():
         # every rank tests LOCALLY whether this stack captures the communicator's all-reduce (capture + instantiate, nothing
         # is launched), then the ranks agree: one rank falling back to eager steps alone would leave its peers inside a
         # collective
-        flag = torch.tensor([1 if gm.comm_capture_ok(st) else 0], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        graph_mode = bool(int(flag.item()))
+        graph_mode = bool(M.comm_all_min(dist, 1 if gm.comm_capture_ok(st) else 0))
     gm.set_graph(graph_mode)
     ctx_cap = args.ctx + K + Wm + 2
 
@@ -488,7 +530,7 @@ def main():
     def reduce_max(dt):
         if world == 1:
             return dt
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=M._ctl_device(dist))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -499,6 +541,13 @@ def main():
                                    fixed_settle_steps=(args.settle_steps if world > 1 else 0), reduce_max=reduce_max)
     dt = tb["median_s"]
     tok_s = B * K / dt
+    # the first greedy tokens of the benchmark's start state (untimed, every rank): a sharded run and the one-GPU run of the same
+    # synthetic model can be compared token by token (tests/test_gpu_tp2.py runs both)
+    reset()
+    head_tokens = []
+    for _ in range(min(8, K + Wm)):
+        gm.decode_step(st)
+        head_tokens.append([int(t) for t in gm.read_tokens(st)])
 
     # ---- algorithmic bytes of one step: every weight byte once + live KV once (+ the write)
     mean_ctx = args.ctx + 1 + Wm + (K - 1) / 2.0
@@ -515,7 +564,8 @@ def main():
         "config": {"workload": "BASELINE configs[1]: Llama-3-8B Q4_K_M GGUF shapes, greedy decode, "
                                f"batch={B}, prompt ctx {args.ctx} in paged KV (block 64), {K} decode steps",
                    "batch": B, "ctx_start": args.ctx + 1 + Wm, "ctx_end": args.ctx + Wm + K,
-                   "parallelism": f"tp{world}", "graph": bool(graph_mode),
+                   "parallelism": f"tp{world}", "graph": bool(graph_mode), "first_tokens": head_tokens,
+                   **({"same_device": True} if args.same_device else {}),
                    "timing": {"blocks_ms_per_step": tb["blocks_ms_per_step"], "value_is": "median block",
                               "tokens_per_s_min": round(B * K / tb["max_s"], 2), "tokens_per_s_max": round(B * K / tb["min_s"], 2),
                               "settle": tb["settle"], "graph_captures_in_timed_region": tb.get("graph_captures_in_timed_region"),

@@ -533,7 +533,11 @@ __device__ __forceinline__ void qmm_epilogue(const QmmArgs& a, const float* red,
     const int nout = NOUT;
     for (int idx = threadIdx.x; idx < nout; idx += blockDim.x) {
         const int rr = idx & 15, b = (idx >> 4) % BT, r = idx / (16 * BT);
+#ifdef QMM_NO_EPI_PRE
+        const bool pre = false;
+#else
         const bool pre = idx == (int)threadIdx.x;                   // first pass: operands were prefetched
+#endif
         if (b >= a.B) continue;
         float rs = 1.f;
         if (a.norm_w) {
@@ -652,8 +656,14 @@ __device__ __forceinline__ void qmm_stamp(const QmmArgs& a, int i) {
 #ifndef QMM_KARG_BURST
 #define QMM_KARG_BURST 1
 #endif
+#ifndef QMM_SEG_SELECT
+#define QMM_SEG_SELECT QMM_KARG_BURST
+#endif
 __device__ __forceinline__ void qmm_kernarg_burst(const QmmArgs& a) {
-#if QMM_KARG_BURST
+#if QMM_KARG_BURST == 2      // only what stands between wave entry and the first weight / activation request
+    asm volatile("" ::"s"(a.seg[0].w), "s"(a.seg[1].w), "s"(a.seg[2].w), "s"(a.seg[0].n_tiles), "s"(a.seg[1].n_tiles), "s"(a.nseg), "s"(a.paired),
+                 "s"(a.x), "s"(a.K), "s"(a.B), "s"(a.norm_w), "s"(a.epi), "s"((int)blockDim.x));
+#elif QMM_KARG_BURST
     asm volatile("" ::"s"(a.seg[0].w), "s"(a.seg[1].w), "s"(a.seg[2].w), "s"(a.seg[0].n_tiles), "s"(a.seg[1].n_tiles), "s"(a.seg[2].n_tiles),
                  "s"(a.seg[0].type), "s"(a.seg[1].type), "s"(a.seg[2].type), "s"(a.seg[0].n_rows), "s"(a.seg[1].n_rows), "s"(a.seg[2].n_rows),
                  "s"(a.seg[0].row0), "s"(a.seg[1].row0), "s"(a.seg[2].row0), "s"(a.nseg), "s"(a.paired), "s"(a.x), "s"(a.ldx), "s"(a.K),
@@ -662,6 +672,31 @@ __device__ __forceinline__ void qmm_kernarg_burst(const QmmArgs& a) {
                  "s"(a.Hkv), "s"(a.D), "s"(a.rot), "s"(a.block_size), "s"(a.kv_layout));
 #endif
 }
+
+// the same for the kernels of the 9..32-token path (staging, GEMM, split-K epilogue): their prologues walk rows_dev pointer -> wait ->
+// *rows_dev -> wait -> three to five further fields, each behind its own wait; here EVERY descriptor field goes out in one burst
+// (the row gate's own load follows as the single dependent round trip it has to be)
+#ifndef QMM_KARG_BURST_WIDE
+#define QMM_KARG_BURST_WIDE QMM_KARG_BURST
+#endif
+__device__ __forceinline__ void qmm_kernarg_burst_all(const QmmArgs& a) {
+#if QMM_KARG_BURST_WIDE
+    qmm_kernarg_burst(a);
+    asm volatile("" ::"s"(a.next_norm_w), "s"(a.chain_next), "s"(a.next_k), "s"(a.rows_dev), "s"(a.rows_min), "s"(a.x_dtype), "s"(a.grp_n),
+                 "s"(a.grp_x), "s"(a.grp_out), "s"(a.moe_stride[0]), "s"(a.moe_stride[1]), "s"(a.moe_stride[2]));
+#endif
+}
+#if QMM_KARG_BURST_WIDE
+#define QMM_BURST_CHAIN(ch) asm volatile("" ::"s"((ch).img), "s"((ch).ssp), "s"((ch).norm_w), "s"((ch).K), "s"((ch).MT), "s"((ch).kbb), "s"((ch).sp))
+#define QMM_BURST_VALS(...) qmm_burst_vals(__VA_ARGS__)
+template <typename T>
+__device__ __forceinline__ int qmm_burst_one(T v) { asm volatile("" ::"s"(v)); return 0; }
+template <typename... T>
+__device__ __forceinline__ void qmm_burst_vals(T... v) { const int u_[] = {qmm_burst_one(v)...}; (void)u_; }
+#else
+#define QMM_BURST_CHAIN(ch) ((void)0)
+#define QMM_BURST_VALS(...) ((void)0)
+#endif
 
 template <int BT, int R, int WT, int XB, int NRM, bool MOE = false>
 __device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po = QmmPairOff{0, 0, 0, 0, 0}) {
@@ -678,7 +713,14 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po =
     constexpr int PFK = PF / R;                                  // ring depth in k-blocks
     static_assert(PF % R == 0, "ring depth must be a multiple of the tiles per workgroup");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+#ifndef QMM_UNIFORM_WAVE
+#define QMM_UNIFORM_WAVE 1
+#endif
+#if QMM_UNIFORM_WAVE   // the wave index as a SCALAR: the k-block loop and its `active` tests become scalar branches instead of exec-masked regions
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), NW = blockDim.x >> 6;
+#else
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
+#endif
     const int nkb = a.K >> 8;
 
     // ---- which tiles does this workgroup own?  slot r in [0,R)
@@ -690,7 +732,7 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po =
         // (the segment walk over values that are already in SGPRs: a loop over a.seg[s] re-loads from the kernarg segment with a
         // run-time index, one dependent scalar round trip per segment in front of the first weight request)
         int t = blockIdx.x * R, s = 0;
-#if QMM_KARG_BURST
+#if QMM_SEG_SELECT
         const int nt0 = a.seg[0].n_tiles, nt1 = a.seg[1].n_tiles;
         if (a.nseg > 1 && t >= nt0) {
             t -= nt0; s = 1;
@@ -706,7 +748,7 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po =
     int wtype[R], wtb[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-#if QMM_KARG_BURST
+#if QMM_SEG_SELECT
         wtype[r] = WT ? WT : (segi[r] == 0 ? a.seg[0].type : segi[r] == 1 ? a.seg[1].type : a.seg[2].type);
         wtb[r] = (wtype[r] == MI355_GGML_Q4_K) ? Q4K_TILE : Q6K_TILE;
         wbase[r] = (segi[r] == 0 ? a.seg[0].w : segi[r] == 1 ? a.seg[1].w : a.seg[2].w) + (size_t)tile[r] * nkb * wtb[r];
@@ -736,7 +778,11 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po =
     for (int b = 0; b < BT; ++b) ss[b] = 0.f;
 
     EpiPre ep;
+#ifdef QMM_NO_EPI_PRE      // bisect switch: no early operand fetch, the epilogue loads in place
+    ep.pos = 0; ep.slot = -1; ep.f0 = 0.f; ep.f1 = 0.f; ep.lrow = 0; ep.sgi = 0; ep.live = false; ep.rope = false;
+#else
     epi_pre_early<BT, R>(a, segi, tile, ep);
+#endif
 
     // this wave's k-blocks: kb = wave + NW*kbi, kbi in [0, n_my_kb); ring slot s <-> (kbi0 + s/R, tile s%R)
     const int n_my_kb = (nkb > wave) ? (nkb - wave + NW - 1) / NW : 0;
@@ -1381,6 +1427,9 @@ __device__ __forceinline__ void qmm_epilogue_body(const QmmArgs& a, const float*
 __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, const float* __restrict__ part, const int ldp,
                                                            const int ks, const int BP, const float* __restrict__ ssp,
                                                            const QmgChainOut ch, const float* __restrict__ rscale = nullptr) {
+    qmm_kernarg_burst_all(a);
+    QMM_BURST_CHAIN(ch);
+    QMM_BURST_VALS(part, ldp, ks, BP, ssp, rscale);
     if (a.rows_dev && *a.rows_dev <= a.rows_min) return;
     qmm_epilogue_body(a, part, ldp, ks, BP, ssp, ch, rscale, 0, a.B);
 }
@@ -1388,6 +1437,9 @@ __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, cons
 __global__ void __launch_bounds__(256) qmm_epilogue_grp_kernel(const QmmArgs a, const float* __restrict__ part, const int ldp,
                                                                const int ks, const int BP, const float* __restrict__ ssp,
                                                                const QmgChainOut ch0, const QwGroup g) {
+    qmm_kernarg_burst_all(a);
+    QMM_BURST_CHAIN(ch0);
+    QMM_BURST_VALS(part, ldp, ks, BP, ssp, g.x, g.out, g.img, g.part, g.chimg);
     const int e = blockIdx.z;
     const int nb = a.rows_dev ? min(a.B, a.rows_dev[e] - a.rows_min) : a.B;
     // rows past the group's count: nothing to sum, and no image entry either -- every kernel of the path keeps rows apart (a row of the

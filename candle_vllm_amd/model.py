@@ -2,12 +2,13 @@
 which mirrors src/openai/models/quantized_llama.rs (forward), src/scheduler/cache_engine.rs (KV cache) and
 src/backend/graph.rs (decode graph).  torch only supplies streams / device memory for tests and the bench."""
 import ctypes
+import os
 
 import numpy as np
 import torch
 
 from ._lib import lib, LlamaConfig
-from .ops import _check, GGML_Q4_K, GGML_Q6_K, KV_FLASH, KV_PAGED, DT_F32  # noqa: F401
+from .ops import _check, GGML_Q4_K, GGML_Q6_K, KV_FLASH, KV_PAGED, DT_F32, DT_BF16  # noqa: F401
 
 KV_PAGED_FP8 = 2          # `--kvcache-dtype fp8`: e4m3fn bytes in the paged layout with x = 16
 
@@ -60,6 +61,70 @@ def random_tiles(ggml_type, n_rows, k, device, gen, d_scale=0.0025):
         tv = t.view(ntile, 3360)
         tv[:, 3328:3360:2] = int(d[0]); tv[:, 3329:3360:2] = int(d[1])
     return t
+
+
+# ---- control-plane helpers of the tensor-parallel set-up (shared by GGUFLLaMa.init_comm and bench.py's fallback path) ---------------
+def _ctl_device(dist):
+    """where the launcher's small agreement tensors live: on the device under the nccl (RCCL) backend, on the host under gloo"""
+    return "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+
+def comm_all_min(dist, v, group=None):
+    """the ranks decide together: minimum of an int flag"""
+    f = torch.tensor([int(v)], dtype=torch.int32, device=_ctl_device(dist) if group is None else "cpu")
+    dist.all_reduce(f, op=dist.ReduceOp.MIN, group=group)
+    return int(f.item())
+
+
+def ranks_have_peer_access(dist, world, group=None):
+    """local answer: can THIS rank's device reach the device of every other rank?  Only the devices the ranks actually use are asked
+    (an unrelated GPU without peer access must not veto the peer kernel); ranks that cannot tell (one visible device per process, e.g.
+    HIP_VISIBLE_DEVICES) answer yes and leave the decision to export / attach / self-test."""
+    try:
+        dev = torch.cuda.current_device()
+        mine = (os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "")), dev)
+        used = [None] * world
+        dist.all_gather_object(used, mine, group=group)
+        if torch.cuda.device_count() < 2 or any(u[0] != mine[0] for u in used):
+            return True
+        return all(torch.cuda.can_device_access_peer(dev, u[1]) for u in used if u[1] != dev)
+    except Exception:
+        return False
+
+
+def p2p_self_test(comm, rank, world):
+    """local answer: known sums through the one-shot peer kernel -- two f32 rounds and a bf16 round (the wire dtype of the 16-bit path
+    and of wire_bf16), result and sticky error word checked.  Every rank must call it (the kernel waits for its peers)."""
+    st = torch.cuda.current_stream().cuda_stream
+    ok = True
+    for rnd, want, dt, tdt in ((1, world * (world + 1) // 2, DT_F32, torch.float32), (2, world * world, DT_F32, torch.float32),
+                               (1, world * (world + 1) // 2, DT_BF16, torch.bfloat16)):
+        x = torch.full((2048,), float(rnd * rank + 1), dtype=tdt, device="cuda")
+        rc = lib.mi355_comm_all_reduce(comm, x.data_ptr(), x.numel(), dt, st)
+        torch.cuda.synchronize()
+        ok = ok and rc == 0 and bool((x.float() == float(want)).all().item()) and lib.mi355_comm_p2p_error(comm) == 0
+    return ok
+
+
+def comm_attach_p2p(dist, comm, rank, world, group=None):
+    """export -> gather the 64-byte IPC handles -> attach -> self-test, the same collective sequence on every rank whatever fails locally;
+    -> True when the peer kernel is usable on EVERY rank"""
+    h = ctypes.create_string_buffer(64)
+    exported = int(lib.mi355_comm_p2p_export(comm, ctypes.addressof(h)) == 0)
+    all_h = [None] * world
+    dist.all_gather_object(all_h, bytes(h.raw), group=group)
+    attached = 0
+    if comm_all_min(dist, exported, group):
+        blob = ctypes.create_string_buffer(b"".join(all_h), 64 * world)
+        attached = int(lib.mi355_comm_p2p_attach(comm, ctypes.addressof(blob), rank, world) == 0)
+    ok = comm_all_min(dist, attached, group)
+    if ok:
+        try:
+            ok = p2p_self_test(comm, rank, world)
+        except Exception:
+            ok = False
+        ok = comm_all_min(dist, ok, group)
+    return bool(ok)
 
 
 class GGUFLLaMa:
@@ -161,27 +226,42 @@ class GGUFLLaMa:
     def load_synthetic(self, seed=1235, recipe="q4_k_m", scale=1.0):
         """Random-init weights of the configured architecture, generated on the GPU already in tile order.  scale: std of the
         projections relative to the default (1.0 = std ~0.04: every branch has gain >> 1 and the 32-layer stack amplifies rounding
-        noise chaotically -- fine for timing; 0.2 = branch gain < 1 as in a trained checkpoint, for comparisons of logits)"""
+        noise chaotically -- fine for timing; 0.2 = branch gain < 1 as in a trained checkpoint, for comparisons of logits).
+        Tensor parallel (round 6): every rank draws the GLOBAL tensor from the same seed and keeps its shard -- row tiles for the
+        column-parallel projections and the lm_head, k-blocks for wo / w2, the kv-head group of `kv_head_shard` for wk / wv
+        (distributed.rs:243-249,696-765) -- so the sharded model IS the one-GPU model and their tokens can be compared."""
+        from .tp import kv_head_shard
         cfg = self.cfg
         gen = torch.Generator(device="cuda")
         gen.manual_seed(seed)
-        Wn = self.tp_world
-        H, Hkv, D, hid = self.local_heads, self.local_kv_heads, cfg.head_dim, cfg.hidden
-        I, V = cfg.intermediate // Wn, cfg.vocab // Wn
-        if (I % 256) or (cfg.intermediate % Wn) or (cfg.vocab % (16 * Wn)) or ((H * D) % 256):
+        Wn, R = self.tp_world, self.tp_rank
+        Hg, Hkvg, D, hid = cfg.n_heads, cfg.n_kv_heads, cfg.head_dim, cfg.hidden
+        Ig, Vg = cfg.intermediate, cfg.vocab
+        H, Hkv = self.local_heads, self.local_kv_heads
+        I, V = Ig // Wn, Vg // Wn
+        if (I % 256) or (Ig % Wn) or (Vg % (16 * Wn)) or ((H * D) % 256):
             raise ValueError("TP shard is not block aligned (the reference re-quantises to Q8_0 here; not built)")
-        shapes = {"wq": (H * D, hid), "wk": (Hkv * D, hid), "wv": (Hkv * D, hid), "wo": (hid, H * D),
-                  "w1": (I, hid), "w2": (hid, I), "w3": (I, hid)}
+        _, kv_rank, kv_world = kv_head_shard(Hkvg, R, Wn)
+        # name -> (global rows, global k, sharded axis, this rank's index on that axis, shards on that axis)
+        plan = {"wq": (Hg * D, hid, 0, R, Wn), "wk": (Hkvg * D, hid, 0, kv_rank, kv_world), "wv": (Hkvg * D, hid, 0, kv_rank, kv_world),
+                "wo": (hid, Hg * D, 1, R, Wn), "w1": (Ig, hid, 0, R, Wn), "w3": (Ig, hid, 0, R, Wn), "w2": (hid, Ig, 1, R, Wn),
+                "output": (Vg, hid, 0, R, Wn)}
         part_of = {"wq": 0, "wk": 0, "wv": 0, "wo": 2, "w1": 3, "w3": 3, "w2": 4}
 
         def f32(layer, which, a):
             a = np.ascontiguousarray(a, np.float32)
             _check(lib.mi355_llama_set_f32(self.h, layer, which, a.ctypes.data, a.size), "set_f32")
 
-        def qw(layer, which, name, n, k):
+        def qw(layer, which, name):
+            ng, kg, axis, idx, cnt = plan[name]
             t = q4km_type_for(name, layer, cfg.n_layers) if recipe == "q4_k_m" else \
                 (GGML_Q6_K if name == "output" else GGML_Q4_K)
-            tiles = random_tiles(t, n, k, "cuda", gen, d_scale=0.0025 * scale)
+            tiles = random_tiles(t, ng, kg, "cuda", gen, d_scale=0.0025 * scale)
+            n, k = (ng // cnt, kg) if axis == 0 else (ng, kg // cnt)
+            if cnt > 1:                                           # [row tile][k-block][tile bytes]: the shard is a slab of that view
+                tv = tiles.view(ng // 16, kg // 256, _TILE_BYTES[t])
+                tv = tv[idx * (n // 16):(idx + 1) * (n // 16)] if axis == 0 else tv[:, idx * (k // 256):(idx + 1) * (k // 256)]
+                tiles = tv.contiguous().view(-1)
             self._keep.append(tiles)
             _check(lib.mi355_llama_set_qweight_tiles(self.h, layer, which, t, tiles.data_ptr(), n, k), "set_tiles")
             nbytes = (n // 16) * (k // 256) * _TILE_BYTES[t]
@@ -190,16 +270,15 @@ class GGUFLLaMa:
             self.part_bytes[key] = self.part_bytes.get(key, 0) + nbytes
         rng = np.random.default_rng(seed)
         emb = torch.randn((cfg.vocab, hid), device="cuda", generator=gen) * 0.02      # identical on every rank
-        gen.manual_seed(seed + 1000 * (self.tp_rank + 1))                              # shards differ per rank
         f32(-1, W_TOK_EMBD, emb.cpu().numpy())
         del emb
         f32(-1, W_OUTPUT_NORM, 1.0 + rng.normal(0, 0.02, hid))
-        qw(-1, W_OUTPUT, "output", V, hid)
+        qw(-1, W_OUTPUT, "output")
         for l in range(cfg.n_layers):
             f32(l, W_ATTN_NORM, 1.0 + rng.normal(0, 0.02, hid))
             f32(l, W_FFN_NORM, 1.0 + rng.normal(0, 0.02, hid))
             for name, slot in _SLOT.items():
-                qw(l, slot, name, *shapes[name])
+                qw(l, slot, name)
         torch.cuda.synchronize()
 
     @property
@@ -212,67 +291,41 @@ class GGUFLLaMa:
         p2p: the transport of the decode-sized all-reduces (<= 256 KiB; C1 / C2 are 16 KiB at batch 1) --
           False  RCCL on its side stream for every message;
           True   the one-shot peer-to-peer kernel (every rank's 64-byte IPC handle gathered through `dist`), in-stream;
-          "auto" (default) the peer kernel when every pair of this node's ranks has peer access AND a self-test across the ranks
-                 (two all-reduces of known data through the peer kernel, the sticky error word clean) passes on every rank;
-                 otherwise every rank goes back to RCCL together.  `self.all_reduce_transport` says what was chosen and why.
-        wire_bf16: the reference's all-reduce numerics (attention.rs:1003-1008)."""
+          "auto" (default) the peer kernel when every pair of the devices the ranks actually use has peer access AND a self-test across
+                 the ranks (f32 and bf16 all-reduces of known data through the peer kernel, the sticky error word clean) passes on every
+                 rank; otherwise every rank goes back to RCCL together.  `self.all_reduce_transport` says what was chosen and why.
+        wire_bf16: the reference's all-reduce numerics (attention.rs:1003-1008).
+        Every rank runs the SAME sequence of collectives whatever fails locally: a local failure becomes a flag, the ranks take the minimum,
+        and all of them raise (or fall back) together -- a rank that raised between two collectives used to leave its peers inside the next
+        one."""
+        all_min = lambda v: comm_all_min(dist, v)
         buf = np.zeros(128, np.uint8)
-        if self.tp_rank == 0:
-            _check(lib.mi355_comm_unique_id(buf.ctypes.data), "comm_unique_id")
-        t = torch.from_numpy(buf).cuda()
+        rc0 = lib.mi355_comm_unique_id(buf.ctypes.data) if self.tp_rank == 0 else 0
+        t = torch.from_numpy(buf).to(_ctl_device(dist))
         dist.broadcast(t, src=0)
         buf = np.ascontiguousarray(t.cpu().numpy())
-        _check(lib.mi355_llama_init_comm(self.h, buf.ctypes.data), "init_comm")
+        if not all_min(rc0 == 0):
+            raise RuntimeError("mi355_comm_unique_id failed on rank 0 (librccl not loadable?)")
+        rc = lib.mi355_llama_init_comm(self.h, buf.ctypes.data)       # collective inside RCCL: every rank enters it
+        if not all_min(rc == 0):
+            raise RuntimeError(f"mi355_llama_init_comm failed on at least one rank (here: hipError / ncclResult {rc})")
         comm = lib.mi355_llama_comm_handle(self.h)
         if wire_bf16:
             _check(lib.mi355_comm_set_options(comm, 1, 1), "comm_set_options")
         self.all_reduce_transport = "RCCL on a side stream"
         if not p2p or (p2p == "auto" and self.tp_world < 2):          # (a one-rank world has no peer to reach)
             return self.all_reduce_transport
-
-        def all_min(v):                                            # the ranks decide together
-            f = torch.tensor([int(v)], dtype=torch.int32, device="cuda")
-            dist.all_reduce(f, op=dist.ReduceOp.MIN)
-            return int(f.item())
-        if p2p == "auto":
-            try:
-                dev, n = torch.cuda.current_device(), torch.cuda.device_count()
-                peers = n >= self.tp_world and all(torch.cuda.can_device_access_peer(dev, j) for j in range(n) if j != dev)
-            except Exception:
-                peers = False
-            if not all_min(peers):
-                self.all_reduce_transport = "RCCL on a side stream (no peer access between every pair of ranks)"
-                return self.all_reduce_transport
-        attached = 0
-        try:
-            h = ctypes.create_string_buffer(64)
-            _check(lib.mi355_comm_p2p_export(comm, ctypes.addressof(h)), "comm_p2p_export")
-            exported = 1
-        except RuntimeError:
-            h, exported = ctypes.create_string_buffer(64), 0
-        all_h = [None] * self.tp_world
-        dist.all_gather_object(all_h, bytes(h.raw))
-        if all_min(exported):
-            blob = ctypes.create_string_buffer(b"".join(all_h), 64 * self.tp_world)
-            attached = int(lib.mi355_comm_p2p_attach(comm, ctypes.addressof(blob), self.tp_rank, self.tp_world) == 0)
-        ok = all_min(attached)
-        if ok:
-            # self-test: every rank contributes rank + 1 (then 2 * rank + 1); a peer that is not there poisons with NaN + error word
-            st = torch.cuda.current_stream().cuda_stream
-            W = self.tp_world
-            for rnd, want in ((1, W * (W + 1) // 2), (2, W * W)):
-                x = torch.full((2048,), float(rnd * self.tp_rank + 1), dtype=torch.float32, device="cuda")
-                rc = lib.mi355_comm_all_reduce(comm, x.data_ptr(), x.numel(), DT_F32, st)
-                torch.cuda.synchronize()
-                ok = ok and rc == 0 and bool((x == float(want)).all().item()) and lib.mi355_comm_p2p_error(comm) == 0
-            ok = all_min(ok)
+        if p2p == "auto" and not all_min(ranks_have_peer_access(dist, self.tp_world)):
+            self.all_reduce_transport = "RCCL on a side stream (no peer access between every pair of the ranks' devices)"
+            return self.all_reduce_transport
+        ok = comm_attach_p2p(dist, comm, self.tp_rank, self.tp_world)
         if ok:
             self.all_reduce_transport = "one-shot peer kernel (<= 256 KiB, in-stream), RCCL above"
         else:
             lib.mi355_comm_p2p_enable(comm, 0)
             if p2p is True:
                 raise RuntimeError("the one-shot peer all-reduce was requested and failed its export / attach / self-test on at least one rank")
-            self.all_reduce_transport = "RCCL on a side stream (the peer kernel failed its self-test on at least one rank)"
+            self.all_reduce_transport = "RCCL on a side stream (the peer kernel failed its export / attach / self-test on at least one rank)"
         return self.all_reduce_transport
 
     def comm_capture_ok(self, stream):
@@ -385,13 +438,25 @@ class GGUFLLaMa:
         return k, v
 
     def kv_fill_random(self, seed=7):
-        """synthetic context: random bf16 K/V (std 1) in every block, as if a prompt had been prefetched"""
+        """synthetic context: random bf16 K/V (std 1) in every block, as if a prompt had been prefetched.  Tensor parallel: every rank
+        draws the GLOBAL cache (all kv heads) from the same seed and keeps its kv-head group, like `load_synthetic`."""
+        from .tp import kv_head_shard
         gen = torch.Generator(device="cuda")
         gen.manual_seed(seed)
         n = lib.mi355_llama_kv_bytes_per_tensor(self.h) // 2
+        Hkvg, hl = self.cfg.n_kv_heads, self.local_kv_heads
+        _, kv_rank, kv_world = kv_head_shard(Hkvg, self.tp_rank, self.tp_world)
+        ks, vs = self.kv_shape() if self.tp_world > 1 else (None, None)
         for l in range(self.cfg.n_layers):
             for which in (0, 1):
-                t = torch.randn((n,), device="cuda", generator=gen).to(torch.bfloat16)
+                if self.tp_world == 1:
+                    t = torch.randn((n,), device="cuda", generator=gen).to(torch.bfloat16)
+                else:
+                    sh = list(ks if which == 0 else vs)
+                    hax = 2 if self.kv_layout == KV_FLASH else 1              # the kv-head axis of the layout
+                    sh[hax] = Hkvg
+                    g = torch.randn(sh, device="cuda", generator=gen).to(torch.bfloat16)
+                    t = g.narrow(hax, kv_rank * hl, hl).contiguous().view(-1)
                 _check(lib.mi355_llama_kv_copy(self.h, l, which, t.data_ptr(), n * 2, 1), "kv_copy")
 
     # ------------------------------------------------------------------ forward

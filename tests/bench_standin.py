@@ -18,6 +18,10 @@ def _fake_model_module(dist, calls):
         def mi355_set_tuning(k, v):
             return 0
 
+        @staticmethod
+        def mi355_comm_unique_id(ptr):                    # bench.py's pre-flight: "librccl loads"
+            return 0
+
     class FakeGGUFLLaMa:
         def __init__(self, cfg, max_batch=1, max_blocks_per_seq=None, kv_layout=0, tp_rank=0, tp_world=1):
             self.cfg, self.tp_rank, self.tp_world = cfg, tp_rank, tp_world
@@ -78,6 +82,12 @@ def _fake_model_module(dist, calls):
 
     m = types.ModuleType("candle_vllm_amd.model")
     m.GGUFLLaMa, m.lib, m.KV_PAGED, m.KV_FLASH = FakeGGUFLLaMa, FakeLib, 1, 0
+
+    def comm_all_min(d, v, group=None):                  # the real helper's arithmetic on host tensors
+        f = torch.tensor([int(v)], dtype=torch.int32)
+        d.all_reduce(f, op=d.ReduceOp.MIN, group=group)
+        return int(f.item())
+    m.comm_all_min, m._ctl_device = comm_all_min, (lambda d: "cpu")
     real = types.SimpleNamespace(hidden=4096, n_layers=32, n_heads=32, n_kv_heads=8, head_dim=128, intermediate=14336, vocab=128256,
                                  rms_eps=1e-5, rope_theta=500000.0, max_seq=8192, block_size=64)
     m.ModelDims = types.SimpleNamespace(llama3_8b=lambda: real)

@@ -86,7 +86,7 @@ def test_bench_main_two_ranks_control_flow():
     assert j["value"] > 0 and abs(j["value"] - 1e3 / j["ms_per_step"]) / j["value"] < 1e-2      # batch 1: tokens/s = steps/s
     for calls in (calls0, calls1):
         assert ("init_comm", "auto") in calls and ("roofline",) in calls and ("graph", True) in calls
-        assert calls.count(("step",)) == 4 + 3 * 5       # 4 settle steps, then 3 blocks of (2 warm-up + 3 timed), on every rank
+        assert calls.count(("step",)) == 4 + 3 * 5 + 5   # 4 settle steps, 3 blocks of (2 warm-up + 3 timed), 5 untimed steps for `first_tokens`, on every rank
     assert calls0[0] == ("create", 0, 2, 1) and calls1[0] == ("create", 1, 2, 1)
 
 

@@ -521,3 +521,47 @@ def test_one_shot_peer_all_reduce_two_processes_one_gpu(lib):
     want = resid + O.round_bf16(O.round_bf16(y0) + O.round_bf16(y1))
     for rank in (0, 1):
         assert np.array_equal(res[rank][0][("wire1",)], want), rank
+
+
+@pytest.mark.timeout(900)
+def test_bench_py_gpus_2_rehearsed_on_one_device():
+    """the command the driver runs for the scaling record -- `python bench.py --gpus 2 ...` -- rehearsed on THIS box with
+    both ranks on cuda:0 (`--same-device`; the line is marked invalid): bench.py spawns its ranks (communicator.rs:704-785), the REAL model is
+    sharded (model.py load_synthetic: every rank keeps its shard of the same global tensors; distributed.rs:243-249,696-765), the ranks agree
+    on the transport (RCCL refuses two ranks on one GPU -> the one-shot peer kernel over IPC for the all-reduces C1 / C2 behind its
+    self-test, host-staged vocabulary gather C3), run the settle / blocks / roofline sequence with a collective inside every step, and rank 0
+    prints ONE line.  Then the same with the device communicator FORCED to fail on rank 1 (MI355_BENCH_FAIL_COMM_RANK): every rank takes the
+    gloo fallback together.  Both sharded runs produce the greedy tokens of the unsharded run of the same synthetic model."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--layers", "2", "--steps", "6", "--warmup", "2", "--no-batch32", "--no-cpu-baseline", "--parity", "off", "--legs", "none",
+              "--settle-steps", "6"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MI355_BENCH_FAIL_COMM_RANK")}
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+
+    def run(extra, **envx):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra + common, env=dict(env, **envx), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=420, cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+    one = run(["--gpus", "1"])
+    assert one["n_gpus"] == 1 and len(one["config"]["first_tokens"]) == 8
+    two = run(["--gpus", "2", "--same-device"])
+    assert two["n_gpus"] == 2 and two["config"]["ranks"] == 2 and two["config"]["parallelism"] == "tp2" and two["config"]["same_device"] is True
+    assert "ONE device" in two["invalid"] and two["scaling"] == "strong"
+    assert two["config"]["all_reduce"].startswith("FALLBACK: one-shot peer kernel over IPC"), two["config"]["all_reduce"]
+    assert "RCCL refuses duplicate GPUs" in two["config"]["all_reduce"]
+    assert two["config"]["graph"] is False                     # host-staged vocabulary gather: eager steps
+    assert two["config"]["first_tokens"] == one["config"]["first_tokens"], (one["config"]["first_tokens"], two["config"]["first_tokens"])
+    assert two["value"] > 0 and two["config"]["timing"]["eager_steps_in_timed_region"] == 3 * 8
+    forced = run(["--gpus", "2", "--same-device"], MI355_BENCH_FAIL_COMM_RANK="1")
+    assert forced["n_gpus"] == 2 and forced["config"]["ranks"] == 2
+    assert forced["config"]["all_reduce"].startswith("FALLBACK: host-staged collectives over gloo"), forced["config"]["all_reduce"]
+    assert "forced failure" in forced["config"]["all_reduce"] and "rank 1" in forced["config"]["all_reduce"]
+    assert forced["config"]["first_tokens"] == one["config"]["first_tokens"]
