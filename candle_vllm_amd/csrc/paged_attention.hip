@@ -787,7 +787,7 @@ __device__ __forceinline__ void pa_mfma_chunk(const PAParams& p, const int b, co
 // compiler loads a kernarg field in the block that first uses it, and this kernel's prologue was context_lens pointer -> wait -> the
 // context length -> wait -> arrive pointer -> wait -> the rest -> wait, four dependent scalar round trips in front of the first K request
 #ifndef PA_KARG_BURST
-#define PA_KARG_BURST 1
+#define PA_KARG_BURST 0      // measured neutral on the batch-1 step (11.15 vs 11.2 us per launch: the kernel's chain is context length -> table entry -> K / V -> merge -> ticket, not its kernarg); off
 #endif
 __device__ __forceinline__ void pa_kernarg_burst(const PAParams& p) {
 #if PA_KARG_BURST

@@ -677,7 +677,7 @@ __device__ __forceinline__ void qmm_kernarg_burst(const QmmArgs& a) {
 // *rows_dev -> wait -> three to five further fields, each behind its own wait; here EVERY descriptor field goes out in one burst
 // (the row gate's own load follows as the single dependent round trip it has to be)
 #ifndef QMM_KARG_BURST_WIDE
-#define QMM_KARG_BURST_WIDE QMM_KARG_BURST
+#define QMM_KARG_BURST_WIDE 0      // measured: the full-descriptor burst needs > 100 SGPRs at once, hipcc splits it into three waits, and the ragged batch-32 step LOST 1.6 % (6230 vs 6330 tok/s, profiles/r06_b32_kernarg_burst_ab.txt)
 #endif
 __device__ __forceinline__ void qmm_kernarg_burst_all(const QmmArgs& a) {
 #if QMM_KARG_BURST_WIDE
@@ -2186,6 +2186,14 @@ static int qmm_launch_btrw(QmmArgs& a, int n_wg, int NW, hipStream_t st) {
         attr_done = true;
     }
     // (token, slot) pairs of a mixture-of-experts launch are workgroups too: all of them should be resident at once
+    // the paired (gate / up) single-token launch runs TWO waves per workgroup: measured on the product build, alternated on one box
+    // (profiles/r06_b1_gateup_waves_ab.txt): 2 waves 1.841 ms per step, 4 waves 1.862, 8 waves 1.875.  The occupancy rule below picked 2 while
+    // the kernel needed 134 VGPRs and flipped to 4 when a register-allocation change brought it to 127 -- a choice that depends on the
+    // allocator's mood is not a choice (QMM_NW_PAIRED: A/B builds)
+#ifndef QMM_NW_PAIRED
+#define QMM_NW_PAIRED 2
+#endif
+    if (NW <= 0 && a.paired && BT == 1 && !a.moe_expert && a.K / 256 >= QMM_NW_PAIRED) NW = QMM_NW_PAIRED;
     if (NW <= 0) NW = qmm_pick_nw<BT, R, WT>(n_wg * (a.moe_expert ? a.moe_pairs : 1), a.K / 256);
     const size_t shm = qmm_lds_bytes(BT, R, NW);
     if (shm > 160 * 1024) return (int)hipErrorInvalidValue;

@@ -228,7 +228,7 @@ class MoePair:
                 first_ref = self.orc.forward(meta, cache0, trace=trace)
                 x_in = [np.ascontiguousarray(self.W["tok_embd"][meta["input_ids"]], np.float32)] + trace[:-1]
                 got = np.empty((B, cfg.hidden), np.float32)
-                errs = []
+                errs, rows_all = [], []
                 for l in range(cfg.n_layers):
                     xi = np.ascontiguousarray(x_in[l], np.float32)
                     M._check(hip.hipMemcpy(xs_ptr, xi.ctypes.data, xi.nbytes, 1), "H2D")
@@ -241,8 +241,14 @@ class MoePair:
                     torch.cuda.synchronize()
                     M._check(hip.hipMemcpy(got.ctypes.data, xs_ptr, got.nbytes, 2), "D2H")
                     added = np.abs(trace[l] - xi).max(axis=1)
-                    errs.append(float((np.abs(got - trace[l]).max(axis=1) / added).max()))
-                layer_res = {"worst_layer_rel_err": max(errs), "worst_layer": int(np.argmax(errs)), "median_layer_rel_err": float(np.median(errs))}
+                    row_err = np.abs(got - trace[l]).max(axis=1) / added
+                    rows_all.append(row_err)
+                    errs.append(float(row_err.max()))
+                rows_all = np.asarray(rows_all)                             # [layer][row]
+                layer_res = {"worst_layer_rel_err": max(errs), "worst_layer": int(np.argmax(errs)), "median_layer_rel_err": float(np.median(errs)),
+                             "median_over_all_rows_and_layers": float(np.median(rows_all)), "p90_over_all_rows_and_layers": float(np.percentile(rows_all, 90)),
+                             "rows_of_worst_layer": [round(float(x), 5) for x in rows_all[int(np.argmax(errs))]],
+                             "per_layer": [round(e, 5) for e in errs], "ctx_of_rows": [int(x) for x in seq_lens]}
                 for l in range(cfg.n_layers):                              # the layer runs wrote K/V of the new token: restore the device pool
                     for which, a in ((0, self.cache[l][0]), (1, self.cache[l][1])):
                         M._check(lib.mi355_llama_kv_copy(gm.h, l, which, a.ctypes.data, a.nbytes, 1), "kv_copy")
