@@ -145,6 +145,7 @@ def cpu_baseline(cfg, steps=8, ctx=4096):
     # count); one step per candidate, then `steps` steps at the best one
     L = cref.lib()
     L.orc_isa.restype = ctypes.c_char_p
+    L.orc_set_attn_fast(1)                                    # the timed baseline may vectorise its QK dot; the parity oracle never does
     nmax = int(L.orc_num_threads())
     trial = {}
 
@@ -167,6 +168,7 @@ def cpu_baseline(cfg, steps=8, ctx=4096):
     times = [one_step() for _ in range(steps)]
     L.orc_llama_phase_times(ph, 1)
     mean = float(np.mean(times))
+    L.orc_set_attn_fast(0)
     return {"value": round(1.0 / mean, 4), "unit": "tokens/s", "cores": nbest, "kind": "port",
             "host": host_cpus(),
             "phase_seconds_per_step": {"quantised_matvecs": round(ph[0] / steps, 4), "attention": round(ph[1] / steps, 4),

@@ -111,3 +111,25 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     __syncthreads();
     return t;
 }
+
+// ---- per-DEVICE "done once" flags and the CU count (host side).  A process that drives more than one device has to set kernel attributes
+// (hipFuncSetAttribute is per device) and size its grids on EACH of them: a process-wide `static bool` set the attribute on the first
+// device only and the second device's launches failed or inherited the wrong CU count.
+#include <atomic>
+struct Mi355DevOnce {
+    std::atomic<unsigned long long> mask{0};
+    static int dev() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+    bool done() const { return (mask.load(std::memory_order_acquire) >> dev()) & 1ull; }
+    void set() { mask.fetch_or(1ull << dev(), std::memory_order_release); }
+};
+static inline int mi355_num_cus() {
+    static std::atomic<int> cus[64];
+    const int d = Mi355DevOnce::dev();
+    int n = cus[d].load(std::memory_order_relaxed);
+    if (n == 0) {
+        hipDeviceProp_t prop;
+        n = (hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        cus[d].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}

@@ -953,12 +953,7 @@ static int dense_launch_dt(const DenseArgs& a, hipStream_t st) {
             const int gx = (wtiles + nwv - 1) / nwv;
             int ks = 1;
             if (!many) {
-                if (g_num_cus_dg == 0) {
-                    int dev = 0;
-                    hipDeviceProp_t prop;
-                    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus_dg = prop.multiProcessorCount;
-                    if (g_num_cus_dg <= 0) g_num_cus_dg = 256;
-                }
+                g_num_cus_dg = mi355_num_cus();                         // per device (common.h)
                 ks = (2 * g_num_cus_dg + gx - 1) / gx;
                 if (ks > nkb_w / 4) ks = nkb_w / 4;
                 if (ks < 1) ks = 1;
@@ -1471,13 +1466,13 @@ static int dense_prompt_gemm(const DenseArgs& a, int dt, hipStream_t st) {
     if (a.K % DG_BK || a.T < 1 || a.N < 1) return (int)hipErrorNotSupported;
     if ((a.ldx * 2) % 16 || (!a.wtiled && (a.ldw * 2) % 16)) return (int)hipErrorNotSupported;          // 16-byte DMA pieces
     if (a.epi == MI355_EPI_SILU_MUL && (a.pair_offset <= 0 || a.N != 2 * a.pair_offset)) return (int)hipErrorNotSupported;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static Mi355DevOnce attr_done;
+    if (!attr_done.done()) {
         (void)hipFuncSetAttribute((const void*)dense_gemm_kernel<MI355_DTYPE_BF16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipFuncSetAttribute((const void*)dense_gemm_kernel<MI355_DTYPE_F16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipFuncSetAttribute((const void*)dense_gemm_kernel<MI355_DTYPE_BF16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         (void)hipFuncSetAttribute((const void*)dense_gemm_kernel<MI355_DTYPE_F16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_done = true;
+        attr_done.set();
     }
     const int n_cols = a.epi == MI355_EPI_SILU_MUL ? a.pair_offset : a.N;
     const int cols_per_wg = a.epi == MI355_EPI_SILU_MUL ? 64 : DG_BN;

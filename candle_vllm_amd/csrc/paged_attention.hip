@@ -1814,11 +1814,12 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
         // Mixtral-shaped batch-32 step, one box: 32-token MFMA partitions 8.03 ms, this stream one workgroup per CU 8.36, two 7.89.
         constexpr int PAS_R8 = 3;
         const int G = p.H / p.Hkv;
+        // dynamic LDS; the kernel also holds 512 B of STATIC LDS (pas_stt): two workgroups per CU need 2 x (64 KiB + 512 B) of the 160 KiB
         const size_t shm8 = (size_t)PAS_R8 * 16384 + 16384 + (G > 8 ? 32768 : 0);
-        static bool attr_done = false;
-        if (!attr_done) {
+        static Mi355DevOnce attr_done;
+        if (!attr_done.done()) {
             (void)hipFuncSetAttribute((const void*)paged_attn_stream_kernel<PAS_R8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PAS_R8 * 16384 + 16384 + 32768);
-            attr_done = true;
+            attr_done.set();
         }
         int W = (G > 8 ? 256 : 512) / p.Hkv;
         if (W < 1) W = 1;
@@ -1837,10 +1838,10 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
         //   token split (the waves share a stage's tokens instead of its output channels), ring of 2, two per CU: the same (6332 vs 6335)
         //   token split, ring of 3 / 4, one workgroup per CU: 6369 / 6360 against 6312 -- the default
         constexpr int PAS_R = PAS_RING;
-        static bool attr_done = false;
-        if (!attr_done) {
+        static Mi355DevOnce attr_done;
+        if (!attr_done.done()) {
             (void)hipFuncSetAttribute((const void*)paged_attn_stream_kernel<PAS_R, PAS_TS != 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PAS_R * 32768 + 16384);
-            attr_done = true;
+            attr_done.set();
         }
         int W = (PAS_RING <= 2 ? 512 : 256) / p.Hkv;                  // two workgroups per CU fit with a ring of two stages only
         if (W < 1) W = 1;
@@ -1857,10 +1858,10 @@ static int pa_dispatch(PAParams p, int B, int P, int layout, int dtype, int64_t 
                (p.partition_size == 1024 || p.partition_size == 2048 || p.partition_size == 4096) && p.partition_size / p.block_size <= 64) {
         // EXPERIMENT (tuning key 44 = 2): chunks of 64-token stages through an LDS ring filled by DMA; partials merged by the reduce launch
         constexpr int PAL_R = 4;
-        static bool attr_done = false;
-        if (!attr_done) {
+        static Mi355DevOnce attr_done;
+        if (!attr_done.done()) {
             (void)hipFuncSetAttribute((const void*)paged_attn_lds_kernel<PAL_R>, hipFuncAttributeMaxDynamicSharedMemorySize, PAL_R * 32768);
-            attr_done = true;
+            attr_done.set();
         }
         hipLaunchKernelGGL((paged_attn_lds_kernel<PAL_R>), dim3(p.Hkv, B, P), dim3(256), PAL_R * 32768, st, p);
         rc = (int)hipGetLastError();
@@ -2014,10 +2015,10 @@ extern "C" int mi355_paged_attention_reference_numerics(void* out, const void* q
         return (int)hipErrorInvalidValue;
     const size_t shm = ((size_t)head_dim + (size_t)(max_context_len > 0 ? max_context_len : 1)) * sizeof(float);
     if (shm > 150 * 1024) return (int)hipErrorInvalidValue;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static Mi355DevOnce attr_done;
+    if (!attr_done.done()) {
         (void)hipFuncSetAttribute((const void*)paged_attn_refnum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_done = true;
+        attr_done.set();
     }
     PAParams p{};
     p.out = out; p.q = q; p.kc = key_cache; p.vc = value_cache; p.block_tables = block_tables; p.context_lens = context_lens;
@@ -2110,11 +2111,11 @@ extern "C" int mi355_paged_attention_window(void* out, const void* q, const void
     const int span = sliding_window < max_context_len ? sliding_window : (max_context_len > 0 ? max_context_len : 1);
     const size_t shm = ((size_t)head_dim + (size_t)span) * sizeof(float);
     if (shm > 150 * 1024) return (int)hipErrorInvalidValue;           // windows beyond ~38 k tokens: not served by this path
-    static bool attr_done = false;
-    if (!attr_done) {
+    static Mi355DevOnce attr_done;
+    if (!attr_done.done()) {
         (void)hipFuncSetAttribute((const void*)paged_attn_window_kernel<MI355_DTYPE_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void)hipFuncSetAttribute((const void*)paged_attn_window_kernel<MI355_DTYPE_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_done = true;
+        attr_done.set();
     }
     PAParams p{};
     p.out = out; p.q = q; p.kc = key_cache; p.vc = value_cache; p.block_tables = block_tables; p.context_lens = context_lens;

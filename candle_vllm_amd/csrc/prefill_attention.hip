@@ -640,11 +640,11 @@ extern "C" int mi355_prefill_attention(void* out, const void* q, const void* k, 
         (block_size == 16 || block_size == 32 || block_size == 64)) {
         // round 4 default (first run on hardware in round 4: its tests green, prompt step 21.8 k -> 23.7 k tok/s at T = 2048): 64 queries x the
         // heads of a GQA group per workgroup, K / V through the LDS ring
-        static bool attr_done = false;
-        if (!attr_done) {
+        static Mi355DevOnce attr_done;
+        if (!attr_done.done()) {
             (void)hipFuncSetAttribute((const void*)prefill_attn_lds_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
             (void)hipFuncSetAttribute((const void*)prefill_attn_lds_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768);
-            attr_done = true;
+            attr_done.set();
         }
         const int G = num_heads / num_kv_heads, hgs = num_kv_heads * ((G + 3) / 4);
         // 64 queries per workgroup when that still gives two workgroups per CU to hand out heaviest first; else 32 (ring of two stages).

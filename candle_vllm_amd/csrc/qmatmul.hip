@@ -495,7 +495,7 @@ __device__ __forceinline__ int seg_row0(const QmmArgs& a, int i) { return seg_pi
 // ---- epilogue operands that do not depend on the mat-vec (residual, RoPE cos/sin, cache slot) are fetched under the
 // weight stream by the threads that will write the outputs: `early` goes out ahead of the first weight loads (the
 // position, the slot, the residual), `late` right after them (cos/sin need the position)
-struct EpiPre { int64_t pos, slot; float f0, f1; int lrow, sgi; bool live, rope; };
+struct EpiPre { int64_t pos, slot; float f0, f1; int lrow, sgi; bool live, rope; int64_t spos, sslot; };
 template <int BT, int R>
 __device__ __forceinline__ void epi_pre_early(const QmmArgs& a, const int (&segi)[R], const int (&tile)[R], EpiPre& ep) {
     constexpr int NOUT = R * BT * 16;
@@ -507,13 +507,36 @@ __device__ __forceinline__ void epi_pre_early(const QmmArgs& a, const int (&segi
     ep.lrow = e_tl * 16 + e_rr;
     ep.live = (int)threadIdx.x < NOUT && e_b < a.B && ep.lrow < seg_n_rows(a, ep.sgi);
     ep.rope = ep.live && a.epi == MI355_EPI_QKV_ROPE_CACHE;
-    ep.pos = 0; ep.slot = -1; ep.f0 = 0.f; ep.f1 = 0.f;               // RESID: f0 = residual value ; ROPE: f0, f1 = cos, sin
-    if (ep.rope && ep.sgi < 2) ep.pos = a.positions[e_b];
-    if (ep.rope && ep.sgi != 0) ep.slot = a.slot_mapping[e_b];
+    ep.pos = 0; ep.slot = -1; ep.f0 = 0.f; ep.f1 = 0.f; ep.spos = 0; ep.sslot = -1;   // RESID: f0 = residual value ; ROPE: f0, f1 = cos, sin
+#ifndef QMM_SCALAR_POS
+#define QMM_SCALAR_POS 0      // measured: scalar position / slot loads made the batch-1 step 1.4 % SLOWER (1.960 vs 1.933 ms, one box, alternated): the
+#endif                         // extra uniform branch and SGPR pairs sit in every variant of the kernel, the stall they remove in one wave of q|k|v
+    if (QMM_SCALAR_POS && BT == 1) {
+        // one token: position and slot are wave-uniform -- SCALAR loads that leave with the kernarg burst's registers instead of vector
+        // loads whose round trip the cos / sin request (epi_pre_late) then waits for in front of the wave's first staging step
+        // (profiles/r06_b1_inside_launch.txt: the wave that holds the epilogue lanes was the straggler of every q|k|v workgroup)
+        if (a.epi == MI355_EPI_QKV_ROPE_CACHE) {
+            // (through the constant address space: hipcc keeps a uniform load from plain global memory on the vector unit and waits
+            // for it at once; both arrays were written by an EARLIER launch, so the scalar cache's view is the current one)
+            typedef const int64_t __attribute__((address_space(4))) * cptr_t;
+            ep.spos = *reinterpret_cast<cptr_t>(reinterpret_cast<uintptr_t>(a.positions));
+            ep.sslot = *reinterpret_cast<cptr_t>(reinterpret_cast<uintptr_t>(a.slot_mapping));
+        }
+    } else {
+        if (ep.rope && ep.sgi < 2) ep.pos = a.positions[e_b];
+        if (ep.rope && ep.sgi != 0) ep.slot = a.slot_mapping[e_b];
+    }
     if (ep.live && a.epi == MI355_EPI_RESID) ep.f0 = a.resid[(size_t)e_b * a.ldo + seg_row0(a, ep.sgi) + ep.lrow];
     __builtin_amdgcn_sched_barrier(0);                             // keep these loads ahead of the weight loads (in-order vmcnt)
 }
+template <int BT>
 __device__ __forceinline__ void epi_pre_late(const QmmArgs& a, EpiPre& ep) {
+    if (QMM_SCALAR_POS && BT == 1) {
+        if (a.epi == MI355_EPI_QKV_ROPE_CACHE) {
+            if (ep.rope && ep.sgi < 2) ep.pos = ep.spos;
+            if (ep.rope && ep.sgi != 0) ep.slot = ep.sslot;
+        }
+    }
     if (ep.rope && ep.sgi < 2) {
         const int d = ep.lrow % a.D;
         if (d < a.rot) {
@@ -676,11 +699,16 @@ __device__ __forceinline__ void qmm_kernarg_burst(const QmmArgs& a) {
 // the same for the kernels of the 9..32-token path (staging, GEMM, split-K epilogue): their prologues walk rows_dev pointer -> wait ->
 // *rows_dev -> wait -> three to five further fields, each behind its own wait; here EVERY descriptor field goes out in one burst
 // (the row gate's own load follows as the single dependent round trip it has to be)
+#ifndef QMM_KARG_BURST_EPI
+#define QMM_KARG_BURST_EPI 0       // A/B: the burst in the split-K epilogue / staging launches only (latency chains of a few microseconds)
+#endif
 #ifndef QMM_KARG_BURST_WIDE
 #define QMM_KARG_BURST_WIDE 0      // measured: the full-descriptor burst needs > 100 SGPRs at once, hipcc splits it into three waits, and the ragged batch-32 step LOST 1.6 % (6230 vs 6330 tok/s, profiles/r06_b32_kernarg_burst_ab.txt)
 #endif
+template <bool EPI = false>
 __device__ __forceinline__ void qmm_kernarg_burst_all(const QmmArgs& a) {
-#if QMM_KARG_BURST_WIDE
+#if QMM_KARG_BURST_WIDE || QMM_KARG_BURST_EPI
+    if (!(QMM_KARG_BURST_WIDE || (EPI && QMM_KARG_BURST_EPI))) return;
     qmm_kernarg_burst(a);
     asm volatile("" ::"s"(a.next_norm_w), "s"(a.chain_next), "s"(a.next_k), "s"(a.rows_dev), "s"(a.rows_min), "s"(a.x_dtype), "s"(a.grp_n),
                  "s"(a.grp_x), "s"(a.grp_out), "s"(a.moe_stride[0]), "s"(a.moe_stride[1]), "s"(a.moe_stride[2]));
@@ -749,9 +777,17 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po =
 #pragma unroll
     for (int r = 0; r < R; ++r) {
 #if QMM_SEG_SELECT
-        wtype[r] = WT ? WT : (segi[r] == 0 ? a.seg[0].type : segi[r] == 1 ? a.seg[1].type : a.seg[2].type);
+        // (seg_pick: opaque SGPR selects -- a plain ?: chain over the three segments is turned into a lookup table in SCRATCH by hipcc,
+        // and the kernel then waits for a scratch load in front of its first weight request)
+        wtype[r] = WT ? WT : seg_pick(a.seg[0].type, a.seg[1].type, a.seg[2].type, segi[r]);
         wtb[r] = (wtype[r] == MI355_GGML_Q4_K) ? Q4K_TILE : Q6K_TILE;
-        wbase[r] = (segi[r] == 0 ? a.seg[0].w : segi[r] == 1 ? a.seg[1].w : a.seg[2].w) + (size_t)tile[r] * nkb * wtb[r];
+        {   // (the pointer keeps its type through the selects: rebuilt from integer halves it loses the GLOBAL address space and every
+            // weight load becomes a flat load that counts against lgkmcnt as well -- no counted wait survives that)
+            const uint8_t* wp = a.seg[0].w;
+            if (segi[r] == 1) wp = a.seg[1].w;
+            else if (segi[r] == 2) wp = a.seg[2].w;
+            wbase[r] = wp + (size_t)tile[r] * nkb * wtb[r];
+        }
 #else
         wtype[r] = WT ? WT : a.seg[segi[r]].type;
         wtb[r] = (wtype[r] == MI355_GGML_Q4_K) ? Q4K_TILE : Q6K_TILE;
@@ -800,7 +836,7 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po =
         }
     }
 
-    epi_pre_late(a, ep);
+    epi_pre_late<BT>(a, ep);
     QMM_TL(2);
 
     for (int kbi0 = 0; kbi0 < n_my_kb; kbi0 += PFK) {
@@ -1427,9 +1463,7 @@ __device__ __forceinline__ void qmm_epilogue_body(const QmmArgs& a, const float*
 __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, const float* __restrict__ part, const int ldp,
                                                            const int ks, const int BP, const float* __restrict__ ssp,
                                                            const QmgChainOut ch, const float* __restrict__ rscale = nullptr) {
-    qmm_kernarg_burst_all(a);
-    QMM_BURST_CHAIN(ch);
-    QMM_BURST_VALS(part, ldp, ks, BP, ssp, rscale);
+    qmm_kernarg_burst_all<true>(a);
     if (a.rows_dev && *a.rows_dev <= a.rows_min) return;
     qmm_epilogue_body(a, part, ldp, ks, BP, ssp, ch, rscale, 0, a.B);
 }
@@ -1437,9 +1471,7 @@ __global__ void __launch_bounds__(256) qmm_epilogue_kernel(const QmmArgs a, cons
 __global__ void __launch_bounds__(256) qmm_epilogue_grp_kernel(const QmmArgs a, const float* __restrict__ part, const int ldp,
                                                                const int ks, const int BP, const float* __restrict__ ssp,
                                                                const QmgChainOut ch0, const QwGroup g) {
-    qmm_kernarg_burst_all(a);
-    QMM_BURST_CHAIN(ch0);
-    QMM_BURST_VALS(part, ldp, ks, BP, ssp, g.x, g.out, g.img, g.part, g.chimg);
+    qmm_kernarg_burst_all<true>(a);
     const int e = blockIdx.z;
     const int nb = a.rows_dev ? min(a.B, a.rows_dev[e] - a.rows_min) : a.B;
     // rows past the group's count: nothing to sum, and no image entry either -- every kernel of the path keeps rows apart (a row of the
@@ -1532,14 +1564,14 @@ static int qmg_launch(const QmmArgs& a0, hipStream_t st) {
     rc = qmg_buf(&partp, MI355_SCR_QMM_PART, (size_t)ks * MT * 8 * ldp * sizeof(float), st);
     if (rc) return rc;
     float* const part = static_cast<float*>(partp);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static Mi355DevOnce attr_done;
+    if (!attr_done.done()) {
         (void)hipFuncSetAttribute((const void*)qmm_gemm_kernel<MT, MI355_GGML_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qmm_gemm_kernel<MT, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qmm_gemm2_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qmm_gemm16_kernel<MT, MI355_GGML_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qmm_gemm16_kernel<MT, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
+        attr_done.set();
     }
     uint8_t* img = static_cast<uint8_t*>(imgp);
     float* ssp = reinterpret_cast<float*>(img + kbb * nkb);                 // [nkb][MT*8] after the image
@@ -1660,15 +1692,15 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
     rc = qmg_buf(&partp, MI355_SCR_QMM_PART, (size_t)G * ks * BP * ldp * sizeof(float), st);
     if (rc) return rc;
     float* const part = static_cast<float*>(partp);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static Mi355DevOnce attr_done;
+    if (!attr_done.done()) {
         (void)hipFuncSetAttribute((const void*)qw1_gemm_kernel<MT, MI355_GGML_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qw1_gemm_kernel<MT, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qw1_gemm2_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qw1_gemm_grp_kernel<MT, MI355_GGML_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qw1_gemm_grp_kernel<MT, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qw1_gemm2_grp_kernel<MT, MI355_GGML_Q4_K, MI355_GGML_Q6_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
+        attr_done.set();
     }
     uint8_t* img = static_cast<uint8_t*>(imgp);
     float* ssp = reinterpret_cast<float*>(img + kbb * nkb);                 // [nkb][BP] after the image
@@ -1940,8 +1972,8 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
     im.Tpad = Tpad;
     im.parts = parts;
     float* C = reinterpret_cast<float*>(base + xa_b + sf_b + 2 * rs_b);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static Mi355DevOnce attr_done;
+    if (!attr_done.done()) {
 #define QPG_ATTR(MTW, NTW, WM, WN, DEEP) \
         (void)hipFuncSetAttribute((const void*)qpg_gemm_kernel<MI355_GGML_Q4_K, MTW, NTW, WM, WN, DEEP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
         (void)hipFuncSetAttribute((const void*)qpg_gemm_kernel<MI355_GGML_Q4_K, MTW, NTW, WM, WN, DEEP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)
@@ -1956,7 +1988,7 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)qpg_gemm_lds2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
+        attr_done.set();
     }
     hipLaunchKernelGGL(qpg_rowprep_kernel, dim3(Tpad), dim3(256), 0, st, a, im);          // row statistics + image, one launch (workgroup = token)
     // EXPERIMENT (mi355_set_tuning(48, 1)): all segments Q4_K, one activation plane, the default wave tile, and an epilogue that is a
@@ -2151,12 +2183,7 @@ extern "C" int mi355_qmv_error(int32_t* out_host, int32_t) { if (out_host) *out_
 template <int BT, int R, int WT>
 static int qmm_pick_nw(int n_wg, int nkb) {
     static int blocks_per_cu[4] = {-1, -1, -1, -1};       // NW = 8,4,2,1
-    if (g_num_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
-        if (g_num_cus <= 0) g_num_cus = 256;
-    }
+    g_num_cus = mi355_num_cus();                         // per device (common.h)
     int pick = 1;
     for (int i = 0; i < 3; ++i) {                         // never below 2 waves: one wave per tile serialises K
         const int nw = 8 >> i;
@@ -2177,13 +2204,13 @@ static int qmm_pick_nw(int n_wg, int nkb) {
 template <int BT, int R, int WT>
 static int qmm_launch_btrw(QmmArgs& a, int n_wg, int NW, hipStream_t st) {
     a.kch = 0;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static Mi355DevOnce attr_done;
+    if (!attr_done.done()) {
         (void)hipFuncSetAttribute((const void*)qmm_kernel<BT, R, WT, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qmm_kernel<BT, R, WT, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qmm_kernel<BT, R, WT, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qmm_kernel<BT, R, WT, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
+        attr_done.set();
     }
     // (token, slot) pairs of a mixture-of-experts launch are workgroups too: all of them should be resident at once
     // the paired (gate / up) single-token launch runs TWO waves per workgroup: measured on the product build, alternated on one box
@@ -2199,13 +2226,13 @@ static int qmm_launch_btrw(QmmArgs& a, int n_wg, int NW, hipStream_t st) {
     if (shm > 160 * 1024) return (int)hipErrorInvalidValue;
     if (a.moe_expert) {
         if constexpr (BT == 1) {
-            static bool moe_attr_done = false;
-            if (!moe_attr_done) {
+            static Mi355DevOnce moe_attr_done;
+            if (!moe_attr_done.done()) {
                 (void)hipFuncSetAttribute((const void*)qmm_moe_kernel<R, WT, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute((const void*)qmm_moe_kernel<R, WT, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute((const void*)qmm_moe_kernel<R, WT, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute((const void*)qmm_moe_kernel<R, WT, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                moe_attr_done = true;
+                moe_attr_done.set();
             }
             const bool xb = a.x_dtype == MI355_DTYPE_BF16, nrm = a.norm_w != nullptr;
             const dim3 mgrid(n_wg, a.moe_pairs), mblock(64 * NW);

@@ -66,7 +66,8 @@ def random_tiles(ggml_type, n_rows, k, device, gen, d_scale=0.0025):
 # ---- control-plane helpers of the tensor-parallel set-up (shared by GGUFLLaMa.init_comm and bench.py's fallback path) ---------------
 def _ctl_device(dist):
     """where the launcher's small agreement tensors live: on the device under the nccl (RCCL) backend, on the host under gloo"""
-    return "cuda" if dist.get_backend() == "nccl" else "cpu"
+    get = getattr(dist, "get_backend", None)            # (single-process callers pass a stub with `broadcast` only)
+    return "cuda" if get is None or get() == "nccl" else "cpu"
 
 
 def comm_all_min(dist, v, group=None):
@@ -298,7 +299,7 @@ class GGUFLLaMa:
         Every rank runs the SAME sequence of collectives whatever fails locally: a local failure becomes a flag, the ranks take the minimum,
         and all of them raise (or fall back) together -- a rank that raised between two collectives used to leave its peers inside the next
         one."""
-        all_min = lambda v: comm_all_min(dist, v)
+        all_min = (lambda v: comm_all_min(dist, v)) if self.tp_world > 1 else (lambda v: int(v))     # a one-rank world agrees with itself
         buf = np.zeros(128, np.uint8)
         rc0 = lib.mi355_comm_unique_id(buf.ctypes.data) if self.tp_rank == 0 else 0
         t = torch.from_numpy(buf).to(_ctl_device(dist))

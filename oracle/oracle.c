@@ -583,6 +583,8 @@ static uint64_t xs64(uint64_t* s) { uint64_t x = *s; x ^= x << 13; x ^= x >> 7; 
  * bf16 [EXT candle CPU matmul / softmax: f32 inside, dtype of the tensor outside].  Used to measure how far the
  * reference's own rounding points move the logits (tests/fullsize_parity.py). */
 static int g_attn_bf16 = 0;
+static int g_attn_fast = 0;      /* 1: vectorised f32 QK dot (timed cpu_baseline only; never the parity oracle) */
+void orc_set_attn_fast(int on) { g_attn_fast = on ? 1 : 0; }
 void orc_llama_set_attn_bf16(int on) { g_attn_bf16 = on; }
 static float g_fill_scale = 1.0f;   /* orc_llama_set_fill_scale: multiplies the super-block scales of the NEXT fill */
 void orc_llama_set_fill_scale(float s) { g_fill_scale = s > 0 ? s : 1.0f; }
@@ -725,11 +727,11 @@ void orc_llama_decode(void* mp, const uint32_t* tokens, const int64_t* positions
                     const uint16_t* kr = kcache[l] + ((blk * bs + t % bs) * Hkv + hk) * D;
                     float s = 0;
 #if defined(__AVX2__) && defined(__FMA__)
-                    if (!g_attn_bf16 && (D & 7) == 0) {
-                        /* f32-attention mode (the parity target O1 and the timed cpu_baseline): eight partial sums -- a CPU backend's
-                         * matmul does not walk a 128-element dot through one dependent FMA chain (that chain alone was 60 % of the
-                         * baseline's step at ctx 4096).  The bf16-attention mode below keeps the index order that the GPU's
-                         * parity-mode kernel mirrors bit for bit. */
+                    if (g_attn_fast && !g_attn_bf16 && (D & 7) == 0) {
+                        /* the TIMED cpu_baseline only (orc_set_attn_fast(1), bench.py): eight partial sums -- a CPU backend's matmul does
+                         * not walk a 128-element dot through one dependent FMA chain (that chain alone was 60 % of the baseline's step
+                         * at ctx 4096).  The PARITY oracle (flag off, the default) keeps the scalar index order below on every host:
+                         * its numerics must not depend on the ISA the checker happens to be compiled for. */
                         __m256 acc = _mm256_setzero_ps();
                         for (int d = 0; d < D; d += 8) {
                             const __m256i kb = _mm256_slli_epi32(_mm256_cvtepu16_epi32(_mm_loadu_si128((const __m128i*)(kr + d))), 16);
