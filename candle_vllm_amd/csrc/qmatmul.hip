@@ -1360,6 +1360,31 @@ __device__ __forceinline__ QmgEpiRow qmm_epilogue_load(const QmmArgs& a, const f
     if (a.epi == MI355_EPI_RESID) e.resid = a.resid[(size_t)b * a.ldo + e.orow];
     return e;
 }
+// q -> bf16 row of q_out; k / v -> bf16 (or e4m3) into the paged / flash cache slot of token b (EPI_QKV_ROPE_CACHE: segment 0 = q, 1 = k, 2 = v)
+__device__ __forceinline__ void qmm_qkv_store(const QmmArgs& a, const int sg, const int lrow, const int b, const float o) {
+    const int D = a.D, d = lrow % D, hh = lrow / D;
+    const uint16_t ob = f32_to_bf16(o);
+    if (sg == 0) {
+        a.q_out[(size_t)b * a.Hq * D + lrow] = ob;
+        return;
+    }
+    const int64_t slot = a.slot_mapping[b];
+    if (slot < 0) return;
+    uint16_t* cache = (sg == 1) ? a.kcache : a.vcache;
+    if (a.kv_layout == MI355_KV_PAGED_FP8) {                // e4m3fn of the bf16 value, K layout x = 16
+        uint8_t* c8 = reinterpret_cast<uint8_t*>(cache);
+        const int64_t blk = slot / a.block_size, off = slot % a.block_size;
+        const uint8_t q8 = to_e4m3(bf16_to_f32(ob));
+        if (sg == 1) c8[((((blk * a.Hkv + hh) * (D / 16) + d / 16) * a.block_size + off) * 16) + d % 16] = q8;
+        else c8[((blk * a.Hkv + hh) * D + d) * (int64_t)a.block_size + off] = q8;
+    } else if (a.kv_layout == MI355_KV_FLASH) {
+        cache[(slot * a.Hkv + hh) * D + d] = ob;
+    } else {
+        const int64_t blk = slot / a.block_size, off = slot % a.block_size;
+        if (sg == 1) cache[((((blk * a.Hkv + hh) * (D / 8) + d / 8) * a.block_size + off) * 8) + d % 8] = ob;
+        else cache[((blk * a.Hkv + hh) * D + d) * (int64_t)a.block_size + off] = ob;
+    }
+}
 // returns the f32 value written to a.out for (token b, out column = the chain's k index), 0 when nothing was written
 // (ooff: elements between a.out and the output of the workgroup's group -- grouped launches; 0 otherwise)
 __device__ __forceinline__ float qmm_epilogue_apply(const QmmArgs& a, const QmgEpiRow& e, const float inv, const int b, const size_t ooff = 0) {
@@ -1387,27 +1412,7 @@ __device__ __forceinline__ float qmm_epilogue_apply(const QmmArgs& a, const QmgE
             const float c = a.cos_t[pos * (a.rot >> 1) + (d >> 1)], sn = a.sin_t[pos * (a.rot >> 1) + (d >> 1)];
             o = (d & 1) ? (partner * sn + val * c) : (val * c - partner * sn);
         }
-        const uint16_t ob = f32_to_bf16(o);
-        if (sg == 0) {
-            a.q_out[(size_t)b * a.Hq * D + lrow] = ob;
-        } else {
-            const int64_t slot = a.slot_mapping[b];
-            if (slot < 0) return 0.f;
-            uint16_t* cache = (sg == 1) ? a.kcache : a.vcache;
-            if (a.kv_layout == MI355_KV_PAGED_FP8) {                // e4m3fn of the bf16 value, K layout x = 16
-                uint8_t* c8 = reinterpret_cast<uint8_t*>(cache);
-                const int64_t blk = slot / a.block_size, off = slot % a.block_size;
-                const uint8_t q8 = to_e4m3(bf16_to_f32(ob));
-                if (sg == 1) c8[((((blk * a.Hkv + hh) * (D / 16) + d / 16) * a.block_size + off) * 16) + d % 16] = q8;
-                else c8[((blk * a.Hkv + hh) * D + d) * (int64_t)a.block_size + off] = q8;
-            } else if (a.kv_layout == MI355_KV_FLASH) {
-                cache[(slot * a.Hkv + hh) * D + d] = ob;
-            } else {
-                const int64_t blk = slot / a.block_size, off = slot % a.block_size;
-                if (sg == 1) cache[((((blk * a.Hkv + hh) * (D / 8) + d / 8) * a.block_size + off) * 8) + d % 8] = ob;
-                else cache[((blk * a.Hkv + hh) * D + d) * (int64_t)a.block_size + off] = ob;
-            }
-        }
+        qmm_qkv_store(a, sg, lrow, b, o);
     }
     return 0.f;
 }
@@ -2013,6 +2018,34 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
             }
             return (int)hipGetLastError();
         }
+    }
+    // q | k | v of a prompt step (EPI_QKV_ROPE_CACHE, round 6): q and k (Q4_K) -- and v where it is Q4_K too -- go through the fused store loop
+    // (RoPE + bf16 + cache scatter in the GEMM); a Q6_K v (half the layers of a Q4_K_M file) keeps its own GEMM + the epilogue launch, which
+    // then sees q and k as empty segments (n_rows = 0: their columns of C were never written)
+#ifndef QPG_FUSE_QKV
+#define QPG_FUSE_QKV 1          // A/B builds: 0 = q | k | v through the C buffer and the epilogue launch (rounds 2-5)
+#endif
+    // (from 1024 tokens: measured +0.7 % at 2048 and +1.2 % at 4096 tokens, -1.9 % at 512 -- profiles/r06_prompt_qkv_fused_ab.txt)
+    if (QPG_FUSE_QKV && T >= 1024 && g_tune_qpg_fepi && parts == 1 && g_tune_qpg == 2 && a.epi == MI355_EPI_QKV_ROPE_CACHE && a.nseg == 3 &&
+        a.seg[0].type == MI355_GGML_Q4_K && a.seg[1].type == MI355_GGML_Q4_K) {
+        const bool v4 = a.seg[2].type == MI355_GGML_Q4_K;
+        QmmArgs r = a;
+        r.norm_w = nullptr;                                         // applied while the image was built
+        if (!v4) r.nseg = 2;
+        int f_slots = 0;
+        for (int q = 0; q < r.nseg; ++q) f_slots += r.seg[q].n_tiles;
+        hipLaunchKernelGGL((qpg_gemm_lds2_kernel<true>), dim3(Tpad / 64, (f_slots + 15) / 16), dim3(512), (size_t)QPG2_BYTES, st, r, im, C, ldp, f_slots, 0);
+        if (v4) return (int)hipGetLastError();
+        QmmArgs rv = a;
+        rv.nseg = 1; rv.seg[0] = a.seg[2];
+        hipLaunchKernelGGL(qpg_gemm_q6k_lds_kernel, dim3(Tpad / 64, (a.seg[2].n_tiles + 15) / 16), dim3(512), (size_t)QPG6_LDS_BYTES, st, rv, im, C, ldp,
+                           a.seg[2].n_tiles, f_slots);
+        QmmArgs e = a;
+        e.norm_w = nullptr;
+        e.seg[0].n_rows = 0; e.seg[1].n_rows = 0;
+        hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, T), dim3(256), 0, st, e, C, ldp, 1, T, (const float*)nullptr,
+                           QmgChainOut{nullptr, nullptr, nullptr, 0, 0, 0, 0}, (const float*)im.row_scale);
+        return (int)hipGetLastError();
     }
     for (int s0 = 0, slot_base = 0; s0 < a.nseg;) {
         int s1 = s0 + 1;
