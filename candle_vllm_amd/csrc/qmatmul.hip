@@ -1992,7 +1992,8 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)qpg_gemm_lds2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_lds2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done.set();
     }
     hipLaunchKernelGGL(qpg_rowprep_kernel, dim3(Tpad), dim3(256), 0, st, a, im);          // row statistics + image, one launch (workgroup = token)
@@ -2022,12 +2023,15 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
     // q | k | v of a prompt step (EPI_QKV_ROPE_CACHE, round 6): q and k (Q4_K) -- and v where it is Q4_K too -- go through the fused store loop
     // (RoPE + bf16 + cache scatter in the GEMM); a Q6_K v (half the layers of a Q4_K_M file) keeps its own GEMM + the epilogue launch, which
     // then sees q and k as empty segments (n_rows = 0: their columns of C were never written)
+#ifndef QPG_FUSE_Q6K
+#define QPG_FUSE_Q6K 1          // A/B builds: 0 = Q6_K prompt GEMMs write the C buffer and an epilogue launch follows (rounds 2-5)
+#endif
 #ifndef QPG_FUSE_QKV
 #define QPG_FUSE_QKV 1          // A/B builds: 0 = q | k | v through the C buffer and the epilogue launch (rounds 2-5)
 #endif
     // (from 1024 tokens: measured +0.7 % at 2048 and +1.2 % at 4096 tokens, -1.9 % at 512 -- profiles/r06_prompt_qkv_fused_ab.txt)
     if (QPG_FUSE_QKV && T >= 1024 && g_tune_qpg_fepi && parts == 1 && g_tune_qpg == 2 && a.epi == MI355_EPI_QKV_ROPE_CACHE && a.nseg == 3 &&
-        a.seg[0].type == MI355_GGML_Q4_K && a.seg[1].type == MI355_GGML_Q4_K) {
+        a.seg[0].type == MI355_GGML_Q4_K && a.seg[1].type == MI355_GGML_Q4_K && (QPG_FUSE_Q6K || a.seg[2].type == MI355_GGML_Q4_K)) {
         const bool v4 = a.seg[2].type == MI355_GGML_Q4_K;
         QmmArgs r = a;
         r.norm_w = nullptr;                                         // applied while the image was built
@@ -2036,15 +2040,13 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
         for (int q = 0; q < r.nseg; ++q) f_slots += r.seg[q].n_tiles;
         hipLaunchKernelGGL((qpg_gemm_lds2_kernel<true>), dim3(Tpad / 64, (f_slots + 15) / 16), dim3(512), (size_t)QPG2_BYTES, st, r, im, C, ldp, f_slots, 0);
         if (v4) return (int)hipGetLastError();
+        // v (Q6_K): its own GEMM with the fused store loop; q and k stay in the descriptor as EMPTY segments (no tiles) so that the value
+        // segment keeps its role (2 = v: bf16 + cache scatter, no rotation) and its row offsets
         QmmArgs rv = a;
-        rv.nseg = 1; rv.seg[0] = a.seg[2];
-        hipLaunchKernelGGL(qpg_gemm_q6k_lds_kernel, dim3(Tpad / 64, (a.seg[2].n_tiles + 15) / 16), dim3(512), (size_t)QPG6_LDS_BYTES, st, rv, im, C, ldp,
-                           a.seg[2].n_tiles, f_slots);
-        QmmArgs e = a;
-        e.norm_w = nullptr;
-        e.seg[0].n_rows = 0; e.seg[1].n_rows = 0;
-        hipLaunchKernelGGL(qmm_epilogue_kernel, dim3((ldp + 255) / 256, T), dim3(256), 0, st, e, C, ldp, 1, T, (const float*)nullptr,
-                           QmgChainOut{nullptr, nullptr, nullptr, 0, 0, 0, 0}, (const float*)im.row_scale);
+        rv.norm_w = nullptr;
+        rv.seg[0].n_tiles = 0; rv.seg[1].n_tiles = 0;
+        hipLaunchKernelGGL((qpg_gemm_q6k_lds_kernel<true>), dim3(Tpad / 64, (a.seg[2].n_tiles + 15) / 16), dim3(512), (size_t)QPG6_LDS_BYTES, st, rv, im, C,
+                           ldp, a.seg[2].n_tiles, 0);
         return (int)hipGetLastError();
     }
     for (int s0 = 0, slot_base = 0; s0 < a.nseg;) {
@@ -2080,7 +2082,13 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
         } else {
             if (parts == 1 && g_tune_qpg == 2) {                        // Q6_K: 64 tokens x 256 rows per workgroup; token blocks fastest
                 const dim3 grid(Tpad / 64, (run_slots + 15) / 16);
-                hipLaunchKernelGGL(qpg_gemm_q6k_lds_kernel, grid, dim3(512), (size_t)QPG6_LDS_BYTES, st, r, im, C, ldp, run_slots, slot_base);
+                // the whole mat-mul is this one Q6_K run and its epilogue is a store / residual add: fused store loop, no C buffer, no launch
+                if (QPG_FUSE_Q6K && g_tune_qpg_fepi && T >= 4096 && s0 == 0 && s1 == a.nseg &&          // (measured: +1.2 % at 4096 tokens, -0.2 % at 2048: profiles/r06_prompt_q6k_fused_ab.txt) (a.epi == MI355_EPI_STORE || a.epi == MI355_EPI_RESID)) {
+                    r.norm_w = nullptr;
+                    hipLaunchKernelGGL((qpg_gemm_q6k_lds_kernel<true>), grid, dim3(512), (size_t)QPG6_LDS_BYTES, st, r, im, C, ldp, run_slots, 0);
+                    return (int)hipGetLastError();
+                }
+                hipLaunchKernelGGL((qpg_gemm_q6k_lds_kernel<false>), grid, dim3(512), (size_t)QPG6_LDS_BYTES, st, r, im, C, ldp, run_slots, slot_base);
             } else {
                 const dim3 grid(Tpad / 32, (run_slots + 15) / 16);     // 32 tokens x 256 rows, register-fed: hi + lo planes ("exact" activations)
 #ifdef MI355_QMM_PROBES
