@@ -2083,7 +2083,8 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
             if (parts == 1 && g_tune_qpg == 2) {                        // Q6_K: 64 tokens x 256 rows per workgroup; token blocks fastest
                 const dim3 grid(Tpad / 64, (run_slots + 15) / 16);
                 // the whole mat-mul is this one Q6_K run and its epilogue is a store / residual add: fused store loop, no C buffer, no launch
-                if (QPG_FUSE_Q6K && g_tune_qpg_fepi && T >= 4096 && s0 == 0 && s1 == a.nseg &&          // (measured: +1.2 % at 4096 tokens, -0.2 % at 2048: profiles/r06_prompt_q6k_fused_ab.txt) (a.epi == MI355_EPI_STORE || a.epi == MI355_EPI_RESID)) {
+                // (from 4096 tokens -- measured: +1.2 % at 4096, -0.2 % at 2048: profiles/r06_prompt_q6k_fused_ab.txt)
+                if (QPG_FUSE_Q6K && g_tune_qpg_fepi && T >= 4096 && s0 == 0 && s1 == a.nseg && (a.epi == MI355_EPI_STORE || a.epi == MI355_EPI_RESID)) {
                     r.norm_w = nullptr;
                     hipLaunchKernelGGL((qpg_gemm_q6k_lds_kernel<true>), grid, dim3(512), (size_t)QPG6_LDS_BYTES, st, r, im, C, ldp, run_slots, 0);
                     return (int)hipGetLastError();
