@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(256) paged_attn_paged_layout_kernel(const PAPa
 // 4(lane>>4)+v), the partition's row maxima m and bf16-rounded probability sums lsum (valid in lane == head)
 template <int D32, int NT, bool KV8>
 __device__ __forceinline__ void pa_mfma_partition(const PAParams& p, const int b, const int hk, const int t0, const int t1,
-                                                  const int lane, f32x4_t (&o)[2 * D32], float& m, float& lsum) {
+                                                  const int lane, f32x4_t (&o)[2 * D32], float& m, float& lsum, const int blk_s = -1) {
     constexpr int D = 32 * D32, NTD = D / 16;
     const int G = p.H / p.Hkv, bs = p.block_size;
     const int c = lane & 15, kg = lane >> 4;
@@ -461,7 +461,9 @@ __device__ __forceinline__ void pa_mfma_partition(const PAParams& p, const int b
     const uint32_t* bt = p.block_tables + (int64_t)b * p.max_blocks;
     auto locate = [&](int tok, int64_t& blk, int& off) {
         const int q = bs_pow2 ? (tok >> bs_shift) : (tok / bs);
-        blk = (int64_t)bt[q];
+        // blk_s >= 0: the partition lies inside ONE block whose id the kernel already fetched with a scalar load next to the context
+        // length (round 6: the per-lane table load was a dependent vector round trip in front of every K / V address)
+        blk = blk_s >= 0 ? (int64_t)blk_s : (int64_t)bt[q];
         off = tok - q * bs;
     };
     // Q^T fragments: lane (head c, kg) holds Q[head][32j + 8kg .. +8]
@@ -797,12 +799,31 @@ __device__ __forceinline__ void pa_kernarg_burst(const PAParams& p) {
 #endif
 }
 
+// Round 6 (-DMI355_PA_TIMELINE builds only, tools/exp_b1_timeline.py): eight 100 MHz timestamps per wave of the batch-1 attention launch, kept in
+// registers, written at exit:  0 entry  1 context length known  2 partition done (table entry -> K / V -> QK^T -> softmax -> P.V)
+// 3 state in LDS + barrier  4 workgroup merge done, partial stores issued  5 stores drained + barrier  6 arrival ticket back  7 exit
+#ifdef MI355_PA_TIMELINE
+__device__ unsigned long long* g_pa_ts = nullptr;
+extern "C" int mi355_debug_set_pa_timestamps(void* dev_ptr) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pa_ts), &dev_ptr, sizeof(dev_ptr)); }
+#define PA_TL_DECL unsigned long long ptl[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PA_TL(i) do { ptl[i] = wall_clock64(); } while (0)
+#define PA_TL_FLUSH() do { ptl[7] = wall_clock64(); if ((threadIdx.x & 63) == 0 && g_pa_ts) { \
+        unsigned long long* d_ = g_pa_ts + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (threadIdx.x >> 6)) * 8; \
+        for (int i_ = 0; i_ < 8; ++i_) d_[i_] = ptl[i_]; } } while (0)
+#else
+#define PA_TL_DECL ((void)0)
+#define PA_TL(i) ((void)0)
+#define PA_TL_FLUSH() ((void)0)
+#endif
+
 template <int D32, int NT, bool KV8 = false, int WPB = 1>
 __global__ void __launch_bounds__(64 * WPB) paged_attn_mfma_kernel(const PAParams p) {
+    PA_TL_DECL;
+    PA_TL(0);
     pa_kernarg_burst(p);
     constexpr int D = 32 * D32, NTD = D / 16;
     const int hk = blockIdx.x, b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: partition index, table address and every `wave`-dependent branch stay on the scalar unit
     const int part = blockIdx.z * WPB + wave;
     // a context longer than the launch was sized for is truncated to the grid (the host layer refuses such a step): the
     // partition count below must match the launched grid or the fused merge's ticket never completes
@@ -814,8 +835,22 @@ __global__ void __launch_bounds__(64 * WPB) paged_attn_mfma_kernel(const PAParam
     if constexpr (NT == 0)
         btv = (int)__hip_atomic_load(p.block_tables + (int64_t)b * p.max_blocks + min(t0 / p.block_size + lane, p.max_blocks - 1),
                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#ifndef PA_SCALAR_TABLE
+#define PA_SCALAR_TABLE 1
+#endif
+    // one-block partitions (NT tiles = 32 tokens inside a block of 32 k tokens): the block id is wave-uniform -- a SCALAR load through the
+    // constant address space, in flight together with the context length (the table was written by an earlier launch / copy)
+    int blk_s = -1;
+    if constexpr (PA_SCALAR_TABLE && NT == 2) {
+        if ((p.block_size & 31) == 0 && p.partition_size == 32) {
+            typedef const uint32_t __attribute__((address_space(4))) * cbt_t;
+            const int q0 = min(t0 / p.block_size, p.max_blocks - 1);
+            blk_s = (int)*reinterpret_cast<cbt_t>(reinterpret_cast<uintptr_t>(p.block_tables + (int64_t)b * p.max_blocks + q0));
+        }
+    }
     const int ctx = min((int)p.context_lens[b], p.max_partitions * p.partition_size);
     if (blockIdx.z * WPB * p.partition_size >= ctx) return;        // uniform for the workgroup
+    PA_TL(1);
     const bool live = t0 < ctx;
     const int t1 = min(ctx, t0 + p.partition_size);
     const int G = p.H / p.Hkv;
@@ -827,8 +862,12 @@ __global__ void __launch_bounds__(64 * WPB) paged_attn_mfma_kernel(const PAParam
     for (int nt = 0; nt < NTD; ++nt) o[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (live) {
         if constexpr (NT == 0) pa_mfma_chunk<D32, KV8>(p, b, hk, t0, t1, lane, btv, o, m, lsum);  // partition = a chunk of 32-token pairs, looped
-        else pa_mfma_partition<D32, NT, KV8>(p, b, hk, t0, t1, lane, o, m, lsum);
+        else pa_mfma_partition<D32, NT, KV8>(p, b, hk, t0, t1, lane, o, m, lsum, blk_s);
     }
+#ifdef MI355_PA_TIMELINE
+    asm volatile("" ::"v"(o[0][0]), "v"(lsum));
+#endif
+    PA_TL(2);
     const int group_tokens = p.partition_size * WPB;               // tokens behind one partial in tmp_out
     const int pslot = blockIdx.z;
     if constexpr (WPB > 1) {
@@ -846,6 +885,7 @@ __global__ void __launch_bounds__(64 * WPB) paged_attn_mfma_kernel(const PAParam
         }
         if (lane < G) { sm_m[wave * G + lane] = m; sm_l[wave * G + lane] = lsum; }
         __syncthreads();
+        PA_TL(3);
         const float vs = KV8 ? p.v_scale : 1.f;
         for (int idx = threadIdx.x; idx < G * D; idx += 64 * WPB) {
             const int g = idx / D, d = idx - g * D;
@@ -878,16 +918,19 @@ __global__ void __launch_bounds__(64 * WPB) paged_attn_mfma_kernel(const PAParam
             }
         }
         if (p.max_partitions <= 1 || p.arrive == nullptr) return;
+        PA_TL(4);
         // fused merge, workgroup form: every wave drains its write-through stores, one thread takes the ticket, the
         // last workgroup merges with one WAVE per query head (64 lanes x D/64 channels)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        PA_TL(5);
         unsigned* sm_t = reinterpret_cast<unsigned*>(pa_smem);
         if (threadIdx.x == 0)
             sm_t[0] = __hip_atomic_fetch_add(p.arrive + (int64_t)b * p.Hkv + hk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
+        PA_TL(6);
         const int Pg = (ctx + group_tokens - 1) / group_tokens;
-        if ((int)sm_t[0] != Pg - 1) return;
+        if ((int)sm_t[0] != Pg - 1) { PA_TL_FLUSH(); return; }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (threadIdx.x == 0) __hip_atomic_store(p.arrive + (int64_t)b * p.Hkv + hk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // one wave per query head; ONE round trip per 32 partials: lane q holds (exp_sum, max_logit) of partial q, every lane its
@@ -962,6 +1005,7 @@ __global__ void __launch_bounds__(64 * WPB) paged_attn_mfma_kernel(const PAParam
 #pragma unroll
             for (int e = 0; e < DL2; ++e) op[e] = f32_to_bf16(accv[e] * inv);
         }
+        PA_TL_FLUSH();
         return;
     } else {
     // ---- epilogue: rows (heads 4kg+v) need the column statistics of lane (4kg+v)

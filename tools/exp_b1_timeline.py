@@ -39,6 +39,9 @@ for part, name in ((0, "qkv"), (2, "wo"), (3, "gateup"), (4, "down")):
         torch.cuda.synchronize()
     t = ts.cpu().numpy().reshape(NWG, 16, 8).astype(np.float64)
     live = t[:, :, 0] > 0
+    if not live.any():
+        print(f"== {name}: no timestamps (this build has no -DMI355_QMM_TIMELINE)")
+        continue
     t0 = t[:, :, 0][live].min()
     us = lambda x: (x - t0) / 100.0
     q = lambda a: "min %5.2f  p10 %5.2f  p50 %5.2f  p90 %5.2f  max %5.2f" % (a.min(), *np.percentile(a, [10, 50, 90]), a.max())
@@ -50,3 +53,34 @@ for part, name in ((0, "qkv"), (2, "wo"), (3, "gateup"), (4, "down")):
                          (3, 4, "first weights arrive + first unit"), (4, 5, "rest of the loop"), (5, 6, "LDS reduction + barrier wait"), (6, 7, "epilogue")):
         print(f"  d{i}{j} {what:50s}", q(cols[j] - cols[i]))
     sys.stdout.flush()
+
+# ---- the attention launch (paged_attn_mfma_kernel, fused workgroup merge): -DMI355_PA_TIMELINE builds export mi355_debug_set_pa_timestamps
+if hasattr(lib, "mi355_debug_set_pa_timestamps"):
+    import ctypes
+    lib.mi355_debug_set_pa_timestamps.argtypes = [ctypes.c_void_p]
+    lib.mi355_debug_set_pa_timestamps.restype = ctypes.c_int
+    _check(lib.mi355_debug_set_pa_timestamps(ts.data_ptr()), "pa ts")
+    anames = ["entry", "context length known", "partition done (table, K/V, QK, PV)", "state in LDS + barrier", "workgroup merge, stores issued",
+              "stores drained + barrier", "arrival ticket back", "exit (last arriver: merged)"]
+    for layer in (4, 5, 6):
+        ts.zero_(); torch.cuda.synchronize()
+        _check(lib.mi355_llama_run_part(gm.h, layer, 0, st), "run_part")            # q|k|v first: the new token's K / V are in the cache
+        torch.cuda.synchronize()
+        ts.zero_(); torch.cuda.synchronize()
+        _check(lib.mi355_llama_run_part(gm.h, layer, 1, st), "run_part")
+        torch.cuda.synchronize()
+    t = ts.cpu().numpy().reshape(NWG, 16, 8).astype(np.float64)
+    live = t[:, :, 7] > 0
+    t0 = t[:, :, 0][live].min()
+    us = lambda x: (x - t0) / 100.0
+    q = lambda a: "min %5.2f  p10 %5.2f  p50 %5.2f  p90 %5.2f  max %5.2f" % (a.min(), *np.percentile(a, [10, 50, 90]), a.max())
+    print(f"== attention: {int(live.sum())} waves in {int(live.any(axis=1).sum())} workgroups; first entry -> last exit {us(t[:, :, 7][live]).max():.2f} us")
+    cols = [us(t[:, :, i][live]) for i in range(8)]
+    for i in range(8):
+        print(f"  {i} {anames[i]:38s}", q(cols[i]))
+    for (i, j, what) in ((0, 1, "kernarg + context length"), (1, 2, "table entry -> K / V -> QK^T -> softmax -> P.V of the partition"), (2, 3, "state to LDS + barrier (slowest wave)"),
+                         (3, 4, "workgroup merge + write-through partial stores issued"), (4, 5, "store drain + barrier"), (5, 6, "arrival ticket (agent-scope atomic) + barrier"),
+                         (6, 7, "exit; the LAST arriver of a kv head: acquire + load 17 partials + merge + store")):
+        print(f"  d{i}{j} {what:66s}", q(cols[j] - cols[i]))
+    last = (cols[7] - cols[6]) > 0.5
+    print(f"  last arrivers: {int(last.sum())} waves; their exit: ", q(cols[7][last]) if last.any() else "-")
