@@ -27,13 +27,16 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 // two f32 -> packed bf16x2 (lo in bits 0-15), round-to-nearest-even in hardware (gfx950 v_cvt_pk_bf16_f32).
-// The write happens inside inline asm, and hipcc pads no wait states between an asm-written VGPR and an MFMA that
-// takes it as an operand in the next instructions (observed: wrong sums on the first m-tile of a wide launch), so the
-// two wait states that pair needs are part of the string.
+// Written as a vector conversion the compiler selects the instruction for, NOT as inline asm: hipcc's hazard pass does not see
+// through an asm string, so (a) an MFMA reading the asm-written VGPR right after got no wait states (wrong sums on the first
+// m-tile of a wide launch, round 3) and (b) when the register allocator put the asm's result in a VGPR that an MFMA still in
+// flight writes as a dead part of its 4-register result (a T=1 launch keeps only rows 0-1 of the tile), the MFMA's late write
+// landed on top of the packed value: the NaN defect of the `<1,*,Q4_K,f32,no norm>` build, rounds 5-6 (profiles/r06_nan_hunt*).
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 // RoPE rotation of one pair in f32, every product and sum rounded on its own (candle's rope on f32 values does not fuse a multiply
 // into the add; with fused multiply-adds the compiler picks a different association in every kernel it inlines this into, and the

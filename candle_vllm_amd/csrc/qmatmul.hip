@@ -836,7 +836,12 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po =
         }
     }
 
+#ifndef QMM_LATE_AFTER_LOOP
+#define QMM_LATE_AFTER_LOOP 1
+#endif
+#if !QMM_LATE_AFTER_LOOP
     epi_pre_late<BT>(a, ep);
+#endif
     QMM_TL(2);
 
     for (int kbi0 = 0; kbi0 < n_my_kb; kbi0 += PFK) {
@@ -905,6 +910,12 @@ __device__ __forceinline__ void qmm_body(const QmmArgs& a, const QmmPairOff po =
     }
     qmm_stamp(a, 1);
     QMM_TL(5);
+#if QMM_LATE_AFTER_LOOP
+    // cos / sin of the RoPE lanes are requested HERE, behind the k-block loop (round 6): asked for in the prologue they made the wave that holds
+    // the epilogue lanes wait for the position's round trip before its first staging step -- the straggler of every q|k|v workgroup
+    // (profiles/r06_b1_inside_launch.txt); here their latency sits under the cross-wave reduction and the barrier
+    epi_pre_late<BT>(a, ep);
+#endif
     // ---- hi + lo, then cross-wave reduction in LDS.  After the xor-32 add, lanes 0..31 hold batch 4*kg+v.
     const int kg = lane >> 4, row = lane & 15;
 #pragma unroll

@@ -74,3 +74,23 @@ def test_copy_of_a_register_in_flight_is_flagged(tmp_path):
 def test_lds_dma_has_no_register_destination(tmp_path):
     rc, out = _run(tmp_path, DMA, "dma")
     assert rc == 0, out
+
+
+def test_no_vector_alu_instruction_is_hidden_in_an_asm_string():
+    """hipcc's hazard pass pads wait states between a matrix instruction and the VALU instructions around it, but not through an inline-asm
+    string.  A `v_cvt_pk_bf16_f32` written that way cost two defects (wrong sums behind it, round 3; the matrix core's late write landing on
+    its result, the round 5-6 NaN -- common.h: cvt_pk_bf16), so the kernels keep every VALU instruction visible to the compiler: asm strings
+    hold only waits / barriers / LDS and DMA traffic whose completion the code counts by hand (tools/check_isa_vmcnt.py checks those)."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "candle_vllm_amd", "csrc")
+    hits = []
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.inc")) + glob.glob(os.path.join(csrc, "*.h"))):
+        for no, line in enumerate(open(path), 1):
+            code = line.split("//")[0]
+            if "asm" not in code:
+                continue
+            for text in re.findall(r'"([^"]*)"', code):
+                if re.search(r"\bv_[a-z0-9_]+\b", text):
+                    hits.append("%s:%d: %s" % (os.path.basename(path), no, text))
+    assert not hits, hits

@@ -308,6 +308,21 @@ def test_qmatmul_vs_oracle(cv, t, T, N, K):
             assert rel_err(mm.forward(dev(x)).cpu().numpy(), ref) < NARROW_TOL
 
 
+@pytest.mark.parametrize("nkb", [16, 24, 56, 57, 72])
+def test_one_token_matvec_every_ring_depth(cv, nkb):
+    """One f32 token through the Q4_K mat-vec at depths where a wave owns two and more k-blocks (the 14336-deep down projection is 56).
+    Round 5-6's NaN defect lived exactly here: the bf16 pack of the activations was inline asm, its VGPR could be a dead part of the
+    result tile of a matrix instruction still in flight, and the late write replaced the packed value (common.h: cvt_pk_bf16)."""
+    for N in (256, 4096):
+        rng = np.random.default_rng(nkb)
+        K = nkb * 256
+        blocks = kq.quantize(rng.normal(0, 0.05, (N, K)).astype(np.float32), kq.GGML_Q4_K)
+        x = rng.normal(0, 1, (1, K)).astype(np.float32)
+        got = cv.QMatMul(blocks, kq.GGML_Q4_K, "cuda").forward(dev(x)).cpu().numpy()
+        assert np.isfinite(got).all()
+        assert rel_err(got, kq.qmatmul_o1(x, blocks, kq.GGML_Q4_K)) < NARROW_TOL
+
+
 @pytest.mark.parametrize("T,N,K", [(1, 64, 384), (5, 40, 1792), (20, 256, 96)])
 def test_q8_0_arm_of_requantised_tp_shards(cv, T, N, K):
     """Q8_0 (the dtype a tensor-parallel shard is re-quantised to when it cuts a k-quant block, quantized_var_builder.rs:
