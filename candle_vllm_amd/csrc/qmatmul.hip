@@ -1667,14 +1667,18 @@ static int qw1_launch(const QmmArgs& a0, hipStream_t st) {
         if (want < 1) want = 1;
         ks = want;
     }
-    if (G == 1 && g_tune_ks_target > 0 && a.nseg == 1 && nkb >= 32 && a.seg[0].type == MI355_GGML_Q6_K) {
-        // a Q6_K launch of long K (the down projection: 256 tiles x 56 k-blocks) is bound by its unpack arithmetic and the latency of
-        // its own chain (411 VALU per tile and k-block, profiles/r03_pmc_sq_b32_set1.json), not by bytes: with the power-of-two split
-        // it runs 37 x 4 = 148 workgroups, ONE per CU on 58 % of the chip.  Measured (round 4, same box): 37 x 7 = 259 workgroups (every
-        // CU, still one each) 27.6 -> 28.5 us; 37 x 14 = 518 (two per CU: the second workgroup's waves fill the first's stalls) 23.8 us,
-        // the ragged batch-32 step 6239 -> 6327 tok/s.  The same split for the Q4_K down projection: -0.3 % (its chain is shorter).
+#ifndef QW1_Q6K_LONGK_WGS
+#define QW1_Q6K_LONGK_WGS 0
+#endif
+    if (QW1_Q6K_LONGK_WGS > 0 && G == 1 && g_tune_ks_target > 0 && a.nseg == 1 && nkb >= 32 && a.seg[0].type == MI355_GGML_Q6_K) {
+        // Rounds 4-5 (two MFMA chains per Q6_K weight, 411 VALU per tile and k-block: profiles/r03_pmc_sq_b32_set1.json): the long-K Q6_K
+        // launch (the down projection: 256 tiles x 56 k-blocks) was bound by its unpack arithmetic, and 37 x 14 = 518 workgroups -- two per
+        // CU, the second one's waves in the first's stalls -- beat the power-of-two split (37 x 4): 27.6 -> 23.8 us.  With ONE operand per
+        // weight (round 6, QW1_Q6K_ONE_PLANE) the arithmetic is no longer the bound and the 14 partial sums per output are pure cost:
+        // same box, ragged batch-32 step: 14 splits 6515 / 6529 tok/s, 7 splits 6699 / 6667, the general rule's 4 splits 6749 / 6729
+        // (profiles/r06_b32_q6k_ab.txt) -- the special case is off (-DQW1_Q6K_LONGK_WGS=512 builds it back for A/B).
         const int n_wg = (n_slots + QMG_NC - 1) / QMG_NC;
-        const int cus = 512;                                              // MI355X: two workgroups per CU (see below)
+        const int cus = QW1_Q6K_LONGK_WGS;
         if (n_wg * ks < cus) {
             int want = (cus + n_wg - 1) / n_wg;
             while (want > 1 && nkb / want < 4) --want;
