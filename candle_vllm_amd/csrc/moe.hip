@@ -167,7 +167,6 @@ __global__ void __launch_bounds__(1024) moe_route16_kernel(int32_t* __restrict__
                                                            int hidden, int E, int K) {
     __shared__ float red[32];
     __shared__ float s_part[16];
-    __shared__ float s_logit[16];
     const int t = blockIdx.x;
     const float* xr = x + (size_t)t * hidden;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -210,37 +209,42 @@ __global__ void __launch_bounds__(1024) moe_route16_kernel(int32_t* __restrict__
     acc = wave_sum_dpp(acc);
     if (lane == 0) s_part[wave] = acc;
     __syncthreads();
-    if (threadIdx.x < (unsigned)E) {
-        float l = 0.f;
-        for (int q = 0; q < wpe; ++q) l += s_part[threadIdx.x * wpe + q];
-        s_logit[threadIdx.x] = l;
+    // ---- softmax + top-k by wave 0 IN REGISTERS (round 6).  The first form ran this tail on one thread over an LDS array: ~60 dependent LDS
+    // round trips (max, exp, sum, divide, K selection scans) = 2.8 of the launch's 9.9 us at E = 8.  Here lane q adds expert q's partial dot
+    // products, every lane gathers the E logits by readlane, and the scans run on registers -- same order of every sum and the same
+    // first-maximum-wins selection as before (bit-identical weights and ids).
+    if (wave != 0) return;
+    float l = 0.f;
+    if (lane < E)
+        for (int q = 0; q < wpe; ++q) l += s_part[lane * wpe + q];
+    float pr[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) pr[q] = __shfl(l, q, 64);
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) if (q < E) m = fmaxf(m, pr[q]);
+    float den = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) if (q < E) { pr[q] = expf(pr[q] - m); den += pr[q]; }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) if (q < E) pr[q] /= den;          // softmax_last_dim
+    float sum = 0.f, wmine = 0.f;
+    unsigned taken = 0;
+    int imine = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {                          // selection sort = stable descending order; lane j keeps pick j
+        if (j >= K) break;
+        int best = -1; float bv = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (q < E && !((taken >> q) & 1u) && pr[q] > bv) { bv = pr[q]; best = q; }
+        taken |= 1u << best;
+        if (lane == j) { imine = best; wmine = bv; }
+        sum += bv;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float m = -INFINITY;
-        for (int q = 0; q < E; ++q) m = fmaxf(m, s_logit[q]);
-        float den = 0.f;
-        for (int q = 0; q < E; ++q) { s_logit[q] = expf(s_logit[q] - m); den += s_logit[q]; }
-        for (int q = 0; q < E; ++q) s_logit[q] /= den;          // softmax_last_dim
-        float sum = 0.f, wsel[16];
-        unsigned taken = 0;                                     // the selection lives in registers: no global round trips in the loop
-        int sel[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {                          // selection sort = stable descending order
-            if (j >= K) break;
-            int best = -1; float bv = -INFINITY;
-            for (int q = 0; q < E; ++q)
-                if (!((taken >> q) & 1u) && s_logit[q] > bv) { bv = s_logit[q]; best = q; }
-            taken |= 1u << best;
-            sel[j] = best; wsel[j] = bv;
-            sum += bv;
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (j >= K) break;
-            ids[(size_t)t * K + j] = sel[j];
-            wts[(size_t)t * K + j] = wsel[j] / sum;
-        }
+    if (lane < K) {
+        ids[(size_t)t * K + lane] = imine;
+        wts[(size_t)t * K + lane] = wmine / sum;
     }
 }
 
