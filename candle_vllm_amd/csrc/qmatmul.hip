@@ -2009,6 +2009,7 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_lds_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done.set();
     }
     hipLaunchKernelGGL(qpg_rowprep_kernel, dim3(Tpad), dim3(256), 0, st, a, im);          // row statistics + image, one launch (workgroup = token)
@@ -2041,6 +2042,9 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
 #ifndef QPG_FUSE_Q6K
 #define QPG_FUSE_Q6K 1          // A/B builds: 0 = Q6_K prompt GEMMs write the C buffer and an epilogue launch follows (rounds 2-5)
 #endif
+#ifndef QPG6_SPLIT_SMALL
+#define QPG6_SPLIT_SMALL 1      // A/B builds: 0 = the Q6_K value projection always in 256-row workgroups
+#endif
 #ifndef QPG_FUSE_QKV
 #define QPG_FUSE_QKV 1          // A/B builds: 0 = q | k | v through the C buffer and the epilogue launch (rounds 2-5)
 #endif
@@ -2060,8 +2064,12 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
         QmmArgs rv = a;
         rv.norm_w = nullptr;
         rv.seg[0].n_tiles = 0; rv.seg[1].n_tiles = 0;
-        hipLaunchKernelGGL((qpg_gemm_q6k_lds_kernel<true>), dim3(Tpad / 64, (a.seg[2].n_tiles + 15) / 16), dim3(512), (size_t)QPG6_LDS_BYTES, st, rv, im, C,
-                           ldp, a.seg[2].n_tiles, 0);
+        // (one row tile per wave where two would leave CUs empty: 1024 rows x 2048 tokens = 128 workgroups of 256 rows)
+        const int vt = a.seg[2].n_tiles;
+        if (QPG6_SPLIT_SMALL && (Tpad / 64) * ((vt + 15) / 16) < mi355_num_cus())
+            hipLaunchKernelGGL((qpg_gemm_q6k_lds_kernel<true, 1>), dim3(Tpad / 64, (vt + 7) / 8), dim3(512), (size_t)QPG6_LDS_BYTES, st, rv, im, C, ldp, vt, 0);
+        else
+            hipLaunchKernelGGL((qpg_gemm_q6k_lds_kernel<true>), dim3(Tpad / 64, (vt + 15) / 16), dim3(512), (size_t)QPG6_LDS_BYTES, st, rv, im, C, ldp, vt, 0);
         return (int)hipGetLastError();
     }
     for (int s0 = 0, slot_base = 0; s0 < a.nseg;) {

@@ -71,7 +71,7 @@ def _simulate(plan, nkb):
     return slack
 
 
-@pytest.mark.parametrize("kind", [6])
+@pytest.mark.parametrize("kind", [6, 61])                            # 61: the Q6_K kernel with one row tile per wave (5 weight DMAs)
 def test_counted_waits_are_safe_and_tight(lib, kind):
     plan = _plan(lib, kind)
     lead, ring, xu, nw, n0, n1 = plan
