@@ -167,6 +167,7 @@ __global__ void __launch_bounds__(1024) moe_route16_kernel(int32_t* __restrict__
                                                            int hidden, int E, int K) {
     __shared__ float red[32];
     __shared__ float s_part[16];
+    __shared__ __attribute__((aligned(16))) float xs[8192];          // the normalised row x * inv * w, built once (round 6)
     const int t = blockIdx.x;
     const float* xr = x + (size_t)t * hidden;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -174,43 +175,56 @@ __global__ void __launch_bounds__(1024) moe_route16_kernel(int32_t* __restrict__
     const int span = hidden / wpe, base = part * span;
     const float* g = gate + (size_t)e * hidden;
     float acc = 0.f, ss = 0.f;
-    // sum of squares: thread i owns elements 4i .. 4i+3 (+ 4096 j)
-    float4 xq[2];
+    // thread i owns elements 4i .. 4i+3 (+ 4096 j) of the row: sum of squares, then the normalised values into LDS.  Rounds 3-5 had every
+    // one of the 16 waves re-read its slice of x and of the RMSNorm weight from global memory: 390 KB through ONE CU's vector memory path
+    // (64 B per clock: 2.6 us of the launch's 9.9); now x and the weight cross it once (32 KB) beside the 128 KB of router rows.
+    float4 xq[2], nq[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int i = 4 * (int)threadIdx.x + 4096 * j;
-        xq[j] = (norm_w && i < hidden) ? *reinterpret_cast<const float4*>(xr + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xq[j] = i < hidden ? *reinterpret_cast<const float4*>(xr + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        nq[j] = (norm_w && i < hidden) ? *reinterpret_cast<const float4*>(norm_w + i) : make_float4(1.f, 1.f, 1.f, 1.f);
     }
     for (int c0 = 0; c0 < span; c0 += 2048) {                         // 8 pieces of 256 elements per lane and pass
-        float4 xv[8], gv[8], nv[8];
+        float4 gv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = base + c0 + 256 * u + 4 * lane;
             const bool in = c0 + 256 * u < span;
-            xv[u] = in ? *reinterpret_cast<const float4*>(xr + i) : make_float4(0.f, 0.f, 0.f, 0.f);
             gv[u] = in ? *reinterpret_cast<const float4*>(g + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-            nv[u] = (in && norm_w) ? *reinterpret_cast<const float4*>(norm_w + i) : make_float4(1.f, 1.f, 1.f, 1.f);
         }
-        if (c0 == 0 && norm_w) {
+        if (c0 == 0) {
+            if (norm_w) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) ss += xq[j].x * xq[j].x + xq[j].y * xq[j].y + xq[j].z * xq[j].z + xq[j].w * xq[j].w;
-            // (hidden <= 8192: the two pieces above are the whole row); DPP sums: every ds_bpermute of wave_sum is an LDS round trip
-            ss = wave_sum_dpp(ss);
-            if (lane == 0) red[wave] = ss;
+                for (int j = 0; j < 2; ++j) ss += xq[j].x * xq[j].x + xq[j].y * xq[j].y + xq[j].z * xq[j].z + xq[j].w * xq[j].w;
+                // (hidden <= 8192: the two pieces above are the whole row); DPP sums: every ds_bpermute of wave_sum is an LDS round trip
+                ss = wave_sum_dpp(ss);
+                if (lane == 0) red[wave] = ss;
+                __syncthreads();
+                ss = wave_sum_dpp(lane < 16 ? red[lane] : 0.f);
+            }
+            const float inv = norm_w ? rsqrtf(ss / (float)hidden + eps) : 1.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int i = 4 * (int)threadIdx.x + 4096 * j;
+                if (i < hidden)
+                    *reinterpret_cast<float4*>(xs + i) = make_float4(xq[j].x * inv * nq[j].x, xq[j].y * inv * nq[j].y, xq[j].z * inv * nq[j].z, xq[j].w * inv * nq[j].w);
+            }
             __syncthreads();
-            ss = wave_sum_dpp(lane < 16 ? red[lane] : 0.f);
         }
-        const float inv = norm_w ? rsqrtf(ss / (float)hidden + eps) : 1.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            acc = fmaf(xv[u].x * inv * nv[u].x, gv[u].x, fmaf(xv[u].y * inv * nv[u].y, gv[u].y,
-                  fmaf(xv[u].z * inv * nv[u].z, gv[u].z, fmaf(xv[u].w * inv * nv[u].w, gv[u].w, acc))));
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + c0 + 256 * u + 4 * lane;
+            const bool in = c0 + 256 * u < span;
+            const float4 xn = in ? *reinterpret_cast<const float4*>(xs + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc = fmaf(xn.x, gv[u].x, fmaf(xn.y, gv[u].y, fmaf(xn.z, gv[u].z, fmaf(xn.w, gv[u].w, acc))));
+        }
     }
     acc = wave_sum_dpp(acc);
     if (lane == 0) s_part[wave] = acc;
     __syncthreads();
-    // ---- softmax + top-k by wave 0 IN REGISTERS (round 6).  The first form ran this tail on one thread over an LDS array: ~60 dependent LDS
-    // round trips (max, exp, sum, divide, K selection scans) = 2.8 of the launch's 9.9 us at E = 8.  Here lane q adds expert q's partial dot
+    // ---- softmax + top-k by wave 0 IN REGISTERS (round 6).  The first form ran this tail on one thread over an LDS array (~60 dependent LDS
+    // accesses: max, exp, sum, divide, K selection scans; measured worth 0.5-1 % of the Mixtral batch-1 step).  Here lane q adds expert q's partial dot
     // products, every lane gathers the E logits by readlane, and the scans run on registers -- same order of every sum and the same
     // first-maximum-wins selection as before (bit-identical weights and ids).
     if (wave != 0) return;
