@@ -48,6 +48,7 @@ class QmmDesc(ctypes.Structure):
         ("chain_next", c_i32), ("chain_next_k", c_i32), ("chain_next_norm", c_vp),
         ("rows_dev", c_vp), ("rows_min", c_i32),
         ("group_count", c_i32), ("group_x_stride", c_i64), ("group_out_stride", c_i64),
+        ("group_block_table", c_vp),
     ]
 
 
@@ -106,6 +107,7 @@ _sig("mi355_moe_combine", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, 
 _sig("mi355_moe_gather", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
 _sig("mi355_moe_group", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
 _sig("mi355_moe_gather_pos", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
+_sig("mi355_moe_group_blocks", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
 _sig("mi355_moe_scatter_combine", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64])
 for _n in ("marlin_4bit_f16", "marlin_4bit_bf16", "marlin_awq_4bit_f16", "marlin_awq_4bit_bf16"):
     _sig(_n, None, [c_vp] * 6 + [c_i32] * 3 + [c_vp, c_i32, c_i64])

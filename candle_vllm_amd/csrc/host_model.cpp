@@ -110,6 +110,7 @@ struct Model {
     int32_t* p_moe_ids = nullptr; float* p_moe_w = nullptr; float* p_moe_y = nullptr;
     // grouped experts on prompt steps: gathered rows in expert order + the permutation and its inverse
     float* p_moe_xg = nullptr; int32_t* p_moe_perm = nullptr; int32_t* p_moe_inv = nullptr;
+    int32_t* p_moe_tab = nullptr;    // block table of the device-grouped prompt path: {expert, row end} per 64-row block
     // decode steps with many (token, slot) pairs: experts grouped on the device, `g_cap` rows per expert (host_model.cpp run_part)
     float* g_moe_xg = nullptr; float* g_moe_h = nullptr; float* g_moe_yg = nullptr; int32_t* g_moe_pos = nullptr; int32_t* g_moe_cnt = nullptr; int g_cap = 0;
     int attn_numerics = 0;          // parity mode (mi355_llama_set_attention_numerics): 1 = the reference CPU path's bf16 rounding points in decode attention
@@ -149,6 +150,8 @@ extern "C" int mi355_internal_pa_stream_reduce_to_image(void* out, const float* 
                                                         int64_t stream);                                                     // qmatmul.hip
 extern "C" int mi355_pa_stream_auto(int32_t num_seqs, int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size);   // paged_attention.hip
 int g_host_ps_override = 0;     // experiments: mi355_set_tuning(5, partition_size)
+// MI355_MOE_PROMPT_DEVICE=0: prompt steps of a mixture-of-experts model sort their (token, slot) pairs on the host again (rounds 2-5; A/B runs)
+static const int g_moe_prompt_device = []() { const char* e = getenv("MI355_MOE_PROMPT_DEVICE"); return e && e[0] == '0' ? 0 : 1; }();
 
 int local_heads(const Model* m) { return m->cfg.n_heads / (m->cfg.tp_world > 0 ? m->cfg.tp_world : 1); }
 int local_kv_heads(const Model* m) {
@@ -315,6 +318,39 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
             // weighted expert outputs to the residual (quantized_llama.rs:93-119, 470).  The per-pair path below reads an
             // expert once per pair: exact, but a 2048-token prompt would stream each expert hundreds of times.
             RCHECK(mi355_moe_route(in.moe_ids, in.moe_w, in.xs, L.ffn_norm, c.rms_eps, L.gate_inp, B, hid, c.n_expert, K, st));
+            if (g_moe_prompt_device && m->p_moe_tab && c.n_expert <= 16 && pairs >= 96 && L.etype[0] == MI355_GGML_Q4_K &&
+                L.etype[1] == MI355_GGML_Q4_K && L.etype[2] == MI355_GGML_Q4_K) {
+                // ---- the same, grouped ON THE DEVICE (round 6): no copy of the routing to the host, no stream synchronisation, and ONE launch
+                // per kernel for all experts.  Every expert owns whole 64-row blocks of the gathered buffers; the prompt GEMM walks a block
+                // table {expert, row end} (mi355_qmm_desc.group_block_table); rows between an expert's end and its last block's end are
+                // computed and never stored.  (Q4_K experts: what the GEMM's fused store loop covers; Q6_K experts take the host-sorted path.)
+                const int nblk = (pairs + 63) / 64 + c.n_expert, rows = 64 * nblk;
+                RCHECK(mi355_moe_group_blocks(m->p_moe_inv, m->p_moe_tab, in.moe_ids, pairs, c.n_expert, nblk + 2, st));
+                RCHECK(mi355_moe_gather_pos(m->p_moe_xg, in.xs, m->p_moe_inv, pairs, K, hid, st));
+                mi355_qmm_desc g;
+                memset(&g, 0, sizeof(g));
+                g.nseg = 2;
+                g.w_tiles[0] = L.eslab[0]; g.ggml_type[0] = L.etype[0]; g.n_rows[0] = L.erows[0];
+                g.w_tiles[1] = L.eslab[2]; g.ggml_type[1] = L.etype[2]; g.n_rows[1] = L.erows[2];
+                g.moe_expert_stride[0] = L.estride[0]; g.moe_expert_stride[1] = L.estride[2];
+                g.x = m->p_moe_xg; g.x_dtype = MI355_DTYPE_F32; g.ldx = hid; g.k = hid; g.num_tokens = rows;
+                g.norm_weight = L.ffn_norm; g.norm_eps = c.rms_eps;
+                g.epilogue = MI355_EPI_SILU_MUL; g.out = in.h; g.ldo = I;
+                g.group_block_table = m->p_moe_tab;
+                RCHECK(mi355_qmatmul_fused(&g, st));
+                mi355_qmm_desc dn;
+                memset(&dn, 0, sizeof(dn));
+                dn.nseg = 1;
+                dn.w_tiles[0] = L.eslab[1]; dn.ggml_type[0] = L.etype[1]; dn.n_rows[0] = L.erows[1];
+                dn.moe_expert_stride[0] = L.estride[1];
+                dn.x = in.h; dn.x_dtype = MI355_DTYPE_F32; dn.ldx = I; dn.k = I; dn.num_tokens = rows;
+                dn.epilogue = MI355_EPI_STORE; dn.out = in.moe_y; dn.ldo = hid;
+                dn.group_block_table = m->p_moe_tab;
+                RCHECK(mi355_qmatmul_fused(&dn, st));
+                RCHECK(mi355_moe_scatter_combine(in.xs, in.moe_y, in.moe_w, m->p_moe_inv, B, hid, K, st));
+                m->moe_grouped_done = true;
+                return 0;
+            }
             std::vector<int32_t> ids((size_t)pairs), perm((size_t)pairs), inv((size_t)pairs);
             HCHECK(hipMemcpyAsync(ids.data(), in.moe_ids, (size_t)pairs * 4, hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(st)));
             HCHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(st)));
@@ -735,7 +771,7 @@ extern "C" void mi355_llama_destroy(void* mp) {
     free_qw(m->output);
     void* ptrs[] = {m->tok_embd, m->output_norm, m->cos_t, m->sin_t, m->xs, m->q, m->attn, m->h, m->logits,
                     m->pa_tmp, m->pa_max, m->pa_sum, m->kv_slab, m->d_tokens, m->d_positions, m->d_slots,
-                    m->d_ctx, m->d_bt, m->logits_local, m->logits_gather, m->tp_y, m->p_tp_y, m->p_moe_xg, m->p_moe_perm, m->p_moe_inv, m->p_xs, m->p_q, m->p_attn, m->p_h,
+                    m->d_ctx, m->d_bt, m->logits_local, m->logits_gather, m->tp_y, m->p_tp_y, m->p_moe_xg, m->p_moe_perm, m->p_moe_inv, m->p_moe_tab, m->p_xs, m->p_q, m->p_attn, m->p_h,
                     m->moe_ids, m->moe_w, m->moe_y, m->p_moe_ids, m->p_moe_w, m->p_moe_y, m->chain_sync, m->g_moe_xg, m->g_moe_h, m->g_moe_yg, m->g_moe_pos, m->g_moe_cnt};
     if (m->comm && m->comm_owned) mi355_comm_destroy(m->comm);
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -881,19 +917,24 @@ static int ensure_prefill_cap(Model* m, int T) {
     HCHECK(hipMalloc((void**)&m->p_q, (size_t)cap * H * D * 2));
     HCHECK(hipMalloc((void**)&m->p_attn, (size_t)cap * H * D * 2));
     const int KE = m->cfg.n_expert > 1 ? m->cfg.n_expert_used : 1;
-    HCHECK(hipMalloc((void**)&m->p_h, (size_t)cap * KE * m->cfg.intermediate * 4));
+    // (+ 64 rows per expert: the device-grouped prompt path gives every expert whole 64-row blocks)
+    const size_t moe_pad = m->cfg.n_expert > 1 ? (size_t)64 * (m->cfg.n_expert + 2) : 0;
+    HCHECK(hipMalloc((void**)&m->p_h, ((size_t)cap * KE + moe_pad) * m->cfg.intermediate * 4));
     if (m->use_comm) HCHECK(hipMalloc((void**)&m->p_tp_y, (size_t)cap * m->cfg.hidden * 4));
     if (m->cfg.n_expert > 1) {
-        void* oldm[] = {m->p_moe_ids, m->p_moe_w, m->p_moe_y, m->p_moe_xg, m->p_moe_perm, m->p_moe_inv};
+        void* oldm[] = {m->p_moe_ids, m->p_moe_w, m->p_moe_y, m->p_moe_xg, m->p_moe_perm, m->p_moe_inv, m->p_moe_tab};
         for (void* p : oldm) if (p) (void)hipFree(p);
         m->p_moe_ids = nullptr; m->p_moe_w = nullptr; m->p_moe_y = nullptr;
-        m->p_moe_xg = nullptr; m->p_moe_perm = nullptr; m->p_moe_inv = nullptr;
-        HCHECK(hipMalloc((void**)&m->p_moe_xg, (size_t)cap * KE * m->cfg.hidden * 4));
+        m->p_moe_xg = nullptr; m->p_moe_perm = nullptr; m->p_moe_inv = nullptr; m->p_moe_tab = nullptr;
+        HCHECK(hipMalloc((void**)&m->p_moe_tab, ((size_t)cap * KE / 64 + m->cfg.n_expert + 4) * 8));
+        HCHECK(hipMalloc((void**)&m->p_moe_xg, ((size_t)cap * KE + moe_pad) * m->cfg.hidden * 4));
+        HCHECK(hipMemsetAsync(m->p_moe_xg, 0, ((size_t)cap * KE + moe_pad) * m->cfg.hidden * 4, 0));   // the rows no pair lands in: finite from the start
         HCHECK(hipMalloc((void**)&m->p_moe_perm, (size_t)cap * KE * 4));
         HCHECK(hipMalloc((void**)&m->p_moe_inv, (size_t)cap * KE * 4));
         HCHECK(hipMalloc((void**)&m->p_moe_ids, (size_t)cap * KE * 4));
         HCHECK(hipMalloc((void**)&m->p_moe_w, (size_t)cap * KE * 4));
-        HCHECK(hipMalloc((void**)&m->p_moe_y, (size_t)cap * KE * m->cfg.hidden * 4));
+        HCHECK(hipMalloc((void**)&m->p_moe_y, ((size_t)cap * KE + moe_pad) * m->cfg.hidden * 4));
+        HCHECK(hipDeviceSynchronize());
     }
     m->p_cap = cap;
     return 0;

@@ -135,6 +135,77 @@ extern "C" int mi355_moe_group(int32_t* pos, int32_t* counts, const int32_t* exp
                                int64_t stream) {
     return mi355_internal_moe_group_limited(pos, counts, expert_ids, num_pairs, n_expert, cap, cap, stream);
 }
+// ---- grouping for PROMPT steps, on the device (round 6; the reference sorts the pairs on the host after `to_vec2`, quantized_llama.rs:70-91,
+// and rounds 2-5 did the same behind one stream synchronisation per layer).  Every expert owns whole 64-row blocks of the gathered buffers --
+// expert e's rows start at row 64 * (blocks of the experts before it) -- so a prompt GEMM workgroup (64 token rows) never sees two experts,
+// and ONE launch walks the blocks of all experts: block b of `block_table` = {expert, one past the expert's last row}, {0, 0} for the blocks
+// past the last expert's (such a workgroup leaves at once).  pos[p] = the row of pair p: stable (token order inside an expert), as the host
+// sort was.  One workgroup: counts, then ranks, chunk by chunk from ballots (1024 pairs per trip).
+__global__ void __launch_bounds__(1024) moe_group_blocks_kernel(int32_t* __restrict__ pos, int32_t* __restrict__ block_table,
+                                                                const int32_t* __restrict__ ids, int num_pairs, int E, int n_blocks) {
+    __shared__ int cnt[16], run[16], blk0[17];
+    __shared__ int wcnt[16][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 16) { cnt[tid] = 0; run[tid] = 0; }
+    __syncthreads();
+    {   // counts: ballots, lane q of every wave keeps expert q's (one LDS atomic per thread serialises 64 lanes on 8 words: 0.7 ms per call)
+        int mine = 0;
+        for (int c0 = 0; c0 < num_pairs; c0 += 1024) {
+            const int p = c0 + tid;
+            int e = p < num_pairs ? ids[p] : -1;
+            if (p < num_pairs) e = e < 0 ? 0 : (e >= E ? E - 1 : e);
+            for (int q = 0; q < E; ++q) {
+                const unsigned long long m = __ballot(e == q);
+                if (lane == q) mine += __popcll(m);
+            }
+        }
+        if (lane < E) atomicAdd(&cnt[lane], mine);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        blk0[0] = 0;
+        for (int e = 0; e < E; ++e) blk0[e + 1] = blk0[e] + (cnt[e] + 63) / 64;
+    }
+    __syncthreads();
+    for (int b = tid; b < n_blocks; b += 1024) {
+        int e = -1;
+        for (int q = 0; q < E; ++q) if (b >= blk0[q] && b < blk0[q + 1]) e = q;
+        block_table[2 * b] = e < 0 ? 0 : e;
+        block_table[2 * b + 1] = e < 0 ? 0 : 64 * blk0[e] + cnt[e];
+    }
+    for (int c0 = 0; c0 < num_pairs; c0 += 1024) {
+        const int p = c0 + tid;
+        int e = p < num_pairs ? ids[p] : -1;
+        if (p < num_pairs) e = e < 0 ? 0 : (e >= E ? E - 1 : e);
+        int below = 0;                                                  // pairs of my expert in lower lanes of this wave
+        for (int q = 0; q < E; ++q) {
+            const unsigned long long m = __ballot(e == q);
+            if (lane == 0) wcnt[wave][q] = __popcll(m);
+            if (e == q) below = __popcll(m & ((1ull << lane) - 1ull));
+        }
+        __syncthreads();
+        if (e >= 0) {
+            int r = run[e] + below;
+            for (int w = 0; w < wave; ++w) r += wcnt[w][e];
+            pos[p] = 64 * blk0[e] + r;
+        }
+        __syncthreads();
+        if (tid < E) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += wcnt[w][tid];
+            run[tid] += t;
+        }
+        __syncthreads();
+    }
+}
+extern "C" int mi355_moe_group_blocks(int32_t* pos, int32_t* block_table, const int32_t* expert_ids, int32_t num_pairs, int32_t n_expert,
+                                      int32_t n_blocks, int64_t stream) {
+    if (num_pairs <= 0) return 0;
+    if (!pos || !block_table || !expert_ids || n_expert < 1 || n_expert > 16 || n_blocks < (num_pairs + 63) / 64 + n_expert)
+        return (int)hipErrorInvalidValue;                               // n_blocks: at least ceil(pairs / 64) + n_expert (every expert may end on a partial block)
+    hipLaunchKernelGGL(moe_group_blocks_kernel, dim3(1), dim3(1024), 0, to_stream(stream), pos, block_table, expert_ids, num_pairs, n_expert, n_blocks);
+    return (int)hipGetLastError();
+}
 extern "C" int mi355_moe_gather_pos(float* dst, const float* src, const int32_t* pos, int32_t num_pairs, int32_t top_k, int32_t hidden,
                                     int64_t stream) {
     if (num_pairs <= 0) return 0;

@@ -215,6 +215,8 @@ struct QmmArgs {
     // moe_stride[s], writes out + e * grp_out (elements), gated by rows_dev[e]
     int32_t grp_n;
     int64_t grp_x, grp_out;
+    // prompt-step grouped launch over a device block table (mi355_qmm_desc.group_block_table): token block b = {expert, row end}
+    const int32_t* blk_tab;
 };
 
 struct TileRegs { uint4 a, b, c, d; uint32_t e; };
@@ -1979,7 +1981,8 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
     const int T = a.B, K = a.K, ldp = n_slots * 16, nkb = K >> 8;
     const int Tpad = (T + QPG_BM - 1) / QPG_BM * QPG_BM;
     const int parts = g_tune_exact_act ? 2 : 1;             // activation planes of the f16 image (mi355_set_tuning(24, 1) = hi + lo)
-    const size_t xa_b = (size_t)K * Tpad * 2 * parts, sf_b = (size_t)nkb * Tpad * 32, rs_b = (size_t)Tpad * 4, c_b = (size_t)T * ldp * 4;
+    // (a block-table launch only exists with the epilogue in the store loop: no C buffer -- it would be 1.9 GB for a Mixtral chunk)
+    const size_t xa_b = (size_t)K * Tpad * 2 * parts, sf_b = (size_t)nkb * Tpad * 32, rs_b = (size_t)Tpad * 4, c_b = a.blk_tab ? 0 : (size_t)T * ldp * 4;
     void* ws = nullptr;
     int rc = qmg_buf(&ws, MI355_SCR_QMP_WS, xa_b + sf_b + 2 * rs_b + c_b + 4096, st);
     if (rc) return rc;
@@ -2006,12 +2009,14 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
 #undef QPG_ATTR
         (void)hipFuncSetAttribute((const void*)qpg_gemm_lds2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_lds2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_lds2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_lds_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done.set();
     }
+    if (a.blk_tab && g_tune_qpg != 2) return (int)hipErrorNotSupported;                   // only the LDS-fed kernel reads a block table
     hipLaunchKernelGGL(qpg_rowprep_kernel, dim3(Tpad), dim3(256), 0, st, a, im);          // row statistics + image, one launch (workgroup = token)
     // EXPERIMENT (mi355_set_tuning(48, 1)): all segments Q4_K, one activation plane, the default wave tile, and an epilogue that is a
     // store / residual add / SiLU * up over two equal segments -> the GEMM writes the outputs itself, no C buffer, no epilogue launch
@@ -2025,7 +2030,8 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
             r.norm_w = nullptr;                                 // applied while the image was built
             if (g_tune_qpg == 2) {                              // 64 tokens x 256 rows per workgroup (waves 64 x 32), two workgroups per CU
                 const dim3 g_(Tpad / 64, (n_slots + 15) / 16), b_(512);
-                hipLaunchKernelGGL((qpg_gemm_lds2_kernel<true>), g_, b_, (size_t)QPG2_BYTES, st, r, im, C, ldp, n_slots, 0);
+                if (a.blk_tab) hipLaunchKernelGGL((qpg_gemm_lds2_kernel<true, true>), g_, b_, (size_t)QPG2_BYTES, st, r, im, C, ldp, n_slots, 0);
+                else hipLaunchKernelGGL((qpg_gemm_lds2_kernel<true>), g_, b_, (size_t)QPG2_BYTES, st, r, im, C, ldp, n_slots, 0);
             } else {
 #ifdef MI355_QMM_PROBES
                 const dim3 g_(Tpad / 32, (n_slots + 31) / 32), b_(512);   // rounds 2-3: 32 x 512, register-fed
@@ -2035,6 +2041,7 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
             }
             return (int)hipGetLastError();
         }
+        if (a.blk_tab) return (int)hipErrorNotSupported;        // block-table launches: Q4_K, one plane, store / SiLU * up epilogues only
     }
     // q | k | v of a prompt step (EPI_QKV_ROPE_CACHE, round 6): q and k (Q4_K) -- and v where it is Q4_K too -- go through the fused store loop
     // (RoPE + bf16 + cache scatter in the GEMM); a Q6_K v (half the layers of a Q4_K_M file) keeps its own GEMM + the epilogue launch, which
@@ -2519,6 +2526,7 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
         a.B = 1;
         return qmm_launch_bt<1>(a, R, wt, n_wg, NW, st);
     }
+    if (a.blk_tab && !(a.B >= g_tune_qpg_min && g_tune_prefill_gemm == 1)) return (int)hipErrorNotSupported;   // only the prompt GEMM reads a block table
     if (a.B >= g_tune_qpg_min && g_tune_prefill_gemm) {
         // prompt step: the hand-written quantised GEMM (qmm_prefill.inc).  mi355_set_tuning(6, 2) = the first-generation path
         // (bf16 hi/lo weight image + three library GEMMs) for A/B runs; (6, 0) = stream the weights 32 tokens at a time.
@@ -2530,7 +2538,7 @@ int mi355_qmm_launch(QmmArgs a, int64_t stream) {
 #endif
         {
             const int rcq = qpg_launch(a, st);
-            if (rcq != (int)hipErrorNotSupported) return rcq;
+            if (rcq != (int)hipErrorNotSupported || a.blk_tab) return rcq;
         }
     }
     const int B = a.B;
@@ -2708,6 +2716,8 @@ static int qmm_args_from_desc(const mi355_qmm_desc* d, QmmArgs& a) {
     for (int s = 0; s < 3; ++s) a.moe_stride[s] = d->moe_expert_stride[s];
     if (d->group_count < 0 || (d->group_count > 1 && (d->moe_expert_ids || d->group_x_stride < 0 || d->group_out_stride < 0))) return (int)hipErrorInvalidValue;
     a.grp_n = d->group_count > 1 ? d->group_count : 0; a.grp_x = d->group_x_stride; a.grp_out = d->group_out_stride;
+    if (d->group_block_table && (d->moe_expert_ids || d->group_count > 1 || (d->num_tokens % 64))) return (int)hipErrorInvalidValue;
+    a.blk_tab = d->group_block_table;
     a.chain_next = (d->chain_next && !d->moe_expert_ids && d->num_tokens > 8 && d->num_tokens <= 8 * QMW_MAXMT) ? 1 : 0;
     a.next_k = d->chain_next_k; a.next_norm_w = d->chain_next_norm;
     return 0;

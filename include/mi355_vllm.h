@@ -262,6 +262,13 @@ typedef struct mi355_qmm_desc {
      * groups' next images); any other token count runs the groups one after the other. */
     int32_t group_count;
     int64_t group_x_stride, group_out_stride;
+    /* grouped PROMPT-step call over a device block table (round 6; NULL = off; not together with moe_expert_ids / group_count): x holds the
+     * rows of ALL groups, every group in whole 64-row blocks (mi355_moe_group_blocks); block b of the table = {group, one past the group's
+     * last row} as two i32 ({0, 0}: no rows), the group's weights start group * moe_expert_stride[s] bytes into w_tiles[s].  ONE launch per
+     * kernel walks every block; rows past a group's end are computed and never stored.  num_tokens = 64 * blocks (>= 96); the table needs
+     * num_tokens / 64 + 2 entries.  Q4_K segments, epilogues STORE / RESID / SILU_MUL (what the prompt GEMM's store loop fuses); any other
+     * call is refused (hipErrorNotSupported) and the caller runs the groups one by one. */
+    const int32_t* group_block_table;
 } mi355_qmm_desc;
 int mi355_qmatmul_fused(const mi355_qmm_desc* desc, int64_t stream);
 /* MoE routing on the device (MlpOrMoe::forward, quantized_llama.rs:56-123, without the host round trip):
@@ -286,6 +293,12 @@ int mi355_moe_combine(float* ys, const float* y_pairs, const float* weights, int
  * the DUMP row n_expert * cap (size the row buffers n_expert * cap + 1): it joins no expert's block and is not counted. */
 int mi355_moe_group(int32_t* pos, int32_t* counts, const int32_t* expert_ids, int32_t num_pairs, int32_t n_expert, int32_t cap, int64_t stream);
 int mi355_moe_gather_pos(float* dst, const float* src, const int32_t* pos, int32_t num_pairs, int32_t top_k, int32_t hidden, int64_t stream);
+/* prompt steps (round 6): the same grouping without a cap per expert and without the host -- every expert owns whole 64-row blocks, expert
+ * e's rows start at 64 * (blocks of the experts before it); pos[p] = the row of pair p (stable), block_table[b] = {expert, row end} for the
+ * n_blocks >= ceil(num_pairs / 64) + n_expert blocks ({0, 0} past the last expert's): the group_block_table of mi355_qmm_desc.  The
+ * reference sorts on the host (quantized_llama.rs:70-91). */
+int mi355_moe_group_blocks(int32_t* pos, int32_t* block_table, const int32_t* expert_ids, int32_t num_pairs, int32_t n_expert,
+                           int32_t n_blocks, int64_t stream);
 int mi355_moe_gather(float* dst, const float* src, const int32_t* perm, int32_t num_pairs, int32_t top_k, int32_t hidden, int64_t stream);
 int mi355_moe_scatter_combine(float* ys, const float* y_sorted, const float* weights, const int32_t* inv, int32_t num_tokens,
                               int32_t hidden, int32_t top_k, int64_t stream);

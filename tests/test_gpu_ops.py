@@ -547,6 +547,100 @@ def test_moe_route_experts_combine(cv, T):
     assert rel_err(ys.cpu().numpy(), ref) < 1e-3
 
 
+@pytest.mark.parametrize("T,E,K", [(300, 8, 2), (64, 4, 2), (1000, 8, 2), (130, 16, 4)])
+def test_prompt_step_experts_grouped_on_the_device(cv, T, E, K):
+    """Prompt steps of a mixture-of-experts layer without the host (round 6): mi355_moe_group_blocks gives every expert whole 64-row blocks
+    (stable, as the host sort of quantized_llama.rs:70-91), and ONE prompt-GEMM launch per kernel walks the block table
+    (mi355_qmm_desc.group_block_table).  Positions and table against numpy; gate/up (fused norm, SiLU * up) and down bit for bit what
+    one call per expert over the same rows leaves."""
+    rng = np.random.default_rng(T + E)
+    hid, I = 256, 512
+    pairs = T * K
+    ids_np = rng.integers(0, E, pairs).astype(np.int32)
+    if E == 16:
+        ids_np[ids_np == 3] = 5                                        # an expert nobody chose
+    nblk = (pairs + 63) // 64 + E
+    ids = torch.from_numpy(ids_np).cuda()
+    pos = torch.full((pairs,), -1, dtype=torch.int32, device="cuda")
+    tab = torch.full((2 * (nblk + 2),), -7, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert cv.lib.mi355_moe_group_blocks(pos.data_ptr(), tab.data_ptr(), ids.data_ptr(), pairs, E, nblk + 2, st) == 0
+    torch.cuda.synchronize()
+    cnt = np.bincount(ids_np, minlength=E)
+    blk0 = np.concatenate([[0], np.cumsum((cnt + 63) // 64)])
+    want_pos = np.empty(pairs, np.int32)
+    fill = 64 * blk0[:-1].copy()
+    for p in range(pairs):
+        want_pos[p] = fill[ids_np[p]]
+        fill[ids_np[p]] += 1
+    assert np.array_equal(pos.cpu().numpy(), want_pos)
+    want_tab = np.zeros((nblk + 2, 2), np.int32)
+    for e in range(E):
+        want_tab[blk0[e]:blk0[e + 1]] = (e, 64 * blk0[e] + cnt[e])
+    assert np.array_equal(tab.cpu().numpy().reshape(-1, 2), want_tab)
+    assert cv.lib.mi355_moe_group_blocks(pos.data_ptr(), tab.data_ptr(), ids.data_ptr(), pairs, E, nblk - 1, st) != 0   # table too short
+    cv.lib.mi355_clear_error()
+    if pairs < 96:
+        return
+    # ---- the grouped GEMMs against one call per expert
+    rows = 64 * nblk
+    x = rng.normal(0, 1, (T, hid)).astype(np.float32)
+    nw = dev((1.0 + rng.normal(0, 0.05, hid)).astype(np.float32))
+    def slab(r, c):
+        parts = [cv.repack_qweight(kq.quantize(rng.normal(0, 0.05, (r, c)).astype(np.float32), kq.GGML_Q4_K), kq.GGML_Q4_K, r, c) for _ in range(E)]
+        return torch.from_numpy(np.concatenate(parts)).cuda(), parts[0].size
+    w1, s1 = slab(I, hid); w3, s3 = slab(I, hid); w2, s2 = slab(hid, I)
+    xg = torch.zeros((rows, hid), dtype=torch.float32, device="cuda")
+    assert cv.lib.mi355_moe_gather_pos(xg.data_ptr(), dev(x).data_ptr(), pos.data_ptr(), pairs, K, hid, st) == 0
+    def gate_up(xp, n, out, w1p, w3p, table, stride):
+        d = cv.QmmDesc()
+        d.nseg = 2
+        d.w_tiles[0], d.w_tiles[1] = w1p, w3p
+        d.ggml_type[0] = d.ggml_type[1] = kq.GGML_Q4_K
+        d.n_rows[0] = d.n_rows[1] = I
+        d.x, d.x_dtype, d.ldx, d.k, d.num_tokens = xp, cv.DT_F32, hid, hid, n
+        d.norm_weight, d.norm_eps = nw.data_ptr(), 1e-5
+        d.epilogue, d.out, d.ldo = cv.EPI_SILU_MUL, out, I
+        if table:
+            d.group_block_table = table
+            d.moe_expert_stride[0], d.moe_expert_stride[1] = stride
+        return cv.lib.mi355_qmatmul_fused(d, st)
+    def down(xp, n, out, w2p, table, stride):
+        d = cv.QmmDesc()
+        d.nseg = 1
+        d.w_tiles[0], d.ggml_type[0], d.n_rows[0] = w2p, kq.GGML_Q4_K, hid
+        d.x, d.x_dtype, d.ldx, d.k, d.num_tokens = xp, cv.DT_F32, I, I, n
+        d.epilogue, d.out, d.ldo = cv.EPI_STORE, out, hid
+        if table:
+            d.group_block_table = table
+            d.moe_expert_stride[0] = stride
+        return cv.lib.mi355_qmatmul_fused(d, st)
+    h = torch.full((rows, I), float("nan"), dtype=torch.float32, device="cuda")
+    y = torch.full((rows, hid), float("nan"), dtype=torch.float32, device="cuda")
+    assert gate_up(xg.data_ptr(), rows, h.data_ptr(), w1.data_ptr(), w3.data_ptr(), tab.data_ptr(), (s1, s3)) == 0
+    assert down(h.data_ptr(), rows, y.data_ptr(), w2.data_ptr(), tab.data_ptr(), s2) == 0
+    torch.cuda.synchronize()
+    live = np.zeros(rows, bool)
+    for e in range(E):
+        live[64 * blk0[e]:64 * blk0[e] + cnt[e]] = True
+    assert torch.isnan(h[torch.from_numpy(~live).cuda()]).all() and torch.isnan(y[torch.from_numpy(~live).cuda()]).all()   # rows past an expert's end: never stored
+    for e in range(E):
+        n = int(cnt[e])
+        if n == 0:
+            continue
+        off = 64 * int(blk0[e])
+        he = torch.empty((n, I), dtype=torch.float32, device="cuda")
+        ye = torch.empty((n, hid), dtype=torch.float32, device="cuda")
+        assert gate_up(xg[off:off + n].data_ptr(), n, he.data_ptr(), w1.data_ptr() + e * s1, w3.data_ptr() + e * s3, None, None) == 0
+        assert down(he.data_ptr(), n, ye.data_ptr(), w2.data_ptr() + e * s2, None, None) == 0
+        torch.cuda.synchronize()
+        if n >= 96:                                                    # the same kernels on the same rows: the same bits
+            assert torch.equal(h[off:off + n], he) and torch.equal(y[off:off + n], ye)
+        else:                                                          # fewer rows run the 1..32-token kernels: their own rounding
+            assert rel_err(h[off:off + n].cpu().numpy(), he.cpu().numpy()) < 2e-3
+            assert rel_err(y[off:off + n].cpu().numpy(), ye.cpu().numpy()) < 2e-3
+
+
 @pytest.mark.parametrize("rows,types", [(32, "446"), (12, "446"), (32, "464"), (5, "444"), (20, "664")])
 def test_grouped_expert_matmuls_one_launch_per_kernel(cv, rows, types):
     """mi355_qmm_desc.group_count: the experts of a layer as ONE call -- gate/up (SiLU * up, chain hint) then down, over per-expert
