@@ -16,6 +16,8 @@
 // tiles they share hit L1/L2).  grid = (ceil(max_seqlen_q/128), heads, seqs): >> 256 workgroups for real prompts.
 #include "common.h"
 #include "pa_lds_layout.h"
+#include "scratch.h"
+#include <stdlib.h>
 #include "../../include/mi355_vllm.h"
 #include <hip/hip_runtime.h>
 
@@ -721,6 +723,52 @@ extern "C" int mi355_prefill_attention_window(void* out, const void* q, const vo
 // attention.rs:574,896), the generic kernel otherwise (and as the A/B: tuning key 43).
 static int g_pf_fp8_generic = 0;
 void mi355_prefill_set_fp8_generic(int v) { g_pf_fp8_generic = v; }
+
+// Round 6: the e4m3 cache blocks of the sequences of a prompt step as bf16 (exact: 3 mantissa bits), in the bf16 cache layouts
+// K [NBt, Hkv, D/8, bs, 8] / V [NBt, Hkv, D, bs], temp block seq * max_blocks + i, with the table that says so -- so that the step's attention
+// runs through prefill_attn_lds_kernel (K / V through the LDS ring: 290 TFLOP/s on the Llama prompt step) instead of the register-fed
+// prefill_attn_kernel<.., SRC_PAGED8> (110 TFLOP/s, 51 % of a 16 k-token Mixtral prompt: profiles/r06_moe_prompt_device_ab.txt).  One pass
+// over ctx x Hkv x D x 2 bytes per layer (33 MB read, 67 MB written at 16 k tokens: ~25 us next to 10 ms of attention).
+__global__ void __launch_bounds__(256) pf_fp8_blocks_to_bf16_kernel(uint16_t* __restrict__ tk, uint16_t* __restrict__ tv, uint32_t* __restrict__ tbt,
+                                                                    const uint8_t* __restrict__ kc, const uint8_t* __restrict__ vc,
+                                                                    const uint32_t* __restrict__ bt, const uint32_t* __restrict__ ctx,
+                                                                    int Hkv, int D, int bs, int max_blocks) {
+    const int i = blockIdx.x, hk = blockIdx.y, seq = blockIdx.z;
+    if (hk == 0 && threadIdx.x == 0) tbt[(size_t)seq * max_blocks + i] = (uint32_t)(seq * max_blocks + i);
+    // tokens past the context become ZERO, up to the end of the 128-token span the last stage of the ring may touch (a cache block holds
+    // finite stale values there; fresh scratch memory and e4m3 bytes need not: 0 x NaN in P.V would poison a row); later blocks: untouched
+    const int n_ctx = (int)ctx[seq], live = n_ctx - i * bs;            // tokens of this block inside the context (<= 0: none)
+    if ((int64_t)i * bs >= (((int64_t)n_ctx + 127) / 128) * 128 + 128) return;
+    const size_t src = live > 0 ? ((size_t)bt[(size_t)seq * max_blocks + i] * Hkv + hk) * D * bs : 0;      // bytes (the table entry of a block past the context may be anything)
+    const size_t dst = ((size_t)(seq * max_blocks + i) * Hkv + hk) * D * bs;                // elements
+    for (int u = threadIdx.x; u < (D / 8) * bs; u += 256) {            // K: (d8, t) -> 8 consecutive d of token t
+        const int d8 = u / bs, t = u - d8 * bs;
+        uint4 o = make_uint4(0, 0, 0, 0);
+        if (t < live) {
+            const uint2 raw = *reinterpret_cast<const uint2*>(kc + src + ((size_t)(d8 >> 1) * bs + t) * 16 + (d8 & 1) * 8);
+            const uint2 lo = pf_fp8x4_to_bf16x4(raw.x), hi = pf_fp8x4_to_bf16x4(raw.y);
+            o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+        *reinterpret_cast<uint4*>(tk + dst + ((size_t)d8 * bs + t) * 8) = o;
+    }
+    for (int u = threadIdx.x; u < D * bs / 8; u += 256) {              // V: [D][bs] in both caches; 8 consecutive tokens of one channel
+        const int t0 = (u * 8) % bs;
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (t0 < live) {
+            const uint2 raw = *reinterpret_cast<const uint2*>(vc + src + (size_t)u * 8);
+            const uint2 lo = pf_fp8x4_to_bf16x4(raw.x), hi = pf_fp8x4_to_bf16x4(raw.y);
+            w[0] = lo.x; w[1] = lo.y; w[2] = hi.x; w[3] = hi.y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (t0 + 2 * e >= live) w[e] = 0;
+                else if (t0 + 2 * e + 1 >= live) w[e] &= 0xFFFFu;
+            }
+        }
+        *reinterpret_cast<uint4*>(tv + dst + (size_t)u * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+// MI355_PF_FP8_VIA_BF16=0 (A/B runs): the register-fed e4m3 kernel as in rounds 3-5
+static const int g_pf_fp8_via_bf16_env = []() { const char* e = getenv("MI355_PF_FP8_VIA_BF16"); return e && e[0] == '0' ? 0 : 1; }();
 extern "C" int mi355_prefill_attention_fp8(void* out, const void* q, const void* key_cache, const void* value_cache,
                                            const uint32_t* block_tables, const uint32_t* context_lens,
                                            const uint32_t* cu_seqlens_q, int32_t num_seqs, int32_t max_seqlen_q,
@@ -736,6 +784,28 @@ extern "C" int mi355_prefill_attention_fp8(void* out, const void* q, const void*
     p.H = num_heads; p.Hkv = num_kv_heads; p.block_size = block_size; p.max_blocks = max_blocks_per_seq;
     p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f; p.softcap = softcap > 0.f ? softcap : 0.f;
     p.kv8 = 1; p.k_scale = k_scale; p.v_scale = v_scale;
+    {
+        // through the LDS-fed bf16 kernel (see pf_fp8_blocks_to_bf16_kernel): head size 128, a unit value scale (k_scale folds into the
+        // logit scale as below), and a temporary of at most 2 GiB
+        const size_t elems = (size_t)num_seqs * max_blocks_per_seq * num_kv_heads * head_dim * block_size;
+        if (g_pf_fp8_via_bf16_env && g_pf_lds && !g_pf_fp8_generic && head_dim == 128 && v_scale == 1.0f &&
+            (block_size == 16 || block_size == 32 || block_size == 64) && elems * 4 <= ((size_t)2 << 30)) {
+            void* ws = nullptr;
+            const size_t tb_bytes = ((size_t)num_seqs * max_blocks_per_seq * 4 + 255) / 256 * 256;
+            const int rc = mi355_scratch_get(&ws, MI355_SCR_PF_FP8, elems * 4 + tb_bytes, (hipStream_t)stream, false);
+            if (rc == 0) {
+                uint16_t* tk = static_cast<uint16_t*>(ws);
+                uint16_t* tv = tk + elems;
+                uint32_t* tbt = reinterpret_cast<uint32_t*>(tv + elems);
+                hipLaunchKernelGGL(pf_fp8_blocks_to_bf16_kernel, dim3(max_blocks_per_seq, num_kv_heads, num_seqs), dim3(256), 0, (hipStream_t)stream, tk, tv, tbt,
+                                   static_cast<const uint8_t*>(key_cache), static_cast<const uint8_t*>(value_cache), block_tables, context_lens,
+                                   num_kv_heads, head_dim, block_size, max_blocks_per_seq);
+                return mi355_prefill_attention(out, q, nullptr, nullptr, tk, tv, tbt, context_lens, cu_seqlens_q, num_seqs, max_seqlen_q, num_heads,
+                                               num_kv_heads, head_dim, block_size, max_blocks_per_seq, scale * k_scale, softcap, MI355_KV_PAGED,
+                                               MI355_DTYPE_BF16, stream);
+            }
+        }
+    }
     if ((head_dim == 64 || head_dim == 128) && block_size % 16 == 0 && !g_pf_fp8_generic) {
         // the MFMA flash kernel over the e4m3 cache: bytes converted to bf16 fragments on the way in (exact), k_scale folded into the
         // logit scale, v_scale into the normalisation

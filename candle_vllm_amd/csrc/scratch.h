@@ -14,6 +14,7 @@ enum {
     MI355_SCR_DENSE_WS = 8,      // dense / GPTQ path staging
     MI355_SCR_COMM = 9,          // one-shot all-reduce staging
     MI355_SCR_GPTQ_WIDE = 10,    // 5..64-token launches of tiled 4-bit weights: split-K partial sums (gptq_wide.inc)
+    MI355_SCR_PF_FP8 = 11,       // prompt attention over an e4m3 cache: the sequences' blocks as bf16 + their block table (prefill_attention.hip)
 };
 
 // *out = a device buffer of >= bytes owned by (current device, st, key).  zero_on_create: the buffer is cleared (on `st`)
