@@ -319,11 +319,11 @@ int run_part(Model* m, int l, int part, const StepIn& in, float* logits, int64_t
             // expert once per pair: exact, but a 2048-token prompt would stream each expert hundreds of times.
             RCHECK(mi355_moe_route(in.moe_ids, in.moe_w, in.xs, L.ffn_norm, c.rms_eps, L.gate_inp, B, hid, c.n_expert, K, st));
             if (g_moe_prompt_device && m->p_moe_tab && c.n_expert <= 16 && pairs >= 96 && L.etype[0] == MI355_GGML_Q4_K &&
-                L.etype[1] == MI355_GGML_Q4_K && L.etype[2] == MI355_GGML_Q4_K) {
+                (L.etype[1] == MI355_GGML_Q4_K || L.etype[1] == MI355_GGML_Q6_K) && L.etype[2] == MI355_GGML_Q4_K) {
                 // ---- the same, grouped ON THE DEVICE (round 6): no copy of the routing to the host, no stream synchronisation, and ONE launch
                 // per kernel for all experts.  Every expert owns whole 64-row blocks of the gathered buffers; the prompt GEMM walks a block
                 // table {expert, row end} (mi355_qmm_desc.group_block_table); rows between an expert's end and its last block's end are
-                // computed and never stored.  (Q4_K experts: what the GEMM's fused store loop covers; Q6_K experts take the host-sorted path.)
+                // computed and never stored.  (Q4_K gate / up and a Q4_K or Q6_K down projection -- a Q4_K_M file; anything else takes the host-sorted path.)
                 const int nblk = (pairs + 63) / 64 + c.n_expert, rows = 64 * nblk;
                 RCHECK(mi355_moe_group_blocks(m->p_moe_inv, m->p_moe_tab, in.moe_ids, pairs, c.n_expert, nblk + 2, st));
                 RCHECK(mi355_moe_gather_pos(m->p_moe_xg, in.xs, m->p_moe_inv, pairs, K, hid, st));

@@ -2014,6 +2014,7 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_lds_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qpg_gemm_q6k_lds_kernel<true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done.set();
     }
     if (a.blk_tab && g_tune_qpg != 2) return (int)hipErrorNotSupported;                   // only the LDS-fed kernel reads a block table
@@ -2041,7 +2042,18 @@ static int qpg_launch(const QmmArgs& a0, hipStream_t st) {
             }
             return (int)hipGetLastError();
         }
-        if (a.blk_tab) return (int)hipErrorNotSupported;        // block-table launches: Q4_K, one plane, store / SiLU * up epilogues only
+        if (a.blk_tab) {
+            // block-table launches: Q4_K above; one Q6_K matrix with a store / residual epilogue here (the down projections of a Q4_K_M file)
+            if (a.nseg == 1 && a.seg[0].type == MI355_GGML_Q6_K && (a.epi == MI355_EPI_STORE || a.epi == MI355_EPI_RESID) && parts == 1 &&
+                g_tune_qpg == 2 && g_tune_qpg_fepi) {
+                QmmArgs r = a;
+                r.norm_w = nullptr;
+                hipLaunchKernelGGL((qpg_gemm_q6k_lds_kernel<true, 2, true>), dim3(Tpad / 64, (n_slots + 15) / 16), dim3(512), (size_t)QPG6_LDS_BYTES, st, r, im, C,
+                                   ldp, n_slots, 0);
+                return (int)hipGetLastError();
+            }
+            return (int)hipErrorNotSupported;
+        }
     }
     // q | k | v of a prompt step (EPI_QKV_ROPE_CACHE, round 6): q and k (Q4_K) -- and v where it is Q4_K too -- go through the fused store loop
     // (RoPE + bf16 + cache scatter in the GEMM); a Q6_K v (half the layers of a Q4_K_M file) keeps its own GEMM + the epilogue launch, which

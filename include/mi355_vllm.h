@@ -266,7 +266,8 @@ typedef struct mi355_qmm_desc {
      * rows of ALL groups, every group in whole 64-row blocks (mi355_moe_group_blocks); block b of the table = {group, one past the group's
      * last row} as two i32 ({0, 0}: no rows), the group's weights start group * moe_expert_stride[s] bytes into w_tiles[s].  ONE launch per
      * kernel walks every block; rows past a group's end are computed and never stored.  num_tokens = 64 * blocks (>= 96); the table needs
-     * num_tokens / 64 + 2 entries.  Q4_K segments, epilogues STORE / RESID / SILU_MUL (what the prompt GEMM's store loop fuses); any other
+     * num_tokens / 64 + 2 entries.  Q4_K segments with epilogues STORE / RESID / SILU_MUL, or one Q6_K matrix with STORE / RESID (what the prompt
+     * GEMMs' store loops fuse); any other
      * call is refused (hipErrorNotSupported) and the caller runs the groups one by one. */
     const int32_t* group_block_table;
 } mi355_qmm_desc;
