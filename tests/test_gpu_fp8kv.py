@@ -119,7 +119,10 @@ def _decode_case(cv, H, Hkv, D, bs, ctxs, ps, seed=0):
 
 
 @pytest.mark.parametrize("generic", [0, 1])
-@pytest.mark.parametrize("H,Hkv,D,bs,lens,cached", [(4, 2, 64, 16, [37, 20], [0, 24]), (8, 2, 128, 64, [150, 33, 5], [0, 70, 129])])
+@pytest.mark.parametrize("H,Hkv,D,bs,lens,cached", [(4, 2, 64, 16, [37, 20], [0, 24]), (8, 2, 128, 64, [150, 33, 5], [0, 70, 129]),
+                                                    # head size 128 (round 6): the blocks as bf16 in a temporary cache + the LDS-fed kernel; 16- and 32-token
+                                                    # blocks put several blocks -- some past the context, their table entries unused -- into one 64-token stage
+                                                    (8, 2, 128, 16, [150, 33, 5, 200], [0, 70, 129, 1000]), (4, 1, 128, 32, [70, 1, 300], [500, 31, 0])])
 def test_prefill_over_fp8_cache(cv, H, Hkv, D, bs, lens, cached, generic):
     """prefill over the e4m3 cache (attention.rs:574,896): the MFMA flash kernel (bytes -> bf16 fragments on the way in; several
     128-query tiles, cached prefixes that cross blocks) and the generic kernel (tuning key 43) against the oracle on the
